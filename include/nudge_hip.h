@@ -1,0 +1,189 @@
+/*
+ * nudge_hip.h -- C ABI of the MI355X-native stepping engine (libnudge_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of rasmusbarr/nudge:
+ *     collide -> [gravity] -> read_cached_impulses -> setup_contact_constraints
+ *             -> apply_impulses x N -> update_cached_impulses -> write_cached_impulses -> advance
+ * Each entry point below replaces the reference function cited next to it (reference nudge.h:134-146,
+ * implemented in reference nudge.cpp:3000-4926) and keeps its argument meaning.  Differences, all forced
+ * by the device boundary or by scale, are:
+ *
+ *   1. Every array pointer inside the structs is DEVICE memory (hipMalloc'ed by the caller, or carved out
+ *      of a torch tensor): the caller still owns every array, the library never allocates on its behalf;
+ *      scratch and the two opaque result objects come out of the caller's `nh_Arena` (device memory) with
+ *      the reference's bump semantics (nudge.h:29-32, nudge.cpp:990-1055): `nh_collide` takes the arena
+ *      BY VALUE (scratch is dead on return), the two `Arena*` functions ADVANCE it.
+ *   2. Indices are widened: body indices and collider tags are 32-bit (the reference packs them in 16 bits:
+ *      nudge.h:68-71, 86, 93, 126 and asserts <= 8192 colliders at nudge.cpp:3010).  A contact's identity
+ *      is therefore split in two words: `tags[i]`  = a_tag | (uint64_t)b_tag << 32   (reference: high 32
+ *      bits of its u64 tag, a16 | b16 << 16) and `features[i]` = the reference's low 32 feature bits.
+ *      Ordering everywhere is the reference's: by b_tag, then a_tag, then feature.
+ *   3. Functions return an error code (NH_OK = 0) instead of assert()-aborting (nudge.cpp:1000, 3010, 4118).
+ *   4. Counts are produced on the device.  With NH_FLAG_SYNC_COUNTS (default) the host-visible `count`
+ *      fields are filled in before the call returns, as in the reference; without it the calls only enqueue
+ *      work on the context's stream and `nh_read_counts` fetches the numbers when the host wants them.
+ *   5. `contacts->data/bodies/tags/features` are returned in TAG ORDER (the order the reference's solver
+ *      consumes them in, nudge.cpp:4027-4044), not in narrowphase emission order: same set, canonical order.
+ *   6. The caller-side gravity/damping loop of the sample app (example/main.cpp:290-305) runs over
+ *      host-invisible memory here, so it is offered as `nh_apply_gravity_damping`.
+ *
+ * Threading: one context = one HIP stream = one world at a time; no global mutable state.
+ */
+#ifndef NUDGE_HIP_H
+#define NUDGE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ------------------------------------------------------------------------------- */
+enum {
+	NH_OK = 0,
+	NH_ERR_INVALID = 1,          /* bad argument */
+	NH_ERR_NO_DEVICE = 2,        /* no HIP device / runtime error */
+	NH_ERR_ARENA = 3,            /* arena exhausted            (reference: assert nudge.cpp:1000-1039) */
+	NH_ERR_CONTACT_CAPACITY = 4, /* contacts->capacity exceeded (reference: unchecked overflow)         */
+	NH_ERR_CACHE_CAPACITY = 5,   /* contact_cache->capacity     (reference: assert nudge.cpp:4118)      */
+	NH_ERR_ACTIVE_CAPACITY = 6,  /* active_bodies->capacity     (reference: unchecked overflow)         */
+	NH_ERR_PAIR_CAPACITY = 7,    /* internal broadphase pair buffer (sized from the arena)              */
+	NH_ERR_HIP = 8               /* a HIP call failed; see nh_last_hip_error                            */
+};
+
+/* ---- context flags ----------------------------------------------------------------------------- */
+enum {
+	NH_FLAG_SYNC_COUNTS = 1u,    /* fill host-side count fields before returning (reference semantics)   */
+	NH_FLAG_EXACT_ORDER = 2u     /* solver visits contacts in the reference's greedy batch order, replayed
+	                                exactly on the device (nudge.cpp:4206-4339); default is the closed-form
+	                                round-robin order, identical whenever the greedy scheduler meets no
+	                                lane conflict (drop scenes)                                            */
+};
+
+/* ---- POD records: layouts identical to reference nudge.h unless marked (wide) -------------------- */
+typedef struct nh_Arena { void* data; uintptr_t size; } nh_Arena;                                   /* nudge.h:29-32 */
+typedef struct nh_Transform { float position[3]; uint32_t body; float rotation[4]; } nh_Transform;   /* nudge.h:34-38 */
+typedef struct nh_BodyProperties { float inertia_inverse[3]; float mass_inverse; } nh_BodyProperties;/* nudge.h:40-43 */
+typedef struct nh_BodyMomentum { float velocity[3]; float unused0; float angular_velocity[3]; float unused1; } nh_BodyMomentum; /* nudge.h:45-50 */
+typedef struct nh_SphereCollider { float radius; } nh_SphereCollider;                                /* nudge.h:52-54 */
+typedef struct nh_BoxCollider { float size[3]; float unused; } nh_BoxCollider;                       /* nudge.h:56-59 */
+typedef struct nh_Contact { float position[3]; float penetration; float normal[3]; float friction; } nh_Contact; /* nudge.h:61-66 */
+typedef struct nh_BodyPair { uint32_t a; uint32_t b; } nh_BodyPair;                                  /* nudge.h:68-71 (wide) */
+typedef struct nh_CachedContactImpulse { float impulse[3]; float unused; } nh_CachedContactImpulse;  /* nudge.h:113-116 */
+
+typedef struct nh_ContactData {                                                                      /* nudge.h:73-82 (wide) */
+	nh_Contact* data;
+	nh_BodyPair* bodies;
+	uint64_t* tags;            /* a_tag | b_tag << 32 */
+	uint32_t* features;        /* feature word (reference: low 32 bits of the tag) */
+	uint32_t capacity;
+	uint32_t count;
+	uint64_t* sleeping_pairs;  /* same packing as `tags` */
+	uint32_t sleeping_count;
+} nh_ContactData;
+
+typedef struct nh_ColliderData {                                                                     /* nudge.h:84-98 (wide tags) */
+	struct { uint32_t* tags; nh_BoxCollider* data; nh_Transform* transforms; uint32_t count; } boxes;
+	struct { uint32_t* tags; nh_SphereCollider* data; nh_Transform* transforms; uint32_t count; } spheres;
+} nh_ColliderData;
+
+typedef struct nh_BodyData {                                                                         /* nudge.h:100-106 */
+	nh_Transform* transforms;
+	nh_BodyProperties* properties;
+	nh_BodyMomentum* momentum;
+	uint8_t* idle_counters;
+	uint32_t count;
+} nh_BodyData;
+
+typedef struct nh_BodyConnections { nh_BodyPair* data; uint32_t count; } nh_BodyConnections;         /* nudge.h:108-111 */
+
+typedef struct nh_ContactCache {                                                                     /* nudge.h:118-123 (wide) */
+	uint64_t* tags;
+	uint32_t* features;
+	nh_CachedContactImpulse* data;
+	uint32_t capacity;
+	uint32_t count;
+} nh_ContactCache;
+
+typedef struct nh_ActiveBodies { uint32_t* indices; uint32_t capacity; uint32_t count; } nh_ActiveBodies; /* nudge.h:125-129 (wide) */
+
+typedef struct nh_ContactImpulseData nh_ContactImpulseData;         /* nudge.h:131, opaque */
+typedef struct nh_ContactConstraintData nh_ContactConstraintData;   /* nudge.h:132, opaque */
+typedef struct nh_context nh_context;
+
+/* Device-side counters of the most recent step, mirrored to the host by nh_read_counts. */
+typedef struct nh_Counts {
+	uint32_t colliders;         /* C */
+	uint32_t pairs;             /* P: broadphase pairs surviving the same-body / sleeping filters */
+	uint32_t contacts;          /* K */
+	uint32_t sleeping_pairs;
+	uint32_t active_bodies;
+	uint32_t cache;             /* entries in the contact cache after the last write */
+	uint32_t culled;            /* cached impulses kept aside for sleeping pairs */
+	uint32_t large_colliders;   /* colliders handled by the brute-force "large x all" broadphase pass */
+	uint32_t general_contacts;  /* contacts solved by the level-scheduled path (not the one-body fast path) */
+	uint32_t levels;            /* dependency levels of that path */
+	uint32_t error;             /* NH_* raised on the device (capacity overflows) */
+	uint32_t static_bodies;     /* bodies solved by the one-body fast path */
+	uint32_t unleveled;         /* internal: progress of the level relaxation */
+	uint32_t raw_pairs;         /* broadphase pairs before any filter (diagnostic) */
+} nh_Counts;
+
+/* ---- lifecycle ---------------------------------------------------------------------------------- */
+/* `stream` is a hipStream_t (or NULL for the default stream) on `device`; the context never creates one. */
+int nh_create(nh_context** out, int device, void* stream, uint32_t flags);
+void nh_destroy(nh_context* ctx);
+int nh_set_flags(nh_context* ctx, uint32_t flags);
+int nh_synchronize(nh_context* ctx);
+int nh_read_counts(nh_context* ctx, nh_Counts* out);        /* synchronises the stream */
+int nh_set_cache_count(nh_context* ctx, uint32_t count);    /* restore a checkpointed ContactCache */
+int nh_set_tag_bits(nh_context* ctx, uint32_t bits);        /* collider tags are < 2^bits (default 32): fewer sort passes */
+const char* nh_error_string(int code);
+int nh_last_hip_error(nh_context* ctx);
+
+/* ---- the hot path: one entry point per reference function ------------------------------------------ */
+/* collide (nudge.h:134, nudge.cpp:3000-4009) */
+int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_ContactData* contacts,
+               const nh_BodyData* bodies, const nh_ColliderData* colliders,
+               const nh_BodyConnections* body_connections, nh_Arena temporary);
+
+/* caller-side loop of the sample app (example/main.cpp:290-305): v -= g*dt; v,w *= 1 - dt*damping_rate */
+int nh_apply_gravity_damping(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_BodyData* bodies,
+                             float time_step, const float gravity[3], float damping_rate);
+
+/* read_cached_impulses (nudge.h:136, nudge.cpp:4021-4108) */
+int nh_read_cached_impulses(nh_context* ctx, const nh_ContactCache* contact_cache, const nh_ContactData* contacts,
+                            nh_Arena* memory, nh_ContactImpulseData** out);
+
+/* write_cached_impulses (nudge.h:138, nudge.cpp:4110-4158) */
+int nh_write_cached_impulses(nh_context* ctx, nh_ContactCache* contact_cache, const nh_ContactData* contacts,
+                             nh_ContactImpulseData* contact_impulses);
+
+/* setup_contact_constraints (nudge.h:140, nudge.cpp:4170-4638) */
+int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_ContactData* contacts,
+                                 const nh_BodyData* bodies, nh_ContactImpulseData* contact_impulses,
+                                 nh_Arena* memory, nh_ContactConstraintData** out);
+
+/* apply_impulses (nudge.h:142, nudge.cpp:4640-4855): `iterations` consecutive calls of the reference */
+int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* data, const nh_BodyData* bodies, uint32_t iterations);
+
+/* update_cached_impulses (nudge.h:144, nudge.cpp:4857-4884) */
+int nh_update_cached_impulses(nh_context* ctx, nh_ContactConstraintData* data, nh_ContactImpulseData* contact_impulses);
+
+/* advance (nudge.h:146, nudge.cpp:4886-4926) */
+int nh_advance(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_BodyData* bodies, float time_step);
+
+/* ---- introspection for tests / measurement --------------------------------------------------------- */
+/* Device pointer to the per-contact warm-start impulses of an nh_ContactImpulseData (K x 16 B, contact order). */
+const nh_CachedContactImpulse* nh_contact_impulses_device(const nh_ContactImpulseData* d);
+/* Per-kernel device time of the last step, measured with HIP events on the context's stream when timing is on. */
+int nh_enable_timing(nh_context* ctx, int on);
+/* Writes up to `cap` (name, milliseconds, launches) triples accumulated since the last reset; returns the number. */
+typedef struct nh_KernelTime { const char* name; double ms; uint32_t launches; uint32_t reserved; } nh_KernelTime;
+int nh_kernel_times(nh_context* ctx, nh_KernelTime* out, int cap, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* NUDGE_HIP_H */

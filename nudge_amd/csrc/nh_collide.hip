@@ -1,0 +1,563 @@
+// nh_collide.hip -- nh_collide: world transforms + AABBs, exact-pair-set broadphase, narrowphase, islands /
+// sleeping, tag-ordered contact output.  Replaces reference nudge.cpp:3000-4009.
+//
+// What is kept from the reference is the RESULT: the set of strictly overlapping AABB pairs
+// (nudge.cpp:3306-3308), which collider of a pair plays "a" in the narrowphase (the one later in Morton order
+// of the AABB min corners, nudge.cpp:3086-3172, 3495, 1202-1203), the per-pair contact arithmetic
+// (nh_narrowphase.h), island membership / sleeping rules (nudge.cpp:3788-4006) and the tag order of contacts.
+// How it is computed is GPU-first: the reference's O(C^2/1024) grouped all-pairs sweep is replaced by a
+// uniform grid over "small" colliders (cell = power of two >= their largest extent) plus a brute-force pass for
+// the few large ones (ground slabs); union-find runs lock-free with atomicCAS hooking.
+#include "nh_internal.h"
+#include "nh_narrowphase.h"
+
+// ---- 1. world transforms, AABBs, bounds, extent histogram ---------------------------------------------
+// aabb_min[c] = (min.xyz, bits(body)), aabb_max[c] = (max.xyz, bits(max extent))
+__global__ __launch_bounds__(256) void k_xform(nh_DevState* __restrict__ st,
+                                               const nh_Transform* __restrict__ body_xf,
+                                               const nh_Transform* __restrict__ box_xf, const nh_BoxCollider* __restrict__ box_data, const uint32_t* __restrict__ box_tags, uint32_t nbox,
+                                               const nh_Transform* __restrict__ sph_xf, const nh_SphereCollider* __restrict__ sph_data, const uint32_t* __restrict__ sph_tags, uint32_t nsph,
+                                               nh_xform* __restrict__ xf, float4* __restrict__ aabb_min, float4* __restrict__ aabb_max, uint32_t* __restrict__ ctag) {
+	__shared__ uint32_t hist[256];
+	__shared__ uint32_t red[6];
+	hist[threadIdx.x] = 0;
+	if (threadIdx.x < 3) { red[threadIdx.x] = 0xffffffffu; red[3 + threadIdx.x] = 0u; }
+	__syncthreads();
+	uint32_t n = nbox + nsph;
+	uint32_t lmin[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, lmax[3] = { 0, 0, 0 };
+	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+		bool is_box = c < nbox;
+		nh_Transform l = is_box ? box_xf[c] : sph_xf[c - nbox];
+		nh_Transform b = body_xf[l.body];
+		// Transform * Transform (nudge.cpp:1165-1175)
+		nh_quat bq = { b.rotation[0], b.rotation[1], b.rotation[2], b.rotation[3] };
+		nh_quat lq = { l.rotation[0], l.rotation[1], l.rotation[2], l.rotation[3] };
+		nh_f3 p = nh_rotate(bq, nh_make3(l.position[0], l.position[1], l.position[2])) + nh_make3(b.position[0], b.position[1], b.position[2]);
+		nh_quat q = nh_qmul(bq, lq);
+		nh_xform w;
+		w.px = p.x; w.py = p.y; w.pz = p.z; w.body = l.body;
+		w.qx = q.x; w.qy = q.y; w.qz = q.z; w.qs = q.s;
+		float sx, sy, sz;
+		if (is_box) {
+			// |R| * size (nudge.cpp:3027-3037)
+			nh_m33 m = nh_matrix(q);
+			nh_BoxCollider bc = box_data[c];
+			nh_f3 c0 = m.c0 * bc.size[0], c1 = m.c1 * bc.size[1], c2 = m.c2 * bc.size[2];
+			sx = fabsf(c0.x) + fabsf(c1.x) + fabsf(c2.x);
+			sy = fabsf(c0.y) + fabsf(c1.y) + fabsf(c2.y);
+			sz = fabsf(c0.z) + fabsf(c1.z) + fabsf(c2.z);
+			ctag[c] = box_tags[c];
+		} else {
+			sx = sy = sz = sph_data[c - nbox].radius;
+			ctag[c] = sph_tags[c - nbox];
+		}
+		float mnx = p.x - sx, mny = p.y - sy, mnz = p.z - sz;
+		float mxx = p.x + sx, mxy = p.y + sy, mxz = p.z + sz;
+		float ext = fmaxf(fmaxf(mxx - mnx, mxy - mny), mxz - mnz);
+		xf[c] = w;
+		aabb_min[c] = make_float4(mnx, mny, mnz, __uint_as_float(l.body));
+		aabb_max[c] = make_float4(mxx, mxy, mxz, ext);
+		uint32_t f;
+		f = nh_float_flip(mnx); lmin[0] = min(lmin[0], f); lmax[0] = max(lmax[0], f);
+		f = nh_float_flip(mny); lmin[1] = min(lmin[1], f); lmax[1] = max(lmax[1], f);
+		f = nh_float_flip(mnz); lmin[2] = min(lmin[2], f); lmax[2] = max(lmax[2], f);
+		atomicAdd(&hist[(__float_as_uint(ext) >> 23) & 255u], 1u);
+	}
+	for (int k = 0; k < 3; ++k) { atomicMin(&red[k], lmin[k]); atomicMax(&red[3 + k], lmax[k]); }
+	__syncthreads();
+	if (hist[threadIdx.x]) atomicAdd(&st->exp_hist[threadIdx.x], hist[threadIdx.x]);
+	if (threadIdx.x < 3) { atomicMin(&st->smin[threadIdx.x], red[threadIdx.x]); atomicMax(&st->smax[threadIdx.x], red[3 + threadIdx.x]); }
+}
+
+// ---- 2. grid parameters (single thread; a few hundred instructions) ------------------------------------
+__global__ void k_grid_params(nh_DevState* st, uint32_t ncolliders, uint32_t max_cells) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	nh_f3 smin = nh_make3(nh_float_unflip(st->smin[0]), nh_float_unflip(st->smin[1]), nh_float_unflip(st->smin[2]));
+	nh_f3 smax = nh_make3(nh_float_unflip(st->smax[0]), nh_float_unflip(st->smax[1]), nh_float_unflip(st->smax[2]));
+	// Morton frame (nudge.cpp:3096-3100)
+	float scale = nh_morton_scale(smin, smax);
+	st->morton_scale = scale;
+	st->morton_min[0] = smin.x * scale; st->morton_min[1] = smin.y * scale; st->morton_min[2] = smin.z * scale;
+	// small/large split: allow at most max(64, C/1024) colliders above the grid's cell size
+	uint32_t budget = ncolliders / 1024u; if (budget < 64u) budget = 64u;
+	uint32_t above = 0;
+	int e = 255;
+	while (e > 0) { uint32_t h = st->exp_hist[e]; if (above + h > budget) break; above += h; --e; }
+	// e = largest exponent kept "small"; never let the cell underflow to denormals
+	if (e < 64) e = 64;
+	if (e > 190) e = 190;
+	st->small_exp = (uint32_t)e;
+	float cell = __uint_as_float((uint32_t)(e + 1) << 23);     // 2^(e+1-127) > every small extent
+	st->cell_inv = 1.0f / cell;
+	st->origin[0] = smin.x; st->origin[1] = smin.y; st->origin[2] = smin.z;
+	float dx = (smax.x - smin.x) * st->cell_inv, dy = (smax.y - smin.y) * st->cell_inv, dz = (smax.z - smin.z) * st->cell_inv;
+	uint64_t nx = (uint64_t)fminf(fmaxf(dx, 0.0f), 1e6f) + 2, ny = (uint64_t)fminf(fmaxf(dy, 0.0f), 1e6f) + 2, nz = (uint64_t)fminf(fmaxf(dz, 0.0f), 1e6f) + 2;
+	while (nx * ny * nz > max_cells) {
+		if (nx >= ny && nx >= nz) nx = (nx + 1) / 2; else if (ny >= nz) ny = (ny + 1) / 2; else nz = (nz + 1) / 2;
+	}
+	st->dims[0] = (uint32_t)nx; st->dims[1] = (uint32_t)ny; st->dims[2] = (uint32_t)nz;
+}
+
+__device__ __forceinline__ int cell_coord(float x, float origin, float inv) {
+	float f = (x - origin) * inv;
+	f = fminf(fmaxf(f, -1.0f), 16777216.0f);
+	return (int)floorf(f);
+}
+
+// ---- 3. cell keys, morton keys, large list ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cell_keys(nh_DevState* __restrict__ st, uint32_t n,
+                                                   const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint64_t* __restrict__ mkey, uint32_t* __restrict__ large_list) {
+	const float inv = st->cell_inv;
+	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
+	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
+	const uint32_t small_exp = st->small_exp;
+	const float mscale = st->morton_scale;
+	const nh_f3 mmin = nh_make3(st->morton_min[0], st->morton_min[1], st->morton_min[2]);
+	uint32_t rounded = (n + 63u) & ~63u;
+	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < rounded; c += gridDim.x * blockDim.x) {
+		bool valid = c < n;
+		bool large = false;
+		if (valid) {
+			float4 mn = aabb_min[c], mx = aabb_max[c];
+			mkey[c] = nh_morton_of(nh_make3(mn.x, mn.y, mn.z), mscale, mmin);
+			int cx0 = cell_coord(mn.x, ox, inv), cy0 = cell_coord(mn.y, oy, inv), cz0 = cell_coord(mn.z, oz, inv);
+			int cx1 = cell_coord(mx.x, ox, inv), cy1 = cell_coord(mx.y, oy, inv), cz1 = cell_coord(mx.z, oz, inv);
+			uint32_t e = (__float_as_uint(mx.w) >> 23) & 255u;
+			// "small" = spans at most 2 cells per axis in THIS arithmetic (makes the neighbour search exact)
+			large = e > small_exp || (cx1 - cx0) > 1 || (cy1 - cy0) > 1 || (cz1 - cz0) > 1 || !(mx.w == mx.w);
+			uint32_t key = NH_LARGE_KEY;
+			if (!large) {
+				int cx = min(max(cx0, 0), nx - 1), cy = min(max(cy0, 0), ny - 1), cz = min(max(cz0, 0), nz - 1);
+				key = (uint32_t)((cz * ny + cy) * nx + cx);
+			}
+			keys[c] = key;
+			vals[c] = c;
+		}
+		uint32_t slot = nh_wave_reserve(&st->large, (valid && large) ? 1u : 0u);
+		if (valid && large) large_list[slot] = c;
+	}
+}
+
+// ---- 4. cell ranges + AABBs in cell order ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cell_bounds(uint32_t n, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                     const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
+                                                     uint2* __restrict__ cells, float4* __restrict__ smin, float4* __restrict__ smax) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		uint32_t key = keys[i];
+		uint32_t c = vals[i];
+		float4 mn = aabb_min[c], mx = aabb_max[c];
+		mx.w = __uint_as_float(c);                 // sorted copy carries (body, collider index) in the w lanes
+		smin[i] = mn; smax[i] = mx;
+		if (key != NH_LARGE_KEY) {
+			if (i == 0 || keys[i - 1] != key) cells[key].x = i;
+			if (i + 1 == n || keys[i + 1] != key) cells[key].y = i + 1;
+		}
+	}
+}
+
+__device__ __forceinline__ bool aabb_overlap(const float4& amin, const float4& amax, const float4& bmin, const float4& bmax) {
+	// strict overlap, nudge.cpp:3306-3308
+	return (bmax.x > amin.x) && (amax.x > bmin.x) && (bmax.y > amin.y) && (amax.y > bmin.y) && (bmax.z > amin.z) && (amax.z > bmin.z);
+}
+
+__device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_t pair_cap, const uint64_t* mkey, uint32_t ca, uint32_t cb, bool hit) {
+	uint32_t slot = nh_wave_reserve(&st->pairs, hit ? 1u : 0u);
+	if (hit) {
+		if (slot < pair_cap) {
+			uint64_t ka = mkey[ca], kb = mkey[cb];
+			bool a_first = (ka < kb) || (ka == kb && ca < cb);
+			// narrowphase "a" = later in Morton order (nudge.cpp:3495, 1202-1203)
+			pairs[slot] = a_first ? make_uint2(cb, ca) : make_uint2(ca, cb);
+		} else {
+			st->error = NH_ERR_PAIR_CAPACITY;
+		}
+	}
+}
+
+// ---- 5. pair search: grid neighbours + large list ---------------------------------------------------------
+__global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st, uint32_t n,
+                                                    const uint32_t* __restrict__ keys, const float4* __restrict__ smin, const float4* __restrict__ smax,
+                                                    const uint2* __restrict__ cells, const uint32_t* __restrict__ large_list,
+                                                    const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
+                                                    const uint64_t* __restrict__ mkey, uint2* __restrict__ pairs, uint32_t pair_cap) {
+	const float inv = st->cell_inv;
+	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
+	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
+	const uint32_t nlarge = st->large;
+	uint32_t rounded = (n + 63u) & ~63u;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
+		bool valid = i < n;
+		float4 amin = make_float4(0, 0, 0, 0), amax = amin;
+		uint32_t key = NH_LARGE_KEY, ca = 0, abody = 0;
+		if (valid) { amin = smin[i]; amax = smax[i]; key = keys[i]; ca = __float_as_uint(amax.w); abody = __float_as_uint(amin.w); }
+		bool small = valid && key != NH_LARGE_KEY;
+		// neighbour cells [c_min-1, c_max] per axis, clamped
+		int x0 = 0, x1 = -1, y0 = 0, y1 = -1, z0 = 0, z1 = -1;
+		if (small) {
+			int cx0 = cell_coord(amin.x, ox, inv), cy0 = cell_coord(amin.y, oy, inv), cz0 = cell_coord(amin.z, oz, inv);
+			int cx1 = cell_coord(amax.x, ox, inv), cy1 = cell_coord(amax.y, oy, inv), cz1 = cell_coord(amax.z, oz, inv);
+			x0 = min(max(cx0 - 1, 0), nx - 1); x1 = min(max(cx1, 0), nx - 1);
+			y0 = min(max(cy0 - 1, 0), ny - 1); y1 = min(max(cy1, 0), ny - 1);
+			z0 = min(max(cz0 - 1, 0), nz - 1); z1 = min(max(cz1, 0), nz - 1);
+		}
+		// The candidate loops are data dependent per lane; emission is wave-synchronous, so run a
+		// wave-uniform loop and let lanes without work idle.
+		int cz = z0, cy = y0, cx = x0;
+		uint32_t j = 0, jend = 0;
+		bool more_cells = small;
+		for (;;) {
+			// advance this lane to its next candidate
+			bool have = false;
+			uint32_t cand = 0;
+			while (more_cells || j < jend) {
+				if (j < jend) {
+					if (j > i) { cand = j; have = true; ++j; break; }
+					// entries at or before i: skip in bulk (cell lists are contiguous ranges of sorted indices)
+					j = (i + 1 > j) ? min(i + 1, jend) : j + 1;
+					continue;
+				}
+				// next cell
+				uint2 range = cells[(cz * ny + cy) * nx + cx];
+				j = range.x; jend = range.y;
+				if (++cx > x1) { cx = x0; if (++cy > y1) { cy = y0; if (++cz > z1) more_cells = false; } }
+			}
+			if (!__any(have)) break;
+			bool hit = false;
+			uint32_t cb = 0;
+			if (have) {
+				float4 bmin = smin[cand], bmax = smax[cand];
+				cb = __float_as_uint(bmax.w);
+				hit = aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != abody);
+			}
+			emit_pair(st, pairs, pair_cap, mkey, ca, cb, hit);
+		}
+		// large colliders: small x every large; large x larger-indexed large
+		for (uint32_t l = 0; l < nlarge; ++l) {
+			uint32_t cb = large_list[l];
+			float4 bmin = aabb_min[cb], bmax = aabb_max[cb];
+			bool hit = valid && (small || cb > ca) && aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != abody);
+			emit_pair(st, pairs, pair_cap, mkey, ca, cb, hit);
+		}
+	}
+}
+
+// ---- 6. narrowphase -----------------------------------------------------------------------------------------
+// raw contacts are appended in arbitrary order; one record per pair that produced contacts.
+struct nh_Record { uint32_t body_a, body_b, start, count; };
+
+__global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ st, const uint2* __restrict__ pairs,
+                                                     const nh_xform* __restrict__ xf, const uint32_t* __restrict__ ctag,
+                                                     const nh_BoxCollider* __restrict__ box_data, const nh_SphereCollider* __restrict__ sph_data, uint32_t nbox,
+                                                     nh_Contact* __restrict__ raw_data, uint32_t* __restrict__ raw_feature, uint32_t raw_cap,
+                                                     uint64_t* __restrict__ rec_key, nh_Record* __restrict__ rec) {
+	uint32_t n = min(st->pairs, raw_cap);
+	uint32_t rounded = (n + 63u) & ~63u;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
+		nh_contact_out out[16];
+		int count = 0;
+		uint64_t key = 0;
+		uint32_t body_a = 0, body_b = 0;
+		if (i < n) {
+			uint2 pr = pairs[i];
+			uint32_t a = pr.x, b = pr.y;            // a = later in Morton order
+			bool a_sph = a >= nbox, b_sph = b >= nbox;
+			if (!a_sph && !b_sph) {
+				nh_xform A = xf[a], B = xf[b];
+				nh_BoxCollider sa = box_data[a], sb = box_data[b];
+				uint32_t ta = ctag[a], tb = ctag[b];
+				nh_pair_result r = nh_box_box(A, B, sa.size, sb.size, ta, tb, out);
+				count = r.count;
+				uint32_t ca = r.swapped ? b : a, cb = r.swapped ? a : b;
+				key = (uint64_t)(r.swapped ? tb : ta) | ((uint64_t)(r.swapped ? ta : tb) << 32);
+				body_a = r.swapped ? B.body : A.body;
+				body_b = r.swapped ? A.body : B.body;
+				(void)ca; (void)cb;
+			} else if (a_sph && b_sph) {
+				// sphere-sphere: first = earlier in Morton order = pair.y (nudge.cpp:3775-3776)
+				nh_xform A = xf[b], B = xf[a];
+				count = nh_sphere_sphere(sph_data[b - nbox].radius, sph_data[a - nbox].radius, A, B, out);
+				key = (uint64_t)ctag[b] | ((uint64_t)ctag[a] << 32);
+				body_a = A.body; body_b = B.body;
+			} else {
+				// box-sphere: box is always "a" (nudge.cpp:3746-3751, 3759-3768)
+				uint32_t bx = a_sph ? b : a, sp = a_sph ? a : b;
+				nh_xform A = xf[bx], B = xf[sp];
+				nh_BoxCollider sz = box_data[bx];
+				count = nh_box_sphere(sz.size, sph_data[sp - nbox].radius, A, B, out);
+				key = (uint64_t)ctag[bx] | ((uint64_t)ctag[sp] << 32);
+				body_a = A.body; body_b = B.body;
+			}
+		}
+		uint32_t base = nh_wave_reserve(&st->raw_contacts, (uint32_t)count);
+		uint32_t slot = nh_wave_reserve(&st->records, count ? 1u : 0u);
+		if (count) {
+			if (base + count <= raw_cap) {
+				for (int k = 0; k < count; ++k) {
+					nh_Contact c;
+					c.position[0] = out[k].px; c.position[1] = out[k].py; c.position[2] = out[k].pz; c.penetration = out[k].penetration;
+					c.normal[0] = out[k].nx; c.normal[1] = out[k].ny; c.normal[2] = out[k].nz; c.friction = out[k].friction;
+					raw_data[base + k] = c;
+					raw_feature[base + k] = out[k].feature;
+				}
+			} else {
+				st->error = NH_ERR_CONTACT_CAPACITY;
+				count = 0;
+			}
+			rec_key[slot] = key;
+			nh_Record r = { body_a, body_b, base, (uint32_t)count };
+			rec[slot] = r;
+		}
+	}
+}
+
+// ---- 7. islands (lock-free union-find), active bodies, sleeping -------------------------------------------
+__global__ __launch_bounds__(256) void k_uf_init(uint32_t nbodies, uint32_t* __restrict__ parent, uint32_t* __restrict__ set_active) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) { parent[i] = i; set_active[i] = 0; }
+}
+
+__device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t x) {
+	uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	while (p != x) {
+		x = p;
+		p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	return x;
+}
+
+__device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t b) {
+	for (;;) {
+		a = uf_find(parent, a);
+		b = uf_find(parent, b);
+		if (a == b) return;
+		if (a < b) { uint32_t t = a; a = b; b = t; }       // hook the larger root under the smaller: root = min index
+		uint32_t old = atomicCAS(&parent[a], a, b);
+		if (old == a) return;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_uf_union_records(const nh_DevState* __restrict__ st, const nh_Record* __restrict__ rec, uint32_t* __restrict__ parent) {
+	uint32_t n = st->records;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		nh_Record r = rec[i];
+		if (r.body_a && r.body_b) uf_union(parent, r.body_a, r.body_b);      // body 0 is the static world (nudge.cpp:3874-3876)
+	}
+}
+
+__global__ __launch_bounds__(256) void k_uf_union_connections(const nh_BodyPair* __restrict__ con, uint32_t ncon, uint32_t* __restrict__ parent) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ncon; i += gridDim.x * blockDim.x) {
+		nh_BodyPair p = con[i];
+		if (p.a && p.b) uf_union(parent, p.a, p.b);                          // nudge.cpp:3799-3807
+	}
+}
+
+// flatten + "a set is active if any member's idle counter != 0xff" (nudge.cpp:3960-3963)
+__global__ __launch_bounds__(256) void k_uf_flatten(uint32_t nbodies, uint32_t* __restrict__ parent, const uint8_t* __restrict__ idle, uint32_t* __restrict__ set_active, uint32_t* __restrict__ root_of) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) {
+		uint32_t r = uf_find(parent, i);
+		root_of[i] = r;
+		if (i >= 1 && idle[i] != 0xff) set_active[r] = 1;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_active_flags(uint32_t nbodies, const uint32_t* __restrict__ root_of, const uint32_t* __restrict__ set_active, uint32_t* __restrict__ flags) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x)
+		flags[i] = (i >= 1 && set_active[root_of[i]]) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_active_write(nh_DevState* __restrict__ st, uint32_t nbodies, const uint32_t* __restrict__ root_of, const uint32_t* __restrict__ set_active,
+                                                      const uint32_t* __restrict__ scan, uint32_t* __restrict__ indices, uint32_t capacity) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) {
+		if (i >= 1 && set_active[root_of[i]]) {
+			uint32_t pos = scan[i];
+			if (pos < capacity) indices[pos] = i; else st->error = NH_ERR_ACTIVE_CAPACITY;
+		}
+	}
+}
+
+// contacts of inactive sets leave the contact list and become sleeping pairs (nudge.cpp:3976-4003)
+__global__ __launch_bounds__(256) void k_filter_records(nh_DevState* __restrict__ st, nh_Record* __restrict__ rec, uint64_t* __restrict__ rec_key, uint32_t* __restrict__ rec_idx,
+                                                        const uint32_t* __restrict__ root_of, const uint32_t* __restrict__ set_active,
+                                                        uint64_t* __restrict__ sleeping_pairs, uint32_t sleeping_cap) {
+	uint32_t n = st->records;
+	uint32_t rounded = (n + 63u) & ~63u;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
+		bool sleeping = false;
+		uint64_t key = 0;
+		if (i < n) {
+			nh_Record r = rec[i];
+			key = rec_key[i];
+			uint32_t set = root_of[r.body_a ? r.body_a : r.body_b];      // sets[a] | sets[b] with sets[0] = 0 (nudge.cpp:3988)
+			sleeping = !set_active[set];
+			rec_idx[i] = i;
+			if (sleeping) { rec[i].count = 0; rec_key[i] = ~0ull; }
+		}
+		uint32_t slot = nh_wave_reserve(&st->sleeping, sleeping ? 1u : 0u);
+		if (sleeping && sleeping_pairs && slot < sleeping_cap) sleeping_pairs[slot] = key;
+	}
+}
+
+// ---- 8. tag-ordered output ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sorted_counts(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ rec_idx, const nh_Record* __restrict__ rec, uint32_t* __restrict__ counts) {
+	uint32_t n = st->records;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) counts[i] = rec[rec_idx[i]].count;
+}
+
+__global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict__ st, const uint32_t* __restrict__ rec_idx, const nh_Record* __restrict__ rec, const uint64_t* __restrict__ rec_key_sorted,
+                                                         const uint32_t* __restrict__ starts, const nh_Contact* __restrict__ raw_data, const uint32_t* __restrict__ raw_feature,
+                                                         nh_Contact* __restrict__ data, nh_BodyPair* __restrict__ bodies, uint64_t* __restrict__ tags, uint32_t* __restrict__ features, uint32_t capacity) {
+	uint32_t n = st->records;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		nh_Record r = rec[rec_idx[i]];
+		if (!r.count) continue;
+		uint32_t dst = starts[i];
+		if (dst + r.count > capacity) { st->error = NH_ERR_CONTACT_CAPACITY; continue; }
+		uint64_t key = rec_key_sorted[i];
+		// stable insertion sort of <= 16 contacts by feature word (reference: low 32 tag bits, nudge.cpp:4031-4036)
+		uint32_t order[16], feat[16];
+		uint32_t cnt = r.count > 16 ? 16 : r.count;
+		for (uint32_t k = 0; k < cnt; ++k) {
+			uint32_t f = raw_feature[r.start + k];
+			uint32_t j = k;
+			while (j > 0 && feat[j - 1] > f) { feat[j] = feat[j - 1]; order[j] = order[j - 1]; --j; }
+			feat[j] = f; order[j] = k;
+		}
+		nh_BodyPair bp = { r.body_a, r.body_b };
+		for (uint32_t k = 0; k < cnt; ++k) {
+			data[dst + k] = raw_data[r.start + order[k]];
+			bodies[dst + k] = bp;
+			tags[dst + k] = key;
+			features[dst + k] = feat[k];
+		}
+	}
+}
+
+__global__ void k_collide_begin(nh_DevState* st, uint32_t ncolliders) {
+	uint32_t t = threadIdx.x;
+	if (t == 0) {
+		st->colliders = ncolliders; st->pairs = 0; st->raw_contacts = 0; st->records = 0; st->contacts = 0; st->sleeping = 0;
+		st->active = 0; st->culled = 0; st->large = 0; st->general_contacts = 0; st->levels = 0; st->error = 0;
+		st->static_bodies = 0; st->unleveled = 0;
+		for (int k = 0; k < 3; ++k) { st->smin[k] = 0xffffffffu; st->smax[k] = 0u; }
+	}
+	st->exp_hist[t] = 0;
+}
+
+__global__ void k_collide_end(nh_DevState* st, uint32_t sleeping_cap) {
+	if (st->sleeping > sleeping_cap) { st->sleeping = sleeping_cap; st->error = NH_ERR_CONTACT_CAPACITY; }
+}
+
+// =================================================================================================================
+extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_ContactData* contacts,
+                          const nh_BodyData* bodies, const nh_ColliderData* colliders,
+                          const nh_BodyConnections* body_connections, nh_Arena temporary) {
+	if (!ctx || !active_bodies || !contacts || !bodies || !colliders) return NH_ERR_INVALID;
+	NH_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+	nh_DevState* st = ctx->d_state;
+	const uint32_t nbox = colliders->boxes.count, nsph = colliders->spheres.count;
+	const uint32_t C = nbox + nsph;
+	const uint32_t B = bodies->count;
+	const uint32_t cap = contacts->capacity;
+	ctx->body_count = B;
+
+	int err = NH_OK;
+	nh_Arena* A = &temporary;
+	nh_xform* xf = nh_arena_array<nh_xform>(A, C, &err);
+	float4* aabb_min = nh_arena_array<float4>(A, C, &err);
+	float4* aabb_max = nh_arena_array<float4>(A, C, &err);
+	float4* smin = nh_arena_array<float4>(A, C, &err);
+	float4* smax = nh_arena_array<float4>(A, C, &err);
+	uint32_t* ctag = nh_arena_array<uint32_t>(A, C, &err);
+	uint64_t* mkey = nh_arena_array<uint64_t>(A, C, &err);
+	uint32_t* keys_a = nh_arena_array<uint32_t>(A, C, &err);
+	uint32_t* keys_b = nh_arena_array<uint32_t>(A, C, &err);
+	uint32_t* vals_a = nh_arena_array<uint32_t>(A, C, &err);
+	uint32_t* vals_b = nh_arena_array<uint32_t>(A, C, &err);
+	uint32_t* large_list = nh_arena_array<uint32_t>(A, C, &err);
+	uint32_t* hist = nh_arena_array<uint32_t>(A, 256 * NH_SORT_GRID + 64, &err);
+	uint32_t* scan_tmp = nh_arena_array<uint32_t>(A, NH_SORT_GRID + 64, &err);
+	// grid: up to 4 cells per collider (power of two), clamped
+	uint64_t want = 1; while (want < 4ull * C) want <<= 1;
+	if (want < (1u << 16)) want = 1u << 16;
+	if (want > NH_MAX_CELLS) want = NH_MAX_CELLS;
+	const uint32_t max_cells = (uint32_t)want;
+	uint2* cells = nh_arena_array<uint2>(A, max_cells, &err);
+	const uint32_t pair_cap = cap;
+	uint2* pairs = nh_arena_array<uint2>(A, pair_cap, &err);
+	nh_Contact* raw_data = nh_arena_array<nh_Contact>(A, cap, &err);
+	uint32_t* raw_feature = nh_arena_array<uint32_t>(A, cap, &err);
+	uint64_t* rec_key_a = nh_arena_array<uint64_t>(A, pair_cap, &err);
+	uint64_t* rec_key_b = nh_arena_array<uint64_t>(A, pair_cap, &err);
+	uint32_t* rec_idx_a = nh_arena_array<uint32_t>(A, pair_cap, &err);
+	uint32_t* rec_idx_b = nh_arena_array<uint32_t>(A, pair_cap, &err);
+	nh_Record* rec = nh_arena_array<nh_Record>(A, pair_cap, &err);
+	uint32_t* rec_counts = nh_arena_array<uint32_t>(A, pair_cap + 1, &err);
+	uint32_t* parent = nh_arena_array<uint32_t>(A, B, &err);
+	uint32_t* set_active = nh_arena_array<uint32_t>(A, B, &err);
+	uint32_t* root_of = nh_arena_array<uint32_t>(A, B, &err);
+	uint32_t* flags = nh_arena_array<uint32_t>(A, B + 1, &err);
+	uint64_t* sleep_tmp = nh_arena_array<uint64_t>(A, cap, &err);
+	if (err) return err;
+
+	hipStream_t s = ctx->stream;
+	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, 1, 256, st, C);
+	if (C) {
+		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 256, 2048), 256, st, bodies->transforms,
+		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
+		          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
+		          xf, aabb_min, aabb_max, ctag);
+		NH_LAUNCH(ctx, "grid_params", k_grid_params, 1, 64, st, C, max_cells);
+		NH_LAUNCH(ctx, "cell_keys", k_cell_keys, nh_grid_for(C, 256, 2048), 256, st, C, aabb_min, aabb_max, keys_a, vals_a, mkey, large_list);
+		nh_sort_u32_u32(ctx, keys_a, keys_b, vals_a, vals_b, &st->colliders, hist, 0, 24);
+		if (ctx->timing) nh_timer_begin(ctx, "memset_cells");
+		NH_HIP_CHECK(ctx, hipMemsetAsync(cells, 0, sizeof(uint2) * (size_t)max_cells, s));
+		if (ctx->timing) nh_timer_end(ctx);
+		NH_LAUNCH(ctx, "cell_bounds", k_cell_bounds, nh_grid_for(C, 256, 2048), 256, C, keys_a, vals_a, aabb_min, aabb_max, cells, smin, smax);
+		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 4096), 256, st, C, keys_a, smin, smax, cells, large_list, aabb_min, aabb_max, mkey, pairs, pair_cap);
+		NH_LAUNCH(ctx, "narrowphase", k_narrowphase, nh_grid_for(pair_cap, 256, 4096), 256, st, pairs, xf, ctag,
+		          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, cap, rec_key_a, rec);
+	}
+	// islands over contact records (+ user connections)
+	NH_LAUNCH(ctx, "uf_init", k_uf_init, nh_grid_for(B, 256, 2048), 256, B, parent, set_active);
+	if (body_connections && body_connections->count)
+		NH_LAUNCH(ctx, "uf_union_connections", k_uf_union_connections, nh_grid_for(body_connections->count, 256, 2048), 256, body_connections->data, body_connections->count, parent);
+	NH_LAUNCH(ctx, "uf_union_records", k_uf_union_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, parent);
+	NH_LAUNCH(ctx, "uf_flatten", k_uf_flatten, nh_grid_for(B, 256, 2048), 256, B, parent, bodies->idle_counters, set_active, root_of);
+	NH_LAUNCH(ctx, "active_flags", k_active_flags, nh_grid_for(B, 256, 2048), 256, B, root_of, set_active, flags);
+	{
+		// number of bodies is known on the host: reuse the device-count scan with a constant count of 0 + extra
+		static_assert(sizeof(uint32_t) == 4, "");
+		nh_scan_u32(ctx, flags, flags, &st->pad0 /* always 0 */, B, scan_tmp, &st->active);
+	}
+	NH_LAUNCH(ctx, "active_write", k_active_write, nh_grid_for(B, 256, 2048), 256, st, B, root_of, set_active, flags, active_bodies->indices, active_bodies->capacity);
+	NH_LAUNCH(ctx, "filter_records", k_filter_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, rec_key_a, rec_idx_a, root_of, set_active, contacts->sleeping_pairs ? sleep_tmp : (uint64_t*)nullptr, cap);
+	// tag order: sort records by (b_tag, a_tag), then lay contacts out pair by pair
+	int key_bits = (int)ctx->tag_bits;
+	if (key_bits < 1) key_bits = 1;
+	if (key_bits > 32) key_bits = 32;
+	// keys are a | b<<32: sort the low field, then the high field (stable) -- dropped records carry ~0 and end up last
+	nh_sort_u64_u32(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, &st->records, hist, 0, ((key_bits + 7) / 8) * 8);
+	nh_sort_u64_u32(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, &st->records, hist, 32, 32 + ((key_bits + 7) / 8) * 8);
+	// (dropped records carry count 0, so where they land in the order is irrelevant)
+	NH_LAUNCH(ctx, "sorted_counts", k_sorted_counts, nh_grid_for(pair_cap, 256, 2048), 256, st, rec_idx_a, rec, rec_counts);
+	nh_scan_u32(ctx, rec_counts, rec_counts, &st->records, 0, scan_tmp, &st->contacts);
+	NH_LAUNCH(ctx, "gather_contacts", k_gather_contacts, nh_grid_for(pair_cap, 256, 4096), 256, st, rec_idx_a, rec, rec_key_a, rec_counts, raw_data, raw_feature,
+	          contacts->data, contacts->bodies, contacts->tags, contacts->features, cap);
+	// sleeping pairs, ascending (nudge.cpp:4008)
+	if (contacts->sleeping_pairs) {
+		NH_LAUNCH(ctx, "collide_end", k_collide_end, 1, 1, st, cap);
+		nh_sort_u64(ctx, sleep_tmp, (uint64_t*)raw_data /* raw contacts are dead now */, &st->sleeping, hist, 0, 64);
+		nh_copy_back_u32(ctx, (const uint32_t*)sleep_tmp, (uint32_t*)contacts->sleeping_pairs, &st->sleeping, 2);
+	}
+
+	if (ctx->flags & NH_FLAG_SYNC_COUNTS) {
+		nh_Counts c;
+		int rc = nh_read_counts(ctx, &c);
+		if (rc) return rc;
+		contacts->count = c.contacts;
+		contacts->sleeping_count = c.sleeping_pairs;
+		active_bodies->count = c.active_bodies;
+		if (c.error) return (int)c.error;
+	}
+	return NH_OK;
+}

@@ -1,0 +1,150 @@
+// nh_context.hip -- context lifecycle, device counters -> host, per-kernel timing, error strings.
+#include "nh_internal.h"
+
+extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t flags) {
+	if (!out) return NH_ERR_INVALID;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return NH_ERR_NO_DEVICE;
+	if (hipSetDevice(device) != hipSuccess) return NH_ERR_NO_DEVICE;
+	nh_context* ctx = new nh_context();
+	ctx->device = device;
+	ctx->stream = (hipStream_t)stream;
+	ctx->flags = flags;
+	ctx->tag_bits = 32;
+	ctx->last_hip_error = 0;
+	ctx->timing = false;
+	ctx->ring_pos = 0;
+	ctx->body_count = 0;
+	ctx->d_state = nullptr;
+	ctx->h_state = nullptr;
+	if (hipMalloc((void**)&ctx->d_state, sizeof(nh_DevState)) != hipSuccess) { delete ctx; return NH_ERR_HIP; }
+	if (hipHostMalloc((void**)&ctx->h_state, sizeof(nh_DevState), 0) != hipSuccess) { hipFree(ctx->d_state); delete ctx; return NH_ERR_HIP; }
+	hipMemsetAsync(ctx->d_state, 0, sizeof(nh_DevState), ctx->stream);
+	hipStreamSynchronize(ctx->stream);
+	*out = ctx;
+	return NH_OK;
+}
+
+extern "C" void nh_destroy(nh_context* ctx) {
+	if (!ctx) return;
+	hipSetDevice(ctx->device);
+	hipStreamSynchronize(ctx->stream);
+	for (auto& s : ctx->timer_slots) { ctx->event_pool.push_back(s.a); ctx->event_pool.push_back(s.b); }
+	for (auto e : ctx->event_pool) hipEventDestroy(e);
+	for (auto p : ctx->impulse_ring) delete p;
+	for (auto p : ctx->constraint_ring) delete p;
+	if (ctx->d_state) hipFree(ctx->d_state);
+	if (ctx->h_state) hipHostFree(ctx->h_state);
+	delete ctx;
+}
+
+extern "C" int nh_set_flags(nh_context* ctx, uint32_t flags) { if (!ctx) return NH_ERR_INVALID; ctx->flags = flags; return NH_OK; }
+extern "C" int nh_set_tag_bits(nh_context* ctx, uint32_t bits) { if (!ctx || bits < 1 || bits > 32) return NH_ERR_INVALID; ctx->tag_bits = bits; return NH_OK; }
+
+extern "C" int nh_synchronize(nh_context* ctx) {
+	if (!ctx) return NH_ERR_INVALID;
+	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+	if (ctx->timing) nh_timer_collect(ctx);
+	return NH_OK;
+}
+
+extern "C" int nh_read_counts(nh_context* ctx, nh_Counts* out) {
+	if (!ctx || !out) return NH_ERR_INVALID;
+	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+	const nh_DevState* h = ctx->h_state;
+	out->colliders = h->colliders; out->pairs = h->pairs > 0 ? h->pairs : 0; out->contacts = h->contacts; out->sleeping_pairs = h->sleeping;
+	out->active_bodies = h->active; out->cache = h->cache; out->culled = h->culled; out->large_colliders = h->large;
+	out->general_contacts = h->general_contacts; out->levels = h->levels; out->error = h->error;
+	out->static_bodies = h->static_bodies; out->unleveled = h->unleveled; out->raw_pairs = h->pairs;
+	if (ctx->timing) nh_timer_collect(ctx);
+	return NH_OK;
+}
+
+__global__ void k_set_cache_count(nh_DevState* st, uint32_t n) { st->cache = n; }
+
+extern "C" int nh_set_cache_count(nh_context* ctx, uint32_t count) {
+	if (!ctx) return NH_ERR_INVALID;
+	hipLaunchKernelGGL(k_set_cache_count, dim3(1), dim3(1), 0, ctx->stream, ctx->d_state, count);
+	return NH_OK;
+}
+
+extern "C" const char* nh_error_string(int code) {
+	switch (code) {
+	case NH_OK: return "ok";
+	case NH_ERR_INVALID: return "invalid argument";
+	case NH_ERR_NO_DEVICE: return "no HIP device";
+	case NH_ERR_ARENA: return "arena exhausted";
+	case NH_ERR_CONTACT_CAPACITY: return "contact capacity exceeded";
+	case NH_ERR_CACHE_CAPACITY: return "contact cache capacity exceeded";
+	case NH_ERR_ACTIVE_CAPACITY: return "active body capacity exceeded";
+	case NH_ERR_PAIR_CAPACITY: return "broadphase pair capacity exceeded";
+	case NH_ERR_HIP: return "HIP runtime error";
+	default: return "unknown error";
+	}
+}
+
+extern "C" int nh_last_hip_error(nh_context* ctx) { return ctx ? ctx->last_hip_error : 0; }
+
+// ---- per-kernel timing with HIP events on the context's stream ----------------------------------------------
+static hipEvent_t take_event(nh_context* ctx) {
+	if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+	hipEvent_t e;
+	hipEventCreate(&e);
+	return e;
+}
+
+void nh_timer_begin(nh_context* ctx, const char* name) {
+	nh_TimerSlot s;
+	s.name = name;
+	s.a = take_event(ctx);
+	s.b = take_event(ctx);
+	hipEventRecord(s.a, ctx->stream);
+	ctx->timer_slots.push_back(s);
+}
+
+void nh_timer_end(nh_context* ctx) {
+	hipEventRecord(ctx->timer_slots.back().b, ctx->stream);
+}
+
+void nh_timer_collect(nh_context* ctx) {
+	for (auto& s : ctx->timer_slots) {
+		float ms = 0.0f;
+		if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+			auto& acc = ctx->kernel_ms[s.name];
+			acc.first += ms;
+			acc.second += 1;
+		}
+		ctx->event_pool.push_back(s.a);
+		ctx->event_pool.push_back(s.b);
+	}
+	ctx->timer_slots.clear();
+}
+
+extern "C" int nh_enable_timing(nh_context* ctx, int on) {
+	if (!ctx) return NH_ERR_INVALID;
+	hipStreamSynchronize(ctx->stream);
+	if (ctx->timing) nh_timer_collect(ctx);
+	ctx->timing = on != 0;
+	return NH_OK;
+}
+
+extern "C" int nh_kernel_times(nh_context* ctx, nh_KernelTime* out, int cap, int reset) {
+	if (!ctx) return 0;
+	hipStreamSynchronize(ctx->stream);
+	nh_timer_collect(ctx);
+	int n = 0;
+	ctx->name_store.clear();
+	ctx->name_store.reserve(ctx->kernel_ms.size());
+	for (auto& kv : ctx->kernel_ms) {
+		if (n >= cap) break;
+		ctx->name_store.push_back(kv.first);
+		out[n].name = ctx->name_store.back().c_str();
+		out[n].ms = kv.second.first;
+		out[n].launches = kv.second.second;
+		out[n].reserved = 0;
+		++n;
+	}
+	if (reset) ctx->kernel_ms.clear();
+	return n;
+}

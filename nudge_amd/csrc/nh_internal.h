@@ -1,0 +1,191 @@
+// nh_internal.h -- shared by the .hip translation units of libnudge_hip.so (not installed).
+#ifndef NH_INTERNAL_H
+#define NH_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/nudge_hip.h"
+#include "nh_math.h"
+
+#define NH_WAVE 64
+#define NH_BLOCK 256
+#define NH_MAX_CELLS 0xFFFFFFu          // cell keys fit 24 bits (3 radix passes); key NH_LARGE_KEY marks a large collider
+#define NH_LARGE_KEY 0xFFFFFFu
+#define NH_SORT_GRID 512                // blocks per radix-sort pass (each owns a contiguous chunk)
+#define NH_MAX_LEVELS 4096
+
+// ---- device-resident step state (one per context) ---------------------------------------------------
+struct nh_DevState {
+	// counters (zeroed at the start of nh_collide, except `cache`)
+	uint32_t colliders;
+	uint32_t pairs;
+	uint32_t raw_contacts;
+	uint32_t records;
+	uint32_t contacts;
+	uint32_t sleeping;
+	uint32_t active;
+	uint32_t cache;
+	uint32_t culled;
+	uint32_t large;
+	uint32_t general_contacts;
+	uint32_t levels;
+	uint32_t error;
+	uint32_t static_bodies;       // bodies solved by the one-body fast path
+	uint32_t unleveled;           // general contacts still without a level (relaxation progress)
+	uint32_t pad0;
+	// scene bounds of AABB min corners, order-preserving uint encoding (atomicMin/Max)
+	uint32_t smin[3];
+	uint32_t smax[3];
+	// broadphase grid parameters (written by k_grid_params)
+	float morton_scale;
+	float morton_min[3];          // scene_min * scale
+	float cell_inv;               // 1 / cell size (cell size is a power of two)
+	float origin[3];
+	uint32_t dims[3];
+	uint32_t small_exp;           // colliders whose max-extent exponent is <= small_exp go to the grid
+	uint32_t exp_hist[256];
+};
+
+struct nh_TimerSlot { const char* name; hipEvent_t a, b; };
+
+struct nh_context {
+	int device;
+	hipStream_t stream;
+	uint32_t flags;
+	uint32_t tag_bits;
+	nh_DevState* d_state;
+	nh_DevState* h_state;          // pinned mirror
+	int last_hip_error;
+	// timing
+	bool timing;
+	std::vector<nh_TimerSlot> timer_slots;
+	std::vector<hipEvent_t> event_pool;
+	std::map<std::string, std::pair<double, uint32_t>> kernel_ms;
+	std::vector<std::string> name_store;
+	// opaque result objects handed to the caller (ring)
+	std::vector<nh_ContactImpulseData*> impulse_ring;
+	std::vector<nh_ContactConstraintData*> constraint_ring;
+	uint32_t ring_pos;
+	// last collide: number of bodies (for sizing), contact capacity
+	uint32_t body_count;
+};
+
+struct nh_ContactImpulseData {
+	nh_CachedContactImpulse* data;        // K, contact (tag) order
+	uint64_t* culled_tags;
+	uint32_t* culled_features;
+	nh_CachedContactImpulse* culled_data;
+	uint32_t capacity;                    // contact capacity the arrays were sized for
+	uint32_t culled_capacity;
+};
+
+struct nh_ContactConstraintData {
+	float* rows;                          // K x 40 floats (nh_row)
+	float* states;                        // K x 4 floats (nh_state + pad)
+	uint32_t* body_off;                   // B+1 CSR offsets into adj
+	uint32_t* adj;                        // contact indices per dynamic body, solver order
+	uint32_t* static_bodies;              // compacted list of bodies on the one-body fast path
+	uint8_t* body_class;                  // 0 none, 1 static-only, 2 general
+	uint32_t* level_order;                // general contacts sorted by level
+	uint32_t level_off[NH_MAX_LEVELS + 2];// host copy of level offsets
+	uint32_t levels;
+	uint32_t general_contacts;
+	uint32_t contact_capacity;
+	uint32_t body_count;
+	uint32_t static_body_count;
+	const nh_BodyPair* bodies;
+};
+
+// ---- arena (host-side bump allocation over device memory, reference nudge.cpp:990-1055) ---------------
+static inline void* nh_arena_alloc(nh_Arena* arena, uintptr_t size, uintptr_t alignment, int* err) {
+	uintptr_t data = (uintptr_t)arena->data;
+	uintptr_t end = data + arena->size;
+	uintptr_t mask = alignment - 1;
+	data = (data + mask) & ~mask;
+	if (data + size > end) { *err = NH_ERR_ARENA; return nullptr; }
+	arena->data = (void*)(data + size);
+	arena->size = end - (data + size);
+	return (void*)data;
+}
+
+template<class T>
+static inline T* nh_arena_array(nh_Arena* arena, uintptr_t count, int* err, uintptr_t alignment = 256) {
+	return static_cast<T*>(nh_arena_alloc(arena, sizeof(T) * (count ? count : 1), alignment, err));
+}
+
+// ---- launch with optional per-kernel timing -----------------------------------------------------------
+void nh_timer_begin(nh_context* ctx, const char* name);
+void nh_timer_end(nh_context* ctx);
+void nh_timer_collect(nh_context* ctx);
+
+#define NH_LAUNCH(ctx, name, kernel, grid, block, ...)                                           \
+	do {                                                                                         \
+		if ((ctx)->timing) nh_timer_begin((ctx), name);                                          \
+		hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__);      \
+		if ((ctx)->timing) nh_timer_end((ctx));                                                  \
+	} while (0)
+
+#define NH_HIP_CHECK(ctx, expr)                                                                  \
+	do {                                                                                         \
+		hipError_t e_ = (expr);                                                                  \
+		if (e_ != hipSuccess) { (ctx)->last_hip_error = (int)e_; return NH_ERR_HIP; }            \
+	} while (0)
+
+static inline uint32_t nh_grid_for(uint64_t n, uint32_t block = NH_BLOCK, uint32_t max_blocks = 4096) {
+	uint64_t g = (n + block - 1) / block;
+	if (g < 1) g = 1;
+	if (g > max_blocks) g = max_blocks;
+	return (uint32_t)g;
+}
+
+// ---- utilities implemented in nh_util.hip (all sizes come from DEVICE counters) ------------------------
+// Stable LSD radix sorts, 8-bit digits, bits [begin_bit, end_bit).  Result ends up in the *_a buffers.
+void nh_sort_u32_u32(nh_context* ctx, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+                     const uint32_t* d_count, uint32_t* hist /* 256*NH_SORT_GRID+8 */, int begin_bit, int end_bit);
+void nh_sort_u64_u32(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+                     const uint32_t* d_count, uint32_t* hist, int begin_bit, int end_bit);
+void nh_sort_u64(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b,
+                 const uint32_t* d_count, uint32_t* hist, int begin_bit, int end_bit);
+// Exclusive scan of `in[0..n)` into `out` (may alias); n read from *d_count (+ `extra` elements);
+// the grand total is also stored to *d_total if non-null.  `tmp` needs NH_SORT_GRID+8 words.
+void nh_scan_u32(nh_context* ctx, const uint32_t* in, uint32_t* out, const uint32_t* d_count, uint32_t extra,
+                 uint32_t* tmp, uint32_t* d_total);
+
+// dst[0 .. *d_count * words_per_item) = src[...]
+void nh_copy_back_u32(nh_context* ctx, const uint32_t* src, uint32_t* dst, const uint32_t* d_count, uint32_t words_per_item);
+
+// ---- device helpers ------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned nh_lane() { return __lane_id(); }
+
+__device__ __forceinline__ uint32_t nh_float_flip(float f) {
+	uint32_t u = __float_as_uint(f);
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float nh_float_unflip(uint32_t u) {
+	u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+	return __uint_as_float(u);
+}
+
+// Wave-aggregated reservation: every active lane asks for `n` slots (may be 0); returns the lane's base.
+__device__ __forceinline__ uint32_t nh_wave_reserve(uint32_t* counter, uint32_t n) {
+	// inclusive prefix sum over the wave (all 64 lanes must call)
+	uint32_t x = n;
+	for (int d = 1; d < 64; d <<= 1) {
+		uint32_t y = __shfl_up(x, d);
+		if ((int)nh_lane() >= d) x += y;
+	}
+	uint32_t total = __shfl(x, 63);
+	uint32_t base = 0;
+	if (nh_lane() == 63 && total) base = atomicAdd(counter, total);
+	base = __shfl(base, 63);
+	return base + x - n;
+}
+#endif
+
+#endif

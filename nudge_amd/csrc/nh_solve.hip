@@ -1,0 +1,681 @@
+// nh_solve.hip -- contact cache (read/write), constraint setup, the sequential-impulse solver, cached-impulse
+// export, gravity/damping and the integrator.  Replaces reference nudge.cpp:4011-4926 and the caller-side
+// loop example/main.cpp:290-305.
+//
+// Solver order.  The reference runs projected Gauss-Seidel over 8-wide batches produced by a sequential
+// greedy scheduler (nudge.cpp:4206-4339); the only thing about that schedule that influences the result is,
+// for every dynamic body, the ORDER in which its contacts are visited (contacts that share no dynamic body
+// commute exactly; body 0 is static and never conflicts, nudge.cpp:4238-4240).  So every contact gets a
+// "slot key" = the index of the reference batch it would be in -- either replayed exactly on the device
+// (NH_FLAG_EXACT_ORDER) or by the closed form batch(i) = (i/128)*16 + i%16, which is what the scheduler
+// produces whenever it meets no lane conflict (single-layer drop scenes) -- and two engines execute that
+// order:
+//   * one-body fast path: a body whose contacts are all against body 0 is an independent problem; one lane
+//     owns it, keeps its velocity in registers and walks its contacts in slot order for all iterations;
+//   * level schedule: remaining contacts get level = 1 + max(level of the previous contact on either body);
+//     levels run one after the other, contacts inside a level are independent.  Executing levels in order
+//     is exactly the sequential Gauss-Seidel sweep in slot order.
+#include "nh_internal.h"
+#include "nh_solver.h"
+
+#define NH_NONE 0xFFFFFFFFu
+#define NH_UNSET 0xFFFFFFFFu
+
+__device__ __forceinline__ bool tag_less(uint64_t ta, uint32_t fa, uint64_t tb, uint32_t fb) { return ta < tb || (ta == tb && fa < fb); }
+
+// ---- gravity + damping over the active list (example/main.cpp:290-305) -------------------------------------
+__global__ __launch_bounds__(256) void k_gravity(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ active, nh_BodyMomentum* __restrict__ momentum,
+                                                 float gx_dt, float gy_dt, float gz_dt, float damping) {
+	uint32_t n = st->active;
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		uint32_t i = active[k];
+		nh_BodyMomentum m = momentum[i];
+		nh_gravity_damping(m.velocity, m.angular_velocity, gx_dt, gy_dt, gz_dt, damping);
+		momentum[i] = m;
+	}
+}
+
+// ---- advance (nudge.cpp:4886-4926) ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_advance(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ active, nh_Transform* __restrict__ xf,
+                                                 const nh_BodyMomentum* __restrict__ momentum, uint8_t* __restrict__ idle, float time_step) {
+	uint32_t n = st->active;
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		uint32_t i = active[k];
+		nh_Transform t = xf[i];
+		nh_BodyMomentum m = momentum[i];
+		idle[i] = nh_advance_body(t.position, t.rotation, m.velocity, m.angular_velocity, idle[i], time_step);
+		xf[i] = t;
+	}
+}
+
+// ---- read_cached_impulses (nudge.cpp:4021-4108) ------------------------------------------------------------------
+// contacts are already in tag order, so the reference's merge-join becomes one binary search per contact.
+__global__ __launch_bounds__(256) void k_cache_lookup(const nh_DevState* __restrict__ st, const uint64_t* __restrict__ tags, const uint32_t* __restrict__ features,
+                                                      const uint64_t* __restrict__ ctags, const uint32_t* __restrict__ cfeatures, const nh_CachedContactImpulse* __restrict__ cdata,
+                                                      nh_CachedContactImpulse* __restrict__ out) {
+	uint32_t n = st->contacts, m = st->cache;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		uint64_t t = tags[i]; uint32_t f = features[i];
+		uint32_t lo = 0, hi = m;
+		while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (tag_less(ctags[mid], cfeatures[mid], t, f)) lo = mid + 1; else hi = mid; }
+		nh_CachedContactImpulse r = { { 0.0f, 0.0f, 0.0f }, 0.0f };
+		if (lo < m && ctags[lo] == t && cfeatures[lo] == f) r = cdata[lo];
+		out[i] = r;
+	}
+}
+
+// cached impulses of sleeping pairs are kept aside (nudge.cpp:4064-4101)
+__global__ __launch_bounds__(256) void k_cull_flags(const nh_DevState* __restrict__ st, const uint64_t* __restrict__ ctags, const uint64_t* __restrict__ sleeping, uint32_t* __restrict__ flags) {
+	uint32_t m = st->cache, ns = st->sleeping;
+	if (blockIdx.x == 0 && threadIdx.x == 0) flags[m] = 0;       // sentinel so that scan[m] = number of culled entries
+	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
+		uint64_t t = ctags[j];
+		uint32_t lo = 0, hi = ns;
+		while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (sleeping[mid] < t) lo = mid + 1; else hi = mid; }
+		flags[j] = (lo < ns && sleeping[lo] == t) ? 1u : 0u;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_cull_write(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ flags_in, const uint32_t* __restrict__ scan,
+                                                    const uint64_t* __restrict__ ctags, const uint32_t* __restrict__ cfeatures, const nh_CachedContactImpulse* __restrict__ cdata,
+                                                    uint64_t* __restrict__ otags, uint32_t* __restrict__ ofeatures, nh_CachedContactImpulse* __restrict__ odata) {
+	uint32_t m = st->cache;
+	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
+		// flags were scanned in place into `scan`; an entry is culled iff scan[j+1] != scan[j]
+		uint32_t p = scan[j], q = scan[j + 1];
+		if (q != p) { otags[p] = ctags[j]; ofeatures[p] = cfeatures[j]; odata[p] = cdata[j]; }
+		(void)flags_in;
+	}
+}
+
+// ---- write_cached_impulses (nudge.cpp:4110-4158): merge of two sorted runs by rank -------------------------------
+__global__ __launch_bounds__(256) void k_write_cache(nh_DevState* __restrict__ st, const uint64_t* __restrict__ tags, const uint32_t* __restrict__ features, const nh_CachedContactImpulse* __restrict__ imp,
+                                                     const uint64_t* __restrict__ ktags, const uint32_t* __restrict__ kfeatures, const nh_CachedContactImpulse* __restrict__ kdata,
+                                                     uint64_t* __restrict__ otags, uint32_t* __restrict__ ofeatures, nh_CachedContactImpulse* __restrict__ odata, uint32_t capacity) {
+	uint32_t n = st->contacts, m = st->culled;
+	uint32_t total = n + m;
+	if (total > capacity) { if (blockIdx.x == 0 && threadIdx.x == 0) { st->error = NH_ERR_CACHE_CAPACITY; st->cache = 0; } return; }
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+		if (i < n) {
+			// contact i goes after every culled entry with key <= its key ("if (a < b) contact else culled")
+			uint64_t t = tags[i]; uint32_t f = features[i];
+			uint32_t lo = 0, hi = m;
+			while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (!tag_less(t, f, ktags[mid], kfeatures[mid])) lo = mid + 1; else hi = mid; }
+			uint32_t pos = i + lo;
+			otags[pos] = t; ofeatures[pos] = f; odata[pos] = imp[i];
+		} else {
+			uint32_t j = i - n;
+			uint64_t t = ktags[j]; uint32_t f = kfeatures[j];
+			uint32_t lo = 0, hi = n;
+			while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (tag_less(tags[mid], features[mid], t, f)) lo = mid + 1; else hi = mid; }
+			uint32_t pos = j + lo;
+			otags[pos] = t; ofeatures[pos] = f; odata[pos] = kdata[j];
+		}
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) st->cache = total;
+}
+
+// ---- setup: per-body adjacency in solver order -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_zero_u32(uint32_t* __restrict__ p, uint32_t n) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_degree(const nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, uint32_t* __restrict__ deg,
+                                                uint32_t* __restrict__ pred_a, uint32_t* __restrict__ pred_b) {
+	uint32_t n = st->contacts;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		nh_BodyPair p = bodies[i];
+		if (p.a) atomicAdd(&deg[p.a], 1u);
+		if (p.b) atomicAdd(&deg[p.b], 1u);
+		pred_a[i] = NH_NONE; pred_b[i] = NH_NONE;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_adj_fill(const nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, const uint32_t* __restrict__ off,
+                                                  uint32_t* __restrict__ cursor, uint32_t* __restrict__ adj) {
+	uint32_t n = st->contacts;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		nh_BodyPair p = bodies[i];
+		if (p.a) adj[off[p.a] + atomicAdd(&cursor[p.a], 1u)] = i;
+		if (p.b) adj[off[p.b] + atomicAdd(&cursor[p.b], 1u)] = i;
+	}
+}
+
+__device__ __forceinline__ uint32_t slot_key_of(uint32_t i, const uint32_t* __restrict__ slot_key) {
+	// closed form of the reference's round-robin scheduler when it meets no lane conflict:
+	// contact i -> bucket i%16, lane (i/16)%8; batches fill (and are emitted) bucket by bucket every 128 contacts.
+	return slot_key ? slot_key[i] : ((i >> 7) * 16u + (i & 15u));
+}
+
+// one lane per body: sort its contact list by slot key, classify, record per-contact predecessors
+__global__ __launch_bounds__(256) void k_adj_sort(nh_DevState* __restrict__ st, uint32_t nbodies, const nh_BodyPair* __restrict__ bodies, const uint32_t* __restrict__ off,
+                                                  uint32_t* __restrict__ adj, const uint32_t* __restrict__ slot_key, uint8_t* __restrict__ body_class,
+                                                  uint32_t* __restrict__ pred_a, uint32_t* __restrict__ pred_b, uint32_t* __restrict__ static_list) {
+	uint32_t rounded = (nbodies + 63u) & ~63u;
+	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < rounded; x += gridDim.x * blockDim.x) {
+		uint32_t cls = 0;
+		if (x >= 1 && x < nbodies) {
+			uint32_t b = off[x], e = off[x + 1];
+			if (e > b) {
+				// insertion sort by (slot key, contact index)
+				for (uint32_t k = b + 1; k < e; ++k) {
+					uint32_t c = adj[k];
+					uint32_t kc = slot_key_of(c, slot_key);
+					uint32_t j = k;
+					while (j > b) {
+						uint32_t d = adj[j - 1];
+						uint32_t kd = slot_key_of(d, slot_key);
+						if (kd < kc || (kd == kc && d < c)) break;
+						adj[j] = d; --j;
+					}
+					adj[j] = c;
+				}
+				bool static_only = true;
+				uint32_t prev = NH_NONE;
+				for (uint32_t k = b; k < e; ++k) {
+					uint32_t c = adj[k];
+					nh_BodyPair p = bodies[c];
+					if (p.a == x) { pred_a[c] = prev; if (p.b) static_only = false; }
+					else          { pred_b[c] = prev; if (p.a) static_only = false; }
+					prev = c;
+				}
+				cls = static_only ? 1u : 2u;
+			}
+			body_class[x] = (uint8_t)cls;
+		} else if (x == 0 && nbodies) {
+			body_class[0] = 0;
+		}
+		uint32_t slot = nh_wave_reserve(&st->static_bodies, cls == 1u ? 1u : 0u);
+		if (cls == 1u) static_list[slot] = x;
+	}
+}
+
+// general contacts: flag, count, level = UNSET
+__global__ __launch_bounds__(256) void k_contact_class(nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, const uint8_t* __restrict__ body_class,
+                                                       uint32_t* __restrict__ level, uint32_t* __restrict__ general_list) {
+	uint32_t n = st->contacts;
+	uint32_t rounded = (n + 63u) & ~63u;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
+		bool general = false;
+		if (i < n) {
+			nh_BodyPair p = bodies[i];
+			general = (p.a && body_class[p.a] == 2) || (p.b && body_class[p.b] == 2);
+			level[i] = general ? NH_UNSET : 0u;
+		}
+		uint32_t slot = nh_wave_reserve(&st->general_contacts, general ? 1u : 0u);
+		if (general) general_list[slot] = i;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) st->unleveled = 1;   // forces at least one relaxation check
+}
+
+// ---- exact replay of the reference's greedy batch scheduler (nudge.cpp:4206-4339), one wave -------------------
+#define GR_BUCKETS 16
+#define GR_OPEN 64          // open (vacant) batches kept per bucket in LDS
+__global__ __launch_bounds__(64) void k_greedy_replay(nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, uint32_t* __restrict__ slot_key) {
+	__shared__ uint2 pair_ab[GR_BUCKETS][GR_OPEN + 1][8];
+	__shared__ uint32_t slot_idx[GR_BUCKETS][GR_OPEN + 1][8];
+	__shared__ uint32_t vacancy[GR_BUCKETS];
+	__shared__ uint32_t emitted;
+	const uint32_t lane = threadIdx.x, sub = lane >> 3, ln = lane & 7;
+	const uint32_t n = st->contacts;
+	if (lane < GR_BUCKETS) { vacancy[lane] = 0; }
+	if (lane == 0) emitted = 0;
+	for (uint32_t k = lane; k < GR_BUCKETS * 8; k += 64) pair_ab[k >> 3][0][k & 7] = make_uint2(NH_NONE, NH_NONE);
+	__syncthreads();
+	for (uint32_t i = 0; i < n; ++i) {
+		nh_BodyPair bp = bodies[i];
+		uint32_t bucket = i % GR_BUCKETS;
+		uint32_t ca = bp.a ? bp.a : bp.b, cb = bp.b ? bp.b : bp.a;     // ignore dependencies on body 0
+		uint32_t vac = vacancy[bucket];
+		// first open batch (or the all-invalid padding entry at index vac) without a conflicting lane
+		uint32_t j = NH_NONE;
+		for (uint32_t base = 0; j == NH_NONE; base += 8) {
+			uint32_t jb = base + sub;
+			bool in_range = jb <= vac;
+			uint2 ab = in_range ? pair_ab[bucket][jb][ln] : make_uint2(NH_NONE, NH_NONE);
+			bool conflict = in_range && (ab.x == ca || ab.y == ca || ab.x == cb || ab.y == cb);
+			unsigned long long bal = __ballot(conflict);
+			unsigned long long rng = __ballot(in_range);
+			for (uint32_t s = 0; s < 8; ++s) {
+				bool ok = ((rng >> (s * 8)) & 1ull) && (((bal >> (s * 8)) & 0xffull) == 0ull);
+				if (ok) { j = base + s; break; }
+			}
+		}
+		// first free lane of that batch
+		uint2 mine = pair_ab[bucket][j][ln];
+		unsigned long long freeb = __ballot(sub == 0 && mine.x == NH_NONE && mine.y == NH_NONE);
+		uint32_t free_lane = (uint32_t)__ffsll((long long)(freeb & 0xffull)) - 1u;
+		__syncthreads();
+		if (lane == 0) {
+			slot_idx[bucket][j][free_lane] = i;
+			pair_ab[bucket][j][free_lane] = make_uint2(ca, cb);
+		}
+		__syncthreads();
+		bool changed = false;
+		if (j == vac) {
+			vac = vac + 1;
+			changed = true;
+			if (vac > GR_OPEN) { if (lane == 0) st->error = NH_ERR_INVALID; return; }
+		} else if (free_lane == 7) {
+			// batch complete: emit it, move the last open batch into its place
+			uint32_t e = emitted;
+			if (lane < 8) slot_key[slot_idx[bucket][j][lane]] = e;
+			vac = vac - 1;
+			__syncthreads();
+			if (lane < 8) {
+				pair_ab[bucket][j][lane] = pair_ab[bucket][vac][lane];
+				slot_idx[bucket][j][lane] = slot_idx[bucket][vac][lane];
+			}
+			if (lane == 0) emitted = e + 1;
+			changed = true;
+		}
+		__syncthreads();
+		if (changed) {
+			if (lane == 0) vacancy[bucket] = vac;
+			if (lane < 8) pair_ab[bucket][vac][lane] = make_uint2(NH_NONE, NH_NONE);
+		}
+		__syncthreads();
+	}
+	// leftovers, bucket by bucket (nudge.cpp:4316-4337)
+	uint32_t e = emitted;
+	for (uint32_t b = 0; b < GR_BUCKETS; ++b) {
+		uint32_t vac = vacancy[b];
+		for (uint32_t j = 0; j < vac; ++j) {
+			if (lane < 8) {
+				uint2 ab = pair_ab[b][j][lane];
+				if (!(ab.x == NH_NONE && ab.y == NH_NONE)) slot_key[slot_idx[b][j][lane]] = e;
+			}
+			++e;
+		}
+	}
+}
+
+// ---- body state access -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ nh_vel load_vel(const nh_BodyMomentum* __restrict__ momentum, const nh_BodyProperties* __restrict__ props, uint32_t i) {
+	nh_BodyMomentum m = momentum[i];
+	nh_vel v;
+	v.vx = m.velocity[0]; v.vy = m.velocity[1]; v.vz = m.velocity[2];
+	v.mass_inverse = props[i].mass_inverse;          // the reference stashes it in unused0 (nudge.cpp:4198)
+	v.wx = m.angular_velocity[0]; v.wy = m.angular_velocity[1]; v.wz = m.angular_velocity[2];
+	v.w_unused = m.unused1;
+	return v;
+}
+
+__device__ __forceinline__ void store_vel(nh_BodyMomentum* __restrict__ momentum, uint32_t i, const nh_vel& v) {
+	nh_BodyMomentum m;
+	m.velocity[0] = v.vx; m.velocity[1] = v.vy; m.velocity[2] = v.vz; m.unused0 = v.mass_inverse;
+	m.angular_velocity[0] = v.wx; m.angular_velocity[1] = v.wy; m.angular_velocity[2] = v.wz; m.unused1 = v.w_unused;
+	momentum[i] = m;
+}
+
+__device__ __forceinline__ nh_inertia body_inertia(const nh_Transform* __restrict__ xf, const nh_BodyProperties* __restrict__ props, uint32_t i) {
+	nh_Transform t = xf[i];
+	nh_BodyProperties p = props[i];
+	nh_quat q = { t.rotation[0], t.rotation[1], t.rotation[2], t.rotation[3] };
+	return nh_world_inertia(q, p.inertia_inverse[0], p.inertia_inverse[1], p.inertia_inverse[2]);
+}
+
+__device__ __forceinline__ void store_row(float* __restrict__ rows, uint32_t c, const nh_row& r) {
+	float4* dst = reinterpret_cast<float4*>(rows + (size_t)c * 40);
+	const float4* src = reinterpret_cast<const float4*>(&r);
+#pragma unroll
+	for (int k = 0; k < 10; ++k) dst[k] = src[k];
+}
+
+__device__ __forceinline__ void load_row(const float* __restrict__ rows, uint32_t c, nh_row& r) {
+	const float4* src = reinterpret_cast<const float4*>(rows + (size_t)c * 40);
+	float4* dst = reinterpret_cast<float4*>(&r);
+#pragma unroll
+	for (int k = 0; k < 10; ++k) dst[k] = src[k];
+}
+
+// ---- one-body fast path: setup (rows + warm start) ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_setup_static(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
+                                                      const nh_Contact* __restrict__ contacts, const nh_BodyPair* __restrict__ bodies, const nh_CachedContactImpulse* __restrict__ cached,
+                                                      const nh_Transform* __restrict__ xf, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
+                                                      float* __restrict__ rows, float4* __restrict__ states) {
+	uint32_t n = st->static_bodies;
+	const nh_inertia I0 = body_inertia(xf, props, 0);
+	const nh_Transform t0 = xf[0];
+	const nh_f3 pos0 = nh_make3(t0.position[0], t0.position[1], t0.position[2]);
+	const nh_vel vel0 = load_vel(momentum, props, 0);
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		uint32_t x = static_list[k];
+		nh_inertia IX = body_inertia(xf, props, x);
+		nh_Transform tx = xf[x];
+		nh_f3 posx = nh_make3(tx.position[0], tx.position[1], tx.position[2]);
+		nh_vel v = load_vel(momentum, props, x);
+		nh_vel z = vel0;
+		uint32_t b = off[x], e = off[x + 1];
+		for (uint32_t q = b; q < e; ++q) {
+			uint32_t c = adj[q];
+			nh_Contact ct = contacts[c];
+			nh_contact_in ci = { ct.position[0], ct.position[1], ct.position[2], ct.penetration, ct.normal[0], ct.normal[1], ct.normal[2], ct.friction };
+			nh_CachedContactImpulse w = cached[c];
+			bool x_is_a = bodies[c].a == x;
+			nh_row r;
+			nh_state s;
+			if (x_is_a) {
+				nh_build_row(ci, posx, pos0, IX, I0, v.mass_inverse, z.mass_inverse, r);
+				nh_warm_start(r, w.impulse[0], w.impulse[1], w.impulse[2], v, z, s);
+			} else {
+				nh_build_row(ci, pos0, posx, I0, IX, z.mass_inverse, v.mass_inverse, r);
+				nh_warm_start(r, w.impulse[0], w.impulse[1], w.impulse[2], z, v, s);
+			}
+			store_row(rows, c, r);
+			states[c] = make_float4(s.normal, s.friction_x, s.friction_y, 0.0f);
+		}
+		store_vel(momentum, x, v);
+	}
+}
+
+// ---- one-body fast path: `iterations` PGS sweeps ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_apply_static(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
+                                                      const nh_BodyPair* __restrict__ bodies, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
+                                                      const float* __restrict__ rows, float4* __restrict__ states, uint32_t iterations) {
+	uint32_t n = st->static_bodies;
+	const nh_vel vel0 = load_vel(momentum, props, 0);
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		uint32_t x = static_list[k];
+		nh_vel v = load_vel(momentum, props, x);
+		nh_vel z = vel0;
+		uint32_t b = off[x], e = off[x + 1];
+		for (uint32_t it = 0; it < iterations; ++it) {
+			for (uint32_t q = b; q < e; ++q) {
+				uint32_t c = adj[q];
+				nh_row r;
+				load_row(rows, c, r);
+				float4 sv = states[c];
+				nh_state s = { sv.x, sv.y, sv.z };
+				if (bodies[c].a == x) nh_apply_one(r, s, v, z); else nh_apply_one(r, s, z, v);
+				states[c] = make_float4(s.normal, s.friction_x, s.friction_y, 0.0f);
+			}
+		}
+		store_vel(momentum, x, v);
+	}
+}
+
+// ---- level-scheduled path ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_level_relax(nh_DevState* __restrict__ st, const uint32_t* __restrict__ general_list, const uint32_t* __restrict__ pred_a, const uint32_t* __restrict__ pred_b, uint32_t* __restrict__ level) {
+	uint32_t n = st->general_contacts;
+	uint32_t left = 0;
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		uint32_t c = general_list[k];
+		if (__hip_atomic_load(&level[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != NH_UNSET) continue;
+		uint32_t pa = pred_a[c], pb = pred_b[c];
+		uint32_t la = pa == NH_NONE ? 0u : __hip_atomic_load(&level[pa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		uint32_t lb = pb == NH_NONE ? 0u : __hip_atomic_load(&level[pb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (la == NH_UNSET || lb == NH_UNSET) { ++left; continue; }
+		uint32_t l = (la > lb ? la : lb) + 1u;
+		__hip_atomic_store(&level[c], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		atomicMax(&st->levels, l);
+	}
+	if (left) atomicAdd(&st->unleveled, left);
+}
+
+__global__ void k_level_reset_progress(nh_DevState* st) { st->unleveled = 0; }
+
+__global__ __launch_bounds__(256) void k_level_hist(nh_DevState* __restrict__ st, const uint32_t* __restrict__ general_list, const uint32_t* __restrict__ level, uint32_t* __restrict__ hist) {
+	uint32_t n = st->general_contacts;
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		uint32_t l = level[general_list[k]];
+		if (l <= NH_MAX_LEVELS) atomicAdd(&hist[l], 1u); else st->error = NH_ERR_INVALID;
+	}
+}
+
+__global__ void k_level_offsets(uint32_t* __restrict__ hist /* NH_MAX_LEVELS+2: in counts, out exclusive offsets */, uint32_t* __restrict__ cursor) {
+	if (threadIdx.x || blockIdx.x) return;
+	uint32_t run = 0;
+	for (uint32_t l = 0; l <= NH_MAX_LEVELS + 1; ++l) { uint32_t v = hist[l]; hist[l] = run; cursor[l] = run; run += v; }
+}
+
+__global__ __launch_bounds__(256) void k_level_scatter(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ general_list, const uint32_t* __restrict__ level, uint32_t* __restrict__ cursor, uint32_t* __restrict__ order) {
+	uint32_t n = st->general_contacts;
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		uint32_t c = general_list[k];
+		uint32_t l = level[c];
+		if (l <= NH_MAX_LEVELS) order[atomicAdd(&cursor[l], 1u)] = c;
+	}
+}
+
+// rows of general contacts (any order), then warm start / PGS level by level
+__global__ __launch_bounds__(256) void k_rows_general(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ general_list,
+                                                      const nh_Contact* __restrict__ contacts, const nh_BodyPair* __restrict__ bodies,
+                                                      const nh_Transform* __restrict__ xf, const nh_BodyProperties* __restrict__ props, float* __restrict__ rows) {
+	uint32_t n = st->general_contacts;
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		uint32_t c = general_list[k];
+		nh_BodyPair p = bodies[c];
+		nh_Contact ct = contacts[c];
+		nh_contact_in ci = { ct.position[0], ct.position[1], ct.position[2], ct.penetration, ct.normal[0], ct.normal[1], ct.normal[2], ct.friction };
+		nh_Transform ta = xf[p.a], tb = xf[p.b];
+		nh_inertia IA = body_inertia(xf, props, p.a), IB = body_inertia(xf, props, p.b);
+		nh_row r;
+		nh_build_row(ci, nh_make3(ta.position[0], ta.position[1], ta.position[2]), nh_make3(tb.position[0], tb.position[1], tb.position[2]),
+		             IA, IB, props[p.a].mass_inverse, props[p.b].mass_inverse, r);
+		store_row(rows, c, r);
+	}
+}
+
+template<bool WARM>
+__global__ __launch_bounds__(256) void k_level_exec(const uint32_t* __restrict__ order, uint32_t begin, uint32_t end,
+                                                    const nh_BodyPair* __restrict__ bodies, const nh_CachedContactImpulse* __restrict__ cached,
+                                                    const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
+                                                    const float* __restrict__ rows, float4* __restrict__ states) {
+	for (uint32_t k = begin + blockIdx.x * blockDim.x + threadIdx.x; k < end; k += gridDim.x * blockDim.x) {
+		uint32_t c = order[k];
+		nh_BodyPair p = bodies[c];
+		nh_vel a = load_vel(momentum, props, p.a), b = load_vel(momentum, props, p.b);
+		nh_row r;
+		load_row(rows, c, r);
+		nh_state s;
+		if (WARM) {
+			nh_CachedContactImpulse w = cached[c];
+			nh_warm_start(r, w.impulse[0], w.impulse[1], w.impulse[2], a, b, s);
+		} else {
+			float4 sv = states[c];
+			s.normal = sv.x; s.friction_x = sv.y; s.friction_y = sv.z;
+			nh_apply_one(r, s, a, b);
+		}
+		states[c] = make_float4(s.normal, s.friction_x, s.friction_y, 0.0f);
+		if (p.a) store_vel(momentum, p.a, a);      // body 0 is the static world: never written
+		if (p.b) store_vel(momentum, p.b, b);
+	}
+}
+
+// ---- update_cached_impulses (nudge.cpp:4857-4884) --------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_update_impulses(const nh_DevState* __restrict__ st, const float* __restrict__ rows, const float4* __restrict__ states, nh_CachedContactImpulse* __restrict__ out) {
+	uint32_t n = st->contacts;
+	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+		nh_row r;
+		load_row(rows, c, r);
+		float4 sv = states[c];
+		nh_state s = { sv.x, sv.y, sv.z };
+		nh_CachedContactImpulse o;
+		nh_export_impulse(r, s, o.impulse[0], o.impulse[1], o.impulse[2]);
+		o.unused = 0.0f;
+		out[c] = o;
+	}
+}
+
+// =====================================================================================================================================
+static nh_ContactImpulseData* new_impulse_data(nh_context* ctx) {
+	if (ctx->impulse_ring.empty()) { ctx->impulse_ring.resize(64, nullptr); ctx->constraint_ring.resize(64, nullptr); }
+	uint32_t k = ctx->ring_pos % 64;
+	if (!ctx->impulse_ring[k]) ctx->impulse_ring[k] = new nh_ContactImpulseData();
+	return ctx->impulse_ring[k];
+}
+
+static nh_ContactConstraintData* new_constraint_data(nh_context* ctx) {
+	if (ctx->constraint_ring.empty()) { ctx->impulse_ring.resize(64, nullptr); ctx->constraint_ring.resize(64, nullptr); }
+	uint32_t k = ctx->ring_pos % 64;
+	if (!ctx->constraint_ring[k]) ctx->constraint_ring[k] = new nh_ContactConstraintData();
+	return ctx->constraint_ring[k];
+}
+
+extern "C" int nh_apply_gravity_damping(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_BodyData* bodies,
+                                        float time_step, const float gravity[3], float damping_rate) {
+	if (!ctx || !active_bodies || !bodies || !gravity) return NH_ERR_INVALID;
+	float damping = 1.0f - time_step * damping_rate;
+	NH_LAUNCH(ctx, "gravity_damping", k_gravity, nh_grid_for(bodies->count, 256, 2048), 256, ctx->d_state, active_bodies->indices, bodies->momentum,
+	          gravity[0] * time_step, gravity[1] * time_step, gravity[2] * time_step, damping);
+	return NH_OK;
+}
+
+extern "C" int nh_advance(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_BodyData* bodies, float time_step) {
+	if (!ctx || !active_bodies || !bodies) return NH_ERR_INVALID;
+	NH_LAUNCH(ctx, "advance", k_advance, nh_grid_for(bodies->count, 256, 2048), 256, ctx->d_state, active_bodies->indices, bodies->transforms,
+	          bodies->momentum, bodies->idle_counters, time_step);
+	return NH_OK;
+}
+
+extern "C" int nh_read_cached_impulses(nh_context* ctx, const nh_ContactCache* cache, const nh_ContactData* contacts, nh_Arena* memory, nh_ContactImpulseData** out) {
+	if (!ctx || !cache || !contacts || !memory || !out) return NH_ERR_INVALID;
+	nh_DevState* st = ctx->d_state;
+	const uint32_t kcap = contacts->capacity, ccap = cache->capacity;
+	int err = NH_OK;
+	ctx->ring_pos++;
+	nh_ContactImpulseData* d = new_impulse_data(ctx);
+	d->data = nh_arena_array<nh_CachedContactImpulse>(memory, kcap, &err);
+	d->culled_tags = nh_arena_array<uint64_t>(memory, ccap, &err);
+	d->culled_features = nh_arena_array<uint32_t>(memory, ccap, &err);
+	d->culled_data = nh_arena_array<nh_CachedContactImpulse>(memory, ccap, &err);
+	d->capacity = kcap; d->culled_capacity = ccap;
+	nh_Arena scratch = *memory;     // scratch below is dead on return
+	uint32_t* flags = nh_arena_array<uint32_t>(&scratch, ccap + 1, &err);
+	uint32_t* tmp = nh_arena_array<uint32_t>(&scratch, NH_SORT_GRID + 64, &err);
+	if (err) return err;
+	NH_LAUNCH(ctx, "cache_lookup", k_cache_lookup, nh_grid_for(kcap, 256, 4096), 256, st, contacts->tags, contacts->features, cache->tags, cache->features, cache->data, d->data);
+	if (contacts->sleeping_pairs) {
+		NH_LAUNCH(ctx, "cull_flags", k_cull_flags, nh_grid_for(ccap, 256, 4096), 256, st, cache->tags, contacts->sleeping_pairs, flags);
+		nh_scan_u32(ctx, flags, flags, &st->cache, 1, tmp, &st->culled);   // +1: the sentinel, so scan[j+1] exists for every j
+		NH_LAUNCH(ctx, "cull_write", k_cull_write, nh_grid_for(ccap, 256, 4096), 256, st, flags, flags, cache->tags, cache->features, cache->data,
+		          d->culled_tags, d->culled_features, d->culled_data);
+	}
+	*out = d;
+	return NH_OK;
+}
+
+extern "C" const nh_CachedContactImpulse* nh_contact_impulses_device(const nh_ContactImpulseData* d) { return d ? d->data : nullptr; }
+
+extern "C" int nh_write_cached_impulses(nh_context* ctx, nh_ContactCache* cache, const nh_ContactData* contacts, nh_ContactImpulseData* imp) {
+	if (!ctx || !cache || !contacts || !imp) return NH_ERR_INVALID;
+	nh_DevState* st = ctx->d_state;
+	NH_LAUNCH(ctx, "write_cache", k_write_cache, nh_grid_for((uint64_t)contacts->capacity + cache->capacity, 256, 4096), 256, st,
+	          contacts->tags, contacts->features, imp->data, imp->culled_tags, imp->culled_features, imp->culled_data,
+	          cache->tags, cache->features, cache->data, cache->capacity);
+	if (ctx->flags & NH_FLAG_SYNC_COUNTS) {
+		nh_Counts c;
+		int rc = nh_read_counts(ctx, &c);
+		if (rc) return rc;
+		cache->count = c.cache;
+		if (c.error) return (int)c.error;
+	}
+	return NH_OK;
+}
+
+extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_ContactData* contacts,
+                                            const nh_BodyData* bodies, nh_ContactImpulseData* imp, nh_Arena* memory, nh_ContactConstraintData** out) {
+	if (!ctx || !contacts || !bodies || !imp || !memory || !out) return NH_ERR_INVALID;
+	(void)active_bodies;
+	nh_DevState* st = ctx->d_state;
+	const uint32_t kcap = contacts->capacity;
+	const uint32_t B = bodies->count;
+	int err = NH_OK;
+	nh_ContactConstraintData* d = new_constraint_data(ctx);
+	d->rows = nh_arena_array<float>(memory, (size_t)kcap * 40, &err);
+	d->states = nh_arena_array<float>(memory, (size_t)kcap * 4, &err);
+	d->body_off = nh_arena_array<uint32_t>(memory, B + 2, &err);
+	d->adj = nh_arena_array<uint32_t>(memory, (size_t)kcap * 2, &err);
+	d->static_bodies = nh_arena_array<uint32_t>(memory, B, &err);
+	d->body_class = nh_arena_array<uint8_t>(memory, B, &err);
+	d->level_order = nh_arena_array<uint32_t>(memory, kcap, &err);
+	uint32_t* cursor = nh_arena_array<uint32_t>(memory, B + 2, &err);
+	uint32_t* pred_a = nh_arena_array<uint32_t>(memory, kcap, &err);
+	uint32_t* pred_b = nh_arena_array<uint32_t>(memory, kcap, &err);
+	uint32_t* level = nh_arena_array<uint32_t>(memory, kcap, &err);
+	uint32_t* general_list = nh_arena_array<uint32_t>(memory, kcap, &err);
+	uint32_t* slot_key = (ctx->flags & NH_FLAG_EXACT_ORDER) ? nh_arena_array<uint32_t>(memory, kcap, &err) : nullptr;
+	uint32_t* level_hist = nh_arena_array<uint32_t>(memory, NH_MAX_LEVELS + 2, &err);
+	uint32_t* level_cursor = nh_arena_array<uint32_t>(memory, NH_MAX_LEVELS + 2, &err);
+	uint32_t* tmp = nh_arena_array<uint32_t>(memory, NH_SORT_GRID + 64, &err);
+	if (err) return err;
+	d->contact_capacity = kcap; d->body_count = B; d->bodies = contacts->bodies;
+	d->levels = 0; d->general_contacts = 0;
+
+	NH_LAUNCH(ctx, "zero_u32", k_zero_u32, nh_grid_for(B + 2, 256, 2048), 256, d->body_off, B + 2);
+	NH_LAUNCH(ctx, "zero_u32", k_zero_u32, nh_grid_for(B + 2, 256, 2048), 256, cursor, B + 2);
+	NH_LAUNCH(ctx, "contact_degree", k_degree, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, d->body_off, pred_a, pred_b);
+	nh_scan_u32(ctx, d->body_off, d->body_off, &st->pad0, B + 1, tmp, nullptr);
+	NH_LAUNCH(ctx, "adjacency_fill", k_adj_fill, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, d->body_off, cursor, d->adj);
+	if (slot_key) NH_LAUNCH(ctx, "greedy_replay", k_greedy_replay, 1, 64, st, contacts->bodies, slot_key);
+	NH_LAUNCH(ctx, "adjacency_sort", k_adj_sort, nh_grid_for(B, 256, 4096), 256, st, B, contacts->bodies, d->body_off, d->adj, slot_key, d->body_class, pred_a, pred_b, d->static_bodies);
+	NH_LAUNCH(ctx, "contact_class", k_contact_class, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, d->body_class, level, general_list);
+	NH_LAUNCH(ctx, "setup_static", k_setup_static, nh_grid_for(B, 256, 4096), 256, st, d->static_bodies, d->body_off, d->adj,
+	          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states);
+
+	// the level-scheduled path needs per-level launch sizes on the host: one round trip
+	nh_Counts c;
+	int rc = nh_read_counts(ctx, &c);
+	if (rc) return rc;
+	if (c.error) return (int)c.error;
+	d->general_contacts = c.general_contacts;
+	d->static_body_count = c.static_bodies;
+	if (c.general_contacts) {
+		const uint32_t G = c.general_contacts;
+		NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, general_list, contacts->data, contacts->bodies, bodies->transforms, bodies->properties, d->rows);
+		// relaxation: every round finalises at least the next level
+		uint32_t rounds = 0;
+		for (;;) {
+			for (int r = 0; r < 8; ++r) {
+				NH_LAUNCH(ctx, "level_reset", k_level_reset_progress, 1, 1, st);
+				NH_LAUNCH(ctx, "level_relax", k_level_relax, nh_grid_for(G, 256, 4096), 256, st, general_list, pred_a, pred_b, level);
+			}
+			rounds += 8;
+			rc = nh_read_counts(ctx, &c);
+			if (rc) return rc;
+			if (c.unleveled == 0) break;
+			if (rounds > NH_MAX_LEVELS + 8) return NH_ERR_INVALID;
+		}
+		if (c.levels > NH_MAX_LEVELS) return NH_ERR_INVALID;
+		d->levels = c.levels;
+		NH_LAUNCH(ctx, "zero_u32", k_zero_u32, 8, 256, level_hist, NH_MAX_LEVELS + 2);
+		NH_LAUNCH(ctx, "level_hist", k_level_hist, nh_grid_for(G, 256, 4096), 256, st, general_list, level, level_hist);
+		NH_LAUNCH(ctx, "level_offsets", k_level_offsets, 1, 1, level_hist, level_cursor);
+		NH_LAUNCH(ctx, "level_scatter", k_level_scatter, nh_grid_for(G, 256, 4096), 256, st, general_list, level, level_cursor, d->level_order);
+		NH_HIP_CHECK(ctx, hipMemcpyAsync(d->level_off, level_hist, sizeof(uint32_t) * (d->levels + 2), hipMemcpyDeviceToHost, ctx->stream));
+		NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+		// warm start in level order (levels are numbered from 1)
+		for (uint32_t l = 1; l <= d->levels; ++l) {
+			uint32_t b = d->level_off[l], e = d->level_off[l + 1];
+			if (e > b)
+				NH_LAUNCH(ctx, "warm_level", (k_level_exec<true>), nh_grid_for(e - b, 256, 4096), 256, d->level_order, b, e, contacts->bodies, imp->data,
+				          bodies->properties, bodies->momentum, d->rows, (float4*)d->states);
+		}
+	}
+	*out = d;
+	return NH_OK;
+}
+
+extern "C" int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations) {
+	if (!ctx || !d || !bodies) return NH_ERR_INVALID;
+	nh_DevState* st = ctx->d_state;
+	NH_LAUNCH(ctx, "apply_static", k_apply_static, nh_grid_for(d->body_count, 256, 4096), 256, st, d->static_bodies, d->body_off, d->adj, d->bodies,
+	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations);
+	if (d->general_contacts) {
+		for (uint32_t it = 0; it < iterations; ++it)
+			for (uint32_t l = 1; l <= d->levels; ++l) {
+				uint32_t b = d->level_off[l], e = d->level_off[l + 1];
+				if (e > b)
+					NH_LAUNCH(ctx, "apply_level", (k_level_exec<false>), nh_grid_for(e - b, 256, 4096), 256, d->level_order, b, e, d->bodies, (const nh_CachedContactImpulse*)nullptr,
+					          bodies->properties, bodies->momentum, d->rows, (float4*)d->states);
+			}
+	}
+	return NH_OK;
+}
+
+extern "C" int nh_update_cached_impulses(nh_context* ctx, nh_ContactConstraintData* d, nh_ContactImpulseData* imp) {
+	if (!ctx || !d || !imp) return NH_ERR_INVALID;
+	NH_LAUNCH(ctx, "update_impulses", k_update_impulses, nh_grid_for(d->contact_capacity, 256, 4096), 256, ctx->d_state, d->rows, (const float4*)d->states, imp->data);
+	return NH_OK;
+}

@@ -1,0 +1,319 @@
+"""ctypes binding of libnudge_hip.so (include/nudge_hip.h) + a `World` convenience wrapper.
+
+Host-side plumbing only: torch owns the device arrays (plain uint8 tensors reinterpreted as the POD records
+of nudge_hip.h), the HIP stream is torch's current stream, and every entry point of the step loop is the
+C-ABI function that replaces the reference call of the same name (reference example/main.cpp:274-328).
+
+There is NO CPU fallback: importing works anywhere, but constructing a `World` raises unless the HIP
+library is built and a GPU is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import scenes as S
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libnudge_hip.so")
+_LIB = None
+
+NH_FLAG_SYNC_COUNTS = 1
+NH_FLAG_EXACT_ORDER = 2
+
+EXPORTS = [
+    "nh_create", "nh_destroy", "nh_set_flags", "nh_synchronize", "nh_read_counts", "nh_set_cache_count",
+    "nh_set_tag_bits", "nh_error_string", "nh_last_hip_error", "nh_collide", "nh_apply_gravity_damping",
+    "nh_read_cached_impulses", "nh_write_cached_impulses", "nh_setup_contact_constraints", "nh_apply_impulses",
+    "nh_update_cached_impulses", "nh_advance", "nh_contact_impulses_device", "nh_enable_timing", "nh_kernel_times",
+]
+
+
+class Arena(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("size", C.c_size_t)]
+
+
+class ContactData(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("bodies", C.c_void_p), ("tags", C.c_void_p), ("features", C.c_void_p),
+                ("capacity", C.c_uint32), ("count", C.c_uint32), ("sleeping_pairs", C.c_void_p), ("sleeping_count", C.c_uint32)]
+
+
+class _Shapes(C.Structure):
+    _fields_ = [("tags", C.c_void_p), ("data", C.c_void_p), ("transforms", C.c_void_p), ("count", C.c_uint32)]
+
+
+class ColliderData(C.Structure):
+    _fields_ = [("boxes", _Shapes), ("spheres", _Shapes)]
+
+
+class BodyData(C.Structure):
+    _fields_ = [("transforms", C.c_void_p), ("properties", C.c_void_p), ("momentum", C.c_void_p),
+                ("idle_counters", C.c_void_p), ("count", C.c_uint32)]
+
+
+class BodyConnections(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("count", C.c_uint32)]
+
+
+class ContactCache(C.Structure):
+    _fields_ = [("tags", C.c_void_p), ("features", C.c_void_p), ("data", C.c_void_p), ("capacity", C.c_uint32), ("count", C.c_uint32)]
+
+
+class ActiveBodies(C.Structure):
+    _fields_ = [("indices", C.c_void_p), ("capacity", C.c_uint32), ("count", C.c_uint32)]
+
+
+class Counts(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("colliders", "pairs", "contacts", "sleeping_pairs", "active_bodies", "cache", "culled",
+                                          "large_colliders", "general_contacts", "levels", "error", "static_bodies", "unleveled", "raw_pairs")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ms", C.c_double), ("launches", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+def build(force=False):
+    """Compile libnudge_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    if force:
+        subprocess.check_call(cmd + ["clean"])
+    subprocess.check_call(cmd)
+    return _LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(f"{_LIB_PATH} is missing: run `make -C nudge_amd/csrc` (there is no CPU fallback)")
+        L = C.CDLL(_LIB_PATH)
+        L.nh_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_uint32]
+        L.nh_destroy.argtypes = [C.c_void_p]
+        L.nh_destroy.restype = None
+        L.nh_set_flags.argtypes = [C.c_void_p, C.c_uint32]
+        L.nh_set_tag_bits.argtypes = [C.c_void_p, C.c_uint32]
+        L.nh_synchronize.argtypes = [C.c_void_p]
+        L.nh_read_counts.argtypes = [C.c_void_p, C.POINTER(Counts)]
+        L.nh_set_cache_count.argtypes = [C.c_void_p, C.c_uint32]
+        L.nh_error_string.argtypes = [C.c_int]
+        L.nh_error_string.restype = C.c_char_p
+        L.nh_last_hip_error.argtypes = [C.c_void_p]
+        L.nh_collide.argtypes = [C.c_void_p, C.POINTER(ActiveBodies), C.POINTER(ContactData), C.POINTER(BodyData),
+                                 C.POINTER(ColliderData), C.POINTER(BodyConnections), Arena]
+        L.nh_apply_gravity_damping.argtypes = [C.c_void_p, C.POINTER(ActiveBodies), C.POINTER(BodyData), C.c_float,
+                                               C.POINTER(C.c_float), C.c_float]
+        L.nh_read_cached_impulses.argtypes = [C.c_void_p, C.POINTER(ContactCache), C.POINTER(ContactData), C.POINTER(Arena), C.POINTER(C.c_void_p)]
+        L.nh_write_cached_impulses.argtypes = [C.c_void_p, C.POINTER(ContactCache), C.POINTER(ContactData), C.c_void_p]
+        L.nh_setup_contact_constraints.argtypes = [C.c_void_p, C.POINTER(ActiveBodies), C.POINTER(ContactData), C.POINTER(BodyData),
+                                                   C.c_void_p, C.POINTER(Arena), C.POINTER(C.c_void_p)]
+        L.nh_apply_impulses.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(BodyData), C.c_uint32]
+        L.nh_update_cached_impulses.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.nh_advance.argtypes = [C.c_void_p, C.POINTER(ActiveBodies), C.POINTER(BodyData), C.c_float]
+        L.nh_contact_impulses_device.argtypes = [C.c_void_p]
+        L.nh_contact_impulses_device.restype = C.c_void_p
+        L.nh_enable_timing.argtypes = [C.c_void_p, C.c_int]
+        L.nh_kernel_times.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int, C.c_int]
+        _LIB = L
+    return _LIB
+
+
+class NudgeError(RuntimeError):
+    pass
+
+
+def _check(L, rc, what):
+    if rc != 0:
+        raise NudgeError(f"{what}: {L.nh_error_string(rc).decode()} ({rc})")
+
+
+class World:
+    """A world resident in HBM, stepped through the C ABI.  `scene` uses the layouts of nudge_amd.scenes."""
+
+    def __init__(self, scene, device=0, max_contacts=None, arena_bytes=None, flags=NH_FLAG_SYNC_COUNTS, tag_bits=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("nudge_amd.World needs a HIP device (no CPU fallback)")
+        self.torch = torch
+        self.L = lib()
+        self.dev = torch.device("cuda", device)
+        torch.cuda.set_device(self.dev)
+        self.params = dict(scene["params"])
+        nb = len(scene["body_transforms"])
+        nbox, nsph = len(scene["box_tags"]), len(scene["sphere_tags"])
+        if max_contacts is None:
+            max_contacts = max(4096, 8 * nb)
+        self.nb, self.nbox, self.nsph, self.max_contacts = nb, nbox, nsph, max_contacts
+        self._keep = {}
+
+        def up(name, arr, min_bytes=16):
+            a = np.ascontiguousarray(arr)
+            raw = a.view(np.uint8).reshape(-1)
+            t = torch.zeros(max(raw.size, min_bytes), dtype=torch.uint8, device=self.dev)
+            if raw.size:
+                t[:raw.size] = torch.from_numpy(raw.copy()).to(self.dev)
+            self._keep[name] = t
+            return t
+
+        def alloc(name, nbytes):
+            t = torch.zeros(max(int(nbytes), 16), dtype=torch.uint8, device=self.dev)
+            self._keep[name] = t
+            return t
+
+        self.bodies = BodyData(up("bt", scene["body_transforms"]).data_ptr(), up("bp", scene["body_properties"]).data_ptr(),
+                               up("bm", scene["body_momentum"]).data_ptr(), up("bi", scene["idle_counters"]).data_ptr(), nb)
+        self.colliders = ColliderData(
+            _Shapes(up("xt", scene["box_tags"].astype(np.uint32)).data_ptr(), up("xd", scene["box_data"]).data_ptr(), up("xx", scene["box_transforms"]).data_ptr(), nbox),
+            _Shapes(up("st", scene["sphere_tags"].astype(np.uint32)).data_ptr(), up("sd", scene["sphere_data"]).data_ptr(), up("sx", scene["sphere_transforms"]).data_ptr(), nsph))
+        con = np.asarray(scene.get("connections", np.zeros((0, 2), np.uint32)), dtype=np.uint32).reshape(-1, 2)
+        self.connections = BodyConnections(up("cn", con).data_ptr(), len(con))
+        K = max_contacts
+        self.contacts = ContactData(alloc("cd", 32 * K).data_ptr(), alloc("cb", 8 * K).data_ptr(), alloc("ct", 8 * K).data_ptr(),
+                                    alloc("cf", 4 * K).data_ptr(), K, 0, alloc("cs", 8 * K).data_ptr(), 0)
+        self.cache = ContactCache(alloc("kt", 8 * K).data_ptr(), alloc("kf", 4 * K).data_ptr(), alloc("kd", 16 * K).data_ptr(), K, 0)
+        self.active = ActiveBodies(alloc("ai", 4 * nb).data_ptr(), nb, 0)
+        if arena_bytes is None:
+            ncol = nbox + nsph
+            cells = 1
+            while cells < 4 * ncol:
+                cells <<= 1
+            cells = min(max(cells, 1 << 16), 0xFFFFFF)
+            arena_bytes = (64 << 20) + ncol * 200 + cells * 8 + K * 420 + nb * 64
+        self.arena_t = alloc("arena", arena_bytes)
+        self.arena = Arena(self.arena_t.data_ptr(), arena_bytes)
+
+        self.ctx = C.c_void_p()
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        _check(self.L, self.L.nh_create(C.byref(self.ctx), device, C.c_void_p(stream), flags), "nh_create")
+        self.flags = flags
+        if tag_bits is None:
+            mt = 1
+            for k in ("box_tags", "sphere_tags"):
+                if len(scene[k]):
+                    mt = max(mt, int(scene[k].max()))
+            tag_bits = max(8, int(mt).bit_length())
+        self.L.nh_set_tag_bits(self.ctx, tag_bits)
+        self.steps_done = 0
+        self.sum_contacts = 0
+        self._imp = C.c_void_p()
+        self._con = C.c_void_p()
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.nh_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- the reference's step loop (example/main.cpp:274-328), one C-ABI call per reference call ----
+    def collide(self):
+        _check(self.L, self.L.nh_collide(self.ctx, C.byref(self.active), C.byref(self.contacts), C.byref(self.bodies),
+                                         C.byref(self.colliders), C.byref(self.connections), self.arena), "nh_collide")
+        self._temp = Arena(self.arena.data, self.arena.size)
+
+    def gravity(self):
+        p = self.params
+        g = (C.c_float * 3)(0.0, p["gravity"], 0.0)
+        _check(self.L, self.L.nh_apply_gravity_damping(self.ctx, C.byref(self.active), C.byref(self.bodies), p["time_step"], g, p["damping_rate"]), "gravity")
+
+    def read_cache(self):
+        _check(self.L, self.L.nh_read_cached_impulses(self.ctx, C.byref(self.cache), C.byref(self.contacts), C.byref(self._temp), C.byref(self._imp)), "read_cached_impulses")
+
+    def setup(self):
+        _check(self.L, self.L.nh_setup_contact_constraints(self.ctx, C.byref(self.active), C.byref(self.contacts), C.byref(self.bodies),
+                                                           self._imp, C.byref(self._temp), C.byref(self._con)), "setup_contact_constraints")
+
+    def apply(self, iterations=None):
+        it = self.params["iterations"] if iterations is None else iterations
+        _check(self.L, self.L.nh_apply_impulses(self.ctx, self._con, C.byref(self.bodies), it), "apply_impulses")
+
+    def update(self):
+        _check(self.L, self.L.nh_update_cached_impulses(self.ctx, self._con, self._imp), "update_cached_impulses")
+
+    def write_cache(self):
+        _check(self.L, self.L.nh_write_cached_impulses(self.ctx, C.byref(self.cache), C.byref(self.contacts), self._imp), "write_cached_impulses")
+
+    def advance(self):
+        _check(self.L, self.L.nh_advance(self.ctx, C.byref(self.active), C.byref(self.bodies), self.params["time_step"]), "advance")
+
+    def step(self, steps=1, iterations=None):
+        for _ in range(steps):
+            self.collide()
+            self.gravity()
+            self.read_cache()
+            self.setup()
+            self.apply(iterations)
+            self.update()
+            self.write_cache()
+            self.advance()
+            self.steps_done += 1
+            if self.flags & NH_FLAG_SYNC_COUNTS:
+                self.sum_contacts += self.contacts.count
+
+    # ---- state ----
+    def synchronize(self):
+        _check(self.L, self.L.nh_synchronize(self.ctx), "synchronize")
+
+    def counts(self):
+        c = Counts()
+        _check(self.L, self.L.nh_read_counts(self.ctx, C.byref(c)), "read_counts")
+        return c.as_dict()
+
+    def _down(self, name, dtype, count):
+        t = self._keep[name]
+        nbytes = np.dtype(dtype).itemsize * count
+        return np.frombuffer(t[:nbytes].cpu().numpy().tobytes(), dtype=dtype, count=count).copy()
+
+    def get_bodies(self):
+        self.synchronize()
+        return dict(transforms=self._down("bt", S.TRANSFORM, self.nb), momentum=self._down("bm", S.MOMENTUM, self.nb),
+                    idle=self._down("bi", np.uint8, self.nb))
+
+    def set_bodies(self, transforms=None, momentum=None, idle=None):
+        torch = self.torch
+        for name, arr in (("bt", transforms), ("bm", momentum), ("bi", idle)):
+            if arr is not None:
+                raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+                self._keep[name][:raw.size] = torch.from_numpy(raw.copy()).to(self.dev)
+
+    def get_contacts(self):
+        c = self.counts()
+        n, ns = c["contacts"], c["sleeping_pairs"]
+        return dict(count=n, data=self._down("cd", S.CONTACT, n), bodies=self._down("cb", np.uint32, 2 * n).reshape(-1, 2),
+                    tags=self._down("ct", np.uint64, n), features=self._down("cf", np.uint32, n),
+                    sleeping_pairs=self._down("cs", np.uint64, ns))
+
+    def get_active(self):
+        c = self.counts()
+        return self._down("ai", np.uint32, c["active_bodies"])
+
+    def get_cache(self):
+        c = self.counts()
+        n = c["cache"]
+        return dict(count=n, tags=self._down("kt", np.uint64, n), features=self._down("kf", np.uint32, n), data=self._down("kd", S.IMPULSE, n))
+
+    def get_contact_impulses(self):
+        c = self.counts()
+        n = c["contacts"]
+        ptr = self.L.nh_contact_impulses_device(self._imp)
+        off = ptr - self.arena_t.data_ptr()
+        raw = self.arena_t[off:off + 16 * n].cpu().numpy().tobytes()
+        return np.frombuffer(raw, dtype=S.IMPULSE, count=n).copy()
+
+    # ---- measurement ----
+    def enable_timing(self, on=True):
+        self.L.nh_enable_timing(self.ctx, 1 if on else 0)
+
+    def kernel_times(self, reset=True):
+        buf = (KernelTime * 128)()
+        n = self.L.nh_kernel_times(self.ctx, buf, 128, 1 if reset else 0)
+        return {buf[i].name.decode(): (buf[i].ms, int(buf[i].launches)) for i in range(n)}
