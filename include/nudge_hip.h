@@ -178,6 +178,8 @@ int nh_advance(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_B
 const nh_CachedContactImpulse* nh_contact_impulses_device(const nh_ContactImpulseData* d);
 /* Per-kernel device time of the last step, measured with HIP events on the context's stream when timing is on. */
 int nh_enable_timing(nh_context* ctx, int on);
+/* Restrict timing to kernels whose name equals `name` (NULL or "" = all): two events per step instead of hundreds. */
+int nh_set_timing_filter(nh_context* ctx, const char* name);
 /* Writes up to `cap` (name, milliseconds, launches) triples accumulated since the last reset; returns the number. */
 typedef struct nh_KernelTime { const char* name; double ms; uint32_t launches; uint32_t reserved; } nh_KernelTime;
 int nh_kernel_times(nh_context* ctx, nh_KernelTime* out, int cap, int reset);

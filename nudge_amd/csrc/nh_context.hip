@@ -13,6 +13,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->tag_bits = 32;
 	ctx->last_hip_error = 0;
 	ctx->timing = false;
+	ctx->timing_current = false;
 	ctx->ring_pos = 0;
 	ctx->body_count = 0;
 	ctx->d_state = nullptr;
@@ -95,6 +96,8 @@ static hipEvent_t take_event(nh_context* ctx) {
 }
 
 void nh_timer_begin(nh_context* ctx, const char* name) {
+	ctx->timing_current = ctx->timing_filter.empty() || ctx->timing_filter == name;
+	if (!ctx->timing_current) return;
 	nh_TimerSlot s;
 	s.name = name;
 	s.a = take_event(ctx);
@@ -104,6 +107,7 @@ void nh_timer_begin(nh_context* ctx, const char* name) {
 }
 
 void nh_timer_end(nh_context* ctx) {
+	if (!ctx->timing_current) return;
 	hipEventRecord(ctx->timer_slots.back().b, ctx->stream);
 }
 
@@ -126,6 +130,12 @@ extern "C" int nh_enable_timing(nh_context* ctx, int on) {
 	hipStreamSynchronize(ctx->stream);
 	if (ctx->timing) nh_timer_collect(ctx);
 	ctx->timing = on != 0;
+	return NH_OK;
+}
+
+extern "C" int nh_set_timing_filter(nh_context* ctx, const char* name) {
+	if (!ctx) return NH_ERR_INVALID;
+	ctx->timing_filter = name ? name : "";
 	return NH_OK;
 }
 

@@ -63,6 +63,8 @@ struct nh_context {
 	int last_hip_error;
 	// timing
 	bool timing;
+	bool timing_current;           // the launch being issued is timed (filter matched)
+	std::string timing_filter;
 	std::vector<nh_TimerSlot> timer_slots;
 	std::vector<hipEvent_t> event_pool;
 	std::map<std::string, std::pair<double, uint32_t>> kernel_ms;

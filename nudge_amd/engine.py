@@ -28,7 +28,7 @@ EXPORTS = [
     "nh_create", "nh_destroy", "nh_set_flags", "nh_synchronize", "nh_read_counts", "nh_set_cache_count",
     "nh_set_tag_bits", "nh_error_string", "nh_last_hip_error", "nh_collide", "nh_apply_gravity_damping",
     "nh_read_cached_impulses", "nh_write_cached_impulses", "nh_setup_contact_constraints", "nh_apply_impulses",
-    "nh_update_cached_impulses", "nh_advance", "nh_contact_impulses_device", "nh_enable_timing", "nh_kernel_times",
+    "nh_update_cached_impulses", "nh_advance", "nh_contact_impulses_device", "nh_enable_timing", "nh_set_timing_filter", "nh_kernel_times",
 ]
 
 
@@ -118,6 +118,7 @@ def lib():
         L.nh_contact_impulses_device.argtypes = [C.c_void_p]
         L.nh_contact_impulses_device.restype = C.c_void_p
         L.nh_enable_timing.argtypes = [C.c_void_p, C.c_int]
+        L.nh_set_timing_filter.argtypes = [C.c_void_p, C.c_char_p]
         L.nh_kernel_times.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int, C.c_int]
         _LIB = L
     return _LIB
@@ -310,7 +311,8 @@ class World:
         return np.frombuffer(raw, dtype=S.IMPULSE, count=n).copy()
 
     # ---- measurement ----
-    def enable_timing(self, on=True):
+    def enable_timing(self, on=True, only=None):
+        self.L.nh_set_timing_filter(self.ctx, only.encode() if only else None)
         self.L.nh_enable_timing(self.ctx, 1 if on else 0)
 
     def kernel_times(self, reset=True):

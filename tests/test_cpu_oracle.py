@@ -1,0 +1,176 @@
+"""CPU-side tests (run everywhere): the oracle is pinned, the golden fixtures are reproducible, the per-item
+device functions (host build) match the compiled reference bit for bit, and the product library loads and
+exports the whole C ABI.  No GPU compute happens here."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+from nudge_amd import scenes as S                  # noqa: E402
+import hostsim_util as H                           # noqa: E402
+import parity_util as P                            # noqa: E402
+import make_golden as G                            # noqa: E402
+from oracle import refworld                        # noqa: E402
+
+have_ref = refworld.available("exact")
+needs_ref = pytest.mark.skipif(not have_ref, reason="oracle/_ref not built (needs /root/reference: make -C oracle)")
+
+
+# ---- the oracle is pinned by the reference's own tests -------------------------------------------
+@needs_ref
+@pytest.mark.parametrize("variant", ["exact", "shipped"])
+def test_reference_own_tests_pass(variant):
+    exe = os.path.join(ROOT, "oracle", "_ref", f"ref_tests_{variant}")
+    if not os.path.exists(exe):
+        pytest.skip("reference test binary not built")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "All tests passed." in out.stdout
+
+
+def test_exact_variant_has_no_approximate_instructions():
+    so = os.path.join(ROOT, "oracle", "_ref", "libnudge_ref_exact.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref not built")
+    dis = subprocess.run(["objdump", "-d", so], capture_output=True, text=True).stdout
+    assert not re.search(r"\brsqrtps\b|\brcpps\b", dis)
+
+
+# ---- golden fixtures ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(G.CASES))
+def test_scene_generator_matches_fixture_inputs(name):
+    scene, _ = G.build(name)
+    fx = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    assert bytes(fx["input_hash"]).decode() == G.scene_hash(scene), "scene generator drifted from the committed fixtures"
+
+
+@needs_ref
+@pytest.mark.parametrize("name", sorted(G.CASES))
+def test_oracle_reproduces_golden(name):
+    scene, steps = G.build(name)
+    fx = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    w = refworld.RefWorld(scene, variant="exact")
+    w.step(steps)
+    b = w.bodies()
+    assert P.bits_equal(b["transforms"], fx["transforms"])
+    assert P.bits_equal(b["momentum"]["velocity"], fx["momentum"]["velocity"])
+    assert np.array_equal(b["idle"], fx["idle"])
+
+
+# ---- kernel arithmetic (host build of nh_*.h) vs the compiled reference, bit for bit ------------------------------
+COLLIDE_CASES = [("pile256", 0), ("pile256", 300), ("pile_mixed", 300), ("grid30", 70), ("mixed20", 80), ("pit6", 120), ("stacks", 60)]
+
+
+@needs_ref
+@pytest.mark.parametrize("name,warm", COLLIDE_CASES)
+def test_narrowphase_math_bit_exact(name, warm):
+    scene, _ = G.build(name)
+    w = refworld.RefWorld(scene)
+    w.step(warm)
+    b = w.bodies()
+    w.collide()
+    od, ob, ok, of, _ = P.oracle_contacts_sorted(w.contacts())
+    h = H.collide(b["transforms"], scene)
+    assert h["count"] == len(ok)
+    assert np.array_equal(h["keys"], ok) and np.array_equal(h["features"], of)
+    assert np.array_equal(h["bodies"], ob)
+    assert P.bits_equal(h["data"], od)
+
+
+@needs_ref
+@pytest.mark.parametrize("name,warm", [("pile256", 350), ("pile_mixed", 400), ("grid30", 70), ("mixed20", 80), ("pit6", 150), ("stacks", 60)])
+def test_solver_math_bit_exact(name, warm):
+    scene, _ = G.build(name)
+    p = scene["params"]
+    w = refworld.RefWorld(scene)
+    w.step(warm)
+    w.collide()
+    act = w.active().astype(np.uint32)
+    m = H.gravity(act, w.bodies()["momentum"], p["time_step"], p["gravity"], p["damping_rate"])
+    w.gravity()
+    assert P.bits_equal(m, w.bodies()["momentum"])
+    w.read_cache()
+    c = w.contacts()
+    cached = w.contact_impulses()
+    b1 = w.bodies()
+    w.setup()
+    order = w.solver_order().reshape(-1)
+    w.apply()
+    w.update()
+    b2 = w.bodies()
+    mom, out = H.solve(b1["transforms"], scene["body_properties"], b1["momentum"], c["data"], c["bodies"], cached, order, p["iterations"])
+    assert P.bits_equal(mom["velocity"], b2["momentum"]["velocity"])
+    assert P.bits_equal(mom["angular_velocity"], b2["momentum"]["angular_velocity"])
+    assert P.bits_equal(out["impulse"], w.contact_impulses()["impulse"])
+    bt, idle = H.advance(act, b2["transforms"], b2["momentum"], b2["idle"], p["time_step"])
+    w.write_cache()
+    w.advance()
+    b3 = w.bodies()
+    assert P.bits_equal(bt, b3["transforms"]) and np.array_equal(idle, b3["idle"])
+
+
+@needs_ref
+def test_closed_form_solver_order_equals_reference_scheduler_on_drop_scenes():
+    """batch(i) = (i/128)*16 + i%16 is what nudge.cpp:4206-4339 produces when no lane conflicts occur."""
+    for scene, warm in ((S.grid_tiles(1, side=30), 70), (S.grid_tiles(1, side=40, sphere_fraction=0.5), 70)):
+        w = refworld.RefWorld(scene)
+        w.step(warm)
+        w.collide(); w.gravity(); w.read_cache(); w.setup()
+        order = w.solver_order()
+        sc = w.sorted_contacts()
+        K = len(sc)
+        batch_of = np.full(K, -1, dtype=np.int64)
+        for b in range(order.shape[0] - 1, -1, -1):
+            batch_of[order[b]] = b                       # padding lanes duplicate lane 0 of the same batch
+        i = np.arange(K)
+        assert np.array_equal(batch_of[sc], (i >> 7) * 16 + (i & 15))
+
+
+# ---- the product library: builds, loads, exports the whole C ABI (no compute without a GPU) --------------------------
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "nudge_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(nh_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nudge_amd import engine
+    so = os.path.join(ROOT, "nudge_amd", "libnudge_hip.so")
+    if not os.path.exists(so):
+        engine.build()
+    lib = ctypes.CDLL(so)
+    declared = _declared_symbols()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/nudge_hip.h but not exported"
+    assert set(engine.EXPORTS) <= set(declared)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    from nudge_amd import engine
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        engine.World(S.pile(8, 0))
+    # the C ABI itself reports the missing device
+    lib = engine.lib()
+    ctx = ctypes.c_void_p()
+    rc = lib.nh_create(ctypes.byref(ctx), 0, None, 1)
+    assert rc != 0 and b"device" in lib.nh_error_string(rc).lower()
+
+
+def test_tile_extraction_round_trip():
+    scene = S.grid_tiles(3, side=5)
+    for t in range(3):
+        sub, body_map = S.extract_tile(scene, t)
+        assert len(sub["body_transforms"]) == 26 and S.narrow_ok(sub)
+        assert np.array_equal(sub["body_transforms"][1:]["position"], scene["body_transforms"][body_map[1:]]["position"])
+        assert sub["box_transforms"]["body"].max() == 25

@@ -1,0 +1,207 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI, against
+  (1) the compiled reference (oracle/_ref, exact-math variant) when it travelled with the repo, and
+  (2) the committed golden fixtures (tests/golden/*.npz, generated from that reference) always.
+Bar: BIT-EXACT body state / contacts for worlds the reference can run (<= 8192 colliders) in
+NH_FLAG_EXACT_ORDER mode and, on conflict-free drop scenes, in the default closed-form order too;
+<= 1e-4 relative for a union of tiles against the per-tile reference."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+from nudge_amd import scenes as S                  # noqa: E402
+from nudge_amd import engine as E                  # noqa: E402
+import parity_util as P                            # noqa: E402
+import make_golden as G                            # noqa: E402
+from oracle import refworld                        # noqa: E402
+
+pytestmark = pytest.mark.gpu
+have_ref = refworld.available("exact")
+needs_ref = pytest.mark.skipif(not have_ref, reason="oracle/_ref did not travel to this box")
+EXACT = E.NH_FLAG_SYNC_COUNTS | E.NH_FLAG_EXACT_ORDER
+FAST = E.NH_FLAG_SYNC_COUNTS
+
+
+def _fixture(name):
+    return np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+
+
+# ---- golden fixtures: always available ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(G.CASES))
+def test_steps_match_golden_bit_exact(name):
+    scene, steps = G.build(name)
+    fx = _fixture(name)
+    w = E.World(scene, flags=EXACT)
+    w.step(steps)
+    b = w.get_bodies()
+    assert P.bits_equal(b["transforms"]["position"], fx["transforms"]["position"])
+    assert P.bits_equal(b["transforms"]["rotation"], fx["transforms"]["rotation"])
+    assert P.bits_equal(b["momentum"]["velocity"], fx["momentum"]["velocity"])
+    assert P.bits_equal(b["momentum"]["angular_velocity"], fx["momentum"]["angular_velocity"])
+    assert np.array_equal(b["idle"], fx["idle"])
+    # contacts / active bodies / sleeping pairs of the next collide
+    w.collide()
+    c = w.get_contacts()
+    tags = fx["contact_tags"]
+    hi = tags >> np.uint64(32)
+    key = (hi & np.uint64(0xFFFF)) | ((hi >> np.uint64(16)) << np.uint64(32))
+    assert np.array_equal(c["tags"], key)
+    assert np.array_equal(c["features"], (tags & np.uint64(0xFFFFFFFF)).astype(np.uint32))
+    assert P.bits_equal(c["data"], fx["contact_data"])
+    assert np.array_equal(c["bodies"], fx["contact_bodies"].astype(np.uint32))
+    assert np.array_equal(w.get_active(), fx["active"].astype(np.uint32))
+    assert np.array_equal(c["sleeping_pairs"], P.widen_sleeping(fx["sleeping_pairs"]))
+    w.close()
+
+
+@pytest.mark.parametrize("name", ["grid30", "grid30_awake", "mixed20"])
+def test_default_order_is_exact_on_drop_scenes(name):
+    """No lane conflicts on single-layer drops => the closed-form order IS the reference's order."""
+    scene, steps = G.build(name)
+    fx = _fixture(name)
+    w = E.World(scene, flags=FAST)
+    w.step(steps)
+    b = w.get_bodies()
+    assert P.bits_equal(b["transforms"], fx["transforms"])
+    assert P.bits_equal(b["momentum"]["velocity"], fx["momentum"]["velocity"])
+    w.close()
+
+
+def test_run_to_run_determinism():
+    scene, _ = G.build("pile_mixed")
+    out = []
+    for _ in range(2):
+        w = E.World(scene, flags=FAST)
+        w.step(150)
+        out.append(w.get_bodies())
+        w.close()
+    assert P.bits_equal(out[0]["transforms"], out[1]["transforms"]) and P.bits_equal(out[0]["momentum"], out[1]["momentum"])
+
+
+# ---- against the compiled reference, stage by stage -----------------------------------------------------------------
+@needs_ref
+@pytest.mark.parametrize("name,warm", [("pile256", 0), ("pile256", 300), ("pile_mixed", 300), ("grid30", 70), ("mixed20", 80), ("pit6", 120), ("stacks", 60)])
+def test_collide_matches_reference(name, warm):
+    scene, _ = G.build(name)
+    ref = refworld.RefWorld(scene)
+    ref.step(warm)
+    b = ref.bodies()
+    w = E.World(scene, flags=FAST)
+    w.set_bodies(b["transforms"], b["momentum"], b["idle"])
+    ref.collide()
+    w.collide()
+    od, ob, ok, of, _ = P.oracle_contacts_sorted(ref.contacts())
+    c = w.get_contacts()
+    assert c["count"] == len(ok)
+    assert np.array_equal(c["tags"], ok) and np.array_equal(c["features"], of) and np.array_equal(c["bodies"], ob)
+    assert P.bits_equal(c["data"], od)
+    assert np.array_equal(w.get_active(), ref.active().astype(np.uint32))
+    w.close()
+
+
+@needs_ref
+@pytest.mark.parametrize("name,warm,steps", [("pile256", 300, 40), ("pit6", 100, 40), ("stacks", 20, 60), ("pile_mixed", 380, 40)])
+def test_exact_order_steps_match_reference_on_piles(name, warm, steps):
+    """Chaotic scenes: short horizon, but bit for bit, warm start and cache included."""
+    scene, _ = G.build(name)
+    ref0 = refworld.RefWorld(scene)
+    ref0.step(warm)
+    b = ref0.bodies()
+    ref = refworld.RefWorld(scene)
+    ref.set_bodies(b["transforms"], b["momentum"], b["idle"])
+    w = E.World(scene, flags=EXACT)
+    w.set_bodies(b["transforms"], b["momentum"], b["idle"])
+    saw_general = 0
+    for s in range(steps):
+        ref.step(1)
+        w.step(1)
+        saw_general = max(saw_general, w.counts()["general_contacts"])
+        rb, gb = ref.bodies(), w.get_bodies()
+        assert P.bits_equal(rb["transforms"], gb["transforms"]), f"step {s}"
+        assert P.bits_equal(rb["momentum"]["velocity"], gb["momentum"]["velocity"]), f"step {s}"
+        assert P.bits_equal(rb["momentum"]["angular_velocity"], gb["momentum"]["angular_velocity"]), f"step {s}"
+    rc, gc = ref.cache(), w.get_cache()
+    assert rc["count"] == gc["count"]
+    assert P.bits_equal(rc["data"]["impulse"], gc["data"]["impulse"])
+    assert saw_general > 0, "scene was meant to exercise the level-scheduled path"
+    w.close()
+
+
+@needs_ref
+def test_union_of_tiles_vs_tiled_reference():
+    """the GPU steps the union world, the reference steps each tile on its own."""
+    scene = S.grid_tiles(4, side=24, seed=11)
+    steps = 300
+    w = E.World(scene, flags=FAST)
+    w.step(steps)
+    gb = w.get_bodies()
+    worst = 0.0
+    for t in range(4):
+        sub, body_map = S.extract_tile(scene, t)
+        ref = refworld.RefWorld(sub)
+        ref.step(steps)
+        rb = ref.bodies()
+        origin = scene["box_transforms"]["position"][t].astype(np.float64)
+        err = P.rel_err(gb["transforms"]["position"][body_map[1:]], rb["transforms"]["position"][1:], origin=origin)
+        worst = max(worst, float(err.max()))
+        dv = np.abs(gb["momentum"]["velocity"][body_map[1:]] - rb["momentum"]["velocity"][1:]).max()
+        assert dv <= 1e-4
+    assert worst <= 1e-4, worst
+    w.close()
+
+
+# ---- error conventions of the boundary --------------------------------------------------------------------------------
+def test_contact_capacity_overflow_is_reported():
+    scene, _ = G.build("grid30_awake")
+    fx = _fixture("grid30_awake")
+    w = E.World(scene, flags=FAST, max_contacts=256, arena_bytes=256 << 20)
+    w.set_bodies(fx["transforms"], fx["momentum"], fx["idle"])
+    with pytest.raises(E.NudgeError, match="capacity"):
+        w.collide()
+    w.close()
+
+
+def test_arena_exhaustion_is_reported():
+    scene, _ = G.build("pile256")
+    w = E.World(scene, flags=FAST, arena_bytes=4096)
+    with pytest.raises(E.NudgeError, match="arena"):
+        w.collide()
+    w.close()
+
+
+# ---- BASELINE.json sizes: size-independent properties ---------------------------------------------------------------------
+def test_million_box_scene_properties():
+    """Config 2 (1,004,400 boxes): every landed box rests on 4 face contacts, nothing is NaN, two runs agree
+    bit for bit, and sampled tiles agree with the per-tile reference when it is available."""
+    scene = S.grid_tiles(124, side=90, seed=2, lattice_cols=11)
+    n = len(scene["body_transforms"]) - 1
+    assert n == 1004400
+    steps = 70
+    finals = []
+    for rep in range(2):
+        w = E.World(scene, flags=E.NH_FLAG_SYNC_COUNTS, max_contacts=6 * n)
+        w.step(steps)
+        c = w.counts()
+        finals.append(w.get_bodies())
+        if rep == 0:
+            assert c["error"] == 0
+            assert c["contacts"] == 4 * n, c
+            assert c["active_bodies"] == n
+            assert c["general_contacts"] == 0
+        w.close()
+    a, b = finals
+    assert np.isfinite(a["transforms"]["position"]).all() and np.isfinite(a["momentum"]["velocity"]).all()
+    assert P.bits_equal(a["transforms"], b["transforms"]) and P.bits_equal(a["momentum"], b["momentum"])
+    if have_ref:
+        for t in (0, 61, 123):
+            sub, body_map = S.extract_tile(scene, t)
+            ref = refworld.RefWorld(sub)
+            ref.step(steps)
+            rb = ref.bodies()
+            origin = scene["box_transforms"]["position"][t].astype(np.float64)
+            err = P.rel_err(a["transforms"]["position"][body_map[1:]], rb["transforms"]["position"][1:], origin=origin)
+            assert err.max() <= 1e-4, (t, err.max())
