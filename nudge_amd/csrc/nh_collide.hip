@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_cell_keys(nh_DevState* __restrict__ st,
 			keys[c] = key;
 			vals[c] = c;
 		}
-		uint32_t slot = nh_wave_reserve(&st->large, (valid && large) ? 1u : 0u);
+		uint32_t slot = nh_wave_reserve1(&st->large, valid && large);
 		if (valid && large) large_list[slot] = c;
 	}
 }
@@ -162,7 +162,7 @@ __device__ __forceinline__ bool aabb_overlap(const float4& amin, const float4& a
 }
 
 __device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_t pair_cap, const uint64_t* mkey, uint32_t ca, uint32_t cb, bool hit) {
-	uint32_t slot = nh_wave_reserve(&st->pairs, hit ? 1u : 0u);
+	uint32_t slot = nh_wave_reserve1(&st->pairs, hit);
 	if (hit) {
 		if (slot < pair_cap) {
 			uint64_t ka = mkey[ca], kb = mkey[cb];
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			}
 		}
 		uint32_t base = nh_wave_reserve(&st->raw_contacts, (uint32_t)count);
-		uint32_t slot = nh_wave_reserve(&st->records, count ? 1u : 0u);
+		uint32_t slot = nh_wave_reserve1(&st->records, count != 0);
 		if (count) {
 			if (base + count <= raw_cap) {
 				for (int k = 0; k < count; ++k) {
@@ -390,17 +390,32 @@ __global__ __launch_bounds__(256) void k_filter_records(nh_DevState* __restrict_
 			uint32_t set = root_of[r.body_a ? r.body_a : r.body_b];      // sets[a] | sets[b] with sets[0] = 0 (nudge.cpp:3988)
 			sleeping = !set_active[set];
 			rec_idx[i] = i;
-			if (sleeping) { rec[i].count = 0; rec_key[i] = ~0ull; }
+			if (sleeping) { rec[i].count = 0; rec[i].start = 0xFFFFFFFFu; }   // key kept: sleeping pairs come out in tag order
 		}
-		uint32_t slot = nh_wave_reserve(&st->sleeping, sleeping ? 1u : 0u);
-		if (sleeping && sleeping_pairs && slot < sleeping_cap) sleeping_pairs[slot] = key;
+		(void)key; (void)sleeping_pairs; (void)sleeping_cap;
 	}
 }
 
 // ---- 8. tag-ordered output ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sorted_counts(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ rec_idx, const nh_Record* __restrict__ rec, uint32_t* __restrict__ counts) {
+__global__ __launch_bounds__(256) void k_sorted_counts(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ rec_idx, const nh_Record* __restrict__ rec,
+                                                       uint32_t* __restrict__ counts, uint32_t* __restrict__ sleep_flags) {
 	uint32_t n = st->records;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) counts[i] = rec[rec_idx[i]].count;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		nh_Record r = rec[rec_idx[i]];
+		counts[i] = r.count;
+		sleep_flags[i] = (r.start == 0xFFFFFFFFu) ? 1u : 0u;
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) sleep_flags[n] = 0;
+}
+
+// sleeping pairs in ascending tag order (reference sorts them at nudge.cpp:4008): ordered compaction of the sorted records
+__global__ __launch_bounds__(256) void k_write_sleeping(nh_DevState* __restrict__ st, const uint32_t* __restrict__ scan, const uint64_t* __restrict__ rec_key_sorted,
+                                                        uint64_t* __restrict__ sleeping_pairs, uint32_t cap) {
+	uint32_t n = st->records;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		uint32_t p = scan[i], q = scan[i + 1];
+		if (q != p) { if (p < cap) sleeping_pairs[p] = rec_key_sorted[i]; else st->error = NH_ERR_CONTACT_CAPACITY; }
+	}
 }
 
 __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict__ st, const uint32_t* __restrict__ rec_idx, const nh_Record* __restrict__ rec, const uint64_t* __restrict__ rec_key_sorted,
@@ -437,7 +452,7 @@ __global__ void k_collide_begin(nh_DevState* st, uint32_t ncolliders) {
 	if (t == 0) {
 		st->colliders = ncolliders; st->pairs = 0; st->raw_contacts = 0; st->records = 0; st->contacts = 0; st->sleeping = 0;
 		st->active = 0; st->culled = 0; st->large = 0; st->general_contacts = 0; st->levels = 0; st->error = 0;
-		st->static_bodies = 0; st->unleveled = 0;
+		st->static_bodies = 0; st->unleveled = 0; st->static4 = 0; st->static8 = 0; st->staticN = 0;
 		for (int k = 0; k < 3; ++k) { st->smin[k] = 0xffffffffu; st->smax[k] = 0u; }
 	}
 	st->exp_hist[t] = 0;
@@ -474,7 +489,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	uint32_t* vals_a = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* vals_b = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* large_list = nh_arena_array<uint32_t>(A, C, &err);
-	uint32_t* hist = nh_arena_array<uint32_t>(A, 256 * NH_SORT_GRID + 64, &err);
+	uint32_t* hist = nh_arena_array<uint32_t>(A, 256 * NH_SORT_GRID + 512, &err);
 	uint32_t* scan_tmp = nh_arena_array<uint32_t>(A, NH_SORT_GRID + 64, &err);
 	// grid: up to 4 cells per collider (power of two), clamped
 	uint64_t want = 1; while (want < 4ull * C) want <<= 1;
@@ -492,11 +507,11 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	uint32_t* rec_idx_b = nh_arena_array<uint32_t>(A, pair_cap, &err);
 	nh_Record* rec = nh_arena_array<nh_Record>(A, pair_cap, &err);
 	uint32_t* rec_counts = nh_arena_array<uint32_t>(A, pair_cap + 1, &err);
+	uint32_t* sleep_flags = nh_arena_array<uint32_t>(A, pair_cap + 1, &err);
 	uint32_t* parent = nh_arena_array<uint32_t>(A, B, &err);
 	uint32_t* set_active = nh_arena_array<uint32_t>(A, B, &err);
 	uint32_t* root_of = nh_arena_array<uint32_t>(A, B, &err);
 	uint32_t* flags = nh_arena_array<uint32_t>(A, B + 1, &err);
-	uint64_t* sleep_tmp = nh_arena_array<uint64_t>(A, cap, &err);
 	if (err) return err;
 
 	hipStream_t s = ctx->stream;
@@ -530,7 +545,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		nh_scan_u32(ctx, flags, flags, &st->pad0 /* always 0 */, B, scan_tmp, &st->active);
 	}
 	NH_LAUNCH(ctx, "active_write", k_active_write, nh_grid_for(B, 256, 2048), 256, st, B, root_of, set_active, flags, active_bodies->indices, active_bodies->capacity);
-	NH_LAUNCH(ctx, "filter_records", k_filter_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, rec_key_a, rec_idx_a, root_of, set_active, contacts->sleeping_pairs ? sleep_tmp : (uint64_t*)nullptr, cap);
+	NH_LAUNCH(ctx, "filter_records", k_filter_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, rec_key_a, rec_idx_a, root_of, set_active, (uint64_t*)nullptr, cap);
 	// tag order: sort records by (b_tag, a_tag), then lay contacts out pair by pair
 	int key_bits = (int)ctx->tag_bits;
 	if (key_bits < 1) key_bits = 1;
@@ -539,16 +554,14 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	nh_sort_u64_u32(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, &st->records, hist, 0, ((key_bits + 7) / 8) * 8);
 	nh_sort_u64_u32(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, &st->records, hist, 32, 32 + ((key_bits + 7) / 8) * 8);
 	// (dropped records carry count 0, so where they land in the order is irrelevant)
-	NH_LAUNCH(ctx, "sorted_counts", k_sorted_counts, nh_grid_for(pair_cap, 256, 2048), 256, st, rec_idx_a, rec, rec_counts);
+	NH_LAUNCH(ctx, "sorted_counts", k_sorted_counts, nh_grid_for(pair_cap, 256, 2048), 256, st, rec_idx_a, rec, rec_counts, sleep_flags);
 	nh_scan_u32(ctx, rec_counts, rec_counts, &st->records, 0, scan_tmp, &st->contacts);
 	NH_LAUNCH(ctx, "gather_contacts", k_gather_contacts, nh_grid_for(pair_cap, 256, 4096), 256, st, rec_idx_a, rec, rec_key_a, rec_counts, raw_data, raw_feature,
 	          contacts->data, contacts->bodies, contacts->tags, contacts->features, cap);
 	// sleeping pairs, ascending (nudge.cpp:4008)
-	if (contacts->sleeping_pairs) {
-		NH_LAUNCH(ctx, "collide_end", k_collide_end, 1, 1, st, cap);
-		nh_sort_u64(ctx, sleep_tmp, (uint64_t*)raw_data /* raw contacts are dead now */, &st->sleeping, hist, 0, 64);
-		nh_copy_back_u32(ctx, (const uint32_t*)sleep_tmp, (uint32_t*)contacts->sleeping_pairs, &st->sleeping, 2);
-	}
+	nh_scan_u32(ctx, sleep_flags, sleep_flags, &st->records, 1, scan_tmp, &st->sleeping);
+	if (contacts->sleeping_pairs)
+		NH_LAUNCH(ctx, "write_sleeping", k_write_sleeping, nh_grid_for(pair_cap, 256, 2048), 256, st, sleep_flags, rec_key_a, contacts->sleeping_pairs, cap);
 
 	if (ctx->flags & NH_FLAG_SYNC_COUNTS) {
 		nh_Counts c;

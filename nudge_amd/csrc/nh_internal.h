@@ -35,9 +35,11 @@ struct nh_DevState {
 	uint32_t general_contacts;
 	uint32_t levels;
 	uint32_t error;
-	uint32_t static_bodies;       // bodies solved by the one-body fast path
+	uint32_t static_bodies;       // bodies solved by the one-body fast path (sum of the three classes below)
 	uint32_t unleveled;           // general contacts still without a level (relaxation progress)
-	uint32_t pad0;
+	uint32_t pad0;                // always 0 (used as a constant device-side count)
+	uint32_t static4, static8, staticN;   // one-body fast path, by contact count: <= 4, <= 8, more
+	uint32_t pad1;
 	// scene bounds of AABB min corners, order-preserving uint encoding (atomicMin/Max)
 	uint32_t smin[3];
 	uint32_t smax[3];
@@ -91,7 +93,7 @@ struct nh_ContactConstraintData {
 	float* states;                        // K x 4 floats (nh_state + pad)
 	uint32_t* body_off;                   // B+1 CSR offsets into adj
 	uint32_t* adj;                        // contact indices per dynamic body, solver order
-	uint32_t* static_bodies;              // compacted list of bodies on the one-body fast path
+	uint32_t* static_bodies;              // 3 x B: bodies on the one-body fast path, by contact count (<=4 | <=8 | more)
 	uint8_t* body_class;                  // 0 none, 1 static-only, 2 general
 	uint32_t* level_order;                // general contacts sorted by level
 	uint32_t level_off[NH_MAX_LEVELS + 2];// host copy of level offsets
@@ -148,7 +150,7 @@ static inline uint32_t nh_grid_for(uint64_t n, uint32_t block = NH_BLOCK, uint32
 // ---- utilities implemented in nh_util.hip (all sizes come from DEVICE counters) ------------------------
 // Stable LSD radix sorts, 8-bit digits, bits [begin_bit, end_bit).  Result ends up in the *_a buffers.
 void nh_sort_u32_u32(nh_context* ctx, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
-                     const uint32_t* d_count, uint32_t* hist /* 256*NH_SORT_GRID+8 */, int begin_bit, int end_bit);
+                     const uint32_t* d_count, uint32_t* hist /* 256*NH_SORT_GRID+512 */, int begin_bit, int end_bit);
 void nh_sort_u64_u32(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                      const uint32_t* d_count, uint32_t* hist, int begin_bit, int end_bit);
 void nh_sort_u64(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b,
@@ -187,6 +189,17 @@ __device__ __forceinline__ uint32_t nh_wave_reserve(uint32_t* counter, uint32_t 
 	if (nh_lane() == 63 && total) base = atomicAdd(counter, total);
 	base = __shfl(base, 63);
 	return base + x - n;
+}
+
+// Same for a 0/1 request: one ballot + popcount instead of a shuffle scan.
+__device__ __forceinline__ uint32_t nh_wave_reserve1(uint32_t* counter, bool flag) {
+	unsigned long long bal = __ballot(flag);
+	if (!bal) return 0;
+	unsigned leader = (unsigned)__ffsll((long long)bal) - 1u;
+	uint32_t base = 0;
+	if (nh_lane() == leader) base = atomicAdd(counter, (uint32_t)__popcll(bal));
+	base = __shfl(base, (int)leader);
+	return base + (uint32_t)__popcll(bal & ((1ull << nh_lane()) - 1ull));
 }
 #endif
 

@@ -185,8 +185,14 @@ __global__ __launch_bounds__(256) void k_adj_sort(nh_DevState* __restrict__ st, 
 		} else if (x == 0 && nbodies) {
 			body_class[0] = 0;
 		}
-		uint32_t slot = nh_wave_reserve(&st->static_bodies, cls == 1u ? 1u : 0u);
-		if (cls == 1u) static_list[slot] = x;
+		uint32_t d = (cls == 1u) ? (off[x + 1] - off[x]) : 0u;
+		bool c4 = cls == 1u && d <= 4u, c8 = cls == 1u && d > 4u && d <= 8u, cn = cls == 1u && d > 8u;
+		uint32_t s4 = nh_wave_reserve1(&st->static4, c4);
+		uint32_t s8 = nh_wave_reserve1(&st->static8, c8);
+		uint32_t sn = nh_wave_reserve1(&st->staticN, cn);
+		if (c4) static_list[s4] = x;
+		if (c8) static_list[nbodies + s8] = x;
+		if (cn) static_list[2u * nbodies + sn] = x;
 	}
 }
 
@@ -202,10 +208,10 @@ __global__ __launch_bounds__(256) void k_contact_class(nh_DevState* __restrict__
 			general = (p.a && body_class[p.a] == 2) || (p.b && body_class[p.b] == 2);
 			level[i] = general ? NH_UNSET : 0u;
 		}
-		uint32_t slot = nh_wave_reserve(&st->general_contacts, general ? 1u : 0u);
+		uint32_t slot = nh_wave_reserve1(&st->general_contacts, general);
 		if (general) general_list[slot] = i;
 	}
-	if (blockIdx.x == 0 && threadIdx.x == 0) st->unleveled = 1;   // forces at least one relaxation check
+	if (blockIdx.x == 0 && threadIdx.x == 0) st->static_bodies = st->static4 + st->static8 + st->staticN;
 }
 
 // ---- exact replay of the reference's greedy batch scheduler (nudge.cpp:4206-4339), one wave -------------------
@@ -330,11 +336,11 @@ __device__ __forceinline__ void load_row(const float* __restrict__ rows, uint32_
 }
 
 // ---- one-body fast path: setup (rows + warm start) ----------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_setup_static(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
+__global__ __launch_bounds__(256) void k_setup_static(const uint32_t* __restrict__ d_count, const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
                                                       const nh_Contact* __restrict__ contacts, const nh_BodyPair* __restrict__ bodies, const nh_CachedContactImpulse* __restrict__ cached,
                                                       const nh_Transform* __restrict__ xf, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                       float* __restrict__ rows, float4* __restrict__ states) {
-	uint32_t n = st->static_bodies;
+	uint32_t n = *d_count;
 	const nh_inertia I0 = body_inertia(xf, props, 0);
 	const nh_Transform t0 = xf[0];
 	const nh_f3 pos0 = nh_make3(t0.position[0], t0.position[1], t0.position[2]);
@@ -370,25 +376,59 @@ __global__ __launch_bounds__(256) void k_setup_static(const nh_DevState* __restr
 }
 
 // ---- one-body fast path: `iterations` PGS sweeps ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_apply_static(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
+// MAXC > 0: the body's <= MAXC constraint rows stay in registers across all iterations (160 B each): every row is
+// read from HBM once per call, not once per iteration.  MAXC == 0: any contact count, rows re-read per iteration.
+template<int MAXC>
+__global__ __launch_bounds__(256) void k_apply_static(const uint32_t* __restrict__ d_count, const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
                                                       const nh_BodyPair* __restrict__ bodies, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                       const float* __restrict__ rows, float4* __restrict__ states, uint32_t iterations) {
-	uint32_t n = st->static_bodies;
+	uint32_t n = *d_count;
 	const nh_vel vel0 = load_vel(momentum, props, 0);
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
 		uint32_t x = static_list[k];
 		nh_vel v = load_vel(momentum, props, x);
 		nh_vel z = vel0;
 		uint32_t b = off[x], e = off[x + 1];
-		for (uint32_t it = 0; it < iterations; ++it) {
-			for (uint32_t q = b; q < e; ++q) {
-				uint32_t c = adj[q];
-				nh_row r;
-				load_row(rows, c, r);
-				float4 sv = states[c];
-				nh_state s = { sv.x, sv.y, sv.z };
-				if (bodies[c].a == x) nh_apply_one(r, s, v, z); else nh_apply_one(r, s, z, v);
-				states[c] = make_float4(s.normal, s.friction_x, s.friction_y, 0.0f);
+		if (MAXC > 0) {
+			constexpr int M = MAXC > 0 ? MAXC : 1;
+			nh_row r[M];
+			nh_state s[M];
+			bool is_a[M];
+			uint32_t cid[M];
+			uint32_t cnt = e - b;
+#pragma unroll
+			for (int q = 0; q < M; ++q) {
+				if ((uint32_t)q < cnt) {
+					uint32_t c = adj[b + q];
+					cid[q] = c;
+					load_row(rows, c, r[q]);
+					float4 sv = states[c];
+					s[q].normal = sv.x; s[q].friction_x = sv.y; s[q].friction_y = sv.z;
+					is_a[q] = bodies[c].a == x;
+				}
+			}
+			for (uint32_t it = 0; it < iterations; ++it) {
+#pragma unroll
+				for (int q = 0; q < M; ++q) {
+					if ((uint32_t)q < cnt) {
+						if (is_a[q]) nh_apply_one(r[q], s[q], v, z); else nh_apply_one(r[q], s[q], z, v);
+					}
+				}
+			}
+#pragma unroll
+			for (int q = 0; q < M; ++q)
+				if ((uint32_t)q < cnt) states[cid[q]] = make_float4(s[q].normal, s[q].friction_x, s[q].friction_y, 0.0f);
+		} else {
+			for (uint32_t it = 0; it < iterations; ++it) {
+				for (uint32_t q = b; q < e; ++q) {
+					uint32_t c = adj[q];
+					nh_row r;
+					load_row(rows, c, r);
+					float4 sv = states[c];
+					nh_state s = { sv.x, sv.y, sv.z };
+					if (bodies[c].a == x) nh_apply_one(r, s, v, z); else nh_apply_one(r, s, z, v);
+					states[c] = make_float4(s.normal, s.friction_x, s.friction_y, 0.0f);
+				}
 			}
 		}
 		store_vel(momentum, x, v);
@@ -587,7 +627,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	d->states = nh_arena_array<float>(memory, (size_t)kcap * 4, &err);
 	d->body_off = nh_arena_array<uint32_t>(memory, B + 2, &err);
 	d->adj = nh_arena_array<uint32_t>(memory, (size_t)kcap * 2, &err);
-	d->static_bodies = nh_arena_array<uint32_t>(memory, B, &err);
+	d->static_bodies = nh_arena_array<uint32_t>(memory, (size_t)3 * B, &err);
 	d->body_class = nh_arena_array<uint8_t>(memory, B, &err);
 	d->level_order = nh_arena_array<uint32_t>(memory, kcap, &err);
 	uint32_t* cursor = nh_arena_array<uint32_t>(memory, B + 2, &err);
@@ -611,8 +651,12 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	if (slot_key) NH_LAUNCH(ctx, "greedy_replay", k_greedy_replay, 1, 64, st, contacts->bodies, slot_key);
 	NH_LAUNCH(ctx, "adjacency_sort", k_adj_sort, nh_grid_for(B, 256, 4096), 256, st, B, contacts->bodies, d->body_off, d->adj, slot_key, d->body_class, pred_a, pred_b, d->static_bodies);
 	NH_LAUNCH(ctx, "contact_class", k_contact_class, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, d->body_class, level, general_list);
-	NH_LAUNCH(ctx, "setup_static", k_setup_static, nh_grid_for(B, 256, 4096), 256, st, d->static_bodies, d->body_off, d->adj,
-	          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states);
+	{
+		const uint32_t* cnts[3] = { &st->static4, &st->static8, &st->staticN };
+		for (int k = 0; k < 3; ++k)
+			NH_LAUNCH(ctx, "setup_static", k_setup_static, nh_grid_for(B, 256, k == 0 ? 4096 : 512), 256, cnts[k], d->static_bodies + (size_t)k * B, d->body_off, d->adj,
+			          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states);
+	}
 
 	// the level-scheduled path needs per-level launch sizes on the host: one round trip
 	nh_Counts c;
@@ -660,7 +704,12 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 extern "C" int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations) {
 	if (!ctx || !d || !bodies) return NH_ERR_INVALID;
 	nh_DevState* st = ctx->d_state;
-	NH_LAUNCH(ctx, "apply_static", k_apply_static, nh_grid_for(d->body_count, 256, 4096), 256, st, d->static_bodies, d->body_off, d->adj, d->bodies,
+	const uint32_t B = d->body_count;
+	NH_LAUNCH(ctx, "apply_static", (k_apply_static<4>), nh_grid_for(B, 256, 8192), 256, &st->static4, d->static_bodies, d->body_off, d->adj, d->bodies,
+	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations);
+	NH_LAUNCH(ctx, "apply_static8", (k_apply_static<8>), nh_grid_for(B, 256, 2048), 256, &st->static8, d->static_bodies + (size_t)B, d->body_off, d->adj, d->bodies,
+	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations);
+	NH_LAUNCH(ctx, "apply_staticN", (k_apply_static<0>), nh_grid_for(B, 256, 512), 256, &st->staticN, d->static_bodies + (size_t)2 * B, d->body_off, d->adj, d->bodies,
 	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations);
 	if (d->general_contacts) {
 		for (uint32_t it = 0; it < iterations; ++it)

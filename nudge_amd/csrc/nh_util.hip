@@ -33,22 +33,19 @@ __global__ __launch_bounds__(256) void rs_hist(const K* __restrict__ keys, const
 	hist[threadIdx.x * RS_G + blockIdx.x] = h[threadIdx.x];
 }
 
-// exclusive scan of 256*RS_G counters, digit-major (one workgroup of 1024 threads)
-__global__ __launch_bounds__(1024) void rs_scan(uint32_t* __restrict__ hist) {
-	const uint32_t per = 256 * RS_G / 1024;
-	__shared__ uint32_t wsum[16];
-	uint32_t base = threadIdx.x * per;
-	uint32_t s = 0;
-	for (uint32_t i = 0; i < per; ++i) s += hist[base + i];
-	// block exclusive scan of s
-	uint32_t x = s;
+// per-digit exclusive scan over the RS_G block counters (one workgroup per digit) + the digit's total
+__global__ __launch_bounds__(RS_G) void rs_rowscan(uint32_t* __restrict__ hist) {
+	__shared__ uint32_t wsum[RS_G / 64];
+	uint32_t* row = hist + blockIdx.x * RS_G;
+	uint32_t v = row[threadIdx.x];
+	uint32_t x = v;
 	for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d); if ((int)(threadIdx.x & 63) >= d) x += y; }
 	if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
 	__syncthreads();
 	uint32_t woff = 0;
 	for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) woff += wsum[w];
-	uint32_t run = woff + x - s;
-	for (uint32_t i = 0; i < per; ++i) { uint32_t v = hist[base + i]; hist[base + i] = run; run += v; }
+	row[threadIdx.x] = woff + x - v;
+	if (threadIdx.x == RS_G - 1) hist[256 * RS_G + blockIdx.x] = woff + x;     // digit total
 }
 
 template<typename K, typename V, bool HAS_V>
@@ -60,7 +57,18 @@ __global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ keys, K*
 	uint32_t n = *d_n;
 	uint32_t begin, end;
 	rs_chunk(n, begin, end);
-	offs[threadIdx.x] = hist[threadIdx.x * RS_G + blockIdx.x];
+	{
+		// digit base = exclusive scan of the 256 digit totals (every workgroup redoes this tiny scan in LDS)
+		uint32_t v = hist[256 * RS_G + threadIdx.x];
+		uint32_t x = v;
+		for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d); if ((int)(threadIdx.x & 63) >= d) x += y; }
+		if ((threadIdx.x & 63) == 63) whist[0][threadIdx.x >> 6] = x;
+		__syncthreads();
+		uint32_t woff = 0;
+		for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) woff += whist[0][w];
+		offs[threadIdx.x] = woff + x - v + hist[threadIdx.x * RS_G + blockIdx.x];
+		__syncthreads();
+	}
 	for (int w = 0; w < 4; ++w) whist[w][threadIdx.x] = 0;
 	__syncthreads();
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -108,7 +116,7 @@ static void sort_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* vals_
 	int passes = 0;
 	for (int shift = begin_bit; shift < end_bit; shift += 8) {
 		NH_LAUNCH(ctx, "radix_hist", (rs_hist<K>), RS_G, 256, kin, d_count, hist, shift);
-		NH_LAUNCH(ctx, "radix_scan", rs_scan, 1, 1024, hist);
+		NH_LAUNCH(ctx, "radix_scan", rs_rowscan, 256, RS_G, hist);
 		NH_LAUNCH(ctx, "radix_scatter", (rs_scatter<K, V, HAS_V>), RS_G, 256, kin, kout, vin, vout, d_count, hist, shift);
 		K* tk = kin; kin = kout; kout = tk;
 		V* tv = vin; vin = vout; vout = tv;
