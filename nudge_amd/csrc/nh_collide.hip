@@ -10,6 +10,7 @@
 // the few large ones (ground slabs); union-find runs lock-free with atomicCAS hooking.
 #include "nh_internal.h"
 #include "nh_narrowphase.h"
+#include <stdlib.h>
 
 // ---- 1. world transforms, AABBs, bounds, extent histogram ---------------------------------------------
 // aabb_min[c] = (min.xyz, bits(body)), aabb_max[c] = (max.xyz, bits(max extent))
@@ -89,13 +90,53 @@ __global__ void k_grid_params(nh_DevState* st, uint32_t ncolliders, uint32_t max
 	st->small_exp = (uint32_t)e;
 	float cell = __uint_as_float((uint32_t)(e + 1) << 23);     // 2^(e+1-127) > every small extent
 	st->cell_inv = 1.0f / cell;
-	st->origin[0] = smin.x; st->origin[1] = smin.y; st->origin[2] = smin.z;
-	float dx = (smax.x - smin.x) * st->cell_inv, dy = (smax.y - smin.y) * st->cell_inv, dz = (smax.z - smin.z) * st->cell_inv;
-	uint64_t nx = (uint64_t)fminf(fmaxf(dx, 0.0f), 1e6f) + 2, ny = (uint64_t)fminf(fmaxf(dy, 0.0f), 1e6f) + 2, nz = (uint64_t)fminf(fmaxf(dz, 0.0f), 1e6f) + 2;
-	while (nx * ny * nz > max_cells) {
-		if (nx >= ny && nx >= nz) nx = (nx + 1) / 2; else if (ny >= nz) ny = (ny + 1) / 2; else nz = (nz + 1) / 2;
+}
+
+// bounds of the min corners of the SMALL colliders (the grid only has to span those)
+__global__ __launch_bounds__(256) void k_small_bounds(nh_DevState* __restrict__ st, uint32_t n, const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max) {
+	__shared__ uint32_t red[6];
+	if (threadIdx.x < 3) { red[threadIdx.x] = 0xffffffffu; red[3 + threadIdx.x] = 0u; }
+	__syncthreads();
+	const uint32_t small_exp = st->small_exp;
+	uint32_t lmin[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, lmax[3] = { 0, 0, 0 };
+	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+		float4 mn = aabb_min[c];
+		float ext = aabb_max[c].w;
+		uint32_t e = (__float_as_uint(ext) >> 23) & 255u;
+		if (e <= small_exp && ext == ext) {
+			uint32_t f;
+			f = nh_float_flip(mn.x); lmin[0] = min(lmin[0], f); lmax[0] = max(lmax[0], f);
+			f = nh_float_flip(mn.y); lmin[1] = min(lmin[1], f); lmax[1] = max(lmax[1], f);
+			f = nh_float_flip(mn.z); lmin[2] = min(lmin[2], f); lmax[2] = max(lmax[2], f);
+		}
 	}
-	st->dims[0] = (uint32_t)nx; st->dims[1] = (uint32_t)ny; st->dims[2] = (uint32_t)nz;
+	for (int k = 0; k < 3; ++k) {
+		for (int d = 32; d >= 1; d >>= 1) { lmin[k] = min(lmin[k], (uint32_t)__shfl_xor((int)lmin[k], d)); lmax[k] = max(lmax[k], (uint32_t)__shfl_xor((int)lmax[k], d)); }
+		if ((threadIdx.x & 63) == 0) { atomicMin(&red[k], lmin[k]); atomicMax(&red[3 + k], lmax[k]); }
+	}
+	__syncthreads();
+	if (threadIdx.x < 3) { atomicMin(&st->gmin[threadIdx.x], red[threadIdx.x]); atomicMax(&st->gmax[threadIdx.x], red[3 + threadIdx.x]); }
+}
+
+// grid origin and dimensions; if the table is too small the CELL grows (never clamp one axis: that piles colliders up)
+__global__ void k_grid_dims(nh_DevState* st, uint32_t max_cells) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	if (st->gmin[0] > st->gmax[0]) {      // no small collider at all
+		st->origin[0] = st->origin[1] = st->origin[2] = 0.0f;
+		st->dims[0] = st->dims[1] = st->dims[2] = 1;
+		return;
+	}
+	nh_f3 gmin = nh_make3(nh_float_unflip(st->gmin[0]), nh_float_unflip(st->gmin[1]), nh_float_unflip(st->gmin[2]));
+	nh_f3 gmax = nh_make3(nh_float_unflip(st->gmax[0]), nh_float_unflip(st->gmax[1]), nh_float_unflip(st->gmax[2]));
+	st->origin[0] = gmin.x; st->origin[1] = gmin.y; st->origin[2] = gmin.z;
+	float inv = st->cell_inv;
+	for (int it = 0; it < 64; ++it) {
+		float dx = (gmax.x - gmin.x) * inv, dy = (gmax.y - gmin.y) * inv, dz = (gmax.z - gmin.z) * inv;
+		uint64_t nx = (uint64_t)fminf(fmaxf(dx, 0.0f), 1e7f) + 2, ny = (uint64_t)fminf(fmaxf(dy, 0.0f), 1e7f) + 2, nz = (uint64_t)fminf(fmaxf(dz, 0.0f), 1e7f) + 2;
+		if (nx * ny * nz <= max_cells) { st->dims[0] = (uint32_t)nx; st->dims[1] = (uint32_t)ny; st->dims[2] = (uint32_t)nz; break; }
+		inv *= 0.5f;
+	}
+	st->cell_inv = inv;
 }
 
 __device__ __forceinline__ int cell_coord(float x, float origin, float inv) {
@@ -184,14 +225,16 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 	const float inv = st->cell_inv;
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
-	const uint32_t nlarge = st->large;
+	const uint32_t nlarge = (pair_cap & 0x80000000u) ? 0u : st->large;
+	const bool dbg_skip_grid = (pair_cap & 0x40000000u) != 0;
+	pair_cap &= 0x3fffffffu;
 	uint32_t rounded = (n + 63u) & ~63u;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
 		bool valid = i < n;
 		float4 amin = make_float4(0, 0, 0, 0), amax = amin;
 		uint32_t key = NH_LARGE_KEY, ca = 0, abody = 0;
 		if (valid) { amin = smin[i]; amax = smax[i]; key = keys[i]; ca = __float_as_uint(amax.w); abody = __float_as_uint(amin.w); }
-		bool small = valid && key != NH_LARGE_KEY;
+		bool small = valid && key != NH_LARGE_KEY && !dbg_skip_grid;
 		// neighbour cells [c_min-1, c_max] per axis, clamped
 		int x0 = 0, x1 = -1, y0 = 0, y1 = -1, z0 = 0, z1 = -1;
 		if (small) {
@@ -453,7 +496,7 @@ __global__ void k_collide_begin(nh_DevState* st, uint32_t ncolliders) {
 		st->colliders = ncolliders; st->pairs = 0; st->raw_contacts = 0; st->records = 0; st->contacts = 0; st->sleeping = 0;
 		st->active = 0; st->culled = 0; st->large = 0; st->general_contacts = 0; st->levels = 0; st->error = 0;
 		st->static_bodies = 0; st->unleveled = 0; st->static4 = 0; st->static8 = 0; st->staticN = 0;
-		for (int k = 0; k < 3; ++k) { st->smin[k] = 0xffffffffu; st->smax[k] = 0u; }
+		for (int k = 0; k < 3; ++k) { st->smin[k] = 0xffffffffu; st->smax[k] = 0u; st->gmin[k] = 0xffffffffu; st->gmax[k] = 0u; }
 	}
 	st->exp_hist[t] = 0;
 }
@@ -522,13 +565,15 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
 		          xf, aabb_min, aabb_max, ctag);
 		NH_LAUNCH(ctx, "grid_params", k_grid_params, 1, 64, st, C, max_cells);
+		NH_LAUNCH(ctx, "small_bounds", k_small_bounds, nh_grid_for(C, 256, 1024), 256, st, C, aabb_min, aabb_max);
+		NH_LAUNCH(ctx, "grid_dims", k_grid_dims, 1, 64, st, max_cells);
 		NH_LAUNCH(ctx, "cell_keys", k_cell_keys, nh_grid_for(C, 256, 2048), 256, st, C, aabb_min, aabb_max, keys_a, vals_a, mkey, large_list);
 		nh_sort_u32_u32(ctx, keys_a, keys_b, vals_a, vals_b, &st->colliders, hist, 0, 24);
 		if (ctx->timing) nh_timer_begin(ctx, "memset_cells");
 		NH_HIP_CHECK(ctx, hipMemsetAsync(cells, 0, sizeof(uint2) * (size_t)max_cells, s));
 		if (ctx->timing) nh_timer_end(ctx);
 		NH_LAUNCH(ctx, "cell_bounds", k_cell_bounds, nh_grid_for(C, 256, 2048), 256, C, keys_a, vals_a, aabb_min, aabb_max, cells, smin, smax);
-		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 4096), 256, st, C, keys_a, smin, smax, cells, large_list, aabb_min, aabb_max, mkey, pairs, pair_cap);
+		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 4096), 256, st, C, keys_a, smin, smax, cells, large_list, aabb_min, aabb_max, mkey, pairs, pair_cap | (getenv("NH_DBG_SKIP_LARGE") ? 0x80000000u : 0u) | (getenv("NH_DBG_SKIP_GRID") ? 0x40000000u : 0u));
 		NH_LAUNCH(ctx, "narrowphase", k_narrowphase, nh_grid_for(pair_cap, 256, 4096), 256, st, pairs, xf, ctag,
 		          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, cap, rec_key_a, rec);
 	}

@@ -43,6 +43,9 @@ struct nh_DevState {
 	// scene bounds of AABB min corners, order-preserving uint encoding (atomicMin/Max)
 	uint32_t smin[3];
 	uint32_t smax[3];
+	// the same over "small" (grid) colliders only: the broadphase grid spans just these
+	uint32_t gmin[3];
+	uint32_t gmax[3];
 	// broadphase grid parameters (written by k_grid_params)
 	float morton_scale;
 	float morton_min[3];          // scene_min * scale
