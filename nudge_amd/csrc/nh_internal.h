@@ -106,6 +106,10 @@ struct nh_ContactConstraintData {
 	uint32_t body_count;
 	uint32_t static_body_count;
 	const nh_BodyPair* bodies;
+	// inputs kept for the one-body fast path, which rebuilds its rows in registers instead of storing them
+	const nh_Contact* contact_data;
+	nh_CachedContactImpulse* impulses;
+	uint32_t* general_list;
 };
 
 // ---- arena (host-side bump allocation over device memory, reference nudge.cpp:990-1055) ---------------

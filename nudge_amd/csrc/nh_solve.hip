@@ -336,8 +336,9 @@ __device__ __forceinline__ void load_row(const float* __restrict__ rows, uint32_
 }
 
 // ---- one-body fast path: setup (rows + warm start) ----------------------------------------------------------------------
+template<bool STORE>
 __global__ __launch_bounds__(256) void k_setup_static(const uint32_t* __restrict__ d_count, const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
-                                                      const nh_Contact* __restrict__ contacts, const nh_BodyPair* __restrict__ bodies, const nh_CachedContactImpulse* __restrict__ cached,
+                                                      const nh_Contact* __restrict__ contacts, const nh_BodyPair* __restrict__ bodies, nh_CachedContactImpulse* __restrict__ cached,
                                                       const nh_Transform* __restrict__ xf, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                       float* __restrict__ rows, float4* __restrict__ states) {
 	uint32_t n = *d_count;
@@ -368,8 +369,13 @@ __global__ __launch_bounds__(256) void k_setup_static(const uint32_t* __restrict
 				nh_build_row(ci, pos0, posx, I0, IX, z.mass_inverse, v.mass_inverse, r);
 				nh_warm_start(r, w.impulse[0], w.impulse[1], w.impulse[2], z, v, s);
 			}
-			store_row(rows, c, r);
+			if (STORE) store_row(rows, c, r);
 			states[c] = make_float4(s.normal, s.friction_x, s.friction_y, 0.0f);
+			// keep update_cached_impulses valid even if apply_impulses is never called
+			nh_CachedContactImpulse o;
+			nh_export_impulse(r, s, o.impulse[0], o.impulse[1], o.impulse[2]);
+			o.unused = 0.0f;
+			cached[c] = o;
 		}
 		store_vel(momentum, x, v);
 	}
@@ -381,9 +387,13 @@ __global__ __launch_bounds__(256) void k_setup_static(const uint32_t* __restrict
 template<int MAXC>
 __global__ __launch_bounds__(256) void k_apply_static(const uint32_t* __restrict__ d_count, const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
                                                       const nh_BodyPair* __restrict__ bodies, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
-                                                      const float* __restrict__ rows, float4* __restrict__ states, uint32_t iterations) {
+                                                      const float* __restrict__ rows, float4* __restrict__ states, uint32_t iterations,
+                                                      const nh_Contact* __restrict__ contacts, const nh_Transform* __restrict__ xf, nh_CachedContactImpulse* __restrict__ impulses) {
 	uint32_t n = *d_count;
 	const nh_vel vel0 = load_vel(momentum, props, 0);
+	const nh_inertia I0 = body_inertia(xf, props, 0);
+	const nh_Transform t0 = xf[0];
+	const nh_f3 pos0 = nh_make3(t0.position[0], t0.position[1], t0.position[2]);
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
 		uint32_t x = static_list[k];
 		nh_vel v = load_vel(momentum, props, x);
@@ -396,15 +406,22 @@ __global__ __launch_bounds__(256) void k_apply_static(const uint32_t* __restrict
 			bool is_a[M];
 			uint32_t cid[M];
 			uint32_t cnt = e - b;
+			// rows are a pure function of (contact, body transforms, properties): rebuilt here, never stored
+			const nh_inertia IX = body_inertia(xf, props, x);
+			const nh_Transform tx = xf[x];
+			const nh_f3 posx = nh_make3(tx.position[0], tx.position[1], tx.position[2]);
 #pragma unroll
 			for (int q = 0; q < M; ++q) {
 				if ((uint32_t)q < cnt) {
 					uint32_t c = adj[b + q];
 					cid[q] = c;
-					load_row(rows, c, r[q]);
+					is_a[q] = bodies[c].a == x;
+					nh_Contact ct = contacts[c];
+					nh_contact_in ci = { ct.position[0], ct.position[1], ct.position[2], ct.penetration, ct.normal[0], ct.normal[1], ct.normal[2], ct.friction };
+					if (is_a[q]) nh_build_row(ci, posx, pos0, IX, I0, v.mass_inverse, z.mass_inverse, r[q]);
+					else         nh_build_row(ci, pos0, posx, I0, IX, z.mass_inverse, v.mass_inverse, r[q]);
 					float4 sv = states[c];
 					s[q].normal = sv.x; s[q].friction_x = sv.y; s[q].friction_y = sv.z;
-					is_a[q] = bodies[c].a == x;
 				}
 			}
 			for (uint32_t it = 0; it < iterations; ++it) {
@@ -417,7 +434,13 @@ __global__ __launch_bounds__(256) void k_apply_static(const uint32_t* __restrict
 			}
 #pragma unroll
 			for (int q = 0; q < M; ++q)
-				if ((uint32_t)q < cnt) states[cid[q]] = make_float4(s[q].normal, s[q].friction_x, s[q].friction_y, 0.0f);
+				if ((uint32_t)q < cnt) {
+					states[cid[q]] = make_float4(s[q].normal, s[q].friction_x, s[q].friction_y, 0.0f);
+					nh_CachedContactImpulse o;        // update_cached_impulses (nudge.cpp:4872-4882) for this contact
+					nh_export_impulse(r[q], s[q], o.impulse[0], o.impulse[1], o.impulse[2]);
+					o.unused = 0.0f;
+					impulses[cid[q]] = o;
+				}
 		} else {
 			for (uint32_t it = 0; it < iterations; ++it) {
 				for (uint32_t q = b; q < e; ++q) {
@@ -428,6 +451,12 @@ __global__ __launch_bounds__(256) void k_apply_static(const uint32_t* __restrict
 					nh_state s = { sv.x, sv.y, sv.z };
 					if (bodies[c].a == x) nh_apply_one(r, s, v, z); else nh_apply_one(r, s, z, v);
 					states[c] = make_float4(s.normal, s.friction_x, s.friction_y, 0.0f);
+					if (it + 1 == iterations) {
+						nh_CachedContactImpulse o;
+						nh_export_impulse(r, s, o.impulse[0], o.impulse[1], o.impulse[2]);
+						o.unused = 0.0f;
+						impulses[c] = o;
+					}
 				}
 			}
 		}
@@ -524,9 +553,11 @@ __global__ __launch_bounds__(256) void k_level_exec(const uint32_t* __restrict__
 }
 
 // ---- update_cached_impulses (nudge.cpp:4857-4884) --------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_update_impulses(const nh_DevState* __restrict__ st, const float* __restrict__ rows, const float4* __restrict__ states, nh_CachedContactImpulse* __restrict__ out) {
-	uint32_t n = st->contacts;
-	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+// (contacts on the one-body fast path export their impulse at the end of every nh_apply_impulses call)
+__global__ __launch_bounds__(256) void k_update_impulses(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ general_list, const float* __restrict__ rows, const float4* __restrict__ states, nh_CachedContactImpulse* __restrict__ out) {
+	uint32_t n = st->general_contacts;
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		uint32_t c = general_list[k];
 		nh_row r;
 		load_row(rows, c, r);
 		float4 sv = states[c];
@@ -641,6 +672,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	uint32_t* tmp = nh_arena_array<uint32_t>(memory, NH_SORT_GRID + 64, &err);
 	if (err) return err;
 	d->contact_capacity = kcap; d->body_count = B; d->bodies = contacts->bodies;
+	d->contact_data = contacts->data; d->impulses = imp->data; d->general_list = general_list;
 	d->levels = 0; d->general_contacts = 0;
 
 	NH_LAUNCH(ctx, "zero_u32", k_zero_u32, nh_grid_for(B + 2, 256, 2048), 256, d->body_off, B + 2);
@@ -653,9 +685,14 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	NH_LAUNCH(ctx, "contact_class", k_contact_class, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, d->body_class, level, general_list);
 	{
 		const uint32_t* cnts[3] = { &st->static4, &st->static8, &st->staticN };
-		for (int k = 0; k < 3; ++k)
-			NH_LAUNCH(ctx, "setup_static", k_setup_static, nh_grid_for(B, 256, k == 0 ? 4096 : 512), 256, cnts[k], d->static_bodies + (size_t)k * B, d->body_off, d->adj,
-			          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states);
+		for (int k = 0; k < 3; ++k) {
+			if (k < 2)
+				NH_LAUNCH(ctx, "setup_static", (k_setup_static<false>), nh_grid_for(B, 256, k == 0 ? 4096 : 512), 256, cnts[k], d->static_bodies + (size_t)k * B, d->body_off, d->adj,
+				          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states);
+			else
+				NH_LAUNCH(ctx, "setup_staticN", (k_setup_static<true>), nh_grid_for(B, 256, 512), 256, cnts[k], d->static_bodies + (size_t)k * B, d->body_off, d->adj,
+				          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states);
+		}
 	}
 
 	// the level-scheduled path needs per-level launch sizes on the host: one round trip
@@ -706,11 +743,11 @@ extern "C" int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* d, c
 	nh_DevState* st = ctx->d_state;
 	const uint32_t B = d->body_count;
 	NH_LAUNCH(ctx, "apply_static", (k_apply_static<4>), nh_grid_for(B, 256, 8192), 256, &st->static4, d->static_bodies, d->body_off, d->adj, d->bodies,
-	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations);
+	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses);
 	NH_LAUNCH(ctx, "apply_static8", (k_apply_static<8>), nh_grid_for(B, 256, 2048), 256, &st->static8, d->static_bodies + (size_t)B, d->body_off, d->adj, d->bodies,
-	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations);
+	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses);
 	NH_LAUNCH(ctx, "apply_staticN", (k_apply_static<0>), nh_grid_for(B, 256, 512), 256, &st->staticN, d->static_bodies + (size_t)2 * B, d->body_off, d->adj, d->bodies,
-	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations);
+	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses);
 	if (d->general_contacts) {
 		for (uint32_t it = 0; it < iterations; ++it)
 			for (uint32_t l = 1; l <= d->levels; ++l) {
@@ -725,6 +762,7 @@ extern "C" int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* d, c
 
 extern "C" int nh_update_cached_impulses(nh_context* ctx, nh_ContactConstraintData* d, nh_ContactImpulseData* imp) {
 	if (!ctx || !d || !imp) return NH_ERR_INVALID;
-	NH_LAUNCH(ctx, "update_impulses", k_update_impulses, nh_grid_for(d->contact_capacity, 256, 4096), 256, ctx->d_state, d->rows, (const float4*)d->states, imp->data);
+	if (d->general_contacts)
+		NH_LAUNCH(ctx, "update_impulses", k_update_impulses, nh_grid_for(d->general_contacts, 256, 4096), 256, ctx->d_state, d->general_list, d->rows, (const float4*)d->states, imp->data);
 	return NH_OK;
 }
