@@ -202,18 +202,37 @@ __device__ __forceinline__ bool aabb_overlap(const float4& amin, const float4& a
 	return (bmax.x > amin.x) && (amax.x > bmin.x) && (bmax.y > amin.y) && (amax.y > bmin.y) && (bmax.z > amin.z) && (amax.z > bmin.z);
 }
 
-__device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_t pair_cap, const uint64_t* mkey, uint32_t ca, uint32_t cb, bool hit) {
-	uint32_t slot = nh_wave_reserve1(&st->pairs, hit);
-	if (hit) {
-		if (slot < pair_cap) {
-			uint64_t ka = mkey[ca], kb = mkey[cb];
-			bool a_first = (ka < kb) || (ka == kb && ca < cb);
-			// narrowphase "a" = later in Morton order (nudge.cpp:3495, 1202-1203)
-			pairs[slot] = a_first ? make_uint2(cb, ca) : make_uint2(ca, cb);
-		} else {
-			st->error = NH_ERR_PAIR_CAPACITY;
-		}
+// Pair emission.  A single global counter takes ~12 ns per atomic (same-address atomics serialise in L2), so
+// one atomic per wave per hit-iteration would cost more than the search itself: every wave stages its pairs in
+// its own LDS buffer and reserves global space once per ~450 pairs.
+#define FP_WBUF 512
+struct pair_stage { uint2* buf; uint32_t count; };
+
+__device__ __forceinline__ void flush_pairs(nh_DevState* st, uint2* pairs, uint32_t pair_cap, pair_stage& ps) {
+	uint32_t n = ps.count;
+	if (!n) return;
+	uint32_t base = 0;
+	if (nh_lane() == 0) base = atomicAdd(&st->pairs, n);
+	base = __shfl(base, 0);
+	__builtin_amdgcn_wave_barrier();
+	for (uint32_t k = nh_lane(); k < n; k += 64) {
+		if (base + k < pair_cap) pairs[base + k] = ps.buf[k]; else st->error = NH_ERR_PAIR_CAPACITY;
 	}
+	__builtin_amdgcn_wave_barrier();
+	ps.count = 0;
+}
+
+__device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_t pair_cap, const uint64_t* mkey, uint32_t ca, uint32_t cb, bool hit, pair_stage& ps) {
+	unsigned long long bal = __ballot(hit);
+	if (!bal) return;
+	if (hit) {
+		uint64_t ka = mkey[ca], kb = mkey[cb];
+		bool a_first = (ka < kb) || (ka == kb && ca < cb);
+		// narrowphase "a" = later in Morton order (nudge.cpp:3495, 1202-1203)
+		ps.buf[ps.count + (uint32_t)__popcll(bal & ((1ull << nh_lane()) - 1ull))] = a_first ? make_uint2(cb, ca) : make_uint2(ca, cb);
+	}
+	ps.count += (uint32_t)__popcll(bal);
+	if (ps.count > FP_WBUF - 64) flush_pairs(st, pairs, pair_cap, ps);
 }
 
 // ---- 5. pair search: grid neighbours + large list ---------------------------------------------------------
@@ -228,6 +247,8 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 	const uint32_t nlarge = (pair_cap & 0x80000000u) ? 0u : st->large;
 	const bool dbg_skip_grid = (pair_cap & 0x40000000u) != 0;
 	pair_cap &= 0x3fffffffu;
+	__shared__ uint2 wave_buf[4][FP_WBUF];
+	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u };
 	uint32_t rounded = (n + 63u) & ~63u;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
 		bool valid = i < n;
@@ -273,28 +294,32 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 				cb = __float_as_uint(bmax.w);
 				hit = aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != abody);
 			}
-			emit_pair(st, pairs, pair_cap, mkey, ca, cb, hit);
+			emit_pair(st, pairs, pair_cap, mkey, ca, cb, hit, ps);
 		}
 		// large colliders: small x every large; large x larger-indexed large
 		for (uint32_t l = 0; l < nlarge; ++l) {
 			uint32_t cb = large_list[l];
 			float4 bmin = aabb_min[cb], bmax = aabb_max[cb];
 			bool hit = valid && (small || cb > ca) && aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != abody);
-			emit_pair(st, pairs, pair_cap, mkey, ca, cb, hit);
+			emit_pair(st, pairs, pair_cap, mkey, ca, cb, hit, ps);
 		}
 	}
+	flush_pairs(st, pairs, pair_cap, ps);
 }
 
 // ---- 6. narrowphase -----------------------------------------------------------------------------------------
 // raw contacts are appended in arbitrary order; one record per pair that produced contacts.
-struct nh_Record { uint32_t body_a, body_b, start, count; };
+// record i belongs to pair i: its first 4 contacts sit at raw[4*i .. 4*i+3], further ones in the overflow area
+struct nh_Record { uint32_t body_a, body_b, overflow, count; };
+#define NH_REC_SLEEPING 0x80000000u
 
 __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ st, const uint2* __restrict__ pairs,
                                                      const nh_xform* __restrict__ xf, const uint32_t* __restrict__ ctag,
                                                      const nh_BoxCollider* __restrict__ box_data, const nh_SphereCollider* __restrict__ sph_data, uint32_t nbox,
-                                                     nh_Contact* __restrict__ raw_data, uint32_t* __restrict__ raw_feature, uint32_t raw_cap,
-                                                     uint64_t* __restrict__ rec_key, nh_Record* __restrict__ rec) {
-	uint32_t n = min(st->pairs, raw_cap);
+                                                     nh_Contact* __restrict__ raw_data, uint32_t* __restrict__ raw_feature, uint32_t pair_cap, uint32_t overflow_cap,
+                                                     uint64_t* __restrict__ rec_key, nh_Record* __restrict__ rec, uint32_t* __restrict__ rec_idx) {
+	uint32_t n = min(st->pairs, pair_cap);
+	if (blockIdx.x == 0 && threadIdx.x == 0) st->records = n;
 	uint32_t rounded = (n + 63u) & ~63u;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
 		nh_contact_out out[16];
@@ -332,24 +357,24 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 				body_a = A.body; body_b = B.body;
 			}
 		}
-		uint32_t base = nh_wave_reserve(&st->raw_contacts, (uint32_t)count);
-		uint32_t slot = nh_wave_reserve1(&st->records, count != 0);
-		if (count) {
-			if (base + count <= raw_cap) {
-				for (int k = 0; k < count; ++k) {
-					nh_Contact c;
-					c.position[0] = out[k].px; c.position[1] = out[k].py; c.position[2] = out[k].pz; c.penetration = out[k].penetration;
-					c.normal[0] = out[k].nx; c.normal[1] = out[k].ny; c.normal[2] = out[k].nz; c.friction = out[k].friction;
-					raw_data[base + k] = c;
-					raw_feature[base + k] = out[k].feature;
-				}
-			} else {
-				st->error = NH_ERR_CONTACT_CAPACITY;
-				count = 0;
+		// more than 4 contacts per pair is the exception (askew face contacts): only those touch the global counter
+		uint32_t extra = count > 4 ? (uint32_t)(count - 4) : 0u;
+		uint32_t ovf = 0;
+		if (__ballot(extra != 0)) ovf = nh_wave_reserve(&st->raw_contacts, extra);
+		if (i < n) {
+			if (extra && ovf + extra > overflow_cap) { st->error = NH_ERR_CONTACT_CAPACITY; count = 4; }
+			for (int k = 0; k < count; ++k) {
+				nh_Contact c;
+				c.position[0] = out[k].px; c.position[1] = out[k].py; c.position[2] = out[k].pz; c.penetration = out[k].penetration;
+				c.normal[0] = out[k].nx; c.normal[1] = out[k].ny; c.normal[2] = out[k].nz; c.friction = out[k].friction;
+				size_t dst = k < 4 ? (size_t)4 * i + k : (size_t)4 * pair_cap + ovf + (k - 4);
+				raw_data[dst] = c;
+				raw_feature[dst] = out[k].feature;
 			}
-			rec_key[slot] = key;
-			nh_Record r = { body_a, body_b, base, (uint32_t)count };
-			rec[slot] = r;
+			rec_key[i] = key;
+			nh_Record r = { body_a, body_b, ovf, (uint32_t)count };
+			rec[i] = r;
+			rec_idx[i] = i;
 		}
 	}
 }
@@ -383,7 +408,7 @@ __global__ __launch_bounds__(256) void k_uf_union_records(const nh_DevState* __r
 	uint32_t n = st->records;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		nh_Record r = rec[i];
-		if (r.body_a && r.body_b) uf_union(parent, r.body_a, r.body_b);      // body 0 is the static world (nudge.cpp:3874-3876)
+		if (r.count && r.body_a && r.body_b) uf_union(parent, r.body_a, r.body_b);      // body 0 is the static world (nudge.cpp:3874-3876)
 	}
 }
 
@@ -429,13 +454,13 @@ __global__ __launch_bounds__(256) void k_filter_records(nh_DevState* __restrict_
 		uint64_t key = 0;
 		if (i < n) {
 			nh_Record r = rec[i];
-			key = rec_key[i];
-			uint32_t set = root_of[r.body_a ? r.body_a : r.body_b];      // sets[a] | sets[b] with sets[0] = 0 (nudge.cpp:3988)
-			sleeping = !set_active[set];
-			rec_idx[i] = i;
-			if (sleeping) { rec[i].count = 0; rec[i].start = 0xFFFFFFFFu; }   // key kept: sleeping pairs come out in tag order
+			if (r.count) {
+				uint32_t set = root_of[r.body_a ? r.body_a : r.body_b];      // sets[a] | sets[b] with sets[0] = 0 (nudge.cpp:3988)
+				sleeping = !set_active[set];
+				if (sleeping) rec[i].count = NH_REC_SLEEPING;                 // no contacts any more; key kept: sleeping pairs come out in tag order
+			}
 		}
-		(void)key; (void)sleeping_pairs; (void)sleeping_cap;
+		(void)key; (void)sleeping_pairs; (void)sleeping_cap; (void)rec_key; (void)rec_idx;
 	}
 }
 
@@ -445,8 +470,8 @@ __global__ __launch_bounds__(256) void k_sorted_counts(const nh_DevState* __rest
 	uint32_t n = st->records;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		nh_Record r = rec[rec_idx[i]];
-		counts[i] = r.count;
-		sleep_flags[i] = (r.start == 0xFFFFFFFFu) ? 1u : 0u;
+		counts[i] = r.count & ~NH_REC_SLEEPING;
+		sleep_flags[i] = (r.count & NH_REC_SLEEPING) ? 1u : 0u;
 	}
 	if (blockIdx.x == 0 && threadIdx.x == 0) sleep_flags[n] = 0;
 }
@@ -463,26 +488,29 @@ __global__ __launch_bounds__(256) void k_write_sleeping(nh_DevState* __restrict_
 
 __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict__ st, const uint32_t* __restrict__ rec_idx, const nh_Record* __restrict__ rec, const uint64_t* __restrict__ rec_key_sorted,
                                                          const uint32_t* __restrict__ starts, const nh_Contact* __restrict__ raw_data, const uint32_t* __restrict__ raw_feature,
-                                                         nh_Contact* __restrict__ data, nh_BodyPair* __restrict__ bodies, uint64_t* __restrict__ tags, uint32_t* __restrict__ features, uint32_t capacity) {
+                                                         nh_Contact* __restrict__ data, nh_BodyPair* __restrict__ bodies, uint64_t* __restrict__ tags, uint32_t* __restrict__ features, uint32_t capacity, uint32_t pair_cap) {
 	uint32_t n = st->records;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		nh_Record r = rec[rec_idx[i]];
-		if (!r.count) continue;
+		uint32_t ri = rec_idx[i];
+		nh_Record r = rec[ri];
+		if (!r.count || (r.count & NH_REC_SLEEPING)) continue;
 		uint32_t dst = starts[i];
 		if (dst + r.count > capacity) { st->error = NH_ERR_CONTACT_CAPACITY; continue; }
 		uint64_t key = rec_key_sorted[i];
 		// stable insertion sort of <= 16 contacts by feature word (reference: low 32 tag bits, nudge.cpp:4031-4036)
 		uint32_t order[16], feat[16];
 		uint32_t cnt = r.count > 16 ? 16 : r.count;
+		const size_t base4 = (size_t)4 * ri, baseo = (size_t)4 * pair_cap + r.overflow;
 		for (uint32_t k = 0; k < cnt; ++k) {
-			uint32_t f = raw_feature[r.start + k];
+			uint32_t f = raw_feature[k < 4 ? base4 + k : baseo + (k - 4)];
 			uint32_t j = k;
 			while (j > 0 && feat[j - 1] > f) { feat[j] = feat[j - 1]; order[j] = order[j - 1]; --j; }
 			feat[j] = f; order[j] = k;
 		}
 		nh_BodyPair bp = { r.body_a, r.body_b };
 		for (uint32_t k = 0; k < cnt; ++k) {
-			data[dst + k] = raw_data[r.start + order[k]];
+			uint32_t o = order[k];
+			data[dst + k] = raw_data[o < 4 ? base4 + o : baseo + (o - 4)];
 			bodies[dst + k] = bp;
 			tags[dst + k] = key;
 			features[dst + k] = feat[k];
@@ -540,10 +568,11 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	if (want > NH_MAX_CELLS) want = NH_MAX_CELLS;
 	const uint32_t max_cells = (uint32_t)want;
 	uint2* cells = nh_arena_array<uint2>(A, max_cells, &err);
-	const uint32_t pair_cap = cap;
+	const uint32_t pair_cap = cap / 2 + 1024;           // broadphase pairs; each owns 4 raw contact slots, the rest overflows
+	const uint32_t overflow_cap = cap;
 	uint2* pairs = nh_arena_array<uint2>(A, pair_cap, &err);
-	nh_Contact* raw_data = nh_arena_array<nh_Contact>(A, cap, &err);
-	uint32_t* raw_feature = nh_arena_array<uint32_t>(A, cap, &err);
+	nh_Contact* raw_data = nh_arena_array<nh_Contact>(A, (size_t)4 * pair_cap + overflow_cap, &err);
+	uint32_t* raw_feature = nh_arena_array<uint32_t>(A, (size_t)4 * pair_cap + overflow_cap, &err);
 	uint64_t* rec_key_a = nh_arena_array<uint64_t>(A, pair_cap, &err);
 	uint64_t* rec_key_b = nh_arena_array<uint64_t>(A, pair_cap, &err);
 	uint32_t* rec_idx_a = nh_arena_array<uint32_t>(A, pair_cap, &err);
@@ -575,7 +604,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "cell_bounds", k_cell_bounds, nh_grid_for(C, 256, 2048), 256, C, keys_a, vals_a, aabb_min, aabb_max, cells, smin, smax);
 		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 4096), 256, st, C, keys_a, smin, smax, cells, large_list, aabb_min, aabb_max, mkey, pairs, pair_cap | (getenv("NH_DBG_SKIP_LARGE") ? 0x80000000u : 0u) | (getenv("NH_DBG_SKIP_GRID") ? 0x40000000u : 0u));
 		NH_LAUNCH(ctx, "narrowphase", k_narrowphase, nh_grid_for(pair_cap, 256, 4096), 256, st, pairs, xf, ctag,
-		          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, cap, rec_key_a, rec);
+		          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a);
 	}
 	// islands over contact records (+ user connections)
 	NH_LAUNCH(ctx, "uf_init", k_uf_init, nh_grid_for(B, 256, 2048), 256, B, parent, set_active);
@@ -602,7 +631,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	NH_LAUNCH(ctx, "sorted_counts", k_sorted_counts, nh_grid_for(pair_cap, 256, 2048), 256, st, rec_idx_a, rec, rec_counts, sleep_flags);
 	nh_scan_u32(ctx, rec_counts, rec_counts, &st->records, 0, scan_tmp, &st->contacts);
 	NH_LAUNCH(ctx, "gather_contacts", k_gather_contacts, nh_grid_for(pair_cap, 256, 4096), 256, st, rec_idx_a, rec, rec_key_a, rec_counts, raw_data, raw_feature,
-	          contacts->data, contacts->bodies, contacts->tags, contacts->features, cap);
+	          contacts->data, contacts->bodies, contacts->tags, contacts->features, cap, pair_cap);
 	// sleeping pairs, ascending (nudge.cpp:4008)
 	nh_scan_u32(ctx, sleep_flags, sleep_flags, &st->records, 1, scan_tmp, &st->sleeping);
 	if (contacts->sleeping_pairs)

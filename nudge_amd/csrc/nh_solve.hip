@@ -19,6 +19,12 @@
 #include "nh_solver.h"
 
 #define NH_NONE 0xFFFFFFFFu
+// body classes: the one-body fast path by contact count (<= 4, <= 8, more) or the level-scheduled path
+#define NH_CLS_NONE 0u
+#define NH_CLS_STATIC4 1u
+#define NH_CLS_STATIC8 2u
+#define NH_CLS_STATICN 3u
+#define NH_CLS_GENERAL 4u
 #define NH_UNSET 0xFFFFFFFFu
 
 __device__ __forceinline__ bool tag_less(uint64_t ta, uint32_t fa, uint64_t tb, uint32_t fb) { return ta < tb || (ta == tb && fa < fb); }
@@ -57,6 +63,8 @@ __global__ __launch_bounds__(256) void k_cache_lookup(const nh_DevState* __restr
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		uint64_t t = tags[i]; uint32_t f = features[i];
 		uint32_t lo = 0, hi = m;
+		// steady state: the cache is last step's contact list, so the entry usually sits at the same index
+		if (i < m && ctags[i] == t && cfeatures[i] == f) { lo = i; hi = i; }
 		while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (tag_less(ctags[mid], cfeatures[mid], t, f)) lo = mid + 1; else hi = mid; }
 		nh_CachedContactImpulse r = { { 0.0f, 0.0f, 0.0f }, 0.0f };
 		if (lo < m && ctags[lo] == t && cfeatures[lo] == f) r = cdata[lo];
@@ -120,24 +128,36 @@ __global__ __launch_bounds__(256) void k_zero_u32(uint32_t* __restrict__ p, uint
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_degree(const nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, uint32_t* __restrict__ deg,
-                                                uint32_t* __restrict__ pred_a, uint32_t* __restrict__ pred_b) {
+// Contacts of one collider pair are contiguous in tag order: the first lane of each run does the pair's bookkeeping
+// (one atomic per pair and body instead of one per contact).
+__device__ __forceinline__ uint32_t run_length(const uint64_t* __restrict__ tags, uint32_t i, uint32_t n) {
+	if (i > 0 && tags[i - 1] == tags[i]) return 0;           // not the head of its run
+	uint64_t t = tags[i];
+	uint32_t len = 1;
+	while (i + len < n && tags[i + len] == t) ++len;
+	return len;
+}
+
+__global__ __launch_bounds__(256) void k_degree(const nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, const uint64_t* __restrict__ tags, uint32_t* __restrict__ deg) {
 	uint32_t n = st->contacts;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		uint32_t len = run_length(tags, i, n);
+		if (!len) continue;
 		nh_BodyPair p = bodies[i];
-		if (p.a) atomicAdd(&deg[p.a], 1u);
-		if (p.b) atomicAdd(&deg[p.b], 1u);
-		pred_a[i] = NH_NONE; pred_b[i] = NH_NONE;
+		if (p.a) atomicAdd(&deg[p.a], len);
+		if (p.b) atomicAdd(&deg[p.b], len);
 	}
 }
 
-__global__ __launch_bounds__(256) void k_adj_fill(const nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, const uint32_t* __restrict__ off,
+__global__ __launch_bounds__(256) void k_adj_fill(const nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, const uint64_t* __restrict__ tags, const uint32_t* __restrict__ off,
                                                   uint32_t* __restrict__ cursor, uint32_t* __restrict__ adj) {
 	uint32_t n = st->contacts;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		uint32_t len = run_length(tags, i, n);
+		if (!len) continue;
 		nh_BodyPair p = bodies[i];
-		if (p.a) adj[off[p.a] + atomicAdd(&cursor[p.a], 1u)] = i;
-		if (p.b) adj[off[p.b] + atomicAdd(&cursor[p.b], 1u)] = i;
+		if (p.a) { uint32_t base = off[p.a] + atomicAdd(&cursor[p.a], len); for (uint32_t k = 0; k < len; ++k) adj[base + k] = i + k; }
+		if (p.b) { uint32_t base = off[p.b] + atomicAdd(&cursor[p.b], len); for (uint32_t k = 0; k < len; ++k) adj[base + k] = i + k; }
 	}
 }
 
@@ -147,71 +167,97 @@ __device__ __forceinline__ uint32_t slot_key_of(uint32_t i, const uint32_t* __re
 	return slot_key ? slot_key[i] : ((i >> 7) * 16u + (i & 15u));
 }
 
-// one lane per body: sort its contact list by slot key, classify, record per-contact predecessors
+// one lane per body: sort its contact list by slot key, classify; bodies off the fast path also record per-contact predecessors
 __global__ __launch_bounds__(256) void k_adj_sort(nh_DevState* __restrict__ st, uint32_t nbodies, const nh_BodyPair* __restrict__ bodies, const uint32_t* __restrict__ off,
                                                   uint32_t* __restrict__ adj, const uint32_t* __restrict__ slot_key, uint8_t* __restrict__ body_class,
                                                   uint32_t* __restrict__ pred_a, uint32_t* __restrict__ pred_b, uint32_t* __restrict__ static_list) {
 	uint32_t rounded = (nbodies + 63u) & ~63u;
 	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < rounded; x += gridDim.x * blockDim.x) {
-		uint32_t cls = 0;
+		uint32_t cls = 0, d = 0;
 		if (x >= 1 && x < nbodies) {
 			uint32_t b = off[x], e = off[x + 1];
-			if (e > b) {
-				// insertion sort by (slot key, contact index)
-				for (uint32_t k = b + 1; k < e; ++k) {
-					uint32_t c = adj[k];
-					uint32_t kc = slot_key_of(c, slot_key);
-					uint32_t j = k;
-					while (j > b) {
-						uint32_t d = adj[j - 1];
-						uint32_t kd = slot_key_of(d, slot_key);
-						if (kd < kc || (kd == kc && d < c)) break;
-						adj[j] = d; --j;
-					}
-					adj[j] = c;
-				}
+			d = e - b;
+			if (d) {
 				bool static_only = true;
-				uint32_t prev = NH_NONE;
-				for (uint32_t k = b; k < e; ++k) {
-					uint32_t c = adj[k];
-					nh_BodyPair p = bodies[c];
-					if (p.a == x) { pred_a[c] = prev; if (p.b) static_only = false; }
-					else          { pred_b[c] = prev; if (p.a) static_only = false; }
-					prev = c;
+				if (d <= 8) {
+					// short list: sort in registers (fully unrolled insertion sort), write back only what moved
+					uint32_t c[8], k[8];
+#pragma unroll
+					for (int q = 0; q < 8; ++q) {
+						c[q] = (uint32_t)q < d ? adj[b + q] : 0xFFFFFFFFu;
+						k[q] = (uint32_t)q < d ? slot_key_of(c[q], slot_key) : 0xFFFFFFFFu;
+					}
+#pragma unroll
+					for (int q = 1; q < 8; ++q) {
+#pragma unroll
+						for (int j = q; j > 0; --j) {
+							bool sw = (k[j] < k[j - 1]) || (k[j] == k[j - 1] && c[j] < c[j - 1]);
+							uint32_t tc = sw ? c[j - 1] : c[j], tk = sw ? k[j - 1] : k[j];
+							c[j - 1] = sw ? c[j] : c[j - 1]; k[j - 1] = sw ? k[j] : k[j - 1];
+							c[j] = tc; k[j] = tk;
+						}
+					}
+#pragma unroll
+					for (int q = 0; q < 8; ++q) {
+						if ((uint32_t)q < d) {
+							adj[b + q] = c[q];
+							nh_BodyPair p = bodies[c[q]];
+							if ((p.a == x ? p.b : p.a) != 0) static_only = false;
+						}
+					}
+				} else {
+					for (uint32_t q = b + 1; q < e; ++q) {
+						uint32_t c = adj[q];
+						uint32_t kc = slot_key_of(c, slot_key);
+						uint32_t j = q;
+						while (j > b) {
+							uint32_t dd = adj[j - 1];
+							uint32_t kd = slot_key_of(dd, slot_key);
+							if (kd < kc || (kd == kc && dd < c)) break;
+							adj[j] = dd; --j;
+						}
+						adj[j] = c;
+					}
+					for (uint32_t q = b; q < e; ++q) {
+						nh_BodyPair p = bodies[adj[q]];
+						if ((p.a == x ? p.b : p.a) != 0) static_only = false;
+					}
 				}
-				cls = static_only ? 1u : 2u;
+				if (!static_only) {
+					uint32_t prev = NH_NONE;
+					for (uint32_t q = b; q < e; ++q) {
+						uint32_t c = adj[q];
+						if (bodies[c].a == x) pred_a[c] = prev; else pred_b[c] = prev;
+						prev = c;
+					}
+				}
+				cls = static_only ? (d <= 4u ? NH_CLS_STATIC4 : (d <= 8u ? NH_CLS_STATIC8 : NH_CLS_STATICN)) : NH_CLS_GENERAL;
 			}
 			body_class[x] = (uint8_t)cls;
 		} else if (x == 0 && nbodies) {
 			body_class[0] = 0;
 		}
-		uint32_t d = (cls == 1u) ? (off[x + 1] - off[x]) : 0u;
-		bool c4 = cls == 1u && d <= 4u, c8 = cls == 1u && d > 4u && d <= 8u, cn = cls == 1u && d > 8u;
-		uint32_t s4 = nh_wave_reserve1(&st->static4, c4);
-		uint32_t s8 = nh_wave_reserve1(&st->static8, c8);
-		uint32_t sn = nh_wave_reserve1(&st->staticN, cn);
-		if (c4) static_list[s4] = x;
-		if (c8) static_list[nbodies + s8] = x;
-		if (cn) static_list[2u * nbodies + sn] = x;
+		(void)static_list;
 	}
 }
 
 // general contacts: flag, count, level = UNSET
 __global__ __launch_bounds__(256) void k_contact_class(nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, const uint8_t* __restrict__ body_class,
-                                                       uint32_t* __restrict__ level, uint32_t* __restrict__ general_list) {
+                                                       uint32_t* __restrict__ level, uint32_t* __restrict__ general_list, uint32_t* __restrict__ pred_a, uint32_t* __restrict__ pred_b) {
 	uint32_t n = st->contacts;
 	uint32_t rounded = (n + 63u) & ~63u;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
 		bool general = false;
 		if (i < n) {
 			nh_BodyPair p = bodies[i];
-			general = (p.a && body_class[p.a] == 2) || (p.b && body_class[p.b] == 2);
+			general = (p.a && body_class[p.a] == NH_CLS_GENERAL) || (p.b && body_class[p.b] == NH_CLS_GENERAL);
 			level[i] = general ? NH_UNSET : 0u;
+			if (general) { if (!p.a) pred_a[i] = NH_NONE; if (!p.b) pred_b[i] = NH_NONE; }
 		}
 		uint32_t slot = nh_wave_reserve1(&st->general_contacts, general);
 		if (general) general_list[slot] = i;
 	}
-	if (blockIdx.x == 0 && threadIdx.x == 0) st->static_bodies = st->static4 + st->static8 + st->staticN;
+
 }
 
 // ---- exact replay of the reference's greedy batch scheduler (nudge.cpp:4206-4339), one wave -------------------
@@ -337,17 +383,17 @@ __device__ __forceinline__ void load_row(const float* __restrict__ rows, uint32_
 
 // ---- one-body fast path: setup (rows + warm start) ----------------------------------------------------------------------
 template<bool STORE>
-__global__ __launch_bounds__(256) void k_setup_static(const uint32_t* __restrict__ d_count, const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
+__global__ __launch_bounds__(256) void k_setup_static(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
                                                       const nh_Contact* __restrict__ contacts, const nh_BodyPair* __restrict__ bodies, nh_CachedContactImpulse* __restrict__ cached,
                                                       const nh_Transform* __restrict__ xf, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                       float* __restrict__ rows, float4* __restrict__ states) {
-	uint32_t n = *d_count;
 	const nh_inertia I0 = body_inertia(xf, props, 0);
 	const nh_Transform t0 = xf[0];
 	const nh_f3 pos0 = nh_make3(t0.position[0], t0.position[1], t0.position[2]);
 	const nh_vel vel0 = load_vel(momentum, props, 0);
-	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-		uint32_t x = static_list[k];
+	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < nbodies; x += gridDim.x * blockDim.x) {
+		uint32_t cls = body_class[x];
+		if (STORE ? (cls != NH_CLS_STATICN) : (cls != NH_CLS_STATIC4 && cls != NH_CLS_STATIC8)) continue;
 		nh_inertia IX = body_inertia(xf, props, x);
 		nh_Transform tx = xf[x];
 		nh_f3 posx = nh_make3(tx.position[0], tx.position[1], tx.position[2]);
@@ -385,17 +431,16 @@ __global__ __launch_bounds__(256) void k_setup_static(const uint32_t* __restrict
 // MAXC > 0: the body's <= MAXC constraint rows stay in registers across all iterations (160 B each): every row is
 // read from HBM once per call, not once per iteration.  MAXC == 0: any contact count, rows re-read per iteration.
 template<int MAXC>
-__global__ __launch_bounds__(256) void k_apply_static(const uint32_t* __restrict__ d_count, const uint32_t* __restrict__ static_list, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
+__global__ __launch_bounds__(256) void k_apply_static(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
                                                       const nh_BodyPair* __restrict__ bodies, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                       const float* __restrict__ rows, float4* __restrict__ states, uint32_t iterations,
                                                       const nh_Contact* __restrict__ contacts, const nh_Transform* __restrict__ xf, nh_CachedContactImpulse* __restrict__ impulses) {
-	uint32_t n = *d_count;
 	const nh_vel vel0 = load_vel(momentum, props, 0);
 	const nh_inertia I0 = body_inertia(xf, props, 0);
 	const nh_Transform t0 = xf[0];
 	const nh_f3 pos0 = nh_make3(t0.position[0], t0.position[1], t0.position[2]);
-	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-		uint32_t x = static_list[k];
+	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < nbodies; x += gridDim.x * blockDim.x) {
+		if (body_class[x] != (MAXC == 4 ? NH_CLS_STATIC4 : (MAXC == 8 ? NH_CLS_STATIC8 : NH_CLS_STATICN))) continue;
 		nh_vel v = load_vel(momentum, props, x);
 		nh_vel z = vel0;
 		uint32_t b = off[x], e = off[x + 1];
@@ -656,12 +701,12 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	nh_ContactConstraintData* d = new_constraint_data(ctx);
 	d->rows = nh_arena_array<float>(memory, (size_t)kcap * 40, &err);
 	d->states = nh_arena_array<float>(memory, (size_t)kcap * 4, &err);
-	d->body_off = nh_arena_array<uint32_t>(memory, B + 2, &err);
+	d->body_off = nh_arena_array<uint32_t>(memory, 2 * (size_t)(B + 2), &err);    // [B+2] offsets, then [B+2] fill cursors
 	d->adj = nh_arena_array<uint32_t>(memory, (size_t)kcap * 2, &err);
 	d->static_bodies = nh_arena_array<uint32_t>(memory, (size_t)3 * B, &err);
 	d->body_class = nh_arena_array<uint8_t>(memory, B, &err);
 	d->level_order = nh_arena_array<uint32_t>(memory, kcap, &err);
-	uint32_t* cursor = nh_arena_array<uint32_t>(memory, B + 2, &err);
+	uint32_t* cursor = d->body_off + (B + 2);
 	uint32_t* pred_a = nh_arena_array<uint32_t>(memory, kcap, &err);
 	uint32_t* pred_b = nh_arena_array<uint32_t>(memory, kcap, &err);
 	uint32_t* level = nh_arena_array<uint32_t>(memory, kcap, &err);
@@ -675,25 +720,17 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	d->contact_data = contacts->data; d->impulses = imp->data; d->general_list = general_list;
 	d->levels = 0; d->general_contacts = 0;
 
-	NH_LAUNCH(ctx, "zero_u32", k_zero_u32, nh_grid_for(B + 2, 256, 2048), 256, d->body_off, B + 2);
-	NH_LAUNCH(ctx, "zero_u32", k_zero_u32, nh_grid_for(B + 2, 256, 2048), 256, cursor, B + 2);
-	NH_LAUNCH(ctx, "contact_degree", k_degree, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, d->body_off, pred_a, pred_b);
+	NH_LAUNCH(ctx, "zero_u32", k_zero_u32, nh_grid_for(2 * (B + 2), 256, 2048), 256, d->body_off, 2 * (B + 2));     // body_off and cursor are adjacent
+	NH_LAUNCH(ctx, "contact_degree", k_degree, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, contacts->tags, d->body_off);
 	nh_scan_u32(ctx, d->body_off, d->body_off, &st->pad0, B + 1, tmp, nullptr);
-	NH_LAUNCH(ctx, "adjacency_fill", k_adj_fill, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, d->body_off, cursor, d->adj);
+	NH_LAUNCH(ctx, "adjacency_fill", k_adj_fill, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, contacts->tags, d->body_off, cursor, d->adj);
 	if (slot_key) NH_LAUNCH(ctx, "greedy_replay", k_greedy_replay, 1, 64, st, contacts->bodies, slot_key);
 	NH_LAUNCH(ctx, "adjacency_sort", k_adj_sort, nh_grid_for(B, 256, 4096), 256, st, B, contacts->bodies, d->body_off, d->adj, slot_key, d->body_class, pred_a, pred_b, d->static_bodies);
-	NH_LAUNCH(ctx, "contact_class", k_contact_class, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, d->body_class, level, general_list);
-	{
-		const uint32_t* cnts[3] = { &st->static4, &st->static8, &st->staticN };
-		for (int k = 0; k < 3; ++k) {
-			if (k < 2)
-				NH_LAUNCH(ctx, "setup_static", (k_setup_static<false>), nh_grid_for(B, 256, k == 0 ? 4096 : 512), 256, cnts[k], d->static_bodies + (size_t)k * B, d->body_off, d->adj,
-				          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states);
-			else
-				NH_LAUNCH(ctx, "setup_staticN", (k_setup_static<true>), nh_grid_for(B, 256, 512), 256, cnts[k], d->static_bodies + (size_t)k * B, d->body_off, d->adj,
-				          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states);
-		}
-	}
+	NH_LAUNCH(ctx, "contact_class", k_contact_class, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, d->body_class, level, general_list, pred_a, pred_b);
+	NH_LAUNCH(ctx, "setup_static", (k_setup_static<false>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj,
+	          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states);
+	NH_LAUNCH(ctx, "setup_staticN", (k_setup_static<true>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj,
+	          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states);
 
 	// the level-scheduled path needs per-level launch sizes on the host: one round trip
 	nh_Counts c;
@@ -740,13 +777,12 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 
 extern "C" int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations) {
 	if (!ctx || !d || !bodies) return NH_ERR_INVALID;
-	nh_DevState* st = ctx->d_state;
 	const uint32_t B = d->body_count;
-	NH_LAUNCH(ctx, "apply_static", (k_apply_static<4>), nh_grid_for(B, 256, 8192), 256, &st->static4, d->static_bodies, d->body_off, d->adj, d->bodies,
+	NH_LAUNCH(ctx, "apply_static", (k_apply_static<4>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies,
 	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses);
-	NH_LAUNCH(ctx, "apply_static8", (k_apply_static<8>), nh_grid_for(B, 256, 2048), 256, &st->static8, d->static_bodies + (size_t)B, d->body_off, d->adj, d->bodies,
+	NH_LAUNCH(ctx, "apply_static8", (k_apply_static<8>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies,
 	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses);
-	NH_LAUNCH(ctx, "apply_staticN", (k_apply_static<0>), nh_grid_for(B, 256, 512), 256, &st->staticN, d->static_bodies + (size_t)2 * B, d->body_off, d->adj, d->bodies,
+	NH_LAUNCH(ctx, "apply_staticN", (k_apply_static<0>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies,
 	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses);
 	if (d->general_contacts) {
 		for (uint32_t it = 0; it < iterations; ++it)
