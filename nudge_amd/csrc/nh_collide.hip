@@ -62,9 +62,20 @@ __global__ __launch_bounds__(256) void k_xform(nh_DevState* __restrict__ st,
 		f = nh_float_flip(mnx); lmin[0] = min(lmin[0], f); lmax[0] = max(lmax[0], f);
 		f = nh_float_flip(mny); lmin[1] = min(lmin[1], f); lmax[1] = max(lmax[1], f);
 		f = nh_float_flip(mnz); lmin[2] = min(lmin[2], f); lmax[2] = max(lmax[2], f);
-		atomicAdd(&hist[(__float_as_uint(ext) >> 23) & 255u], 1u);
+		// exponent histogram: one LDS atomic per distinct exponent in the wave (usually 2-3), not one per lane
+		uint32_t ebin = (__float_as_uint(ext) >> 23) & 255u;
+		unsigned long long todo = __ballot(1);
+		while (todo) {
+			uint32_t e0 = (uint32_t)__shfl((int)ebin, (int)(__ffsll((long long)todo) - 1));
+			unsigned long long same = __ballot(ebin == e0);
+			if (nh_lane() == (unsigned)(__ffsll((long long)same) - 1)) atomicAdd(&hist[e0], (uint32_t)__popcll(same));
+			todo &= ~same;
+		}
 	}
-	for (int k = 0; k < 3; ++k) { atomicMin(&red[k], lmin[k]); atomicMax(&red[3 + k], lmax[k]); }
+	for (int k = 0; k < 3; ++k) {
+		for (int d = 32; d >= 1; d >>= 1) { lmin[k] = min(lmin[k], (uint32_t)__shfl_xor((int)lmin[k], d)); lmax[k] = max(lmax[k], (uint32_t)__shfl_xor((int)lmax[k], d)); }
+		if ((threadIdx.x & 63) == 0) { atomicMin(&red[k], lmin[k]); atomicMax(&red[3 + k], lmax[k]); }
+	}
 	__syncthreads();
 	if (hist[threadIdx.x]) atomicAdd(&st->exp_hist[threadIdx.x], hist[threadIdx.x]);
 	if (threadIdx.x < 3) { atomicMin(&st->smin[threadIdx.x], red[threadIdx.x]); atomicMax(&st->smax[threadIdx.x], red[3 + threadIdx.x]); }
@@ -523,7 +534,7 @@ __global__ void k_collide_begin(nh_DevState* st, uint32_t ncolliders) {
 	if (t == 0) {
 		st->colliders = ncolliders; st->pairs = 0; st->raw_contacts = 0; st->records = 0; st->contacts = 0; st->sleeping = 0;
 		st->active = 0; st->culled = 0; st->large = 0; st->general_contacts = 0; st->levels = 0; st->error = 0;
-		st->static_bodies = 0; st->unleveled = 0; st->static4 = 0; st->static8 = 0; st->staticN = 0;
+		st->static_bodies = 0; st->unleveled = 0; st->has_static8 = 0; st->has_staticN = 0;
 		for (int k = 0; k < 3; ++k) { st->smin[k] = 0xffffffffu; st->smax[k] = 0u; st->gmin[k] = 0xffffffffu; st->gmax[k] = 0u; }
 	}
 	st->exp_hist[t] = 0;
@@ -589,7 +600,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	hipStream_t s = ctx->stream;
 	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, 1, 256, st, C);
 	if (C) {
-		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 256, 2048), 256, st, bodies->transforms,
+		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 256, 1024), 256, st, bodies->transforms,
 		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
 		          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
 		          xf, aabb_min, aabb_max, ctag);
@@ -597,7 +608,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "small_bounds", k_small_bounds, nh_grid_for(C, 256, 1024), 256, st, C, aabb_min, aabb_max);
 		NH_LAUNCH(ctx, "grid_dims", k_grid_dims, 1, 64, st, max_cells);
 		NH_LAUNCH(ctx, "cell_keys", k_cell_keys, nh_grid_for(C, 256, 2048), 256, st, C, aabb_min, aabb_max, keys_a, vals_a, mkey, large_list);
-		nh_sort_u32_u32(ctx, keys_a, keys_b, vals_a, vals_b, &st->colliders, hist, 0, 24);
+		if (nh_sort_u32_u32(ctx, keys_a, keys_b, vals_a, vals_b, &st->colliders, hist, 0, 24)) { uint32_t* t = keys_a; keys_a = keys_b; keys_b = t; t = vals_a; vals_a = vals_b; vals_b = t; }
 		if (ctx->timing) nh_timer_begin(ctx, "memset_cells");
 		NH_HIP_CHECK(ctx, hipMemsetAsync(cells, 0, sizeof(uint2) * (size_t)max_cells, s));
 		if (ctx->timing) nh_timer_end(ctx);
@@ -625,8 +636,12 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	if (key_bits < 1) key_bits = 1;
 	if (key_bits > 32) key_bits = 32;
 	// keys are a | b<<32: sort the low field, then the high field (stable) -- dropped records carry ~0 and end up last
-	nh_sort_u64_u32(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, &st->records, hist, 0, ((key_bits + 7) / 8) * 8);
-	nh_sort_u64_u32(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, &st->records, hist, 32, 32 + ((key_bits + 7) / 8) * 8);
+	if (nh_sort_u64_u32(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, &st->records, hist, 0, ((key_bits + 7) / 8) * 8)) {
+		uint64_t* t = rec_key_a; rec_key_a = rec_key_b; rec_key_b = t; uint32_t* u = rec_idx_a; rec_idx_a = rec_idx_b; rec_idx_b = u;
+	}
+	if (nh_sort_u64_u32(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, &st->records, hist, 32, 32 + ((key_bits + 7) / 8) * 8)) {
+		uint64_t* t = rec_key_a; rec_key_a = rec_key_b; rec_key_b = t; uint32_t* u = rec_idx_a; rec_idx_a = rec_idx_b; rec_idx_b = u;
+	}
 	// (dropped records carry count 0, so where they land in the order is irrelevant)
 	NH_LAUNCH(ctx, "sorted_counts", k_sorted_counts, nh_grid_for(pair_cap, 256, 2048), 256, st, rec_idx_a, rec, rec_counts, sleep_flags);
 	nh_scan_u32(ctx, rec_counts, rec_counts, &st->records, 0, scan_tmp, &st->contacts);

@@ -38,8 +38,8 @@ struct nh_DevState {
 	uint32_t static_bodies;       // bodies solved by the one-body fast path (sum of the three classes below)
 	uint32_t unleveled;           // general contacts still without a level (relaxation progress)
 	uint32_t pad0;                // always 0 (used as a constant device-side count)
-	uint32_t static4, static8, staticN;   // one-body fast path, by contact count: <= 4, <= 8, more
-	uint32_t pad1;
+	uint32_t has_static8, has_staticN;    // any body in the rarer fast-path classes (plain stores, no counting)
+	uint32_t pad1, pad2;
 	// scene bounds of AABB min corners, order-preserving uint encoding (atomicMin/Max)
 	uint32_t smin[3];
 	uint32_t smax[3];
@@ -105,6 +105,7 @@ struct nh_ContactConstraintData {
 	uint32_t contact_capacity;
 	uint32_t body_count;
 	uint32_t static_body_count;
+	bool has_static8, has_staticN;
 	const nh_BodyPair* bodies;
 	// inputs kept for the one-body fast path, which rebuilds its rows in registers instead of storing them
 	const nh_Contact* contact_data;
@@ -155,12 +156,12 @@ static inline uint32_t nh_grid_for(uint64_t n, uint32_t block = NH_BLOCK, uint32
 }
 
 // ---- utilities implemented in nh_util.hip (all sizes come from DEVICE counters) ------------------------
-// Stable LSD radix sorts, 8-bit digits, bits [begin_bit, end_bit).  Result ends up in the *_a buffers.
-void nh_sort_u32_u32(nh_context* ctx, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+// Stable LSD radix sorts, 8-bit digits, bits [begin_bit, end_bit).  Returns 0 if the result is in the *_a buffers, 1 if in *_b.
+int nh_sort_u32_u32(nh_context* ctx, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                      const uint32_t* d_count, uint32_t* hist /* 256*NH_SORT_GRID+512 */, int begin_bit, int end_bit);
-void nh_sort_u64_u32(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+int nh_sort_u64_u32(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                      const uint32_t* d_count, uint32_t* hist, int begin_bit, int end_bit);
-void nh_sort_u64(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b,
+int nh_sort_u64(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b,
                  const uint32_t* d_count, uint32_t* hist, int begin_bit, int end_bit);
 // Exclusive scan of `in[0..n)` into `out` (may alias); n read from *d_count (+ `extra` elements);
 // the grand total is also stored to *d_total if non-null.  `tmp` needs NH_SORT_GRID+8 words.

@@ -76,6 +76,10 @@ __global__ __launch_bounds__(256) void k_cache_lookup(const nh_DevState* __restr
 __global__ __launch_bounds__(256) void k_cull_flags(const nh_DevState* __restrict__ st, const uint64_t* __restrict__ ctags, const uint64_t* __restrict__ sleeping, uint32_t* __restrict__ flags) {
 	uint32_t m = st->cache, ns = st->sleeping;
 	if (blockIdx.x == 0 && threadIdx.x == 0) flags[m] = 0;       // sentinel so that scan[m] = number of culled entries
+	if (ns == 0) {                                               // nothing sleeps: no cached impulse is kept aside
+		for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) flags[j] = 0;
+		return;
+	}
 	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
 		uint64_t t = ctags[j];
 		uint32_t lo = 0, hi = ns;
@@ -234,6 +238,8 @@ __global__ __launch_bounds__(256) void k_adj_sort(nh_DevState* __restrict__ st, 
 				cls = static_only ? (d <= 4u ? NH_CLS_STATIC4 : (d <= 8u ? NH_CLS_STATIC8 : NH_CLS_STATICN)) : NH_CLS_GENERAL;
 			}
 			body_class[x] = (uint8_t)cls;
+			if (cls == NH_CLS_STATIC8) st->has_static8 = 1;
+			if (cls == NH_CLS_STATICN) st->has_staticN = 1;
 		} else if (x == 0 && nbodies) {
 			body_class[0] = 0;
 		}
@@ -386,7 +392,8 @@ template<bool STORE>
 __global__ __launch_bounds__(256) void k_setup_static(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
                                                       const nh_Contact* __restrict__ contacts, const nh_BodyPair* __restrict__ bodies, nh_CachedContactImpulse* __restrict__ cached,
                                                       const nh_Transform* __restrict__ xf, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
-                                                      float* __restrict__ rows, float4* __restrict__ states) {
+                                                      float* __restrict__ rows, float4* __restrict__ states, const uint32_t* __restrict__ d_any) {
+	if (d_any && !*d_any) return;
 	const nh_inertia I0 = body_inertia(xf, props, 0);
 	const nh_Transform t0 = xf[0];
 	const nh_f3 pos0 = nh_make3(t0.position[0], t0.position[1], t0.position[2]);
@@ -728,9 +735,10 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	NH_LAUNCH(ctx, "adjacency_sort", k_adj_sort, nh_grid_for(B, 256, 4096), 256, st, B, contacts->bodies, d->body_off, d->adj, slot_key, d->body_class, pred_a, pred_b, d->static_bodies);
 	NH_LAUNCH(ctx, "contact_class", k_contact_class, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, d->body_class, level, general_list, pred_a, pred_b);
 	NH_LAUNCH(ctx, "setup_static", (k_setup_static<false>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj,
-	          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states);
+	          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states, (const uint32_t*)nullptr);
+	// (bodies with more than 8 static contacts are rare; the kernel only finds work if k_adj_sort flagged some)
 	NH_LAUNCH(ctx, "setup_staticN", (k_setup_static<true>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj,
-	          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states);
+	          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states, &st->has_staticN);
 
 	// the level-scheduled path needs per-level launch sizes on the host: one round trip
 	nh_Counts c;
@@ -739,6 +747,8 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	if (c.error) return (int)c.error;
 	d->general_contacts = c.general_contacts;
 	d->static_body_count = c.static_bodies;
+	d->has_static8 = ctx->h_state->has_static8 != 0;
+	d->has_staticN = ctx->h_state->has_staticN != 0;
 	if (c.general_contacts) {
 		const uint32_t G = c.general_contacts;
 		NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, general_list, contacts->data, contacts->bodies, bodies->transforms, bodies->properties, d->rows);
@@ -780,8 +790,10 @@ extern "C" int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* d, c
 	const uint32_t B = d->body_count;
 	NH_LAUNCH(ctx, "apply_static", (k_apply_static<4>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies,
 	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses);
+	if (d->has_static8)
 	NH_LAUNCH(ctx, "apply_static8", (k_apply_static<8>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies,
 	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses);
+	if (d->has_staticN)
 	NH_LAUNCH(ctx, "apply_staticN", (k_apply_static<0>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies,
 	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses);
 	if (d->general_contacts) {

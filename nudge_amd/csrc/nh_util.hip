@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void rs_scatter(const K* __restrict__ keys, K*
 }
 
 template<typename K, typename V, bool HAS_V>
-static void sort_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* vals_b, const uint32_t* d_count, uint32_t* hist, int begin_bit, int end_bit) {
+static int sort_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* vals_b, const uint32_t* d_count, uint32_t* hist, int begin_bit, int end_bit) {
 	K* kin = keys_a; K* kout = keys_b;
 	V* vin = vals_a; V* vout = vals_b;
 	int passes = 0;
@@ -122,12 +122,7 @@ static void sort_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* vals_
 		V* tv = vin; vin = vout; vout = tv;
 		++passes;
 	}
-	if (passes & 1) {
-		// result sits in the *_b buffers: one more (stable, all-zero digit) pass would be wasteful; copy back instead
-		// (counts are device-side, so copy the whole chunked range through a kernel)
-		nh_copy_back_u32(ctx, (const uint32_t*)keys_b, (uint32_t*)keys_a, d_count, sizeof(K) / 4);
-		if (HAS_V) nh_copy_back_u32(ctx, (const uint32_t*)vals_b, (uint32_t*)vals_a, d_count, sizeof(V) / 4);
-	}
+	return passes & 1;      // 1: the sorted data sits in the *_b buffers
 }
 
 __global__ __launch_bounds__(256) void k_copy_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const uint32_t* __restrict__ d_n, uint32_t words_per_item) {
@@ -139,18 +134,18 @@ void nh_copy_back_u32(nh_context* ctx, const uint32_t* src, uint32_t* dst, const
 	NH_LAUNCH(ctx, "copy_words", k_copy_words, 1024, 256, src, dst, d_count, words_per_item);
 }
 
-void nh_sort_u32_u32(nh_context* ctx, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+int nh_sort_u32_u32(nh_context* ctx, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                      const uint32_t* d_count, uint32_t* hist, int begin_bit, int end_bit) {
-	sort_impl<uint32_t, uint32_t, true>(ctx, keys_a, keys_b, vals_a, vals_b, d_count, hist, begin_bit, end_bit);
+	return sort_impl<uint32_t, uint32_t, true>(ctx, keys_a, keys_b, vals_a, vals_b, d_count, hist, begin_bit, end_bit);
 }
 
-void nh_sort_u64_u32(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+int nh_sort_u64_u32(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                      const uint32_t* d_count, uint32_t* hist, int begin_bit, int end_bit) {
-	sort_impl<uint64_t, uint32_t, true>(ctx, keys_a, keys_b, vals_a, vals_b, d_count, hist, begin_bit, end_bit);
+	return sort_impl<uint64_t, uint32_t, true>(ctx, keys_a, keys_b, vals_a, vals_b, d_count, hist, begin_bit, end_bit);
 }
 
-void nh_sort_u64(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, const uint32_t* d_count, uint32_t* hist, int begin_bit, int end_bit) {
-	sort_impl<uint64_t, uint32_t, false>(ctx, keys_a, keys_b, (uint32_t*)nullptr, (uint32_t*)nullptr, d_count, hist, begin_bit, end_bit);
+int nh_sort_u64(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, const uint32_t* d_count, uint32_t* hist, int begin_bit, int end_bit) {
+	return sort_impl<uint64_t, uint32_t, false>(ctx, keys_a, keys_b, (uint32_t*)nullptr, (uint32_t*)nullptr, d_count, hist, begin_bit, end_bit);
 }
 
 // ---- exclusive scan -------------------------------------------------------------------------------------
