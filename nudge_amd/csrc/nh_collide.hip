@@ -194,10 +194,12 @@ __global__ __launch_bounds__(256) void k_cell_keys(nh_DevState* __restrict__ st,
 // ---- 4. cell ranges + AABBs in cell order ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_cell_bounds(uint32_t n, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                      const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
-                                                     uint2* __restrict__ cells, float4* __restrict__ smin, float4* __restrict__ smax) {
+                                                     uint2* __restrict__ cells, float4* __restrict__ smin, float4* __restrict__ smax,
+                                                     const uint64_t* __restrict__ mkey, uint64_t* __restrict__ smk) {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		uint32_t key = keys[i];
 		uint32_t c = vals[i];
+		smk[i] = mkey[c];
 		float4 mn = aabb_min[c], mx = aabb_max[c];
 		mx.w = __uint_as_float(c);                 // sorted copy carries (body, collider index) in the w lanes
 		smin[i] = mn; smax[i] = mx;
@@ -233,11 +235,11 @@ __device__ __forceinline__ void flush_pairs(nh_DevState* st, uint2* pairs, uint3
 	ps.count = 0;
 }
 
-__device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_t pair_cap, const uint64_t* mkey, uint32_t ca, uint32_t cb, bool hit, pair_stage& ps) {
+__device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_t pair_cap, uint64_t ka, const uint64_t* kb_ptr, uint32_t ca, uint32_t cb, bool hit, pair_stage& ps) {
 	unsigned long long bal = __ballot(hit);
 	if (!bal) return;
 	if (hit) {
-		uint64_t ka = mkey[ca], kb = mkey[cb];
+		uint64_t kb = *kb_ptr;
 		bool a_first = (ka < kb) || (ka == kb && ca < cb);
 		// narrowphase "a" = later in Morton order (nudge.cpp:3495, 1202-1203)
 		ps.buf[ps.count + (uint32_t)__popcll(bal & ((1ull << nh_lane()) - 1ull))] = a_first ? make_uint2(cb, ca) : make_uint2(ca, cb);
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
                                                     const uint32_t* __restrict__ keys, const float4* __restrict__ smin, const float4* __restrict__ smax,
                                                     const uint2* __restrict__ cells, const uint32_t* __restrict__ large_list,
                                                     const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
-                                                    const uint64_t* __restrict__ mkey, uint2* __restrict__ pairs, uint32_t pair_cap) {
+                                                    const uint64_t* __restrict__ mkey, const uint64_t* __restrict__ smk, uint2* __restrict__ pairs, uint32_t pair_cap) {
 	const float inv = st->cell_inv;
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
@@ -265,7 +267,8 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 		bool valid = i < n;
 		float4 amin = make_float4(0, 0, 0, 0), amax = amin;
 		uint32_t key = NH_LARGE_KEY, ca = 0, abody = 0;
-		if (valid) { amin = smin[i]; amax = smax[i]; key = keys[i]; ca = __float_as_uint(amax.w); abody = __float_as_uint(amin.w); }
+		uint64_t ka = 0;
+		if (valid) { amin = smin[i]; amax = smax[i]; key = keys[i]; ca = __float_as_uint(amax.w); abody = __float_as_uint(amin.w); ka = smk[i]; }
 		bool small = valid && key != NH_LARGE_KEY && !dbg_skip_grid;
 		// neighbour cells [c_min-1, c_max] per axis, clamped
 		int x0 = 0, x1 = -1, y0 = 0, y1 = -1, z0 = 0, z1 = -1;
@@ -305,17 +308,31 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 				cb = __float_as_uint(bmax.w);
 				hit = aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != abody);
 			}
-			emit_pair(st, pairs, pair_cap, mkey, ca, cb, hit, ps);
+			emit_pair(st, pairs, pair_cap, ka, smk + cand, ca, cb, hit, ps);
 		}
 		// large colliders: small x every large; large x larger-indexed large
 		for (uint32_t l = 0; l < nlarge; ++l) {
 			uint32_t cb = large_list[l];
 			float4 bmin = aabb_min[cb], bmax = aabb_max[cb];
 			bool hit = valid && (small || cb > ca) && aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != abody);
-			emit_pair(st, pairs, pair_cap, mkey, ca, cb, hit, ps);
+			emit_pair(st, pairs, pair_cap, ka, mkey + cb, ca, cb, hit, ps);
 		}
 	}
-	flush_pairs(st, pairs, pair_cap, ps);
+	// final flush once per workgroup, not once per wave (every wave ends with a partly filled stage)
+	__shared__ uint32_t wave_count[4];
+	__shared__ uint32_t block_base;
+	if (nh_lane() == 0) wave_count[threadIdx.x >> 6] = ps.count;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+		block_base = total ? atomicAdd(&st->pairs, total) : 0u;
+	}
+	__syncthreads();
+	uint32_t base = block_base;
+	for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) base += wave_count[w];
+	for (uint32_t k = nh_lane(); k < ps.count; k += 64) {
+		if (base + k < pair_cap) pairs[base + k] = ps.buf[k]; else st->error = NH_ERR_PAIR_CAPACITY;
+	}
 }
 
 // ---- 6. narrowphase -----------------------------------------------------------------------------------------
@@ -333,7 +350,9 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 	if (blockIdx.x == 0 && threadIdx.x == 0) st->records = n;
 	uint32_t rounded = (n + 63u) & ~63u;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
-		nh_contact_out out[16];
+		nh_bb_result bb;
+		bb.kind = 0; bb.mask = 0;
+		nh_contact_out single;          // sphere paths produce at most one contact
 		int count = 0;
 		uint64_t key = 0;
 		uint32_t body_a = 0, body_b = 0;
@@ -345,17 +364,15 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 				nh_xform A = xf[a], B = xf[b];
 				nh_BoxCollider sa = box_data[a], sb = box_data[b];
 				uint32_t ta = ctag[a], tb = ctag[b];
-				nh_pair_result r = nh_box_box(A, B, sa.size, sb.size, ta, tb, out);
-				count = r.count;
-				uint32_t ca = r.swapped ? b : a, cb = r.swapped ? a : b;
-				key = (uint64_t)(r.swapped ? tb : ta) | ((uint64_t)(r.swapped ? ta : tb) << 32);
-				body_a = r.swapped ? B.body : A.body;
-				body_b = r.swapped ? A.body : B.body;
-				(void)ca; (void)cb;
+				nh_box_box_eval(A, B, sa.size, sb.size, ta, tb, bb);
+				count = nh_bb_count(bb);
+				key = (uint64_t)(bb.swapped ? tb : ta) | ((uint64_t)(bb.swapped ? ta : tb) << 32);
+				body_a = bb.swapped ? B.body : A.body;
+				body_b = bb.swapped ? A.body : B.body;
 			} else if (a_sph && b_sph) {
 				// sphere-sphere: first = earlier in Morton order = pair.y (nudge.cpp:3775-3776)
 				nh_xform A = xf[b], B = xf[a];
-				count = nh_sphere_sphere(sph_data[b - nbox].radius, sph_data[a - nbox].radius, A, B, out);
+				count = nh_sphere_sphere(sph_data[b - nbox].radius, sph_data[a - nbox].radius, A, B, &single);
 				key = (uint64_t)ctag[b] | ((uint64_t)ctag[a] << 32);
 				body_a = A.body; body_b = B.body;
 			} else {
@@ -363,7 +380,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 				uint32_t bx = a_sph ? b : a, sp = a_sph ? a : b;
 				nh_xform A = xf[bx], B = xf[sp];
 				nh_BoxCollider sz = box_data[bx];
-				count = nh_box_sphere(sz.size, sph_data[sp - nbox].radius, A, B, out);
+				count = nh_box_sphere(sz.size, sph_data[sp - nbox].radius, A, B, &single);
 				key = (uint64_t)ctag[bx] | ((uint64_t)ctag[sp] << 32);
 				body_a = A.body; body_b = B.body;
 			}
@@ -374,13 +391,28 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		if (__ballot(extra != 0)) ovf = nh_wave_reserve(&st->raw_contacts, extra);
 		if (i < n) {
 			if (extra && ovf + extra > overflow_cap) { st->error = NH_ERR_CONTACT_CAPACITY; count = 4; }
-			for (int k = 0; k < count; ++k) {
-				nh_Contact c;
-				c.position[0] = out[k].px; c.position[1] = out[k].py; c.position[2] = out[k].pz; c.penetration = out[k].penetration;
-				c.normal[0] = out[k].nx; c.normal[1] = out[k].ny; c.normal[2] = out[k].nz; c.friction = out[k].friction;
+			auto put = [&](int k, const nh_contact_out& o) {
 				size_t dst = k < 4 ? (size_t)4 * i + k : (size_t)4 * pair_cap + ovf + (k - 4);
-				raw_data[dst] = c;
-				raw_feature[dst] = out[k].feature;
+				float4* dp = reinterpret_cast<float4*>(raw_data + dst);
+				dp[0] = make_float4(o.px, o.py, o.pz, o.penetration);
+				dp[1] = make_float4(o.nx, o.ny, o.nz, o.friction);
+				raw_feature[dst] = o.feature;
+			};
+			if (bb.kind == 2) {
+				int k = 0;
+#pragma unroll
+				for (int index = 0; index < 16; ++index) {
+					if (((bb.mask >> index) & 1u) && k < count) {
+						nh_contact_out o;
+						nh_bb_contact(bb, index, bb.lx[index], bb.ly[index], bb.lz[index], bb.penetration[index], bb.tags[index], o);
+						put(k, o);
+						++k;
+					}
+				}
+			} else if (bb.kind == 1) {
+				put(0, bb.edge);
+			} else if (count) {
+				put(0, single);
 			}
 			rec_key[i] = key;
 			nh_Record r = { body_a, body_b, ovf, (uint32_t)count };
@@ -497,35 +529,39 @@ __global__ __launch_bounds__(256) void k_write_sleeping(nh_DevState* __restrict_
 	}
 }
 
+// One lane per OUTPUT contact (coalesced 32-B stores): find the owning record by binary search in the scanned
+// counts, then pick the record's k-th contact in feature order (reference: low 32 tag bits, nudge.cpp:4031-4036).
 __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict__ st, const uint32_t* __restrict__ rec_idx, const nh_Record* __restrict__ rec, const uint64_t* __restrict__ rec_key_sorted,
                                                          const uint32_t* __restrict__ starts, const nh_Contact* __restrict__ raw_data, const uint32_t* __restrict__ raw_feature,
                                                          nh_Contact* __restrict__ data, nh_BodyPair* __restrict__ bodies, uint64_t* __restrict__ tags, uint32_t* __restrict__ features, uint32_t capacity, uint32_t pair_cap) {
-	uint32_t n = st->records;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		uint32_t ri = rec_idx[i];
-		nh_Record r = rec[ri];
-		if (!r.count || (r.count & NH_REC_SLEEPING)) continue;
-		uint32_t dst = starts[i];
-		if (dst + r.count > capacity) { st->error = NH_ERR_CONTACT_CAPACITY; continue; }
-		uint64_t key = rec_key_sorted[i];
-		// stable insertion sort of <= 16 contacts by feature word (reference: low 32 tag bits, nudge.cpp:4031-4036)
-		uint32_t order[16], feat[16];
-		uint32_t cnt = r.count > 16 ? 16 : r.count;
+	const uint32_t nrec = st->records;
+	uint32_t total = st->contacts;
+	if (total > capacity) { if (blockIdx.x == 0 && threadIdx.x == 0) st->error = NH_ERR_CONTACT_CAPACITY; total = capacity; }
+	for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < total; d += gridDim.x * blockDim.x) {
+		// largest record index whose start <= d (empty records share their successor's start)
+		uint32_t lo = 0, hi = nrec;
+		while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (starts[mid] <= d) lo = mid; else hi = mid; }
+		const uint32_t ri = rec_idx[lo];
+		const nh_Record r = rec[ri];
+		const uint32_t k = d - starts[lo];
+		const uint32_t cnt = r.count > 16 ? 16 : r.count;
 		const size_t base4 = (size_t)4 * ri, baseo = (size_t)4 * pair_cap + r.overflow;
-		for (uint32_t k = 0; k < cnt; ++k) {
-			uint32_t f = raw_feature[k < 4 ? base4 + k : baseo + (k - 4)];
-			uint32_t j = k;
-			while (j > 0 && feat[j - 1] > f) { feat[j] = feat[j - 1]; order[j] = order[j - 1]; --j; }
-			feat[j] = f; order[j] = k;
+		uint32_t feat[16];
+		for (uint32_t j = 0; j < cnt; ++j) feat[j] = raw_feature[j < 4 ? base4 + j : baseo + (j - 4)];
+		uint32_t src = 0, f = 0;
+		for (uint32_t j = 0; j < cnt; ++j) {
+			uint32_t rank = 0;
+			for (uint32_t i = 0; i < cnt; ++i) rank += (feat[i] < feat[j] || (feat[i] == feat[j] && i < j)) ? 1u : 0u;
+			if (rank == k) { src = j; f = feat[j]; }
 		}
+		const float4* sp = reinterpret_cast<const float4*>(raw_data + (src < 4 ? base4 + src : baseo + (src - 4)));
+		float4 c0 = sp[0], c1 = sp[1];
+		float4* dp = reinterpret_cast<float4*>(data + d);
+		dp[0] = c0; dp[1] = c1;
 		nh_BodyPair bp = { r.body_a, r.body_b };
-		for (uint32_t k = 0; k < cnt; ++k) {
-			uint32_t o = order[k];
-			data[dst + k] = raw_data[o < 4 ? base4 + o : baseo + (o - 4)];
-			bodies[dst + k] = bp;
-			tags[dst + k] = key;
-			features[dst + k] = feat[k];
-		}
+		bodies[d] = bp;
+		tags[d] = rec_key_sorted[lo];
+		features[d] = f;
 	}
 }
 
@@ -566,6 +602,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	float4* smax = nh_arena_array<float4>(A, C, &err);
 	uint32_t* ctag = nh_arena_array<uint32_t>(A, C, &err);
 	uint64_t* mkey = nh_arena_array<uint64_t>(A, C, &err);
+	uint64_t* smk = nh_arena_array<uint64_t>(A, C, &err);
 	uint32_t* keys_a = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* keys_b = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* vals_a = nh_arena_array<uint32_t>(A, C, &err);
@@ -612,8 +649,8 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		if (ctx->timing) nh_timer_begin(ctx, "memset_cells");
 		NH_HIP_CHECK(ctx, hipMemsetAsync(cells, 0, sizeof(uint2) * (size_t)max_cells, s));
 		if (ctx->timing) nh_timer_end(ctx);
-		NH_LAUNCH(ctx, "cell_bounds", k_cell_bounds, nh_grid_for(C, 256, 2048), 256, C, keys_a, vals_a, aabb_min, aabb_max, cells, smin, smax);
-		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 4096), 256, st, C, keys_a, smin, smax, cells, large_list, aabb_min, aabb_max, mkey, pairs, pair_cap | (getenv("NH_DBG_SKIP_LARGE") ? 0x80000000u : 0u) | (getenv("NH_DBG_SKIP_GRID") ? 0x40000000u : 0u));
+		NH_LAUNCH(ctx, "cell_bounds", k_cell_bounds, nh_grid_for(C, 256, 2048), 256, C, keys_a, vals_a, aabb_min, aabb_max, cells, smin, smax, mkey, smk);
+		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 1024), 256, st, C, keys_a, smin, smax, cells, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap | (getenv("NH_DBG_SKIP_LARGE") ? 0x80000000u : 0u) | (getenv("NH_DBG_SKIP_GRID") ? 0x40000000u : 0u));
 		NH_LAUNCH(ctx, "narrowphase", k_narrowphase, nh_grid_for(pair_cap, 256, 4096), 256, st, pairs, xf, ctag,
 		          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a);
 	}
@@ -645,7 +682,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	// (dropped records carry count 0, so where they land in the order is irrelevant)
 	NH_LAUNCH(ctx, "sorted_counts", k_sorted_counts, nh_grid_for(pair_cap, 256, 2048), 256, st, rec_idx_a, rec, rec_counts, sleep_flags);
 	nh_scan_u32(ctx, rec_counts, rec_counts, &st->records, 0, scan_tmp, &st->contacts);
-	NH_LAUNCH(ctx, "gather_contacts", k_gather_contacts, nh_grid_for(pair_cap, 256, 4096), 256, st, rec_idx_a, rec, rec_key_a, rec_counts, raw_data, raw_feature,
+	NH_LAUNCH(ctx, "gather_contacts", k_gather_contacts, nh_grid_for(cap, 256, 16384), 256, st, rec_idx_a, rec, rec_key_a, rec_counts, raw_data, raw_feature,
 	          contacts->data, contacts->bodies, contacts->tags, contacts->features, cap, pair_cap);
 	// sleeping pairs, ascending (nudge.cpp:4008)
 	nh_scan_u32(ctx, sleep_flags, sleep_flags, &st->records, 1, scan_tmp, &st->sleeping);

@@ -31,6 +31,37 @@ struct nh_pair_result {
 	int swapped;             // 1: canonical "a" is the pair's second collider (input b)
 };
 
+// Result of the box-box test before contacts are materialised.  Every array is indexed with compile-time
+// constants only (fully unrolled loops), so on the GPU it lives in registers, not in scratch memory.
+struct nh_bb_result {
+	int kind;                // 0: separated, 1: one edge-edge contact (in `edge`), 2: face clipping (mask over 16 candidates)
+	int swapped;
+	unsigned mask;
+	unsigned tag_swap;
+	nh_contact_out edge;
+	float lx[16], ly[16], lz[16], penetration[16];   // candidate points in a's local frame
+	uint32_t tags[16];
+	float w0[3], w1[3], w2[3], wn[3], apos[3];
+};
+
+NH_HD int nh_bb_count(const nh_bb_result& r) {
+	if (r.kind == 1) return 1;
+	if (r.kind == 2) return __builtin_popcount(r.mask);
+	return 0;
+}
+
+// materialise candidate `index` (0..15) of a face result (nudge.cpp:2095-2108)
+NH_HD void nh_bb_contact(const nh_bb_result& r, int index, float lx, float ly, float lz, float pen, uint32_t tag, nh_contact_out& o) {
+	(void)index;
+	o.px = r.w0[0] * lx + r.w1[0] * ly + r.w2[0] * lz + r.apos[0];
+	o.py = r.w0[1] * lx + r.w1[1] * ly + r.w2[1] * lz + r.apos[1];
+	o.pz = r.w0[2] * lx + r.w1[2] * ly + r.w2[2] * lz + r.apos[2];
+	o.penetration = pen;
+	o.nx = r.wn[0]; o.ny = r.wn[1]; o.nz = r.wn[2];
+	o.friction = 0.5f;
+	o.feature = r.tag_swap ? ((tag >> 16) | (tag << 16)) : tag;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Phase-1/2 shared: relative rotation matrix "a to b" as three vectors vx,vy,vz (nudge.cpp:1228-1268).
 struct nh_rel { float m[9]; };   // m[r*3+c], r = vector (x,y,z), c = component: layout of a_to_b[] (nudge.cpp:1507-1519)
@@ -163,11 +194,12 @@ NH_HD void nh_box_box_edge(const nh_xform& A, const nh_xform& B, const float* sa
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Full box-box test of one pair.  Returns 0..16 contacts (8 is the geometric maximum) in out[].
-// A/B, sa/sb, tag_a/tag_b describe the pair in ARRIVAL order (A = later in Morton order).
-NH_HD nh_pair_result nh_box_box(nh_xform A, nh_xform B, const float* size_a, const float* size_b,
-                                uint32_t tag_a, uint32_t tag_b, nh_contact_out* out) {
-	nh_pair_result res = { 0, 0 };
+// Full box-box test of one pair: SAT over 15 axes, then either one edge-edge contact or up to 16 clipped candidates
+// (8 is the geometric maximum) described by res.mask.  A/B, sa/sb, tag_a/tag_b describe the pair in ARRIVAL order
+// (A = later in Morton order).
+NH_HD void nh_box_box_eval(nh_xform A, nh_xform B, const float* size_a, const float* size_b,
+                           uint32_t tag_a, uint32_t tag_b, nh_bb_result& res) {
+	res.kind = 0; res.swapped = 0; res.mask = 0; res.tag_swap = 0;
 	float sa[3] = { size_a[0], size_a[1], size_a[2] };
 	float sb[3] = { size_b[0], size_b[1], size_b[2] };
 	int swapped = 0;          // A/B currently exchanged relative to arrival order
@@ -202,7 +234,7 @@ NH_HD nh_pair_result nh_box_box(nh_xform A, nh_xform B, const float* size_a, con
 		unsigned aface = (payz == pa ? 1u : 0u) + (paz == pa ? 1u : 0u);
 		unsigned bface = (pbyz == pb ? 1u : 0u) + (pbz == pb ? 1u : 0u);
 		bool swap = (pa == p);
-		if (!(p > 0.0f)) return res;
+		if (!(p > 0.0f)) return;
 		face_penetration = p;
 		a_face = swap ? aface : bface;
 		if (swap) {
@@ -272,22 +304,22 @@ NH_HD nh_pair_result nh_box_box(nh_xform A, nh_xform B, const float* size_a, con
 
 	bool is_edge = face_penetration > penetration + 1e-3f;
 	bool overlapping = penetration > 0.0f;
-	if (!overlapping) return res;
+	if (!overlapping) return;
 
 	if (is_edge) {
 		// canonicalise: a = larger tag (nudge.cpp:2127-2132), then phase 3
 		uint32_t feature;
 		if (tag_a > tag_b) {
 			feature = a_edge | (b_edge << 16);
-			nh_box_box_edge(A, B, sa, sb, feature, penetration, out);
+			nh_box_box_edge(A, B, sa, sb, feature, penetration, &res.edge);
 		} else {
 			feature = b_edge | (a_edge << 16);
-			nh_box_box_edge(B, A, sb, sa, feature, penetration, out);
+			nh_box_box_edge(B, A, sb, sa, feature, penetration, &res.edge);
 			swapped ^= 1;
 		}
-		res.count = 1;
+		res.kind = 1;
 		res.swapped = swapped;
-		return res;
+		return;
 	}
 
 	// ---- face-face clipping (nudge.cpp:1678-2112) ----
@@ -325,8 +357,9 @@ NH_HD nh_pair_result nh_box_box(nh_xform A, nh_xform B, const float* size_a, con
 	float dxx = dxv[AX], dxy_ = dxv[AY], dxz = dxv[AZ];
 	float dyx = dyv[AX], dyy = dyv[AY], dyz = dyv[AZ];
 
-	float support_x[16], support_y[16], support_z[16], penetrations[16];
-	uint32_t support_tags[16];
+	float support_x[16], support_y[16], support_z[16];
+	float* penetrations = res.penetration;
+	uint32_t* support_tags = res.tags;
 	unsigned mask;
 	{
 		// sign patterns over the 4 lanes
@@ -441,6 +474,7 @@ NH_HD nh_pair_result nh_box_box(nh_xform A, nh_xform B, const float* size_a, con
 		uint32_t z_sign = b_offset_neg ? 0x80000000u : 0u;
 		float half_signed = nh_xorf(0.5f, z_sign);
 		unsigned penetration_mask = 0;
+#pragma unroll
 		for (int i = 0; i < 16; ++i) {
 			float x = support_x[i], y = support_y[i];
 			float z = x * plane0 + y * plane1 + plane2;
@@ -479,26 +513,36 @@ NH_HD nh_pair_result nh_box_box(nh_xform A, nh_xform B, const float* size_a, con
 		wn[0] = nh_neg(wn[0]); wn[1] = nh_neg(wn[1]); wn[2] = nh_neg(wn[2]);
 	}
 
-	// local axes of the support blocks: X' = (a_face+1)%3, Y' = (a_face+2)%3, Z' = a_face
-	const float* loc[3];
-	loc[AX] = support_x; loc[AY] = support_y; loc[AZ] = support_z;
-
-	int count = 0;
-	for (int index = 0; index < 16; ++index) {
-		if (!((mask >> index) & 1u)) continue;
-		float lx = loc[0][index], ly = loc[1][index], lz = loc[2][index];
-		nh_contact_out& o = out[count++];
-		o.px = w0[0] * lx + w1[0] * ly + w2[0] * lz + A.px;
-		o.py = w0[1] * lx + w1[1] * ly + w2[1] * lz + A.py;
-		o.pz = w0[2] * lx + w1[2] * ly + w2[2] * lz + A.pz;
-		o.penetration = penetrations[index];
-		o.nx = wn[0]; o.ny = wn[1]; o.nz = wn[2];
-		o.friction = 0.5f;
-		uint32_t t = support_tags[index];
-		o.feature = tag_swap ? ((t >> 16) | (t << 16)) : t;
+	// local axes of the support blocks: X' = (a_face+1)%3, Y' = (a_face+2)%3, Z' = a_face (nudge.cpp:2021-2026);
+	// selected with compile-time indices so the candidate arrays stay in registers
+#pragma unroll
+	for (int i = 0; i < 16; ++i) {
+		float bx = support_x[i], by = support_y[i], bz = support_z[i];
+		res.lx[i] = a_face == 0 ? bz : (a_face == 1 ? by : bx);
+		res.ly[i] = a_face == 0 ? bx : (a_face == 1 ? bz : by);
+		res.lz[i] = a_face == 0 ? by : (a_face == 1 ? bx : bz);
 	}
-	res.count = count;
+	for (int k = 0; k < 3; ++k) { res.w0[k] = w0[k]; res.w1[k] = w1[k]; res.w2[k] = w2[k]; res.wn[k] = wn[k]; }
+	res.apos[0] = A.px; res.apos[1] = A.py; res.apos[2] = A.pz;
+	res.kind = 2;
+	res.mask = mask;
+	res.tag_swap = tag_swap;
 	res.swapped = swapped;
+}
+
+// Convenience wrapper (host-side unit tests): materialises the contacts into out[], in candidate order.
+NH_HD nh_pair_result nh_box_box(nh_xform A, nh_xform B, const float* size_a, const float* size_b,
+                                uint32_t tag_a, uint32_t tag_b, nh_contact_out* out) {
+	nh_bb_result r;
+	nh_box_box_eval(A, B, size_a, size_b, tag_a, tag_b, r);
+	nh_pair_result res = { 0, r.swapped };
+	if (r.kind == 1) { out[0] = r.edge; res.count = 1; }
+	else if (r.kind == 2) {
+		for (int index = 0; index < 16; ++index) {
+			if (!((r.mask >> index) & 1u)) continue;
+			nh_bb_contact(r, index, r.lx[index], r.ly[index], r.lz[index], r.penetration[index], r.tags[index], out[res.count++]);
+		}
+	}
 	return res;
 }
 
