@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void k_filter_records(nh_DevState* __restrict_
 			if (r.count) {
 				uint32_t set = root_of[r.body_a ? r.body_a : r.body_b];      // sets[a] | sets[b] with sets[0] = 0 (nudge.cpp:3988)
 				sleeping = !set_active[set];
-				if (sleeping) rec[i].count = NH_REC_SLEEPING;                 // no contacts any more; key kept: sleeping pairs come out in tag order
+				if (sleeping) { rec[i].count = NH_REC_SLEEPING; st->any_sleeping = 1; }   // no contacts any more; key kept: sleeping pairs come out in tag order
 			}
 		}
 		(void)key; (void)sleeping_pairs; (void)sleeping_cap; (void)rec_key; (void)rec_idx;
@@ -523,6 +523,7 @@ __global__ __launch_bounds__(256) void k_sorted_counts(const nh_DevState* __rest
 __global__ __launch_bounds__(256) void k_write_sleeping(nh_DevState* __restrict__ st, const uint32_t* __restrict__ scan, const uint64_t* __restrict__ rec_key_sorted,
                                                         uint64_t* __restrict__ sleeping_pairs, uint32_t cap) {
 	uint32_t n = st->records;
+	if (!st->any_sleeping) return;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		uint32_t p = scan[i], q = scan[i + 1];
 		if (q != p) { if (p < cap) sleeping_pairs[p] = rec_key_sorted[i]; else st->error = NH_ERR_CONTACT_CAPACITY; }
@@ -570,7 +571,7 @@ __global__ void k_collide_begin(nh_DevState* st, uint32_t ncolliders) {
 	if (t == 0) {
 		st->colliders = ncolliders; st->pairs = 0; st->raw_contacts = 0; st->records = 0; st->contacts = 0; st->sleeping = 0;
 		st->active = 0; st->culled = 0; st->large = 0; st->general_contacts = 0; st->levels = 0; st->error = 0;
-		st->static_bodies = 0; st->unleveled = 0; st->has_static8 = 0; st->has_staticN = 0;
+		st->static_bodies = 0; st->unleveled = 0; st->has_static8 = 0; st->has_staticN = 0; st->any_sleeping = 0;
 		for (int k = 0; k < 3; ++k) { st->smin[k] = 0xffffffffu; st->smax[k] = 0u; st->gmin[k] = 0xffffffffu; st->gmax[k] = 0u; }
 	}
 	st->exp_hist[t] = 0;
@@ -685,7 +686,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	NH_LAUNCH(ctx, "gather_contacts", k_gather_contacts, nh_grid_for(cap, 256, 16384), 256, st, rec_idx_a, rec, rec_key_a, rec_counts, raw_data, raw_feature,
 	          contacts->data, contacts->bodies, contacts->tags, contacts->features, cap, pair_cap);
 	// sleeping pairs, ascending (nudge.cpp:4008)
-	nh_scan_u32(ctx, sleep_flags, sleep_flags, &st->records, 1, scan_tmp, &st->sleeping);
+	nh_scan_u32(ctx, sleep_flags, sleep_flags, &st->records, 1, scan_tmp, &st->sleeping, &st->any_sleeping);
 	if (contacts->sleeping_pairs)
 		NH_LAUNCH(ctx, "write_sleeping", k_write_sleeping, nh_grid_for(pair_cap, 256, 2048), 256, st, sleep_flags, rec_key_a, contacts->sleeping_pairs, cap);
 

@@ -39,7 +39,8 @@ struct nh_DevState {
 	uint32_t unleveled;           // general contacts still without a level (relaxation progress)
 	uint32_t pad0;                // always 0 (used as a constant device-side count)
 	uint32_t has_static8, has_staticN;    // any body in the rarer fast-path classes (plain stores, no counting)
-	uint32_t pad1, pad2;
+	uint32_t any_sleeping;                // some contact record belongs to a sleeping island this step
+	uint32_t pad2;
 	// scene bounds of AABB min corners, order-preserving uint encoding (atomicMin/Max)
 	uint32_t smin[3];
 	uint32_t smax[3];
@@ -165,8 +166,9 @@ int nh_sort_u64(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b,
                  const uint32_t* d_count, uint32_t* hist, int begin_bit, int end_bit);
 // Exclusive scan of `in[0..n)` into `out` (may alias); n read from *d_count (+ `extra` elements);
 // the grand total is also stored to *d_total if non-null.  `tmp` needs NH_SORT_GRID+8 words.
+// If `d_enable` is given and *d_enable == 0 the scan is skipped on the device (the total is reported as 0).
 void nh_scan_u32(nh_context* ctx, const uint32_t* in, uint32_t* out, const uint32_t* d_count, uint32_t extra,
-                 uint32_t* tmp, uint32_t* d_total);
+                 uint32_t* tmp, uint32_t* d_total, const uint32_t* d_enable = nullptr);
 
 // dst[0 .. *d_count * words_per_item) = src[...]
 void nh_copy_back_u32(nh_context* ctx, const uint32_t* src, uint32_t* dst, const uint32_t* d_count, uint32_t words_per_item);

@@ -76,10 +76,7 @@ __global__ __launch_bounds__(256) void k_cache_lookup(const nh_DevState* __restr
 __global__ __launch_bounds__(256) void k_cull_flags(const nh_DevState* __restrict__ st, const uint64_t* __restrict__ ctags, const uint64_t* __restrict__ sleeping, uint32_t* __restrict__ flags) {
 	uint32_t m = st->cache, ns = st->sleeping;
 	if (blockIdx.x == 0 && threadIdx.x == 0) flags[m] = 0;       // sentinel so that scan[m] = number of culled entries
-	if (ns == 0) {                                               // nothing sleeps: no cached impulse is kept aside
-		for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) flags[j] = 0;
-		return;
-	}
+	if (ns == 0) return;                                         // nothing sleeps: the scan and the write below are skipped on the device
 	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
 		uint64_t t = ctags[j];
 		uint32_t lo = 0, hi = ns;
@@ -92,6 +89,7 @@ __global__ __launch_bounds__(256) void k_cull_write(const nh_DevState* __restric
                                                     const uint64_t* __restrict__ ctags, const uint32_t* __restrict__ cfeatures, const nh_CachedContactImpulse* __restrict__ cdata,
                                                     uint64_t* __restrict__ otags, uint32_t* __restrict__ ofeatures, nh_CachedContactImpulse* __restrict__ odata) {
 	uint32_t m = st->cache;
+	if (st->sleeping == 0) return;
 	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
 		// flags were scanned in place into `scan`; an entry is culled iff scan[j+1] != scan[j]
 		uint32_t p = scan[j], q = scan[j + 1];
@@ -686,10 +684,10 @@ extern "C" int nh_read_cached_impulses(nh_context* ctx, const nh_ContactCache* c
 	uint32_t* flags = nh_arena_array<uint32_t>(&scratch, ccap + 1, &err);
 	uint32_t* tmp = nh_arena_array<uint32_t>(&scratch, NH_SORT_GRID + 64, &err);
 	if (err) return err;
-	NH_LAUNCH(ctx, "cache_lookup", k_cache_lookup, nh_grid_for(kcap, 256, 4096), 256, st, contacts->tags, contacts->features, cache->tags, cache->features, cache->data, d->data);
+	NH_LAUNCH(ctx, "cache_lookup", k_cache_lookup, nh_grid_for(kcap, 256, 16384), 256, st, contacts->tags, contacts->features, cache->tags, cache->features, cache->data, d->data);
 	if (contacts->sleeping_pairs) {
 		NH_LAUNCH(ctx, "cull_flags", k_cull_flags, nh_grid_for(ccap, 256, 4096), 256, st, cache->tags, contacts->sleeping_pairs, flags);
-		nh_scan_u32(ctx, flags, flags, &st->cache, 1, tmp, &st->culled);   // +1: the sentinel, so scan[j+1] exists for every j
+		nh_scan_u32(ctx, flags, flags, &st->cache, 1, tmp, &st->culled, &st->sleeping);   // +1: the sentinel, so scan[j+1] exists for every j
 		NH_LAUNCH(ctx, "cull_write", k_cull_write, nh_grid_for(ccap, 256, 4096), 256, st, flags, flags, cache->tags, cache->features, cache->data,
 		          d->culled_tags, d->culled_features, d->culled_data);
 	}

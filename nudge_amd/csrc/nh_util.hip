@@ -161,8 +161,9 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 	return woff + x - v;
 }
 
-__global__ __launch_bounds__(256) void sc_sums(const uint32_t* __restrict__ in, const uint32_t* __restrict__ d_n, uint32_t extra, uint32_t* __restrict__ tmp) {
+__global__ __launch_bounds__(256) void sc_sums(const uint32_t* __restrict__ in, const uint32_t* __restrict__ d_n, uint32_t extra, uint32_t* __restrict__ tmp, const uint32_t* __restrict__ d_enable) {
 	__shared__ uint32_t wsum[4];
+	if (d_enable && !*d_enable) return;
 	uint32_t n = *d_n + extra;
 	uint32_t begin, end;
 	rs_chunk(n, begin, end);
@@ -174,8 +175,9 @@ __global__ __launch_bounds__(256) void sc_sums(const uint32_t* __restrict__ in, 
 	if (threadIdx.x == 0) tmp[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-__global__ __launch_bounds__(RS_G) void sc_top(uint32_t* __restrict__ tmp, uint32_t* __restrict__ d_total) {
+__global__ __launch_bounds__(RS_G) void sc_top(uint32_t* __restrict__ tmp, uint32_t* __restrict__ d_total, const uint32_t* __restrict__ d_enable) {
 	__shared__ uint32_t wsum[RS_G / 64];
+	if (d_enable && !*d_enable) { if (threadIdx.x == 0 && d_total) *d_total = 0; return; }
 	uint32_t v = tmp[threadIdx.x];
 	uint32_t x = v;
 	for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d); if ((int)(threadIdx.x & 63) >= d) x += y; }
@@ -191,8 +193,9 @@ __global__ __launch_bounds__(RS_G) void sc_top(uint32_t* __restrict__ tmp, uint3
 	}
 }
 
-__global__ __launch_bounds__(256) void sc_final(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ d_n, uint32_t extra, const uint32_t* __restrict__ tmp) {
+__global__ __launch_bounds__(256) void sc_final(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ d_n, uint32_t extra, const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ d_enable) {
 	__shared__ uint32_t wsum[4];
+	if (d_enable && !*d_enable) return;
 	uint32_t n = *d_n + extra;
 	uint32_t begin, end;
 	rs_chunk(n, begin, end);
@@ -208,8 +211,8 @@ __global__ __launch_bounds__(256) void sc_final(const uint32_t* __restrict__ in,
 	}
 }
 
-void nh_scan_u32(nh_context* ctx, const uint32_t* in, uint32_t* out, const uint32_t* d_count, uint32_t extra, uint32_t* tmp, uint32_t* d_total) {
-	NH_LAUNCH(ctx, "scan_sums", sc_sums, RS_G, 256, in, d_count, extra, tmp);
-	NH_LAUNCH(ctx, "scan_top", sc_top, 1, RS_G, tmp, d_total);
-	NH_LAUNCH(ctx, "scan_final", sc_final, RS_G, 256, in, out, d_count, extra, tmp);
+void nh_scan_u32(nh_context* ctx, const uint32_t* in, uint32_t* out, const uint32_t* d_count, uint32_t extra, uint32_t* tmp, uint32_t* d_total, const uint32_t* d_enable) {
+	NH_LAUNCH(ctx, "scan_sums", sc_sums, RS_G, 256, in, d_count, extra, tmp, d_enable);
+	NH_LAUNCH(ctx, "scan_top", sc_top, 1, RS_G, tmp, d_total, d_enable);
+	NH_LAUNCH(ctx, "scan_final", sc_final, RS_G, 256, in, out, d_count, extra, tmp, d_enable);
 }
