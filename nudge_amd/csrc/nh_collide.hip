@@ -235,6 +235,24 @@ __device__ __forceinline__ void flush_pairs(nh_DevState* st, uint2* pairs, uint3
 	ps.count = 0;
 }
 
+// final flush once per workgroup, not once per wave (every wave ends with a partly filled stage)
+__device__ __forceinline__ void flush_pairs_block(nh_DevState* st, uint2* pairs, uint32_t pair_cap, pair_stage& ps) {
+	__shared__ uint32_t wave_count[4];
+	__shared__ uint32_t block_base;
+	if (nh_lane() == 0) wave_count[threadIdx.x >> 6] = ps.count;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+		block_base = total ? atomicAdd(&st->pairs, total) : 0u;
+	}
+	__syncthreads();
+	uint32_t base = block_base;
+	for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) base += wave_count[w];
+	for (uint32_t k = nh_lane(); k < ps.count; k += 64) {
+		if (base + k < pair_cap) pairs[base + k] = ps.buf[k]; else st->error = NH_ERR_PAIR_CAPACITY;
+	}
+}
+
 __device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_t pair_cap, uint64_t ka, const uint64_t* kb_ptr, uint32_t ca, uint32_t cb, bool hit, pair_stage& ps) {
 	unsigned long long bal = __ballot(hit);
 	if (!bal) return;
@@ -310,29 +328,68 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 			}
 			emit_pair(st, pairs, pair_cap, ka, smk + cand, ca, cb, hit, ps);
 		}
-		// large colliders: small x every large; large x larger-indexed large
-		for (uint32_t l = 0; l < nlarge; ++l) {
-			uint32_t cb = large_list[l];
-			float4 bmin = aabb_min[cb], bmax = aabb_max[cb];
-			bool hit = valid && (small || cb > ca) && aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != abody);
-			emit_pair(st, pairs, pair_cap, ka, mkey + cb, ca, cb, hit, ps);
+		// large x larger-indexed large (small x large is found from the large side: k_large_pairs)
+		const bool a_large = valid && key == NH_LARGE_KEY;
+		if (__ballot(a_large)) {
+			for (uint32_t l = 0; l < nlarge; ++l) {
+				uint32_t cb = large_list[l];
+				float4 bmin = aabb_min[cb], bmax = aabb_max[cb];
+				bool hit = a_large && cb > ca && aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != abody);
+				emit_pair(st, pairs, pair_cap, ka, mkey + cb, ca, cb, hit, ps);
+			}
 		}
 	}
-	// final flush once per workgroup, not once per wave (every wave ends with a partly filled stage)
-	__shared__ uint32_t wave_count[4];
-	__shared__ uint32_t block_base;
-	if (nh_lane() == 0) wave_count[threadIdx.x >> 6] = ps.count;
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		uint32_t total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
-		block_base = total ? atomicAdd(&st->pairs, total) : 0u;
+	flush_pairs_block(st, pairs, pair_cap, ps);
+}
+
+// small x large pairs, found from the LARGE side: a large collider (ground slab, wall) visits the grid cells its AABB
+// covers instead of every small collider testing every large one (124 slabs x 1 M boxes = 1.2e8 tests otherwise).
+#define LP_SLICES 16
+__global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ st, const float4* __restrict__ smin, const float4* __restrict__ smax,
+                                                     const uint2* __restrict__ cells, const uint32_t* __restrict__ large_list,
+                                                     const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
+                                                     const uint64_t* __restrict__ mkey, const uint64_t* __restrict__ smk, uint2* __restrict__ pairs, uint32_t pair_cap) {
+	const float inv = st->cell_inv;
+	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
+	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
+	const uint32_t nlarge = st->large;
+	__shared__ uint2 wave_buf[4][FP_WBUF];
+	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u };
+	const uint32_t slice = blockIdx.x % LP_SLICES;
+	for (uint32_t l = blockIdx.x / LP_SLICES; l < nlarge; l += gridDim.x / LP_SLICES) {
+		const uint32_t ca = large_list[l];
+		const float4 amin = aabb_min[ca], amax = aabb_max[ca];
+		const uint32_t abody = __float_as_uint(amin.w);
+		const uint64_t ka = mkey[ca];
+		// a small collider B overlapping A has its min-corner cell in [c_min(A) - 1, c_max(A)] per axis
+		int x0 = min(max(cell_coord(amin.x, ox, inv) - 1, 0), nx - 1), x1 = min(max(cell_coord(amax.x, ox, inv), 0), nx - 1);
+		int y0 = min(max(cell_coord(amin.y, oy, inv) - 1, 0), ny - 1), y1 = min(max(cell_coord(amax.y, oy, inv), 0), ny - 1);
+		int z0 = min(max(cell_coord(amin.z, oz, inv) - 1, 0), nz - 1), z1 = min(max(cell_coord(amax.z, oz, inv), 0), nz - 1);
+		const uint32_t wx = (uint32_t)(x1 - x0 + 1), wy = (uint32_t)(y1 - y0 + 1), wz = (uint32_t)(z1 - z0 + 1);
+		const uint32_t ncell = wx * wy * wz;
+		const uint32_t rounded = (ncell + LP_SLICES * 256u - 1) / (LP_SLICES * 256u) * (LP_SLICES * 256u);
+		for (uint32_t ci = slice * 256u + threadIdx.x; ci < rounded; ci += LP_SLICES * 256u) {
+			uint32_t j = 0, jend = 0;
+			if (ci < ncell) {
+				uint32_t cx = ci % wx, cy = (ci / wx) % wy, cz = ci / (wx * wy);
+				uint2 range = cells[((z0 + (int)cz) * ny + (y0 + (int)cy)) * nx + (x0 + (int)cx)];
+				j = range.x; jend = range.y;
+			}
+			while (__ballot(j < jend)) {
+				bool have = j < jend;
+				bool hit = false;
+				uint32_t cb = 0, cand = have ? j : 0;
+				if (have) {
+					float4 bmin = smin[cand], bmax = smax[cand];
+					cb = __float_as_uint(bmax.w);
+					hit = aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != abody);
+					++j;
+				}
+				emit_pair(st, pairs, pair_cap, ka, smk + cand, ca, cb, hit, ps);
+			}
+		}
 	}
-	__syncthreads();
-	uint32_t base = block_base;
-	for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) base += wave_count[w];
-	for (uint32_t k = nh_lane(); k < ps.count; k += 64) {
-		if (base + k < pair_cap) pairs[base + k] = ps.buf[k]; else st->error = NH_ERR_PAIR_CAPACITY;
-	}
+	flush_pairs_block(st, pairs, pair_cap, ps);
 }
 
 // ---- 6. narrowphase -----------------------------------------------------------------------------------------
@@ -652,6 +709,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		if (ctx->timing) nh_timer_end(ctx);
 		NH_LAUNCH(ctx, "cell_bounds", k_cell_bounds, nh_grid_for(C, 256, 2048), 256, C, keys_a, vals_a, aabb_min, aabb_max, cells, smin, smax, mkey, smk);
 		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 1024), 256, st, C, keys_a, smin, smax, cells, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap | (getenv("NH_DBG_SKIP_LARGE") ? 0x80000000u : 0u) | (getenv("NH_DBG_SKIP_GRID") ? 0x40000000u : 0u));
+		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, 2048, 256, st, smin, smax, cells, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap);
 		NH_LAUNCH(ctx, "narrowphase", k_narrowphase, nh_grid_for(pair_cap, 256, 4096), 256, st, pairs, xf, ctag,
 		          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a);
 	}

@@ -40,7 +40,7 @@ struct nh_DevState {
 	uint32_t pad0;                // always 0 (used as a constant device-side count)
 	uint32_t has_static8, has_staticN;    // any body in the rarer fast-path classes (plain stores, no counting)
 	uint32_t any_sleeping;                // some contact record belongs to a sleeping island this step
-	uint32_t pad2;
+	uint32_t unleveled_odd;               // progress counter of odd relaxation / colouring rounds
 	// scene bounds of AABB min corners, order-preserving uint encoding (atomicMin/Max)
 	uint32_t smin[3];
 	uint32_t smax[3];

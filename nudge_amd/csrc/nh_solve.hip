@@ -533,9 +533,27 @@ __global__ __launch_bounds__(256) void k_apply_static(uint32_t nbodies, const ui
 }
 
 // ---- level-scheduled path ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_level_relax(nh_DevState* __restrict__ st, const uint32_t* __restrict__ general_list, const uint32_t* __restrict__ pred_a, const uint32_t* __restrict__ pred_b, uint32_t* __restrict__ level) {
+// one atomicAdd / atomicMax per workgroup (same-address atomics cost ~12 ns each on this chip)
+__device__ __forceinline__ void block_report(nh_DevState* st, uint32_t left, uint32_t lmax, uint32_t round) {
+	// progress counters alternate between rounds; each round clears the counter of the next one (nobody touches it meanwhile)
+	uint32_t* mine = (round & 1u) ? &st->unleveled_odd : &st->unleveled;
+	uint32_t* next = (round & 1u) ? &st->unleveled : &st->unleveled_odd;
+	if (blockIdx.x == 0 && threadIdx.x == 0) *next = 0;
+	__shared__ uint32_t s_left[4], s_max[4];
+	for (int d = 32; d >= 1; d >>= 1) { left += (uint32_t)__shfl_xor((int)left, d); lmax = max(lmax, (uint32_t)__shfl_xor((int)lmax, d)); }
+	if ((threadIdx.x & 63) == 0) { s_left[threadIdx.x >> 6] = left; s_max[threadIdx.x >> 6] = lmax; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t l = s_left[0] + s_left[1] + s_left[2] + s_left[3];
+		uint32_t m = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+		if (l) atomicAdd(mine, l);
+		if (m) atomicMax(&st->levels, m);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_level_relax(nh_DevState* __restrict__ st, const uint32_t* __restrict__ general_list, const uint32_t* __restrict__ pred_a, const uint32_t* __restrict__ pred_b, uint32_t* __restrict__ level, uint32_t round) {
 	uint32_t n = st->general_contacts;
-	uint32_t left = 0;
+	uint32_t left = 0, lmax = 0;
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
 		uint32_t c = general_list[k];
 		if (__hip_atomic_load(&level[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != NH_UNSET) continue;
@@ -545,33 +563,125 @@ __global__ __launch_bounds__(256) void k_level_relax(nh_DevState* __restrict__ s
 		if (la == NH_UNSET || lb == NH_UNSET) { ++left; continue; }
 		uint32_t l = (la > lb ? la : lb) + 1u;
 		__hip_atomic_store(&level[c], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		atomicMax(&st->levels, l);
+		lmax = max(lmax, l);
 	}
-	if (left) atomicAdd(&st->unleveled, left);
+	block_report(st, left, lmax, round);
 }
 
-__global__ void k_level_reset_progress(nh_DevState* st) { st->unleveled = 0; }
 
+// Default (throughput) order for contacts off the one-body fast path: a deterministic greedy COLOURING of the contact graph
+// (two contacts conflict iff they share a dynamic body).  Jones-Plassmann rounds with fixed hashed priorities: a contact whose
+// priority beats every still-uncoloured neighbour takes the smallest colour none of its neighbours holds.  Two such contacts
+// are never adjacent, so a round is race free in place.  colour+1 is stored where the exact mode stores the dependency level,
+// and the same executor runs colour classes in order: a valid Gauss-Seidel sweep (a different one than the reference's; on
+// chaotic scenes that is the statistical-parity regime), with ~max-degree classes instead of one level per
+// link of the longest dependency chain.
+__global__ void k_level_reset_progress(nh_DevState* st) { st->unleveled = 0; st->unleveled_odd = 0; }
+
+__device__ __forceinline__ uint32_t colour_priority(uint32_t c) { uint32_t h = c * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; return h; }
+
+__global__ __launch_bounds__(256) void k_colour_round(nh_DevState* __restrict__ st, const uint32_t* __restrict__ general_list, const nh_BodyPair* __restrict__ bodies,
+                                                      const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj, uint32_t* __restrict__ level, uint32_t round) {
+	uint32_t n = st->general_contacts;
+	uint32_t left = 0, lmax = 0;
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		uint32_t c = general_list[k];
+		if (__hip_atomic_load(&level[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != NH_UNSET) continue;
+		const uint32_t pc = colour_priority(c);
+		nh_BodyPair p = bodies[c];
+		bool is_max = true;
+		unsigned long long used = 0ull;        // colours 1..64 held by neighbours
+		bool overflow = false;
+		for (int side = 0; side < 2 && is_max; ++side) {
+			uint32_t x = side ? p.b : p.a;
+			if (!x) continue;
+			uint32_t b = off[x], e = off[x + 1];
+			for (uint32_t q = b; q < e; ++q) {
+				uint32_t m = adj[q];
+				if (m == c) continue;
+				uint32_t lm = __hip_atomic_load(&level[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (lm == NH_UNSET) {
+					uint32_t pm = colour_priority(m);
+					if (pm > pc || (pm == pc && m > c)) { is_max = false; break; }
+				} else if (lm >= 1 && lm <= 64) {
+					used |= 1ull << (lm - 1);
+				} else if (lm > 64) {
+					overflow = true;
+				}
+			}
+		}
+		if (!is_max) { ++left; continue; }
+		uint32_t colour;
+		if (~used) colour = (uint32_t)__ffsll((long long)~used);          // smallest free colour in 1..64
+		else { colour = 65; overflow = true; }
+		if (overflow && colour > 64) {
+			// more than 64 colours around one contact: fall back to "one past the largest neighbour colour"
+			uint32_t mx = 64;
+			for (int side = 0; side < 2; ++side) {
+				uint32_t x = side ? p.b : p.a;
+				if (!x) continue;
+				for (uint32_t q = off[x]; q < off[x + 1]; ++q) {
+					uint32_t lm = __hip_atomic_load(&level[adj[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (lm != NH_UNSET && lm > mx) mx = lm;
+				}
+			}
+			colour = mx + 1;
+		}
+		__hip_atomic_store(&level[c], colour, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		lmax = max(lmax, colour);
+	}
+	block_report(st, left, lmax, round);
+}
+
+// counting sort of the general contacts by level / colour.  Levels are few and hot: histogram and cursors are kept per
+// workgroup in LDS, global atomics happen once per (workgroup, level).
 __global__ __launch_bounds__(256) void k_level_hist(nh_DevState* __restrict__ st, const uint32_t* __restrict__ general_list, const uint32_t* __restrict__ level, uint32_t* __restrict__ hist) {
+	__shared__ uint32_t h[NH_MAX_LEVELS + 2];
+	for (uint32_t l = threadIdx.x; l < NH_MAX_LEVELS + 2; l += blockDim.x) h[l] = 0;
+	__syncthreads();
 	uint32_t n = st->general_contacts;
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
 		uint32_t l = level[general_list[k]];
-		if (l <= NH_MAX_LEVELS) atomicAdd(&hist[l], 1u); else st->error = NH_ERR_INVALID;
+		if (l <= NH_MAX_LEVELS) atomicAdd(&h[l], 1u); else st->error = NH_ERR_INVALID;
 	}
+	__syncthreads();
+	for (uint32_t l = threadIdx.x; l < NH_MAX_LEVELS + 2; l += blockDim.x) if (h[l]) atomicAdd(&hist[l], h[l]);
 }
 
-__global__ void k_level_offsets(uint32_t* __restrict__ hist /* NH_MAX_LEVELS+2: in counts, out exclusive offsets */, uint32_t* __restrict__ cursor) {
-	if (threadIdx.x || blockIdx.x) return;
-	uint32_t run = 0;
-	for (uint32_t l = 0; l <= NH_MAX_LEVELS + 1; ++l) { uint32_t v = hist[l]; hist[l] = run; cursor[l] = run; run += v; }
+__global__ __launch_bounds__(1024) void k_level_offsets(uint32_t* __restrict__ hist /* NH_MAX_LEVELS+2: in counts, out exclusive offsets */, uint32_t* __restrict__ cursor) {
+	__shared__ uint32_t wsum[16];
+	const uint32_t per = (NH_MAX_LEVELS + 2 + 1023) / 1024;
+	uint32_t base = threadIdx.x * per, s = 0;
+	for (uint32_t i = 0; i < per; ++i) if (base + i < NH_MAX_LEVELS + 2) s += hist[base + i];
+	uint32_t x = s;
+	for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d); if ((int)(threadIdx.x & 63) >= d) x += y; }
+	if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+	__syncthreads();
+	uint32_t woff = 0;
+	for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) woff += wsum[w];
+	uint32_t run = woff + x - s;
+	for (uint32_t i = 0; i < per; ++i) if (base + i < NH_MAX_LEVELS + 2) { uint32_t v = hist[base + i]; hist[base + i] = run; cursor[base + i] = run; run += v; }
 }
 
 __global__ __launch_bounds__(256) void k_level_scatter(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ general_list, const uint32_t* __restrict__ level, uint32_t* __restrict__ cursor, uint32_t* __restrict__ order) {
+	__shared__ uint32_t h[NH_MAX_LEVELS + 2];
+	for (uint32_t l = threadIdx.x; l < NH_MAX_LEVELS + 2; l += blockDim.x) h[l] = 0;
+	__syncthreads();
 	uint32_t n = st->general_contacts;
-	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+	// each workgroup owns a contiguous chunk so that both passes see the same contacts
+	uint32_t chunk = (n + gridDim.x - 1) / gridDim.x;
+	uint32_t begin = min(blockIdx.x * chunk, n), end = min(begin + chunk, n);
+	for (uint32_t k = begin + threadIdx.x; k < end; k += blockDim.x) {
+		uint32_t l = level[general_list[k]];
+		if (l <= NH_MAX_LEVELS) atomicAdd(&h[l], 1u);
+	}
+	__syncthreads();
+	for (uint32_t l = threadIdx.x; l < NH_MAX_LEVELS + 2; l += blockDim.x) { uint32_t c = h[l]; h[l] = c ? atomicAdd(&cursor[l], c) : 0u; }
+	__syncthreads();
+	for (uint32_t k = begin + threadIdx.x; k < end; k += blockDim.x) {
 		uint32_t c = general_list[k];
 		uint32_t l = level[c];
-		if (l <= NH_MAX_LEVELS) order[atomicAdd(&cursor[l], 1u)] = c;
+		if (l <= NH_MAX_LEVELS) order[atomicAdd(&h[l], 1u)] = c;
 	}
 }
 
@@ -770,23 +880,26 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 		NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, general_list, contacts->data, contacts->bodies, bodies->transforms, bodies->properties, d->rows);
 		// relaxation: every round finalises at least the next level
 		uint32_t rounds = 0;
+		NH_LAUNCH(ctx, "level_reset", k_level_reset_progress, 1, 1, st);
 		for (;;) {
-			for (int r = 0; r < 8; ++r) {
-				NH_LAUNCH(ctx, "level_reset", k_level_reset_progress, 1, 1, st);
-				NH_LAUNCH(ctx, "level_relax", k_level_relax, nh_grid_for(G, 256, 4096), 256, st, general_list, pred_a, pred_b, level);
+			for (int r = 0; r < 8; ++r, ++rounds) {
+				if (ctx->flags & NH_FLAG_EXACT_ORDER)
+					NH_LAUNCH(ctx, "level_relax", k_level_relax, nh_grid_for(G, 256, 1024), 256, st, general_list, pred_a, pred_b, level, rounds);
+				else
+					NH_LAUNCH(ctx, "colour_round", k_colour_round, nh_grid_for(G, 256, 1024), 256, st, general_list, contacts->bodies, d->body_off, d->adj, level, rounds);
 			}
-			rounds += 8;
 			rc = nh_read_counts(ctx, &c);
 			if (rc) return rc;
-			if (c.unleveled == 0) break;
+			uint32_t left = ((rounds - 1) & 1u) ? ctx->h_state->unleveled_odd : ctx->h_state->unleveled;
+			if (left == 0) break;
 			if (rounds > NH_MAX_LEVELS + 8) return NH_ERR_INVALID;
 		}
 		if (c.levels > NH_MAX_LEVELS) return NH_ERR_INVALID;
 		d->levels = c.levels;
 		NH_LAUNCH(ctx, "zero_u32", k_zero_u32, 8, 256, level_hist, NH_MAX_LEVELS + 2);
-		NH_LAUNCH(ctx, "level_hist", k_level_hist, nh_grid_for(G, 256, 4096), 256, st, general_list, level, level_hist);
-		NH_LAUNCH(ctx, "level_offsets", k_level_offsets, 1, 1, level_hist, level_cursor);
-		NH_LAUNCH(ctx, "level_scatter", k_level_scatter, nh_grid_for(G, 256, 4096), 256, st, general_list, level, level_cursor, d->level_order);
+		NH_LAUNCH(ctx, "level_hist", k_level_hist, nh_grid_for(G, 256, 512), 256, st, general_list, level, level_hist);
+		NH_LAUNCH(ctx, "level_offsets", k_level_offsets, 1, 1024, level_hist, level_cursor);
+		NH_LAUNCH(ctx, "level_scatter", k_level_scatter, nh_grid_for(G, 256, 512), 256, st, general_list, level, level_cursor, d->level_order);
 		NH_HIP_CHECK(ctx, hipMemcpyAsync(d->level_off, level_hist, sizeof(uint32_t) * (d->levels + 2), hipMemcpyDeviceToHost, ctx->stream));
 		NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 		// warm start in level order (levels are numbered from 1)
