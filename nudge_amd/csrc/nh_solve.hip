@@ -172,7 +172,8 @@ __device__ __forceinline__ uint32_t slot_key_of(uint32_t i, const uint32_t* __re
 // one lane per body: sort its contact list by slot key, classify; bodies off the fast path also record per-contact predecessors
 __global__ __launch_bounds__(256) void k_adj_sort(nh_DevState* __restrict__ st, uint32_t nbodies, const nh_BodyPair* __restrict__ bodies, const uint32_t* __restrict__ off,
                                                   uint32_t* __restrict__ adj, const uint32_t* __restrict__ slot_key, uint8_t* __restrict__ body_class,
-                                                  uint32_t* __restrict__ pred_a, uint32_t* __restrict__ pred_b, uint32_t* __restrict__ static_list) {
+                                                  uint32_t* __restrict__ pred_a, uint32_t* __restrict__ pred_b,
+                                                  const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum) {
 	uint32_t rounded = (nbodies + 63u) & ~63u;
 	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < rounded; x += gridDim.x * blockDim.x) {
 		uint32_t cls = 0, d = 0;
@@ -238,10 +239,13 @@ __global__ __launch_bounds__(256) void k_adj_sort(nh_DevState* __restrict__ st, 
 			body_class[x] = (uint8_t)cls;
 			if (cls == NH_CLS_STATIC8) st->has_static8 = 1;
 			if (cls == NH_CLS_STATICN) st->has_staticN = 1;
+			// the reference stashes mass_inverse in momentum.unused0 of EVERY body (nudge.cpp:4198); bodies with contacts
+			// get it from the solver's velocity write-back, the rest here
+			if (cls == NH_CLS_NONE) momentum[x].unused0 = props[x].mass_inverse;
 		} else if (x == 0 && nbodies) {
 			body_class[0] = 0;
+			momentum[0].unused0 = props[0].mass_inverse;
 		}
-		(void)static_list;
 	}
 }
 
@@ -858,7 +862,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	nh_scan_u32(ctx, d->body_off, d->body_off, &st->pad0, B + 1, tmp, nullptr);
 	NH_LAUNCH(ctx, "adjacency_fill", k_adj_fill, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, contacts->tags, d->body_off, cursor, d->adj);
 	if (slot_key) NH_LAUNCH(ctx, "greedy_replay", k_greedy_replay, 1, 64, st, contacts->bodies, slot_key);
-	NH_LAUNCH(ctx, "adjacency_sort", k_adj_sort, nh_grid_for(B, 256, 4096), 256, st, B, contacts->bodies, d->body_off, d->adj, slot_key, d->body_class, pred_a, pred_b, d->static_bodies);
+	NH_LAUNCH(ctx, "adjacency_sort", k_adj_sort, nh_grid_for(B, 256, 4096), 256, st, B, contacts->bodies, d->body_off, d->adj, slot_key, d->body_class, pred_a, pred_b, bodies->properties, bodies->momentum);
 	NH_LAUNCH(ctx, "contact_class", k_contact_class, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, d->body_class, level, general_list, pred_a, pred_b);
 	NH_LAUNCH(ctx, "setup_static", (k_setup_static<false>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj,
 	          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states, (const uint32_t*)nullptr);

@@ -1,0 +1,132 @@
+// tests/callsite/replay.cpp -- a CALL SITE of the reference API, written once, linked twice.
+//
+// This is what an adopter's code looks like: it includes the reference's `nudge.h`, owns every array in host
+// memory (reference layouts, 16-bit indices), and drives one sub-step the way the reference's sample does
+// (call order and arena handling of example/main.cpp:274-328; the gravity/damping loop runs on the host between
+// collide() and read_cached_impulses()).  tests/callsite/Makefile links this file
+//   (a) against the reference's own nudge.cpp                    -> oracle/_ref/replay_ref   (the checker)
+//   (b) against nudge_amd/compat/nudge_compat.cpp + libnudge_hip -> nudge_amd/compat/_build/replay_hip
+// and tests/test_gpu_callsite.py requires the two binaries to produce bit-identical worlds.
+//
+// usage: replay <scene.bin> <out.bin> <steps>
+// scene.bin: u32 header { bodies, boxes, spheres, iterations, max_contacts } + f32 { time_step, gravity, damping_rate }
+//            then Transform[bodies] BodyProperties[bodies] BodyMomentum[bodies] u8 idle[bodies]
+//            u16 box_tags[boxes] BoxCollider[boxes] Transform[boxes] u16 sphere_tags[spheres] SphereCollider[spheres] Transform[spheres]
+// out.bin:   Transform[bodies] BodyMomentum[bodies] u8 idle[bodies] u64 sum_of_contact_counts u32 last_contact_count u32 last_active_count
+#include <nudge.h>
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+template<class T>
+static T* aligned_array(size_t n) {
+	void* p = nullptr;
+	if (posix_memalign(&p, 64, sizeof(T) * (n ? n : 1) + 64)) abort();
+	memset(p, 0, sizeof(T) * (n ? n : 1) + 64);
+	return static_cast<T*>(p);
+}
+
+template<class T>
+static void read_array(FILE* f, T* dst, size_t n) {
+	if (n && fread(dst, sizeof(T), n, f) != n) { fprintf(stderr, "replay: short scene file\n"); exit(2); }
+}
+
+int main(int argc, char** argv) {
+	if (argc < 4) { fprintf(stderr, "usage: %s scene.bin out.bin steps\n", argv[0]); return 2; }
+	FILE* f = fopen(argv[1], "rb");
+	if (!f) { perror(argv[1]); return 2; }
+	uint32_t head[5];
+	float par[3];
+	read_array(f, head, 5);
+	read_array(f, par, 3);
+	const uint32_t nb = head[0], nbox = head[1], nsph = head[2], iterations = head[3], max_contacts = head[4];
+	const float time_step = par[0], gravity = par[1], damping_rate = par[2];
+	const unsigned steps = (unsigned)atoi(argv[3]);
+
+	nudge::BodyData bodies = {};
+	bodies.transforms = aligned_array<nudge::Transform>(nb);
+	bodies.properties = aligned_array<nudge::BodyProperties>(nb);
+	bodies.momentum = aligned_array<nudge::BodyMomentum>(nb);
+	bodies.idle_counters = aligned_array<uint8_t>(nb);
+	bodies.count = nb;
+	read_array(f, bodies.transforms, nb);
+	read_array(f, bodies.properties, nb);
+	read_array(f, bodies.momentum, nb);
+	read_array(f, bodies.idle_counters, nb);
+
+	nudge::ColliderData colliders = {};
+	colliders.boxes.tags = aligned_array<uint16_t>(nbox);
+	colliders.boxes.data = aligned_array<nudge::BoxCollider>(nbox);
+	colliders.boxes.transforms = aligned_array<nudge::Transform>(nbox);
+	colliders.boxes.count = nbox;
+	read_array(f, colliders.boxes.tags, nbox);
+	read_array(f, colliders.boxes.data, nbox);
+	read_array(f, colliders.boxes.transforms, nbox);
+	colliders.spheres.tags = aligned_array<uint16_t>(nsph);
+	colliders.spheres.data = aligned_array<nudge::SphereCollider>(nsph);
+	colliders.spheres.transforms = aligned_array<nudge::Transform>(nsph);
+	colliders.spheres.count = nsph;
+	read_array(f, colliders.spheres.tags, nsph);
+	read_array(f, colliders.spheres.data, nsph);
+	read_array(f, colliders.spheres.transforms, nsph);
+	fclose(f);
+
+	nudge::ContactData contacts = {};
+	contacts.data = aligned_array<nudge::Contact>(max_contacts);
+	contacts.bodies = aligned_array<nudge::BodyPair>(max_contacts);
+	contacts.tags = aligned_array<uint64_t>(max_contacts);
+	contacts.sleeping_pairs = aligned_array<uint32_t>(max_contacts);
+	contacts.capacity = max_contacts;
+
+	nudge::ContactCache cache = {};
+	cache.tags = aligned_array<uint64_t>(max_contacts);
+	cache.data = aligned_array<nudge::CachedContactImpulse>(max_contacts);
+	cache.capacity = max_contacts;
+
+	nudge::ActiveBodies active = {};
+	active.indices = aligned_array<uint16_t>(nb);
+	active.capacity = nb;
+
+	nudge::Arena arena = {};
+	arena.size = ((size_t)64 << 20) + (size_t)max_contacts * 1400;
+	arena.data = aligned_array<uint8_t>(arena.size);
+
+	uint64_t sum_contacts = 0;
+	for (unsigned n = 0; n < steps; ++n) {
+		nudge::Arena temporary = arena;                       // same scratch every sub-step
+		nudge::BodyConnections connections = {};
+		nudge::collide(&active, &contacts, bodies, colliders, connections, temporary);
+		sum_contacts += contacts.count;
+
+		// caller-side gravity and damping over the active list
+		const float damping = 1.0f - time_step * damping_rate;
+		for (unsigned i = 0; i < active.count; ++i) {
+			nudge::BodyMomentum& m = bodies.momentum[active.indices[i]];
+			m.velocity[1] -= gravity * time_step;
+			for (int k = 0; k < 3; ++k) { m.velocity[k] *= damping; m.angular_velocity[k] *= damping; }
+		}
+
+		nudge::ContactImpulseData* impulses = nudge::read_cached_impulses(cache, contacts, &temporary);
+		nudge::ContactConstraintData* constraints = nudge::setup_contact_constraints(active, contacts, bodies, impulses, &temporary);
+		for (unsigned i = 0; i < iterations; ++i)
+			nudge::apply_impulses(constraints, bodies);
+		nudge::update_cached_impulses(constraints, impulses);
+		nudge::write_cached_impulses(&cache, contacts, impulses);
+		nudge::advance(active, bodies, time_step);
+	}
+
+	FILE* o = fopen(argv[2], "wb");
+	if (!o) { perror(argv[2]); return 2; }
+	fwrite(bodies.transforms, sizeof(nudge::Transform), nb, o);
+	fwrite(bodies.momentum, sizeof(nudge::BodyMomentum), nb, o);
+	fwrite(bodies.idle_counters, 1, nb, o);
+	fwrite(&sum_contacts, 8, 1, o);
+	fwrite(&contacts.count, 4, 1, o);
+	fwrite(&active.count, 4, 1, o);
+	fclose(o);
+	printf("replay: %u steps, %u bodies, last step %u contacts, %u active, sum of contacts %llu\n", steps, nb, contacts.count, active.count, (unsigned long long)sum_contacts);
+	return 0;
+}

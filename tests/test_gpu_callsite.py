@@ -1,0 +1,68 @@
+"""The drop-in boundary in the reference's own language: C++ call sites of `namespace nudge` (nudge.h:134-146),
+linked against the GPU backend (nudge_amd/compat/nudge_compat.cpp over the C ABI of include/nudge_hip.h).
+
+  * tests/callsite/replay.cpp is one call site compiled twice -- against the reference's nudge.cpp (exact-math
+    variant, the checker) and against the drop-in; both must leave bit-identical worlds;
+  * the reference's OWN test program (tests/main.cpp: 6 known-answer / property tests of collide) runs unmodified
+    on the drop-in.
+The binaries are built where the reference's header exists (`make -C nudge_amd/compat`, `make -C oracle`) and travel
+with the repository; the tests fail, not skip, when a GPU is present and they are missing.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import callsite_util as CU      # noqa: E402
+import make_golden as G         # noqa: E402
+import parity_util as P         # noqa: E402
+from oracle import refworld     # noqa: E402
+
+
+def test_replay_call_site_is_the_reference_step_loop(tmp_path):
+    """CPU: replay.cpp linked against the reference reproduces the golden fixture (so it IS a faithful call site)."""
+    if not os.path.exists(CU.REPLAY_REF):
+        pytest.skip("oracle/_ref/replay_ref not built (needs /root/reference)")
+    scene, steps = G.build("pile256")
+    nb = CU.write_scene(str(tmp_path / "s.bin"), scene)
+    CU.run_replay(CU.REPLAY_REF, str(tmp_path / "s.bin"), str(tmp_path / "o.bin"), steps)
+    r = CU.read_result(str(tmp_path / "o.bin"), nb)
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pile256.npz"))
+    assert P.bits_equal(r["transforms"], fx["transforms"])
+    assert P.bits_equal(r["momentum"]["velocity"], fx["momentum"]["velocity"])
+    assert P.bits_equal(r["idle"], fx["idle"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["pile256", "pile_mixed", "mixed20", "stacks", "pit6"])
+def test_same_call_site_two_backends_bit_identical(name, tmp_path):
+    assert os.path.exists(CU.REPLAY_HIP), "nudge_amd/compat/_build/replay_hip missing: make -C nudge_amd/compat"
+    scene, steps = G.build(name)
+    steps = min(steps, 150)
+    nb = CU.write_scene(str(tmp_path / "s.bin"), scene)
+    CU.run_replay(CU.REPLAY_HIP, str(tmp_path / "s.bin"), str(tmp_path / "hip.bin"), steps)
+    got = CU.read_result(str(tmp_path / "hip.bin"), nb)
+    if os.path.exists(CU.REPLAY_REF):
+        CU.run_replay(CU.REPLAY_REF, str(tmp_path / "s.bin"), str(tmp_path / "ref.bin"), steps)
+        ref = CU.read_result(str(tmp_path / "ref.bin"), nb)
+    else:
+        assert refworld.available("exact"), "neither oracle/_ref/replay_ref nor the compiled reference travelled with the repo"
+        w = refworld.RefWorld(scene)
+        w.step(steps)
+        b = w.bodies()
+        ref = dict(transforms=b["transforms"], momentum=b["momentum"], idle=b["idle"], sum_contacts=w.sum_contacts(), last_contacts=None, last_active=None)
+    assert P.bits_equal(got["transforms"], ref["transforms"])
+    assert P.bits_equal(got["momentum"], ref["momentum"])          # including unused0 = mass_inverse (nudge.cpp:4198)
+    assert P.bits_equal(got["idle"], ref["idle"])
+    assert got["sum_contacts"] == ref["sum_contacts"]
+
+
+@pytest.mark.gpu
+def test_reference_own_test_program_passes_on_the_gpu_backend():
+    assert os.path.exists(CU.REF_TESTS_HIP), "nudge_amd/compat/_build/ref_tests_hip missing: make -C nudge_amd/compat"
+    r = subprocess.run([CU.REF_TESTS_HIP], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "All tests passed." in r.stdout
