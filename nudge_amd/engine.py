@@ -136,7 +136,9 @@ def _check(L, rc, what):
 class World:
     """A world resident in HBM, stepped through the C ABI.  `scene` uses the layouts of nudge_amd.scenes."""
 
-    def __init__(self, scene, device=0, max_contacts=None, arena_bytes=None, flags=NH_FLAG_SYNC_COUNTS, tag_bits=None):
+    def __init__(self, scene, device=0, max_contacts=None, arena_bytes=None, flags=NH_FLAG_SYNC_COUNTS, tag_bits=None, capacity=None):
+        """`capacity` = dict(bodies=, boxes=, spheres=): allocate room for more records than the scene holds (the
+        partitioned world appends ghost / migrated bodies, nudge_amd/partition.py); counts then change via set_counts()."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("nudge_amd.World needs a HIP device (no CPU fallback)")
@@ -150,12 +152,15 @@ class World:
         if max_contacts is None:
             max_contacts = max(4096, 8 * nb)
         self.nb, self.nbox, self.nsph, self.max_contacts = nb, nbox, nsph, max_contacts
+        capacity = capacity or {}
+        cap_b, cap_x, cap_s = max(nb, capacity.get("bodies", 0)), max(nbox, capacity.get("boxes", 0)), max(nsph, capacity.get("spheres", 0))
+        self.capacity = dict(bodies=cap_b, boxes=cap_x, spheres=cap_s)
         self._keep = {}
 
-        def up(name, arr, min_bytes=16):
+        def up(name, arr, min_bytes=16, cap=0):
             a = np.ascontiguousarray(arr)
             raw = a.view(np.uint8).reshape(-1)
-            t = torch.zeros(max(raw.size, min_bytes), dtype=torch.uint8, device=self.dev)
+            t = torch.zeros(max(raw.size, min_bytes, cap * a.dtype.itemsize), dtype=torch.uint8, device=self.dev)
             if raw.size:
                 t[:raw.size] = torch.from_numpy(raw.copy()).to(self.dev)
             self._keep[name] = t
@@ -166,20 +171,23 @@ class World:
             self._keep[name] = t
             return t
 
-        self.bodies = BodyData(up("bt", scene["body_transforms"]).data_ptr(), up("bp", scene["body_properties"]).data_ptr(),
-                               up("bm", scene["body_momentum"]).data_ptr(), up("bi", scene["idle_counters"]).data_ptr(), nb)
+        self.bodies = BodyData(up("bt", scene["body_transforms"], cap=cap_b).data_ptr(), up("bp", scene["body_properties"], cap=cap_b).data_ptr(),
+                               up("bm", scene["body_momentum"], cap=cap_b).data_ptr(), up("bi", scene["idle_counters"], cap=cap_b).data_ptr(), nb)
         self.colliders = ColliderData(
-            _Shapes(up("xt", scene["box_tags"].astype(np.uint32)).data_ptr(), up("xd", scene["box_data"]).data_ptr(), up("xx", scene["box_transforms"]).data_ptr(), nbox),
-            _Shapes(up("st", scene["sphere_tags"].astype(np.uint32)).data_ptr(), up("sd", scene["sphere_data"]).data_ptr(), up("sx", scene["sphere_transforms"]).data_ptr(), nsph))
+            _Shapes(up("xt", scene["box_tags"].astype(np.uint32), cap=cap_x).data_ptr(), up("xd", scene["box_data"], cap=cap_x).data_ptr(),
+                    up("xx", scene["box_transforms"], cap=cap_x).data_ptr(), nbox),
+            _Shapes(up("st", scene["sphere_tags"].astype(np.uint32), cap=cap_s).data_ptr(), up("sd", scene["sphere_data"], cap=cap_s).data_ptr(),
+                    up("sx", scene["sphere_transforms"], cap=cap_s).data_ptr(), nsph))
         con = np.asarray(scene.get("connections", np.zeros((0, 2), np.uint32)), dtype=np.uint32).reshape(-1, 2)
         self.connections = BodyConnections(up("cn", con).data_ptr(), len(con))
         K = max_contacts
         self.contacts = ContactData(alloc("cd", 32 * K).data_ptr(), alloc("cb", 8 * K).data_ptr(), alloc("ct", 8 * K).data_ptr(),
                                     alloc("cf", 4 * K).data_ptr(), K, 0, alloc("cs", 8 * K).data_ptr(), 0)
         self.cache = ContactCache(alloc("kt", 8 * K).data_ptr(), alloc("kf", 4 * K).data_ptr(), alloc("kd", 16 * K).data_ptr(), K, 0)
-        self.active = ActiveBodies(alloc("ai", 4 * nb).data_ptr(), nb, 0)
+        self.active = ActiveBodies(alloc("ai", 4 * cap_b).data_ptr(), cap_b, 0)
         if arena_bytes is None:
-            ncol = nbox + nsph
+            ncol = cap_x + cap_s
+            nb = cap_b
             cells = 1
             while cells < 4 * ncol:
                 cells <<= 1
@@ -259,6 +267,22 @@ class World:
             self.steps_done += 1
             if self.flags & NH_FLAG_SYNC_COUNTS:
                 self.sum_contacts += self.contacts.count
+
+    # ---- variable membership (partitioned worlds) ----
+    def set_counts(self, bodies, boxes, spheres):
+        c = self.capacity
+        if bodies > c["bodies"] or boxes > c["boxes"] or spheres > c["spheres"]:
+            raise NudgeError(f"set_counts({bodies}, {boxes}, {spheres}) exceeds the capacity {c}")
+        self.nb, self.nbox, self.nsph = bodies, boxes, spheres
+        self.bodies.count = bodies
+        self.colliders.boxes.count = boxes
+        self.colliders.spheres.count = spheres
+
+    def records(self, name, record_bytes):
+        """Device tensor behind one caller-owned array, as [capacity, record_bytes] uint8 (no copy)."""
+        t = self._keep[name]
+        n = t.numel() // record_bytes
+        return t[:n * record_bytes].view(n, record_bytes)
 
     # ---- state ----
     def synchronize(self):

@@ -1,0 +1,435 @@
+"""Spatial partition of one world across ranks: x-slabs, ghost-body halo exchange, migration.
+
+Every rank steps an ordinary world through the C ABI (nudge_amd.engine.World) that holds
+    slot 0            the static body with ALL static colliders (replicated: ground slabs / walls are few),
+    slots 1..n_owned  the dynamic bodies whose centre lies in the rank's slab [lo, hi)  -- authoritative here,
+    the tail          GHOSTS: read-only copies of neighbour-owned bodies that may touch something owned here.
+A step is  [halo exchange]  ->  collide .. advance on the local world.  Nothing else crosses ranks: there is no
+collective on the data path, only neighbour point-to-point messages (RCCL send/recv over xGMI when the tensors are
+on the GPU, gloo on the CPU tests).
+
+The exchange is epoch based so that the per-step cost is three gathers, one message per neighbour and three
+contiguous copies:
+  * every `epoch` steps (and at step 0) -- REFRESH: bodies whose centre left the slab migrate to the neighbour
+    (full record: transform, properties, momentum, idle counter, collider shape / local transform / tag); then every
+    rank lists the owned bodies that can reach across a cut within the coming epoch,
+        distance to the cut  <  reach(body) + max reach of any body + epoch * dt * speed bound,
+    and sends their full records once; both sides remember the list;
+  * every step: the dynamic part (transform, momentum, idle counter; 68 B) of the listed bodies is sent, the
+    receiver overwrites its ghost slots.  Ghosts are integrated locally as well (they are ordinary bodies to the
+    engine) and corrected by the owner's state at the next step.
+Contacts between an owned body and a ghost are solved on BOTH ranks, each against its own picture of the other
+body's island; the owner's result is the one that survives.  With no cross-cut contacts (drop scenes: config 5)
+the partitioned world reproduces the single world exactly up to the broadphase frame; with cross-cut contacts it is
+an overlapping-subdomain (Schwarz) Gauss-Seidel -- a valid solver whose result differs from the single-world sweep
+in the chaotic regime.  The warm-start cache follows a body for free: it is keyed by collider
+tags, and a body is a ghost on the new owner before it migrates there.
+
+Restriction: a dynamic body carries exactly ONE collider (any local transform); static colliders are unrestricted.
+
+Transport is pluggable: `LocalCluster` moves tensors between partitions living in one process (tests, one GPU),
+`DistCluster` uses torch.distributed point-to-point ops (one process per GPU).  The same `Partition` code runs in both.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import scenes as S
+
+FULL_BYTES = 32 + 16 + 32 + 16 + 32 + 4 + 4        # transform, properties, momentum, shape, collider transform, tag, (kind, idle)
+STEP_BYTES = 32 + 32 + 4                          # transform, momentum, idle
+
+
+def body_reach(scene):
+    """Per dynamic body: distance from the body origin to the farthest point of its collider; raises unless every
+    dynamic body has exactly one collider.  Returns (kind[B], collider_index[B], reach[B]) with kind 0 box / 1 sphere."""
+    nb = len(scene["body_transforms"])
+    kind = np.full(nb, 255, dtype=np.uint8)
+    cidx = np.zeros(nb, dtype=np.int64)
+    reach = np.zeros(nb, dtype=np.float32)
+    for k, (xf, data) in enumerate(((scene["box_transforms"], scene["box_data"]), (scene["sphere_transforms"], scene["sphere_data"]))):
+        body = xf["body"].astype(np.int64)
+        dyn = np.flatnonzero(body > 0)
+        if len(dyn) and (kind[body[dyn]] != 255).any() or len(np.unique(body[dyn])) != len(dyn):
+            raise ValueError("partitioned worlds need exactly one collider per dynamic body")
+        kind[body[dyn]] = k
+        cidx[body[dyn]] = dyn
+        off = np.linalg.norm(xf["position"][dyn].astype(np.float64), axis=1)
+        ext = np.linalg.norm(data["size"][dyn].astype(np.float64), axis=1) if k == 0 else data["radius"][dyn].astype(np.float64)
+        reach[body[dyn]] = (off + ext).astype(np.float32) * np.float32(1.0001)
+    if (kind[1:] == 255).any():
+        raise ValueError("partitioned worlds need exactly one collider per dynamic body")
+    return kind, cidx, reach
+
+
+def split_scene(scene, cuts, rank, slack=0.15, min_extra=4096):
+    """Rank `rank`'s initial local scene for slabs bounded by `cuts` (ascending x, len = ranks - 1).
+    Returns (local_scene, info) where info holds what `Partition` needs besides the engine arrays."""
+    kind, cidx, reach = body_reach(scene)
+    x = scene["body_transforms"]["position"][:, 0]
+    lo = -np.inf if rank == 0 else cuts[rank - 1]
+    hi = np.inf if rank == len(cuts) else cuts[rank]
+    owned = np.flatnonzero((x >= lo) & (x < hi) & (np.arange(len(x)) > 0))
+    body_map = np.concatenate([[0], owned]).astype(np.int64)
+    n = len(body_map)
+
+    local = dict(name=f"{scene.get('name', 'scene')}/rank{rank}", params=dict(scene["params"]))
+    for k in ("body_transforms", "body_properties", "body_momentum", "idle_counters"):
+        local[k] = scene[k][body_map].copy()
+    local["body_transforms"]["body"] = body_map.astype(np.uint32)          # global id rides in the unused field (nudge.h:36)
+
+    def pick(prefix, k):
+        xf = scene[prefix + "_transforms"]
+        static = np.flatnonzero(xf["body"] == 0)
+        dyn_local = np.flatnonzero(kind[body_map[1:]] == k) + 1             # local body slots with a collider of this kind
+        sel = np.concatenate([static, cidx[body_map[dyn_local]]]).astype(np.int64)
+        t = xf[sel].copy()
+        t["body"][len(static):] = dyn_local.astype(np.uint32)
+        return scene[prefix + "_tags"][sel].astype(np.uint32), scene[prefix + "_data"][sel].copy(), t, len(static)
+
+    local["box_tags"], local["box_data"], local["box_transforms"], n_static_box = pick("box", 0)
+    local["sphere_tags"], local["sphere_data"], local["sphere_transforms"], n_static_sph = pick("sphere", 1)
+
+    # body-parallel collider description (what travels with a body)
+    shape = np.zeros((n, 4), dtype=np.float32)
+    cxf = np.zeros(n, dtype=S.TRANSFORM)
+    tag = np.zeros(n, dtype=np.uint32)
+    kk = kind[body_map]
+    for k, prefix in ((0, "box"), (1, "sphere")):
+        sel = np.flatnonzero(kk[1:] == k) + 1
+        ci = cidx[body_map[sel]]
+        if k == 0:
+            shape[sel, :3] = scene["box_data"]["size"][ci]
+        else:
+            shape[sel, 0] = scene["sphere_data"]["radius"][ci]
+        cxf[sel] = scene[prefix + "_transforms"][ci]
+        tag[sel] = scene[prefix + "_tags"][ci]
+    extra = max(min_extra, int(slack * n))
+    info = dict(rank=rank, ranks=len(cuts) + 1, lo=float(lo), hi=float(hi), n_owned=n - 1, kind=kk.copy(), shape=shape, cxf=cxf, tag=tag,
+                reach=reach[body_map].copy(), max_reach=float(reach.max()) if len(reach) else 0.0,
+                n_static_box=n_static_box, n_static_sph=n_static_sph,
+                capacity=dict(bodies=n + extra, boxes=len(local["box_tags"]) + extra, spheres=len(local["sphere_tags"]) + extra),
+                tag_bits=max(8, int(max(int(scene["box_tags"].max()) if len(scene["box_tags"]) else 1,
+                                        int(scene["sphere_tags"].max()) if len(scene["sphere_tags"]) else 1)).bit_length()))
+    return local, info
+
+
+class Partition:
+    """One rank's share of the world.  `engine` exposes the caller-owned arrays as [capacity, record] uint8 torch
+    tensors (`records(name, bytes)`), `set_counts(bodies, boxes, spheres)`, `step(n)` and `params` -- nudge_amd.engine.World
+    does; the CPU tests plug the oracle in behind the same four members."""
+
+    def __init__(self, engine, info, epoch=16, speed_floor=1.0):
+        import torch
+        self.torch = torch
+        self.e = engine
+        self.rank, self.ranks = info["rank"], info["ranks"]
+        self.lo, self.hi = info["lo"], info["hi"]
+        self.n_owned = info["n_owned"]
+        self.n_static_box, self.n_static_sph = info["n_static_box"], info["n_static_sph"]
+        self.max_reach = info["max_reach"]
+        self.epoch, self.speed_floor = epoch, speed_floor
+        self.dt = float(engine.params["time_step"])
+        self.gravity = abs(float(engine.params["gravity"]))
+        r = engine.records
+        self.bt, self.bp, self.bm, self.bi = r("bt", 32), r("bp", 16), r("bm", 32), r("bi", 1)
+        self.xt, self.xd, self.xx = r("xt", 4), r("xd", 16), r("xx", 32)
+        self.st, self.sd, self.sx = r("st", 4), r("sd", 4), r("sx", 32)
+        dev = self.bt.device
+        cap = self.bt.shape[0]
+        n = self.n_owned + 1
+
+        def dev_rec(a, width):
+            t = torch.zeros((cap, width), dtype=torch.uint8, device=dev)
+            raw = np.ascontiguousarray(a).view(np.uint8).reshape(len(a), -1)
+            t[:n] = torch.from_numpy(raw.copy()).to(dev)
+            return t
+
+        # body-parallel collider description + reach
+        self.shape = dev_rec(info["shape"], 16)
+        self.cxf = dev_rec(info["cxf"], 32)
+        self.tag = dev_rec(info["tag"], 4)
+        self.kind = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        self.kind[:n] = torch.from_numpy(info["kind"].copy()).to(dev)
+        self.reach = torch.zeros(cap, dtype=torch.float32, device=dev)
+        self.reach[:n] = torch.from_numpy(info["reach"].copy()).to(dev)
+        self.ghost_out = {-1: None, +1: None}      # owned slots sent to the left / right neighbour every step
+        self.ghost_in = {-1: 0, +1: 0}             # ghost records received from the left / right neighbour
+        self.steps = 0
+        self.stats = dict(refreshes=0, migrated_out=0, migrated_in=0, ghosts=0, late_bodies=0, step_bytes=0, refresh_bytes=0)
+
+    # ---- helpers -------------------------------------------------------------------------------------------------
+    def neighbours(self):
+        return [d for d in (-1, +1) if 0 <= self.rank + d < self.ranks]
+
+    def _f32(self, rec):
+        return rec.view(self.torch.float32)
+
+    def _x(self, n):
+        return self._f32(self.bt[:n])[:, 0]
+
+    def _full(self, idx):
+        """Full records of the given body slots: [len, FULL_BYTES] uint8."""
+        t = self.torch
+        meta = t.zeros((len(idx), 4), dtype=t.uint8, device=idx.device)
+        meta[:, 0] = self.kind[idx]
+        meta[:, 1] = self.bi[idx, 0]
+        return t.cat([self.bt[idx], self.bp[idx], self.bm[idx], self.shape[idx], self.cxf[idx], self.tag[idx], meta], dim=1)
+
+    def _install_full(self, rec, at):
+        """Writes full records into body slots [at, at + len)."""
+        m = rec.shape[0]
+        s = slice(at, at + m)
+        o = 0
+        for dst, w in ((self.bt, 32), (self.bp, 16), (self.bm, 32), (self.shape, 16), (self.cxf, 32), (self.tag, 4)):
+            dst[s] = rec[:, o:o + w]
+            o += w
+        self.kind[s] = rec[:, o]
+        self.bi[s, 0] = rec[:, o + 1]
+        # reach is a function of the collider: |local offset| + extent
+        t = self.torch
+        off = self._f32(self.cxf[s])[:, :3].norm(dim=1)
+        sh = self._f32(self.shape[s])
+        ext = t.where(self.kind[s] == 0, sh[:, :3].norm(dim=1), sh[:, 0])
+        self.reach[s] = (off + ext) * 1.0001
+
+    def _step_records(self, idx):
+        t = self.torch
+        pad = t.zeros((len(idx), 4), dtype=t.uint8, device=idx.device)
+        pad[:, 0] = self.bi[idx, 0]
+        return t.cat([self.bt[idx], self.bm[idx], pad], dim=1)
+
+    # ---- refresh: phase 1 (migration) --------------------------------------------------------------------------
+    def refresh_pack_migrants(self):
+        t = self.torch
+        n = self.n_owned + 1
+        x = self._x(n)
+        own = t.arange(n, device=x.device) > 0
+        out = {}
+        self._leave = t.zeros(n, dtype=t.bool, device=x.device)
+        for d in self.neighbours():
+            m = own & ((x < self.lo) if d < 0 else (x >= self.hi))
+            idx = t.nonzero(m).flatten()
+            out[d] = self._full(idx)
+            self._leave |= m
+            self.stats["migrated_out"] += int(idx.numel())
+        return out
+
+    def refresh_unpack_migrants(self, incoming):
+        """Drops the bodies that left, appends the ones that arrived (owned region stays contiguous from slot 1)."""
+        t = self.torch
+        n = self.n_owned + 1
+        keep = t.nonzero(~self._leave).flatten()          # includes slot 0
+        if keep.numel() != n:
+            for arr in (self.bt, self.bp, self.bm, self.bi, self.shape, self.cxf, self.tag):
+                arr[:keep.numel()] = arr[keep]
+            self.kind[:keep.numel()] = self.kind[keep]
+            self.reach[:keep.numel()] = self.reach[keep]
+        at = int(keep.numel())
+        for d in self.neighbours():
+            rec = incoming.get(d)
+            if rec is not None and rec.shape[0]:
+                if at + rec.shape[0] > self.bt.shape[0]:
+                    raise RuntimeError("partition: body capacity exceeded by migration")
+                self._install_full(rec, at)
+                at += rec.shape[0]
+                self.stats["migrated_in"] += int(rec.shape[0])
+        self.n_owned = at - 1
+
+    # ---- refresh: phase 2 (ghost lists) ------------------------------------------------------------------------------
+    def refresh_pack_ghosts(self):
+        t = self.torch
+        n = self.n_owned + 1
+        x = self._x(n)
+        v = self._f32(self.bm[:n])[:, :3].norm(dim=1)
+        vmax = float(v[1:].max()) if n > 1 else 0.0
+        # how far anything can travel in one epoch: current top speed + free-fall gain, never below the floor
+        drift = self.epoch * self.dt * (max(vmax, self.speed_floor) + self.gravity * self.epoch * self.dt)
+        margin = self.reach[:n] + (self.max_reach + 2.0 * drift)
+        own = t.arange(n, device=x.device) > 0
+        out = {}
+        for d in self.neighbours():
+            m = own & ((x - margin < self.lo) if d < 0 else (x + margin >= self.hi))
+            idx = t.nonzero(m).flatten()
+            self.ghost_out[d] = idx
+            out[d] = self._full(idx)
+        self._drift = drift
+        return out
+
+    def refresh_unpack_ghosts(self, incoming):
+        at = self.n_owned + 1
+        for d in (-1, +1):
+            rec = incoming.get(d) if d in self.neighbours() else None
+            m = 0 if rec is None else int(rec.shape[0])
+            if at + m > self.bt.shape[0]:
+                raise RuntimeError("partition: body capacity exceeded by ghosts")
+            if m:
+                self._install_full(rec, at)
+            self.ghost_in[d] = m
+            at += m
+        self.n_bodies = at
+        self._rebuild_colliders()
+        self.stats["refreshes"] += 1
+        self.stats["ghosts"] = self.ghost_in[-1] + self.ghost_in[+1]
+
+    def _rebuild_colliders(self):
+        """Collider arrays = static colliders, then one collider per dynamic body slot (owned, then ghosts)."""
+        t = self.torch
+        n = self.n_bodies
+        kind = self.kind[:n]
+        slots = t.arange(n, device=kind.device)
+        counts = []
+        for k, (tags, data, xf, n_static, width) in enumerate(((self.xt, self.xd, self.xx, self.n_static_box, 16), (self.st, self.sd, self.sx, self.n_static_sph, 4))):
+            idx = t.nonzero((kind == k) & (slots > 0)).flatten()
+            m = int(idx.numel())
+            if n_static + m > tags.shape[0]:
+                raise RuntimeError("partition: collider capacity exceeded")
+            s = slice(n_static, n_static + m)
+            tags[s] = self.tag[idx]
+            data[s] = self.shape[idx][:, :width]
+            xf[s] = self.cxf[idx]
+            xf[s].view(t.int32)[:, 3] = idx.to(t.int32)               # Transform.body = local body slot (nudge.h:36)
+            counts.append(n_static + m)
+        self.e.set_counts(n, counts[0], counts[1])
+
+    # ---- every step ---------------------------------------------------------------------------------------------------
+    def step_pack(self):
+        out = {}
+        for d in self.neighbours():
+            rec = self._step_records(self.ghost_out[d])
+            out[d] = rec
+            self.stats["step_bytes"] += int(rec.numel())
+        return out
+
+    def step_unpack(self, incoming):
+        at = self.n_owned + 1
+        for d in (-1, +1):
+            m = self.ghost_in[d]
+            if m:
+                rec = incoming[d]
+                s = slice(at, at + m)
+                self.bt[s, :12] = rec[:, :12]                 # position
+                self.bt[s, 16:] = rec[:, 16:32]               # rotation (the `body` field keeps the global id)
+                self.bm[s] = rec[:, 32:64]
+                self.bi[s, 0] = rec[:, 64]
+            at += m
+
+    def local_step(self):
+        self.e.step(1)
+        self.steps += 1
+
+    def needs_refresh(self):
+        return self.steps % self.epoch == 0
+
+    # ---- results ------------------------------------------------------------------------------------------------------------
+    def owned_state(self):
+        """(global ids, transforms, momentum, idle) of the owned bodies, as numpy arrays."""
+        n = self.n_owned + 1
+        if hasattr(self.e, "synchronize"):
+            self.e.synchronize()
+        bt = np.frombuffer(self.bt[1:n].cpu().numpy().tobytes(), dtype=S.TRANSFORM).copy()
+        bm = np.frombuffer(self.bm[1:n].cpu().numpy().tobytes(), dtype=S.MOMENTUM).copy()
+        bi = self.bi[1:n, 0].cpu().numpy().copy()
+        return bt["body"].astype(np.int64), bt, bm, bi
+
+
+class LocalCluster:
+    """All partitions in one process (one GPU or the CPU): messages are tensor hand-overs."""
+
+    def __init__(self, partitions):
+        self.parts = partitions
+
+    def _route(self, outs):
+        ins = [dict() for _ in self.parts]
+        for r, out in enumerate(outs):
+            for d, rec in out.items():
+                ins[r + d][-d] = rec.clone()
+        return ins
+
+    def step(self, steps=1):
+        for _ in range(steps):
+            if self.parts[0].needs_refresh():
+                ins = self._route([p.refresh_pack_migrants() for p in self.parts])
+                for p, i in zip(self.parts, ins):
+                    p.refresh_unpack_migrants(i)
+                ins = self._route([p.refresh_pack_ghosts() for p in self.parts])
+                for p, i in zip(self.parts, ins):
+                    p.refresh_unpack_ghosts(i)
+            else:
+                ins = self._route([p.step_pack() for p in self.parts])
+                for p, i in zip(self.parts, ins):
+                    p.step_unpack(i)
+            for p in self.parts:
+                p.local_step()
+
+    def gather(self):
+        """Owned bodies of all partitions merged by global id: dict(ids, transforms, momentum, idle), sorted by id."""
+        parts = [p.owned_state() for p in self.parts]
+        ids = np.concatenate([q[0] for q in parts])
+        order = np.argsort(ids, kind="stable")
+        return dict(ids=ids[order], transforms=np.concatenate([q[1] for q in parts])[order],
+                    momentum=np.concatenate([q[2] for q in parts])[order], idle=np.concatenate([q[3] for q in parts])[order])
+
+
+class DistCluster:
+    """One partition per process; neighbour messages over torch.distributed point-to-point ops
+    (backend "nccl" = RCCL over xGMI for GPU tensors, "gloo" for the CPU tests)."""
+
+    def __init__(self, partition, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.p = partition
+        self.group = group
+        self.torch = partition.torch
+
+    def _exchange(self, out, widths=None, known_counts=None):
+        """Sends out[d] to rank+d and returns what the neighbours sent.  Counts are exchanged first unless known."""
+        t, dist, p = self.torch, self.dist, self.p
+        nb = p.neighbours()
+        dev = p.bt.device
+        if known_counts is None:
+            ops, cin = [], {}
+            for d in nb:
+                cout = t.tensor([out[d].shape[0]], dtype=t.int64, device=dev)
+                cin[d] = t.zeros(1, dtype=t.int64, device=dev)
+                ops.append(dist.P2POp(dist.isend, cout, p.rank + d, self.group))
+                ops.append(dist.P2POp(dist.irecv, cin[d], p.rank + d, self.group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+            known_counts = {d: int(cin[d].item()) for d in nb}
+        ops, ins = [], {}
+        for d in nb:
+            ins[d] = t.empty((known_counts[d], widths), dtype=t.uint8, device=dev)
+            if out[d].shape[0]:
+                ops.append(dist.P2POp(dist.isend, out[d].contiguous(), p.rank + d, self.group))
+            if known_counts[d]:
+                ops.append(dist.P2POp(dist.irecv, ins[d], p.rank + d, self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return ins
+
+    def step(self, steps=1):
+        p = self.p
+        for _ in range(steps):
+            if p.needs_refresh():
+                p.refresh_unpack_migrants(self._exchange(p.refresh_pack_migrants(), FULL_BYTES))
+                p.refresh_unpack_ghosts(self._exchange(p.refresh_pack_ghosts(), FULL_BYTES))
+            else:
+                p.step_unpack(self._exchange(p.step_pack(), STEP_BYTES, known_counts={d: p.ghost_in[d] for d in p.neighbours()}))
+            p.local_step()
+
+    def gather(self, dst=0):
+        """Owned bodies of all ranks merged by global id on rank `dst` (None elsewhere)."""
+        dist = self.dist
+        mine = self.p.owned_state()
+        world = dist.get_world_size(self.group)
+        objs = [None] * world if dist.get_rank(self.group) == dst else None
+        dist.gather_object(mine, objs, dst=dst, group=self.group)
+        if objs is None:
+            return None
+        ids = np.concatenate([q[0] for q in objs])
+        order = np.argsort(ids, kind="stable")
+        return dict(ids=ids[order], transforms=np.concatenate([q[1] for q in objs])[order],
+                    momentum=np.concatenate([q[2] for q in objs])[order], idle=np.concatenate([q[3] for q in objs])[order])

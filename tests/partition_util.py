@@ -1,0 +1,85 @@
+"""Test-only engine for nudge_amd.partition on the CPU: the compiled reference (oracle/_ref) behind the four
+members `Partition` needs (records, set_counts, step, params).  Arrays are kept in the WIDE layouts of
+include/nudge_hip.h as CPU torch tensors and mirrored into a reference world (16-bit tags) around every step, so the
+partition / halo logic that runs on the GPU in production is exercised here with gloo and no GPU."""
+import numpy as np
+import torch
+
+from nudge_amd import scenes as S
+from oracle import refworld
+from oracle.refworld import _view_array
+
+
+class OracleEngine:
+    _REC = dict(bt=32, bp=16, bm=32, bi=1, xt=4, xd=16, xx=32, st=4, sd=4, sx=32)
+    _KEY = dict(bt="body_transforms", bp="body_properties", bm="body_momentum", bi="idle_counters", xt="box_tags", xd="box_data",
+                xx="box_transforms", st="sphere_tags", sd="sphere_data", sx="sphere_transforms")
+
+    def __init__(self, scene, capacity):
+        self.params = dict(scene["params"])
+        self.cap = dict(capacity)
+        self.t = {}
+        for name, w in self._REC.items():
+            src = scene[self._KEY[name]]
+            if name in ("xt", "st"):
+                src = src.astype(np.uint32)
+            which = "bodies" if name[0] == "b" else ("boxes" if name[0] == "x" else "spheres")
+            t = torch.zeros((self.cap[which], w), dtype=torch.uint8)
+            raw = np.ascontiguousarray(src).view(np.uint8).reshape(len(src), -1) if len(src) else np.zeros((0, w), np.uint8)
+            t[:len(src)] = torch.from_numpy(raw.copy())
+            self.t[name] = t
+        self.nb, self.nbox, self.nsph = len(scene["body_transforms"]), len(scene["box_tags"]), len(scene["sphere_tags"])
+        pad = dict(scene)
+        pad["body_transforms"] = np.zeros(self.cap["bodies"], S.TRANSFORM); pad["body_properties"] = np.zeros(self.cap["bodies"], S.PROPERTIES)
+        pad["body_momentum"] = np.zeros(self.cap["bodies"], S.MOMENTUM); pad["idle_counters"] = np.zeros(self.cap["bodies"], np.uint8)
+        pad["box_tags"] = np.zeros(self.cap["boxes"], np.uint32); pad["box_data"] = np.zeros(self.cap["boxes"], S.BOX); pad["box_transforms"] = np.zeros(self.cap["boxes"], S.TRANSFORM)
+        pad["sphere_tags"] = np.zeros(self.cap["spheres"], np.uint32); pad["sphere_data"] = np.zeros(self.cap["spheres"], S.SPHERE); pad["sphere_transforms"] = np.zeros(self.cap["spheres"], S.TRANSFORM)
+        self.ref = refworld.RefWorld(pad, max_contacts=max(4096, 16 * self.cap["bodies"]))
+
+    def records(self, name, record_bytes):
+        assert self._REC[name] == record_bytes
+        return self.t[name]
+
+    def set_counts(self, bodies, boxes, spheres):
+        assert bodies <= self.cap["bodies"] and boxes <= self.cap["boxes"] and spheres <= self.cap["spheres"]
+        self.nb, self.nbox, self.nsph = bodies, boxes, spheres
+
+    def _np(self, name, dtype, n):
+        return np.frombuffer(self.t[name][:n].numpy().tobytes(), dtype=dtype, count=n)
+
+    def step(self, steps=1):
+        r, v = self.ref, self.ref._view()
+        nb, nx, ns = self.nb, self.nbox, self.nsph
+        for _ in range(steps):
+            _view_array(v.body_transforms, S.TRANSFORM, nb)[:] = self._np("bt", S.TRANSFORM, nb)
+            _view_array(v.body_properties, S.PROPERTIES, nb)[:] = self._np("bp", S.PROPERTIES, nb)
+            _view_array(v.body_momentum, S.MOMENTUM, nb)[:] = self._np("bm", S.MOMENTUM, nb)
+            _view_array(v.idle_counters, np.uint8, nb)[:] = self._np("bi", np.uint8, nb)
+            if nx:
+                tags = self._np("xt", np.uint32, nx)
+                assert tags.max() < 65536
+                _view_array(v.box_tags, np.uint16, nx)[:] = tags.astype(np.uint16)
+                _view_array(v.box_data, S.BOX, nx)[:] = self._np("xd", S.BOX, nx)
+                _view_array(v.box_transforms, S.TRANSFORM, nx)[:] = self._np("xx", S.TRANSFORM, nx)
+            if ns:
+                tags = self._np("st", np.uint32, ns)
+                assert tags.max() < 65536
+                _view_array(v.sphere_tags, np.uint16, ns)[:] = tags.astype(np.uint16)
+                _view_array(v.sphere_data, S.SPHERE, ns)[:] = self._np("sd", S.SPHERE, ns)
+                _view_array(v.sphere_transforms, S.TRANSFORM, ns)[:] = self._np("sx", S.TRANSFORM, ns)
+            r.L.ref_world_set_counts(r.h, nb, nx, ns, 0)
+            r.n_bodies, r.n_boxes, r.n_spheres = nb, nx, ns
+            r.step(1)
+            out = r.bodies()
+            gid = self._np("bt", S.TRANSFORM, nb)["body"].copy()
+            bt = out["transforms"].copy()
+            bt["body"] = gid                                             # the global id rides in the unused field
+            self.t["bt"][:nb] = torch.from_numpy(np.ascontiguousarray(bt).view(np.uint8).reshape(nb, 32).copy())
+            self.t["bm"][:nb] = torch.from_numpy(np.ascontiguousarray(out["momentum"]).view(np.uint8).reshape(nb, 32).copy())
+            self.t["bi"][:nb, 0] = torch.from_numpy(out["idle"].copy())
+
+
+def single_world_reference(scene, steps):
+    w = refworld.RefWorld(scene)
+    w.step(steps)
+    return w.bodies()

@@ -1,0 +1,68 @@
+"""Partitioned world on the GPU: several partitions of one scene as separate device-resident worlds on cuda:0
+(LocalCluster: the same Partition code the multi-process run uses, with tensor hand-over instead of RCCL), against the
+single device-resident world."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import parity_util as P                      # noqa: E402
+from nudge_amd import engine as E           # noqa: E402
+from nudge_amd import partition as PT       # noqa: E402
+from nudge_amd import scenes as S           # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _cluster(scene, ranks, epoch=8, **kw):
+    x = scene["body_transforms"]["position"][1:, 0]
+    cuts = [float(np.quantile(x, (r + 1) / ranks)) + 0.41 for r in range(ranks - 1)]
+    parts = []
+    for r in range(ranks):
+        local, info = PT.split_scene(scene, cuts, r, min_extra=2048)
+        w = E.World(local, flags=0, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=8 * info["capacity"]["bodies"])
+        parts.append(PT.Partition(w, info, epoch=epoch, **kw))
+    return PT.LocalCluster(parts), parts
+
+
+@pytest.mark.parametrize("sphere_fraction", [0.0, 0.5])
+def test_three_partitions_match_single_world(sphere_fraction):
+    scene = S.grid_tiles(6, side=40, sphere_fraction=sphere_fraction, seed=21, lattice_cols=3)
+    cl, parts = _cluster(scene, 3)
+    single = E.World(scene, flags=0)
+    # airborne: nothing depends on solver slots yet -> bit-identical
+    cl.step(20); single.step(20)
+    got, ref = cl.gather(), single.get_bodies()
+    assert np.array_equal(got["ids"], np.arange(1, len(scene["body_transforms"])))
+    assert P.bits_equal(got["transforms"]["position"], ref["transforms"]["position"][1:])
+    assert P.bits_equal(got["momentum"]["velocity"], ref["momentum"]["velocity"][1:])
+    assert sum(p.stats["ghosts"] for p in parts) > 0
+    # landed and settled: SURVEY 8(d) bar (the slot-order effect explained in tests/test_partition_cpu.py)
+    cl.step(280); single.step(280)
+    got, ref = cl.gather(), single.get_bodies()
+    p, pr = got["transforms"]["position"], ref["transforms"]["position"][1:]
+    assert np.isfinite(p).all()
+    assert P.rel_err(p, pr).max() <= 1e-4
+    assert np.abs(got["momentum"]["velocity"] - ref["momentum"]["velocity"][1:]).max() <= 2e-4
+    for q in parts:
+        assert q.e.counts()["error"] == 0
+        q.e.close()
+    single.close()
+
+
+def test_migration_on_the_gpu():
+    scene = S.grid_tiles(1, side=40, seed=5)            # one tile: the median cut passes through it
+    scene["body_momentum"]["velocity"][1:, 0] = 12.0      # 3 units (one pitch) in 30 steps, all still airborne
+    cl, parts = _cluster(scene, 2, epoch=4, speed_floor=14.0)
+    single = E.World(scene, flags=0)
+    cl.step(30); single.step(30)
+    got, ref = cl.gather(), single.get_bodies()
+    assert parts[0].stats["migrated_out"] > 0 and parts[1].stats["migrated_in"] == parts[0].stats["migrated_out"]
+    assert np.array_equal(got["ids"], np.arange(1, len(scene["body_transforms"])))
+    assert P.bits_equal(got["transforms"]["position"], ref["transforms"]["position"][1:])
+    assert P.bits_equal(got["transforms"]["rotation"], ref["transforms"]["rotation"][1:])
+    for q in parts:
+        q.e.close()
+    single.close()
