@@ -6,9 +6,11 @@
 A "step" is one full pass of the hot path (collide -> gravity -> read cache -> setup -> apply x I -> update ->
 write cache -> advance, reference example/main.cpp:274-328) over one world resident in HBM.
 Workload at N = 1: BASELINE.json configs[1] -- 1,004,400 boxes in 124 single-layer drop tiles, 8 solver
-iterations, fp32.  For N > 1 every rank owns its own 124 tiles (the scene of config 5 is a lattice of such
-independent tiles, so the path shards with no data-path collective): weak scaling, `value` = partition-steps
-of all ranks per second.
+iterations, fp32.  For N > 1 (config 5's shape, weak scaling) the world is ONE lattice of 124 x N tiles cut into N
+x-slabs of equal body count -- the cuts pass through tiles -- and every rank steps its slab with a ghost-body halo
+exchange per step over RCCL point-to-point (nudge_amd/partition.py); there is no collective on the data path.
+`value` = (1,004,400-box partitions stepped by all ranks) per second.  NUDGE_BENCH_HALO=0 falls back to N
+independent 124-tile worlds (no exchange at all).
 
 The JSON line also carries
   roofline     -- the dominant kernel's algorithmic bytes / its mean duration (HIP events on the launch
@@ -99,28 +101,61 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
-    torch.cuda.set_device(local_rank)
+    # NUDGE_BENCH_BACKEND=gloo + NUDGE_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 path on a box with ONE GPU (all ranks share
+    # cuda:0, halo messages staged through the host).  The driver's runs use neither: one rank per GPU over RCCL.
+    backend = os.environ.get("NUDGE_BENCH_BACKEND", "nccl")
+    device_index = 0 if os.environ.get("NUDGE_BENCH_ONE_DEVICE", "0") == "1" else local_rank
+    torch.cuda.set_device(device_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     from nudge_amd import scenes as S
     from nudge_amd import engine as E
 
-    # every rank owns its own lattice of independent tiles (different seed per rank)
-    if args.scene == "boxes":
-        scene = S.grid_tiles(args.tiles, side=args.side, seed=2 + 1000 * rank, lattice_cols=11)
-        workload = f"c2: {args.tiles * args.side * args.side:,} boxes in {args.tiles} single-layer drop tiles ({args.side}x{args.side}), 8 solver iterations, dt 1/120"
-    elif args.scene == "mixed":
-        scene = S.grid_tiles(args.tiles, side=args.side, sphere_fraction=0.5, seed=3 + 1000 * rank, lattice_cols=16)
-        workload = f"c3: {args.tiles * args.side * args.side:,} mixed boxes+spheres in {args.tiles} tiles"
+    halo = world > 1 and os.environ.get("NUDGE_BENCH_HALO", "1") != "0" and args.scene in ("boxes", "mixed")
+    sphere_fraction = 0.5 if args.scene == "mixed" else 0.0
+    cluster = None
+    if halo:
+        # ONE world of world x tiles; equal-count x-slabs whose cuts pass through tiles
+        from nudge_amd import partition as PT
+        g = S.grid_tiles(args.tiles * world, side=args.side, sphere_fraction=sphere_fraction, seed=2, lattice_cols=11 * world)
+        gx = g["body_transforms"]["position"][1:, 0]
+        cuts = [float(np.quantile(gx, (r + 1) / world)) + 0.41 for r in range(world - 1)]
+        scene, info = PT.split_scene(g, cuts, rank)
+        del g, gx
+        sharding = (f"{world} x-slabs of one {args.tiles * world}-tile world, ghost halo exchange every step "
+                    f"({'RCCL' if backend == 'nccl' else backend} p2p), refresh + migration every 16 steps")
+    elif args.scene in ("boxes", "mixed"):
+        # every rank owns its own lattice of independent tiles (different seed per rank)
+        scene = S.grid_tiles(args.tiles, side=args.side, sphere_fraction=sphere_fraction, seed=(2 if args.scene == "boxes" else 3) + 1000 * rank,
+                             lattice_cols=11 if args.scene == "boxes" else 16)
+        sharding = "independent tiles per rank, no data-path collective" if world > 1 else "single GPU"
     else:
         scene = S.ball_pit(args.side, args.side, args.side, seed=4 + rank)
-        workload = f"c4: {args.side ** 3:,}-sphere ball pit, 16 iterations"
-    nb = len(scene["body_transforms"]) - 1
+        sharding = "independent replicas" if world > 1 else "single GPU"
+    n_units = args.tiles * args.side * args.side
+    workload = {"boxes": f"c2: {n_units:,} boxes in {args.tiles} single-layer drop tiles ({args.side}x{args.side}), 8 solver iterations, dt 1/120",
+                "mixed": f"c3: {n_units:,} mixed boxes+spheres in {args.tiles} tiles",
+                "pit": f"c4: {args.side ** 3:,}-sphere ball pit, 16 iterations"}[args.scene]
     I = scene["params"]["iterations"]
-    w = E.World(scene, device=local_rank, flags=0, max_contacts=max(4096, (6 if args.scene != "pit" else 10) * nb))
+    nb = len(scene["body_transforms"]) - 1
+    if halo:
+        w = E.World(scene, device=device_index, flags=0, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=6 * info["capacity"]["bodies"])
+        cluster = PT.DistCluster(PT.Partition(w, info, epoch=16), host_staging=(backend != "nccl"))
+    else:
+        w = E.World(scene, device=device_index, flags=0, max_contacts=max(4096, (6 if args.scene != "pit" else 10) * nb))
+
+    def advance_world(n):
+        if cluster is not None:
+            cluster.step(n)
+        else:
+            w.step(n)
 
     def barrier():
         if world > 1:
@@ -128,9 +163,9 @@ def main():
         torch.cuda.synchronize()
 
     # ---- warm-up (untimed): boxes land; also one fully profiled step to find the dominant kernel ----
-    w.step(max(args.warmup - 3, 0))
+    advance_world(max(args.warmup - 3, 0))
     w.enable_timing(True)
-    w.step(min(3, args.warmup))
+    advance_world(min(3, args.warmup))
     w.synchronize()
     ktimes = w.kernel_times(reset=True)
     w.enable_timing(False)
@@ -146,7 +181,7 @@ def main():
         w.enable_timing(True, only=dominant)
     barrier()
     t0 = time.perf_counter()
-    w.step(args.steps)
+    advance_world(args.steps)
     barrier()
     t1 = time.perf_counter()
     dt = t1 - t0
@@ -157,10 +192,10 @@ def main():
         raise SystemExit(f"device error {counts1['error']}")
 
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        ksum = torch.tensor([float(counts1["contacts"])], dtype=torch.float64, device="cuda")
+        ksum = torch.tensor([float(counts1["contacts"])], dtype=torch.float64, device=red_dev)
         dist.all_reduce(ksum, op=dist.ReduceOp.SUM)
         contacts_all = float(ksum.item())
     else:
@@ -181,7 +216,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "bodies_per_gpu": nb, "colliders_per_gpu": C, "iterations": I,
-                       "sharding": "independent tiles per rank, no data-path collective" if world > 1 else "single GPU",
+                       "sharding": sharding,
                        "contacts_per_step": K, "pairs_per_step": P, "timed_window": f"steps [{args.warmup}, {args.warmup + args.steps})"},
             "contacts_solved_per_sec": contacts_all * I * args.steps / dt,
         }
@@ -208,6 +243,10 @@ def main():
                 cb = {"error": repr(e)}
             if cb:
                 out["cpu_baseline"] = cb
+        if cluster is not None:
+            st = cluster.p.stats
+            out["halo"] = {"ghost_bodies_rank0": st["ghosts"], "refreshes": st["refreshes"], "migrated_out_rank0": st["migrated_out"],
+                           "bytes_sent_per_step_rank0": st["step_bytes"] / max(1, cluster.p.steps)}
         print(json.dumps(out))
     w.close()
     if world > 1:

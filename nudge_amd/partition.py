@@ -375,18 +375,23 @@ class DistCluster:
     """One partition per process; neighbour messages over torch.distributed point-to-point ops
     (backend "nccl" = RCCL over xGMI for GPU tensors, "gloo" for the CPU tests)."""
 
-    def __init__(self, partition, group=None):
+    def __init__(self, partition, group=None, host_staging=False):
+        """`host_staging`: move messages through host memory (for backends without device p2p, e.g. gloo with GPU worlds)."""
         import torch.distributed as dist
         self.dist = dist
         self.p = partition
         self.group = group
         self.torch = partition.torch
+        self.host_staging = host_staging
 
     def _exchange(self, out, widths=None, known_counts=None):
         """Sends out[d] to rank+d and returns what the neighbours sent.  Counts are exchanged first unless known."""
         t, dist, p = self.torch, self.dist, self.p
         nb = p.neighbours()
-        dev = p.bt.device
+        home = p.bt.device
+        dev = t.device("cpu") if self.host_staging else home
+        if self.host_staging:
+            out = {d: r.cpu() for d, r in out.items()}
         if known_counts is None:
             ops, cin = [], {}
             for d in nb:
@@ -408,6 +413,8 @@ class DistCluster:
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
+        if self.host_staging:
+            ins = {d: r.to(home) for d, r in ins.items()}
         return ins
 
     def step(self, steps=1):
