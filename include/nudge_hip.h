@@ -26,6 +26,13 @@
  *      consumes them in, nudge.cpp:4027-4044), not in narrowphase emission order: same set, canonical order.
  *   6. The caller-side gravity/damping loop of the sample app (example/main.cpp:290-305) runs over
  *      host-invisible memory here, so it is offered as `nh_apply_gravity_damping`.
+ *   7. Deferred execution.  `nh_read_cached_impulses` and `nh_setup_contact_constraints` may postpone part of their
+ *      work (the per-contact cache lookup; row build + warm start of bodies that only touch the static world) and
+ *      run it fused with the first `nh_apply_impulses`, so that a constraint row lives only in registers.  Every
+ *      entry point of this library that reads or writes momentum, impulses or counters first completes pending
+ *      work, and so does `nh_synchronize`: through the API the reference's call-by-call semantics are kept.  Only
+ *      foreign kernels enqueued on the stream BETWEEN setup and the first apply would see momentum without the
+ *      warm start; call `nh_synchronize` (or any entry point) first if you need that.
  *
  * Threading: one context = one HIP stream = one world at a time; no global mutable state.
  */

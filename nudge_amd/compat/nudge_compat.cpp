@@ -195,7 +195,7 @@ void collide(ActiveBodies* active_bodies, ContactData* contacts, BodyData bodies
 	const uint64_t ncol = (uint64_t)nbox + nsph;
 	uint64_t cells = 1; while (cells < 4 * ncol) cells <<= 1;
 	if (cells < (1u << 16)) cells = 1u << 16;
-	if (cells > 0xFFFFFFu) cells = 0xFFFFFFu;
+	if (cells > (1u << 24)) cells = 1u << 24;
 	const size_t arena_bytes = ((size_t)64 << 20) + ncol * 200 + cells * 8 + (size_t)K * 420 + (size_t)bodies.count * 64;
 	s.arena.reserve(arena_bytes);
 	s.temporary = nh_Arena{ s.arena.p, s.arena.cap };

@@ -144,7 +144,7 @@ __global__ void k_grid_dims(nh_DevState* st, uint32_t max_cells) {
 	for (int it = 0; it < 64; ++it) {
 		float dx = (gmax.x - gmin.x) * inv, dy = (gmax.y - gmin.y) * inv, dz = (gmax.z - gmin.z) * inv;
 		uint64_t nx = (uint64_t)fminf(fmaxf(dx, 0.0f), 1e7f) + 2, ny = (uint64_t)fminf(fmaxf(dy, 0.0f), 1e7f) + 2, nz = (uint64_t)fminf(fmaxf(dz, 0.0f), 1e7f) + 2;
-		if (nx * ny * nz <= max_cells) { st->dims[0] = (uint32_t)nx; st->dims[1] = (uint32_t)ny; st->dims[2] = (uint32_t)nz; break; }
+		if (nx * ny * nz < max_cells) { st->dims[0] = (uint32_t)nx; st->dims[1] = (uint32_t)ny; st->dims[2] = (uint32_t)nz; break; }
 		inv *= 0.5f;
 	}
 	st->cell_inv = inv;
@@ -587,39 +587,85 @@ __global__ __launch_bounds__(256) void k_write_sleeping(nh_DevState* __restrict_
 	}
 }
 
-// One lane per OUTPUT contact (coalesced 32-B stores): find the owning record by binary search in the scanned
-// counts, then pick the record's k-th contact in feature order (reference: low 32 tag bits, nudge.cpp:4031-4036).
+// Tag-ordered output.  A wave takes 64 consecutive records (= collider pairs with contacts, in tag order); their contacts
+// occupy ONE contiguous range of the output.  Each lane ranks its record's contacts by feature (reference: low 32 tag bits,
+// nudge.cpp:4031-4036) and posts "output slot -> raw slot, owner lane" to LDS; then the wave copies the range with one lane
+// per output contact: coalesced 32-B stores, no search.
 __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict__ st, const uint32_t* __restrict__ rec_idx, const nh_Record* __restrict__ rec, const uint64_t* __restrict__ rec_key_sorted,
                                                          const uint32_t* __restrict__ starts, const nh_Contact* __restrict__ raw_data, const uint32_t* __restrict__ raw_feature,
                                                          nh_Contact* __restrict__ data, nh_BodyPair* __restrict__ bodies, uint64_t* __restrict__ tags, uint32_t* __restrict__ features, uint32_t capacity, uint32_t pair_cap) {
+	__shared__ uint32_t s_src[4][1024];
+	__shared__ uint32_t s_feat[4][1024];
+	__shared__ uint8_t s_own[4][1024];
 	const uint32_t nrec = st->records;
-	uint32_t total = st->contacts;
-	if (total > capacity) { if (blockIdx.x == 0 && threadIdx.x == 0) st->error = NH_ERR_CONTACT_CAPACITY; total = capacity; }
-	for (uint32_t d = blockIdx.x * blockDim.x + threadIdx.x; d < total; d += gridDim.x * blockDim.x) {
-		// largest record index whose start <= d (empty records share their successor's start)
-		uint32_t lo = 0, hi = nrec;
-		while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (starts[mid] <= d) lo = mid; else hi = mid; }
-		const uint32_t ri = rec_idx[lo];
-		const nh_Record r = rec[ri];
-		const uint32_t k = d - starts[lo];
-		const uint32_t cnt = r.count > 16 ? 16 : r.count;
-		const size_t base4 = (size_t)4 * ri, baseo = (size_t)4 * pair_cap + r.overflow;
-		uint32_t feat[16];
-		for (uint32_t j = 0; j < cnt; ++j) feat[j] = raw_feature[j < 4 ? base4 + j : baseo + (j - 4)];
-		uint32_t src = 0, f = 0;
-		for (uint32_t j = 0; j < cnt; ++j) {
-			uint32_t rank = 0;
-			for (uint32_t i = 0; i < cnt; ++i) rank += (feat[i] < feat[j] || (feat[i] == feat[j] && i < j)) ? 1u : 0u;
-			if (rank == k) { src = j; f = feat[j]; }
+	if (st->contacts > capacity && blockIdx.x == 0 && threadIdx.x == 0) st->error = NH_ERR_CONTACT_CAPACITY;
+	const uint32_t wave = threadIdx.x >> 6, lane = nh_lane();
+	uint32_t* src = s_src[wave];
+	uint32_t* sft = s_feat[wave];
+	uint8_t* own = s_own[wave];
+	for (uint32_t lo0 = (blockIdx.x * 4u + wave) * 64u; lo0 < nrec; lo0 += gridDim.x * 256u) {
+		const uint32_t lo = lo0 + lane;
+		uint32_t cnt = 0, start = 0, body_a = 0, body_b = 0, base4 = 0, baseo = 0;
+		uint64_t key = 0;
+		if (lo < nrec) {
+			const uint32_t ri = rec_idx[lo];
+			const nh_Record r = rec[ri];
+			start = starts[lo];
+			cnt = (r.count & NH_REC_SLEEPING) ? 0u : (r.count > 16u ? 16u : r.count);
+			key = rec_key_sorted[lo];
+			body_a = r.body_a; body_b = r.body_b;
+			base4 = 4u * ri; baseo = 4u * pair_cap + r.overflow;
 		}
-		const float4* sp = reinterpret_cast<const float4*>(raw_data + (src < 4 ? base4 + src : baseo + (src - 4)));
-		float4 c0 = sp[0], c1 = sp[1];
-		float4* dp = reinterpret_cast<float4*>(data + d);
-		dp[0] = c0; dp[1] = c1;
-		nh_BodyPair bp = { r.body_a, r.body_b };
-		bodies[d] = bp;
-		tags[d] = rec_key_sorted[lo];
-		features[d] = f;
+		const uint32_t base = __shfl(start, 0);                  // lane 0 is always a valid record here
+		{
+			const uint32_t rel = start - base;
+			if (cnt && cnt <= 4) {
+				const uint4 fv = *reinterpret_cast<const uint4*>(raw_feature + base4);
+				const uint32_t f[4] = { fv.x, fv.y, fv.z, fv.w };
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					if ((uint32_t)j < cnt) {
+						uint32_t rank = 0;
+#pragma unroll
+						for (int i = 0; i < 4; ++i) rank += ((uint32_t)i < cnt && (f[i] < f[j] || (f[i] == f[j] && i < j))) ? 1u : 0u;
+						src[rel + rank] = base4 + j; sft[rel + rank] = f[j]; own[rel + rank] = (uint8_t)lane;
+					}
+				}
+			} else if (cnt) {
+				for (uint32_t j = 0; j < cnt; ++j) {
+					const uint32_t sj = j < 4 ? base4 + j : baseo + (j - 4);
+					const uint32_t fj = raw_feature[sj];
+					uint32_t rank = 0;
+					for (uint32_t i = 0; i < cnt; ++i) {
+						const uint32_t fi = raw_feature[i < 4 ? base4 + i : baseo + (i - 4)];
+						rank += (fi < fj || (fi == fj && i < j)) ? 1u : 0u;
+					}
+					src[rel + rank] = sj; sft[rel + rank] = fj; own[rel + rank] = (uint8_t)lane;
+				}
+			}
+		}
+		uint32_t total = (lo < nrec) ? (start - base + cnt) : 0u;
+		for (int d = 32; d >= 1; d >>= 1) total = max(total, (uint32_t)__shfl_xor((int)total, d));
+		__builtin_amdgcn_wave_barrier();
+		for (uint32_t k0 = 0; k0 < total; k0 += 64) {           // wave-uniform: every lane takes part in the shuffles
+			const uint32_t k = k0 + lane;
+			const bool on = k < total;
+			const uint32_t o = on ? own[k] : 0u;
+			const uint32_t ba = (uint32_t)__shfl((int)body_a, (int)o), bb = (uint32_t)__shfl((int)body_b, (int)o);
+			const uint32_t klo = (uint32_t)__shfl((int)(uint32_t)key, (int)o), khi = (uint32_t)__shfl((int)(uint32_t)(key >> 32), (int)o);
+			const uint32_t d = base + k;
+			if (on && d < capacity) {
+				const float4* sp = reinterpret_cast<const float4*>(raw_data + src[k]);
+				float4 c0 = sp[0], c1 = sp[1];
+				float4* dp = reinterpret_cast<float4*>(data + d);
+				dp[0] = c0; dp[1] = c1;
+				nh_BodyPair bp = { ba, bb };
+				bodies[d] = bp;
+				tags[d] = (uint64_t)klo | ((uint64_t)khi << 32);
+				features[d] = sft[k];
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
 	}
 }
 
@@ -644,6 +690,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
                           const nh_BodyConnections* body_connections, nh_Arena temporary) {
 	if (!ctx || !active_bodies || !contacts || !bodies || !colliders) return NH_ERR_INVALID;
 	NH_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	nh_DevState* st = ctx->d_state;
 	const uint32_t nbox = colliders->boxes.count, nsph = colliders->spheres.count;
 	const uint32_t C = nbox + nsph;
@@ -668,11 +715,14 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	uint32_t* large_list = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* hist = nh_arena_array<uint32_t>(A, 256 * NH_SORT_GRID + 512, &err);
 	uint32_t* scan_tmp = nh_arena_array<uint32_t>(A, NH_SORT_GRID + 64, &err);
-	// grid: up to 4 cells per collider (power of two), clamped
+	// grid table: a power of two, up to 4 cells per collider; 2^22 entries (two 11-bit radix passes) while that leaves at
+	// least one cell per collider.  Cell keys are < max_cells - 1, so the large key (all ones) sorts last on cell_bits bits.
 	uint64_t want = 1; while (want < 4ull * C) want <<= 1;
 	if (want < (1u << 16)) want = 1u << 16;
-	if (want > NH_MAX_CELLS) want = NH_MAX_CELLS;
+	if (want > (1u << 22) && C <= (1u << 22)) want = 1u << 22;
+	if (want > (1u << 24)) want = 1u << 24;
 	const uint32_t max_cells = (uint32_t)want;
+	int cell_bits = 0; while ((1ull << cell_bits) < want) ++cell_bits;
 	uint2* cells = nh_arena_array<uint2>(A, max_cells, &err);
 	const uint32_t pair_cap = cap / 2 + 1024;           // broadphase pairs; each owns 4 raw contact slots, the rest overflows
 	const uint32_t overflow_cap = cap;
@@ -703,7 +753,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "small_bounds", k_small_bounds, nh_grid_for(C, 256, 1024), 256, st, C, aabb_min, aabb_max);
 		NH_LAUNCH(ctx, "grid_dims", k_grid_dims, 1, 64, st, max_cells);
 		NH_LAUNCH(ctx, "cell_keys", k_cell_keys, nh_grid_for(C, 256, 2048), 256, st, C, aabb_min, aabb_max, keys_a, vals_a, mkey, large_list);
-		if (nh_sort_u32_u32(ctx, keys_a, keys_b, vals_a, vals_b, &st->colliders, hist, 0, 24)) { uint32_t* t = keys_a; keys_a = keys_b; keys_b = t; t = vals_a; vals_a = vals_b; vals_b = t; }
+		if (nh_sort_u32_u32(ctx, keys_a, keys_b, vals_a, vals_b, &st->colliders, hist, 0, ((cell_bits + 7) / 8) * 8)) { uint32_t* t = keys_a; keys_a = keys_b; keys_b = t; t = vals_a; vals_a = vals_b; vals_b = t; }
 		if (ctx->timing) nh_timer_begin(ctx, "memset_cells");
 		NH_HIP_CHECK(ctx, hipMemsetAsync(cells, 0, sizeof(uint2) * (size_t)max_cells, s));
 		if (ctx->timing) nh_timer_end(ctx);
@@ -741,7 +791,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	// (dropped records carry count 0, so where they land in the order is irrelevant)
 	NH_LAUNCH(ctx, "sorted_counts", k_sorted_counts, nh_grid_for(pair_cap, 256, 2048), 256, st, rec_idx_a, rec, rec_counts, sleep_flags);
 	nh_scan_u32(ctx, rec_counts, rec_counts, &st->records, 0, scan_tmp, &st->contacts);
-	NH_LAUNCH(ctx, "gather_contacts", k_gather_contacts, nh_grid_for(cap, 256, 16384), 256, st, rec_idx_a, rec, rec_key_a, rec_counts, raw_data, raw_feature,
+	NH_LAUNCH(ctx, "gather_contacts", k_gather_contacts, nh_grid_for(pair_cap, 256, 8192), 256, st, rec_idx_a, rec, rec_key_a, rec_counts, raw_data, raw_feature,
 	          contacts->data, contacts->bodies, contacts->tags, contacts->features, cap, pair_cap);
 	// sleeping pairs, ascending (nudge.cpp:4008)
 	nh_scan_u32(ctx, sleep_flags, sleep_flags, &st->records, 1, scan_tmp, &st->sleeping, &st->any_sleeping);

@@ -16,6 +16,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->timing_current = false;
 	ctx->ring_pos = 0;
 	ctx->body_count = 0;
+	ctx->pending = nullptr;
 	ctx->d_state = nullptr;
 	ctx->h_state = nullptr;
 	if (hipMalloc((void**)&ctx->d_state, sizeof(nh_DevState)) != hipSuccess) { delete ctx; return NH_ERR_HIP; }
@@ -44,6 +45,8 @@ extern "C" int nh_set_tag_bits(nh_context* ctx, uint32_t bits) { if (!ctx || bit
 
 extern "C" int nh_synchronize(nh_context* ctx) {
 	if (!ctx) return NH_ERR_INVALID;
+	int rc = nh_flush_pending(ctx);
+	if (rc) return rc;
 	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 	if (ctx->timing) nh_timer_collect(ctx);
 	return NH_OK;
@@ -51,6 +54,7 @@ extern "C" int nh_synchronize(nh_context* ctx) {
 
 extern "C" int nh_read_counts(nh_context* ctx, nh_Counts* out) {
 	if (!ctx || !out) return NH_ERR_INVALID;
+	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, 20 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 	const nh_DevState* h = ctx->h_state;

@@ -81,10 +81,21 @@ struct nh_context {
 	uint32_t ring_pos;
 	// last collide: number of bodies (for sizing), contact capacity
 	uint32_t body_count;
+	// deferred one-body setup (see nh_ContactConstraintData::setup_pending)
+	nh_ContactConstraintData* pending;
 };
 
+// Runs work that an earlier call deferred; every entry point that reads or writes momentum / impulses calls it first.
+int nh_flush_pending(nh_context* ctx);
+
 struct nh_ContactImpulseData {
-	nh_CachedContactImpulse* data;        // K, contact (tag) order
+	nh_CachedContactImpulse* data;        // K, contact (tag) order; holds the warm-start impulses once `lookup_pending` is false
+	// the warm-start lookup is deferred: bodies on the one-body path fetch their cached impulses inside the fused solver kernel
+	bool lookup_pending;
+	bool consumed;                        // a setup_contact_constraints took this handle: every contact's impulse gets (re)written by the solver
+	nh_context* ctx;
+	const uint64_t* tags; const uint32_t* features;                       // this step's contacts
+	const uint64_t* ctags; const uint32_t* cfeatures; const nh_CachedContactImpulse* cdata;   // the cache as read
 	uint64_t* culled_tags;
 	uint32_t* culled_features;
 	nh_CachedContactImpulse* culled_data;
@@ -112,6 +123,11 @@ struct nh_ContactConstraintData {
 	const nh_Contact* contact_data;
 	nh_CachedContactImpulse* impulses;
 	uint32_t* general_list;
+	// one-body path: row build + warm start are deferred into the first nh_apply_impulses (or the next call that observes
+	// momentum / impulses); `setup_pending` says they have not run yet
+	bool setup_pending;
+	nh_ContactImpulseData* imp;
+	nh_BodyData bodies_at_setup;
 };
 
 // ---- arena (host-side bump allocation over device memory, reference nudge.cpp:990-1055) ---------------

@@ -457,11 +457,17 @@ __global__ __launch_bounds__(256) void k_setup_static(uint32_t nbodies, const ui
 // ---- one-body fast path: `iterations` PGS sweeps ---------------------------------------------------------------------------
 // MAXC > 0: the body's <= MAXC constraint rows stay in registers across all iterations (160 B each): every row is
 // read from HBM once per call, not once per iteration.  MAXC == 0: any contact count, rows re-read per iteration.
-template<int MAXC>
+// FUSED: the call also does what nh_setup_contact_constraints deferred for these bodies -- fetch the cached impulse of every
+// contact (read_cached_impulses, nudge.cpp:4057-4083: same-index probe, then binary search in the tag-sorted cache), build the
+// rows and warm start (nudge.cpp:4563-4632) -- before the sweeps, so a contact's row exists only in registers, once per step.
+struct nh_CacheView { const uint64_t* tags; const uint32_t* features; const uint64_t* ctags; const uint32_t* cfeatures; const nh_CachedContactImpulse* cdata; const nh_DevState* st; };
+
+template<int MAXC, bool FUSED>
 __global__ __launch_bounds__(256) void k_apply_static(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
                                                       const nh_BodyPair* __restrict__ bodies, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                       const float* __restrict__ rows, float4* __restrict__ states, uint32_t iterations,
-                                                      const nh_Contact* __restrict__ contacts, const nh_Transform* __restrict__ xf, nh_CachedContactImpulse* __restrict__ impulses) {
+                                                      const nh_Contact* __restrict__ contacts, const nh_Transform* __restrict__ xf, nh_CachedContactImpulse* __restrict__ impulses,
+                                                      nh_CacheView cv) {
 	const nh_vel vel0 = load_vel(momentum, props, 0);
 	const nh_inertia I0 = body_inertia(xf, props, 0);
 	const nh_Transform t0 = xf[0];
@@ -482,18 +488,60 @@ __global__ __launch_bounds__(256) void k_apply_static(uint32_t nbodies, const ui
 			const nh_inertia IX = body_inertia(xf, props, x);
 			const nh_Transform tx = xf[x];
 			const nh_f3 posx = nh_make3(tx.position[0], tx.position[1], tx.position[2]);
+			// phase A: everything the body needs from memory, as independent loads (one round trip at this occupancy)
+			nh_Contact ctc[M];
+			float wx[M], wy[M], wz[M];
+			bool miss[M];
+			const uint32_t m = FUSED ? cv.st->cache : 0u;
+#pragma unroll
+			for (int q = 0; q < M; ++q) cid[q] = (uint32_t)q < cnt ? adj[b + q] : 0u;
+#pragma unroll
+			for (int q = 0; q < M; ++q) {
+				miss[q] = false; wx[q] = wy[q] = wz[q] = 0.0f;
+				if ((uint32_t)q < cnt) {
+					const uint32_t c = cid[q];
+					is_a[q] = bodies[c].a == x;
+					ctc[q] = contacts[c];
+					if (FUSED) {
+						// steady state: the cache is last step's contact list, so the entry usually sits at the same index
+						const uint64_t t = cv.tags[c]; const uint32_t f = cv.features[c];
+						const bool in = c < m;
+						const uint64_t ct = in ? cv.ctags[c] : 0ull; const uint32_t cf = in ? cv.cfeatures[c] : 0u;
+						nh_CachedContactImpulse wc = { { 0.0f, 0.0f, 0.0f }, 0.0f };
+						if (in) wc = cv.cdata[c];
+						const bool hit = in && ct == t && cf == f;
+						if (hit) { wx[q] = wc.impulse[0]; wy[q] = wc.impulse[1]; wz[q] = wc.impulse[2]; }
+						miss[q] = !hit;
+					} else {
+						float4 sv = states[c];
+						s[q].normal = sv.x; s[q].friction_x = sv.y; s[q].friction_y = sv.z;
+					}
+				}
+			}
+			if (FUSED) {
+#pragma unroll
+				for (int q = 0; q < M; ++q) {
+					if (miss[q]) {      // new or shifted contact: binary search in the tag-sorted cache (nudge.cpp:4057-4083 is a merge-join)
+						const uint32_t c = cid[q];
+						const uint64_t t = cv.tags[c]; const uint32_t f = cv.features[c];
+						uint32_t lo = 0, hi = m;
+						while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (tag_less(cv.ctags[mid], cv.cfeatures[mid], t, f)) lo = mid + 1; else hi = mid; }
+						if (lo < m && cv.ctags[lo] == t && cv.cfeatures[lo] == f) { nh_CachedContactImpulse w = cv.cdata[lo]; wx[q] = w.impulse[0]; wy[q] = w.impulse[1]; wz[q] = w.impulse[2]; }
+					}
+				}
+			}
+			// phase B: rows, and (fused) the warm start in slot order
 #pragma unroll
 			for (int q = 0; q < M; ++q) {
 				if ((uint32_t)q < cnt) {
-					uint32_t c = adj[b + q];
-					cid[q] = c;
-					is_a[q] = bodies[c].a == x;
-					nh_Contact ct = contacts[c];
+					const nh_Contact& ct = ctc[q];
 					nh_contact_in ci = { ct.position[0], ct.position[1], ct.position[2], ct.penetration, ct.normal[0], ct.normal[1], ct.normal[2], ct.friction };
 					if (is_a[q]) nh_build_row(ci, posx, pos0, IX, I0, v.mass_inverse, z.mass_inverse, r[q]);
 					else         nh_build_row(ci, pos0, posx, I0, IX, z.mass_inverse, v.mass_inverse, r[q]);
-					float4 sv = states[c];
-					s[q].normal = sv.x; s[q].friction_x = sv.y; s[q].friction_y = sv.z;
+					if (FUSED) {
+						if (is_a[q]) nh_warm_start(r[q], wx[q], wy[q], wz[q], v, z, s[q]);
+						else         nh_warm_start(r[q], wx[q], wy[q], wz[q], z, v, s[q]);
+					}
 				}
 			}
 			for (uint32_t it = 0; it < iterations; ++it) {
@@ -769,6 +817,7 @@ static nh_ContactConstraintData* new_constraint_data(nh_context* ctx) {
 extern "C" int nh_apply_gravity_damping(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_BodyData* bodies,
                                         float time_step, const float gravity[3], float damping_rate) {
 	if (!ctx || !active_bodies || !bodies || !gravity) return NH_ERR_INVALID;
+	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	float damping = 1.0f - time_step * damping_rate;
 	NH_LAUNCH(ctx, "gravity_damping", k_gravity, nh_grid_for(bodies->count, 256, 2048), 256, ctx->d_state, active_bodies->indices, bodies->momentum,
 	          gravity[0] * time_step, gravity[1] * time_step, gravity[2] * time_step, damping);
@@ -777,6 +826,7 @@ extern "C" int nh_apply_gravity_damping(nh_context* ctx, const nh_ActiveBodies* 
 
 extern "C" int nh_advance(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_BodyData* bodies, float time_step) {
 	if (!ctx || !active_bodies || !bodies) return NH_ERR_INVALID;
+	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	NH_LAUNCH(ctx, "advance", k_advance, nh_grid_for(bodies->count, 256, 2048), 256, ctx->d_state, active_bodies->indices, bodies->transforms,
 	          bodies->momentum, bodies->idle_counters, time_step);
 	return NH_OK;
@@ -784,6 +834,7 @@ extern "C" int nh_advance(nh_context* ctx, const nh_ActiveBodies* active_bodies,
 
 extern "C" int nh_read_cached_impulses(nh_context* ctx, const nh_ContactCache* cache, const nh_ContactData* contacts, nh_Arena* memory, nh_ContactImpulseData** out) {
 	if (!ctx || !cache || !contacts || !memory || !out) return NH_ERR_INVALID;
+	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	nh_DevState* st = ctx->d_state;
 	const uint32_t kcap = contacts->capacity, ccap = cache->capacity;
 	int err = NH_OK;
@@ -798,7 +849,11 @@ extern "C" int nh_read_cached_impulses(nh_context* ctx, const nh_ContactCache* c
 	uint32_t* flags = nh_arena_array<uint32_t>(&scratch, ccap + 1, &err);
 	uint32_t* tmp = nh_arena_array<uint32_t>(&scratch, NH_SORT_GRID + 64, &err);
 	if (err) return err;
-	NH_LAUNCH(ctx, "cache_lookup", k_cache_lookup, nh_grid_for(kcap, 256, 16384), 256, st, contacts->tags, contacts->features, cache->tags, cache->features, cache->data, d->data);
+	// the per-contact lookup is deferred: bodies on the one-body path fetch their impulses inside the fused solver kernel, and
+	// materialize_lookup() fills d->data for everything else (only if such contacts exist, which setup learns)
+	d->lookup_pending = true; d->ctx = ctx; d->consumed = false;
+	d->tags = contacts->tags; d->features = contacts->features;
+	d->ctags = cache->tags; d->cfeatures = cache->features; d->cdata = cache->data;
 	if (contacts->sleeping_pairs) {
 		NH_LAUNCH(ctx, "cull_flags", k_cull_flags, nh_grid_for(ccap, 256, 4096), 256, st, cache->tags, contacts->sleeping_pairs, flags);
 		nh_scan_u32(ctx, flags, flags, &st->cache, 1, tmp, &st->culled, &st->sleeping);   // +1: the sentinel, so scan[j+1] exists for every j
@@ -809,10 +864,27 @@ extern "C" int nh_read_cached_impulses(nh_context* ctx, const nh_ContactCache* c
 	return NH_OK;
 }
 
-extern "C" const nh_CachedContactImpulse* nh_contact_impulses_device(const nh_ContactImpulseData* d) { return d ? d->data : nullptr; }
+static void materialize_lookup(nh_context* ctx, nh_ContactImpulseData* d) {
+	if (!d->lookup_pending) return;
+	d->lookup_pending = false;
+	NH_LAUNCH(ctx, "cache_lookup", k_cache_lookup, nh_grid_for(d->capacity, 256, 16384), 256, ctx->d_state, d->tags, d->features, d->ctags, d->cfeatures, d->cdata, d->data);
+}
+
+extern "C" const nh_CachedContactImpulse* nh_contact_impulses_device(const nh_ContactImpulseData* d) {
+	if (!d) return nullptr;
+	nh_ContactImpulseData* m = const_cast<nh_ContactImpulseData*>(d);
+	if (m->ctx) {
+		// before the solver has run this holds the warm-start impulses, afterwards the solved ones: make either visible
+		if (m->ctx->pending) nh_flush_pending(m->ctx);
+		else materialize_lookup(m->ctx, m);
+	}
+	return d->data;
+}
 
 extern "C" int nh_write_cached_impulses(nh_context* ctx, nh_ContactCache* cache, const nh_ContactData* contacts, nh_ContactImpulseData* imp) {
 	if (!ctx || !cache || !contacts || !imp) return NH_ERR_INVALID;
+	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	if (!imp->consumed) materialize_lookup(ctx, imp);      // no setup ran on this handle: the cache is rewritten from the looked-up impulses
 	nh_DevState* st = ctx->d_state;
 	NH_LAUNCH(ctx, "write_cache", k_write_cache, nh_grid_for((uint64_t)contacts->capacity + cache->capacity, 256, 4096), 256, st,
 	          contacts->tags, contacts->features, imp->data, imp->culled_tags, imp->culled_features, imp->culled_data,
@@ -830,6 +902,7 @@ extern "C" int nh_write_cached_impulses(nh_context* ctx, nh_ContactCache* cache,
 extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_ContactData* contacts,
                                             const nh_BodyData* bodies, nh_ContactImpulseData* imp, nh_Arena* memory, nh_ContactConstraintData** out) {
 	if (!ctx || !contacts || !bodies || !imp || !memory || !out) return NH_ERR_INVALID;
+	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	(void)active_bodies;
 	nh_DevState* st = ctx->d_state;
 	const uint32_t kcap = contacts->capacity;
@@ -864,12 +937,6 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	if (slot_key) NH_LAUNCH(ctx, "greedy_replay", k_greedy_replay, 1, 64, st, contacts->bodies, slot_key);
 	NH_LAUNCH(ctx, "adjacency_sort", k_adj_sort, nh_grid_for(B, 256, 4096), 256, st, B, contacts->bodies, d->body_off, d->adj, slot_key, d->body_class, pred_a, pred_b, bodies->properties, bodies->momentum);
 	NH_LAUNCH(ctx, "contact_class", k_contact_class, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, d->body_class, level, general_list, pred_a, pred_b);
-	NH_LAUNCH(ctx, "setup_static", (k_setup_static<false>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj,
-	          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states, (const uint32_t*)nullptr);
-	// (bodies with more than 8 static contacts are rare; the kernel only finds work if k_adj_sort flagged some)
-	NH_LAUNCH(ctx, "setup_staticN", (k_setup_static<true>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj,
-	          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states, &st->has_staticN);
-
 	// the level-scheduled path needs per-level launch sizes on the host: one round trip
 	nh_Counts c;
 	int rc = nh_read_counts(ctx, &c);
@@ -879,8 +946,20 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	d->static_body_count = c.static_bodies;
 	d->has_static8 = ctx->h_state->has_static8 != 0;
 	d->has_staticN = ctx->h_state->has_staticN != 0;
+	// one-body path (<= 8 contacts per body): lookup + rows + warm start run fused with the first sweeps (nh_apply_impulses),
+	// or at the next call that observes momentum / impulses (nh_flush_pending)
+	d->setup_pending = true; d->imp = imp; d->bodies_at_setup = *bodies;
+	imp->consumed = true;
+	ctx->pending = d;
+	if (d->has_staticN) {
+		// bodies with more than 8 static contacts are rare: rows are stored, the warm start reads the materialised lookup
+		materialize_lookup(ctx, imp);
+		NH_LAUNCH(ctx, "setup_staticN", (k_setup_static<true>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj,
+		          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states, (const uint32_t*)nullptr);
+	}
 	if (c.general_contacts) {
 		const uint32_t G = c.general_contacts;
+		materialize_lookup(ctx, imp);
 		NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, general_list, contacts->data, contacts->bodies, bodies->transforms, bodies->properties, d->rows);
 		// relaxation: every round finalises at least the next level
 		uint32_t rounds = 0;
@@ -918,17 +997,42 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	return NH_OK;
 }
 
+static void launch_apply_static(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations, bool fused) {
+	const uint32_t B = d->body_count;
+	nh_CacheView cv = { nullptr, nullptr, nullptr, nullptr, nullptr, ctx->d_state };
+	if (fused) { cv.tags = d->imp->tags; cv.features = d->imp->features; cv.ctags = d->imp->ctags; cv.cfeatures = d->imp->cfeatures; cv.cdata = d->imp->cdata; }
+	auto go = [&](const char* name, auto kernel) {
+		NH_LAUNCH(ctx, name, kernel, nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
+		          d->rows, (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv);
+	};
+	if (fused) {
+		go("apply_static", k_apply_static<4, true>);
+		if (d->has_static8) go("apply_static8", k_apply_static<8, true>);
+	} else {
+		go("apply_static", k_apply_static<4, false>);
+		if (d->has_static8) go("apply_static8", k_apply_static<8, false>);
+	}
+	if (d->has_staticN && iterations) go("apply_staticN", k_apply_static<0, false>);
+}
+
+int nh_flush_pending(nh_context* ctx) {
+	nh_ContactConstraintData* d = ctx->pending;
+	if (!d) return NH_OK;
+	ctx->pending = nullptr;
+	if (d->setup_pending) {
+		d->setup_pending = false;
+		launch_apply_static(ctx, d, &d->bodies_at_setup, 0, true);       // zero sweeps: lookup + rows + warm start only
+	}
+	return NH_OK;
+}
+
 extern "C" int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations) {
 	if (!ctx || !d || !bodies) return NH_ERR_INVALID;
-	const uint32_t B = d->body_count;
-	NH_LAUNCH(ctx, "apply_static", (k_apply_static<4>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies,
-	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses);
-	if (d->has_static8)
-	NH_LAUNCH(ctx, "apply_static8", (k_apply_static<8>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies,
-	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses);
-	if (d->has_staticN)
-	NH_LAUNCH(ctx, "apply_staticN", (k_apply_static<0>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies,
-	          bodies->properties, bodies->momentum, d->rows, (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses);
+	if (ctx->pending && ctx->pending != d) { int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	const bool fused = d->setup_pending;
+	d->setup_pending = false;
+	ctx->pending = nullptr;
+	launch_apply_static(ctx, d, bodies, iterations, fused);
 	if (d->general_contacts) {
 		for (uint32_t it = 0; it < iterations; ++it)
 			for (uint32_t l = 1; l <= d->levels; ++l) {
@@ -943,6 +1047,7 @@ extern "C" int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* d, c
 
 extern "C" int nh_update_cached_impulses(nh_context* ctx, nh_ContactConstraintData* d, nh_ContactImpulseData* imp) {
 	if (!ctx || !d || !imp) return NH_ERR_INVALID;
+	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	if (d->general_contacts)
 		NH_LAUNCH(ctx, "update_impulses", k_update_impulses, nh_grid_for(d->general_contacts, 256, 4096), 256, ctx->d_state, d->general_list, d->rows, (const float4*)d->states, imp->data);
 	return NH_OK;

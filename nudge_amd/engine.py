@@ -191,7 +191,7 @@ class World:
             cells = 1
             while cells < 4 * ncol:
                 cells <<= 1
-            cells = min(max(cells, 1 << 16), 0xFFFFFF)
+            cells = min(max(cells, 1 << 16), 1 << 24)
             arena_bytes = (64 << 20) + ncol * 200 + cells * 8 + K * 420 + nb * 64
         self.arena_t = alloc("arena", arena_bytes)
         self.arena = Arena(self.arena_t.data_ptr(), arena_bytes)
