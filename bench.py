@@ -43,6 +43,10 @@ KERNEL_BYTES = {
     "cache_lookup": ("K", 12 + 28 + 16),                   # tag+feature, cache probe (tag, feature, impulse) -> impulse
     "setup_static": ("K", 32 + 16 + 8 + 160 + 16 + 36),    # contact, cached impulse, pair -> row + state (+ body state/4)
     "apply_static": ("K", 160 + 32 + 36),                  # row + state rw (+ body state/4) for ALL iterations of one call
+    # fused one-body solver (lookup + rows + warm start + all sweeps + export), per contact: contact 32, pair 8, tag+feature 12,
+    # cache probe 12 + 16, state 16 w, impulse 16 w = 112; per body (4 contacts): class/offsets/adjacency/hint 33, transform 32,
+    # properties 16, momentum 32 r + 32 w = 145 -> 36 per contact
+    "solve_one_body": ("K", 112 + 36),
     "update_impulses": ("K", 160 + 16 + 16),
     "write_cache": ("K", 12 + 16 + 28),
     "radix_hist": ("N", 8),

@@ -17,6 +17,8 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->ring_pos = 0;
 	ctx->body_count = 0;
 	ctx->pending = nullptr;
+	ctx->hint = nullptr;
+	ctx->hint_capacity = 0;
 	ctx->d_state = nullptr;
 	ctx->h_state = nullptr;
 	if (hipMalloc((void**)&ctx->d_state, sizeof(nh_DevState)) != hipSuccess) { delete ctx; return NH_ERR_HIP; }
@@ -35,6 +37,7 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	for (auto e : ctx->event_pool) hipEventDestroy(e);
 	for (auto p : ctx->impulse_ring) delete p;
 	for (auto p : ctx->constraint_ring) delete p;
+	if (ctx->hint) hipFree(ctx->hint);
 	if (ctx->d_state) hipFree(ctx->d_state);
 	if (ctx->h_state) hipHostFree(ctx->h_state);
 	delete ctx;
@@ -55,7 +58,7 @@ extern "C" int nh_synchronize(nh_context* ctx) {
 extern "C" int nh_read_counts(nh_context* ctx, nh_Counts* out) {
 	if (!ctx || !out) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
-	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, 20 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, 21 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 	const nh_DevState* h = ctx->h_state;
 	out->colliders = h->colliders; out->pairs = h->pairs > 0 ? h->pairs : 0; out->contacts = h->contacts; out->sleeping_pairs = h->sleeping;

@@ -41,6 +41,7 @@ struct nh_DevState {
 	uint32_t has_static8, has_staticN;    // any body in the rarer fast-path classes (plain stores, no counting)
 	uint32_t any_sleeping;                // some contact record belongs to a sleeping island this step
 	uint32_t unleveled_odd;               // progress counter of odd relaxation / colouring rounds
+	uint32_t static_inert;                // body 0 has all-zero velocity, inverse mass and inverse inertia (nh_is_inert)
 	// scene bounds of AABB min corners, order-preserving uint encoding (atomicMin/Max)
 	uint32_t smin[3];
 	uint32_t smax[3];
@@ -83,6 +84,9 @@ struct nh_context {
 	uint32_t body_count;
 	// deferred one-body setup (see nh_ContactConstraintData::setup_pending)
 	nh_ContactConstraintData* pending;
+	// warm-start hints (per body: index of its first contact in the previous step's contact list); library-owned device memory
+	uint32_t* hint;
+	uint32_t hint_capacity;
 };
 
 // Runs work that an earlier call deferred; every entry point that reads or writes momentum / impulses calls it first.
@@ -117,7 +121,7 @@ struct nh_ContactConstraintData {
 	uint32_t contact_capacity;
 	uint32_t body_count;
 	uint32_t static_body_count;
-	bool has_static8, has_staticN;
+	bool has_static8, has_staticN, static_inert;
 	const nh_BodyPair* bodies;
 	// inputs kept for the one-body fast path, which rebuilds its rows in registers instead of storing them
 	const nh_Contact* contact_data;

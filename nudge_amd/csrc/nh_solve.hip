@@ -245,6 +245,9 @@ __global__ __launch_bounds__(256) void k_adj_sort(nh_DevState* __restrict__ st, 
 		} else if (x == 0 && nbodies) {
 			body_class[0] = 0;
 			momentum[0].unused0 = props[0].mass_inverse;
+			const nh_BodyMomentum m0 = momentum[0];
+			const nh_BodyProperties p0 = props[0];
+			st->static_inert = nh_is_inert(m0.velocity, m0.angular_velocity, p0.inertia_inverse, p0.mass_inverse) ? 1u : 0u;
 		}
 	}
 }
@@ -581,6 +584,126 @@ __global__ __launch_bounds__(256) void k_apply_static(uint32_t nbodies, const ui
 			}
 		}
 		store_vel(momentum, x, v);
+	}
+}
+
+// ---- one-body fast path, inert static world (the usual case): one-body forms of nh_solver.h ---------------------------------
+// Same contract as k_apply_static<MAXC, FUSED>, for MAXC in {4, 8}; rows are the 27-float nh_row1.
+//
+// Warm-start lookup (FUSED).  The cache is last step's contact list (plus culled entries), sorted like this step's, so a
+// contact sits where it sat last step unless contacts before it appeared or vanished -- which shifts EVERYTHING after them.
+// `hint[x]` therefore remembers the index body x's first contact had last step: guess = hint[x] + (c - first contact of x).
+// A wrong guess is repaired by looking at the 8 entries around it (sorted: if they bracket the key without containing it the
+// contact is proven new), and only then by binary search (the reference does a linear merge-join, nudge.cpp:4057-4083).
+#define NH_HINT_NONE 0xFFFFFFFFu
+
+__device__ __forceinline__ bool cache_probe(const nh_CacheView& cv, uint32_t m, uint32_t guess, uint64_t t, uint32_t f, float& wx, float& wy, float& wz) {
+	if (guess < m && cv.ctags[guess] == t && cv.cfeatures[guess] == f) {
+		const float4 w = *reinterpret_cast<const float4*>(cv.cdata + guess);
+		wx = w.x; wy = w.y; wz = w.z;
+		return true;
+	}
+	return false;
+}
+
+__device__ __noinline__ void cache_search(const nh_CacheView& cv, uint32_t m, uint32_t guess, uint64_t t, uint32_t f, float& wx, float& wy, float& wz) {
+	uint32_t lo = 0, hi = m;
+	if (guess != NH_HINT_NONE && m) {
+		// window [g-4, g+4): entries are sorted by (tag, feature)
+		const uint32_t g = guess < m ? guess : m - 1;
+		const uint32_t w0 = g >= 4 ? g - 4 : 0, w1 = g + 4 < m ? g + 4 : m;
+		bool below = false, above = false;
+		for (uint32_t k = w0; k < w1; ++k) {
+			const uint64_t ct = cv.ctags[k]; const uint32_t cf = cv.cfeatures[k];
+			if (ct == t && cf == f) { const float4 w = *reinterpret_cast<const float4*>(cv.cdata + k); wx = w.x; wy = w.y; wz = w.z; return; }
+			if (tag_less(ct, cf, t, f)) below = true; else above = true;
+		}
+		if ((below || w0 == 0) && (above || w1 == m)) return;       // bracketed and absent: a new contact
+		if (!below) hi = w0; else lo = w1;
+	}
+	while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (tag_less(cv.ctags[mid], cv.cfeatures[mid], t, f)) lo = mid + 1; else hi = mid; }
+	if (lo < m && cv.ctags[lo] == t && cv.cfeatures[lo] == f) { const float4 w = *reinterpret_cast<const float4*>(cv.cdata + lo); wx = w.x; wy = w.y; wz = w.z; }
+}
+
+// four 27-float rows fit in 256 registers: two waves per SIMD (the compiler would otherwise spend 260 and run one)
+template<int MAXC, bool FUSED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ? 2 : 1, MAXC == 4 ? 2 : 1))) void k_solve_one_body(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
+                                                        const nh_BodyPair* __restrict__ bodies, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
+                                                        float4* __restrict__ states, uint32_t iterations,
+                                                        const nh_Contact* __restrict__ contacts, const nh_Transform* __restrict__ xf, nh_CachedContactImpulse* __restrict__ impulses,
+                                                        nh_CacheView cv, uint32_t* __restrict__ hint) {
+	constexpr int M = MAXC;
+	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < nbodies; x += gridDim.x * blockDim.x) {
+		if (body_class[x] != (MAXC == 4 ? NH_CLS_STATIC4 : NH_CLS_STATIC8)) continue;
+		const uint32_t b = off[x], cnt = off[x + 1] - b;
+		// body state: 16-byte loads (the records are 16 / 32 bytes and aligned, include/nudge_hip.h)
+		const float4 m0 = reinterpret_cast<const float4*>(momentum + x)[0], m1 = reinterpret_cast<const float4*>(momentum + x)[1];
+		const float4 pr = *reinterpret_cast<const float4*>(props + x);
+		const float4 t0 = reinterpret_cast<const float4*>(xf + x)[0], t1 = reinterpret_cast<const float4*>(xf + x)[1];
+		nh_vel v = { m0.x, m0.y, m0.z, pr.w, m1.x, m1.y, m1.z, m1.w };
+		const nh_quat qx = { t1.x, t1.y, t1.z, t1.w };
+		const nh_inertia IX = nh_world_inertia(qx, pr.x, pr.y, pr.z);
+		const nh_f3 posx = nh_make3(t0.x, t0.y, t0.z);
+		nh_row1 r[M];
+		nh_state s[M];
+		bool is_a[M];
+		uint32_t cid[M];
+		// phase A: everything the body needs from memory, as independent loads
+		float4 c0[M], c1[M];
+		float wx[M], wy[M], wz[M];
+		bool miss[M];
+		const uint32_t m = FUSED ? cv.st->cache : 0u;
+		const uint32_t h = FUSED ? hint[x] : NH_HINT_NONE;
+		uint32_t first = 0xFFFFFFFFu;
+#pragma unroll
+		for (int q = 0; q < M; ++q) { cid[q] = (uint32_t)q < cnt ? adj[b + q] : 0xFFFFFFFFu; first = min(first, cid[q]); }
+#pragma unroll
+		for (int q = 0; q < M; ++q) {
+			miss[q] = false; wx[q] = wy[q] = wz[q] = 0.0f; is_a[q] = false;
+			if ((uint32_t)q < cnt) {
+				const uint32_t c = cid[q];
+				is_a[q] = bodies[c].a == x;
+				c0[q] = reinterpret_cast<const float4*>(contacts + c)[0];
+				c1[q] = reinterpret_cast<const float4*>(contacts + c)[1];
+				if (FUSED) {
+					const uint32_t guess = h != NH_HINT_NONE ? h + (c - first) : c;
+					miss[q] = !cache_probe(cv, m, guess, cv.tags[c], cv.features[c], wx[q], wy[q], wz[q]);
+				} else {
+					float4 sv = states[c];
+					s[q].normal = sv.x; s[q].friction_x = sv.y; s[q].friction_y = sv.z;
+				}
+			}
+		}
+		if (FUSED) {
+#pragma unroll
+			for (int q = 0; q < M; ++q)
+				if (miss[q]) cache_search(cv, m, h != NH_HINT_NONE ? h + (cid[q] - first) : cid[q], cv.tags[cid[q]], cv.features[cid[q]], wx[q], wy[q], wz[q]);
+			hint[x] = first;                    // where this body's contacts start in what becomes the next step's cache
+		}
+		// phase B: rows, and (fused) the warm start in slot order
+#pragma unroll
+		for (int q = 0; q < M; ++q) {
+			if ((uint32_t)q < cnt) {
+				nh_contact_in ci = { c0[q].x, c0[q].y, c0[q].z, c0[q].w, c1[q].x, c1[q].y, c1[q].z, c1[q].w };
+				nh_build_row1(ci, posx, IX, v.mass_inverse, is_a[q], r[q]);
+				if (FUSED) nh_warm_start1(r[q], wx[q], wy[q], wz[q], v, is_a[q], s[q]);
+			}
+		}
+		for (uint32_t it = 0; it < iterations; ++it) {
+#pragma unroll
+			for (int q = 0; q < M; ++q)
+				if ((uint32_t)q < cnt) nh_apply_one1(r[q], s[q], v, is_a[q]);
+		}
+#pragma unroll
+		for (int q = 0; q < M; ++q)
+			if ((uint32_t)q < cnt) {
+				states[cid[q]] = make_float4(s[q].normal, s[q].friction_x, s[q].friction_y, 0.0f);
+				float ox, oy, oz;                 // update_cached_impulses (nudge.cpp:4872-4882) for this contact
+				nh_export_impulse1(r[q], s[q], ox, oy, oz);
+				*reinterpret_cast<float4*>(impulses + cid[q]) = make_float4(ox, oy, oz, 0.0f);
+			}
+		reinterpret_cast<float4*>(momentum + x)[0] = make_float4(v.vx, v.vy, v.vz, v.mass_inverse);
+		reinterpret_cast<float4*>(momentum + x)[1] = make_float4(v.wx, v.wy, v.wz, v.w_unused);
 	}
 }
 
@@ -946,6 +1069,15 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	d->static_body_count = c.static_bodies;
 	d->has_static8 = ctx->h_state->has_static8 != 0;
 	d->has_staticN = ctx->h_state->has_staticN != 0;
+	d->static_inert = ctx->h_state->static_inert != 0;
+	if (ctx->hint_capacity < B) {
+		// library-owned, persistent across steps: per body, where its contacts started in the previous step's list (warm-start hint)
+		if (ctx->hint) NH_HIP_CHECK(ctx, hipFree(ctx->hint));
+		ctx->hint = nullptr; ctx->hint_capacity = 0;
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->hint, sizeof(uint32_t) * (size_t)B));
+		NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->hint, 0xFF, sizeof(uint32_t) * (size_t)B, ctx->stream));
+		ctx->hint_capacity = B;
+	}
 	// one-body path (<= 8 contacts per body): lookup + rows + warm start run fused with the first sweeps (nh_apply_impulses),
 	// or at the next call that observes momentum / impulses (nh_flush_pending)
 	d->setup_pending = true; d->imp = imp; d->bodies_at_setup = *bodies;
@@ -1005,7 +1137,20 @@ static void launch_apply_static(nh_context* ctx, nh_ContactConstraintData* d, co
 		NH_LAUNCH(ctx, name, kernel, nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
 		          d->rows, (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv);
 	};
-	if (fused) {
+	auto go1 = [&](const char* name, auto kernel) {
+		NH_LAUNCH(ctx, name, kernel, nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
+		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint);
+	};
+	if (d->static_inert) {
+		// body 0 is inert (all-zero velocity, inverse mass, inverse inertia): one-body forms, 27-float rows
+		if (fused) {
+			go1("solve_one_body", k_solve_one_body<4, true>);
+			if (d->has_static8) go1("solve_one_body8", k_solve_one_body<8, true>);
+		} else {
+			go1("solve_one_body", k_solve_one_body<4, false>);
+			if (d->has_static8) go1("solve_one_body8", k_solve_one_body<8, false>);
+		}
+	} else if (fused) {
 		go("apply_static", k_apply_static<4, true>);
 		if (d->has_static8) go("apply_static8", k_apply_static<8, true>);
 	} else {

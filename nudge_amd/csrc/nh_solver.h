@@ -317,6 +317,250 @@ NH_HD void nh_apply_one(const nh_row& r, nh_state& st, nh_vel& a, nh_vel& b) {
 	b.w_unused = 0.0f;
 }
 
+// ---- one-body forms ---------------------------------------------------------------------------------------------------
+// A contact between a dynamic body D and an INERT static world body S (velocity, inverse mass and inverse inertia all +0:
+// what body 0 is in every scene of the reference).  In the general functions above every S-side quantity is then a product
+// with zero: S's velocity stays +0 for good (x*0 + 0 = +0 in round-to-nearest for finite x), S's half of the row
+// (nb/ub/vb or na/ua/va) is +-0, and S's lever arm only ever appears as fma(0, p, y).  The functions below are the general
+// ones with those operations removed -- same operations, same order, same fused multiply-adds on everything that can be
+// non-zero -- so D's velocity, the impulses and the exported cache entries come out bit-identical for finite inputs
+// (tests/test_cpu_oracle.py::test_one_body_forms_equal_general_forms checks that on the golden scenes).  The only
+// numbers that can differ are signs of exact zeros that are provably never observed: friction_coefficient_z (only ever
+// added to a non-negative accumulator) and r (added to a positive inverse mass).
+// A row shrinks from 39 to 27 floats: four of them fit in registers with room for a second wave per SIMD.
+struct nh_row1 {
+	float p_z, p_x, p_y;                   // lever arm of D
+	float n_x, u_x, v_x;
+	float n_y, u_y, v_y;
+	float n_z, u_z, v_z;
+	float bias, friction, normal_velocity_to_normal_impulse;
+	float friction_coefficient_x, friction_coefficient_y, friction_coefficient_z;
+	float nd_x, nd_y, nd_z;                // angular response of D to the normal / u / v impulse (negated when D is "a", like nh_row)
+	float ud_x, ud_y, ud_z;
+	float vd_x, vd_y, vd_z;
+};
+
+// nh_build_row with S's terms removed.  `d_is_a`: D plays the role of body a (S = b), else D = b.
+NH_HD void nh_build_row1(const nh_contact_in& c, nh_f3 dpos, const nh_inertia& D, float d_mass_inverse, bool d_is_a, nh_row1& r) {
+	float nx = c.nx, ny = c.ny, nz = c.nz;
+	float p_x = c.px - dpos.x, p_y = c.py - dpos.y, p_z = c.pz - dpos.z;
+
+	float n_xt = p_y * nz - p_z * ny, n_yt = p_z * nx - p_x * nz, n_zt = p_x * ny - p_y * nx;
+	float nd_x = D.xx * n_xt + D.xy * n_yt + D.xz * n_zt;
+	float nd_y = D.xy * n_xt + D.yy * n_yt + D.yz * n_zt;
+	float nd_z = D.xz * n_xt + D.yz * n_yt + D.zz * n_zt;
+
+	// cross(nd, p)
+	float rx = nd_y * p_z - nd_z * p_y, ry = nd_z * p_x - nd_x * p_z, rz = nd_x * p_y - nd_y * p_x;
+	float r_dot_n = rx * nx + ry * ny + rz * nz;
+
+	float mass_inverse = d_mass_inverse;
+	float nvtni = mass_inverse + r_dot_n;
+	bool nonzero = (nvtni < 0.0f) || (nvtni > 0.0f);
+	nvtni = nonzero ? (-1.0f / nvtni) : 0.0f;
+
+	float bias = (-NH_BIAS_FACTOR) * nh_max(c.penetration - NH_ALLOWED_PENETRATION, 0.0f) * nvtni;
+
+	float s = nh_abs(nx);
+	float u_x = nz * s;
+	float u_y = u_x - nz;
+	float u_z = nh_madd(nx - ny, s, ny);
+	u_x = nh_neg(u_x);
+	{
+		float f = nh_rsqrt(u_x * u_x + u_y * u_y + u_z * u_z);
+		u_x *= f; u_y *= f; u_z *= f;
+	}
+	float v_x = u_y * nz - u_z * ny, v_y = u_z * nx - u_x * nz, v_z = u_x * ny - u_y * nx;
+
+	float ud_x = p_y * u_z - p_z * u_y, ud_y = p_z * u_x - p_x * u_z, ud_z = p_x * u_y - p_y * u_x;
+	float vd_x = p_y * v_z - p_z * v_y, vd_y = p_z * v_x - p_x * v_z, vd_z = p_x * v_y - p_y * v_x;
+
+	float duu = D.xx * ud_x * ud_x + D.yy * ud_y * ud_y + D.zz * ud_z * ud_z;
+	float dvv = D.xx * vd_x * vd_x + D.yy * vd_y * vd_y + D.zz * vd_z * vd_z;
+	float duv = D.xx * ud_x * vd_x + D.yy * ud_y * vd_y + D.zz * ud_z * vd_z;
+	float suu = D.xy * ud_x * ud_y + D.xz * ud_x * ud_z + D.yz * ud_y * ud_z;
+	float svv = D.xy * vd_x * vd_y + D.xz * vd_x * vd_z + D.yz * vd_y * vd_z;
+	float suv = D.xy * (ud_x * vd_y + ud_y * vd_x) + D.xz * (ud_x * vd_z + ud_z * vd_x) + D.yz * (ud_y * vd_z + ud_z * vd_y);
+
+	float friction_x = mass_inverse + duu + suu + suu;
+	float friction_y = mass_inverse + dvv + svv + svv;
+	float friction_z = duv + duv + suv + suv;
+
+	float ud_xt = D.xx * ud_x + D.xy * ud_y + D.xz * ud_z;
+	float ud_yt = D.xy * ud_x + D.yy * ud_y + D.yz * ud_z;
+	float ud_zt = D.xz * ud_x + D.yz * ud_y + D.zz * ud_z;
+	float vd_xt = D.xx * vd_x + D.xy * vd_y + D.xz * vd_z;
+	float vd_yt = D.xy * vd_x + D.yy * vd_y + D.yz * vd_z;
+	float vd_zt = D.xz * vd_x + D.yz * vd_y + D.zz * vd_z;
+
+	r.p_x = p_x; r.p_y = p_y; r.p_z = p_z;
+	r.n_x = nx; r.n_y = ny; r.n_z = nz;
+	r.u_x = u_x; r.u_y = u_y; r.u_z = u_z;
+	r.v_x = v_x; r.v_y = v_y; r.v_z = v_z;
+	r.bias = bias; r.friction = c.friction; r.normal_velocity_to_normal_impulse = nvtni;
+	r.friction_coefficient_x = friction_x; r.friction_coefficient_y = friction_y; r.friction_coefficient_z = friction_z;
+	if (d_is_a) {
+		r.nd_x = nh_neg(nd_x); r.nd_y = nh_neg(nd_y); r.nd_z = nh_neg(nd_z);
+		r.ud_x = nh_neg(ud_xt); r.ud_y = nh_neg(ud_yt); r.ud_z = nh_neg(ud_zt);
+		r.vd_x = nh_neg(vd_xt); r.vd_y = nh_neg(vd_yt); r.vd_z = nh_neg(vd_zt);
+	} else {
+		r.nd_x = nd_x; r.nd_y = nd_y; r.nd_z = nd_z;
+		r.ud_x = ud_xt; r.ud_y = ud_yt; r.ud_z = ud_zt;
+		r.vd_x = vd_xt; r.vd_y = vd_yt; r.vd_z = vd_zt;
+	}
+}
+
+// nh_warm_start, D's half
+NH_HD void nh_warm_start1(const nh_row1& r, float cix, float ciy, float ciz, nh_vel& d, bool d_is_a, nh_state& st) {
+	float normal_impulse = nh_max(r.n_x * cix + r.n_y * ciy + r.n_z * ciz, 0.0f);
+	float max_friction_impulse = normal_impulse * r.friction;
+	float fx = r.u_x * cix + r.u_y * ciy + r.u_z * ciz;
+	float fy = r.v_x * cix + r.v_y * ciy + r.v_z * ciz;
+	float scale = fx * fx + fy * fy;
+	scale = nh_rsqrt(scale);
+	scale = scale * max_friction_impulse;
+	scale = nh_min(1.0f, scale);
+	fx = fx * scale;
+	fy = fy * scale;
+
+	float lx = fx * r.u_x + fy * r.v_x + r.n_x * normal_impulse;
+	float ly = fx * r.u_y + fy * r.v_y + r.n_y * normal_impulse;
+	float lz = fx * r.u_z + fy * r.v_z + r.n_z * normal_impulse;
+
+	float ax = fx * r.ud_x + fy * r.vd_x + normal_impulse * r.nd_x;
+	float ay = fx * r.ud_y + fy * r.vd_y + normal_impulse * r.nd_y;
+	float az = fx * r.ud_z + fy * r.vd_z + normal_impulse * r.nd_z;
+
+	if (d_is_a) { d.vx -= lx * d.mass_inverse; d.vy -= ly * d.mass_inverse; d.vz -= lz * d.mass_inverse; }
+	else        { d.vx += lx * d.mass_inverse; d.vy += ly * d.mass_inverse; d.vz += lz * d.mass_inverse; }
+	d.wx += ax; d.wy += ay; d.wz += az;
+
+	st.normal = normal_impulse; st.friction_x = fx; st.friction_y = fy;
+}
+
+// nh_apply_one, D's half
+NH_HD void nh_apply_one1(const nh_row1& r, nh_state& st, nh_vel& d, bool d_is_a) {
+	// velocity of the contact point on D, split the way the general form splits it between its two accumulators
+	float l_x = nh_madd(d.wy, r.p_z, d.vx);
+	float l_y = nh_madd(d.wz, r.p_x, d.vy);
+	float l_z = nh_madd(d.wx, r.p_y, d.vz);
+	float c_x = nh_madd(d.wz, r.p_y, 0.0f);
+	float c_y = nh_madd(d.wx, r.p_z, 0.0f);
+	float c_z = nh_madd(d.wy, r.p_x, 0.0f);
+	// general: v = v_b - v_a with (v_a, v_b) = (l, c) when D is a, (c, l) when D is b
+	float v_x = d_is_a ? (c_x - l_x) : (l_x - c_x);
+	float v_y = d_is_a ? (c_y - l_y) : (l_y - c_y);
+	float v_z = d_is_a ? (c_z - l_z) : (l_z - c_z);
+
+	float t_z = r.n_x * v_x;
+	float t_x = v_x * r.u_x;
+	float t_y = v_x * r.v_x;
+
+	float normal_bias = r.bias;
+	float old_normal_impulse = st.normal;
+	float normal_factor = r.normal_velocity_to_normal_impulse;
+
+	t_z = nh_madd(r.n_y, v_y, t_z);
+	t_x = nh_madd(v_y, r.u_y, t_x);
+	t_y = nh_madd(v_y, r.v_y, t_y);
+
+	normal_bias = normal_bias + old_normal_impulse;
+
+	t_z = nh_madd(r.n_z, v_z, t_z);
+	t_x = nh_madd(v_z, r.u_z, t_x);
+	t_y = nh_madd(v_z, r.v_z, t_y);
+
+	float normal_impulse = nh_madd(normal_factor, t_z, normal_bias);
+
+	float t_xx = t_x * t_x, t_yy = t_y * t_y, t_xy = t_x * t_y;
+	float tl2 = t_xx + t_yy;
+
+	normal_impulse = nh_max(normal_impulse, 0.0f);
+
+	t_x *= tl2;
+	t_y *= tl2;
+
+	st.normal = normal_impulse;
+
+	float max_friction_impulse = normal_impulse * r.friction;
+	normal_impulse = normal_impulse - old_normal_impulse;
+
+	float friction_factor = t_xx * r.friction_coefficient_x;
+	float linear_impulse_x = r.n_x * normal_impulse;
+	friction_factor = nh_madd(t_yy, r.friction_coefficient_y, friction_factor);
+	float linear_impulse_y = r.n_y * normal_impulse;
+	friction_factor = nh_madd(t_xy, r.friction_coefficient_z, friction_factor);
+	float linear_impulse_z = r.n_z * normal_impulse;
+
+	friction_factor = nh_recip(friction_factor);
+
+	d.wx = nh_madd(r.nd_x, normal_impulse, d.wx);
+	d.wy = nh_madd(r.nd_y, normal_impulse, d.wy);
+	d.wz = nh_madd(r.nd_z, normal_impulse, d.wz);
+
+	float old_friction_impulse_x = st.friction_x, old_friction_impulse_y = st.friction_y;
+
+	friction_factor = nh_min(1e+6f, friction_factor);
+
+	float friction_impulse_x = t_x * friction_factor;
+	float friction_impulse_y = t_y * friction_factor;
+
+	friction_impulse_x = old_friction_impulse_x - friction_impulse_x;
+	friction_impulse_y = old_friction_impulse_y - friction_impulse_y;
+
+	float friction_clamp_scale = friction_impulse_x * friction_impulse_x + friction_impulse_y * friction_impulse_y;
+	friction_clamp_scale = nh_rsqrt(friction_clamp_scale);
+
+	friction_clamp_scale = friction_clamp_scale * max_friction_impulse;
+	friction_clamp_scale = nh_min(1.0f, friction_clamp_scale);
+
+	friction_impulse_x = friction_impulse_x * friction_clamp_scale;
+	friction_impulse_y = friction_impulse_y * friction_clamp_scale;
+
+	st.friction_x = friction_impulse_x;
+	st.friction_y = friction_impulse_y;
+
+	friction_impulse_x -= old_friction_impulse_x;
+	friction_impulse_y -= old_friction_impulse_y;
+
+	linear_impulse_x = nh_madd(r.u_x, friction_impulse_x, linear_impulse_x);
+	linear_impulse_y = nh_madd(r.u_y, friction_impulse_x, linear_impulse_y);
+	linear_impulse_z = nh_madd(r.u_z, friction_impulse_x, linear_impulse_z);
+
+	linear_impulse_x = nh_madd(r.v_x, friction_impulse_y, linear_impulse_x);
+	linear_impulse_y = nh_madd(r.v_y, friction_impulse_y, linear_impulse_y);
+	linear_impulse_z = nh_madd(r.v_z, friction_impulse_y, linear_impulse_z);
+
+	float signed_mass_inverse = d_is_a ? nh_neg(d.mass_inverse) : d.mass_inverse;
+
+	d.vx = nh_madd(linear_impulse_x, signed_mass_inverse, d.vx);
+	d.vy = nh_madd(linear_impulse_y, signed_mass_inverse, d.vy);
+	d.vz = nh_madd(linear_impulse_z, signed_mass_inverse, d.vz);
+
+	d.wx = nh_madd(r.ud_x, friction_impulse_x, d.wx);
+	d.wy = nh_madd(r.ud_y, friction_impulse_x, d.wy);
+	d.wz = nh_madd(r.ud_z, friction_impulse_x, d.wz);
+
+	d.wx = nh_madd(r.vd_x, friction_impulse_y, d.wx);
+	d.wy = nh_madd(r.vd_y, friction_impulse_y, d.wy);
+	d.wz = nh_madd(r.vd_z, friction_impulse_y, d.wz);
+
+	d.w_unused = 0.0f;
+}
+
+NH_HD void nh_export_impulse1(const nh_row1& r, const nh_state& st, float& ix, float& iy, float& iz) {
+	ix = st.normal * r.n_x + st.friction_x * r.u_x + st.friction_y * r.v_x;
+	iy = st.normal * r.n_y + st.friction_x * r.u_y + st.friction_y * r.v_y;
+	iz = st.normal * r.n_z + st.friction_x * r.u_z + st.friction_y * r.v_z;
+}
+
+// true iff body 0 qualifies as S above (all bits zero)
+NH_HD bool nh_is_inert(const float* velocity, const float* angular_velocity, const float* inertia_inverse, float mass_inverse) {
+	uint32_t acc = nh_asuint(mass_inverse);
+	for (int k = 0; k < 3; ++k) acc |= nh_asuint(velocity[k]) | nh_asuint(angular_velocity[k]) | nh_asuint(inertia_inverse[k]);
+	return acc == 0u;
+}
+
 // update_cached_impulses, one contact (nudge.cpp:4872-4882)
 NH_HD void nh_export_impulse(const nh_row& r, const nh_state& st, float& ix, float& iy, float& iz) {
 	ix = st.normal * r.n_x + st.friction_x * r.u_x + st.friction_y * r.v_x;

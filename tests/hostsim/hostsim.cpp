@@ -152,6 +152,70 @@ void hs_solve(uint32_t nbodies, const Xf* body_xf, const float* props /*4 per: i
 	}
 }
 
+// Same solve, but contacts against body 0 go through the ONE-BODY forms (nh_row1 / nh_apply_one1 ...) the fused GPU kernel uses
+// when body 0 is inert.  Returns the number of contacts that took that path (0 if body 0 is not inert).
+int hs_solve_one_body(uint32_t nbodies, const Xf* body_xf, const float* props, float* momentum,
+                      uint32_t ncontacts, const float* contacts, const uint32_t* bodies, const float* cached,
+                      uint32_t norder, const uint32_t* order, uint32_t iterations, float* out_impulses) {
+	if (!nh_is_inert(momentum, momentum + 4, props, props[3])) return 0;
+	std::vector<nh_row> rows(ncontacts);
+	std::vector<nh_row1> rows1(ncontacts);
+	std::vector<nh_state> st(ncontacts);
+	std::vector<uint32_t> seq;
+	std::vector<uint8_t> seen(ncontacts, 0);
+	for (uint32_t i = 0; i < norder; ++i) { uint32_t c = order[i]; if (!seen[c]) { seen[c] = 1; seq.push_back(c); } }
+	for (uint32_t i = 0; i < nbodies; ++i) momentum[8*i+3] = props[4*i+3];
+	auto load = [&](uint32_t b) { nh_vel v; memcpy(&v, momentum + 8*b, 32); return v; };
+	auto store = [&](uint32_t b, const nh_vel& v) { memcpy(momentum + 8*b, &v, 32); };
+	auto one = [&](uint32_t c) { return (bodies[2*c] == 0) != (bodies[2*c+1] == 0); };
+	int taken = 0;
+	for (uint32_t c : seq) {
+		uint32_t a = bodies[2*c], b = bodies[2*c+1];
+		nh_contact_in ci; memcpy(&ci, contacts + 8*c, 32);
+		if (one(c)) {
+			uint32_t d = a ? a : b;
+			nh_quat qd = { body_xf[d].q[0], body_xf[d].q[1], body_xf[d].q[2], body_xf[d].q[3] };
+			nh_inertia ID = nh_world_inertia(qd, props[4*d], props[4*d+1], props[4*d+2]);
+			nh_build_row1(ci, nh_make3(body_xf[d].p[0], body_xf[d].p[1], body_xf[d].p[2]), ID, props[4*d+3], a != 0, rows1[c]);
+			nh_vel vd = load(d);
+			nh_warm_start1(rows1[c], cached[4*c], cached[4*c+1], cached[4*c+2], vd, a != 0, st[c]);
+			store(d, vd);
+			++taken;
+			continue;
+		}
+		nh_quat qa = { body_xf[a].q[0], body_xf[a].q[1], body_xf[a].q[2], body_xf[a].q[3] };
+		nh_quat qb = { body_xf[b].q[0], body_xf[b].q[1], body_xf[b].q[2], body_xf[b].q[3] };
+		nh_inertia IA = nh_world_inertia(qa, props[4*a], props[4*a+1], props[4*a+2]);
+		nh_inertia IB = nh_world_inertia(qb, props[4*b], props[4*b+1], props[4*b+2]);
+		nh_build_row(ci, nh_make3(body_xf[a].p[0], body_xf[a].p[1], body_xf[a].p[2]), nh_make3(body_xf[b].p[0], body_xf[b].p[1], body_xf[b].p[2]),
+		             IA, IB, props[4*a+3], props[4*b+3], rows[c]);
+		nh_vel va = load(a), vb = load(b);
+		nh_warm_start(rows[c], cached[4*c], cached[4*c+1], cached[4*c+2], va, vb, st[c]);
+		store(a, va); store(b, vb);
+	}
+	for (uint32_t it = 0; it < iterations; ++it)
+		for (uint32_t c : seq) {
+			uint32_t a = bodies[2*c], b = bodies[2*c+1];
+			if (one(c)) {
+				uint32_t d = a ? a : b;
+				nh_vel vd = load(d);
+				nh_apply_one1(rows1[c], st[c], vd, a != 0);
+				store(d, vd);
+				continue;
+			}
+			nh_vel va = load(a), vb = load(b);
+			nh_apply_one(rows[c], st[c], va, vb);
+			store(a, va); store(b, vb);
+		}
+	for (uint32_t c = 0; c < ncontacts; ++c) {
+		if (!seen[c]) continue;
+		if (one(c)) nh_export_impulse1(rows1[c], st[c], out_impulses[4*c], out_impulses[4*c+1], out_impulses[4*c+2]);
+		else nh_export_impulse(rows[c], st[c], out_impulses[4*c], out_impulses[4*c+1], out_impulses[4*c+2]);
+	}
+	// the general path zeroes unused1 of every body it touches, body 0 included (nudge.cpp:4823, 4849)
+	return taken;
+}
+
 void hs_advance(uint32_t nactive, const uint32_t* active, Xf* body_xf, const float* momentum, uint8_t* idle, float dt) {
 	for (uint32_t n = 0; n < nactive; ++n) {
 		uint32_t i = active[n];

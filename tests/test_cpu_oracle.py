@@ -117,6 +117,41 @@ def test_solver_math_bit_exact(name, warm):
 
 
 @needs_ref
+@pytest.mark.parametrize("name,warms", [("pile256", (30, 100, 350)), ("pile_mixed", (60, 400)), ("grid30", (38, 45, 70)), ("mixed20", (40, 80)), ("pit6", (40, 150)), ("stacks", (5, 60))])
+def test_one_body_forms_equal_general_forms(name, warms):
+    """The fused GPU kernel solves contacts against the inert body 0 with nh_row1 / nh_apply_one1 (the general arithmetic minus
+    the operations that only ever multiply zeros): bit-identical to the reference on the golden scenes, first impacts included."""
+    scene, _ = G.build(name)
+    p = scene["params"]
+    w = refworld.RefWorld(scene)
+    done = 0
+    total = 0
+    for warm in warms:
+        w.step(warm - done)
+        done = warm
+        w.collide()
+        w.gravity()
+        w.read_cache()
+        c = w.contacts()
+        cached = w.contact_impulses()
+        b1 = w.bodies()
+        w.setup()
+        order = w.solver_order().reshape(-1)
+        w.apply()
+        w.update()
+        b2 = w.bodies()
+        mom, out, taken = H.solve(b1["transforms"], scene["body_properties"], b1["momentum"], c["data"], c["bodies"], cached, order, p["iterations"], one_body=True)
+        total += taken
+        assert P.bits_equal(mom["velocity"][1:], b2["momentum"]["velocity"][1:])
+        assert P.bits_equal(mom["angular_velocity"][1:], b2["momentum"]["angular_velocity"][1:])
+        assert P.bits_equal(out["impulse"], w.contact_impulses()["impulse"])
+        w.write_cache()
+        w.advance()
+        done += 1
+    assert total > 0
+
+
+@needs_ref
 def test_closed_form_solver_order_equals_reference_scheduler_on_drop_scenes():
     """batch(i) = (i/128)*16 + i%16 is what nudge.cpp:4206-4339 produces when no lane conflicts occur."""
     for scene, warm in ((S.grid_tiles(1, side=30), 70), (S.grid_tiles(1, side=40, sphere_fraction=0.5), 70)):
