@@ -625,7 +625,13 @@ __device__ __noinline__ void cache_search(const nh_CacheView& cv, uint32_t m, ui
 	if (lo < m && cv.ctags[lo] == t && cv.cfeatures[lo] == f) { const float4 w = *reinterpret_cast<const float4*>(cv.cdata + lo); wx = w.x; wy = w.y; wz = w.z; }
 }
 
-// four 27-float rows fit in 256 registers: two waves per SIMD (the compiler would otherwise spend 260 and run one)
+// Memory access.  One lane owns one body, but a body's per-contact records (contact, pair, tags, cache entry: 8 arrays) are
+// fetched by the WAVE: slot e = 4 * body + q of the wave's 64 bodies is loaded by lane e % 64 in round e / 64, so that
+// consecutive lanes read consecutive contacts (a body's contacts are adjacent in tag order, and so are its neighbours')
+// instead of 64 lanes striding 128 bytes apart; the records reach their owner through LDS.  Results go back the same way.
+// Four 27-float rows fit in 256 registers: two waves per SIMD (the compiler would otherwise spend 260 and run one).
+struct nh_ob_slot { float4 c0, c1, w; };      // contact (32 B), cached impulse xyz + flags in w.w (bit 0 miss, bit 1 body is "a")
+
 template<int MAXC, bool FUSED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ? 2 : 1, MAXC == 4 ? 2 : 1))) void k_solve_one_body(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
                                                         const nh_BodyPair* __restrict__ bodies, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
@@ -633,13 +639,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
                                                         const nh_Contact* __restrict__ contacts, const nh_Transform* __restrict__ xf, nh_CachedContactImpulse* __restrict__ impulses,
                                                         nh_CacheView cv, uint32_t* __restrict__ hint) {
 	constexpr int M = MAXC;
-	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < nbodies; x += gridDim.x * blockDim.x) {
-		if (body_class[x] != (MAXC == 4 ? NH_CLS_STATIC4 : NH_CLS_STATIC8)) continue;
-		const uint32_t b = off[x], cnt = off[x + 1] - b;
+	__shared__ nh_ob_slot s_slot[4][64 * M];
+	__shared__ uint32_t s_cid[4][64 * M];
+	__shared__ uint32_t s_hint[4][64], s_first[4][64];
+	const uint32_t wave = threadIdx.x >> 6, lane = nh_lane();
+	nh_ob_slot* slot = s_slot[wave];
+	uint32_t* scid = s_cid[wave];
+	const uint32_t m = FUSED ? cv.st->cache : 0u;
+	const uint32_t rounded = (nbodies + 255u) & ~255u;
+	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < rounded; x += gridDim.x * blockDim.x) {       // block-uniform trip count
+		const bool mine = x < nbodies && body_class[x] == (MAXC == 4 ? NH_CLS_STATIC4 : NH_CLS_STATIC8);
+		const uint32_t wave_x0 = x - lane;
+		uint32_t b = 0, cnt = 0;
+		if (mine) { b = off[x]; cnt = off[x + 1] - b; }
 		// body state: 16-byte loads (the records are 16 / 32 bytes and aligned, include/nudge_hip.h)
-		const float4 m0 = reinterpret_cast<const float4*>(momentum + x)[0], m1 = reinterpret_cast<const float4*>(momentum + x)[1];
-		const float4 pr = *reinterpret_cast<const float4*>(props + x);
-		const float4 t0 = reinterpret_cast<const float4*>(xf + x)[0], t1 = reinterpret_cast<const float4*>(xf + x)[1];
+		float4 m0 = make_float4(0, 0, 0, 0), m1 = m0, pr = m0, t0 = m0, t1 = make_float4(0, 0, 0, 1);
+		uint32_t h = NH_HINT_NONE;
+		if (mine) {
+			m0 = reinterpret_cast<const float4*>(momentum + x)[0]; m1 = reinterpret_cast<const float4*>(momentum + x)[1];
+			pr = *reinterpret_cast<const float4*>(props + x);
+			t0 = reinterpret_cast<const float4*>(xf + x)[0]; t1 = reinterpret_cast<const float4*>(xf + x)[1];
+			if (FUSED) h = hint[x];
+		}
+		uint32_t cid[M];
+		uint32_t first = 0xFFFFFFFFu;
+#pragma unroll
+		for (int q = 0; q < M; ++q) { cid[q] = (uint32_t)q < cnt ? adj[b + q] : 0xFFFFFFFFu; first = min(first, cid[q]); }
+#pragma unroll
+		for (int q = 0; q < M; ++q) scid[lane * M + q] = cid[q];
+		s_hint[wave][lane] = h; s_first[wave][lane] = first;
+		__builtin_amdgcn_wave_barrier();
+		// phase A: the wave fetches the per-contact records slot by slot
+#pragma unroll
+		for (int k = 0; k < M; ++k) {
+			const uint32_t e = 64u * k + lane, j = e / M;
+			const uint32_t c = scid[e];
+			nh_ob_slot o;
+			o.c0 = make_float4(0, 0, 0, 0); o.c1 = o.c0; o.w = o.c0;
+			if (c != 0xFFFFFFFFu) {
+				o.c0 = reinterpret_cast<const float4*>(contacts + c)[0];
+				o.c1 = reinterpret_cast<const float4*>(contacts + c)[1];
+				uint32_t flags = bodies[c].a == wave_x0 + j ? 2u : 0u;
+				if (FUSED) {
+					const uint32_t hj = s_hint[wave][j];
+					const uint32_t guess = hj != NH_HINT_NONE ? hj + (c - s_first[wave][j]) : c;
+					float wx = 0.0f, wy = 0.0f, wz = 0.0f;
+					if (!cache_probe(cv, m, guess, cv.tags[c], cv.features[c], wx, wy, wz)) flags |= 1u;
+					o.w = make_float4(wx, wy, wz, __uint_as_float(flags));
+				} else {
+					const float4 sv = states[c];
+					o.w = make_float4(sv.x, sv.y, sv.z, __uint_as_float(flags));
+				}
+			}
+			slot[e] = o;
+		}
+		__builtin_amdgcn_wave_barrier();
 		nh_vel v = { m0.x, m0.y, m0.z, pr.w, m1.x, m1.y, m1.z, m1.w };
 		const nh_quat qx = { t1.x, t1.y, t1.z, t1.w };
 		const nh_inertia IX = nh_world_inertia(qx, pr.x, pr.y, pr.z);
@@ -647,63 +701,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
 		nh_row1 r[M];
 		nh_state s[M];
 		bool is_a[M];
-		uint32_t cid[M];
-		// phase A: everything the body needs from memory, as independent loads
-		float4 c0[M], c1[M];
-		float wx[M], wy[M], wz[M];
-		bool miss[M];
-		const uint32_t m = FUSED ? cv.st->cache : 0u;
-		const uint32_t h = FUSED ? hint[x] : NH_HINT_NONE;
-		uint32_t first = 0xFFFFFFFFu;
-#pragma unroll
-		for (int q = 0; q < M; ++q) { cid[q] = (uint32_t)q < cnt ? adj[b + q] : 0xFFFFFFFFu; first = min(first, cid[q]); }
-#pragma unroll
-		for (int q = 0; q < M; ++q) {
-			miss[q] = false; wx[q] = wy[q] = wz[q] = 0.0f; is_a[q] = false;
-			if ((uint32_t)q < cnt) {
-				const uint32_t c = cid[q];
-				is_a[q] = bodies[c].a == x;
-				c0[q] = reinterpret_cast<const float4*>(contacts + c)[0];
-				c1[q] = reinterpret_cast<const float4*>(contacts + c)[1];
-				if (FUSED) {
-					const uint32_t guess = h != NH_HINT_NONE ? h + (c - first) : c;
-					miss[q] = !cache_probe(cv, m, guess, cv.tags[c], cv.features[c], wx[q], wy[q], wz[q]);
-				} else {
-					float4 sv = states[c];
-					s[q].normal = sv.x; s[q].friction_x = sv.y; s[q].friction_y = sv.z;
-				}
-			}
-		}
-		if (FUSED) {
-#pragma unroll
-			for (int q = 0; q < M; ++q)
-				if (miss[q]) cache_search(cv, m, h != NH_HINT_NONE ? h + (cid[q] - first) : cid[q], cv.tags[cid[q]], cv.features[cid[q]], wx[q], wy[q], wz[q]);
-			hint[x] = first;                    // where this body's contacts start in what becomes the next step's cache
-		}
 		// phase B: rows, and (fused) the warm start in slot order
 #pragma unroll
 		for (int q = 0; q < M; ++q) {
+			is_a[q] = false;
 			if ((uint32_t)q < cnt) {
-				nh_contact_in ci = { c0[q].x, c0[q].y, c0[q].z, c0[q].w, c1[q].x, c1[q].y, c1[q].z, c1[q].w };
+				const nh_ob_slot o = slot[lane * M + q];
+				const uint32_t flags = __float_as_uint(o.w.w);
+				is_a[q] = (flags & 2u) != 0;
+				nh_contact_in ci = { o.c0.x, o.c0.y, o.c0.z, o.c0.w, o.c1.x, o.c1.y, o.c1.z, o.c1.w };
 				nh_build_row1(ci, posx, IX, v.mass_inverse, is_a[q], r[q]);
-				if (FUSED) nh_warm_start1(r[q], wx[q], wy[q], wz[q], v, is_a[q], s[q]);
+				if (FUSED) {
+					float wx = o.w.x, wy = o.w.y, wz = o.w.z;
+					if (flags & 1u) cache_search(cv, m, h != NH_HINT_NONE ? h + (cid[q] - first) : cid[q], cv.tags[cid[q]], cv.features[cid[q]], wx, wy, wz);
+					nh_warm_start1(r[q], wx, wy, wz, v, is_a[q], s[q]);
+				} else {
+					s[q].normal = o.w.x; s[q].friction_x = o.w.y; s[q].friction_y = o.w.z;
+				}
 			}
 		}
+		if (FUSED && mine) hint[x] = first;          // where this body's contacts start in what becomes the next step's cache
 		for (uint32_t it = 0; it < iterations; ++it) {
 #pragma unroll
 			for (int q = 0; q < M; ++q)
 				if ((uint32_t)q < cnt) nh_apply_one1(r[q], s[q], v, is_a[q]);
 		}
+		// results: state + exported impulse (update_cached_impulses, nudge.cpp:4872-4882) per contact, written by the wave slot by slot
+		__builtin_amdgcn_wave_barrier();
 #pragma unroll
-		for (int q = 0; q < M; ++q)
+		for (int q = 0; q < M; ++q) {
 			if ((uint32_t)q < cnt) {
-				states[cid[q]] = make_float4(s[q].normal, s[q].friction_x, s[q].friction_y, 0.0f);
-				float ox, oy, oz;                 // update_cached_impulses (nudge.cpp:4872-4882) for this contact
+				float ox, oy, oz;
 				nh_export_impulse1(r[q], s[q], ox, oy, oz);
-				*reinterpret_cast<float4*>(impulses + cid[q]) = make_float4(ox, oy, oz, 0.0f);
+				slot[lane * M + q].c0 = make_float4(s[q].normal, s[q].friction_x, s[q].friction_y, 0.0f);
+				slot[lane * M + q].c1 = make_float4(ox, oy, oz, 0.0f);
 			}
-		reinterpret_cast<float4*>(momentum + x)[0] = make_float4(v.vx, v.vy, v.vz, v.mass_inverse);
-		reinterpret_cast<float4*>(momentum + x)[1] = make_float4(v.wx, v.wy, v.wz, v.w_unused);
+		}
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (int k = 0; k < M; ++k) {
+			const uint32_t e = 64u * k + lane;
+			const uint32_t c = scid[e];
+			if (c != 0xFFFFFFFFu) {
+				states[c] = slot[e].c0;
+				*reinterpret_cast<float4*>(impulses + c) = slot[e].c1;
+			}
+		}
+		if (mine) {
+			reinterpret_cast<float4*>(momentum + x)[0] = make_float4(v.vx, v.vy, v.vz, v.mass_inverse);
+			reinterpret_cast<float4*>(momentum + x)[1] = make_float4(v.wx, v.wy, v.wz, v.w_unused);
+		}
+		__builtin_amdgcn_wave_barrier();
 	}
 }
 
