@@ -713,7 +713,11 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	uint32_t* vals_a = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* vals_b = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* large_list = nh_arena_array<uint32_t>(A, C, &err);
-	uint32_t* hist = nh_arena_array<uint32_t>(A, 256 * NH_SORT_GRID + 512, &err);
+	const uint32_t pair_cap = cap / 2 + 1024;           // broadphase pairs; each owns 4 raw contact slots, the rest overflows
+	const bool onesweep = getenv("NH_SORT_CLASSIC") == nullptr;      // one kernel per radix pass (nh_util.hip); NH_SORT_CLASSIC=1: three
+	size_t hist_words = 256 * NH_SORT_GRID + 512;
+	if (onesweep && nh_sort_scratch_words(C > pair_cap ? C : pair_cap) > hist_words) hist_words = nh_sort_scratch_words(C > pair_cap ? C : pair_cap);
+	uint32_t* hist = nh_arena_array<uint32_t>(A, hist_words, &err);
 	uint32_t* scan_tmp = nh_arena_array<uint32_t>(A, NH_SORT_GRID + 64, &err);
 	// grid table: a power of two, up to 4 cells per collider; 2^22 entries (two 11-bit radix passes) while that leaves at
 	// least one cell per collider.  Cell keys are < max_cells - 1, so the large key (all ones) sorts last on cell_bits bits.
@@ -724,7 +728,6 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	const uint32_t max_cells = (uint32_t)want;
 	int cell_bits = 0; while ((1ull << cell_bits) < want) ++cell_bits;
 	uint2* cells = nh_arena_array<uint2>(A, max_cells, &err);
-	const uint32_t pair_cap = cap / 2 + 1024;           // broadphase pairs; each owns 4 raw contact slots, the rest overflows
 	const uint32_t overflow_cap = cap;
 	uint2* pairs = nh_arena_array<uint2>(A, pair_cap, &err);
 	nh_Contact* raw_data = nh_arena_array<nh_Contact>(A, (size_t)4 * pair_cap + overflow_cap, &err);
@@ -753,7 +756,8 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "small_bounds", k_small_bounds, nh_grid_for(C, 256, 1024), 256, st, C, aabb_min, aabb_max);
 		NH_LAUNCH(ctx, "grid_dims", k_grid_dims, 1, 64, st, max_cells);
 		NH_LAUNCH(ctx, "cell_keys", k_cell_keys, nh_grid_for(C, 256, 2048), 256, st, C, aabb_min, aabb_max, keys_a, vals_a, mkey, large_list);
-		if (nh_sort_u32_u32(ctx, keys_a, keys_b, vals_a, vals_b, &st->colliders, hist, 0, ((cell_bits + 7) / 8) * 8)) { uint32_t* t = keys_a; keys_a = keys_b; keys_b = t; t = vals_a; vals_a = vals_b; vals_b = t; }
+		if (onesweep ? nh_onesweep_u32_u32(ctx, keys_a, keys_b, vals_a, vals_b, &st->colliders, C, C, hist, 0, ((cell_bits + 7) / 8) * 8)
+		             : nh_sort_u32_u32(ctx, keys_a, keys_b, vals_a, vals_b, &st->colliders, hist, 0, ((cell_bits + 7) / 8) * 8)) { uint32_t* t = keys_a; keys_a = keys_b; keys_b = t; t = vals_a; vals_a = vals_b; vals_b = t; }
 		if (ctx->timing) nh_timer_begin(ctx, "memset_cells");
 		NH_HIP_CHECK(ctx, hipMemsetAsync(cells, 0, sizeof(uint2) * (size_t)max_cells, s));
 		if (ctx->timing) nh_timer_end(ctx);
@@ -782,11 +786,17 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	if (key_bits < 1) key_bits = 1;
 	if (key_bits > 32) key_bits = 32;
 	// keys are a | b<<32: sort the low field, then the high field (stable) -- dropped records carry ~0 and end up last
-	if (nh_sort_u64_u32(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, &st->records, hist, 0, ((key_bits + 7) / 8) * 8)) {
-		uint64_t* t = rec_key_a; rec_key_a = rec_key_b; rec_key_b = t; uint32_t* u = rec_idx_a; rec_idx_a = rec_idx_b; rec_idx_b = u;
-	}
-	if (nh_sort_u64_u32(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, &st->records, hist, 32, 32 + ((key_bits + 7) / 8) * 8)) {
-		uint64_t* t = rec_key_a; rec_key_a = rec_key_b; rec_key_b = t; uint32_t* u = rec_idx_a; rec_idx_a = rec_idx_b; rec_idx_b = u;
+	if (onesweep) {
+		if (nh_onesweep_u64_u32_two_fields(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, &st->records, pair_cap, ctx->h_state->records, hist, 0, ((key_bits + 7) / 8) * 8, 32, 32 + ((key_bits + 7) / 8) * 8)) {
+			uint64_t* t = rec_key_a; rec_key_a = rec_key_b; rec_key_b = t; uint32_t* u = rec_idx_a; rec_idx_a = rec_idx_b; rec_idx_b = u;
+		}
+	} else {
+		if (nh_sort_u64_u32(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, &st->records, hist, 0, ((key_bits + 7) / 8) * 8)) {
+			uint64_t* t = rec_key_a; rec_key_a = rec_key_b; rec_key_b = t; uint32_t* u = rec_idx_a; rec_idx_a = rec_idx_b; rec_idx_b = u;
+		}
+		if (nh_sort_u64_u32(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, &st->records, hist, 32, 32 + ((key_bits + 7) / 8) * 8)) {
+			uint64_t* t = rec_key_a; rec_key_a = rec_key_b; rec_key_b = t; uint32_t* u = rec_idx_a; rec_idx_a = rec_idx_b; rec_idx_b = u;
+		}
 	}
 	// (dropped records carry count 0, so where they land in the order is irrelevant)
 	NH_LAUNCH(ctx, "sorted_counts", k_sorted_counts, nh_grid_for(pair_cap, 256, 2048), 256, st, rec_idx_a, rec, rec_counts, sleep_flags);

@@ -125,6 +125,200 @@ static int sort_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* vals_b
 	return passes & 1;      // 1: the sorted data sits in the *_b buffers
 }
 
+// ---- stable LSD radix sort, 8-bit digits, ONE kernel per pass ------------------------------------------------------------
+// For the ~1 M-key sorts of this engine the three-kernel pass above is bound by launch latency and by its serial tile loops,
+// not by bandwidth.  Here a sort is: clear a control block, ONE histogram kernel that counts the digits of every pass, then one
+// kernel per pass in which every workgroup takes the next tile of OS_TILE consecutive keys (tickets: tiles start in order, so
+// everything a tile waits for belongs to a workgroup that is already running), ranks its keys, publishes the tile's 256 digit
+// counts and obtains the number of equal digits in earlier tiles from what the others published:
+//     exclusive(t, d) = sum of GROUP sums of the groups before t's  +  counts of the earlier tiles of t's own group,
+// where the last tile of a group of OS_GROUP tiles publishes the group sum once its group has published.  Every wait is on
+// loads that are independent of each other (no chain of dependent look-backs: with all tiles resident at once a chained
+// look-back is ~500 serial hops): two visibility hops per pass.
+// Control block (words): ghist[OS_MAX_PASSES][256] | ticket[256] | per pass: tile counts [tiles][256], group sums [groups][256].
+#define OS_KPT 8
+#define OS_TILE (256 * OS_KPT)
+#define OS_GROUP 32
+#define OS_MAX_GRID 1024                  // 4 workgroups of 256 per CU: resident for sure (5 KB LDS, < 64 VGPRs)
+#define OS_MAX_PASSES 8
+#define OS_READY 0x80000000u
+#define OS_VALUE_MASK 0x7FFFFFFFu
+
+struct os_shifts { int s[OS_MAX_PASSES]; int n; };
+
+static inline uint32_t os_tiles(uint32_t capacity) { return (uint32_t)(((size_t)capacity + OS_TILE - 1) / OS_TILE) + 1; }
+static inline uint32_t os_groups(uint32_t tiles) { return (tiles + OS_GROUP - 1) / OS_GROUP; }
+
+size_t nh_sort_scratch_words(uint32_t capacity) {
+	size_t tiles = os_tiles(capacity);
+	return (size_t)OS_MAX_PASSES * 256 + 256 + (size_t)OS_MAX_PASSES * (tiles + os_groups((uint32_t)tiles)) * 256;
+}
+
+template<typename K>
+__global__ __launch_bounds__(256) void os_hist(const K* __restrict__ keys, const uint32_t* __restrict__ d_n, uint32_t* __restrict__ ghist, os_shifts sh) {
+	__shared__ uint32_t h[OS_MAX_PASSES][256];
+	for (int p = 0; p < sh.n; ++p) h[p][threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t n = *d_n;
+	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+		K k = keys[i];
+		for (int p = 0; p < sh.n; ++p) atomicAdd(&h[p][(uint32_t)(k >> sh.s[p]) & 255u], 1u);
+	}
+	__syncthreads();
+	for (int p = 0; p < sh.n; ++p) { uint32_t c = h[p][threadIdx.x]; if (c) atomicAdd(&ghist[p * 256 + threadIdx.x], c); }
+}
+
+// sum of `count` published values p[0], p[stride], ... : sixteen independent loads in flight, re-polling only what is not there yet
+__device__ __forceinline__ uint32_t os_sum_published(const uint32_t* p, uint32_t count, size_t stride) {
+	uint32_t sum = 0;
+	for (uint32_t t0 = 0; t0 < count; t0 += 16) {
+		uint32_t v[16];
+#pragma unroll
+		for (int k = 0; k < 16; ++k) v[k] = t0 + k < count ? __hip_atomic_load(p + (size_t)(t0 + k) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : OS_READY;
+#pragma unroll
+		for (int k = 0; k < 16; ++k) {
+			while (!(v[k] & OS_READY)) { __builtin_amdgcn_s_sleep(1); v[k] = __hip_atomic_load(p + (size_t)(t0 + k) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+			sum += v[k] & OS_VALUE_MASK;
+		}
+	}
+	return sum;
+}
+
+template<typename K, typename V, bool HAS_V>
+__global__ __launch_bounds__(256) void os_pass(const K* __restrict__ keys, K* __restrict__ keys_out, const V* __restrict__ vals, V* __restrict__ vals_out,
+                                               const uint32_t* __restrict__ d_n, const uint32_t* __restrict__ ghist, uint32_t* __restrict__ ticket,
+                                               uint32_t* __restrict__ tile_count, uint32_t* __restrict__ group_sum, int shift) {
+	__shared__ uint32_t s_tile;
+	__shared__ uint32_t offs[256];
+	__shared__ uint32_t whist[4][256];
+	__shared__ uint32_t wtot[4];
+	const uint32_t n = *d_n;
+	const uint32_t ntiles = (n + OS_TILE - 1) / OS_TILE;
+	// Tile = workgroup index for the first gridDim.x tiles: the launch never exceeds what is resident at once (OS_MAX_GRID), so
+	// every tile a workgroup waits for belongs to a workgroup that is running or done.  (One ticket per workgroup on a single hot
+	// counter would serialise ~12 ns each.)  Surplus tiles -- more keys than the launch was sized for, or more than OS_MAX_GRID
+	// tiles -- go out by ticket to the workgroups that finish, in order, so they too only wait on tiles that are held.
+	for (uint32_t tile = blockIdx.x; tile < ntiles; ) {
+	whist[0][threadIdx.x] = 0; whist[1][threadIdx.x] = 0; whist[2][threadIdx.x] = 0; whist[3][threadIdx.x] = 0;
+	__syncthreads();
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t tile_begin = tile * OS_TILE;
+	uint32_t* wh = whist[wave];
+	K key[OS_KPT];
+	V val[OS_KPT];
+	uint32_t dig[OS_KPT], local[OS_KPT];
+#pragma unroll
+	for (int q = 0; q < OS_KPT; ++q) {
+		uint32_t i = tile_begin + wave * (64u * OS_KPT) + q * 64u + lane;       // a wave owns 512 consecutive keys
+		key[q] = i < n ? keys[i] : (K)0;
+		if (HAS_V) val[q] = i < n ? vals[i] : V();
+	}
+	// digit base of this pass: exclusive scan of the 256 digit totals
+	uint32_t base;
+	{
+		uint32_t v = ghist[threadIdx.x];
+		uint32_t x = v;
+		for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+		if (lane == 63) wtot[wave] = x;
+		__syncthreads();
+		base = x - v;
+		for (unsigned w = 0; w < wave; ++w) base += wtot[w];
+	}
+#pragma unroll
+	for (int q = 0; q < OS_KPT; ++q) {
+		uint32_t i = tile_begin + wave * (64u * OS_KPT) + q * 64u + lane;
+		bool valid = i < n;
+		uint32_t d = (uint32_t)(key[q] >> shift) & 255u;
+		dig[q] = d;
+		unsigned long long mask = __ballot(valid);
+#pragma unroll
+		for (int b = 0; b < 8; ++b) {
+			unsigned long long bal = __ballot((d >> b) & 1u);
+			mask &= ((d >> b) & 1u) ? bal : ~bal;
+		}
+		uint32_t rank = __popcll(mask & ((1ull << lane) - 1ull));
+		uint32_t before = valid ? wh[d] : 0u;                    // keys of this digit seen by this wave in earlier rounds
+		__builtin_amdgcn_wave_barrier();
+		if (valid && rank == 0) wh[d] = before + (uint32_t)__popcll(mask);
+		__builtin_amdgcn_wave_barrier();
+		local[q] = before + rank;
+	}
+	__syncthreads();
+	{
+		// thread d owns digit d
+		const uint32_t d = threadIdx.x;
+		const uint32_t cnt = whist[0][d] + whist[1][d] + whist[2][d] + whist[3][d];
+		__hip_atomic_store(tile_count + (size_t)tile * 256 + d, OS_READY | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t group = tile / OS_GROUP, first = group * OS_GROUP;
+		const uint32_t in_group = os_sum_published(tile_count + (size_t)first * 256 + d, tile - first, 256);
+		const bool closes_group = (tile % OS_GROUP) == OS_GROUP - 1 || tile == ntiles - 1;
+		if (closes_group) __hip_atomic_store(group_sum + (size_t)group * 256 + d, OS_READY | (in_group + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t before_groups = os_sum_published(group_sum + d, group, 256);
+		offs[d] = base + before_groups + in_group;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int q = 0; q < OS_KPT; ++q) {
+		uint32_t i = tile_begin + wave * (64u * OS_KPT) + q * 64u + lane;
+		if (i < n) {
+			uint32_t d = dig[q];
+			uint32_t pos = offs[d] + local[q];
+			for (unsigned w = 0; w < wave; ++w) pos += whist[w][d];
+			keys_out[pos] = key[q];
+			if (HAS_V) vals_out[pos] = val[q];
+		}
+	}
+	if (ntiles <= gridDim.x) break;
+	__syncthreads();
+	if (threadIdx.x == 0) s_tile = gridDim.x + atomicAdd(ticket, 1u);
+	__syncthreads();
+	tile = s_tile;
+	}
+}
+
+template<typename K, typename V, bool HAS_V>
+static int onesweep_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* vals_b, const uint32_t* d_count, uint32_t capacity, uint32_t expected, uint32_t* scratch, const os_shifts& sh) {
+	K* kin = keys_a; K* kout = keys_b;
+	V* vin = vals_a; V* vout = vals_b;
+	const uint32_t tiles = os_tiles(capacity), groups = os_groups(tiles);
+	uint32_t* ghist = scratch;
+	uint32_t* ticket = scratch + OS_MAX_PASSES * 256;
+	uint32_t* state = ticket + 256;
+	const size_t per_pass = (size_t)(tiles + groups) * 256;
+	// one workgroup per expected tile (+12 %); more tiles than that are still sorted correctly, just by ticket
+	uint64_t want = ((uint64_t)expected + expected / 8 + OS_TILE - 1) / OS_TILE + 2;
+	uint32_t grid = expected == 0 || want > tiles ? tiles : (uint32_t)want;
+	if (grid > OS_MAX_GRID) grid = OS_MAX_GRID;
+	if (ctx->timing) nh_timer_begin(ctx, "radix_clear");
+	hipError_t e = hipMemsetAsync(scratch, 0, sizeof(uint32_t) * ((size_t)OS_MAX_PASSES * 256 + 256 + (size_t)sh.n * per_pass), ctx->stream);
+	if (ctx->timing) nh_timer_end(ctx);
+	if (e != hipSuccess) ctx->last_hip_error = (int)e;
+	NH_LAUNCH(ctx, "radix_hist", (os_hist<K>), nh_grid_for(capacity, 256 * 16, 256), 256, kin, d_count, ghist, sh);
+	for (int p = 0; p < sh.n; ++p) {
+		uint32_t* tc = state + (size_t)p * per_pass;
+		NH_LAUNCH(ctx, "radix_pass", (os_pass<K, V, HAS_V>), grid, 256, kin, kout, vin, vout, d_count, ghist + p * 256, ticket + p, tc, tc + (size_t)tiles * 256, sh.s[p]);
+		K* tk = kin; kin = kout; kout = tk;
+		V* tv = vin; vin = vout; vout = tv;
+	}
+	return sh.n & 1;      // 1: the sorted data sits in the *_b buffers
+}
+
+static os_shifts shifts_for(int begin_bit, int end_bit, os_shifts sh = os_shifts{ {}, 0 }) {
+	for (int s = begin_bit; s < end_bit && sh.n < OS_MAX_PASSES; s += 8) sh.s[sh.n++] = s;
+	return sh;
+}
+
+int nh_onesweep_u32_u32(nh_context* ctx, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+                         const uint32_t* d_count, uint32_t capacity, uint32_t expected, uint32_t* scratch, int begin_bit, int end_bit) {
+	return onesweep_impl<uint32_t, uint32_t, true>(ctx, keys_a, keys_b, vals_a, vals_b, d_count, capacity, expected, scratch, shifts_for(begin_bit, end_bit));
+}
+
+// sorts by bits [lo_begin, lo_end) first, then (stable) by bits [hi_begin, hi_end): one histogram kernel for all passes
+int nh_onesweep_u64_u32_two_fields(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+                                    const uint32_t* d_count, uint32_t capacity, uint32_t expected, uint32_t* scratch, int lo_begin, int lo_end, int hi_begin, int hi_end) {
+	return onesweep_impl<uint64_t, uint32_t, true>(ctx, keys_a, keys_b, vals_a, vals_b, d_count, capacity, expected, scratch, shifts_for(hi_begin, hi_end, shifts_for(lo_begin, lo_end)));
+}
+
 __global__ __launch_bounds__(256) void k_copy_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const uint32_t* __restrict__ d_n, uint32_t words_per_item) {
 	uint64_t n = (uint64_t)(*d_n) * words_per_item;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
