@@ -14,18 +14,23 @@
 
 // ---- 1. world transforms, AABBs, bounds, extent histogram ---------------------------------------------
 // aabb_min[c] = (min.xyz, bits(body)), aabb_max[c] = (max.xyz, bits(max extent))
-__global__ __launch_bounds__(256) void k_xform(nh_DevState* __restrict__ st,
+// 1024-thread workgroups, one per CU: the scene bounds / histogram end in a handful of global atomics per WORKGROUP on the same
+// few addresses (~12 ns each, serialised), so the fewer workgroups the better.
+__global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
                                                const nh_Transform* __restrict__ body_xf,
                                                const nh_Transform* __restrict__ box_xf, const nh_BoxCollider* __restrict__ box_data, const uint32_t* __restrict__ box_tags, uint32_t nbox,
                                                const nh_Transform* __restrict__ sph_xf, const nh_SphereCollider* __restrict__ sph_data, const uint32_t* __restrict__ sph_tags, uint32_t nsph,
                                                nh_xform* __restrict__ xf, float4* __restrict__ aabb_min, float4* __restrict__ aabb_max, uint32_t* __restrict__ ctag) {
 	__shared__ uint32_t hist[256];
-	__shared__ uint32_t red[6];
-	hist[threadIdx.x] = 0;
-	if (threadIdx.x < 3) { red[threadIdx.x] = 0xffffffffu; red[3 + threadIdx.x] = 0u; }
+	__shared__ uint32_t red[12];
+	if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+	if (threadIdx.x < 3) { red[threadIdx.x] = 0xffffffffu; red[3 + threadIdx.x] = 0u; red[6 + threadIdx.x] = 0xffffffffu; red[9 + threadIdx.x] = 0u; }
 	__syncthreads();
 	uint32_t n = nbox + nsph;
 	uint32_t lmin[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, lmax[3] = { 0, 0, 0 };
+	// bounds of the "small" colliders under LAST step's size split (k_grid_params confirms the guess or orders k_small_bounds to redo them)
+	const uint32_t guess_exp = st->small_exp;
+	uint32_t gmn[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, gmx[3] = { 0, 0, 0 };
 	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
 		bool is_box = c < nbox;
 		nh_Transform l = is_box ? box_xf[c] : sph_xf[c - nbox];
@@ -64,6 +69,11 @@ __global__ __launch_bounds__(256) void k_xform(nh_DevState* __restrict__ st,
 		f = nh_float_flip(mnz); lmin[2] = min(lmin[2], f); lmax[2] = max(lmax[2], f);
 		// exponent histogram: one LDS atomic per distinct exponent in the wave (usually 2-3), not one per lane
 		uint32_t ebin = (__float_as_uint(ext) >> 23) & 255u;
+		if (ebin <= guess_exp && ext == ext) {
+			f = nh_float_flip(mnx); gmn[0] = min(gmn[0], f); gmx[0] = max(gmx[0], f);
+			f = nh_float_flip(mny); gmn[1] = min(gmn[1], f); gmx[1] = max(gmx[1], f);
+			f = nh_float_flip(mnz); gmn[2] = min(gmn[2], f); gmx[2] = max(gmx[2], f);
+		}
 		unsigned long long todo = __ballot(1);
 		while (todo) {
 			uint32_t e0 = (uint32_t)__shfl((int)ebin, (int)(__ffsll((long long)todo) - 1));
@@ -73,12 +83,18 @@ __global__ __launch_bounds__(256) void k_xform(nh_DevState* __restrict__ st,
 		}
 	}
 	for (int k = 0; k < 3; ++k) {
-		for (int d = 32; d >= 1; d >>= 1) { lmin[k] = min(lmin[k], (uint32_t)__shfl_xor((int)lmin[k], d)); lmax[k] = max(lmax[k], (uint32_t)__shfl_xor((int)lmax[k], d)); }
-		if ((threadIdx.x & 63) == 0) { atomicMin(&red[k], lmin[k]); atomicMax(&red[3 + k], lmax[k]); }
+		for (int d = 32; d >= 1; d >>= 1) {
+			lmin[k] = min(lmin[k], (uint32_t)__shfl_xor((int)lmin[k], d)); lmax[k] = max(lmax[k], (uint32_t)__shfl_xor((int)lmax[k], d));
+			gmn[k] = min(gmn[k], (uint32_t)__shfl_xor((int)gmn[k], d)); gmx[k] = max(gmx[k], (uint32_t)__shfl_xor((int)gmx[k], d));
+		}
+		if ((threadIdx.x & 63) == 0) { atomicMin(&red[k], lmin[k]); atomicMax(&red[3 + k], lmax[k]); atomicMin(&red[6 + k], gmn[k]); atomicMax(&red[9 + k], gmx[k]); }
 	}
 	__syncthreads();
-	if (hist[threadIdx.x]) atomicAdd(&st->exp_hist[threadIdx.x], hist[threadIdx.x]);
-	if (threadIdx.x < 3) { atomicMin(&st->smin[threadIdx.x], red[threadIdx.x]); atomicMax(&st->smax[threadIdx.x], red[3 + threadIdx.x]); }
+	if (threadIdx.x < 256 && hist[threadIdx.x]) atomicAdd(&st->exp_hist[threadIdx.x], hist[threadIdx.x]);
+	if (threadIdx.x < 3) {
+		atomicMin(&st->smin[threadIdx.x], red[threadIdx.x]); atomicMax(&st->smax[threadIdx.x], red[3 + threadIdx.x]);
+		if (red[6 + threadIdx.x] <= red[9 + threadIdx.x]) { atomicMin(&st->gmin[threadIdx.x], red[6 + threadIdx.x]); atomicMax(&st->gmax[threadIdx.x], red[9 + threadIdx.x]); }
+	}
 }
 
 // ---- 2. grid parameters (single thread; a few hundred instructions) ------------------------------------
@@ -98,6 +114,13 @@ __global__ void k_grid_params(nh_DevState* st, uint32_t ncolliders, uint32_t max
 	// e = largest exponent kept "small"; never let the cell underflow to denormals
 	if (e < 64) e = 64;
 	if (e > 190) e = 190;
+	// k_xform gathered the small colliders' bounds under last step's split: good if the split has not moved
+	if (st->small_exp != (uint32_t)e) {
+		st->redo_small = 1;
+		for (int k = 0; k < 3; ++k) { st->gmin[k] = 0xffffffffu; st->gmax[k] = 0u; }
+	} else {
+		st->redo_small = 0;
+	}
 	st->small_exp = (uint32_t)e;
 	float cell = __uint_as_float((uint32_t)(e + 1) << 23);     // 2^(e+1-127) > every small extent
 	st->cell_inv = 1.0f / cell;
@@ -106,6 +129,7 @@ __global__ void k_grid_params(nh_DevState* st, uint32_t ncolliders, uint32_t max
 // bounds of the min corners of the SMALL colliders (the grid only has to span those)
 __global__ __launch_bounds__(256) void k_small_bounds(nh_DevState* __restrict__ st, uint32_t n, const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max) {
 	__shared__ uint32_t red[6];
+	if (!st->redo_small) return;           // k_xform's bounds stand
 	if (threadIdx.x < 3) { red[threadIdx.x] = 0xffffffffu; red[3 + threadIdx.x] = 0u; }
 	__syncthreads();
 	const uint32_t small_exp = st->small_exp;
@@ -573,18 +597,7 @@ __global__ __launch_bounds__(256) void k_sorted_counts(const nh_DevState* __rest
 		counts[i] = r.count & ~NH_REC_SLEEPING;
 		sleep_flags[i] = (r.count & NH_REC_SLEEPING) ? 1u : 0u;
 	}
-	if (blockIdx.x == 0 && threadIdx.x == 0) sleep_flags[n] = 0;
-}
-
-// sleeping pairs in ascending tag order (reference sorts them at nudge.cpp:4008): ordered compaction of the sorted records
-__global__ __launch_bounds__(256) void k_write_sleeping(nh_DevState* __restrict__ st, const uint32_t* __restrict__ scan, const uint64_t* __restrict__ rec_key_sorted,
-                                                        uint64_t* __restrict__ sleeping_pairs, uint32_t cap) {
-	uint32_t n = st->records;
-	if (!st->any_sleeping) return;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		uint32_t p = scan[i], q = scan[i + 1];
-		if (q != p) { if (p < cap) sleeping_pairs[p] = rec_key_sorted[i]; else st->error = NH_ERR_CONTACT_CAPACITY; }
-	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) { sleep_flags[n] = 0; counts[n] = 0; }
 }
 
 // Tag-ordered output.  A wave takes 64 consecutive records (= collider pairs with contacts, in tag order); their contacts
@@ -593,7 +606,8 @@ __global__ __launch_bounds__(256) void k_write_sleeping(nh_DevState* __restrict_
 // per output contact: coalesced 32-B stores, no search.
 __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict__ st, const uint32_t* __restrict__ rec_idx, const nh_Record* __restrict__ rec, const uint64_t* __restrict__ rec_key_sorted,
                                                          const uint32_t* __restrict__ starts, const nh_Contact* __restrict__ raw_data, const uint32_t* __restrict__ raw_feature,
-                                                         nh_Contact* __restrict__ data, nh_BodyPair* __restrict__ bodies, uint64_t* __restrict__ tags, uint32_t* __restrict__ features, uint32_t capacity, uint32_t pair_cap) {
+                                                         nh_Contact* __restrict__ data, nh_BodyPair* __restrict__ bodies, uint64_t* __restrict__ tags, uint32_t* __restrict__ features, uint32_t capacity, uint32_t pair_cap,
+                                                         const uint32_t* __restrict__ sleep_scan, uint64_t* __restrict__ sleeping_pairs) {
 	__shared__ uint32_t s_src[4][1024];
 	__shared__ uint32_t s_feat[4][1024];
 	__shared__ uint8_t s_own[4][1024];
@@ -613,6 +627,11 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 			start = starts[lo];
 			cnt = (r.count & NH_REC_SLEEPING) ? 0u : (r.count > 16u ? 16u : r.count);
 			key = rec_key_sorted[lo];
+			// sleeping pairs in ascending tag order (the reference sorts them at nudge.cpp:4008): ordered compaction of the sorted records
+			if ((r.count & NH_REC_SLEEPING) && sleeping_pairs) {
+				const uint32_t p = sleep_scan[lo];
+				if (p < capacity) sleeping_pairs[p] = key; else st->error = NH_ERR_CONTACT_CAPACITY;
+			}
 			body_a = r.body_a; body_b = r.body_b;
 			base4 = 4u * ri; baseo = 4u * pair_cap + r.overflow;
 		}
@@ -669,7 +688,10 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 	}
 }
 
-__global__ void k_collide_begin(nh_DevState* st, uint32_t ncolliders) {
+// counters, bounds, and the union-find / island arrays (parent[i] = i, nothing active yet)
+__global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t ncolliders, uint32_t nbodies, uint32_t* __restrict__ parent, uint32_t* __restrict__ set_active) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) { parent[i] = i; set_active[i] = 0; }
+	if (blockIdx.x != 0) return;
 	uint32_t t = threadIdx.x;
 	if (t == 0) {
 		st->colliders = ncolliders; st->pairs = 0; st->raw_contacts = 0; st->records = 0; st->contacts = 0; st->sleeping = 0;
@@ -718,7 +740,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	size_t hist_words = 256 * NH_SORT_GRID + 512;
 	if (onesweep && nh_sort_scratch_words(C > pair_cap ? C : pair_cap) > hist_words) hist_words = nh_sort_scratch_words(C > pair_cap ? C : pair_cap);
 	uint32_t* hist = nh_arena_array<uint32_t>(A, hist_words, &err);
-	uint32_t* scan_tmp = nh_arena_array<uint32_t>(A, NH_SORT_GRID + 64, &err);
+	uint32_t* scan_tmp = nh_arena_array<uint32_t>(A, 2 * NH_SORT_GRID + 64, &err);
 	// grid table: a power of two, up to 4 cells per collider; 2^22 entries (two 11-bit radix passes) while that leaves at
 	// least one cell per collider.  Cell keys are < max_cells - 1, so the large key (all ones) sorts last on cell_bits bits.
 	uint64_t want = 1; while (want < 4ull * C) want <<= 1;
@@ -746,9 +768,9 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	if (err) return err;
 
 	hipStream_t s = ctx->stream;
-	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, 1, 256, st, C);
+	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, nh_grid_for(B, 256, 2048), 256, st, C, B, parent, set_active);
 	if (C) {
-		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 256, 1024), 256, st, bodies->transforms,
+		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 1024, 256), 1024, st, bodies->transforms,
 		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
 		          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
 		          xf, aabb_min, aabb_max, ctag);
@@ -767,8 +789,15 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "narrowphase", k_narrowphase, nh_grid_for(pair_cap, 256, 4096), 256, st, pairs, xf, ctag,
 		          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a);
 	}
-	// islands over contact records (+ user connections)
-	NH_LAUNCH(ctx, "uf_init", k_uf_init, nh_grid_for(B, 256, 2048), 256, B, parent, set_active);
+	// islands over contact records (+ user connections): a chain of small kernels that the tag sort of the records does not depend
+	// on -- it runs on the side stream while the caller's stream sorts (fork here, join before k_sorted_counts)
+	const bool fork = ctx->side != nullptr;
+	hipStream_t main_stream = ctx->stream;
+	if (fork) {
+		NH_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, main_stream));
+		NH_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+		ctx->stream = ctx->side;
+	}
 	if (body_connections && body_connections->count)
 		NH_LAUNCH(ctx, "uf_union_connections", k_uf_union_connections, nh_grid_for(body_connections->count, 256, 2048), 256, body_connections->data, body_connections->count, parent);
 	NH_LAUNCH(ctx, "uf_union_records", k_uf_union_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, parent);
@@ -781,6 +810,10 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	}
 	NH_LAUNCH(ctx, "active_write", k_active_write, nh_grid_for(B, 256, 2048), 256, st, B, root_of, set_active, flags, active_bodies->indices, active_bodies->capacity);
 	NH_LAUNCH(ctx, "filter_records", k_filter_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, rec_key_a, rec_idx_a, root_of, set_active, (uint64_t*)nullptr, cap);
+	if (fork) {
+		ctx->stream = main_stream;
+		NH_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+	}
 	// tag order: sort records by (b_tag, a_tag), then lay contacts out pair by pair
 	int key_bits = (int)ctx->tag_bits;
 	if (key_bits < 1) key_bits = 1;
@@ -799,14 +832,12 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		}
 	}
 	// (dropped records carry count 0, so where they land in the order is irrelevant)
+	if (fork) NH_HIP_CHECK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
 	NH_LAUNCH(ctx, "sorted_counts", k_sorted_counts, nh_grid_for(pair_cap, 256, 2048), 256, st, rec_idx_a, rec, rec_counts, sleep_flags);
-	nh_scan_u32(ctx, rec_counts, rec_counts, &st->records, 0, scan_tmp, &st->contacts);
+	// contact starts and sleeping-pair slots: two scans over the sorted records in one pair of launches
+	nh_scan2_u32(ctx, rec_counts, rec_counts, &st->contacts, sleep_flags, sleep_flags, &st->sleeping, &st->records, 1, scan_tmp);
 	NH_LAUNCH(ctx, "gather_contacts", k_gather_contacts, nh_grid_for(pair_cap, 256, 8192), 256, st, rec_idx_a, rec, rec_key_a, rec_counts, raw_data, raw_feature,
-	          contacts->data, contacts->bodies, contacts->tags, contacts->features, cap, pair_cap);
-	// sleeping pairs, ascending (nudge.cpp:4008)
-	nh_scan_u32(ctx, sleep_flags, sleep_flags, &st->records, 1, scan_tmp, &st->sleeping, &st->any_sleeping);
-	if (contacts->sleeping_pairs)
-		NH_LAUNCH(ctx, "write_sleeping", k_write_sleeping, nh_grid_for(pair_cap, 256, 2048), 256, st, sleep_flags, rec_key_a, contacts->sleeping_pairs, cap);
+	          contacts->data, contacts->bodies, contacts->tags, contacts->features, cap, pair_cap, sleep_flags, contacts->sleeping_pairs);
 
 	if (ctx->flags & NH_FLAG_SYNC_COUNTS) {
 		nh_Counts c;

@@ -23,6 +23,9 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->h_state = nullptr;
 	if (hipMalloc((void**)&ctx->d_state, sizeof(nh_DevState)) != hipSuccess) { delete ctx; return NH_ERR_HIP; }
 	if (hipHostMalloc((void**)&ctx->h_state, sizeof(nh_DevState), 0) != hipSuccess) { hipFree(ctx->d_state); delete ctx; return NH_ERR_HIP; }
+	ctx->side = nullptr; ctx->ev_fork = nullptr; ctx->ev_join = nullptr;
+	if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { ctx->side = nullptr; }       // no side stream: everything stays on the caller's
 	hipMemsetAsync(ctx->d_state, 0, sizeof(nh_DevState), ctx->stream);
 	hipStreamSynchronize(ctx->stream);
 	*out = ctx;
@@ -37,6 +40,9 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	for (auto e : ctx->event_pool) hipEventDestroy(e);
 	for (auto p : ctx->impulse_ring) delete p;
 	for (auto p : ctx->constraint_ring) delete p;
+	if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
+	if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+	if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
 	if (ctx->hint) hipFree(ctx->hint);
 	if (ctx->d_state) hipFree(ctx->d_state);
 	if (ctx->h_state) hipHostFree(ctx->h_state);

@@ -54,7 +54,8 @@ struct nh_DevState {
 	float cell_inv;               // 1 / cell size (cell size is a power of two)
 	float origin[3];
 	uint32_t dims[3];
-	uint32_t small_exp;           // colliders whose max-extent exponent is <= small_exp go to the grid
+	uint32_t small_exp;           // colliders whose max-extent exponent is <= small_exp go to the grid (kept across steps: next step's guess)
+	uint32_t redo_small;          // the guess was wrong: k_small_bounds recomputes gmin/gmax
 	uint32_t exp_hist[256];
 };
 
@@ -87,6 +88,9 @@ struct nh_context {
 	// warm-start hints (per body: index of its first contact in the previous step's contact list); library-owned device memory
 	uint32_t* hint;
 	uint32_t hint_capacity;
+	// fork/join inside one entry point: independent kernel chains run on `side` while the caller's stream does the long one
+	hipStream_t side;
+	hipEvent_t ev_fork, ev_join;
 };
 
 // Runs work that an earlier call deferred; every entry point that reads or writes momentum / impulses calls it first.
@@ -104,6 +108,11 @@ struct nh_ContactImpulseData {
 	uint32_t* culled_features;
 	nh_CachedContactImpulse* culled_data;
 	uint32_t capacity;                    // contact capacity the arrays were sized for
+	// culling of sleeping pairs' cached impulses, run once the host knows whether anything sleeps
+	bool cull_pending;
+	const uint64_t* sleeping_pairs;
+	uint32_t* cull_flags; uint32_t* cull_tmp;
+	uint32_t cache_capacity;
 	uint32_t culled_capacity;
 };
 
@@ -163,6 +172,9 @@ void nh_timer_collect(nh_context* ctx);
 		if ((ctx)->timing) nh_timer_end((ctx));                                                  \
 	} while (0)
 
+// launch on the side stream (untimed; only between a fork and its join inside one entry point)
+#define NH_LAUNCH_SIDE(ctx, kernel, grid, block, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->side, __VA_ARGS__)
+
 #define NH_HIP_CHECK(ctx, expr)                                                                  \
 	do {                                                                                         \
 		hipError_t e_ = (expr);                                                                  \
@@ -192,10 +204,13 @@ int nh_onesweep_u32_u32(nh_context* ctx, uint32_t* keys_a, uint32_t* keys_b, uin
 int nh_onesweep_u64_u32_two_fields(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                                     const uint32_t* d_count, uint32_t capacity, uint32_t expected, uint32_t* scratch, int lo_begin, int lo_end, int hi_begin, int hi_end);
 // Exclusive scan of `in[0..n)` into `out` (may alias); n read from *d_count (+ `extra` elements);
-// the grand total is also stored to *d_total if non-null.  `tmp` needs NH_SORT_GRID+8 words.
+// the grand total is also stored to *d_total if non-null.  `tmp` needs 2 * NH_SORT_GRID words.
 // If `d_enable` is given and *d_enable == 0 the scan is skipped on the device (the total is reported as 0).
 void nh_scan_u32(nh_context* ctx, const uint32_t* in, uint32_t* out, const uint32_t* d_count, uint32_t extra,
                  uint32_t* tmp, uint32_t* d_total, const uint32_t* d_enable = nullptr);
+// the same for two arrays of equal length in one pair of launches
+void nh_scan2_u32(nh_context* ctx, const uint32_t* in_a, uint32_t* out_a, uint32_t* d_total_a, const uint32_t* in_b, uint32_t* out_b, uint32_t* d_total_b,
+                  const uint32_t* d_count, uint32_t extra, uint32_t* tmp);
 
 // dst[0 .. *d_count * words_per_item) = src[...]
 void nh_copy_back_u32(nh_context* ctx, const uint32_t* src, uint32_t* dst, const uint32_t* d_count, uint32_t words_per_item);

@@ -1003,6 +1003,19 @@ extern "C" int nh_advance(nh_context* ctx, const nh_ActiveBodies* active_bodies,
 	return NH_OK;
 }
 
+// cached impulses of sleeping pairs are kept aside (nudge.cpp:4064-4101); skipped entirely when nothing sleeps (culled = 0 since nh_collide)
+static void run_cull(nh_context* ctx, nh_ContactImpulseData* d, uint32_t sleeping_on_host) {
+	if (!d->cull_pending) return;
+	d->cull_pending = false;
+	if (sleeping_on_host == 0) return;
+	nh_DevState* st = ctx->d_state;
+	const uint32_t ccap = d->cache_capacity;
+	NH_LAUNCH(ctx, "cull_flags", k_cull_flags, nh_grid_for(ccap, 256, 4096), 256, st, d->ctags, d->sleeping_pairs, d->cull_flags);
+	nh_scan_u32(ctx, d->cull_flags, d->cull_flags, &st->cache, 1, d->cull_tmp, &st->culled, &st->sleeping);   // +1: the sentinel, so scan[j+1] exists for every j
+	NH_LAUNCH(ctx, "cull_write", k_cull_write, nh_grid_for(ccap, 256, 4096), 256, st, d->cull_flags, d->cull_flags, d->ctags, d->cfeatures, d->cdata,
+	          d->culled_tags, d->culled_features, d->culled_data);
+}
+
 extern "C" int nh_read_cached_impulses(nh_context* ctx, const nh_ContactCache* cache, const nh_ContactData* contacts, nh_Arena* memory, nh_ContactImpulseData** out) {
 	if (!ctx || !cache || !contacts || !memory || !out) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
@@ -1016,20 +1029,22 @@ extern "C" int nh_read_cached_impulses(nh_context* ctx, const nh_ContactCache* c
 	d->culled_features = nh_arena_array<uint32_t>(memory, ccap, &err);
 	d->culled_data = nh_arena_array<nh_CachedContactImpulse>(memory, ccap, &err);
 	d->capacity = kcap; d->culled_capacity = ccap;
-	nh_Arena scratch = *memory;     // scratch below is dead on return
-	uint32_t* flags = nh_arena_array<uint32_t>(&scratch, ccap + 1, &err);
-	uint32_t* tmp = nh_arena_array<uint32_t>(&scratch, NH_SORT_GRID + 64, &err);
+	// culling of cached impulses of sleeping pairs (nudge.cpp:4064-4101) only has work when something sleeps; the scratch for it is
+	// reserved here, the kernels run once the host knows the sleeping-pair count (run_cull)
+	d->cull_flags = nh_arena_array<uint32_t>(memory, ccap + 1, &err);
+	d->cull_tmp = nh_arena_array<uint32_t>(memory, 2 * NH_SORT_GRID + 64, &err);
 	if (err) return err;
 	// the per-contact lookup is deferred: bodies on the one-body path fetch their impulses inside the fused solver kernel, and
 	// materialize_lookup() fills d->data for everything else (only if such contacts exist, which setup learns)
 	d->lookup_pending = true; d->ctx = ctx; d->consumed = false;
 	d->tags = contacts->tags; d->features = contacts->features;
 	d->ctags = cache->tags; d->cfeatures = cache->features; d->cdata = cache->data;
-	if (contacts->sleeping_pairs) {
-		NH_LAUNCH(ctx, "cull_flags", k_cull_flags, nh_grid_for(ccap, 256, 4096), 256, st, cache->tags, contacts->sleeping_pairs, flags);
-		nh_scan_u32(ctx, flags, flags, &st->cache, 1, tmp, &st->culled, &st->sleeping);   // +1: the sentinel, so scan[j+1] exists for every j
-		NH_LAUNCH(ctx, "cull_write", k_cull_write, nh_grid_for(ccap, 256, 4096), 256, st, flags, flags, cache->tags, cache->features, cache->data,
-		          d->culled_tags, d->culled_features, d->culled_data);
+	d->cull_pending = contacts->sleeping_pairs != nullptr;
+	d->sleeping_pairs = contacts->sleeping_pairs;
+	d->cache_capacity = ccap;
+	if (d->cull_pending && (ctx->flags & NH_FLAG_SYNC_COUNTS)) {
+		// reference semantics: nh_collide has just synchronised, the count is on the host
+		run_cull(ctx, d, ctx->h_state->sleeping);
 	}
 	*out = d;
 	return NH_OK;
@@ -1056,6 +1071,12 @@ extern "C" int nh_write_cached_impulses(nh_context* ctx, nh_ContactCache* cache,
 	if (!ctx || !cache || !contacts || !imp) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	if (!imp->consumed) materialize_lookup(ctx, imp);      // no setup ran on this handle: the cache is rewritten from the looked-up impulses
+	if (imp->cull_pending) {
+		nh_Counts c;
+		int rc = nh_read_counts(ctx, &c);
+		if (rc) return rc;
+		run_cull(ctx, imp, c.sleeping_pairs);
+	}
 	nh_DevState* st = ctx->d_state;
 	NH_LAUNCH(ctx, "write_cache", k_write_cache, nh_grid_for((uint64_t)contacts->capacity + cache->capacity, 256, 4096), 256, st,
 	          contacts->tags, contacts->features, imp->data, imp->culled_tags, imp->culled_features, imp->culled_data,
@@ -1095,7 +1116,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	uint32_t* slot_key = (ctx->flags & NH_FLAG_EXACT_ORDER) ? nh_arena_array<uint32_t>(memory, kcap, &err) : nullptr;
 	uint32_t* level_hist = nh_arena_array<uint32_t>(memory, NH_MAX_LEVELS + 2, &err);
 	uint32_t* level_cursor = nh_arena_array<uint32_t>(memory, NH_MAX_LEVELS + 2, &err);
-	uint32_t* tmp = nh_arena_array<uint32_t>(memory, NH_SORT_GRID + 64, &err);
+	uint32_t* tmp = nh_arena_array<uint32_t>(memory, 2 * NH_SORT_GRID + 64, &err);
 	if (err) return err;
 	d->contact_capacity = kcap; d->body_count = B; d->bodies = contacts->bodies;
 	d->contact_data = contacts->data; d->impulses = imp->data; d->general_list = general_list;
@@ -1113,6 +1134,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	int rc = nh_read_counts(ctx, &c);
 	if (rc) return rc;
 	if (c.error) return (int)c.error;
+	run_cull(ctx, imp, c.sleeping_pairs);
 	d->general_contacts = c.general_contacts;
 	d->static_body_count = c.static_bodies;
 	d->has_static8 = ctx->h_state->has_static8 != 0;

@@ -160,9 +160,23 @@ __global__ __launch_bounds__(256) void os_hist(const K* __restrict__ keys, const
 	for (int p = 0; p < sh.n; ++p) h[p][threadIdx.x] = 0;
 	__syncthreads();
 	const uint32_t n = *d_n;
-	for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-		K k = keys[i];
-		for (int p = 0; p < sh.n; ++p) atomicAdd(&h[p][(uint32_t)(k >> sh.s[p]) & 255u], 1u);
+	// tiles of 2048 keys, eight independent loads per lane in flight
+	for (uint32_t t0 = blockIdx.x * (uint32_t)OS_TILE; t0 < n; t0 += gridDim.x * (uint32_t)OS_TILE) {
+		K k[OS_KPT];
+#pragma unroll
+		for (int q = 0; q < OS_KPT; ++q) { uint32_t i = t0 + q * 256u + threadIdx.x; k[q] = i < n ? keys[i] : (K)0; }
+#pragma unroll
+		for (int q = 0; q < OS_KPT; ++q) {
+			const bool valid = t0 + q * 256u + threadIdx.x < n;
+			const unsigned long long live = __ballot(valid);
+			for (int p = 0; p < sh.n; ++p) {
+				// high digits of neighbouring keys are usually all equal: one add for the wave instead of 64 serialised ones
+				const uint32_t d = (uint32_t)(k[q] >> sh.s[p]) & 255u;
+				const uint32_t d0 = (uint32_t)__shfl((int)d, (int)(__ffsll((long long)live) - 1));
+				if (live && __ballot(valid && d != d0) == 0ull) { if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)live) - 1)) atomicAdd(&h[p][d0], (uint32_t)__popcll(live)); }
+				else if (valid) atomicAdd(&h[p][d], 1u);
+			}
+		}
 	}
 	__syncthreads();
 	for (int p = 0; p < sh.n; ++p) { uint32_t c = h[p][threadIdx.x]; if (c) atomicAdd(&ghist[p * 256 + threadIdx.x], c); }
@@ -293,7 +307,7 @@ static int onesweep_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* va
 	hipError_t e = hipMemsetAsync(scratch, 0, sizeof(uint32_t) * ((size_t)OS_MAX_PASSES * 256 + 256 + (size_t)sh.n * per_pass), ctx->stream);
 	if (ctx->timing) nh_timer_end(ctx);
 	if (e != hipSuccess) ctx->last_hip_error = (int)e;
-	NH_LAUNCH(ctx, "radix_hist", (os_hist<K>), nh_grid_for(capacity, 256 * 16, 256), 256, kin, d_count, ghist, sh);
+	NH_LAUNCH(ctx, "radix_hist", (os_hist<K>), grid < 256 ? grid : 256, 256, kin, d_count, ghist, sh);
 	for (int p = 0; p < sh.n; ++p) {
 		uint32_t* tc = state + (size_t)p * per_pass;
 		NH_LAUNCH(ctx, "radix_pass", (os_pass<K, V, HAS_V>), grid, 256, kin, kout, vin, vout, d_count, ghist + p * 256, ticket + p, tc, tc + (size_t)tiles * 256, sh.s[p]);
@@ -355,58 +369,76 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_
 	return woff + x - v;
 }
 
-__global__ __launch_bounds__(256) void sc_sums(const uint32_t* __restrict__ in, const uint32_t* __restrict__ d_n, uint32_t extra, uint32_t* __restrict__ tmp, const uint32_t* __restrict__ d_enable) {
-	__shared__ uint32_t wsum[4];
+// Two kernels per scan: per-chunk sums, then every workgroup adds up the sums of the chunks before its own (<= 511 values) and
+// scans its chunk.  Up to two arrays of the same length are scanned by the same pair of launches.
+__global__ __launch_bounds__(256) void sc_sums(const uint32_t* __restrict__ in_a, const uint32_t* __restrict__ in_b, const uint32_t* __restrict__ d_n, uint32_t extra,
+                                               uint32_t* __restrict__ tmp, const uint32_t* __restrict__ d_enable) {
+	__shared__ uint32_t wsum[2][4];
 	if (d_enable && !*d_enable) return;
 	uint32_t n = *d_n + extra;
 	uint32_t begin, end;
 	rs_chunk(n, begin, end);
-	uint32_t s = 0;
-	for (uint32_t i = begin + threadIdx.x; i < end; i += 256) s += in[i];
-	for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-	if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+	uint32_t sa = 0, sb = 0;
+	for (uint32_t i = begin + threadIdx.x; i < end; i += 256) { sa += in_a[i]; if (in_b) sb += in_b[i]; }
+	for (int d = 32; d >= 1; d >>= 1) { sa += __shfl_xor(sa, d); sb += __shfl_xor(sb, d); }
+	if ((threadIdx.x & 63) == 0) { wsum[0][threadIdx.x >> 6] = sa; wsum[1][threadIdx.x >> 6] = sb; }
 	__syncthreads();
-	if (threadIdx.x == 0) tmp[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-__global__ __launch_bounds__(RS_G) void sc_top(uint32_t* __restrict__ tmp, uint32_t* __restrict__ d_total, const uint32_t* __restrict__ d_enable) {
-	__shared__ uint32_t wsum[RS_G / 64];
-	if (d_enable && !*d_enable) { if (threadIdx.x == 0 && d_total) *d_total = 0; return; }
-	uint32_t v = tmp[threadIdx.x];
-	uint32_t x = v;
-	for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d); if ((int)(threadIdx.x & 63) >= d) x += y; }
-	if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
-	__syncthreads();
-	uint32_t woff = 0;
-	for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) woff += wsum[w];
-	tmp[threadIdx.x] = woff + x - v;
-	if (threadIdx.x == RS_G - 1) {
-		uint32_t total = woff + x;
-		tmp[RS_G] = total;
-		if (d_total) *d_total = total;
+	if (threadIdx.x == 0) {
+		tmp[blockIdx.x] = wsum[0][0] + wsum[0][1] + wsum[0][2] + wsum[0][3];
+		tmp[RS_G + blockIdx.x] = wsum[1][0] + wsum[1][1] + wsum[1][2] + wsum[1][3];
 	}
 }
 
-__global__ __launch_bounds__(256) void sc_final(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, const uint32_t* __restrict__ d_n, uint32_t extra, const uint32_t* __restrict__ tmp, const uint32_t* __restrict__ d_enable) {
+__global__ __launch_bounds__(256) void sc_final(const uint32_t* __restrict__ in_a, uint32_t* __restrict__ out_a, const uint32_t* __restrict__ in_b, uint32_t* __restrict__ out_b,
+                                                const uint32_t* __restrict__ d_n, uint32_t extra, const uint32_t* __restrict__ tmp,
+                                                uint32_t* __restrict__ d_total_a, uint32_t* __restrict__ d_total_b, const uint32_t* __restrict__ d_enable) {
 	__shared__ uint32_t wsum[4];
-	if (d_enable && !*d_enable) return;
+	__shared__ uint32_t red[2][4];
+	if (d_enable && !*d_enable) {
+		if (blockIdx.x == 0 && threadIdx.x == 0) { if (d_total_a) *d_total_a = 0; if (d_total_b) *d_total_b = 0; }
+		return;
+	}
 	uint32_t n = *d_n + extra;
 	uint32_t begin, end;
 	rs_chunk(n, begin, end);
-	uint32_t carry = tmp[blockIdx.x];
+	// carry = sum of the chunk sums before this one
+	uint32_t ca = 0, cb = 0;
+	for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256) { ca += tmp[i]; cb += tmp[RS_G + i]; }
+	for (int d = 32; d >= 1; d >>= 1) { ca += __shfl_xor(ca, d); cb += __shfl_xor(cb, d); }
+	if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ca; red[1][threadIdx.x >> 6] = cb; }
+	__syncthreads();
+	uint32_t carry_a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+	uint32_t carry_b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+		if (d_total_a) *d_total_a = carry_a + tmp[blockIdx.x];
+		if (d_total_b) *d_total_b = carry_b + tmp[RS_G + blockIdx.x];
+	}
 	for (uint32_t tile = begin; tile < end; tile += RS_TILE) {
 		uint32_t i = tile + threadIdx.x;
-		uint32_t v = i < end ? in[i] : 0u;
 		uint32_t total;
+		uint32_t v = i < end ? in_a[i] : 0u;
 		uint32_t ex = block_exclusive_scan_256(v, wsum, total);
-		if (i < end) out[i] = carry + ex;
-		carry += total;
+		if (i < end) out_a[i] = carry_a + ex;
+		carry_a += total;
 		__syncthreads();
+		if (in_b) {
+			v = i < end ? in_b[i] : 0u;
+			ex = block_exclusive_scan_256(v, wsum, total);
+			if (i < end) out_b[i] = carry_b + ex;
+			carry_b += total;
+			__syncthreads();
+		}
 	}
 }
 
+// `tmp` needs 2 * NH_SORT_GRID words
 void nh_scan_u32(nh_context* ctx, const uint32_t* in, uint32_t* out, const uint32_t* d_count, uint32_t extra, uint32_t* tmp, uint32_t* d_total, const uint32_t* d_enable) {
-	NH_LAUNCH(ctx, "scan_sums", sc_sums, RS_G, 256, in, d_count, extra, tmp, d_enable);
-	NH_LAUNCH(ctx, "scan_top", sc_top, 1, RS_G, tmp, d_total, d_enable);
-	NH_LAUNCH(ctx, "scan_final", sc_final, RS_G, 256, in, out, d_count, extra, tmp, d_enable);
+	NH_LAUNCH(ctx, "scan_sums", sc_sums, RS_G, 256, in, (const uint32_t*)nullptr, d_count, extra, tmp, d_enable);
+	NH_LAUNCH(ctx, "scan_final", sc_final, RS_G, 256, in, out, (const uint32_t*)nullptr, (uint32_t*)nullptr, d_count, extra, tmp, d_total, (uint32_t*)nullptr, d_enable);
+}
+
+void nh_scan2_u32(nh_context* ctx, const uint32_t* in_a, uint32_t* out_a, uint32_t* d_total_a, const uint32_t* in_b, uint32_t* out_b, uint32_t* d_total_b,
+                  const uint32_t* d_count, uint32_t extra, uint32_t* tmp) {
+	NH_LAUNCH(ctx, "scan_sums", sc_sums, RS_G, 256, in_a, in_b, d_count, extra, tmp, (const uint32_t*)nullptr);
+	NH_LAUNCH(ctx, "scan_final", sc_final, RS_G, 256, in_a, out_a, in_b, out_b, d_count, extra, tmp, d_total_a, d_total_b, (const uint32_t*)nullptr);
 }
