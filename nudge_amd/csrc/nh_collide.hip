@@ -508,11 +508,15 @@ __global__ __launch_bounds__(256) void k_uf_init(uint32_t nbodies, uint32_t* __r
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) { parent[i] = i; set_active[i] = 0; }
 }
 
+// find with path halving: every visited node is re-pointed at its grandparent (an ancestor stays an ancestor whatever other
+// lanes do, and parent[x] <= x is preserved), so the long chains of one big island (ball pit) collapse as they are walked
 __device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t x) {
 	uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	while (p != x) {
+		uint32_t gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		x = p;
-		p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		p = gp;
 	}
 	return x;
 }

@@ -127,60 +127,29 @@ static int sort_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* vals_b
 
 // ---- stable LSD radix sort, 8-bit digits, ONE kernel per pass ------------------------------------------------------------
 // For the ~1 M-key sorts of this engine the three-kernel pass above is bound by launch latency and by its serial tile loops,
-// not by bandwidth.  Here a sort is: clear a control block, ONE histogram kernel that counts the digits of every pass, then one
-// kernel per pass in which every workgroup takes the next tile of OS_TILE consecutive keys (tickets: tiles start in order, so
-// everything a tile waits for belongs to a workgroup that is already running), ranks its keys, publishes the tile's 256 digit
-// counts and obtains the number of equal digits in earlier tiles from what the others published:
-//     exclusive(t, d) = sum of GROUP sums of the groups before t's  +  counts of the earlier tiles of t's own group,
-// where the last tile of a group of OS_GROUP tiles publishes the group sum once its group has published.  Every wait is on
-// loads that are independent of each other (no chain of dependent look-backs: with all tiles resident at once a chained
-// look-back is ~500 serial hops): two visibility hops per pass.
-// Control block (words): ghist[OS_MAX_PASSES][256] | ticket[256] | per pass: tile counts [tiles][256], group sums [groups][256].
+// not by bandwidth.  Here a pass is one kernel whose workgroups are all RESIDENT at once (<= OS_MAX_GRID) and talk through a
+// control block:
+//   1. workgroup w owns the contiguous chunk of m = ceil(tiles / workgroups) tiles (OS_TILE keys each); it counts its digits --
+//      for m = 1 (<= 2 M keys) by ranking its keys, which then stay in registers -- and PUBLISHES its 256 counts;
+//   2. the last workgroup of every group of OS_GROUP publishes the group's sums once its group has published;
+//   3. every workgroup reads the earlier counts of its own group and ALL group sums (independent loads, two visibility hops --
+//      no chained look-back: with every workgroup resident a chain is hundreds of serial hops) and so knows, per digit, the total
+//      (-> the digit's base, by a block scan) and how many equal digits precede its chunk;
+//   4. it scatters (m = 1: from registers; m > 1: a second sweep over its chunk, tile by tile).
+// No histogram kernel, no ticket counter (one ticket per workgroup on one address would serialise ~12 ns each), no key is read twice
+// for m = 1.  Control block per pass (words): counts[OS_MAX_GRID][256] | group sums [OS_MAX_GRID / OS_GROUP][256], zeroed per sort.
 #define OS_KPT 8
 #define OS_TILE (256 * OS_KPT)
 #define OS_GROUP 32
-#define OS_MAX_GRID 1024                  // 4 workgroups of 256 per CU: resident for sure (5 KB LDS, < 64 VGPRs)
+#define OS_MAX_GRID 1024                  // rows of the control block; the launch is further bounded by what is resident (onesweep_impl)
 #define OS_MAX_PASSES 8
 #define OS_READY 0x80000000u
 #define OS_VALUE_MASK 0x7FFFFFFFu
+#define OS_PASS_WORDS ((OS_MAX_GRID + OS_MAX_GRID / OS_GROUP) * 256)
 
 struct os_shifts { int s[OS_MAX_PASSES]; int n; };
 
-static inline uint32_t os_tiles(uint32_t capacity) { return (uint32_t)(((size_t)capacity + OS_TILE - 1) / OS_TILE) + 1; }
-static inline uint32_t os_groups(uint32_t tiles) { return (tiles + OS_GROUP - 1) / OS_GROUP; }
-
-size_t nh_sort_scratch_words(uint32_t capacity) {
-	size_t tiles = os_tiles(capacity);
-	return (size_t)OS_MAX_PASSES * 256 + 256 + (size_t)OS_MAX_PASSES * (tiles + os_groups((uint32_t)tiles)) * 256;
-}
-
-template<typename K>
-__global__ __launch_bounds__(256) void os_hist(const K* __restrict__ keys, const uint32_t* __restrict__ d_n, uint32_t* __restrict__ ghist, os_shifts sh) {
-	__shared__ uint32_t h[OS_MAX_PASSES][256];
-	for (int p = 0; p < sh.n; ++p) h[p][threadIdx.x] = 0;
-	__syncthreads();
-	const uint32_t n = *d_n;
-	// tiles of 2048 keys, eight independent loads per lane in flight
-	for (uint32_t t0 = blockIdx.x * (uint32_t)OS_TILE; t0 < n; t0 += gridDim.x * (uint32_t)OS_TILE) {
-		K k[OS_KPT];
-#pragma unroll
-		for (int q = 0; q < OS_KPT; ++q) { uint32_t i = t0 + q * 256u + threadIdx.x; k[q] = i < n ? keys[i] : (K)0; }
-#pragma unroll
-		for (int q = 0; q < OS_KPT; ++q) {
-			const bool valid = t0 + q * 256u + threadIdx.x < n;
-			const unsigned long long live = __ballot(valid);
-			for (int p = 0; p < sh.n; ++p) {
-				// high digits of neighbouring keys are usually all equal: one add for the wave instead of 64 serialised ones
-				const uint32_t d = (uint32_t)(k[q] >> sh.s[p]) & 255u;
-				const uint32_t d0 = (uint32_t)__shfl((int)d, (int)(__ffsll((long long)live) - 1));
-				if (live && __ballot(valid && d != d0) == 0ull) { if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)live) - 1)) atomicAdd(&h[p][d0], (uint32_t)__popcll(live)); }
-				else if (valid) atomicAdd(&h[p][d], 1u);
-			}
-		}
-	}
-	__syncthreads();
-	for (int p = 0; p < sh.n; ++p) { uint32_t c = h[p][threadIdx.x]; if (c) atomicAdd(&ghist[p * 256 + threadIdx.x], c); }
-}
+size_t nh_sort_scratch_words(uint32_t capacity) { (void)capacity; return (size_t)OS_MAX_PASSES * OS_PASS_WORDS; }
 
 // sum of `count` published values p[0], p[stride], ... : sixteen independent loads in flight, re-polling only what is not there yet
 __device__ __forceinline__ uint32_t os_sum_published(const uint32_t* p, uint32_t count, size_t stride) {
@@ -198,46 +167,13 @@ __device__ __forceinline__ uint32_t os_sum_published(const uint32_t* p, uint32_t
 	return sum;
 }
 
-template<typename K, typename V, bool HAS_V>
-__global__ __launch_bounds__(256) void os_pass(const K* __restrict__ keys, K* __restrict__ keys_out, const V* __restrict__ vals, V* __restrict__ vals_out,
-                                               const uint32_t* __restrict__ d_n, const uint32_t* __restrict__ ghist, uint32_t* __restrict__ ticket,
-                                               uint32_t* __restrict__ tile_count, uint32_t* __restrict__ group_sum, int shift) {
-	__shared__ uint32_t s_tile;
-	__shared__ uint32_t offs[256];
-	__shared__ uint32_t whist[4][256];
-	__shared__ uint32_t wtot[4];
-	const uint32_t n = *d_n;
-	const uint32_t ntiles = (n + OS_TILE - 1) / OS_TILE;
-	// Tile = workgroup index for the first gridDim.x tiles: the launch never exceeds what is resident at once (OS_MAX_GRID), so
-	// every tile a workgroup waits for belongs to a workgroup that is running or done.  (One ticket per workgroup on a single hot
-	// counter would serialise ~12 ns each.)  Surplus tiles -- more keys than the launch was sized for, or more than OS_MAX_GRID
-	// tiles -- go out by ticket to the workgroups that finish, in order, so they too only wait on tiles that are held.
-	for (uint32_t tile = blockIdx.x; tile < ntiles; ) {
-	whist[0][threadIdx.x] = 0; whist[1][threadIdx.x] = 0; whist[2][threadIdx.x] = 0; whist[3][threadIdx.x] = 0;
-	__syncthreads();
+// ranks the (up to) OS_TILE keys of one tile held by the workgroup: a wave owns 512 consecutive keys (8 rounds of 64); rank within
+// the round by ballots (match-any on the digit bits), plus the wave's running count of the digit in LDS.  On return wh_all[w][d] =
+// keys of digit d in wave w's part of the tile, local[q] = rank of key q among the wave's keys of its digit.
+template<typename K>
+__device__ __forceinline__ void os_rank_tile(const K (&key)[OS_KPT], uint32_t tile_begin, uint32_t n, int shift, uint32_t (*whist)[256], uint32_t (&dig)[OS_KPT], uint32_t (&local)[OS_KPT]) {
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const uint32_t tile_begin = tile * OS_TILE;
 	uint32_t* wh = whist[wave];
-	K key[OS_KPT];
-	V val[OS_KPT];
-	uint32_t dig[OS_KPT], local[OS_KPT];
-#pragma unroll
-	for (int q = 0; q < OS_KPT; ++q) {
-		uint32_t i = tile_begin + wave * (64u * OS_KPT) + q * 64u + lane;       // a wave owns 512 consecutive keys
-		key[q] = i < n ? keys[i] : (K)0;
-		if (HAS_V) val[q] = i < n ? vals[i] : V();
-	}
-	// digit base of this pass: exclusive scan of the 256 digit totals
-	uint32_t base;
-	{
-		uint32_t v = ghist[threadIdx.x];
-		uint32_t x = v;
-		for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
-		if (lane == 63) wtot[wave] = x;
-		__syncthreads();
-		base = x - v;
-		for (unsigned w = 0; w < wave; ++w) base += wtot[w];
-	}
 #pragma unroll
 	for (int q = 0; q < OS_KPT; ++q) {
 		uint32_t i = tile_begin + wave * (64u * OS_KPT) + q * 64u + lane;
@@ -257,36 +193,108 @@ __global__ __launch_bounds__(256) void os_pass(const K* __restrict__ keys, K* __
 		__builtin_amdgcn_wave_barrier();
 		local[q] = before + rank;
 	}
+}
+
+template<typename K, typename V, bool HAS_V>
+__global__ __launch_bounds__(256) void os_pass(const K* __restrict__ keys, K* __restrict__ keys_out, const V* __restrict__ vals, V* __restrict__ vals_out,
+                                               const uint32_t* __restrict__ d_n, uint32_t* __restrict__ counts, uint32_t* __restrict__ group_sum, int shift) {
+	__shared__ uint32_t offs[256];
+	__shared__ uint32_t whist[4][256];
+	__shared__ uint32_t chunk_count[256];
+	__shared__ uint32_t wtot[4];
+	const uint32_t n = *d_n;
+	const uint32_t ntiles = (n + OS_TILE - 1) / OS_TILE;
+	const uint32_t m = (ntiles + gridDim.x - 1) / gridDim.x;               // tiles per workgroup (1 up to 2 M keys)
+	const uint32_t nwg = m ? (ntiles + m - 1) / m : 0;                       // workgroups that own a chunk
+	const uint32_t w = blockIdx.x;
+	if (w >= nwg) return;
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t first_tile = w * m, last_tile = min(first_tile + m, ntiles);
+	K key[OS_KPT];
+	V val[OS_KPT];
+	uint32_t dig[OS_KPT], local[OS_KPT];
+	whist[0][threadIdx.x] = 0; whist[1][threadIdx.x] = 0; whist[2][threadIdx.x] = 0; whist[3][threadIdx.x] = 0;
+	chunk_count[threadIdx.x] = 0;
 	__syncthreads();
+	// 1. count the chunk's digits
+	for (uint32_t t = first_tile; t < last_tile; ++t) {
+		const uint32_t tile_begin = t * OS_TILE;
+#pragma unroll
+		for (int q = 0; q < OS_KPT; ++q) {
+			uint32_t i = tile_begin + wave * (64u * OS_KPT) + q * 64u + lane;
+			key[q] = i < n ? keys[i] : (K)0;
+			if (HAS_V && m == 1) val[q] = i < n ? vals[i] : V();
+		}
+		os_rank_tile<K>(key, tile_begin, n, shift, whist, dig, local);
+		__syncthreads();
+		if (m > 1) {
+			chunk_count[threadIdx.x] += whist[0][threadIdx.x] + whist[1][threadIdx.x] + whist[2][threadIdx.x] + whist[3][threadIdx.x];
+			whist[0][threadIdx.x] = 0; whist[1][threadIdx.x] = 0; whist[2][threadIdx.x] = 0; whist[3][threadIdx.x] = 0;
+			__syncthreads();
+		}
+	}
 	{
-		// thread d owns digit d
+		// 2./3. thread d owns digit d: publish, collect
 		const uint32_t d = threadIdx.x;
-		const uint32_t cnt = whist[0][d] + whist[1][d] + whist[2][d] + whist[3][d];
-		__hip_atomic_store(tile_count + (size_t)tile * 256 + d, OS_READY | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		const uint32_t group = tile / OS_GROUP, first = group * OS_GROUP;
-		const uint32_t in_group = os_sum_published(tile_count + (size_t)first * 256 + d, tile - first, 256);
-		const bool closes_group = (tile % OS_GROUP) == OS_GROUP - 1 || tile == ntiles - 1;
-		if (closes_group) __hip_atomic_store(group_sum + (size_t)group * 256 + d, OS_READY | (in_group + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t cnt = m == 1 ? whist[0][d] + whist[1][d] + whist[2][d] + whist[3][d] : chunk_count[d];
+		__hip_atomic_store(counts + (size_t)w * 256 + d, OS_READY | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t group = w / OS_GROUP, first = group * OS_GROUP, ngroups = (nwg + OS_GROUP - 1) / OS_GROUP;
+		const uint32_t in_group = os_sum_published(counts + (size_t)first * 256 + d, w - first, 256);
+		if ((w % OS_GROUP) == OS_GROUP - 1 || w == nwg - 1)
+			__hip_atomic_store(group_sum + (size_t)group * 256 + d, OS_READY | (in_group + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		const uint32_t before_groups = os_sum_published(group_sum + d, group, 256);
+		const uint32_t total = before_groups + os_sum_published(group_sum + (size_t)group * 256 + d, ngroups - group, 256);
+		// digit base: exclusive scan of the 256 digit totals
+		uint32_t x = total;
+		for (int k = 1; k < 64; k <<= 1) { uint32_t y = __shfl_up(x, k); if ((int)lane >= k) x += y; }
+		if (lane == 63) wtot[wave] = x;
+		__syncthreads();
+		uint32_t base = x - total;
+		for (unsigned v = 0; v < wave; ++v) base += wtot[v];
 		offs[d] = base + before_groups + in_group;
 	}
 	__syncthreads();
+	// 4. scatter
+	if (m == 1) {
+		const uint32_t tile_begin = first_tile * OS_TILE;
 #pragma unroll
-	for (int q = 0; q < OS_KPT; ++q) {
-		uint32_t i = tile_begin + wave * (64u * OS_KPT) + q * 64u + lane;
-		if (i < n) {
-			uint32_t d = dig[q];
-			uint32_t pos = offs[d] + local[q];
-			for (unsigned w = 0; w < wave; ++w) pos += whist[w][d];
-			keys_out[pos] = key[q];
-			if (HAS_V) vals_out[pos] = val[q];
+		for (int q = 0; q < OS_KPT; ++q) {
+			uint32_t i = tile_begin + wave * (64u * OS_KPT) + q * 64u + lane;
+			if (i < n) {
+				uint32_t d = dig[q];
+				uint32_t pos = offs[d] + local[q];
+				for (unsigned v = 0; v < wave; ++v) pos += whist[v][d];
+				keys_out[pos] = key[q];
+				if (HAS_V) vals_out[pos] = val[q];
+			}
 		}
+		return;
 	}
-	if (ntiles <= gridDim.x) break;
-	__syncthreads();
-	if (threadIdx.x == 0) s_tile = gridDim.x + atomicAdd(ticket, 1u);
-	__syncthreads();
-	tile = s_tile;
+	for (uint32_t t = first_tile; t < last_tile; ++t) {
+		const uint32_t tile_begin = t * OS_TILE;
+#pragma unroll
+		for (int q = 0; q < OS_KPT; ++q) {
+			uint32_t i = tile_begin + wave * (64u * OS_KPT) + q * 64u + lane;
+			key[q] = i < n ? keys[i] : (K)0;
+			if (HAS_V) val[q] = i < n ? vals[i] : V();
+		}
+		os_rank_tile<K>(key, tile_begin, n, shift, whist, dig, local);
+		__syncthreads();
+#pragma unroll
+		for (int q = 0; q < OS_KPT; ++q) {
+			uint32_t i = tile_begin + wave * (64u * OS_KPT) + q * 64u + lane;
+			if (i < n) {
+				uint32_t d = dig[q];
+				uint32_t pos = offs[d] + local[q];
+				for (unsigned v = 0; v < wave; ++v) pos += whist[v][d];
+				keys_out[pos] = key[q];
+				if (HAS_V) vals_out[pos] = val[q];
+			}
+		}
+		__syncthreads();
+		offs[threadIdx.x] += whist[0][threadIdx.x] + whist[1][threadIdx.x] + whist[2][threadIdx.x] + whist[3][threadIdx.x];
+		whist[0][threadIdx.x] = 0; whist[1][threadIdx.x] = 0; whist[2][threadIdx.x] = 0; whist[3][threadIdx.x] = 0;
+		__syncthreads();
 	}
 }
 
@@ -294,23 +302,30 @@ template<typename K, typename V, bool HAS_V>
 static int onesweep_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* vals_b, const uint32_t* d_count, uint32_t capacity, uint32_t expected, uint32_t* scratch, const os_shifts& sh) {
 	K* kin = keys_a; K* kout = keys_b;
 	V* vin = vals_a; V* vout = vals_b;
-	const uint32_t tiles = os_tiles(capacity), groups = os_groups(tiles);
-	uint32_t* ghist = scratch;
-	uint32_t* ticket = scratch + OS_MAX_PASSES * 256;
-	uint32_t* state = ticket + 256;
-	const size_t per_pass = (size_t)(tiles + groups) * 256;
-	// one workgroup per expected tile (+12 %); more tiles than that are still sorted correctly, just by ticket
-	uint64_t want = ((uint64_t)expected + expected / 8 + OS_TILE - 1) / OS_TILE + 2;
-	uint32_t grid = expected == 0 || want > tiles ? tiles : (uint32_t)want;
-	if (grid > OS_MAX_GRID) grid = OS_MAX_GRID;
+	// one workgroup per expected tile (+12 %), never more than are resident at once; any count is still sorted correctly
+	// (workgroups then own chunks of several tiles)
+	const uint64_t cap_tiles = ((uint64_t)capacity + OS_TILE - 1) / OS_TILE + 1;
+	uint64_t want = expected ? ((uint64_t)expected + expected / 8 + OS_TILE - 1) / OS_TILE + 2 : cap_tiles;
+	if (want > cap_tiles) want = cap_tiles;
+	// every workgroup of a pass must be resident at once (they wait for each other): bound the launch by 3/4 of what the
+	// occupancy calculator says fits (kernels of the side stream may hold some slots for a while; they never wait for us)
+	static int resident = 0;
+	if (!resident) {
+		int per_cu = 0, cus = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, os_pass<K, V, HAS_V>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+		if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1) cus = 64;
+		resident = per_cu * cus * 3 / 4;
+		if (resident > OS_MAX_GRID) resident = OS_MAX_GRID;
+		if (resident < 16) resident = 16;
+	}
+	const uint32_t grid = want > (uint64_t)resident ? (uint32_t)resident : (uint32_t)want;
 	if (ctx->timing) nh_timer_begin(ctx, "radix_clear");
-	hipError_t e = hipMemsetAsync(scratch, 0, sizeof(uint32_t) * ((size_t)OS_MAX_PASSES * 256 + 256 + (size_t)sh.n * per_pass), ctx->stream);
+	hipError_t e = hipMemsetAsync(scratch, 0, sizeof(uint32_t) * (size_t)sh.n * OS_PASS_WORDS, ctx->stream);
 	if (ctx->timing) nh_timer_end(ctx);
 	if (e != hipSuccess) ctx->last_hip_error = (int)e;
-	NH_LAUNCH(ctx, "radix_hist", (os_hist<K>), grid < 256 ? grid : 256, 256, kin, d_count, ghist, sh);
 	for (int p = 0; p < sh.n; ++p) {
-		uint32_t* tc = state + (size_t)p * per_pass;
-		NH_LAUNCH(ctx, "radix_pass", (os_pass<K, V, HAS_V>), grid, 256, kin, kout, vin, vout, d_count, ghist + p * 256, ticket + p, tc, tc + (size_t)tiles * 256, sh.s[p]);
+		uint32_t* c = scratch + (size_t)p * OS_PASS_WORDS;
+		NH_LAUNCH(ctx, "radix_pass", (os_pass<K, V, HAS_V>), grid, 256, kin, kout, vin, vout, d_count, c, c + (size_t)OS_MAX_GRID * 256, sh.s[p]);
 		K* tk = kin; kin = kout; kout = tk;
 		V* tv = vin; vin = vout; vout = tv;
 	}
