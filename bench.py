@@ -51,9 +51,31 @@ KERNEL_BYTES = {
     "write_cache": ("K", 12 + 16 + 28),
     "radix_hist": ("N", 8),
     "radix_scatter": ("N", 24),
+    "radix_pass": ("P", 24),                               # one 8-bit pass over the pair records: key 8 + index 4, read and written
     "advance": ("B", 32 + 32 + 1 + 32 + 1),
     "gravity_damping": ("B", 64 + 4),
 }
+
+
+# timer name (nh_* launch sites) -> kernel symbol prefix in the rocprofv3 PMC export (profiles/export_pmc.py)
+PMC_KERNEL = {"solve_one_body": "k_solve_one_body<4, true>", "apply_static": "k_apply_static<4, true>", "narrowphase": "k_narrowphase",
+              "gather_contacts": "k_gather_contacts", "find_pairs": "k_find_pairs", "radix_pass": "os_pass<unsigned long, unsigned int, true>",
+              "apply_level": "k_level_exec<false>", "write_cache": "k_write_cache", "xform_aabb": "k_xform"}
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC export (FETCH_SIZE x 2 + WRITE_SIZE, see
+    profiles/export_pmc.py and MI355X_MICROARCH.md): measured in a separate rocprofv3 --pmc run of this same command."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), key=os.path.getmtime)
+    sym = PMC_KERNEL.get(kernel)
+    if not files or not sym:
+        return None, None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(sym)
+    except Exception:
+        return None, None
+    return (k["hbm_bytes_corrected"], os.path.basename(files[-1])) if k else (None, None)
 
 
 def step_algorithmic_bytes(B, C, P, K, I):
@@ -233,8 +255,9 @@ def main():
             launches_per_step = dom[1] / args.steps
             ms = dom[0] / dom[1]
             bytes_per_launch = per * units
+            traffic, traffic_src = pmc_traffic(dominant) if args.scene == "boxes" and args.tiles == 124 else (None, None)
             out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": bytes_per_launch / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": bytes_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                               "unit": "GB/s", "frac": bytes_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                "avg_launch_ms": ms, "launches_per_step": launches_per_step,
                                "algorithmic_bytes_per_launch": bytes_per_launch, "share_of_step": dom[0] / (1e3 * dt)}
         elif dom:
