@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) void k_sorted_counts(const nh_DevState* __rest
 __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict__ st, const uint32_t* __restrict__ rec_idx, const nh_Record* __restrict__ rec, const uint64_t* __restrict__ rec_key_sorted,
                                                          const uint32_t* __restrict__ starts, const nh_Contact* __restrict__ raw_data, const uint32_t* __restrict__ raw_feature,
                                                          nh_Contact* __restrict__ data, nh_BodyPair* __restrict__ bodies, uint64_t* __restrict__ tags, uint32_t* __restrict__ features, uint32_t capacity, uint32_t pair_cap,
-                                                         const uint32_t* __restrict__ sleep_scan, uint64_t* __restrict__ sleeping_pairs) {
+                                                         const uint32_t* __restrict__ sleep_scan, uint64_t* __restrict__ sleeping_pairs, uint32_t* __restrict__ deg) {
 	__shared__ uint32_t s_src[4][1024];
 	__shared__ uint32_t s_feat[4][1024];
 	__shared__ uint8_t s_own[4][1024];
@@ -638,6 +638,8 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 			}
 			body_a = r.body_a; body_b = r.body_b;
 			base4 = 4u * ri; baseo = 4u * pair_cap + r.overflow;
+			// contact degree of the two bodies (body 0 is the static world): the solver's adjacency starts from these
+			if (cnt && start + cnt <= capacity) { if (body_a) atomicAdd(&deg[body_a], cnt); if (body_b) atomicAdd(&deg[body_b], cnt); }
 		}
 		const uint32_t base = __shfl(start, 0);                  // lane 0 is always a valid record here
 		{
@@ -693,8 +695,9 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 }
 
 // counters, bounds, and the union-find / island arrays (parent[i] = i, nothing active yet)
-__global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t ncolliders, uint32_t nbodies, uint32_t* __restrict__ parent, uint32_t* __restrict__ set_active) {
+__global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t ncolliders, uint32_t nbodies, uint32_t* __restrict__ parent, uint32_t* __restrict__ set_active, uint32_t* __restrict__ deg) {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) { parent[i] = i; set_active[i] = 0; }
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < 2u * (nbodies + 2u); i += gridDim.x * blockDim.x) deg[i] = 0;      // degrees + fill cursors
 	if (blockIdx.x != 0) return;
 	uint32_t t = threadIdx.x;
 	if (t == 0) {
@@ -772,7 +775,14 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	if (err) return err;
 
 	hipStream_t s = ctx->stream;
-	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, nh_grid_for(B, 256, 2048), 256, st, C, B, parent, set_active);
+	if (ctx->deg_capacity < 2u * (B + 2u)) {
+		// library-owned: per-body contact degrees, counted while the contacts are laid out and consumed by nh_setup_contact_constraints
+		if (ctx->deg) NH_HIP_CHECK(ctx, hipFree(ctx->deg));
+		ctx->deg = nullptr; ctx->deg_capacity = 0;
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->deg, sizeof(uint32_t) * 2u * ((size_t)B + 2u)));
+		ctx->deg_capacity = 2u * (B + 2u);
+	}
+	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, nh_grid_for(B, 256, 2048), 256, st, C, B, parent, set_active, ctx->deg);
 	if (C) {
 		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 1024, 256), 1024, st, bodies->transforms,
 		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
@@ -841,7 +851,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	// contact starts and sleeping-pair slots: two scans over the sorted records in one pair of launches
 	nh_scan2_u32(ctx, rec_counts, rec_counts, &st->contacts, sleep_flags, sleep_flags, &st->sleeping, &st->records, 1, scan_tmp);
 	NH_LAUNCH(ctx, "gather_contacts", k_gather_contacts, nh_grid_for(pair_cap, 256, 8192), 256, st, rec_idx_a, rec, rec_key_a, rec_counts, raw_data, raw_feature,
-	          contacts->data, contacts->bodies, contacts->tags, contacts->features, cap, pair_cap, sleep_flags, contacts->sleeping_pairs);
+	          contacts->data, contacts->bodies, contacts->tags, contacts->features, cap, pair_cap, sleep_flags, contacts->sleeping_pairs, ctx->deg);
 
 	if (ctx->flags & NH_FLAG_SYNC_COUNTS) {
 		nh_Counts c;

@@ -19,6 +19,8 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->pending = nullptr;
 	ctx->hint = nullptr;
 	ctx->hint_capacity = 0;
+	ctx->deg = nullptr;
+	ctx->deg_capacity = 0;
 	ctx->d_state = nullptr;
 	ctx->h_state = nullptr;
 	if (hipMalloc((void**)&ctx->d_state, sizeof(nh_DevState)) != hipSuccess) { delete ctx; return NH_ERR_HIP; }
@@ -44,6 +46,7 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
 	if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
 	if (ctx->hint) hipFree(ctx->hint);
+	if (ctx->deg) hipFree(ctx->deg);
 	if (ctx->d_state) hipFree(ctx->d_state);
 	if (ctx->h_state) hipHostFree(ctx->h_state);
 	delete ctx;

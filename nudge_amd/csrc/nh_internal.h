@@ -88,6 +88,9 @@ struct nh_context {
 	// warm-start hints (per body: index of its first contact in the previous step's contact list); library-owned device memory
 	uint32_t* hint;
 	uint32_t hint_capacity;
+	// per-body contact degree (filled by nh_collide's contact gather, turned into CSR offsets by setup) + fill cursors: 2 x (B + 2) words
+	uint32_t* deg;
+	uint32_t deg_capacity;
 	// fork/join inside one entry point: independent kernel chains run on `side` while the caller's stream does the long one
 	hipStream_t side;
 	hipEvent_t ev_fork, ev_join;

@@ -1103,7 +1103,8 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	nh_ContactConstraintData* d = new_constraint_data(ctx);
 	d->rows = nh_arena_array<float>(memory, (size_t)kcap * 40, &err);
 	d->states = nh_arena_array<float>(memory, (size_t)kcap * 4, &err);
-	d->body_off = nh_arena_array<uint32_t>(memory, 2 * (size_t)(B + 2), &err);    // [B+2] offsets, then [B+2] fill cursors
+	if (!ctx->deg || ctx->deg_capacity < 2u * (B + 2u)) return NH_ERR_INVALID;      // nh_collide of this step sized and filled it
+	d->body_off = ctx->deg;                                                         // [B+2] degrees -> offsets, then [B+2] fill cursors
 	d->adj = nh_arena_array<uint32_t>(memory, (size_t)kcap * 2, &err);
 	d->static_bodies = nh_arena_array<uint32_t>(memory, (size_t)3 * B, &err);
 	d->body_class = nh_arena_array<uint8_t>(memory, B, &err);
@@ -1122,8 +1123,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	d->contact_data = contacts->data; d->impulses = imp->data; d->general_list = general_list;
 	d->levels = 0; d->general_contacts = 0;
 
-	NH_LAUNCH(ctx, "zero_u32", k_zero_u32, nh_grid_for(2 * (B + 2), 256, 2048), 256, d->body_off, 2 * (B + 2));     // body_off and cursor are adjacent
-	NH_LAUNCH(ctx, "contact_degree", k_degree, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, contacts->tags, d->body_off);
+	// (degrees were counted by nh_collide while it laid the contacts out)
 	nh_scan_u32(ctx, d->body_off, d->body_off, &st->pad0, B + 1, tmp, nullptr);
 	NH_LAUNCH(ctx, "adjacency_fill", k_adj_fill, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, contacts->tags, d->body_off, cursor, d->adj);
 	if (slot_key) NH_LAUNCH(ctx, "greedy_replay", k_greedy_replay, 1, 64, st, contacts->bodies, slot_key);
