@@ -180,6 +180,16 @@ int nh_update_cached_impulses(nh_context* ctx, nh_ContactConstraintData* data, n
 /* advance (nudge.h:146, nudge.cpp:4886-4926) */
 int nh_advance(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_BodyData* bodies, float time_step);
 
+/* ---- multi-GPU helpers (nudge_amd/partition.py): the per-step halo record of a body ---------------------- */
+/* record = transform.position (12 B) | transform.rotation (16 B) | momentum (32 B) | idle counter (1 B) + 3 B pad = 64 B.
+   nh_halo_pack gathers the records of the bodies listed in `indices` (device memory) into `out` (device memory, count x 64 B);
+   nh_halo_unpack writes `count` records into the consecutive body slots first_slot .. first_slot+count-1 (the `body` field of
+   their transforms -- unused by the engine for bodies, nudge.h:36 -- is left alone).  Transport between the two is the host's
+   business (RCCL send/recv). */
+#define NH_HALO_RECORD_BYTES 64
+int nh_halo_pack(nh_context* ctx, const nh_BodyData* bodies, const uint32_t* indices, uint32_t count, void* out);
+int nh_halo_unpack(nh_context* ctx, const nh_BodyData* bodies, uint32_t first_slot, uint32_t count, const void* in);
+
 /* ---- introspection for tests / measurement --------------------------------------------------------- */
 /* Device pointer to the per-contact warm-start impulses of an nh_ContactImpulseData (K x 16 B, contact order). */
 const nh_CachedContactImpulse* nh_contact_impulses_device(const nh_ContactImpulseData* d);

@@ -1267,3 +1267,50 @@ extern "C" int nh_update_cached_impulses(nh_context* ctx, nh_ContactConstraintDa
 		NH_LAUNCH(ctx, "update_impulses", k_update_impulses, nh_grid_for(d->general_contacts, 256, 4096), 256, ctx->d_state, d->general_list, d->rows, (const float4*)d->states, imp->data);
 	return NH_OK;
 }
+
+// ---- halo records (multi-GPU partitions, include/nudge_hip.h) ---------------------------------------------------------------------
+struct nh_HaloRecord { float position[3]; float rotation[4]; float momentum[8]; uint32_t idle; };     // 64 B
+static_assert(sizeof(nh_HaloRecord) == NH_HALO_RECORD_BYTES, "halo record layout");
+
+__global__ __launch_bounds__(256) void k_halo_pack(const nh_Transform* __restrict__ xf, const nh_BodyMomentum* __restrict__ momentum, const uint8_t* __restrict__ idle,
+                                                   const uint32_t* __restrict__ indices, uint32_t count, nh_HaloRecord* __restrict__ out) {
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+		const uint32_t i = indices[k];
+		const float4 t0 = reinterpret_cast<const float4*>(xf + i)[0], t1 = reinterpret_cast<const float4*>(xf + i)[1];
+		const float4 m0 = reinterpret_cast<const float4*>(momentum + i)[0], m1 = reinterpret_cast<const float4*>(momentum + i)[1];
+		float4* o = reinterpret_cast<float4*>(out + k);
+		o[0] = make_float4(t0.x, t0.y, t0.z, t1.x);
+		o[1] = make_float4(t1.y, t1.z, t1.w, m0.x);
+		o[2] = make_float4(m0.y, m0.z, m0.w, m1.x);
+		o[3] = make_float4(m1.y, m1.z, m1.w, __uint_as_float((uint32_t)idle[i]));
+	}
+}
+
+__global__ __launch_bounds__(256) void k_halo_unpack(nh_Transform* __restrict__ xf, nh_BodyMomentum* __restrict__ momentum, uint8_t* __restrict__ idle,
+                                                     uint32_t first_slot, uint32_t count, const nh_HaloRecord* __restrict__ in) {
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+		const uint32_t i = first_slot + k;
+		const float4* r = reinterpret_cast<const float4*>(in + k);
+		const float4 a = r[0], b = r[1], c = r[2], d = r[3];
+		nh_Transform* t = xf + i;
+		t->position[0] = a.x; t->position[1] = a.y; t->position[2] = a.z;             // t->body keeps what the owner of the slot put there
+		reinterpret_cast<float4*>(t)[1] = make_float4(a.w, b.x, b.y, b.z);
+		reinterpret_cast<float4*>(momentum + i)[0] = make_float4(b.w, c.x, c.y, c.z);
+		reinterpret_cast<float4*>(momentum + i)[1] = make_float4(c.w, d.x, d.y, d.z);
+		idle[i] = (uint8_t)__float_as_uint(d.w);
+	}
+}
+
+extern "C" int nh_halo_pack(nh_context* ctx, const nh_BodyData* bodies, const uint32_t* indices, uint32_t count, void* out) {
+	if (!ctx || !bodies || (count && (!indices || !out))) return NH_ERR_INVALID;
+	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	if (count) NH_LAUNCH(ctx, "halo_pack", k_halo_pack, nh_grid_for(count, 256, 1024), 256, bodies->transforms, bodies->momentum, bodies->idle_counters, indices, count, (nh_HaloRecord*)out);
+	return NH_OK;
+}
+
+extern "C" int nh_halo_unpack(nh_context* ctx, const nh_BodyData* bodies, uint32_t first_slot, uint32_t count, const void* in) {
+	if (!ctx || !bodies || (count && !in) || (uint64_t)first_slot + count > bodies->count) return NH_ERR_INVALID;
+	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	if (count) NH_LAUNCH(ctx, "halo_unpack", k_halo_unpack, nh_grid_for(count, 256, 1024), 256, bodies->transforms, bodies->momentum, bodies->idle_counters, first_slot, count, (const nh_HaloRecord*)in);
+	return NH_OK;
+}

@@ -29,7 +29,9 @@ EXPORTS = [
     "nh_set_tag_bits", "nh_error_string", "nh_last_hip_error", "nh_collide", "nh_apply_gravity_damping",
     "nh_read_cached_impulses", "nh_write_cached_impulses", "nh_setup_contact_constraints", "nh_apply_impulses",
     "nh_update_cached_impulses", "nh_advance", "nh_contact_impulses_device", "nh_enable_timing", "nh_set_timing_filter", "nh_kernel_times",
+    "nh_halo_pack", "nh_halo_unpack",
 ]
+HALO_RECORD_BYTES = 64
 
 
 class Arena(C.Structure):
@@ -120,6 +122,8 @@ def lib():
         L.nh_enable_timing.argtypes = [C.c_void_p, C.c_int]
         L.nh_set_timing_filter.argtypes = [C.c_void_p, C.c_char_p]
         L.nh_kernel_times.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int, C.c_int]
+        L.nh_halo_pack.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_void_p, C.c_uint32, C.c_void_p]
+        L.nh_halo_unpack.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_uint32, C.c_uint32, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -283,6 +287,21 @@ class World:
         t = self._keep[name]
         n = t.numel() // record_bytes
         return t[:n * record_bytes].view(n, record_bytes)
+
+    # ---- halo records of the partitioned world (include/nudge_hip.h: nh_halo_pack / nh_halo_unpack) ----
+    def halo_pack(self, indices_i32):
+        """indices_i32: int32 device tensor of body slots -> uint8 device tensor [len, 64] of their per-step records."""
+        n = int(indices_i32.numel())
+        out = self.torch.empty((n, HALO_RECORD_BYTES), dtype=self.torch.uint8, device=self.dev)
+        _check(self.L, self.L.nh_halo_pack(self.ctx, C.byref(self.bodies), C.c_void_p(indices_i32.data_ptr() if n else 0), n,
+                                           C.c_void_p(out.data_ptr() if n else 0)), "halo_pack")
+        return out
+
+    def halo_unpack(self, first_slot, records):
+        n = int(records.shape[0])
+        if n:
+            assert records.is_contiguous() and records.shape[1] == HALO_RECORD_BYTES
+            _check(self.L, self.L.nh_halo_unpack(self.ctx, C.byref(self.bodies), first_slot, n, C.c_void_p(records.data_ptr())), "halo_unpack")
 
     # ---- state ----
     def synchronize(self):

@@ -15,7 +15,7 @@ contiguous copies:
     rank lists the owned bodies that can reach across a cut within the coming epoch,
         distance to the cut  <  reach(body) + max reach of any body + epoch * dt * speed bound,
     and sends their full records once; both sides remember the list;
-  * every step: the dynamic part (transform, momentum, idle counter; 68 B) of the listed bodies is sent, the
+  * every step: the dynamic part (position, rotation, momentum, idle counter; 64 B) of the listed bodies is sent, the
     receiver overwrites its ghost slots.  Ghosts are integrated locally as well (they are ordinary bodies to the
     engine) and corrected by the owner's state at the next step.
 Contacts between an owned body and a ghost are solved on BOTH ranks, each against its own picture of the other
@@ -37,7 +37,7 @@ import numpy as np
 from . import scenes as S
 
 FULL_BYTES = 32 + 16 + 32 + 16 + 32 + 4 + 4        # transform, properties, momentum, shape, collider transform, tag, (kind, idle)
-STEP_BYTES = 32 + 32 + 4                          # transform, momentum, idle
+STEP_BYTES = 64                                   # position 12, rotation 16, momentum 32, idle 1 + pad (nh_halo_pack's record)
 
 
 def body_reach(scene):
@@ -154,6 +154,7 @@ class Partition:
         self.reach = torch.zeros(cap, dtype=torch.float32, device=dev)
         self.reach[:n] = torch.from_numpy(info["reach"].copy()).to(dev)
         self.ghost_out = {-1: None, +1: None}      # owned slots sent to the left / right neighbour every step
+        self.ghost_out32 = {-1: None, +1: None}
         self.ghost_in = {-1: 0, +1: 0}             # ghost records received from the left / right neighbour
         self.steps = 0
         self.stats = dict(refreshes=0, migrated_out=0, migrated_in=0, ghosts=0, late_bodies=0, step_bytes=0, refresh_bytes=0)
@@ -193,11 +194,14 @@ class Partition:
         ext = t.where(self.kind[s] == 0, sh[:, :3].norm(dim=1), sh[:, 0])
         self.reach[s] = (off + ext) * 1.0001
 
-    def _step_records(self, idx):
+    def _step_records(self, idx, idx32=None):
+        """Per-step records [len, 64] of the given body slots: the engine's HIP kernel when it has one (nh_halo_pack), else torch ops."""
+        if hasattr(self.e, "halo_pack"):
+            return self.e.halo_pack(idx32 if idx32 is not None else idx.to(self.torch.int32))
         t = self.torch
         pad = t.zeros((len(idx), 4), dtype=t.uint8, device=idx.device)
         pad[:, 0] = self.bi[idx, 0]
-        return t.cat([self.bt[idx], self.bm[idx], pad], dim=1)
+        return t.cat([self.bt[idx][:, :12], self.bt[idx][:, 16:], self.bm[idx], pad], dim=1)
 
     # ---- refresh: phase 1 (migration) --------------------------------------------------------------------------
     def refresh_pack_migrants(self):
@@ -252,6 +256,7 @@ class Partition:
             m = own & ((x - margin < self.lo) if d < 0 else (x + margin >= self.hi))
             idx = t.nonzero(m).flatten()
             self.ghost_out[d] = idx
+            self.ghost_out32[d] = idx.to(t.int32)
             out[d] = self._full(idx)
         self._drift = drift
         return out
@@ -296,7 +301,7 @@ class Partition:
     def step_pack(self):
         out = {}
         for d in self.neighbours():
-            rec = self._step_records(self.ghost_out[d])
+            rec = self._step_records(self.ghost_out[d], self.ghost_out32[d])
             out[d] = rec
             self.stats["step_bytes"] += int(rec.numel())
         return out
@@ -307,11 +312,14 @@ class Partition:
             m = self.ghost_in[d]
             if m:
                 rec = incoming[d]
-                s = slice(at, at + m)
-                self.bt[s, :12] = rec[:, :12]                 # position
-                self.bt[s, 16:] = rec[:, 16:32]               # rotation (the `body` field keeps the global id)
-                self.bm[s] = rec[:, 32:64]
-                self.bi[s, 0] = rec[:, 64]
+                if hasattr(self.e, "halo_unpack"):
+                    self.e.halo_unpack(at, rec.contiguous())
+                else:
+                    s = slice(at, at + m)
+                    self.bt[s, :12] = rec[:, :12]                 # position
+                    self.bt[s, 16:] = rec[:, 12:28]               # rotation (the `body` field keeps the global id)
+                    self.bm[s] = rec[:, 28:60]
+                    self.bi[s, 0] = rec[:, 60]
             at += m
 
     def local_step(self):
