@@ -284,3 +284,35 @@ def test_ball_pit_invariants_default_order():
     assert abs(gc["count"] - rc["count"]) <= 0.05 * rc["count"] + 50, (gc["count"], rc["count"])
     assert gc["data"]["penetration"].max() <= rc["data"]["penetration"].max() + 0.02
     w.close()
+
+
+# ---- deferred execution: unusual call patterns must still look like the reference's call-by-call semantics ---------------------
+@needs_ref
+@pytest.mark.parametrize("name,warm", [("grid30", 60), ("pile256", 330)])
+def test_setup_without_apply_and_zero_iterations(name, warm):
+    """nh_setup_contact_constraints defers the warm start of one-body bodies into the first nh_apply_impulses.  A caller that
+    never applies (update / write / advance straight after setup), or applies zero sweeps, must get what the reference gives:
+    momentum after the warm start only, and the cache rewritten from the warm-start impulses."""
+    scene, _ = G.build(name)
+    for pattern in ("no_apply", "zero_iterations", "synchronize_after_setup"):
+        w = E.World(scene, flags=E.NH_FLAG_SYNC_COUNTS | E.NH_FLAG_EXACT_ORDER)
+        ref = refworld.RefWorld(scene)
+        w.step(warm); ref.step(warm)
+        for _ in range(3):
+            w.collide(); w.gravity(); w.read_cache(); w.setup()
+            ref.collide(); ref.gravity(); ref.read_cache(); ref.setup()
+            if pattern == "zero_iterations":
+                w.apply(0)
+            elif pattern == "synchronize_after_setup":
+                # the warm start must be visible to whoever synchronises and reads momentum right after setup
+                assert P.bits_equal(w.get_bodies()["momentum"]["velocity"], ref.bodies()["momentum"]["velocity"])
+                w.apply(2); ref.apply(2)
+            w.update(); w.write_cache(); w.advance()
+            ref.update(); ref.write_cache(); ref.advance()
+            a, b = w.get_bodies(), ref.bodies()
+            assert P.bits_equal(a["transforms"], b["transforms"]), pattern
+            assert P.bits_equal(a["momentum"]["velocity"], b["momentum"]["velocity"]), pattern
+            ca, cb = w.get_cache(), ref.cache()
+            assert ca["count"] == cb["count"]
+            assert P.bits_equal(ca["data"]["impulse"], cb["data"]["impulse"]), pattern
+        w.close()
