@@ -150,9 +150,10 @@ def main():
     if halo:
         # ONE world of world x tiles; equal-count x-slabs whose cuts pass through tiles
         from nudge_amd import partition as PT
-        # 4 x world columns of tiles (31 rows at 124 tiles per GPU): a compact 2-D lattice like config 5's, so that coordinates stay
+        # 4 x world + 1 columns of tiles (~30 rows at 124 tiles per GPU; the odd column count puts the equal-count cuts INSIDE tiles,
+        # not in the gaps between them): a compact 2-D lattice like config 5's, so that coordinates stay
         # small enough for fp32 (a 1-D strip of 88 columns would put boxes at x = 24,000 where one ulp is 2 mm)
-        g = S.grid_tiles(args.tiles * world, side=args.side, sphere_fraction=sphere_fraction, seed=2, lattice_cols=4 * world)
+        g = S.grid_tiles(args.tiles * world, side=args.side, sphere_fraction=sphere_fraction, seed=2, lattice_cols=4 * world + 1)
         gx = g["body_transforms"]["position"][1:, 0]
         cuts = [float(np.quantile(gx, (r + 1) / world)) + 0.41 for r in range(world - 1)]
         scene, info = PT.split_scene(g, cuts, rank)
