@@ -127,6 +127,8 @@ struct nh_ContactConstraintData {
 	uint32_t* static_bodies;              // 3 x B: bodies on the one-body fast path, by contact count (<=4 | <=8 | more)
 	uint8_t* body_class;                  // 0 none, 1 static-only, 2 general
 	uint32_t* level_order;                // general contacts sorted by level
+	uint2* gpair;                         // per general contact, LEVEL order: body pair
+	float4* gstates;                      //   solver state (rows of general contacts are structure-of-float4 in `rows`, level order, stride = contact_capacity)
 	uint32_t level_off[NH_MAX_LEVELS + 2];// host copy of level offsets
 	uint32_t levels;
 	uint32_t general_contacts;

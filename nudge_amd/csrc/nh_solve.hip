@@ -240,8 +240,8 @@ __global__ __launch_bounds__(256) void k_adj_sort(nh_DevState* __restrict__ st, 
 			if (cls == NH_CLS_STATIC8) st->has_static8 = 1;
 			if (cls == NH_CLS_STATICN) st->has_staticN = 1;
 			// the reference stashes mass_inverse in momentum.unused0 of EVERY body (nudge.cpp:4198); bodies with contacts
-			// get it from the solver's velocity write-back, the rest here
-			if (cls == NH_CLS_NONE) momentum[x].unused0 = props[x].mass_inverse;
+			// on the one-body path get it from the solver's velocity write-back, the rest here (the level-scheduled sweeps read it from there)
+			if (cls == NH_CLS_NONE || cls == NH_CLS_GENERAL) momentum[x].unused0 = props[x].mass_inverse;
 		} else if (x == 0 && nbodies) {
 			body_class[0] = 0;
 			momentum[0].unused0 = props[0].mass_inverse;
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void k_setup_static(uint32_t nbodies, const ui
 			o.unused = 0.0f;
 			float4 sv = make_float4(s.normal, s.friction_x, s.friction_y, 0.0f);
 			if (STORE) {
-				store_row(rows, c, r);
+				// (rows are not stored: bodies with more than 8 static contacts rebuild them in every sweep, see k_apply_static<0>)
 				states[c] = sv;
 				cached[c] = o;
 			} else {
@@ -565,14 +565,23 @@ __global__ __launch_bounds__(256) void k_apply_static(uint32_t nbodies, const ui
 					impulses[cid[q]] = o;
 				}
 		} else {
+			// any contact count (rare: a body resting on more than 8 static contacts): rows are rebuilt from the contact in every sweep
+			// instead of being stored -- a pure function of (contact, body transforms, properties), so the same bits every time
+			const nh_inertia IXn = body_inertia(xf, props, x);
+			const nh_Transform txn = xf[x];
+			const nh_f3 posxn = nh_make3(txn.position[0], txn.position[1], txn.position[2]);
 			for (uint32_t it = 0; it < iterations; ++it) {
 				for (uint32_t q = b; q < e; ++q) {
 					uint32_t c = adj[q];
+					const bool x_is_a = bodies[c].a == x;
+					nh_Contact ct = contacts[c];
+					nh_contact_in ci = { ct.position[0], ct.position[1], ct.position[2], ct.penetration, ct.normal[0], ct.normal[1], ct.normal[2], ct.friction };
 					nh_row r;
-					load_row(rows, c, r);
+					if (x_is_a) nh_build_row(ci, posxn, pos0, IXn, I0, v.mass_inverse, z.mass_inverse, r);
+					else        nh_build_row(ci, pos0, posxn, I0, IXn, z.mass_inverse, v.mass_inverse, r);
 					float4 sv = states[c];
 					nh_state s = { sv.x, sv.y, sv.z };
-					if (bodies[c].a == x) nh_apply_one(r, s, v, z); else nh_apply_one(r, s, z, v);
+					if (x_is_a) nh_apply_one(r, s, v, z); else nh_apply_one(r, s, z, v);
 					states[c] = make_float4(s.normal, s.friction_x, s.friction_y, 0.0f);
 					if (it + 1 == iterations) {
 						nh_CachedContactImpulse o;
@@ -908,13 +917,40 @@ __global__ __launch_bounds__(256) void k_level_scatter(const nh_DevState* __rest
 	}
 }
 
-// rows of general contacts (any order), then warm start / PGS level by level
-__global__ __launch_bounds__(256) void k_rows_general(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ general_list,
+// ---- general contacts: everything per contact lives in LEVEL ORDER (position k in level_order) ------------------------------------
+// rows as structure-of-float4 (chunk q of contact k at rows4[q * stride + k]: a wave's ten row loads are ten contiguous
+// kilobytes), the body pair, the solver state.  The sweeps then stream rows / pairs / states and only gather the two momentum
+// records (32 B each; mass_inverse rides in momentum.unused0 like in the reference, nudge.cpp:4198 -- k_adj_sort put it there).
+__device__ __forceinline__ void store_row_soa(float4* __restrict__ rows4, size_t stride, uint32_t k, const nh_row& r) {
+	const float4* src = reinterpret_cast<const float4*>(&r);
+#pragma unroll
+	for (int q = 0; q < 10; ++q) rows4[(size_t)q * stride + k] = src[q];
+}
+
+__device__ __forceinline__ void load_row_soa(const float4* __restrict__ rows4, size_t stride, uint32_t k, nh_row& r) {
+	float4* dst = reinterpret_cast<float4*>(&r);
+#pragma unroll
+	for (int q = 0; q < 10; ++q) dst[q] = rows4[(size_t)q * stride + k];
+}
+
+__device__ __forceinline__ nh_vel load_vel_m(const nh_BodyMomentum* __restrict__ momentum, uint32_t i) {
+	const float4 m0 = reinterpret_cast<const float4*>(momentum + i)[0], m1 = reinterpret_cast<const float4*>(momentum + i)[1];
+	nh_vel v = { m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w };
+	return v;
+}
+
+__device__ __forceinline__ void store_vel_m(nh_BodyMomentum* __restrict__ momentum, uint32_t i, const nh_vel& v) {
+	reinterpret_cast<float4*>(momentum + i)[0] = make_float4(v.vx, v.vy, v.vz, v.mass_inverse);
+	reinterpret_cast<float4*>(momentum + i)[1] = make_float4(v.wx, v.wy, v.wz, v.w_unused);
+}
+
+__global__ __launch_bounds__(256) void k_rows_general(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ order,
                                                       const nh_Contact* __restrict__ contacts, const nh_BodyPair* __restrict__ bodies,
-                                                      const nh_Transform* __restrict__ xf, const nh_BodyProperties* __restrict__ props, float* __restrict__ rows) {
+                                                      const nh_Transform* __restrict__ xf, const nh_BodyProperties* __restrict__ props,
+                                                      float4* __restrict__ rows4, size_t stride, uint2* __restrict__ gpair) {
 	uint32_t n = st->general_contacts;
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-		uint32_t c = general_list[k];
+		uint32_t c = order[k];
 		nh_BodyPair p = bodies[c];
 		nh_Contact ct = contacts[c];
 		nh_contact_in ci = { ct.position[0], ct.position[1], ct.position[2], ct.penetration, ct.normal[0], ct.normal[1], ct.normal[2], ct.friction };
@@ -923,50 +959,49 @@ __global__ __launch_bounds__(256) void k_rows_general(const nh_DevState* __restr
 		nh_row r;
 		nh_build_row(ci, nh_make3(ta.position[0], ta.position[1], ta.position[2]), nh_make3(tb.position[0], tb.position[1], tb.position[2]),
 		             IA, IB, props[p.a].mass_inverse, props[p.b].mass_inverse, r);
-		store_row(rows, c, r);
+		store_row_soa(rows4, stride, k, r);
+		gpair[k] = make_uint2(p.a, p.b);
 	}
 }
 
 template<bool WARM>
 __global__ __launch_bounds__(256) void k_level_exec(const uint32_t* __restrict__ order, uint32_t begin, uint32_t end,
-                                                    const nh_BodyPair* __restrict__ bodies, const nh_CachedContactImpulse* __restrict__ cached,
-                                                    const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
-                                                    const float* __restrict__ rows, float4* __restrict__ states) {
+                                                    const uint2* __restrict__ gpair, const nh_CachedContactImpulse* __restrict__ cached,
+                                                    nh_BodyMomentum* __restrict__ momentum,
+                                                    const float4* __restrict__ rows4, size_t stride, float4* __restrict__ gstates) {
 	for (uint32_t k = begin + blockIdx.x * blockDim.x + threadIdx.x; k < end; k += gridDim.x * blockDim.x) {
-		uint32_t c = order[k];
-		nh_BodyPair p = bodies[c];
-		nh_vel a = load_vel(momentum, props, p.a), b = load_vel(momentum, props, p.b);
+		const uint2 p = gpair[k];
+		nh_vel a = load_vel_m(momentum, p.x), b = load_vel_m(momentum, p.y);
 		nh_row r;
-		load_row(rows, c, r);
+		load_row_soa(rows4, stride, k, r);
 		nh_state s;
 		if (WARM) {
-			nh_CachedContactImpulse w = cached[c];
-			nh_warm_start(r, w.impulse[0], w.impulse[1], w.impulse[2], a, b, s);
+			const float4 w = *reinterpret_cast<const float4*>(cached + order[k]);
+			nh_warm_start(r, w.x, w.y, w.z, a, b, s);
 		} else {
-			float4 sv = states[c];
+			float4 sv = gstates[k];
 			s.normal = sv.x; s.friction_x = sv.y; s.friction_y = sv.z;
 			nh_apply_one(r, s, a, b);
 		}
-		states[c] = make_float4(s.normal, s.friction_x, s.friction_y, 0.0f);
-		if (p.a) store_vel(momentum, p.a, a);      // body 0 is the static world: never written
-		if (p.b) store_vel(momentum, p.b, b);
+		gstates[k] = make_float4(s.normal, s.friction_x, s.friction_y, 0.0f);
+		if (p.x) store_vel_m(momentum, p.x, a);      // body 0 is the static world: never written
+		if (p.y) store_vel_m(momentum, p.y, b);
 	}
 }
 
 // ---- update_cached_impulses (nudge.cpp:4857-4884) --------------------------------------------------------------------------------
 // (contacts on the one-body fast path export their impulse at the end of every nh_apply_impulses call)
-__global__ __launch_bounds__(256) void k_update_impulses(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ general_list, const float* __restrict__ rows, const float4* __restrict__ states, nh_CachedContactImpulse* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_update_impulses(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ order, const float4* __restrict__ rows4, size_t stride,
+                                                         const float4* __restrict__ gstates, nh_CachedContactImpulse* __restrict__ out) {
 	uint32_t n = st->general_contacts;
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-		uint32_t c = general_list[k];
 		nh_row r;
-		load_row(rows, c, r);
-		float4 sv = states[c];
+		load_row_soa(rows4, stride, k, r);
+		float4 sv = gstates[k];
 		nh_state s = { sv.x, sv.y, sv.z };
-		nh_CachedContactImpulse o;
-		nh_export_impulse(r, s, o.impulse[0], o.impulse[1], o.impulse[2]);
-		o.unused = 0.0f;
-		out[c] = o;
+		float ox, oy, oz;
+		nh_export_impulse(r, s, ox, oy, oz);
+		*reinterpret_cast<float4*>(out + order[k]) = make_float4(ox, oy, oz, 0.0f);
 	}
 }
 
@@ -1109,6 +1144,8 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	d->static_bodies = nh_arena_array<uint32_t>(memory, (size_t)3 * B, &err);
 	d->body_class = nh_arena_array<uint8_t>(memory, B, &err);
 	d->level_order = nh_arena_array<uint32_t>(memory, kcap, &err);
+	d->gpair = nh_arena_array<uint2>(memory, kcap, &err);
+	d->gstates = nh_arena_array<float4>(memory, kcap, &err);
 	uint32_t* cursor = d->body_off + (B + 2);
 	uint32_t* pred_a = nh_arena_array<uint32_t>(memory, kcap, &err);
 	uint32_t* pred_b = nh_arena_array<uint32_t>(memory, kcap, &err);
@@ -1162,7 +1199,6 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	if (c.general_contacts) {
 		const uint32_t G = c.general_contacts;
 		materialize_lookup(ctx, imp);
-		NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, general_list, contacts->data, contacts->bodies, bodies->transforms, bodies->properties, d->rows);
 		// relaxation: every round finalises at least the next level
 		uint32_t rounds = 0;
 		NH_LAUNCH(ctx, "level_reset", k_level_reset_progress, 1, 1, st);
@@ -1185,14 +1221,16 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 		NH_LAUNCH(ctx, "level_hist", k_level_hist, nh_grid_for(G, 256, 512), 256, st, general_list, level, level_hist);
 		NH_LAUNCH(ctx, "level_offsets", k_level_offsets, 1, 1024, level_hist, level_cursor);
 		NH_LAUNCH(ctx, "level_scatter", k_level_scatter, nh_grid_for(G, 256, 512), 256, st, general_list, level, level_cursor, d->level_order);
+		NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, d->level_order, contacts->data, contacts->bodies, bodies->transforms, bodies->properties,
+		          (float4*)d->rows, (size_t)kcap, d->gpair);
 		NH_HIP_CHECK(ctx, hipMemcpyAsync(d->level_off, level_hist, sizeof(uint32_t) * (d->levels + 2), hipMemcpyDeviceToHost, ctx->stream));
 		NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 		// warm start in level order (levels are numbered from 1)
 		for (uint32_t l = 1; l <= d->levels; ++l) {
 			uint32_t b = d->level_off[l], e = d->level_off[l + 1];
 			if (e > b)
-				NH_LAUNCH(ctx, "warm_level", (k_level_exec<true>), nh_grid_for(e - b, 256, 4096), 256, d->level_order, b, e, contacts->bodies, imp->data,
-				          bodies->properties, bodies->momentum, d->rows, (float4*)d->states);
+				NH_LAUNCH(ctx, "warm_level", (k_level_exec<true>), nh_grid_for(e - b, 256, 4096), 256, d->level_order, b, e, d->gpair, imp->data,
+				          bodies->momentum, (const float4*)d->rows, (size_t)kcap, d->gstates);
 		}
 	}
 	*out = d;
@@ -1253,8 +1291,8 @@ extern "C" int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* d, c
 			for (uint32_t l = 1; l <= d->levels; ++l) {
 				uint32_t b = d->level_off[l], e = d->level_off[l + 1];
 				if (e > b)
-					NH_LAUNCH(ctx, "apply_level", (k_level_exec<false>), nh_grid_for(e - b, 256, 4096), 256, d->level_order, b, e, d->bodies, (const nh_CachedContactImpulse*)nullptr,
-					          bodies->properties, bodies->momentum, d->rows, (float4*)d->states);
+					NH_LAUNCH(ctx, "apply_level", (k_level_exec<false>), nh_grid_for(e - b, 256, 4096), 256, d->level_order, b, e, d->gpair, (const nh_CachedContactImpulse*)nullptr,
+					          bodies->momentum, (const float4*)d->rows, (size_t)d->contact_capacity, d->gstates);
 			}
 	}
 	return NH_OK;
@@ -1264,7 +1302,8 @@ extern "C" int nh_update_cached_impulses(nh_context* ctx, nh_ContactConstraintDa
 	if (!ctx || !d || !imp) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	if (d->general_contacts)
-		NH_LAUNCH(ctx, "update_impulses", k_update_impulses, nh_grid_for(d->general_contacts, 256, 4096), 256, ctx->d_state, d->general_list, d->rows, (const float4*)d->states, imp->data);
+		NH_LAUNCH(ctx, "update_impulses", k_update_impulses, nh_grid_for(d->general_contacts, 256, 4096), 256, ctx->d_state, d->level_order, (const float4*)d->rows, (size_t)d->contact_capacity,
+		          (const float4*)d->gstates, imp->data);
 	return NH_OK;
 }
 
