@@ -21,9 +21,9 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
                                                const nh_Transform* __restrict__ box_xf, const nh_BoxCollider* __restrict__ box_data, const uint32_t* __restrict__ box_tags, uint32_t nbox,
                                                const nh_Transform* __restrict__ sph_xf, const nh_SphereCollider* __restrict__ sph_data, const uint32_t* __restrict__ sph_tags, uint32_t nsph,
                                                nh_xform* __restrict__ xf, float4* __restrict__ aabb_min, float4* __restrict__ aabb_max, uint32_t* __restrict__ ctag) {
-	__shared__ uint32_t hist[256];
+	__shared__ uint32_t hist[1024];
 	__shared__ uint32_t red[12];
-	if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+	hist[threadIdx.x] = 0;
 	if (threadIdx.x < 3) { red[threadIdx.x] = 0xffffffffu; red[3 + threadIdx.x] = 0u; red[6 + threadIdx.x] = 0xffffffffu; red[9 + threadIdx.x] = 0u; }
 	__syncthreads();
 	uint32_t n = nbox + nsph;
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 		f = nh_float_flip(mny); lmin[1] = min(lmin[1], f); lmax[1] = max(lmax[1], f);
 		f = nh_float_flip(mnz); lmin[2] = min(lmin[2], f); lmax[2] = max(lmax[2], f);
 		// exponent histogram: one LDS atomic per distinct exponent in the wave (usually 2-3), not one per lane
-		uint32_t ebin = (__float_as_uint(ext) >> 23) & 255u;
+		uint32_t ebin = (__float_as_uint(ext) >> 21) & 1023u;          // size class: exponent + two mantissa bits (quarter octaves)
 		if (ebin <= guess_exp && ext == ext) {
 			f = nh_float_flip(mnx); gmn[0] = min(gmn[0], f); gmx[0] = max(gmx[0], f);
 			f = nh_float_flip(mny); gmn[1] = min(gmn[1], f); gmx[1] = max(gmx[1], f);
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 		if ((threadIdx.x & 63) == 0) { atomicMin(&red[k], lmin[k]); atomicMax(&red[3 + k], lmax[k]); atomicMin(&red[6 + k], gmn[k]); atomicMax(&red[9 + k], gmx[k]); }
 	}
 	__syncthreads();
-	if (threadIdx.x < 256 && hist[threadIdx.x]) atomicAdd(&st->exp_hist[threadIdx.x], hist[threadIdx.x]);
+	if (hist[threadIdx.x]) atomicAdd(&st->exp_hist[threadIdx.x], hist[threadIdx.x]);
 	if (threadIdx.x < 3) {
 		atomicMin(&st->smin[threadIdx.x], red[threadIdx.x]); atomicMax(&st->smax[threadIdx.x], red[3 + threadIdx.x]);
 		if (red[6 + threadIdx.x] <= red[9 + threadIdx.x]) { atomicMin(&st->gmin[threadIdx.x], red[6 + threadIdx.x]); atomicMax(&st->gmax[threadIdx.x], red[9 + threadIdx.x]); }
@@ -99,6 +99,9 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 
 // ---- 2. grid parameters (single thread; a few hundred instructions) ------------------------------------
 __global__ void k_grid_params(nh_DevState* st, uint32_t ncolliders, uint32_t max_cells) {
+	__shared__ uint32_t s_hist[1024];
+	for (uint32_t k = threadIdx.x; k < 1024u; k += blockDim.x) s_hist[k] = st->exp_hist[k];       // one round of loads, then a scan out of LDS
+	__syncthreads();
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
 	nh_f3 smin = nh_make3(nh_float_unflip(st->smin[0]), nh_float_unflip(st->smin[1]), nh_float_unflip(st->smin[2]));
 	nh_f3 smax = nh_make3(nh_float_unflip(st->smax[0]), nh_float_unflip(st->smax[1]), nh_float_unflip(st->smax[2]));
@@ -109,11 +112,11 @@ __global__ void k_grid_params(nh_DevState* st, uint32_t ncolliders, uint32_t max
 	// small/large split: allow at most max(64, C/1024) colliders above the grid's cell size
 	uint32_t budget = ncolliders / 1024u; if (budget < 64u) budget = 64u;
 	uint32_t above = 0;
-	int e = 255;
-	while (e > 0) { uint32_t h = st->exp_hist[e]; if (above + h > budget) break; above += h; --e; }
-	// e = largest exponent kept "small"; never let the cell underflow to denormals
-	if (e < 64) e = 64;
-	if (e > 190) e = 190;
+	int e = 1023;
+	while (e > 0) { uint32_t h = s_hist[e]; if (above + h > budget) break; above += h; --e; }
+	// e = largest size class (exponent << 2 | two mantissa bits) kept "small"; never let the cell underflow to denormals
+	if (e < (64 << 2)) e = 64 << 2;
+	if (e > (190 << 2)) e = 190 << 2;
 	// k_xform gathered the small colliders' bounds under last step's split: good if the split has not moved
 	if (st->small_exp != (uint32_t)e) {
 		st->redo_small = 1;
@@ -122,7 +125,7 @@ __global__ void k_grid_params(nh_DevState* st, uint32_t ncolliders, uint32_t max
 		st->redo_small = 0;
 	}
 	st->small_exp = (uint32_t)e;
-	float cell = __uint_as_float((uint32_t)(e + 1) << 23);     // 2^(e+1-127) > every small extent
+	float cell = __uint_as_float((uint32_t)(e + 1) << 21);     // upper edge of the class: > every small extent, at most 25 % above the largest
 	st->cell_inv = 1.0f / cell;
 }
 
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256) void k_small_bounds(nh_DevState* __restrict__ 
 	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
 		float4 mn = aabb_min[c];
 		float ext = aabb_max[c].w;
-		uint32_t e = (__float_as_uint(ext) >> 23) & 255u;
+		uint32_t e = (__float_as_uint(ext) >> 21) & 1023u;
 		if (e <= small_exp && ext == ext) {
 			uint32_t f;
 			f = nh_float_flip(mn.x); lmin[0] = min(lmin[0], f); lmax[0] = max(lmax[0], f);
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void k_cell_keys(nh_DevState* __restrict__ st,
 			mkey[c] = nh_morton_of(nh_make3(mn.x, mn.y, mn.z), mscale, mmin);
 			int cx0 = cell_coord(mn.x, ox, inv), cy0 = cell_coord(mn.y, oy, inv), cz0 = cell_coord(mn.z, oz, inv);
 			int cx1 = cell_coord(mx.x, ox, inv), cy1 = cell_coord(mx.y, oy, inv), cz1 = cell_coord(mx.z, oz, inv);
-			uint32_t e = (__float_as_uint(mx.w) >> 23) & 255u;
+			uint32_t e = (__float_as_uint(mx.w) >> 21) & 1023u;
 			// "small" = spans at most 2 cells per axis in THIS arithmetic (makes the neighbour search exact)
 			large = e > small_exp || (cx1 - cx0) > 1 || (cy1 - cy0) > 1 || (cz1 - cz0) > 1 || !(mx.w == mx.w);
 			uint32_t key = NH_LARGE_KEY;
@@ -532,7 +535,8 @@ __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t 
 	}
 }
 
-__global__ __launch_bounds__(256) void k_uf_union_records(const nh_DevState* __restrict__ st, const nh_Record* __restrict__ rec, uint32_t* __restrict__ parent) {
+__global__ __launch_bounds__(256) void k_uf_union_records(const nh_DevState* __restrict__ st, const nh_Record* __restrict__ rec, uint32_t* __restrict__ parent, uint32_t parity) {
+	if (!st->any_idle[parity]) return;          // nobody sleeps: every set is active, no need to know the sets
 	uint32_t n = st->records;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		nh_Record r = rec[i];
@@ -540,7 +544,8 @@ __global__ __launch_bounds__(256) void k_uf_union_records(const nh_DevState* __r
 	}
 }
 
-__global__ __launch_bounds__(256) void k_uf_union_connections(const nh_BodyPair* __restrict__ con, uint32_t ncon, uint32_t* __restrict__ parent) {
+__global__ __launch_bounds__(256) void k_uf_union_connections(const nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ con, uint32_t ncon, uint32_t* __restrict__ parent, uint32_t parity) {
+	if (!st->any_idle[parity]) return;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ncon; i += gridDim.x * blockDim.x) {
 		nh_BodyPair p = con[i];
 		if (p.a && p.b) uf_union(parent, p.a, p.b);                          // nudge.cpp:3799-3807
@@ -695,8 +700,15 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 }
 
 // counters, bounds, and the union-find / island arrays (parent[i] = i, nothing active yet)
-__global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t ncolliders, uint32_t nbodies, uint32_t* __restrict__ parent, uint32_t* __restrict__ set_active, uint32_t* __restrict__ deg) {
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) { parent[i] = i; set_active[i] = 0; }
+// Also notes whether ANY body is asleep (idle counter saturated): if none is, every island is active whatever its shape and the
+// union-find over the contact records -- expensive when millions of bodies form one island -- is skipped.  The flag is double
+// buffered by step parity: this step's launch sets any_idle[parity] with plain stores and clears the other one for the next step.
+__global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t ncolliders, uint32_t nbodies, uint32_t* __restrict__ parent, uint32_t* __restrict__ set_active, uint32_t* __restrict__ deg,
+                                                       const uint8_t* __restrict__ idle, uint32_t parity) {
+	bool asleep = false;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) { parent[i] = i; set_active[i] = 0; asleep |= i >= 1 && idle[i] == 0xff; }
+	if (asleep) st->any_idle[parity] = 1;
+	if (blockIdx.x == 0 && threadIdx.x == 0) st->any_idle[parity ^ 1u] = 0;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < 2u * (nbodies + 2u); i += gridDim.x * blockDim.x) deg[i] = 0;      // degrees + fill cursors
 	if (blockIdx.x != 0) return;
 	uint32_t t = threadIdx.x;
@@ -706,7 +718,7 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 		st->static_bodies = 0; st->unleveled = 0; st->has_static8 = 0; st->has_staticN = 0; st->any_sleeping = 0;
 		for (int k = 0; k < 3; ++k) { st->smin[k] = 0xffffffffu; st->smax[k] = 0u; st->gmin[k] = 0xffffffffu; st->gmax[k] = 0u; }
 	}
-	st->exp_hist[t] = 0;
+	for (uint32_t k = t; k < 1024u; k += blockDim.x) st->exp_hist[k] = 0;
 }
 
 __global__ void k_collide_end(nh_DevState* st, uint32_t sleeping_cap) {
@@ -720,6 +732,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	if (!ctx || !active_bodies || !contacts || !bodies || !colliders) return NH_ERR_INVALID;
 	NH_HIP_CHECK(ctx, hipSetDevice(ctx->device));
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	ctx->step_parity ^= 1u;
 	nh_DevState* st = ctx->d_state;
 	const uint32_t nbox = colliders->boxes.count, nsph = colliders->spheres.count;
 	const uint32_t C = nbox + nsph;
@@ -782,7 +795,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->deg, sizeof(uint32_t) * 2u * ((size_t)B + 2u)));
 		ctx->deg_capacity = 2u * (B + 2u);
 	}
-	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, nh_grid_for(B, 256, 2048), 256, st, C, B, parent, set_active, ctx->deg);
+	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, nh_grid_for(B, 256, 2048), 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity);
 	if (C) {
 		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 1024, 256), 1024, st, bodies->transforms,
 		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
@@ -805,7 +818,9 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	}
 	// islands over contact records (+ user connections): a chain of small kernels that the tag sort of the records does not depend
 	// on -- it runs on the side stream while the caller's stream sorts (fork here, join before k_sorted_counts)
-	const bool fork = ctx->side != nullptr;
+	// (only while the side chain is small: the radix passes spin-wait on each other and must not share the machine with a long
+	// kernel -- with millions of records in one island the union-find alone takes a millisecond)
+	const bool fork = ctx->side != nullptr && ctx->h_state->records <= 1500000u;
 	hipStream_t main_stream = ctx->stream;
 	if (fork) {
 		NH_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, main_stream));
@@ -813,8 +828,8 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		ctx->stream = ctx->side;
 	}
 	if (body_connections && body_connections->count)
-		NH_LAUNCH(ctx, "uf_union_connections", k_uf_union_connections, nh_grid_for(body_connections->count, 256, 2048), 256, body_connections->data, body_connections->count, parent);
-	NH_LAUNCH(ctx, "uf_union_records", k_uf_union_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, parent);
+		NH_LAUNCH(ctx, "uf_union_connections", k_uf_union_connections, nh_grid_for(body_connections->count, 256, 2048), 256, st, body_connections->data, body_connections->count, parent, ctx->step_parity);
+	NH_LAUNCH(ctx, "uf_union_records", k_uf_union_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, parent, ctx->step_parity);
 	NH_LAUNCH(ctx, "uf_flatten", k_uf_flatten, nh_grid_for(B, 256, 2048), 256, B, parent, bodies->idle_counters, set_active, root_of);
 	NH_LAUNCH(ctx, "active_flags", k_active_flags, nh_grid_for(B, 256, 2048), 256, B, root_of, set_active, flags);
 	{

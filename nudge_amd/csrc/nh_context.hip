@@ -21,6 +21,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->hint_capacity = 0;
 	ctx->deg = nullptr;
 	ctx->deg_capacity = 0;
+	ctx->step_parity = 0;
 	ctx->d_state = nullptr;
 	ctx->h_state = nullptr;
 	if (hipMalloc((void**)&ctx->d_state, sizeof(nh_DevState)) != hipSuccess) { delete ctx; return NH_ERR_HIP; }

@@ -54,9 +54,10 @@ struct nh_DevState {
 	float cell_inv;               // 1 / cell size (cell size is a power of two)
 	float origin[3];
 	uint32_t dims[3];
-	uint32_t small_exp;           // colliders whose max-extent exponent is <= small_exp go to the grid (kept across steps: next step's guess)
+	uint32_t small_exp;           // colliders whose size class (extent bits >> 21: exponent + 2 mantissa bits) is <= this go to the grid (kept across steps: next step's guess)
 	uint32_t redo_small;          // the guess was wrong: k_small_bounds recomputes gmin/gmax
-	uint32_t exp_hist[256];
+	uint32_t exp_hist[1024];      // histogram of size classes
+	uint32_t any_idle[2];         // by step parity: some body's idle counter is saturated (asleep)
 };
 
 struct nh_TimerSlot { const char* name; hipEvent_t a, b; };
@@ -91,6 +92,7 @@ struct nh_context {
 	// per-body contact degree (filled by nh_collide's contact gather, turned into CSR offsets by setup) + fill cursors: 2 x (B + 2) words
 	uint32_t* deg;
 	uint32_t deg_capacity;
+	uint32_t step_parity;
 	// fork/join inside one entry point: independent kernel chains run on `side` while the caller's stream does the long one
 	hipStream_t side;
 	hipEvent_t ev_fork, ev_join;
