@@ -99,8 +99,25 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 
 // ---- 2. grid parameters (single thread; a few hundred instructions) ------------------------------------
 __global__ void k_grid_params(nh_DevState* st, uint32_t ncolliders, uint32_t max_cells) {
-	__shared__ uint32_t s_hist[1024];
-	for (uint32_t k = threadIdx.x; k < 1024u; k += blockDim.x) s_hist[k] = st->exp_hist[k];       // one round of loads, then a scan out of LDS
+	// small/large split: allow at most max(64, C/1024) colliders above the grid's cell size.  e = largest size class kept small =
+	// the highest class whose suffix count (colliders in classes >= e) exceeds the budget.  One wave: lane l owns classes 16l..16l+15.
+	__shared__ int s_e;
+	const uint32_t budget = max(ncolliders / 1024u, 64u);
+	const uint32_t lane = threadIdx.x & 63u;
+	uint32_t h[16], mine = 0;
+#pragma unroll
+	for (int k = 0; k < 16; ++k) { h[k] = st->exp_hist[16u * lane + k]; mine += h[k]; }
+	uint32_t suffix = mine;                                    // inclusive suffix sum over lanes >= l
+	for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_down(suffix, d); if (lane + d < 64u) suffix += y; }
+	const unsigned long long over = __ballot(suffix > budget);
+	if (threadIdx.x == 0) s_e = 0;
+	__syncthreads();
+	if (over && lane == 63u - (uint32_t)__clzll(over)) {       // highest lane whose suffix exceeds the budget: the class is in its range
+		uint32_t above = suffix - mine;
+		int e = (int)(16u * lane + 15u);
+		while (e > (int)(16u * lane) && above + h[e - (int)(16u * lane)] <= budget) { above += h[e - (int)(16u * lane)]; --e; }
+		s_e = e;
+	}
 	__syncthreads();
 	if (threadIdx.x != 0 || blockIdx.x != 0) return;
 	nh_f3 smin = nh_make3(nh_float_unflip(st->smin[0]), nh_float_unflip(st->smin[1]), nh_float_unflip(st->smin[2]));
@@ -109,11 +126,7 @@ __global__ void k_grid_params(nh_DevState* st, uint32_t ncolliders, uint32_t max
 	float scale = nh_morton_scale(smin, smax);
 	st->morton_scale = scale;
 	st->morton_min[0] = smin.x * scale; st->morton_min[1] = smin.y * scale; st->morton_min[2] = smin.z * scale;
-	// small/large split: allow at most max(64, C/1024) colliders above the grid's cell size
-	uint32_t budget = ncolliders / 1024u; if (budget < 64u) budget = 64u;
-	uint32_t above = 0;
-	int e = 1023;
-	while (e > 0) { uint32_t h = s_hist[e]; if (above + h > budget) break; above += h; --e; }
+	int e = s_e;
 	// e = largest size class (exponent << 2 | two mantissa bits) kept "small"; never let the cell underflow to denormals
 	if (e < (64 << 2)) e = 64 << 2;
 	if (e > (190 << 2)) e = 190 << 2;
