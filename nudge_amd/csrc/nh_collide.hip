@@ -315,9 +315,7 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 	const float inv = st->cell_inv;
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
-	const uint32_t nlarge = (pair_cap & 0x80000000u) ? 0u : st->large;
-	const bool dbg_skip_grid = (pair_cap & 0x40000000u) != 0;
-	pair_cap &= 0x3fffffffu;
+	const uint32_t nlarge = st->large;
 	__shared__ uint2 wave_buf[4][FP_WBUF];
 	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u };
 	uint32_t rounded = (n + 63u) & ~63u;
@@ -327,7 +325,7 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 		uint32_t key = NH_LARGE_KEY, ca = 0, abody = 0;
 		uint64_t ka = 0;
 		if (valid) { amin = smin[i]; amax = smax[i]; key = keys[i]; ca = __float_as_uint(amax.w); abody = __float_as_uint(amin.w); ka = smk[i]; }
-		bool small = valid && key != NH_LARGE_KEY && !dbg_skip_grid;
+		bool small = valid && key != NH_LARGE_KEY;
 		// neighbour cells [c_min-1, c_max] per axis, clamped
 		int x0 = 0, x1 = -1, y0 = 0, y1 = -1, z0 = 0, z1 = -1;
 		if (small) {
@@ -520,10 +518,6 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 }
 
 // ---- 7. islands (lock-free union-find), active bodies, sleeping -------------------------------------------
-__global__ __launch_bounds__(256) void k_uf_init(uint32_t nbodies, uint32_t* __restrict__ parent, uint32_t* __restrict__ set_active) {
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) { parent[i] = i; set_active[i] = 0; }
-}
-
 // find with path halving: every visited node is re-pointed at its grandparent (an ancestor stays an ancestor whatever other
 // lanes do, and parent[x] <= x is preserved), so the long chains of one big island (ball pit) collapse as they are walked
 __device__ __forceinline__ uint32_t uf_find(uint32_t* parent, uint32_t x) {
@@ -734,10 +728,6 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 	for (uint32_t k = t; k < 1024u; k += blockDim.x) st->exp_hist[k] = 0;
 }
 
-__global__ void k_collide_end(nh_DevState* st, uint32_t sleeping_cap) {
-	if (st->sleeping > sleeping_cap) { st->sleeping = sleeping_cap; st->error = NH_ERR_CONTACT_CAPACITY; }
-}
-
 // =================================================================================================================
 extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_ContactData* contacts,
                           const nh_BodyData* bodies, const nh_ColliderData* colliders,
@@ -824,7 +814,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_HIP_CHECK(ctx, hipMemsetAsync(cells, 0, sizeof(uint2) * (size_t)max_cells, s));
 		if (ctx->timing) nh_timer_end(ctx);
 		NH_LAUNCH(ctx, "cell_bounds", k_cell_bounds, nh_grid_for(C, 256, 2048), 256, C, keys_a, vals_a, aabb_min, aabb_max, cells, smin, smax, mkey, smk);
-		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 1024), 256, st, C, keys_a, smin, smax, cells, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap | (getenv("NH_DBG_SKIP_LARGE") ? 0x80000000u : 0u) | (getenv("NH_DBG_SKIP_GRID") ? 0x40000000u : 0u));
+		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 1024), 256, st, C, keys_a, smin, smax, cells, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap);
 		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, 2048, 256, st, smin, smax, cells, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap);
 		NH_LAUNCH(ctx, "narrowphase", k_narrowphase, nh_grid_for(pair_cap, 256, 4096), 256, st, pairs, xf, ctag,
 		          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a);

@@ -140,17 +140,6 @@ __device__ __forceinline__ uint32_t run_length(const uint64_t* __restrict__ tags
 	return len;
 }
 
-__global__ __launch_bounds__(256) void k_degree(const nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, const uint64_t* __restrict__ tags, uint32_t* __restrict__ deg) {
-	uint32_t n = st->contacts;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		uint32_t len = run_length(tags, i, n);
-		if (!len) continue;
-		nh_BodyPair p = bodies[i];
-		if (p.a) atomicAdd(&deg[p.a], len);
-		if (p.b) atomicAdd(&deg[p.b], len);
-	}
-}
-
 __global__ __launch_bounds__(256) void k_adj_fill(const nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, const uint64_t* __restrict__ tags, const uint32_t* __restrict__ off,
                                                   uint32_t* __restrict__ cursor, uint32_t* __restrict__ adj) {
 	uint32_t n = st->contacts;

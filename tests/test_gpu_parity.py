@@ -316,3 +316,30 @@ def test_setup_without_apply_and_zero_iterations(name, warm):
             assert ca["count"] == cb["count"]
             assert P.bits_equal(ca["data"]["impulse"], cb["data"]["impulse"]), pattern
         w.close()
+
+
+# ---- BodyConnections (nudge.h:108-111): user constraints join islands (nudge.cpp:3799-3807) ----------------------------------
+@needs_ref
+def test_body_connections_join_islands():
+    """Connected bodies sleep and wake together: a chain of connections ties resting boxes to one that keeps spinning, so the
+    active list, idle counters and sleeping pairs differ from the unconnected world -- and match the reference bit for bit."""
+    scene, _ = G.build("grid30")
+    n = len(scene["body_transforms"]) - 1
+    chain = np.arange(1, 121, dtype=np.uint32)
+    scene["connections"] = np.stack([chain[:-1], chain[1:]], axis=1)
+    scene["body_momentum"]["angular_velocity"][1] = (0.0, 40.0, 0.0)          # body 1 spins on for a long time
+    plain = dict(scene); plain["connections"] = np.zeros((0, 2), np.uint32)
+    w = E.World(scene, flags=E.NH_FLAG_SYNC_COUNTS | E.NH_FLAG_EXACT_ORDER)
+    w0 = E.World(plain, flags=E.NH_FLAG_SYNC_COUNTS | E.NH_FLAG_EXACT_ORDER)
+    ref = refworld.RefWorld(scene)
+    differed = False
+    for steps in (200, 150, 100):
+        w.step(steps); w0.step(steps); ref.step(steps)
+        a, b = w.get_bodies(), ref.bodies()
+        assert P.bits_equal(a["transforms"], b["transforms"])
+        assert P.bits_equal(a["momentum"]["velocity"], b["momentum"]["velocity"])
+        assert np.array_equal(a["idle"], b["idle"])
+        assert np.array_equal(w.get_active(), ref.active().astype(np.uint32))
+        differed |= len(w.get_active()) != len(w0.get_active())
+    assert differed, "the connections were meant to keep part of the grid awake"
+    w.close(); w0.close()
