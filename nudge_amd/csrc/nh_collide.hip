@@ -623,8 +623,10 @@ __global__ __launch_bounds__(256) void k_sorted_counts(const nh_DevState* __rest
 __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict__ st, const uint32_t* __restrict__ rec_idx, const nh_Record* __restrict__ rec, const uint64_t* __restrict__ rec_key_sorted,
                                                          const uint32_t* __restrict__ starts, const nh_Contact* __restrict__ raw_data, const uint32_t* __restrict__ raw_feature,
                                                          nh_Contact* __restrict__ data, nh_BodyPair* __restrict__ bodies, uint64_t* __restrict__ tags, uint32_t* __restrict__ features, uint32_t capacity, uint32_t pair_cap,
-                                                         const uint32_t* __restrict__ sleep_scan, uint64_t* __restrict__ sleeping_pairs, uint32_t* __restrict__ deg) {
+                                                         const uint32_t* __restrict__ sleep_scan, uint64_t* __restrict__ sleeping_pairs, uint32_t* __restrict__ deg, uint32_t nbodies) {
 	__shared__ uint32_t s_src[4][1024];
+	uint32_t* __restrict__ info = deg + 2u * (nbodies + 2u);
+	uint32_t* __restrict__ first_contact = deg + 3u * (nbodies + 2u);
 	__shared__ uint32_t s_feat[4][1024];
 	__shared__ uint8_t s_own[4][1024];
 	const uint32_t nrec = st->records;
@@ -651,7 +653,11 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 			body_a = r.body_a; body_b = r.body_b;
 			base4 = 4u * ri; baseo = 4u * pair_cap + r.overflow;
 			// contact degree of the two bodies (body 0 is the static world): the solver's adjacency starts from these
-			if (cnt && start + cnt <= capacity) { if (body_a) atomicAdd(&deg[body_a], cnt); if (body_b) atomicAdd(&deg[body_b], cnt); }
+			// and what lets setup skip the general CSR build for a body that sits in ONE pair with the static world: its contacts are start .. start+cnt-1
+			if (cnt && start + cnt <= capacity) {
+				if (body_a) { atomicAdd(&deg[body_a], cnt); atomicAdd(&info[body_a], body_b ? 0x10001u : 1u); first_contact[body_a] = start; }
+				if (body_b) { atomicAdd(&deg[body_b], cnt); atomicAdd(&info[body_b], body_a ? 0x10001u : 1u); first_contact[body_b] = start; }
+			}
 		}
 		const uint32_t base = __shfl(start, 0);                  // lane 0 is always a valid record here
 		{
@@ -716,13 +722,13 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) { parent[i] = i; set_active[i] = 0; asleep |= i >= 1 && idle[i] == 0xff; }
 	if (asleep) st->any_idle[parity] = 1;
 	if (blockIdx.x == 0 && threadIdx.x == 0) st->any_idle[parity ^ 1u] = 0;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < 2u * (nbodies + 2u); i += gridDim.x * blockDim.x) deg[i] = 0;      // degrees + fill cursors
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < 3u * (nbodies + 2u); i += gridDim.x * blockDim.x) deg[i] = 0;      // degrees, fill cursors, pair info
 	if (blockIdx.x != 0) return;
 	uint32_t t = threadIdx.x;
 	if (t == 0) {
 		st->colliders = ncolliders; st->pairs = 0; st->raw_contacts = 0; st->records = 0; st->contacts = 0; st->sleeping = 0;
 		st->active = 0; st->culled = 0; st->large = 0; st->general_contacts = 0; st->levels = 0; st->error = 0;
-		st->static_bodies = 0; st->unleveled = 0; st->has_static8 = 0; st->has_staticN = 0; st->any_sleeping = 0;
+		st->static_bodies = 0; st->unleveled = 0; st->has_static8 = 0; st->has_staticN = 0; st->any_sleeping = 0; st->has_pending = 0;
 		for (int k = 0; k < 3; ++k) { st->smin[k] = 0xffffffffu; st->smax[k] = 0u; st->gmin[k] = 0xffffffffu; st->gmax[k] = 0u; }
 	}
 	for (uint32_t k = t; k < 1024u; k += blockDim.x) st->exp_hist[k] = 0;
@@ -791,12 +797,13 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	if (err) return err;
 
 	hipStream_t s = ctx->stream;
-	if (ctx->deg_capacity < 2u * (B + 2u)) {
-		// library-owned: per-body contact degrees, counted while the contacts are laid out and consumed by nh_setup_contact_constraints
+	if (ctx->deg_capacity < 4u * (B + 2u)) {
+		// library-owned, 4 x (B + 2) words: per body the contact degree, a fill cursor, the pair info (collider pairs it is in | pairs with a
+		// dynamic partner << 16) and the first contact of its last pair -- written while the contacts are laid out, consumed by setup
 		if (ctx->deg) NH_HIP_CHECK(ctx, hipFree(ctx->deg));
 		ctx->deg = nullptr; ctx->deg_capacity = 0;
-		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->deg, sizeof(uint32_t) * 2u * ((size_t)B + 2u)));
-		ctx->deg_capacity = 2u * (B + 2u);
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->deg, sizeof(uint32_t) * 4u * ((size_t)B + 2u)));
+		ctx->deg_capacity = 4u * (B + 2u);
 	}
 	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, nh_grid_for(B, 256, 2048), 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity);
 	if (C) {
@@ -869,7 +876,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	// contact starts and sleeping-pair slots: two scans over the sorted records in one pair of launches
 	nh_scan2_u32(ctx, rec_counts, rec_counts, &st->contacts, sleep_flags, sleep_flags, &st->sleeping, &st->records, 1, scan_tmp);
 	NH_LAUNCH(ctx, "gather_contacts", k_gather_contacts, nh_grid_for(pair_cap, 256, 8192), 256, st, rec_idx_a, rec, rec_key_a, rec_counts, raw_data, raw_feature,
-	          contacts->data, contacts->bodies, contacts->tags, contacts->features, cap, pair_cap, sleep_flags, contacts->sleeping_pairs, ctx->deg);
+	          contacts->data, contacts->bodies, contacts->tags, contacts->features, cap, pair_cap, sleep_flags, contacts->sleeping_pairs, ctx->deg, B);
 
 	if (ctx->flags & NH_FLAG_SYNC_COUNTS) {
 		nh_Counts c;

@@ -57,6 +57,7 @@ struct nh_DevState {
 	uint32_t small_exp;           // colliders whose size class (extent bits >> 21: exponent + 2 mantissa bits) is <= this go to the grid (kept across steps: next step's guess)
 	uint32_t redo_small;          // the guess was wrong: k_small_bounds recomputes gmin/gmax
 	uint32_t exp_hist[1024];      // histogram of size classes
+	uint32_t has_pending;         // some body needs the general adjacency build (k_adj_simple could not settle it)
 	uint32_t any_idle[2];         // by step parity: some body's idle counter is saturated (asleep)
 };
 

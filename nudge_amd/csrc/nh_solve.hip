@@ -25,6 +25,7 @@
 #define NH_CLS_STATIC8 2u
 #define NH_CLS_STATICN 3u
 #define NH_CLS_GENERAL 4u
+#define NH_CLS_PENDING 0xFFu         // k_adj_simple could not settle it: k_adj_fill / k_adj_sort do
 #define NH_UNSET 0xFFFFFFFFu
 
 __device__ __forceinline__ bool tag_less(uint64_t ta, uint32_t fa, uint64_t tb, uint32_t fb) { return ta < tb || (ta == tb && fa < fb); }
@@ -140,15 +141,17 @@ __device__ __forceinline__ uint32_t run_length(const uint64_t* __restrict__ tags
 	return len;
 }
 
+// general CSR fill, only for the bodies k_adj_simple left pending (several pairs, or a dynamic partner)
 __global__ __launch_bounds__(256) void k_adj_fill(const nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, const uint64_t* __restrict__ tags, const uint32_t* __restrict__ off,
-                                                  uint32_t* __restrict__ cursor, uint32_t* __restrict__ adj) {
+                                                  uint32_t* __restrict__ cursor, uint32_t* __restrict__ adj, const uint8_t* __restrict__ body_class) {
+	if (!st->has_pending) return;
 	uint32_t n = st->contacts;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		uint32_t len = run_length(tags, i, n);
 		if (!len) continue;
 		nh_BodyPair p = bodies[i];
-		if (p.a) { uint32_t base = off[p.a] + atomicAdd(&cursor[p.a], len); for (uint32_t k = 0; k < len; ++k) adj[base + k] = i + k; }
-		if (p.b) { uint32_t base = off[p.b] + atomicAdd(&cursor[p.b], len); for (uint32_t k = 0; k < len; ++k) adj[base + k] = i + k; }
+		if (p.a && body_class[p.a] == NH_CLS_PENDING) { uint32_t base = off[p.a] + atomicAdd(&cursor[p.a], len); for (uint32_t k = 0; k < len; ++k) adj[base + k] = i + k; }
+		if (p.b && body_class[p.b] == NH_CLS_PENDING) { uint32_t base = off[p.b] + atomicAdd(&cursor[p.b], len); for (uint32_t k = 0; k < len; ++k) adj[base + k] = i + k; }
 	}
 }
 
@@ -158,15 +161,65 @@ __device__ __forceinline__ uint32_t slot_key_of(uint32_t i, const uint32_t* __re
 	return slot_key ? slot_key[i] : ((i >> 7) * 16u + (i & 15u));
 }
 
+// One lane per body.  A body that sits in exactly ONE collider pair, with the static world, and has <= 8 contacts -- the box on the
+// ground -- needs no CSR build: its contacts are first .. first+d-1 (a pair's contacts are adjacent in tag order), written here in
+// slot order.  Everything else is left PENDING for the general k_adj_fill / k_adj_sort, which do not even start when nothing is pending.
+__global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st, uint32_t nbodies, const uint32_t* __restrict__ off, const uint32_t* __restrict__ info,
+                                                    const uint32_t* __restrict__ first_contact, uint32_t* __restrict__ adj, const uint32_t* __restrict__ slot_key,
+                                                    uint8_t* __restrict__ body_class, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum) {
+	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < nbodies; x += gridDim.x * blockDim.x) {
+		if (x == 0) {
+			body_class[0] = 0;
+			momentum[0].unused0 = props[0].mass_inverse;             // the reference stashes mass_inverse in unused0 of EVERY body (nudge.cpp:4198)
+			const nh_BodyMomentum m0 = momentum[0];
+			const nh_BodyProperties p0 = props[0];
+			st->static_inert = nh_is_inert(m0.velocity, m0.angular_velocity, p0.inertia_inverse, p0.mass_inverse) ? 1u : 0u;
+			continue;
+		}
+		const uint32_t b = off[x], d = off[x + 1] - b;
+		uint32_t cls = NH_CLS_NONE;
+		if (d) {
+			const uint32_t inf = info[x];
+			if ((inf & 0xFFFFu) == 1u && (inf >> 16) == 0u && d <= 8u) {
+				const uint32_t f = first_contact[x];
+				uint32_t c[8], k[8];
+#pragma unroll
+				for (int q = 0; q < 8; ++q) { c[q] = (uint32_t)q < d ? f + q : 0xFFFFFFFFu; k[q] = (uint32_t)q < d ? slot_key_of(c[q], slot_key) : 0xFFFFFFFFu; }
+#pragma unroll
+				for (int q = 1; q < 8; ++q) {
+#pragma unroll
+					for (int j = q; j > 0; --j) {
+						bool sw = (k[j] < k[j - 1]) || (k[j] == k[j - 1] && c[j] < c[j - 1]);
+						uint32_t tc = sw ? c[j - 1] : c[j], tk = sw ? k[j - 1] : k[j];
+						c[j - 1] = sw ? c[j] : c[j - 1]; k[j - 1] = sw ? k[j] : k[j - 1];
+						c[j] = tc; k[j] = tk;
+					}
+				}
+#pragma unroll
+				for (int q = 0; q < 8; ++q) if ((uint32_t)q < d) adj[b + q] = c[q];
+				cls = d <= 4u ? NH_CLS_STATIC4 : NH_CLS_STATIC8;
+				if (cls == NH_CLS_STATIC8) st->has_static8 = 1;
+			} else {
+				cls = NH_CLS_PENDING;
+				st->has_pending = 1;
+			}
+		} else {
+			momentum[x].unused0 = props[x].mass_inverse;
+		}
+		body_class[x] = (uint8_t)cls;
+	}
+}
+
 // one lane per body: sort its contact list by slot key, classify; bodies off the fast path also record per-contact predecessors
 __global__ __launch_bounds__(256) void k_adj_sort(nh_DevState* __restrict__ st, uint32_t nbodies, const nh_BodyPair* __restrict__ bodies, const uint32_t* __restrict__ off,
                                                   uint32_t* __restrict__ adj, const uint32_t* __restrict__ slot_key, uint8_t* __restrict__ body_class,
                                                   uint32_t* __restrict__ pred_a, uint32_t* __restrict__ pred_b,
                                                   const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum) {
+	if (!st->has_pending) return;
 	uint32_t rounded = (nbodies + 63u) & ~63u;
 	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < rounded; x += gridDim.x * blockDim.x) {
 		uint32_t cls = 0, d = 0;
-		if (x >= 1 && x < nbodies) {
+		if (x >= 1 && x < nbodies && body_class[x] == NH_CLS_PENDING) {
 			uint32_t b = off[x], e = off[x + 1];
 			d = e - b;
 			if (d) {
@@ -228,15 +281,8 @@ __global__ __launch_bounds__(256) void k_adj_sort(nh_DevState* __restrict__ st, 
 			body_class[x] = (uint8_t)cls;
 			if (cls == NH_CLS_STATIC8) st->has_static8 = 1;
 			if (cls == NH_CLS_STATICN) st->has_staticN = 1;
-			// the reference stashes mass_inverse in momentum.unused0 of EVERY body (nudge.cpp:4198); bodies with contacts
-			// on the one-body path get it from the solver's velocity write-back, the rest here (the level-scheduled sweeps read it from there)
+			// (mass_inverse -> momentum.unused0, nudge.cpp:4198: the level-scheduled sweeps read it from there)
 			if (cls == NH_CLS_NONE || cls == NH_CLS_GENERAL) momentum[x].unused0 = props[x].mass_inverse;
-		} else if (x == 0 && nbodies) {
-			body_class[0] = 0;
-			momentum[0].unused0 = props[0].mass_inverse;
-			const nh_BodyMomentum m0 = momentum[0];
-			const nh_BodyProperties p0 = props[0];
-			st->static_inert = nh_is_inert(m0.velocity, m0.angular_velocity, p0.inertia_inverse, p0.mass_inverse) ? 1u : 0u;
 		}
 	}
 }
@@ -244,6 +290,7 @@ __global__ __launch_bounds__(256) void k_adj_sort(nh_DevState* __restrict__ st, 
 // general contacts: flag, count, level = UNSET
 __global__ __launch_bounds__(256) void k_contact_class(nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, const uint8_t* __restrict__ body_class,
                                                        uint32_t* __restrict__ level, uint32_t* __restrict__ general_list, uint32_t* __restrict__ pred_a, uint32_t* __restrict__ pred_b) {
+	if (!st->has_pending) return;             // every body with contacts is on the one-body path: no general contacts
 	uint32_t n = st->contacts;
 	uint32_t rounded = (n + 63u) & ~63u;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
@@ -1127,7 +1174,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	nh_ContactConstraintData* d = new_constraint_data(ctx);
 	d->rows = nh_arena_array<float>(memory, (size_t)kcap * 40, &err);
 	d->states = nh_arena_array<float>(memory, (size_t)kcap * 4, &err);
-	if (!ctx->deg || ctx->deg_capacity < 2u * (B + 2u)) return NH_ERR_INVALID;      // nh_collide of this step sized and filled it
+	if (!ctx->deg || ctx->deg_capacity < 4u * (B + 2u)) return NH_ERR_INVALID;      // nh_collide of this step sized and filled it
 	d->body_off = ctx->deg;                                                         // [B+2] degrees -> offsets, then [B+2] fill cursors
 	d->adj = nh_arena_array<uint32_t>(memory, (size_t)kcap * 2, &err);
 	d->static_bodies = nh_arena_array<uint32_t>(memory, (size_t)3 * B, &err);
@@ -1151,8 +1198,10 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 
 	// (degrees were counted by nh_collide while it laid the contacts out)
 	nh_scan_u32(ctx, d->body_off, d->body_off, &st->pad0, B + 1, tmp, nullptr);
-	NH_LAUNCH(ctx, "adjacency_fill", k_adj_fill, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, contacts->tags, d->body_off, cursor, d->adj);
 	if (slot_key) NH_LAUNCH(ctx, "greedy_replay", k_greedy_replay, 1, 64, st, contacts->bodies, slot_key);
+	NH_LAUNCH(ctx, "adjacency_simple", k_adj_simple, nh_grid_for(B, 256, 4096), 256, st, B, d->body_off, ctx->deg + 2 * (size_t)(B + 2), ctx->deg + 3 * (size_t)(B + 2), d->adj, slot_key,
+	          d->body_class, bodies->properties, bodies->momentum);
+	NH_LAUNCH(ctx, "adjacency_fill", k_adj_fill, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, contacts->tags, d->body_off, cursor, d->adj, d->body_class);
 	NH_LAUNCH(ctx, "adjacency_sort", k_adj_sort, nh_grid_for(B, 256, 4096), 256, st, B, contacts->bodies, d->body_off, d->adj, slot_key, d->body_class, pred_a, pred_b, bodies->properties, bodies->momentum);
 	NH_LAUNCH(ctx, "contact_class", k_contact_class, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, d->body_class, level, general_list, pred_a, pred_b);
 	// the level-scheduled path needs per-level launch sizes on the host: one round trip
