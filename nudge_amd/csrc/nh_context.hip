@@ -68,7 +68,7 @@ extern "C" int nh_synchronize(nh_context* ctx) {
 extern "C" int nh_read_counts(nh_context* ctx, nh_Counts* out) {
 	if (!ctx || !out) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
-	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, 21 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, 22 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 	const nh_DevState* h = ctx->h_state;
 	out->colliders = h->colliders; out->pairs = h->pairs > 0 ? h->pairs : 0; out->contacts = h->contacts; out->sleeping_pairs = h->sleeping;

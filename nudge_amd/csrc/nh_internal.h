@@ -42,6 +42,8 @@ struct nh_DevState {
 	uint32_t any_sleeping;                // some contact record belongs to a sleeping island this step
 	uint32_t unleveled_odd;               // progress counter of odd relaxation / colouring rounds
 	uint32_t static_inert;                // body 0 has all-zero velocity, inverse mass and inverse inertia (nh_is_inert)
+	uint32_t has_pending;                 // some body needs the general adjacency build (k_adj_simple could not settle it)
+	// ---- (the 22 words above are what nh_read_counts mirrors to the host) ----
 	// scene bounds of AABB min corners, order-preserving uint encoding (atomicMin/Max)
 	uint32_t smin[3];
 	uint32_t smax[3];
@@ -57,7 +59,6 @@ struct nh_DevState {
 	uint32_t small_exp;           // colliders whose size class (extent bits >> 21: exponent + 2 mantissa bits) is <= this go to the grid (kept across steps: next step's guess)
 	uint32_t redo_small;          // the guess was wrong: k_small_bounds recomputes gmin/gmax
 	uint32_t exp_hist[1024];      // histogram of size classes
-	uint32_t has_pending;         // some body needs the general adjacency build (k_adj_simple could not settle it)
 	uint32_t any_idle[2];         // by step parity: some body's idle counter is saturated (asleep)
 };
 

@@ -1201,14 +1201,20 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	if (slot_key) NH_LAUNCH(ctx, "greedy_replay", k_greedy_replay, 1, 64, st, contacts->bodies, slot_key);
 	NH_LAUNCH(ctx, "adjacency_simple", k_adj_simple, nh_grid_for(B, 256, 4096), 256, st, B, d->body_off, ctx->deg + 2 * (size_t)(B + 2), ctx->deg + 3 * (size_t)(B + 2), d->adj, slot_key,
 	          d->body_class, bodies->properties, bodies->momentum);
-	NH_LAUNCH(ctx, "adjacency_fill", k_adj_fill, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, contacts->tags, d->body_off, cursor, d->adj, d->body_class);
-	NH_LAUNCH(ctx, "adjacency_sort", k_adj_sort, nh_grid_for(B, 256, 4096), 256, st, B, contacts->bodies, d->body_off, d->adj, slot_key, d->body_class, pred_a, pred_b, bodies->properties, bodies->momentum);
-	NH_LAUNCH(ctx, "contact_class", k_contact_class, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, d->body_class, level, general_list, pred_a, pred_b);
-	// the level-scheduled path needs per-level launch sizes on the host: one round trip
+	// one round trip: body classes, whether anything sleeps, whether the general adjacency build has work
 	nh_Counts c;
 	int rc = nh_read_counts(ctx, &c);
 	if (rc) return rc;
 	if (c.error) return (int)c.error;
+	if (ctx->h_state->has_pending) {
+		// bodies in several pairs or with dynamic partners (piles, pits): general CSR fill + sort + classification, then the counts again
+		NH_LAUNCH(ctx, "adjacency_fill", k_adj_fill, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, contacts->tags, d->body_off, cursor, d->adj, d->body_class);
+		NH_LAUNCH(ctx, "adjacency_sort", k_adj_sort, nh_grid_for(B, 256, 4096), 256, st, B, contacts->bodies, d->body_off, d->adj, slot_key, d->body_class, pred_a, pred_b, bodies->properties, bodies->momentum);
+		NH_LAUNCH(ctx, "contact_class", k_contact_class, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, d->body_class, level, general_list, pred_a, pred_b);
+		rc = nh_read_counts(ctx, &c);
+		if (rc) return rc;
+		if (c.error) return (int)c.error;
+	}
 	run_cull(ctx, imp, c.sleeping_pairs);
 	d->general_contacts = c.general_contacts;
 	d->static_body_count = c.static_bodies;
