@@ -441,6 +441,9 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
                                                      const nh_BoxCollider* __restrict__ box_data, const nh_SphereCollider* __restrict__ sph_data, uint32_t nbox,
                                                      nh_Contact* __restrict__ raw_data, uint32_t* __restrict__ raw_feature, uint32_t pair_cap, uint32_t overflow_cap,
                                                      uint64_t* __restrict__ rec_key, nh_Record* __restrict__ rec, uint32_t* __restrict__ rec_idx) {
+	__shared__ float4 s_c0[4][256], s_c1[4][256];
+	__shared__ uint32_t s_f[4][256];
+	__shared__ uint8_t s_n[4][64];
 	uint32_t n = min(st->pairs, pair_cap);
 	if (blockIdx.x == 0 && threadIdx.x == 0) st->records = n;
 	uint32_t rounded = (n + 63u) & ~63u;
@@ -484,14 +487,28 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		uint32_t extra = count > 4 ? (uint32_t)(count - 4) : 0u;
 		uint32_t ovf = 0;
 		if (__ballot(extra != 0)) ovf = nh_wave_reserve(&st->raw_contacts, extra);
+		// The first four contacts of a pair go to its four raw slots: the wave's 64 pairs own ONE contiguous run of 256 slots, so the
+		// lanes post their contacts to LDS and the wave writes the run with consecutive lanes on consecutive slots (a lane writing
+		// its own 128 bytes would put 64 different lines behind every store instruction).  Contacts 5+ (rare) go out directly.
+		float4* w_c0 = s_c0[threadIdx.x >> 6];
+		float4* w_c1 = s_c1[threadIdx.x >> 6];
+		uint32_t* w_f = s_f[threadIdx.x >> 6];
+		uint8_t* w_n = s_n[threadIdx.x >> 6];
+		const uint32_t lane = nh_lane();
 		if (i < n) {
 			if (extra && ovf + extra > overflow_cap) { st->error = NH_ERR_CONTACT_CAPACITY; count = 4; }
 			auto put = [&](int k, const nh_contact_out& o) {
-				size_t dst = k < 4 ? (size_t)4 * i + k : (size_t)4 * pair_cap + ovf + (k - 4);
-				float4* dp = reinterpret_cast<float4*>(raw_data + dst);
-				dp[0] = make_float4(o.px, o.py, o.pz, o.penetration);
-				dp[1] = make_float4(o.nx, o.ny, o.nz, o.friction);
-				raw_feature[dst] = o.feature;
+				if (k < 4) {
+					w_c0[4u * lane + k] = make_float4(o.px, o.py, o.pz, o.penetration);
+					w_c1[4u * lane + k] = make_float4(o.nx, o.ny, o.nz, o.friction);
+					w_f[4u * lane + k] = o.feature;
+				} else {
+					size_t dst = (size_t)4 * pair_cap + ovf + (k - 4);
+					float4* dp = reinterpret_cast<float4*>(raw_data + dst);
+					dp[0] = make_float4(o.px, o.py, o.pz, o.penetration);
+					dp[1] = make_float4(o.nx, o.ny, o.nz, o.friction);
+					raw_feature[dst] = o.feature;
+				}
 			};
 			if (bb.kind == 2) {
 				int k = 0;
@@ -514,6 +531,21 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			rec[i] = r;
 			rec_idx[i] = i;
 		}
+		w_n[lane] = (uint8_t)(i < n ? (count < 4 ? count : 4) : 0);
+		__builtin_amdgcn_wave_barrier();
+		{
+			const size_t run = (size_t)4 * (i - lane);            // first raw slot of the wave's pairs
+#pragma unroll
+			for (int r4 = 0; r4 < 4; ++r4) {
+				const uint32_t e = 64u * r4 + lane;
+				if ((e & 3u) < (uint32_t)w_n[e >> 2]) {
+					float4* dp = reinterpret_cast<float4*>(raw_data + run + e);
+					dp[0] = w_c0[e]; dp[1] = w_c1[e];
+					raw_feature[run + e] = w_f[e];
+				}
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
 	}
 }
 
