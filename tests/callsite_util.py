@@ -9,6 +9,7 @@ from nudge_amd import scenes as S
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPLAY_REF = os.path.join(ROOT, "oracle", "_ref", "replay_ref")                      # replay.cpp + the reference's nudge.cpp (checker)
 REPLAY_HIP = os.path.join(ROOT, "nudge_amd", "compat", "_build", "replay_hip")       # replay.cpp + the C++ drop-in + libnudge_hip.so
+RESIDENT_REPLAY = os.path.join(ROOT, "nudge_amd", "resident_replay")                          # examples/resident_replay.cpp: C++ host on the device-resident C ABI
 REF_TESTS_HIP = os.path.join(ROOT, "nudge_amd", "compat", "_build", "ref_tests_hip")  # the reference's own tests/main.cpp on the GPU backend
 
 
@@ -44,8 +45,8 @@ def read_result(path, nb):
     return dict(transforms=t, momentum=m, idle=idle, sum_contacts=sum_contacts, last_contacts=last_contacts, last_active=last_active)
 
 
-def run_replay(binary, scene_path, out_path, steps, timeout=600):
-    r = subprocess.run([binary, scene_path, out_path, str(steps)], capture_output=True, text=True, timeout=timeout)
+def run_replay(binary, scene_path, out_path, steps, timeout=600, extra=()):
+    r = subprocess.run([binary, scene_path, out_path, str(steps)] + list(extra), capture_output=True, text=True, timeout=timeout)
     if r.returncode != 0:
         raise RuntimeError(f"{binary} failed ({r.returncode}):\n{r.stdout}\n{r.stderr}")
     return r.stdout

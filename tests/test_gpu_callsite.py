@@ -66,3 +66,24 @@ def test_reference_own_test_program_passes_on_the_gpu_backend():
     r = subprocess.run([CU.REF_TESTS_HIP], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "All tests passed." in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["pile256", "mixed20", "pit6"])
+def test_cpp_host_on_the_resident_abi_matches_reference(name, tmp_path):
+    """examples/resident_replay.cpp: a C++ host that keeps every array in HBM and calls the C ABI directly (the performance path),
+    against the reference stepping the same scene file."""
+    assert os.path.exists(CU.RESIDENT_REPLAY), "nudge_amd/resident_replay missing: make -C nudge_amd/csrc"
+    scene, steps = G.build(name)
+    steps = min(steps, 150)
+    nb = CU.write_scene(str(tmp_path / "s.bin"), scene)
+    CU.run_replay(CU.RESIDENT_REPLAY, str(tmp_path / "s.bin"), str(tmp_path / "gpu.bin"), steps, extra=["exact"])
+    got = CU.read_result(str(tmp_path / "gpu.bin"), nb)
+    assert refworld.available("exact")
+    w = refworld.RefWorld(scene)
+    w.step(steps)
+    b = w.bodies()
+    assert P.bits_equal(got["transforms"], b["transforms"])
+    assert P.bits_equal(got["momentum"], b["momentum"])
+    assert P.bits_equal(got["idle"], b["idle"])
+    assert got["sum_contacts"] == w.sum_contacts()
