@@ -343,3 +343,51 @@ def test_body_connections_join_islands():
         differed |= len(w.get_active()) != len(w0.get_active())
     assert differed, "the connections were meant to keep part of the grid awake"
     w.close(); w0.close()
+
+
+# ---- degenerate inputs ------------------------------------------------------------------------------------------------------------
+def _tiny_scene(n_boxes, n_spheres, apart=True):
+    scene = S.pile(n_boxes=max(n_boxes, 1), n_spheres=n_spheres, seed=3)
+    if n_boxes == 0:
+        # keep only the static ground box (collider 0 on body 0) and the spheres
+        keep_bodies = np.concatenate([[0], np.arange(2, len(scene["body_transforms"]))]).astype(np.int64)
+        for k in ("body_transforms", "body_properties", "body_momentum", "idle_counters"):
+            scene[k] = scene[k][keep_bodies]
+        scene["box_tags"] = scene["box_tags"][:1]; scene["box_data"] = scene["box_data"][:1]; scene["box_transforms"] = scene["box_transforms"][:1]
+        scene["sphere_transforms"]["body"] -= 1
+    if apart:
+        scene["body_transforms"]["position"][1:, 0] = 50.0 * np.arange(1, len(scene["body_transforms"]))      # nobody touches anybody
+        scene["body_transforms"]["position"][1:, 1] = 500.0
+    return scene
+
+
+@needs_ref
+@pytest.mark.parametrize("case", ["static_only", "one_box_free_fall", "spheres_only_no_contacts", "two_bodies_landing"])
+def test_degenerate_worlds(case):
+    """Empty and near-empty worlds go through every kernel with zero-length inputs (no pairs, no contacts, no active islands with
+    contacts) and must match the reference like any other."""
+    if case == "static_only":
+        scene = _tiny_scene(1, 0)
+        for k in ("body_transforms", "body_properties", "body_momentum", "idle_counters"):
+            scene[k] = scene[k][:1]                                  # body 0 only
+        scene["box_tags"] = scene["box_tags"][:1]; scene["box_data"] = scene["box_data"][:1]; scene["box_transforms"] = scene["box_transforms"][:1]
+    elif case == "one_box_free_fall":
+        scene = _tiny_scene(1, 0)
+    elif case == "spheres_only_no_contacts":
+        scene = _tiny_scene(0, 3)
+    else:
+        scene = _tiny_scene(1, 1, apart=False)
+        scene["body_transforms"]["position"][1:, 1] = (1.0, 4.0)     # about to land on the ground / on each other
+        scene["body_transforms"]["position"][1:, 0] = 0.0
+        scene["body_transforms"]["position"][1:, 2] = 0.0
+    for flags in (E.NH_FLAG_SYNC_COUNTS | E.NH_FLAG_EXACT_ORDER, 0):
+        w = E.World(scene, flags=flags)
+        ref = refworld.RefWorld(scene)
+        for _ in range(4):
+            w.step(40); ref.step(40)
+            a, b = w.get_bodies(), ref.bodies()
+            assert w.counts()["error"] == 0
+            assert P.bits_equal(a["transforms"], b["transforms"]), (case, flags)
+            assert P.bits_equal(a["momentum"]["velocity"], b["momentum"]["velocity"]), (case, flags)
+            assert np.array_equal(a["idle"], b["idle"])
+        w.close()
