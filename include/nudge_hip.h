@@ -28,7 +28,8 @@
  *      host-invisible memory here, so it is offered as `nh_apply_gravity_damping`.
  *   7. Deferred execution.  `nh_read_cached_impulses` and `nh_setup_contact_constraints` may postpone part of their
  *      work (the per-contact cache lookup; row build + warm start of bodies that only touch the static world) and
- *      run it fused with the first `nh_apply_impulses`, so that a constraint row lives only in registers.  Every
+ *      run it fused with the first `nh_apply_impulses`, so that a constraint row lives only in registers; the one host
+ *      round trip of a step (device counters) is also taken there, behind the solver kernel it has just launched.  Every
  *      entry point of this library that reads or writes momentum, impulses or counters first completes pending
  *      work, and so does `nh_synchronize`: through the API the reference's call-by-call semantics are kept.  Only
  *      foreign kernels enqueued on the stream BETWEEN setup and the first apply would see momentum without the

@@ -150,6 +150,14 @@ struct nh_ContactConstraintData {
 	bool setup_pending;
 	nh_ContactImpulseData* imp;
 	nh_BodyData bodies_at_setup;
+	// nh_setup_contact_constraints returns WITHOUT a host round trip; what needs the device counters (general adjacency, culling,
+	// the level-scheduled path) is finished by the first nh_apply_impulses / flush, behind the speculatively launched one-body solver
+	bool finish_pending;
+	bool has_late;                        // bodies classified after the round trip (classes *_LATE)
+	struct {
+		nh_ContactData contacts;
+		uint32_t *cursor, *pred_a, *pred_b, *level, *slot_key, *level_hist, *level_cursor, *tmp;
+	} cont;
 };
 
 // ---- arena (host-side bump allocation over device memory, reference nudge.cpp:990-1055) ---------------

@@ -26,6 +26,9 @@
 #define NH_CLS_STATICN 3u
 #define NH_CLS_GENERAL 4u
 #define NH_CLS_PENDING 0xFFu         // k_adj_simple could not settle it: k_adj_fill / k_adj_sort do
+// one-body bodies classified by k_adj_sort (after the counts round trip): the kernel speculatively launched before it has not seen them
+#define NH_CLS_STATIC4_LATE 5u
+#define NH_CLS_STATIC8_LATE 6u
 #define NH_UNSET 0xFFFFFFFFu
 
 __device__ __forceinline__ bool tag_less(uint64_t ta, uint32_t fa, uint64_t tb, uint32_t fb) { return ta < tb || (ta == tb && fa < fb); }
@@ -59,9 +62,16 @@ __global__ __launch_bounds__(256) void k_advance(const nh_DevState* __restrict__
 // contacts are already in tag order, so the reference's merge-join becomes one binary search per contact.
 __global__ __launch_bounds__(256) void k_cache_lookup(const nh_DevState* __restrict__ st, const uint64_t* __restrict__ tags, const uint32_t* __restrict__ features,
                                                       const uint64_t* __restrict__ ctags, const uint32_t* __restrict__ cfeatures, const nh_CachedContactImpulse* __restrict__ cdata,
-                                                      nh_CachedContactImpulse* __restrict__ out) {
+                                                      nh_CachedContactImpulse* __restrict__ out, const nh_BodyPair* __restrict__ bodies, const uint8_t* __restrict__ body_class) {
 	uint32_t n = st->contacts, m = st->cache;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		if (body_class) {
+			// only contacts of the >8-contact one-body class and of the level-scheduled path read their warm start from `out`; the
+			// fused one-body solver looks its own up and may already have put its SOLVED impulses there
+			const nh_BodyPair p = bodies[i];
+			const uint32_t ca = p.a ? body_class[p.a] : 0u, cb = p.b ? body_class[p.b] : 0u;
+			if (ca != NH_CLS_GENERAL && cb != NH_CLS_GENERAL && ca != NH_CLS_STATICN && cb != NH_CLS_STATICN) continue;
+		}
 		uint64_t t = tags[i]; uint32_t f = features[i];
 		uint32_t lo = 0, hi = m;
 		// steady state: the cache is last step's contact list, so the entry usually sits at the same index
@@ -276,10 +286,10 @@ __global__ __launch_bounds__(256) void k_adj_sort(nh_DevState* __restrict__ st, 
 						prev = c;
 					}
 				}
-				cls = static_only ? (d <= 4u ? NH_CLS_STATIC4 : (d <= 8u ? NH_CLS_STATIC8 : NH_CLS_STATICN)) : NH_CLS_GENERAL;
+				cls = static_only ? (d <= 4u ? NH_CLS_STATIC4_LATE : (d <= 8u ? NH_CLS_STATIC8_LATE : NH_CLS_STATICN)) : NH_CLS_GENERAL;
 			}
 			body_class[x] = (uint8_t)cls;
-			if (cls == NH_CLS_STATIC8) st->has_static8 = 1;
+			if (cls == NH_CLS_STATIC8_LATE) st->has_static8 = 1;
 			if (cls == NH_CLS_STATICN) st->has_staticN = 1;
 			// (mass_inverse -> momentum.unused0, nudge.cpp:4198: the level-scheduled sweeps read it from there)
 			if (cls == NH_CLS_NONE || cls == NH_CLS_GENERAL) momentum[x].unused0 = props[x].mass_inverse;
@@ -506,13 +516,13 @@ __global__ __launch_bounds__(256) void k_apply_static(uint32_t nbodies, const ui
                                                       const nh_BodyPair* __restrict__ bodies, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                       const float* __restrict__ rows, float4* __restrict__ states, uint32_t iterations,
                                                       const nh_Contact* __restrict__ contacts, const nh_Transform* __restrict__ xf, nh_CachedContactImpulse* __restrict__ impulses,
-                                                      nh_CacheView cv) {
+                                                      nh_CacheView cv, uint32_t cls_a, uint32_t cls_b) {
 	const nh_vel vel0 = load_vel(momentum, props, 0);
 	const nh_inertia I0 = body_inertia(xf, props, 0);
 	const nh_Transform t0 = xf[0];
 	const nh_f3 pos0 = nh_make3(t0.position[0], t0.position[1], t0.position[2]);
 	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < nbodies; x += gridDim.x * blockDim.x) {
-		if (body_class[x] != (MAXC == 4 ? NH_CLS_STATIC4 : (MAXC == 8 ? NH_CLS_STATIC8 : NH_CLS_STATICN))) continue;
+		{ const uint32_t my_class = body_class[x]; if (my_class != cls_a && my_class != cls_b) continue; }
 		nh_vel v = load_vel(momentum, props, x);
 		nh_vel z = vel0;
 		uint32_t b = off[x], e = off[x + 1];
@@ -682,8 +692,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
                                                         const nh_BodyPair* __restrict__ bodies, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                         float4* __restrict__ states, uint32_t iterations,
                                                         const nh_Contact* __restrict__ contacts, const nh_Transform* __restrict__ xf, nh_CachedContactImpulse* __restrict__ impulses,
-                                                        nh_CacheView cv, uint32_t* __restrict__ hint) {
+                                                        nh_CacheView cv, uint32_t* __restrict__ hint, uint32_t cls_a, uint32_t cls_b, uint32_t require_inert) {
 	constexpr int M = MAXC;
+	// launched before the host knew whether body 0 is inert: if it is not, the general kernels take these bodies after the round trip
+	if (require_inert && !cv.st->static_inert) return;
 	__shared__ nh_ob_slot s_slot[4][64 * M];
 	__shared__ uint32_t s_cid[4][64 * M];
 	__shared__ uint32_t s_hint[4][64], s_first[4][64];
@@ -693,7 +705,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
 	const uint32_t m = FUSED ? cv.st->cache : 0u;
 	const uint32_t rounded = (nbodies + 255u) & ~255u;
 	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < rounded; x += gridDim.x * blockDim.x) {       // block-uniform trip count
-		const bool mine = x < nbodies && body_class[x] == (MAXC == 4 ? NH_CLS_STATIC4 : NH_CLS_STATIC8);
+		const uint32_t my_class = x < nbodies ? body_class[x] : 0u;
+		const bool mine = x < nbodies && (my_class == cls_a || my_class == cls_b);
 		const uint32_t wave_x0 = x - lane;
 		uint32_t b = 0, cnt = 0;
 		if (mine) { b = off[x]; cnt = off[x + 1] - b; }
@@ -1121,10 +1134,11 @@ extern "C" int nh_read_cached_impulses(nh_context* ctx, const nh_ContactCache* c
 	return NH_OK;
 }
 
-static void materialize_lookup(nh_context* ctx, nh_ContactImpulseData* d) {
+// `bodies` / `body_class` given: restrict to the contacts that read their warm start from d->data (see k_cache_lookup)
+static void materialize_lookup(nh_context* ctx, nh_ContactImpulseData* d, const nh_BodyPair* bodies = nullptr, const uint8_t* body_class = nullptr) {
 	if (!d->lookup_pending) return;
 	d->lookup_pending = false;
-	NH_LAUNCH(ctx, "cache_lookup", k_cache_lookup, nh_grid_for(d->capacity, 256, 16384), 256, ctx->d_state, d->tags, d->features, d->ctags, d->cfeatures, d->cdata, d->data);
+	NH_LAUNCH(ctx, "cache_lookup", k_cache_lookup, nh_grid_for(d->capacity, 256, 16384), 256, ctx->d_state, d->tags, d->features, d->ctags, d->cfeatures, d->cdata, d->data, bodies, body_class);
 }
 
 extern "C" const nh_CachedContactImpulse* nh_contact_impulses_device(const nh_ContactImpulseData* d) {
@@ -1133,7 +1147,7 @@ extern "C" const nh_CachedContactImpulse* nh_contact_impulses_device(const nh_Co
 	if (m->ctx) {
 		// before the solver has run this holds the warm-start impulses, afterwards the solved ones: make either visible
 		if (m->ctx->pending) nh_flush_pending(m->ctx);
-		else materialize_lookup(m->ctx, m);
+		else if (!m->consumed) materialize_lookup(m->ctx, m);
 	}
 	return d->data;
 }
@@ -1201,12 +1215,48 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	if (slot_key) NH_LAUNCH(ctx, "greedy_replay", k_greedy_replay, 1, 64, st, contacts->bodies, slot_key);
 	NH_LAUNCH(ctx, "adjacency_simple", k_adj_simple, nh_grid_for(B, 256, 4096), 256, st, B, d->body_off, ctx->deg + 2 * (size_t)(B + 2), ctx->deg + 3 * (size_t)(B + 2), d->adj, slot_key,
 	          d->body_class, bodies->properties, bodies->momentum);
+	if (ctx->hint_capacity < B) {
+		// library-owned, persistent across steps: per body, where its contacts started in the previous step's list (warm-start hint)
+		if (ctx->hint) NH_HIP_CHECK(ctx, hipFree(ctx->hint));
+		ctx->hint = nullptr; ctx->hint_capacity = 0;
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->hint, sizeof(uint32_t) * (size_t)B));
+		NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->hint, 0xFF, sizeof(uint32_t) * (size_t)B, ctx->stream));
+		ctx->hint_capacity = B;
+	}
+	// No host round trip here.  The one-body path (lookup + rows + warm start) runs fused with the first sweeps, and everything that
+	// needs the device counters is finished behind it (finish_setup), by nh_apply_impulses or by the next call that observes
+	// momentum / impulses / counters (nh_flush_pending).
+	d->cont.contacts = *contacts;
+	d->cont.cursor = cursor; d->cont.pred_a = pred_a; d->cont.pred_b = pred_b; d->cont.level = level; d->cont.slot_key = slot_key;
+	d->cont.level_hist = level_hist; d->cont.level_cursor = level_cursor; d->cont.tmp = tmp;
+	d->has_static8 = d->has_staticN = d->has_late = false; d->static_inert = false;
+	d->finish_pending = true;
+	d->setup_pending = true; d->imp = imp; d->bodies_at_setup = *bodies;
+	imp->consumed = true;
+	ctx->pending = d;
+	*out = d;
+	return NH_OK;
+}
+
+// The part of setup_contact_constraints that needs the device counters on the host: general adjacency for bodies k_adj_simple left
+// pending, culling when something sleeps, the >8-contact one-body class, and the level-scheduled path (colouring / levels, rows,
+// warm start).  Runs once per setup, with ctx->pending already cleared.
+static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
+	nh_DevState* st = ctx->d_state;
+	const nh_ContactData* contacts = &d->cont.contacts;
+	const nh_BodyData* bodies = &d->bodies_at_setup;
+	nh_ContactImpulseData* imp = d->imp;
+	const uint32_t kcap = d->contact_capacity, B = d->body_count;
+	uint32_t* cursor = d->cont.cursor; uint32_t* pred_a = d->cont.pred_a; uint32_t* pred_b = d->cont.pred_b; uint32_t* level = d->cont.level;
+	uint32_t* slot_key = d->cont.slot_key; uint32_t* level_hist = d->cont.level_hist; uint32_t* level_cursor = d->cont.level_cursor;
+	uint32_t* general_list = d->general_list;
 	// one round trip: body classes, whether anything sleeps, whether the general adjacency build has work
 	nh_Counts c;
 	int rc = nh_read_counts(ctx, &c);
 	if (rc) return rc;
 	if (c.error) return (int)c.error;
-	if (ctx->h_state->has_pending) {
+	d->has_late = ctx->h_state->has_pending != 0;
+	if (d->has_late) {
 		// bodies in several pairs or with dynamic partners (piles, pits): general CSR fill + sort + classification, then the counts again
 		NH_LAUNCH(ctx, "adjacency_fill", k_adj_fill, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, contacts->tags, d->body_off, cursor, d->adj, d->body_class);
 		NH_LAUNCH(ctx, "adjacency_sort", k_adj_sort, nh_grid_for(B, 256, 4096), 256, st, B, contacts->bodies, d->body_off, d->adj, slot_key, d->body_class, pred_a, pred_b, bodies->properties, bodies->momentum);
@@ -1221,28 +1271,15 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	d->has_static8 = ctx->h_state->has_static8 != 0;
 	d->has_staticN = ctx->h_state->has_staticN != 0;
 	d->static_inert = ctx->h_state->static_inert != 0;
-	if (ctx->hint_capacity < B) {
-		// library-owned, persistent across steps: per body, where its contacts started in the previous step's list (warm-start hint)
-		if (ctx->hint) NH_HIP_CHECK(ctx, hipFree(ctx->hint));
-		ctx->hint = nullptr; ctx->hint_capacity = 0;
-		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->hint, sizeof(uint32_t) * (size_t)B));
-		NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->hint, 0xFF, sizeof(uint32_t) * (size_t)B, ctx->stream));
-		ctx->hint_capacity = B;
-	}
-	// one-body path (<= 8 contacts per body): lookup + rows + warm start run fused with the first sweeps (nh_apply_impulses),
-	// or at the next call that observes momentum / impulses (nh_flush_pending)
-	d->setup_pending = true; d->imp = imp; d->bodies_at_setup = *bodies;
-	imp->consumed = true;
-	ctx->pending = d;
 	if (d->has_staticN) {
-		// bodies with more than 8 static contacts are rare: rows are stored, the warm start reads the materialised lookup
-		materialize_lookup(ctx, imp);
+		// bodies with more than 8 static contacts are rare: the warm start reads the materialised lookup
+		materialize_lookup(ctx, imp, contacts->bodies, d->body_class);
 		NH_LAUNCH(ctx, "setup_staticN", (k_setup_static<true>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj,
 		          contacts->data, contacts->bodies, imp->data, bodies->transforms, bodies->properties, bodies->momentum, d->rows, (float4*)d->states, (const uint32_t*)nullptr);
 	}
 	if (c.general_contacts) {
 		const uint32_t G = c.general_contacts;
-		materialize_lookup(ctx, imp);
+		materialize_lookup(ctx, imp, contacts->bodies, d->body_class);
 		// relaxation: every round finalises at least the next level
 		uint32_t rounds = 0;
 		NH_LAUNCH(ctx, "level_reset", k_level_reset_progress, 1, 1, st);
@@ -1277,39 +1314,61 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 				          bodies->momentum, (const float4*)d->rows, (size_t)kcap, d->gstates);
 		}
 	}
-	*out = d;
 	return NH_OK;
 }
 
-static void launch_apply_static(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations, bool fused) {
+// Solver launches for the one-body classes.  `early4_done`: the STATIC4 bodies classified by k_adj_simple have already been taken by
+// the speculative launch (only possible when body 0 is inert: that launch checks it on the device and leaves otherwise).
+static void launch_apply_static(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations, bool fused, bool early4_done) {
 	const uint32_t B = d->body_count;
 	nh_CacheView cv = { nullptr, nullptr, nullptr, nullptr, nullptr, ctx->d_state };
 	if (fused) { cv.tags = d->imp->tags; cv.features = d->imp->features; cv.ctags = d->imp->ctags; cv.cfeatures = d->imp->cfeatures; cv.cdata = d->imp->cdata; }
-	auto go = [&](const char* name, auto kernel) {
+	auto go = [&](const char* name, auto kernel, uint32_t cls_a, uint32_t cls_b) {
 		NH_LAUNCH(ctx, name, kernel, nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
-		          d->rows, (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv);
+		          d->rows, (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, cls_a, cls_b);
 	};
-	auto go1 = [&](const char* name, auto kernel) {
+	auto go1 = [&](const char* name, auto kernel, uint32_t cls_a, uint32_t cls_b) {
 		NH_LAUNCH(ctx, name, kernel, nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
-		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint);
+		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, cls_a, cls_b, 0u);
 	};
+	const bool late = d->has_late;
 	if (d->static_inert) {
 		// body 0 is inert (all-zero velocity, inverse mass, inverse inertia): one-body forms, 27-float rows
+		const bool need4 = !early4_done || late;
+		const uint32_t a4 = early4_done ? NH_CLS_STATIC4_LATE : NH_CLS_STATIC4;
 		if (fused) {
-			go1("solve_one_body", k_solve_one_body<4, true>);
-			if (d->has_static8) go1("solve_one_body8", k_solve_one_body<8, true>);
+			if (need4) go1("solve_one_body", k_solve_one_body<4, true>, a4, NH_CLS_STATIC4_LATE);
+			if (d->has_static8) go1("solve_one_body8", k_solve_one_body<8, true>, NH_CLS_STATIC8, NH_CLS_STATIC8_LATE);
 		} else {
-			go1("solve_one_body", k_solve_one_body<4, false>);
-			if (d->has_static8) go1("solve_one_body8", k_solve_one_body<8, false>);
+			if (need4) go1("solve_one_body", k_solve_one_body<4, false>, a4, NH_CLS_STATIC4_LATE);
+			if (d->has_static8) go1("solve_one_body8", k_solve_one_body<8, false>, NH_CLS_STATIC8, NH_CLS_STATIC8_LATE);
 		}
 	} else if (fused) {
-		go("apply_static", k_apply_static<4, true>);
-		if (d->has_static8) go("apply_static8", k_apply_static<8, true>);
+		go("apply_static", k_apply_static<4, true>, NH_CLS_STATIC4, NH_CLS_STATIC4_LATE);
+		if (d->has_static8) go("apply_static8", k_apply_static<8, true>, NH_CLS_STATIC8, NH_CLS_STATIC8_LATE);
 	} else {
-		go("apply_static", k_apply_static<4, false>);
-		if (d->has_static8) go("apply_static8", k_apply_static<8, false>);
+		go("apply_static", k_apply_static<4, false>, NH_CLS_STATIC4, NH_CLS_STATIC4_LATE);
+		if (d->has_static8) go("apply_static8", k_apply_static<8, false>, NH_CLS_STATIC8, NH_CLS_STATIC8_LATE);
 	}
-	if (d->has_staticN && iterations) go("apply_staticN", k_apply_static<0, false>);
+	if (d->has_staticN && iterations) go("apply_staticN", k_apply_static<0, false>, NH_CLS_STATICN, NH_CLS_STATICN);
+}
+
+// First solver call after a setup (or its flush with zero sweeps): the common one-body kernel goes out BEFORE the counters round trip --
+// the round trip then overlaps with it instead of idling the GPU -- and the rest follows once the host knows what else there is.
+static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations) {
+	bool early4_done = false;
+	if (d->finish_pending) {
+		d->finish_pending = false;
+		const uint32_t B = d->body_count;
+		nh_CacheView cv = { d->imp->tags, d->imp->features, d->imp->ctags, d->imp->cfeatures, d->imp->cdata, ctx->d_state };
+		NH_LAUNCH(ctx, "solve_one_body", (k_solve_one_body<4, true>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
+		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 1u);
+		int rc = finish_setup(ctx, d);
+		if (rc) return rc;
+		early4_done = d->static_inert;          // (if body 0 is not inert the speculative launch left at once and the general kernels take everything)
+	}
+	launch_apply_static(ctx, d, bodies, iterations, true, early4_done);
+	return NH_OK;
 }
 
 int nh_flush_pending(nh_context* ctx) {
@@ -1318,7 +1377,7 @@ int nh_flush_pending(nh_context* ctx) {
 	ctx->pending = nullptr;
 	if (d->setup_pending) {
 		d->setup_pending = false;
-		launch_apply_static(ctx, d, &d->bodies_at_setup, 0, true);       // zero sweeps: lookup + rows + warm start only
+		return first_apply(ctx, d, &d->bodies_at_setup, 0);       // zero sweeps: lookup + rows + warm start only
 	}
 	return NH_OK;
 }
@@ -1326,10 +1385,11 @@ int nh_flush_pending(nh_context* ctx) {
 extern "C" int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations) {
 	if (!ctx || !d || !bodies) return NH_ERR_INVALID;
 	if (ctx->pending && ctx->pending != d) { int rc = nh_flush_pending(ctx); if (rc) return rc; }
-	const bool fused = d->setup_pending;
+	const bool first = d->setup_pending;
 	d->setup_pending = false;
 	ctx->pending = nullptr;
-	launch_apply_static(ctx, d, bodies, iterations, fused);
+	if (first) { int rc = first_apply(ctx, d, bodies, iterations); if (rc) return rc; }
+	else launch_apply_static(ctx, d, bodies, iterations, false, false);
 	if (d->general_contacts) {
 		for (uint32_t it = 0; it < iterations; ++it)
 			for (uint32_t l = 1; l <= d->levels; ++l) {
