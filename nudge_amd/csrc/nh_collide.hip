@@ -196,10 +196,15 @@ __device__ __forceinline__ int cell_coord(float x, float origin, float inv) {
 	return (int)floorf(f);
 }
 
-// ---- 3. cell keys, morton keys, large list ---------------------------------------------------------------
+// ---- 3. cell keys, morton keys, large list; 4. counting sort by cell -----------------------------------------------
+// The colliders are grouped by grid cell with a COUNTING sort: k_cell_keys takes a rank inside the cell from an atomic counter,
+// the counters are scanned into cell starts, k_cell_scatter writes the AABBs in cell order.  (The order INSIDE a cell is
+// whatever the atomics gave; nothing downstream depends on it: a pair is emitted once whichever member comes first, its roles
+// are decided by Morton keys, and contacts come out in tag order.)  Large colliders follow the small ones, in list order.
 __global__ __launch_bounds__(256) void k_cell_keys(nh_DevState* __restrict__ st, uint32_t n,
                                                    const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
-                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint64_t* __restrict__ mkey, uint32_t* __restrict__ large_list) {
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ rank, uint64_t* __restrict__ mkey, uint32_t* __restrict__ large_list,
+                                                   uint32_t* __restrict__ cstart) {
 	const float inv = st->cell_inv;
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
@@ -210,6 +215,7 @@ __global__ __launch_bounds__(256) void k_cell_keys(nh_DevState* __restrict__ st,
 	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < rounded; c += gridDim.x * blockDim.x) {
 		bool valid = c < n;
 		bool large = false;
+		uint32_t key = NH_LARGE_KEY;
 		if (valid) {
 			float4 mn = aabb_min[c], mx = aabb_max[c];
 			mkey[c] = nh_morton_of(nh_make3(mn.x, mn.y, mn.z), mscale, mmin);
@@ -218,35 +224,74 @@ __global__ __launch_bounds__(256) void k_cell_keys(nh_DevState* __restrict__ st,
 			uint32_t e = (__float_as_uint(mx.w) >> 21) & 1023u;
 			// "small" = spans at most 2 cells per axis in THIS arithmetic (makes the neighbour search exact)
 			large = e > small_exp || (cx1 - cx0) > 1 || (cy1 - cy0) > 1 || (cz1 - cz0) > 1 || !(mx.w == mx.w);
-			uint32_t key = NH_LARGE_KEY;
 			if (!large) {
 				int cx = min(max(cx0, 0), nx - 1), cy = min(max(cy0, 0), ny - 1), cz = min(max(cz0, 0), nz - 1);
 				key = (uint32_t)((cz * ny + cy) * nx + cx);
+				rank[c] = atomicAdd(&cstart[key], 1u);
 			}
 			keys[c] = key;
-			vals[c] = c;
 		}
 		uint32_t slot = nh_wave_reserve1(&st->large, valid && large);
-		if (valid && large) large_list[slot] = c;
+		if (valid && large) { large_list[slot] = c; rank[c] = slot; }
 	}
 }
 
-// ---- 4. cell ranges + AABBs in cell order ---------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_cell_bounds(uint32_t n, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                     const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
-                                                     uint2* __restrict__ cells, float4* __restrict__ smin, float4* __restrict__ smax,
-                                                     const uint64_t* __restrict__ mkey, uint64_t* __restrict__ smk) {
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		uint32_t key = keys[i];
-		uint32_t c = vals[i];
-		smk[i] = mkey[c];
+// exclusive scan of the per-cell counts (n = table size, a multiple of CS_TILE) into cell starts, in place; cstart[n] = total
+#define CS_PER_THREAD 16
+#define CS_TILE (256 * CS_PER_THREAD)
+__global__ __launch_bounds__(256) void k_cscan_sums(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ block_sums) {
+	__shared__ uint32_t wsum[4];
+	const uint4* p = reinterpret_cast<const uint4*>(cnt + (size_t)blockIdx.x * CS_TILE + threadIdx.x * CS_PER_THREAD);
+	uint32_t s = 0;
+#pragma unroll
+	for (int q = 0; q < CS_PER_THREAD / 4; ++q) { uint4 v = p[q]; s += v.x + v.y + v.z + v.w; }
+	for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+	if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+	__syncthreads();
+	if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(256) void k_cscan_final(uint32_t* __restrict__ cnt, const uint32_t* __restrict__ block_sums, uint32_t n) {
+	__shared__ uint32_t wsum[4];
+	__shared__ uint32_t red[4];
+	// carry = sum of the block sums before this block
+	uint32_t ca = 0;
+	for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256) ca += block_sums[i];
+	for (int d = 32; d >= 1; d >>= 1) ca += __shfl_xor(ca, d);
+	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ca;
+	uint4* p = reinterpret_cast<uint4*>(cnt + (size_t)blockIdx.x * CS_TILE + threadIdx.x * CS_PER_THREAD);
+	uint4 v[CS_PER_THREAD / 4];
+	uint32_t mine = 0;
+#pragma unroll
+	for (int q = 0; q < CS_PER_THREAD / 4; ++q) { v[q] = p[q]; mine += v[q].x + v[q].y + v[q].z + v[q].w; }
+	uint32_t x = mine;
+	for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d); if ((int)(threadIdx.x & 63) >= d) x += y; }
+	if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+	__syncthreads();
+	uint32_t run = red[0] + red[1] + red[2] + red[3] + x - mine;
+	for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) run += wsum[w];
+#pragma unroll
+	for (int q = 0; q < CS_PER_THREAD / 4; ++q) {
+		uint4 o;
+		o.x = run; run += v[q].x; o.y = run; run += v[q].y; o.z = run; run += v[q].z; o.w = run; run += v[q].w;
+		p[q] = o;
+	}
+	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) cnt[n] = run;
+}
+
+__global__ __launch_bounds__(256) void k_cell_scatter(const nh_DevState* __restrict__ st, uint32_t n, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ rank,
+                                                      const uint32_t* __restrict__ cstart, const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
+                                                      uint32_t* __restrict__ skeys, float4* __restrict__ smin, float4* __restrict__ smax,
+                                                      const uint64_t* __restrict__ mkey, uint64_t* __restrict__ smk) {
+	const uint32_t nsmall = n - st->large;
+	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+		const uint32_t key = keys[c];
+		const uint32_t pos = key != NH_LARGE_KEY ? cstart[key] + rank[c] : nsmall + rank[c];
 		float4 mn = aabb_min[c], mx = aabb_max[c];
 		mx.w = __uint_as_float(c);                 // sorted copy carries (body, collider index) in the w lanes
-		smin[i] = mn; smax[i] = mx;
-		if (key != NH_LARGE_KEY) {
-			if (i == 0 || keys[i - 1] != key) cells[key].x = i;
-			if (i + 1 == n || keys[i + 1] != key) cells[key].y = i + 1;
-		}
+		skeys[pos] = key;
+		smin[pos] = mn; smax[pos] = mx;
+		smk[pos] = mkey[c];
 	}
 }
 
@@ -309,7 +354,7 @@ __device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_
 // ---- 5. pair search: grid neighbours + large list ---------------------------------------------------------
 __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st, uint32_t n,
                                                     const uint32_t* __restrict__ keys, const float4* __restrict__ smin, const float4* __restrict__ smax,
-                                                    const uint2* __restrict__ cells, const uint32_t* __restrict__ large_list,
+                                                    const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
                                                     const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
                                                     const uint64_t* __restrict__ mkey, const uint64_t* __restrict__ smk, uint2* __restrict__ pairs, uint32_t pair_cap) {
 	const float inv = st->cell_inv;
@@ -352,8 +397,8 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 					continue;
 				}
 				// next cell
-				uint2 range = cells[(cz * ny + cy) * nx + cx];
-				j = range.x; jend = range.y;
+				const uint32_t cell = (uint32_t)((cz * ny + cy) * nx + cx);
+				j = cstart[cell]; jend = cstart[cell + 1];
 				if (++cx > x1) { cx = x0; if (++cy > y1) { cy = y0; if (++cz > z1) more_cells = false; } }
 			}
 			if (!__any(have)) break;
@@ -384,7 +429,7 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 // covers instead of every small collider testing every large one (124 slabs x 1 M boxes = 1.2e8 tests otherwise).
 #define LP_SLICES 16
 __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ st, const float4* __restrict__ smin, const float4* __restrict__ smax,
-                                                     const uint2* __restrict__ cells, const uint32_t* __restrict__ large_list,
+                                                     const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
                                                      const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
                                                      const uint64_t* __restrict__ mkey, const uint64_t* __restrict__ smk, uint2* __restrict__ pairs, uint32_t pair_cap) {
 	const float inv = st->cell_inv;
@@ -410,8 +455,8 @@ __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ s
 			uint32_t j = 0, jend = 0;
 			if (ci < ncell) {
 				uint32_t cx = ci % wx, cy = (ci / wx) % wy, cz = ci / (wx * wy);
-				uint2 range = cells[((z0 + (int)cz) * ny + (y0 + (int)cy)) * nx + (x0 + (int)cx)];
-				j = range.x; jend = range.y;
+				const uint32_t cell = (uint32_t)(((z0 + (int)cz) * ny + (y0 + (int)cy)) * nx + (x0 + (int)cx));
+				j = cstart[cell]; jend = cstart[cell + 1];
 			}
 			while (__ballot(j < jend)) {
 				bool have = j < jend;
@@ -810,7 +855,8 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	if (want > (1u << 24)) want = 1u << 24;
 	const uint32_t max_cells = (uint32_t)want;
 	int cell_bits = 0; while ((1ull << cell_bits) < want) ++cell_bits;
-	uint2* cells = nh_arena_array<uint2>(A, max_cells, &err);
+	uint32_t* cstart = nh_arena_array<uint32_t>(A, (size_t)max_cells + 8, &err);          // per-cell counts -> starts (+ sentinel)
+	uint32_t* cscan_sums = nh_arena_array<uint32_t>(A, max_cells / CS_TILE + 8, &err);
 	const uint32_t overflow_cap = cap;
 	uint2* pairs = nh_arena_array<uint2>(A, pair_cap, &err);
 	nh_Contact* raw_data = nh_arena_array<nh_Contact>(A, (size_t)4 * pair_cap + overflow_cap, &err);
@@ -846,15 +892,15 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "grid_params", k_grid_params, 1, 64, st, C, max_cells);
 		NH_LAUNCH(ctx, "small_bounds", k_small_bounds, nh_grid_for(C, 256, 1024), 256, st, C, aabb_min, aabb_max);
 		NH_LAUNCH(ctx, "grid_dims", k_grid_dims, 1, 64, st, max_cells);
-		NH_LAUNCH(ctx, "cell_keys", k_cell_keys, nh_grid_for(C, 256, 2048), 256, st, C, aabb_min, aabb_max, keys_a, vals_a, mkey, large_list);
-		if (onesweep ? nh_onesweep_u32_u32(ctx, keys_a, keys_b, vals_a, vals_b, &st->colliders, C, C, hist, 0, ((cell_bits + 7) / 8) * 8)
-		             : nh_sort_u32_u32(ctx, keys_a, keys_b, vals_a, vals_b, &st->colliders, hist, 0, ((cell_bits + 7) / 8) * 8)) { uint32_t* t = keys_a; keys_a = keys_b; keys_b = t; t = vals_a; vals_a = vals_b; vals_b = t; }
 		if (ctx->timing) nh_timer_begin(ctx, "memset_cells");
-		NH_HIP_CHECK(ctx, hipMemsetAsync(cells, 0, sizeof(uint2) * (size_t)max_cells, s));
+		NH_HIP_CHECK(ctx, hipMemsetAsync(cstart, 0, sizeof(uint32_t) * ((size_t)max_cells + 1), s));
 		if (ctx->timing) nh_timer_end(ctx);
-		NH_LAUNCH(ctx, "cell_bounds", k_cell_bounds, nh_grid_for(C, 256, 2048), 256, C, keys_a, vals_a, aabb_min, aabb_max, cells, smin, smax, mkey, smk);
-		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 1024), 256, st, C, keys_a, smin, smax, cells, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap);
-		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, 2048, 256, st, smin, smax, cells, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap);
+		NH_LAUNCH(ctx, "cell_keys", k_cell_keys, nh_grid_for(C, 256, 2048), 256, st, C, aabb_min, aabb_max, keys_a, vals_a, mkey, large_list, cstart);
+		NH_LAUNCH(ctx, "cell_scan", k_cscan_sums, max_cells / CS_TILE, 256, cstart, cscan_sums);
+		NH_LAUNCH(ctx, "cell_scan", k_cscan_final, max_cells / CS_TILE, 256, cstart, cscan_sums, max_cells);
+		NH_LAUNCH(ctx, "cell_scatter", k_cell_scatter, nh_grid_for(C, 256, 2048), 256, st, C, keys_a, vals_a, cstart, aabb_min, aabb_max, keys_b, smin, smax, mkey, smk);
+		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 1024), 256, st, C, keys_b, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap);
+		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, 2048, 256, st, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap);
 		NH_LAUNCH(ctx, "narrowphase", k_narrowphase, nh_grid_for(pair_cap, 256, 4096), 256, st, pairs, xf, ctag,
 		          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a);
 	}
