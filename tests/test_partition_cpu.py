@@ -105,12 +105,14 @@ def _gloo_worker(rank, world, port, steps, out_path):
     dist.destroy_process_group()
 
 
-def test_two_gloo_ranks_match_single_world(tmp_path):
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_ranks_match_single_world(tmp_path, world):
+    """world = 3: the middle rank talks to two neighbours (the shape every rank but the first and last has on 8 GPUs)."""
     import torch.multiprocessing as mp
     steps = 200
     out = str(tmp_path / "gathered.npz")
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_gloo_worker, args=(2, port, steps, out), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.spawn(_gloo_worker, args=(world, port, steps, out), nprocs=world, join=True)
     z = np.load(out)
     assert int(z["ghosts"]) > 0
     _check_against_single_world(_drop_scene(), dict(ids=z["ids"], transforms=z["transforms"], momentum=z["momentum"]), steps)
