@@ -289,6 +289,55 @@ def stacks(n_stacks=64, height=3, seed=5, iterations=8):
                      params, name=f"stacks{n_stacks}x{height}")
 
 
+def compound(n_bodies=150, seed=6, iterations=8):
+    """Compound bodies (nudge.h:34-38: a collider transform is LOCAL to its body, `body` names the owner; composed at
+    nudge.cpp:3021-3079): every dynamic body carries two rotated, offset boxes and an offset sphere, dropped in two layers so
+    that they also land on each other.  Pairs of colliders of one body never collide (nudge.cpp:3683)."""
+    f = np.float32
+    n = n_bodies
+    d = _draws(0x9E3779B97F4A7C15 ^ seed, n)
+    st = _identity_transforms(1)
+    st["position"][0] = (0.0, -20.0, 0.0)
+    ssz = np.array([[400.0, 10.0, 400.0]], dtype=np.float32)
+    side = int(np.ceil(np.sqrt((n + 1) // 2)))
+    cell = np.arange(n) // 2
+    layer = np.arange(n) % 2
+    yaw = d[:, 5] * f(3.0)
+    bt = _identity_transforms(n)
+    bt["position"][:, 0] = (cell % side).astype(np.float32) * f(2.6) + d[:, 3] * f(0.4)
+    bt["position"][:, 1] = f(-10.0) + f(1.0) + d[:, 4] * f(0.5) + layer.astype(np.float32) * f(2.2)
+    bt["position"][:, 2] = (cell // side).astype(np.float32) * f(2.6) + d[:, 6] * f(0.4)
+    bt["rotation"][:, 1] = np.sin(yaw * f(0.5))
+    bt["rotation"][:, 3] = np.cos(yaw * f(0.5))
+    bp = _box_properties(np.full(n, 1.1, np.float32), np.full(n, 0.5, np.float32), np.full(n, 0.4, np.float32))
+    empty_t = _identity_transforms(0)
+    params = dict(DEFAULT_PARAMS, iterations=iterations)
+    scene = _assemble((st, ssz), (bt, np.zeros((n, 3), np.float32), bp), (empty_t, np.zeros(0, np.float32), np.zeros(0, PROPERTIES)),
+                      params, name=f"compound{n}")
+    owner = np.arange(1, n + 1, dtype=np.uint32)
+    # two boxes per body: A at (-0.6, 0, 0) turned 0.3 rad about z, B at (+0.6, 0.1, 0) turned 0.5 rad about y
+    box_t = _identity_transforms(1 + 2 * n)
+    box_t[0] = st[0]
+    box_t["body"][1::2] = owner
+    box_t["body"][2::2] = owner
+    box_t["position"][1::2] = (-0.6, 0.0, 0.0)
+    box_t["rotation"][1::2] = (0.0, 0.0, np.sin(f(0.15)), np.cos(f(0.15)))
+    box_t["position"][2::2] = (0.6, 0.1, 0.0)
+    box_t["rotation"][2::2] = (0.0, np.sin(f(0.25)), 0.0, np.cos(f(0.25)))
+    box_d = np.zeros(1 + 2 * n, dtype=BOX)
+    box_d["size"][0] = ssz[0]
+    box_d["size"][1::2] = np.stack([d[:, 0] * f(0.2) + f(0.4), np.full(n, 0.3, np.float32), np.full(n, 0.3, np.float32)], axis=1)
+    box_d["size"][2::2] = np.stack([np.full(n, 0.3, np.float32), d[:, 1] * f(0.2) + f(0.4), np.full(n, 0.3, np.float32)], axis=1)
+    sph_t = _identity_transforms(n)
+    sph_t["body"] = owner
+    sph_t["position"][:] = (0.0, 0.6, 0.2)
+    sph_d = np.zeros(n, dtype=SPHERE)
+    sph_d["radius"] = d[:, 2] * f(0.1) + f(0.3)
+    scene.update(box_tags=np.arange(1 + 2 * n, dtype=np.uint32), box_data=box_d, box_transforms=box_t,
+                 sphere_tags=np.arange(1 + 2 * n, 1 + 3 * n, dtype=np.uint32), sphere_data=sph_d, sphere_transforms=sph_t)
+    return scene
+
+
 def narrow_ok(scene) -> bool:
     """True if the scene fits the reference's 16-bit API limits (nudge.cpp:3010, nudge.h:69-70)."""
     c = len(scene["box_tags"]) + len(scene["sphere_tags"])

@@ -25,6 +25,8 @@ CASES = {
     "mixed20": (S.grid_tiles, dict(n_tiles=1, side=20, sphere_fraction=0.5, seed=7), 200),
     "pit6": (S.ball_pit, dict(nx=6, ny=6, nz=6, seed=4), 150),
     "stacks": (S.stacks, dict(n_stacks=25, height=3, seed=5), 100),
+    # compound bodies: two offset, rotated boxes + an offset sphere per body (local collider transforms, same-body pairs)
+    "compound": (S.compound, dict(n_bodies=150, seed=6), 330),
 }
 
 
@@ -41,7 +43,7 @@ def build(name):
 
 
 def main():
-    for name in CASES:
+    for name in (sys.argv[1:] or CASES):
         scene, steps = build(name)
         w = RefWorld(scene, variant="exact")
         w.step(steps)

@@ -65,7 +65,7 @@ def test_oracle_reproduces_golden(name):
 
 
 # ---- kernel arithmetic (host build of nh_*.h) vs the compiled reference, bit for bit ------------------------------
-COLLIDE_CASES = [("pile256", 0), ("pile256", 300), ("pile_mixed", 300), ("grid30", 70), ("mixed20", 80), ("pit6", 120), ("stacks", 60)]
+COLLIDE_CASES = [("pile256", 0), ("pile256", 300), ("pile_mixed", 300), ("grid30", 70), ("mixed20", 80), ("pit6", 120), ("stacks", 60), ("compound", 200)]
 
 
 @needs_ref
@@ -85,7 +85,7 @@ def test_narrowphase_math_bit_exact(name, warm):
 
 
 @needs_ref
-@pytest.mark.parametrize("name,warm", [("pile256", 350), ("pile_mixed", 400), ("grid30", 70), ("mixed20", 80), ("pit6", 150), ("stacks", 60)])
+@pytest.mark.parametrize("name,warm", [("pile256", 350), ("pile_mixed", 400), ("grid30", 70), ("mixed20", 80), ("pit6", 150), ("stacks", 60), ("compound", 200)])
 def test_solver_math_bit_exact(name, warm):
     scene, _ = G.build(name)
     p = scene["params"]

@@ -84,7 +84,7 @@ def test_run_to_run_determinism():
 
 # ---- against the compiled reference, stage by stage -----------------------------------------------------------------
 @needs_ref
-@pytest.mark.parametrize("name,warm", [("pile256", 0), ("pile256", 300), ("pile_mixed", 300), ("grid30", 70), ("mixed20", 80), ("pit6", 120), ("stacks", 60)])
+@pytest.mark.parametrize("name,warm", [("pile256", 0), ("pile256", 300), ("pile_mixed", 300), ("grid30", 70), ("mixed20", 80), ("pit6", 120), ("stacks", 60), ("compound", 200)])
 def test_collide_matches_reference(name, warm):
     scene, _ = G.build(name)
     ref = refworld.RefWorld(scene)
@@ -104,7 +104,7 @@ def test_collide_matches_reference(name, warm):
 
 
 @needs_ref
-@pytest.mark.parametrize("name,warm,steps", [("pile256", 300, 40), ("pit6", 100, 40), ("stacks", 20, 60), ("pile_mixed", 380, 40)])
+@pytest.mark.parametrize("name,warm,steps", [("pile256", 300, 40), ("pit6", 100, 40), ("stacks", 20, 60), ("pile_mixed", 380, 40), ("compound", 150, 60)])
 def test_exact_order_steps_match_reference_on_piles(name, warm, steps):
     """Chaotic scenes: short horizon, but bit for bit, warm start and cache included."""
     scene, _ = G.build(name)
