@@ -19,6 +19,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "gol
 import callsite_util as CU      # noqa: E402
 import make_golden as G         # noqa: E402
 import parity_util as P         # noqa: E402
+from nudge_amd import scenes as S   # noqa: E402
 from oracle import refworld     # noqa: E402
 
 
@@ -36,12 +37,20 @@ def test_replay_call_site_is_the_reference_step_loop(tmp_path):
     assert P.bits_equal(r["idle"], fx["idle"])
 
 
+def _build(name):
+    if name == "example":
+        # the scene of the reference's sample application (example/main.cpp:390-432): 1024 boxes + 512 spheres dropped in one
+        # column, 20 solver iterations (example/main.cpp:276) -- long enough that a pile has formed
+        return S.pile(n_boxes=1024, n_spheres=512, seed=9, iterations=20), 420
+    scene, steps = G.build(name)
+    return scene, min(steps, 150)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["pile256", "pile_mixed", "mixed20", "stacks", "pit6"])
+@pytest.mark.parametrize("name", ["pile256", "pile_mixed", "mixed20", "stacks", "pit6", "compound", "example"])
 def test_same_call_site_two_backends_bit_identical(name, tmp_path):
     assert os.path.exists(CU.REPLAY_HIP), "nudge_amd/compat/_build/replay_hip missing: make -C nudge_amd/compat"
-    scene, steps = G.build(name)
-    steps = min(steps, 150)
+    scene, steps = _build(name)
     nb = CU.write_scene(str(tmp_path / "s.bin"), scene)
     CU.run_replay(CU.REPLAY_HIP, str(tmp_path / "s.bin"), str(tmp_path / "hip.bin"), steps)
     got = CU.read_result(str(tmp_path / "hip.bin"), nb)
