@@ -937,7 +937,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	if (key_bits > 32) key_bits = 32;
 	// keys are a | b<<32: sort the low field, then the high field (stable) -- dropped records carry ~0 and end up last
 	if (onesweep) {
-		if (nh_onesweep_u64_u32_two_fields(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, &st->records, pair_cap, ctx->h_state->records, hist, 0, ((key_bits + 7) / 8) * 8, 32, 32 + ((key_bits + 7) / 8) * 8)) {
+		if (nh_onesweep_u64_u32_two_fields(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, &st->records, pair_cap, ctx->h_state->records, hist, key_bits)) {
 			uint64_t* t = rec_key_a; rec_key_a = rec_key_b; rec_key_b = t; uint32_t* u = rec_idx_a; rec_idx_a = rec_idx_b; rec_idx_b = u;
 		}
 	} else {

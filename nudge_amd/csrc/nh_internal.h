@@ -219,7 +219,7 @@ size_t nh_sort_scratch_words(uint32_t capacity);
 int nh_onesweep_u32_u32(nh_context* ctx, uint32_t* keys_a, uint32_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                          const uint32_t* d_count, uint32_t capacity, uint32_t expected, uint32_t* scratch, int begin_bit, int end_bit);
 int nh_onesweep_u64_u32_two_fields(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
-                                    const uint32_t* d_count, uint32_t capacity, uint32_t expected, uint32_t* scratch, int lo_begin, int lo_end, int hi_begin, int hi_end);
+                                    const uint32_t* d_count, uint32_t capacity, uint32_t expected, uint32_t* scratch, int field_bits);
 // Exclusive scan of `in[0..n)` into `out` (may alias); n read from *d_count (+ `extra` elements);
 // the grand total is also stored to *d_total if non-null.  `tmp` needs 2 * NH_SORT_GRID words.
 // If `d_enable` is given and *d_enable == 0 the scan is skipped on the device (the total is reported as 0).

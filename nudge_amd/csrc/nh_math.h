@@ -42,6 +42,39 @@ NH_HD float nh_msub(float x, float y, float z) { return __builtin_fmaf(x, y, -z)
 NH_HD float nh_rsqrt(float x) { return 1.0f / sqrtf(x); }                               // exact stand-in for nudge.cpp:296-298
 NH_HD float nh_recip(float x) { return 1.0f / x; }                                      // exact stand-in for nudge.cpp:300-302
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Short device sequence for 1/sqrt(x): hardware estimates + one fused correction each.  Whenever the `_ok` predicate holds for
+// the short result it IS the correctly rounded value (= nh_rsqrt, bit for bit) -- verified over all 2^32 inputs by
+// tests/fastmath/exhaustive.hip -- so the guarded form takes the exact form only when some lane's result falls outside (zero,
+// negative, non-finite arguments): same bits as nh_rsqrt, a third of the instructions.  Used where reciprocal roots are dense and
+// off the critical dependency chain (narrowphase edge axes); the solver sweeps keep the exact forms (measured: no gain there).
+__device__ __forceinline__ float nh_recip_fast(float x) {
+	float r = __builtin_amdgcn_rcpf(x);
+	float e = __builtin_fmaf(-x, r, 1.0f);
+	return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ bool nh_recip_fast_ok(float r) { return __builtin_amdgcn_classf(r, 0x108 /* -normal | +normal */); }
+__device__ __forceinline__ float nh_rsqrt_fast(float x) {
+	// arguments below 2^-64 are scaled by 2^64 so that the correction term stays a normal number; both scalings are exact
+	const bool small = x < 5.421010862427522e-20f;
+	const float xs = small ? x * 18446744073709551616.0f : x;
+	float y = __builtin_amdgcn_rsqf(xs);
+	float s = xs * y;                                     // sqrt(xs) estimate, then RN(sqrt(xs))
+	float e = __builtin_fmaf(-s, s, xs);
+	s = __builtin_fmaf(e, 0.5f * y, s);
+	s = small ? s * 2.3283064365386963e-10f : s;
+	return nh_recip_fast(s);
+}
+__device__ __forceinline__ bool nh_rsqrt_fast_ok(float r) { return __builtin_amdgcn_classf(r, 0x100 /* +normal */); }
+__device__ __forceinline__ float nh_rsqrt_guarded(float x) {
+	float r = nh_rsqrt_fast(x);
+	if (__builtin_expect(__builtin_amdgcn_ballot_w64(!nh_rsqrt_fast_ok(r)) != 0, 0)) r = nh_rsqrt(x);
+	return r;
+}
+#else
+NH_HD float nh_rsqrt_guarded(float x) { return nh_rsqrt(x); }
+#endif
+
 // x86 cvttps2dq semantics (nudge.cpp:336-338): truncate; out of range or NaN -> 0x80000000.
 NH_HD int32_t nh_toint(float x) {
 	if (!(x > -2147483904.0f && x < 2147483648.0f)) return (int32_t)0x80000000u;

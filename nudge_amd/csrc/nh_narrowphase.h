@@ -186,7 +186,7 @@ NH_HD void nh_box_box_edge(const nh_xform& A, const nh_xform& B, const float* sa
 	out->py = (cay - cby) * 0.5f + uy * s_a + vy * s_b;
 	out->pz = (caz - cbz) * 0.5f + uz * s_a + vz * s_b;
 
-	float f = nh_rsqrt(nx * nx + ny * ny + nz * nz);
+	float f = nh_rsqrt_guarded(nx * nx + ny * ny + nz * nz);
 	out->nx = nx * f; out->ny = ny * f; out->nz = nz * f;
 	out->penetration = penetration;
 	out->friction = 0.5f;
@@ -270,12 +270,12 @@ NH_HD void nh_box_box_eval(nh_xform A, nh_xform B, const float* size_a, const fl
 			const float nan_threshold = 1e-3f;
 			// rsqrt OR all-ones when r <= threshold -> NaN (nudge.cpp:1613-1619)
 			const float qnan = nh_asfloat(0xffffffffu);
-			r_a0 = (r_a0 <= nan_threshold) ? qnan : nh_rsqrt(r_a0);
-			r_a1 = (r_a1 <= nan_threshold) ? qnan : nh_rsqrt(r_a1);
-			r_a2 = (r_a2 <= nan_threshold) ? qnan : nh_rsqrt(r_a2);
-			r_b0 = (r_b0 <= nan_threshold) ? qnan : nh_rsqrt(r_b0);
-			r_b1 = (r_b1 <= nan_threshold) ? qnan : nh_rsqrt(r_b1);
-			r_b2 = (r_b2 <= nan_threshold) ? qnan : nh_rsqrt(r_b2);
+			r_a0 = (r_a0 <= nan_threshold) ? qnan : nh_rsqrt_guarded((r_a0 <= nan_threshold) ? 1.0f : r_a0);
+			r_a1 = (r_a1 <= nan_threshold) ? qnan : nh_rsqrt_guarded((r_a1 <= nan_threshold) ? 1.0f : r_a1);
+			r_a2 = (r_a2 <= nan_threshold) ? qnan : nh_rsqrt_guarded((r_a2 <= nan_threshold) ? 1.0f : r_a2);
+			r_b0 = (r_b0 <= nan_threshold) ? qnan : nh_rsqrt_guarded((r_b0 <= nan_threshold) ? 1.0f : r_b0);
+			r_b1 = (r_b1 <= nan_threshold) ? qnan : nh_rsqrt_guarded((r_b1 <= nan_threshold) ? 1.0f : r_b1);
+			r_b2 = (r_b2 <= nan_threshold) ? qnan : nh_rsqrt_guarded((r_b2 <= nan_threshold) ? 1.0f : r_b2);
 			float pa0 = aacy * sa[2] + aacz * sa[1];
 			float pa1 = aacz * sa[0] + aacx * sa[2];
 			float pa2 = aacx * sa[1] + aacy * sa[0];

@@ -147,6 +147,15 @@ static int sort_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* vals_b
 #define OS_VALUE_MASK 0x7FFFFFFFu
 #define OS_PASS_WORDS ((OS_MAX_GRID + OS_MAX_GRID / OS_GROUP) * 256)
 
+// a pass descriptor: digit = ((key >> s0) & (2^b0 - 1)) | ((key >> s1) << b0) & 255 -- s0 | b0 << 8 | s1 << 16.  b0 = 8 is the plain
+// byte at s0; b0 < 8 glues the top bits of one key field to the low bits of the next (nh_onesweep_u64_u32_two_fields)
+#define OS_DESC(s0, b0, s1) ((s0) | ((b0) << 8) | ((s1) << 16))
+template<typename K>
+__device__ __forceinline__ uint32_t os_digit(K key, int desc) {
+	const int s0 = desc & 255, b0 = (desc >> 8) & 255, s1 = (desc >> 16) & 255;
+	return ((uint32_t)(key >> s0) & ((1u << b0) - 1u)) | (((uint32_t)(key >> s1) << b0) & 255u);
+}
+
 struct os_shifts { int s[OS_MAX_PASSES]; int n; };
 
 size_t nh_sort_scratch_words(uint32_t capacity) { (void)capacity; return (size_t)OS_MAX_PASSES * OS_PASS_WORDS; }
@@ -178,7 +187,7 @@ __device__ __forceinline__ void os_rank_tile(const K (&key)[OS_KPT], uint32_t ti
 	for (int q = 0; q < OS_KPT; ++q) {
 		uint32_t i = tile_begin + wave * (64u * OS_KPT) + q * 64u + lane;
 		bool valid = i < n;
-		uint32_t d = (uint32_t)(key[q] >> shift) & 255u;
+		uint32_t d = os_digit<K>(key[q], shift);
 		dig[q] = d;
 		unsigned long long mask = __ballot(valid);
 #pragma unroll
@@ -333,7 +342,7 @@ static int onesweep_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* va
 }
 
 static os_shifts shifts_for(int begin_bit, int end_bit, os_shifts sh = os_shifts{ {}, 0 }) {
-	for (int s = begin_bit; s < end_bit && sh.n < OS_MAX_PASSES; s += 8) sh.s[sh.n++] = s;
+	for (int s = begin_bit; s < end_bit && sh.n < OS_MAX_PASSES; s += 8) sh.s[sh.n++] = OS_DESC(s, 8, 0);
 	return sh;
 }
 
@@ -342,10 +351,17 @@ int nh_onesweep_u32_u32(nh_context* ctx, uint32_t* keys_a, uint32_t* keys_b, uin
 	return onesweep_impl<uint32_t, uint32_t, true>(ctx, keys_a, keys_b, vals_a, vals_b, d_count, capacity, expected, scratch, shifts_for(begin_bit, end_bit));
 }
 
-// sorts by bits [lo_begin, lo_end) first, then (stable) by bits [hi_begin, hi_end): one histogram kernel for all passes
+// sorts 64-bit keys made of two `bits`-wide fields, one at bit 0 and one at bit 32, by (high field, low field): the 2 x bits
+// significant bits are consumed eight at a time as if the fields were adjacent, so 20-bit fields take 5 passes, not 6
 int nh_onesweep_u64_u32_two_fields(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
-                                    const uint32_t* d_count, uint32_t capacity, uint32_t expected, uint32_t* scratch, int lo_begin, int lo_end, int hi_begin, int hi_end) {
-	return onesweep_impl<uint64_t, uint32_t, true>(ctx, keys_a, keys_b, vals_a, vals_b, d_count, capacity, expected, scratch, shifts_for(hi_begin, hi_end, shifts_for(lo_begin, lo_end)));
+                                    const uint32_t* d_count, uint32_t capacity, uint32_t expected, uint32_t* scratch, int bits) {
+	os_shifts sh = os_shifts{ {}, 0 };
+	for (int lo = 0; lo < 2 * bits && sh.n < OS_MAX_PASSES; lo += 8) {
+		if (lo + 8 <= bits) sh.s[sh.n++] = OS_DESC(lo, 8, 0);                    // inside the low field
+		else if (lo >= bits) sh.s[sh.n++] = OS_DESC(32 + lo - bits, 8, 0);       // inside the high field
+		else sh.s[sh.n++] = OS_DESC(lo, bits - lo, 32);                          // the last bits of the low field + the first of the high
+	}
+	return onesweep_impl<uint64_t, uint32_t, true>(ctx, keys_a, keys_b, vals_a, vals_b, d_count, capacity, expected, scratch, sh);
 }
 
 __global__ __launch_bounds__(256) void k_copy_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const uint32_t* __restrict__ d_n, uint32_t words_per_item) {

@@ -18,7 +18,8 @@ import numpy as np
 from . import scenes as S
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libnudge_hip.so")
+# NUDGE_HIP_LIBRARY: another build of the same library (A/B timing of kernel variants on one box)
+_LIB_PATH = os.environ.get("NUDGE_HIP_LIBRARY") or os.path.join(_HERE, "libnudge_hip.so")
 _LIB = None
 
 NH_FLAG_SYNC_COUNTS = 1
