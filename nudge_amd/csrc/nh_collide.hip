@@ -806,6 +806,7 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 		st->colliders = ncolliders; st->pairs = 0; st->raw_contacts = 0; st->records = 0; st->contacts = 0; st->sleeping = 0;
 		st->active = 0; st->culled = 0; st->large = 0; st->general_contacts = 0; st->levels = 0; st->error = 0;
 		st->static_bodies = 0; st->unleveled = 0; st->has_static8 = 0; st->has_staticN = 0; st->any_sleeping = 0; st->has_pending = 0;
+		st->sort_buckets = st->sort_buckets_next;
 		for (int k = 0; k < 3; ++k) { st->smin[k] = 0xffffffffu; st->smax[k] = 0u; st->gmin[k] = 0xffffffffu; st->gmax[k] = 0u; }
 	}
 	for (uint32_t k = t; k < 1024u; k += blockDim.x) st->exp_hist[k] = 0;
@@ -866,6 +867,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	uint32_t* rec_idx_a = nh_arena_array<uint32_t>(A, pair_cap, &err);
 	uint32_t* rec_idx_b = nh_arena_array<uint32_t>(A, pair_cap, &err);
 	nh_Record* rec = nh_arena_array<nh_Record>(A, pair_cap, &err);
+	uint2* sort_place = nh_arena_array<uint2>(A, pair_cap, &err);
 	uint32_t* rec_counts = nh_arena_array<uint32_t>(A, pair_cap + 1, &err);
 	uint32_t* sleep_flags = nh_arena_array<uint32_t>(A, pair_cap + 1, &err);
 	uint32_t* parent = nh_arena_array<uint32_t>(A, B, &err);
@@ -882,6 +884,19 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		ctx->deg = nullptr; ctx->deg_capacity = 0;
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->deg, sizeof(uint32_t) * 4u * ((size_t)B + 2u)));
 		ctx->deg_capacity = 4u * (B + 2u);
+	}
+	if (ctx->sort_capacity != pair_cap) {
+		// library-owned: splitters of the seeded tag sort (they persist from one nh_collide to the next) + its bucket counters
+		if (ctx->sort_splitters) NH_HIP_CHECK(ctx, hipFree(ctx->sort_splitters));
+		if (ctx->sort_counts) NH_HIP_CHECK(ctx, hipFree(ctx->sort_counts));
+		if (ctx->sort_starts) NH_HIP_CHECK(ctx, hipFree(ctx->sort_starts));
+		ctx->sort_splitters = nullptr; ctx->sort_counts = nullptr; ctx->sort_starts = nullptr; ctx->sort_capacity = 0; ctx->sort_seeded = false;
+		const size_t nbk = (size_t)nh_bucket_sort_max_buckets(pair_cap) + 1u;
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sort_splitters, sizeof(uint64_t) * nbk));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sort_counts, sizeof(uint32_t) * nbk));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sort_starts, sizeof(uint32_t) * nbk));
+		NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->sort_counts, 0, sizeof(uint32_t) * nbk, s));
+		ctx->sort_capacity = pair_cap;
 	}
 	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, nh_grid_for(B, 256, 2048), 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity);
 	if (C) {
@@ -908,7 +923,8 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	// on -- it runs on the side stream while the caller's stream sorts (fork here, join before k_sorted_counts)
 	// (only while the side chain is small: the radix passes spin-wait on each other and must not share the machine with a long
 	// kernel -- with millions of records in one island the union-find alone takes a millisecond)
-	const bool fork = ctx->side != nullptr && ctx->h_state->records <= 1500000u;
+	const bool seeded_sort = onesweep && ctx->sort_seeded && getenv("NH_SORT_RADIX") == nullptr;      // (NH_SORT_RADIX=1: radix passes every step)
+	const bool fork = ctx->side != nullptr && (seeded_sort || ctx->h_state->records <= 1500000u);
 	hipStream_t main_stream = ctx->stream;
 	if (fork) {
 		NH_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, main_stream));
@@ -936,7 +952,9 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	if (key_bits < 1) key_bits = 1;
 	if (key_bits > 32) key_bits = 32;
 	// keys are a | b<<32: sort the low field, then the high field (stable) -- dropped records carry ~0 and end up last
-	if (onesweep) {
+	if (seeded_sort) {
+		nh_bucket_sort_u64_u32(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, pair_cap, sort_place, key_bits);
+	} else if (onesweep) {
 		if (nh_onesweep_u64_u32_two_fields(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, &st->records, pair_cap, ctx->h_state->records, hist, key_bits)) {
 			uint64_t* t = rec_key_a; rec_key_a = rec_key_b; rec_key_b = t; uint32_t* u = rec_idx_a; rec_idx_a = rec_idx_b; rec_idx_b = u;
 		}
@@ -949,6 +967,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		}
 	}
 	// (dropped records carry count 0, so where they land in the order is irrelevant)
+	if (onesweep && !seeded_sort) { nh_bucket_sort_seed(ctx, rec_key_a, pair_cap); ctx->sort_seeded = true; }
 	if (fork) NH_HIP_CHECK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
 	NH_LAUNCH(ctx, "sorted_counts", k_sorted_counts, nh_grid_for(pair_cap, 256, 2048), 256, st, rec_idx_a, rec, rec_counts, sleep_flags);
 	// contact starts and sleeping-pair slots: two scans over the sorted records in one pair of launches

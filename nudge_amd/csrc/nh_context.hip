@@ -21,6 +21,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->hint_capacity = 0;
 	ctx->deg = nullptr;
 	ctx->deg_capacity = 0;
+	ctx->sort_splitters = nullptr; ctx->sort_counts = nullptr; ctx->sort_starts = nullptr; ctx->sort_capacity = 0; ctx->sort_seeded = false;
 	ctx->step_parity = 0;
 	ctx->d_state = nullptr;
 	ctx->h_state = nullptr;
@@ -48,6 +49,9 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
 	if (ctx->hint) hipFree(ctx->hint);
 	if (ctx->deg) hipFree(ctx->deg);
+	if (ctx->sort_splitters) hipFree(ctx->sort_splitters);
+	if (ctx->sort_counts) hipFree(ctx->sort_counts);
+	if (ctx->sort_starts) hipFree(ctx->sort_starts);
 	if (ctx->d_state) hipFree(ctx->d_state);
 	if (ctx->h_state) hipHostFree(ctx->h_state);
 	delete ctx;

@@ -60,6 +60,8 @@ struct nh_DevState {
 	uint32_t redo_small;          // the guess was wrong: k_small_bounds recomputes gmin/gmax
 	uint32_t exp_hist[1024];      // histogram of size classes
 	uint32_t any_idle[2];         // by step parity: some body's idle counter is saturated (asleep)
+	uint32_t sort_buckets;        // buckets of this step's tag sort = splitters of the previous step + 1 (nh_util.hip, bucket sort)
+	uint32_t sort_buckets_next;   // written by this step's sort for the next one
 };
 
 struct nh_TimerSlot { const char* name; hipEvent_t a, b; };
@@ -95,6 +97,13 @@ struct nh_context {
 	uint32_t* deg;
 	uint32_t deg_capacity;
 	uint32_t step_parity;
+	// tag sort seeded by the previous step's order (nh_util.hip): splitters persist across steps; counts / starts are scratch that must
+	// outlive nothing but is zeroed by its own kernels.  `sort_seeded`: the splitters describe the previous nh_collide of this capacity
+	uint64_t* sort_splitters;
+	uint32_t* sort_counts;
+	uint32_t* sort_starts;
+	uint32_t sort_capacity;
+	bool sort_seeded;
 	// fork/join inside one entry point: independent kernel chains run on `side` while the caller's stream does the long one
 	hipStream_t side;
 	hipEvent_t ev_fork, ev_join;
@@ -220,6 +229,10 @@ int nh_onesweep_u32_u32(nh_context* ctx, uint32_t* keys_a, uint32_t* keys_b, uin
                          const uint32_t* d_count, uint32_t capacity, uint32_t expected, uint32_t* scratch, int begin_bit, int end_bit);
 int nh_onesweep_u64_u32_two_fields(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                                     const uint32_t* d_count, uint32_t capacity, uint32_t expected, uint32_t* scratch, int field_bits);
+// Tag sort of st->records (key, value) pairs seeded by the previous step's result (see nh_util.hip).  Sorted data ends in keys_a / vals_a.
+uint32_t nh_bucket_sort_max_buckets(uint32_t capacity);
+void nh_bucket_sort_u64_u32(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t capacity, uint2* place, int field_bits);
+void nh_bucket_sort_seed(nh_context* ctx, const uint64_t* sorted_keys, uint32_t capacity);
 // Exclusive scan of `in[0..n)` into `out` (may alias); n read from *d_count (+ `extra` elements);
 // the grand total is also stored to *d_total if non-null.  `tmp` needs 2 * NH_SORT_GRID words.
 // If `d_enable` is given and *d_enable == 0 the scan is skipped on the device (the total is reported as 0).

@@ -353,15 +353,283 @@ int nh_onesweep_u32_u32(nh_context* ctx, uint32_t* keys_a, uint32_t* keys_b, uin
 
 // sorts 64-bit keys made of two `bits`-wide fields, one at bit 0 and one at bit 32, by (high field, low field): the 2 x bits
 // significant bits are consumed eight at a time as if the fields were adjacent, so 20-bit fields take 5 passes, not 6
-int nh_onesweep_u64_u32_two_fields(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
-                                    const uint32_t* d_count, uint32_t capacity, uint32_t expected, uint32_t* scratch, int bits) {
+static os_shifts two_field_shifts(int bits) {
 	os_shifts sh = os_shifts{ {}, 0 };
 	for (int lo = 0; lo < 2 * bits && sh.n < OS_MAX_PASSES; lo += 8) {
 		if (lo + 8 <= bits) sh.s[sh.n++] = OS_DESC(lo, 8, 0);                    // inside the low field
 		else if (lo >= bits) sh.s[sh.n++] = OS_DESC(32 + lo - bits, 8, 0);       // inside the high field
 		else sh.s[sh.n++] = OS_DESC(lo, bits - lo, 32);                          // the last bits of the low field + the first of the high
 	}
-	return onesweep_impl<uint64_t, uint32_t, true>(ctx, keys_a, keys_b, vals_a, vals_b, d_count, capacity, expected, scratch, sh);
+	return sh;
+}
+
+int nh_onesweep_u64_u32_two_fields(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+                                    const uint32_t* d_count, uint32_t capacity, uint32_t expected, uint32_t* scratch, int bits) {
+	return onesweep_impl<uint64_t, uint32_t, true>(ctx, keys_a, keys_b, vals_a, vals_b, d_count, capacity, expected, scratch, two_field_shifts(bits));
+}
+
+// ---- tag sort seeded by the previous step's order ---------------------------------------------------------------------------
+// Contact records barely change from one step to the next, so last step's sorted keys are near-perfect SPLITTERS for this
+// step's: every BK_TARGET-th key of the previous result bounds a bucket that again receives about BK_TARGET keys.  Four
+// kernels without any workgroup waiting for another (the radix passes above are chains of grid-wide hand-offs):
+//   bk_count    bucket of every key (binary search over the splitters, held in LDS) + its arrival rank in the bucket
+//   bk_scan     bucket starts (one workgroup)
+//   bk_scatter  keys / values to their bucket
+//   bk_sort     one workgroup per bucket: LSD radix sort in registers + LDS (a bucket of up to 2048 keys = one tile of the
+//               ranking primitive above), written out in place; also emits the splitters of the next step
+// Any distribution is sorted correctly: a bucket larger than a tile is sorted by its workgroup through global memory (slow,
+// only seen when the world changes abruptly); with no history (first step, capacity change) the radix passes run instead and
+// seed the splitters.  Keys are unique (one record per collider pair), so the arrival order inside a bucket never shows.
+#define BK_TARGET 1024u
+#define BK_LDS_SPLITTERS 4096u
+
+__global__ __launch_bounds__(256) void bk_count(const uint64_t* __restrict__ keys, const nh_DevState* __restrict__ st, const uint64_t* __restrict__ splitters,
+                                                uint2* __restrict__ place, uint32_t* __restrict__ counts) {
+	__shared__ uint64_t s_spl[BK_LDS_SPLITTERS];
+	const uint32_t n = st->records;
+	const uint32_t nb = st->sort_buckets ? st->sort_buckets : 1u, ns = nb - 1u;
+	const bool in_lds = ns <= BK_LDS_SPLITTERS;
+	if (in_lds) {
+		for (uint32_t k = threadIdx.x; k < ns; k += 256) s_spl[k] = splitters[k];
+		__syncthreads();
+	}
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t nbits = 32u - (uint32_t)__clz(nb);             // bucket ids are < 2^nbits
+	const uint32_t rounded = (n + 63u) & ~63u;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
+		const bool valid = i < n;
+		const uint64_t key = valid ? keys[i] : 0ull;
+		uint32_t lo = 0, hi = ns;                          // bucket = number of splitters <= key
+		if (in_lds) { while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (s_spl[mid] <= key) lo = mid + 1; else hi = mid; } }
+		else        { while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (splitters[mid] <= key) lo = mid + 1; else hi = mid; } }
+		const uint32_t b = lo;
+		// neighbouring records usually share a bucket (and arrive in waves that hammer the same few counters): lanes with equal
+		// buckets find each other by ballots over the bucket bits, and the lowest lane of every group does ONE atomic for it
+		unsigned long long m = __ballot(valid);
+		for (uint32_t bit = 0; bit < nbits; ++bit) {
+			const unsigned long long bal = __ballot((b >> bit) & 1u);
+			m &= ((b >> bit) & 1u) ? bal : ~bal;
+		}
+		uint32_t rank = 0;
+		{
+			const int leader = valid ? __ffsll((long long)m) - 1 : (int)lane;
+			uint32_t base = 0;
+			if (valid && (int)lane == leader) base = atomicAdd(&counts[b], (uint32_t)__popcll(m));
+			base = (uint32_t)__shfl((int)base, leader);
+			rank = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+		}
+		if (valid) place[i] = make_uint2(b, rank);
+	}
+}
+
+__global__ __launch_bounds__(1024) void bk_scan(const nh_DevState* __restrict__ st, uint32_t* __restrict__ counts, uint32_t* __restrict__ starts) {
+	__shared__ uint32_t wsum[16];
+	const uint32_t nb = st->sort_buckets ? st->sort_buckets : 1u;
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base < nb; base += 1024) {
+		const uint32_t i = base + threadIdx.x;
+		const uint32_t v = i < nb ? counts[i] : 0u;
+		if (i < nb) counts[i] = 0;                              // ready for the next step
+		uint32_t x = v;
+		for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d); if ((int)lane >= d) x += y; }
+		if (lane == 63) wsum[wave] = x;
+		__syncthreads();
+		uint32_t woff = 0, total = 0;
+		for (uint32_t w = 0; w < 16; ++w) { if (w < wave) woff += wsum[w]; total += wsum[w]; }
+		if (i < nb) starts[i] = carry + woff + x - v;
+		carry += total;
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) starts[nb] = carry;
+}
+
+__global__ __launch_bounds__(256) void bk_scatter(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, const nh_DevState* __restrict__ st,
+                                                  const uint2* __restrict__ place, const uint32_t* __restrict__ starts, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+	const uint32_t n = st->records;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const uint2 p = place[i];
+		const uint32_t pos = starts[p.x] + p.y;
+		keys_out[pos] = keys[i];
+		vals_out[pos] = vals[i];
+	}
+}
+
+// digit totals of the workgroup (whist summed over its four waves) -> exclusive bases in offs[]
+__device__ __forceinline__ void bk_digit_bases(const uint32_t total, uint32_t* offs, uint32_t* wtot) {
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint32_t x = total;
+	for (int k = 1; k < 64; k <<= 1) { uint32_t y = __shfl_up(x, k); if ((int)lane >= k) x += y; }
+	if (lane == 63) wtot[wave] = x;
+	__syncthreads();
+	uint32_t base = x - total;
+	for (unsigned v = 0; v < wave; ++v) base += wtot[v];
+	offs[threadIdx.x] = base;
+	__syncthreads();
+}
+
+// one LSD pass over `cnt` keys by ONE workgroup through global memory (buckets that do not fit a tile)
+__device__ void bk_pass_global(const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, uint32_t cnt, int desc,
+                               uint32_t (*whist)[256], uint32_t* offs, uint32_t* wtot) {
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	uint64_t key[OS_KPT];
+	uint32_t val[OS_KPT], dig[OS_KPT], local[OS_KPT];
+	const uint32_t ntiles = (cnt + OS_TILE - 1) / OS_TILE;
+	uint32_t mine = 0;                                          // keys of digit threadIdx.x
+	for (uint32_t t = 0; t < ntiles; ++t) {
+#pragma unroll
+		for (int q = 0; q < OS_KPT; ++q) { uint32_t i = t * OS_TILE + wave * (64u * OS_KPT) + q * 64u + lane; key[q] = i < cnt ? kin[i] : 0ull; }
+		os_rank_tile<uint64_t>(key, t * OS_TILE, cnt, desc, whist, dig, local);
+		__syncthreads();
+		mine += whist[0][threadIdx.x] + whist[1][threadIdx.x] + whist[2][threadIdx.x] + whist[3][threadIdx.x];
+		whist[0][threadIdx.x] = 0; whist[1][threadIdx.x] = 0; whist[2][threadIdx.x] = 0; whist[3][threadIdx.x] = 0;
+		__syncthreads();
+	}
+	bk_digit_bases(mine, offs, wtot);
+	for (uint32_t t = 0; t < ntiles; ++t) {
+#pragma unroll
+		for (int q = 0; q < OS_KPT; ++q) {
+			uint32_t i = t * OS_TILE + wave * (64u * OS_KPT) + q * 64u + lane;
+			key[q] = i < cnt ? kin[i] : 0ull; val[q] = i < cnt ? vin[i] : 0u;
+		}
+		os_rank_tile<uint64_t>(key, t * OS_TILE, cnt, desc, whist, dig, local);
+		__syncthreads();
+#pragma unroll
+		for (int q = 0; q < OS_KPT; ++q) {
+			uint32_t i = t * OS_TILE + wave * (64u * OS_KPT) + q * 64u + lane;
+			if (i < cnt) {
+				uint32_t pos = offs[dig[q]] + local[q];
+				for (unsigned v = 0; v < wave; ++v) pos += whist[v][dig[q]];
+				kout[pos] = key[q]; vout[pos] = val[q];
+			}
+		}
+		__syncthreads();
+		offs[threadIdx.x] += whist[0][threadIdx.x] + whist[1][threadIdx.x] + whist[2][threadIdx.x] + whist[3][threadIdx.x];
+		whist[0][threadIdx.x] = 0; whist[1][threadIdx.x] = 0; whist[2][threadIdx.x] = 0; whist[3][threadIdx.x] = 0;
+		__syncthreads();
+	}
+}
+
+__global__ __launch_bounds__(256) void bk_sort(uint64_t* kb, uint32_t* vb, uint64_t* ka, uint32_t* va,      // (no __restrict__: oversized buckets ping-pong between the two)
+                                               const uint32_t* __restrict__ starts, nh_DevState* __restrict__ st, os_shifts sh, int field_bits, uint64_t* __restrict__ splitters, uint32_t lds_cap) {
+	__shared__ uint64_t s_key[OS_TILE];
+	__shared__ uint32_t s_val[OS_TILE];
+	__shared__ uint32_t whist[4][256];
+	__shared__ uint32_t offs[256];
+	__shared__ uint32_t wtot[4];
+	__shared__ uint64_t s_ref, s_diff[4];
+	const uint32_t nb = st->sort_buckets ? st->sort_buckets : 1u;
+	const uint32_t n = st->records;
+	const uint64_t lomask = field_bits >= 32 ? 0xFFFFFFFFull : ((1ull << field_bits) - 1ull);
+	if (blockIdx.x == 0 && threadIdx.x == 0) st->sort_buckets_next = n ? (n + BK_TARGET - 1u) / BK_TARGET : 1u;
+	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	whist[0][threadIdx.x] = 0; whist[1][threadIdx.x] = 0; whist[2][threadIdx.x] = 0; whist[3][threadIdx.x] = 0;
+	__syncthreads();
+	for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+		const uint32_t s = starts[b], cnt = starts[b + 1] - s;
+		if (cnt == 0) continue;
+		if (cnt <= lds_cap) {
+			uint64_t key[OS_KPT];
+			uint32_t val[OS_KPT], dig[OS_KPT], local[OS_KPT];
+			// the two tag fields packed side by side: one plain 2 x field_bits number.  The keys of a bucket lie between two neighbouring
+			// splitters, so they agree in their high bits: only the bits in which any of them differs from the first are sorted on
+#pragma unroll
+			for (int q = 0; q < OS_KPT; ++q) {
+				uint32_t i = wave * (64u * OS_KPT) + q * 64u + lane;
+				const uint64_t k = i < cnt ? kb[s + i] : 0ull;
+				key[q] = (k & lomask) | ((k >> 32) << field_bits);
+				val[q] = i < cnt ? vb[s + i] : 0u;
+			}
+			if (threadIdx.x == 0) s_ref = key[0];
+			__syncthreads();
+			uint64_t diff = 0;
+			{
+				const uint64_t ref = s_ref;
+#pragma unroll
+				for (int q = 0; q < OS_KPT; ++q) { uint32_t i = wave * (64u * OS_KPT) + q * 64u + lane; if (i < cnt) diff |= key[q] ^ ref; }
+				for (int d = 32; d >= 1; d >>= 1) diff |= (uint64_t)__shfl_xor((long long)diff, d);
+				if (lane == 0) s_diff[wave] = diff;
+				__syncthreads();
+				diff = s_diff[0] | s_diff[1] | s_diff[2] | s_diff[3];
+			}
+			const int npass = diff ? (64 - __clzll((long long)diff) + 7) / 8 : 0;
+			for (int p = 0; p < npass; ++p) {
+				os_rank_tile<uint64_t>(key, 0u, cnt, OS_DESC(8 * p, 8, 0), whist, dig, local);
+				__syncthreads();
+				bk_digit_bases(whist[0][threadIdx.x] + whist[1][threadIdx.x] + whist[2][threadIdx.x] + whist[3][threadIdx.x], offs, wtot);
+#pragma unroll
+				for (int q = 0; q < OS_KPT; ++q) {
+					uint32_t i = wave * (64u * OS_KPT) + q * 64u + lane;
+					if (i < cnt) {
+						uint32_t pos = offs[dig[q]] + local[q];
+						for (unsigned v = 0; v < wave; ++v) pos += whist[v][dig[q]];
+						s_key[pos] = key[q]; s_val[pos] = val[q];
+					}
+				}
+				__syncthreads();
+#pragma unroll
+				for (int q = 0; q < OS_KPT; ++q) {
+					uint32_t i = wave * (64u * OS_KPT) + q * 64u + lane;
+					if (i < cnt) { key[q] = s_key[i]; val[q] = s_val[i]; }
+				}
+				whist[0][threadIdx.x] = 0; whist[1][threadIdx.x] = 0; whist[2][threadIdx.x] = 0; whist[3][threadIdx.x] = 0;
+				__syncthreads();
+			}
+#pragma unroll
+			for (int q = 0; q < OS_KPT; ++q) {
+				uint32_t i = wave * (64u * OS_KPT) + q * 64u + lane;
+				if (i < cnt) {
+					const uint32_t g = s + i;
+					const uint64_t k = (key[q] & lomask) | ((key[q] >> field_bits) << 32);
+					ka[g] = k; va[g] = val[q];
+					if (g && (g % BK_TARGET) == 0) splitters[g / BK_TARGET - 1u] = k;
+				}
+			}
+		} else {
+			uint64_t* ck = kb + s; uint32_t* cv = vb + s;
+			uint64_t* ok = ka + s; uint32_t* ov = va + s;
+			for (int p = 0; p < sh.n; ++p) {
+				bk_pass_global(ck, cv, ok, ov, cnt, sh.s[p], whist, offs, wtot);
+				uint64_t* tk = ck; ck = ok; ok = tk;
+				uint32_t* tv = cv; cv = ov; ov = tv;
+			}
+			// the result sits in `ck`: ka + s after an odd number of passes
+			for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+				const uint32_t g = s + i;
+				const uint64_t k = ck[i];
+				if (ck != ka + s) { ka[g] = k; va[g] = cv[i]; }
+				if (g && (g % BK_TARGET) == 0) splitters[g / BK_TARGET - 1u] = k;
+			}
+			__syncthreads();
+		}
+	}
+}
+
+// splitters for the next step from a sorted key array (after the radix passes ran: first step, capacity change)
+__global__ __launch_bounds__(256) void bk_seed(const uint64_t* __restrict__ sorted, nh_DevState* __restrict__ st, uint64_t* __restrict__ splitters) {
+	const uint32_t n = st->records;
+	const uint32_t nb = n ? (n + BK_TARGET - 1u) / BK_TARGET : 1u;
+	if (blockIdx.x == 0 && threadIdx.x == 0) st->sort_buckets_next = nb;
+	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j + 1 < nb; j += gridDim.x * blockDim.x) splitters[j] = sorted[(size_t)(j + 1u) * BK_TARGET];
+}
+
+uint32_t nh_bucket_sort_max_buckets(uint32_t capacity) { return capacity / BK_TARGET + 2u; }
+
+// keys_a/vals_a: in and out; keys_b/vals_b: scratch of the same size.  st->records keys; splitters / counts / starts: the context's
+// (nh_bucket_sort_max_buckets(capacity) + 1 entries each, counts zeroed once); place: capacity entries of scratch.
+void nh_bucket_sort_u64_u32(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t capacity, uint2* place, int field_bits) {
+	nh_DevState* st = ctx->d_state;
+	static int lds_cap = -1;
+	if (lds_cap < 0) { const char* e = getenv("NH_BUCKET_TILE"); lds_cap = e ? atoi(e) : (int)OS_TILE; if (lds_cap < 1 || lds_cap > (int)OS_TILE) lds_cap = OS_TILE; }
+	const uint32_t max_buckets = nh_bucket_sort_max_buckets(capacity);
+	NH_LAUNCH(ctx, "bucket_count", bk_count, nh_grid_for(capacity, 256, 2048), 256, keys_a, st, ctx->sort_splitters, place, ctx->sort_counts);
+	NH_LAUNCH(ctx, "bucket_scan", bk_scan, 1, 1024, st, ctx->sort_counts, ctx->sort_starts);
+	NH_LAUNCH(ctx, "bucket_scatter", bk_scatter, nh_grid_for(capacity, 256, 2048), 256, keys_a, vals_a, st, place, ctx->sort_starts, keys_b, vals_b);
+	NH_LAUNCH(ctx, "bucket_sort", bk_sort, max_buckets < 4096u ? max_buckets : 4096u, 256, keys_b, vals_b, keys_a, vals_a, ctx->sort_starts, st, two_field_shifts(field_bits), field_bits, ctx->sort_splitters, (uint32_t)lds_cap);
+}
+
+void nh_bucket_sort_seed(nh_context* ctx, const uint64_t* sorted_keys, uint32_t capacity) {
+	NH_LAUNCH(ctx, "bucket_seed", bk_seed, nh_grid_for(nh_bucket_sort_max_buckets(capacity), 256, 64), 256, sorted_keys, ctx->d_state, ctx->sort_splitters);
 }
 
 __global__ __launch_bounds__(256) void k_copy_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const uint32_t* __restrict__ d_n, uint32_t words_per_item) {
