@@ -22,6 +22,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->deg = nullptr;
 	ctx->deg_capacity = 0;
 	ctx->sort_splitters = nullptr; ctx->sort_counts = nullptr; ctx->sort_starts = nullptr; ctx->sort_capacity = 0; ctx->sort_seeded = false;
+	{ const char* e = getenv("NH_BUCKET_TILE"); ctx->sort_tile = e ? (uint32_t)atoi(e) : 0u; }
 	ctx->step_parity = 0;
 	ctx->d_state = nullptr;
 	ctx->h_state = nullptr;

@@ -103,6 +103,7 @@ struct nh_context {
 	uint32_t* sort_counts;
 	uint32_t* sort_starts;
 	uint32_t sort_capacity;
+	uint32_t sort_tile;
 	bool sort_seeded;
 	// fork/join inside one entry point: independent kernel chains run on `side` while the caller's stream does the long one
 	hipStream_t side;

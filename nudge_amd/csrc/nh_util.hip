@@ -619,13 +619,13 @@ uint32_t nh_bucket_sort_max_buckets(uint32_t capacity) { return capacity / BK_TA
 // (nh_bucket_sort_max_buckets(capacity) + 1 entries each, counts zeroed once); place: capacity entries of scratch.
 void nh_bucket_sort_u64_u32(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t capacity, uint2* place, int field_bits) {
 	nh_DevState* st = ctx->d_state;
-	static int lds_cap = -1;
-	if (lds_cap < 0) { const char* e = getenv("NH_BUCKET_TILE"); lds_cap = e ? atoi(e) : (int)OS_TILE; if (lds_cap < 1 || lds_cap > (int)OS_TILE) lds_cap = OS_TILE; }
+	// NH_BUCKET_TILE (read per context): buckets above this size take the through-global-memory path -- a test knob, the default is the tile
+	const uint32_t lds_cap = ctx->sort_tile >= 1u && ctx->sort_tile <= (uint32_t)OS_TILE ? ctx->sort_tile : (uint32_t)OS_TILE;
 	const uint32_t max_buckets = nh_bucket_sort_max_buckets(capacity);
 	NH_LAUNCH(ctx, "bucket_count", bk_count, nh_grid_for(capacity, 256, 2048), 256, keys_a, st, ctx->sort_splitters, place, ctx->sort_counts);
 	NH_LAUNCH(ctx, "bucket_scan", bk_scan, 1, 1024, st, ctx->sort_counts, ctx->sort_starts);
 	NH_LAUNCH(ctx, "bucket_scatter", bk_scatter, nh_grid_for(capacity, 256, 2048), 256, keys_a, vals_a, st, place, ctx->sort_starts, keys_b, vals_b);
-	NH_LAUNCH(ctx, "bucket_sort", bk_sort, max_buckets < 4096u ? max_buckets : 4096u, 256, keys_b, vals_b, keys_a, vals_a, ctx->sort_starts, st, two_field_shifts(field_bits), field_bits, ctx->sort_splitters, (uint32_t)lds_cap);
+	NH_LAUNCH(ctx, "bucket_sort", bk_sort, max_buckets < 4096u ? max_buckets : 4096u, 256, keys_b, vals_b, keys_a, vals_a, ctx->sort_starts, st, two_field_shifts(field_bits), field_bits, ctx->sort_splitters, lds_cap);
 }
 
 void nh_bucket_sort_seed(nh_context* ctx, const uint64_t* sorted_keys, uint32_t capacity) {

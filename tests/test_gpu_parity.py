@@ -403,3 +403,34 @@ def test_short_rsqrt_sequences_are_exact_wherever_their_guard_passes():
     assert os.path.exists(exe), "tests/fastmath/exhaustive missing: make -C nudge_amd/csrc"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "EXHAUSTIVE OK" in r.stdout, r.stdout + r.stderr
+
+
+# ---- the seeded tag sort's uncommon paths ----------------------------------------------------------------------------
+@needs_ref
+@pytest.mark.parametrize("tile", ["1", "37", "700"])
+def test_seeded_sort_oversized_buckets_and_abrupt_change(tile, monkeypatch):
+    """nh_util.hip: a bucket that outgrows its workgroup's tile is sorted through global memory.  NH_BUCKET_TILE shrinks the tile so
+    that (nearly) every bucket of a forming pile takes that path; the world must still match the reference bit for bit, including
+    across an abrupt change of the contact set (bodies teleported apart, then dropped again)."""
+    monkeypatch.setenv("NH_BUCKET_TILE", tile)
+    scene = S.pile(n_boxes=700, n_spheres=300, seed=11, iterations=4)
+    scene["body_transforms"]["position"][1:, 1] *= 0.08        # a dense column: many pairs from the first steps on
+    w = E.World(scene, flags=EXACT, max_contacts=60000)
+    ref = refworld.RefWorld(scene, max_contacts=60000)
+    for phase in range(2):
+        w.step(60)
+        ref.step(60)
+        b, rb = w.get_bodies(), ref.bodies()
+        assert P.bits_equal(b["transforms"], rb["transforms"]) and P.bits_equal(b["momentum"]["velocity"], rb["momentum"]["velocity"])
+        w.collide(); ref.collide()
+        c, rc = w.get_contacts(), ref.contacts()
+        assert c["count"] == rc["count"] and c["count"] > (1000 if phase == 0 else 100)
+        order = np.argsort(rc["tags"], kind="stable")
+        assert P.bits_equal(c["data"], rc["data"][order])
+        if phase == 0:
+            # scatter the bodies: almost every pair disappears at once, new ones form as they land again
+            t = b["transforms"].copy()
+            t["position"][1:, 0] += np.arange(len(t) - 1, dtype=np.float32) % 37 * 3.0
+            t["position"][1:, 2] += np.arange(len(t) - 1, dtype=np.float32) // 37 * 3.0
+            w.set_bodies(transforms=t); ref.set_bodies(transforms=t)
+    w.close()
