@@ -637,7 +637,8 @@ __global__ __launch_bounds__(256) void k_uf_union_connections(const nh_DevState*
 }
 
 // flatten + "a set is active if any member's idle counter != 0xff" (nudge.cpp:3960-3963)
-__global__ __launch_bounds__(256) void k_uf_flatten(uint32_t nbodies, uint32_t* __restrict__ parent, const uint8_t* __restrict__ idle, uint32_t* __restrict__ set_active, uint32_t* __restrict__ root_of) {
+__global__ __launch_bounds__(256) void k_uf_flatten(const nh_DevState* __restrict__ st, uint32_t parity, uint32_t nbodies, uint32_t* __restrict__ parent, const uint8_t* __restrict__ idle, uint32_t* __restrict__ set_active, uint32_t* __restrict__ root_of) {
+	if (!st->any_idle[parity]) return;          // nobody sleeps: every body is active, the sets are not needed (k_active_write)
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) {
 		uint32_t r = uf_find(parent, i);
 		root_of[i] = r;
@@ -645,13 +646,22 @@ __global__ __launch_bounds__(256) void k_uf_flatten(uint32_t nbodies, uint32_t* 
 	}
 }
 
-__global__ __launch_bounds__(256) void k_active_flags(uint32_t nbodies, const uint32_t* __restrict__ root_of, const uint32_t* __restrict__ set_active, uint32_t* __restrict__ flags) {
+__global__ __launch_bounds__(256) void k_active_flags(const nh_DevState* __restrict__ st, uint32_t parity, uint32_t nbodies, const uint32_t* __restrict__ root_of, const uint32_t* __restrict__ set_active, uint32_t* __restrict__ flags) {
+	if (!st->any_idle[parity]) return;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x)
 		flags[i] = (i >= 1 && set_active[root_of[i]]) ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void k_active_write(nh_DevState* __restrict__ st, uint32_t nbodies, const uint32_t* __restrict__ root_of, const uint32_t* __restrict__ set_active,
-                                                      const uint32_t* __restrict__ scan, uint32_t* __restrict__ indices, uint32_t capacity) {
+                                                      const uint32_t* __restrict__ scan, uint32_t* __restrict__ indices, uint32_t capacity, uint32_t parity) {
+	if (!st->any_idle[parity]) {
+		// nobody sleeps: the active list is every body but the static world, ascending (nudge.cpp:3966-3971 with all sets active)
+		for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x + 1u; i < nbodies; i += gridDim.x * blockDim.x) {
+			if (i - 1u < capacity) indices[i - 1u] = i; else st->error = NH_ERR_ACTIVE_CAPACITY;
+		}
+		if (blockIdx.x == 0 && threadIdx.x == 0) st->active = nbodies ? nbodies - 1u : 0u;
+		return;
+	}
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) {
 		if (i >= 1 && set_active[root_of[i]]) {
 			uint32_t pos = scan[i];
@@ -663,7 +673,8 @@ __global__ __launch_bounds__(256) void k_active_write(nh_DevState* __restrict__ 
 // contacts of inactive sets leave the contact list and become sleeping pairs (nudge.cpp:3976-4003)
 __global__ __launch_bounds__(256) void k_filter_records(nh_DevState* __restrict__ st, nh_Record* __restrict__ rec, uint64_t* __restrict__ rec_key, uint32_t* __restrict__ rec_idx,
                                                         const uint32_t* __restrict__ root_of, const uint32_t* __restrict__ set_active,
-                                                        uint64_t* __restrict__ sleeping_pairs, uint32_t sleeping_cap) {
+                                                        uint64_t* __restrict__ sleeping_pairs, uint32_t sleeping_cap, uint32_t parity) {
+	if (!st->any_idle[parity]) return;          // nobody sleeps: no record can belong to a sleeping set
 	uint32_t n = st->records;
 	uint32_t rounded = (n + 63u) & ~63u;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
@@ -934,15 +945,15 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	if (body_connections && body_connections->count)
 		NH_LAUNCH(ctx, "uf_union_connections", k_uf_union_connections, nh_grid_for(body_connections->count, 256, 2048), 256, st, body_connections->data, body_connections->count, parent, ctx->step_parity);
 	NH_LAUNCH(ctx, "uf_union_records", k_uf_union_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, parent, ctx->step_parity);
-	NH_LAUNCH(ctx, "uf_flatten", k_uf_flatten, nh_grid_for(B, 256, 2048), 256, B, parent, bodies->idle_counters, set_active, root_of);
-	NH_LAUNCH(ctx, "active_flags", k_active_flags, nh_grid_for(B, 256, 2048), 256, B, root_of, set_active, flags);
+	NH_LAUNCH(ctx, "uf_flatten", k_uf_flatten, nh_grid_for(B, 256, 2048), 256, st, ctx->step_parity, B, parent, bodies->idle_counters, set_active, root_of);
+	NH_LAUNCH(ctx, "active_flags", k_active_flags, nh_grid_for(B, 256, 2048), 256, st, ctx->step_parity, B, root_of, set_active, flags);
 	{
 		// number of bodies is known on the host: reuse the device-count scan with a constant count of 0 + extra
 		static_assert(sizeof(uint32_t) == 4, "");
-		nh_scan_u32(ctx, flags, flags, &st->pad0 /* always 0 */, B, scan_tmp, &st->active);
+		nh_scan_u32(ctx, flags, flags, &st->pad0 /* always 0 */, B, scan_tmp, &st->active, &st->any_idle[ctx->step_parity]);    // (skipped on the device when nobody sleeps)
 	}
-	NH_LAUNCH(ctx, "active_write", k_active_write, nh_grid_for(B, 256, 2048), 256, st, B, root_of, set_active, flags, active_bodies->indices, active_bodies->capacity);
-	NH_LAUNCH(ctx, "filter_records", k_filter_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, rec_key_a, rec_idx_a, root_of, set_active, (uint64_t*)nullptr, cap);
+	NH_LAUNCH(ctx, "active_write", k_active_write, nh_grid_for(B, 256, 2048), 256, st, B, root_of, set_active, flags, active_bodies->indices, active_bodies->capacity, ctx->step_parity);
+	NH_LAUNCH(ctx, "filter_records", k_filter_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, rec_key_a, rec_idx_a, root_of, set_active, (uint64_t*)nullptr, cap, ctx->step_parity);
 	if (fork) {
 		ctx->stream = main_stream;
 		NH_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, ctx->side));
