@@ -20,13 +20,16 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
                                                const nh_Transform* __restrict__ body_xf,
                                                const nh_Transform* __restrict__ box_xf, const nh_BoxCollider* __restrict__ box_data, const uint32_t* __restrict__ box_tags, uint32_t nbox,
                                                const nh_Transform* __restrict__ sph_xf, const nh_SphereCollider* __restrict__ sph_data, const uint32_t* __restrict__ sph_tags, uint32_t nsph,
-                                               nh_xform* __restrict__ xf, float4* __restrict__ aabb_min, float4* __restrict__ aabb_max, uint32_t* __restrict__ ctag) {
+                                               nh_xform* __restrict__ xf, float4* __restrict__ aabb_min, float4* __restrict__ aabb_max, uint32_t* __restrict__ ctag,
+                                               uint4* __restrict__ zero16, uint32_t zero16_count) {
 	__shared__ uint32_t hist[1024];
 	__shared__ uint32_t red[12];
 	hist[threadIdx.x] = 0;
 	if (threadIdx.x < 3) { red[threadIdx.x] = 0xffffffffu; red[3 + threadIdx.x] = 0u; red[6 + threadIdx.x] = 0xffffffffu; red[9 + threadIdx.x] = 0u; }
 	__syncthreads();
 	uint32_t n = nbox + nsph;
+	// (the cell counters of the counting sort further down are cleared here: one launch less than a memset of their own)
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < zero16_count; k += gridDim.x * blockDim.x) zero16[k] = make_uint4(0u, 0u, 0u, 0u);
 	uint32_t lmin[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, lmax[3] = { 0, 0, 0 };
 	// bounds of the "small" colliders under LAST step's size split (k_grid_params confirms the guess or orders k_small_bounds to redo them)
 	const uint32_t guess_exp = st->small_exp;
@@ -914,13 +917,10 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 1024, 256), 1024, st, bodies->transforms,
 		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
 		          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
-		          xf, aabb_min, aabb_max, ctag);
+		          xf, aabb_min, aabb_max, ctag, reinterpret_cast<uint4*>(cstart), (max_cells + 8u) / 4u);
 		NH_LAUNCH(ctx, "grid_params", k_grid_params, 1, 64, st, C, max_cells);
 		NH_LAUNCH(ctx, "small_bounds", k_small_bounds, nh_grid_for(C, 256, 1024), 256, st, C, aabb_min, aabb_max);
 		NH_LAUNCH(ctx, "grid_dims", k_grid_dims, 1, 64, st, max_cells);
-		if (ctx->timing) nh_timer_begin(ctx, "memset_cells");
-		NH_HIP_CHECK(ctx, hipMemsetAsync(cstart, 0, sizeof(uint32_t) * ((size_t)max_cells + 1), s));
-		if (ctx->timing) nh_timer_end(ctx);
 		NH_LAUNCH(ctx, "cell_keys", k_cell_keys, nh_grid_for(C, 256, 2048), 256, st, C, aabb_min, aabb_max, keys_a, vals_a, mkey, large_list, cstart);
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_sums, max_cells / CS_TILE, 256, cstart, cscan_sums);
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_final, max_cells / CS_TILE, 256, cstart, cscan_sums, max_cells);
