@@ -139,7 +139,8 @@ struct nh_ContactConstraintData {
 	uint32_t* body_off;                   // B+1 CSR offsets into adj
 	uint32_t* adj;                        // contact indices per dynamic body, solver order
 	uint32_t* static_bodies;              // 3 x B: bodies on the one-body fast path, by contact count (<=4 | <=8 | more)
-	uint8_t* body_class;                  // 0 none, 1 static-only, 2 general
+	uint8_t* body_class;
+	uint2* simple;                        // per body of k_adj_simple's classes: first contact, count | slot order << 4 (nh_solve.hip)                  // 0 none, 1 static-only, 2 general
 	uint32_t* level_order;                // general contacts sorted by level
 	uint2* gpair;                         // per general contact, LEVEL order: body pair
 	float4* gstates;                      //   solver state (rows of general contacts are structure-of-float4 in `rows`, level order, stride = contact_capacity)

@@ -176,7 +176,8 @@ __device__ __forceinline__ uint32_t slot_key_of(uint32_t i, const uint32_t* __re
 // slot order.  Everything else is left PENDING for the general k_adj_fill / k_adj_sort, which do not even start when nothing is pending.
 __global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st, uint32_t nbodies, const uint32_t* __restrict__ off, const uint32_t* __restrict__ info,
                                                     const uint32_t* __restrict__ first_contact, uint32_t* __restrict__ adj, const uint32_t* __restrict__ slot_key,
-                                                    uint8_t* __restrict__ body_class, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum) {
+                                                    uint8_t* __restrict__ body_class, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
+                                                    uint2* __restrict__ simple) {
 	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < nbodies; x += gridDim.x * blockDim.x) {
 		if (x == 0) {
 			body_class[0] = 0;
@@ -207,6 +208,13 @@ __global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st
 				}
 #pragma unroll
 				for (int q = 0; q < 8; ++q) if ((uint32_t)q < d) adj[b + q] = c[q];
+				// the same list in one record for the solver (no walk through off[] and adj[]): first contact, count, slot order as 3-bit offsets
+				{
+					uint32_t perm = 0;
+#pragma unroll
+					for (int q = 0; q < 8; ++q) if ((uint32_t)q < d) perm |= (c[q] - f) << (3 * q);
+					simple[x] = make_uint2(f, d | (perm << 4));
+				}
 				cls = d <= 4u ? NH_CLS_STATIC4 : NH_CLS_STATIC8;
 				if (cls == NH_CLS_STATIC8) st->has_static8 = 1;
 			} else {
@@ -653,10 +661,12 @@ __global__ __launch_bounds__(256) void k_apply_static(uint32_t nbodies, const ui
 #define NH_HINT_NONE 0xFFFFFFFFu
 
 __device__ __forceinline__ bool cache_probe(const nh_CacheView& cv, uint32_t m, uint32_t guess, uint64_t t, uint32_t f, float& wx, float& wy, float& wz) {
-	if (guess < m && cv.ctags[guess] == t && cv.cfeatures[guess] == f) {
+	// the three loads go out together (the impulse is fetched before the tags are known to match: one memory round trip, not two)
+	if (guess < m) {
+		const uint64_t ct = cv.ctags[guess];
+		const uint32_t cf = cv.cfeatures[guess];
 		const float4 w = *reinterpret_cast<const float4*>(cv.cdata + guess);
-		wx = w.x; wy = w.y; wz = w.z;
-		return true;
+		if (ct == t && cf == f) { wx = w.x; wy = w.y; wz = w.z; return true; }
 	}
 	return false;
 }
@@ -687,12 +697,15 @@ __device__ __noinline__ void cache_search(const nh_CacheView& cv, uint32_t m, ui
 // Four 27-float rows fit in 256 registers: two waves per SIMD (the compiler would otherwise spend 260 and run one).
 struct nh_ob_slot { float4 c0, c1, w; };      // contact (32 B), cached impulse xyz + flags in w.w (bit 0 miss, bit 1 body is "a")
 
-template<int MAXC, bool FUSED>
+template<int MAXC, bool FUSED, bool CONTIG = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ? 2 : 1, MAXC == 4 ? 2 : 1))) void k_solve_one_body(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
                                                         const nh_BodyPair* __restrict__ bodies, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                         float4* __restrict__ states, uint32_t iterations,
                                                         const nh_Contact* __restrict__ contacts, const nh_Transform* __restrict__ xf, nh_CachedContactImpulse* __restrict__ impulses,
-                                                        nh_CacheView cv, uint32_t* __restrict__ hint, uint32_t cls_a, uint32_t cls_b, uint32_t require_inert) {
+                                                        nh_CacheView cv, uint32_t* __restrict__ hint, uint32_t cls_a, uint32_t cls_b, uint32_t require_inert,
+                                                        const uint2* __restrict__ simple = nullptr) {
+	// CONTIG: every body of the class comes from k_adj_simple (one collider pair with the static world): its contact list is the record
+	// simple[x] -- one load next to the body state instead of the dependent chain off[x] -> adj[] -> contact
 	constexpr int M = MAXC;
 	// launched before the host knew whether body 0 is inert: if it is not, the general kernels take these bodies after the round trip
 	if (require_inert && !cv.st->static_inert) return;
@@ -709,7 +722,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
 		const bool mine = x < nbodies && (my_class == cls_a || my_class == cls_b);
 		const uint32_t wave_x0 = x - lane;
 		uint32_t b = 0, cnt = 0;
-		if (mine) { b = off[x]; cnt = off[x + 1] - b; }
+		uint2 sp = make_uint2(0u, 0u);
+		if (mine) {
+			if (CONTIG) { sp = simple[x]; cnt = sp.y & 15u; }
+			else { b = off[x]; cnt = off[x + 1] - b; }
+		}
 		// body state: 16-byte loads (the records are 16 / 32 bytes and aligned, include/nudge_hip.h)
 		float4 m0 = make_float4(0, 0, 0, 0), m1 = m0, pr = m0, t0 = m0, t1 = make_float4(0, 0, 0, 1);
 		uint32_t h = NH_HINT_NONE;
@@ -722,7 +739,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
 		uint32_t cid[M];
 		uint32_t first = 0xFFFFFFFFu;
 #pragma unroll
-		for (int q = 0; q < M; ++q) { cid[q] = (uint32_t)q < cnt ? adj[b + q] : 0xFFFFFFFFu; first = min(first, cid[q]); }
+		for (int q = 0; q < M; ++q) {
+			if (CONTIG) cid[q] = (uint32_t)q < cnt ? sp.x + ((sp.y >> (4 + 3 * q)) & 7u) : 0xFFFFFFFFu;
+			else cid[q] = (uint32_t)q < cnt ? adj[b + q] : 0xFFFFFFFFu;
+			first = min(first, cid[q]);
+		}
 #pragma unroll
 		for (int q = 0; q < M; ++q) scid[lane * M + q] = cid[q];
 		s_hint[wave][lane] = h; s_first[wave][lane] = first;
@@ -1193,6 +1214,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	d->adj = nh_arena_array<uint32_t>(memory, (size_t)kcap * 2, &err);
 	d->static_bodies = nh_arena_array<uint32_t>(memory, (size_t)3 * B, &err);
 	d->body_class = nh_arena_array<uint8_t>(memory, B, &err);
+	d->simple = nh_arena_array<uint2>(memory, B, &err);
 	d->level_order = nh_arena_array<uint32_t>(memory, kcap, &err);
 	d->gpair = nh_arena_array<uint2>(memory, kcap, &err);
 	d->gstates = nh_arena_array<float4>(memory, kcap, &err);
@@ -1214,7 +1236,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	nh_scan_u32(ctx, d->body_off, d->body_off, &st->pad0, B + 1, tmp, nullptr);
 	if (slot_key) NH_LAUNCH(ctx, "greedy_replay", k_greedy_replay, 1, 64, st, contacts->bodies, slot_key);
 	NH_LAUNCH(ctx, "adjacency_simple", k_adj_simple, nh_grid_for(B, 256, 4096), 256, st, B, d->body_off, ctx->deg + 2 * (size_t)(B + 2), ctx->deg + 3 * (size_t)(B + 2), d->adj, slot_key,
-	          d->body_class, bodies->properties, bodies->momentum);
+	          d->body_class, bodies->properties, bodies->momentum, d->simple);
 	if (ctx->hint_capacity < B) {
 		// library-owned, persistent across steps: per body, where its contacts started in the previous step's list (warm-start hint)
 		if (ctx->hint) NH_HIP_CHECK(ctx, hipFree(ctx->hint));
@@ -1329,7 +1351,7 @@ static void launch_apply_static(nh_context* ctx, nh_ContactConstraintData* d, co
 	};
 	auto go1 = [&](const char* name, auto kernel, uint32_t cls_a, uint32_t cls_b) {
 		NH_LAUNCH(ctx, name, kernel, nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
-		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, cls_a, cls_b, 0u);
+		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, cls_a, cls_b, 0u, (const uint2*)nullptr);
 	};
 	const bool late = d->has_late;
 	if (d->static_inert) {
@@ -1361,8 +1383,8 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 		d->finish_pending = false;
 		const uint32_t B = d->body_count;
 		nh_CacheView cv = { d->imp->tags, d->imp->features, d->imp->ctags, d->imp->cfeatures, d->imp->cdata, ctx->d_state };
-		NH_LAUNCH(ctx, "solve_one_body", (k_solve_one_body<4, true>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
-		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 1u);
+		NH_LAUNCH(ctx, "solve_one_body", (k_solve_one_body<4, true, true>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
+		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 1u, d->simple);
 		int rc = finish_setup(ctx, d);
 		if (rc) return rc;
 		early4_done = d->static_inert;          // (if body 0 is not inert the speculative launch left at once and the general kernels take everything)
