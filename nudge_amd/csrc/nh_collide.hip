@@ -385,7 +385,9 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 		}
 		// The candidate loops are data dependent per lane; emission is wave-synchronous, so run a
 		// wave-uniform loop and let lanes without work idle.
-		int cz = z0, cy = y0, cx = x0;
+		// (cells that are neighbours along x are neighbours in the table, and cell lists are contiguous ranges of the cell-sorted
+		// order: one x-row of cells is ONE range of candidates, two table reads instead of two per cell)
+		int cz = z0, cy = y0;
 		uint32_t j = 0, jend = 0;
 		bool more_cells = small;
 		for (;;) {
@@ -399,10 +401,10 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 					j = (i + 1 > j) ? min(i + 1, jend) : j + 1;
 					continue;
 				}
-				// next cell
-				const uint32_t cell = (uint32_t)((cz * ny + cy) * nx + cx);
-				j = cstart[cell]; jend = cstart[cell + 1];
-				if (++cx > x1) { cx = x0; if (++cy > y1) { cy = y0; if (++cz > z1) more_cells = false; } }
+				// next row of cells
+				const uint32_t row = (uint32_t)((cz * ny + cy) * nx);
+				j = cstart[row + (uint32_t)x0]; jend = cstart[row + (uint32_t)x1 + 1u];
+				if (++cy > y1) { cy = y0; if (++cz > z1) more_cells = false; }
 			}
 			if (!__any(have)) break;
 			bool hit = false;
