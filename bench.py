@@ -58,7 +58,7 @@ KERNEL_BYTES = {
 
 
 # timer name (nh_* launch sites) -> kernel symbol prefix in the rocprofv3 PMC export (profiles/export_pmc.py)
-PMC_KERNEL = {"solve_one_body": "k_solve_one_body<4, true>", "apply_static": "k_apply_static<4, true>", "narrowphase": "k_narrowphase",
+PMC_KERNEL = {"solve_one_body": "k_solve_one_body<4, true, true>", "apply_static": "k_apply_static<4, true>", "narrowphase": "k_narrowphase",
               "gather_contacts": "k_gather_contacts", "find_pairs": "k_find_pairs", "radix_pass": "os_pass<unsigned long, unsigned int, true>",
               "apply_level": "k_level_exec<false>", "write_cache": "k_write_cache", "xform_aabb": "k_xform"}
 

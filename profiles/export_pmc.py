@@ -20,7 +20,7 @@ res = {}
 for name in vals["FETCH_SIZE"]:
     f = vals["FETCH_SIZE"][name][-last:]
     w = vals["WRITE_SIZE"].get(name, [0.0])[-last:]
-    if not name.startswith(("k_", "rs_", "sc_")):
+    if not name.startswith(("k_", "rs_", "sc_", "os_", "bk_")):
         continue
     fr = sum(f) / len(f) * 1024.0
     wr = sum(w) / len(w) * 1024.0
