@@ -453,27 +453,26 @@ __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ s
 		int x0 = min(max(cell_coord(amin.x, ox, inv) - 1, 0), nx - 1), x1 = min(max(cell_coord(amax.x, ox, inv), 0), nx - 1);
 		int y0 = min(max(cell_coord(amin.y, oy, inv) - 1, 0), ny - 1), y1 = min(max(cell_coord(amax.y, oy, inv), 0), ny - 1);
 		int z0 = min(max(cell_coord(amin.z, oz, inv) - 1, 0), nz - 1), z1 = min(max(cell_coord(amax.z, oz, inv), 0), nz - 1);
-		const uint32_t wx = (uint32_t)(x1 - x0 + 1), wy = (uint32_t)(y1 - y0 + 1), wz = (uint32_t)(z1 - z0 + 1);
-		const uint32_t ncell = wx * wy * wz;
-		const uint32_t rounded = (ncell + LP_SLICES * 256u - 1) / (LP_SLICES * 256u) * (LP_SLICES * 256u);
-		for (uint32_t ci = slice * 256u + threadIdx.x; ci < rounded; ci += LP_SLICES * 256u) {
-			uint32_t j = 0, jend = 0;
-			if (ci < ncell) {
-				uint32_t cx = ci % wx, cy = (ci / wx) % wy, cz = ci / (wx * wy);
-				const uint32_t cell = (uint32_t)(((z0 + (int)cz) * ny + (y0 + (int)cy)) * nx + (x0 + (int)cx));
-				j = cstart[cell]; jend = cstart[cell + 1];
-			}
-			while (__ballot(j < jend)) {
-				bool have = j < jend;
+		// an x-row of cells is one contiguous range of the cell-sorted order: a wave takes rows, its lanes take consecutive candidates
+		// (coalesced, no lane idling on an empty cell)
+		const uint32_t wy = (uint32_t)(y1 - y0 + 1), wz = (uint32_t)(z1 - z0 + 1);
+		const uint32_t nrows = wy * wz;
+		const uint32_t lane = threadIdx.x & 63u;
+		for (uint32_t r = slice * 4u + (threadIdx.x >> 6); r < nrows; r += LP_SLICES * 4u) {       // wave-uniform
+			const uint32_t cy = r % wy, cz = r / wy;
+			const uint32_t row = (uint32_t)(((z0 + (int)cz) * ny + (y0 + (int)cy)) * nx);
+			const uint32_t j0 = cstart[row + (uint32_t)x0], jend = cstart[row + (uint32_t)x1 + 1u];
+			for (uint32_t base = j0; base < jend; base += 64u) {
+				const uint32_t cand = base + lane;
+				const bool have = cand < jend;
 				bool hit = false;
-				uint32_t cb = 0, cand = have ? j : 0;
+				uint32_t cb = 0;
 				if (have) {
 					float4 bmin = smin[cand], bmax = smax[cand];
 					cb = __float_as_uint(bmax.w);
 					hit = aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != abody);
-					++j;
 				}
-				emit_pair(st, pairs, pair_cap, ka, smk + cand, ca, cb, hit, ps);
+				emit_pair(st, pairs, pair_cap, ka, smk + (have ? cand : 0u), ca, cb, hit, ps);
 			}
 		}
 	}
@@ -856,7 +855,6 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	uint32_t* keys_a = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* keys_b = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* vals_a = nh_arena_array<uint32_t>(A, C, &err);
-	uint32_t* vals_b = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* large_list = nh_arena_array<uint32_t>(A, C, &err);
 	const uint32_t pair_cap = cap / 2 + 1024;           // broadphase pairs; each owns 4 raw contact slots, the rest overflows
 	const bool onesweep = getenv("NH_SORT_CLASSIC") == nullptr;      // one kernel per radix pass (nh_util.hip); NH_SORT_CLASSIC=1: three

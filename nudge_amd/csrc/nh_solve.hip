@@ -1124,7 +1124,6 @@ static void run_cull(nh_context* ctx, nh_ContactImpulseData* d, uint32_t sleepin
 extern "C" int nh_read_cached_impulses(nh_context* ctx, const nh_ContactCache* cache, const nh_ContactData* contacts, nh_Arena* memory, nh_ContactImpulseData** out) {
 	if (!ctx || !cache || !contacts || !memory || !out) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
-	nh_DevState* st = ctx->d_state;
 	const uint32_t kcap = contacts->capacity, ccap = cache->capacity;
 	int err = NH_OK;
 	ctx->ring_pos++;
