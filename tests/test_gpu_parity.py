@@ -434,3 +434,30 @@ def test_seeded_sort_oversized_buckets_and_abrupt_change(tile, monkeypatch):
             t["position"][1:, 2] += np.arange(len(t) - 1, dtype=np.float32) // 37 * 3.0
             w.set_bodies(transforms=t); ref.set_bodies(transforms=t)
     w.close()
+
+
+@pytest.mark.parametrize("mult,offset", [(1, 0), (257, 3), (70001, 12345), (1048573, 4000000000 - 1048573 * 500)])
+@pytest.mark.parametrize("sort", ["seeded", "radix", "classic"])
+def test_wide_sparse_collider_tags_do_not_change_the_world(mult, offset, sort, monkeypatch):
+    """Collider tags are 32-bit in this ABI and only their ORDER matters (contacts come out in tag order, the solver order follows):
+    an order-preserving re-tagging up to the top of the 32-bit range (9..32 significant bits: 2 to 8 digit passes of the packed key,
+    seeded sort, one-kernel and three-kernel radix passes alike) must leave bodies bit-identical and map the contact tags one to one."""
+    if sort != "seeded":
+        monkeypatch.setenv("NH_SORT_RADIX" if sort == "radix" else "NH_SORT_CLASSIC", "1")
+    scene = S.pile(n_boxes=300, n_spheres=150, seed=21, iterations=4)
+    scene["body_transforms"]["position"][1:, 1] *= 0.1
+    wide = dict(scene)
+    f = lambda t: (t.astype(np.uint64) * np.uint64(mult) + np.uint64(offset)).astype(np.uint32)
+    wide["box_tags"], wide["sphere_tags"] = f(scene["box_tags"]), f(scene["sphere_tags"])
+    assert int(wide["sphere_tags"].max()) < 2 ** 32 and np.all(np.diff(np.concatenate([wide["box_tags"], wide["sphere_tags"]]).astype(np.int64)) > 0)
+    a, b = E.World(scene, flags=EXACT, max_contacts=40000), E.World(wide, flags=EXACT, max_contacts=40000)
+    a.step(45); b.step(45)
+    ba, bb = a.get_bodies(), b.get_bodies()
+    assert P.bits_equal(ba["transforms"], bb["transforms"]) and P.bits_equal(ba["momentum"], bb["momentum"])
+    a.collide(); b.collide()
+    ca, cb = a.get_contacts(), b.get_contacts()
+    assert ca["count"] == cb["count"] and ca["count"] > 500
+    lo, hi = ca["tags"] & np.uint64(0xFFFFFFFF), ca["tags"] >> np.uint64(32)
+    assert np.array_equal((lo * np.uint64(mult) + np.uint64(offset)) | ((hi * np.uint64(mult) + np.uint64(offset)) << np.uint64(32)), cb["tags"])
+    assert np.array_equal(ca["features"], cb["features"]) and P.bits_equal(ca["data"], cb["data"])
+    a.close(); b.close()
