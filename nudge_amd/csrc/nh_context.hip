@@ -21,6 +21,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->hint_capacity = 0;
 	ctx->deg = nullptr;
 	ctx->deg_capacity = 0;
+	ctx->order_seq = 0;
 	ctx->sort_splitters = nullptr; ctx->sort_counts = nullptr; ctx->sort_starts = nullptr; ctx->sort_capacity = 0; ctx->sort_seeded = false;
 	{ const char* e = getenv("NH_BUCKET_TILE"); ctx->sort_tile = e ? (uint32_t)atoi(e) : 0u; }
 	ctx->step_parity = 0;

@@ -62,6 +62,7 @@ struct nh_DevState {
 	uint32_t any_idle[2];         // by step parity: some body's idle counter is saturated (asleep)
 	uint32_t sort_buckets;        // buckets of this step's tag sort = splitters of the previous step + 1 (nh_util.hip, bucket sort)
 	uint32_t sort_buckets_next;   // written by this step's sort for the next one
+	uint32_t order_conflict;      // exact-order mode: sequence number of the setup call whose closed-form schedule has a lane conflict (nh_solve.hip)
 };
 
 struct nh_TimerSlot { const char* name; hipEvent_t a, b; };
@@ -97,6 +98,7 @@ struct nh_context {
 	uint32_t* deg;
 	uint32_t deg_capacity;
 	uint32_t step_parity;
+	uint32_t order_seq;
 	// tag sort seeded by the previous step's order (nh_util.hip): splitters persist across steps; counts / starts are scratch that must
 	// outlive nothing but is zeroed by its own kernels.  `sort_seeded`: the splitters describe the previous nh_collide of this capacity
 	uint64_t* sort_splitters;

@@ -328,7 +328,36 @@ __global__ __launch_bounds__(256) void k_contact_class(nh_DevState* __restrict__
 // ---- exact replay of the reference's greedy batch scheduler (nudge.cpp:4206-4339), one wave -------------------
 #define GR_BUCKETS 16
 #define GR_OPEN 64          // open (vacant) batches kept per bucket in LDS
-__global__ __launch_bounds__(64) void k_greedy_replay(nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, uint32_t* __restrict__ slot_key) {
+// Exact-order mode, common case first.  When the scheduler below never meets a lane conflict, contact i ends up in batch
+// (i / 128) * 16 + i % 16 (its bucket's batch completes with every eighth contact of the bucket, batches are emitted in that order,
+// leftovers bucket by bucket).  The first conflict the scheduler can meet is two contacts of ONE such batch sharing a dynamic body, so if no
+// batch of the closed form holds one, the closed form IS the schedule: checked here with one lane per batch; only otherwise the
+// sequential replay runs (it is a single wave walking all contacts: milliseconds for tens of thousands).
+__global__ __launch_bounds__(256) void k_order_check(nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, uint32_t* __restrict__ slot_key, uint32_t seq) {
+	const uint32_t n = st->contacts;
+	const uint32_t nbatch = ((n + 127u) / 128u) * 16u;
+	for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nbatch; t += gridDim.x * blockDim.x) {
+		const uint32_t first = (t >> 4) * 128u + (t & 15u);
+		uint32_t ca[8], cb[8];
+		bool conflict = false;
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			const uint32_t i = first + 16u * k;
+			ca[k] = NH_NONE; cb[k] = NH_NONE;
+			if (i < n) {
+				const nh_BodyPair bp = bodies[i];
+				ca[k] = bp.a ? bp.a : bp.b; cb[k] = bp.b ? bp.b : bp.a;      // dependencies on body 0 do not count (nudge.cpp:4238-4240)
+				slot_key[i] = t;
+#pragma unroll
+				for (int j = 0; j < k; ++j) conflict |= ca[j] == ca[k] || cb[j] == ca[k] || ca[j] == cb[k] || cb[j] == cb[k];
+			}
+		}
+		if (conflict) st->order_conflict = seq;
+	}
+}
+
+__global__ __launch_bounds__(64) void k_greedy_replay(nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, uint32_t* __restrict__ slot_key, uint32_t seq) {
+	if (st->order_conflict != seq) return;          // k_order_check: the closed form it wrote is the schedule
 	__shared__ uint2 pair_ab[GR_BUCKETS][GR_OPEN + 1][8];
 	__shared__ uint32_t slot_idx[GR_BUCKETS][GR_OPEN + 1][8];
 	__shared__ uint32_t vacancy[GR_BUCKETS];
@@ -1233,7 +1262,11 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 
 	// (degrees were counted by nh_collide while it laid the contacts out)
 	nh_scan_u32(ctx, d->body_off, d->body_off, &st->pad0, B + 1, tmp, nullptr);
-	if (slot_key) NH_LAUNCH(ctx, "greedy_replay", k_greedy_replay, 1, 64, st, contacts->bodies, slot_key);
+	if (slot_key) {
+		const uint32_t seq = ++ctx->order_seq ? ctx->order_seq : ++ctx->order_seq;       // never 0: tells this call's verdict from an older one
+		NH_LAUNCH(ctx, "order_check", k_order_check, nh_grid_for(kcap / 8u + 16u, 256, 1024), 256, st, contacts->bodies, slot_key, seq);
+		NH_LAUNCH(ctx, "greedy_replay", k_greedy_replay, 1, 64, st, contacts->bodies, slot_key, seq);
+	}
 	NH_LAUNCH(ctx, "adjacency_simple", k_adj_simple, nh_grid_for(B, 256, 4096), 256, st, B, d->body_off, ctx->deg + 2 * (size_t)(B + 2), ctx->deg + 3 * (size_t)(B + 2), d->adj, slot_key,
 	          d->body_class, bodies->properties, bodies->momentum, d->simple);
 	if (ctx->hint_capacity < B) {

@@ -16,6 +16,7 @@
 #include <nudge.h>
 
 #include <stdint.h>
+#include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -95,6 +96,7 @@ int main(int argc, char** argv) {
 	arena.data = aligned_array<uint8_t>(arena.size);
 
 	uint64_t sum_contacts = 0;
+	const auto t0 = std::chrono::steady_clock::now();
 	for (unsigned n = 0; n < steps; ++n) {
 		nudge::Arena temporary = arena;                       // same scratch every sub-step
 		nudge::BodyConnections connections = {};
@@ -117,6 +119,7 @@ int main(int argc, char** argv) {
 		nudge::write_cached_impulses(&cache, contacts, impulses);
 		nudge::advance(active, bodies, time_step);
 	}
+	const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
 	FILE* o = fopen(argv[2], "wb");
 	if (!o) { perror(argv[2]); return 2; }
@@ -127,6 +130,6 @@ int main(int argc, char** argv) {
 	fwrite(&contacts.count, 4, 1, o);
 	fwrite(&active.count, 4, 1, o);
 	fclose(o);
-	printf("replay: %u steps, %u bodies, last step %u contacts, %u active, sum of contacts %llu\n", steps, nb, contacts.count, active.count, (unsigned long long)sum_contacts);
+	printf("replay: %u steps, %u bodies, last step %u contacts, %u active, sum of contacts %llu, %.1f steps/s\n", steps, nb, contacts.count, active.count, (unsigned long long)sum_contacts, steps / seconds);
 	return 0;
 }
