@@ -905,7 +905,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		if (ctx->sort_counts) NH_HIP_CHECK(ctx, hipFree(ctx->sort_counts));
 		if (ctx->sort_starts) NH_HIP_CHECK(ctx, hipFree(ctx->sort_starts));
 		ctx->sort_splitters = nullptr; ctx->sort_counts = nullptr; ctx->sort_starts = nullptr; ctx->sort_capacity = 0; ctx->sort_seeded = false;
-		const size_t nbk = (size_t)nh_bucket_sort_max_buckets(pair_cap) + 1u;
+		const size_t nbk = (size_t)nh_bucket_sort_max_buckets(ctx, pair_cap) + 1u;
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sort_splitters, sizeof(uint64_t) * nbk));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sort_counts, sizeof(uint32_t) * nbk));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sort_starts, sizeof(uint32_t) * nbk));

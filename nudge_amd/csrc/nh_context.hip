@@ -24,6 +24,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->order_seq = 0;
 	ctx->sort_splitters = nullptr; ctx->sort_counts = nullptr; ctx->sort_starts = nullptr; ctx->sort_capacity = 0; ctx->sort_seeded = false;
 	{ const char* e = getenv("NH_BUCKET_TILE"); ctx->sort_tile = e ? (uint32_t)atoi(e) : 0u; }
+	{ const char* e = getenv("NH_BUCKET_TARGET"); ctx->sort_target = e ? (uint32_t)atoi(e) : 0u; }
 	ctx->step_parity = 0;
 	ctx->d_state = nullptr;
 	ctx->h_state = nullptr;

@@ -105,7 +105,7 @@ struct nh_context {
 	uint32_t* sort_counts;
 	uint32_t* sort_starts;
 	uint32_t sort_capacity;
-	uint32_t sort_tile;
+	uint32_t sort_tile, sort_target;      // test knobs (NH_BUCKET_TILE, NH_BUCKET_TARGET), 0 = defaults
 	bool sort_seeded;
 	// fork/join inside one entry point: independent kernel chains run on `side` while the caller's stream does the long one
 	hipStream_t side;
@@ -234,7 +234,7 @@ int nh_onesweep_u32_u32(nh_context* ctx, uint32_t* keys_a, uint32_t* keys_b, uin
 int nh_onesweep_u64_u32_two_fields(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b,
                                     const uint32_t* d_count, uint32_t capacity, uint32_t expected, uint32_t* scratch, int field_bits);
 // Tag sort of st->records (key, value) pairs seeded by the previous step's result (see nh_util.hip).  Sorted data ends in keys_a / vals_a.
-uint32_t nh_bucket_sort_max_buckets(uint32_t capacity);
+uint32_t nh_bucket_sort_max_buckets(const nh_context* ctx, uint32_t capacity);
 void nh_bucket_sort_u64_u32(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t capacity, uint2* place, int field_bits);
 void nh_bucket_sort_seed(nh_context* ctx, const uint64_t* sorted_keys, uint32_t capacity);
 // Exclusive scan of `in[0..n)` into `out` (may alias); n read from *d_count (+ `extra` elements);

@@ -380,7 +380,7 @@ int nh_onesweep_u64_u32_two_fields(nh_context* ctx, uint64_t* keys_a, uint64_t* 
 // Any distribution is sorted correctly: a bucket larger than a tile is sorted by its workgroup through global memory (slow,
 // only seen when the world changes abruptly); with no history (first step, capacity change) the radix passes run instead and
 // seed the splitters.  Keys are unique (one record per collider pair), so the arrival order inside a bucket never shows.
-#define BK_TARGET 1024u
+#define BK_TARGET 1024u                 // default; NH_BUCKET_TARGET (read per context) changes it -- a test knob
 #define BK_LDS_SPLITTERS 4096u
 
 __global__ __launch_bounds__(256) void bk_count(const uint64_t* __restrict__ keys, const nh_DevState* __restrict__ st, const uint64_t* __restrict__ splitters,
@@ -511,7 +511,7 @@ __device__ void bk_pass_global(const uint64_t* kin, const uint32_t* vin, uint64_
 }
 
 __global__ __launch_bounds__(256) void bk_sort(uint64_t* kb, uint32_t* vb, uint64_t* ka, uint32_t* va,      // (no __restrict__: oversized buckets ping-pong between the two)
-                                               const uint32_t* __restrict__ starts, nh_DevState* __restrict__ st, os_shifts sh, int field_bits, uint64_t* __restrict__ splitters, uint32_t lds_cap) {
+                                               const uint32_t* __restrict__ starts, nh_DevState* __restrict__ st, os_shifts sh, int field_bits, uint64_t* __restrict__ splitters, uint32_t lds_cap, uint32_t target) {
 	__shared__ uint64_t s_key[OS_TILE];
 	__shared__ uint32_t s_val[OS_TILE];
 	__shared__ uint32_t whist[4][256];
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256) void bk_sort(uint64_t* kb, uint32_t* vb, uint6
 	const uint32_t nb = st->sort_buckets ? st->sort_buckets : 1u;
 	const uint32_t n = st->records;
 	const uint64_t lomask = field_bits >= 32 ? 0xFFFFFFFFull : ((1ull << field_bits) - 1ull);
-	if (blockIdx.x == 0 && threadIdx.x == 0) st->sort_buckets_next = n ? (n + BK_TARGET - 1u) / BK_TARGET : 1u;
+	if (blockIdx.x == 0 && threadIdx.x == 0) st->sort_buckets_next = n ? (n + target - 1u) / target : 1u;
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	whist[0][threadIdx.x] = 0; whist[1][threadIdx.x] = 0; whist[2][threadIdx.x] = 0; whist[3][threadIdx.x] = 0;
 	__syncthreads();
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void bk_sort(uint64_t* kb, uint32_t* vb, uint6
 					const uint32_t g = s + i;
 					const uint64_t k = (key[q] & lomask) | ((key[q] >> field_bits) << 32);
 					ka[g] = k; va[g] = val[q];
-					if (g && (g % BK_TARGET) == 0) splitters[g / BK_TARGET - 1u] = k;
+					if (g && (g % target) == 0) splitters[g / target - 1u] = k;
 				}
 			}
 		} else {
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void bk_sort(uint64_t* kb, uint32_t* vb, uint6
 				const uint32_t g = s + i;
 				const uint64_t k = ck[i];
 				if (ck != ka + s) { ka[g] = k; va[g] = cv[i]; }
-				if (g && (g % BK_TARGET) == 0) splitters[g / BK_TARGET - 1u] = k;
+				if (g && (g % target) == 0) splitters[g / target - 1u] = k;
 			}
 			__syncthreads();
 		}
@@ -606,14 +606,15 @@ __global__ __launch_bounds__(256) void bk_sort(uint64_t* kb, uint32_t* vb, uint6
 }
 
 // splitters for the next step from a sorted key array (after the radix passes ran: first step, capacity change)
-__global__ __launch_bounds__(256) void bk_seed(const uint64_t* __restrict__ sorted, nh_DevState* __restrict__ st, uint64_t* __restrict__ splitters) {
+__global__ __launch_bounds__(256) void bk_seed(const uint64_t* __restrict__ sorted, nh_DevState* __restrict__ st, uint64_t* __restrict__ splitters, uint32_t target) {
 	const uint32_t n = st->records;
-	const uint32_t nb = n ? (n + BK_TARGET - 1u) / BK_TARGET : 1u;
+	const uint32_t nb = n ? (n + target - 1u) / target : 1u;
 	if (blockIdx.x == 0 && threadIdx.x == 0) st->sort_buckets_next = nb;
-	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j + 1 < nb; j += gridDim.x * blockDim.x) splitters[j] = sorted[(size_t)(j + 1u) * BK_TARGET];
+	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j + 1 < nb; j += gridDim.x * blockDim.x) splitters[j] = sorted[(size_t)(j + 1u) * target];
 }
 
-uint32_t nh_bucket_sort_max_buckets(uint32_t capacity) { return capacity / BK_TARGET + 2u; }
+static uint32_t bucket_target(const nh_context* ctx) { return ctx->sort_target >= 1u && ctx->sort_target <= (uint32_t)OS_TILE ? ctx->sort_target : BK_TARGET; }
+uint32_t nh_bucket_sort_max_buckets(const nh_context* ctx, uint32_t capacity) { return capacity / bucket_target(ctx) + 2u; }
 
 // keys_a/vals_a: in and out; keys_b/vals_b: scratch of the same size.  st->records keys; splitters / counts / starts: the context's
 // (nh_bucket_sort_max_buckets(capacity) + 1 entries each, counts zeroed once); place: capacity entries of scratch.
@@ -621,15 +622,15 @@ void nh_bucket_sort_u64_u32(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b,
 	nh_DevState* st = ctx->d_state;
 	// NH_BUCKET_TILE (read per context): buckets above this size take the through-global-memory path -- a test knob, the default is the tile
 	const uint32_t lds_cap = ctx->sort_tile >= 1u && ctx->sort_tile <= (uint32_t)OS_TILE ? ctx->sort_tile : (uint32_t)OS_TILE;
-	const uint32_t max_buckets = nh_bucket_sort_max_buckets(capacity);
+	const uint32_t max_buckets = nh_bucket_sort_max_buckets(ctx, capacity);
 	NH_LAUNCH(ctx, "bucket_count", bk_count, nh_grid_for(capacity, 256, 2048), 256, keys_a, st, ctx->sort_splitters, place, ctx->sort_counts);
 	NH_LAUNCH(ctx, "bucket_scan", bk_scan, 1, 1024, st, ctx->sort_counts, ctx->sort_starts);
 	NH_LAUNCH(ctx, "bucket_scatter", bk_scatter, nh_grid_for(capacity, 256, 2048), 256, keys_a, vals_a, st, place, ctx->sort_starts, keys_b, vals_b);
-	NH_LAUNCH(ctx, "bucket_sort", bk_sort, max_buckets < 4096u ? max_buckets : 4096u, 256, keys_b, vals_b, keys_a, vals_a, ctx->sort_starts, st, two_field_shifts(field_bits), field_bits, ctx->sort_splitters, lds_cap);
+	NH_LAUNCH(ctx, "bucket_sort", bk_sort, max_buckets < 4096u ? max_buckets : 4096u, 256, keys_b, vals_b, keys_a, vals_a, ctx->sort_starts, st, two_field_shifts(field_bits), field_bits, ctx->sort_splitters, lds_cap, bucket_target(ctx));
 }
 
 void nh_bucket_sort_seed(nh_context* ctx, const uint64_t* sorted_keys, uint32_t capacity) {
-	NH_LAUNCH(ctx, "bucket_seed", bk_seed, nh_grid_for(nh_bucket_sort_max_buckets(capacity), 256, 64), 256, sorted_keys, ctx->d_state, ctx->sort_splitters);
+	NH_LAUNCH(ctx, "bucket_seed", bk_seed, nh_grid_for(nh_bucket_sort_max_buckets(ctx, capacity), 256, 64), 256, sorted_keys, ctx->d_state, ctx->sort_splitters, bucket_target(ctx));
 }
 
 __global__ __launch_bounds__(256) void k_copy_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const uint32_t* __restrict__ d_n, uint32_t words_per_item) {

@@ -407,12 +407,15 @@ def test_short_rsqrt_sequences_are_exact_wherever_their_guard_passes():
 
 # ---- the seeded tag sort's uncommon paths ----------------------------------------------------------------------------
 @needs_ref
-@pytest.mark.parametrize("tile", ["1", "37", "700"])
-def test_seeded_sort_oversized_buckets_and_abrupt_change(tile, monkeypatch):
+@pytest.mark.parametrize("tile,target", [("1", None), ("37", None), ("700", None), (None, "2"), ("3", "2")])
+def test_seeded_sort_oversized_buckets_and_abrupt_change(tile, target, monkeypatch):
     """nh_util.hip: a bucket that outgrows its workgroup's tile is sorted through global memory.  NH_BUCKET_TILE shrinks the tile so
     that (nearly) every bucket of a forming pile takes that path; the world must still match the reference bit for bit, including
     across an abrupt change of the contact set (bodies teleported apart, then dropped again)."""
-    monkeypatch.setenv("NH_BUCKET_TILE", tile)
+    if tile:
+        monkeypatch.setenv("NH_BUCKET_TILE", tile)
+    if target:
+        monkeypatch.setenv("NH_BUCKET_TARGET", target)       # 2 keys per bucket: thousands of buckets, splitters searched in global memory
     scene = S.pile(n_boxes=700, n_spheres=300, seed=11, iterations=4)
     scene["body_transforms"]["position"][1:, 1] *= 0.08        # a dense column: many pairs from the first steps on
     w = E.World(scene, flags=EXACT, max_contacts=60000)
