@@ -16,6 +16,7 @@
 //     levels run one after the other, contacts inside a level are independent.  Executing levels in order
 //     is exactly the sequential Gauss-Seidel sweep in slot order.
 #include "nh_internal.h"
+#include <type_traits>
 #include "nh_solver.h"
 
 #define NH_NONE 0xFFFFFFFFu
@@ -193,28 +194,30 @@ __global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st
 			const uint32_t inf = info[x];
 			if ((inf & 0xFFFFu) == 1u && (inf >> 16) == 0u && d <= 8u) {
 				const uint32_t f = first_contact[x];
-				uint32_t c[8], k[8];
+				// contacts f .. f+d-1 in slot order (insertion sort in registers: a 4-entry network for the usual box on the ground, 8 otherwise),
+				// as the adjacency list and, in one record for the solver (no walk through off[] and adj[]), as first contact, count and
+				// 3-bit offsets in slot order
+				auto emit = [&](auto tag) {
+					constexpr int W = decltype(tag)::value;
+					uint32_t c[W], k[W];
 #pragma unroll
-				for (int q = 0; q < 8; ++q) { c[q] = (uint32_t)q < d ? f + q : 0xFFFFFFFFu; k[q] = (uint32_t)q < d ? slot_key_of(c[q], slot_key) : 0xFFFFFFFFu; }
+					for (int q = 0; q < W; ++q) { c[q] = (uint32_t)q < d ? f + q : 0xFFFFFFFFu; k[q] = (uint32_t)q < d ? slot_key_of(c[q], slot_key) : 0xFFFFFFFFu; }
 #pragma unroll
-				for (int q = 1; q < 8; ++q) {
+					for (int q = 1; q < W; ++q) {
 #pragma unroll
-					for (int j = q; j > 0; --j) {
-						bool sw = (k[j] < k[j - 1]) || (k[j] == k[j - 1] && c[j] < c[j - 1]);
-						uint32_t tc = sw ? c[j - 1] : c[j], tk = sw ? k[j - 1] : k[j];
-						c[j - 1] = sw ? c[j] : c[j - 1]; k[j - 1] = sw ? k[j] : k[j - 1];
-						c[j] = tc; k[j] = tk;
+						for (int j = q; j > 0; --j) {
+							bool sw = (k[j] < k[j - 1]) || (k[j] == k[j - 1] && c[j] < c[j - 1]);
+							uint32_t tc = sw ? c[j - 1] : c[j], tk = sw ? k[j - 1] : k[j];
+							c[j - 1] = sw ? c[j] : c[j - 1]; k[j - 1] = sw ? k[j] : k[j - 1];
+							c[j] = tc; k[j] = tk;
+						}
 					}
-				}
-#pragma unroll
-				for (int q = 0; q < 8; ++q) if ((uint32_t)q < d) adj[b + q] = c[q];
-				// the same list in one record for the solver (no walk through off[] and adj[]): first contact, count, slot order as 3-bit offsets
-				{
 					uint32_t perm = 0;
 #pragma unroll
-					for (int q = 0; q < 8; ++q) if ((uint32_t)q < d) perm |= (c[q] - f) << (3 * q);
+					for (int q = 0; q < W; ++q) if ((uint32_t)q < d) { adj[b + q] = c[q]; perm |= (c[q] - f) << (3 * q); }
 					simple[x] = make_uint2(f, d | (perm << 4));
-				}
+				};
+				if (d <= 4u) emit(std::integral_constant<int, 4>()); else emit(std::integral_constant<int, 8>());
 				cls = d <= 4u ? NH_CLS_STATIC4 : NH_CLS_STATIC8;
 				if (cls == NH_CLS_STATIC8) st->has_static8 = 1;
 			} else {
