@@ -307,7 +307,7 @@ __device__ __forceinline__ bool aabb_overlap(const float4& amin, const float4& a
 // one atomic per wave per hit-iteration would cost more than the search itself: every wave stages its pairs in
 // its own LDS buffer and reserves global space once per ~450 pairs.
 #define FP_WBUF 512
-struct pair_stage { uint2* buf; uint32_t count; };
+struct pair_stage { uint2* buf; uint32_t count; uint32_t cap; };
 
 __device__ __forceinline__ void flush_pairs(nh_DevState* st, uint2* pairs, uint32_t pair_cap, pair_stage& ps) {
 	uint32_t n = ps.count;
@@ -351,7 +351,7 @@ __device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_
 		ps.buf[ps.count + (uint32_t)__popcll(bal & ((1ull << nh_lane()) - 1ull))] = a_first ? make_uint2(cb, ca) : make_uint2(ca, cb);
 	}
 	ps.count += (uint32_t)__popcll(bal);
-	if (ps.count > FP_WBUF - 64) flush_pairs(st, pairs, pair_cap, ps);
+	if (ps.count > ps.cap - 64) flush_pairs(st, pairs, pair_cap, ps);
 }
 
 // ---- 5. pair search: grid neighbours + large list ---------------------------------------------------------
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
 	const uint32_t nlarge = st->large;
 	__shared__ uint2 wave_buf[4][FP_WBUF];
-	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u };
+	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u, FP_WBUF };
 	uint32_t rounded = (n + 63u) & ~63u;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
 		bool valid = i < n;
@@ -432,7 +432,9 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 
 // small x large pairs, found from the LARGE side: a large collider (ground slab, wall) visits the grid cells its AABB
 // covers instead of every small collider testing every large one (124 slabs x 1 M boxes = 1.2e8 tests otherwise).
-#define LP_SLICES 16
+// One reservation of pair slots (an atomic on ONE counter: ~12 ns each, serialised) per workgroup: few, large workgroup shares
+#define LP_SLICES 8
+#define LP_WBUF 1024
 __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ st, const float4* __restrict__ smin, const float4* __restrict__ smax,
                                                      const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
                                                      const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
@@ -441,8 +443,8 @@ __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ s
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
 	const uint32_t nlarge = st->large;
-	__shared__ uint2 wave_buf[4][FP_WBUF];
-	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u };
+	__shared__ uint2 wave_buf[4][LP_WBUF];
+	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u, LP_WBUF };
 	const uint32_t slice = blockIdx.x % LP_SLICES;
 	for (uint32_t l = blockIdx.x / LP_SLICES; l < nlarge; l += gridDim.x / LP_SLICES) {
 		const uint32_t ca = large_list[l];
