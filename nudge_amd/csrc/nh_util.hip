@@ -713,19 +713,52 @@ __global__ __launch_bounds__(256) void sc_final(const uint32_t* __restrict__ in_
 		if (d_total_a) *d_total_a = carry_a + tmp[blockIdx.x];
 		if (d_total_b) *d_total_b = carry_b + tmp[RS_G + blockIdx.x];
 	}
-	for (uint32_t tile = begin; tile < end; tile += RS_TILE) {
-		uint32_t i = tile + threadIdx.x;
+	// eight consecutive items per thread: local sums, ONE workgroup scan per 2048 items and array, eight outputs
+	constexpr uint32_t SC_IPT = 8;
+	for (uint32_t tile = begin; tile < end; tile += RS_TILE * SC_IPT) {
+		const uint32_t i0 = tile + threadIdx.x * SC_IPT;
+		uint32_t va[SC_IPT], vb[SC_IPT], sa = 0, sb = 0;
+#pragma unroll
+		for (uint32_t k = 0; k < SC_IPT; ++k) va[k] = vb[k] = 0u;
+		const bool full = i0 + SC_IPT <= end;           // (chunks start at multiples of 256 items and the arrays are 16-byte aligned)
+		if (full) {
+			const uint4 x0 = *reinterpret_cast<const uint4*>(in_a + i0), x1 = *reinterpret_cast<const uint4*>(in_a + i0 + 4);
+			va[0] = x0.x; va[1] = x0.y; va[2] = x0.z; va[3] = x0.w; va[4] = x1.x; va[5] = x1.y; va[6] = x1.z; va[7] = x1.w;
+			if (in_b) {
+				const uint4 y0 = *reinterpret_cast<const uint4*>(in_b + i0), y1 = *reinterpret_cast<const uint4*>(in_b + i0 + 4);
+				vb[0] = y0.x; vb[1] = y0.y; vb[2] = y0.z; vb[3] = y0.w; vb[4] = y1.x; vb[5] = y1.y; vb[6] = y1.z; vb[7] = y1.w;
+			}
+		} else {
+#pragma unroll
+			for (uint32_t k = 0; k < SC_IPT; ++k) { if (i0 + k < end) { va[k] = in_a[i0 + k]; if (in_b) vb[k] = in_b[i0 + k]; } }
+		}
+#pragma unroll
+		for (uint32_t k = 0; k < SC_IPT; ++k) { sa += va[k]; sb += vb[k]; }
 		uint32_t total;
-		uint32_t v = i < end ? in_a[i] : 0u;
-		uint32_t ex = block_exclusive_scan_256(v, wsum, total);
-		if (i < end) out_a[i] = carry_a + ex;
+		uint32_t ex = carry_a + block_exclusive_scan_256(sa, wsum, total);
 		carry_a += total;
+#pragma unroll
+		for (uint32_t k = 0; k < SC_IPT; ++k) { const uint32_t v = va[k]; va[k] = ex; ex += v; }
+		if (full) {
+			*reinterpret_cast<uint4*>(out_a + i0) = make_uint4(va[0], va[1], va[2], va[3]);
+			*reinterpret_cast<uint4*>(out_a + i0 + 4) = make_uint4(va[4], va[5], va[6], va[7]);
+		} else {
+#pragma unroll
+			for (uint32_t k = 0; k < SC_IPT; ++k) if (i0 + k < end) out_a[i0 + k] = va[k];
+		}
 		__syncthreads();
 		if (in_b) {
-			v = i < end ? in_b[i] : 0u;
-			ex = block_exclusive_scan_256(v, wsum, total);
-			if (i < end) out_b[i] = carry_b + ex;
+			ex = carry_b + block_exclusive_scan_256(sb, wsum, total);
 			carry_b += total;
+#pragma unroll
+			for (uint32_t k = 0; k < SC_IPT; ++k) { const uint32_t v = vb[k]; vb[k] = ex; ex += v; }
+			if (full) {
+				*reinterpret_cast<uint4*>(out_b + i0) = make_uint4(vb[0], vb[1], vb[2], vb[3]);
+				*reinterpret_cast<uint4*>(out_b + i0 + 4) = make_uint4(vb[4], vb[5], vb[6], vb[7]);
+			} else {
+#pragma unroll
+				for (uint32_t k = 0; k < SC_IPT; ++k) if (i0 + k < end) out_b[i0 + k] = vb[k];
+			}
 			__syncthreads();
 		}
 	}
