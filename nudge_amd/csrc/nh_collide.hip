@@ -432,8 +432,11 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 
 // small x large pairs, found from the LARGE side: a large collider (ground slab, wall) visits the grid cells its AABB
 // covers instead of every small collider testing every large one (124 slabs x 1 M boxes = 1.2e8 tests otherwise).
-// One reservation of pair slots (an atomic on ONE counter: ~12 ns each, serialised) per workgroup: few, large workgroup shares
-#define LP_SLICES 8
+// One reservation of pair slots (an atomic on ONE counter: ~12 ns each, serialised) per workgroup: few, large workgroup shares --
+// about LP_BLOCKS workgroups are active in all, so a large collider is cut into LP_BLOCKS / (number of large colliders) slices:
+// 8 for the 124 ground slabs of the drop scenes, 200 for the five walls of the ball pit (whose 25,000 cell rows each would
+// otherwise be walked one after the other by a handful of waves)
+#define LP_BLOCKS 1024u
 #define LP_WBUF 1024
 __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ st, const float4* __restrict__ smin, const float4* __restrict__ smax,
                                                      const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
@@ -445,8 +448,10 @@ __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ s
 	const uint32_t nlarge = st->large;
 	__shared__ uint2 wave_buf[4][LP_WBUF];
 	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u, LP_WBUF };
-	const uint32_t slice = blockIdx.x % LP_SLICES;
-	for (uint32_t l = blockIdx.x / LP_SLICES; l < nlarge; l += gridDim.x / LP_SLICES) {
+	uint32_t slices = nlarge ? LP_BLOCKS / nlarge : 1u;
+	slices = min(max(slices, 1u), gridDim.x);
+	const uint32_t slice = blockIdx.x % slices;
+	for (uint32_t l = blockIdx.x / slices; l < nlarge; l += gridDim.x / slices) {
 		const uint32_t ca = large_list[l];
 		const float4 amin = aabb_min[ca], amax = aabb_max[ca];
 		const uint32_t abody = __float_as_uint(amin.w);
@@ -460,7 +465,7 @@ __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ s
 		const uint32_t wy = (uint32_t)(y1 - y0 + 1), wz = (uint32_t)(z1 - z0 + 1);
 		const uint32_t nrows = wy * wz;
 		const uint32_t lane = threadIdx.x & 63u;
-		for (uint32_t r = slice * 4u + (threadIdx.x >> 6); r < nrows; r += LP_SLICES * 4u) {       // wave-uniform
+		for (uint32_t r = slice * 4u + (threadIdx.x >> 6); r < nrows; r += slices * 4u) {       // wave-uniform
 			const uint32_t cy = r % wy, cz = r / wy;
 			const uint32_t row = (uint32_t)(((z0 + (int)cz) * ny + (y0 + (int)cy)) * nx);
 			const uint32_t j0 = cstart[row + (uint32_t)x0], jend = cstart[row + (uint32_t)x1 + 1u];
