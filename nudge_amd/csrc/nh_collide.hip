@@ -341,9 +341,15 @@ __device__ __forceinline__ void flush_pairs_block(nh_DevState* st, uint2* pairs,
 	}
 }
 
-__device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_t pair_cap, uint64_t ka, const uint64_t* kb_ptr, uint32_t ca, uint32_t cb, bool hit, pair_stage& ps) {
+__device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t b);
+
+// `islands`: non-null while some body is asleep -- the coarse islands (nudge.cpp:3575-3650: sets over the broadphase pairs, body 0 ignored) are
+// united right where a pair is found
+__device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_t pair_cap, uint64_t ka, const uint64_t* kb_ptr, uint32_t ca, uint32_t cb, bool hit, pair_stage& ps,
+                                          uint32_t* islands, uint32_t body_a, uint32_t body_b) {
 	unsigned long long bal = __ballot(hit);
 	if (!bal) return;
+	if (hit && islands && body_a && body_b) uf_union(islands, body_a, body_b);
 	if (hit) {
 		uint64_t kb = *kb_ptr;
 		bool a_first = (ka < kb) || (ka == kb && ca < cb);
@@ -359,7 +365,9 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
                                                     const uint32_t* __restrict__ keys, const float4* __restrict__ smin, const float4* __restrict__ smax,
                                                     const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
                                                     const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
-                                                    const uint64_t* __restrict__ mkey, const uint64_t* __restrict__ smk, uint2* __restrict__ pairs, uint32_t pair_cap) {
+                                                    const uint64_t* __restrict__ mkey, const uint64_t* __restrict__ smk, uint2* __restrict__ pairs, uint32_t pair_cap,
+                                                    uint32_t* __restrict__ coarse_parent, uint32_t parity) {
+	uint32_t* const islands = st->any_idle[parity] ? coarse_parent : nullptr;
 	const float inv = st->cell_inv;
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
@@ -408,13 +416,13 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 			}
 			if (!__any(have)) break;
 			bool hit = false;
-			uint32_t cb = 0;
+			uint32_t cb = 0, bbody = 0;
 			if (have) {
 				float4 bmin = smin[cand], bmax = smax[cand];
-				cb = __float_as_uint(bmax.w);
-				hit = aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != abody);
+				cb = __float_as_uint(bmax.w); bbody = __float_as_uint(bmin.w);
+				hit = aabb_overlap(amin, amax, bmin, bmax) && (bbody != abody);
 			}
-			emit_pair(st, pairs, pair_cap, ka, smk + cand, ca, cb, hit, ps);
+			emit_pair(st, pairs, pair_cap, ka, smk + cand, ca, cb, hit, ps, islands, abody, bbody);
 		}
 		// large x larger-indexed large (small x large is found from the large side: k_large_pairs)
 		const bool a_large = valid && key == NH_LARGE_KEY;
@@ -423,7 +431,7 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 				uint32_t cb = large_list[l];
 				float4 bmin = aabb_min[cb], bmax = aabb_max[cb];
 				bool hit = a_large && cb > ca && aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != abody);
-				emit_pair(st, pairs, pair_cap, ka, mkey + cb, ca, cb, hit, ps);
+				emit_pair(st, pairs, pair_cap, ka, mkey + cb, ca, cb, hit, ps, islands, abody, __float_as_uint(bmin.w));
 			}
 		}
 	}
@@ -441,7 +449,9 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ st, const float4* __restrict__ smin, const float4* __restrict__ smax,
                                                      const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
                                                      const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
-                                                     const uint64_t* __restrict__ mkey, const uint64_t* __restrict__ smk, uint2* __restrict__ pairs, uint32_t pair_cap) {
+                                                     const uint64_t* __restrict__ mkey, const uint64_t* __restrict__ smk, uint2* __restrict__ pairs, uint32_t pair_cap,
+                                                    uint32_t* __restrict__ coarse_parent, uint32_t parity) {
+	uint32_t* const islands = st->any_idle[parity] ? coarse_parent : nullptr;
 	const float inv = st->cell_inv;
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
@@ -473,13 +483,13 @@ __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ s
 				const uint32_t cand = base + lane;
 				const bool have = cand < jend;
 				bool hit = false;
-				uint32_t cb = 0;
+				uint32_t cb = 0, bbody = 0;
 				if (have) {
 					float4 bmin = smin[cand], bmax = smax[cand];
-					cb = __float_as_uint(bmax.w);
-					hit = aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != abody);
+					cb = __float_as_uint(bmax.w); bbody = __float_as_uint(bmin.w);
+					hit = aabb_overlap(amin, amax, bmin, bmax) && (bbody != abody);
 				}
-				emit_pair(st, pairs, pair_cap, ka, smk + (have ? cand : 0u), ca, cb, hit, ps);
+				emit_pair(st, pairs, pair_cap, ka, smk + (have ? cand : 0u), ca, cb, hit, ps, islands, abody, bbody);
 			}
 		}
 	}
@@ -496,7 +506,11 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
                                                      const nh_xform* __restrict__ xf, const uint32_t* __restrict__ ctag,
                                                      const nh_BoxCollider* __restrict__ box_data, const nh_SphereCollider* __restrict__ sph_data, uint32_t nbox,
                                                      nh_Contact* __restrict__ raw_data, uint32_t* __restrict__ raw_feature, uint32_t pair_cap, uint32_t overflow_cap,
-                                                     uint64_t* __restrict__ rec_key, nh_Record* __restrict__ rec, uint32_t* __restrict__ rec_idx) {
+                                                     uint64_t* __restrict__ rec_key, nh_Record* __restrict__ rec, uint32_t* __restrict__ rec_idx,
+                                                     const uint32_t* __restrict__ coarse_root, const uint32_t* __restrict__ coarse_active, uint32_t parity) {
+	// coarse islands (nudge.cpp:3500-3703): a pair whose bodies belong to a set of sleeping bodies (sets over the BROADPHASE pairs and the
+	// user's connections) never reaches the narrowphase: it becomes a sleeping pair, larger tag in the low half (3697)
+	const bool some_asleep = st->any_idle[parity] != 0;
 	__shared__ float4 s_c0[4][256], s_c1[4][256];
 	__shared__ uint32_t s_f[4][256];
 	__shared__ uint8_t s_n[4][64];
@@ -510,11 +524,25 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		int count = 0;
 		uint64_t key = 0;
 		uint32_t body_a = 0, body_b = 0;
+		bool asleep = false;
 		if (i < n) {
 			uint2 pr = pairs[i];
 			uint32_t a = pr.x, b = pr.y;            // a = later in Morton order
 			bool a_sph = a >= nbox, b_sph = b >= nbox;
-			if (!a_sph && !b_sph) {
+			bool coarse_asleep = false;
+			if (some_asleep) {
+				const uint32_t ba = xf[a].body, bb2 = xf[b].body;
+				const uint32_t set = coarse_root[ba ? ba : bb2];            // sets[a] | sets[b] with sets[0] = 0 (nudge.cpp:3687)
+				coarse_asleep = !coarse_active[set];
+				if (coarse_asleep) {
+					const uint32_t ta = ctag[a], tb = ctag[b];
+					key = ta > tb ? ((uint64_t)ta | ((uint64_t)tb << 32)) : ((uint64_t)tb | ((uint64_t)ta << 32));
+					body_a = ba; body_b = bb2;
+					asleep = true;
+				}
+			}
+			if (coarse_asleep) {
+			} else if (!a_sph && !b_sph) {
 				nh_xform A = xf[a], B = xf[b];
 				nh_BoxCollider sa = box_data[a], sb = box_data[b];
 				uint32_t ta = ctag[a], tb = ctag[b];
@@ -583,7 +611,8 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 				put(0, single);
 			}
 			rec_key[i] = key;
-			nh_Record r = { body_a, body_b, ovf, (uint32_t)count };
+			nh_Record r = { body_a, body_b, ovf, asleep ? NH_REC_SLEEPING : (uint32_t)count };
+			if (asleep) st->any_sleeping = 1;
 			rec[i] = r;
 			rec_idx[i] = i;
 		}
@@ -635,7 +664,7 @@ __global__ __launch_bounds__(256) void k_uf_union_records(const nh_DevState* __r
 	uint32_t n = st->records;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		nh_Record r = rec[i];
-		if (r.count && r.body_a && r.body_b) uf_union(parent, r.body_a, r.body_b);      // body 0 is the static world (nudge.cpp:3874-3876)
+		if ((r.count & ~NH_REC_SLEEPING) && r.body_a && r.body_b) uf_union(parent, r.body_a, r.body_b);      // body 0 is the static world (nudge.cpp:3874-3876); pairs dropped at the coarse level have no contacts
 	}
 }
 
@@ -693,7 +722,7 @@ __global__ __launch_bounds__(256) void k_filter_records(nh_DevState* __restrict_
 		uint64_t key = 0;
 		if (i < n) {
 			nh_Record r = rec[i];
-			if (r.count) {
+			if (r.count && !(r.count & NH_REC_SLEEPING)) {
 				uint32_t set = root_of[r.body_a ? r.body_a : r.body_b];      // sets[a] | sets[b] with sets[0] = 0 (nudge.cpp:3988)
 				sleeping = !set_active[set];
 				if (sleeping) { rec[i].count = NH_REC_SLEEPING; st->any_sleeping = 1; }   // no contacts any more; key kept: sleeping pairs come out in tag order
@@ -816,9 +845,9 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 // union-find over the contact records -- expensive when millions of bodies form one island -- is skipped.  The flag is double
 // buffered by step parity: this step's launch sets any_idle[parity] with plain stores and clears the other one for the next step.
 __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t ncolliders, uint32_t nbodies, uint32_t* __restrict__ parent, uint32_t* __restrict__ set_active, uint32_t* __restrict__ deg,
-                                                       const uint8_t* __restrict__ idle, uint32_t parity) {
+                                                       const uint8_t* __restrict__ idle, uint32_t parity, uint32_t* __restrict__ coarse_parent, uint32_t* __restrict__ coarse_active) {
 	bool asleep = false;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) { parent[i] = i; set_active[i] = 0; asleep |= i >= 1 && idle[i] == 0xff; }
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) { parent[i] = i; set_active[i] = 0; coarse_parent[i] = i; coarse_active[i] = 0; asleep |= i >= 1 && idle[i] == 0xff; }
 	if (asleep) st->any_idle[parity] = 1;
 	if (blockIdx.x == 0 && threadIdx.x == 0) st->any_idle[parity ^ 1u] = 0;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < 3u * (nbodies + 2u); i += gridDim.x * blockDim.x) deg[i] = 0;      // degrees, fill cursors, pair info
@@ -895,6 +924,9 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	uint32_t* set_active = nh_arena_array<uint32_t>(A, B, &err);
 	uint32_t* root_of = nh_arena_array<uint32_t>(A, B, &err);
 	uint32_t* flags = nh_arena_array<uint32_t>(A, B + 1, &err);
+	uint32_t* coarse_parent = nh_arena_array<uint32_t>(A, B, &err);
+	uint32_t* coarse_active = nh_arena_array<uint32_t>(A, B, &err);
+	uint32_t* coarse_root = nh_arena_array<uint32_t>(A, B, &err);
 	if (err) return err;
 
 	hipStream_t s = ctx->stream;
@@ -919,7 +951,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->sort_counts, 0, sizeof(uint32_t) * nbk, s));
 		ctx->sort_capacity = pair_cap;
 	}
-	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, nh_grid_for(B, 256, 2048), 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity);
+	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, nh_grid_for(B, 256, 2048), 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity, coarse_parent, coarse_active);
 	if (C) {
 		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 1024, 256), 1024, st, bodies->transforms,
 		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
@@ -932,10 +964,16 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_sums, max_cells / CS_TILE, 256, cstart, cscan_sums);
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_final, max_cells / CS_TILE, 256, cstart, cscan_sums, max_cells);
 		NH_LAUNCH(ctx, "cell_scatter", k_cell_scatter, nh_grid_for(C, 256, 2048), 256, st, C, keys_a, vals_a, cstart, aabb_min, aabb_max, keys_b, smin, smax, mkey, smk);
-		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 1024), 256, st, C, keys_b, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap);
-		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, 2048, 256, st, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap);
+		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 1024), 256, st, C, keys_b, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap, coarse_parent, ctx->step_parity);
+		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, 2048, 256, st, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap, coarse_parent, ctx->step_parity);
+		// coarse islands over the broadphase pairs (united where the pairs were emitted) + connections: only when some body is asleep (a device
+		// flag: the kernels leave at once otherwise)
+		if (body_connections && body_connections->count)
+			NH_LAUNCH(ctx, "uf_union_connections", k_uf_union_connections, nh_grid_for(body_connections->count, 256, 512), 256, st, body_connections->data, body_connections->count, coarse_parent, ctx->step_parity);
+		NH_LAUNCH(ctx, "coarse_flatten", k_uf_flatten, nh_grid_for(B, 256, 512), 256, st, ctx->step_parity, B, coarse_parent, bodies->idle_counters, coarse_active, coarse_root);
 		NH_LAUNCH(ctx, "narrowphase", k_narrowphase, nh_grid_for(pair_cap, 256, 4096), 256, st, pairs, xf, ctag,
-		          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a);
+		          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a,
+		          coarse_root, coarse_active, ctx->step_parity);
 	}
 	// islands over contact records (+ user connections): a chain of small kernels that the tag sort of the records does not depend
 	// on -- it runs on the side stream while the caller's stream sorts (fork here, join before k_sorted_counts)

@@ -464,3 +464,43 @@ def test_wide_sparse_collider_tags_do_not_change_the_world(mult, offset, sort, m
     assert np.array_equal((lo * np.uint64(mult) + np.uint64(offset)) | ((hi * np.uint64(mult) + np.uint64(offset)) << np.uint64(32)), cb["tags"])
     assert np.array_equal(ca["features"], cb["features"]) and P.bits_equal(ca["data"], cb["data"])
     a.close(); b.close()
+
+
+# ---- sleeping: coarse (broadphase-level) and fine (contact-level) islands ------------------------------------------------
+def _ref_cache_wide(rc):
+    """reference cache tags (feature | (a16 | b16 << 16) << 32) -> this ABI's (a | b << 32, feature)"""
+    t = rc["tags"]
+    hi = t >> np.uint64(32)
+    return (hi & np.uint64(0xFFFF)) | ((hi >> np.uint64(16)) << np.uint64(32)), (t & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+
+
+@needs_ref
+@pytest.mark.parametrize("name,steps,checks", [("settling pile", 1500, (1100, 1300, 1500)), ("mixed tile falling asleep", 560, (300, 420, 560))])
+def test_sleeping_pairs_and_cache_match_reference_while_a_world_falls_asleep(name, steps, checks):
+    """nudge.cpp:3500-3703 drops the pairs of sleeping sets BEFORE the narrowphase (sets over broadphase pairs: a pair whose boxes
+    overlap without touching is a sleeping pair too, and it is reported larger-tag-first), 3788-4006 those of sleeping contact islands
+    after it; 4064-4101 keeps the cached impulses whose tag matches a sleeping pair (which, for box-sphere pairs dropped at the coarse
+    level, it does not: the formats differ).  Bodies, active list, sleeping pairs and the cache must all follow the reference."""
+    if name == "settling pile":
+        scene = S.pile(n_boxes=256, n_spheres=0, seed=1, iterations=4)
+    else:
+        scene = S.grid_tiles(1, side=12, sphere_fraction=0.5, seed=7)
+    w = E.World(scene, flags=EXACT)
+    ref = refworld.RefWorld(scene)
+    done, seen_sleeping = 0, 0
+    for upto in checks:
+        w.step(upto - done); ref.step(upto - done); done = upto
+        b, rb = w.get_bodies(), ref.bodies()
+        assert P.bits_equal(b["transforms"], rb["transforms"]) and np.array_equal(b["idle"], rb["idle"])
+        kc, rk = w.get_cache(), ref.cache()
+        wt, wf = _ref_cache_wide(rk)
+        assert kc["count"] == rk["count"] and np.array_equal(kc["tags"], wt) and np.array_equal(kc["features"], wf)
+        assert P.bits_equal(kc["data"]["impulse"], rk["data"]["impulse"])
+        w.collide(); ref.collide()
+        c, rc = w.get_contacts(), ref.contacts()
+        assert c["count"] == rc["count"]
+        assert np.array_equal(c["sleeping_pairs"], P.widen_sleeping(rc["sleeping_pairs"]))
+        assert np.array_equal(w.get_active(), ref.active().astype(np.uint32))
+        seen_sleeping = max(seen_sleeping, len(rc["sleeping_pairs"]))
+    assert seen_sleeping > 0
+    w.close()
