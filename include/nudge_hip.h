@@ -86,7 +86,8 @@ typedef struct nh_ContactData {                                                 
 	uint32_t* features;        /* feature word (reference: low 32 bits of the tag) */
 	uint32_t capacity;
 	uint32_t count;
-	uint64_t* sleeping_pairs;  /* same packing as `tags` */
+	uint64_t* sleeping_pairs;  /* tag | tag << 32, ascending: pairs of sleeping sets dropped before the narrowphase carry the larger tag low
+	                              (nudge.cpp:3697), pairs of sleeping contact islands the order of their contact tags (nudge.cpp:3979) */
 	uint32_t sleeping_count;
 } nh_ContactData;
 
