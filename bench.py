@@ -273,6 +273,10 @@ def main():
                 cb = {"error": repr(e)}
             if cb:
                 out["cpu_baseline"] = cb
+        if ktimes:
+            # per-kernel milliseconds per step from the three fully instrumented warm-up steps (events around EVERY launch: the sum exceeds
+            # ms_per_step, small kernels are inflated; the timed region only instruments the dominant kernel)
+            out["kernel_ms_per_step"] = {k: round(ms / 3.0, 5) for k, (ms, n) in sorted(ktimes.items(), key=lambda kv: -kv[1][0])[:16]}
         if cluster is not None:
             st = cluster.p.stats
             out["halo"] = {"ghost_bodies_rank0": st["ghosts"], "refreshes": st["refreshes"], "migrated_out_rank0": st["migrated_out"],
