@@ -101,8 +101,9 @@ def cpu_baseline(scene, warmup, tiles_total, budget_s=20.0):
     wall = refworld.step_tiles(worlds, steps, threads=cores, ftz=True)
     tile_steps_per_s = ntiles * steps / wall
     value = tile_steps_per_s / tiles_total                               # steps/s of the whole 124-tile world
+    per_tile = len(scene['body_transforms']) // max(1, tiles_total)
     return {"value": value, "unit": "steps/s", "cores": cores, "kind": "reference",
-            "sample": f"{ntiles} of {tiles_total} tiles (8100 boxes each) x {steps} steps after {warmup + 10} warm-up steps, "
+            "sample": f"{ntiles} of {tiles_total} tiles ({per_tile} bodies each) x {steps} steps after {warmup + 10} warm-up steps, "
                       f"one tile per host thread, unmodified reference -O3 -mavx2 -mfma, FTZ/DAZ on; scaled by tiles",
             "tile_steps_per_s_per_core": tile_steps_per_s / cores}
 
@@ -266,7 +267,7 @@ def main():
         elif dom:
             out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                                "avg_launch_ms": dom[0] / dom[1]}
-        if world == 1 and not args.no_cpu and args.scene == "boxes":
+        if world == 1 and not args.no_cpu and args.scene in ("boxes", "mixed"):
             try:
                 cb = cpu_baseline(scene, args.warmup, args.tiles)
             except Exception as e:      # the baseline is a report, never a reason to lose the GPU number
