@@ -388,20 +388,27 @@ __global__ __launch_bounds__(256) void bk_count(const uint64_t* __restrict__ key
 	__shared__ uint64_t s_spl[BK_LDS_SPLITTERS];
 	const uint32_t n = st->records;
 	const uint32_t nb = st->sort_buckets ? st->sort_buckets : 1u, ns = nb - 1u;
-	const bool in_lds = ns <= BK_LDS_SPLITTERS;
-	if (in_lds) {
-		for (uint32_t k = threadIdx.x; k < ns; k += 256) s_spl[k] = splitters[k];
-		__syncthreads();
-	}
+	// all splitters in LDS when they fit; otherwise every stride-th one (the last of each block of `stride`): the search first finds the block
+	// in LDS, then finishes inside it in global memory (at most log2(stride) dependent loads instead of log2(ns))
+	const uint32_t stride = (ns + BK_LDS_SPLITTERS - 1u) / BK_LDS_SPLITTERS > 1u ? (ns + BK_LDS_SPLITTERS - 1u) / BK_LDS_SPLITTERS : 1u;
+	const uint32_t nblocks = (ns + stride - 1u) / stride;                   // <= BK_LDS_SPLITTERS
+	for (uint32_t k = threadIdx.x; k < nblocks; k += 256) { const uint32_t last = (k + 1u) * stride - 1u; s_spl[k] = splitters[last < ns ? last : ns - 1u]; }
+	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t nbits = 32u - (uint32_t)__clz(nb);             // bucket ids are < 2^nbits
 	const uint32_t rounded = (n + 63u) & ~63u;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
 		const bool valid = i < n;
 		const uint64_t key = valid ? keys[i] : 0ull;
-		uint32_t lo = 0, hi = ns;                          // bucket = number of splitters <= key
-		if (in_lds) { while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (s_spl[mid] <= key) lo = mid + 1; else hi = mid; } }
-		else        { while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (splitters[mid] <= key) lo = mid + 1; else hi = mid; } }
+		uint32_t lo = 0, hi = nblocks;                     // bucket = number of splitters <= key
+		while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (s_spl[mid] <= key) lo = mid + 1; else hi = mid; }
+		if (stride > 1u) {
+			// blocks 0 .. lo-1 lie entirely at or below the key; the answer is inside block lo (if there is one)
+			uint32_t f0 = lo * stride, f1 = min(f0 + stride, ns);
+			if (lo >= nblocks) { f0 = ns; f1 = ns; }
+			while (f0 < f1) { uint32_t mid = (f0 + f1) >> 1; if (splitters[mid] <= key) f0 = mid + 1; else f1 = mid; }
+			lo = f0;
+		}
 		const uint32_t b = lo;
 		// neighbouring records usually share a bucket (and arrive in waves that hammer the same few counters): lanes with equal
 		// buckets find each other by ballots over the bucket bits, and the lowest lane of every group does ONE atomic for it
