@@ -62,6 +62,7 @@ struct nh_DevState {
 	uint32_t any_idle[2];         // by step parity: some body's idle counter is saturated (asleep)
 	uint32_t sort_buckets;        // buckets of this step's tag sort = splitters of the previous step + 1 (nh_util.hip, bucket sort)
 	uint32_t sort_buckets_next;   // written by this step's sort for the next one
+	uint32_t colour_cursor;       // append cursor of the colouring's list compaction (nh_solve.hip)
 	uint32_t order_conflict;      // exact-order mode: sequence number of the setup call whose closed-form schedule has a lane conflict (nh_solve.hip)
 };
 

@@ -915,8 +915,9 @@ __global__ void k_level_reset_progress(nh_DevState* st) { st->unleveled = 0; st-
 __device__ __forceinline__ uint32_t colour_priority(uint32_t c) { uint32_t h = c * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; return h; }
 
 __global__ __launch_bounds__(256) void k_colour_round(nh_DevState* __restrict__ st, const uint32_t* __restrict__ general_list, const nh_BodyPair* __restrict__ bodies,
-                                                      const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj, uint32_t* __restrict__ level, uint32_t round) {
-	uint32_t n = st->general_contacts;
+                                                      const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj, uint32_t* __restrict__ level, uint32_t round, uint32_t n_list) {
+	// n_list != 0: `general_list` is the compacted list of the contacts that were still uncoloured after an earlier batch of rounds
+	uint32_t n = n_list ? n_list : st->general_contacts;
 	uint32_t left = 0, lmax = 0;
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
 		uint32_t c = general_list[k];
@@ -969,6 +970,34 @@ __global__ __launch_bounds__(256) void k_colour_round(nh_DevState* __restrict__ 
 
 // counting sort of the general contacts by level / colour.  Levels are few and hot: histogram and cursors are kept per
 // workgroup in LDS, global atomics happen once per (workgroup, level).
+// the contacts of `list` that are still uncoloured, in any order (a round's outcome does not depend on who looks at which contact).
+// A workgroup owns a contiguous chunk: it counts, reserves its output range with ONE atomic on the global cursor (same-address atomics are
+// ~12 ns each, serialised), and fills the range through a cursor in LDS.
+__global__ __launch_bounds__(256) void k_colour_compact(nh_DevState* __restrict__ st, const uint32_t* __restrict__ list, uint32_t n_list, const uint32_t* __restrict__ level, uint32_t* __restrict__ out) {
+	__shared__ uint32_t s_count, s_base, s_cursor;
+	const uint32_t n = n_list ? n_list : st->general_contacts;
+	const uint32_t chunk = (n + gridDim.x - 1u) / gridDim.x;
+	const uint32_t begin = min(blockIdx.x * chunk, n), end = min(begin + chunk, n);
+	if (threadIdx.x == 0) { s_count = 0; s_cursor = 0; }
+	__syncthreads();
+	uint32_t mine = 0;
+	for (uint32_t k = begin + threadIdx.x; k < end; k += 256) mine += level[list[k]] == NH_UNSET ? 1u : 0u;
+	for (int d = 32; d >= 1; d >>= 1) mine += (uint32_t)__shfl_xor((int)mine, d);
+	if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&s_count, mine);
+	__syncthreads();
+	if (threadIdx.x == 0) s_base = s_count ? atomicAdd(&st->colour_cursor, s_count) : 0u;
+	__syncthreads();
+	const uint32_t base = s_base;
+	for (uint32_t k0 = begin; k0 < end; k0 += 256) {              // block-uniform trip count
+		const uint32_t k = k0 + threadIdx.x;
+		uint32_t c = 0;
+		bool keep = false;
+		if (k < end) { c = list[k]; keep = level[c] == NH_UNSET; }
+		const uint32_t slot = nh_wave_reserve1(&s_cursor, keep);
+		if (keep) out[base + slot] = c;
+	}
+}
+
 __global__ __launch_bounds__(256) void k_level_hist(nh_DevState* __restrict__ st, const uint32_t* __restrict__ general_list, const uint32_t* __restrict__ level, uint32_t* __restrict__ hist) {
 	__shared__ uint32_t h[NH_MAX_LEVELS + 2];
 	for (uint32_t l = threadIdx.x; l < NH_MAX_LEVELS + 2; l += blockDim.x) h[l] = 0;
@@ -1340,18 +1369,31 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		// relaxation: every round finalises at least the next level
 		uint32_t rounds = 0;
 		NH_LAUNCH(ctx, "level_reset", k_level_reset_progress, 1, 1, st);
+		// colouring: most contacts are settled by the first rounds; the later ones walk a compacted list of the rest (pred_a / pred_b, which
+		// only the exact mode uses, serve as its two buffers)
+		const uint32_t* colour_list = general_list;
+		uint32_t colour_n = 0;                         // 0: the whole general list
+		uint32_t* spare[2] = { pred_a, pred_b };
+		int spare_at = 0;
 		for (;;) {
-			for (int r = 0; r < 8; ++r, ++rounds) {
+			// (short batches first while colouring: the list shrinks fastest in the first rounds, and a batch ends with its compaction)
+			const int batch = (ctx->flags & NH_FLAG_EXACT_ORDER) ? 8 : (rounds < 4 ? 2 : (rounds < 8 ? 4 : 8));
+			for (int r = 0; r < batch; ++r, ++rounds) {
 				if (ctx->flags & NH_FLAG_EXACT_ORDER)
 					NH_LAUNCH(ctx, "level_relax", k_level_relax, nh_grid_for(G, 256, 1024), 256, st, general_list, pred_a, pred_b, level, rounds);
 				else
-					NH_LAUNCH(ctx, "colour_round", k_colour_round, nh_grid_for(G, 256, 1024), 256, st, general_list, contacts->bodies, d->body_off, d->adj, level, rounds);
+					NH_LAUNCH(ctx, "colour_round", k_colour_round, nh_grid_for(colour_n ? colour_n : G, 256, 1024), 256, st, colour_list, contacts->bodies, d->body_off, d->adj, level, rounds, colour_n);
 			}
 			rc = nh_read_counts(ctx, &c);
 			if (rc) return rc;
 			uint32_t left = ((rounds - 1) & 1u) ? ctx->h_state->unleveled_odd : ctx->h_state->unleveled;
 			if (left == 0) break;
 			if (rounds > NH_MAX_LEVELS + 8) return NH_ERR_INVALID;
+			if (!(ctx->flags & NH_FLAG_EXACT_ORDER) && left <= (colour_n ? colour_n : G) / 2u) {
+				NH_HIP_CHECK(ctx, hipMemsetAsync(&st->colour_cursor, 0, sizeof(uint32_t), ctx->stream));
+				NH_LAUNCH(ctx, "colour_compact", k_colour_compact, nh_grid_for(colour_n ? colour_n : G, 256, 1024), 256, st, colour_list, colour_n, level, spare[spare_at]);
+				colour_list = spare[spare_at]; spare_at ^= 1; colour_n = left;
+			}
 		}
 		if (c.levels > NH_MAX_LEVELS) return NH_ERR_INVALID;
 		d->levels = c.levels;
