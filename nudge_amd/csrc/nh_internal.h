@@ -170,7 +170,7 @@ struct nh_ContactConstraintData {
 	bool has_late;                        // bodies classified after the round trip (classes *_LATE)
 	struct {
 		nh_ContactData contacts;
-		uint32_t *cursor, *pred_a, *pred_b, *level, *slot_key, *level_hist, *level_cursor, *tmp;
+		uint32_t *cursor, *pred_a, *pred_b, *level, *slot_key, *level_hist, *level_cursor, *tmp, *tent;
 	} cont;
 };
 

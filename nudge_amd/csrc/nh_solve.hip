@@ -970,6 +970,82 @@ __global__ __launch_bounds__(256) void k_colour_round(nh_DevState* __restrict__ 
 
 // counting sort of the general contacts by level / colour.  Levels are few and hot: histogram and cursors are kept per
 // workgroup in LDS, global atomics happen once per (workgroup, level).
+// Colouring, speculative form (the default; NH_COLOUR_JP=1 selects the Jones-Plassmann rounds above).  A round is two kernels:
+//   try     every uncoloured contact picks the smallest colour that none of its FINISHED neighbours holds -> tent[c]   (reads only `level`,
+//           which nobody writes meanwhile)
+//   settle  two neighbours that picked the same colour in this round are in conflict: the one with the lower hashed priority stays
+//           uncoloured, everybody else takes its pick.  A neighbour showing my pick must be from this round (an older one would have
+//           been in my `used` set), and its colour reads the same from `level` or `tent`, so the outcome does not depend on timing.
+// Most contacts settle in the first round (a pick conflicts only with same-round neighbours), so a handful of rounds replace the ~30 rounds
+// in which Jones-Plassmann colours one local maximum per neighbourhood.
+// round 0 of a step: last step's colour of every contact that existed then (it comes back with the warm-start impulse: spare word of the
+// cache record) is its pick; new contacts make no pick yet (0) and choose in the next round against the settled ones
+__global__ __launch_bounds__(256) void k_colour_seed(nh_DevState* __restrict__ st, const uint32_t* __restrict__ list, const nh_CachedContactImpulse* __restrict__ warm, uint32_t* __restrict__ tent) {
+	const uint32_t n = st->general_contacts;
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		const uint32_t c = list[k];
+		const uint32_t old = __float_as_uint(warm[c].unused);
+		tent[c] = old >= 1u && old <= NH_MAX_LEVELS ? old : 0u;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_colour_try(nh_DevState* __restrict__ st, const uint32_t* __restrict__ list, uint32_t n_list, const nh_BodyPair* __restrict__ bodies,
+                                                    const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj, const uint32_t* __restrict__ level, uint32_t* __restrict__ tent) {
+	const uint32_t n = n_list ? n_list : st->general_contacts;
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		const uint32_t c = list[k];
+		if (level[c] != NH_UNSET) continue;
+		const nh_BodyPair p = bodies[c];
+		unsigned long long used = 0ull;        // colours 1..64 held by finished neighbours
+		uint32_t mx = 64;
+		for (int side = 0; side < 2; ++side) {
+			const uint32_t x = side ? p.b : p.a;
+			if (!x) continue;
+			for (uint32_t q = off[x]; q < off[x + 1]; ++q) {
+				const uint32_t m = adj[q];
+				if (m == c) continue;
+				const uint32_t lm = level[m];
+				if (lm == NH_UNSET) continue;
+				if (lm >= 1 && lm <= 64) used |= 1ull << (lm - 1);
+				else if (lm > mx) mx = lm;
+			}
+		}
+		tent[c] = ~used ? (uint32_t)__ffsll((long long)~used) : mx + 1u;      // more than 64 colours around one contact: one past the largest
+	}
+}
+
+__global__ __launch_bounds__(256) void k_colour_settle(nh_DevState* __restrict__ st, const uint32_t* __restrict__ list, uint32_t n_list, const nh_BodyPair* __restrict__ bodies,
+                                                       const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj, uint32_t* __restrict__ level, const uint32_t* __restrict__ tent, uint32_t round) {
+	const uint32_t n = n_list ? n_list : st->general_contacts;
+	uint32_t left = 0, lmax = 0;
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		const uint32_t c = list[k];
+		if (__hip_atomic_load(&level[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != NH_UNSET) continue;       // finished in an earlier round (only I write my own entry)
+		const uint32_t mine = tent[c];
+		if (mine == 0u) { ++left; continue; }                 // (a new contact in round 0: no pick yet)
+		const uint32_t pc = colour_priority(c);
+		const nh_BodyPair p = bodies[c];
+		bool lose = false;
+		for (int side = 0; side < 2 && !lose; ++side) {
+			const uint32_t x = side ? p.b : p.a;
+			if (!x) continue;
+			for (uint32_t q = off[x]; q < off[x + 1]; ++q) {
+				const uint32_t m = adj[q];
+				if (m == c) continue;
+				const uint32_t lm = __hip_atomic_load(&level[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const uint32_t cm = lm != NH_UNSET ? lm : tent[m];       // (tent[m] of a contact finished long ago is stale, but then lm is set)
+				if (cm != mine) continue;
+				const uint32_t pm = colour_priority(m);
+				if (pm > pc || (pm == pc && m > c)) { lose = true; break; }
+			}
+		}
+		if (lose) { ++left; continue; }
+		__hip_atomic_store(&level[c], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		lmax = max(lmax, mine);
+	}
+	block_report(st, left, lmax, round);
+}
+
 // the contacts of `list` that are still uncoloured, in any order (a round's outcome does not depend on who looks at which contact).
 // A workgroup owns a contiguous chunk: it counts, reserves its output range with ONE atomic on the global cursor (same-address atomics are
 // ~12 ns each, serialised), and fills the range through a cursor in LDS.
@@ -1123,7 +1199,9 @@ __global__ __launch_bounds__(256) void k_level_exec(const uint32_t* __restrict__
 // ---- update_cached_impulses (nudge.cpp:4857-4884) --------------------------------------------------------------------------------
 // (contacts on the one-body fast path export their impulse at the end of every nh_apply_impulses call)
 __global__ __launch_bounds__(256) void k_update_impulses(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ order, const float4* __restrict__ rows4, size_t stride,
-                                                         const float4* __restrict__ gstates, nh_CachedContactImpulse* __restrict__ out) {
+                                                         const float4* __restrict__ gstates, nh_CachedContactImpulse* __restrict__ out, const uint32_t* __restrict__ colour) {
+	// colour != nullptr (default solver order): the contact's colour rides in the spare word of its cached impulse, so that the next
+	// step's colouring can start from it (k_colour_seed)
 	uint32_t n = st->general_contacts;
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
 		nh_row r;
@@ -1132,7 +1210,8 @@ __global__ __launch_bounds__(256) void k_update_impulses(const nh_DevState* __re
 		nh_state s = { sv.x, sv.y, sv.z };
 		float ox, oy, oz;
 		nh_export_impulse(r, s, ox, oy, oz);
-		*reinterpret_cast<float4*>(out + order[k]) = make_float4(ox, oy, oz, 0.0f);
+		const uint32_t c = order[k];
+		*reinterpret_cast<float4*>(out + c) = make_float4(ox, oy, oz, colour ? __uint_as_float(colour[c]) : 0.0f);
 	}
 }
 
@@ -1284,6 +1363,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	uint32_t* level = nh_arena_array<uint32_t>(memory, kcap, &err);
 	uint32_t* general_list = nh_arena_array<uint32_t>(memory, kcap, &err);
 	uint32_t* slot_key = (ctx->flags & NH_FLAG_EXACT_ORDER) ? nh_arena_array<uint32_t>(memory, kcap, &err) : nullptr;
+	uint32_t* tent = (ctx->flags & NH_FLAG_EXACT_ORDER) ? nullptr : nh_arena_array<uint32_t>(memory, kcap, &err);      // colouring: this round's picks
 	uint32_t* level_hist = nh_arena_array<uint32_t>(memory, NH_MAX_LEVELS + 2, &err);
 	uint32_t* level_cursor = nh_arena_array<uint32_t>(memory, NH_MAX_LEVELS + 2, &err);
 	uint32_t* tmp = nh_arena_array<uint32_t>(memory, 2 * NH_SORT_GRID + 64, &err);
@@ -1314,7 +1394,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	// momentum / impulses / counters (nh_flush_pending).
 	d->cont.contacts = *contacts;
 	d->cont.cursor = cursor; d->cont.pred_a = pred_a; d->cont.pred_b = pred_b; d->cont.level = level; d->cont.slot_key = slot_key;
-	d->cont.level_hist = level_hist; d->cont.level_cursor = level_cursor; d->cont.tmp = tmp;
+	d->cont.level_hist = level_hist; d->cont.level_cursor = level_cursor; d->cont.tmp = tmp; d->cont.tent = tent;
 	d->has_static8 = d->has_staticN = d->has_late = false; d->static_inert = false;
 	d->finish_pending = true;
 	d->setup_pending = true; d->imp = imp; d->bodies_at_setup = *bodies;
@@ -1371,18 +1451,26 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		NH_LAUNCH(ctx, "level_reset", k_level_reset_progress, 1, 1, st);
 		// colouring: most contacts are settled by the first rounds; the later ones walk a compacted list of the rest (pred_a / pred_b, which
 		// only the exact mode uses, serve as its two buffers)
+		const bool colour_jp = getenv("NH_COLOUR_JP") != nullptr;
 		const uint32_t* colour_list = general_list;
 		uint32_t colour_n = 0;                         // 0: the whole general list
 		uint32_t* spare[2] = { pred_a, pred_b };
 		int spare_at = 0;
 		for (;;) {
 			// (short batches first while colouring: the list shrinks fastest in the first rounds, and a batch ends with its compaction)
-			const int batch = (ctx->flags & NH_FLAG_EXACT_ORDER) ? 8 : (rounds < 4 ? 2 : (rounds < 8 ? 4 : 8));
+			const int batch = (ctx->flags & NH_FLAG_EXACT_ORDER) ? 8 : (colour_jp ? (rounds < 4 ? 2 : (rounds < 8 ? 4 : 8)) : 1);
 			for (int r = 0; r < batch; ++r, ++rounds) {
 				if (ctx->flags & NH_FLAG_EXACT_ORDER)
 					NH_LAUNCH(ctx, "level_relax", k_level_relax, nh_grid_for(G, 256, 1024), 256, st, general_list, pred_a, pred_b, level, rounds);
-				else
+				else if (colour_jp)
 					NH_LAUNCH(ctx, "colour_round", k_colour_round, nh_grid_for(colour_n ? colour_n : G, 256, 1024), 256, st, colour_list, contacts->bodies, d->body_off, d->adj, level, rounds, colour_n);
+				else {
+					if (rounds == 0)
+						NH_LAUNCH(ctx, "colour_seed", k_colour_seed, nh_grid_for(G, 256, 2048), 256, st, general_list, imp->data, d->cont.tent);
+					else
+					NH_LAUNCH(ctx, "colour_try", k_colour_try, nh_grid_for(colour_n ? colour_n : G, 256, 2048), 256, st, colour_list, colour_n, contacts->bodies, d->body_off, d->adj, level, d->cont.tent);
+					NH_LAUNCH(ctx, "colour_settle", k_colour_settle, nh_grid_for(colour_n ? colour_n : G, 256, 2048), 256, st, colour_list, colour_n, contacts->bodies, d->body_off, d->adj, level, d->cont.tent, rounds);
+				}
 			}
 			rc = nh_read_counts(ctx, &c);
 			if (rc) return rc;
@@ -1506,7 +1594,7 @@ extern "C" int nh_update_cached_impulses(nh_context* ctx, nh_ContactConstraintDa
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	if (d->general_contacts)
 		NH_LAUNCH(ctx, "update_impulses", k_update_impulses, nh_grid_for(d->general_contacts, 256, 4096), 256, ctx->d_state, d->level_order, (const float4*)d->rows, (size_t)d->contact_capacity,
-		          (const float4*)d->gstates, imp->data);
+		          (const float4*)d->gstates, imp->data, (ctx->flags & NH_FLAG_EXACT_ORDER) ? (const uint32_t*)nullptr : (const uint32_t*)d->cont.level);
 	return NH_OK;
 }
 
