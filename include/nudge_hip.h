@@ -78,6 +78,8 @@ typedef struct nh_BoxCollider { float size[3]; float unused; } nh_BoxCollider;  
 typedef struct nh_Contact { float position[3]; float penetration; float normal[3]; float friction; } nh_Contact; /* nudge.h:61-66 */
 typedef struct nh_BodyPair { uint32_t a; uint32_t b; } nh_BodyPair;                                  /* nudge.h:68-71 (wide) */
 typedef struct nh_CachedContactImpulse { float impulse[3]; float unused; } nh_CachedContactImpulse;  /* nudge.h:113-116 */
+/* (`unused`: zero, as in the reference, under NH_FLAG_EXACT_ORDER; in the default solver order the library keeps the contact's
+   colour of the last sweep there -- an integer bit pattern, never read as a number -- to warm-start the next step's colouring) */
 
 typedef struct nh_ContactData {                                                                      /* nudge.h:73-82 (wide) */
 	nh_Contact* data;
