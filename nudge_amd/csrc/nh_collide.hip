@@ -4,7 +4,8 @@
 // What is kept from the reference is the RESULT: the set of strictly overlapping AABB pairs
 // (nudge.cpp:3306-3308), which collider of a pair plays "a" in the narrowphase (the one later in Morton order
 // of the AABB min corners, nudge.cpp:3086-3172, 3495, 1202-1203), the per-pair contact arithmetic
-// (nh_narrowphase.h), island membership / sleeping rules (nudge.cpp:3788-4006) and the tag order of contacts.
+// (nh_narrowphase.h), island membership / sleeping rules at both levels (coarse: nudge.cpp:3500-3703, over the broadphase pairs, before
+// the narrowphase; fine: 3788-4006, over the contacts) and the tag order of contacts.
 // How it is computed is GPU-first: the reference's O(C^2/1024) grouped all-pairs sweep is replaced by a
 // uniform grid over "small" colliders (cell = power of two >= their largest extent) plus a brute-force pass for
 // the few large ones (ground slabs); union-find runs lock-free with atomicCAS hooking.
