@@ -965,7 +965,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_sums, max_cells / CS_TILE, 256, cstart, cscan_sums);
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_final, max_cells / CS_TILE, 256, cstart, cscan_sums, max_cells);
 		NH_LAUNCH(ctx, "cell_scatter", k_cell_scatter, nh_grid_for(C, 256, 2048), 256, st, C, keys_a, vals_a, cstart, aabb_min, aabb_max, keys_b, smin, smax, mkey, smk);
-		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 1024), 256, st, C, keys_b, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap, coarse_parent, ctx->step_parity);
+		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 4096), 256, st, C, keys_b, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap, coarse_parent, ctx->step_parity);
 		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, 2048, 256, st, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap, coarse_parent, ctx->step_parity);
 		// coarse islands over the broadphase pairs (united where the pairs were emitted) + connections: only when some body is asleep (a device
 		// flag: the kernels leave at once otherwise)
