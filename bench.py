@@ -5,21 +5,33 @@
 
 A "step" is one full pass of the hot path (collide -> gravity -> read cache -> setup -> apply x I -> update ->
 write cache -> advance, reference example/main.cpp:274-328) over one world resident in HBM.
+
+WHAT IS TIMED.  The metric is quoted on the LANDED, AWAKE scene (while the boxes fall there are no
+contacts, once they sleep there are none either, nudge.cpp:4896-4898).  So whatever --warmup says, the bench first
+steps (untimed) until the scene has landed -- contacts >= 95 % of the scene's resting count and every body awake --
+and fails loudly if that never happens; --warmup steps follow (untimed); then K steps are timed between
+barrier + synchronize.  At N = 1 that K-step block is repeated from a device-side checkpoint of the landed state
+until about half a second has been timed (the awake window is only ~250 steps long): every block times exactly
+the same K steps; `ms_per_step` is the mean over all of them.  A line whose timed window saw no contacts is refused.
+
 Workload at N = 1: BASELINE.json configs[1] -- 1,004,400 boxes in 124 single-layer drop tiles, 8 solver
-iterations, fp32.  For N > 1 (config 5's shape, weak scaling) the world is ONE lattice of 124 x N tiles cut into N
-x-slabs of equal body count -- the cuts pass through tiles -- and every rank steps its slab with a ghost-body halo
-exchange per step over RCCL point-to-point (nudge_amd/partition.py); there is no collective on the data path.
-`value` = (1,004,400-box partitions stepped by all ranks) per second.  NUDGE_BENCH_HALO=0 falls back to N
-independent 124-tile worlds (no exchange at all).
+iterations, fp32.  For N > 1 (config 5's shape) the world is ONE lattice of 248 x N tiles (N = 8: the 1984 tiles /
+16 M boxes of configs[4]) cut into N x-slabs of equal body count -- cuts pass through tiles -- and every rank
+steps its slab with a ghost-body halo exchange per step over RCCL point-to-point (nudge_amd/partition.py); there is no
+collective on the data path.  `value` = bodies stepped per second by all ranks / 1,004,400: steps/s of a config-2 sized
+world, the same unit at every N.  NUDGE_BENCH_HALO=0 falls back to independent worlds per rank (no exchange at all).
 
 The JSON line also carries
   roofline     -- the dominant kernel's algorithmic bytes / its mean duration (HIP events on the launch
                   stream, recorded during the timed region) against the 8 TB/s HBM peak;
+  step_traffic -- sum of the algorithmic bytes of every kernel of a step / ms_per_step against the same peak (and
+                  the same with the PMC-measured bytes when profiles/ holds them);
   cpu_baseline -- the compiled reference (oracle/_ref) timed on this box's host cores on a bounded sample of
-                  the same workload (rank 0, N = 1 only).
+                  the same workload, all cores and one core (rank 0, N = 1 only).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -30,32 +42,54 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
+C2_BODIES = 1004400
 
 # Algorithmic bytes per unit for each kernel (DESIGN.md "Kernels"; itemisation of SURVEY.md 8(d)).
-# unit: B bodies, C colliders, P pairs, K contacts, KI contact-iterations, R contact records (= pairs with contacts)
+# unit: B bodies, C colliders, P pairs, K contacts, R contact records (= pairs), G general contacts, T grid table entries
 KERNEL_BYTES = {
+    "collide_begin": ("B", 12 + 1),                        # degree / cursor / info words cleared, idle counter read
     "xform_aabb": ("C", 32 + 32 + 16 + 4 + 32 + 32 + 4),   # local+body transform, shape, tag -> world transform, AABB, tag
-    "cell_keys": ("C", 32 + 8 + 8),                        # AABB -> cell key, value, morton key
-    "cell_bounds": ("C", 8 + 32 + 32),                     # key/val + AABB -> AABB in cell order
+    "cell_keys": ("C", 32 + 8 + 8),                        # AABB -> cell key, rank, morton key
+    "cell_scan": ("T", 6),                                 # per-cell counts -> starts: read twice, written once, over two launches
+    "cell_scatter": ("C", 8 + 32 + 8 + 4 + 32 + 8),        # key/rank + AABB + morton -> the same in cell order
     "find_pairs": ("C", 32 + 4),                           # AABB in cell order + key (+ 8 B per emitted pair)
+    "large_pairs": ("P", 32 + 8),                          # candidates of the large colliders: AABB read, pair written
     "narrowphase": ("P", 8 + 2 * (32 + 16 + 4) + 4 * 36 + 24),  # pair, 2 x (transform, shape, tag) -> ~4 contacts x 36 B + record
+    "narrowphase_bb": ("P", 8 + 2 * (32 + 16 + 4) + 4 * 36 + 24),
+    "narrowphase_sph": ("P", 8 + 2 * (32 + 4 + 4) + 36 + 24),
+    "bucket_count": ("R", 8 + 8),                          # key -> bucket, rank
+    "bucket_scatter": ("R", 8 + 12 + 12),
+    "bucket_sort": ("R", 12 + 12),
+    "sorted_counts": ("R", 4 + 16 + 8),
     "gather_contacts": ("K", 36 + 52),                     # raw contact + feature -> contact, pair, tag, feature
     "cache_lookup": ("K", 12 + 28 + 16),                   # tag+feature, cache probe (tag, feature, impulse) -> impulse
-    "setup_static": ("K", 32 + 16 + 8 + 160 + 16 + 36),    # contact, cached impulse, pair -> row + state (+ body state/4)
-    "apply_static": ("K", 160 + 32 + 36),                  # row + state rw (+ body state/4) for ALL iterations of one call
+    "gravity_damping": ("B", 4 + 32 + 32),
+    "adjacency_simple": ("B", 4 + 4 + 4 + 1 + 8),          # degree, pair info, first contact -> class, contact list record
     # fused one-body solver (lookup + rows + warm start + all sweeps + export), per contact: contact 32, pair 8, tag+feature 12,
     # cache probe 12 + 16, state 16 w, impulse 16 w = 112; per body (4 contacts): class/offsets/adjacency/hint 33, transform 32,
     # properties 16, momentum 32 r + 32 w = 145 -> 36 per contact
     "solve_one_body": ("K", 112 + 36),
-    "update_impulses": ("K", 160 + 16 + 16),
+    "solve_one_body8": ("K", 112 + 36),
+    "apply_static": ("K", 160 + 32 + 36),
+    "rows_general": ("G", 4 + 32 + 8 + 2 * (32 + 16) + 160 + 8),
+    "warm_level": ("G", 160 + 8 + 16 + 16 + 2 * 64),
+    "apply_level": ("G", 160 + 8 + 16 + 16 + 2 * 64),      # one sweep of one colour class: rows, pair, state rw, two momentum records rw
+    "solve_colours": ("GI", 2 * 64),                       # persistent coloured sweeps: per contact-iteration two momentum records rw (rows stay on chip)
+    "update_impulses": ("G", 160 + 16 + 16),
     "write_cache": ("K", 12 + 16 + 28),
-    "radix_hist": ("N", 8),
-    "radix_scatter": ("N", 24),
-    "radix_pass": ("P", 24),                               # one 8-bit pass over the pair records: key 8 + index 4, read and written
-    "advance": ("B", 32 + 32 + 1 + 32 + 1),
-    "gravity_damping": ("B", 64 + 4),
+    "advance": ("B", 4 + 32 + 32 + 1 + 32 + 1),
 }
 
+
+def grid_table_entries(C):
+    """Entries of the broadphase grid table for C colliders (nh_collide: a power of two >= 4 C, 2^16 .. 2^22 / 2^24)."""
+    want = 1
+    while want < 4 * C:
+        want <<= 1
+    want = max(want, 1 << 16)
+    if want > (1 << 22) and C <= (1 << 22):
+        want = 1 << 22
+    return min(want, 1 << 24)
 
 # timer name (nh_* launch sites) -> kernel symbol prefix in the rocprofv3 PMC export (profiles/export_pmc.py)
 PMC_KERNEL = {"solve_one_body": "k_solve_one_body<4, true, true>", "apply_static": "k_apply_static<4, true>", "narrowphase": "k_narrowphase",
@@ -63,59 +97,83 @@ PMC_KERNEL = {"solve_one_body": "k_solve_one_body<4, true, true>", "apply_static
               "apply_level": "k_level_exec<false>", "write_cache": "k_write_cache", "xform_aabb": "k_xform"}
 
 
+def _pmc_file():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")))
+    return files[-1] if files else None
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC export (FETCH_SIZE x 2 + WRITE_SIZE, see
     profiles/export_pmc.py and MI355X_MICROARCH.md): measured in a separate rocprofv3 --pmc run of this same command."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), key=os.path.getmtime)
-    sym = PMC_KERNEL.get(kernel)
-    if not files or not sym:
+    f, sym = _pmc_file(), PMC_KERNEL.get(kernel)
+    if not f or not sym:
         return None, None
     try:
-        k = json.load(open(files[-1]))["kernels"].get(sym)
+        k = json.load(open(f))["kernels"].get(sym)
     except Exception:
         return None, None
-    return (k["hbm_bytes_corrected"], os.path.basename(files[-1])) if k else (None, None)
+    return (k["hbm_bytes_corrected"], os.path.basename(f)) if k else (None, None)
 
 
-def step_algorithmic_bytes(B, C, P, K, I):
-    """A = 146 B + 260 C + 96 P + 504 K + 128 K I   (bytes per step)."""
-    return 146.0 * B + 260.0 * C + 96.0 * P + 504.0 * K + 128.0 * K * I
+def pmc_step_total():
+    """Sum over ALL kernels of the PMC export: HBM bytes of one landed step (each kernel's per-launch mean x its launches per step
+    when the export carries them, else x 1)."""
+    f = _pmc_file()
+    if not f:
+        return None, None
+    try:
+        ks = json.load(open(f))["kernels"]
+        return sum(v["hbm_bytes_corrected"] * v.get("launches_per_step", 1) for v in ks.values()), os.path.basename(f)
+    except Exception:
+        return None, None
 
 
-def cpu_baseline(scene, warmup, tiles_total, budget_s=20.0):
-    """Compiled reference on the host cores: `cores` tiles in parallel, same phase of the simulation."""
+def cpu_baseline(scene, land_steps, tiles_total, budget_s=14.0):
+    """Compiled reference on the host cores, same phase of the simulation (landed, awake): all cores with one tile per thread,
+    and ONE core stepping one tile (the reference is single-threaded: a whole-scene step on one core = the tiles one after another)."""
     from nudge_amd import scenes as S
     from oracle import refworld
     if not refworld.available("exact"):
         return None
+    variant = "shipped" if refworld.available("shipped") else "exact"
     cores = os.cpu_count() or 1
     ntiles = min(cores, tiles_total)
     worlds = []
     for t in range(ntiles):
         sub, _ = S.extract_tile(scene, t)
-        worlds.append(refworld.RefWorld(sub, variant="shipped" if refworld.available("shipped") else "exact", ftz=True))
-    refworld.step_tiles(worlds, warmup, threads=cores, ftz=True)          # untimed: let the boxes land
+        worlds.append(refworld.RefWorld(sub, variant=variant, ftz=True))
+    refworld.step_tiles(worlds, land_steps, threads=cores, ftz=True)          # untimed: let the boxes land
     probe = refworld.step_tiles(worlds, 10, threads=cores, ftz=True)
-    steps = int(max(10, min(2000, budget_s / max(probe / 10.0, 1e-6))))
+    steps = int(max(10, min(150, budget_s / max(probe / 10.0, 1e-6))))        # <= 150: stay inside the awake window
     wall = refworld.step_tiles(worlds, steps, threads=cores, ftz=True)
     tile_steps_per_s = ntiles * steps / wall
-    value = tile_steps_per_s / tiles_total                               # steps/s of the whole 124-tile world
     per_tile = len(scene['body_transforms']) // max(1, tiles_total)
-    return {"value": value, "unit": "steps/s", "cores": cores, "kind": "reference",
-            "sample": f"{ntiles} of {tiles_total} tiles ({per_tile} bodies each) x {steps} steps after {warmup + 10} warm-up steps, "
-                      f"one tile per host thread, unmodified reference -O3 -mavx2 -mfma, FTZ/DAZ on; scaled by tiles",
-            "tile_steps_per_s_per_core": tile_steps_per_s / cores}
+    # one core: one more tile, alone on the machine's first thread, same phase
+    sub, _ = S.extract_tile(scene, 0)
+    one = [refworld.RefWorld(sub, variant=variant, ftz=True)]
+    refworld.step_tiles(one, land_steps + 10, threads=1, ftz=True)
+    p1 = refworld.step_tiles(one, 5, threads=1, ftz=True)
+    s1 = int(max(5, min(150, 4.0 / max(p1 / 5.0, 1e-6))))
+    w1 = refworld.step_tiles(one, s1, threads=1, ftz=True)
+    return {"value": tile_steps_per_s / tiles_total, "unit": "steps/s", "cores": cores, "kind": "reference",
+            "sample": f"{ntiles} of {tiles_total} tiles ({per_tile} bodies each) x {steps} steps after {land_steps + 10} untimed steps (landed, awake), "
+                      f"one tile per host thread, unmodified reference ({variant}) -O3 -mavx2 -mfma, FTZ/DAZ on; scaled by tiles",
+            "tile_steps_per_s_per_core": tile_steps_per_s / cores,
+            "one_core": {"value": (s1 / w1) / tiles_total, "unit": "steps/s", "cores": 1,
+                         "sample": f"1 tile x {s1} steps on one thread (tile steps/s {s1 / w1:.1f}); whole scene = {tiles_total} tiles one after another"}}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=60)
-    ap.add_argument("--tiles", type=int, default=124, help="tiles per GPU (124 = config 2)")
-    ap.add_argument("--side", type=int, default=90)
+    ap.add_argument("--warmup", type=int, default=5, help="extra untimed steps AFTER the scene has landed")
+    ap.add_argument("--tiles", type=int, default=None, help="tiles per GPU (default 124 = config 2 at one GPU, 248 = config 5's share otherwise)")
+    ap.add_argument("--side", type=int, default=None)
     ap.add_argument("--scene", default="boxes", choices=["boxes", "mixed", "pit"])
+    ap.add_argument("--min-time", type=float, default=0.5, help="seconds to time at N = 1 (the K-step block is repeated from a checkpoint)")
+    ap.add_argument("--land-cap", type=int, default=None, help="give up if the scene has not landed after this many steps")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--profile-kernels", action="store_true", help="also print the per-kernel time table (stderr)")
     args = ap.parse_args()
@@ -145,41 +203,51 @@ def main():
     from nudge_amd import scenes as S
     from nudge_amd import engine as E
 
+    if args.tiles is None:
+        args.tiles = 124 if world == 1 else 248
+    if args.side is None:
+        args.side = 160 if args.scene == "pit" else 90
     halo = world > 1 and os.environ.get("NUDGE_BENCH_HALO", "1") != "0" and args.scene in ("boxes", "mixed")
     sphere_fraction = 0.5 if args.scene == "mixed" else 0.0
     cluster = None
     if halo:
-        # ONE world of world x tiles; equal-count x-slabs whose cuts pass through tiles
+        # ONE world of world x tiles (N = 8: 1984 tiles = 16 M boxes, a 44-column lattice like SURVEY 8(d) c5); equal-count x-slabs.  With
+        # 44 / N columns per rank some cuts pass through tiles and some along the gaps between them
         from nudge_amd import partition as PT
-        # 4 x world + 1 columns of tiles (~30 rows at 124 tiles per GPU; the odd column count puts the equal-count cuts INSIDE tiles,
-        # not in the gaps between them): a compact 2-D lattice like config 5's, so that coordinates stay
-        # small enough for fp32 (a 1-D strip of 88 columns would put boxes at x = 24,000 where one ulp is 2 mm)
-        g = S.grid_tiles(args.tiles * world, side=args.side, sphere_fraction=sphere_fraction, seed=2, lattice_cols=4 * world + 1)
+        total = args.tiles * world
+        cols = max(2, int(round(math.sqrt(total) - 0.5)))
+        if cols % world == 0:
+            cols += 1                                       # never ALL cuts in gaps: at least the odd ones cross tiles
+        g = S.grid_tiles(total, side=args.side, sphere_fraction=sphere_fraction, seed=2, lattice_cols=cols)
         gx = g["body_transforms"]["position"][1:, 0]
         cuts = [float(np.quantile(gx, (r + 1) / world)) + 0.41 for r in range(world - 1)]
-        scene, info = PT.split_scene(g, cuts, rank)
+        scene, info = PT.split_scene(g, cuts, rank, static_margin=64.0)
         del g, gx
-        sharding = (f"{world} x-slabs of one {args.tiles * world}-tile world, ghost halo exchange every step "
+        sharding = (f"{world} x-slabs of one {total}-tile world ({total * args.side * args.side:,} bodies), ghost halo exchange every step "
                     f"({'RCCL' if backend == 'nccl' else backend} p2p), refresh + migration every 16 steps")
     elif args.scene in ("boxes", "mixed"):
         # every rank owns its own lattice of independent tiles (different seed per rank)
         scene = S.grid_tiles(args.tiles, side=args.side, sphere_fraction=sphere_fraction, seed=(2 if args.scene == "boxes" else 3) + 1000 * rank,
-                             lattice_cols=11 if args.scene == "boxes" else 16)
+                             lattice_cols=11 if args.tiles == 124 else None)
         sharding = "independent tiles per rank, no data-path collective" if world > 1 else "single GPU"
     else:
         scene = S.ball_pit(args.side, args.side, args.side, seed=4 + rank)
         sharding = "independent replicas" if world > 1 else "single GPU"
     n_units = args.tiles * args.side * args.side
-    workload = {"boxes": f"c2: {n_units:,} boxes in {args.tiles} single-layer drop tiles ({args.side}x{args.side}), 8 solver iterations, dt 1/120",
+    workload = {"boxes": f"c2: {n_units:,} boxes in {args.tiles} single-layer drop tiles ({args.side}x{args.side}), 8 solver iterations, dt 1/120" if world == 1 else
+                         f"c5: {n_units * world:,} boxes in {args.tiles * world} drop tiles cut into {world} x-slabs, 8 solver iterations",
                 "mixed": f"c3: {n_units:,} mixed boxes+spheres in {args.tiles} tiles",
                 "pit": f"c4: {args.side ** 3:,}-sphere ball pit, 16 iterations"}[args.scene]
     I = scene["params"]["iterations"]
     nb = len(scene["body_transforms"]) - 1
+    n_box_dyn = int((scene["box_transforms"]["body"] > 0).sum())
+    n_sph_dyn = int((scene["sphere_transforms"]["body"] > 0).sum())
     if halo:
         w = E.World(scene, device=device_index, flags=0, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=6 * info["capacity"]["bodies"])
         cluster = PT.DistCluster(PT.Partition(w, info, epoch=16), host_staging=(backend != "nccl"))
     else:
-        w = E.World(scene, device=device_index, flags=0, max_contacts=max(4096, (6 if args.scene != "pit" else 10) * nb))
+        w = E.World(scene, device=device_index, flags=0, max_contacts=max(4096, (6 if args.scene != "pit" else 5) * nb),
+                    max_pairs=None if args.scene != "pit" else 7 * nb)
 
     def advance_world(n):
         if cluster is not None:
@@ -192,10 +260,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up (untimed): boxes land; also one fully profiled step to find the dominant kernel ----
-    advance_world(max(args.warmup - 3, 0))
+    def all_ranks(flag):
+        if world == 1:
+            return flag
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    # ---- untimed: step until the scene has LANDED and is still awake (the configuration the metric is quoted on) ----
+    if args.scene == "pit":
+        k_rest, chunk, cap = 2.6 * nb, 20, args.land_cap or 900             # the settled pit holds ~2.8 contacts per sphere
+    else:
+        k_rest, chunk, cap = 0.95 * (4.0 * n_box_dyn + 1.0 * n_sph_dyn), 4, args.land_cap or 400   # a resting box: 4 face contacts, a sphere: 1
+    landed_at = None
+    done = 0
+    while done < cap:
+        advance_world(chunk)
+        done += chunk
+        c = w.counts()
+        if c["error"]:
+            raise SystemExit(f"device error {c['error']} while landing")
+        # (a partition counts its ghosts among the active bodies; its own share of the resting contacts is what matters)
+        ok = c["contacts"] >= k_rest and (halo or args.scene == "pit" or c["active_bodies"] >= nb)
+        if all_ranks(ok):
+            landed_at = done
+            break
+    if landed_at is None:
+        raise SystemExit(f"bench.py: the scene did not land within {cap} steps (contacts {c['contacts']} < {k_rest:.0f}): refusing to time free fall")
+    advance_world(args.warmup)
+    w.synchronize()
+    first_timed = landed_at + args.warmup
+
+    # ---- one fully instrumented pass over 3 landed steps: per-kernel table, dominant kernel (state restored afterwards at N = 1) ----
+    snap = w.snapshot() if cluster is None else None
     w.enable_timing(True)
-    advance_world(min(3, args.warmup))
+    advance_world(3)
     w.synchronize()
     ktimes = w.kernel_times(reset=True)
     w.enable_timing(False)
@@ -203,63 +302,100 @@ def main():
     if args.profile_kernels and rank == 0:
         tot = sum(v[0] for v in ktimes.values())
         for k, (ms, n) in sorted(ktimes.items(), key=lambda kv: -kv[1][0]):
-            print(f"  {k:24s} {ms / 3:9.4f} ms/step  {n // 3:4d} launches/step  {100 * ms / tot:5.1f} %", file=sys.stderr)
-    counts0 = w.counts()
+            print(f"  {k:24s} {ms / 3:9.4f} ms/step  {n / 3:6.1f} launches/step  {100 * ms / tot:5.1f} %", file=sys.stderr)
+    if snap is not None:
+        w.restore(snap)
+    else:
+        first_timed += 3
 
-    # ---- timed region: exactly K steps, only the dominant kernel carries events ----
+    # ---- timed region: blocks of exactly K steps between barrier + synchronize; only the dominant kernel carries events ----
     if dominant:
         w.enable_timing(True, only=dominant)
-    barrier()
-    t0 = time.perf_counter()
-    advance_world(args.steps)
-    barrier()
-    t1 = time.perf_counter()
-    dt = t1 - t0
+    dt, blocks, contact_sum, pair_sum, general_sum = 0.0, 0, 0.0, 0.0, 0.0
+    while True:
+        if snap is not None and blocks:
+            w.restore(snap)
+        c0 = w.counts()
+        barrier()
+        t0 = time.perf_counter()
+        advance_world(args.steps)
+        barrier()
+        t1 = time.perf_counter()
+        c1 = w.counts()
+        if c1["error"]:
+            raise SystemExit(f"device error {c1['error']}")
+        dt += t1 - t0
+        blocks += 1
+        contact_sum += 0.5 * (c0["contacts"] + c1["contacts"])
+        pair_sum += 0.5 * (c0["pairs"] + c1["pairs"])
+        general_sum += 0.5 * (c0["general_contacts"] + c1["general_contacts"])
+        if snap is None or dt >= args.min_time or blocks >= 200:
+            break
     dom = w.kernel_times(reset=True).get(dominant) if dominant else None
     w.enable_timing(False)
-    counts1 = w.counts()
-    if counts1["error"]:
-        raise SystemExit(f"device error {counts1['error']}")
+    timed_steps = blocks * args.steps
+    K, P, G = contact_sum / blocks, pair_sum / blocks, general_sum / blocks
 
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        ksum = torch.tensor([float(counts1["contacts"])], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(ksum, op=dist.ReduceOp.SUM)
-        contacts_all = float(ksum.item())
+        sums = torch.tensor([K, float(nb if not halo else cluster.p.n_owned)], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        contacts_all, bodies_all = float(sums[0].item()), float(sums[1].item())
     else:
-        contacts_all = float(counts1["contacts"])
+        contacts_all, bodies_all = K, float(nb)
 
     if rank == 0:
-        K = 0.5 * (counts0["contacts"] + counts1["contacts"])
-        P = 0.5 * (counts0["pairs"] + counts1["pairs"])
-        C = counts1["colliders"]
+        if contacts_all <= 0:
+            raise SystemExit("bench.py: no contacts in the timed window: not a measurement of the hot path")
+        C = c1["colliders"]
         B = nb + 1
-        steps_per_s = world * args.steps / dt
+        sec_per_step = dt / timed_steps
+        if args.scene == "boxes":
+            value = bodies_all / C2_BODIES / sec_per_step       # = steps/s at N = 1
+            unit = "steps/s" if world == 1 else "steps/s x (bodies / 1,004,400): config-2-sized worlds stepped per second by all GPUs"
+        else:
+            value, unit = world / sec_per_step, "steps/s"
         out = {
             "metric": "simulation steps/s (contacts solved/s alongside), 1M-box drop scene",
-            "value": steps_per_s,
-            "unit": "steps/s" if world == 1 else "partition-steps/s (one 1,004,400-box partition per GPU)",
+            "value": value, "unit": unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps,
+            "ms_per_step": 1e3 * sec_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "bodies_per_gpu": nb, "colliders_per_gpu": C, "iterations": I,
-                       "sharding": sharding,
-                       "contacts_per_step": K, "pairs_per_step": P, "timed_window": f"steps [{args.warmup}, {args.warmup + args.steps})"},
-            "contacts_solved_per_sec": contacts_all * I * args.steps / dt,
+                       "sharding": sharding, "bodies_all_gpus": bodies_all,
+                       "contacts_per_step": K, "pairs_per_step": P, "general_contacts_per_step": G,
+                       "landed_after_steps": landed_at,
+                       "timed_window": f"steps [{first_timed}, {first_timed + args.steps}) (landed and awake), timed {blocks}x from a device checkpoint" if snap is not None
+                                       else f"steps [{first_timed}, {first_timed + args.steps}) (landed and awake)",
+                       "timed_blocks": blocks, "timed_steps": timed_steps, "timed_seconds": dt},
+            "contacts_solved_per_sec": contacts_all * I / sec_per_step,
         }
-        A = step_algorithmic_bytes(B, C, P, K, I)
-        out["step_roofline"] = {"bound": "hbm", "algorithmic_bytes_per_step": A, "achieved": A / (dt / args.steps) / 1e9,
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": A / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
-        if dom and dominant in KERNEL_BYTES:
-            unit, per = KERNEL_BYTES[dominant]
-            units = {"B": B, "C": C, "P": P, "K": K, "N": K}[unit]
-            launches_per_step = dom[1] / args.steps
+        units = {"B": B, "C": C, "P": P, "K": K, "R": P, "G": G, "GI": G * I, "T": grid_table_entries(C)}
+        # whole step: sum of the per-kernel algorithmic bytes over the kernels the instrumented pass saw, against the peak
+        # (a kernel launched once per colour class / level moves its share of the items per launch: priced per step, not per launch)
+        alg, unpriced = 0.0, []
+        for name in ktimes:
+            kb = KERNEL_BYTES.get(name)
+            if kb is None:
+                unpriced.append(name)
+                continue
+            alg += kb[1] * units[kb[0]] * (I if name == "apply_level" else 1)
+        pmc_sum, pmc_src = pmc_step_total() if args.scene == "boxes" and args.tiles == 124 and world == 1 else (None, None)
+        out["step_traffic"] = {"bound": "hbm", "algorithmic_bytes_per_step": alg, "achieved": alg / sec_per_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": alg / sec_per_step / 1e9 / HBM_PEAK_GBS, "unpriced_kernels": sorted(unpriced),
+                               "pmc_bytes_per_step": pmc_sum, "pmc_frac": (pmc_sum / sec_per_step / 1e9 / HBM_PEAK_GBS) if pmc_sum else None, "pmc_source": pmc_src}
+        if dom and dominant in KERNEL_BYTES and units.get(KERNEL_BYTES[dominant][0]) is not None:
+            unit_k, per = KERNEL_BYTES[dominant]
+            launches_per_step = dom[1] / timed_steps
             ms = dom[0] / dom[1]
-            bytes_per_launch = per * units
-            traffic, traffic_src = pmc_traffic(dominant) if args.scene == "boxes" and args.tiles == 124 else (None, None)
+            n_items = units[unit_k]
+            if dominant in ("apply_level", "warm_level"):
+                n_items = n_items * (I if dominant == "apply_level" else 1) / max(1.0, launches_per_step)      # one colour class per launch
+            bytes_per_launch = per * n_items
+            traffic, traffic_src = pmc_traffic(dominant) if args.scene == "boxes" and args.tiles == 124 and world == 1 else (None, None)
             out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": bytes_per_launch / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": bytes_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                                "avg_launch_ms": ms, "launches_per_step": launches_per_step,
@@ -269,15 +405,16 @@ def main():
                                "avg_launch_ms": dom[0] / dom[1]}
         if world == 1 and not args.no_cpu and args.scene in ("boxes", "mixed"):
             try:
-                cb = cpu_baseline(scene, args.warmup, args.tiles)
+                cb = cpu_baseline(scene, landed_at + args.warmup, args.tiles)
             except Exception as e:      # the baseline is a report, never a reason to lose the GPU number
                 cb = {"error": repr(e)}
             if cb:
                 out["cpu_baseline"] = cb
         if ktimes:
-            # per-kernel milliseconds per step from the three fully instrumented warm-up steps (events around EVERY launch: the sum exceeds
+            # per-kernel milliseconds per step from the three fully instrumented landed steps (events around EVERY launch: the sum exceeds
             # ms_per_step, small kernels are inflated; the timed region only instruments the dominant kernel)
             out["kernel_ms_per_step"] = {k: round(ms / 3.0, 5) for k, (ms, n) in sorted(ktimes.items(), key=lambda kv: -kv[1][0])[:16]}
+            out["launches_per_step"] = round(sum(n for _, n in ktimes.values()) / 3.0, 1)
         if cluster is not None:
             st = cluster.p.stats
             out["halo"] = {"ghost_bodies_rank0": st["ghosts"], "refreshes": st["refreshes"], "migrated_out_rank0": st["migrated_out"],

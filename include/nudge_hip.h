@@ -9,10 +9,15 @@
  * by the device boundary or by scale, are:
  *
  *   1. Every array pointer inside the structs is DEVICE memory (hipMalloc'ed by the caller, or carved out
- *      of a torch tensor): the caller still owns every array, the library never allocates on its behalf;
- *      scratch and the two opaque result objects come out of the caller's `nh_Arena` (device memory) with
+ *      of a torch tensor): the caller still owns every array; per-step scratch and the device side of the
+ *      two opaque result objects come out of the caller's `nh_Arena` (device memory) with
  *      the reference's bump semantics (nudge.h:29-32, nudge.cpp:990-1055): `nh_collide` takes the arena
  *      BY VALUE (scratch is dead on return), the two `Arena*` functions ADVANCE it.
+ *      What the library DOES allocate itself (hipMalloc, freed by nh_destroy; all of it state that must survive from one
+ *      step to the next, which the by-value arena cannot hold): the counter block (~5 KB device + a pinned host mirror);
+ *      per body 4 B of warm-start hint and 16 B of contact degree / adjacency bookkeeping (grown to the largest
+ *      `bodies->count` seen); the splitters and bucket counters of the tag sort (16 B per 1024 broadphase pairs of
+ *      capacity); a side stream and two events; two small host-side rings of opaque-object descriptors.
  *   2. Indices are widened: body indices and collider tags are 32-bit (the reference packs them in 16 bits:
  *      nudge.h:68-71, 86, 93, 126 and asserts <= 8192 colliders at nudge.cpp:3010).  A contact's identity
  *      is therefore split in two words: `tags[i]`  = a_tag | (uint64_t)b_tag << 32   (reference: high 32
@@ -35,6 +40,12 @@
  *      foreign kernels enqueued on the stream BETWEEN setup and the first apply would see momentum without the
  *      warm start; call `nh_synchronize` (or any entry point) first if you need that.
  *
+ *   8. The solver consumes the contact list as nh_collide laid it out (tag order, per-body degrees, adjacency seeds).
+ *      Contacts appended by the caller between nh_collide and nh_setup_contact_constraints (the reference allows that:
+ *      "Custom contacts can be added here", example/main.cpp:287) are NOT picked up: edit fields of existing contacts in
+ *      place (friction, penetration ...) instead, or express the constraint as impulses between nh_apply_impulses calls.
+ *      One nh_setup_contact_constraints per nh_collide (a second one returns NH_ERR_STALE_SETUP).
+ *
  * Threading: one context = one HIP stream = one world at a time; no global mutable state.
  */
 #ifndef NUDGE_HIP_H
@@ -55,8 +66,14 @@ enum {
 	NH_ERR_CONTACT_CAPACITY = 4, /* contacts->capacity exceeded (reference: unchecked overflow)         */
 	NH_ERR_CACHE_CAPACITY = 5,   /* contact_cache->capacity     (reference: assert nudge.cpp:4118)      */
 	NH_ERR_ACTIVE_CAPACITY = 6,  /* active_bodies->capacity     (reference: unchecked overflow)         */
-	NH_ERR_PAIR_CAPACITY = 7,    /* internal broadphase pair buffer (sized from the arena)              */
-	NH_ERR_HIP = 8               /* a HIP call failed; see nh_last_hip_error                            */
+	NH_ERR_PAIR_CAPACITY = 7,    /* broadphase pair buffer: nh_set_pair_capacity (default contacts->capacity / 2 + 1024;
+	                                AABB-overlap pairs can outnumber contacts in dense scenes: size it from the colliders) */
+	NH_ERR_HIP = 8,              /* a HIP call failed; see nh_last_hip_error                            */
+	NH_ERR_SCHEDULER_CAPACITY = 9, /* NH_FLAG_EXACT_ORDER only: the replay of the reference's greedy batch scheduler ran out of open
+	                                batches (more than ~130,000 contacts on ONE dynamic body; the reference sizes this by
+	                                contacts.count, nudge.cpp:4222-4223)                                  */
+	NH_ERR_STALE_SETUP = 10      /* nh_setup_contact_constraints called twice for one nh_collide, or contacts->count changed in
+	                                between: the solver's inputs are laid out by nh_collide (note 8)         */
 };
 
 /* ---- context flags ----------------------------------------------------------------------------- */
@@ -149,6 +166,11 @@ int nh_synchronize(nh_context* ctx);
 int nh_read_counts(nh_context* ctx, nh_Counts* out);        /* synchronises the stream */
 int nh_set_cache_count(nh_context* ctx, uint32_t count);    /* restore a checkpointed ContactCache */
 int nh_set_tag_bits(nh_context* ctx, uint32_t bits);        /* collider tags are < 2^bits (default 32): fewer sort passes */
+/* Capacity of the broadphase pair buffer (AABB-overlap pairs after the same-body filter), carved from the arena at ~210 B per
+   pair by nh_collide.  0 (default) = contacts->capacity / 2 + 1024.  The reference has no such limit (its pair list lives in the
+   arena too, nudge.cpp:3473): dense scenes hold more overlapping pairs than contacts (a settled ball pit: 1.7 x), so size it from
+   the collider count there.  Overflow is reported as NH_ERR_PAIR_CAPACITY. */
+int nh_set_pair_capacity(nh_context* ctx, uint32_t pairs);
 const char* nh_error_string(int code);
 int nh_last_hip_error(nh_context* ctx);
 

@@ -196,7 +196,11 @@ void collide(ActiveBodies* active_bodies, ContactData* contacts, BodyData bodies
 	uint64_t cells = 1; while (cells < 4 * ncol) cells <<= 1;
 	if (cells < (1u << 16)) cells = 1u << 16;
 	if (cells > (1u << 24)) cells = 1u << 24;
-	const size_t arena_bytes = ((size_t)64 << 20) + ncol * 200 + cells * 8 + (size_t)K * 420 + (size_t)bodies.count * 64;
+	// broadphase pairs are not bounded by the contact capacity (a pit of balls holds more overlapping AABB pairs than contacts): like the
+	// reference, whose pair list is only bounded by the arena (nudge.cpp:3473), size the pair buffer from the colliders as well
+	const uint64_t pair_cap = (uint64_t)K / 2 + 1024 > 16 * ncol + 1024 ? (uint64_t)K / 2 + 1024 : 16 * ncol + 1024;
+	check(nh_set_pair_capacity(s.ctx, (uint32_t)pair_cap), "set_pair_capacity");
+	const size_t arena_bytes = ((size_t)64 << 20) + ncol * 200 + cells * 8 + (size_t)K * 320 + (size_t)pair_cap * 216 + (size_t)bodies.count * 64;
 	s.arena.reserve(arena_bytes);
 	s.temporary = nh_Arena{ s.arena.p, s.arena.cap };
 
@@ -286,7 +290,10 @@ ContactConstraintData* setup_contact_constraints(ActiveBodies active_bodies, Con
 	nh_BodyData db = device_bodies(s, bodies, true, true, true, false);      // the gravity loop has touched momentum
 	nh_ContactConstraintData* dev = nullptr;
 	check(nh_setup_contact_constraints(s.ctx, &s.active_bodies, &s.contacts, &db, h->dev, &s.temporary, &dev), "setup_contact_constraints");
-	download(bodies.momentum, s.body_mom.p, sizeof(BodyMomentum) * (size_t)bodies.count);     // warm start (nudge.cpp:4563-4632) + unused0 (4198)
+	// the C ABI defers row build + warm start to the first apply (nudge_hip.h note 7); the reference has applied the warm start when setup
+	// returns (nudge.cpp:4563-4632) and host code may read momentum right away: complete the pending work before the download
+	check(nh_synchronize(s.ctx), "synchronize");
+	download(bodies.momentum, s.body_mom.p, sizeof(BodyMomentum) * (size_t)bodies.count);     // warm start + unused0 (4198)
 	ConstraintHandle* c = static_cast<ConstraintHandle*>(arena_take(memory, sizeof(ConstraintHandle), 16));
 	c->magic = CONSTRAINT_MAGIC; c->dev = dev;
 	return reinterpret_cast<ContactConstraintData*>(c);

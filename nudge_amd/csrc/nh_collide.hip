@@ -712,24 +712,17 @@ __global__ __launch_bounds__(256) void k_active_write(nh_DevState* __restrict__ 
 }
 
 // contacts of inactive sets leave the contact list and become sleeping pairs (nudge.cpp:3976-4003)
-__global__ __launch_bounds__(256) void k_filter_records(nh_DevState* __restrict__ st, nh_Record* __restrict__ rec, uint64_t* __restrict__ rec_key, uint32_t* __restrict__ rec_idx,
-                                                        const uint32_t* __restrict__ root_of, const uint32_t* __restrict__ set_active,
-                                                        uint64_t* __restrict__ sleeping_pairs, uint32_t sleeping_cap, uint32_t parity) {
+__global__ __launch_bounds__(256) void k_filter_records(nh_DevState* __restrict__ st, nh_Record* __restrict__ rec,
+                                                        const uint32_t* __restrict__ root_of, const uint32_t* __restrict__ set_active, uint32_t parity) {
 	if (!st->any_idle[parity]) return;          // nobody sleeps: no record can belong to a sleeping set
-	uint32_t n = st->records;
-	uint32_t rounded = (n + 63u) & ~63u;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
-		bool sleeping = false;
-		uint64_t key = 0;
-		if (i < n) {
-			nh_Record r = rec[i];
-			if (r.count && !(r.count & NH_REC_SLEEPING)) {
-				uint32_t set = root_of[r.body_a ? r.body_a : r.body_b];      // sets[a] | sets[b] with sets[0] = 0 (nudge.cpp:3988)
-				sleeping = !set_active[set];
-				if (sleeping) { rec[i].count = NH_REC_SLEEPING; st->any_sleeping = 1; }   // no contacts any more; key kept: sleeping pairs come out in tag order
-			}
+	const uint32_t n = st->records;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const nh_Record r = rec[i];
+		if (r.count && !(r.count & NH_REC_SLEEPING)) {
+			const uint32_t set = root_of[r.body_a ? r.body_a : r.body_b];      // sets[a] | sets[b] with sets[0] = 0 (nudge.cpp:3988)
+			// no contacts any more; the record keeps its key: sleeping pairs come out in tag order with the sorted records (k_gather_contacts)
+			if (!set_active[set]) { rec[i].count = NH_REC_SLEEPING; st->any_sleeping = 1; }
 		}
-		(void)key; (void)sleeping_pairs; (void)sleeping_cap; (void)rec_key; (void)rec_idx;
 	}
 }
 
@@ -872,6 +865,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	NH_HIP_CHECK(ctx, hipSetDevice(ctx->device));
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	ctx->step_parity ^= 1u;
+	ctx->collide_seq++;
 	nh_DevState* st = ctx->d_state;
 	const uint32_t nbox = colliders->boxes.count, nsph = colliders->spheres.count;
 	const uint32_t C = nbox + nsph;
@@ -893,8 +887,9 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	uint32_t* keys_b = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* vals_a = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* large_list = nh_arena_array<uint32_t>(A, C, &err);
-	const uint32_t pair_cap = cap / 2 + 1024;           // broadphase pairs; each owns 4 raw contact slots, the rest overflows
-	const bool onesweep = getenv("NH_SORT_CLASSIC") == nullptr;      // one kernel per radix pass (nh_util.hip); NH_SORT_CLASSIC=1: three
+	// broadphase pairs (each owns 4 raw contact slots, further contacts overflow): nh_set_pair_capacity, else half the contact capacity
+	const uint32_t pair_cap = ctx->pair_capacity ? ctx->pair_capacity : cap / 2 + 1024;
+	const bool onesweep = !ctx->env_sort_classic;                    // one kernel per radix pass (nh_util.hip); NH_SORT_CLASSIC=1: three
 	size_t hist_words = 256 * NH_SORT_GRID + 512;
 	if (onesweep && nh_sort_scratch_words(C > pair_cap ? C : pair_cap) > hist_words) hist_words = nh_sort_scratch_words(C > pair_cap ? C : pair_cap);
 	uint32_t* hist = nh_arena_array<uint32_t>(A, hist_words, &err);
@@ -980,7 +975,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	// on -- it runs on the side stream while the caller's stream sorts (fork here, join before k_sorted_counts)
 	// (only while the side chain is small: the radix passes spin-wait on each other and must not share the machine with a long
 	// kernel -- with millions of records in one island the union-find alone takes a millisecond)
-	const bool seeded_sort = onesweep && ctx->sort_seeded && getenv("NH_SORT_RADIX") == nullptr;      // (NH_SORT_RADIX=1: radix passes every step)
+	const bool seeded_sort = onesweep && ctx->sort_seeded && !ctx->env_sort_radix;      // (NH_SORT_RADIX=1: radix passes every step)
 	const bool fork = ctx->side != nullptr && (seeded_sort || ctx->h_state->records <= 1500000u);
 	hipStream_t main_stream = ctx->stream;
 	if (fork) {
@@ -999,7 +994,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		nh_scan_u32(ctx, flags, flags, &st->pad0 /* always 0 */, B, scan_tmp, &st->active, &st->any_idle[ctx->step_parity]);    // (skipped on the device when nobody sleeps)
 	}
 	NH_LAUNCH(ctx, "active_write", k_active_write, nh_grid_for(B, 256, 2048), 256, st, B, root_of, set_active, flags, active_bodies->indices, active_bodies->capacity, ctx->step_parity);
-	NH_LAUNCH(ctx, "filter_records", k_filter_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, rec_key_a, rec_idx_a, root_of, set_active, (uint64_t*)nullptr, cap, ctx->step_parity);
+	NH_LAUNCH(ctx, "filter_records", k_filter_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, root_of, set_active, ctx->step_parity);
 	if (fork) {
 		ctx->stream = main_stream;
 		NH_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, ctx->side));

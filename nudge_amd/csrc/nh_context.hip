@@ -1,5 +1,6 @@
 // nh_context.hip -- context lifecycle, device counters -> host, per-kernel timing, error strings.
 #include "nh_internal.h"
+#include <stdlib.h>
 
 extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t flags) {
 	if (!out) return NH_ERR_INVALID;
@@ -26,6 +27,14 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	{ const char* e = getenv("NH_BUCKET_TILE"); ctx->sort_tile = e ? (uint32_t)atoi(e) : 0u; }
 	{ const char* e = getenv("NH_BUCKET_TARGET"); ctx->sort_target = e ? (uint32_t)atoi(e) : 0u; }
 	ctx->step_parity = 0;
+	ctx->pair_capacity = 0;
+	ctx->collide_seq = 0; ctx->setup_seq = 0;
+	// NH_SORT_CLASSIC=1: three-kernel radix passes; NH_SORT_RADIX=1: radix passes every step (no seeded bucket sort);
+	// NH_COLOUR_JP=1: Jones-Plassmann colouring rounds.  Read here once, never on the step path.
+	ctx->env_sort_classic = getenv("NH_SORT_CLASSIC") != nullptr;
+	ctx->env_sort_radix = getenv("NH_SORT_RADIX") != nullptr;
+	ctx->env_colour_jp = getenv("NH_COLOUR_JP") != nullptr;
+	ctx->os_resident = 0;
 	ctx->d_state = nullptr;
 	ctx->h_state = nullptr;
 	if (hipMalloc((void**)&ctx->d_state, sizeof(nh_DevState)) != hipSuccess) { delete ctx; return NH_ERR_HIP; }
@@ -62,6 +71,8 @@ extern "C" void nh_destroy(nh_context* ctx) {
 
 extern "C" int nh_set_flags(nh_context* ctx, uint32_t flags) { if (!ctx) return NH_ERR_INVALID; ctx->flags = flags; return NH_OK; }
 extern "C" int nh_set_tag_bits(nh_context* ctx, uint32_t bits) { if (!ctx || bits < 1 || bits > 32) return NH_ERR_INVALID; ctx->tag_bits = bits; return NH_OK; }
+
+extern "C" int nh_set_pair_capacity(nh_context* ctx, uint32_t pairs) { if (!ctx) return NH_ERR_INVALID; ctx->pair_capacity = pairs; return NH_OK; }
 
 extern "C" int nh_synchronize(nh_context* ctx) {
 	if (!ctx) return NH_ERR_INVALID;
@@ -105,6 +116,8 @@ extern "C" const char* nh_error_string(int code) {
 	case NH_ERR_ACTIVE_CAPACITY: return "active body capacity exceeded";
 	case NH_ERR_PAIR_CAPACITY: return "broadphase pair capacity exceeded";
 	case NH_ERR_HIP: return "HIP runtime error";
+	case NH_ERR_SCHEDULER_CAPACITY: return "exact-order scheduler replay out of open batches";
+	case NH_ERR_STALE_SETUP: return "setup_contact_constraints does not match the last collide";
 	default: return "unknown error";
 	}
 }

@@ -100,6 +100,11 @@ struct nh_context {
 	uint32_t deg_capacity;
 	uint32_t step_parity;
 	uint32_t order_seq;
+	uint32_t pair_capacity;               // nh_set_pair_capacity; 0 = contacts->capacity / 2 + 1024
+	uint32_t collide_seq, setup_seq;      // one nh_setup_contact_constraints per nh_collide (NH_ERR_STALE_SETUP)
+	// behaviour switches read ONCE from the environment by nh_create (test / A-B knobs, see nh_context.hip)
+	bool env_sort_classic, env_sort_radix, env_colour_jp;
+	int os_resident;                      // co-resident workgroups of a one-kernel radix pass on THIS device (nh_util.hip), 0 = not yet asked
 	// tag sort seeded by the previous step's order (nh_util.hip): splitters persist across steps; counts / starts are scratch that must
 	// outlive nothing but is zeroed by its own kernels.  `sort_seeded`: the splitters describe the previous nh_collide of this capacity
 	uint64_t* sort_splitters;

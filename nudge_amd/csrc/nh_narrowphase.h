@@ -9,6 +9,20 @@
 //   * emitted contacts are canonicalised so that "a" is the collider with the LARGER tag
 //     (nudge.cpp:2074-2087 for faces, 2131-2132 for edges); normal points from a to b
 //   * feature word = a-features in one 16-bit half, b-features in the other
+//
+// DERIVED WORK NOTICE.  The per-contact / per-pair arithmetic in this file follows rasmusbarr/nudge's nudge.cpp statement by statement
+// (nh_box_box_eval: nudge.cpp:1177-2487 incl. its feature-tag tables; nh_sphere_sphere / nh_box_sphere: nudge.cpp:2489-2604): operation order and fused-multiply-add placement are the numeric contract of bit-exact parity
+// with that library, so those functions are a scalar restatement of its SIMD loops, not an independent design.  nudge is
+//     Copyright (c) 2017 Rasmus Barringer
+// and distributed under the MIT license: "Permission is hereby granted, free of charge, to any person obtaining a copy of this software
+// and associated documentation files (the "Software"), to deal in the Software without restriction, including without limitation the
+// rights to use, copy, modify, merge, publish, distribute, sublicense, and/or sell copies of the Software, and to permit persons to whom
+// the Software is furnished to do so, subject to the following conditions: The above copyright notice and this permission notice shall
+// be included in all copies or substantial portions of the Software.  THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND,
+// EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND
+// NONINFRINGEMENT.  IN NO EVENT SHALL THE AUTHORS OR COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN
+// ACTION OF CONTRACT, TORT OR OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE
+// SOFTWARE."
 #ifndef NH_NARROWPHASE_H
 #define NH_NARROWPHASE_H
 

@@ -359,12 +359,40 @@ __global__ __launch_bounds__(256) void k_order_check(nh_DevState* __restrict__ s
 	}
 }
 
-__global__ __launch_bounds__(64) void k_greedy_replay(nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, uint32_t* __restrict__ slot_key, uint32_t seq) {
+// Open batches beyond the GR_OPEN kept in LDS spill to global memory (`spill_ab` / `spill_idx`: GR_BUCKETS x spill_cap x 8 entries from the
+// arena): a dynamic hub body with thousands of contacts (a tray of boxes) makes every contact of a bucket conflict, so no batch completes
+// and the open list grows with the contact count -- the reference sizes these arrays by contacts.count (nudge.cpp:4222-4223).
+struct gr_store {
+	uint2 (*lds_ab)[GR_OPEN + 1][8];
+	uint32_t (*lds_idx)[GR_OPEN + 1][8];
+	uint2* spill_ab; uint32_t* spill_idx; uint32_t spill_cap;
+	__device__ __forceinline__ size_t at(uint32_t b, uint32_t j, uint32_t l) const { return ((size_t)b * spill_cap + (j - (GR_OPEN + 1u))) * 8u + l; }
+	__device__ __forceinline__ uint2 ab(uint32_t b, uint32_t j, uint32_t l) const {
+		if (j <= GR_OPEN) return lds_ab[b][j][l];
+		const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(spill_ab + at(b, j, l)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+	}
+	__device__ __forceinline__ void set_ab(uint32_t b, uint32_t j, uint32_t l, uint2 v) const {
+		if (j <= GR_OPEN) lds_ab[b][j][l] = v;
+		else __hip_atomic_store(reinterpret_cast<unsigned long long*>(spill_ab + at(b, j, l)), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	__device__ __forceinline__ uint32_t idx(uint32_t b, uint32_t j, uint32_t l) const {
+		return j <= GR_OPEN ? lds_idx[b][j][l] : __hip_atomic_load(spill_idx + at(b, j, l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+	__device__ __forceinline__ void set_idx(uint32_t b, uint32_t j, uint32_t l, uint32_t v) const {
+		if (j <= GR_OPEN) lds_idx[b][j][l] = v; else __hip_atomic_store(spill_idx + at(b, j, l), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+};
+
+__global__ __launch_bounds__(64) void k_greedy_replay(nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, uint32_t* __restrict__ slot_key, uint32_t seq,
+                                                      uint2* __restrict__ spill_ab, uint32_t* __restrict__ spill_idx, uint32_t spill_cap) {
 	if (st->order_conflict != seq) return;          // k_order_check: the closed form it wrote is the schedule
 	__shared__ uint2 pair_ab[GR_BUCKETS][GR_OPEN + 1][8];
 	__shared__ uint32_t slot_idx[GR_BUCKETS][GR_OPEN + 1][8];
 	__shared__ uint32_t vacancy[GR_BUCKETS];
 	__shared__ uint32_t emitted;
+	const gr_store S = { pair_ab, slot_idx, spill_ab, spill_idx, spill_cap };
+	const uint32_t max_open = GR_OPEN + spill_cap;      // largest legal index of the all-invalid padding entry
 	const uint32_t lane = threadIdx.x, sub = lane >> 3, ln = lane & 7;
 	const uint32_t n = st->contacts;
 	if (lane < GR_BUCKETS) { vacancy[lane] = 0; }
@@ -381,7 +409,7 @@ __global__ __launch_bounds__(64) void k_greedy_replay(nh_DevState* __restrict__ 
 		for (uint32_t base = 0; j == NH_NONE; base += 8) {
 			uint32_t jb = base + sub;
 			bool in_range = jb <= vac;
-			uint2 ab = in_range ? pair_ab[bucket][jb][ln] : make_uint2(NH_NONE, NH_NONE);
+			uint2 ab = in_range ? S.ab(bucket, jb, ln) : make_uint2(NH_NONE, NH_NONE);
 			bool conflict = in_range && (ab.x == ca || ab.y == ca || ab.x == cb || ab.y == cb);
 			unsigned long long bal = __ballot(conflict);
 			unsigned long long rng = __ballot(in_range);
@@ -391,29 +419,29 @@ __global__ __launch_bounds__(64) void k_greedy_replay(nh_DevState* __restrict__ 
 			}
 		}
 		// first free lane of that batch
-		uint2 mine = pair_ab[bucket][j][ln];
+		uint2 mine = S.ab(bucket, j, ln);
 		unsigned long long freeb = __ballot(sub == 0 && mine.x == NH_NONE && mine.y == NH_NONE);
 		uint32_t free_lane = (uint32_t)__ffsll((long long)(freeb & 0xffull)) - 1u;
 		__syncthreads();
 		if (lane == 0) {
-			slot_idx[bucket][j][free_lane] = i;
-			pair_ab[bucket][j][free_lane] = make_uint2(ca, cb);
+			S.set_idx(bucket, j, free_lane, i);
+			S.set_ab(bucket, j, free_lane, make_uint2(ca, cb));
 		}
 		__syncthreads();
 		bool changed = false;
 		if (j == vac) {
 			vac = vac + 1;
 			changed = true;
-			if (vac > GR_OPEN) { if (lane == 0) st->error = NH_ERR_INVALID; return; }
+			if (vac > max_open) { if (lane == 0) st->error = NH_ERR_SCHEDULER_CAPACITY; return; }
 		} else if (free_lane == 7) {
 			// batch complete: emit it, move the last open batch into its place
 			uint32_t e = emitted;
-			if (lane < 8) slot_key[slot_idx[bucket][j][lane]] = e;
+			if (lane < 8) slot_key[S.idx(bucket, j, lane)] = e;
 			vac = vac - 1;
 			__syncthreads();
 			if (lane < 8) {
-				pair_ab[bucket][j][lane] = pair_ab[bucket][vac][lane];
-				slot_idx[bucket][j][lane] = slot_idx[bucket][vac][lane];
+				S.set_ab(bucket, j, lane, S.ab(bucket, vac, lane));
+				S.set_idx(bucket, j, lane, S.idx(bucket, vac, lane));
 			}
 			if (lane == 0) emitted = e + 1;
 			changed = true;
@@ -421,7 +449,7 @@ __global__ __launch_bounds__(64) void k_greedy_replay(nh_DevState* __restrict__ 
 		__syncthreads();
 		if (changed) {
 			if (lane == 0) vacancy[bucket] = vac;
-			if (lane < 8) pair_ab[bucket][vac][lane] = make_uint2(NH_NONE, NH_NONE);
+			if (lane < 8) S.set_ab(bucket, vac, lane, make_uint2(NH_NONE, NH_NONE));
 		}
 		__syncthreads();
 	}
@@ -431,8 +459,8 @@ __global__ __launch_bounds__(64) void k_greedy_replay(nh_DevState* __restrict__ 
 		uint32_t vac = vacancy[b];
 		for (uint32_t j = 0; j < vac; ++j) {
 			if (lane < 8) {
-				uint2 ab = pair_ab[b][j][lane];
-				if (!(ab.x == NH_NONE && ab.y == NH_NONE)) slot_key[slot_idx[b][j][lane]] = e;
+				uint2 ab = S.ab(b, j, lane);
+				if (!(ab.x == NH_NONE && ab.y == NH_NONE)) slot_key[S.idx(b, j, lane)] = e;
 			}
 			++e;
 		}
@@ -1349,7 +1377,11 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	d->rows = nh_arena_array<float>(memory, (size_t)kcap * 40, &err);
 	d->states = nh_arena_array<float>(memory, (size_t)kcap * 4, &err);
 	if (!ctx->deg || ctx->deg_capacity < 4u * (B + 2u)) return NH_ERR_INVALID;      // nh_collide of this step sized and filled it
-	d->body_off = ctx->deg;                                                         // [B+2] degrees -> offsets, then [B+2] fill cursors
+	// one setup per collide: the fill cursors and the contact layout below belong to the last nh_collide (header note 8)
+	if (ctx->setup_seq == ctx->collide_seq) return NH_ERR_STALE_SETUP;
+	if ((ctx->flags & NH_FLAG_SYNC_COUNTS) && contacts->count != ctx->h_state->contacts) return NH_ERR_STALE_SETUP;
+	ctx->setup_seq = ctx->collide_seq;
+	d->body_off = nh_arena_array<uint32_t>(memory, (size_t)B + 2u, &err);           // CSR offsets (scan of the degrees nh_collide counted)
 	d->adj = nh_arena_array<uint32_t>(memory, (size_t)kcap * 2, &err);
 	d->static_bodies = nh_arena_array<uint32_t>(memory, (size_t)3 * B, &err);
 	d->body_class = nh_arena_array<uint8_t>(memory, B, &err);
@@ -1357,13 +1389,17 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	d->level_order = nh_arena_array<uint32_t>(memory, kcap, &err);
 	d->gpair = nh_arena_array<uint2>(memory, kcap, &err);
 	d->gstates = nh_arena_array<float4>(memory, kcap, &err);
-	uint32_t* cursor = d->body_off + (B + 2);
+	uint32_t* cursor = ctx->deg + (B + 2);                                          // fill cursors (zeroed by nh_collide)
 	uint32_t* pred_a = nh_arena_array<uint32_t>(memory, kcap, &err);
 	uint32_t* pred_b = nh_arena_array<uint32_t>(memory, kcap, &err);
 	uint32_t* level = nh_arena_array<uint32_t>(memory, kcap, &err);
 	uint32_t* general_list = nh_arena_array<uint32_t>(memory, kcap, &err);
 	uint32_t* slot_key = (ctx->flags & NH_FLAG_EXACT_ORDER) ? nh_arena_array<uint32_t>(memory, kcap, &err) : nullptr;
 	uint32_t* tent = (ctx->flags & NH_FLAG_EXACT_ORDER) ? nullptr : nh_arena_array<uint32_t>(memory, kcap, &err);      // colouring: this round's picks
+	// exact order: spill space of the scheduler replay's open batches (k_greedy_replay), at most 8192 per bucket = 12.6 MB
+	const uint32_t spill_cap = slot_key ? (kcap / GR_BUCKETS + 1u < 8192u ? kcap / GR_BUCKETS + 1u : 8192u) : 0u;
+	uint2* spill_ab = slot_key ? nh_arena_array<uint2>(memory, (size_t)GR_BUCKETS * spill_cap * 8u, &err) : nullptr;
+	uint32_t* spill_idx = slot_key ? nh_arena_array<uint32_t>(memory, (size_t)GR_BUCKETS * spill_cap * 8u, &err) : nullptr;
 	uint32_t* level_hist = nh_arena_array<uint32_t>(memory, NH_MAX_LEVELS + 2, &err);
 	uint32_t* level_cursor = nh_arena_array<uint32_t>(memory, NH_MAX_LEVELS + 2, &err);
 	uint32_t* tmp = nh_arena_array<uint32_t>(memory, 2 * NH_SORT_GRID + 64, &err);
@@ -1373,11 +1409,11 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	d->levels = 0; d->general_contacts = 0;
 
 	// (degrees were counted by nh_collide while it laid the contacts out)
-	nh_scan_u32(ctx, d->body_off, d->body_off, &st->pad0, B + 1, tmp, nullptr);
+	nh_scan_u32(ctx, ctx->deg, d->body_off, &st->pad0, B + 1, tmp, nullptr);
 	if (slot_key) {
 		const uint32_t seq = ++ctx->order_seq ? ctx->order_seq : ++ctx->order_seq;       // never 0: tells this call's verdict from an older one
 		NH_LAUNCH(ctx, "order_check", k_order_check, nh_grid_for(kcap / 8u + 16u, 256, 1024), 256, st, contacts->bodies, slot_key, seq);
-		NH_LAUNCH(ctx, "greedy_replay", k_greedy_replay, 1, 64, st, contacts->bodies, slot_key, seq);
+		NH_LAUNCH(ctx, "greedy_replay", k_greedy_replay, 1, 64, st, contacts->bodies, slot_key, seq, spill_ab, spill_idx, spill_cap);
 	}
 	NH_LAUNCH(ctx, "adjacency_simple", k_adj_simple, nh_grid_for(B, 256, 4096), 256, st, B, d->body_off, ctx->deg + 2 * (size_t)(B + 2), ctx->deg + 3 * (size_t)(B + 2), d->adj, slot_key,
 	          d->body_class, bodies->properties, bodies->momentum, d->simple);
@@ -1451,7 +1487,7 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		NH_LAUNCH(ctx, "level_reset", k_level_reset_progress, 1, 1, st);
 		// colouring: most contacts are settled by the first rounds; the later ones walk a compacted list of the rest (pred_a / pred_b, which
 		// only the exact mode uses, serve as its two buffers)
-		const bool colour_jp = getenv("NH_COLOUR_JP") != nullptr;
+		const bool colour_jp = ctx->env_colour_jp;
 		const uint32_t* colour_list = general_list;
 		uint32_t colour_n = 0;                         // 0: the whole general list
 		uint32_t* spare[2] = { pred_a, pred_b };

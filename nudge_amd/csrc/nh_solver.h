@@ -4,6 +4,21 @@
 // Scalar restatement-for-GPU of the reference's 8-wide AVX2 loops with the SAME operation order and the
 // same fused-multiply-add placement (reference nudge.cpp:4182-4199, 4386-4633, 4646-4854, 4864-4883,
 // 4890-4925).  See nh_math.h for the numeric contract.
+//
+// DERIVED WORK NOTICE.  The per-contact / per-pair arithmetic in this file follows rasmusbarr/nudge's nudge.cpp statement by statement
+// (nh_build_row / nh_warm_start / nh_apply_one / nh_export_impulse / nh_advance_body: nudge.cpp:4182-4199, 4393-4854, 4864-4883, 4890-4925;
+// the one-body forms nh_*1 are those with the static body's terms removed): operation order and fused-multiply-add placement are the numeric contract of bit-exact parity
+// with that library, so those functions are a scalar restatement of its SIMD loops, not an independent design.  nudge is
+//     Copyright (c) 2017 Rasmus Barringer
+// and distributed under the MIT license: "Permission is hereby granted, free of charge, to any person obtaining a copy of this software
+// and associated documentation files (the "Software"), to deal in the Software without restriction, including without limitation the
+// rights to use, copy, modify, merge, publish, distribute, sublicense, and/or sell copies of the Software, and to permit persons to whom
+// the Software is furnished to do so, subject to the following conditions: The above copyright notice and this permission notice shall
+// be included in all copies or substantial portions of the Software.  THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND,
+// EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO THE WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND
+// NONINFRINGEMENT.  IN NO EVENT SHALL THE AUTHORS OR COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN
+// ACTION OF CONTRACT, TORT OR OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE
+// SOFTWARE."
 #ifndef NH_SOLVER_H
 #define NH_SOLVER_H
 

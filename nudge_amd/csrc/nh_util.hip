@@ -318,7 +318,7 @@ static int onesweep_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* va
 	if (want > cap_tiles) want = cap_tiles;
 	// every workgroup of a pass must be resident at once (they wait for each other): bound the launch by 3/4 of what the
 	// occupancy calculator says fits (kernels of the side stream may hold some slots for a while; they never wait for us)
-	static int resident = 0;
+	int& resident = ctx->os_resident;          // per context (= per device): the bound differs between devices
 	if (!resident) {
 		int per_cu = 0, cus = 0;
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, os_pass<K, V, HAS_V>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;

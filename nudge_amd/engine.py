@@ -27,7 +27,7 @@ NH_FLAG_EXACT_ORDER = 2
 
 EXPORTS = [
     "nh_create", "nh_destroy", "nh_set_flags", "nh_synchronize", "nh_read_counts", "nh_set_cache_count",
-    "nh_set_tag_bits", "nh_error_string", "nh_last_hip_error", "nh_collide", "nh_apply_gravity_damping",
+    "nh_set_tag_bits", "nh_set_pair_capacity", "nh_error_string", "nh_last_hip_error", "nh_collide", "nh_apply_gravity_damping",
     "nh_read_cached_impulses", "nh_write_cached_impulses", "nh_setup_contact_constraints", "nh_apply_impulses",
     "nh_update_cached_impulses", "nh_advance", "nh_contact_impulses_device", "nh_enable_timing", "nh_set_timing_filter", "nh_kernel_times",
     "nh_halo_pack", "nh_halo_unpack",
@@ -101,6 +101,7 @@ def lib():
         L.nh_destroy.restype = None
         L.nh_set_flags.argtypes = [C.c_void_p, C.c_uint32]
         L.nh_set_tag_bits.argtypes = [C.c_void_p, C.c_uint32]
+        L.nh_set_pair_capacity.argtypes = [C.c_void_p, C.c_uint32]
         L.nh_synchronize.argtypes = [C.c_void_p]
         L.nh_read_counts.argtypes = [C.c_void_p, C.POINTER(Counts)]
         L.nh_set_cache_count.argtypes = [C.c_void_p, C.c_uint32]
@@ -141,9 +142,10 @@ def _check(L, rc, what):
 class World:
     """A world resident in HBM, stepped through the C ABI.  `scene` uses the layouts of nudge_amd.scenes."""
 
-    def __init__(self, scene, device=0, max_contacts=None, arena_bytes=None, flags=NH_FLAG_SYNC_COUNTS, tag_bits=None, capacity=None):
+    def __init__(self, scene, device=0, max_contacts=None, arena_bytes=None, flags=NH_FLAG_SYNC_COUNTS, tag_bits=None, capacity=None, max_pairs=None):
         """`capacity` = dict(bodies=, boxes=, spheres=): allocate room for more records than the scene holds (the
-        partitioned world appends ghost / migrated bodies, nudge_amd/partition.py); counts then change via set_counts()."""
+        partitioned world appends ghost / migrated bodies, nudge_amd/partition.py); counts then change via set_counts().
+        `max_pairs`: capacity of the broadphase pair buffer (nh_set_pair_capacity); default max_contacts / 2 + 1024."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("nudge_amd.World needs a HIP device (no CPU fallback)")
@@ -197,7 +199,8 @@ class World:
             while cells < 4 * ncol:
                 cells <<= 1
             cells = min(max(cells, 1 << 16), 1 << 24)
-            arena_bytes = (64 << 20) + ncol * 200 + cells * 8 + K * 420 + nb * 64
+            pairs = max_pairs if max_pairs else K // 2 + 1024
+            arena_bytes = (64 << 20) + ncol * 200 + cells * 8 + K * 320 + pairs * 216 + nb * 64
         self.arena_t = alloc("arena", arena_bytes)
         self.arena = Arena(self.arena_t.data_ptr(), arena_bytes)
 
@@ -212,6 +215,8 @@ class World:
                     mt = max(mt, int(scene[k].max()))
             tag_bits = max(8, int(mt).bit_length())
         self.L.nh_set_tag_bits(self.ctx, tag_bits)
+        if max_pairs:
+            _check(self.L, self.L.nh_set_pair_capacity(self.ctx, int(max_pairs)), "nh_set_pair_capacity")
         self.steps_done = 0
         self.sum_contacts = 0
         self._imp = C.c_void_p()
@@ -272,6 +277,19 @@ class World:
             self.steps_done += 1
             if self.flags & NH_FLAG_SYNC_COUNTS:
                 self.sum_contacts += self.contacts.count
+
+    # ---- checkpoint / restore of the caller-owned persistent state (bodies + contact cache), device to device ----
+    def snapshot(self):
+        """Everything that persists from one step to the next on the caller's side (nudge.h: BodyData transforms / momentum / idle
+        counters and the ContactCache), cloned on the device."""
+        c = self.counts()
+        return dict(cache_count=c["cache"], arrays={k: self._keep[k].clone() for k in ("bt", "bm", "bi", "kt", "kf", "kd")})
+
+    def restore(self, snap):
+        self.synchronize()
+        for k, t in snap["arrays"].items():
+            self._keep[k].copy_(t)
+        _check(self.L, self.L.nh_set_cache_count(self.ctx, snap["cache_count"]), "set_cache_count")
 
     # ---- variable membership (partitioned worlds) ----
     def set_counts(self, bodies, boxes, spheres):

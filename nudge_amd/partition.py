@@ -62,9 +62,12 @@ def body_reach(scene):
     return kind, cidx, reach
 
 
-def split_scene(scene, cuts, rank, slack=0.15, min_extra=4096):
+def split_scene(scene, cuts, rank, slack=0.15, min_extra=4096, static_margin=None):
     """Rank `rank`'s initial local scene for slabs bounded by `cuts` (ascending x, len = ranks - 1).
-    Returns (local_scene, info) where info holds what `Partition` needs besides the engine arrays."""
+    Returns (local_scene, info) where info holds what `Partition` needs besides the engine arrays.
+    `static_margin`: keep only the static colliders whose x-extent comes within this distance of the rank's slab or of a
+    neighbour's (bodies only ever arrive from a neighbour, and they bring the ground they stand on into reach one slab at a
+    time) -- None keeps all of them (small scenes); a rank of the 16 M-box world holds ~500 of the 1984 ground slabs."""
     kind, cidx, reach = body_reach(scene)
     x = scene["body_transforms"]["position"][:, 0]
     lo = -np.inf if rank == 0 else cuts[rank - 1]
@@ -81,6 +84,15 @@ def split_scene(scene, cuts, rank, slack=0.15, min_extra=4096):
     def pick(prefix, k):
         xf = scene[prefix + "_transforms"]
         static = np.flatnonzero(xf["body"] == 0)
+        if static_margin is not None and len(static):
+            # conservative x-extent of a static collider: centre +- |half extents| (any rotation) or radius
+            data = scene[prefix + "_data"][static]
+            ext = np.linalg.norm(data["size"].astype(np.float64), axis=1) if k == 0 else data["radius"].astype(np.float64)
+            cx = xf["position"][static, 0].astype(np.float64)
+            # this slab and both neighbours' (a ghost or migrant arriving from next door may rest on ground beyond the cut)
+            lo2 = -np.inf if rank <= 1 else cuts[rank - 2]
+            hi2 = np.inf if rank + 1 >= len(cuts) else cuts[rank + 1]
+            static = static[(cx + ext >= lo2 - static_margin) & (cx - ext <= hi2 + static_margin)]
         dyn_local = np.flatnonzero(kind[body_map[1:]] == k) + 1             # local body slots with a collider of this kind
         sel = np.concatenate([static, cidx[body_map[dyn_local]]]).astype(np.int64)
         t = xf[sel].copy()

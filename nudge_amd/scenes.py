@@ -338,6 +338,33 @@ def compound(n_bodies=150, seed=6, iterations=8):
     return scene
 
 
+def tray(nx=17, nz=18, seed=8, iterations=8):
+    """A dynamic HUB body: one wide tray box resting on the ground carries nx*nz small boxes, so a single dynamic body sits in
+    4*nx*nz + 4 contacts (> 1000 for the default).  Every contact on the tray conflicts with every other one in the reference's
+    batch scheduler (nudge.cpp:4206-4339): no batch ever fills, the open list grows with the contact count."""
+    f = np.float32
+    n = nx * nz
+    d = _draws(0x9E3779B97F4A7C15 ^ seed, n + 1)
+    st = _identity_transforms(1)
+    st["position"][0] = (0.0, -20.0, 0.0)
+    ssz = np.array([[400.0, 10.0, 400.0]], dtype=np.float32)
+    hx, hz = f(nx * 1.1 + 1.0), f(nz * 1.1 + 1.0)
+    bt = _identity_transforms(n + 1)
+    bsz = np.zeros((n + 1, 3), dtype=np.float32)
+    bt["position"][0] = (0.0, -10.0 + 0.5 + 0.01, 0.0)
+    bsz[0] = (hx, 0.5, hz)
+    i = np.arange(n)
+    sx = d[1:, 0] * f(0.2) + f(0.4)
+    bt["position"][1:, 0] = ((i % nx).astype(np.float32) - f((nx - 1) * 0.5)) * f(2.2) + d[1:, 1] * f(0.1)
+    bt["position"][1:, 1] = f(-10.0 + 1.0 + 0.02) + sx
+    bt["position"][1:, 2] = ((i // nx).astype(np.float32) - f((nz - 1) * 0.5)) * f(2.2) + d[1:, 2] * f(0.1)
+    bsz[1:] = np.stack([sx, sx, sx], axis=1)
+    bp = _box_properties(bsz[:, 0].copy(), bsz[:, 1].copy(), bsz[:, 2].copy())
+    empty_t = _identity_transforms(0)
+    params = dict(DEFAULT_PARAMS, iterations=iterations)
+    return _assemble((st, ssz), (bt, bsz, bp), (empty_t, np.zeros(0, np.float32), np.zeros(0, PROPERTIES)), params, name=f"tray{nx}x{nz}")
+
+
 def narrow_ok(scene) -> bool:
     """True if the scene fits the reference's 16-bit API limits (nudge.cpp:3010, nudge.h:69-70)."""
     c = len(scene["box_tags"]) + len(scene["sphere_tags"])

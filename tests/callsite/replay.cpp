@@ -8,11 +8,16 @@
 //   (b) against nudge_amd/compat/nudge_compat.cpp + libnudge_hip -> nudge_amd/compat/_build/replay_hip
 // and tests/test_gpu_callsite.py requires the two binaries to produce bit-identical worlds.
 //
-// usage: replay <scene.bin> <out.bin> <steps>
+// usage: replay <scene.bin> <out.bin> <steps> [mode]
+// mode (what the call site does besides the plain loop; every variant is legal use of the reference API):
+//   plain             (default)
+//   zero_iterations   never calls apply_impulses: the warm start applied by setup_contact_constraints (nudge.cpp:4563-4632) is all the solver does
+//   peek_after_setup  reads bodies.momentum right after setup_contact_constraints (folds it into the checksum): the warm start must be visible there
+//   custom_impulses   user impulses between two apply_impulses calls, the way custom constraints interleave (example/main.cpp:314-317)
 // scene.bin: u32 header { bodies, boxes, spheres, iterations, max_contacts } + f32 { time_step, gravity, damping_rate }
 //            then Transform[bodies] BodyProperties[bodies] BodyMomentum[bodies] u8 idle[bodies]
 //            u16 box_tags[boxes] BoxCollider[boxes] Transform[boxes] u16 sphere_tags[spheres] SphereCollider[spheres] Transform[spheres]
-// out.bin:   Transform[bodies] BodyMomentum[bodies] u8 idle[bodies] u64 sum_of_contact_counts u32 last_contact_count u32 last_active_count
+// out.bin:   Transform[bodies] BodyMomentum[bodies] u8 idle[bodies] u64 sum_of_contact_counts u32 last_contact_count u32 last_active_count u64 checksum
 #include <nudge.h>
 
 #include <stdint.h>
@@ -46,6 +51,10 @@ int main(int argc, char** argv) {
 	const uint32_t nb = head[0], nbox = head[1], nsph = head[2], iterations = head[3], max_contacts = head[4];
 	const float time_step = par[0], gravity = par[1], damping_rate = par[2];
 	const unsigned steps = (unsigned)atoi(argv[3]);
+	const char* mode = argc > 4 ? argv[4] : "plain";
+	const bool zero_iterations = !strcmp(mode, "zero_iterations"), peek = !strcmp(mode, "peek_after_setup"), custom = !strcmp(mode, "custom_impulses");
+	if (!zero_iterations && !peek && !custom && strcmp(mode, "plain") && strcmp(mode, "exact")) { fprintf(stderr, "replay: unknown mode %s\n", mode); return 2; }
+	uint64_t checksum = 1469598103934665603ull;      // FNV-1a over whatever the mode looks at
 
 	nudge::BodyData bodies = {};
 	bodies.transforms = aligned_array<nudge::Transform>(nb);
@@ -113,8 +122,17 @@ int main(int argc, char** argv) {
 
 		nudge::ContactImpulseData* impulses = nudge::read_cached_impulses(cache, contacts, &temporary);
 		nudge::ContactConstraintData* constraints = nudge::setup_contact_constraints(active, contacts, bodies, impulses, &temporary);
-		for (unsigned i = 0; i < iterations; ++i)
+		if (peek) {
+			const unsigned char* raw = reinterpret_cast<const unsigned char*>(bodies.momentum);
+			for (size_t k = 0; k < sizeof(nudge::BodyMomentum) * (size_t)nb; ++k) { checksum ^= raw[k]; checksum *= 1099511628211ull; }
+		}
+		for (unsigned i = 0; i < (zero_iterations ? 0u : iterations); ++i) {
 			nudge::apply_impulses(constraints, bodies);
+			if (custom) {
+				// a stand-in for a user constraint: small fixed impulses on the first few dynamic bodies after every sweep
+				for (unsigned b = 1; b < nb && b <= 8; ++b) { bodies.momentum[b].angular_velocity[1] += 0.01f; bodies.momentum[b].velocity[0] -= 0.002f; }
+			}
+		}
 		nudge::update_cached_impulses(constraints, impulses);
 		nudge::write_cached_impulses(&cache, contacts, impulses);
 		nudge::advance(active, bodies, time_step);
@@ -129,6 +147,7 @@ int main(int argc, char** argv) {
 	fwrite(&sum_contacts, 8, 1, o);
 	fwrite(&contacts.count, 4, 1, o);
 	fwrite(&active.count, 4, 1, o);
+	fwrite(&checksum, 8, 1, o);
 	fclose(o);
 	printf("replay: %u steps, %u bodies, last step %u contacts, %u active, sum of contacts %llu, %.1f steps/s\n", steps, nb, contacts.count, active.count, (unsigned long long)sum_contacts, steps / seconds);
 	return 0;

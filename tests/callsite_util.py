@@ -41,8 +41,9 @@ def read_result(path, nb):
     m = np.frombuffer(raw, dtype=S.MOMENTUM, count=nb, offset=o); o += 32 * nb
     idle = np.frombuffer(raw, dtype=np.uint8, count=nb, offset=o); o += nb
     sum_contacts = int(np.frombuffer(raw, dtype=np.uint64, count=1, offset=o)[0]); o += 8
-    last_contacts, last_active = [int(x) for x in np.frombuffer(raw, dtype=np.uint32, count=2, offset=o)]
-    return dict(transforms=t, momentum=m, idle=idle, sum_contacts=sum_contacts, last_contacts=last_contacts, last_active=last_active)
+    last_contacts, last_active = [int(x) for x in np.frombuffer(raw, dtype=np.uint32, count=2, offset=o)]; o += 8
+    checksum = int(np.frombuffer(raw, dtype=np.uint64, count=1, offset=o)[0]) if len(raw) >= o + 8 else None
+    return dict(transforms=t, momentum=m, idle=idle, sum_contacts=sum_contacts, last_contacts=last_contacts, last_active=last_active, checksum=checksum)
 
 
 def run_replay(binary, scene_path, out_path, steps, timeout=600, extra=()):

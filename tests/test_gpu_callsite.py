@@ -70,6 +70,29 @@ def test_same_call_site_two_backends_bit_identical(name, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["zero_iterations", "peek_after_setup", "custom_impulses"])
+@pytest.mark.parametrize("name", ["pile256", "mixed20"])
+def test_unusual_call_patterns_two_backends_bit_identical(name, mode, tmp_path):
+    """Call sites the plain loop does not cover, all legal use of the reference API: no apply_impulses at all (the warm start of
+    setup_contact_constraints, nudge.cpp:4563-4632, must still reach momentum -- and stay in the caller's host arrays), reading
+    momentum between setup and the first apply_impulses, and user impulses between two apply_impulses calls (the custom-constraint
+    hook, example/main.cpp:314-317).  Same source file, reference vs GPU backend, bit-identical worlds and checksums."""
+    assert os.path.exists(CU.REPLAY_HIP), "nudge_amd/compat/_build/replay_hip missing: make -C nudge_amd/compat"
+    assert os.path.exists(CU.REPLAY_REF), "oracle/_ref/replay_ref missing: make -C oracle"
+    scene, steps = _build(name)
+    steps = min(steps, 110)
+    nb = CU.write_scene(str(tmp_path / "s.bin"), scene)
+    CU.run_replay(CU.REPLAY_HIP, str(tmp_path / "s.bin"), str(tmp_path / "hip.bin"), steps, extra=[mode])
+    CU.run_replay(CU.REPLAY_REF, str(tmp_path / "s.bin"), str(tmp_path / "ref.bin"), steps, extra=[mode])
+    got, ref = CU.read_result(str(tmp_path / "hip.bin"), nb), CU.read_result(str(tmp_path / "ref.bin"), nb)
+    assert ref["sum_contacts"] > 0
+    assert P.bits_equal(got["transforms"], ref["transforms"]), mode
+    assert P.bits_equal(got["momentum"], ref["momentum"]), mode
+    assert P.bits_equal(got["idle"], ref["idle"]), mode
+    assert got["sum_contacts"] == ref["sum_contacts"] and got["checksum"] == ref["checksum"], mode
+
+
+@pytest.mark.gpu
 def test_reference_own_test_program_passes_on_the_gpu_backend():
     assert os.path.exists(CU.REF_TESTS_HIP), "nudge_amd/compat/_build/ref_tests_hip missing: make -C nudge_amd/compat"
     r = subprocess.run([CU.REF_TESTS_HIP], capture_output=True, text=True, timeout=1500)

@@ -173,71 +173,7 @@ def test_arena_exhaustion_is_reported():
     w.close()
 
 
-# ---- BASELINE.json sizes: size-independent properties ---------------------------------------------------------------------
-def test_million_box_scene_properties():
-    """Config 2 (1,004,400 boxes): every landed box rests on 4 face contacts, nothing is NaN, two runs agree
-    bit for bit, and sampled tiles agree with the per-tile reference when it is available."""
-    scene = S.grid_tiles(124, side=90, seed=2, lattice_cols=11)
-    n = len(scene["body_transforms"]) - 1
-    assert n == 1004400
-    steps = 70
-    finals = []
-    for rep in range(2):
-        w = E.World(scene, flags=E.NH_FLAG_SYNC_COUNTS, max_contacts=6 * n)
-        w.step(steps)
-        c = w.counts()
-        finals.append(w.get_bodies())
-        if rep == 0:
-            assert c["error"] == 0
-            assert 3.9 * n <= c["contacts"] <= 4 * n, c          # landed boxes rest on 4 face contacts
-            assert c["active_bodies"] == n
-            assert c["general_contacts"] == 0
-        w.close()
-    a, b = finals
-    assert np.isfinite(a["transforms"]["position"]).all() and np.isfinite(a["momentum"]["velocity"]).all()
-    assert P.bits_equal(a["transforms"], b["transforms"]) and P.bits_equal(a["momentum"], b["momentum"])
-    if have_ref:
-        for t in (0, 61, 123):
-            sub, body_map = S.extract_tile(scene, t)
-            ref = refworld.RefWorld(sub)
-            ref.step(steps)
-            rb = ref.bodies()
-            origin = scene["box_transforms"]["position"][t].astype(np.float64)
-            err = P.rel_err(a["transforms"]["position"][body_map[1:]], rb["transforms"]["position"][1:], origin=origin)
-            assert err.max() <= 1e-4, (t, err.max())
-
-
-@needs_ref
-def test_million_boxes_1000_steps_vs_tiled_reference():
-    """BASELINE.json north star: body state within 1e-4 relative of the reference after 1000 steps on the 1 M-box scene
-    (SURVEY 8(d), config 2): the GPU steps the union world in its default mode, the reference steps sampled tiles on their own.
-    By step 1000 every box has landed, settled and fallen asleep: the whole pipeline incl. islands, sleeping and cache culling ran."""
-    scene = S.grid_tiles(124, side=90, seed=2, lattice_cols=11)
-    n = len(scene["body_transforms"]) - 1
-    steps = 1000
-    w = E.World(scene, flags=0, max_contacts=6 * n)            # the bench's mode: one host sync per step
-    w.step(steps)
-    c = w.counts()
-    assert c["error"] == 0
-    gb = w.get_bodies()
-    assert c["sleeping_pairs"] > 0.9 * n, c                    # the scene went to sleep (nudge.cpp:4896-4902)
-    assert np.isfinite(gb["transforms"]["position"]).all() and np.isfinite(gb["momentum"]["velocity"]).all()
-    worst = 0.0
-    for t in (0, 61, 123):
-        sub, body_map = S.extract_tile(scene, t)
-        ref = refworld.RefWorld(sub)
-        ref.step(steps)
-        rb = ref.bodies()
-        origin = scene["box_transforms"]["position"][t].astype(np.float64)
-        err = P.rel_err(gb["transforms"]["position"][body_map[1:]], rb["transforms"]["position"][1:], origin=origin)
-        worst = max(worst, float(err.max()))
-        dv = np.abs(gb["momentum"]["velocity"][body_map[1:]] - rb["momentum"]["velocity"][1:]).max()
-        # residual velocities frozen when a body fell asleep (|v| < 0.1): measured 1.6e-4 absolute, against 6e-5 between the reference's
-        # own exact and shipped builds; the excess is the slot-order effect of stepping a union instead of a tile (DESIGN.md section 2)
-        assert dv <= 3e-4, (t, dv)
-        assert np.array_equal(gb["idle"][body_map[1:]] == 0xff, rb["idle"][1:] == 0xff)
-    assert worst <= 1e-4, worst
-    w.close()
+# (BASELINE.json sizes -- configs 2, 3, 4 at 1 M / 2 M / 4 M bodies: tests/test_gpu_atsize.py)
 
 
 # ---- config 4 (ball pit): chaotic, so short-horizon exactness + invariants (SURVEY 8(d) c4) ---------------------------------
@@ -277,12 +213,15 @@ def test_ball_pit_invariants_default_order():
     m = 1.0 / scene["body_properties"]["mass_inverse"][1:]
     ke = lambda v: float((0.5 * m * (v[1:].astype(np.float64) ** 2).sum(axis=1)).sum())
     ke_a, ke_b = ke(a["momentum"]["velocity"]), ke(b["momentum"]["velocity"])
-    assert ke_a <= 10.0 * ke_b + 1e-3 * len(m), (ke_a, ke_b)       # both have come to rest
+    assert ke_b / 3.0 - 1e-4 * len(m) <= ke_a <= 3.0 * ke_b + 1e-4 * len(m), (ke_a, ke_b)       # the same residual jitter, within a factor 3
     gc = w.get_contacts()
     ref.collide()
     rc = ref.contacts()
-    assert abs(gc["count"] - rc["count"]) <= 0.05 * rc["count"] + 50, (gc["count"], rc["count"])
-    assert gc["data"]["penetration"].max() <= rc["data"]["penetration"].max() + 0.02
+    assert abs(gc["count"] - rc["count"]) <= 0.02 * rc["count"] + 50, (gc["count"], rc["count"])
+    assert gc["data"]["penetration"].max() <= 1.5 * rc["data"]["penetration"].max() + 0.005
+    # contacts per sphere: same distribution (bins 0..12), each bin within 5 points
+    deg = lambda bodies: np.bincount(np.minimum(np.bincount(bodies.reshape(-1).astype(np.int64), minlength=len(m) + 1)[1:], 12), minlength=13) / len(m)
+    assert np.abs(deg(gc["bodies"]) - deg(rc["bodies"])).max() <= 0.05
     w.close()
 
 
@@ -343,6 +282,94 @@ def test_body_connections_join_islands():
         differed |= len(w.get_active()) != len(w0.get_active())
     assert differed, "the connections were meant to keep part of the grid awake"
     w.close(); w0.close()
+
+
+@needs_ref
+@pytest.mark.parametrize("name,warm", [("grid30", 70), ("pile256", 330)])
+def test_custom_impulses_between_apply_calls(name, warm):
+    """SURVEY 8(f)-1 / example/main.cpp:314-317: user code changes body momentum BETWEEN two apply_impulses calls (that is how custom
+    constraints interleave with the contact solver).  nh_apply_impulses(..., 1) per sweep with momentum edited in between must match the
+    reference doing the same, on the one-body path (grid30) and on the level-scheduled path (pile256), bit for bit."""
+    scene, _ = G.build(name)
+    w = E.World(scene, flags=EXACT)
+    ref = refworld.RefWorld(scene)
+    w.step(warm); ref.step(warm)
+
+    def nudge(m):
+        m = m.copy()
+        m["angular_velocity"][1:9, 1] += np.float32(0.01)
+        m["velocity"][1:9, 0] -= np.float32(0.002)
+        return m
+
+    for step in range(4):
+        w.collide(); w.gravity(); w.read_cache(); w.setup()
+        ref.collide(); ref.gravity(); ref.read_cache(); ref.setup()
+        for it in range(scene["params"]["iterations"]):
+            w.apply(1); ref.apply(1)
+            gm, rm = w.get_bodies()["momentum"], ref.bodies()["momentum"]
+            assert P.bits_equal(gm, rm), (step, it)
+            w.set_bodies(momentum=nudge(gm)); ref.set_bodies(momentum=nudge(rm))
+        w.update(); w.write_cache(); w.advance()
+        ref.update(); ref.write_cache(); ref.advance()
+        a, b = w.get_bodies(), ref.bodies()
+        assert P.bits_equal(a["transforms"], b["transforms"]) and P.bits_equal(a["momentum"], b["momentum"]), step
+        ca, cb = w.get_cache(), ref.cache()
+        assert ca["count"] == cb["count"] and P.bits_equal(ca["data"]["impulse"], cb["data"]["impulse"])
+    w.close()
+
+
+@needs_ref
+def test_hub_body_with_a_thousand_contacts_exact_order():
+    """A dynamic tray carrying 306 boxes sits in 1228 contacts.  In the reference's batch scheduler (nudge.cpp:4206-4339) every one of
+    them conflicts with every other, no batch ever fills and the list of open batches grows with the contact count: the replay spills
+    it from LDS to global memory (k_greedy_replay).  Exact order, bit for bit against the reference."""
+    scene = S.tray()
+    w = E.World(scene, flags=EXACT)
+    ref = refworld.RefWorld(scene)
+    w.step(8); ref.step(8)
+    seen = 0
+    for s in range(14):
+        w.step(1); ref.step(1)
+        c = w.counts()
+        assert c["error"] == 0, c
+        seen = max(seen, c["contacts"])
+        a, b = w.get_bodies(), ref.bodies()
+        assert P.bits_equal(a["transforms"], b["transforms"]), s
+        assert P.bits_equal(a["momentum"]["velocity"], b["momentum"]["velocity"]) and P.bits_equal(a["momentum"]["angular_velocity"], b["momentum"]["angular_velocity"]), s
+    assert seen > 1100, seen
+    w.close()
+
+
+def test_second_setup_for_one_collide_is_refused():
+    """include/nudge_hip.h note 8: the solver's inputs are laid out by nh_collide; a second nh_setup_contact_constraints for the same
+    nh_collide returns NH_ERR_STALE_SETUP instead of computing garbage."""
+    scene, _ = G.build("grid30_awake")
+    w = E.World(scene, flags=FAST)
+    w.step(75)
+    w.collide(); w.gravity(); w.read_cache(); w.setup()
+    with pytest.raises(E.NudgeError, match="setup_contact_constraints"):
+        w.setup()
+    w.apply(); w.update(); w.write_cache(); w.advance()
+    w.step(2)
+    assert w.counts()["error"] == 0
+    w.close()
+
+
+def test_pair_capacity_is_independent_of_contact_capacity():
+    """nh_set_pair_capacity: a dense scene holds more overlapping AABB pairs than contacts.  With the default (contact capacity / 2 + 1024)
+    a small contact capacity overflows the pair buffer (reported, not silent); sized from the colliders it runs."""
+    scene = S.ball_pit(12, 12, 12, seed=3)
+    n = 12 ** 3
+    # the settled pit holds 3884 contacts (reference) and at least as many pairs; default pair capacity here: 4608 / 2 + 1024 = 3328
+    w = E.World(scene, flags=FAST, max_contacts=4608, arena_bytes=512 << 20)
+    with pytest.raises(E.NudgeError, match="pair capacity"):
+        w.step(400)
+    w.close()
+    w = E.World(scene, flags=FAST, max_contacts=4608, max_pairs=8 * n)
+    w.step(400)
+    c = w.counts()
+    assert c["error"] == 0 and c["pairs"] > 3328 and 3700 <= c["contacts"] <= 4100, c
+    w.close()
 
 
 # ---- degenerate inputs ------------------------------------------------------------------------------------------------------------
