@@ -346,11 +346,14 @@ __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t 
 
 // `islands`: non-null while some body is asleep -- the coarse islands (nudge.cpp:3575-3650: sets over the broadphase pairs, body 0 ignored) are
 // united right where a pair is found
+// (an edge between two AWAKE bodies cannot change which sets are active -- a set is active iff it holds an awake body, and a path from a sleeping
+// body to an awake one reaches its first awake body over edges that all have a sleeping end -- so only edges with a sleeping end are united:
+// while a few bodies of a million-sphere pile doze off, almost every edge is skipped)
 __device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_t pair_cap, uint64_t ka, const uint64_t* kb_ptr, uint32_t ca, uint32_t cb, bool hit, pair_stage& ps,
-                                          uint32_t* islands, uint32_t body_a, uint32_t body_b) {
+                                          uint32_t* islands, const uint8_t* __restrict__ idle, uint32_t body_a, uint32_t body_b) {
 	unsigned long long bal = __ballot(hit);
 	if (!bal) return;
-	if (hit && islands && body_a && body_b) uf_union(islands, body_a, body_b);
+	if (hit && islands && body_a && body_b && (idle[body_a] == 0xff || idle[body_b] == 0xff)) uf_union(islands, body_a, body_b);
 	if (hit) {
 		uint64_t kb = *kb_ptr;
 		bool a_first = (ka < kb) || (ka == kb && ca < cb);
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
                                                     const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
                                                     const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
                                                     const uint64_t* __restrict__ mkey, const uint64_t* __restrict__ smk, uint2* __restrict__ pairs, uint32_t pair_cap,
-                                                    uint32_t* __restrict__ coarse_parent, uint32_t parity) {
+                                                    uint32_t* __restrict__ coarse_parent, uint32_t parity, const uint8_t* __restrict__ idle) {
 	uint32_t* const islands = st->any_idle[parity] ? coarse_parent : nullptr;
 	const float inv = st->cell_inv;
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 				cb = __float_as_uint(bmax.w); bbody = __float_as_uint(bmin.w);
 				hit = aabb_overlap(amin, amax, bmin, bmax) && (bbody != abody);
 			}
-			emit_pair(st, pairs, pair_cap, ka, smk + cand, ca, cb, hit, ps, islands, abody, bbody);
+			emit_pair(st, pairs, pair_cap, ka, smk + cand, ca, cb, hit, ps, islands, idle, abody, bbody);
 		}
 		// large x larger-indexed large (small x large is found from the large side: k_large_pairs)
 		const bool a_large = valid && key == NH_LARGE_KEY;
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 				uint32_t cb = large_list[l];
 				float4 bmin = aabb_min[cb], bmax = aabb_max[cb];
 				bool hit = a_large && cb > ca && aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != abody);
-				emit_pair(st, pairs, pair_cap, ka, mkey + cb, ca, cb, hit, ps, islands, abody, __float_as_uint(bmin.w));
+				emit_pair(st, pairs, pair_cap, ka, mkey + cb, ca, cb, hit, ps, islands, idle, abody, __float_as_uint(bmin.w));
 			}
 		}
 	}
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ s
                                                      const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
                                                      const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
                                                      const uint64_t* __restrict__ mkey, const uint64_t* __restrict__ smk, uint2* __restrict__ pairs, uint32_t pair_cap,
-                                                    uint32_t* __restrict__ coarse_parent, uint32_t parity) {
+                                                    uint32_t* __restrict__ coarse_parent, uint32_t parity, const uint8_t* __restrict__ idle) {
 	uint32_t* const islands = st->any_idle[parity] ? coarse_parent : nullptr;
 	const float inv = st->cell_inv;
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ s
 					cb = __float_as_uint(bmax.w); bbody = __float_as_uint(bmin.w);
 					hit = aabb_overlap(amin, amax, bmin, bmax) && (bbody != abody);
 				}
-				emit_pair(st, pairs, pair_cap, ka, smk + (have ? cand : 0u), ca, cb, hit, ps, islands, abody, bbody);
+				emit_pair(st, pairs, pair_cap, ka, smk + (have ? cand : 0u), ca, cb, hit, ps, islands, idle, abody, bbody);
 			}
 		}
 	}
@@ -660,20 +663,23 @@ __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t 
 	}
 }
 
-__global__ __launch_bounds__(256) void k_uf_union_records(const nh_DevState* __restrict__ st, const nh_Record* __restrict__ rec, uint32_t* __restrict__ parent, uint32_t parity) {
+__global__ __launch_bounds__(256) void k_uf_union_records(const nh_DevState* __restrict__ st, const nh_Record* __restrict__ rec, uint32_t* __restrict__ parent, uint32_t parity,
+                                                          const uint8_t* __restrict__ idle) {
 	if (!st->any_idle[parity]) return;          // nobody sleeps: every set is active, no need to know the sets
 	uint32_t n = st->records;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		nh_Record r = rec[i];
-		if ((r.count & ~NH_REC_SLEEPING) && r.body_a && r.body_b) uf_union(parent, r.body_a, r.body_b);      // body 0 is the static world (nudge.cpp:3874-3876); pairs dropped at the coarse level have no contacts
+		// body 0 is the static world (nudge.cpp:3874-3876); pairs dropped at the coarse level have no contacts; edges between two awake bodies: see emit_pair
+		if ((r.count & ~NH_REC_SLEEPING) && r.body_a && r.body_b && (idle[r.body_a] == 0xff || idle[r.body_b] == 0xff)) uf_union(parent, r.body_a, r.body_b);
 	}
 }
 
-__global__ __launch_bounds__(256) void k_uf_union_connections(const nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ con, uint32_t ncon, uint32_t* __restrict__ parent, uint32_t parity) {
+__global__ __launch_bounds__(256) void k_uf_union_connections(const nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ con, uint32_t ncon, uint32_t* __restrict__ parent, uint32_t parity,
+                                                              const uint8_t* __restrict__ idle) {
 	if (!st->any_idle[parity]) return;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < ncon; i += gridDim.x * blockDim.x) {
 		nh_BodyPair p = con[i];
-		if (p.a && p.b) uf_union(parent, p.a, p.b);                          // nudge.cpp:3799-3807
+		if (p.a && p.b && (idle[p.a] == 0xff || idle[p.b] == 0xff)) uf_union(parent, p.a, p.b);                          // nudge.cpp:3799-3807
 	}
 }
 
@@ -960,12 +966,12 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_sums, max_cells / CS_TILE, 256, cstart, cscan_sums);
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_final, max_cells / CS_TILE, 256, cstart, cscan_sums, max_cells);
 		NH_LAUNCH(ctx, "cell_scatter", k_cell_scatter, nh_grid_for(C, 256, 2048), 256, st, C, keys_a, vals_a, cstart, aabb_min, aabb_max, keys_b, smin, smax, mkey, smk);
-		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 4096), 256, st, C, keys_b, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap, coarse_parent, ctx->step_parity);
-		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, 2048, 256, st, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap, coarse_parent, ctx->step_parity);
+		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 4096), 256, st, C, keys_b, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, 2048, 256, st, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
 		// coarse islands over the broadphase pairs (united where the pairs were emitted) + connections: only when some body is asleep (a device
 		// flag: the kernels leave at once otherwise)
 		if (body_connections && body_connections->count)
-			NH_LAUNCH(ctx, "uf_union_connections", k_uf_union_connections, nh_grid_for(body_connections->count, 256, 512), 256, st, body_connections->data, body_connections->count, coarse_parent, ctx->step_parity);
+			NH_LAUNCH(ctx, "uf_union_connections", k_uf_union_connections, nh_grid_for(body_connections->count, 256, 512), 256, st, body_connections->data, body_connections->count, coarse_parent, ctx->step_parity, bodies->idle_counters);
 		NH_LAUNCH(ctx, "coarse_flatten", k_uf_flatten, nh_grid_for(B, 256, 512), 256, st, ctx->step_parity, B, coarse_parent, bodies->idle_counters, coarse_active, coarse_root);
 		NH_LAUNCH(ctx, "narrowphase", k_narrowphase, nh_grid_for(pair_cap, 256, 4096), 256, st, pairs, xf, ctag,
 		          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a,
@@ -984,8 +990,8 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		ctx->stream = ctx->side;
 	}
 	if (body_connections && body_connections->count)
-		NH_LAUNCH(ctx, "uf_union_connections", k_uf_union_connections, nh_grid_for(body_connections->count, 256, 2048), 256, st, body_connections->data, body_connections->count, parent, ctx->step_parity);
-	NH_LAUNCH(ctx, "uf_union_records", k_uf_union_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, parent, ctx->step_parity);
+		NH_LAUNCH(ctx, "uf_union_connections", k_uf_union_connections, nh_grid_for(body_connections->count, 256, 2048), 256, st, body_connections->data, body_connections->count, parent, ctx->step_parity, bodies->idle_counters);
+	NH_LAUNCH(ctx, "uf_union_records", k_uf_union_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, parent, ctx->step_parity, bodies->idle_counters);
 	NH_LAUNCH(ctx, "uf_flatten", k_uf_flatten, nh_grid_for(B, 256, 2048), 256, st, ctx->step_parity, B, parent, bodies->idle_counters, set_active, root_of);
 	NH_LAUNCH(ctx, "active_flags", k_active_flags, nh_grid_for(B, 256, 2048), 256, st, ctx->step_parity, B, root_of, set_active, flags);
 	{

@@ -308,24 +308,44 @@ __global__ __launch_bounds__(256) void k_adj_sort(nh_DevState* __restrict__ st, 
 	}
 }
 
-// general contacts: flag, count, level = UNSET
+// general contacts: flag, count, level = UNSET; `general_list` = their indices, ascending.
+// A workgroup owns a contiguous chunk of the contacts: it counts its general contacts, reserves its share of the list with ONE atomic on the
+// global counter (one per wave cost 2 ms for the 12 M contacts of the ball pit: same-address atomics serialise), and fills it in order.
 __global__ __launch_bounds__(256) void k_contact_class(nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, const uint8_t* __restrict__ body_class,
                                                        uint32_t* __restrict__ level, uint32_t* __restrict__ general_list, uint32_t* __restrict__ pred_a, uint32_t* __restrict__ pred_b) {
 	if (!st->has_pending) return;             // every body with contacts is on the one-body path: no general contacts
-	uint32_t n = st->contacts;
-	uint32_t rounded = (n + 63u) & ~63u;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
-		bool general = false;
-		if (i < n) {
-			nh_BodyPair p = bodies[i];
-			general = (p.a && body_class[p.a] == NH_CLS_GENERAL) || (p.b && body_class[p.b] == NH_CLS_GENERAL);
-			level[i] = general ? NH_UNSET : 0u;
-			if (general) { if (!p.a) pred_a[i] = NH_NONE; if (!p.b) pred_b[i] = NH_NONE; }
-		}
-		uint32_t slot = nh_wave_reserve1(&st->general_contacts, general);
-		if (general) general_list[slot] = i;
+	__shared__ uint32_t s_wave[4], s_base;
+	const uint32_t n = st->contacts;
+	const uint32_t chunk = (((n + gridDim.x - 1u) / gridDim.x) + 255u) & ~255u;
+	const uint32_t begin = min(blockIdx.x * chunk, n), end = min(begin + chunk, n);
+	const uint32_t lane = nh_lane(), wave = threadIdx.x >> 6;
+	// pass 1: classify (level[] remembers the verdict), count
+	uint32_t mine = 0;
+	for (uint32_t i = begin + threadIdx.x; i < end; i += 256) {
+		const nh_BodyPair p = bodies[i];
+		const bool general = (p.a && body_class[p.a] == NH_CLS_GENERAL) || (p.b && body_class[p.b] == NH_CLS_GENERAL);
+		level[i] = general ? NH_UNSET : 0u;
+		if (general) { if (!p.a) pred_a[i] = NH_NONE; if (!p.b) pred_b[i] = NH_NONE; ++mine; }
 	}
-
+	for (int d = 32; d >= 1; d >>= 1) mine += (uint32_t)__shfl_xor((int)mine, d);
+	if (lane == 0) s_wave[wave] = mine;
+	__syncthreads();
+	if (threadIdx.x == 0) { const uint32_t total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3]; s_base = total ? atomicAdd(&st->general_contacts, total) : 0u; }
+	__syncthreads();
+	// pass 2: ordered fill (block-uniform trip count; a wave's share of a 256-contact slice follows the shares of the waves before it)
+	uint32_t cursor = s_base;
+	for (uint32_t i0 = begin; i0 < end; i0 += 256) {
+		const uint32_t i = i0 + threadIdx.x;
+		const bool general = i < end && level[i] == NH_UNSET;
+		const unsigned long long bal = __ballot(general);
+		__syncthreads();
+		if (lane == 0) s_wave[wave] = (uint32_t)__popcll(bal);
+		__syncthreads();
+		uint32_t before = 0, total = 0;
+		for (uint32_t w = 0; w < 4; ++w) { if (w < wave) before += s_wave[w]; total += s_wave[w]; }
+		if (general) general_list[cursor + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = i;
+		cursor += total;
+	}
 }
 
 // ---- exact replay of the reference's greedy batch scheduler (nudge.cpp:4206-4339), one wave -------------------
@@ -1179,23 +1199,50 @@ __device__ __forceinline__ void store_vel_m(nh_BodyMomentum* __restrict__ moment
 	reinterpret_cast<float4*>(momentum + i)[1] = make_float4(v.wx, v.wy, v.wz, v.w_unused);
 }
 
+// Rows of the general contacts, in level order.  A contact that qualifies (nh_side_is_radial on both sides: sphere contacts) and is not
+// solved in the reference's exact order gets the 12-float radial row (nh_rowr: chunks 0..2 of its column in `rows4`), flagged in bit 31 of
+// gpair.x; everything else the full 40-float row.
+#define NH_RADIAL_BIT 0x80000000u
+__device__ __forceinline__ void store_rowr_soa(float4* __restrict__ rows4, size_t stride, uint32_t k, const nh_rowr& r) {
+	const float4* src = reinterpret_cast<const float4*>(&r);
+#pragma unroll
+	for (int q = 0; q < 3; ++q) rows4[(size_t)q * stride + k] = src[q];
+}
+
+__device__ __forceinline__ void load_rowr_soa(const float4* __restrict__ rows4, size_t stride, uint32_t k, nh_rowr& r) {
+	float4* dst = reinterpret_cast<float4*>(&r);
+#pragma unroll
+	for (int q = 0; q < 3; ++q) dst[q] = rows4[(size_t)q * stride + k];
+}
+
 __global__ __launch_bounds__(256) void k_rows_general(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ order,
                                                       const nh_Contact* __restrict__ contacts, const nh_BodyPair* __restrict__ bodies,
                                                       const nh_Transform* __restrict__ xf, const nh_BodyProperties* __restrict__ props,
-                                                      float4* __restrict__ rows4, size_t stride, uint2* __restrict__ gpair) {
+                                                      float4* __restrict__ rows4, size_t stride, uint2* __restrict__ gpair, uint32_t allow_radial, uint32_t static_inert) {
 	uint32_t n = st->general_contacts;
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
 		uint32_t c = order[k];
 		nh_BodyPair p = bodies[c];
 		nh_Contact ct = contacts[c];
 		nh_contact_in ci = { ct.position[0], ct.position[1], ct.position[2], ct.penetration, ct.normal[0], ct.normal[1], ct.normal[2], ct.friction };
-		nh_Transform ta = xf[p.a], tb = xf[p.b];
-		nh_inertia IA = body_inertia(xf, props, p.a), IB = body_inertia(xf, props, p.b);
-		nh_row r;
-		nh_build_row(ci, nh_make3(ta.position[0], ta.position[1], ta.position[2]), nh_make3(tb.position[0], tb.position[1], tb.position[2]),
-		             IA, IB, props[p.a].mass_inverse, props[p.b].mass_inverse, r);
-		store_row_soa(rows4, stride, k, r);
-		gpair[k] = make_uint2(p.a, p.b);
+		const float4 ta0 = reinterpret_cast<const float4*>(xf + p.a)[0], tb0 = reinterpret_cast<const float4*>(xf + p.b)[0];
+		const float4 pa = *reinterpret_cast<const float4*>(props + p.a), pb = *reinterpret_cast<const float4*>(props + p.b);
+		const nh_f3 apos = nh_make3(ta0.x, ta0.y, ta0.z), bpos = nh_make3(tb0.x, tb0.y, tb0.z);
+		const bool ia = static_inert && p.a == 0u, ib = static_inert && p.b == 0u;
+		const bool radial = allow_radial &&
+			nh_side_is_radial(ci.px - apos.x, ci.py - apos.y, ci.pz - apos.z, ci.nx, ci.ny, ci.nz, pa.x, pa.y, pa.z, ia) &&
+			nh_side_is_radial(ci.px - bpos.x, ci.py - bpos.y, ci.pz - bpos.z, ci.nx, ci.ny, ci.nz, pb.x, pb.y, pb.z, ib);
+		if (radial) {
+			nh_rowr r;
+			nh_build_rowr(ci, apos, bpos, pa.x, pb.x, pa.w, pb.w, ia, ib, r);
+			store_rowr_soa(rows4, stride, k, r);
+		} else {
+			nh_inertia IA = body_inertia(xf, props, p.a), IB = body_inertia(xf, props, p.b);
+			nh_row r;
+			nh_build_row(ci, apos, bpos, IA, IB, pa.w, pb.w, r);
+			store_row_soa(rows4, stride, k, r);
+		}
+		gpair[k] = make_uint2(p.a | (radial ? NH_RADIAL_BIT : 0u), p.b);
 	}
 }
 
@@ -1205,18 +1252,22 @@ __global__ __launch_bounds__(256) void k_level_exec(const uint32_t* __restrict__
                                                     nh_BodyMomentum* __restrict__ momentum,
                                                     const float4* __restrict__ rows4, size_t stride, float4* __restrict__ gstates) {
 	for (uint32_t k = begin + blockIdx.x * blockDim.x + threadIdx.x; k < end; k += gridDim.x * blockDim.x) {
-		const uint2 p = gpair[k];
+		uint2 p = gpair[k];
+		const bool radial = (p.x & NH_RADIAL_BIT) != 0u;
+		p.x &= ~NH_RADIAL_BIT;
 		nh_vel a = load_vel_m(momentum, p.x), b = load_vel_m(momentum, p.y);
-		nh_row r;
-		load_row_soa(rows4, stride, k, r);
 		nh_state s;
-		if (WARM) {
-			const float4 w = *reinterpret_cast<const float4*>(cached + order[k]);
-			nh_warm_start(r, w.x, w.y, w.z, a, b, s);
+		float4 w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (WARM) w = *reinterpret_cast<const float4*>(cached + order[k]);
+		else { const float4 sv = gstates[k]; s.normal = sv.x; s.friction_x = sv.y; s.friction_y = sv.z; }
+		if (radial) {
+			nh_rowr r;
+			load_rowr_soa(rows4, stride, k, r);
+			if (WARM) nh_warm_start_r(r, w.x, w.y, w.z, a, b, s); else nh_apply_radial(r, s, a, b);
 		} else {
-			float4 sv = gstates[k];
-			s.normal = sv.x; s.friction_x = sv.y; s.friction_y = sv.z;
-			nh_apply_one(r, s, a, b);
+			nh_row r;
+			load_row_soa(rows4, stride, k, r);
+			if (WARM) nh_warm_start(r, w.x, w.y, w.z, a, b, s); else nh_apply_one(r, s, a, b);
 		}
 		gstates[k] = make_float4(s.normal, s.friction_x, s.friction_y, 0.0f);
 		if (p.x) store_vel_m(momentum, p.x, a);      // body 0 is the static world: never written
@@ -1227,17 +1278,25 @@ __global__ __launch_bounds__(256) void k_level_exec(const uint32_t* __restrict__
 // ---- update_cached_impulses (nudge.cpp:4857-4884) --------------------------------------------------------------------------------
 // (contacts on the one-body fast path export their impulse at the end of every nh_apply_impulses call)
 __global__ __launch_bounds__(256) void k_update_impulses(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ order, const float4* __restrict__ rows4, size_t stride,
-                                                         const float4* __restrict__ gstates, nh_CachedContactImpulse* __restrict__ out, const uint32_t* __restrict__ colour) {
+                                                         const float4* __restrict__ gstates, nh_CachedContactImpulse* __restrict__ out, const uint32_t* __restrict__ colour,
+                                                         const uint2* __restrict__ gpair) {
 	// colour != nullptr (default solver order): the contact's colour rides in the spare word of its cached impulse, so that the next
 	// step's colouring can start from it (k_colour_seed)
 	uint32_t n = st->general_contacts;
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-		nh_row r;
-		load_row_soa(rows4, stride, k, r);
 		float4 sv = gstates[k];
 		nh_state s = { sv.x, sv.y, sv.z };
 		float ox, oy, oz;
-		nh_export_impulse(r, s, ox, oy, oz);
+		if (gpair[k].x & NH_RADIAL_BIT) {
+			nh_rowr r;
+			load_rowr_soa(rows4, stride, k, r);
+			nh_export_impulse_r(r, s, ox, oy, oz);
+		} else {
+			// (only n, u, v of the full row are needed: chunks 1..3 hold them)
+			nh_row r;
+			load_row_soa(rows4, stride, k, r);
+			nh_export_impulse(r, s, ox, oy, oz);
+		}
 		const uint32_t c = order[k];
 		*reinterpret_cast<float4*>(out + c) = make_float4(ox, oy, oz, colour ? __uint_as_float(colour[c]) : 0.0f);
 	}
@@ -1462,7 +1521,7 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		// bodies in several pairs or with dynamic partners (piles, pits): general CSR fill + sort + classification, then the counts again
 		NH_LAUNCH(ctx, "adjacency_fill", k_adj_fill, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, contacts->tags, d->body_off, cursor, d->adj, d->body_class);
 		NH_LAUNCH(ctx, "adjacency_sort", k_adj_sort, nh_grid_for(B, 256, 4096), 256, st, B, contacts->bodies, d->body_off, d->adj, slot_key, d->body_class, pred_a, pred_b, bodies->properties, bodies->momentum);
-		NH_LAUNCH(ctx, "contact_class", k_contact_class, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, d->body_class, level, general_list, pred_a, pred_b);
+		NH_LAUNCH(ctx, "contact_class", k_contact_class, nh_grid_for(kcap, 256, 2048), 256, st, contacts->bodies, d->body_class, level, general_list, pred_a, pred_b);
 		rc = nh_read_counts(ctx, &c);
 		if (rc) return rc;
 		if (c.error) return (int)c.error;
@@ -1526,7 +1585,7 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		NH_LAUNCH(ctx, "level_offsets", k_level_offsets, 1, 1024, level_hist, level_cursor);
 		NH_LAUNCH(ctx, "level_scatter", k_level_scatter, nh_grid_for(G, 256, 512), 256, st, general_list, level, level_cursor, d->level_order);
 		NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, d->level_order, contacts->data, contacts->bodies, bodies->transforms, bodies->properties,
-		          (float4*)d->rows, (size_t)kcap, d->gpair);
+		          (float4*)d->rows, (size_t)kcap, d->gpair, (ctx->flags & NH_FLAG_EXACT_ORDER) ? 0u : 1u, d->static_inert ? 1u : 0u);
 		NH_HIP_CHECK(ctx, hipMemcpyAsync(d->level_off, level_hist, sizeof(uint32_t) * (d->levels + 2), hipMemcpyDeviceToHost, ctx->stream));
 		NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 		// warm start in level order (levels are numbered from 1)
@@ -1630,7 +1689,7 @@ extern "C" int nh_update_cached_impulses(nh_context* ctx, nh_ContactConstraintDa
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	if (d->general_contacts)
 		NH_LAUNCH(ctx, "update_impulses", k_update_impulses, nh_grid_for(d->general_contacts, 256, 4096), 256, ctx->d_state, d->level_order, (const float4*)d->rows, (size_t)d->contact_capacity,
-		          (const float4*)d->gstates, imp->data, (ctx->flags & NH_FLAG_EXACT_ORDER) ? (const uint32_t*)nullptr : (const uint32_t*)d->cont.level);
+		          (const float4*)d->gstates, imp->data, (ctx->flags & NH_FLAG_EXACT_ORDER) ? (const uint32_t*)nullptr : (const uint32_t*)d->cont.level, d->gpair);
 	return NH_OK;
 }
 

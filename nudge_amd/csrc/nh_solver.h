@@ -569,6 +569,161 @@ NH_HD void nh_export_impulse1(const nh_row1& r, const nh_state& st, float& ix, f
 	iz = st.normal * r.n_z + st.friction_x * r.u_z + st.friction_y * r.v_z;
 }
 
+// ---- radial forms ------------------------------------------------------------------------------------------------------
+// A contact whose two lever arms are PARALLEL to its normal (p_a = alpha * n, p_b = beta * n) between bodies of ISOTROPIC inverse
+// inertia (k * identity) -- every sphere-sphere contact and every contact of a sphere with the inert static world: the ball pit of
+// config 4.  With those two facts the 39-float row collapses algebraically (nh_build_row, term by term):
+//     na = nb = 0                          (p x n = 0)               => normal_velocity_to_normal_impulse = -1 / (1/m_a + 1/m_b)
+//     ua = k_a alpha v, va = -k_a alpha u, ub = -k_b beta v, vb = k_b beta u     (n x u = -v, n x v = u for v = u x n)
+//     friction_coefficient_x = _y = 1/m_a + 1/m_b + k_a alpha^2 + k_b beta^2,   friction_coefficient_z = 0
+// so a row is 12 floats (48 B) instead of 40 and the tangent frame is recomputed from n exactly as nh_build_row computes it.  The
+// level / colour scheduled path streams rows from HBM once per sweep, and 16 sweeps over 12 M contacts is what config 4 costs.
+// These are the SAME formulas evaluated with exact zeros dropped and the isotropic inertia applied as a scalar; they round
+// differently from the general forms in the last bits (k * (p x u) instead of a 3x3 product whose off-diagonal terms are ~1e-8 k), so
+// they are used only in the default (colour-ordered) sweep -- already a different Gauss-Seidel order than the reference's --
+// never under NH_FLAG_EXACT_ORDER.  tests/test_cpu_oracle.py::test_radial_forms_agree_with_general_forms bounds the difference.
+struct nh_rowr {
+	float n_x, n_y, n_z, bias;
+	float alpha, beta, normal_velocity_to_normal_impulse, friction_coefficient;
+	float c_a, c_b, friction, pad;        // c_a = k_a * alpha, c_b = k_b * beta
+};
+
+// the smoothly varying tangent basis of nh_build_row (nudge.cpp:4445-4456)
+NH_HD void nh_tangents(float nx, float ny, float nz, nh_f3& u, nh_f3& v) {
+	float s = nh_abs(nx);
+	float u_x = nz * s;
+	float u_y = u_x - nz;
+	float u_z = nh_madd(nx - ny, s, ny);
+	u_x = nh_neg(u_x);
+	float f = nh_rsqrt(u_x * u_x + u_y * u_y + u_z * u_z);
+	u_x *= f; u_y *= f; u_z *= f;
+	u = nh_make3(u_x, u_y, u_z);
+	v = nh_make3(u_y * nz - u_z * ny, u_z * nx - u_x * nz, u_x * ny - u_y * nx);
+}
+
+// Is side `p` (lever arm of a body with inverse inertia diag(ix, iy, iz)) radial?  `inert`: the body is the inert static world,
+// whose lever arm never matters.  The perpendicular part of a sphere's lever arm is rounding noise of (contact point - centre):
+// anything below 1e-3 of the arm counts as parallel (and is dropped).
+NH_HD bool nh_side_is_radial(float px, float py, float pz, float nx, float ny, float nz, float ix, float iy, float iz, bool inert) {
+	if (inert) return true;
+	if (!(nh_asuint(ix) == nh_asuint(iy) && nh_asuint(iy) == nh_asuint(iz))) return false;
+	float cx = py * nz - pz * ny, cy = pz * nx - px * nz, cz = px * ny - py * nx;
+	return cx * cx + cy * cy + cz * cz <= 1e-6f * (px * px + py * py + pz * pz);
+}
+
+NH_HD void nh_build_rowr(const nh_contact_in& c, nh_f3 apos, nh_f3 bpos, float k_a, float k_b, float a_mass_inverse, float b_mass_inverse,
+                         bool a_inert, bool b_inert, nh_rowr& r) {
+	float alpha = a_inert ? 0.0f : (c.px - apos.x) * c.nx + (c.py - apos.y) * c.ny + (c.pz - apos.z) * c.nz;
+	float beta = b_inert ? 0.0f : (c.px - bpos.x) * c.nx + (c.py - bpos.y) * c.ny + (c.pz - bpos.z) * c.nz;
+	float mass_inverse = a_mass_inverse + b_mass_inverse;
+	bool nonzero = (mass_inverse < 0.0f) || (mass_inverse > 0.0f);
+	float nvtni = nonzero ? (-1.0f / mass_inverse) : 0.0f;
+	r.n_x = c.nx; r.n_y = c.ny; r.n_z = c.nz;
+	r.bias = (-NH_BIAS_FACTOR) * nh_max(c.penetration - NH_ALLOWED_PENETRATION, 0.0f) * nvtni;
+	r.alpha = alpha; r.beta = beta;
+	r.normal_velocity_to_normal_impulse = nvtni;
+	r.friction_coefficient = mass_inverse + k_a * alpha * alpha + k_b * beta * beta;
+	r.c_a = k_a * alpha; r.c_b = k_b * beta;
+	r.friction = c.friction; r.pad = 0.0f;
+}
+
+NH_HD void nh_warm_start_r(const nh_rowr& r, float cix, float ciy, float ciz, nh_vel& a, nh_vel& b, nh_state& st) {
+	nh_f3 u, v;
+	nh_tangents(r.n_x, r.n_y, r.n_z, u, v);
+	float normal_impulse = nh_max(r.n_x * cix + r.n_y * ciy + r.n_z * ciz, 0.0f);
+	float max_friction_impulse = normal_impulse * r.friction;
+	float fx = u.x * cix + u.y * ciy + u.z * ciz;
+	float fy = v.x * cix + v.y * ciy + v.z * ciz;
+	float scale = fx * fx + fy * fy;
+	scale = nh_rsqrt(scale);
+	scale = scale * max_friction_impulse;
+	scale = nh_min(1.0f, scale);
+	fx = fx * scale;
+	fy = fy * scale;
+	float lx = fx * u.x + fy * v.x + r.n_x * normal_impulse;
+	float ly = fx * u.y + fy * v.y + r.n_y * normal_impulse;
+	float lz = fx * u.z + fy * v.z + r.n_z * normal_impulse;
+	float wx = fx * v.x - fy * u.x, wy = fx * v.y - fy * u.y, wz = fx * v.z - fy * u.z;
+	a.vx -= lx * a.mass_inverse; a.vy -= ly * a.mass_inverse; a.vz -= lz * a.mass_inverse;
+	a.wx += r.c_a * wx; a.wy += r.c_a * wy; a.wz += r.c_a * wz;
+	b.vx += lx * b.mass_inverse; b.vy += ly * b.mass_inverse; b.vz += lz * b.mass_inverse;
+	b.wx -= r.c_b * wx; b.wy -= r.c_b * wy; b.wz -= r.c_b * wz;
+	st.normal = normal_impulse; st.friction_x = fx; st.friction_y = fy;
+}
+
+// nh_apply_one for a radial row: p_a = alpha n, p_b = beta n  =>  w x p = s (w x n)
+NH_HD void nh_apply_radial(const nh_rowr& r, nh_state& st, nh_vel& a, nh_vel& b) {
+	nh_f3 u, v;
+	nh_tangents(r.n_x, r.n_y, r.n_z, u, v);
+	// relative velocity of the contact point: (v_b + w_b x p_b) - (v_a + w_a x p_a)
+	float dwx = r.beta * b.wx - r.alpha * a.wx, dwy = r.beta * b.wy - r.alpha * a.wy, dwz = r.beta * b.wz - r.alpha * a.wz;
+	float v_x = (b.vx - a.vx) + (dwy * r.n_z - dwz * r.n_y);
+	float v_y = (b.vy - a.vy) + (dwz * r.n_x - dwx * r.n_z);
+	float v_z = (b.vz - a.vz) + (dwx * r.n_y - dwy * r.n_x);
+
+	float t_z = nh_madd(r.n_z, v_z, nh_madd(r.n_y, v_y, r.n_x * v_x));
+	float t_x = nh_madd(v_z, u.z, nh_madd(v_y, u.y, v_x * u.x));
+	float t_y = nh_madd(v_z, v.z, nh_madd(v_y, v.y, v_x * v.x));
+
+	float old_normal_impulse = st.normal;
+	float normal_impulse = nh_madd(r.normal_velocity_to_normal_impulse, t_z, r.bias + old_normal_impulse);
+	float t_xx = t_x * t_x, t_yy = t_y * t_y;
+	float tl2 = t_xx + t_yy;
+	normal_impulse = nh_max(normal_impulse, 0.0f);
+	t_x *= tl2;
+	t_y *= tl2;
+	st.normal = normal_impulse;
+	float max_friction_impulse = normal_impulse * r.friction;
+	normal_impulse = normal_impulse - old_normal_impulse;
+
+	float friction_factor = nh_madd(t_yy, r.friction_coefficient, t_xx * r.friction_coefficient);
+	friction_factor = nh_recip(friction_factor);
+	friction_factor = nh_min(1e+6f, friction_factor);
+
+	float old_fx = st.friction_x, old_fy = st.friction_y;
+	float fx = old_fx - t_x * friction_factor;
+	float fy = old_fy - t_y * friction_factor;
+	float clamp = nh_rsqrt(fx * fx + fy * fy);
+	clamp = clamp * max_friction_impulse;
+	clamp = nh_min(1.0f, clamp);
+	fx = fx * clamp;
+	fy = fy * clamp;
+	st.friction_x = fx;
+	st.friction_y = fy;
+	fx -= old_fx;
+	fy -= old_fy;
+
+	float lx = nh_madd(v.x, fy, nh_madd(u.x, fx, r.n_x * normal_impulse));
+	float ly = nh_madd(v.y, fy, nh_madd(u.y, fx, r.n_y * normal_impulse));
+	float lz = nh_madd(v.z, fy, nh_madd(u.z, fx, r.n_z * normal_impulse));
+	float wx = fx * v.x - fy * u.x, wy = fx * v.y - fy * u.y, wz = fx * v.z - fy * u.z;
+
+	float a_mass_inverse_neg = nh_neg(a.mass_inverse);
+	a.vx = nh_madd(lx, a_mass_inverse_neg, a.vx);
+	a.vy = nh_madd(ly, a_mass_inverse_neg, a.vy);
+	a.vz = nh_madd(lz, a_mass_inverse_neg, a.vz);
+	a.wx = nh_madd(r.c_a, wx, a.wx);
+	a.wy = nh_madd(r.c_a, wy, a.wy);
+	a.wz = nh_madd(r.c_a, wz, a.wz);
+	a.w_unused = 0.0f;
+	b.vx = nh_madd(lx, b.mass_inverse, b.vx);
+	b.vy = nh_madd(ly, b.mass_inverse, b.vy);
+	b.vz = nh_madd(lz, b.mass_inverse, b.vz);
+	float c_b_neg = nh_neg(r.c_b);
+	b.wx = nh_madd(c_b_neg, wx, b.wx);
+	b.wy = nh_madd(c_b_neg, wy, b.wy);
+	b.wz = nh_madd(c_b_neg, wz, b.wz);
+	b.w_unused = 0.0f;
+}
+
+NH_HD void nh_export_impulse_r(const nh_rowr& r, const nh_state& st, float& ix, float& iy, float& iz) {
+	nh_f3 u, v;
+	nh_tangents(r.n_x, r.n_y, r.n_z, u, v);
+	ix = st.normal * r.n_x + st.friction_x * u.x + st.friction_y * v.x;
+	iy = st.normal * r.n_y + st.friction_x * u.y + st.friction_y * v.y;
+	iz = st.normal * r.n_z + st.friction_x * u.z + st.friction_y * v.z;
+}
+
 // true iff body 0 qualifies as S above (all bits zero)
 NH_HD bool nh_is_inert(const float* velocity, const float* angular_velocity, const float* inertia_inverse, float mass_inverse) {
 	uint32_t acc = nh_asuint(mass_inverse);

@@ -396,8 +396,16 @@ __global__ __launch_bounds__(256) void bk_count(const uint64_t* __restrict__ key
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t nbits = 32u - (uint32_t)__clz(nb);             // bucket ids are < 2^nbits
-	const uint32_t rounded = (n + 63u) & ~63u;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
+	// Arrival ranks.  Lanes of a wave that share a bucket find each other by ballots; the groups of the workgroup's four waves then meet in
+	// a small LDS table (open addressing on the bucket id), so that ONE global atomic per bucket and 256-record slice hands out the ranks --
+	// when records arrive in key order (a settled ball pit: tag order follows the lattice, and so do the broadphase cells) every wave
+	// of the machine otherwise queues up on the same few counters, and same-address atomics are ~12 ns each, serialised.  A full table
+	// (records arriving in scattered order: many buckets per slice) falls back to one global atomic per group.
+	constexpr uint32_t TAB = 32u, EMPTY = 0xFFFFFFFFu;
+	__shared__ uint32_t t_key[TAB], t_cnt[TAB], t_base[TAB];
+	const uint32_t rounded = (n + 255u) & ~255u;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {       // block-uniform trip count
+		if (threadIdx.x < TAB) { t_key[threadIdx.x] = EMPTY; t_cnt[threadIdx.x] = 0u; }
 		const bool valid = i < n;
 		const uint64_t key = valid ? keys[i] : 0ull;
 		uint32_t lo = 0, hi = nblocks;                     // bucket = number of splitters <= key
@@ -410,21 +418,30 @@ __global__ __launch_bounds__(256) void bk_count(const uint64_t* __restrict__ key
 			lo = f0;
 		}
 		const uint32_t b = lo;
-		// neighbouring records usually share a bucket (and arrive in waves that hammer the same few counters): lanes with equal
-		// buckets find each other by ballots over the bucket bits, and the lowest lane of every group does ONE atomic for it
 		unsigned long long m = __ballot(valid);
 		for (uint32_t bit = 0; bit < nbits; ++bit) {
 			const unsigned long long bal = __ballot((b >> bit) & 1u);
 			m &= ((b >> bit) & 1u) ? bal : ~bal;
 		}
-		uint32_t rank = 0;
-		{
-			const int leader = valid ? __ffsll((long long)m) - 1 : (int)lane;
-			uint32_t base = 0;
-			if (valid && (int)lane == leader) base = atomicAdd(&counts[b], (uint32_t)__popcll(m));
-			base = (uint32_t)__shfl((int)base, leader);
-			rank = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+		const int leader = valid ? __ffsll((long long)m) - 1 : (int)lane;
+		const bool is_leader = valid && (int)lane == leader;
+		const uint32_t group = (uint32_t)__popcll(m);
+		__syncthreads();                                   // the table is clear
+		uint32_t slot = EMPTY, off = 0;
+		if (is_leader) {
+			uint32_t h = (b * 2654435761u) >> 27;          // 5 bits
+			for (uint32_t probe = 0; probe < TAB; ++probe, h = (h + 1u) & (TAB - 1u)) {
+				const uint32_t old = atomicCAS(&t_key[h], EMPTY, b);
+				if (old == EMPTY || old == b) { slot = h; break; }
+			}
+			if (slot != EMPTY) off = atomicAdd(&t_cnt[slot], group);
+			else off = atomicAdd(&counts[b], group);           // table full: straight to the global counter
 		}
+		__syncthreads();
+		if (threadIdx.x < TAB && t_key[threadIdx.x] != EMPTY) t_base[threadIdx.x] = atomicAdd(&counts[t_key[threadIdx.x]], t_cnt[threadIdx.x]);
+		__syncthreads();
+		if (is_leader && slot != EMPTY) off += t_base[slot];
+		const uint32_t rank = (uint32_t)__shfl((int)off, leader) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 		if (valid) place[i] = make_uint2(b, rank);
 	}
 }

@@ -216,6 +216,59 @@ int hs_solve_one_body(uint32_t nbodies, const Xf* body_xf, const float* props, f
 	return taken;
 }
 
+// Same solve with RADIAL rows (nh_rowr, nh_solver.h) wherever a contact qualifies (both lever arms parallel to the normal, isotropic
+// inertia, or the inert static world): what the colour-scheduled GPU sweeps of the default solver order run.  Returns how many did.
+int hs_solve_radial(uint32_t nbodies, const Xf* body_xf, const float* props, float* momentum,
+                    uint32_t ncontacts, const float* contacts, const uint32_t* bodies, const float* cached,
+                    uint32_t norder, const uint32_t* order, uint32_t iterations, float* out_impulses) {
+	const bool inert0 = nh_is_inert(momentum, momentum + 4, props, props[3]);
+	std::vector<nh_row> rows(ncontacts);
+	std::vector<nh_rowr> rowsr(ncontacts);
+	std::vector<uint8_t> radial(ncontacts, 0);
+	std::vector<nh_state> st(ncontacts);
+	std::vector<uint32_t> seq;
+	std::vector<uint8_t> seen(ncontacts, 0);
+	for (uint32_t i = 0; i < norder; ++i) { uint32_t c = order[i]; if (!seen[c]) { seen[c] = 1; seq.push_back(c); } }
+	for (uint32_t i = 0; i < nbodies; ++i) momentum[8*i+3] = props[4*i+3];
+	auto load = [&](uint32_t b) { nh_vel v; memcpy(&v, momentum + 8*b, 32); return v; };
+	auto store = [&](uint32_t b, const nh_vel& v) { memcpy(momentum + 8*b, &v, 32); };
+	int taken = 0;
+	for (uint32_t c : seq) {
+		uint32_t a = bodies[2*c], b = bodies[2*c+1];
+		nh_contact_in ci; memcpy(&ci, contacts + 8*c, 32);
+		nh_f3 pa = nh_make3(body_xf[a].p[0], body_xf[a].p[1], body_xf[a].p[2]), pb = nh_make3(body_xf[b].p[0], body_xf[b].p[1], body_xf[b].p[2]);
+		const bool ia = inert0 && a == 0, ib = inert0 && b == 0;
+		radial[c] = nh_side_is_radial(ci.px - pa.x, ci.py - pa.y, ci.pz - pa.z, ci.nx, ci.ny, ci.nz, props[4*a], props[4*a+1], props[4*a+2], ia) &&
+		            nh_side_is_radial(ci.px - pb.x, ci.py - pb.y, ci.pz - pb.z, ci.nx, ci.ny, ci.nz, props[4*b], props[4*b+1], props[4*b+2], ib);
+		nh_vel va = load(a), vb = load(b);
+		if (radial[c]) {
+			nh_build_rowr(ci, pa, pb, props[4*a], props[4*b], props[4*a+3], props[4*b+3], ia, ib, rowsr[c]);
+			nh_warm_start_r(rowsr[c], cached[4*c], cached[4*c+1], cached[4*c+2], va, vb, st[c]);
+			++taken;
+		} else {
+			nh_quat qa = { body_xf[a].q[0], body_xf[a].q[1], body_xf[a].q[2], body_xf[a].q[3] };
+			nh_quat qb = { body_xf[b].q[0], body_xf[b].q[1], body_xf[b].q[2], body_xf[b].q[3] };
+			nh_build_row(ci, pa, pb, nh_world_inertia(qa, props[4*a], props[4*a+1], props[4*a+2]), nh_world_inertia(qb, props[4*b], props[4*b+1], props[4*b+2]),
+			             props[4*a+3], props[4*b+3], rows[c]);
+			nh_warm_start(rows[c], cached[4*c], cached[4*c+1], cached[4*c+2], va, vb, st[c]);
+		}
+		store(a, va); store(b, vb);
+	}
+	for (uint32_t it = 0; it < iterations; ++it)
+		for (uint32_t c : seq) {
+			uint32_t a = bodies[2*c], b = bodies[2*c+1];
+			nh_vel va = load(a), vb = load(b);
+			if (radial[c]) nh_apply_radial(rowsr[c], st[c], va, vb); else nh_apply_one(rows[c], st[c], va, vb);
+			store(a, va); store(b, vb);
+		}
+	for (uint32_t c = 0; c < ncontacts; ++c) {
+		if (!seen[c]) continue;
+		if (radial[c]) nh_export_impulse_r(rowsr[c], st[c], out_impulses[4*c], out_impulses[4*c+1], out_impulses[4*c+2]);
+		else nh_export_impulse(rows[c], st[c], out_impulses[4*c], out_impulses[4*c+1], out_impulses[4*c+2]);
+	}
+	return taken;
+}
+
 void hs_advance(uint32_t nactive, const uint32_t* active, Xf* body_xf, const float* momentum, uint8_t* idle, float dt) {
 	for (uint32_t n = 0; n < nactive; ++n) {
 		uint32_t i = active[n];

@@ -52,20 +52,21 @@ def narrow_tags(keys, features):
     return ((a | (b << np.uint64(16))) << np.uint64(32)) | features.astype(np.uint64)
 
 
-def solve(body_transforms, props, momentum, contacts, bodies, cached, order, iterations, one_body=False):
-    """`one_body`: contacts against body 0 use the one-body forms of nh_solver.h (what the fused GPU kernel runs)."""
+def solve(body_transforms, props, momentum, contacts, bodies, cached, order, iterations, one_body=False, radial=False):
+    """`one_body`: contacts against body 0 use the one-body forms of nh_solver.h (what the fused GPU kernel runs);
+    `radial`: contacts that qualify use the radial 12-float rows (the colour-scheduled sweeps of the default order)."""
     L = lib()
     mom = np.ascontiguousarray(momentum).copy()
     n = len(contacts)
     out = np.zeros(n, dtype=S.IMPULSE)
     order = np.ascontiguousarray(order, dtype=np.uint32)
     bodies = np.ascontiguousarray(bodies, dtype=np.uint32)
-    fn = L.hs_solve_one_body if one_body else L.hs_solve
+    fn = L.hs_solve_radial if radial else (L.hs_solve_one_body if one_body else L.hs_solve)
     fn.restype = C.c_int
     taken = fn(C.c_uint32(len(body_transforms)), _p(np.ascontiguousarray(body_transforms)), _p(np.ascontiguousarray(props)), _p(mom),
                C.c_uint32(n), _p(np.ascontiguousarray(contacts)), _p(bodies), _p(np.ascontiguousarray(cached)),
                C.c_uint32(len(order)), _p(order), C.c_uint32(iterations), _p(out))
-    if one_body:
+    if one_body or radial:
         return mom, out, taken
     return mom, out
 

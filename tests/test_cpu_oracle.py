@@ -152,6 +152,35 @@ def test_one_body_forms_equal_general_forms(name, warms):
 
 
 @needs_ref
+@pytest.mark.parametrize("name,warm,expect", [("pit6", 150, 1.0), ("mixed20", 80, 0.19), ("pile_mixed", 400, 0.1), ("pile256", 350, 0.0)])
+def test_radial_forms_agree_with_general_forms(name, warm, expect):
+    """The colour-scheduled sweeps of the DEFAULT solver order use 12-float radial rows for sphere contacts (nh_rowr, nh_solver.h): the
+    reference's formulas with exact zeros dropped and the isotropic inertia applied as a scalar.  In the reference's own contact order, one
+    full solve (setup + warm start + all sweeps) must agree with the reference to rounding: velocities within 2e-5 absolute (a few ulp of
+    the ~10 units/s these bodies move at), exported impulses within 1e-4 relative.  Box contacts never qualify (expect 0.0)."""
+    scene, _ = G.build(name)
+    p = scene["params"]
+    w = refworld.RefWorld(scene)
+    w.step(warm)
+    w.collide(); w.gravity(); w.read_cache()
+    c, cached, b1 = w.contacts(), w.contact_impulses(), w.bodies()
+    w.setup()
+    order = w.solver_order().reshape(-1)
+    w.apply(); w.update()
+    b2 = w.bodies()
+    mom, out, taken = H.solve(b1["transforms"], scene["body_properties"], b1["momentum"], c["data"], c["bodies"], cached, order, p["iterations"], radial=True)
+    assert c["count"] > 0 and taken >= expect * c["count"] and (expect > 0 or taken == 0), (taken, c["count"])
+    dv = np.abs(mom["velocity"] - b2["momentum"]["velocity"]).max()
+    dw = np.abs(mom["angular_velocity"] - b2["momentum"]["angular_velocity"]).max()
+    ref_imp = w.contact_impulses()["impulse"]
+    di = np.abs(out["impulse"] - ref_imp).max() / max(1e-6, np.abs(ref_imp).max())
+    print(f"\n{name}: {taken} of {c['count']} contacts radial; max |dv| {dv:.2e}, |dw| {dw:.2e}, relative impulse difference {di:.2e}")
+    assert dv <= 2e-5 and dw <= 2e-4 and di <= 1e-4, (dv, dw, di)
+    if taken == 0:
+        assert P.bits_equal(mom["velocity"], b2["momentum"]["velocity"])
+
+
+@needs_ref
 def test_closed_form_solver_order_equals_reference_scheduler_on_drop_scenes():
     """batch(i) = (i/128)*16 + i%16 is what nudge.cpp:4206-4339 produces when no lane conflicts occur."""
     for scene, warm in ((S.grid_tiles(1, side=30), 70), (S.grid_tiles(1, side=40, sphere_fraction=0.5), 70)):
