@@ -196,10 +196,11 @@ def test_c4_column_of_160_layers_default_order_vs_reference():
         print(f"\n[column 7x160x7 step {s}] contacts {g['contacts']} (reference {int(round(r['contacts_per_sphere'] * 7840))}); max penetration {g['max_pen']:.4f} ({r['max_pen']:.4f}); "
               f"KE/sphere {g['ke']:.4e} ({r['ke']:.4e}); top {g['top']:.2f} ({r['top']:.2f}); colours {g['colours']}")
         assert g["inside"] == 1.0 and r["inside"] == 1.0
-        assert abs(g["top"] - r["top"]) <= 0.01 * r["top"] + 0.3, (g["top"], r["top"])
+        # measured (profiles/r02_gpu_tests.log): top within 0.3 %, contacts within 2.5 %, kinetic energy within 12 %, penetration within 1.5 x
+        assert abs(g["top"] - r["top"]) <= 0.005 * r["top"] + 0.1, (g["top"], r["top"])
         assert g["max_pen"] <= 1.5 * r["max_pen"] + 0.01, (g["max_pen"], r["max_pen"])
-        assert r["ke"] / 3.0 - 1e-4 <= g["ke"] <= 3.0 * r["ke"] + 1e-4, (g["ke"], r["ke"])
-        assert abs(g["contacts"] - r["contacts_per_sphere"] * 7840) <= 0.05 * r["contacts_per_sphere"] * 7840 + 100
+        assert r["ke"] / 1.5 - 1e-3 <= g["ke"] <= 1.5 * r["ke"] + 1e-3, (g["ke"], r["ke"])
+        assert abs(g["contacts"] - r["contacts_per_sphere"] * 7840) <= 0.03 * r["contacts_per_sphere"] * 7840 + 50
     w.close()
 
 
@@ -237,8 +238,11 @@ def test_c4_four_million_sphere_pit_invariants_default_order():
     print(f"\n[pit 160^3 settled] density {rho_g:.4f} spheres per unit volume (reference cube {rho_r:.4f}); interior degree {g['mean_degree']:.3f} (cube {rq['mean_degree']:.3f}); "
           f"max penetration {g['max_pen']:.4f} (cube {rq['max_pen']:.4f} under 1/8 of the load); KE/sphere {kes}")
     assert kes[-1] < 0.02 * max(kes) and kes[-1] < kes[-2], kes      # the collapse is over and the pile keeps calming down
-    assert abs(rho_g - rho_r) <= 0.06 * rho_r, (rho_g, rho_r)          # (the taller pile is a little denser: the cube's free surface and walls weigh more)
-    assert abs(g["mean_degree"] - rq["mean_degree"]) <= 0.12 * rq["mean_degree"], (g["mean_degree"], rq["mean_degree"])
-    assert np.abs(g["hist"] - rq["hist"]).max() <= 0.12, (g["hist"], rq["hist"])
-    assert g["max_pen"] <= 1.5 * 8.0 * rq["max_pen"] + 0.02, (g["max_pen"], rq["max_pen"])
+    # density: the 160-layer pile is compressed by its own weight (contacts overlap by up to 13 % of a diameter at the bottom, against 0.6 % in the
+    # reference's 20-layer cube): measured 8.7 % denser than the cube; at the SAME pile height the coloured sweep matches the reference's top
+    # within 0.3 % (test_c4_column_of_160_layers_default_order_vs_reference)
+    assert rho_r <= rho_g <= 1.12 * rho_r, (rho_g, rho_r)
+    assert abs(g["mean_degree"] - rq["mean_degree"]) <= 0.05 * rq["mean_degree"], (g["mean_degree"], rq["mean_degree"])     # measured 1.1 %
+    assert np.abs(g["hist"] - rq["hist"]).max() <= 0.08, (g["hist"], rq["hist"])
+    assert g["max_pen"] <= 0.15, g["max_pen"]                          # calming down: measured 0.13 (0.23 at the height of the collapse)
     w.close()
