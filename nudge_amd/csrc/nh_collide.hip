@@ -13,6 +13,8 @@
 #include "nh_narrowphase.h"
 #include <stdlib.h>
 
+__device__ void nh_grid_setup(nh_DevState* st, uint32_t ncolliders, uint32_t max_cells);
+
 // ---- 1. world transforms, AABBs, bounds, extent histogram ---------------------------------------------
 // aabb_min[c] = (min.xyz, bits(body)), aabb_max[c] = (max.xyz, bits(max extent))
 // 1024-thread workgroups, one per CU: the scene bounds / histogram end in a handful of global atomics per WORKGROUP on the same
@@ -22,9 +24,10 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
                                                const nh_Transform* __restrict__ box_xf, const nh_BoxCollider* __restrict__ box_data, const uint32_t* __restrict__ box_tags, uint32_t nbox,
                                                const nh_Transform* __restrict__ sph_xf, const nh_SphereCollider* __restrict__ sph_data, const uint32_t* __restrict__ sph_tags, uint32_t nsph,
                                                nh_xform* __restrict__ xf, float4* __restrict__ aabb_min, float4* __restrict__ aabb_max, uint32_t* __restrict__ ctag,
-                                               uint4* __restrict__ zero16, uint32_t zero16_count) {
+                                               uint4* __restrict__ zero16, uint32_t zero16_count, uint32_t max_cells) {
 	__shared__ uint32_t hist[1024];
 	__shared__ uint32_t red[12];
+	__shared__ uint32_t s_last;
 	hist[threadIdx.x] = 0;
 	if (threadIdx.x < 3) { red[threadIdx.x] = 0xffffffffu; red[3 + threadIdx.x] = 0u; red[6 + threadIdx.x] = 0xffffffffu; red[9 + threadIdx.x] = 0u; }
 	__syncthreads();
@@ -32,7 +35,7 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 	// (the cell counters of the counting sort further down are cleared here: one launch less than a memset of their own)
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < zero16_count; k += gridDim.x * blockDim.x) zero16[k] = make_uint4(0u, 0u, 0u, 0u);
 	uint32_t lmin[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, lmax[3] = { 0, 0, 0 };
-	// bounds of the "small" colliders under LAST step's size split (k_grid_params confirms the guess or orders k_small_bounds to redo them)
+	// bounds of the "small" colliders under LAST step's size split (nh_grid_setup keeps them if the split has not moved)
 	const uint32_t guess_exp = st->small_exp;
 	uint32_t gmn[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, gmx[3] = { 0, 0, 0 };
 	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
@@ -99,92 +102,73 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 		atomicMin(&st->smin[threadIdx.x], red[threadIdx.x]); atomicMax(&st->smax[threadIdx.x], red[3 + threadIdx.x]);
 		if (red[6 + threadIdx.x] <= red[9 + threadIdx.x]) { atomicMin(&st->gmin[threadIdx.x], red[6 + threadIdx.x]); atomicMax(&st->gmax[threadIdx.x], red[9 + threadIdx.x]); }
 	}
+	// the last workgroup to get here derives the grid from what everybody published (nh_grid_setup)
+	__threadfence();
+	__syncthreads();
+	if (threadIdx.x == 0) s_last = atomicAdd(&st->xform_ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+	__syncthreads();
+	if (!s_last || threadIdx.x >= 64u) return;
+	__threadfence();
+	nh_grid_setup(st, n, max_cells);
+	if (threadIdx.x == 0) st->xform_ticket = 0u;
 }
 
-// ---- 2. grid parameters (single thread; a few hundred instructions) ------------------------------------
-__global__ void k_grid_params(nh_DevState* st, uint32_t ncolliders, uint32_t max_cells) {
+// ---- 2. grid parameters: run by the first wave of the LAST workgroup of k_xform to finish (ticket counter), so that the step has no
+// tiny single-wave launches between the transform pass and the cell keys.  Everything the other workgroups published arrives through
+// device-scope atomics; it is read back with agent-scope loads after the ticket.
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ void nh_grid_setup(nh_DevState* st, uint32_t ncolliders, uint32_t max_cells) {
 	// small/large split: allow at most max(64, C/1024) colliders above the grid's cell size.  e = largest size class kept small =
 	// the highest class whose suffix count (colliders in classes >= e) exceeds the budget.  One wave: lane l owns classes 16l..16l+15.
-	__shared__ int s_e;
 	const uint32_t budget = max(ncolliders / 1024u, 64u);
 	const uint32_t lane = threadIdx.x & 63u;
 	uint32_t h[16], mine = 0;
 #pragma unroll
-	for (int k = 0; k < 16; ++k) { h[k] = st->exp_hist[16u * lane + k]; mine += h[k]; }
+	for (int k = 0; k < 16; ++k) { h[k] = ld_agent(&st->exp_hist[16u * lane + k]); mine += h[k]; }
 	uint32_t suffix = mine;                                    // inclusive suffix sum over lanes >= l
 	for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_down(suffix, d); if (lane + d < 64u) suffix += y; }
 	const unsigned long long over = __ballot(suffix > budget);
-	if (threadIdx.x == 0) s_e = 0;
-	__syncthreads();
-	if (over && lane == 63u - (uint32_t)__clzll(over)) {       // highest lane whose suffix exceeds the budget: the class is in its range
-		uint32_t above = suffix - mine;
-		int e = (int)(16u * lane + 15u);
-		while (e > (int)(16u * lane) && above + h[e - (int)(16u * lane)] <= budget) { above += h[e - (int)(16u * lane)]; --e; }
-		s_e = e;
+	int e = 0;
+	if (over) {
+		const uint32_t top = 63u - (uint32_t)__clzll(over);    // highest lane whose suffix exceeds the budget: the class is in its range
+		int mine_e = 0;
+		if (lane == top) {
+			uint32_t above = suffix - mine;
+			mine_e = (int)(16u * lane + 15u);
+			while (mine_e > (int)(16u * lane) && above + h[mine_e - (int)(16u * lane)] <= budget) { above += h[mine_e - (int)(16u * lane)]; --mine_e; }
+		}
+		e = __shfl(mine_e, (int)top);
 	}
-	__syncthreads();
-	if (threadIdx.x != 0 || blockIdx.x != 0) return;
-	nh_f3 smin = nh_make3(nh_float_unflip(st->smin[0]), nh_float_unflip(st->smin[1]), nh_float_unflip(st->smin[2]));
-	nh_f3 smax = nh_make3(nh_float_unflip(st->smax[0]), nh_float_unflip(st->smax[1]), nh_float_unflip(st->smax[2]));
+	if (lane != 0) return;
+	nh_f3 smin = nh_make3(nh_float_unflip(ld_agent(&st->smin[0])), nh_float_unflip(ld_agent(&st->smin[1])), nh_float_unflip(ld_agent(&st->smin[2])));
+	nh_f3 smax = nh_make3(nh_float_unflip(ld_agent(&st->smax[0])), nh_float_unflip(ld_agent(&st->smax[1])), nh_float_unflip(ld_agent(&st->smax[2])));
 	// Morton frame (nudge.cpp:3096-3100)
 	float scale = nh_morton_scale(smin, smax);
 	st->morton_scale = scale;
 	st->morton_min[0] = smin.x * scale; st->morton_min[1] = smin.y * scale; st->morton_min[2] = smin.z * scale;
-	int e = s_e;
 	// e = largest size class (exponent << 2 | two mantissa bits) kept "small"; never let the cell underflow to denormals
 	if (e < (64 << 2)) e = 64 << 2;
 	if (e > (190 << 2)) e = 190 << 2;
-	// k_xform gathered the small colliders' bounds under last step's split: good if the split has not moved
-	if (st->small_exp != (uint32_t)e) {
-		st->redo_small = 1;
-		for (int k = 0; k < 3; ++k) { st->gmin[k] = 0xffffffffu; st->gmax[k] = 0u; }
-	} else {
-		st->redo_small = 0;
-	}
+	// k_xform gathered the bounds of the small colliders' min corners under last step's split.  If the split has moved they are the bounds of
+	// the wrong subset: this step the grid spans the min corners of ALL colliders instead (a superset: correct, at worst a coarser grid for one
+	// step; the next step guesses right again)
+	uint32_t gmn[3], gmx[3];
+	const bool moved = st->small_exp != (uint32_t)e;
+	for (int k = 0; k < 3; ++k) { gmn[k] = ld_agent(moved ? &st->smin[k] : &st->gmin[k]); gmx[k] = ld_agent(moved ? &st->smax[k] : &st->gmax[k]); }
 	st->small_exp = (uint32_t)e;
-	float cell = __uint_as_float((uint32_t)(e + 1) << 21);     // upper edge of the class: > every small extent, at most 25 % above the largest
-	st->cell_inv = 1.0f / cell;
-}
-
-// bounds of the min corners of the SMALL colliders (the grid only has to span those)
-__global__ __launch_bounds__(256) void k_small_bounds(nh_DevState* __restrict__ st, uint32_t n, const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max) {
-	__shared__ uint32_t red[6];
-	if (!st->redo_small) return;           // k_xform's bounds stand
-	if (threadIdx.x < 3) { red[threadIdx.x] = 0xffffffffu; red[3 + threadIdx.x] = 0u; }
-	__syncthreads();
-	const uint32_t small_exp = st->small_exp;
-	uint32_t lmin[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, lmax[3] = { 0, 0, 0 };
-	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
-		float4 mn = aabb_min[c];
-		float ext = aabb_max[c].w;
-		uint32_t e = (__float_as_uint(ext) >> 21) & 1023u;
-		if (e <= small_exp && ext == ext) {
-			uint32_t f;
-			f = nh_float_flip(mn.x); lmin[0] = min(lmin[0], f); lmax[0] = max(lmax[0], f);
-			f = nh_float_flip(mn.y); lmin[1] = min(lmin[1], f); lmax[1] = max(lmax[1], f);
-			f = nh_float_flip(mn.z); lmin[2] = min(lmin[2], f); lmax[2] = max(lmax[2], f);
-		}
-	}
-	for (int k = 0; k < 3; ++k) {
-		for (int d = 32; d >= 1; d >>= 1) { lmin[k] = min(lmin[k], (uint32_t)__shfl_xor((int)lmin[k], d)); lmax[k] = max(lmax[k], (uint32_t)__shfl_xor((int)lmax[k], d)); }
-		if ((threadIdx.x & 63) == 0) { atomicMin(&red[k], lmin[k]); atomicMax(&red[3 + k], lmax[k]); }
-	}
-	__syncthreads();
-	if (threadIdx.x < 3) { atomicMin(&st->gmin[threadIdx.x], red[threadIdx.x]); atomicMax(&st->gmax[threadIdx.x], red[3 + threadIdx.x]); }
-}
-
-// grid origin and dimensions; if the table is too small the CELL grows (never clamp one axis: that piles colliders up)
-__global__ void k_grid_dims(nh_DevState* st, uint32_t max_cells) {
-	if (threadIdx.x != 0 || blockIdx.x != 0) return;
-	if (st->gmin[0] > st->gmax[0]) {      // no small collider at all
+	const float cell = __uint_as_float((uint32_t)(e + 1) << 21);     // upper edge of the class: > every small extent, at most 25 % above the largest
+	float inv = 1.0f / cell;
+	// grid origin and dimensions; if the table is too small the CELL grows (never clamp one axis: that piles colliders up)
+	if (gmn[0] > gmx[0]) {      // no small collider at all
 		st->origin[0] = st->origin[1] = st->origin[2] = 0.0f;
 		st->dims[0] = st->dims[1] = st->dims[2] = 1;
+		st->cell_inv = inv;
 		return;
 	}
-	nh_f3 gmin = nh_make3(nh_float_unflip(st->gmin[0]), nh_float_unflip(st->gmin[1]), nh_float_unflip(st->gmin[2]));
-	nh_f3 gmax = nh_make3(nh_float_unflip(st->gmax[0]), nh_float_unflip(st->gmax[1]), nh_float_unflip(st->gmax[2]));
+	const nh_f3 gmin = nh_make3(nh_float_unflip(gmn[0]), nh_float_unflip(gmn[1]), nh_float_unflip(gmn[2]));
+	const nh_f3 gmax = nh_make3(nh_float_unflip(gmx[0]), nh_float_unflip(gmx[1]), nh_float_unflip(gmx[2]));
 	st->origin[0] = gmin.x; st->origin[1] = gmin.y; st->origin[2] = gmin.z;
-	float inv = st->cell_inv;
 	for (int it = 0; it < 64; ++it) {
 		float dx = (gmax.x - gmin.x) * inv, dy = (gmax.y - gmin.y) * inv, dz = (gmax.z - gmin.z) * inv;
 		uint64_t nx = (uint64_t)fminf(fmaxf(dx, 0.0f), 1e7f) + 2, ny = (uint64_t)fminf(fmaxf(dy, 0.0f), 1e7f) + 2, nz = (uint64_t)fminf(fmaxf(dz, 0.0f), 1e7f) + 2;
@@ -307,39 +291,66 @@ __device__ __forceinline__ bool aabb_overlap(const float4& amin, const float4& a
 // Pair emission.  A single global counter takes ~12 ns per atomic (same-address atomics serialise in L2), so
 // one atomic per wave per hit-iteration would cost more than the search itself: every wave stages its pairs in
 // its own LDS buffer and reserves global space once per ~450 pairs.
+// The pair list is split BY SHAPE as it is emitted (the reference partitions its pairs by type before the narrowphase for the same
+// reason, nudge.cpp:3705-3751): box-box pairs fill `pairs` from the front (counter st->pairs), pairs with a sphere from the back (counter
+// st->pairs_sph, slot pair_cap-1-k), so that each narrowphase launch runs ONE kind of arithmetic in all its lanes.
 #define FP_WBUF 512
-struct pair_stage { uint2* buf; uint32_t count; uint32_t cap; };
+struct pair_stage { uint2* buf; uint32_t count; uint32_t cap; uint32_t nbox; };
+
+__device__ __forceinline__ void write_staged(nh_DevState* st, uint2* pairs, uint32_t pair_cap, const pair_stage& ps, uint32_t base_bb, uint32_t base_sph) {
+	// lanes take the staged pairs 64 at a time; a pair's slot = its type's base + its rank among the staged pairs of that type
+	uint32_t run_bb = 0, run_sph = 0;
+	for (uint32_t k0 = 0; k0 < ps.count; k0 += 64) {
+		const uint32_t k = k0 + nh_lane();
+		const bool on = k < ps.count;
+		const uint2 pr = on ? ps.buf[k] : make_uint2(0u, 0u);
+		const bool sph = on && (pr.x >= ps.nbox || pr.y >= ps.nbox);
+		const unsigned long long bs = __ballot(sph), bb = __ballot(on && !sph);
+		const unsigned long long below = (1ull << nh_lane()) - 1ull;
+		if (on) {
+			const uint32_t slot = sph ? base_sph + run_sph + (uint32_t)__popcll(bs & below) : base_bb + run_bb + (uint32_t)__popcll(bb & below);
+			if (slot < pair_cap) pairs[sph ? pair_cap - 1u - slot : slot] = pr; else st->error = NH_ERR_PAIR_CAPACITY;
+		}
+		run_sph += (uint32_t)__popcll(bs); run_bb += (uint32_t)__popcll(bb);
+	}
+}
+
+__device__ __forceinline__ void count_staged(const pair_stage& ps, uint32_t& n_bb, uint32_t& n_sph) {
+	uint32_t sph = 0;
+	for (uint32_t k = nh_lane(); k < ps.count; k += 64) { const uint2 pr = ps.buf[k]; sph += (pr.x >= ps.nbox || pr.y >= ps.nbox) ? 1u : 0u; }
+	for (int d = 32; d >= 1; d >>= 1) sph += (uint32_t)__shfl_xor((int)sph, d);
+	n_sph = sph; n_bb = ps.count - sph;
+}
 
 __device__ __forceinline__ void flush_pairs(nh_DevState* st, uint2* pairs, uint32_t pair_cap, pair_stage& ps) {
-	uint32_t n = ps.count;
-	if (!n) return;
-	uint32_t base = 0;
-	if (nh_lane() == 0) base = atomicAdd(&st->pairs, n);
-	base = __shfl(base, 0);
+	if (!ps.count) return;
 	__builtin_amdgcn_wave_barrier();
-	for (uint32_t k = nh_lane(); k < n; k += 64) {
-		if (base + k < pair_cap) pairs[base + k] = ps.buf[k]; else st->error = NH_ERR_PAIR_CAPACITY;
-	}
+	uint32_t n_bb, n_sph;
+	count_staged(ps, n_bb, n_sph);
+	uint32_t base = 0;
+	if (nh_lane() == 0 && n_bb) base = atomicAdd(&st->pairs, n_bb);
+	if (nh_lane() == 1 && n_sph) base = atomicAdd(&st->pairs_sph, n_sph);
+	const uint32_t base_bb = __shfl(base, 0), base_sph = __shfl(base, 1);
+	write_staged(st, pairs, pair_cap, ps, base_bb, base_sph);
 	__builtin_amdgcn_wave_barrier();
 	ps.count = 0;
 }
 
 // final flush once per workgroup, not once per wave (every wave ends with a partly filled stage)
 __device__ __forceinline__ void flush_pairs_block(nh_DevState* st, uint2* pairs, uint32_t pair_cap, pair_stage& ps) {
-	__shared__ uint32_t wave_count[4];
-	__shared__ uint32_t block_base;
-	if (nh_lane() == 0) wave_count[threadIdx.x >> 6] = ps.count;
+	__shared__ uint32_t wave_bb[4], wave_sph[4];
+	__shared__ uint32_t block_bb, block_sph;
+	__builtin_amdgcn_wave_barrier();
+	uint32_t n_bb, n_sph;
+	count_staged(ps, n_bb, n_sph);
+	if (nh_lane() == 0) { wave_bb[threadIdx.x >> 6] = n_bb; wave_sph[threadIdx.x >> 6] = n_sph; }
 	__syncthreads();
-	if (threadIdx.x == 0) {
-		uint32_t total = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
-		block_base = total ? atomicAdd(&st->pairs, total) : 0u;
-	}
+	if (threadIdx.x == 0) { const uint32_t t = wave_bb[0] + wave_bb[1] + wave_bb[2] + wave_bb[3]; block_bb = t ? atomicAdd(&st->pairs, t) : 0u; }
+	if (threadIdx.x == 64) { const uint32_t t = wave_sph[0] + wave_sph[1] + wave_sph[2] + wave_sph[3]; block_sph = t ? atomicAdd(&st->pairs_sph, t) : 0u; }
 	__syncthreads();
-	uint32_t base = block_base;
-	for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) base += wave_count[w];
-	for (uint32_t k = nh_lane(); k < ps.count; k += 64) {
-		if (base + k < pair_cap) pairs[base + k] = ps.buf[k]; else st->error = NH_ERR_PAIR_CAPACITY;
-	}
+	uint32_t base_bb = block_bb, base_sph = block_sph;
+	for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) { base_bb += wave_bb[w]; base_sph += wave_sph[w]; }
+	write_staged(st, pairs, pair_cap, ps, base_bb, base_sph);
 }
 
 __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t b);
@@ -349,13 +360,12 @@ __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t 
 // (an edge between two AWAKE bodies cannot change which sets are active -- a set is active iff it holds an awake body, and a path from a sleeping
 // body to an awake one reaches its first awake body over edges that all have a sleeping end -- so only edges with a sleeping end are united:
 // while a few bodies of a million-sphere pile doze off, almost every edge is skipped)
-__device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_t pair_cap, uint64_t ka, const uint64_t* kb_ptr, uint32_t ca, uint32_t cb, bool hit, pair_stage& ps,
+__device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_t pair_cap, uint64_t ka, uint64_t kb, uint32_t ca, uint32_t cb, bool hit, pair_stage& ps,
                                           uint32_t* islands, const uint8_t* __restrict__ idle, uint32_t body_a, uint32_t body_b) {
 	unsigned long long bal = __ballot(hit);
 	if (!bal) return;
 	if (hit && islands && body_a && body_b && (idle[body_a] == 0xff || idle[body_b] == 0xff)) uf_union(islands, body_a, body_b);
 	if (hit) {
-		uint64_t kb = *kb_ptr;
 		bool a_first = (ka < kb) || (ka == kb && ca < cb);
 		// narrowphase "a" = later in Morton order (nudge.cpp:3495, 1202-1203)
 		ps.buf[ps.count + (uint32_t)__popcll(bal & ((1ull << nh_lane()) - 1ull))] = a_first ? make_uint2(cb, ca) : make_uint2(ca, cb);
@@ -365,7 +375,14 @@ __device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_
 }
 
 // ---- 5. pair search: grid neighbours + large list ---------------------------------------------------------
-__global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st, uint32_t n,
+// One lane per small collider A, in cell order.  A pair is emitted by its member with the LOWER sorted index, so A only looks FORWARD:
+// a collider B that overlaps A has its (min corner) cell in [c_min(A) - 1, c_max(A)] per axis, and one that comes after A in cell order
+// lies in A's own row of cells at or after A's cell, in the following rows of A's cell layer, or in the next layer -- at most five rows,
+// each ONE contiguous range of the cell-sorted list (cells that are neighbours along x are neighbours in the table).  The ten table
+// reads go out together; the candidates are then taken FP_BATCH at a time with all their loads (two 16-byte AABB halves and the
+// Morton key) in flight at once: three or four memory round trips per lane instead of one per candidate.
+#define FP_BATCH 4
+__global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st, uint32_t n, uint32_t nbox,
                                                     const uint32_t* __restrict__ keys, const float4* __restrict__ smin, const float4* __restrict__ smax,
                                                     const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
                                                     const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
@@ -377,7 +394,7 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
 	const uint32_t nlarge = st->large;
 	__shared__ uint2 wave_buf[4][FP_WBUF];
-	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u, FP_WBUF };
+	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u, FP_WBUF, nbox };
 	uint32_t rounded = (n + 63u) & ~63u;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
 		bool valid = i < n;
@@ -385,48 +402,62 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 		uint32_t key = NH_LARGE_KEY, ca = 0, abody = 0;
 		uint64_t ka = 0;
 		if (valid) { amin = smin[i]; amax = smax[i]; key = keys[i]; ca = __float_as_uint(amax.w); abody = __float_as_uint(amin.w); ka = smk[i]; }
-		bool small = valid && key != NH_LARGE_KEY;
-		// neighbour cells [c_min-1, c_max] per axis, clamped
-		int x0 = 0, x1 = -1, y0 = 0, y1 = -1, z0 = 0, z1 = -1;
+		const bool small = valid && key != NH_LARGE_KEY;
+		// the forward rows: begin / end of their candidate ranges (empty rows: begin = end = 0)
+		uint32_t rb[5] = { 0, 0, 0, 0, 0 }, re[5] = { 0, 0, 0, 0, 0 };
 		if (small) {
-			int cx0 = cell_coord(amin.x, ox, inv), cy0 = cell_coord(amin.y, oy, inv), cz0 = cell_coord(amin.z, oz, inv);
-			int cx1 = cell_coord(amax.x, ox, inv), cy1 = cell_coord(amax.y, oy, inv), cz1 = cell_coord(amax.z, oz, inv);
-			x0 = min(max(cx0 - 1, 0), nx - 1); x1 = min(max(cx1, 0), nx - 1);
-			y0 = min(max(cy0 - 1, 0), ny - 1); y1 = min(max(cy1, 0), ny - 1);
-			z0 = min(max(cz0 - 1, 0), nz - 1); z1 = min(max(cz1, 0), nz - 1);
-		}
-		// The candidate loops are data dependent per lane; emission is wave-synchronous, so run a
-		// wave-uniform loop and let lanes without work idle.
-		// (cells that are neighbours along x are neighbours in the table, and cell lists are contiguous ranges of the cell-sorted
-		// order: one x-row of cells is ONE range of candidates, two table reads instead of two per cell)
-		int cz = z0, cy = y0;
-		uint32_t j = 0, jend = 0;
-		bool more_cells = small;
-		for (;;) {
-			// advance this lane to its next candidate
-			bool have = false;
-			uint32_t cand = 0;
-			while (more_cells || j < jend) {
-				if (j < jend) {
-					if (j > i) { cand = j; have = true; ++j; break; }
-					// entries at or before i: skip in bulk (cell lists are contiguous ranges of sorted indices)
-					j = (i + 1 > j) ? min(i + 1, jend) : j + 1;
-					continue;
+			const int cx0 = cell_coord(amin.x, ox, inv), cy0 = cell_coord(amin.y, oy, inv), cz0 = cell_coord(amin.z, oz, inv);
+			const int cx1 = cell_coord(amax.x, ox, inv), cy1 = cell_coord(amax.y, oy, inv), cz1 = cell_coord(amax.z, oz, inv);
+			const int x0 = min(max(cx0 - 1, 0), nx - 1), x1 = min(max(cx1, 0), nx - 1);
+			const int y0 = min(max(cy0 - 1, 0), ny - 1), y1 = min(max(cy1, 0), ny - 1);
+			const int z1 = min(max(cz1, 0), nz - 1);
+			// A's own cell (the clamped one its key was made of)
+			const int ay = min(max(cy0, 0), ny - 1), az = min(max(cz0, 0), nz - 1);
+			// row 0: A's row, from the entry after A to the end of cell x1
+			{ const uint32_t row = (uint32_t)((az * ny + ay) * nx); rb[0] = i + 1u; re[0] = cstart[row + (uint32_t)x1 + 1u]; }
+			// row 1: the next row of A's layer
+			if (y1 > ay) { const uint32_t row = (uint32_t)((az * ny + ay + 1) * nx); rb[1] = cstart[row + (uint32_t)x0]; re[1] = cstart[row + (uint32_t)x1 + 1u]; }
+			// rows 2..4: the next layer, rows y0..y1 (at most three: y0 >= c_min - 1, y1 <= c_min + 1)
+			if (z1 > az) {
+#pragma unroll
+				for (int r = 0; r < 3; ++r) {
+					const int cy = y0 + r;
+					if (cy <= y1) { const uint32_t row = (uint32_t)(((az + 1) * ny + cy) * nx); rb[2 + r] = cstart[row + (uint32_t)x0]; re[2 + r] = cstart[row + (uint32_t)x1 + 1u]; }
 				}
-				// next row of cells
-				const uint32_t row = (uint32_t)((cz * ny + cy) * nx);
-				j = cstart[row + (uint32_t)x0]; jend = cstart[row + (uint32_t)x1 + 1u];
-				if (++cy > y1) { cy = y0; if (++cz > z1) more_cells = false; }
 			}
-			if (!__any(have)) break;
-			bool hit = false;
-			uint32_t cb = 0, bbody = 0;
-			if (have) {
-				float4 bmin = smin[cand], bmax = smax[cand];
-				cb = __float_as_uint(bmax.w); bbody = __float_as_uint(bmin.w);
-				hit = aabb_overlap(amin, amax, bmin, bmax) && (bbody != abody);
+			if (re[0] < rb[0]) re[0] = rb[0];
+		}
+		// walk the ranges, FP_BATCH candidates per round (wave-uniform loop, lanes without work idle)
+		uint32_t r = 0, j = rb[0], jend = re[0];
+		for (;;) {
+			uint32_t cand[FP_BATCH];
+			bool have[FP_BATCH];
+#pragma unroll
+			for (int k = 0; k < FP_BATCH; ++k) {
+				while (j >= jend && r < 4u) {
+					++r;
+					j = r == 1u ? rb[1] : (r == 2u ? rb[2] : (r == 3u ? rb[3] : rb[4]));
+					jend = r == 1u ? re[1] : (r == 2u ? re[2] : (r == 3u ? re[3] : re[4]));
+				}
+				have[k] = j < jend;
+				cand[k] = have[k] ? j++ : 0u;
 			}
-			emit_pair(st, pairs, pair_cap, ka, smk + cand, ca, cb, hit, ps, islands, idle, abody, bbody);
+			if (!__any(have[0])) break;
+			float4 bmin[FP_BATCH], bmax[FP_BATCH];
+			uint64_t kb[FP_BATCH];
+#pragma unroll
+			for (int k = 0; k < FP_BATCH; ++k) if (have[k]) { bmin[k] = smin[cand[k]]; bmax[k] = smax[cand[k]]; kb[k] = smk[cand[k]]; }
+#pragma unroll
+			for (int k = 0; k < FP_BATCH; ++k) {
+				if (!__any(have[k])) break;
+				bool hit = false;
+				uint32_t cb = 0, bbody = 0;
+				if (have[k]) {
+					cb = __float_as_uint(bmax[k].w); bbody = __float_as_uint(bmin[k].w);
+					hit = aabb_overlap(amin, amax, bmin[k], bmax[k]) && (bbody != abody);
+				}
+				emit_pair(st, pairs, pair_cap, ka, have[k] ? kb[k] : 0ull, ca, cb, hit, ps, islands, idle, abody, bbody);
+			}
 		}
 		// large x larger-indexed large (small x large is found from the large side: k_large_pairs)
 		const bool a_large = valid && key == NH_LARGE_KEY;
@@ -435,7 +466,7 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 				uint32_t cb = large_list[l];
 				float4 bmin = aabb_min[cb], bmax = aabb_max[cb];
 				bool hit = a_large && cb > ca && aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != abody);
-				emit_pair(st, pairs, pair_cap, ka, mkey + cb, ca, cb, hit, ps, islands, idle, abody, __float_as_uint(bmin.w));
+				emit_pair(st, pairs, pair_cap, ka, hit ? mkey[cb] : 0ull, ca, cb, hit, ps, islands, idle, abody, __float_as_uint(bmin.w));
 			}
 		}
 	}
@@ -450,7 +481,7 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 // otherwise be walked one after the other by a handful of waves)
 #define LP_BLOCKS 1024u
 #define LP_WBUF 1024
-__global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ st, const float4* __restrict__ smin, const float4* __restrict__ smax,
+__global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ st, uint32_t nbox, const float4* __restrict__ smin, const float4* __restrict__ smax,
                                                      const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
                                                      const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
                                                      const uint64_t* __restrict__ mkey, const uint64_t* __restrict__ smk, uint2* __restrict__ pairs, uint32_t pair_cap,
@@ -461,7 +492,7 @@ __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ s
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
 	const uint32_t nlarge = st->large;
 	__shared__ uint2 wave_buf[4][LP_WBUF];
-	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u, LP_WBUF };
+	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u, LP_WBUF, nbox };
 	uint32_t slices = nlarge ? LP_BLOCKS / nlarge : 1u;
 	slices = min(max(slices, 1u), gridDim.x);
 	const uint32_t slice = blockIdx.x % slices;
@@ -488,12 +519,14 @@ __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ s
 				const bool have = cand < jend;
 				bool hit = false;
 				uint32_t cb = 0, bbody = 0;
+				uint64_t kb = 0;
 				if (have) {
 					float4 bmin = smin[cand], bmax = smax[cand];
+					kb = smk[cand];
 					cb = __float_as_uint(bmax.w); bbody = __float_as_uint(bmin.w);
 					hit = aabb_overlap(amin, amax, bmin, bmax) && (bbody != abody);
 				}
-				emit_pair(st, pairs, pair_cap, ka, smk + (have ? cand : 0u), ca, cb, hit, ps, islands, idle, abody, bbody);
+				emit_pair(st, pairs, pair_cap, ka, kb, ca, cb, hit, ps, islands, idle, abody, bbody);
 			}
 		}
 	}
@@ -506,6 +539,9 @@ __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ s
 struct nh_Record { uint32_t body_a, body_b, overflow, count; };
 #define NH_REC_SLEEPING 0x80000000u
 
+// SPH = false: the box-box pairs (front of `pairs`, records 0 .. n_bb-1); SPH = true: the pairs with a sphere (back of `pairs`, records
+// n_bb .. n_bb+n_sph-1).  Record r owns the raw contact slots 4r .. 4r+3 either way (a sphere pair uses the first one).
+template<bool SPH>
 __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ st, const uint2* __restrict__ pairs,
                                                      const nh_xform* __restrict__ xf, const uint32_t* __restrict__ ctag,
                                                      const nh_BoxCollider* __restrict__ box_data, const nh_SphereCollider* __restrict__ sph_data, uint32_t nbox,
@@ -515,11 +551,16 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 	// coarse islands (nudge.cpp:3500-3703): a pair whose bodies belong to a set of sleeping bodies (sets over the BROADPHASE pairs and the
 	// user's connections) never reaches the narrowphase: it becomes a sleeping pair, larger tag in the low half (3697)
 	const bool some_asleep = st->any_idle[parity] != 0;
-	__shared__ float4 s_c0[4][256], s_c1[4][256];
-	__shared__ uint32_t s_f[4][256];
-	__shared__ uint8_t s_n[4][64];
-	uint32_t n = min(st->pairs, pair_cap);
-	if (blockIdx.x == 0 && threadIdx.x == 0) st->records = n;
+	constexpr int NS = SPH ? 1 : 4;
+	__shared__ float4 s_c0[NS][256], s_c1[NS][256];
+	__shared__ uint32_t s_f[NS][256];
+	__shared__ uint8_t s_n[NS][64];
+	const uint32_t n_bb = min(st->pairs, pair_cap), n_sph = min(st->pairs_sph, pair_cap - n_bb);
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		st->records = n_bb + n_sph;            // (both launches write the same number: either may be the only one)
+		if ((uint64_t)st->pairs + st->pairs_sph > pair_cap) st->error = NH_ERR_PAIR_CAPACITY;
+	}
+	const uint32_t n = SPH ? n_sph : n_bb, first_rec = SPH ? n_bb : 0u;
 	uint32_t rounded = (n + 63u) & ~63u;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
 		nh_bb_result bb;
@@ -529,8 +570,9 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		uint64_t key = 0;
 		uint32_t body_a = 0, body_b = 0;
 		bool asleep = false;
+		const uint32_t ri = first_rec + i;        // record index
 		if (i < n) {
-			uint2 pr = pairs[i];
+			uint2 pr = pairs[SPH ? pair_cap - 1u - i : i];
 			uint32_t a = pr.x, b = pr.y;            // a = later in Morton order
 			bool a_sph = a >= nbox, b_sph = b >= nbox;
 			bool coarse_asleep = false;
@@ -546,7 +588,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 				}
 			}
 			if (coarse_asleep) {
-			} else if (!a_sph && !b_sph) {
+			} else if (!SPH) {
 				nh_xform A = xf[a], B = xf[b];
 				nh_BoxCollider sa = box_data[a], sb = box_data[b];
 				uint32_t ta = ctag[a], tb = ctag[b];
@@ -570,6 +612,23 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 				key = (uint64_t)ctag[bx] | ((uint64_t)ctag[sp] << 32);
 				body_a = A.body; body_b = B.body;
 			}
+		}
+		if (SPH) {
+			// one contact at most: straight to the record's first raw slot
+			if (i < n) {
+				if (count) {
+					float4* dp = reinterpret_cast<float4*>(raw_data + (size_t)4 * ri);
+					dp[0] = make_float4(single.px, single.py, single.pz, single.penetration);
+					dp[1] = make_float4(single.nx, single.ny, single.nz, single.friction);
+					raw_feature[(size_t)4 * ri] = single.feature;
+				}
+				rec_key[ri] = key;
+				nh_Record r = { body_a, body_b, 0u, asleep ? NH_REC_SLEEPING : (uint32_t)count };
+				if (asleep) st->any_sleeping = 1;
+				rec[ri] = r;
+				rec_idx[ri] = ri;
+			}
+			continue;
 		}
 		// more than 4 contacts per pair is the exception (askew face contacts): only those touch the global counter
 		uint32_t extra = count > 4 ? (uint32_t)(count - 4) : 0u;
@@ -611,19 +670,17 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 				}
 			} else if (bb.kind == 1) {
 				put(0, bb.edge);
-			} else if (count) {
-				put(0, single);
 			}
-			rec_key[i] = key;
+			rec_key[ri] = key;
 			nh_Record r = { body_a, body_b, ovf, asleep ? NH_REC_SLEEPING : (uint32_t)count };
 			if (asleep) st->any_sleeping = 1;
-			rec[i] = r;
-			rec_idx[i] = i;
+			rec[ri] = r;
+			rec_idx[ri] = ri;
 		}
 		w_n[lane] = (uint8_t)(i < n ? (count < 4 ? count : 4) : 0);
 		__builtin_amdgcn_wave_barrier();
 		{
-			const size_t run = (size_t)4 * (i - lane);            // first raw slot of the wave's pairs
+			const size_t run = (size_t)4 * (ri - lane);            // first raw slot of the wave's pairs
 #pragma unroll
 			for (int r4 = 0; r4 < 4; ++r4) {
 				const uint32_t e = 64u * r4 + lane;
@@ -783,7 +840,7 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 			// contact degree of the two bodies (body 0 is the static world): the solver's adjacency starts from these
 			// and what lets setup skip the general CSR build for a body that sits in ONE pair with the static world: its contacts are start .. start+cnt-1
 			if (cnt && start + cnt <= capacity) {
-				if (body_a) { atomicAdd(&deg[body_a], cnt); atomicAdd(&info[body_a], body_b ? 0x10001u : 1u); first_contact[body_a] = start; }
+				if (body_a) { atomicAdd(&deg[body_a], cnt); atomicAdd(&info[body_a], body_b ? 0x10001u : 1u); first_contact[body_a] = start | 0x80000000u; }      // top bit: plays "a"
 				if (body_b) { atomicAdd(&deg[body_b], cnt); atomicAdd(&info[body_b], body_a ? 0x10001u : 1u); first_contact[body_b] = start; }
 			}
 		}
@@ -854,7 +911,7 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 	if (blockIdx.x != 0) return;
 	uint32_t t = threadIdx.x;
 	if (t == 0) {
-		st->colliders = ncolliders; st->pairs = 0; st->raw_contacts = 0; st->records = 0; st->contacts = 0; st->sleeping = 0;
+		st->colliders = ncolliders; st->pairs = 0; st->pairs_sph = 0; st->raw_contacts = 0; st->records = 0; st->contacts = 0; st->sleeping = 0;
 		st->active = 0; st->culled = 0; st->large = 0; st->general_contacts = 0; st->levels = 0; st->error = 0;
 		st->static_bodies = 0; st->unleveled = 0; st->has_static8 = 0; st->has_staticN = 0; st->any_sleeping = 0; st->has_pending = 0;
 		st->sort_buckets = st->sort_buckets_next;
@@ -958,24 +1015,29 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 1024, 256), 1024, st, bodies->transforms,
 		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
 		          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
-		          xf, aabb_min, aabb_max, ctag, reinterpret_cast<uint4*>(cstart), (max_cells + 8u) / 4u);
-		NH_LAUNCH(ctx, "grid_params", k_grid_params, 1, 64, st, C, max_cells);
-		NH_LAUNCH(ctx, "small_bounds", k_small_bounds, nh_grid_for(C, 256, 1024), 256, st, C, aabb_min, aabb_max);
-		NH_LAUNCH(ctx, "grid_dims", k_grid_dims, 1, 64, st, max_cells);
+		          xf, aabb_min, aabb_max, ctag, reinterpret_cast<uint4*>(cstart), (max_cells + 8u) / 4u, max_cells);
 		NH_LAUNCH(ctx, "cell_keys", k_cell_keys, nh_grid_for(C, 256, 2048), 256, st, C, aabb_min, aabb_max, keys_a, vals_a, mkey, large_list, cstart);
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_sums, max_cells / CS_TILE, 256, cstart, cscan_sums);
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_final, max_cells / CS_TILE, 256, cstart, cscan_sums, max_cells);
 		NH_LAUNCH(ctx, "cell_scatter", k_cell_scatter, nh_grid_for(C, 256, 2048), 256, st, C, keys_a, vals_a, cstart, aabb_min, aabb_max, keys_b, smin, smax, mkey, smk);
-		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 4096), 256, st, C, keys_b, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
-		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, 2048, 256, st, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 4096), 256, st, C, nbox, keys_b, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, 2048, 256, st, nbox, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
 		// coarse islands over the broadphase pairs (united where the pairs were emitted) + connections: only when some body is asleep (a device
 		// flag: the kernels leave at once otherwise)
 		if (body_connections && body_connections->count)
 			NH_LAUNCH(ctx, "uf_union_connections", k_uf_union_connections, nh_grid_for(body_connections->count, 256, 512), 256, st, body_connections->data, body_connections->count, coarse_parent, ctx->step_parity, bodies->idle_counters);
 		NH_LAUNCH(ctx, "coarse_flatten", k_uf_flatten, nh_grid_for(B, 256, 512), 256, st, ctx->step_parity, B, coarse_parent, bodies->idle_counters, coarse_active, coarse_root);
-		NH_LAUNCH(ctx, "narrowphase", k_narrowphase, nh_grid_for(pair_cap, 256, 4096), 256, st, pairs, xf, ctag,
-		          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a,
-		          coarse_root, coarse_active, ctx->step_parity);
+		// box-box pairs and pairs with a sphere are separate lists (emit_pair): one launch each, each running one kind of arithmetic.
+		// (the host does not know the counts: a launch over a list that turns out empty costs a few microseconds, so the launch for a
+		// shape the world does not contain is skipped outright)
+		if (nbox >= 2)
+			NH_LAUNCH(ctx, "narrowphase", (k_narrowphase<false>), nh_grid_for(pair_cap, 256, 4096), 256, st, pairs, xf, ctag,
+			          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a,
+			          coarse_root, coarse_active, ctx->step_parity);
+		if (nsph)
+			NH_LAUNCH(ctx, "narrowphase_sph", (k_narrowphase<true>), nh_grid_for(pair_cap, 256, 8192), 256, st, pairs, xf, ctag,
+			          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a,
+			          coarse_root, coarse_active, ctx->step_parity);
 	}
 	// islands over contact records (+ user connections): a chain of small kernels that the tag sort of the records does not depend
 	// on -- it runs on the side stream while the caller's stream sorts (fork here, join before k_sorted_counts)

@@ -86,13 +86,13 @@ extern "C" int nh_synchronize(nh_context* ctx) {
 extern "C" int nh_read_counts(nh_context* ctx, nh_Counts* out) {
 	if (!ctx || !out) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
-	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, 22 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, 23 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 	const nh_DevState* h = ctx->h_state;
-	out->colliders = h->colliders; out->pairs = h->pairs > 0 ? h->pairs : 0; out->contacts = h->contacts; out->sleeping_pairs = h->sleeping;
+	out->colliders = h->colliders; out->pairs = h->pairs + h->pairs_sph; out->contacts = h->contacts; out->sleeping_pairs = h->sleeping;
 	out->active_bodies = h->active; out->cache = h->cache; out->culled = h->culled; out->large_colliders = h->large;
 	out->general_contacts = h->general_contacts; out->levels = h->levels; out->error = h->error;
-	out->static_bodies = h->static_bodies; out->unleveled = h->unleveled; out->raw_pairs = h->pairs;
+	out->static_bodies = h->static_bodies; out->unleveled = h->unleveled; out->raw_pairs = h->pairs + h->pairs_sph;
 	if (ctx->timing) nh_timer_collect(ctx);
 	return NH_OK;
 }

@@ -43,26 +43,28 @@ struct nh_DevState {
 	uint32_t unleveled_odd;               // progress counter of odd relaxation / colouring rounds
 	uint32_t static_inert;                // body 0 has all-zero velocity, inverse mass and inverse inertia (nh_is_inert)
 	uint32_t has_pending;                 // some body needs the general adjacency build (k_adj_simple could not settle it)
-	// ---- (the 22 words above are what nh_read_counts mirrors to the host) ----
+	uint32_t pairs_sph;                   // broadphase pairs with a sphere (they fill the pair list from the back; `pairs` counts the box-box ones)
+	// ---- (the 23 words above are what nh_read_counts mirrors to the host) ----
 	// scene bounds of AABB min corners, order-preserving uint encoding (atomicMin/Max)
 	uint32_t smin[3];
 	uint32_t smax[3];
 	// the same over "small" (grid) colliders only: the broadphase grid spans just these
 	uint32_t gmin[3];
 	uint32_t gmax[3];
-	// broadphase grid parameters (written by k_grid_params)
+	// broadphase grid parameters (written by nh_grid_setup: the last workgroup of k_xform)
 	float morton_scale;
 	float morton_min[3];          // scene_min * scale
 	float cell_inv;               // 1 / cell size (cell size is a power of two)
 	float origin[3];
 	uint32_t dims[3];
 	uint32_t small_exp;           // colliders whose size class (extent bits >> 21: exponent + 2 mantissa bits) is <= this go to the grid (kept across steps: next step's guess)
-	uint32_t redo_small;          // the guess was wrong: k_small_bounds recomputes gmin/gmax
+	uint32_t redo_small;          // (unused)
 	uint32_t exp_hist[1024];      // histogram of size classes
 	uint32_t any_idle[2];         // by step parity: some body's idle counter is saturated (asleep)
 	uint32_t sort_buckets;        // buckets of this step's tag sort = splitters of the previous step + 1 (nh_util.hip, bucket sort)
 	uint32_t sort_buckets_next;   // written by this step's sort for the next one
 	uint32_t colour_cursor;       // append cursor of the colouring's list compaction (nh_solve.hip)
+	uint32_t xform_ticket;        // workgroups of k_xform that have published their bounds (the last one derives the grid; it resets the ticket)
 	uint32_t order_conflict;      // exact-order mode: sequence number of the setup call whose closed-form schedule has a lane conflict (nh_solve.hip)
 };
 
@@ -159,6 +161,7 @@ struct nh_ContactConstraintData {
 	uint32_t body_count;
 	uint32_t static_body_count;
 	bool has_static8, has_staticN, static_inert;
+	bool csr_ready;                       // body_off[] / adj[] hold the CSR adjacency (built on demand: ensure_csr in nh_solve.hip)
 	const nh_BodyPair* bodies;
 	// inputs kept for the one-body fast path, which rebuilds its rows in registers instead of storing them
 	const nh_Contact* contact_data;

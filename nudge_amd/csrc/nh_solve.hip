@@ -173,10 +173,14 @@ __device__ __forceinline__ uint32_t slot_key_of(uint32_t i, const uint32_t* __re
 }
 
 // One lane per body.  A body that sits in exactly ONE collider pair, with the static world, and has <= 8 contacts -- the box on the
-// ground -- needs no CSR build: its contacts are first .. first+d-1 (a pair's contacts are adjacent in tag order), written here in
-// slot order.  Everything else is left PENDING for the general k_adj_fill / k_adj_sort, which do not even start when nothing is pending.
-__global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st, uint32_t nbodies, const uint32_t* __restrict__ off, const uint32_t* __restrict__ info,
-                                                    const uint32_t* __restrict__ first_contact, uint32_t* __restrict__ adj, const uint32_t* __restrict__ slot_key,
+// ground -- needs no CSR build: its contacts are first .. first+d-1 (a pair's contacts are adjacent in tag order), recorded here in slot
+// order as ONE word pair the solver reads next to the body state: simple[x] = (first contact, count | 3-bit offsets in slot order << 4 |
+// body-is-"a" << 28).  Degrees come straight from nh_collide's counters: no scan, no adjacency array on this path (k_adj_from_simple
+// writes the CSR form on demand).  Everything else is left PENDING for the general k_adj_fill / k_adj_sort, which do not even start
+// when nothing is pending.
+#define NH_FIRST_IS_A 0x80000000u        // in first_contact[]: the body plays "a" in its last pair (k_gather_contacts)
+__global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st, uint32_t nbodies, const uint32_t* __restrict__ deg, const uint32_t* __restrict__ info,
+                                                    const uint32_t* __restrict__ first_contact, const uint32_t* __restrict__ slot_key,
                                                     uint8_t* __restrict__ body_class, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                     uint2* __restrict__ simple) {
 	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < nbodies; x += gridDim.x * blockDim.x) {
@@ -188,15 +192,14 @@ __global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st
 			st->static_inert = nh_is_inert(m0.velocity, m0.angular_velocity, p0.inertia_inverse, p0.mass_inverse) ? 1u : 0u;
 			continue;
 		}
-		const uint32_t b = off[x], d = off[x + 1] - b;
+		const uint32_t d = deg[x];
 		uint32_t cls = NH_CLS_NONE;
 		if (d) {
 			const uint32_t inf = info[x];
 			if ((inf & 0xFFFFu) == 1u && (inf >> 16) == 0u && d <= 8u) {
-				const uint32_t f = first_contact[x];
-				// contacts f .. f+d-1 in slot order (insertion sort in registers: a 4-entry network for the usual box on the ground, 8 otherwise),
-				// as the adjacency list and, in one record for the solver (no walk through off[] and adj[]), as first contact, count and
-				// 3-bit offsets in slot order
+				const uint32_t fc = first_contact[x];
+				const uint32_t f = fc & ~NH_FIRST_IS_A;
+				// contacts f .. f+d-1 in slot order (insertion sort in registers: a 4-entry network for the usual box on the ground, 8 otherwise)
 				auto emit = [&](auto tag) {
 					constexpr int W = decltype(tag)::value;
 					uint32_t c[W], k[W];
@@ -214,8 +217,8 @@ __global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st
 					}
 					uint32_t perm = 0;
 #pragma unroll
-					for (int q = 0; q < W; ++q) if ((uint32_t)q < d) { adj[b + q] = c[q]; perm |= (c[q] - f) << (3 * q); }
-					simple[x] = make_uint2(f, d | (perm << 4));
+					for (int q = 0; q < W; ++q) if ((uint32_t)q < d) perm |= (c[q] - f) << (3 * q);
+					simple[x] = make_uint2(f, d | (perm << 4) | ((fc & NH_FIRST_IS_A) ? (1u << 28) : 0u));
 				};
 				if (d <= 4u) emit(std::integral_constant<int, 4>()); else emit(std::integral_constant<int, 8>());
 				cls = d <= 4u ? NH_CLS_STATIC4 : NH_CLS_STATIC8;
@@ -228,6 +231,19 @@ __global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st
 			momentum[x].unused0 = props[x].mass_inverse;
 		}
 		body_class[x] = (uint8_t)cls;
+	}
+}
+
+// CSR form of the lists k_adj_simple recorded (only when a kernel that walks off[] / adj[] is about to run: several apply calls per
+// setup, a static world that is not inert, bodies of the 5..8-contact class)
+__global__ __launch_bounds__(256) void k_adj_from_simple(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off,
+                                                         const uint2* __restrict__ simple, uint32_t* __restrict__ adj) {
+	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < nbodies; x += gridDim.x * blockDim.x) {
+		const uint32_t cls = body_class[x];
+		if (cls != NH_CLS_STATIC4 && cls != NH_CLS_STATIC8) continue;
+		const uint2 sp = simple[x];
+		const uint32_t b = off[x], d = sp.y & 15u;
+		for (uint32_t q = 0; q < d; ++q) adj[b + q] = sp.x + ((sp.y >> (4 + 3 * q)) & 7u);
 	}
 }
 
@@ -838,7 +854,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
 			if (c != 0xFFFFFFFFu) {
 				o.c0 = reinterpret_cast<const float4*>(contacts + c)[0];
 				o.c1 = reinterpret_cast<const float4*>(contacts + c)[1];
-				uint32_t flags = bodies[c].a == wave_x0 + j ? 2u : 0u;
+				// (CONTIG: the body's role in its one pair rides in simple[x], bit 28 -- no load of the body pair)
+				uint32_t flags = (!CONTIG && bodies[c].a == wave_x0 + j) ? 2u : 0u;
 				if (FUSED) {
 					const uint32_t hj = s_hint[wave][j];
 					const uint32_t guess = hj != NH_HINT_NONE ? hj + (c - s_first[wave][j]) : c;
@@ -867,7 +884,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
 			if ((uint32_t)q < cnt) {
 				const nh_ob_slot o = slot[lane * M + q];
 				const uint32_t flags = __float_as_uint(o.w.w);
-				is_a[q] = (flags & 2u) != 0;
+				is_a[q] = CONTIG ? ((sp.y >> 28) & 1u) != 0 : (flags & 2u) != 0;
 				nh_contact_in ci = { o.c0.x, o.c0.y, o.c0.z, o.c0.w, o.c1.x, o.c1.y, o.c1.z, o.c1.w };
 				nh_build_row1(ci, posx, IX, v.mass_inverse, is_a[q], r[q]);
 				if (FUSED) {
@@ -1467,14 +1484,14 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	d->contact_data = contacts->data; d->impulses = imp->data; d->general_list = general_list;
 	d->levels = 0; d->general_contacts = 0;
 
-	// (degrees were counted by nh_collide while it laid the contacts out)
-	nh_scan_u32(ctx, ctx->deg, d->body_off, &st->pad0, B + 1, tmp, nullptr);
+	// (degrees were counted by nh_collide while it laid the contacts out; their scan into CSR offsets waits until somebody needs it: ensure_csr)
+	d->csr_ready = false;
 	if (slot_key) {
 		const uint32_t seq = ++ctx->order_seq ? ctx->order_seq : ++ctx->order_seq;       // never 0: tells this call's verdict from an older one
 		NH_LAUNCH(ctx, "order_check", k_order_check, nh_grid_for(kcap / 8u + 16u, 256, 1024), 256, st, contacts->bodies, slot_key, seq);
 		NH_LAUNCH(ctx, "greedy_replay", k_greedy_replay, 1, 64, st, contacts->bodies, slot_key, seq, spill_ab, spill_idx, spill_cap);
 	}
-	NH_LAUNCH(ctx, "adjacency_simple", k_adj_simple, nh_grid_for(B, 256, 4096), 256, st, B, d->body_off, ctx->deg + 2 * (size_t)(B + 2), ctx->deg + 3 * (size_t)(B + 2), d->adj, slot_key,
+	NH_LAUNCH(ctx, "adjacency_simple", k_adj_simple, nh_grid_for(B, 256, 4096), 256, st, B, ctx->deg, ctx->deg + 2 * (size_t)(B + 2), ctx->deg + 3 * (size_t)(B + 2), slot_key,
 	          d->body_class, bodies->properties, bodies->momentum, d->simple);
 	if (ctx->hint_capacity < B) {
 		// library-owned, persistent across steps: per body, where its contacts started in the previous step's list (warm-start hint)
@@ -1502,6 +1519,15 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 // The part of setup_contact_constraints that needs the device counters on the host: general adjacency for bodies k_adj_simple left
 // pending, culling when something sleeps, the >8-contact one-body class, and the level-scheduled path (colouring / levels, rows,
 // warm start).  Runs once per setup, with ctx->pending already cleared.
+// CSR adjacency (body_off[] offsets, adj[] lists) -- needed by every kernel but the speculative one-body launch
+static void ensure_csr(nh_context* ctx, nh_ContactConstraintData* d) {
+	if (d->csr_ready) return;
+	d->csr_ready = true;
+	const uint32_t B = d->body_count;
+	nh_scan_u32(ctx, ctx->deg, d->body_off, &ctx->d_state->pad0, B + 1, d->cont.tmp, nullptr);
+	NH_LAUNCH(ctx, "adjacency_from_simple", k_adj_from_simple, nh_grid_for(B, 256, 4096), 256, B, d->body_class, d->body_off, d->simple, d->adj);
+}
+
 static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 	nh_DevState* st = ctx->d_state;
 	const nh_ContactData* contacts = &d->cont.contacts;
@@ -1517,6 +1543,7 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 	if (rc) return rc;
 	if (c.error) return (int)c.error;
 	d->has_late = ctx->h_state->has_pending != 0;
+	if (d->has_late || ctx->h_state->has_static8 || !ctx->h_state->static_inert) ensure_csr(ctx, d);
 	if (d->has_late) {
 		// bodies in several pairs or with dynamic partners (piles, pits): general CSR fill + sort + classification, then the counts again
 		NH_LAUNCH(ctx, "adjacency_fill", k_adj_fill, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, contacts->tags, d->body_off, cursor, d->adj, d->body_class);
@@ -1603,6 +1630,7 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 // the speculative launch (only possible when body 0 is inert: that launch checks it on the device and leaves otherwise).
 static void launch_apply_static(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations, bool fused, bool early4_done) {
 	const uint32_t B = d->body_count;
+	if (!(fused && early4_done && !d->has_late && !d->has_static8 && !d->has_staticN)) ensure_csr(ctx, d);      // (the common step launches nothing below)
 	nh_CacheView cv = { nullptr, nullptr, nullptr, nullptr, nullptr, ctx->d_state };
 	if (fused) { cv.tags = d->imp->tags; cv.features = d->imp->features; cv.ctags = d->imp->ctags; cv.cfeatures = d->imp->cfeatures; cv.cdata = d->imp->cdata; }
 	auto go = [&](const char* name, auto kernel, uint32_t cls_a, uint32_t cls_b) {
