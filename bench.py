@@ -49,9 +49,9 @@ C2_BODIES = 1004400
 KERNEL_BYTES = {
     "collide_begin": ("B", 12 + 1),                        # degree / cursor / info words cleared, idle counter read
     "xform_aabb": ("C", 32 + 32 + 16 + 4 + 32 + 32 + 4),   # local+body transform, shape, tag -> world transform, AABB, tag
-    "cell_keys": ("C", 32 + 8 + 8),                        # AABB -> cell key, rank, morton key
+    "cell_keys": ("C", 32 + 8),                            # AABB -> cell key, rank in the cell
     "cell_scan": ("T", 6),                                 # per-cell counts -> starts: read twice, written once, over two launches
-    "cell_scatter": ("C", 8 + 32 + 8 + 4 + 32 + 8),        # key/rank + AABB + morton -> the same in cell order
+    "cell_scatter": ("C", 8 + 32 + 4 + 32),                # key/rank + AABB -> key + 32-byte AABB record in cell order
     "find_pairs": ("C", 32 + 4),                           # AABB in cell order + key (+ 8 B per emitted pair)
     "large_pairs": ("P", 32 + 8),                          # candidates of the large colliders: AABB read, pair written
     "narrowphase": ("P", 8 + 2 * (32 + 16 + 4) + 4 * 36 + 24),  # pair, 2 x (transform, shape, tag) -> ~4 contacts x 36 B + record

@@ -13,8 +13,6 @@
 #include "nh_narrowphase.h"
 #include <stdlib.h>
 
-__device__ void nh_grid_setup(nh_DevState* st, uint32_t ncolliders, uint32_t max_cells);
-
 // ---- 1. world transforms, AABBs, bounds, extent histogram ---------------------------------------------
 // aabb_min[c] = (min.xyz, bits(body)), aabb_max[c] = (max.xyz, bits(max extent))
 // 1024-thread workgroups, one per CU: the scene bounds / histogram end in a handful of global atomics per WORKGROUP on the same
@@ -24,10 +22,9 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
                                                const nh_Transform* __restrict__ box_xf, const nh_BoxCollider* __restrict__ box_data, const uint32_t* __restrict__ box_tags, uint32_t nbox,
                                                const nh_Transform* __restrict__ sph_xf, const nh_SphereCollider* __restrict__ sph_data, const uint32_t* __restrict__ sph_tags, uint32_t nsph,
                                                nh_xform* __restrict__ xf, float4* __restrict__ aabb_min, float4* __restrict__ aabb_max, uint32_t* __restrict__ ctag,
-                                               uint4* __restrict__ zero16, uint32_t zero16_count, uint32_t max_cells) {
+                                               uint4* __restrict__ zero16, uint32_t zero16_count) {
 	__shared__ uint32_t hist[1024];
 	__shared__ uint32_t red[12];
-	__shared__ uint32_t s_last;
 	hist[threadIdx.x] = 0;
 	if (threadIdx.x < 3) { red[threadIdx.x] = 0xffffffffu; red[3 + threadIdx.x] = 0u; red[6 + threadIdx.x] = 0xffffffffu; red[9 + threadIdx.x] = 0u; }
 	__syncthreads();
@@ -102,23 +99,14 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 		atomicMin(&st->smin[threadIdx.x], red[threadIdx.x]); atomicMax(&st->smax[threadIdx.x], red[3 + threadIdx.x]);
 		if (red[6 + threadIdx.x] <= red[9 + threadIdx.x]) { atomicMin(&st->gmin[threadIdx.x], red[6 + threadIdx.x]); atomicMax(&st->gmax[threadIdx.x], red[9 + threadIdx.x]); }
 	}
-	// the last workgroup to get here derives the grid from what everybody published (nh_grid_setup)
-	__threadfence();
-	__syncthreads();
-	if (threadIdx.x == 0) s_last = atomicAdd(&st->xform_ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
-	__syncthreads();
-	if (!s_last || threadIdx.x >= 64u) return;
-	__threadfence();
-	nh_grid_setup(st, n, max_cells);
-	if (threadIdx.x == 0) st->xform_ticket = 0u;
 }
 
-// ---- 2. grid parameters: run by the first wave of the LAST workgroup of k_xform to finish (ticket counter), so that the step has no
-// tiny single-wave launches between the transform pass and the cell keys.  Everything the other workgroups published arrives through
-// device-scope atomics; it is read back with agent-scope loads after the ticket.
-__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ---- 2. grid parameters: ONE single-wave launch between the transform pass and the cell keys (Morton frame, small / large split, grid
+// origin, cell size and dimensions).  (Folding it into the last workgroup of k_xform to finish was measured: the agent-scope fence that
+// needs -- an L2 write-back per workgroup on this multi-die part -- cost 100 us, twenty times the launch it saved.)
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return *p; }
 
-__device__ void nh_grid_setup(nh_DevState* st, uint32_t ncolliders, uint32_t max_cells) {
+__global__ __launch_bounds__(64) void k_grid_setup(nh_DevState* st, uint32_t ncolliders, uint32_t max_cells) {
 	// small/large split: allow at most max(64, C/1024) colliders above the grid's cell size.  e = largest size class kept small =
 	// the highest class whose suffix count (colliders in classes >= e) exceeds the budget.  One wave: lane l owns classes 16l..16l+15.
 	const uint32_t budget = max(ncolliders / 1024u, 64u);
@@ -169,7 +157,9 @@ __device__ void nh_grid_setup(nh_DevState* st, uint32_t ncolliders, uint32_t max
 	const nh_f3 gmin = nh_make3(nh_float_unflip(gmn[0]), nh_float_unflip(gmn[1]), nh_float_unflip(gmn[2]));
 	const nh_f3 gmax = nh_make3(nh_float_unflip(gmx[0]), nh_float_unflip(gmx[1]), nh_float_unflip(gmx[2]));
 	st->origin[0] = gmin.x; st->origin[1] = gmin.y; st->origin[2] = gmin.z;
-	for (int it = 0; it < 64; ++it) {
+	// (with fewer colliders than the budget every one of them is "large" and the cell is tiny: the loop then walks down to a single cell)
+	st->dims[0] = st->dims[1] = st->dims[2] = 1;
+	for (int it = 0; it < 256; ++it) {
 		float dx = (gmax.x - gmin.x) * inv, dy = (gmax.y - gmin.y) * inv, dz = (gmax.z - gmin.z) * inv;
 		uint64_t nx = (uint64_t)fminf(fmaxf(dx, 0.0f), 1e7f) + 2, ny = (uint64_t)fminf(fmaxf(dy, 0.0f), 1e7f) + 2, nz = (uint64_t)fminf(fmaxf(dz, 0.0f), 1e7f) + 2;
 		if (nx * ny * nz < max_cells) { st->dims[0] = (uint32_t)nx; st->dims[1] = (uint32_t)ny; st->dims[2] = (uint32_t)nz; break; }
@@ -191,14 +181,12 @@ __device__ __forceinline__ int cell_coord(float x, float origin, float inv) {
 // are decided by Morton keys, and contacts come out in tag order.)  Large colliders follow the small ones, in list order.
 __global__ __launch_bounds__(256) void k_cell_keys(nh_DevState* __restrict__ st, uint32_t n,
                                                    const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
-                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ rank, uint64_t* __restrict__ mkey, uint32_t* __restrict__ large_list,
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ rank, uint32_t* __restrict__ large_list,
                                                    uint32_t* __restrict__ cstart) {
 	const float inv = st->cell_inv;
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
 	const uint32_t small_exp = st->small_exp;
-	const float mscale = st->morton_scale;
-	const nh_f3 mmin = nh_make3(st->morton_min[0], st->morton_min[1], st->morton_min[2]);
 	uint32_t rounded = (n + 63u) & ~63u;
 	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < rounded; c += gridDim.x * blockDim.x) {
 		bool valid = c < n;
@@ -206,7 +194,6 @@ __global__ __launch_bounds__(256) void k_cell_keys(nh_DevState* __restrict__ st,
 		uint32_t key = NH_LARGE_KEY;
 		if (valid) {
 			float4 mn = aabb_min[c], mx = aabb_max[c];
-			mkey[c] = nh_morton_of(nh_make3(mn.x, mn.y, mn.z), mscale, mmin);
 			int cx0 = cell_coord(mn.x, ox, inv), cy0 = cell_coord(mn.y, oy, inv), cz0 = cell_coord(mn.z, oz, inv);
 			int cx1 = cell_coord(mx.x, ox, inv), cy1 = cell_coord(mx.y, oy, inv), cz1 = cell_coord(mx.z, oz, inv);
 			uint32_t e = (__float_as_uint(mx.w) >> 21) & 1023u;
@@ -267,10 +254,12 @@ __global__ __launch_bounds__(256) void k_cscan_final(uint32_t* __restrict__ cnt,
 	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) cnt[n] = run;
 }
 
+// cell-sorted copy of the AABBs: ONE 32-byte record per collider, sbox[2 pos] = (min.xyz, body), sbox[2 pos + 1] = (max.xyz, collider index),
+// so that a candidate of the pair search costs one cache line, not two.  (Morton keys are not carried along: the pair search computes them
+// from the min corners of the few pairs that actually overlap.)
 __global__ __launch_bounds__(256) void k_cell_scatter(const nh_DevState* __restrict__ st, uint32_t n, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ rank,
                                                       const uint32_t* __restrict__ cstart, const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
-                                                      uint32_t* __restrict__ skeys, float4* __restrict__ smin, float4* __restrict__ smax,
-                                                      const uint64_t* __restrict__ mkey, uint64_t* __restrict__ smk) {
+                                                      uint32_t* __restrict__ skeys, float4* __restrict__ sbox) {
 	const uint32_t nsmall = n - st->large;
 	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
 		const uint32_t key = keys[c];
@@ -278,8 +267,7 @@ __global__ __launch_bounds__(256) void k_cell_scatter(const nh_DevState* __restr
 		float4 mn = aabb_min[c], mx = aabb_max[c];
 		mx.w = __uint_as_float(c);                 // sorted copy carries (body, collider index) in the w lanes
 		skeys[pos] = key;
-		smin[pos] = mn; smax[pos] = mx;
-		smk[pos] = mkey[c];
+		sbox[2u * pos] = mn; sbox[2u * pos + 1u] = mx;
 	}
 }
 
@@ -383,16 +371,19 @@ __device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_
 // Morton key) in flight at once: three or four memory round trips per lane instead of one per candidate.
 #define FP_BATCH 4
 __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st, uint32_t n, uint32_t nbox,
-                                                    const uint32_t* __restrict__ keys, const float4* __restrict__ smin, const float4* __restrict__ smax,
+                                                    const uint32_t* __restrict__ keys, const float4* __restrict__ sbox,
                                                     const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
                                                     const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
-                                                    const uint64_t* __restrict__ mkey, const uint64_t* __restrict__ smk, uint2* __restrict__ pairs, uint32_t pair_cap,
+                                                    uint2* __restrict__ pairs, uint32_t pair_cap,
                                                     uint32_t* __restrict__ coarse_parent, uint32_t parity, const uint8_t* __restrict__ idle) {
 	uint32_t* const islands = st->any_idle[parity] ? coarse_parent : nullptr;
 	const float inv = st->cell_inv;
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
 	const uint32_t nlarge = st->large;
+	// Morton frame (nudge.cpp:3096-3100): which collider of a pair plays "a" is decided by the Morton order of the AABB min corners
+	const float mscale = st->morton_scale;
+	const nh_f3 mmin = nh_make3(st->morton_min[0], st->morton_min[1], st->morton_min[2]);
 	__shared__ uint2 wave_buf[4][FP_WBUF];
 	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u, FP_WBUF, nbox };
 	uint32_t rounded = (n + 63u) & ~63u;
@@ -401,7 +392,7 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 		float4 amin = make_float4(0, 0, 0, 0), amax = amin;
 		uint32_t key = NH_LARGE_KEY, ca = 0, abody = 0;
 		uint64_t ka = 0;
-		if (valid) { amin = smin[i]; amax = smax[i]; key = keys[i]; ca = __float_as_uint(amax.w); abody = __float_as_uint(amin.w); ka = smk[i]; }
+		if (valid) { amin = sbox[2u * i]; amax = sbox[2u * i + 1u]; key = keys[i]; ca = __float_as_uint(amax.w); abody = __float_as_uint(amin.w); ka = nh_morton_of(nh_make3(amin.x, amin.y, amin.z), mscale, mmin); }
 		const bool small = valid && key != NH_LARGE_KEY;
 		// the forward rows: begin / end of their candidate ranges (empty rows: begin = end = 0)
 		uint32_t rb[5] = { 0, 0, 0, 0, 0 }, re[5] = { 0, 0, 0, 0, 0 };
@@ -444,9 +435,8 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 			}
 			if (!__any(have[0])) break;
 			float4 bmin[FP_BATCH], bmax[FP_BATCH];
-			uint64_t kb[FP_BATCH];
 #pragma unroll
-			for (int k = 0; k < FP_BATCH; ++k) if (have[k]) { bmin[k] = smin[cand[k]]; bmax[k] = smax[cand[k]]; kb[k] = smk[cand[k]]; }
+			for (int k = 0; k < FP_BATCH; ++k) if (have[k]) { bmin[k] = sbox[2u * cand[k]]; bmax[k] = sbox[2u * cand[k] + 1u]; }
 #pragma unroll
 			for (int k = 0; k < FP_BATCH; ++k) {
 				if (!__any(have[k])) break;
@@ -456,7 +446,8 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 					cb = __float_as_uint(bmax[k].w); bbody = __float_as_uint(bmin[k].w);
 					hit = aabb_overlap(amin, amax, bmin[k], bmax[k]) && (bbody != abody);
 				}
-				emit_pair(st, pairs, pair_cap, ka, have[k] ? kb[k] : 0ull, ca, cb, hit, ps, islands, idle, abody, bbody);
+				const uint64_t kb = hit ? nh_morton_of(nh_make3(bmin[k].x, bmin[k].y, bmin[k].z), mscale, mmin) : 0ull;
+				emit_pair(st, pairs, pair_cap, ka, kb, ca, cb, hit, ps, islands, idle, abody, bbody);
 			}
 		}
 		// large x larger-indexed large (small x large is found from the large side: k_large_pairs)
@@ -466,7 +457,8 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 				uint32_t cb = large_list[l];
 				float4 bmin = aabb_min[cb], bmax = aabb_max[cb];
 				bool hit = a_large && cb > ca && aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != abody);
-				emit_pair(st, pairs, pair_cap, ka, hit ? mkey[cb] : 0ull, ca, cb, hit, ps, islands, idle, abody, __float_as_uint(bmin.w));
+				const uint64_t kb = hit ? nh_morton_of(nh_make3(bmin.x, bmin.y, bmin.z), mscale, mmin) : 0ull;
+				emit_pair(st, pairs, pair_cap, ka, kb, ca, cb, hit, ps, islands, idle, abody, __float_as_uint(bmin.w));
 			}
 		}
 	}
@@ -481,16 +473,18 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 // otherwise be walked one after the other by a handful of waves)
 #define LP_BLOCKS 1024u
 #define LP_WBUF 1024
-__global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ st, uint32_t nbox, const float4* __restrict__ smin, const float4* __restrict__ smax,
+__global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ st, uint32_t nbox, const float4* __restrict__ sbox,
                                                      const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
                                                      const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
-                                                     const uint64_t* __restrict__ mkey, const uint64_t* __restrict__ smk, uint2* __restrict__ pairs, uint32_t pair_cap,
+                                                     uint2* __restrict__ pairs, uint32_t pair_cap,
                                                     uint32_t* __restrict__ coarse_parent, uint32_t parity, const uint8_t* __restrict__ idle) {
 	uint32_t* const islands = st->any_idle[parity] ? coarse_parent : nullptr;
 	const float inv = st->cell_inv;
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
 	const uint32_t nlarge = st->large;
+	const float mscale = st->morton_scale;
+	const nh_f3 mmin = nh_make3(st->morton_min[0], st->morton_min[1], st->morton_min[2]);
 	__shared__ uint2 wave_buf[4][LP_WBUF];
 	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u, LP_WBUF, nbox };
 	uint32_t slices = nlarge ? LP_BLOCKS / nlarge : 1u;
@@ -500,7 +494,7 @@ __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ s
 		const uint32_t ca = large_list[l];
 		const float4 amin = aabb_min[ca], amax = aabb_max[ca];
 		const uint32_t abody = __float_as_uint(amin.w);
-		const uint64_t ka = mkey[ca];
+		const uint64_t ka = nh_morton_of(nh_make3(amin.x, amin.y, amin.z), mscale, mmin);
 		// a small collider B overlapping A has its min-corner cell in [c_min(A) - 1, c_max(A)] per axis
 		int x0 = min(max(cell_coord(amin.x, ox, inv) - 1, 0), nx - 1), x1 = min(max(cell_coord(amax.x, ox, inv), 0), nx - 1);
 		int y0 = min(max(cell_coord(amin.y, oy, inv) - 1, 0), ny - 1), y1 = min(max(cell_coord(amax.y, oy, inv), 0), ny - 1);
@@ -521,10 +515,10 @@ __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ s
 				uint32_t cb = 0, bbody = 0;
 				uint64_t kb = 0;
 				if (have) {
-					float4 bmin = smin[cand], bmax = smax[cand];
-					kb = smk[cand];
+					float4 bmin = sbox[2u * cand], bmax = sbox[2u * cand + 1u];
 					cb = __float_as_uint(bmax.w); bbody = __float_as_uint(bmin.w);
 					hit = aabb_overlap(amin, amax, bmin, bmax) && (bbody != abody);
+					if (hit) kb = nh_morton_of(nh_make3(bmin.x, bmin.y, bmin.z), mscale, mmin);
 				}
 				emit_pair(st, pairs, pair_cap, ka, kb, ca, cb, hit, ps, islands, idle, abody, bbody);
 			}
@@ -941,11 +935,8 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	nh_xform* xf = nh_arena_array<nh_xform>(A, C, &err);
 	float4* aabb_min = nh_arena_array<float4>(A, C, &err);
 	float4* aabb_max = nh_arena_array<float4>(A, C, &err);
-	float4* smin = nh_arena_array<float4>(A, C, &err);
-	float4* smax = nh_arena_array<float4>(A, C, &err);
+	float4* sbox = nh_arena_array<float4>(A, (size_t)2 * C, &err);         // cell-sorted AABBs, one 32-byte record per collider
 	uint32_t* ctag = nh_arena_array<uint32_t>(A, C, &err);
-	uint64_t* mkey = nh_arena_array<uint64_t>(A, C, &err);
-	uint64_t* smk = nh_arena_array<uint64_t>(A, C, &err);
 	uint32_t* keys_a = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* keys_b = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* vals_a = nh_arena_array<uint32_t>(A, C, &err);
@@ -1015,13 +1006,14 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 1024, 256), 1024, st, bodies->transforms,
 		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
 		          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
-		          xf, aabb_min, aabb_max, ctag, reinterpret_cast<uint4*>(cstart), (max_cells + 8u) / 4u, max_cells);
-		NH_LAUNCH(ctx, "cell_keys", k_cell_keys, nh_grid_for(C, 256, 2048), 256, st, C, aabb_min, aabb_max, keys_a, vals_a, mkey, large_list, cstart);
+		          xf, aabb_min, aabb_max, ctag, reinterpret_cast<uint4*>(cstart), (max_cells + 8u) / 4u);
+		NH_LAUNCH(ctx, "grid_setup", k_grid_setup, 1, 64, st, C, max_cells);
+		NH_LAUNCH(ctx, "cell_keys", k_cell_keys, nh_grid_for(C, 256, 2048), 256, st, C, aabb_min, aabb_max, keys_a, vals_a, large_list, cstart);
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_sums, max_cells / CS_TILE, 256, cstart, cscan_sums);
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_final, max_cells / CS_TILE, 256, cstart, cscan_sums, max_cells);
-		NH_LAUNCH(ctx, "cell_scatter", k_cell_scatter, nh_grid_for(C, 256, 2048), 256, st, C, keys_a, vals_a, cstart, aabb_min, aabb_max, keys_b, smin, smax, mkey, smk);
-		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 4096), 256, st, C, nbox, keys_b, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
-		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, 2048, 256, st, nbox, smin, smax, cstart, large_list, aabb_min, aabb_max, mkey, smk, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+		NH_LAUNCH(ctx, "cell_scatter", k_cell_scatter, nh_grid_for(C, 256, 2048), 256, st, C, keys_a, vals_a, cstart, aabb_min, aabb_max, keys_b, sbox);
+		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 4096), 256, st, C, nbox, keys_b, sbox, cstart, large_list, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, 2048, 256, st, nbox, sbox, cstart, large_list, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
 		// coarse islands over the broadphase pairs (united where the pairs were emitted) + connections: only when some body is asleep (a device
 		// flag: the kernels leave at once otherwise)
 		if (body_connections && body_connections->count)
