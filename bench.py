@@ -243,10 +243,10 @@ def main():
     n_box_dyn = int((scene["box_transforms"]["body"] > 0).sum())
     n_sph_dyn = int((scene["sphere_transforms"]["body"] > 0).sum())
     if halo:
-        w = E.World(scene, device=device_index, flags=0, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=6 * info["capacity"]["bodies"])
+        w = E.World(scene, device=device_index, flags=E.NH_FLAG_SINGLE_APPLY, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=6 * info["capacity"]["bodies"])
         cluster = PT.DistCluster(PT.Partition(w, info, epoch=16), host_staging=(backend != "nccl"))
     else:
-        w = E.World(scene, device=device_index, flags=0, max_contacts=max(4096, (6 if args.scene != "pit" else 5) * nb),
+        w = E.World(scene, device=device_index, flags=E.NH_FLAG_SINGLE_APPLY, max_contacts=max(4096, (6 if args.scene != "pit" else 5) * nb),
                     max_pairs=None if args.scene != "pit" else 7 * nb)
 
     def advance_world(n):

@@ -72,6 +72,8 @@ enum {
 	NH_ERR_SCHEDULER_CAPACITY = 9, /* NH_FLAG_EXACT_ORDER only: the replay of the reference's greedy batch scheduler ran out of open
 	                                batches (more than ~130,000 contacts on ONE dynamic body; the reference sizes this by
 	                                contacts.count, nudge.cpp:4222-4223)                                  */
+	NH_ERR_STALE_HINT = 11,      /* idle_counters were changed behind the library's back (see nh_bodies_changed): a body was asleep in a step
+	                                for which the host had ruled that out                                 */
 	NH_ERR_STALE_SETUP = 10      /* nh_setup_contact_constraints called twice for one nh_collide, or contacts->count changed in
 	                                between: the solver's inputs are laid out by nh_collide (note 8)         */
 };
@@ -79,6 +81,10 @@ enum {
 /* ---- context flags ----------------------------------------------------------------------------- */
 enum {
 	NH_FLAG_SYNC_COUNTS = 1u,    /* fill host-side count fields before returning (reference semantics)   */
+	NH_FLAG_SINGLE_APPLY = 4u,   /* the caller promises ONE nh_apply_impulses(..., iterations) per nh_setup_contact_constraints (the whole
+	                                iteration loop of example/main.cpp:313-318 in one call): the per-contact solver states that only a
+	                                further nh_apply_impulses call would read are then not written (16 B per contact per step); a
+	                                second call for the same setup returns NH_ERR_INVALID                                   */
 	NH_FLAG_EXACT_ORDER = 2u     /* solver visits contacts in the reference's greedy batch order, replayed
 	                                exactly on the device (nudge.cpp:4206-4339); default is the closed-form
 	                                round-robin order, identical whenever the greedy scheduler meets no
@@ -165,6 +171,11 @@ int nh_set_flags(nh_context* ctx, uint32_t flags);
 int nh_synchronize(nh_context* ctx);
 int nh_read_counts(nh_context* ctx, nh_Counts* out);        /* synchronises the stream */
 int nh_set_cache_count(nh_context* ctx, uint32_t count);    /* restore a checkpointed ContactCache */
+/* Tell the library that the caller has written `idle_counters` itself (initial upload excepted: a fresh context assumes nothing).  The
+   library predicts on the host when a body can first be asleep -- counters rise by at most one per nh_advance -- and launches none of the
+   island / sleeping kernels before that; counters written from outside invalidate the prediction until the next nh_collide has looked at
+   them.  A forgotten call is detected on the device and reported as NH_ERR_STALE_HINT, never silently wrong. */
+int nh_bodies_changed(nh_context* ctx);
 int nh_set_tag_bits(nh_context* ctx, uint32_t bits);        /* collider tags are < 2^bits (default 32): fewer sort passes */
 /* Capacity of the broadphase pair buffer (AABB-overlap pairs after the same-body filter), carved from the arena at ~210 B per
    pair by nh_collide.  0 (default) = contacts->capacity / 2 + 1024.  The reference has no such limit (its pair list lives in the

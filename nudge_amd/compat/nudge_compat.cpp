@@ -169,6 +169,7 @@ void collide(ActiveBodies* active_bodies, ContactData* contacts, BodyData bodies
 	const uint32_t nbox = colliders.boxes.count, nsph = colliders.spheres.count, K = contacts->capacity;
 
 	nh_BodyData db = device_bodies(s, bodies, true, false, false, true);
+	check(nh_bodies_changed(s.ctx), "bodies_changed");       // idle counters come from the caller's host array every step
 	upload_tags16(s, s.box_tags, colliders.boxes.tags, nbox);
 	upload(s.box_data, colliders.boxes.data, sizeof(BoxCollider) * nbox);
 	upload(s.box_xf, colliders.boxes.transforms, sizeof(Transform) * nbox);

@@ -751,8 +751,11 @@ __global__ __launch_bounds__(256) void k_active_flags(const nh_DevState* __restr
 }
 
 __global__ __launch_bounds__(256) void k_active_write(nh_DevState* __restrict__ st, uint32_t nbodies, const uint32_t* __restrict__ root_of, const uint32_t* __restrict__ set_active,
-                                                      const uint32_t* __restrict__ scan, uint32_t* __restrict__ indices, uint32_t capacity, uint32_t parity) {
-	if (!st->any_idle[parity]) {
+                                                      const uint32_t* __restrict__ scan, uint32_t* __restrict__ indices, uint32_t capacity, uint32_t parity, uint32_t no_islands) {
+	// `no_islands`: the host ruled out sleepers and launched no island kernel; if the device disagrees the idle counters were changed behind
+	// the library's back (nh_bodies_changed): reported, and the step falls back to "everybody active" instead of reading unset arrays
+	if (st->stale_hint && blockIdx.x == 0 && threadIdx.x == 0) { st->error = NH_ERR_STALE_HINT; st->stale_hint = 0; }
+	if (no_islands || !st->any_idle[parity]) {
 		// nobody sleeps: the active list is every body but the static world, ascending (nudge.cpp:3966-3971 with all sets active)
 		for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x + 1u; i < nbodies; i += gridDim.x * blockDim.x) {
 			if (i - 1u < capacity) indices[i - 1u] = i; else st->error = NH_ERR_ACTIVE_CAPACITY;
@@ -896,11 +899,22 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 // union-find over the contact records -- expensive when millions of bodies form one island -- is skipped.  The flag is double
 // buffered by step parity: this step's launch sets any_idle[parity] with plain stores and clears the other one for the next step.
 __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t ncolliders, uint32_t nbodies, uint32_t* __restrict__ parent, uint32_t* __restrict__ set_active, uint32_t* __restrict__ deg,
-                                                       const uint8_t* __restrict__ idle, uint32_t parity, uint32_t* __restrict__ coarse_parent, uint32_t* __restrict__ coarse_active) {
+                                                       const uint8_t* __restrict__ idle, uint32_t parity, uint32_t* __restrict__ coarse_parent, uint32_t* __restrict__ coarse_active, uint32_t no_islands) {
+	// `no_islands`: the host has ruled out that anybody is asleep this step (nh_collide): no island kernel will run, their arrays stay untouched
 	bool asleep = false;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) { parent[i] = i; set_active[i] = 0; coarse_parent[i] = i; coarse_active[i] = 0; asleep |= i >= 1 && idle[i] == 0xff; }
-	if (asleep) st->any_idle[parity] = 1;
-	if (blockIdx.x == 0 && threadIdx.x == 0) st->any_idle[parity ^ 1u] = 0;
+	uint32_t top = 0;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) {
+		if (!no_islands) { parent[i] = i; set_active[i] = 0; coarse_parent[i] = i; coarse_active[i] = 0; }
+		const uint32_t c = i >= 1 ? idle[i] : 0u;
+		top = max(top, c);
+		asleep |= c == 0xffu;
+	}
+	// (asleep although the host ruled it out: a broken promise, see nh_bodies_changed.  The step then runs as if nobody slept -- every kernel keyed
+	// on any_idle stays off the unset island arrays -- and k_active_write reports NH_ERR_STALE_HINT)
+	if (asleep) { if (no_islands) st->stale_hint = 1; else st->any_idle[parity] = 1; }
+	for (int d = 32; d >= 1; d >>= 1) top = max(top, (uint32_t)__shfl_xor((int)top, d));
+	if (nh_lane() == 0 && top > st->max_idle[parity]) atomicMax(&st->max_idle[parity], top);      // (a plain read first: most waves bring nothing new)
+	if (blockIdx.x == 0 && threadIdx.x == 0) { st->any_idle[parity ^ 1u] = 0; st->max_idle[parity ^ 1u] = 0; }
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < 3u * (nbodies + 2u); i += gridDim.x * blockDim.x) deg[i] = 0;      // degrees, fill cursors, pair info
 	if (blockIdx.x != 0) return;
 	uint32_t t = threadIdx.x;
@@ -923,6 +937,10 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	ctx->step_parity ^= 1u;
 	ctx->collide_seq++;
+	ctx->collide_mark = ctx->advance_count;
+	// can anybody be asleep?  (counters rise by at most one per nh_advance since the nh_collide that measured them)
+	const bool no_islands = ctx->idle_bound >= 0 && (uint64_t)ctx->idle_bound + (ctx->advance_count - ctx->idle_bound_mark) < 0xffu;
+	ctx->islands_skipped = no_islands;
 	nh_DevState* st = ctx->d_state;
 	const uint32_t nbox = colliders->boxes.count, nsph = colliders->spheres.count;
 	const uint32_t C = nbox + nsph;
@@ -1001,7 +1019,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->sort_counts, 0, sizeof(uint32_t) * nbk, s));
 		ctx->sort_capacity = pair_cap;
 	}
-	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, nh_grid_for(B, 256, 2048), 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity, coarse_parent, coarse_active);
+	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, nh_grid_for(B, 256, 2048), 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity, coarse_parent, coarse_active, no_islands ? 1u : 0u);
 	if (C) {
 		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 1024, 256), 1024, st, bodies->transforms,
 		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
@@ -1016,9 +1034,9 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, 2048, 256, st, nbox, sbox, cstart, large_list, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
 		// coarse islands over the broadphase pairs (united where the pairs were emitted) + connections: only when some body is asleep (a device
 		// flag: the kernels leave at once otherwise)
-		if (body_connections && body_connections->count)
+		if (!no_islands && body_connections && body_connections->count)
 			NH_LAUNCH(ctx, "uf_union_connections", k_uf_union_connections, nh_grid_for(body_connections->count, 256, 512), 256, st, body_connections->data, body_connections->count, coarse_parent, ctx->step_parity, bodies->idle_counters);
-		NH_LAUNCH(ctx, "coarse_flatten", k_uf_flatten, nh_grid_for(B, 256, 512), 256, st, ctx->step_parity, B, coarse_parent, bodies->idle_counters, coarse_active, coarse_root);
+		if (!no_islands) NH_LAUNCH(ctx, "coarse_flatten", k_uf_flatten, nh_grid_for(B, 256, 512), 256, st, ctx->step_parity, B, coarse_parent, bodies->idle_counters, coarse_active, coarse_root);
 		// box-box pairs and pairs with a sphere are separate lists (emit_pair): one launch each, each running one kind of arithmetic.
 		// (the host does not know the counts: a launch over a list that turns out empty costs a few microseconds, so the launch for a
 		// shape the world does not contain is skipped outright)
@@ -1036,25 +1054,25 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	// (only while the side chain is small: the radix passes spin-wait on each other and must not share the machine with a long
 	// kernel -- with millions of records in one island the union-find alone takes a millisecond)
 	const bool seeded_sort = onesweep && ctx->sort_seeded && !ctx->env_sort_radix;      // (NH_SORT_RADIX=1: radix passes every step)
-	const bool fork = ctx->side != nullptr && (seeded_sort || ctx->h_state->records <= 1500000u);
+	const bool fork = !no_islands && ctx->side != nullptr && (seeded_sort || ctx->h_state->records <= 1500000u);
 	hipStream_t main_stream = ctx->stream;
 	if (fork) {
 		NH_HIP_CHECK(ctx, hipEventRecord(ctx->ev_fork, main_stream));
 		NH_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
 		ctx->stream = ctx->side;
 	}
-	if (body_connections && body_connections->count)
-		NH_LAUNCH(ctx, "uf_union_connections", k_uf_union_connections, nh_grid_for(body_connections->count, 256, 2048), 256, st, body_connections->data, body_connections->count, parent, ctx->step_parity, bodies->idle_counters);
-	NH_LAUNCH(ctx, "uf_union_records", k_uf_union_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, parent, ctx->step_parity, bodies->idle_counters);
-	NH_LAUNCH(ctx, "uf_flatten", k_uf_flatten, nh_grid_for(B, 256, 2048), 256, st, ctx->step_parity, B, parent, bodies->idle_counters, set_active, root_of);
-	NH_LAUNCH(ctx, "active_flags", k_active_flags, nh_grid_for(B, 256, 2048), 256, st, ctx->step_parity, B, root_of, set_active, flags);
-	{
+	if (!no_islands) {
+		if (body_connections && body_connections->count)
+			NH_LAUNCH(ctx, "uf_union_connections", k_uf_union_connections, nh_grid_for(body_connections->count, 256, 2048), 256, st, body_connections->data, body_connections->count, parent, ctx->step_parity, bodies->idle_counters);
+		NH_LAUNCH(ctx, "uf_union_records", k_uf_union_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, parent, ctx->step_parity, bodies->idle_counters);
+		NH_LAUNCH(ctx, "uf_flatten", k_uf_flatten, nh_grid_for(B, 256, 2048), 256, st, ctx->step_parity, B, parent, bodies->idle_counters, set_active, root_of);
+		NH_LAUNCH(ctx, "active_flags", k_active_flags, nh_grid_for(B, 256, 2048), 256, st, ctx->step_parity, B, root_of, set_active, flags);
 		// number of bodies is known on the host: reuse the device-count scan with a constant count of 0 + extra
-		static_assert(sizeof(uint32_t) == 4, "");
 		nh_scan_u32(ctx, flags, flags, &st->pad0 /* always 0 */, B, scan_tmp, &st->active, &st->any_idle[ctx->step_parity]);    // (skipped on the device when nobody sleeps)
 	}
-	NH_LAUNCH(ctx, "active_write", k_active_write, nh_grid_for(B, 256, 2048), 256, st, B, root_of, set_active, flags, active_bodies->indices, active_bodies->capacity, ctx->step_parity);
-	NH_LAUNCH(ctx, "filter_records", k_filter_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, root_of, set_active, ctx->step_parity);
+	// (nobody asleep -- known on the device, or already on the host: the active list is 1 .. B-1, written without looking at any set)
+	NH_LAUNCH(ctx, "active_write", k_active_write, nh_grid_for(B, 256, 2048), 256, st, B, root_of, set_active, flags, active_bodies->indices, active_bodies->capacity, ctx->step_parity, no_islands ? 1u : 0u);
+	if (!no_islands) NH_LAUNCH(ctx, "filter_records", k_filter_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, root_of, set_active, ctx->step_parity);
 	if (fork) {
 		ctx->stream = main_stream;
 		NH_HIP_CHECK(ctx, hipEventRecord(ctx->ev_join, ctx->side));

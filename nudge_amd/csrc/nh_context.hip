@@ -29,6 +29,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->step_parity = 0;
 	ctx->pair_capacity = 0;
 	ctx->collide_seq = 0; ctx->setup_seq = 0;
+	ctx->idle_bound = -1; ctx->advance_count = 0; ctx->collide_mark = 0; ctx->idle_bound_mark = 0; ctx->islands_skipped = false;
 	// NH_SORT_CLASSIC=1: three-kernel radix passes; NH_SORT_RADIX=1: radix passes every step (no seeded bucket sort);
 	// NH_COLOUR_JP=1: Jones-Plassmann colouring rounds.  Read here once, never on the step path.
 	ctx->env_sort_classic = getenv("NH_SORT_CLASSIC") != nullptr;
@@ -72,6 +73,8 @@ extern "C" void nh_destroy(nh_context* ctx) {
 extern "C" int nh_set_flags(nh_context* ctx, uint32_t flags) { if (!ctx) return NH_ERR_INVALID; ctx->flags = flags; return NH_OK; }
 extern "C" int nh_set_tag_bits(nh_context* ctx, uint32_t bits) { if (!ctx || bits < 1 || bits > 32) return NH_ERR_INVALID; ctx->tag_bits = bits; return NH_OK; }
 
+extern "C" int nh_bodies_changed(nh_context* ctx) { if (!ctx) return NH_ERR_INVALID; ctx->idle_bound = -1; return NH_OK; }
+
 extern "C" int nh_set_pair_capacity(nh_context* ctx, uint32_t pairs) { if (!ctx) return NH_ERR_INVALID; ctx->pair_capacity = pairs; return NH_OK; }
 
 extern "C" int nh_synchronize(nh_context* ctx) {
@@ -86,9 +89,10 @@ extern "C" int nh_synchronize(nh_context* ctx) {
 extern "C" int nh_read_counts(nh_context* ctx, nh_Counts* out) {
 	if (!ctx || !out) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
-	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, 23 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, 25 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 	const nh_DevState* h = ctx->h_state;
+	if (ctx->collide_seq) { ctx->idle_bound = (int)h->max_idle[ctx->step_parity]; ctx->idle_bound_mark = ctx->collide_mark; }      // what the last nh_collide saw
 	out->colliders = h->colliders; out->pairs = h->pairs + h->pairs_sph; out->contacts = h->contacts; out->sleeping_pairs = h->sleeping;
 	out->active_bodies = h->active; out->cache = h->cache; out->culled = h->culled; out->large_colliders = h->large;
 	out->general_contacts = h->general_contacts; out->levels = h->levels; out->error = h->error;
@@ -117,6 +121,7 @@ extern "C" const char* nh_error_string(int code) {
 	case NH_ERR_PAIR_CAPACITY: return "broadphase pair capacity exceeded";
 	case NH_ERR_HIP: return "HIP runtime error";
 	case NH_ERR_SCHEDULER_CAPACITY: return "exact-order scheduler replay out of open batches";
+	case NH_ERR_STALE_HINT: return "idle counters changed without nh_bodies_changed";
 	case NH_ERR_STALE_SETUP: return "setup_contact_constraints does not match the last collide";
 	default: return "unknown error";
 	}

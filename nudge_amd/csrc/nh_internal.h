@@ -44,7 +44,8 @@ struct nh_DevState {
 	uint32_t static_inert;                // body 0 has all-zero velocity, inverse mass and inverse inertia (nh_is_inert)
 	uint32_t has_pending;                 // some body needs the general adjacency build (k_adj_simple could not settle it)
 	uint32_t pairs_sph;                   // broadphase pairs with a sphere (they fill the pair list from the back; `pairs` counts the box-box ones)
-	// ---- (the 23 words above are what nh_read_counts mirrors to the host) ----
+	uint32_t max_idle[2];                 // by step parity: largest idle counter seen by this step's nh_collide (host-side sleep prediction, nh_collide)
+	// ---- (the 25 words above are what nh_read_counts mirrors to the host) ----
 	// scene bounds of AABB min corners, order-preserving uint encoding (atomicMin/Max)
 	uint32_t smin[3];
 	uint32_t smax[3];
@@ -64,7 +65,7 @@ struct nh_DevState {
 	uint32_t sort_buckets;        // buckets of this step's tag sort = splitters of the previous step + 1 (nh_util.hip, bucket sort)
 	uint32_t sort_buckets_next;   // written by this step's sort for the next one
 	uint32_t colour_cursor;       // append cursor of the colouring's list compaction (nh_solve.hip)
-	uint32_t xform_ticket;        // workgroups of k_xform that have published their bounds (the last one derives the grid; it resets the ticket)
+	uint32_t stale_hint;          // a body was asleep in a step for which the host had ruled that out (k_collide_begin -> k_active_write -> NH_ERR_STALE_HINT)
 	uint32_t order_conflict;      // exact-order mode: sequence number of the setup call whose closed-form schedule has a lane conflict (nh_solve.hip)
 };
 
@@ -104,6 +105,12 @@ struct nh_context {
 	uint32_t order_seq;
 	uint32_t pair_capacity;               // nh_set_pair_capacity; 0 = contacts->capacity / 2 + 1024
 	uint32_t collide_seq, setup_seq;      // one nh_setup_contact_constraints per nh_collide (NH_ERR_STALE_SETUP)
+	// Sleep prediction.  A body is asleep when its idle counter is saturated (0xff) and nh_advance raises a counter by at most one, so from the
+	// largest counter an earlier nh_collide saw (mirrored with the step's one round trip) the host knows how soon anybody CAN be asleep:
+	// until then the island / sleeping kernels are not launched at all.  idle_bound < 0: unknown (start, nh_bodies_changed, halo unpack).
+	int idle_bound;                       // largest idle counter at the nh_collide that `idle_bound_mark` belongs to
+	uint64_t advance_count, collide_mark, idle_bound_mark;     // nh_advance calls so far; their number at the last nh_collide / at the measuring one
+	bool islands_skipped;                 // the last nh_collide launched no island kernels (its prediction is checked on the device: NH_ERR_STALE_HINT)
 	// behaviour switches read ONCE from the environment by nh_create (test / A-B knobs, see nh_context.hip)
 	bool env_sort_classic, env_sort_radix, env_colour_jp;
 	int os_resident;                      // co-resident workgroups of a one-kernel radix pass on THIS device (nh_util.hip), 0 = not yet asked

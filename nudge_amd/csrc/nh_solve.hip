@@ -804,7 +804,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
 	// simple[x] -- one load next to the body state instead of the dependent chain off[x] -> adj[] -> contact
 	constexpr int M = MAXC;
 	// launched before the host knew whether body 0 is inert: if it is not, the general kernels take these bodies after the round trip
-	if (require_inert && !cv.st->static_inert) return;
+	// `require_inert`: bit 0 -- launched before the host knew whether body 0 is inert (leave if it is not); bit 1 -- NH_FLAG_SINGLE_APPLY: no later
+	// nh_apply_impulses will continue from the solver states, so they are not stored
+	const bool keep_states = !(require_inert & 2u);
+	if ((require_inert & 1u) && !cv.st->static_inert) return;
 	__shared__ nh_ob_slot s_slot[4][64 * M];
 	__shared__ uint32_t s_cid[4][64 * M];
 	__shared__ uint32_t s_hint[4][64], s_first[4][64];
@@ -919,7 +922,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
 			const uint32_t e = 64u * k + lane;
 			const uint32_t c = scid[e];
 			if (c != 0xFFFFFFFFu) {
-				states[c] = slot[e].c0;
+				if (keep_states) states[c] = slot[e].c0;
 				*reinterpret_cast<float4*>(impulses + c) = slot[e].c1;
 			}
 		}
@@ -1347,6 +1350,7 @@ extern "C" int nh_apply_gravity_damping(nh_context* ctx, const nh_ActiveBodies* 
 extern "C" int nh_advance(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_BodyData* bodies, float time_step) {
 	if (!ctx || !active_bodies || !bodies) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	ctx->advance_count++;
 	NH_LAUNCH(ctx, "advance", k_advance, nh_grid_for(bodies->count, 256, 2048), 256, ctx->d_state, active_bodies->indices, bodies->transforms,
 	          bodies->momentum, bodies->idle_counters, time_step);
 	return NH_OK;
@@ -1639,7 +1643,8 @@ static void launch_apply_static(nh_context* ctx, nh_ContactConstraintData* d, co
 	};
 	auto go1 = [&](const char* name, auto kernel, uint32_t cls_a, uint32_t cls_b) {
 		NH_LAUNCH(ctx, name, kernel, nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
-		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, cls_a, cls_b, 0u, (const uint2*)nullptr);
+		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, cls_a, cls_b,
+		          (fused && (ctx->flags & NH_FLAG_SINGLE_APPLY)) ? 2u : 0u, (const uint2*)nullptr);
 	};
 	const bool late = d->has_late;
 	if (d->static_inert) {
@@ -1672,7 +1677,8 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 		const uint32_t B = d->body_count;
 		nh_CacheView cv = { d->imp->tags, d->imp->features, d->imp->ctags, d->imp->cfeatures, d->imp->cdata, ctx->d_state };
 		NH_LAUNCH(ctx, "solve_one_body", (k_solve_one_body<4, true, true>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
-		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 1u, d->simple);
+		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4,
+		          1u | ((ctx->flags & NH_FLAG_SINGLE_APPLY) ? 2u : 0u), d->simple);
 		int rc = finish_setup(ctx, d);
 		if (rc) return rc;
 		early4_done = d->static_inert;          // (if body 0 is not inert the speculative launch left at once and the general kernels take everything)
@@ -1696,6 +1702,7 @@ extern "C" int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* d, c
 	if (!ctx || !d || !bodies) return NH_ERR_INVALID;
 	if (ctx->pending && ctx->pending != d) { int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	const bool first = d->setup_pending;
+	if (!first && (ctx->flags & NH_FLAG_SINGLE_APPLY)) return NH_ERR_INVALID;      // the states of the first call were not kept
 	d->setup_pending = false;
 	ctx->pending = nullptr;
 	if (first) { int rc = first_apply(ctx, d, bodies, iterations); if (rc) return rc; }
@@ -1764,6 +1771,7 @@ extern "C" int nh_halo_pack(nh_context* ctx, const nh_BodyData* bodies, const ui
 extern "C" int nh_halo_unpack(nh_context* ctx, const nh_BodyData* bodies, uint32_t first_slot, uint32_t count, const void* in) {
 	if (!ctx || !bodies || (count && !in) || (uint64_t)first_slot + count > bodies->count) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	if (count) ctx->idle_bound = -1;             // idle counters arrive from another world: nothing is known about them until the next nh_collide has looked
 	if (count) NH_LAUNCH(ctx, "halo_unpack", k_halo_unpack, nh_grid_for(count, 256, 1024), 256, bodies->transforms, bodies->momentum, bodies->idle_counters, first_slot, count, (const nh_HaloRecord*)in);
 	return NH_OK;
 }

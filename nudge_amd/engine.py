@@ -24,10 +24,11 @@ _LIB = None
 
 NH_FLAG_SYNC_COUNTS = 1
 NH_FLAG_EXACT_ORDER = 2
+NH_FLAG_SINGLE_APPLY = 4
 
 EXPORTS = [
     "nh_create", "nh_destroy", "nh_set_flags", "nh_synchronize", "nh_read_counts", "nh_set_cache_count",
-    "nh_set_tag_bits", "nh_set_pair_capacity", "nh_error_string", "nh_last_hip_error", "nh_collide", "nh_apply_gravity_damping",
+    "nh_set_tag_bits", "nh_set_pair_capacity", "nh_bodies_changed", "nh_error_string", "nh_last_hip_error", "nh_collide", "nh_apply_gravity_damping",
     "nh_read_cached_impulses", "nh_write_cached_impulses", "nh_setup_contact_constraints", "nh_apply_impulses",
     "nh_update_cached_impulses", "nh_advance", "nh_contact_impulses_device", "nh_enable_timing", "nh_set_timing_filter", "nh_kernel_times",
     "nh_halo_pack", "nh_halo_unpack",
@@ -102,6 +103,7 @@ def lib():
         L.nh_set_flags.argtypes = [C.c_void_p, C.c_uint32]
         L.nh_set_tag_bits.argtypes = [C.c_void_p, C.c_uint32]
         L.nh_set_pair_capacity.argtypes = [C.c_void_p, C.c_uint32]
+        L.nh_bodies_changed.argtypes = [C.c_void_p]
         L.nh_synchronize.argtypes = [C.c_void_p]
         L.nh_read_counts.argtypes = [C.c_void_p, C.POINTER(Counts)]
         L.nh_set_cache_count.argtypes = [C.c_void_p, C.c_uint32]
@@ -289,6 +291,7 @@ class World:
         self.synchronize()
         for k, t in snap["arrays"].items():
             self._keep[k].copy_(t)
+        self.L.nh_bodies_changed(self.ctx)
         _check(self.L, self.L.nh_set_cache_count(self.ctx, snap["cache_count"]), "set_cache_count")
 
     # ---- variable membership (partitioned worlds) ----
@@ -297,6 +300,7 @@ class World:
         if bodies > c["bodies"] or boxes > c["boxes"] or spheres > c["spheres"]:
             raise NudgeError(f"set_counts({bodies}, {boxes}, {spheres}) exceeds the capacity {c}")
         self.nb, self.nbox, self.nsph = bodies, boxes, spheres
+        self.L.nh_bodies_changed(self.ctx)            # (the caller has rewritten body records, idle counters included)
         self.bodies.count = bodies
         self.colliders.boxes.count = boxes
         self.colliders.spheres.count = spheres
@@ -347,6 +351,8 @@ class World:
             if arr is not None:
                 raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
                 self._keep[name][:raw.size] = torch.from_numpy(raw.copy()).to(self.dev)
+        if idle is not None:
+            self.L.nh_bodies_changed(self.ctx)
 
     def get_contacts(self):
         c = self.counts()

@@ -53,7 +53,7 @@ def _tiled_reference(scene, n_tiles, steps):
 
 def _union_vs_tiled_reference(scene, n_tiles, steps, sample_tiles):
     n = len(scene["body_transforms"]) - 1
-    w = E.World(scene, flags=0, max_contacts=6 * n)            # the bench's mode: one host round trip per step
+    w = E.World(scene, flags=E.NH_FLAG_SINGLE_APPLY, max_contacts=6 * n)            # the bench's mode: one host round trip per step, one apply call per step
     w.step(steps)
     c = w.counts()
     assert c["error"] == 0
@@ -86,7 +86,7 @@ def _union_vs_tiled_reference(scene, n_tiles, steps, sample_tiles):
     # the two-part bound on sampled tiles: GPU(tile) == reference(tile) bit for bit, GPU(union) vs GPU(tile) within the bar
     for t in sample_tiles:
         sub, body_map = S.extract_tile(scene, t)
-        wt = E.World(sub, flags=0)
+        wt = E.World(sub, flags=E.NH_FLAG_SINGLE_APPLY)
         wt.step(steps)
         tb, rb = wt.get_bodies(), worlds[t].bodies()
         wt.close()
@@ -188,7 +188,7 @@ def test_c4_column_of_160_layers_default_order_vs_reference():
     checkpoints = (150, 300, 450, 600, 800)
     ref = _reference_pit(7, 160, 7, 14, checkpoints)
     scene = S.ball_pit(7, 160, 7, seed=14)
-    w = E.World(scene, flags=0, max_contacts=8 * 7840, max_pairs=10 * 7840)
+    w = E.World(scene, flags=E.NH_FLAG_SINGLE_APPLY, max_contacts=8 * 7840, max_pairs=10 * 7840)
     done = 0
     for s in checkpoints:
         w.step(s - done); done = s
@@ -217,7 +217,7 @@ def test_c4_four_million_sphere_pit_invariants_default_order():
     scene = S.ball_pit(160, 160, 160, seed=4)
     nb = len(scene["body_transforms"]) - 1
     assert nb == 4096000
-    w = E.World(scene, flags=0, max_contacts=5 * nb, max_pairs=7 * nb)
+    w = E.World(scene, flags=E.NH_FLAG_SINGLE_APPLY, max_contacts=5 * nb, max_pairs=7 * nb)
     done, kes, g = 0, [], None
     for s in checkpoints:
         w.step(s - done); done = s

@@ -372,6 +372,40 @@ def test_pair_capacity_is_independent_of_contact_capacity():
     w.close()
 
 
+def test_idle_counters_written_behind_the_librarys_back_are_reported():
+    """The host predicts when a body can first be asleep and launches no island kernels before that (nh_collide); idle counters written
+    from outside without nh_bodies_changed break the prediction: NH_ERR_STALE_HINT, not a silently wrong active list."""
+    scene, _ = G.build("grid30_awake")
+    w = E.World(scene, flags=FAST)
+    w.step(75)                                   # everybody landed and awake; the largest idle counter is far from 0xff
+    assert w.counts()["active_bodies"] == len(scene["body_transforms"]) - 1
+    w._keep["bi"][5] = 255                       # put body 5 to sleep without telling anybody
+    with pytest.raises(E.NudgeError, match="idle counters"):
+        w.step(1)
+    w.step(3)                                    # the failed step has looked at the counters: the library is back in sync
+    assert w.counts()["error"] == 0
+    b = w.get_bodies()
+    idle = b["idle"].copy(); idle[7] = 255
+    w.set_bodies(idle=idle)                      # the engine wrapper calls nh_bodies_changed
+    w.step(2)
+    assert w.counts()["error"] == 0
+    w.close()
+
+
+def test_single_apply_flag_gives_identical_results_and_refuses_a_second_apply():
+    scene, _ = G.build("grid30_awake")
+    a, b = E.World(scene, flags=0), E.World(scene, flags=E.NH_FLAG_SINGLE_APPLY)
+    a.step(90); b.step(90)
+    x, y = a.get_bodies(), b.get_bodies()
+    assert P.bits_equal(x["transforms"], y["transforms"]) and P.bits_equal(x["momentum"], y["momentum"])
+    ca, cb = a.get_cache(), b.get_cache()
+    assert ca["count"] == cb["count"] > 0 and P.bits_equal(ca["data"]["impulse"], cb["data"]["impulse"])
+    b.collide(); b.gravity(); b.read_cache(); b.setup(); b.apply(4)
+    with pytest.raises(E.NudgeError, match="invalid"):
+        b.apply(4)
+    a.close(); b.close()
+
+
 # ---- degenerate inputs ------------------------------------------------------------------------------------------------------------
 def _tiny_scene(n_boxes, n_spheres, apart=True):
     scene = S.pile(n_boxes=max(n_boxes, 1), n_spheres=n_spheres, seed=3)
