@@ -326,15 +326,16 @@ __device__ __forceinline__ void flush_pairs(nh_DevState* st, uint2* pairs, uint3
 
 // final flush once per workgroup, not once per wave (every wave ends with a partly filled stage)
 __device__ __forceinline__ void flush_pairs_block(nh_DevState* st, uint2* pairs, uint32_t pair_cap, pair_stage& ps) {
-	__shared__ uint32_t wave_bb[4], wave_sph[4];
+	__shared__ uint32_t wave_bb[8], wave_sph[8];            // (workgroups of up to 8 waves)
 	__shared__ uint32_t block_bb, block_sph;
+	const uint32_t nwaves = blockDim.x >> 6;
 	__builtin_amdgcn_wave_barrier();
 	uint32_t n_bb, n_sph;
 	count_staged(ps, n_bb, n_sph);
 	if (nh_lane() == 0) { wave_bb[threadIdx.x >> 6] = n_bb; wave_sph[threadIdx.x >> 6] = n_sph; }
 	__syncthreads();
-	if (threadIdx.x == 0) { const uint32_t t = wave_bb[0] + wave_bb[1] + wave_bb[2] + wave_bb[3]; block_bb = t ? atomicAdd(&st->pairs, t) : 0u; }
-	if (threadIdx.x == 64) { const uint32_t t = wave_sph[0] + wave_sph[1] + wave_sph[2] + wave_sph[3]; block_sph = t ? atomicAdd(&st->pairs_sph, t) : 0u; }
+	if (threadIdx.x == 0) { uint32_t t = 0; for (uint32_t w = 0; w < nwaves; ++w) t += wave_bb[w]; block_bb = t ? atomicAdd(&st->pairs, t) : 0u; }
+	if (threadIdx.x == 64) { uint32_t t = 0; for (uint32_t w = 0; w < nwaves; ++w) t += wave_sph[w]; block_sph = t ? atomicAdd(&st->pairs_sph, t) : 0u; }
 	__syncthreads();
 	uint32_t base_bb = block_bb, base_sph = block_sph;
 	for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) { base_bb += wave_bb[w]; base_sph += wave_sph[w]; }
@@ -369,7 +370,9 @@ __device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_
 // each ONE contiguous range of the cell-sorted list (cells that are neighbours along x are neighbours in the table).  The ten table
 // reads go out together; the candidates are then taken FP_BATCH at a time with all their loads (two 16-byte AABB halves and the
 // Morton key) in flight at once: three or four memory round trips per lane instead of one per candidate.
-#define FP_BATCH 4
+#ifndef FP_BATCH
+#define FP_BATCH 2          // (A/B on one box, 1 M boxes: 2 -> 42 us, 4 -> 45 us)
+#endif
 __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st, uint32_t n, uint32_t nbox,
                                                     const uint32_t* __restrict__ keys, const float4* __restrict__ sbox,
                                                     const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
@@ -471,9 +474,13 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 // about LP_BLOCKS workgroups are active in all, so a large collider is cut into LP_BLOCKS / (number of large colliders) slices:
 // 8 for the 124 ground slabs of the drop scenes, 200 for the five walls of the ball pit (whose 25,000 cell rows each would
 // otherwise be walked one after the other by a handful of waves)
-#define LP_BLOCKS 1024u
+#ifndef LP_THREADS
+#define LP_THREADS 512              // threads per workgroup; LP_GRID workgroups are launched (A/B: 512 x 512 -> 21 us, 2048 x 256 -> 25 us at 1 M boxes:
+#define LP_GRID 512u                // every workgroup ends with one reservation on the same counter)
+#define LP_BLOCKS 512u
+#endif
 #define LP_WBUF 1024
-__global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ st, uint32_t nbox, const float4* __restrict__ sbox,
+__global__ __launch_bounds__(LP_THREADS) void k_large_pairs(nh_DevState* __restrict__ st, uint32_t nbox, const float4* __restrict__ sbox,
                                                      const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
                                                      const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
                                                      uint2* __restrict__ pairs, uint32_t pair_cap,
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ s
 	const uint32_t nlarge = st->large;
 	const float mscale = st->morton_scale;
 	const nh_f3 mmin = nh_make3(st->morton_min[0], st->morton_min[1], st->morton_min[2]);
-	__shared__ uint2 wave_buf[4][LP_WBUF];
+	__shared__ uint2 wave_buf[LP_THREADS / 64][LP_WBUF];
 	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u, LP_WBUF, nbox };
 	uint32_t slices = nlarge ? LP_BLOCKS / nlarge : 1u;
 	slices = min(max(slices, 1u), gridDim.x);
@@ -504,7 +511,7 @@ __global__ __launch_bounds__(256) void k_large_pairs(nh_DevState* __restrict__ s
 		const uint32_t wy = (uint32_t)(y1 - y0 + 1), wz = (uint32_t)(z1 - z0 + 1);
 		const uint32_t nrows = wy * wz;
 		const uint32_t lane = threadIdx.x & 63u;
-		for (uint32_t r = slice * 4u + (threadIdx.x >> 6); r < nrows; r += slices * 4u) {       // wave-uniform
+		for (uint32_t r = slice * (LP_THREADS / 64u) + (threadIdx.x >> 6); r < nrows; r += slices * (LP_THREADS / 64u)) {       // wave-uniform
 			const uint32_t cy = r % wy, cz = r / wy;
 			const uint32_t row = (uint32_t)(((z0 + (int)cz) * ny + (y0 + (int)cy)) * nx);
 			const uint32_t j0 = cstart[row + (uint32_t)x0], jend = cstart[row + (uint32_t)x1 + 1u];
@@ -751,7 +758,15 @@ __global__ __launch_bounds__(256) void k_active_flags(const nh_DevState* __restr
 }
 
 __global__ __launch_bounds__(256) void k_active_write(nh_DevState* __restrict__ st, uint32_t nbodies, const uint32_t* __restrict__ root_of, const uint32_t* __restrict__ set_active,
-                                                      const uint32_t* __restrict__ scan, uint32_t* __restrict__ indices, uint32_t capacity, uint32_t parity, uint32_t no_islands) {
+                                                      const uint32_t* __restrict__ scan, uint32_t* __restrict__ indices, uint32_t capacity, uint32_t parity, uint32_t no_islands,
+                                                      const uint32_t* __restrict__ block_top, uint32_t n_block_top) {
+	if (blockIdx.x == 0 && threadIdx.x < 64u) {
+		// largest idle counter seen by k_collide_begin's workgroups -> the counter block the host mirrors
+		uint32_t top = 0;
+		for (uint32_t k = threadIdx.x; k < n_block_top; k += 64u) top = max(top, block_top[k]);
+		for (int d = 32; d >= 1; d >>= 1) top = max(top, (uint32_t)__shfl_xor((int)top, d));
+		if (threadIdx.x == 0) st->max_idle[parity] = top;
+	}
 	// `no_islands`: the host ruled out sleepers and launched no island kernel; if the device disagrees the idle counters were changed behind
 	// the library's back (nh_bodies_changed): reported, and the step falls back to "everybody active" instead of reading unset arrays
 	if (st->stale_hint && blockIdx.x == 0 && threadIdx.x == 0) { st->error = NH_ERR_STALE_HINT; st->stale_hint = 0; }
@@ -899,7 +914,9 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 // union-find over the contact records -- expensive when millions of bodies form one island -- is skipped.  The flag is double
 // buffered by step parity: this step's launch sets any_idle[parity] with plain stores and clears the other one for the next step.
 __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t ncolliders, uint32_t nbodies, uint32_t* __restrict__ parent, uint32_t* __restrict__ set_active, uint32_t* __restrict__ deg,
-                                                       const uint8_t* __restrict__ idle, uint32_t parity, uint32_t* __restrict__ coarse_parent, uint32_t* __restrict__ coarse_active, uint32_t no_islands) {
+                                                       const uint8_t* __restrict__ idle, uint32_t parity, uint32_t* __restrict__ coarse_parent, uint32_t* __restrict__ coarse_active, uint32_t no_islands,
+                                                       uint32_t* __restrict__ block_top) {
+	__shared__ uint32_t s_top[4];
 	// `no_islands`: the host has ruled out that anybody is asleep this step (nh_collide): no island kernel will run, their arrays stay untouched
 	bool asleep = false;
 	uint32_t top = 0;
@@ -912,9 +929,13 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 	// (asleep although the host ruled it out: a broken promise, see nh_bodies_changed.  The step then runs as if nobody slept -- every kernel keyed
 	// on any_idle stays off the unset island arrays -- and k_active_write reports NH_ERR_STALE_HINT)
 	if (asleep) { if (no_islands) st->stale_hint = 1; else st->any_idle[parity] = 1; }
+	// largest idle counter of the world, for the host's sleep prediction: per workgroup here (plain stores: thousands of atomics on one
+	// address would cost ~12 ns each, serialised), finished by k_active_write
 	for (int d = 32; d >= 1; d >>= 1) top = max(top, (uint32_t)__shfl_xor((int)top, d));
-	if (nh_lane() == 0 && top > st->max_idle[parity]) atomicMax(&st->max_idle[parity], top);      // (a plain read first: most waves bring nothing new)
-	if (blockIdx.x == 0 && threadIdx.x == 0) { st->any_idle[parity ^ 1u] = 0; st->max_idle[parity ^ 1u] = 0; }
+	if (nh_lane() == 0) s_top[threadIdx.x >> 6] = top;
+	__syncthreads();
+	if (threadIdx.x == 0) block_top[blockIdx.x] = max(max(s_top[0], s_top[1]), max(s_top[2], s_top[3]));
+	if (blockIdx.x == 0 && threadIdx.x == 0) st->any_idle[parity ^ 1u] = 0;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < 3u * (nbodies + 2u); i += gridDim.x * blockDim.x) deg[i] = 0;      // degrees, fill cursors, pair info
 	if (blockIdx.x != 0) return;
 	uint32_t t = threadIdx.x;
@@ -995,6 +1016,8 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	uint32_t* coarse_parent = nh_arena_array<uint32_t>(A, B, &err);
 	uint32_t* coarse_active = nh_arena_array<uint32_t>(A, B, &err);
 	uint32_t* coarse_root = nh_arena_array<uint32_t>(A, B, &err);
+	const uint32_t begin_grid = nh_grid_for(B, 256, 2048);
+	uint32_t* block_top = nh_arena_array<uint32_t>(A, begin_grid, &err);
 	if (err) return err;
 
 	hipStream_t s = ctx->stream;
@@ -1019,7 +1042,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->sort_counts, 0, sizeof(uint32_t) * nbk, s));
 		ctx->sort_capacity = pair_cap;
 	}
-	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, nh_grid_for(B, 256, 2048), 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity, coarse_parent, coarse_active, no_islands ? 1u : 0u);
+	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, begin_grid, 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity, coarse_parent, coarse_active, no_islands ? 1u : 0u, block_top);
 	if (C) {
 		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 1024, 256), 1024, st, bodies->transforms,
 		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
@@ -1031,7 +1054,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_final, max_cells / CS_TILE, 256, cstart, cscan_sums, max_cells);
 		NH_LAUNCH(ctx, "cell_scatter", k_cell_scatter, nh_grid_for(C, 256, 2048), 256, st, C, keys_a, vals_a, cstart, aabb_min, aabb_max, keys_b, sbox);
 		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 4096), 256, st, C, nbox, keys_b, sbox, cstart, large_list, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
-		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, 2048, 256, st, nbox, sbox, cstart, large_list, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, LP_GRID, LP_THREADS, st, nbox, sbox, cstart, large_list, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
 		// coarse islands over the broadphase pairs (united where the pairs were emitted) + connections: only when some body is asleep (a device
 		// flag: the kernels leave at once otherwise)
 		if (!no_islands && body_connections && body_connections->count)
@@ -1071,7 +1094,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		nh_scan_u32(ctx, flags, flags, &st->pad0 /* always 0 */, B, scan_tmp, &st->active, &st->any_idle[ctx->step_parity]);    // (skipped on the device when nobody sleeps)
 	}
 	// (nobody asleep -- known on the device, or already on the host: the active list is 1 .. B-1, written without looking at any set)
-	NH_LAUNCH(ctx, "active_write", k_active_write, nh_grid_for(B, 256, 2048), 256, st, B, root_of, set_active, flags, active_bodies->indices, active_bodies->capacity, ctx->step_parity, no_islands ? 1u : 0u);
+	NH_LAUNCH(ctx, "active_write", k_active_write, nh_grid_for(B, 256, 2048), 256, st, B, root_of, set_active, flags, active_bodies->indices, active_bodies->capacity, ctx->step_parity, no_islands ? 1u : 0u, block_top, begin_grid);
 	if (!no_islands) NH_LAUNCH(ctx, "filter_records", k_filter_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, root_of, set_active, ctx->step_parity);
 	if (fork) {
 		ctx->stream = main_stream;
