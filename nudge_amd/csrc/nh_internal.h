@@ -162,6 +162,7 @@ struct nh_ContactConstraintData {
 	uint2* gpair;                         // per general contact, LEVEL order: body pair
 	float4* gstates;                      //   solver state (rows of general contacts are structure-of-float4 in `rows`, level order, stride = contact_capacity)
 	uint32_t level_off[NH_MAX_LEVELS + 2];// host copy of level offsets
+	uint32_t level_full[NH_MAX_LEVELS + 2];// host copy: the level / colour class holds a full (40-float) row, not only radial ones
 	uint32_t levels;
 	uint32_t general_contacts;
 	uint32_t contact_capacity;

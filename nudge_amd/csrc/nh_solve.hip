@@ -1238,7 +1238,8 @@ __device__ __forceinline__ void load_rowr_soa(const float4* __restrict__ rows4, 
 __global__ __launch_bounds__(256) void k_rows_general(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ order,
                                                       const nh_Contact* __restrict__ contacts, const nh_BodyPair* __restrict__ bodies,
                                                       const nh_Transform* __restrict__ xf, const nh_BodyProperties* __restrict__ props,
-                                                      float4* __restrict__ rows4, size_t stride, uint2* __restrict__ gpair, uint32_t allow_radial, uint32_t static_inert) {
+                                                      float4* __restrict__ rows4, size_t stride, uint2* __restrict__ gpair, uint32_t allow_radial, uint32_t static_inert,
+                                                      const uint32_t* __restrict__ level, uint32_t* __restrict__ level_has_full) {
 	uint32_t n = st->general_contacts;
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
 		uint32_t c = order[k];
@@ -1261,19 +1262,22 @@ __global__ __launch_bounds__(256) void k_rows_general(const nh_DevState* __restr
 			nh_row r;
 			nh_build_row(ci, apos, bpos, IA, IB, pa.w, pb.w, r);
 			store_row_soa(rows4, stride, k, r);
+			level_has_full[level[c]] = 1u;             // this level / colour class needs the kernel that knows full rows (plain store of a constant)
 		}
 		gpair[k] = make_uint2(p.a | (radial ? NH_RADIAL_BIT : 0u), p.b);
 	}
 }
 
-template<bool WARM>
+// RADIAL_ONLY: every contact of the class has a radial row (the host knows from k_rows_general's per-class flags): the kernel without the
+// 40-float path needs a third of the registers and runs at full occupancy -- what a gather / scatter bound sweep wants.
+template<bool WARM, bool RADIAL_ONLY = false>
 __global__ __launch_bounds__(256) void k_level_exec(const uint32_t* __restrict__ order, uint32_t begin, uint32_t end,
                                                     const uint2* __restrict__ gpair, const nh_CachedContactImpulse* __restrict__ cached,
                                                     nh_BodyMomentum* __restrict__ momentum,
                                                     const float4* __restrict__ rows4, size_t stride, float4* __restrict__ gstates) {
 	for (uint32_t k = begin + blockIdx.x * blockDim.x + threadIdx.x; k < end; k += gridDim.x * blockDim.x) {
 		uint2 p = gpair[k];
-		const bool radial = (p.x & NH_RADIAL_BIT) != 0u;
+		const bool radial = RADIAL_ONLY || (p.x & NH_RADIAL_BIT) != 0u;
 		p.x &= ~NH_RADIAL_BIT;
 		nh_vel a = load_vel_m(momentum, p.x), b = load_vel_m(momentum, p.y);
 		nh_state s;
@@ -1284,7 +1288,7 @@ __global__ __launch_bounds__(256) void k_level_exec(const uint32_t* __restrict__
 			nh_rowr r;
 			load_rowr_soa(rows4, stride, k, r);
 			if (WARM) nh_warm_start_r(r, w.x, w.y, w.z, a, b, s); else nh_apply_radial(r, s, a, b);
-		} else {
+		} else if (!RADIAL_ONLY) {
 			nh_row r;
 			load_row_soa(rows4, stride, k, r);
 			if (WARM) nh_warm_start(r, w.x, w.y, w.z, a, b, s); else nh_apply_one(r, s, a, b);
@@ -1480,7 +1484,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	const uint32_t spill_cap = slot_key ? (kcap / GR_BUCKETS + 1u < 8192u ? kcap / GR_BUCKETS + 1u : 8192u) : 0u;
 	uint2* spill_ab = slot_key ? nh_arena_array<uint2>(memory, (size_t)GR_BUCKETS * spill_cap * 8u, &err) : nullptr;
 	uint32_t* spill_idx = slot_key ? nh_arena_array<uint32_t>(memory, (size_t)GR_BUCKETS * spill_cap * 8u, &err) : nullptr;
-	uint32_t* level_hist = nh_arena_array<uint32_t>(memory, NH_MAX_LEVELS + 2, &err);
+	uint32_t* level_hist = nh_arena_array<uint32_t>(memory, 2 * (NH_MAX_LEVELS + 2), &err);       // [0, L+2): histogram -> offsets; [L+2, 2L+4): class has a full row
 	uint32_t* level_cursor = nh_arena_array<uint32_t>(memory, NH_MAX_LEVELS + 2, &err);
 	uint32_t* tmp = nh_arena_array<uint32_t>(memory, 2 * NH_SORT_GRID + 64, &err);
 	if (err) return err;
@@ -1611,18 +1615,23 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		}
 		if (c.levels > NH_MAX_LEVELS) return NH_ERR_INVALID;
 		d->levels = c.levels;
-		NH_LAUNCH(ctx, "zero_u32", k_zero_u32, 8, 256, level_hist, NH_MAX_LEVELS + 2);
+		NH_LAUNCH(ctx, "zero_u32", k_zero_u32, 8, 256, level_hist, 2 * (NH_MAX_LEVELS + 2));       // histogram + the per-class "has a full row" flags behind it
 		NH_LAUNCH(ctx, "level_hist", k_level_hist, nh_grid_for(G, 256, 512), 256, st, general_list, level, level_hist);
 		NH_LAUNCH(ctx, "level_offsets", k_level_offsets, 1, 1024, level_hist, level_cursor);
 		NH_LAUNCH(ctx, "level_scatter", k_level_scatter, nh_grid_for(G, 256, 512), 256, st, general_list, level, level_cursor, d->level_order);
 		NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, d->level_order, contacts->data, contacts->bodies, bodies->transforms, bodies->properties,
-		          (float4*)d->rows, (size_t)kcap, d->gpair, (ctx->flags & NH_FLAG_EXACT_ORDER) ? 0u : 1u, d->static_inert ? 1u : 0u);
+		          (float4*)d->rows, (size_t)kcap, d->gpair, (ctx->flags & NH_FLAG_EXACT_ORDER) ? 0u : 1u, d->static_inert ? 1u : 0u,
+		          level, level_hist + (NH_MAX_LEVELS + 2));
 		NH_HIP_CHECK(ctx, hipMemcpyAsync(d->level_off, level_hist, sizeof(uint32_t) * (d->levels + 2), hipMemcpyDeviceToHost, ctx->stream));
+		NH_HIP_CHECK(ctx, hipMemcpyAsync(d->level_full, level_hist + (NH_MAX_LEVELS + 2), sizeof(uint32_t) * (d->levels + 2), hipMemcpyDeviceToHost, ctx->stream));
 		NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 		// warm start in level order (levels are numbered from 1)
 		for (uint32_t l = 1; l <= d->levels; ++l) {
 			uint32_t b = d->level_off[l], e = d->level_off[l + 1];
-			if (e > b)
+			if (e > b && !d->level_full[l])
+				NH_LAUNCH(ctx, "warm_level", (k_level_exec<true, true>), nh_grid_for(e - b, 256, 8192), 256, d->level_order, b, e, d->gpair, imp->data,
+				          bodies->momentum, (const float4*)d->rows, (size_t)kcap, d->gstates);
+			else if (e > b)
 				NH_LAUNCH(ctx, "warm_level", (k_level_exec<true>), nh_grid_for(e - b, 256, 4096), 256, d->level_order, b, e, d->gpair, imp->data,
 				          bodies->momentum, (const float4*)d->rows, (size_t)kcap, d->gstates);
 		}
