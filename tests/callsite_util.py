@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REPLAY_REF = os.path.join(ROOT, "oracle", "_ref", "replay_ref")                      # replay.cpp + the reference's nudge.cpp (checker)
 REPLAY_HIP = os.path.join(ROOT, "nudge_amd", "compat", "_build", "replay_hip")       # replay.cpp + the C++ drop-in + libnudge_hip.so
 RESIDENT_REPLAY = os.path.join(ROOT, "nudge_amd", "resident_replay")                          # examples/resident_replay.cpp: C++ host on the device-resident C ABI
+PARTITION_RCCL = os.path.join(ROOT, "nudge_amd", "partition_rccl")                            # examples/partition_rccl.cpp: C++ host of the multi-GPU path (RCCL)
 REF_TESTS_HIP = os.path.join(ROOT, "nudge_amd", "compat", "_build", "ref_tests_hip")  # the reference's own tests/main.cpp on the GPU backend
 
 

@@ -119,3 +119,16 @@ def test_cpp_host_on_the_resident_abi_matches_reference(name, tmp_path):
     assert P.bits_equal(got["momentum"], b["momentum"])
     assert P.bits_equal(got["idle"], b["idle"])
     assert got["sum_contacts"] == w.sum_contacts()
+
+
+@pytest.mark.gpu
+def test_cpp_rccl_host_runs_a_slab_on_one_gpu():
+    """examples/partition_rccl.cpp (C++ host of the multi-GPU path: x-slabs, ghost halo exchange with ncclSend / ncclRecv on the records of
+    nh_halo_pack / nh_halo_unpack) with WORLD_SIZE = 1: the whole world is one slab, nothing is exchanged -- what a one-GPU box can check is that the
+    program builds against RCCL, generates and steps its world, and that every box has landed on four contacts.  (Its communication path
+    needs one GPU per rank: RCCL refuses two ranks on one device.)"""
+    assert os.path.exists(CU.PARTITION_RCCL), "nudge_amd/partition_rccl missing: make -C nudge_amd/csrc"
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([CU.PARTITION_RCCL, "3", "2", "24", "90"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "3456 owned + 0 ghost bodies" in r.stdout and "(4.000 per owned+ghost body)" in r.stdout, r.stdout

@@ -116,3 +116,21 @@ def test_gloo_ranks_match_single_world(tmp_path, world):
     z = np.load(out)
     assert int(z["ghosts"]) > 0
     _check_against_single_world(_drop_scene(), dict(ids=z["ids"], transforms=z["transforms"], momentum=z["momentum"]), steps)
+
+
+def test_static_colliders_are_filtered_to_the_slab_and_its_neighbours():
+    """bench.py --gpus 8 cuts ONE 1984-tile world into 8 slabs; a rank keeps only the ground slabs that reach its own slab or a
+    neighbour's (`static_margin`), not all 1984 of them.  The partitioned world must still match the single world."""
+    import partition_util as PU
+    scene = S.grid_tiles(8, side=8, seed=17, lattice_cols=8)          # eight tiles in a row along x
+    ranks = 4
+    cuts = _cuts_through(scene, ranks)
+    parts, kept = [], []
+    for r in range(ranks):
+        local, info = PT.split_scene(scene, cuts, r, min_extra=256, static_margin=4.0)
+        kept.append(info["n_static_box"])
+        parts.append(PT.Partition(PU.OracleEngine(local, info["capacity"]), info, epoch=8))
+    assert kept[0] < 8 and kept[-1] < 8 and max(kept) <= 7 and min(kept) >= 3, kept      # own slab (2 tiles) + what the neighbours stand on
+    cl = PT.LocalCluster(parts)
+    cl.step(120)
+    _check_against_single_world(scene, cl.gather(), 120)
