@@ -1,0 +1,43 @@
+#!/bin/bash
+# profiles/collect.sh <tag> -- run ON THE GPU BOX (gpurun): collects what profiles/ holds for one build.
+#   bench lines (driver invocation, default, c3, c4), per-kernel tables, rocprofv3 --kernel-trace --stats of the driver invocation,
+#   two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass on gfx950) and the one-GPU rehearsal of the N = 2 path.
+# Raw output goes to gpurun_out/<tag>/ (scratch); the summaries are exported into gpurun_out/<tag>/export/ ready to be copied to profiles/.
+set -u
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O/export
+cd /tmp; export TMPDIR=/tmp
+python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/export/${TAG}_bench_driver_invocation.json 2> $O/bench_driver.err
+python $R/bench.py --profile-kernels > $O/export/${TAG}_bench_default.json 2> $O/export/${TAG}_bench_kernel_table.log
+python $R/bench.py --scene mixed --tiles 248 --no-cpu --profile-kernels > $O/export/${TAG}_bench_c3_mixed_2M.json 2> $O/export/${TAG}_bench_c3_kernel_table.log
+timeout 400 python $R/bench.py --scene pit --no-cpu --steps 10 --profile-kernels > $O/export/${TAG}_bench_c4_pit_4M_settled.json 2> $O/export/${TAG}_bench_c4_kernel_table.log
+# rocprofv3: kernel trace + stats of the driver's invocation
+rocprofv3 --kernel-trace --stats -d $O/prof -o stats -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu > $O/prof_bench.json 2> $O/prof.log
+DB=$(find $O/prof -name "*.db" | head -1)
+if [ -n "$DB" ]; then
+  python - "$O/prof_bench.json" "$DB" "$O/export/${TAG}_rocprofv3_kernel_stats.tsv" <<'PY'
+import json, subprocess, sys, os
+d = json.load(open(sys.argv[1]))
+c = d["config"]
+total = c["landed_after_steps"] + d["warmup"] + 3 + c["timed_steps"] + (c["timed_blocks"] - 1) * 0
+note = (f"python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu under rocprofv3 --kernel-trace --stats: {d['value']:.1f} steps/s, "
+        f"{c['timed_steps']} timed steps of {total} ({c['timed_window']})")
+root = os.path.dirname(os.path.dirname(os.path.abspath(sys.argv[3])))
+subprocess.check_call([sys.executable, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "profiles", "export_rocprof.py"), sys.argv[2], sys.argv[3], note, str(c["timed_steps"]), str(total)])
+PY
+fi
+# PMC passes (one block of the timed region is enough; counters serialise the kernels)
+for CNT in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $O/pmc -o $CNT -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --min-time 0 > $O/pmc_$CNT.json 2> $O/pmc_$CNT.log
+done
+F=$(find $O/pmc -name "FETCH_SIZE_counter_collection.csv" | head -1)
+if [ -n "$F" ]; then
+  D=$(dirname $F); W=$(find $O/pmc -name "WRITE_SIZE_counter_collection.csv" | head -1); [ "$(dirname $W)" != "$D" ] && cp $W $D/
+  python $R/profiles/export_pmc.py $D $O/export/${TAG}_pmc_traffic.json 20 > $O/export/${TAG}_pmc_traffic.log
+fi
+# N = 2 rehearsal on one GPU
+cd $R; timeout 600 tests/gpu_rehearsal_n2.sh > $O/rehearsal.out 2> $O/export/${TAG}_bench_n2_rehearsal_kernel_table.log
+grep '^{' $O/rehearsal.out | tail -1 > $O/export/${TAG}_bench_n2_rehearsal_one_gpu.json
+ls -la $O/export
