@@ -82,13 +82,11 @@ KERNEL_BYTES = {
 
 
 def grid_table_entries(C):
-    """Entries of the broadphase grid table for C colliders (nh_collide: a power of two >= 4 C, 2^16 .. 2^22 / 2^24)."""
+    """Entries of the broadphase grid table for C colliders (nh_collide: a power of two >= 4 C, 2^16 .. 2^24)."""
     want = 1
     while want < 4 * C:
         want <<= 1
     want = max(want, 1 << 16)
-    if want > (1 << 22) and C <= (1 << 22):
-        want = 1 << 22
     return min(want, 1 << 24)
 
 # timer name (nh_* launch sites) -> kernel symbol prefix in the rocprofv3 PMC export (profiles/export_pmc.py)

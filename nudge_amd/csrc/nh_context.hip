@@ -40,9 +40,10 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->h_state = nullptr;
 	if (hipMalloc((void**)&ctx->d_state, sizeof(nh_DevState)) != hipSuccess) { delete ctx; return NH_ERR_HIP; }
 	if (hipHostMalloc((void**)&ctx->h_state, sizeof(nh_DevState), 0) != hipSuccess) { hipFree(ctx->d_state); delete ctx; return NH_ERR_HIP; }
-	ctx->side = nullptr; ctx->ev_fork = nullptr; ctx->ev_join = nullptr;
+	ctx->side = nullptr; ctx->ev_fork = nullptr; ctx->ev_join = nullptr; ctx->ev_active = nullptr; ctx->ev_gravity = nullptr; ctx->gravity_may_overlap = false;
 	if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { ctx->side = nullptr; }       // no side stream: everything stays on the caller's
+	    hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_active, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&ctx->ev_gravity, hipEventDisableTiming) != hipSuccess) { ctx->side = nullptr; }       // no side stream: everything stays on the caller's
 	hipMemsetAsync(ctx->d_state, 0, sizeof(nh_DevState), ctx->stream);
 	hipStreamSynchronize(ctx->stream);
 	*out = ctx;
@@ -60,6 +61,8 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
 	if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
 	if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+	if (ctx->ev_active) hipEventDestroy(ctx->ev_active);
+	if (ctx->ev_gravity) hipEventDestroy(ctx->ev_gravity);
 	if (ctx->hint) hipFree(ctx->hint);
 	if (ctx->deg) hipFree(ctx->deg);
 	if (ctx->sort_splitters) hipFree(ctx->sort_splitters);

@@ -125,6 +125,11 @@ struct nh_context {
 	// fork/join inside one entry point: independent kernel chains run on `side` while the caller's stream does the long one
 	hipStream_t side;
 	hipEvent_t ev_fork, ev_join;
+	// gravity / damping beside the tag sort: nh_collide records `ev_active` right after the active list is written; an nh_apply_gravity_damping
+	// that FOLLOWS nh_collide directly (gravity_may_overlap) runs on the side stream behind that event -- concurrently with the sort / gather
+	// chain still queued on the caller's stream, which never touches momentum -- and the caller's stream waits for `ev_gravity`
+	hipEvent_t ev_active, ev_gravity;
+	bool gravity_may_overlap;
 };
 
 // Runs work that an earlier call deferred; every entry point that reads or writes momentum / impulses calls it first.

@@ -1344,10 +1344,21 @@ static nh_ContactConstraintData* new_constraint_data(nh_context* ctx) {
 extern "C" int nh_apply_gravity_damping(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_BodyData* bodies,
                                         float time_step, const float gravity[3], float damping_rate) {
 	if (!ctx || !active_bodies || !bodies || !gravity) return NH_ERR_INVALID;
+	const bool follows_collide = ctx->gravity_may_overlap;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	float damping = 1.0f - time_step * damping_rate;
+	// directly after nh_collide (the sample's loop, example/main.cpp:286-305): on the side stream, behind the kernel that wrote the active list and
+	// beside the tag sort / contact gather still queued on the caller's stream (they never touch momentum); the caller's stream then waits
+	const bool overlap = follows_collide && ctx->side != nullptr;
+	hipStream_t main_stream = ctx->stream;
+	if (overlap) { NH_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_active, 0)); ctx->stream = ctx->side; }
 	NH_LAUNCH(ctx, "gravity_damping", k_gravity, nh_grid_for(bodies->count, 256, 2048), 256, ctx->d_state, active_bodies->indices, bodies->momentum,
 	          gravity[0] * time_step, gravity[1] * time_step, gravity[2] * time_step, damping);
+	if (overlap) {
+		ctx->stream = main_stream;
+		NH_HIP_CHECK(ctx, hipEventRecord(ctx->ev_gravity, ctx->side));
+		NH_HIP_CHECK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_gravity, 0));
+	}
 	return NH_OK;
 }
 
@@ -1697,6 +1708,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 }
 
 int nh_flush_pending(nh_context* ctx) {
+	ctx->gravity_may_overlap = false;            // some entry point other than nh_collide is enqueueing work: gravity no longer "directly follows" it
 	nh_ContactConstraintData* d = ctx->pending;
 	if (!d) return NH_OK;
 	ctx->pending = nullptr;
