@@ -35,6 +35,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->env_sort_classic = getenv("NH_SORT_CLASSIC") != nullptr;
 	ctx->env_sort_radix = getenv("NH_SORT_RADIX") != nullptr;
 	ctx->env_colour_jp = getenv("NH_COLOUR_JP") != nullptr;
+	ctx->env_no_resident = getenv("NH_NO_RESIDENT") != nullptr;      // NH_NO_RESIDENT=1: small general sets also take the one-launch-per-level path (A/B, tests)
 	ctx->os_resident = 0;
 	ctx->d_state = nullptr;
 	ctx->h_state = nullptr;

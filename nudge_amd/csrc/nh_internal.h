@@ -112,7 +112,7 @@ struct nh_context {
 	uint64_t advance_count, collide_mark, idle_bound_mark;     // nh_advance calls so far; their number at the last nh_collide / at the measuring one
 	bool islands_skipped;                 // the last nh_collide launched no island kernels (its prediction is checked on the device: NH_ERR_STALE_HINT)
 	// behaviour switches read ONCE from the environment by nh_create (test / A-B knobs, see nh_context.hip)
-	bool env_sort_classic, env_sort_radix, env_colour_jp;
+	bool env_sort_classic, env_sort_radix, env_colour_jp, env_no_resident;
 	int os_resident;                      // co-resident workgroups of a one-kernel radix pass on THIS device (nh_util.hip), 0 = not yet asked
 	// tag sort seeded by the previous step's order (nh_util.hip): splitters persist across steps; counts / starts are scratch that must
 	// outlive nothing but is zeroed by its own kernels.  `sort_seeded`: the splitters describe the previous nh_collide of this capacity
@@ -174,6 +174,8 @@ struct nh_ContactConstraintData {
 	uint32_t body_count;
 	uint32_t static_body_count;
 	bool has_static8, has_staticN, static_inert;
+	uint32_t resident_cap;                // its row stride in LDS (all rows radial: 1792, else 704)
+	bool resident;                        // the general set is small enough for the one-workgroup LDS-resident solver (k_solve_resident)
 	bool csr_ready;                       // body_off[] / adj[] hold the CSR adjacency (built on demand: ensure_csr in nh_solve.hip)
 	const nh_BodyPair* bodies;
 	// inputs kept for the one-body fast path, which rebuilds its rows in registers instead of storing them

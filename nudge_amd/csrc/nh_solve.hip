@@ -1299,6 +1299,75 @@ __global__ __launch_bounds__(256) void k_level_exec(const uint32_t* __restrict__
 	}
 }
 
+// ---- small general sets: ONE workgroup, constraint rows resident in LDS across the warm start and all sweeps ------------------------------------
+// The level / colour schedule needs a synchronisation between consecutive levels.  Across workgroups that is a kernel boundary (a device-wide
+// barrier costs more than one on this part); inside ONE workgroup it is __syncthreads().  So when the whole general set fits one compute unit's
+// LDS -- 704 rows of 160 B (or 1792 radial rows of 48 B), their states and body pairs: 155 KB of the 160 KB -- one workgroup loads the rows ONCE and walks
+// levels x sweeps with barriers only: the north star's "constraints staged in LDS across solver iterations".  Momentum stays in global memory:
+// the waves of a workgroup share their compute unit's L1, stores write through it, and __syncthreads() orders them -- the ordinary way a
+// workgroup communicates through global memory.  Arithmetic and order are exactly those of k_level_exec (levels in order, any order inside a level).
+#define NH_RES_MAX_FULL 704u            // general sets with a full (40-float) row: 10 x 704 sixteen-byte words of row storage
+#define NH_RES_MAX_RADIAL 1792u         // all rows radial (12 floats): 3 x 1792 words
+#define NH_RES_ROW_WORDS 7168u
+#define NH_RES_THREADS 1024
+__global__ __launch_bounds__(NH_RES_THREADS) void k_solve_resident(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ level_off, uint32_t levels,
+                                                                   const uint32_t* __restrict__ order, const uint2* __restrict__ gpair, const nh_CachedContactImpulse* __restrict__ cached,
+                                                                   nh_BodyMomentum* momentum, const float4* __restrict__ rows4, size_t stride, float4* __restrict__ gstates,
+                                                                   uint32_t iterations, uint32_t warm, uint32_t cap /* NH_RES_MAX_FULL or _RADIAL: the row stride in LDS */) {
+	__shared__ float4 s_rows[NH_RES_ROW_WORDS];          // chunk q of contact k at s_rows[q * cap + k]
+	__shared__ float4 s_state[NH_RES_MAX_RADIAL];
+	__shared__ uint2 s_pair[NH_RES_MAX_RADIAL];
+	const uint32_t G = min(st->general_contacts, cap);
+	for (uint32_t k = threadIdx.x; k < G; k += NH_RES_THREADS) {
+		const uint2 p = gpair[k];
+		s_pair[k] = p;
+		const uint32_t chunks = (p.x & NH_RADIAL_BIT) ? 3u : 10u;
+		for (uint32_t q = 0; q < chunks; ++q) s_rows[q * cap + k] = rows4[(size_t)q * stride + k];
+		s_state[k] = warm ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : gstates[k];
+	}
+	__syncthreads();
+	auto one = [&](uint32_t k, bool warm_start) {
+		uint2 p = s_pair[k];
+		const bool radial = (p.x & NH_RADIAL_BIT) != 0u;
+		p.x &= ~NH_RADIAL_BIT;
+		nh_vel a = load_vel_m(momentum, p.x), b = load_vel_m(momentum, p.y);
+		nh_state s;
+		float4 w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (warm_start) w = *reinterpret_cast<const float4*>(cached + order[k]);
+		else { const float4 sv = s_state[k]; s.normal = sv.x; s.friction_x = sv.y; s.friction_y = sv.z; }
+		if (radial) {
+			nh_rowr r;
+			float4* dst = reinterpret_cast<float4*>(&r);
+#pragma unroll
+			for (uint32_t q = 0; q < 3; ++q) dst[q] = s_rows[q * cap + k];
+			if (warm_start) nh_warm_start_r(r, w.x, w.y, w.z, a, b, s); else nh_apply_radial(r, s, a, b);
+		} else {
+			nh_row r;
+			float4* dst = reinterpret_cast<float4*>(&r);
+#pragma unroll
+			for (uint32_t q = 0; q < 10; ++q) dst[q] = s_rows[q * cap + k];
+			if (warm_start) nh_warm_start(r, w.x, w.y, w.z, a, b, s); else nh_apply_one(r, s, a, b);
+		}
+		s_state[k] = make_float4(s.normal, s.friction_x, s.friction_y, 0.0f);
+		if (p.x) store_vel_m(momentum, p.x, a);      // body 0 is the static world: never written
+		if (p.y) store_vel_m(momentum, p.y, b);
+	};
+	if (warm) {
+		for (uint32_t l = 1; l <= levels; ++l) {
+			const uint32_t b = level_off[l], e = min(level_off[l + 1], G);
+			for (uint32_t k = b + threadIdx.x; k < e; k += NH_RES_THREADS) one(k, true);
+			__syncthreads();
+		}
+	}
+	for (uint32_t it = 0; it < iterations; ++it)
+		for (uint32_t l = 1; l <= levels; ++l) {
+			const uint32_t b = level_off[l], e = min(level_off[l + 1], G);
+			for (uint32_t k = b + threadIdx.x; k < e; k += NH_RES_THREADS) one(k, false);
+			__syncthreads();
+		}
+	for (uint32_t k = threadIdx.x; k < G; k += NH_RES_THREADS) gstates[k] = s_state[k];
+}
+
 // ---- update_cached_impulses (nudge.cpp:4857-4884) --------------------------------------------------------------------------------
 // (contacts on the one-body fast path export their impulse at the end of every nh_apply_impulses call)
 __global__ __launch_bounds__(256) void k_update_impulses(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ order, const float4* __restrict__ rows4, size_t stride,
@@ -1636,6 +1705,17 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		NH_HIP_CHECK(ctx, hipMemcpyAsync(d->level_off, level_hist, sizeof(uint32_t) * (d->levels + 2), hipMemcpyDeviceToHost, ctx->stream));
 		NH_HIP_CHECK(ctx, hipMemcpyAsync(d->level_full, level_hist + (NH_MAX_LEVELS + 2), sizeof(uint32_t) * (d->levels + 2), hipMemcpyDeviceToHost, ctx->stream));
 		NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+		// A small general set (a pile of a few hundred boxes, a pit of a thousand balls) is solved by ONE workgroup with its rows resident in LDS for
+		// the warm start and all sweeps (k_solve_resident): one launch per nh_apply_impulses call instead of one per level and sweep
+		bool all_radial = true;
+		for (uint32_t l = 1; l <= d->levels; ++l) all_radial &= d->level_full[l] == 0u;
+		d->resident_cap = all_radial ? NH_RES_MAX_RADIAL : NH_RES_MAX_FULL;
+		d->resident = G <= d->resident_cap && !ctx->env_no_resident;
+		if (d->resident) {
+			NH_LAUNCH(ctx, "solve_resident", k_solve_resident, 1, NH_RES_THREADS, st, level_hist, d->levels, d->level_order, d->gpair, imp->data,
+			          bodies->momentum, (const float4*)d->rows, (size_t)kcap, d->gstates, 0u, 1u, d->resident_cap);
+			return NH_OK;
+		}
 		// warm start in level order (levels are numbered from 1)
 		for (uint32_t l = 1; l <= d->levels; ++l) {
 			uint32_t b = d->level_off[l], e = d->level_off[l + 1];
@@ -1728,11 +1808,19 @@ extern "C" int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* d, c
 	ctx->pending = nullptr;
 	if (first) { int rc = first_apply(ctx, d, bodies, iterations); if (rc) return rc; }
 	else launch_apply_static(ctx, d, bodies, iterations, false, false);
-	if (d->general_contacts) {
+	if (d->general_contacts && d->resident) {
+		// small general set: one workgroup, rows in LDS for all sweeps (k_solve_resident)
+		if (iterations)
+			NH_LAUNCH(ctx, "solve_resident", k_solve_resident, 1, NH_RES_THREADS, ctx->d_state, d->cont.level_hist, d->levels, d->level_order, d->gpair, (const nh_CachedContactImpulse*)nullptr,
+			          bodies->momentum, (const float4*)d->rows, (size_t)d->contact_capacity, d->gstates, iterations, 0u, d->resident_cap);
+	} else if (d->general_contacts) {
 		for (uint32_t it = 0; it < iterations; ++it)
 			for (uint32_t l = 1; l <= d->levels; ++l) {
 				uint32_t b = d->level_off[l], e = d->level_off[l + 1];
-				if (e > b)
+				if (e > b && !d->level_full[l])
+					NH_LAUNCH(ctx, "apply_level", (k_level_exec<false, true>), nh_grid_for(e - b, 256, 8192), 256, d->level_order, b, e, d->gpair, (const nh_CachedContactImpulse*)nullptr,
+					          bodies->momentum, (const float4*)d->rows, (size_t)d->contact_capacity, d->gstates);
+				else if (e > b)
 					NH_LAUNCH(ctx, "apply_level", (k_level_exec<false>), nh_grid_for(e - b, 256, 4096), 256, d->level_order, b, e, d->gpair, (const nh_CachedContactImpulse*)nullptr,
 					          bodies->momentum, (const float4*)d->rows, (size_t)d->contact_capacity, d->gstates);
 			}
