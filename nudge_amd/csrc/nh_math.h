@@ -71,8 +71,47 @@ __device__ __forceinline__ float nh_rsqrt_guarded(float x) {
 	if (__builtin_expect(__builtin_amdgcn_ballot_w64(!nh_rsqrt_fast_ok(r)) != 0, 0)) r = nh_rsqrt(x);
 	return r;
 }
+// Forms for the solver sweeps, where the argument is very often EXACTLY zero (a box at rest has no tangential velocity and no friction
+// impulse: 1/0 = inf is the common case there, and the reference clamps it with min()).  The hardware estimates return the right
+// infinity for +-0, so a select keeps it; arguments below 2^-64 (reciprocal root) are not rescaled but sent to the exact form.  Same
+// proof obligation as above -- short != exact implies the predicate fails -- over all 2^32 inputs in tests/fastmath/exhaustive.hip.
+__device__ __forceinline__ float nh_recip_fast_z(float x) {
+	float r = __builtin_amdgcn_rcpf(x);
+	float e = __builtin_fmaf(-x, r, 1.0f);
+	float y = __builtin_fmaf(e, r, r);
+	return x == 0.0f ? r : y;                              // 1 / +-0 = +-inf, which the estimate returns
+}
+// bad: NaN, denormal or zero result (arguments at either end of the range; 1 / +-inf = +-0 takes the exact form too)
+__device__ __forceinline__ bool nh_recip_fast_z_bad(float r) { return __builtin_amdgcn_classf(r, 0x0F3); }
+__device__ __forceinline__ float nh_rsqrt_fast_z(float x) {
+	float y = __builtin_amdgcn_rsqf(x);
+	float s = x * y;
+	float e = __builtin_fmaf(-s, s, x);
+	s = __builtin_fmaf(e, 0.5f * y, s);                    // RN(sqrt(x)) for x >= 2^-64
+	float r = __builtin_amdgcn_rcpf(s);
+	float e2 = __builtin_fmaf(-s, r, 1.0f);
+	float q = __builtin_fmaf(e2, r, r);
+	return x == 0.0f ? y : q;
+}
+// bad: anything but a positive normal number or +inf
+__device__ __forceinline__ bool nh_rsqrt_fast_z_bad(float r) { return !(r >= 1.17549435e-38f); }
+__device__ __forceinline__ bool nh_rsqrt_fast_z_small(float x) { return x < 5.421010862427522e-20f; }      // (and not zero: see the guard)
+__device__ __forceinline__ float nh_recip_guarded(float x) {
+	float r = nh_recip_fast_z(x);
+	if (__builtin_expect(__builtin_amdgcn_ballot_w64(nh_recip_fast_z_bad(r)) != 0, 0)) r = nh_recip(x);
+	return r;
+}
+__device__ __forceinline__ float nh_rsqrt_guarded_z(float x) {
+	float r = nh_rsqrt_fast_z(x);
+	const uint64_t zero = __builtin_amdgcn_ballot_w64(x == 0.0f);
+	const uint64_t bad = __builtin_amdgcn_ballot_w64(nh_rsqrt_fast_z_bad(r)) | (__builtin_amdgcn_ballot_w64(nh_rsqrt_fast_z_small(x)) & ~zero);
+	if (__builtin_expect(bad != 0, 0)) r = nh_rsqrt(x);
+	return r;
+}
 #else
 NH_HD float nh_rsqrt_guarded(float x) { return nh_rsqrt(x); }
+NH_HD float nh_recip_guarded(float x) { return nh_recip(x); }
+NH_HD float nh_rsqrt_guarded_z(float x) { return nh_rsqrt(x); }
 #endif
 
 // x86 cvttps2dq semantics (nudge.cpp:336-338): truncate; out of range or NaN -> 0x80000000.

@@ -767,7 +767,11 @@ __device__ __forceinline__ bool cache_probe(const nh_CacheView& cv, uint32_t m, 
 	return false;
 }
 
-__device__ __noinline__ void cache_search(const nh_CacheView& cv, uint32_t m, uint32_t guess, uint64_t t, uint32_t f, float& wx, float& wy, float& wz) {
+// (arguments and result by value: a reference to the view or to the impulse would pin them in scratch memory across the call, and the scratch
+// traffic shares the vector memory counter with the global loads of the kernel)
+__device__ __noinline__ float4 cache_search(const uint64_t* __restrict__ ctags, const uint32_t* __restrict__ cfeatures, const nh_CachedContactImpulse* __restrict__ cdata,
+                                            uint32_t m, uint32_t guess, uint64_t t, uint32_t f) {
+	const float4 none = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	uint32_t lo = 0, hi = m;
 	if (guess != NH_HINT_NONE && m) {
 		// window [g-4, g+4): entries are sorted by (tag, feature)
@@ -775,15 +779,16 @@ __device__ __noinline__ void cache_search(const nh_CacheView& cv, uint32_t m, ui
 		const uint32_t w0 = g >= 4 ? g - 4 : 0, w1 = g + 4 < m ? g + 4 : m;
 		bool below = false, above = false;
 		for (uint32_t k = w0; k < w1; ++k) {
-			const uint64_t ct = cv.ctags[k]; const uint32_t cf = cv.cfeatures[k];
-			if (ct == t && cf == f) { const float4 w = *reinterpret_cast<const float4*>(cv.cdata + k); wx = w.x; wy = w.y; wz = w.z; return; }
+			const uint64_t ct = ctags[k]; const uint32_t cf = cfeatures[k];
+			if (ct == t && cf == f) return *reinterpret_cast<const float4*>(cdata + k);
 			if (tag_less(ct, cf, t, f)) below = true; else above = true;
 		}
-		if ((below || w0 == 0) && (above || w1 == m)) return;       // bracketed and absent: a new contact
+		if ((below || w0 == 0) && (above || w1 == m)) return none;       // bracketed and absent: a new contact
 		if (!below) hi = w0; else lo = w1;
 	}
-	while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (tag_less(cv.ctags[mid], cv.cfeatures[mid], t, f)) lo = mid + 1; else hi = mid; }
-	if (lo < m && cv.ctags[lo] == t && cv.cfeatures[lo] == f) { const float4 w = *reinterpret_cast<const float4*>(cv.cdata + lo); wx = w.x; wy = w.y; wz = w.z; }
+	while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (tag_less(ctags[mid], cfeatures[mid], t, f)) lo = mid + 1; else hi = mid; }
+	if (lo < m && ctags[lo] == t && cfeatures[lo] == f) return *reinterpret_cast<const float4*>(cdata + lo);
+	return none;
 }
 
 // Memory access.  One lane owns one body, but a body's per-contact records (contact, pair, tags, cache entry: 8 arrays) are
@@ -807,7 +812,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
 	// `require_inert`: bit 0 -- launched before the host knew whether body 0 is inert (leave if it is not); bit 1 -- NH_FLAG_SINGLE_APPLY: no later
 	// nh_apply_impulses will continue from the solver states, so they are not stored
 	const bool keep_states = !(require_inert & 2u);
-	if ((require_inert & 1u) && !cv.st->static_inert) return;
+	if (nbodies == 0u || ((require_inert & 1u) && !cv.st->static_inert)) return;
 	__shared__ nh_ob_slot s_slot[4][64 * M];
 	__shared__ uint32_t s_cid[4][64 * M];
 	__shared__ uint32_t s_hint[4][64], s_first[4][64];
@@ -817,24 +822,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
 	const uint32_t m = FUSED ? cv.st->cache : 0u;
 	const uint32_t rounded = (nbodies + 255u) & ~255u;
 	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < rounded; x += gridDim.x * blockDim.x) {       // block-uniform trip count
-		const uint32_t my_class = x < nbodies ? body_class[x] : 0u;
+		// Two memory round trips per body, not one per dependent step: (1) class, contact-list record and cache hint -- unconditional loads at a
+		// clamped index, a few bytes wasted on bodies of other classes; (2) everything per contact for all slots at once -- contact, tag, feature,
+		// the cache entry at the guessed position and its impulse, again at clamped indices and without branches, so that the ~28 loads of a lane
+		// are in flight together -- with the body state issued behind them (it is needed only in phase B).  Loads under divergent branches are
+		// issued and awaited branch by branch: that form spent 61 % of the wave cycles parked at s_waitcnt (SQ_WAIT_ANY, profiles/r02_solver_sq_counters.json).
+		const uint32_t xc = min(x, nbodies - 1u);
+		const uint32_t my_class = body_class[xc];
+		uint2 sp = make_uint2(0u, 0u);
+		uint32_t h = NH_HINT_NONE;
+		if (CONTIG) sp = simple[xc];
+		if (FUSED) h = hint[xc];
 		const bool mine = x < nbodies && (my_class == cls_a || my_class == cls_b);
 		const uint32_t wave_x0 = x - lane;
 		uint32_t b = 0, cnt = 0;
-		uint2 sp = make_uint2(0u, 0u);
-		if (mine) {
-			if (CONTIG) { sp = simple[x]; cnt = sp.y & 15u; }
-			else { b = off[x]; cnt = off[x + 1] - b; }
-		}
-		// body state: 16-byte loads (the records are 16 / 32 bytes and aligned, include/nudge_hip.h)
-		float4 m0 = make_float4(0, 0, 0, 0), m1 = m0, pr = m0, t0 = m0, t1 = make_float4(0, 0, 0, 1);
-		uint32_t h = NH_HINT_NONE;
-		if (mine) {
-			m0 = reinterpret_cast<const float4*>(momentum + x)[0]; m1 = reinterpret_cast<const float4*>(momentum + x)[1];
-			pr = *reinterpret_cast<const float4*>(props + x);
-			t0 = reinterpret_cast<const float4*>(xf + x)[0]; t1 = reinterpret_cast<const float4*>(xf + x)[1];
-			if (FUSED) h = hint[x];
-		}
+		if (!mine) { sp = make_uint2(0u, 0u); h = NH_HINT_NONE; }
+		if (CONTIG) cnt = sp.y & 15u;
+		else if (mine) { b = off[x]; cnt = off[x + 1] - b; }
 		uint32_t cid[M];
 		uint32_t first = 0xFFFFFFFFu;
 #pragma unroll
@@ -847,27 +851,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
 		for (int q = 0; q < M; ++q) scid[lane * M + q] = cid[q];
 		s_hint[wave][lane] = h; s_first[wave][lane] = first;
 		__builtin_amdgcn_wave_barrier();
-		// phase A: the wave fetches the per-contact records slot by slot
+		// phase A: the wave fetches the per-contact records slot by slot; all loads first, then the comparisons
+		uint32_t sc[M], sflags[M];
+		float4 sc0[M], sc1[M], sw[M];
+		uint64_t stag[M], sctag[M];
+		uint32_t sfeat[M], scfeat[M], sguess[M];
 #pragma unroll
 		for (int k = 0; k < M; ++k) {
 			const uint32_t e = 64u * k + lane, j = e / M;
-			const uint32_t c = scid[e];
+			sc[k] = scid[e];
+			const uint32_t c = sc[k] != 0xFFFFFFFFu ? sc[k] : 0u;
+			sc0[k] = reinterpret_cast<const float4*>(contacts + c)[0];
+			sc1[k] = reinterpret_cast<const float4*>(contacts + c)[1];
+			// (CONTIG: the body's role in its one pair rides in simple[x], bit 28 -- no load of the body pair)
+			sflags[k] = (!CONTIG && bodies[c].a == wave_x0 + j) ? 2u : 0u;
+			if (FUSED) {
+				const uint32_t hj = s_hint[wave][j];
+				sguess[k] = hj != NH_HINT_NONE ? hj + (sc[k] - s_first[wave][j]) : sc[k];
+				const uint32_t g = sguess[k] < m ? sguess[k] : 0u;
+				stag[k] = cv.tags[c]; sfeat[k] = cv.features[c];
+				sctag[k] = cv.ctags[g]; scfeat[k] = cv.cfeatures[g];
+				sw[k] = *reinterpret_cast<const float4*>(cv.cdata + g);
+			} else {
+				sw[k] = states[c];
+			}
+		}
+		// body state: 16-byte loads (the records are 16 / 32 bytes and aligned, include/nudge_hip.h)
+		float4 m0 = make_float4(0, 0, 0, 0), m1 = m0, pr = m0, t0 = m0, t1 = make_float4(0, 0, 0, 1);
+		if (mine) {
+			m0 = reinterpret_cast<const float4*>(momentum + x)[0]; m1 = reinterpret_cast<const float4*>(momentum + x)[1];
+			pr = *reinterpret_cast<const float4*>(props + x);
+			t0 = reinterpret_cast<const float4*>(xf + x)[0]; t1 = reinterpret_cast<const float4*>(xf + x)[1];
+		}
+#pragma unroll
+		for (int k = 0; k < M; ++k) {
+			const uint32_t e = 64u * k + lane;
 			nh_ob_slot o;
 			o.c0 = make_float4(0, 0, 0, 0); o.c1 = o.c0; o.w = o.c0;
-			if (c != 0xFFFFFFFFu) {
-				o.c0 = reinterpret_cast<const float4*>(contacts + c)[0];
-				o.c1 = reinterpret_cast<const float4*>(contacts + c)[1];
-				// (CONTIG: the body's role in its one pair rides in simple[x], bit 28 -- no load of the body pair)
-				uint32_t flags = (!CONTIG && bodies[c].a == wave_x0 + j) ? 2u : 0u;
+			if (sc[k] != 0xFFFFFFFFu) {
+				uint32_t flags = sflags[k];
+				o.c0 = sc0[k]; o.c1 = sc1[k];
 				if (FUSED) {
-					const uint32_t hj = s_hint[wave][j];
-					const uint32_t guess = hj != NH_HINT_NONE ? hj + (c - s_first[wave][j]) : c;
-					float wx = 0.0f, wy = 0.0f, wz = 0.0f;
-					if (!cache_probe(cv, m, guess, cv.tags[c], cv.features[c], wx, wy, wz)) flags |= 1u;
-					o.w = make_float4(wx, wy, wz, __uint_as_float(flags));
+					const bool hit = sguess[k] < m && sctag[k] == stag[k] && scfeat[k] == sfeat[k];
+					if (!hit) flags |= 1u;
+					o.w = hit ? make_float4(sw[k].x, sw[k].y, sw[k].z, __uint_as_float(flags)) : make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(flags));
 				} else {
-					const float4 sv = states[c];
-					o.w = make_float4(sv.x, sv.y, sv.z, __uint_as_float(flags));
+					o.w = make_float4(sw[k].x, sw[k].y, sw[k].z, __uint_as_float(flags));
 				}
 			}
 			slot[e] = o;
@@ -892,7 +921,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
 				nh_build_row1(ci, posx, IX, v.mass_inverse, is_a[q], r[q]);
 				if (FUSED) {
 					float wx = o.w.x, wy = o.w.y, wz = o.w.z;
-					if (flags & 1u) cache_search(cv, m, h != NH_HINT_NONE ? h + (cid[q] - first) : cid[q], cv.tags[cid[q]], cv.features[cid[q]], wx, wy, wz);
+					if (flags & 1u) {
+						const float4 found = cache_search(cv.ctags, cv.cfeatures, cv.cdata, m, h != NH_HINT_NONE ? h + (cid[q] - first) : cid[q], cv.tags[cid[q]], cv.features[cid[q]]);
+						wx = found.x; wy = found.y; wz = found.z;
+					}
 					nh_warm_start1(r[q], wx, wy, wz, v, is_a[q], s[q]);
 				} else {
 					s[q].normal = o.w.x; s[q].friction_x = o.w.y; s[q].friction_y = o.w.z;
@@ -900,10 +932,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
 			}
 		}
 		if (FUSED && mine) hint[x] = first;          // where this body's contacts start in what becomes the next step's cache
-		for (uint32_t it = 0; it < iterations; ++it) {
+		// (CONTIG: a body's role is one bit for all its contacts, and in most scenes the static world is always "a": when no lane of the wave
+		// has D = a the role selects drop out of the sweep)
+		if (CONTIG && __builtin_amdgcn_ballot_w64(mine && ((sp.y >> 28) & 1u) != 0) == 0) {
+			for (uint32_t it = 0; it < iterations; ++it) {
 #pragma unroll
-			for (int q = 0; q < M; ++q)
-				if ((uint32_t)q < cnt) nh_apply_one1(r[q], s[q], v, is_a[q]);
+				for (int q = 0; q < M; ++q)
+					if ((uint32_t)q < cnt) nh_apply_one1(r[q], s[q], v, false);
+			}
+		} else {
+			for (uint32_t it = 0; it < iterations; ++it) {
+#pragma unroll
+				for (int q = 0; q < M; ++q)
+					if ((uint32_t)q < cnt) nh_apply_one1(r[q], s[q], v, is_a[q]);
+			}
 		}
 		// results: state + exported impulse (update_cached_impulses, nudge.cpp:4872-4882) per contact, written by the wave slot by slot
 		__builtin_amdgcn_wave_barrier();

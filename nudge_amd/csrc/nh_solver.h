@@ -343,6 +343,16 @@ NH_HD void nh_apply_one(const nh_row& r, nh_state& st, nh_vel& a, nh_vel& b) {
 // numbers that can differ are signs of exact zeros that are provably never observed: friction_coefficient_z (only ever
 // added to a non-negative accumulator) and r (added to a positive inverse mass).
 // A row shrinks from 39 to 27 floats: four of them fit in registers with room for a second wave per SIMD.
+// division and reciprocal root of the one-body forms: the guarded short sequences of nh_math.h (bit-identical to nh_recip / nh_rsqrt by the
+// exhaustive check, a third of the instructions -- k_solve_one_body is bound by VALU issue); -DNH_SOLVER_EXACT_DIV selects the plain forms
+#if defined(NH_SOLVER_EXACT_DIV)
+NH_HD float nh_recip_s(float x) { return nh_recip(x); }
+NH_HD float nh_rsqrt_s(float x) { return nh_rsqrt(x); }
+#else
+NH_HD float nh_recip_s(float x) { return nh_recip_guarded(x); }
+NH_HD float nh_rsqrt_s(float x) { return nh_rsqrt_guarded_z(x); }
+#endif
+
 struct nh_row1 {
 	float p_z, p_x, p_y;                   // lever arm of D
 	float n_x, u_x, v_x;
@@ -372,7 +382,7 @@ NH_HD void nh_build_row1(const nh_contact_in& c, nh_f3 dpos, const nh_inertia& D
 	float mass_inverse = d_mass_inverse;
 	float nvtni = mass_inverse + r_dot_n;
 	bool nonzero = (nvtni < 0.0f) || (nvtni > 0.0f);
-	nvtni = nonzero ? (-1.0f / nvtni) : 0.0f;
+	nvtni = nonzero ? nh_neg(nh_recip_s(nvtni)) : 0.0f;
 
 	float bias = (-NH_BIAS_FACTOR) * nh_max(c.penetration - NH_ALLOWED_PENETRATION, 0.0f) * nvtni;
 
@@ -382,7 +392,7 @@ NH_HD void nh_build_row1(const nh_contact_in& c, nh_f3 dpos, const nh_inertia& D
 	float u_z = nh_madd(nx - ny, s, ny);
 	u_x = nh_neg(u_x);
 	{
-		float f = nh_rsqrt(u_x * u_x + u_y * u_y + u_z * u_z);
+		float f = nh_rsqrt_s(u_x * u_x + u_y * u_y + u_z * u_z);
 		u_x *= f; u_y *= f; u_z *= f;
 	}
 	float v_x = u_y * nz - u_z * ny, v_y = u_z * nx - u_x * nz, v_z = u_x * ny - u_y * nx;
@@ -432,7 +442,7 @@ NH_HD void nh_warm_start1(const nh_row1& r, float cix, float ciy, float ciz, nh_
 	float fx = r.u_x * cix + r.u_y * ciy + r.u_z * ciz;
 	float fy = r.v_x * cix + r.v_y * ciy + r.v_z * ciz;
 	float scale = fx * fx + fy * fy;
-	scale = nh_rsqrt(scale);
+	scale = nh_rsqrt_s(scale);
 	scale = scale * max_friction_impulse;
 	scale = nh_min(1.0f, scale);
 	fx = fx * scale;
@@ -507,7 +517,7 @@ NH_HD void nh_apply_one1(const nh_row1& r, nh_state& st, nh_vel& d, bool d_is_a)
 	friction_factor = nh_madd(t_xy, r.friction_coefficient_z, friction_factor);
 	float linear_impulse_z = r.n_z * normal_impulse;
 
-	friction_factor = nh_recip(friction_factor);
+	friction_factor = nh_recip_s(friction_factor);
 
 	d.wx = nh_madd(r.nd_x, normal_impulse, d.wx);
 	d.wy = nh_madd(r.nd_y, normal_impulse, d.wy);
@@ -524,7 +534,7 @@ NH_HD void nh_apply_one1(const nh_row1& r, nh_state& st, nh_vel& d, bool d_is_a)
 	friction_impulse_y = old_friction_impulse_y - friction_impulse_y;
 
 	float friction_clamp_scale = friction_impulse_x * friction_impulse_x + friction_impulse_y * friction_impulse_y;
-	friction_clamp_scale = nh_rsqrt(friction_clamp_scale);
+	friction_clamp_scale = nh_rsqrt_s(friction_clamp_scale);
 
 	friction_clamp_scale = friction_clamp_scale * max_friction_impulse;
 	friction_clamp_scale = nh_min(1.0f, friction_clamp_scale);

@@ -426,7 +426,7 @@ def test_lds_resident_solver_is_bit_identical_to_the_per_level_launches(name, kw
         seen = max(seen, a.counts()["general_contacts"])
     ca, cb = a.get_cache(), b.get_cache()
     assert ca["count"] == cb["count"] and P.bits_equal(ca["data"]["impulse"], cb["data"]["impulse"]) and P.bits_equal(ca["tags"], cb["tags"])
-    assert seen > 100, "the scene never produced a general set"
+    assert seen > 20, "the scene never produced a general set"
     a.close(); b.close()
 
 
