@@ -68,7 +68,10 @@ KERNEL_BYTES = {
     # fused one-body solver (lookup + rows + warm start + all sweeps + export), per contact: contact 32, pair 8, tag+feature 12,
     # cache probe 12 + 16, state 16 w, impulse 16 w = 112; per body (4 contacts): class/offsets/adjacency/hint 33, transform 32,
     # properties 16, momentum 32 r + 32 w = 145 -> 36 per contact
-    "solve_one_body": ("K", 112 + 36),
+    # + NH_FLAG_FUSED_STEP (what bench.py runs): the advance's outputs, transform 32 w + idle 1 r + 1 w per body = 8.5 per contact
+    "solve_one_body": ("K", 112 + 36 + 8.5),
+    "gravity_rest": ("B", 4 + 1),                           # active list + class of every body; momentum only of bodies outside the fused solver
+    "advance_rest": ("B", 4 + 1),
     "solve_one_body8": ("K", 112 + 36),
     "apply_static": ("K", 160 + 32 + 36),
     "rows_general": ("G", 4 + 32 + 8 + 2 * (32 + 16) + 160 + 8),
@@ -247,7 +250,7 @@ def main():
         w = E.World(scene, device=device_index, flags=E.NH_FLAG_SINGLE_APPLY, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=6 * info["capacity"]["bodies"])
         cluster = PT.DistCluster(PT.Partition(w, info, epoch=16), host_staging=(backend != "nccl"))
     else:
-        w = E.World(scene, device=device_index, flags=E.NH_FLAG_SINGLE_APPLY, max_contacts=max(4096, (6 if args.scene != "pit" else 5) * nb),
+        w = E.World(scene, device=device_index, flags=E.NH_FLAG_SINGLE_APPLY | E.NH_FLAG_FUSED_STEP, max_contacts=max(4096, (6 if args.scene != "pit" else 5) * nb),
                     max_pairs=None if args.scene != "pit" else 7 * nb)
 
     def advance_world(n):

@@ -956,6 +956,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	if (!ctx || !active_bodies || !contacts || !bodies || !colliders) return NH_ERR_INVALID;
 	NH_HIP_CHECK(ctx, hipSetDevice(ctx->device));
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	ctx->adv.done = false;
 	ctx->step_parity ^= 1u;
 	ctx->collide_seq++;
 	ctx->collide_mark = ctx->advance_count;
@@ -1138,5 +1139,6 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		if (c.error) return (int)c.error;
 	}
 	ctx->gravity_may_overlap = ctx->side != nullptr;       // until any other entry point enqueues work
+	ctx->after_collide = true;
 	return NH_OK;
 }

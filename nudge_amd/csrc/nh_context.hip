@@ -10,7 +10,8 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	nh_context* ctx = new nh_context();
 	ctx->device = device;
 	ctx->stream = (hipStream_t)stream;
-	ctx->flags = flags;
+	ctx->flags = (flags & NH_FLAG_FUSED_STEP) ? (flags | NH_FLAG_SINGLE_APPLY) : flags;
+	ctx->after_collide = false; ctx->grav.pending = false; ctx->adv.done = false;
 	ctx->tag_bits = 32;
 	ctx->last_hip_error = 0;
 	ctx->timing = false;
@@ -35,6 +36,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->env_sort_classic = getenv("NH_SORT_CLASSIC") != nullptr;
 	ctx->env_sort_radix = getenv("NH_SORT_RADIX") != nullptr;
 	ctx->env_colour_jp = getenv("NH_COLOUR_JP") != nullptr;
+	ctx->env_solver_waves = getenv("NH_SOLVER_WAVES") ? atoi(getenv("NH_SOLVER_WAVES")) : 1;      // wavefronts per workgroup of the fused solver (A/B: 1, 2, 4)
 	ctx->env_no_resident = getenv("NH_NO_RESIDENT") != nullptr;      // NH_NO_RESIDENT=1: small general sets also take the one-launch-per-level path (A/B, tests)
 	ctx->os_resident = 0;
 	ctx->d_state = nullptr;
@@ -74,7 +76,12 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	delete ctx;
 }
 
-extern "C" int nh_set_flags(nh_context* ctx, uint32_t flags) { if (!ctx) return NH_ERR_INVALID; ctx->flags = flags; return NH_OK; }
+extern "C" int nh_set_flags(nh_context* ctx, uint32_t flags) {
+	if (!ctx) return NH_ERR_INVALID;
+	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	ctx->flags = (flags & NH_FLAG_FUSED_STEP) ? (flags | NH_FLAG_SINGLE_APPLY) : flags;
+	return NH_OK;
+}
 extern "C" int nh_set_tag_bits(nh_context* ctx, uint32_t bits) { if (!ctx || bits < 1 || bits > 32) return NH_ERR_INVALID; ctx->tag_bits = bits; return NH_OK; }
 
 extern "C" int nh_bodies_changed(nh_context* ctx) { if (!ctx) return NH_ERR_INVALID; ctx->idle_bound = -1; return NH_OK; }
@@ -92,7 +99,7 @@ extern "C" int nh_synchronize(nh_context* ctx) {
 
 extern "C" int nh_read_counts(nh_context* ctx, nh_Counts* out) {
 	if (!ctx || !out) return NH_ERR_INVALID;
-	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	{ int rc = nh_flush_pending(ctx, true); if (rc) return rc; }      // (counters only: a pending NH_FLAG_FUSED_STEP gravity stays pending)
 	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, 25 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 	const nh_DevState* h = ctx->h_state;

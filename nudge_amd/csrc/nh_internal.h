@@ -71,6 +71,9 @@ struct nh_DevState {
 
 struct nh_TimerSlot { const char* name; hipEvent_t a, b; };
 
+// what the fused one-body solver does besides solving (NH_FLAG_FUSED_STEP): bits 1 = gravity / damping on load, 2 = advance on store
+struct nh_FusedStep { float gx_dt, gy_dt, gz_dt, damping, time_step; uint32_t bits; uint8_t* idle; };
+
 struct nh_context {
 	int device;
 	hipStream_t stream;
@@ -113,6 +116,7 @@ struct nh_context {
 	bool islands_skipped;                 // the last nh_collide launched no island kernels (its prediction is checked on the device: NH_ERR_STALE_HINT)
 	// behaviour switches read ONCE from the environment by nh_create (test / A-B knobs, see nh_context.hip)
 	bool env_sort_classic, env_sort_radix, env_colour_jp, env_no_resident;
+	int env_solver_waves;
 	int os_resident;                      // co-resident workgroups of a one-kernel radix pass on THIS device (nh_util.hip), 0 = not yet asked
 	// tag sort seeded by the previous step's order (nh_util.hip): splitters persist across steps; counts / starts are scratch that must
 	// outlive nothing but is zeroed by its own kernels.  `sort_seeded`: the splitters describe the previous nh_collide of this capacity
@@ -130,10 +134,15 @@ struct nh_context {
 	// chain still queued on the caller's stream, which never touches momentum -- and the caller's stream waits for `ev_gravity`
 	hipEvent_t ev_active, ev_gravity;
 	bool gravity_may_overlap;
+	// NH_FLAG_FUSED_STEP: gravity / damping recorded by an nh_apply_gravity_damping that directly follows nh_collide (`after_collide`) and applied by
+	// the fused one-body solver when it loads a body's momentum (everybody else: k_gravity_rest); the advance that solver performed for its bodies
+	bool after_collide;
+	struct { bool pending; float gx_dt, gy_dt, gz_dt, damping, time_step; const uint32_t* active; nh_BodyMomentum* momentum; uint32_t body_count; } grav;
+	struct { bool done; float time_step; const uint8_t* body_class; } adv;
 };
 
 // Runs work that an earlier call deferred; every entry point that reads or writes momentum / impulses calls it first.
-int nh_flush_pending(nh_context* ctx);
+int nh_flush_pending(nh_context* ctx, bool keep_gravity = false);
 
 struct nh_ContactImpulseData {
 	nh_CachedContactImpulse* data;        // K, contact (tag) order; holds the warm-start impulses once `lookup_pending` is false

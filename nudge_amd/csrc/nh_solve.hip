@@ -59,6 +59,35 @@ __global__ __launch_bounds__(256) void k_advance(const nh_DevState* __restrict__
 	}
 }
 
+// NH_FLAG_FUSED_STEP: the bodies the fused one-body solver owns (class STATIC4 while the static world is inert) get gravity / damping and their
+// advance inside that kernel; these two take everybody else on the active list
+__global__ __launch_bounds__(256) void k_gravity_rest(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ active, const uint8_t* __restrict__ body_class,
+                                                      nh_BodyMomentum* __restrict__ momentum, float gx_dt, float gy_dt, float gz_dt, float damping) {
+	const uint32_t n = st->active;
+	const bool inert = st->static_inert != 0u;
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		const uint32_t i = active[k];
+		if (inert && body_class[i] == NH_CLS_STATIC4) continue;
+		nh_BodyMomentum m = momentum[i];
+		nh_gravity_damping(m.velocity, m.angular_velocity, gx_dt, gy_dt, gz_dt, damping);
+		momentum[i] = m;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_advance_rest(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ active, const uint8_t* __restrict__ body_class,
+                                                      nh_Transform* __restrict__ xf, const nh_BodyMomentum* __restrict__ momentum, uint8_t* __restrict__ idle, float time_step) {
+	const uint32_t n = st->active;
+	const bool inert = st->static_inert != 0u;
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		const uint32_t i = active[k];
+		if (inert && body_class[i] == NH_CLS_STATIC4) continue;
+		nh_Transform t = xf[i];
+		nh_BodyMomentum m = momentum[i];
+		idle[i] = nh_advance_body(t.position, t.rotation, m.velocity, m.angular_velocity, idle[i], time_step);
+		xf[i] = t;
+	}
+}
+
 // ---- read_cached_impulses (nudge.cpp:4021-4108) ------------------------------------------------------------------
 // contacts are already in tag order, so the reference's merge-join becomes one binary search per contact.
 __global__ __launch_bounds__(256) void k_cache_lookup(const nh_DevState* __restrict__ st, const uint64_t* __restrict__ tags, const uint32_t* __restrict__ features,
@@ -798,13 +827,13 @@ __device__ __noinline__ float4 cache_search(const uint64_t* __restrict__ ctags, 
 // Four 27-float rows fit in 256 registers: two waves per SIMD (the compiler would otherwise spend 260 and run one).
 struct nh_ob_slot { float4 c0, c1, w; };      // contact (32 B), cached impulse xyz + flags in w.w (bit 0 miss, bit 1 body is "a")
 
-template<int MAXC, bool FUSED, bool CONTIG = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ? 2 : 1, MAXC == 4 ? 2 : 1))) void k_solve_one_body(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
+template<int MAXC, bool FUSED, bool CONTIG = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ? 2 : 1, MAXC == 4 ? 2 : 1))) void k_solve_one_body(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
                                                         const nh_BodyPair* __restrict__ bodies, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                         float4* __restrict__ states, uint32_t iterations,
-                                                        const nh_Contact* __restrict__ contacts, const nh_Transform* __restrict__ xf, nh_CachedContactImpulse* __restrict__ impulses,
+                                                        const nh_Contact* __restrict__ contacts, nh_Transform* xf, nh_CachedContactImpulse* __restrict__ impulses,
                                                         nh_CacheView cv, uint32_t* __restrict__ hint, uint32_t cls_a, uint32_t cls_b, uint32_t require_inert,
-                                                        const uint2* __restrict__ simple = nullptr) {
+                                                        const uint2* __restrict__ simple = nullptr, nh_FusedStep fs = nh_FusedStep()) {
 	// CONTIG: every body of the class comes from k_adj_simple (one collider pair with the static world): its contact list is the record
 	// simple[x] -- one load next to the body state instead of the dependent chain off[x] -> adj[] -> contact
 	constexpr int M = MAXC;
@@ -813,15 +842,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
 	// nh_apply_impulses will continue from the solver states, so they are not stored
 	const bool keep_states = !(require_inert & 2u);
 	if (nbodies == 0u || ((require_inert & 1u) && !cv.st->static_inert)) return;
-	__shared__ nh_ob_slot s_slot[4][64 * M];
-	__shared__ uint32_t s_cid[4][64 * M];
-	__shared__ uint32_t s_hint[4][64], s_first[4][64];
+	__shared__ nh_ob_slot s_slot[NW][64 * M];
+	__shared__ uint32_t s_cid[NW][64 * M];
+	__shared__ uint32_t s_hint[NW][64], s_first[NW][64];
 	const uint32_t wave = threadIdx.x >> 6, lane = nh_lane();
 	nh_ob_slot* slot = s_slot[wave];
 	uint32_t* scid = s_cid[wave];
 	const uint32_t m = FUSED ? cv.st->cache : 0u;
-	const uint32_t rounded = (nbodies + 255u) & ~255u;
-	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < rounded; x += gridDim.x * blockDim.x) {       // block-uniform trip count
+	const uint32_t rounded = (nbodies + (64u * NW - 1u)) / (64u * NW) * (64u * NW);
+	// block-uniform trip count; the CONTIG launch covers every body with one pass (no loop: nothing is carried in registers across iterations)
+	uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+	if (x >= rounded) return;
+	do {
 		// Two memory round trips per body, not one per dependent step: (1) class, contact-list record and cache hint -- unconditional loads at a
 		// clamped index, a few bytes wasted on bodies of other classes; (2) everything per contact for all slots at once -- contact, tag, feature,
 		// the cache entry at the guessed position and its impulse, again at clamped indices and without branches, so that the ~28 loads of a lane
@@ -882,6 +914,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
 			m0 = reinterpret_cast<const float4*>(momentum + x)[0]; m1 = reinterpret_cast<const float4*>(momentum + x)[1];
 			pr = *reinterpret_cast<const float4*>(props + x);
 			t0 = reinterpret_cast<const float4*>(xf + x)[0]; t1 = reinterpret_cast<const float4*>(xf + x)[1];
+			if (CONTIG && (fs.bits & 1u)) {          // NH_FLAG_FUSED_STEP: gravity / damping (k_gravity) on the way in
+				float vel[3] = { m0.x, m0.y, m0.z }, ang[3] = { m1.x, m1.y, m1.z };
+				nh_gravity_damping(vel, ang, fs.gx_dt, fs.gy_dt, fs.gz_dt, fs.damping);
+				m0.x = vel[0]; m0.y = vel[1]; m0.z = vel[2]; m1.x = ang[0]; m1.y = ang[1]; m1.z = ang[2];
+			}
 		}
 #pragma unroll
 		for (int k = 0; k < M; ++k) {
@@ -947,6 +984,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
 					if ((uint32_t)q < cnt) nh_apply_one1(r[q], s[q], v, is_a[q]);
 			}
 		}
+		// NH_FLAG_FUSED_STEP: the advance (k_advance) on the way out; the transform is fetched again here rather than held across the sweeps
+		float4 a0 = make_float4(0, 0, 0, 0), a1 = a0;
+		uint32_t idle_in = 0;
+		const bool advance_here = CONTIG && (fs.bits & 2u) && mine;
+		if (advance_here) { a0 = reinterpret_cast<const float4*>(xf + x)[0]; a1 = reinterpret_cast<const float4*>(xf + x)[1]; idle_in = fs.idle[x]; }
 		// results: state + exported impulse (update_cached_impulses, nudge.cpp:4872-4882) per contact, written by the wave slot by slot
 		__builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -972,8 +1014,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ?
 			reinterpret_cast<float4*>(momentum + x)[0] = make_float4(v.vx, v.vy, v.vz, v.mass_inverse);
 			reinterpret_cast<float4*>(momentum + x)[1] = make_float4(v.wx, v.wy, v.wz, v.w_unused);
 		}
+		if (advance_here) {
+			float pos[3] = { a0.x, a0.y, a0.z }, rot[4] = { a1.x, a1.y, a1.z, a1.w };
+			const float vel[3] = { v.vx, v.vy, v.vz }, ang[3] = { v.wx, v.wy, v.wz };
+			fs.idle[x] = nh_advance_body(pos, rot, vel, ang, (uint8_t)idle_in, fs.time_step);
+			reinterpret_cast<float4*>(xf + x)[0] = make_float4(pos[0], pos[1], pos[2], a0.w);
+			reinterpret_cast<float4*>(xf + x)[1] = make_float4(rot[0], rot[1], rot[2], rot[3]);
+		}
 		__builtin_amdgcn_wave_barrier();
-	}
+		if (CONTIG) break;
+		x += gridDim.x * blockDim.x;
+	} while (x < rounded);
 }
 
 // ---- level-scheduled path ------------------------------------------------------------------------------------------------------
@@ -1455,9 +1506,17 @@ static nh_ContactConstraintData* new_constraint_data(nh_context* ctx) {
 extern "C" int nh_apply_gravity_damping(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_BodyData* bodies,
                                         float time_step, const float gravity[3], float damping_rate) {
 	if (!ctx || !active_bodies || !bodies || !gravity) return NH_ERR_INVALID;
-	const bool follows_collide = ctx->gravity_may_overlap;
+	const bool follows_collide = ctx->gravity_may_overlap, after_collide = ctx->after_collide;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	float damping = 1.0f - time_step * damping_rate;
+	if ((ctx->flags & NH_FLAG_FUSED_STEP) && after_collide) {
+		// applied by the fused solver when it loads a body (first_apply), by k_gravity_rest for the others; any other entry point settles it first
+		ctx->grav.pending = true;
+		ctx->grav.gx_dt = gravity[0] * time_step; ctx->grav.gy_dt = gravity[1] * time_step; ctx->grav.gz_dt = gravity[2] * time_step;
+		ctx->grav.damping = damping; ctx->grav.time_step = time_step;
+		ctx->grav.active = active_bodies->indices; ctx->grav.momentum = bodies->momentum; ctx->grav.body_count = bodies->count;
+		return NH_OK;
+	}
 	// directly after nh_collide (the sample's loop, example/main.cpp:286-305): on the side stream, behind the kernel that wrote the active list and
 	// beside the tag sort / contact gather still queued on the caller's stream (they never touch momentum); the caller's stream then waits
 	const bool overlap = follows_collide && ctx->side != nullptr;
@@ -1477,6 +1536,14 @@ extern "C" int nh_advance(nh_context* ctx, const nh_ActiveBodies* active_bodies,
 	if (!ctx || !active_bodies || !bodies) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	ctx->advance_count++;
+	if (ctx->adv.done) {
+		// NH_FLAG_FUSED_STEP: the one-body solver advanced its own bodies with the time step gravity was given
+		ctx->adv.done = false;
+		if (nh_asuint(time_step) != nh_asuint(ctx->adv.time_step)) return NH_ERR_INVALID;
+		NH_LAUNCH(ctx, "advance_rest", k_advance_rest, nh_grid_for(bodies->count, 256, 2048), 256, ctx->d_state, active_bodies->indices, ctx->adv.body_class, bodies->transforms,
+		          bodies->momentum, bodies->idle_counters, time_step);
+		return NH_OK;
+	}
 	NH_LAUNCH(ctx, "advance", k_advance, nh_grid_for(bodies->count, 256, 2048), 256, ctx->d_state, active_bodies->indices, bodies->transforms,
 	          bodies->momentum, bodies->idle_counters, time_step);
 	return NH_OK;
@@ -1497,7 +1564,7 @@ static void run_cull(nh_context* ctx, nh_ContactImpulseData* d, uint32_t sleepin
 
 extern "C" int nh_read_cached_impulses(nh_context* ctx, const nh_ContactCache* cache, const nh_ContactData* contacts, nh_Arena* memory, nh_ContactImpulseData** out) {
 	if (!ctx || !cache || !contacts || !memory || !out) return NH_ERR_INVALID;
-	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	{ int rc = nh_flush_pending(ctx, true); if (rc) return rc; }
 	const uint32_t kcap = contacts->capacity, ccap = cache->capacity;
 	int err = NH_OK;
 	ctx->ring_pos++;
@@ -1573,7 +1640,7 @@ extern "C" int nh_write_cached_impulses(nh_context* ctx, nh_ContactCache* cache,
 extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_ContactData* contacts,
                                             const nh_BodyData* bodies, nh_ContactImpulseData* imp, nh_Arena* memory, nh_ContactConstraintData** out) {
 	if (!ctx || !contacts || !bodies || !imp || !memory || !out) return NH_ERR_INVALID;
-	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	{ int rc = nh_flush_pending(ctx, true); if (rc) return rc; }
 	(void)active_bodies;
 	nh_DevState* st = ctx->d_state;
 	const uint32_t kcap = contacts->capacity;
@@ -1786,7 +1853,7 @@ static void launch_apply_static(nh_context* ctx, nh_ContactConstraintData* d, co
 	auto go1 = [&](const char* name, auto kernel, uint32_t cls_a, uint32_t cls_b) {
 		NH_LAUNCH(ctx, name, kernel, nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
 		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, cls_a, cls_b,
-		          (fused && (ctx->flags & NH_FLAG_SINGLE_APPLY)) ? 2u : 0u, (const uint2*)nullptr);
+		          (fused && (ctx->flags & NH_FLAG_SINGLE_APPLY)) ? 2u : 0u, (const uint2*)nullptr, nh_FusedStep());
 	};
 	const bool late = d->has_late;
 	if (d->static_inert) {
@@ -1812,15 +1879,39 @@ static void launch_apply_static(nh_context* ctx, nh_ContactConstraintData* d, co
 
 // First solver call after a setup (or its flush with zero sweeps): the common one-body kernel goes out BEFORE the counters round trip --
 // the round trip then overlaps with it instead of idling the GPU -- and the rest follows once the host knows what else there is.
-static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations) {
+static int settle_gravity(nh_context* ctx) {
+	if (!ctx->grav.pending) return NH_OK;
+	ctx->grav.pending = false;
+	NH_LAUNCH(ctx, "gravity_damping", k_gravity, nh_grid_for(ctx->grav.body_count, 256, 2048), 256, ctx->d_state, ctx->grav.active, ctx->grav.momentum,
+	          ctx->grav.gx_dt, ctx->grav.gy_dt, ctx->grav.gz_dt, ctx->grav.damping);
+	return NH_OK;
+}
+
+// `from_apply`: called by nh_apply_impulses itself (not by the flush of a setup nobody applied): with NH_FLAG_FUSED_STEP the caller has promised
+// that this is the step's only solver call, so the bodies of the fused kernel are advanced there too
+static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations, bool from_apply = false) {
 	bool early4_done = false;
+	if (!d->finish_pending) { int rc = settle_gravity(ctx); if (rc) return rc; }
 	if (d->finish_pending) {
 		d->finish_pending = false;
 		const uint32_t B = d->body_count;
 		nh_CacheView cv = { d->imp->tags, d->imp->features, d->imp->ctags, d->imp->cfeatures, d->imp->cdata, ctx->d_state };
-		NH_LAUNCH(ctx, "solve_one_body", (k_solve_one_body<4, true, true>), nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
-		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4,
-		          1u | ((ctx->flags & NH_FLAG_SINGLE_APPLY) ? 2u : 0u), d->simple);
+		nh_FusedStep fs = nh_FusedStep();
+		const bool gravity_here = ctx->grav.pending && ctx->grav.momentum == bodies->momentum;
+		if (ctx->grav.pending && !gravity_here) { int rc = settle_gravity(ctx); if (rc) return rc; }
+		if (gravity_here) {
+			ctx->grav.pending = false;
+			fs.gx_dt = ctx->grav.gx_dt; fs.gy_dt = ctx->grav.gy_dt; fs.gz_dt = ctx->grav.gz_dt; fs.damping = ctx->grav.damping; fs.time_step = ctx->grav.time_step;
+			fs.bits = 1u;
+			if (from_apply && bodies->idle_counters) { fs.bits |= 2u; fs.idle = bodies->idle_counters; ctx->adv.done = true; ctx->adv.time_step = fs.time_step; ctx->adv.body_class = d->body_class; }
+		}
+#define NH_SOLVE_CONTIG(NWAVES) NH_LAUNCH(ctx, "solve_one_body", (k_solve_one_body<4, true, true, NWAVES>), (B + 64u * NWAVES - 1u) / (64u * NWAVES), 64 * NWAVES, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum, \
+		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, \
+		          1u | ((ctx->flags & NH_FLAG_SINGLE_APPLY) ? 2u : 0u), d->simple, fs)
+		if (ctx->env_solver_waves == 4) NH_SOLVE_CONTIG(4); else if (ctx->env_solver_waves == 2) NH_SOLVE_CONTIG(2); else NH_SOLVE_CONTIG(1);
+		if (gravity_here)
+			NH_LAUNCH(ctx, "gravity_rest", k_gravity_rest, nh_grid_for(ctx->grav.body_count, 256, 2048), 256, ctx->d_state, ctx->grav.active, d->body_class, bodies->momentum,
+			          fs.gx_dt, fs.gy_dt, fs.gz_dt, fs.damping);
 		int rc = finish_setup(ctx, d);
 		if (rc) return rc;
 		early4_done = d->static_inert;          // (if body 0 is not inert the speculative launch left at once and the general kernels take everything)
@@ -1829,27 +1920,32 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 	return NH_OK;
 }
 
-int nh_flush_pending(nh_context* ctx) {
+int nh_flush_pending(nh_context* ctx, bool keep_gravity) {
 	ctx->gravity_may_overlap = false;            // some entry point other than nh_collide is enqueueing work: gravity no longer "directly follows" it
+	ctx->after_collide = false;
 	nh_ContactConstraintData* d = ctx->pending;
-	if (!d) return NH_OK;
-	ctx->pending = nullptr;
-	if (d->setup_pending) {
-		d->setup_pending = false;
-		return first_apply(ctx, d, &d->bodies_at_setup, 0);       // zero sweeps: lookup + rows + warm start only
+	if (d) {
+		ctx->pending = nullptr;
+		if (d->setup_pending) {
+			d->setup_pending = false;
+			int rc = first_apply(ctx, d, &d->bodies_at_setup, 0);       // zero sweeps: lookup + rows + warm start only
+			if (rc) return rc;
+		}
 	}
-	return NH_OK;
+	// NH_FLAG_FUSED_STEP: gravity waits for the solver only across nh_read_cached_impulses / nh_setup_contact_constraints / nh_apply_impulses
+	return keep_gravity ? NH_OK : settle_gravity(ctx);
 }
 
 extern "C" int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations) {
 	if (!ctx || !d || !bodies) return NH_ERR_INVALID;
 	if (ctx->pending && ctx->pending != d) { int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	ctx->gravity_may_overlap = false; ctx->after_collide = false;
 	const bool first = d->setup_pending;
 	if (!first && (ctx->flags & NH_FLAG_SINGLE_APPLY)) return NH_ERR_INVALID;      // the states of the first call were not kept
 	d->setup_pending = false;
 	ctx->pending = nullptr;
-	if (first) { int rc = first_apply(ctx, d, bodies, iterations); if (rc) return rc; }
-	else launch_apply_static(ctx, d, bodies, iterations, false, false);
+	if (first) { int rc = first_apply(ctx, d, bodies, iterations, (ctx->flags & NH_FLAG_FUSED_STEP) != 0); if (rc) return rc; }
+	else { int rc = settle_gravity(ctx); if (rc) return rc; launch_apply_static(ctx, d, bodies, iterations, false, false); }
 	if (d->general_contacts && d->resident) {
 		// small general set: one workgroup, rows in LDS for all sweeps (k_solve_resident)
 		if (iterations)

@@ -25,6 +25,7 @@ _LIB = None
 NH_FLAG_SYNC_COUNTS = 1
 NH_FLAG_EXACT_ORDER = 2
 NH_FLAG_SINGLE_APPLY = 4
+NH_FLAG_FUSED_STEP = 8
 
 EXPORTS = [
     "nh_create", "nh_destroy", "nh_set_flags", "nh_synchronize", "nh_read_counts", "nh_set_cache_count",
@@ -263,8 +264,9 @@ class World:
     def write_cache(self):
         _check(self.L, self.L.nh_write_cached_impulses(self.ctx, C.byref(self.cache), C.byref(self.contacts), self._imp), "write_cached_impulses")
 
-    def advance(self):
-        _check(self.L, self.L.nh_advance(self.ctx, C.byref(self.active), C.byref(self.bodies), self.params["time_step"]), "advance")
+    def advance(self, time_step=None):
+        dt = self.params["time_step"] if time_step is None else time_step
+        _check(self.L, self.L.nh_advance(self.ctx, C.byref(self.active), C.byref(self.bodies), dt), "advance")
 
     def step(self, steps=1, iterations=None):
         for _ in range(steps):

@@ -430,6 +430,48 @@ def test_lds_resident_solver_is_bit_identical_to_the_per_level_launches(name, kw
     a.close(); b.close()
 
 
+@needs_ref
+@pytest.mark.parametrize("name,steps", [("grid30", 460), ("grid30_awake", 90), ("mixed20", 120), ("pile256", 420), ("stacks", 80), ("compound", 220)])
+@pytest.mark.parametrize("flags", [0, E.NH_FLAG_EXACT_ORDER])
+def test_fused_step_flag_changes_nothing(name, steps, flags):
+    """NH_FLAG_FUSED_STEP: gravity / damping and the advance of the one-body bodies happen inside their solver kernel.  Same arithmetic in the
+    same order: transforms, momentum, idle counters and the cache must equal the unfused run bit for bit -- while bodies fall, land, rest and
+    (grid30: sleeping allowed) fall asleep, and for worlds where most bodies are NOT of the fused class (pile, compound)."""
+    scene, _ = G.build(name)
+    a, b = E.World(scene, flags=flags), E.World(scene, flags=flags | E.NH_FLAG_FUSED_STEP)
+    for _ in range(steps // 10):
+        a.step(10); b.step(10)
+        x, y = a.get_bodies(), b.get_bodies()
+        assert P.bits_equal(x["transforms"], y["transforms"]) and P.bits_equal(x["momentum"], y["momentum"])
+        assert np.array_equal(x["idle"], y["idle"])
+    ca, cb = a.get_cache(), b.get_cache()
+    assert ca["count"] == cb["count"] and P.bits_equal(ca["data"]["impulse"], cb["data"]["impulse"]) and P.bits_equal(ca["tags"], cb["tags"])
+    a.close(); b.close()
+
+
+def test_fused_step_survives_calls_that_break_the_promised_order():
+    """Any entry point other than read / setup / apply between gravity and the solver settles the pending gravity with the ordinary kernel, a
+    flush of the setup (update without apply) consumes it without advancing anybody, and nh_advance with another time step is refused."""
+    scene, _ = G.build("grid30_awake")
+    a, b = E.World(scene, flags=0), E.World(scene, flags=E.NH_FLAG_FUSED_STEP)
+    a.step(60); b.step(60)
+    for variant in range(4):
+        for w in (a, b):
+            w.collide(); w.gravity()
+            if variant == 1: w.synchronize()                      # settles gravity (the caller may look at body state after a synchronize)
+            if variant == 2: w.gravity()                          # a second gravity call: the first is settled, the second pending
+            w.read_cache(); w.setup()
+            if variant == 3: w.update()                           # setup flushed without apply: lookup + warm start, no advance
+            else: w.apply(4); w.update()
+            w.write_cache(); w.advance()
+        x, y = a.get_bodies(), b.get_bodies()
+        assert P.bits_equal(x["transforms"], y["transforms"]) and P.bits_equal(x["momentum"], y["momentum"]) and np.array_equal(x["idle"], y["idle"]), variant
+    b.collide(); b.gravity(); b.read_cache(); b.setup(); b.apply(4); b.update(); b.write_cache()
+    with pytest.raises(E.NudgeError, match="invalid"):
+        b.advance(time_step=1.0 / 60.0)
+    a.close(); b.close()
+
+
 # ---- degenerate inputs ------------------------------------------------------------------------------------------------------------
 def _tiny_scene(n_boxes, n_spheres, apart=True):
     scene = S.pile(n_boxes=max(n_boxes, 1), n_spheres=n_spheres, seed=3)
