@@ -114,7 +114,8 @@ def pmc_traffic(kernel):
     if not f or not sym:
         return None, None
     try:
-        k = json.load(open(f))["kernels"].get(sym)
+        ks = json.load(open(f))["kernels"]
+        k = ks.get(sym) or next((v for name, v in ks.items() if name.startswith(sym.rstrip(">"))), None)      # (template arguments may have grown)
     except Exception:
         return None, None
     return (k["hbm_bytes_corrected"], os.path.basename(f)) if k else (None, None)

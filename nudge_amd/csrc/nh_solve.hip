@@ -858,7 +858,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		// clamped index, a few bytes wasted on bodies of other classes; (2) everything per contact for all slots at once -- contact, tag, feature,
 		// the cache entry at the guessed position and its impulse, again at clamped indices and without branches, so that the ~28 loads of a lane
 		// are in flight together -- with the body state issued behind them (it is needed only in phase B).  Loads under divergent branches are
-		// issued and awaited branch by branch: that form spent 61 % of the wave cycles parked at s_waitcnt (SQ_WAIT_ANY, profiles/r02_solver_sq_counters.json).
+		// issued and awaited branch by branch: that form spent 61 % of the wave cycles parked at s_waitcnt (SQ_WAIT_ANY; now 33 %: profiles/r02_sq_wave_states.json).
 		const uint32_t xc = min(x, nbodies - 1u);
 		const uint32_t my_class = body_class[xc];
 		uint2 sp = make_uint2(0u, 0u);

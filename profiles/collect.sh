@@ -1,7 +1,7 @@
 #!/bin/bash
 # profiles/collect.sh <tag> -- run ON THE GPU BOX (gpurun): collects what profiles/ holds for one build.
 #   bench lines (driver invocation, default, c3, c4), per-kernel tables, rocprofv3 --kernel-trace --stats of the driver invocation,
-#   two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass on gfx950) and the one-GPU rehearsal of the N = 2 path.
+#   two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass on gfx950), one SQ wave-state pass and the one-GPU rehearsal of the N = 2 path.
 # Raw output goes to gpurun_out/<tag>/ (scratch); the summaries are exported into gpurun_out/<tag>/export/ ready to be copied to profiles/.
 set -u
 TAG=${1:-r02}
@@ -37,6 +37,11 @@ if [ -n "$F" ]; then
   D=$(dirname $F); W=$(find $O/pmc -name "WRITE_SIZE_counter_collection.csv" | head -1); [ "$(dirname $W)" != "$D" ] && cp $W $D/
   python $R/profiles/export_pmc.py $D $O/export/${TAG}_pmc_traffic.json 20 > $O/export/${TAG}_pmc_traffic.log
 fi
+# SQ wave-state counters of every kernel (where the wave cycles go: issuing, parked at s_waitcnt, stalled at issue)
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/sq -o sq -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --min-time 0 > $O/sq_bench.json 2> $O/sq.log
+F=$(find $O/sq -name "*counter_collection.csv" | head -1)
+[ -n "$F" ] && python $R/profiles/export_sq.py $(dirname $F) $O/export/${TAG}_sq_wave_states.json > $O/export/${TAG}_sq_wave_states.log 2>&1
+rm -rf $O/sq $O/pmc $O/prof
 # N = 2 rehearsal on one GPU
 cd $R; timeout 600 tests/gpu_rehearsal_n2.sh > $O/rehearsal.out 2> $O/export/${TAG}_bench_n2_rehearsal_kernel_table.log
 grep '^{' $O/rehearsal.out | tail -1 > $O/export/${TAG}_bench_n2_rehearsal_one_gpu.json

@@ -22,6 +22,8 @@ for name, disp in per.items():
         for c, key in (("SQ_ACTIVE_INST_ANY", "active"), ("SQ_WAIT_ANY", "parked_at_waitcnt"), ("SQ_WAIT_INST_ANY", "issue_stall"), ("SQ_ACTIVE_INST_VALU", "valu")):
             if c in mean:
                 r[key + "_share_of_wave_cycles"] = mean[c] / wc
+    if mean.get("SQ_WAVES") and "SQ_INSTS_VALU" in mean:
+        r["valu_instructions_per_wave"] = mean["SQ_INSTS_VALU"] / mean["SQ_WAVES"]
     res[name] = r
 json.dump({"note": "mean per launch over the last dispatches of each kernel (landed, awake steps); quad-cycles", "kernels": res}, open(out, "w"), indent=1)
 rows = sorted(res.items(), key=lambda kv: -kv[1]["counters_per_launch"].get("SQ_WAVE_CYCLES", 0))[:24]
