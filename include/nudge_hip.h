@@ -165,7 +165,7 @@ typedef struct nh_Counts {
 	uint32_t general_contacts;  /* contacts solved by the level-scheduled path (not the one-body fast path) */
 	uint32_t levels;            /* dependency levels of that path */
 	uint32_t error;             /* NH_* raised on the device (capacity overflows) */
-	uint32_t static_bodies;     /* bodies solved by the one-body fast path */
+	uint32_t has_other_bodies;  /* non-zero: some body is outside the one-body fast path's common class (several pairs, dynamic partners, no contacts) */
 	uint32_t unleveled;         /* internal: progress of the level relaxation */
 	uint32_t raw_pairs;         /* broadphase pairs before any filter (diagnostic) */
 } nh_Counts;

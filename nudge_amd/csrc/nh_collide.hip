@@ -942,7 +942,7 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 	if (t == 0) {
 		st->colliders = ncolliders; st->pairs = 0; st->pairs_sph = 0; st->raw_contacts = 0; st->records = 0; st->contacts = 0; st->sleeping = 0;
 		st->active = 0; st->culled = 0; st->large = 0; st->general_contacts = 0; st->levels = 0; st->error = 0;
-		st->static_bodies = 0; st->unleveled = 0; st->has_static8 = 0; st->has_staticN = 0; st->any_sleeping = 0; st->has_pending = 0;
+		st->has_other = 0; st->unleveled = 0; st->has_static8 = 0; st->has_staticN = 0; st->any_sleeping = 0; st->has_pending = 0;
 		st->sort_buckets = st->sort_buckets_next;
 		for (int k = 0; k < 3; ++k) { st->smin[k] = 0xffffffffu; st->smax[k] = 0u; st->gmin[k] = 0xffffffffu; st->gmax[k] = 0u; }
 	}

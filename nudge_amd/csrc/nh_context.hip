@@ -11,7 +11,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->device = device;
 	ctx->stream = (hipStream_t)stream;
 	ctx->flags = (flags & NH_FLAG_FUSED_STEP) ? (flags | NH_FLAG_SINGLE_APPLY) : flags;
-	ctx->after_collide = false; ctx->grav.pending = false; ctx->adv.done = false;
+	ctx->after_collide = false; ctx->grav.pending = false; ctx->grav.rest_pending = false; ctx->adv.done = false; ctx->adv.rest = true;
 	ctx->tag_bits = 32;
 	ctx->last_hip_error = 0;
 	ctx->timing = false;
@@ -107,7 +107,7 @@ extern "C" int nh_read_counts(nh_context* ctx, nh_Counts* out) {
 	out->colliders = h->colliders; out->pairs = h->pairs + h->pairs_sph; out->contacts = h->contacts; out->sleeping_pairs = h->sleeping;
 	out->active_bodies = h->active; out->cache = h->cache; out->culled = h->culled; out->large_colliders = h->large;
 	out->general_contacts = h->general_contacts; out->levels = h->levels; out->error = h->error;
-	out->static_bodies = h->static_bodies; out->unleveled = h->unleveled; out->raw_pairs = h->pairs + h->pairs_sph;
+	out->has_other_bodies = h->has_other; out->unleveled = h->unleveled; out->raw_pairs = h->pairs + h->pairs_sph;
 	if (ctx->timing) nh_timer_collect(ctx);
 	return NH_OK;
 }

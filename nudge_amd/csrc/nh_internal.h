@@ -35,7 +35,7 @@ struct nh_DevState {
 	uint32_t general_contacts;
 	uint32_t levels;
 	uint32_t error;
-	uint32_t static_bodies;       // bodies solved by the one-body fast path (sum of the three classes below)
+	uint32_t has_other;           // some body is NOT of the class the fused one-body solver owns (k_adj_simple; NH_FLAG_FUSED_STEP: the rest kernels have work)
 	uint32_t unleveled;           // general contacts still without a level (relaxation progress)
 	uint32_t pad0;                // always 0 (used as a constant device-side count)
 	uint32_t has_static8, has_staticN;    // any body in the rarer fast-path classes (plain stores, no counting)
@@ -137,8 +137,8 @@ struct nh_context {
 	// NH_FLAG_FUSED_STEP: gravity / damping recorded by an nh_apply_gravity_damping that directly follows nh_collide (`after_collide`) and applied by
 	// the fused one-body solver when it loads a body's momentum (everybody else: k_gravity_rest); the advance that solver performed for its bodies
 	bool after_collide;
-	struct { bool pending; float gx_dt, gy_dt, gz_dt, damping, time_step; const uint32_t* active; nh_BodyMomentum* momentum; uint32_t body_count; } grav;
-	struct { bool done; float time_step; const uint8_t* body_class; } adv;
+	struct { bool pending, rest_pending; float gx_dt, gy_dt, gz_dt, damping, time_step; const uint32_t* active; nh_BodyMomentum* momentum; uint32_t body_count; } grav;
+	struct { bool done, rest; float time_step; const uint8_t* body_class; } adv;      // `rest`: some active body is not the fused solver's (the step's round trip told)
 };
 
 // Runs work that an earlier call deferred; every entry point that reads or writes momentum / impulses calls it first.
@@ -169,7 +169,6 @@ struct nh_ContactConstraintData {
 	float* states;                        // K x 4 floats (nh_state + pad)
 	uint32_t* body_off;                   // B+1 CSR offsets into adj
 	uint32_t* adj;                        // contact indices per dynamic body, solver order
-	uint32_t* static_bodies;              // 3 x B: bodies on the one-body fast path, by contact count (<=4 | <=8 | more)
 	uint8_t* body_class;
 	uint2* simple;                        // per body of k_adj_simple's classes: first contact, count | slot order << 4 (nh_solve.hip)                  // 0 none, 1 static-only, 2 general
 	uint32_t* level_order;                // general contacts sorted by level
@@ -181,7 +180,6 @@ struct nh_ContactConstraintData {
 	uint32_t general_contacts;
 	uint32_t contact_capacity;
 	uint32_t body_count;
-	uint32_t static_body_count;
 	bool has_static8, has_staticN, static_inert;
 	uint32_t resident_cap;                // its row stride in LDS (all rows radial: 1792, else 704)
 	bool resident;                        // the general set is small enough for the one-workgroup LDS-resident solver (k_solve_resident)

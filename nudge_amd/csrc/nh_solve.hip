@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st
                                                     const uint32_t* __restrict__ first_contact, const uint32_t* __restrict__ slot_key,
                                                     uint8_t* __restrict__ body_class, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                     uint2* __restrict__ simple) {
+	bool other = false;
 	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < nbodies; x += gridDim.x * blockDim.x) {
 		if (x == 0) {
 			body_class[0] = 0;
@@ -260,7 +261,10 @@ __global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st
 			momentum[x].unused0 = props[x].mass_inverse;
 		}
 		body_class[x] = (uint8_t)cls;
+		other |= cls != NH_CLS_STATIC4;
 	}
+	// (one plain store per wave that has such a body: no counting)
+	if (__builtin_amdgcn_ballot_w64(other) != 0 && nh_lane() == 0) st->has_other = 1u;
 }
 
 // CSR form of the lists k_adj_simple recorded (only when a kernel that walks off[] / adj[] is about to run: several apply calls per
@@ -841,7 +845,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 	// `require_inert`: bit 0 -- launched before the host knew whether body 0 is inert (leave if it is not); bit 1 -- NH_FLAG_SINGLE_APPLY: no later
 	// nh_apply_impulses will continue from the solver states, so they are not stored
 	const bool keep_states = !(require_inert & 2u);
-	if (nbodies == 0u || ((require_inert & 1u) && !cv.st->static_inert)) return;
+	if (nbodies == 0u) return;
+	// (the two words of device state -- is body 0 inert, how long is the cache -- are fetched beside the first round of loads, not before it)
+	const uint32_t inert_word = (require_inert & 1u) ? cv.st->static_inert : 1u;
 	__shared__ nh_ob_slot s_slot[NW][64 * M];
 	__shared__ uint32_t s_cid[NW][64 * M];
 	__shared__ uint32_t s_hint[NW][64], s_first[NW][64];
@@ -865,6 +871,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		uint32_t h = NH_HINT_NONE;
 		if (CONTIG) sp = simple[xc];
 		if (FUSED) h = hint[xc];
+		if (!inert_word) return;
 		const bool mine = x < nbodies && (my_class == cls_a || my_class == cls_b);
 		const uint32_t wave_x0 = x - lane;
 		uint32_t b = 0, cnt = 0;
@@ -910,10 +917,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		}
 		// body state: 16-byte loads (the records are 16 / 32 bytes and aligned, include/nudge_hip.h)
 		float4 m0 = make_float4(0, 0, 0, 0), m1 = m0, pr = m0, t0 = m0, t1 = make_float4(0, 0, 0, 1);
+		uint32_t idle_early = 0;
 		if (mine) {
 			m0 = reinterpret_cast<const float4*>(momentum + x)[0]; m1 = reinterpret_cast<const float4*>(momentum + x)[1];
 			pr = *reinterpret_cast<const float4*>(props + x);
 			t0 = reinterpret_cast<const float4*>(xf + x)[0]; t1 = reinterpret_cast<const float4*>(xf + x)[1];
+			if (CONTIG && (fs.bits & 2u)) idle_early = fs.idle[x];
 			if (CONTIG && (fs.bits & 1u)) {          // NH_FLAG_FUSED_STEP: gravity / damping (k_gravity) on the way in
 				float vel[3] = { m0.x, m0.y, m0.z }, ang[3] = { m1.x, m1.y, m1.z };
 				nh_gravity_damping(vel, ang, fs.gx_dt, fs.gy_dt, fs.gz_dt, fs.damping);
@@ -984,11 +993,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 					if ((uint32_t)q < cnt) nh_apply_one1(r[q], s[q], v, is_a[q]);
 			}
 		}
-		// NH_FLAG_FUSED_STEP: the advance (k_advance) on the way out; the transform is fetched again here rather than held across the sweeps
+		// NH_FLAG_FUSED_STEP: the advance (k_advance) on the way out, from the transform held since phase A (7 registers; a reload would be a third exposed round trip)
 		float4 a0 = make_float4(0, 0, 0, 0), a1 = a0;
 		uint32_t idle_in = 0;
 		const bool advance_here = CONTIG && (fs.bits & 2u) && mine;
-		if (advance_here) { a0 = reinterpret_cast<const float4*>(xf + x)[0]; a1 = reinterpret_cast<const float4*>(xf + x)[1]; idle_in = fs.idle[x]; }
+		if (advance_here) { a0 = t0; a1 = t1; idle_in = idle_early; }
 		// results: state + exported impulse (update_cached_impulses, nudge.cpp:4872-4882) per contact, written by the wave slot by slot
 		__builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -1540,8 +1549,9 @@ extern "C" int nh_advance(nh_context* ctx, const nh_ActiveBodies* active_bodies,
 		// NH_FLAG_FUSED_STEP: the one-body solver advanced its own bodies with the time step gravity was given
 		ctx->adv.done = false;
 		if (nh_asuint(time_step) != nh_asuint(ctx->adv.time_step)) return NH_ERR_INVALID;
-		NH_LAUNCH(ctx, "advance_rest", k_advance_rest, nh_grid_for(bodies->count, 256, 2048), 256, ctx->d_state, active_bodies->indices, ctx->adv.body_class, bodies->transforms,
-		          bodies->momentum, bodies->idle_counters, time_step);
+		if (ctx->adv.rest)
+			NH_LAUNCH(ctx, "advance_rest", k_advance_rest, nh_grid_for(bodies->count, 256, 2048), 256, ctx->d_state, active_bodies->indices, ctx->adv.body_class, bodies->transforms,
+			          bodies->momentum, bodies->idle_counters, time_step);
 		return NH_OK;
 	}
 	NH_LAUNCH(ctx, "advance", k_advance, nh_grid_for(bodies->count, 256, 2048), 256, ctx->d_state, active_bodies->indices, bodies->transforms,
@@ -1656,7 +1666,6 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	ctx->setup_seq = ctx->collide_seq;
 	d->body_off = nh_arena_array<uint32_t>(memory, (size_t)B + 2u, &err);           // CSR offsets (scan of the degrees nh_collide counted)
 	d->adj = nh_arena_array<uint32_t>(memory, (size_t)kcap * 2, &err);
-	d->static_bodies = nh_arena_array<uint32_t>(memory, (size_t)3 * B, &err);
 	d->body_class = nh_arena_array<uint8_t>(memory, B, &err);
 	d->simple = nh_arena_array<uint2>(memory, B, &err);
 	d->level_order = nh_arena_array<uint32_t>(memory, kcap, &err);
@@ -1740,6 +1749,15 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 	if (rc) return rc;
 	if (c.error) return (int)c.error;
 	d->has_late = ctx->h_state->has_pending != 0;
+	// NH_FLAG_FUSED_STEP: gravity / damping of the bodies the fused solver does not own, before anything else reads their momentum -- not launched
+	// at all when every body is the fused solver's (a landed drop scene)
+	ctx->adv.rest = ctx->h_state->has_other != 0 || !ctx->h_state->static_inert;
+	if (ctx->grav.rest_pending) {
+		ctx->grav.rest_pending = false;
+		if (ctx->adv.rest)
+			NH_LAUNCH(ctx, "gravity_rest", k_gravity_rest, nh_grid_for(ctx->grav.body_count, 256, 2048), 256, st, ctx->grav.active, d->body_class, ctx->grav.momentum,
+			          ctx->grav.gx_dt, ctx->grav.gy_dt, ctx->grav.gz_dt, ctx->grav.damping);
+	}
 	if (d->has_late || ctx->h_state->has_static8 || !ctx->h_state->static_inert) ensure_csr(ctx, d);
 	if (d->has_late) {
 		// bodies in several pairs or with dynamic partners (piles, pits): general CSR fill + sort + classification, then the counts again
@@ -1752,7 +1770,6 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 	}
 	run_cull(ctx, imp, c.sleeping_pairs);
 	d->general_contacts = c.general_contacts;
-	d->static_body_count = c.static_bodies;
 	d->has_static8 = ctx->h_state->has_static8 != 0;
 	d->has_staticN = ctx->h_state->has_staticN != 0;
 	d->static_inert = ctx->h_state->static_inert != 0;
@@ -1909,9 +1926,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, \
 		          1u | ((ctx->flags & NH_FLAG_SINGLE_APPLY) ? 2u : 0u), d->simple, fs)
 		if (ctx->env_solver_waves == 4) NH_SOLVE_CONTIG(4); else if (ctx->env_solver_waves == 2) NH_SOLVE_CONTIG(2); else NH_SOLVE_CONTIG(1);
-		if (gravity_here)
-			NH_LAUNCH(ctx, "gravity_rest", k_gravity_rest, nh_grid_for(ctx->grav.body_count, 256, 2048), 256, ctx->d_state, ctx->grav.active, d->body_class, bodies->momentum,
-			          fs.gx_dt, fs.gy_dt, fs.gz_dt, fs.damping);
+		ctx->grav.rest_pending = gravity_here;        // everybody else's gravity: finish_setup, once the round trip has told whether there is anybody else
 		int rc = finish_setup(ctx, d);
 		if (rc) return rc;
 		early4_done = d->static_inert;          // (if body 0 is not inert the speculative launch left at once and the general kernels take everything)
