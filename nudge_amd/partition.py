@@ -25,6 +25,12 @@ an overlapping-subdomain (Schwarz) Gauss-Seidel -- a valid solver whose result d
 in the chaotic regime.  The warm-start cache follows a body for free: it is keyed by collider
 tags, and a body is a ghost on the new owner before it migrates there.
 
+`Partition(..., per_iteration=True)` -- for worlds whose contacts DO cross the cuts (piles, pits): the solver runs one sweep at a
+time (`apply_impulses(…, 1)`, the reference's own loop, example/main.cpp:314-317) and after every sweep each rank sends the
+MOMENTUM (32 B) of the listed bodies again and overwrites its ghosts' momentum with the owner's: both ranks solve a contact that
+crosses the cut, but every sweep starts from the owners' values on both sides instead of drifting apart for a whole step
+(the per-iteration ghost exchange).  Costs I extra neighbour messages per step; off by default.
+
 Restriction: a dynamic body carries exactly ONE collider (any local transform); static colliders are unrestricted.
 
 Transport is pluggable: `LocalCluster` moves tensors between partitions living in one process (tests, one GPU),
@@ -131,8 +137,9 @@ class Partition:
     tensors (`records(name, bytes)`), `set_counts(bodies, boxes, spheres)`, `step(n)` and `params` -- nudge_amd.engine.World
     does; the CPU tests plug the oracle in behind the same four members."""
 
-    def __init__(self, engine, info, epoch=16, speed_floor=1.0):
+    def __init__(self, engine, info, epoch=16, speed_floor=1.0, per_iteration=False):
         import torch
+        self.per_iteration = per_iteration
         self.torch = torch
         self.e = engine
         self.rank, self.ranks = info["rank"], info["ranks"]
@@ -338,6 +345,42 @@ class Partition:
         self.e.step(1)
         self.steps += 1
 
+    # ---- per-iteration mode: the step in phases, ghost momentum refreshed after every sweep ---------------------------
+    def step_begin(self):
+        e = self.e
+        e.collide(); e.gravity(); e.read_cache(); e.setup()
+
+    def sweep(self):
+        self.e.apply(1)
+
+    def momentum_pack(self):
+        out = {}
+        for d in self.neighbours():
+            rec = self.bm[self.ghost_out[d]]
+            out[d] = rec
+            self.stats["step_bytes"] += int(rec.numel())
+        return out
+
+    def momentum_unpack(self, incoming):
+        at = self.n_owned + 1
+        for d in (-1, +1):
+            m = self.ghost_in[d]
+            if m:
+                self.bm[at:at + m] = incoming[d]
+                if hasattr(self.e, "momentum_written"):
+                    self.e.momentum_written()
+            at += m
+
+    def step_end(self):
+        e = self.e
+        e.update(); e.write_cache(); e.advance()
+        if hasattr(e, "step_done"):
+            e.step_done()
+        self.steps += 1
+
+    def iterations(self):
+        return int(self.e.params["iterations"])
+
     def needs_refresh(self):
         return self.steps % self.epoch == 0
 
@@ -379,8 +422,20 @@ class LocalCluster:
                 ins = self._route([p.step_pack() for p in self.parts])
                 for p, i in zip(self.parts, ins):
                     p.step_unpack(i)
-            for p in self.parts:
-                p.local_step()
+            if self.parts[0].per_iteration:
+                for p in self.parts:
+                    p.step_begin()
+                for _it in range(self.parts[0].iterations()):
+                    for p in self.parts:
+                        p.sweep()
+                    ins = self._route([p.momentum_pack() for p in self.parts])
+                    for p, i in zip(self.parts, ins):
+                        p.momentum_unpack(i)
+                for p in self.parts:
+                    p.step_end()
+            else:
+                for p in self.parts:
+                    p.local_step()
 
     def gather(self):
         """Owned bodies of all partitions merged by global id: dict(ids, transforms, momentum, idle), sorted by id."""
@@ -445,7 +500,14 @@ class DistCluster:
                 p.refresh_unpack_ghosts(self._exchange(p.refresh_pack_ghosts(), FULL_BYTES))
             else:
                 p.step_unpack(self._exchange(p.step_pack(), STEP_BYTES, known_counts={d: p.ghost_in[d] for d in p.neighbours()}))
-            p.local_step()
+            if p.per_iteration:
+                p.step_begin()
+                for _it in range(p.iterations()):
+                    p.sweep()
+                    p.momentum_unpack(self._exchange(p.momentum_pack(), 32, known_counts={d: p.ghost_in[d] for d in p.neighbours()}))
+                p.step_end()
+            else:
+                p.local_step()
 
     def gather(self, dst=0):
         """Owned bodies of all ranks merged by global id on rank `dst` (None elsewhere)."""

@@ -47,7 +47,50 @@ class OracleEngine:
     def _np(self, name, dtype, n):
         return np.frombuffer(self.t[name][:n].numpy().tobytes(), dtype=dtype, count=n)
 
-    def step(self, steps=1):
+    # the step in phases (Partition(per_iteration=True)): the caller-side tensors are the truth between phases, so the momentum goes in
+    # before every sweep and comes out after it
+    def _upload(self):
+        self._phase = True
+        self.step(1, only_upload=True)
+
+    def collide(self): self._upload(); self.ref.collide()
+    def gravity(self): self.ref.gravity()
+    def read_cache(self): self.ref.read_cache()
+
+    def setup(self):
+        self.ref.setup()
+        self._download(momentum_only=True)
+
+    def apply(self, iterations):
+        v = self.ref._view()
+        _view_array(v.body_momentum, S.MOMENTUM, self.nb)[:] = self._np("bm", S.MOMENTUM, self.nb)
+        self.ref.apply(iterations)
+        self._download(momentum_only=True)
+
+    def update(self):
+        v = self.ref._view()
+        _view_array(v.body_momentum, S.MOMENTUM, self.nb)[:] = self._np("bm", S.MOMENTUM, self.nb)
+        self.ref.update()
+
+    def write_cache(self): self.ref.write_cache()
+
+    def advance(self):
+        self.ref.advance()
+        self._download()
+
+    def _download(self, momentum_only=False):
+        nb = self.nb
+        out = self.ref.bodies()
+        self.t["bm"][:nb] = torch.from_numpy(np.ascontiguousarray(out["momentum"]).view(np.uint8).reshape(nb, 32).copy())
+        if momentum_only:
+            return
+        gid = self._np("bt", S.TRANSFORM, nb)["body"].copy()
+        bt = out["transforms"].copy()
+        bt["body"] = gid                                             # the global id rides in the unused field
+        self.t["bt"][:nb] = torch.from_numpy(np.ascontiguousarray(bt).view(np.uint8).reshape(nb, 32).copy())
+        self.t["bi"][:nb, 0] = torch.from_numpy(out["idle"].copy())
+
+    def step(self, steps=1, only_upload=False):
         r, v = self.ref, self.ref._view()
         nb, nx, ns = self.nb, self.nbox, self.nsph
         for _ in range(steps):
@@ -69,14 +112,10 @@ class OracleEngine:
                 _view_array(v.sphere_transforms, S.TRANSFORM, ns)[:] = self._np("sx", S.TRANSFORM, ns)
             r.L.ref_world_set_counts(r.h, nb, nx, ns, 0)
             r.n_bodies, r.n_boxes, r.n_spheres = nb, nx, ns
+            if only_upload:
+                return
             r.step(1)
-            out = r.bodies()
-            gid = self._np("bt", S.TRANSFORM, nb)["body"].copy()
-            bt = out["transforms"].copy()
-            bt["body"] = gid                                             # the global id rides in the unused field
-            self.t["bt"][:nb] = torch.from_numpy(np.ascontiguousarray(bt).view(np.uint8).reshape(nb, 32).copy())
-            self.t["bm"][:nb] = torch.from_numpy(np.ascontiguousarray(out["momentum"]).view(np.uint8).reshape(nb, 32).copy())
-            self.t["bi"][:nb, 0] = torch.from_numpy(out["idle"].copy())
+            self._download()
 
 
 def single_world_reference(scene, steps):

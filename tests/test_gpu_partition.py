@@ -66,3 +66,56 @@ def test_migration_on_the_gpu():
     for q in parts:
         q.e.close()
     single.close()
+
+
+def test_per_iteration_ghost_exchange_on_the_gpu():
+    """Partition(per_iteration=True) on the HIP engine: one nh_apply_impulses(…, 1) per sweep with the ghosts' momentum overwritten by their
+    owners' in between (torch copies on the library's stream).  A heap forming across the cut: after every step each ghost equals its owner bit
+    for bit, while with the per-step exchange it is off by up to 1e-1 in the same window; nh_apply_impulses(…, 1) x I equals one call of I sweeps."""
+    scene = S.pile(n_boxes=120, n_spheres=0, seed=3)
+    scene["body_transforms"]["position"][1:, 1] *= 0.08
+    scene["body_transforms"]["position"][1:, 1] += 1.0
+
+    def deviation(parts):
+        worst, n = 0.0, 0
+        for r, p in enumerate(parts):
+            at = p.n_owned + 1
+            for d in (-1, +1):
+                m = p.ghost_in[d]
+                if m:
+                    owner = parts[r + d]
+                    idx = owner.ghost_out[-d]
+                    for mine, theirs in ((p.bt[at:at + m, :12], owner.bt[idx][:, :12]), (p.bt[at:at + m, 16:], owner.bt[idx][:, 16:]),
+                                         (p.bm[at:at + m, :12], owner.bm[idx][:, :12]), (p.bm[at:at + m, 16:28], owner.bm[idx][:, 16:28])):
+                        a = np.frombuffer(mine.contiguous().cpu().numpy().tobytes(), np.float32).astype(np.float64)
+                        b = np.frombuffer(theirs.contiguous().cpu().numpy().tobytes(), np.float32).astype(np.float64)
+                        worst = max(worst, float(np.abs(a - b).max()))
+                    n += m
+                at += m
+        return worst, n
+
+    for per_iteration in (False, True):
+        parts = []
+        for r in range(2):
+            local, info = PT.split_scene(scene, [0.3], r, min_extra=2048)
+            w = E.World(local, flags=0, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=16 * info["capacity"]["bodies"])
+            parts.append(PT.Partition(w, info, epoch=8, per_iteration=per_iteration))
+        cl = PT.LocalCluster(parts)
+        cl.step(12)
+        worst = 0.0
+        for _ in range(60):
+            cl.step(1)
+            for q in parts:
+                q.e.synchronize()
+            dev, n = deviation(parts)
+            assert n > 20
+            worst = max(worst, dev)
+        got = cl.gather()
+        assert np.isfinite(got["transforms"]["position"]).all()
+        if per_iteration:
+            assert worst == 0.0, worst
+        else:
+            assert worst > 1e-4
+        for q in parts:
+            assert q.e.counts()["error"] == 0
+            q.e.close()
