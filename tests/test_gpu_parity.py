@@ -472,6 +472,46 @@ def test_fused_step_survives_calls_that_break_the_promised_order():
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("case", ["pit 12^3 settling", "pile falling asleep and woken", "pit 6^3 (resident solver)"])
+def test_colours_seeded_from_the_cache_are_final_without_a_check(case, monkeypatch):
+    """Default order: a contact that existed last step starts with last step's colour (it rides in the cache record), and k_colour_seed_final takes
+    those colours as FINAL -- two cached colours cannot clash, because the two contacts already shared their body when a proper colouring wrote them.
+    NH_COLOUR_CHECK_SEEDS=1 sends the seeds through a settle round (which would un-colour the loser of a clash): the two runs must stay bit-identical
+    while a pit forms and settles, and while a pile falls asleep and is woken by a box dropped on it (cached entries of sleeping sets come back)."""
+    if case.startswith("pit 12"):
+        scene, steps = S.ball_pit(nx=12, ny=12, nz=12, seed=4), 400
+    elif case.startswith("pit 6"):
+        scene, steps = S.ball_pit(nx=6, ny=6, nz=6, seed=4), 300
+    else:
+        scene, steps = S.pile(n_boxes=256, n_spheres=0, seed=1, iterations=4), 1600
+    a = E.World(scene, flags=FAST)
+    monkeypatch.setenv("NH_COLOUR_CHECK_SEEDS", "1")
+    b = E.World(scene, flags=FAST)
+    monkeypatch.delenv("NH_COLOUR_CHECK_SEEDS")
+    most_general, slept = 0, False
+    for k in range(steps // 50):
+        a.step(50); b.step(50)
+        x, y = a.get_bodies(), b.get_bodies()
+        assert P.bits_equal(x["transforms"], y["transforms"]) and P.bits_equal(x["momentum"], y["momentum"]) and np.array_equal(x["idle"], y["idle"]), (case, k)
+        most_general = max(most_general, a.counts()["general_contacts"])
+        if case.startswith("pile") and (x["idle"][1:] == 0xff).any() and not slept:
+            slept = True                                  # somebody is asleep: drop a box onto the heap (same edit in both worlds)
+            for w in (a, b):
+                bodies = w.get_bodies()
+                t, m, idle = bodies["transforms"].copy(), bodies["momentum"].copy(), bodies["idle"].copy()
+                top = 1 + int(np.argmax(t["position"][1:, 1]))
+                t["position"][top] = (t["position"][1:, 0].mean(), t["position"][1:, 1].max() + 6.0, t["position"][1:, 2].mean())
+                m["velocity"][top] = (0.0, -12.0, 0.0)
+                idle[top] = 0
+                w.set_bodies(transforms=t, momentum=m, idle=idle)
+    ca, cb = a.get_cache(), b.get_cache()
+    assert ca["count"] == cb["count"] and P.bits_equal(ca["data"]["impulse"], cb["data"]["impulse"])
+    assert most_general > 50
+    if case.startswith("pile"):
+        assert slept, "the pile never fell asleep: nothing was woken"
+    a.close(); b.close()
+
+
 # ---- degenerate inputs ------------------------------------------------------------------------------------------------------------
 def _tiny_scene(n_boxes, n_spheres, apart=True):
     scene = S.pile(n_boxes=max(n_boxes, 1), n_spheres=n_spheres, seed=3)
