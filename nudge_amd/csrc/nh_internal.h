@@ -182,6 +182,7 @@ struct nh_ContactConstraintData {
 	uint32_t body_count;
 	bool has_static8, has_staticN, static_inert;
 	uint32_t resident_cap;                // its row stride in LDS (all rows radial: 1792, else 704)
+	bool resident_bodies;                 // small world, larger general set: every body's momentum in one workgroup's LDS (k_solve_resident_bodies)
 	bool resident;                        // the general set is small enough for the one-workgroup LDS-resident solver (k_solve_resident)
 	bool csr_ready;                       // body_off[] / adj[] hold the CSR adjacency (built on demand: ensure_csr in nh_solve.hip)
 	const nh_BodyPair* bodies;

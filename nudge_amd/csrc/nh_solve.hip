@@ -1490,6 +1490,98 @@ __global__ __launch_bounds__(NH_RES_THREADS) void k_solve_resident(const nh_DevS
 
 // ---- update_cached_impulses (nudge.cpp:4857-4884) --------------------------------------------------------------------------------
 // (contacts on the one-body fast path export their impulse at the end of every nh_apply_impulses call)
+// ---- mid-size general sets in small worlds: ONE workgroup, every body's momentum resident in LDS ------------------------------------------------
+// When the rows do not fit one compute unit's LDS (k_solve_resident) but the WORLD is small -- at most NH_RESB_MAX_BODIES bodies: the sample
+// application's 1536-body pile -- the other half of the per-sweep traffic does: one workgroup keeps the momentum of every body in LDS (32 B each) for
+// the warm start and all sweeps, streams rows, pairs and states from L2, and separates levels with __syncthreads() instead of kernel boundaries.
+// What a level costs is then one LDS round trip, not a memory round trip, PROVIDED its rows are already there: every thread fetches its contact of
+// the NEXT level (pair, row, state: they do not depend on the sweep in progress) before it processes the current one.  Same arithmetic and level order
+// as k_level_exec; a thread always handles the same contacts, so a state it wrote is its own to read back.
+#define NH_RESB_MAX_BODIES 3584u
+#define NH_RESB_MAX_LEVELS 2046u
+#define NH_RESB_THREADS 512
+struct nh_resb_item { float4 row[10]; float4 sv; uint2 p; uint32_t k; bool valid; };
+__global__ __launch_bounds__(NH_RESB_THREADS) void k_solve_resident_bodies(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ level_off, const uint32_t* __restrict__ level_full,
+                                                                           uint32_t levels, const uint32_t* __restrict__ order, const uint2* __restrict__ gpair,
+                                                                           const nh_CachedContactImpulse* __restrict__ cached, nh_BodyMomentum* momentum, uint32_t nbodies,
+                                                                           const float4* __restrict__ rows4, size_t stride, float4* gstates, uint32_t iterations, uint32_t warm) {
+	__shared__ float4 s_m0[NH_RESB_MAX_BODIES], s_m1[NH_RESB_MAX_BODIES];
+	__shared__ uint32_t s_off[NH_RESB_MAX_LEVELS + 2];
+	__shared__ uint8_t s_full[NH_RESB_MAX_LEVELS + 2];
+	const uint32_t G = st->general_contacts, T = NH_RESB_THREADS, tid = threadIdx.x;
+	for (uint32_t x = tid; x < nbodies; x += T) { s_m0[x] = reinterpret_cast<const float4*>(momentum + x)[0]; s_m1[x] = reinterpret_cast<const float4*>(momentum + x)[1]; }
+	for (uint32_t l = tid; l <= levels + 1u; l += T) { s_off[l] = min(level_off[l], G); s_full[l] = (uint8_t)(level_full[l] != 0u); }
+	__syncthreads();
+	// the contact this thread handles first in level l: loads issued here, consumed one level later
+	auto fetch = [&](uint32_t l, bool with_state, nh_resb_item& it) {
+		const uint32_t k = s_off[l] + tid;
+		it.valid = k < s_off[l + 1];
+		it.k = k;
+		if (it.valid) {
+			it.p = gpair[k];
+			const uint32_t chunks = s_full[l] ? 10u : 3u;            // (a level without a full row holds radial rows only: three chunks)
+#pragma unroll
+			for (uint32_t q = 0; q < 10; ++q) if (q < chunks) it.row[q] = rows4[(size_t)q * stride + k];
+			if (with_state) it.sv = gstates[k];
+		}
+	};
+	auto process = [&](const nh_resb_item& it, bool warm_start, bool state_fetched) {
+		uint2 p = it.p;
+		const bool radial = (p.x & NH_RADIAL_BIT) != 0u;
+		p.x &= ~NH_RADIAL_BIT;
+		const float4 a0 = s_m0[p.x], a1 = s_m1[p.x], b0 = s_m0[p.y], b1 = s_m1[p.y];
+		nh_vel a = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w }, b = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
+		nh_state s;
+		float4 w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (warm_start) w = *reinterpret_cast<const float4*>(cached + order[it.k]);
+		else { const float4 sv = state_fetched ? it.sv : gstates[it.k]; s.normal = sv.x; s.friction_x = sv.y; s.friction_y = sv.z; }
+		if (radial) {
+			nh_rowr r;
+			float4* dst = reinterpret_cast<float4*>(&r);
+#pragma unroll
+			for (uint32_t q = 0; q < 3; ++q) dst[q] = it.row[q];
+			if (warm_start) nh_warm_start_r(r, w.x, w.y, w.z, a, b, s); else nh_apply_radial(r, s, a, b);
+		} else {
+			nh_row r;
+			float4* dst = reinterpret_cast<float4*>(&r);
+#pragma unroll
+			for (uint32_t q = 0; q < 10; ++q) dst[q] = it.row[q];
+			if (warm_start) nh_warm_start(r, w.x, w.y, w.z, a, b, s); else nh_apply_one(r, s, a, b);
+		}
+		gstates[it.k] = make_float4(s.normal, s.friction_x, s.friction_y, 0.0f);
+		if (p.x) { s_m0[p.x] = make_float4(a.vx, a.vy, a.vz, a.mass_inverse); s_m1[p.x] = make_float4(a.wx, a.wy, a.wz, a.w_unused); }      // body 0 is the static world: never written
+		if (p.y) { s_m0[p.y] = make_float4(b.vx, b.vy, b.vz, b.mass_inverse); s_m1[p.y] = make_float4(b.wx, b.wy, b.wz, b.w_unused); }
+	};
+	// the passes as one sequence of level steps: [warm start: levels 1..L] then `iterations` x [levels 1..L]
+	const uint32_t passes = (warm ? 1u : 0u) + iterations;
+	if (passes == 0u || levels == 0u) return;
+	const bool prefetch_state = levels > 1u;            // (with one level the next step's state is the one being written right now)
+	nh_resb_item cur, nxt;
+	fetch(1u, prefetch_state && !warm, cur);
+	for (uint32_t pass = 0; pass < passes; ++pass) {
+		const bool warm_pass = warm && pass == 0u;
+		for (uint32_t l = 1; l <= levels; ++l) {
+			const bool last = l == levels;
+			const bool more = !last || pass + 1u < passes;
+			if (more) fetch(last ? 1u : l + 1u, prefetch_state && !(warm_pass && !last), nxt);        // (the next step is a sweep unless it is still the warm start)
+			if (cur.valid) process(cur, warm_pass, prefetch_state && !warm_pass);
+			// a level with more contacts than threads: the rest, fetched in place
+			for (uint32_t k = s_off[l] + tid + T; k < s_off[l + 1]; k += T) {
+				nh_resb_item extra;
+				extra.k = k; extra.valid = true; extra.p = gpair[k];
+#pragma unroll
+				for (uint32_t q = 0; q < 10; ++q) if (q < (s_full[l] ? 10u : 3u)) extra.row[q] = rows4[(size_t)q * stride + k];
+				process(extra, warm_pass, false);
+			}
+			__syncthreads();
+			if (more) cur = nxt;
+		}
+	}
+	for (uint32_t x = tid + (tid == 0 ? T : 0u); x < nbodies; x += T) {            // (x = 0, the static world, is never written back)
+		reinterpret_cast<float4*>(momentum + x)[0] = s_m0[x]; reinterpret_cast<float4*>(momentum + x)[1] = s_m1[x];
+	}
+}
+
 __global__ __launch_bounds__(256) void k_update_impulses(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ order, const float4* __restrict__ rows4, size_t stride,
                                                          const float4* __restrict__ gstates, nh_CachedContactImpulse* __restrict__ out, const uint32_t* __restrict__ colour,
                                                          const uint2* __restrict__ gpair) {
@@ -1859,9 +1951,17 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		for (uint32_t l = 1; l <= d->levels; ++l) all_radial &= d->level_full[l] == 0u;
 		d->resident_cap = all_radial ? NH_RES_MAX_RADIAL : NH_RES_MAX_FULL;
 		d->resident = G <= d->resident_cap && !ctx->env_no_resident;
+		d->resident_bodies = false;
 		if (d->resident) {
 			NH_LAUNCH(ctx, "solve_resident", k_solve_resident, 1, NH_RES_THREADS, st, level_hist, d->levels, d->level_order, d->gpair, imp->data,
 			          bodies->momentum, (const float4*)d->rows, (size_t)kcap, d->gstates, 0u, 1u, d->resident_cap);
+			return NH_OK;
+		}
+		// more rows than one compute unit's LDS holds, but a small world: every body's momentum resident instead (k_solve_resident_bodies)
+		d->resident_bodies = B <= NH_RESB_MAX_BODIES && d->levels <= NH_RESB_MAX_LEVELS && !ctx->env_no_resident;
+		if (d->resident_bodies) {
+			NH_LAUNCH(ctx, "solve_resident_bodies", k_solve_resident_bodies, 1, NH_RESB_THREADS, st, level_hist, level_hist + (NH_MAX_LEVELS + 2), d->levels, d->level_order, d->gpair,
+			          imp->data, bodies->momentum, B, (const float4*)d->rows, (size_t)kcap, d->gstates, 0u, 1u);
 			return NH_OK;
 		}
 		// warm start in level order (levels are numbered from 1)
@@ -1988,6 +2088,11 @@ extern "C" int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* d, c
 		if (iterations)
 			NH_LAUNCH(ctx, "solve_resident", k_solve_resident, 1, NH_RES_THREADS, ctx->d_state, d->cont.level_hist, d->levels, d->level_order, d->gpair, (const nh_CachedContactImpulse*)nullptr,
 			          bodies->momentum, (const float4*)d->rows, (size_t)d->contact_capacity, d->gstates, iterations, 0u, d->resident_cap);
+	} else if (d->general_contacts && d->resident_bodies) {
+		if (iterations)
+			NH_LAUNCH(ctx, "solve_resident_bodies", k_solve_resident_bodies, 1, NH_RESB_THREADS, ctx->d_state, d->cont.level_hist, d->cont.level_hist + (NH_MAX_LEVELS + 2), d->levels,
+			          d->level_order, d->gpair, (const nh_CachedContactImpulse*)nullptr, bodies->momentum, d->body_count, (const float4*)d->rows, (size_t)d->contact_capacity, d->gstates,
+			          iterations, 0u);
 	} else if (d->general_contacts) {
 		for (uint32_t it = 0; it < iterations; ++it)
 			for (uint32_t l = 1; l <= d->levels; ++l) {

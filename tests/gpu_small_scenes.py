@@ -9,7 +9,9 @@ import time
 CASES = [("pile256 (config 1: 256 boxes, I = 4)", "pile", dict(n_boxes=256, seed=1, iterations=4), 600, 300),
          ("stacks 64 x 3", "stacks", dict(), 100, 300),
          ("pit 6^3 spheres", "ball_pit", dict(nx=6, ny=6, nz=6, seed=4), 200, 300),
-         ("pit 9x9x9 spheres", "ball_pit", dict(nx=9, ny=9, nz=9, seed=4), 250, 300)]
+         ("pit 9x9x9 spheres", "ball_pit", dict(nx=9, ny=9, nz=9, seed=4), 250, 300),
+         ("pit 12^3 spheres", "ball_pit", dict(nx=12, ny=12, nz=12, seed=4), 300, 300),
+         ("sample pile: 1024 boxes + 512 spheres, I = 20", "pile", dict(n_boxes=1024, n_spheres=512, seed=1, iterations=20), 900, 200)]
 
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -408,11 +408,13 @@ def test_single_apply_flag_gives_identical_results_and_refuses_a_second_apply():
 
 @pytest.mark.parametrize("flags", [EXACT, FAST])
 @pytest.mark.parametrize("name,kw,steps,full", [("pile", dict(n_boxes=256, seed=1), 400, True), ("pile", dict(n_boxes=120, n_spheres=60, seed=5), 400, True),
-                                                ("ball_pit", dict(nx=6, ny=6, nz=6, seed=4), 260, False), ("ball_pit", dict(nx=9, ny=9, nz=9, seed=4), 300, False)])
+                                                ("ball_pit", dict(nx=6, ny=6, nz=6, seed=4), 260, False), ("ball_pit", dict(nx=9, ny=9, nz=9, seed=4), 300, False),
+                                                ("ball_pit", dict(nx=12, ny=12, nz=12, seed=4), 300, False), ("pile", dict(n_boxes=1024, n_spheres=512, seed=1), 500, True)])
 def test_lds_resident_solver_is_bit_identical_to_the_per_level_launches(name, kw, steps, full, flags, monkeypatch):
-    """Small general sets are solved by ONE workgroup with the rows in LDS (k_solve_resident); NH_NO_RESIDENT=1 selects the launch-per-level path
-    the large scenes use.  Same level schedule, same arithmetic: every body and every cached impulse must agree bit for bit, in both orders
-    (the 9^3 pit only fits in default order, where all its rows are radial)."""
+    """Small general sets are solved by ONE workgroup with the rows in LDS (k_solve_resident), larger ones in small worlds (the 12^3 pit, the sample
+    application's 1536-body pile) by one workgroup with every body's momentum in LDS (k_solve_resident_bodies); NH_NO_RESIDENT=1 selects the
+    launch-per-level path the large scenes use.  Same level schedule, same arithmetic: every body and every cached impulse must agree bit for bit,
+    in both orders (the 9^3 pit only fits the first kernel in default order, where all its rows are radial)."""
     scene = getattr(S, name)(**kw)
     a = E.World(scene, flags=flags)
     monkeypatch.setenv("NH_NO_RESIDENT", "1")
