@@ -1177,28 +1177,54 @@ __global__ __launch_bounds__(256) void k_colour_seed_final(nh_DevState* __restri
 	block_report(st, left, lmax, 0u);
 }
 
+// the smallest colour none of c's FINISHED neighbours holds
+__device__ __forceinline__ uint32_t colour_pick(uint32_t c, const nh_BodyPair* __restrict__ bodies, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj, const uint32_t* level) {
+	const nh_BodyPair p = bodies[c];
+	unsigned long long used = 0ull;        // colours 1..64 held by finished neighbours
+	uint32_t mx = 64;
+	for (int side = 0; side < 2; ++side) {
+		const uint32_t x = side ? p.b : p.a;
+		if (!x) continue;
+		for (uint32_t q = off[x]; q < off[x + 1]; ++q) {
+			const uint32_t m = adj[q];
+			if (m == c) continue;
+			const uint32_t lm = level[m];
+			if (lm == NH_UNSET) continue;
+			if (lm >= 1 && lm <= 64) used |= 1ull << (lm - 1);
+			else if (lm > mx) mx = lm;
+		}
+	}
+	return ~used ? (uint32_t)__ffsll((long long)~used) : mx + 1u;      // more than 64 colours around one contact: one past the largest
+}
+
+// does c keep its pick `mine`?  Not if a neighbour holds or picked the same colour and has the higher hashed priority.
+__device__ __forceinline__ bool colour_loses(uint32_t c, uint32_t mine, const nh_BodyPair* __restrict__ bodies, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
+                                             uint32_t* level, const uint32_t* tent) {
+	const uint32_t pc = colour_priority(c);
+	const nh_BodyPair p = bodies[c];
+	for (int side = 0; side < 2; ++side) {
+		const uint32_t x = side ? p.b : p.a;
+		if (!x) continue;
+		for (uint32_t q = off[x]; q < off[x + 1]; ++q) {
+			const uint32_t m = adj[q];
+			if (m == c) continue;
+			const uint32_t lm = __hip_atomic_load(&level[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t cm = lm != NH_UNSET ? lm : tent[m];       // (tent[m] of a contact finished long ago is stale, but then lm is set)
+			if (cm != mine) continue;
+			const uint32_t pm = colour_priority(m);
+			if (pm > pc || (pm == pc && m > c)) return true;
+		}
+	}
+	return false;
+}
+
 __global__ __launch_bounds__(256) void k_colour_try(nh_DevState* __restrict__ st, const uint32_t* __restrict__ list, uint32_t n_list, const nh_BodyPair* __restrict__ bodies,
                                                     const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj, const uint32_t* __restrict__ level, uint32_t* __restrict__ tent) {
 	const uint32_t n = n_list ? n_list : st->general_contacts;
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
 		const uint32_t c = list[k];
 		if (level[c] != NH_UNSET) continue;
-		const nh_BodyPair p = bodies[c];
-		unsigned long long used = 0ull;        // colours 1..64 held by finished neighbours
-		uint32_t mx = 64;
-		for (int side = 0; side < 2; ++side) {
-			const uint32_t x = side ? p.b : p.a;
-			if (!x) continue;
-			for (uint32_t q = off[x]; q < off[x + 1]; ++q) {
-				const uint32_t m = adj[q];
-				if (m == c) continue;
-				const uint32_t lm = level[m];
-				if (lm == NH_UNSET) continue;
-				if (lm >= 1 && lm <= 64) used |= 1ull << (lm - 1);
-				else if (lm > mx) mx = lm;
-			}
-		}
-		tent[c] = ~used ? (uint32_t)__ffsll((long long)~used) : mx + 1u;      // more than 64 colours around one contact: one past the largest
+		tent[c] = colour_pick(c, bodies, off, adj, level);
 	}
 }
 
@@ -1211,27 +1237,77 @@ __global__ __launch_bounds__(256) void k_colour_settle(nh_DevState* __restrict__
 		if (__hip_atomic_load(&level[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != NH_UNSET) continue;       // finished in an earlier round (only I write my own entry)
 		const uint32_t mine = tent[c];
 		if (mine == 0u) { ++left; continue; }                 // (a new contact in round 0: no pick yet)
-		const uint32_t pc = colour_priority(c);
-		const nh_BodyPair p = bodies[c];
-		bool lose = false;
-		for (int side = 0; side < 2 && !lose; ++side) {
-			const uint32_t x = side ? p.b : p.a;
-			if (!x) continue;
-			for (uint32_t q = off[x]; q < off[x + 1]; ++q) {
-				const uint32_t m = adj[q];
-				if (m == c) continue;
-				const uint32_t lm = __hip_atomic_load(&level[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				const uint32_t cm = lm != NH_UNSET ? lm : tent[m];       // (tent[m] of a contact finished long ago is stale, but then lm is set)
-				if (cm != mine) continue;
-				const uint32_t pm = colour_priority(m);
-				if (pm > pc || (pm == pc && m > c)) { lose = true; break; }
-			}
-		}
-		if (lose) { ++left; continue; }
+		if (colour_loses(c, mine, bodies, off, adj, level, tent)) { ++left; continue; }
 		__hip_atomic_store(&level[c], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		lmax = max(lmax, mine);
 	}
 	block_report(st, left, lmax, round);
+}
+
+// ---- small general sets: the whole colouring and the level order in ONE workgroup -------------------------------------------------------------
+// Seeds, try / settle rounds, level histogram, offsets and the scatter into level order are seven kinds of launches and, between the rounds, one host
+// round trip each (the host asks whether anybody is still uncoloured).  For a few thousand contacts the round trips ARE the cost (the sample
+// application's pile: 0.37 of its 1.0 ms step).  One 1024-thread workgroup does all of it with __syncthreads() between the phases; same rules as the
+// grid kernels (colour_pick / colour_loses), so the colouring is the same proper, deterministic one.  Writes st->levels, the level offsets and the
+// "level has a full row" flags' zero state where k_level_offsets / k_zero_u32 would.
+#define NH_COLOUR_SMALL_MAX 8192u
+__global__ __launch_bounds__(1024) void k_colour_small(nh_DevState* __restrict__ st, const uint32_t* __restrict__ list, const nh_CachedContactImpulse* __restrict__ warm,
+                                                       const nh_BodyPair* __restrict__ bodies, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
+                                                       uint32_t* level, uint32_t* tent, uint32_t* __restrict__ hist /* 2 x (NH_MAX_LEVELS + 2) */, uint32_t* __restrict__ order) {
+	__shared__ uint32_t s_hist[NH_MAX_LEVELS + 2];
+	__shared__ uint32_t s_left, s_max, s_wsum[16];
+	const uint32_t n = min(st->general_contacts, NH_COLOUR_SMALL_MAX), T = 1024u, tid = threadIdx.x;
+	if (tid == 0) { s_left = 0; s_max = 0; }
+	for (uint32_t l = tid; l < NH_MAX_LEVELS + 2; l += T) { s_hist[l] = 0; hist[NH_MAX_LEVELS + 2 + l] = 0; }
+	__syncthreads();
+	// round 0: colours that came back with the cache are final (k_colour_seed_final)
+	uint32_t lmax = 0, left = 0;
+	for (uint32_t k = tid; k < n; k += T) {
+		const uint32_t c = list[k];
+		const uint32_t old = __float_as_uint(warm[c].unused);
+		if (old >= 1u && old <= NH_MAX_LEVELS) { level[c] = old; lmax = max(lmax, old); }
+		else { tent[c] = 0u; ++left; }
+	}
+	if (left) atomicAdd(&s_left, left);
+	__syncthreads();
+	for (uint32_t round = 1; s_left != 0u && round <= NH_MAX_LEVELS + 8u; ++round) {
+		__syncthreads();                                     // (everybody has read s_left)
+		if (tid == 0) s_left = 0;
+		for (uint32_t k = tid; k < n; k += T) {
+			const uint32_t c = list[k];
+			if (level[c] == NH_UNSET) tent[c] = colour_pick(c, bodies, off, adj, level);
+		}
+		__syncthreads();
+		left = 0;
+		for (uint32_t k = tid; k < n; k += T) {
+			const uint32_t c = list[k];
+			if (__hip_atomic_load(&level[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != NH_UNSET) continue;
+			const uint32_t mine = tent[c];
+			if (colour_loses(c, mine, bodies, off, adj, level, tent)) { ++left; continue; }
+			__hip_atomic_store(&level[c], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			lmax = max(lmax, mine);
+		}
+		if (left) atomicAdd(&s_left, left);
+		__syncthreads();
+	}
+	// levels, histogram, exclusive offsets (k_level_hist + k_level_offsets), scatter into level order (k_level_scatter)
+	if (lmax) atomicMax(&s_max, lmax);
+	for (uint32_t k = tid; k < n; k += T) { const uint32_t l = level[list[k]]; if (l <= NH_MAX_LEVELS) atomicAdd(&s_hist[l], 1u); else st->error = NH_ERR_INVALID; }
+	__syncthreads();
+	if (tid == 0) { st->levels = s_max; if (s_left) st->error = NH_ERR_INVALID; }
+	const uint32_t per = (NH_MAX_LEVELS + 2 + T - 1) / T;
+	const uint32_t base = tid * per;
+	uint32_t sum = 0;
+	for (uint32_t i = 0; i < per; ++i) if (base + i < NH_MAX_LEVELS + 2) sum += s_hist[base + i];
+	uint32_t x = sum;
+	for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if ((int)(tid & 63) >= d) x += y; }
+	if ((tid & 63) == 63) s_wsum[tid >> 6] = x;
+	__syncthreads();
+	uint32_t run = x - sum;
+	for (uint32_t w = 0; w < (tid >> 6); ++w) run += s_wsum[w];
+	for (uint32_t i = 0; i < per; ++i) if (base + i < NH_MAX_LEVELS + 2) { const uint32_t v = s_hist[base + i]; hist[base + i] = run; s_hist[base + i] = run; run += v; }
+	__syncthreads();
+	for (uint32_t k = tid; k < n; k += T) { const uint32_t c = list[k]; const uint32_t l = level[c]; if (l <= NH_MAX_LEVELS) order[atomicAdd(&s_hist[l], 1u)] = c; }
 }
 
 // the contacts of `list` that are still uncoloured, in any order (a round's outcome does not depend on who looks at which contact).
@@ -1438,6 +1514,7 @@ __global__ __launch_bounds__(NH_RES_THREADS) void k_solve_resident(const nh_DevS
 	__shared__ float4 s_state[NH_RES_MAX_RADIAL];
 	__shared__ uint2 s_pair[NH_RES_MAX_RADIAL];
 	const uint32_t G = min(st->general_contacts, cap);
+	if (levels == 0u) levels = st->levels;               // (the one-workgroup colouring leaves the count on the device: no host round trip)
 	for (uint32_t k = threadIdx.x; k < G; k += NH_RES_THREADS) {
 		const uint2 p = gpair[k];
 		s_pair[k] = p;
@@ -1509,6 +1586,8 @@ __global__ __launch_bounds__(NH_RESB_THREADS) void k_solve_resident_bodies(const
 	__shared__ uint32_t s_off[NH_RESB_MAX_LEVELS + 2];
 	__shared__ uint8_t s_full[NH_RESB_MAX_LEVELS + 2];
 	const uint32_t G = st->general_contacts, T = NH_RESB_THREADS, tid = threadIdx.x;
+	if (levels == 0u) levels = st->levels;               // (the one-workgroup colouring leaves the count on the device: no host round trip)
+	if (levels > NH_RESB_MAX_LEVELS) { if (tid == 0) const_cast<nh_DevState*>(st)->error = NH_ERR_INVALID; return; }
 	for (uint32_t x = tid; x < nbodies; x += T) { s_m0[x] = reinterpret_cast<const float4*>(momentum + x)[0]; s_m1[x] = reinterpret_cast<const float4*>(momentum + x)[1]; }
 	for (uint32_t l = tid; l <= levels + 1u; l += T) { s_off[l] = min(level_off[l], G); s_full[l] = (uint8_t)(level_full[l] != 0u); }
 	__syncthreads();
@@ -1892,6 +1971,22 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 	if (c.general_contacts) {
 		const uint32_t G = c.general_contacts;
 		materialize_lookup(ctx, imp, contacts->bodies, d->body_class);
+		// A few thousand contacts in default order: colouring and level order by ONE workgroup, no host round trip until the solver's (k_colour_small)
+		if (!(ctx->flags & NH_FLAG_EXACT_ORDER) && !ctx->env_colour_jp && !ctx->env_no_resident && !ctx->env_colour_check_seeds && G <= NH_COLOUR_SMALL_MAX &&
+		    (G <= NH_RES_MAX_FULL || B <= NH_RESB_MAX_BODIES)) {
+			NH_LAUNCH(ctx, "colour_small", k_colour_small, 1, 1024, st, general_list, imp->data, contacts->bodies, d->body_off, d->adj, level, d->cont.tent, level_hist, d->level_order);
+			NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, d->level_order, contacts->data, contacts->bodies, bodies->transforms, bodies->properties,
+			          (float4*)d->rows, (size_t)kcap, d->gpair, 1u, d->static_inert ? 1u : 0u, level, level_hist + (NH_MAX_LEVELS + 2));
+			d->levels = 0;                                  // on the device (st->levels)
+			d->resident = G <= NH_RES_MAX_FULL; d->resident_cap = NH_RES_MAX_FULL; d->resident_bodies = !d->resident;
+			if (d->resident)
+				NH_LAUNCH(ctx, "solve_resident", k_solve_resident, 1, NH_RES_THREADS, st, level_hist, 0u, d->level_order, d->gpair, imp->data,
+				          bodies->momentum, (const float4*)d->rows, (size_t)kcap, d->gstates, 0u, 1u, d->resident_cap);
+			else
+				NH_LAUNCH(ctx, "solve_resident_bodies", k_solve_resident_bodies, 1, NH_RESB_THREADS, st, level_hist, level_hist + (NH_MAX_LEVELS + 2), 0u, d->level_order, d->gpair,
+				          imp->data, bodies->momentum, B, (const float4*)d->rows, (size_t)kcap, d->gstates, 0u, 1u);
+			return NH_OK;
+		}
 		// relaxation: every round finalises at least the next level
 		uint32_t rounds = 0;
 		NH_LAUNCH(ctx, "level_reset", k_level_reset_progress, 1, 1, st);

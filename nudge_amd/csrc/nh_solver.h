@@ -24,6 +24,17 @@
 
 #include "nh_math.h"
 
+// division and reciprocal root of the solver rows: the guarded short sequences of nh_math.h (bit-identical to nh_recip / nh_rsqrt by the
+// exhaustive check, a third of the instructions -- the fused one-body solver and the one-workgroup solvers are bound by instruction issue);
+// -DNH_SOLVER_EXACT_DIV selects the plain forms
+#if defined(NH_SOLVER_EXACT_DIV)
+NH_HD float nh_recip_s(float x) { return nh_recip(x); }
+NH_HD float nh_rsqrt_s(float x) { return nh_rsqrt(x); }
+#else
+NH_HD float nh_recip_s(float x) { return nh_recip_guarded(x); }
+NH_HD float nh_rsqrt_s(float x) { return nh_rsqrt_guarded_z(x); }
+#endif
+
 // World-space inverse inertia R diag R^T, 6 unique terms (nudge.cpp:4182-4197).
 struct nh_inertia { float xx, yy, zz, xy, xz, yz; };
 
@@ -97,7 +108,7 @@ NH_HD void nh_build_row(const nh_contact_in& c, nh_f3 apos, nh_f3 bpos, const nh
 	float nvtni = mass_inverse + r_dot_n;
 	// AVX2 build: cmp_neq is ordered (false on NaN), nudge.cpp:636-638, 4439-4440
 	bool nonzero = (nvtni < 0.0f) || (nvtni > 0.0f);
-	nvtni = nonzero ? (-1.0f / nvtni) : 0.0f;
+	nvtni = nonzero ? nh_neg(nh_recip_s(nvtni)) : 0.0f;
 
 	float bias = (-NH_BIAS_FACTOR) * nh_max(c.penetration - NH_ALLOWED_PENETRATION, 0.0f) * nvtni;
 
@@ -108,7 +119,7 @@ NH_HD void nh_build_row(const nh_contact_in& c, nh_f3 apos, nh_f3 bpos, const nh
 	float u_z = nh_madd(nx - ny, s, ny);
 	u_x = nh_neg(u_x);
 	{
-		float f = nh_rsqrt(u_x * u_x + u_y * u_y + u_z * u_z);
+		float f = nh_rsqrt_s(u_x * u_x + u_y * u_y + u_z * u_z);
 		u_x *= f; u_y *= f; u_z *= f;
 	}
 	float v_x = u_y * nz - u_z * ny, v_y = u_z * nx - u_x * nz, v_z = u_x * ny - u_y * nx;
@@ -173,7 +184,7 @@ NH_HD void nh_warm_start(const nh_row& r, float cix, float ciy, float ciz, nh_ve
 	float fx = r.u_x * cix + r.u_y * ciy + r.u_z * ciz;
 	float fy = r.v_x * cix + r.v_y * ciy + r.v_z * ciz;
 	float scale = fx * fx + fy * fy;
-	scale = nh_rsqrt(scale);
+	scale = nh_rsqrt_s(scale);
 	scale = scale * max_friction_impulse;
 	scale = nh_min(1.0f, scale);
 	fx = fx * scale;
@@ -258,7 +269,7 @@ NH_HD void nh_apply_one(const nh_row& r, nh_state& st, nh_vel& a, nh_vel& b) {
 	friction_factor = nh_madd(t_xy, r.friction_coefficient_z, friction_factor);
 	float linear_impulse_z = r.n_z * normal_impulse;
 
-	friction_factor = nh_recip(friction_factor);
+	friction_factor = nh_recip_s(friction_factor);
 
 	a.wx = nh_madd(r.na_x, normal_impulse, a.wx);
 	a.wy = nh_madd(r.na_y, normal_impulse, a.wy);
@@ -275,7 +286,7 @@ NH_HD void nh_apply_one(const nh_row& r, nh_state& st, nh_vel& a, nh_vel& b) {
 	friction_impulse_y = old_friction_impulse_y - friction_impulse_y;
 
 	float friction_clamp_scale = friction_impulse_x * friction_impulse_x + friction_impulse_y * friction_impulse_y;
-	friction_clamp_scale = nh_rsqrt(friction_clamp_scale);
+	friction_clamp_scale = nh_rsqrt_s(friction_clamp_scale);
 
 	b.wx = nh_madd(r.nb_x, normal_impulse, b.wx);
 	b.wy = nh_madd(r.nb_y, normal_impulse, b.wy);
@@ -343,15 +354,6 @@ NH_HD void nh_apply_one(const nh_row& r, nh_state& st, nh_vel& a, nh_vel& b) {
 // numbers that can differ are signs of exact zeros that are provably never observed: friction_coefficient_z (only ever
 // added to a non-negative accumulator) and r (added to a positive inverse mass).
 // A row shrinks from 39 to 27 floats: four of them fit in registers with room for a second wave per SIMD.
-// division and reciprocal root of the one-body forms: the guarded short sequences of nh_math.h (bit-identical to nh_recip / nh_rsqrt by the
-// exhaustive check, a third of the instructions -- k_solve_one_body is bound by VALU issue); -DNH_SOLVER_EXACT_DIV selects the plain forms
-#if defined(NH_SOLVER_EXACT_DIV)
-NH_HD float nh_recip_s(float x) { return nh_recip(x); }
-NH_HD float nh_rsqrt_s(float x) { return nh_rsqrt(x); }
-#else
-NH_HD float nh_recip_s(float x) { return nh_recip_guarded(x); }
-NH_HD float nh_rsqrt_s(float x) { return nh_rsqrt_guarded_z(x); }
-#endif
 
 struct nh_row1 {
 	float p_z, p_x, p_y;                   // lever arm of D
@@ -605,7 +607,7 @@ NH_HD void nh_tangents(float nx, float ny, float nz, nh_f3& u, nh_f3& v) {
 	float u_y = u_x - nz;
 	float u_z = nh_madd(nx - ny, s, ny);
 	u_x = nh_neg(u_x);
-	float f = nh_rsqrt(u_x * u_x + u_y * u_y + u_z * u_z);
+	float f = nh_rsqrt_s(u_x * u_x + u_y * u_y + u_z * u_z);
 	u_x *= f; u_y *= f; u_z *= f;
 	u = nh_make3(u_x, u_y, u_z);
 	v = nh_make3(u_y * nz - u_z * ny, u_z * nx - u_x * nz, u_x * ny - u_y * nx);
@@ -627,7 +629,7 @@ NH_HD void nh_build_rowr(const nh_contact_in& c, nh_f3 apos, nh_f3 bpos, float k
 	float beta = b_inert ? 0.0f : (c.px - bpos.x) * c.nx + (c.py - bpos.y) * c.ny + (c.pz - bpos.z) * c.nz;
 	float mass_inverse = a_mass_inverse + b_mass_inverse;
 	bool nonzero = (mass_inverse < 0.0f) || (mass_inverse > 0.0f);
-	float nvtni = nonzero ? (-1.0f / mass_inverse) : 0.0f;
+	float nvtni = nonzero ? nh_neg(nh_recip_s(mass_inverse)) : 0.0f;
 	r.n_x = c.nx; r.n_y = c.ny; r.n_z = c.nz;
 	r.bias = (-NH_BIAS_FACTOR) * nh_max(c.penetration - NH_ALLOWED_PENETRATION, 0.0f) * nvtni;
 	r.alpha = alpha; r.beta = beta;
@@ -645,7 +647,7 @@ NH_HD void nh_warm_start_r(const nh_rowr& r, float cix, float ciy, float ciz, nh
 	float fx = u.x * cix + u.y * ciy + u.z * ciz;
 	float fy = v.x * cix + v.y * ciy + v.z * ciz;
 	float scale = fx * fx + fy * fy;
-	scale = nh_rsqrt(scale);
+	scale = nh_rsqrt_s(scale);
 	scale = scale * max_friction_impulse;
 	scale = nh_min(1.0f, scale);
 	fx = fx * scale;
@@ -687,13 +689,13 @@ NH_HD void nh_apply_radial(const nh_rowr& r, nh_state& st, nh_vel& a, nh_vel& b)
 	normal_impulse = normal_impulse - old_normal_impulse;
 
 	float friction_factor = nh_madd(t_yy, r.friction_coefficient, t_xx * r.friction_coefficient);
-	friction_factor = nh_recip(friction_factor);
+	friction_factor = nh_recip_s(friction_factor);
 	friction_factor = nh_min(1e+6f, friction_factor);
 
 	float old_fx = st.friction_x, old_fy = st.friction_y;
 	float fx = old_fx - t_x * friction_factor;
 	float fy = old_fy - t_y * friction_factor;
-	float clamp = nh_rsqrt(fx * fx + fy * fy);
+	float clamp = nh_rsqrt_s(fx * fx + fy * fy);
 	clamp = clamp * max_friction_impulse;
 	clamp = nh_min(1.0f, clamp);
 	fx = fx * clamp;
@@ -768,7 +770,7 @@ NH_HD uint8_t nh_advance_body(float* pos, float* rot, const float* vel, const fl
 	pos[2] += velocity.z * time_step;
 
 	float rx = rot[0] + dr.x, ry = rot[1] + dr.y, rz = rot[2] + dr.z, rs = rot[3] + dr.s;
-	float f = 1.0f / sqrtf(rs * rs + rx * rx + ry * ry + rz * rz);   // nudge.cpp:1128-1133
+	float f = nh_rsqrt_s(rs * rs + rx * rx + ry * ry + rz * rz);   // nudge.cpp:1128-1133
 	rot[0] = rx * f; rot[1] = ry * f; rot[2] = rz * f; rot[3] = rs * f;
 	return idle;
 }
