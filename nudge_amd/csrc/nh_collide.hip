@@ -373,6 +373,11 @@ __device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_
 #ifndef FP_BATCH
 #define FP_BATCH 2          // (A/B on one box, 1 M boxes: 2 -> 42 us, 4 -> 45 us)
 #endif
+// SUB: lanes per collider.  A SMALL world (a pile of a thousand bodies) neither fills the machine with one lane per collider nor has short candidate
+// lists (its cells are as large as its largest box, its boxes lie on top of each other): SUB consecutive lanes then share a collider and take every
+// SUB-th candidate of its ranges -- 16 x the lanes, 1/16 of the dependent rounds (the sample application's pile: 84 -> ~10 us).  Each lane emits its
+// own hits; nothing else changes.
+template<int SUB>
 __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st, uint32_t n, uint32_t nbox,
                                                     const uint32_t* __restrict__ keys, const float4* __restrict__ sbox,
                                                     const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
@@ -389,8 +394,9 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 	const nh_f3 mmin = nh_make3(st->morton_min[0], st->morton_min[1], st->morton_min[2]);
 	__shared__ uint2 wave_buf[4][FP_WBUF];
 	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u, FP_WBUF, nbox };
-	uint32_t rounded = (n + 63u) & ~63u;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
+	const uint32_t rounded = ((n + 63u) & ~63u) * SUB;
+	for (uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x; gi < rounded; gi += gridDim.x * blockDim.x) {
+		const uint32_t i = gi / SUB, sub = gi % SUB;
 		bool valid = i < n;
 		float4 amin = make_float4(0, 0, 0, 0), amax = amin;
 		uint32_t key = NH_LARGE_KEY, ca = 0, abody = 0;
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 			if (re[0] < rb[0]) re[0] = rb[0];
 		}
 		// walk the ranges, FP_BATCH candidates per round (wave-uniform loop, lanes without work idle)
-		uint32_t r = 0, j = rb[0], jend = re[0];
+		uint32_t r = 0, j = rb[0] + sub, jend = re[0];
 		for (;;) {
 			uint32_t cand[FP_BATCH];
 			bool have[FP_BATCH];
@@ -430,11 +436,12 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 			for (int k = 0; k < FP_BATCH; ++k) {
 				while (j >= jend && r < 4u) {
 					++r;
-					j = r == 1u ? rb[1] : (r == 2u ? rb[2] : (r == 3u ? rb[3] : rb[4]));
+					j = (r == 1u ? rb[1] : (r == 2u ? rb[2] : (r == 3u ? rb[3] : rb[4]))) + sub;
 					jend = r == 1u ? re[1] : (r == 2u ? re[2] : (r == 3u ? re[3] : re[4]));
 				}
 				have[k] = j < jend;
-				cand[k] = have[k] ? j++ : 0u;
+				cand[k] = have[k] ? j : 0u;
+				if (have[k]) j += SUB;
 			}
 			if (!__any(have[0])) break;
 			float4 bmin[FP_BATCH], bmax[FP_BATCH];
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 			}
 		}
 		// large x larger-indexed large (small x large is found from the large side: k_large_pairs)
-		const bool a_large = valid && key == NH_LARGE_KEY;
+		const bool a_large = valid && key == NH_LARGE_KEY && sub == 0u;
 		if (__ballot(a_large)) {
 			for (uint32_t l = 0; l < nlarge; ++l) {
 				uint32_t cb = large_list[l];
@@ -1053,7 +1060,15 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_sums, max_cells / CS_TILE, 256, cstart, cscan_sums);
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_final, max_cells / CS_TILE, 256, cstart, cscan_sums, max_cells);
 		NH_LAUNCH(ctx, "cell_scatter", k_cell_scatter, nh_grid_for(C, 256, 2048), 256, st, C, keys_a, vals_a, cstart, aabb_min, aabb_max, keys_b, sbox);
-		NH_LAUNCH(ctx, "find_pairs", k_find_pairs, nh_grid_for(C, 256, 4096), 256, st, C, nbox, keys_b, sbox, cstart, large_list, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+		const int fp_sub = ctx->env_fp_sub ? ctx->env_fp_sub : (C <= 16384u ? 16 : 1);
+		if (fp_sub == 4)
+			NH_LAUNCH(ctx, "find_pairs", k_find_pairs<4>, nh_grid_for((uint64_t)C * 4u, 256, 16384), 256, st, C, nbox, keys_b, sbox, cstart, large_list, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+		else if (fp_sub == 2)
+			NH_LAUNCH(ctx, "find_pairs", k_find_pairs<2>, nh_grid_for((uint64_t)C * 2u, 256, 8192), 256, st, C, nbox, keys_b, sbox, cstart, large_list, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+		else if (fp_sub == 16)
+			NH_LAUNCH(ctx, "find_pairs", k_find_pairs<16>, nh_grid_for((uint64_t)C * 16u, 256, 4096), 256, st, C, nbox, keys_b, sbox, cstart, large_list, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+		else
+			NH_LAUNCH(ctx, "find_pairs", k_find_pairs<1>, nh_grid_for(C, 256, 4096), 256, st, C, nbox, keys_b, sbox, cstart, large_list, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
 		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, LP_GRID, LP_THREADS, st, nbox, sbox, cstart, large_list, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
 		// coarse islands over the broadphase pairs (united where the pairs were emitted) + connections: only when some body is asleep (a device
 		// flag: the kernels leave at once otherwise)

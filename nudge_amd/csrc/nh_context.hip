@@ -37,6 +37,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->env_sort_radix = getenv("NH_SORT_RADIX") != nullptr;
 	ctx->env_colour_jp = getenv("NH_COLOUR_JP") != nullptr;
 	ctx->env_solver_waves = getenv("NH_SOLVER_WAVES") ? atoi(getenv("NH_SOLVER_WAVES")) : 1;      // wavefronts per workgroup of the fused solver (A/B: 1, 2, 4)
+	ctx->env_fp_sub = getenv("NH_FP_SUB") ? atoi(getenv("NH_FP_SUB")) : 0;      // lanes per collider in the pair search (A/B: 1, 2, 4, 16; 0 = by world size)
 	ctx->env_colour_check_seeds = getenv("NH_COLOUR_CHECK_SEEDS") != nullptr;      // colours seeded from the cache go through a settle round instead of being final at once (A/B, tests)
 	ctx->env_no_resident = getenv("NH_NO_RESIDENT") != nullptr;      // NH_NO_RESIDENT=1: small general sets also take the one-launch-per-level path (A/B, tests)
 	ctx->os_resident = 0;
