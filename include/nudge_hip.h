@@ -168,6 +168,7 @@ typedef struct nh_Counts {
 	uint32_t has_other_bodies;  /* non-zero: some body is outside the one-body fast path's common class (several pairs, dynamic partners, no contacts) */
 	uint32_t unleveled;         /* internal: progress of the level relaxation */
 	uint32_t raw_pairs;         /* broadphase pairs before any filter (diagnostic) */
+	uint32_t broadphase_rebuilds; /* nh_collide calls since nh_create that regrouped the colliders and searched the grid; the others re-used the kept pair list */
 } nh_Counts;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */

@@ -17,12 +17,15 @@
 // aabb_min[c] = (min.xyz, bits(body)), aabb_max[c] = (max.xyz, bits(max extent))
 // 1024-thread workgroups, one per CU: the scene bounds / histogram end in a handful of global atomics per WORKGROUP on the same
 // few addresses (~12 ns each, serialised), so the fewer workgroups the better.
+// inflation of the kept pair list's boxes: 1/32 of the last grid's cell (nothing is known before the first grid)
+__device__ __forceinline__ float nh_kept_margin(float cell_inv) { return cell_inv > 0.0f ? 0.03125f / cell_inv : 0.05f; }
+
 __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
                                                const nh_Transform* __restrict__ body_xf,
                                                const nh_Transform* __restrict__ box_xf, const nh_BoxCollider* __restrict__ box_data, const uint32_t* __restrict__ box_tags, uint32_t nbox,
                                                const nh_Transform* __restrict__ sph_xf, const nh_SphereCollider* __restrict__ sph_data, const uint32_t* __restrict__ sph_tags, uint32_t nsph,
                                                nh_xform* __restrict__ xf, float4* __restrict__ aabb_min, float4* __restrict__ aabb_max, uint32_t* __restrict__ ctag,
-                                               uint4* __restrict__ zero16, uint32_t zero16_count) {
+                                               uint4* __restrict__ zero16, uint32_t zero16_count, const float4* __restrict__ fat_box) {
 	__shared__ uint32_t hist[1024];
 	__shared__ uint32_t red[12];
 	hist[threadIdx.x] = 0;
@@ -35,6 +38,10 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 	// bounds of the "small" colliders under LAST step's size split (nh_grid_setup keeps them if the split has not moved)
 	const uint32_t guess_exp = st->small_exp;
 	uint32_t gmn[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, gmx[3] = { 0, 0, 0 };
+	// kept pair list (below, "6. kept pairs"): is every AABB still inside the inflated box the kept pairs were found with?
+	const bool fat_valid = st->fat_valid != 0u;
+	const float margin = nh_kept_margin(st->cell_inv);           // (k_grid_setup records the same value for k_cell_keys before it moves the grid)
+	bool escaped = false;
 	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
 		bool is_box = c < nbox;
 		nh_Transform l = is_box ? box_xf[c] : sph_xf[c - nbox];
@@ -67,16 +74,24 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 		xf[c] = w;
 		aabb_min[c] = make_float4(mnx, mny, mnz, __uint_as_float(l.body));
 		aabb_max[c] = make_float4(mxx, mxy, mxz, ext);
+		if (fat_valid) {
+			const float4 fmn = fat_box[2u * c], fmx = fat_box[2u * c + 1u];
+			escaped |= !(mnx >= fmn.x && mny >= fmn.y && mnz >= fmn.z && mxx <= fmx.x && mxy <= fmx.y && mxz <= fmx.z);       // (NaN: escaped)
+		}
+		// the inflated box a rebuild would sort and search (k_cell_keys writes it then): the grid's statistics (size class, bounds of the small
+		// ones) are taken from it; the Morton frame (lmin / lmax) is the exact AABBs' (nudge.cpp:3086-3100)
+		const float fx0 = mnx - margin, fy0 = mny - margin, fz0 = mnz - margin, fx1 = mxx + margin, fy1 = mxy + margin, fz1 = mxz + margin;
+		const float fext = fmaxf(fmaxf(fx1 - fx0, fy1 - fy0), fz1 - fz0);
 		uint32_t f;
 		f = nh_float_flip(mnx); lmin[0] = min(lmin[0], f); lmax[0] = max(lmax[0], f);
 		f = nh_float_flip(mny); lmin[1] = min(lmin[1], f); lmax[1] = max(lmax[1], f);
 		f = nh_float_flip(mnz); lmin[2] = min(lmin[2], f); lmax[2] = max(lmax[2], f);
 		// exponent histogram: one LDS atomic per distinct exponent in the wave (usually 2-3), not one per lane
-		uint32_t ebin = (__float_as_uint(ext) >> 21) & 1023u;          // size class: exponent + two mantissa bits (quarter octaves)
-		if (ebin <= guess_exp && ext == ext) {
-			f = nh_float_flip(mnx); gmn[0] = min(gmn[0], f); gmx[0] = max(gmx[0], f);
-			f = nh_float_flip(mny); gmn[1] = min(gmn[1], f); gmx[1] = max(gmx[1], f);
-			f = nh_float_flip(mnz); gmn[2] = min(gmn[2], f); gmx[2] = max(gmx[2], f);
+		uint32_t ebin = (__float_as_uint(fext) >> 21) & 1023u;          // size class: exponent + two mantissa bits (quarter octaves)
+		if (ebin <= guess_exp && fext == fext) {
+			f = nh_float_flip(fx0); gmn[0] = min(gmn[0], f); gmx[0] = max(gmx[0], f);
+			f = nh_float_flip(fy0); gmn[1] = min(gmn[1], f); gmx[1] = max(gmx[1], f);
+			f = nh_float_flip(fz0); gmn[2] = min(gmn[2], f); gmx[2] = max(gmx[2], f);
 		}
 		unsigned long long todo = __ballot(1);
 		while (todo) {
@@ -93,6 +108,7 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 		}
 		if ((threadIdx.x & 63) == 0) { atomicMin(&red[k], lmin[k]); atomicMax(&red[3 + k], lmax[k]); atomicMin(&red[6 + k], gmn[k]); atomicMax(&red[9 + k], gmx[k]); }
 	}
+	if (__ballot(escaped) != 0ull && nh_lane() == 0) st->fat_escaped = 1u;          // (plain store of a constant)
 	__syncthreads();
 	if (hist[threadIdx.x]) atomicAdd(&st->exp_hist[threadIdx.x], hist[threadIdx.x]);
 	if (threadIdx.x < 3) {
@@ -135,6 +151,14 @@ __global__ __launch_bounds__(64) void k_grid_setup(nh_DevState* st, uint32_t nco
 	float scale = nh_morton_scale(smin, smax);
 	st->morton_scale = scale;
 	st->morton_min[0] = smin.x * scale; st->morton_min[1] = smin.y * scale; st->morton_min[2] = smin.z * scale;
+	// kept pair list: while it is valid and nobody has left its inflated box the grid below is not needed this step -- every kernel of the chain
+	// (k_cell_keys .. k_large_pairs) leaves at once and k_kept_filter re-tests the kept pairs; otherwise the candidate boxes k_xform just
+	// wrote become the current ones and the chain rebuilds the list from them
+	const bool rebuild = st->fat_valid == 0u || st->fat_escaped != 0u;
+	st->fat_rebuild = rebuild ? 1u : 0u;
+	if (!rebuild) return;
+	st->fat_margin = nh_kept_margin(st->cell_inv);           // (of the grid about to be replaced: what k_xform used)
+	st->fat_valid = 1u; st->fat_count = 0u; st->fat_rebuilds += 1u;
 	// e = largest size class (exponent << 2 | two mantissa bits) kept "small"; never let the cell underflow to denormals
 	if (e < (64 << 2)) e = 64 << 2;
 	if (e > (190 << 2)) e = 190 << 2;
@@ -180,9 +204,13 @@ __device__ __forceinline__ int cell_coord(float x, float origin, float inv) {
 // whatever the atomics gave; nothing downstream depends on it: a pair is emitted once whichever member comes first, its roles
 // are decided by Morton keys, and contacts come out in tag order.)  Large colliders follow the small ones, in list order.
 __global__ __launch_bounds__(256) void k_cell_keys(nh_DevState* __restrict__ st, uint32_t n,
-                                                   const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
+                                                   const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max, float4* __restrict__ box,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ rank, uint32_t* __restrict__ large_list,
                                                    uint32_t* __restrict__ cstart) {
+	if (!st->fat_rebuild) return;
+	// (the inflated boxes of this rebuild: box[2c] = min, body; box[2c + 1] = max, extent -- written here, read by the rest of the chain and,
+	// in the steps that re-use the kept pairs, by k_xform)
+	const float margin = st->fat_margin;
 	const float inv = st->cell_inv;
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
@@ -194,6 +222,9 @@ __global__ __launch_bounds__(256) void k_cell_keys(nh_DevState* __restrict__ st,
 		uint32_t key = NH_LARGE_KEY;
 		if (valid) {
 			float4 mn = aabb_min[c], mx = aabb_max[c];
+			mn.x -= margin; mn.y -= margin; mn.z -= margin; mx.x += margin; mx.y += margin; mx.z += margin;
+			mx.w = fmaxf(fmaxf(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
+			box[2u * c] = mn; box[2u * c + 1u] = mx;
 			int cx0 = cell_coord(mn.x, ox, inv), cy0 = cell_coord(mn.y, oy, inv), cz0 = cell_coord(mn.z, oz, inv);
 			int cx1 = cell_coord(mx.x, ox, inv), cy1 = cell_coord(mx.y, oy, inv), cz1 = cell_coord(mx.z, oz, inv);
 			uint32_t e = (__float_as_uint(mx.w) >> 21) & 1023u;
@@ -214,7 +245,8 @@ __global__ __launch_bounds__(256) void k_cell_keys(nh_DevState* __restrict__ st,
 // exclusive scan of the per-cell counts (n = table size, a multiple of CS_TILE) into cell starts, in place; cstart[n] = total
 #define CS_PER_THREAD 16
 #define CS_TILE (256 * CS_PER_THREAD)
-__global__ __launch_bounds__(256) void k_cscan_sums(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ block_sums) {
+__global__ __launch_bounds__(256) void k_cscan_sums(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ block_sums) {
+	if (!st->fat_rebuild) return;
 	__shared__ uint32_t wsum[4];
 	const uint4* p = reinterpret_cast<const uint4*>(cnt + (size_t)blockIdx.x * CS_TILE + threadIdx.x * CS_PER_THREAD);
 	uint32_t s = 0;
@@ -226,7 +258,8 @@ __global__ __launch_bounds__(256) void k_cscan_sums(const uint32_t* __restrict__
 	if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-__global__ __launch_bounds__(256) void k_cscan_final(uint32_t* __restrict__ cnt, const uint32_t* __restrict__ block_sums, uint32_t n) {
+__global__ __launch_bounds__(256) void k_cscan_final(const nh_DevState* __restrict__ st, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ block_sums, uint32_t n) {
+	if (!st->fat_rebuild) return;
 	__shared__ uint32_t wsum[4];
 	__shared__ uint32_t red[4];
 	// carry = sum of the block sums before this block
@@ -258,13 +291,14 @@ __global__ __launch_bounds__(256) void k_cscan_final(uint32_t* __restrict__ cnt,
 // so that a candidate of the pair search costs one cache line, not two.  (Morton keys are not carried along: the pair search computes them
 // from the min corners of the few pairs that actually overlap.)
 __global__ __launch_bounds__(256) void k_cell_scatter(const nh_DevState* __restrict__ st, uint32_t n, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ rank,
-                                                      const uint32_t* __restrict__ cstart, const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
+                                                      const uint32_t* __restrict__ cstart, const float4* __restrict__ box,
                                                       uint32_t* __restrict__ skeys, float4* __restrict__ sbox) {
+	if (!st->fat_rebuild) return;
 	const uint32_t nsmall = n - st->large;
 	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
 		const uint32_t key = keys[c];
 		const uint32_t pos = key != NH_LARGE_KEY ? cstart[key] + rank[c] : nsmall + rank[c];
-		float4 mn = aabb_min[c], mx = aabb_max[c];
+		float4 mn = box[2u * c], mx = box[2u * c + 1u];
 		mx.w = __uint_as_float(c);                 // sorted copy carries (body, collider index) in the w lanes
 		skeys[pos] = key;
 		sbox[2u * pos] = mn; sbox[2u * pos + 1u] = mx;
@@ -363,6 +397,42 @@ __device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_
 	if (ps.count > ps.cap - 64) flush_pairs(st, pairs, pair_cap, ps);
 }
 
+// ---- kept pair list: what the grid search emits -----------------------------------------------------------------------------------
+// Pairs of overlapping INFLATED boxes, unordered and unfiltered (same-body pairs included: who belongs to which body is looked at when a pair is
+// used, k_kept_filter), staged per wave like the pairs above; one reservation on st->fat_count per workgroup at the end.
+__device__ __forceinline__ void flush_kept(nh_DevState* st, uint2* __restrict__ kept, uint32_t kept_cap, pair_stage& ps) {
+	if (!ps.count) return;
+	__builtin_amdgcn_wave_barrier();
+	uint32_t base = 0;
+	if (nh_lane() == 0) base = atomicAdd(&st->fat_count, ps.count);
+	base = __shfl(base, 0);
+	for (uint32_t k = nh_lane(); k < ps.count; k += 64) { if (base + k < kept_cap) kept[base + k] = ps.buf[k]; else st->error = NH_ERR_PAIR_CAPACITY; }
+	__builtin_amdgcn_wave_barrier();
+	ps.count = 0;
+}
+
+__device__ __forceinline__ void flush_kept_block(nh_DevState* st, uint2* __restrict__ kept, uint32_t kept_cap, pair_stage& ps) {
+	__shared__ uint32_t wave_n[8];
+	__shared__ uint32_t block_base;
+	const uint32_t nwaves = blockDim.x >> 6;
+	__builtin_amdgcn_wave_barrier();
+	if (nh_lane() == 0) wave_n[threadIdx.x >> 6] = ps.count;
+	__syncthreads();
+	if (threadIdx.x == 0) { uint32_t t = 0; for (uint32_t w = 0; w < nwaves; ++w) t += wave_n[w]; block_base = t ? atomicAdd(&st->fat_count, t) : 0u; }
+	__syncthreads();
+	uint32_t base = block_base;
+	for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) base += wave_n[w];
+	for (uint32_t k = nh_lane(); k < ps.count; k += 64) { if (base + k < kept_cap) kept[base + k] = ps.buf[k]; else st->error = NH_ERR_PAIR_CAPACITY; }
+}
+
+__device__ __forceinline__ void emit_kept(nh_DevState* st, uint2* __restrict__ kept, uint32_t kept_cap, uint32_t ca, uint32_t cb, bool hit, pair_stage& ps) {
+	const unsigned long long bal = __ballot(hit);
+	if (!bal) return;
+	if (hit) ps.buf[ps.count + (uint32_t)__popcll(bal & ((1ull << nh_lane()) - 1ull))] = make_uint2(ca, cb);
+	ps.count += (uint32_t)__popcll(bal);
+	if (ps.count > ps.cap - 64) flush_kept(st, kept, kept_cap, ps);
+}
+
 // ---- 5. pair search: grid neighbours + large list ---------------------------------------------------------
 // One lane per small collider A, in cell order.  A pair is emitted by its member with the LOWER sorted index, so A only looks FORWARD:
 // a collider B that overlaps A has its (min corner) cell in [c_min(A) - 1, c_max(A)] per axis, and one that comes after A in cell order
@@ -381,17 +451,14 @@ template<int SUB>
 __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st, uint32_t n, uint32_t nbox,
                                                     const uint32_t* __restrict__ keys, const float4* __restrict__ sbox,
                                                     const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
-                                                    const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
-                                                    uint2* __restrict__ pairs, uint32_t pair_cap,
-                                                    uint32_t* __restrict__ coarse_parent, uint32_t parity, const uint8_t* __restrict__ idle) {
-	uint32_t* const islands = st->any_idle[parity] ? coarse_parent : nullptr;
+                                                    const float4* __restrict__ box,
+                                                    uint2* __restrict__ kept, uint32_t kept_cap) {
+	// (runs on the inflated boxes and fills the KEPT list; roles, same-body pairs and sleeping sets are k_kept_filter's business)
+	if (!st->fat_rebuild) return;
 	const float inv = st->cell_inv;
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
 	const uint32_t nlarge = st->large;
-	// Morton frame (nudge.cpp:3096-3100): which collider of a pair plays "a" is decided by the Morton order of the AABB min corners
-	const float mscale = st->morton_scale;
-	const nh_f3 mmin = nh_make3(st->morton_min[0], st->morton_min[1], st->morton_min[2]);
 	__shared__ uint2 wave_buf[4][FP_WBUF];
 	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u, FP_WBUF, nbox };
 	const uint32_t rounded = ((n + 63u) & ~63u) * SUB;
@@ -399,9 +466,8 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 		const uint32_t i = gi / SUB, sub = gi % SUB;
 		bool valid = i < n;
 		float4 amin = make_float4(0, 0, 0, 0), amax = amin;
-		uint32_t key = NH_LARGE_KEY, ca = 0, abody = 0;
-		uint64_t ka = 0;
-		if (valid) { amin = sbox[2u * i]; amax = sbox[2u * i + 1u]; key = keys[i]; ca = __float_as_uint(amax.w); abody = __float_as_uint(amin.w); ka = nh_morton_of(nh_make3(amin.x, amin.y, amin.z), mscale, mmin); }
+		uint32_t key = NH_LARGE_KEY, ca = 0;
+		if (valid) { amin = sbox[2u * i]; amax = sbox[2u * i + 1u]; key = keys[i]; ca = __float_as_uint(amax.w); }
 		const bool small = valid && key != NH_LARGE_KEY;
 		// the forward rows: begin / end of their candidate ranges (empty rows: begin = end = 0)
 		uint32_t rb[5] = { 0, 0, 0, 0, 0 }, re[5] = { 0, 0, 0, 0, 0 };
@@ -451,13 +517,12 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 			for (int k = 0; k < FP_BATCH; ++k) {
 				if (!__any(have[k])) break;
 				bool hit = false;
-				uint32_t cb = 0, bbody = 0;
+				uint32_t cb = 0;
 				if (have[k]) {
-					cb = __float_as_uint(bmax[k].w); bbody = __float_as_uint(bmin[k].w);
-					hit = aabb_overlap(amin, amax, bmin[k], bmax[k]) && (bbody != abody);
+					cb = __float_as_uint(bmax[k].w);
+					hit = aabb_overlap(amin, amax, bmin[k], bmax[k]);
 				}
-				const uint64_t kb = hit ? nh_morton_of(nh_make3(bmin[k].x, bmin[k].y, bmin[k].z), mscale, mmin) : 0ull;
-				emit_pair(st, pairs, pair_cap, ka, kb, ca, cb, hit, ps, islands, idle, abody, bbody);
+				emit_kept(st, kept, kept_cap, ca, cb, hit, ps);
 			}
 		}
 		// large x larger-indexed large (small x large is found from the large side: k_large_pairs)
@@ -465,14 +530,13 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 		if (__ballot(a_large)) {
 			for (uint32_t l = 0; l < nlarge; ++l) {
 				uint32_t cb = large_list[l];
-				float4 bmin = aabb_min[cb], bmax = aabb_max[cb];
-				bool hit = a_large && cb > ca && aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != abody);
-				const uint64_t kb = hit ? nh_morton_of(nh_make3(bmin.x, bmin.y, bmin.z), mscale, mmin) : 0ull;
-				emit_pair(st, pairs, pair_cap, ka, kb, ca, cb, hit, ps, islands, idle, abody, __float_as_uint(bmin.w));
+				float4 bmin = box[2u * cb], bmax = box[2u * cb + 1u];
+				bool hit = a_large && cb > ca && aabb_overlap(amin, amax, bmin, bmax);
+				emit_kept(st, kept, kept_cap, ca, cb, hit, ps);
 			}
 		}
 	}
-	flush_pairs_block(st, pairs, pair_cap, ps);
+	flush_kept_block(st, kept, kept_cap, ps);
 }
 
 // small x large pairs, found from the LARGE side: a large collider (ground slab, wall) visits the grid cells its AABB
@@ -489,16 +553,13 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 #define LP_WBUF 1024
 __global__ __launch_bounds__(LP_THREADS) void k_large_pairs(nh_DevState* __restrict__ st, uint32_t nbox, const float4* __restrict__ sbox,
                                                      const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
-                                                     const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
-                                                     uint2* __restrict__ pairs, uint32_t pair_cap,
-                                                    uint32_t* __restrict__ coarse_parent, uint32_t parity, const uint8_t* __restrict__ idle) {
-	uint32_t* const islands = st->any_idle[parity] ? coarse_parent : nullptr;
+                                                     const float4* __restrict__ box,
+                                                     uint2* __restrict__ kept, uint32_t kept_cap) {
+	if (!st->fat_rebuild) return;
 	const float inv = st->cell_inv;
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
 	const uint32_t nlarge = st->large;
-	const float mscale = st->morton_scale;
-	const nh_f3 mmin = nh_make3(st->morton_min[0], st->morton_min[1], st->morton_min[2]);
 	__shared__ uint2 wave_buf[LP_THREADS / 64][LP_WBUF];
 	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u, LP_WBUF, nbox };
 	uint32_t slices = nlarge ? LP_BLOCKS / nlarge : 1u;
@@ -506,9 +567,7 @@ __global__ __launch_bounds__(LP_THREADS) void k_large_pairs(nh_DevState* __restr
 	const uint32_t slice = blockIdx.x % slices;
 	for (uint32_t l = blockIdx.x / slices; l < nlarge; l += gridDim.x / slices) {
 		const uint32_t ca = large_list[l];
-		const float4 amin = aabb_min[ca], amax = aabb_max[ca];
-		const uint32_t abody = __float_as_uint(amin.w);
-		const uint64_t ka = nh_morton_of(nh_make3(amin.x, amin.y, amin.z), mscale, mmin);
+		const float4 amin = box[2u * ca], amax = box[2u * ca + 1u];
 		// a small collider B overlapping A has its min-corner cell in [c_min(A) - 1, c_max(A)] per axis
 		int x0 = min(max(cell_coord(amin.x, ox, inv) - 1, 0), nx - 1), x1 = min(max(cell_coord(amax.x, ox, inv), 0), nx - 1);
 		int y0 = min(max(cell_coord(amin.y, oy, inv) - 1, 0), ny - 1), y1 = min(max(cell_coord(amax.y, oy, inv), 0), ny - 1);
@@ -526,17 +585,55 @@ __global__ __launch_bounds__(LP_THREADS) void k_large_pairs(nh_DevState* __restr
 				const uint32_t cand = base + lane;
 				const bool have = cand < jend;
 				bool hit = false;
-				uint32_t cb = 0, bbody = 0;
-				uint64_t kb = 0;
+				uint32_t cb = 0;
 				if (have) {
 					float4 bmin = sbox[2u * cand], bmax = sbox[2u * cand + 1u];
-					cb = __float_as_uint(bmax.w); bbody = __float_as_uint(bmin.w);
-					hit = aabb_overlap(amin, amax, bmin, bmax) && (bbody != abody);
-					if (hit) kb = nh_morton_of(nh_make3(bmin.x, bmin.y, bmin.z), mscale, mmin);
+					cb = __float_as_uint(bmax.w);
+					hit = aabb_overlap(amin, amax, bmin, bmax);
 				}
-				emit_pair(st, pairs, pair_cap, ka, kb, ca, cb, hit, ps, islands, idle, abody, bbody);
+				emit_kept(st, kept, kept_cap, ca, cb, hit, ps);
 			}
 		}
+	}
+	flush_kept_block(st, kept, kept_cap, ps);
+}
+
+// ---- 6. kept pairs -> this step's pairs ------------------------------------------------------------------------------------------------
+// Temporal coherence.  The grid search above runs on AABBs inflated by 1/32 of a cell and its result is KEPT.  As long as every collider's
+// AABB lies inside the inflated box it had then (checked by k_xform every step; a moved, resized or re-parented collider simply leaves its
+// box), two AABBs that overlap now had overlapping inflated boxes then: the kept list is a superset of this step's pairs, and this one pass
+// -- the EXACT boxes of this step, the strict test of nudge.cpp:3306-3308, bodies and roles as they are now -- produces exactly the pairs the
+// full search would (k_grid_setup decides on the device; the kernels of the chain are launched either way and leave at once when they are not
+// needed).  A scene at rest re-uses its list for hundreds of steps: at 1 M boxes the regrouping and the search cost 117 us, this pass 15.
+// NH_NO_KEPT_PAIRS=1 rebuilds every step; the results must be the same bit for bit (test_kept_pair_list_*).
+__global__ __launch_bounds__(256) void k_kept_filter(nh_DevState* __restrict__ st, const uint2* __restrict__ kept, uint32_t kept_cap, uint32_t nbox,
+                                                     const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
+                                                     uint2* __restrict__ pairs, uint32_t pair_cap,
+                                                     uint32_t* __restrict__ coarse_parent, uint32_t parity, const uint8_t* __restrict__ idle) {
+	uint32_t* const islands = st->any_idle[parity] ? coarse_parent : nullptr;
+	// Morton frame (nudge.cpp:3096-3100): which collider of a pair plays "a" is decided by the Morton order of the AABB min corners
+	const float mscale = st->morton_scale;
+	const nh_f3 mmin = nh_make3(st->morton_min[0], st->morton_min[1], st->morton_min[2]);
+	__shared__ uint2 wave_buf[4][FP_WBUF];
+	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u, FP_WBUF, nbox };
+	const uint32_t n = min(st->fat_count, kept_cap);
+	// One reservation on the pair counters per WORKGROUP and flush (a same-address atomic costs ~12 ns, serialised: with one per wave the counters, not the
+	// memory system, set the pace): the waves stage their pairs separately but flush together, so the trip count is uniform over the workgroup
+	const uint32_t rounded = (n + blockDim.x - 1u) / blockDim.x * blockDim.x;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
+		bool hit = false;
+		uint32_t ca = 0, cb = 0, abody = 0, bbody = 0;
+		uint64_t ka = 0, kb = 0;
+		if (i < n) {
+			const uint2 pr = kept[i];
+			ca = pr.x; cb = pr.y;
+			const float4 amin = aabb_min[ca], amax = aabb_max[ca], bmin = aabb_min[cb], bmax = aabb_max[cb];
+			abody = __float_as_uint(amin.w); bbody = __float_as_uint(bmin.w);
+			hit = aabb_overlap(amin, amax, bmin, bmax) && (bbody != abody);
+			if (hit) { ka = nh_morton_of(nh_make3(amin.x, amin.y, amin.z), mscale, mmin); kb = nh_morton_of(nh_make3(bmin.x, bmin.y, bmin.z), mscale, mmin); }
+		}
+		emit_pair(st, pairs, pair_cap, ka, kb, ca, cb, hit, ps, islands, idle, abody, bbody);
+		if (__syncthreads_or(ps.count > ps.cap - 192u)) { flush_pairs_block(st, pairs, pair_cap, ps); ps.count = 0; __syncthreads(); }
 	}
 	flush_pairs_block(st, pairs, pair_cap, ps);
 }
@@ -922,7 +1019,7 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 // buffered by step parity: this step's launch sets any_idle[parity] with plain stores and clears the other one for the next step.
 __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t ncolliders, uint32_t nbodies, uint32_t* __restrict__ parent, uint32_t* __restrict__ set_active, uint32_t* __restrict__ deg,
                                                        const uint8_t* __restrict__ idle, uint32_t parity, uint32_t* __restrict__ coarse_parent, uint32_t* __restrict__ coarse_active, uint32_t no_islands,
-                                                       uint32_t* __restrict__ block_top) {
+                                                       uint32_t* __restrict__ block_top, uint32_t drop_kept_pairs) {
 	__shared__ uint32_t s_top[4];
 	// `no_islands`: the host has ruled out that anybody is asleep this step (nh_collide): no island kernel will run, their arrays stay untouched
 	bool asleep = false;
@@ -951,6 +1048,8 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 		st->active = 0; st->culled = 0; st->large = 0; st->general_contacts = 0; st->levels = 0; st->error = 0;
 		st->has_other = 0; st->unleveled = 0; st->has_static8 = 0; st->has_staticN = 0; st->any_sleeping = 0; st->has_pending = 0;
 		st->sort_buckets = st->sort_buckets_next;
+		st->fat_escaped = 0; st->fat_rebuild = 0;
+		if (drop_kept_pairs) st->fat_valid = 0;       // (collider counts or buffers changed, or NH_NO_KEPT_PAIRS: the kept pair list describes another world)
 		for (int k = 0; k < 3; ++k) { st->smin[k] = 0xffffffffu; st->smax[k] = 0u; st->gmin[k] = 0xffffffffu; st->gmax[k] = 0u; }
 	}
 	for (uint32_t k = t; k < 1024u; k += blockDim.x) st->exp_hist[k] = 0;
@@ -1049,27 +1148,54 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->sort_counts, 0, sizeof(uint32_t) * nbk, s));
 		ctx->sort_capacity = pair_cap;
 	}
-	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, begin_grid, 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity, coarse_parent, coarse_active, no_islands ? 1u : 0u, block_top);
+	// library-owned: the kept pair list of the broadphase and the two buffers of inflated boxes (they persist from one nh_collide to the next)
+	bool drop_kept = ctx->env_no_fat || ctx->fat_nbox != nbox || ctx->fat_nsph != nsph;
+	// (the kept list holds pairs of INFLATED boxes: more than overlap exactly -- twice the pair capacity, at least 4096)
+	const uint32_t want_kept = pair_cap > 0x7fffffffu / 2u ? 0xfffffffeu : (2u * pair_cap > 4096u ? 2u * pair_cap : 4096u);
+	if (ctx->fat_pair_capacity != want_kept) {
+		if (ctx->fat_pairs) NH_HIP_CHECK(ctx, hipFree(ctx->fat_pairs));
+		ctx->fat_pairs = nullptr; ctx->fat_pair_capacity = 0;
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->fat_pairs, sizeof(uint2) * (size_t)want_kept));
+		ctx->fat_pair_capacity = want_kept;
+		drop_kept = true;
+	}
+	if (ctx->fat_collider_capacity < C) {
+		if (ctx->fat_box[0]) NH_HIP_CHECK(ctx, hipFree(ctx->fat_box[0]));
+		ctx->fat_box[0] = nullptr; ctx->fat_collider_capacity = 0;
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->fat_box[0], sizeof(float4) * 2u * (size_t)C));
+		ctx->fat_collider_capacity = C;
+		drop_kept = true;
+	}
+	ctx->fat_nbox = nbox; ctx->fat_nsph = nsph;
+	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, begin_grid, 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity, coarse_parent, coarse_active, no_islands ? 1u : 0u, block_top,
+	          drop_kept ? 1u : 0u);
 	if (C) {
 		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 1024, 256), 1024, st, bodies->transforms,
 		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
 		          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
-		          xf, aabb_min, aabb_max, ctag, reinterpret_cast<uint4*>(cstart), (max_cells + 8u) / 4u);
+		          xf, aabb_min, aabb_max, ctag, reinterpret_cast<uint4*>(cstart), (max_cells + 8u) / 4u, ctx->fat_box[0]);
+		// Morton frame; and the decision whether the grid chain below runs this step or the kept pair list is re-used (its kernels are launched
+		// either way: the decision is made on the device, and a kernel that leaves at once costs two microseconds)
 		NH_LAUNCH(ctx, "grid_setup", k_grid_setup, 1, 64, st, C, max_cells);
-		NH_LAUNCH(ctx, "cell_keys", k_cell_keys, nh_grid_for(C, 256, 2048), 256, st, C, aabb_min, aabb_max, keys_a, vals_a, large_list, cstart);
-		NH_LAUNCH(ctx, "cell_scan", k_cscan_sums, max_cells / CS_TILE, 256, cstart, cscan_sums);
-		NH_LAUNCH(ctx, "cell_scan", k_cscan_final, max_cells / CS_TILE, 256, cstart, cscan_sums, max_cells);
-		NH_LAUNCH(ctx, "cell_scatter", k_cell_scatter, nh_grid_for(C, 256, 2048), 256, st, C, keys_a, vals_a, cstart, aabb_min, aabb_max, keys_b, sbox);
+		float4* fbox = ctx->fat_box[0];
+		uint2* kept = ctx->fat_pairs;
+		const uint32_t kept_cap = ctx->fat_pair_capacity;
+		NH_LAUNCH(ctx, "cell_keys", k_cell_keys, nh_grid_for(C, 256, 2048), 256, st, C, aabb_min, aabb_max, fbox, keys_a, vals_a, large_list, cstart);
+		NH_LAUNCH(ctx, "cell_scan", k_cscan_sums, max_cells / CS_TILE, 256, st, cstart, cscan_sums);
+		NH_LAUNCH(ctx, "cell_scan", k_cscan_final, max_cells / CS_TILE, 256, st, cstart, cscan_sums, max_cells);
+		NH_LAUNCH(ctx, "cell_scatter", k_cell_scatter, nh_grid_for(C, 256, 2048), 256, st, C, keys_a, vals_a, cstart, fbox, keys_b, sbox);
 		const int fp_sub = ctx->env_fp_sub ? ctx->env_fp_sub : (C <= 16384u ? 16 : 1);
 		if (fp_sub == 4)
-			NH_LAUNCH(ctx, "find_pairs", k_find_pairs<4>, nh_grid_for((uint64_t)C * 4u, 256, 16384), 256, st, C, nbox, keys_b, sbox, cstart, large_list, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+			NH_LAUNCH(ctx, "find_pairs", k_find_pairs<4>, nh_grid_for((uint64_t)C * 4u, 256, 16384), 256, st, C, nbox, keys_b, sbox, cstart, large_list, fbox, kept, kept_cap);
 		else if (fp_sub == 2)
-			NH_LAUNCH(ctx, "find_pairs", k_find_pairs<2>, nh_grid_for((uint64_t)C * 2u, 256, 8192), 256, st, C, nbox, keys_b, sbox, cstart, large_list, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+			NH_LAUNCH(ctx, "find_pairs", k_find_pairs<2>, nh_grid_for((uint64_t)C * 2u, 256, 8192), 256, st, C, nbox, keys_b, sbox, cstart, large_list, fbox, kept, kept_cap);
 		else if (fp_sub == 16)
-			NH_LAUNCH(ctx, "find_pairs", k_find_pairs<16>, nh_grid_for((uint64_t)C * 16u, 256, 4096), 256, st, C, nbox, keys_b, sbox, cstart, large_list, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+			NH_LAUNCH(ctx, "find_pairs", k_find_pairs<16>, nh_grid_for((uint64_t)C * 16u, 256, 4096), 256, st, C, nbox, keys_b, sbox, cstart, large_list, fbox, kept, kept_cap);
 		else
-			NH_LAUNCH(ctx, "find_pairs", k_find_pairs<1>, nh_grid_for(C, 256, 4096), 256, st, C, nbox, keys_b, sbox, cstart, large_list, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
-		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, LP_GRID, LP_THREADS, st, nbox, sbox, cstart, large_list, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+			NH_LAUNCH(ctx, "find_pairs", k_find_pairs<1>, nh_grid_for(C, 256, 4096), 256, st, C, nbox, keys_b, sbox, cstart, large_list, fbox, kept, kept_cap);
+		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, LP_GRID, LP_THREADS, st, nbox, sbox, cstart, large_list, fbox, kept, kept_cap);
+		// this step's pairs: the kept ones whose exact AABBs overlap now (every step)
+		NH_LAUNCH(ctx, "kept_filter", k_kept_filter, nh_grid_for(kept_cap, 256, 1024), 256, st, kept, kept_cap, nbox, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
 		// coarse islands over the broadphase pairs (united where the pairs were emitted) + connections: only when some body is asleep (a device
 		// flag: the kernels leave at once otherwise)
 		if (!no_islands && body_connections && body_connections->count)

@@ -45,7 +45,17 @@ struct nh_DevState {
 	uint32_t has_pending;                 // some body needs the general adjacency build (k_adj_simple could not settle it)
 	uint32_t pairs_sph;                   // broadphase pairs with a sphere (they fill the pair list from the back; `pairs` counts the box-box ones)
 	uint32_t max_idle[2];                 // by step parity: largest idle counter seen by this step's nh_collide (host-side sleep prediction, nh_collide)
-	// ---- (the 25 words above are what nh_read_counts mirrors to the host) ----
+	uint32_t fat_rebuilds;                // broadphase rebuilds since nh_create (the steps in between re-used the kept pair list: below)
+	// ---- (the 26 words above are what nh_read_counts mirrors to the host) ----
+	// Temporal coherence of the broadphase (nh_collide.hip, "kept pair list"): the grid search runs over AABBs inflated by `fat_margin` and its
+	// pairs are KEPT; while every collider's AABB stays inside its inflated box the kept list is a superset of the overlapping pairs and one filter
+	// pass (exact AABBs, exact test) replaces the whole regrouping + search.
+	uint32_t fat_count;                   // pairs in the kept list
+	uint32_t fat_valid;                   // the kept list and the inflated boxes describe the current collider arrays
+	uint32_t fat_escaped;                 // this step: some AABB left its inflated box (k_xform)
+	uint32_t fat_rebuild;                 // this step: the grid chain runs (k_grid_setup: !fat_valid || fat_escaped)
+	uint32_t fat_cur;                     // which of the two inflated-box buffers is current (k_xform writes the candidate into the other)
+	float fat_margin;                     // inflation used for this step's candidate boxes
 	// scene bounds of AABB min corners, order-preserving uint encoding (atomicMin/Max)
 	uint32_t smin[3];
 	uint32_t smax[3];
@@ -104,6 +114,11 @@ struct nh_context {
 	// per-body contact degree (filled by nh_collide's contact gather, turned into CSR offsets by setup) + fill cursors: 2 x (B + 2) words
 	uint32_t* deg;
 	uint32_t deg_capacity;
+	// kept pair list of the broadphase (library-owned, persists from one nh_collide to the next): pairs of inflated boxes, two box buffers
+	uint2* fat_pairs; uint32_t fat_pair_capacity;
+	float4* fat_box[2]; uint32_t fat_collider_capacity;
+	uint32_t fat_nbox, fat_nsph;          // collider counts of the last nh_collide (a change invalidates the list)
+	bool env_no_fat;                      // NH_NO_KEPT_PAIRS=1: rebuild every step (A/B, tests)
 	uint32_t step_parity;
 	uint32_t order_seq;
 	uint32_t pair_capacity;               // nh_set_pair_capacity; 0 = contacts->capacity / 2 + 1024

@@ -514,6 +514,64 @@ def test_colours_seeded_from_the_cache_are_final_without_a_check(case, monkeypat
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("name,steps", [("grid30", 460), ("mixed20", 200), ("pile256", 600), ("pit6", 250), ("compound", 330)])
+def test_kept_pair_list_gives_the_pairs_of_a_full_search(name, steps, monkeypatch):
+    """The broadphase keeps the pairs of AABBs inflated by 1/32 of a cell and, while every AABB stays inside its inflated box, only re-tests the
+    kept pairs with this step's exact boxes.  NH_NO_KEPT_PAIRS=1 regroups and searches every step.  Same pairs either way: bodies, contacts and
+    the cache must agree bit for bit while a scene falls, lands, rests and sleeps -- and the default run must actually have re-used its list."""
+    scene, _ = G.build(name)
+    a = E.World(scene, flags=FAST)
+    monkeypatch.setenv("NH_NO_KEPT_PAIRS", "1")
+    b = E.World(scene, flags=FAST)
+    monkeypatch.delenv("NH_NO_KEPT_PAIRS")
+    for k in range(steps // 25):
+        a.step(25); b.step(25)
+        x, y = a.get_bodies(), b.get_bodies()
+        assert P.bits_equal(x["transforms"], y["transforms"]) and P.bits_equal(x["momentum"], y["momentum"]) and np.array_equal(x["idle"], y["idle"]), (name, k)
+    a.collide(); b.collide()
+    ca, cb = a.get_contacts(), b.get_contacts()
+    assert ca["count"] == cb["count"] and np.array_equal(ca["tags"], cb["tags"]) and P.bits_equal(ca["data"], cb["data"])
+    assert np.array_equal(ca["sleeping_pairs"], cb["sleeping_pairs"])
+    ra, rb = a.counts()["broadphase_rebuilds"], b.counts()["broadphase_rebuilds"]
+    assert rb == steps // 25 * 25 + 1, rb
+    assert ra < rb, (ra, rb)
+    a.close(); b.close()
+
+
+def test_kept_pair_list_survives_teleports_and_collider_edits():
+    """Bodies moved by the caller, a collider resized in place and a collider handed to another body: each leaves its inflated box (or stays
+    inside and changes nothing the kept list depends on); the next nh_collide must produce the same contacts as a world that searches every step."""
+    import copy
+    scene, _ = G.build("grid30_awake")
+    worlds = []
+    for env in (None, "1"):
+        if env: os.environ["NH_NO_KEPT_PAIRS"] = env
+        worlds.append(E.World(copy.deepcopy(scene), flags=FAST))
+        os.environ.pop("NH_NO_KEPT_PAIRS", None)
+    for w in worlds:
+        w.step(120)
+    for edit in range(3):
+        for w in worlds:
+            b = w.get_bodies()
+            t = b["transforms"].copy()
+            if edit == 0:
+                t["position"][5] = t["position"][6] + np.float32(0.3)              # onto its neighbour
+                w.set_bodies(transforms=t)
+            elif edit == 1:
+                raw = w.records("xd", 16)                                            # box sizes in place: box 9 grows by half
+                sz = np.frombuffer(raw[9].cpu().numpy().tobytes(), np.float32).copy(); sz[:3] *= 1.5
+                raw[9] = w.torch.from_numpy(sz.view(np.uint8).copy()).to(raw.device)
+            else:
+                raw = w.records("xx", 32)                                            # collider 12 now belongs to body 40
+                rec = np.frombuffer(raw[12].cpu().numpy().tobytes(), np.uint32).copy(); rec[3] = 40
+                raw[12] = w.torch.from_numpy(rec.view(np.uint8).copy()).to(raw.device)
+            w.step(3)
+        x, y = worlds[0].get_bodies(), worlds[1].get_bodies()
+        assert P.bits_equal(x["transforms"], y["transforms"]) and P.bits_equal(x["momentum"], y["momentum"]), edit
+    for w in worlds:
+        w.close()
+
+
 # ---- degenerate inputs ------------------------------------------------------------------------------------------------------------
 def _tiny_scene(n_boxes, n_spheres, apart=True):
     scene = S.pile(n_boxes=max(n_boxes, 1), n_spheres=n_spheres, seed=3)
