@@ -54,6 +54,7 @@ KERNEL_BYTES = {
     "cell_scatter": ("C", 8 + 32 + 4 + 32),                # key/rank + AABB -> key + 32-byte AABB record in cell order
     "find_pairs": ("C", 32 + 4),                           # AABB in cell order + key (+ 8 B per emitted pair)
     "large_pairs": ("P", 32 + 8),                          # candidates of the large colliders: AABB read, pair written
+    "kept_filter": ("P", 8 + 2 * 32 + 8),                  # per kept pair (~ per pair at rest): the pair, two exact AABBs (gathered), the pair written
     "narrowphase": ("P", 8 + 2 * (32 + 16 + 4) + 4 * 36 + 24),  # pair, 2 x (transform, shape, tag) -> ~4 contacts x 36 B + record
     "narrowphase_bb": ("P", 8 + 2 * (32 + 16 + 4) + 4 * 36 + 24),
     "narrowphase_sph": ("P", 8 + 2 * (32 + 4 + 4) + 36 + 24),
