@@ -1160,9 +1160,9 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		drop_kept = true;
 	}
 	if (ctx->fat_collider_capacity < C) {
-		if (ctx->fat_box[0]) NH_HIP_CHECK(ctx, hipFree(ctx->fat_box[0]));
-		ctx->fat_box[0] = nullptr; ctx->fat_collider_capacity = 0;
-		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->fat_box[0], sizeof(float4) * 2u * (size_t)C));
+		if (ctx->fat_box) NH_HIP_CHECK(ctx, hipFree(ctx->fat_box));
+		ctx->fat_box = nullptr; ctx->fat_collider_capacity = 0;
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->fat_box, sizeof(float4) * 2u * (size_t)C));
 		ctx->fat_collider_capacity = C;
 		drop_kept = true;
 	}
@@ -1173,11 +1173,11 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 1024, 256), 1024, st, bodies->transforms,
 		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
 		          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
-		          xf, aabb_min, aabb_max, ctag, reinterpret_cast<uint4*>(cstart), (max_cells + 8u) / 4u, ctx->fat_box[0]);
+		          xf, aabb_min, aabb_max, ctag, reinterpret_cast<uint4*>(cstart), (max_cells + 8u) / 4u, ctx->fat_box);
 		// Morton frame; and the decision whether the grid chain below runs this step or the kept pair list is re-used (its kernels are launched
 		// either way: the decision is made on the device, and a kernel that leaves at once costs two microseconds)
 		NH_LAUNCH(ctx, "grid_setup", k_grid_setup, 1, 64, st, C, max_cells);
-		float4* fbox = ctx->fat_box[0];
+		float4* fbox = ctx->fat_box;
 		uint2* kept = ctx->fat_pairs;
 		const uint32_t kept_cap = ctx->fat_pair_capacity;
 		NH_LAUNCH(ctx, "cell_keys", k_cell_keys, nh_grid_for(C, 256, 2048), 256, st, C, aabb_min, aabb_max, fbox, keys_a, vals_a, large_list, cstart);

@@ -39,7 +39,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->env_solver_waves = getenv("NH_SOLVER_WAVES") ? atoi(getenv("NH_SOLVER_WAVES")) : 1;      // wavefronts per workgroup of the fused solver (A/B: 1, 2, 4)
 	ctx->env_fp_sub = getenv("NH_FP_SUB") ? atoi(getenv("NH_FP_SUB")) : 0;      // lanes per collider in the pair search (A/B: 1, 2, 4, 16; 0 = by world size)
 	ctx->env_no_fat = getenv("NH_NO_KEPT_PAIRS") != nullptr;      // the broadphase regroups and searches every step instead of re-using its kept pair list (A/B, tests)
-	ctx->fat_pairs = nullptr; ctx->fat_pair_capacity = 0; ctx->fat_box[0] = ctx->fat_box[1] = nullptr; ctx->fat_collider_capacity = 0; ctx->fat_nbox = ctx->fat_nsph = 0xffffffffu;
+	ctx->fat_pairs = nullptr; ctx->fat_pair_capacity = 0; ctx->fat_box = nullptr; ctx->fat_collider_capacity = 0; ctx->fat_nbox = ctx->fat_nsph = 0xffffffffu;
 	ctx->env_colour_check_seeds = getenv("NH_COLOUR_CHECK_SEEDS") != nullptr;      // colours seeded from the cache go through a settle round instead of being final at once (A/B, tests)
 	ctx->env_no_resident = getenv("NH_NO_RESIDENT") != nullptr;      // NH_NO_RESIDENT=1: small general sets also take the one-launch-per-level path (A/B, tests)
 	ctx->os_resident = 0;
@@ -73,8 +73,7 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	if (ctx->hint) hipFree(ctx->hint);
 	if (ctx->deg) hipFree(ctx->deg);
 	if (ctx->fat_pairs) hipFree(ctx->fat_pairs);
-	if (ctx->fat_box[0]) hipFree(ctx->fat_box[0]);
-	if (ctx->fat_box[1]) hipFree(ctx->fat_box[1]);
+	if (ctx->fat_box) hipFree(ctx->fat_box);
 	if (ctx->sort_splitters) hipFree(ctx->sort_splitters);
 	if (ctx->sort_counts) hipFree(ctx->sort_counts);
 	if (ctx->sort_starts) hipFree(ctx->sort_starts);

@@ -54,8 +54,7 @@ struct nh_DevState {
 	uint32_t fat_valid;                   // the kept list and the inflated boxes describe the current collider arrays
 	uint32_t fat_escaped;                 // this step: some AABB left its inflated box (k_xform)
 	uint32_t fat_rebuild;                 // this step: the grid chain runs (k_grid_setup: !fat_valid || fat_escaped)
-	uint32_t fat_cur;                     // which of the two inflated-box buffers is current (k_xform writes the candidate into the other)
-	float fat_margin;                     // inflation used for this step's candidate boxes
+	float fat_margin;                     // inflation of the boxes a rebuild writes this step (k_grid_setup -> k_cell_keys)
 	// scene bounds of AABB min corners, order-preserving uint encoding (atomicMin/Max)
 	uint32_t smin[3];
 	uint32_t smax[3];
@@ -114,9 +113,9 @@ struct nh_context {
 	// per-body contact degree (filled by nh_collide's contact gather, turned into CSR offsets by setup) + fill cursors: 2 x (B + 2) words
 	uint32_t* deg;
 	uint32_t deg_capacity;
-	// kept pair list of the broadphase (library-owned, persists from one nh_collide to the next): pairs of inflated boxes, two box buffers
+	// kept pair list of the broadphase (library-owned, persists from one nh_collide to the next): pairs of inflated boxes, and the boxes
 	uint2* fat_pairs; uint32_t fat_pair_capacity;
-	float4* fat_box[2]; uint32_t fat_collider_capacity;
+	float4* fat_box; uint32_t fat_collider_capacity;
 	uint32_t fat_nbox, fat_nsph;          // collider counts of the last nh_collide (a change invalidates the list)
 	bool env_no_fat;                      // NH_NO_KEPT_PAIRS=1: rebuild every step (A/B, tests)
 	uint32_t step_parity;
