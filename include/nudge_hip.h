@@ -171,6 +171,8 @@ typedef struct nh_Counts {
 	uint32_t unleveled;         /* internal: progress of the level relaxation */
 	uint32_t raw_pairs;         /* broadphase pairs before any filter (diagnostic) */
 	uint32_t broadphase_rebuilds; /* nh_collide calls since nh_create that regrouped the colliders and searched the grid; the others re-used the kept pair list */
+	uint32_t sort_reuses;       /* nh_collide calls since nh_create that skipped the tag sort of the contact records: every record sat where it sat the step
+	                               before, with the same key */
 } nh_Counts;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64) void k_grid_setup(nh_DevState* st, uint32_t nco
 	st->fat_rebuild = rebuild ? 1u : 0u;
 	if (!rebuild) return;
 	st->fat_margin = nh_kept_margin(st->cell_inv);           // (of the grid about to be replaced: what k_xform used)
-	st->fat_valid = 1u; st->fat_count = 0u; st->fat_rebuilds += 1u;
+	st->fat_valid = 1u; st->fat_count = 0u; st->fat_count_sph = 0u; st->fat_rebuilds += 1u;
 	// e = largest size class (exponent << 2 | two mantissa bits) kept "small"; never let the cell underflow to denormals
 	if (e < (64 << 2)) e = 64 << 2;
 	if (e > (190 << 2)) e = 190 << 2;
@@ -344,14 +344,16 @@ __device__ __forceinline__ void count_staged(const pair_stage& ps, uint32_t& n_b
 	n_sph = sph; n_bb = ps.count - sph;
 }
 
-__device__ __forceinline__ void flush_pairs(nh_DevState* st, uint2* pairs, uint32_t pair_cap, pair_stage& ps) {
+// (`cnt_bb`, `cnt_sph`: the two counters of the list being filled -- st->pairs / st->pairs_sph for this step's pairs, st->fat_count / st->fat_count_sph
+// for the kept list)
+__device__ __forceinline__ void flush_pairs(nh_DevState* st, uint2* pairs, uint32_t pair_cap, pair_stage& ps, uint32_t* cnt_bb, uint32_t* cnt_sph) {
 	if (!ps.count) return;
 	__builtin_amdgcn_wave_barrier();
 	uint32_t n_bb, n_sph;
 	count_staged(ps, n_bb, n_sph);
 	uint32_t base = 0;
-	if (nh_lane() == 0 && n_bb) base = atomicAdd(&st->pairs, n_bb);
-	if (nh_lane() == 1 && n_sph) base = atomicAdd(&st->pairs_sph, n_sph);
+	if (nh_lane() == 0 && n_bb) base = atomicAdd(cnt_bb, n_bb);
+	if (nh_lane() == 1 && n_sph) base = atomicAdd(cnt_sph, n_sph);
 	const uint32_t base_bb = __shfl(base, 0), base_sph = __shfl(base, 1);
 	write_staged(st, pairs, pair_cap, ps, base_bb, base_sph);
 	__builtin_amdgcn_wave_barrier();
@@ -359,7 +361,7 @@ __device__ __forceinline__ void flush_pairs(nh_DevState* st, uint2* pairs, uint3
 }
 
 // final flush once per workgroup, not once per wave (every wave ends with a partly filled stage)
-__device__ __forceinline__ void flush_pairs_block(nh_DevState* st, uint2* pairs, uint32_t pair_cap, pair_stage& ps) {
+__device__ __forceinline__ void flush_pairs_block(nh_DevState* st, uint2* pairs, uint32_t pair_cap, pair_stage& ps, uint32_t* cnt_bb, uint32_t* cnt_sph) {
 	__shared__ uint32_t wave_bb[8], wave_sph[8];            // (workgroups of up to 8 waves)
 	__shared__ uint32_t block_bb, block_sph;
 	const uint32_t nwaves = blockDim.x >> 6;
@@ -368,8 +370,8 @@ __device__ __forceinline__ void flush_pairs_block(nh_DevState* st, uint2* pairs,
 	count_staged(ps, n_bb, n_sph);
 	if (nh_lane() == 0) { wave_bb[threadIdx.x >> 6] = n_bb; wave_sph[threadIdx.x >> 6] = n_sph; }
 	__syncthreads();
-	if (threadIdx.x == 0) { uint32_t t = 0; for (uint32_t w = 0; w < nwaves; ++w) t += wave_bb[w]; block_bb = t ? atomicAdd(&st->pairs, t) : 0u; }
-	if (threadIdx.x == 64) { uint32_t t = 0; for (uint32_t w = 0; w < nwaves; ++w) t += wave_sph[w]; block_sph = t ? atomicAdd(&st->pairs_sph, t) : 0u; }
+	if (threadIdx.x == 0) { uint32_t t = 0; for (uint32_t w = 0; w < nwaves; ++w) t += wave_bb[w]; block_bb = t ? atomicAdd(cnt_bb, t) : 0u; }
+	if (threadIdx.x == 64) { uint32_t t = 0; for (uint32_t w = 0; w < nwaves; ++w) t += wave_sph[w]; block_sph = t ? atomicAdd(cnt_sph, t) : 0u; }
 	__syncthreads();
 	uint32_t base_bb = block_bb, base_sph = block_sph;
 	for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) { base_bb += wave_bb[w]; base_sph += wave_sph[w]; }
@@ -394,43 +396,19 @@ __device__ __forceinline__ void emit_pair(nh_DevState* st, uint2* pairs, uint32_
 		ps.buf[ps.count + (uint32_t)__popcll(bal & ((1ull << nh_lane()) - 1ull))] = a_first ? make_uint2(cb, ca) : make_uint2(ca, cb);
 	}
 	ps.count += (uint32_t)__popcll(bal);
-	if (ps.count > ps.cap - 64) flush_pairs(st, pairs, pair_cap, ps);
+	if (ps.count > ps.cap - 64) flush_pairs(st, pairs, pair_cap, ps, &st->pairs, &st->pairs_sph);
 }
 
 // ---- kept pair list: what the grid search emits -----------------------------------------------------------------------------------
 // Pairs of overlapping INFLATED boxes, unordered and unfiltered (same-body pairs included: who belongs to which body is looked at when a pair is
-// used, k_kept_filter), staged per wave like the pairs above; one reservation on st->fat_count per workgroup at the end.
-__device__ __forceinline__ void flush_kept(nh_DevState* st, uint2* __restrict__ kept, uint32_t kept_cap, pair_stage& ps) {
-	if (!ps.count) return;
-	__builtin_amdgcn_wave_barrier();
-	uint32_t base = 0;
-	if (nh_lane() == 0) base = atomicAdd(&st->fat_count, ps.count);
-	base = __shfl(base, 0);
-	for (uint32_t k = nh_lane(); k < ps.count; k += 64) { if (base + k < kept_cap) kept[base + k] = ps.buf[k]; else st->error = NH_ERR_PAIR_CAPACITY; }
-	__builtin_amdgcn_wave_barrier();
-	ps.count = 0;
-}
-
-__device__ __forceinline__ void flush_kept_block(nh_DevState* st, uint2* __restrict__ kept, uint32_t kept_cap, pair_stage& ps) {
-	__shared__ uint32_t wave_n[8];
-	__shared__ uint32_t block_base;
-	const uint32_t nwaves = blockDim.x >> 6;
-	__builtin_amdgcn_wave_barrier();
-	if (nh_lane() == 0) wave_n[threadIdx.x >> 6] = ps.count;
-	__syncthreads();
-	if (threadIdx.x == 0) { uint32_t t = 0; for (uint32_t w = 0; w < nwaves; ++w) t += wave_n[w]; block_base = t ? atomicAdd(&st->fat_count, t) : 0u; }
-	__syncthreads();
-	uint32_t base = block_base;
-	for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) base += wave_n[w];
-	for (uint32_t k = nh_lane(); k < ps.count; k += 64) { if (base + k < kept_cap) kept[base + k] = ps.buf[k]; else st->error = NH_ERR_PAIR_CAPACITY; }
-}
-
+// used, k_kept_filter), staged per wave and split by shape like the pairs above (box-box from the front of the kept buffer, pairs with a sphere from its
+// back: a kept pair then has a POSITION that lasts until the next rebuild, see k_kept_filter).
 __device__ __forceinline__ void emit_kept(nh_DevState* st, uint2* __restrict__ kept, uint32_t kept_cap, uint32_t ca, uint32_t cb, bool hit, pair_stage& ps) {
 	const unsigned long long bal = __ballot(hit);
 	if (!bal) return;
 	if (hit) ps.buf[ps.count + (uint32_t)__popcll(bal & ((1ull << nh_lane()) - 1ull))] = make_uint2(ca, cb);
 	ps.count += (uint32_t)__popcll(bal);
-	if (ps.count > ps.cap - 64) flush_kept(st, kept, kept_cap, ps);
+	if (ps.count > ps.cap - 64) flush_pairs(st, kept, kept_cap, ps, &st->fat_count, &st->fat_count_sph);
 }
 
 // ---- 5. pair search: grid neighbours + large list ---------------------------------------------------------
@@ -536,7 +514,7 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 			}
 		}
 	}
-	flush_kept_block(st, kept, kept_cap, ps);
+	flush_pairs_block(st, kept, kept_cap, ps, &st->fat_count, &st->fat_count_sph);
 }
 
 // small x large pairs, found from the LARGE side: a large collider (ground slab, wall) visits the grid cells its AABB
@@ -595,7 +573,7 @@ __global__ __launch_bounds__(LP_THREADS) void k_large_pairs(nh_DevState* __restr
 			}
 		}
 	}
-	flush_kept_block(st, kept, kept_cap, ps);
+	flush_pairs_block(st, kept, kept_cap, ps, &st->fat_count, &st->fat_count_sph);
 }
 
 // ---- 6. kept pairs -> this step's pairs ------------------------------------------------------------------------------------------------
@@ -606,36 +584,66 @@ __global__ __launch_bounds__(LP_THREADS) void k_large_pairs(nh_DevState* __restr
 // full search would (k_grid_setup decides on the device; the kernels of the chain are launched either way and leave at once when they are not
 // needed).  A scene at rest re-uses its list for hundreds of steps: at 1 M boxes the regrouping and the search cost 117 us, this pass 15.
 // NH_NO_KEPT_PAIRS=1 rebuilds every step; the results must be the same bit for bit (test_kept_pair_list_*).
+// Two ways of writing the result.  COMPACT: hits are staged and appended (box-box pairs from the front of `pairs`, pairs with a sphere from the back),
+// in whatever order the workgroups reserve their slots.  IN PLACE: a kept pair's position in the kept buffer is also its position in `pairs`, a miss
+// leaves an invalid entry (~0, ~0) there -- chosen when the last pass found at least 15 of 16 kept pairs overlapping and nothing was rebuilt since.
+// A record (one per pair, k_narrowphase) then sits where it sat last step, and when its key is the same too -- in a landed scene it is, for every pair,
+// step after step -- the tag sort of the records has nothing to do (nh_collide: "sort re-use").
+#define NH_PAIR_INVALID 0xFFFFFFFFu
 __global__ __launch_bounds__(256) void k_kept_filter(nh_DevState* __restrict__ st, const uint2* __restrict__ kept, uint32_t kept_cap, uint32_t nbox,
                                                      const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
                                                      uint2* __restrict__ pairs, uint32_t pair_cap,
-                                                     uint32_t* __restrict__ coarse_parent, uint32_t parity, const uint8_t* __restrict__ idle) {
+                                                     uint32_t* __restrict__ coarse_parent, uint32_t parity, const uint8_t* __restrict__ idle, uint32_t allow_in_place) {
 	uint32_t* const islands = st->any_idle[parity] ? coarse_parent : nullptr;
 	// Morton frame (nudge.cpp:3096-3100): which collider of a pair plays "a" is decided by the Morton order of the AABB min corners
 	const float mscale = st->morton_scale;
 	const nh_f3 mmin = nh_make3(st->morton_min[0], st->morton_min[1], st->morton_min[2]);
 	__shared__ uint2 wave_buf[4][FP_WBUF];
+	__shared__ uint32_t s_hits;
 	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u, FP_WBUF, nbox };
-	const uint32_t n = min(st->fat_count, kept_cap);
+	const uint32_t n_bb = min(st->fat_count, kept_cap), n_sph = min(st->fat_count_sph, kept_cap - n_bb);
+	const uint32_t n = n_bb + n_sph;
+	if (blockIdx.x == 0 && threadIdx.x == 0 && (uint64_t)st->fat_count + st->fat_count_sph > kept_cap) st->error = NH_ERR_PAIR_CAPACITY;
+	// (every workgroup derives the same decision from values nobody writes during this kernel)
+	const bool in_place = allow_in_place && !st->fat_rebuild && n <= pair_cap && (uint64_t)st->fat_hits_prev * 16u >= (uint64_t)n * 15u;
+	if (threadIdx.x == 0) s_hits = 0;
+	if (blockIdx.x == 0 && threadIdx.x == 0 && in_place) { st->pairs = n_bb; st->pairs_sph = n_sph; }
+	__syncthreads();
 	// One reservation on the pair counters per WORKGROUP and flush (a same-address atomic costs ~12 ns, serialised: with one per wave the counters, not the
 	// memory system, set the pace): the waves stage their pairs separately but flush together, so the trip count is uniform over the workgroup
 	const uint32_t rounded = (n + blockDim.x - 1u) / blockDim.x * blockDim.x;
+	uint32_t hits = 0;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
 		bool hit = false;
 		uint32_t ca = 0, cb = 0, abody = 0, bbody = 0;
 		uint64_t ka = 0, kb = 0;
 		if (i < n) {
-			const uint2 pr = kept[i];
+			const uint2 pr = i < n_bb ? kept[i] : kept[kept_cap - 1u - (i - n_bb)];
 			ca = pr.x; cb = pr.y;
 			const float4 amin = aabb_min[ca], amax = aabb_max[ca], bmin = aabb_min[cb], bmax = aabb_max[cb];
 			abody = __float_as_uint(amin.w); bbody = __float_as_uint(bmin.w);
 			hit = aabb_overlap(amin, amax, bmin, bmax) && (bbody != abody);
 			if (hit) { ka = nh_morton_of(nh_make3(amin.x, amin.y, amin.z), mscale, mmin); kb = nh_morton_of(nh_make3(bmin.x, bmin.y, bmin.z), mscale, mmin); }
 		}
-		emit_pair(st, pairs, pair_cap, ka, kb, ca, cb, hit, ps, islands, idle, abody, bbody);
-		if (__syncthreads_or(ps.count > ps.cap - 192u)) { flush_pairs_block(st, pairs, pair_cap, ps); ps.count = 0; __syncthreads(); }
+		hits += hit ? 1u : 0u;
+		if (in_place) {
+			if (hit && islands && abody && bbody && (idle[abody] == 0xff || idle[bbody] == 0xff)) uf_union(islands, abody, bbody);
+			if (i < n) {
+				const bool a_first = (ka < kb) || (ka == kb && ca < cb);
+				const uint2 out = hit ? (a_first ? make_uint2(cb, ca) : make_uint2(ca, cb)) : make_uint2(NH_PAIR_INVALID, NH_PAIR_INVALID);       // narrowphase "a" = later in Morton order (emit_pair)
+				pairs[i < n_bb ? i : pair_cap - 1u - (i - n_bb)] = out;
+			}
+		} else {
+			emit_pair(st, pairs, pair_cap, ka, kb, ca, cb, hit, ps, islands, idle, abody, bbody);
+			if (__syncthreads_or(ps.count > ps.cap - 192u)) { flush_pairs_block(st, pairs, pair_cap, ps, &st->pairs, &st->pairs_sph); ps.count = 0; __syncthreads(); }
+		}
 	}
-	flush_pairs_block(st, pairs, pair_cap, ps);
+	if (!in_place) flush_pairs_block(st, pairs, pair_cap, ps, &st->pairs, &st->pairs_sph);
+	// how many kept pairs overlap: next step's choice between the two ways
+	for (int d = 32; d >= 1; d >>= 1) hits += (uint32_t)__shfl_xor((int)hits, d);
+	if (nh_lane() == 0 && hits) atomicAdd(&s_hits, hits);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_hits) atomicAdd(&st->fat_hits, s_hits);
 }
 
 // ---- 6. narrowphase -----------------------------------------------------------------------------------------
@@ -666,6 +674,8 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		if ((uint64_t)st->pairs + st->pairs_sph > pair_cap) st->error = NH_ERR_PAIR_CAPACITY;
 	}
 	const uint32_t n = SPH ? n_sph : n_bb, first_rec = SPH ? n_bb : 0u;
+	// sort re-use (nh_collide): `rec_key` is the context's buffer of keys by record position, still holding last step's -- is every key what it was?
+	bool changed = false;
 	uint32_t rounded = (n + 63u) & ~63u;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
 		nh_bb_result bb;
@@ -676,12 +686,15 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		uint32_t body_a = 0, body_b = 0;
 		bool asleep = false;
 		const uint32_t ri = first_rec + i;        // record index
+		bool invalid = false;
 		if (i < n) {
 			uint2 pr = pairs[SPH ? pair_cap - 1u - i : i];
+			invalid = pr.x == NH_PAIR_INVALID;       // (k_kept_filter, in-place form: a kept pair that does not overlap this step -- an empty record, key ~0)
+			if (invalid) { pr = make_uint2(0u, 0u); key = ~0ull; }
 			uint32_t a = pr.x, b = pr.y;            // a = later in Morton order
 			bool a_sph = a >= nbox, b_sph = b >= nbox;
-			bool coarse_asleep = false;
-			if (some_asleep) {
+			bool coarse_asleep = invalid;
+			if (some_asleep && !invalid) {
 				const uint32_t ba = xf[a].body, bb2 = xf[b].body;
 				const uint32_t set = coarse_root[ba ? ba : bb2];            // sets[a] | sets[b] with sets[0] = 0 (nudge.cpp:3687)
 				coarse_asleep = !coarse_active[set];
@@ -727,7 +740,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 					dp[1] = make_float4(single.nx, single.ny, single.nz, single.friction);
 					raw_feature[(size_t)4 * ri] = single.feature;
 				}
-				rec_key[ri] = key;
+				{ const uint64_t was = rec_key[ri]; changed |= was != key; rec_key[ri] = key; }
 				nh_Record r = { body_a, body_b, 0u, asleep ? NH_REC_SLEEPING : (uint32_t)count };
 				if (asleep) st->any_sleeping = 1;
 				rec[ri] = r;
@@ -776,7 +789,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			} else if (bb.kind == 1) {
 				put(0, bb.edge);
 			}
-			rec_key[ri] = key;
+			{ const uint64_t was = rec_key[ri]; changed |= was != key; rec_key[ri] = key; }
 			nh_Record r = { body_a, body_b, ovf, asleep ? NH_REC_SLEEPING : (uint32_t)count };
 			if (asleep) st->any_sleeping = 1;
 			rec[ri] = r;
@@ -798,6 +811,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		}
 		__builtin_amdgcn_wave_barrier();
 	}
+	if (__ballot(changed) != 0ull && nh_lane() == 0) st->keys_changed = 1u;          // (plain store of a constant)
 }
 
 // ---- 7. islands (lock-free union-find), active bodies, sleeping -------------------------------------------
@@ -906,9 +920,12 @@ __global__ __launch_bounds__(256) void k_filter_records(nh_DevState* __restrict_
 }
 
 // ---- 8. tag-ordered output ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sorted_counts(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ rec_idx, const nh_Record* __restrict__ rec,
-                                                       uint32_t* __restrict__ counts, uint32_t* __restrict__ sleep_flags) {
+__global__ __launch_bounds__(256) void k_sorted_counts(nh_DevState* __restrict__ st, const uint32_t* __restrict__ rec_idx, const nh_Record* __restrict__ rec,
+                                                       uint32_t* __restrict__ counts, uint32_t* __restrict__ sleep_flags, uint32_t order_kept) {
 	uint32_t n = st->records;
+	// sort re-use: `rec_idx` is the context's kept tag order (order_kept), sorted this step or still holding from an earlier one -- either way it now
+	// belongs to the keys k_narrowphase left in the context's buffer and to this record count
+	if (blockIdx.x == 0 && threadIdx.x == 0) { st->sort_valid = order_kept; st->records_kept = n; }
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		nh_Record r = rec[rec_idx[i]];
 		counts[i] = r.count & ~NH_REC_SLEEPING;
@@ -1019,7 +1036,7 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 // buffered by step parity: this step's launch sets any_idle[parity] with plain stores and clears the other one for the next step.
 __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t ncolliders, uint32_t nbodies, uint32_t* __restrict__ parent, uint32_t* __restrict__ set_active, uint32_t* __restrict__ deg,
                                                        const uint8_t* __restrict__ idle, uint32_t parity, uint32_t* __restrict__ coarse_parent, uint32_t* __restrict__ coarse_active, uint32_t no_islands,
-                                                       uint32_t* __restrict__ block_top, uint32_t drop_kept_pairs) {
+                                                       uint32_t* __restrict__ block_top, uint32_t drop_kept_pairs, uint32_t drop_sort_order) {
 	__shared__ uint32_t s_top[4];
 	// `no_islands`: the host has ruled out that anybody is asleep this step (nh_collide): no island kernel will run, their arrays stay untouched
 	bool asleep = false;
@@ -1049,6 +1066,9 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 		st->has_other = 0; st->unleveled = 0; st->has_static8 = 0; st->has_staticN = 0; st->any_sleeping = 0; st->has_pending = 0;
 		st->sort_buckets = st->sort_buckets_next;
 		st->fat_escaped = 0; st->fat_rebuild = 0;
+		st->fat_hits_prev = st->fat_hits; st->fat_hits = 0;
+		st->keys_changed = 0;
+		if (drop_sort_order) st->sort_valid = 0;
 		if (drop_kept_pairs) st->fat_valid = 0;       // (collider counts or buffers changed, or NH_NO_KEPT_PAIRS: the kept pair list describes another world)
 		for (int k = 0; k < 3; ++k) { st->smin[k] = 0xffffffffu; st->smax[k] = 0u; st->gmin[k] = 0xffffffffu; st->gmax[k] = 0u; }
 	}
@@ -1107,7 +1127,6 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	uint2* pairs = nh_arena_array<uint2>(A, pair_cap, &err);
 	nh_Contact* raw_data = nh_arena_array<nh_Contact>(A, (size_t)4 * pair_cap + overflow_cap, &err);
 	uint32_t* raw_feature = nh_arena_array<uint32_t>(A, (size_t)4 * pair_cap + overflow_cap, &err);
-	uint64_t* rec_key_a = nh_arena_array<uint64_t>(A, pair_cap, &err);
 	uint64_t* rec_key_b = nh_arena_array<uint64_t>(A, pair_cap, &err);
 	uint32_t* rec_idx_a = nh_arena_array<uint32_t>(A, pair_cap, &err);
 	uint32_t* rec_idx_b = nh_arena_array<uint32_t>(A, pair_cap, &err);
@@ -1127,6 +1146,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	if (err) return err;
 
 	hipStream_t s = ctx->stream;
+	bool drop_sort_order = ctx->env_no_sort_reuse;
 	if (ctx->deg_capacity < 4u * (B + 2u)) {
 		// library-owned, 4 x (B + 2) words: per body the contact degree, a fill cursor, the pair info (collider pairs it is in | pairs with a
 		// dynamic partner << 16) and the first contact of its last pair -- written while the contacts are laid out, consumed by setup
@@ -1140,12 +1160,22 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		if (ctx->sort_splitters) NH_HIP_CHECK(ctx, hipFree(ctx->sort_splitters));
 		if (ctx->sort_counts) NH_HIP_CHECK(ctx, hipFree(ctx->sort_counts));
 		if (ctx->sort_starts) NH_HIP_CHECK(ctx, hipFree(ctx->sort_starts));
+		if (ctx->sort_keys_by_position) NH_HIP_CHECK(ctx, hipFree(ctx->sort_keys_by_position));
+		if (ctx->sort_sorted_keys) NH_HIP_CHECK(ctx, hipFree(ctx->sort_sorted_keys));
+		if (ctx->sort_sorted_idx) NH_HIP_CHECK(ctx, hipFree(ctx->sort_sorted_idx));
+		ctx->sort_keys_by_position = nullptr; ctx->sort_sorted_keys = nullptr; ctx->sort_sorted_idx = nullptr;
 		ctx->sort_splitters = nullptr; ctx->sort_counts = nullptr; ctx->sort_starts = nullptr; ctx->sort_capacity = 0; ctx->sort_seeded = false;
 		const size_t nbk = (size_t)nh_bucket_sort_max_buckets(ctx, pair_cap) + 1u;
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sort_splitters, sizeof(uint64_t) * nbk));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sort_counts, sizeof(uint32_t) * nbk));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sort_starts, sizeof(uint32_t) * nbk));
 		NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->sort_counts, 0, sizeof(uint32_t) * nbk, s));
+		// sort re-use: the record keys by record position (k_narrowphase compares and rewrites them every step) and the tag order of the last sort
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sort_keys_by_position, sizeof(uint64_t) * (size_t)pair_cap));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sort_sorted_keys, sizeof(uint64_t) * (size_t)pair_cap));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sort_sorted_idx, sizeof(uint32_t) * (size_t)pair_cap));
+		NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->sort_keys_by_position, 0, sizeof(uint64_t) * (size_t)pair_cap, s));
+		drop_sort_order = true;
 		ctx->sort_capacity = pair_cap;
 	}
 	// library-owned: the kept pair list of the broadphase and the two buffers of inflated boxes (they persist from one nh_collide to the next)
@@ -1168,7 +1198,9 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	}
 	ctx->fat_nbox = nbox; ctx->fat_nsph = nsph;
 	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, begin_grid, 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity, coarse_parent, coarse_active, no_islands ? 1u : 0u, block_top,
-	          drop_kept ? 1u : 0u);
+	          drop_kept ? 1u : 0u, drop_sort_order ? 1u : 0u);
+	const bool seeded_sort = !ctx->env_sort_classic && ctx->sort_seeded && !ctx->env_sort_radix;      // (NH_SORT_RADIX=1: radix passes every step)
+	uint64_t* rec_key_a = ctx->sort_keys_by_position;
 	if (C) {
 		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 1024, 256), 1024, st, bodies->transforms,
 		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
@@ -1195,7 +1227,8 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 			NH_LAUNCH(ctx, "find_pairs", k_find_pairs<1>, nh_grid_for(C, 256, 4096), 256, st, C, nbox, keys_b, sbox, cstart, large_list, fbox, kept, kept_cap);
 		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, LP_GRID, LP_THREADS, st, nbox, sbox, cstart, large_list, fbox, kept, kept_cap);
 		// this step's pairs: the kept ones whose exact AABBs overlap now (every step)
-		NH_LAUNCH(ctx, "kept_filter", k_kept_filter, nh_grid_for(kept_cap, 256, 1024), 256, st, kept, kept_cap, nbox, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+		NH_LAUNCH(ctx, "kept_filter", k_kept_filter, nh_grid_for(kept_cap, 256, 1024), 256, st, kept, kept_cap, nbox, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters,
+		          (seeded_sort && !ctx->env_no_sort_reuse) ? 1u : 0u);
 		// coarse islands over the broadphase pairs (united where the pairs were emitted) + connections: only when some body is asleep (a device
 		// flag: the kernels leave at once otherwise)
 		if (!no_islands && body_connections && body_connections->count)
@@ -1217,7 +1250,6 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	// on -- it runs on the side stream while the caller's stream sorts (fork here, join before k_sorted_counts)
 	// (only while the side chain is small: the radix passes spin-wait on each other and must not share the machine with a long
 	// kernel -- with millions of records in one island the union-find alone takes a millisecond)
-	const bool seeded_sort = onesweep && ctx->sort_seeded && !ctx->env_sort_radix;      // (NH_SORT_RADIX=1: radix passes every step)
 	const bool fork = !no_islands && ctx->side != nullptr && (seeded_sort || ctx->h_state->records <= 1500000u);
 	hipStream_t main_stream = ctx->stream;
 	if (fork) {
@@ -1247,8 +1279,14 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	if (key_bits < 1) key_bits = 1;
 	if (key_bits > 32) key_bits = 32;
 	// keys are a | b<<32: sort the low field, then the high field (stable) -- dropped records carry ~0 and end up last
+	// Sort re-use.  The record keys live in a context buffer indexed by record position; k_narrowphase has compared every key with what that position
+	// held last step.  When nothing differs (and the record count is the same) the order the last sort left in the context's buffers still holds: the four
+	// kernels below leave at once.  That happens whenever k_kept_filter wrote the pairs in place and no pair changed its key -- a landed scene, step after step.
+	const uint64_t* sorted_keys = rec_key_a;
+	const uint32_t* sorted_idx = rec_idx_a;
 	if (seeded_sort) {
-		nh_bucket_sort_u64_u32(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, pair_cap, sort_place, key_bits);
+		nh_bucket_sort_u64_u32(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, pair_cap, sort_place, key_bits, ctx->sort_sorted_keys, ctx->sort_sorted_idx);
+		sorted_keys = ctx->sort_sorted_keys; sorted_idx = ctx->sort_sorted_idx;
 	} else if (onesweep) {
 		if (nh_onesweep_u64_u32_two_fields(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, &st->records, pair_cap, ctx->h_state->records, hist, key_bits)) {
 			uint64_t* t = rec_key_a; rec_key_a = rec_key_b; rec_key_b = t; uint32_t* u = rec_idx_a; rec_idx_a = rec_idx_b; rec_idx_b = u;
@@ -1262,12 +1300,13 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		}
 	}
 	// (dropped records carry count 0, so where they land in the order is irrelevant)
+	if (!seeded_sort) { sorted_keys = rec_key_a; sorted_idx = rec_idx_a; }         // (the radix passes leave the result in whichever buffer they ended in)
 	if (onesweep && !seeded_sort) { nh_bucket_sort_seed(ctx, rec_key_a, pair_cap); ctx->sort_seeded = true; }
 	if (fork) NH_HIP_CHECK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
-	NH_LAUNCH(ctx, "sorted_counts", k_sorted_counts, nh_grid_for(pair_cap, 256, 2048), 256, st, rec_idx_a, rec, rec_counts, sleep_flags);
+	NH_LAUNCH(ctx, "sorted_counts", k_sorted_counts, nh_grid_for(pair_cap, 256, 2048), 256, st, sorted_idx, rec, rec_counts, sleep_flags, seeded_sort ? 1u : 0u);
 	// contact starts and sleeping-pair slots: two scans over the sorted records in one pair of launches
 	nh_scan2_u32(ctx, rec_counts, rec_counts, &st->contacts, sleep_flags, sleep_flags, &st->sleeping, &st->records, 1, scan_tmp);
-	NH_LAUNCH(ctx, "gather_contacts", k_gather_contacts, nh_grid_for(pair_cap, 256, 8192), 256, st, rec_idx_a, rec, rec_key_a, rec_counts, raw_data, raw_feature,
+	NH_LAUNCH(ctx, "gather_contacts", k_gather_contacts, nh_grid_for(pair_cap, 256, 8192), 256, st, sorted_idx, rec, sorted_keys, rec_counts, raw_data, raw_feature,
 	          contacts->data, contacts->bodies, contacts->tags, contacts->features, cap, pair_cap, sleep_flags, contacts->sleeping_pairs, ctx->deg, B);
 
 	if (ctx->flags & NH_FLAG_SYNC_COUNTS) {

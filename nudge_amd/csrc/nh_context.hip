@@ -38,6 +38,8 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->env_colour_jp = getenv("NH_COLOUR_JP") != nullptr;
 	ctx->env_solver_waves = getenv("NH_SOLVER_WAVES") ? atoi(getenv("NH_SOLVER_WAVES")) : 1;      // wavefronts per workgroup of the fused solver (A/B: 1, 2, 4)
 	ctx->env_fp_sub = getenv("NH_FP_SUB") ? atoi(getenv("NH_FP_SUB")) : 0;      // lanes per collider in the pair search (A/B: 1, 2, 4, 16; 0 = by world size)
+	ctx->env_no_sort_reuse = getenv("NH_NO_SORT_REUSE") != nullptr;      // the tag sort of the contact records runs every step even when nothing has changed (A/B, tests)
+	ctx->sort_keys_by_position = nullptr; ctx->sort_sorted_keys = nullptr; ctx->sort_sorted_idx = nullptr;
 	ctx->env_no_fat = getenv("NH_NO_KEPT_PAIRS") != nullptr;      // the broadphase regroups and searches every step instead of re-using its kept pair list (A/B, tests)
 	ctx->fat_pairs = nullptr; ctx->fat_pair_capacity = 0; ctx->fat_box = nullptr; ctx->fat_collider_capacity = 0; ctx->fat_nbox = ctx->fat_nsph = 0xffffffffu;
 	ctx->env_colour_check_seeds = getenv("NH_COLOUR_CHECK_SEEDS") != nullptr;      // colours seeded from the cache go through a settle round instead of being final at once (A/B, tests)
@@ -74,6 +76,9 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	if (ctx->deg) hipFree(ctx->deg);
 	if (ctx->fat_pairs) hipFree(ctx->fat_pairs);
 	if (ctx->fat_box) hipFree(ctx->fat_box);
+	if (ctx->sort_keys_by_position) hipFree(ctx->sort_keys_by_position);
+	if (ctx->sort_sorted_keys) hipFree(ctx->sort_sorted_keys);
+	if (ctx->sort_sorted_idx) hipFree(ctx->sort_sorted_idx);
 	if (ctx->sort_splitters) hipFree(ctx->sort_splitters);
 	if (ctx->sort_counts) hipFree(ctx->sort_counts);
 	if (ctx->sort_starts) hipFree(ctx->sort_starts);
@@ -106,14 +111,14 @@ extern "C" int nh_synchronize(nh_context* ctx) {
 extern "C" int nh_read_counts(nh_context* ctx, nh_Counts* out) {
 	if (!ctx || !out) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx, true); if (rc) return rc; }      // (counters only: a pending NH_FLAG_FUSED_STEP gravity stays pending)
-	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, 26 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, 27 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 	const nh_DevState* h = ctx->h_state;
 	if (ctx->collide_seq) { ctx->idle_bound = (int)h->max_idle[ctx->step_parity]; ctx->idle_bound_mark = ctx->collide_mark; }      // what the last nh_collide saw
 	out->colliders = h->colliders; out->pairs = h->pairs + h->pairs_sph; out->contacts = h->contacts; out->sleeping_pairs = h->sleeping;
 	out->active_bodies = h->active; out->cache = h->cache; out->culled = h->culled; out->large_colliders = h->large;
 	out->general_contacts = h->general_contacts; out->levels = h->levels; out->error = h->error;
-	out->has_other_bodies = h->has_other; out->broadphase_rebuilds = h->fat_rebuilds; out->unleveled = h->unleveled; out->raw_pairs = h->pairs + h->pairs_sph;
+	out->has_other_bodies = h->has_other; out->broadphase_rebuilds = h->fat_rebuilds; out->sort_reuses = h->sort_reuses; out->unleveled = h->unleveled; out->raw_pairs = h->pairs + h->pairs_sph;
 	if (ctx->timing) nh_timer_collect(ctx);
 	return NH_OK;
 }

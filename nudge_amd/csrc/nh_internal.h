@@ -46,7 +46,8 @@ struct nh_DevState {
 	uint32_t pairs_sph;                   // broadphase pairs with a sphere (they fill the pair list from the back; `pairs` counts the box-box ones)
 	uint32_t max_idle[2];                 // by step parity: largest idle counter seen by this step's nh_collide (host-side sleep prediction, nh_collide)
 	uint32_t fat_rebuilds;                // broadphase rebuilds since nh_create (the steps in between re-used the kept pair list: below)
-	// ---- (the 26 words above are what nh_read_counts mirrors to the host) ----
+	uint32_t sort_reuses;                 // steps since nh_create whose record sort was skipped because last step's tag order still held
+	// ---- (the 27 words above are what nh_read_counts mirrors to the host) ----
 	// Temporal coherence of the broadphase (nh_collide.hip, "kept pair list"): the grid search runs over AABBs inflated by `fat_margin` and its
 	// pairs are KEPT; while every collider's AABB stays inside its inflated box the kept list is a superset of the overlapping pairs and one filter
 	// pass (exact AABBs, exact test) replaces the whole regrouping + search.
@@ -55,6 +56,12 @@ struct nh_DevState {
 	uint32_t fat_escaped;                 // this step: some AABB left its inflated box (k_xform)
 	uint32_t fat_rebuild;                 // this step: the grid chain runs (k_grid_setup: !fat_valid || fat_escaped)
 	float fat_margin;                     // inflation of the boxes a rebuild writes this step (k_grid_setup -> k_cell_keys)
+	uint32_t fat_count_sph;               // kept pairs with a sphere (they fill the kept buffer from the back; fat_count counts the box-box ones)
+	uint32_t fat_hits, fat_hits_prev;     // kept pairs that overlapped in this / the last k_kept_filter pass
+	// sort re-use (nh_collide): this step's records sit where last step's sat and carry the same keys => last step's tag order still holds
+	uint32_t keys_changed;                // some record's key differs from the key that position had last step (k_narrowphase)
+	uint32_t records_kept, records_prev;  // records of the step the kept tag order belongs to / as saved at the start of this step
+	uint32_t sort_valid;                  // the kept tag order (context buffers) is a sort of the keys k_narrowphase compared against
 	// scene bounds of AABB min corners, order-preserving uint encoding (atomicMin/Max)
 	uint32_t smin[3];
 	uint32_t smax[3];
@@ -113,6 +120,9 @@ struct nh_context {
 	// per-body contact degree (filled by nh_collide's contact gather, turned into CSR offsets by setup) + fill cursors: 2 x (B + 2) words
 	uint32_t* deg;
 	uint32_t deg_capacity;
+	// sort re-use (library-owned, pair capacity entries each): record keys by record position, and the tag order the last sort left
+	uint64_t* sort_keys_by_position; uint64_t* sort_sorted_keys; uint32_t* sort_sorted_idx;
+	bool env_no_sort_reuse;               // NH_NO_SORT_REUSE=1 (A/B, tests)
 	// kept pair list of the broadphase (library-owned, persists from one nh_collide to the next): pairs of inflated boxes, and the boxes
 	uint2* fat_pairs; uint32_t fat_pair_capacity;
 	float4* fat_box; uint32_t fat_collider_capacity;
@@ -281,7 +291,8 @@ int nh_onesweep_u64_u32_two_fields(nh_context* ctx, uint64_t* keys_a, uint64_t* 
                                     const uint32_t* d_count, uint32_t capacity, uint32_t expected, uint32_t* scratch, int field_bits);
 // Tag sort of st->records (key, value) pairs seeded by the previous step's result (see nh_util.hip).  Sorted data ends in keys_a / vals_a.
 uint32_t nh_bucket_sort_max_buckets(const nh_context* ctx, uint32_t capacity);
-void nh_bucket_sort_u64_u32(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t capacity, uint2* place, int field_bits);
+void nh_bucket_sort_u64_u32(nh_context* ctx, const uint64_t* keys_a, uint64_t* keys_b, const uint32_t* vals_a, uint32_t* vals_b, uint32_t capacity, uint2* place, int field_bits,
+                            uint64_t* keys_out, uint32_t* vals_out);
 void nh_bucket_sort_seed(nh_context* ctx, const uint64_t* sorted_keys, uint32_t capacity);
 // Exclusive scan of `in[0..n)` into `out` (may alias); n read from *d_count (+ `extra` elements);
 // the grand total is also stored to *d_total if non-null.  `tmp` needs 2 * NH_SORT_GRID words.

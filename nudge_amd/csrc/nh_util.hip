@@ -380,12 +380,17 @@ int nh_onesweep_u64_u32_two_fields(nh_context* ctx, uint64_t* keys_a, uint64_t* 
 // Any distribution is sorted correctly: a bucket larger than a tile is sorted by its workgroup through global memory (slow,
 // only seen when the world changes abruptly); with no history (first step, capacity change) the radix passes run instead and
 // seed the splitters.  Keys are unique (one record per collider pair), so the arrival order inside a bucket never shows.
+// Sort re-use (nh_collide): when this step's records sit at last step's positions with last step's keys, the order this sort left in the context's
+// buffers still holds and its four kernels leave at once (they are launched either way: the decision is made on the device, by k_narrowphase).
+__device__ __forceinline__ bool bk_order_still_holds(const nh_DevState* st) { return st->sort_valid != 0u && st->keys_changed == 0u && st->records == st->records_kept; }
+
 #define BK_TARGET 1024u                 // default; NH_BUCKET_TARGET (read per context) changes it -- a test knob
 #define BK_LDS_SPLITTERS 4096u
 
 __global__ __launch_bounds__(256) void bk_count(const uint64_t* __restrict__ keys, const nh_DevState* __restrict__ st, const uint64_t* __restrict__ splitters,
                                                 uint2* __restrict__ place, uint32_t* __restrict__ counts) {
 	__shared__ uint64_t s_spl[BK_LDS_SPLITTERS];
+	if (bk_order_still_holds(st)) { if (blockIdx.x == 0 && threadIdx.x == 0) const_cast<nh_DevState*>(st)->sort_reuses += 1u; return; }
 	const uint32_t n = st->records;
 	const uint32_t nb = st->sort_buckets ? st->sort_buckets : 1u, ns = nb - 1u;
 	// all splitters in LDS when they fit; otherwise every stride-th one (the last of each block of `stride`): the search first finds the block
@@ -448,6 +453,7 @@ __global__ __launch_bounds__(256) void bk_count(const uint64_t* __restrict__ key
 
 __global__ __launch_bounds__(1024) void bk_scan(const nh_DevState* __restrict__ st, uint32_t* __restrict__ counts, uint32_t* __restrict__ starts) {
 	__shared__ uint32_t wsum[16];
+	if (bk_order_still_holds(st)) return;
 	const uint32_t nb = st->sort_buckets ? st->sort_buckets : 1u;
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	uint32_t carry = 0;
@@ -470,6 +476,7 @@ __global__ __launch_bounds__(1024) void bk_scan(const nh_DevState* __restrict__ 
 
 __global__ __launch_bounds__(256) void bk_scatter(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, const nh_DevState* __restrict__ st,
                                                   const uint2* __restrict__ place, const uint32_t* __restrict__ starts, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+	if (bk_order_still_holds(st)) return;
 	const uint32_t n = st->records;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const uint2 p = place[i];
@@ -542,6 +549,7 @@ __global__ __launch_bounds__(256) void bk_sort(uint64_t* kb, uint32_t* vb, uint6
 	__shared__ uint32_t offs[256];
 	__shared__ uint32_t wtot[4];
 	__shared__ uint64_t s_ref, s_diff[4];
+	if (bk_order_still_holds(st)) return;
 	const uint32_t nb = st->sort_buckets ? st->sort_buckets : 1u;
 	const uint32_t n = st->records;
 	const uint64_t lomask = field_bits >= 32 ? 0xFFFFFFFFull : ((1ull << field_bits) - 1ull);
@@ -640,9 +648,10 @@ __global__ __launch_bounds__(256) void bk_seed(const uint64_t* __restrict__ sort
 static uint32_t bucket_target(const nh_context* ctx) { return ctx->sort_target >= 1u && ctx->sort_target <= (uint32_t)OS_TILE ? ctx->sort_target : BK_TARGET; }
 uint32_t nh_bucket_sort_max_buckets(const nh_context* ctx, uint32_t capacity) { return capacity / bucket_target(ctx) + 2u; }
 
-// keys_a/vals_a: in and out; keys_b/vals_b: scratch of the same size.  st->records keys; splitters / counts / starts: the context's
-// (nh_bucket_sort_max_buckets(capacity) + 1 entries each, counts zeroed once); place: capacity entries of scratch.
-void nh_bucket_sort_u64_u32(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals_a, uint32_t* vals_b, uint32_t capacity, uint2* place, int field_bits) {
+// keys_a/vals_a: in (left as they are); keys_b/vals_b: scratch of the same size; keys_out/vals_out: the sorted result.  st->records keys; splitters /
+// counts / starts: the context's (nh_bucket_sort_max_buckets(capacity) + 1 entries each, counts zeroed once); place: capacity entries of scratch.
+void nh_bucket_sort_u64_u32(nh_context* ctx, const uint64_t* keys_a, uint64_t* keys_b, const uint32_t* vals_a, uint32_t* vals_b, uint32_t capacity, uint2* place, int field_bits,
+                            uint64_t* keys_out, uint32_t* vals_out) {
 	nh_DevState* st = ctx->d_state;
 	// NH_BUCKET_TILE (read per context): buckets above this size take the through-global-memory path -- a test knob, the default is the tile
 	const uint32_t lds_cap = ctx->sort_tile >= 1u && ctx->sort_tile <= (uint32_t)OS_TILE ? ctx->sort_tile : (uint32_t)OS_TILE;
@@ -650,7 +659,7 @@ void nh_bucket_sort_u64_u32(nh_context* ctx, uint64_t* keys_a, uint64_t* keys_b,
 	NH_LAUNCH(ctx, "bucket_count", bk_count, nh_grid_for(capacity, 256, 2048), 256, keys_a, st, ctx->sort_splitters, place, ctx->sort_counts);
 	NH_LAUNCH(ctx, "bucket_scan", bk_scan, 1, 1024, st, ctx->sort_counts, ctx->sort_starts);
 	NH_LAUNCH(ctx, "bucket_scatter", bk_scatter, nh_grid_for(capacity, 256, 2048), 256, keys_a, vals_a, st, place, ctx->sort_starts, keys_b, vals_b);
-	NH_LAUNCH(ctx, "bucket_sort", bk_sort, max_buckets < 4096u ? max_buckets : 4096u, 256, keys_b, vals_b, keys_a, vals_a, ctx->sort_starts, st, two_field_shifts(field_bits), field_bits, ctx->sort_splitters, lds_cap, bucket_target(ctx));
+	NH_LAUNCH(ctx, "bucket_sort", bk_sort, max_buckets < 4096u ? max_buckets : 4096u, 256, keys_b, vals_b, keys_out, vals_out, ctx->sort_starts, st, two_field_shifts(field_bits), field_bits, ctx->sort_splitters, lds_cap, bucket_target(ctx));
 }
 
 void nh_bucket_sort_seed(nh_context* ctx, const uint64_t* sorted_keys, uint32_t capacity) {

@@ -572,6 +572,33 @@ def test_kept_pair_list_survives_teleports_and_collider_edits():
         w.close()
 
 
+@pytest.mark.parametrize("name,steps", [("grid30", 460), ("mixed20", 250), ("pile256", 600), ("stacks", 150)])
+def test_sort_reuse_changes_nothing(name, steps, monkeypatch):
+    """When k_kept_filter writes the pairs in place, a contact record sits where it sat last step; when every record also has last step's key the
+    tag sort of the records is skipped and last step's order is used.  NH_NO_SORT_REUSE=1 sorts every step: contacts (in tag order), bodies and the
+    cache must be the same bit for bit -- and the default run must actually have skipped sorts on the scenes that come to rest."""
+    scene, _ = G.build(name)
+    a = E.World(scene, flags=FAST)
+    monkeypatch.setenv("NH_NO_SORT_REUSE", "1")
+    b = E.World(scene, flags=FAST)
+    monkeypatch.delenv("NH_NO_SORT_REUSE")
+    for k in range(steps // 25):
+        a.step(25); b.step(25)
+        x, y = a.get_bodies(), b.get_bodies()
+        assert P.bits_equal(x["transforms"], y["transforms"]) and P.bits_equal(x["momentum"], y["momentum"]) and np.array_equal(x["idle"], y["idle"]), (name, k)
+        a.collide(); b.collide()
+        ca, cb = a.get_contacts(), b.get_contacts()
+        assert ca["count"] == cb["count"] and np.array_equal(ca["tags"], cb["tags"]) and np.array_equal(ca["features"], cb["features"]) and P.bits_equal(ca["data"], cb["data"])
+        assert np.array_equal(ca["bodies"], cb["bodies"]) and np.array_equal(ca["sleeping_pairs"], cb["sleeping_pairs"])
+        for w in (a, b):                                  # (finish the step the collide above began)
+            w.gravity(); w.read_cache(); w.setup(); w.apply(); w.update(); w.write_cache(); w.advance()
+    ra, rb = a.counts()["sort_reuses"], b.counts()["sort_reuses"]
+    assert rb == 0, rb
+    if name != "pile256":
+        assert ra > steps // 4, (ra, steps)
+    a.close(); b.close()
+
+
 # ---- degenerate inputs ------------------------------------------------------------------------------------------------------------
 def _tiny_scene(n_boxes, n_spheres, apart=True):
     scene = S.pile(n_boxes=max(n_boxes, 1), n_spheres=n_spheres, seed=3)
