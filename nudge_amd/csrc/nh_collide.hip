@@ -25,7 +25,7 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
                                                const nh_Transform* __restrict__ box_xf, const nh_BoxCollider* __restrict__ box_data, const uint32_t* __restrict__ box_tags, uint32_t nbox,
                                                const nh_Transform* __restrict__ sph_xf, const nh_SphereCollider* __restrict__ sph_data, const uint32_t* __restrict__ sph_tags, uint32_t nsph,
                                                nh_xform* __restrict__ xf, float4* __restrict__ aabb_min, float4* __restrict__ aabb_max, uint32_t* __restrict__ ctag,
-                                               uint4* __restrict__ zero16, uint32_t zero16_count, const float4* __restrict__ fat_box) {
+                                               uint4* __restrict__ zero16, uint32_t zero16_count, const float4* __restrict__ fat_box, uint32_t direct) {
 	__shared__ uint32_t hist[1024];
 	__shared__ uint32_t red[12];
 	hist[threadIdx.x] = 0;
@@ -39,8 +39,9 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 	const uint32_t guess_exp = st->small_exp;
 	uint32_t gmn[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, gmx[3] = { 0, 0, 0 };
 	// kept pair list (below, "6. kept pairs"): is every AABB still inside the inflated box the kept pairs were found with?
-	const bool fat_valid = st->fat_valid != 0u;
-	const float margin = nh_kept_margin(st->cell_inv);           // (k_grid_setup records the same value for k_cell_keys before it moves the grid)
+	// (`direct`: this step searches the grid with the exact boxes and keeps nothing, nh_collide)
+	const bool fat_valid = st->fat_valid != 0u && !direct;
+	const float margin = direct ? 0.0f : nh_kept_margin(st->cell_inv);           // (k_grid_setup records the same value for k_cell_keys before it moves the grid)
 	bool escaped = false;
 	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
 		bool is_box = c < nbox;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 // needs -- an L2 write-back per workgroup on this multi-die part -- cost 100 us, twenty times the launch it saved.)
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return *p; }
 
-__global__ __launch_bounds__(64) void k_grid_setup(nh_DevState* st, uint32_t ncolliders, uint32_t max_cells) {
+__global__ __launch_bounds__(64) void k_grid_setup(nh_DevState* st, uint32_t ncolliders, uint32_t max_cells, uint32_t direct) {
 	// small/large split: allow at most max(64, C/1024) colliders above the grid's cell size.  e = largest size class kept small =
 	// the highest class whose suffix count (colliders in classes >= e) exceeds the budget.  One wave: lane l owns classes 16l..16l+15.
 	const uint32_t budget = max(ncolliders / 1024u, 64u);
@@ -154,11 +155,11 @@ __global__ __launch_bounds__(64) void k_grid_setup(nh_DevState* st, uint32_t nco
 	// kept pair list: while it is valid and nobody has left its inflated box the grid below is not needed this step -- every kernel of the chain
 	// (k_cell_keys .. k_large_pairs) leaves at once and k_kept_filter re-tests the kept pairs; otherwise the candidate boxes k_xform just
 	// wrote become the current ones and the chain rebuilds the list from them
-	const bool rebuild = st->fat_valid == 0u || st->fat_escaped != 0u;
+	const bool rebuild = direct || st->fat_valid == 0u || st->fat_escaped != 0u;
 	st->fat_rebuild = rebuild ? 1u : 0u;
 	if (!rebuild) return;
-	st->fat_margin = nh_kept_margin(st->cell_inv);           // (of the grid about to be replaced: what k_xform used)
-	st->fat_valid = 1u; st->fat_count = 0u; st->fat_count_sph = 0u; st->fat_rebuilds += 1u;
+	st->fat_margin = direct ? 0.0f : nh_kept_margin(st->cell_inv);           // (of the grid about to be replaced: what k_xform used)
+	st->fat_valid = direct ? 0u : 1u; st->fat_count = 0u; st->fat_count_sph = 0u; st->fat_rebuilds += 1u;
 	// e = largest size class (exponent << 2 | two mantissa bits) kept "small"; never let the cell underflow to denormals
 	if (e < (64 << 2)) e = 64 << 2;
 	if (e > (190 << 2)) e = 190 << 2;
@@ -411,6 +412,23 @@ __device__ __forceinline__ void emit_kept(nh_DevState* st, uint2* __restrict__ k
 	if (ps.count > ps.cap - 64) flush_pairs(st, kept, kept_cap, ps, &st->fat_count, &st->fat_count_sph);
 }
 
+// What the grid search does with two overlapping boxes.  KEPT mode: the boxes are inflated, the pair goes to the kept list as it is.  DIRECT mode (a
+// world in which somebody leaves its box every step: keeping pairs would only add the filter pass): the boxes are the exact AABBs, and the pair --
+// unless both colliders sit on one body -- goes straight to this step's pairs, roles by Morton order, coarse islands united (emit_pair).
+template<bool DIRECT>
+__device__ __forceinline__ void emit_found(nh_DevState* st, uint2* __restrict__ out, uint32_t out_cap, const float4& amin, const float4& bmin, uint32_t ca, uint32_t cb, bool hit,
+                                           pair_stage& ps, float mscale, const nh_f3& mmin, uint32_t* islands, const uint8_t* __restrict__ idle) {
+	if (DIRECT) {
+		const uint32_t abody = __float_as_uint(amin.w), bbody = __float_as_uint(bmin.w);
+		hit = hit && abody != bbody;
+		uint64_t ka = 0, kb = 0;
+		if (hit) { ka = nh_morton_of(nh_make3(amin.x, amin.y, amin.z), mscale, mmin); kb = nh_morton_of(nh_make3(bmin.x, bmin.y, bmin.z), mscale, mmin); }
+		emit_pair(st, out, out_cap, ka, kb, ca, cb, hit, ps, islands, idle, abody, bbody);
+	} else {
+		emit_kept(st, out, out_cap, ca, cb, hit, ps);
+	}
+}
+
 // ---- 5. pair search: grid neighbours + large list ---------------------------------------------------------
 // One lane per small collider A, in cell order.  A pair is emitted by its member with the LOWER sorted index, so A only looks FORWARD:
 // a collider B that overlaps A has its (min corner) cell in [c_min(A) - 1, c_max(A)] per axis, and one that comes after A in cell order
@@ -425,14 +443,19 @@ __device__ __forceinline__ void emit_kept(nh_DevState* st, uint2* __restrict__ k
 // lists (its cells are as large as its largest box, its boxes lie on top of each other): SUB consecutive lanes then share a collider and take every
 // SUB-th candidate of its ranges -- 16 x the lanes, 1/16 of the dependent rounds (the sample application's pile: 84 -> ~10 us).  Each lane emits its
 // own hits; nothing else changes.
-template<int SUB>
+template<int SUB, bool DIRECT>
 __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st, uint32_t n, uint32_t nbox,
                                                     const uint32_t* __restrict__ keys, const float4* __restrict__ sbox,
                                                     const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
                                                     const float4* __restrict__ box,
-                                                    uint2* __restrict__ kept, uint32_t kept_cap) {
-	// (runs on the inflated boxes and fills the KEPT list; roles, same-body pairs and sleeping sets are k_kept_filter's business)
+                                                    uint2* __restrict__ kept, uint32_t kept_cap,
+                                                    uint32_t* __restrict__ coarse_parent, uint32_t parity, const uint8_t* __restrict__ idle) {
+	// (KEPT mode: runs on the inflated boxes and fills the kept list; roles, same-body pairs and sleeping sets are k_kept_filter's business.
+	// DIRECT mode: `box` / `sbox` hold the exact AABBs and `kept` is this step's pair list)
 	if (!st->fat_rebuild) return;
+	uint32_t* const islands = DIRECT && st->any_idle[parity] ? coarse_parent : nullptr;
+	const float mscale = st->morton_scale;
+	const nh_f3 mmin = nh_make3(st->morton_min[0], st->morton_min[1], st->morton_min[2]);
 	const float inv = st->cell_inv;
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
@@ -500,7 +523,7 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 					cb = __float_as_uint(bmax[k].w);
 					hit = aabb_overlap(amin, amax, bmin[k], bmax[k]);
 				}
-				emit_kept(st, kept, kept_cap, ca, cb, hit, ps);
+				emit_found<DIRECT>(st, kept, kept_cap, amin, bmin[k], ca, cb, hit, ps, mscale, mmin, islands, idle);
 			}
 		}
 		// large x larger-indexed large (small x large is found from the large side: k_large_pairs)
@@ -510,11 +533,11 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 				uint32_t cb = large_list[l];
 				float4 bmin = box[2u * cb], bmax = box[2u * cb + 1u];
 				bool hit = a_large && cb > ca && aabb_overlap(amin, amax, bmin, bmax);
-				emit_kept(st, kept, kept_cap, ca, cb, hit, ps);
+				emit_found<DIRECT>(st, kept, kept_cap, amin, bmin, ca, cb, hit, ps, mscale, mmin, islands, idle);
 			}
 		}
 	}
-	flush_pairs_block(st, kept, kept_cap, ps, &st->fat_count, &st->fat_count_sph);
+	flush_pairs_block(st, kept, kept_cap, ps, DIRECT ? &st->pairs : &st->fat_count, DIRECT ? &st->pairs_sph : &st->fat_count_sph);
 }
 
 // small x large pairs, found from the LARGE side: a large collider (ground slab, wall) visits the grid cells its AABB
@@ -529,11 +552,16 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 #define LP_BLOCKS 512u
 #endif
 #define LP_WBUF 1024
+template<bool DIRECT>
 __global__ __launch_bounds__(LP_THREADS) void k_large_pairs(nh_DevState* __restrict__ st, uint32_t nbox, const float4* __restrict__ sbox,
                                                      const uint32_t* __restrict__ cstart, const uint32_t* __restrict__ large_list,
                                                      const float4* __restrict__ box,
-                                                     uint2* __restrict__ kept, uint32_t kept_cap) {
+                                                     uint2* __restrict__ kept, uint32_t kept_cap,
+                                                     uint32_t* __restrict__ coarse_parent, uint32_t parity, const uint8_t* __restrict__ idle) {
 	if (!st->fat_rebuild) return;
+	uint32_t* const islands = DIRECT && st->any_idle[parity] ? coarse_parent : nullptr;
+	const float mscale = st->morton_scale;
+	const nh_f3 mmin = nh_make3(st->morton_min[0], st->morton_min[1], st->morton_min[2]);
 	const float inv = st->cell_inv;
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
@@ -564,16 +592,18 @@ __global__ __launch_bounds__(LP_THREADS) void k_large_pairs(nh_DevState* __restr
 				const bool have = cand < jend;
 				bool hit = false;
 				uint32_t cb = 0;
+				float4 bmin = make_float4(0, 0, 0, 0);
 				if (have) {
-					float4 bmin = sbox[2u * cand], bmax = sbox[2u * cand + 1u];
+					bmin = sbox[2u * cand];
+					const float4 bmax = sbox[2u * cand + 1u];
 					cb = __float_as_uint(bmax.w);
 					hit = aabb_overlap(amin, amax, bmin, bmax);
 				}
-				emit_kept(st, kept, kept_cap, ca, cb, hit, ps);
+				emit_found<DIRECT>(st, kept, kept_cap, amin, bmin, ca, cb, hit, ps, mscale, mmin, islands, idle);
 			}
 		}
 	}
-	flush_pairs_block(st, kept, kept_cap, ps, &st->fat_count, &st->fat_count_sph);
+	flush_pairs_block(st, kept, kept_cap, ps, DIRECT ? &st->pairs : &st->fat_count, DIRECT ? &st->pairs_sph : &st->fat_count_sph);
 }
 
 // ---- 6. kept pairs -> this step's pairs ------------------------------------------------------------------------------------------------
@@ -1178,8 +1208,22 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		drop_sort_order = true;
 		ctx->sort_capacity = pair_cap;
 	}
+	// Kept pair list or direct search?  Keeping pairs pays while the list outlives a few steps.  In a world where somebody leaves its box every step
+	// (millions of bodies of which a few always roll) every step rebuilds and the filter pass only adds to it: after eight rebuilds in a row (the count
+	// rides back with every step's round trip) the next 64 steps search the grid with the exact boxes and write the pairs directly, then the list gets
+	// another chance.
+	{
+		const uint32_t seen = ctx->h_state->fat_rebuilds;
+		if (ctx->bp_direct_left > 0) { if (--ctx->bp_direct_left == 0) ctx->bp_rebuild_streak = 0; }
+		else {
+			ctx->bp_rebuild_streak = seen != ctx->bp_seen_rebuilds ? ctx->bp_rebuild_streak + 1u : 0u;
+			if (ctx->bp_rebuild_streak >= 8u) ctx->bp_direct_left = 64;
+		}
+		ctx->bp_seen_rebuilds = seen;
+	}
+	const bool bp_direct = ctx->env_no_fat || ctx->bp_direct_left > 0;
 	// library-owned: the kept pair list of the broadphase and the two buffers of inflated boxes (they persist from one nh_collide to the next)
-	bool drop_kept = ctx->env_no_fat || ctx->fat_nbox != nbox || ctx->fat_nsph != nsph;
+	bool drop_kept = ctx->fat_nbox != nbox || ctx->fat_nsph != nsph;
 	// (the kept list holds pairs of INFLATED boxes: more than overlap exactly -- twice the pair capacity, at least 4096)
 	const uint32_t want_kept = pair_cap > 0x7fffffffu / 2u ? 0xfffffffeu : (2u * pair_cap > 4096u ? 2u * pair_cap : 4096u);
 	if (ctx->fat_pair_capacity != want_kept) {
@@ -1205,10 +1249,10 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 1024, 256), 1024, st, bodies->transforms,
 		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
 		          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
-		          xf, aabb_min, aabb_max, ctag, reinterpret_cast<uint4*>(cstart), (max_cells + 8u) / 4u, ctx->fat_box);
+		          xf, aabb_min, aabb_max, ctag, reinterpret_cast<uint4*>(cstart), (max_cells + 8u) / 4u, ctx->fat_box, bp_direct ? 1u : 0u);
 		// Morton frame; and the decision whether the grid chain below runs this step or the kept pair list is re-used (its kernels are launched
 		// either way: the decision is made on the device, and a kernel that leaves at once costs two microseconds)
-		NH_LAUNCH(ctx, "grid_setup", k_grid_setup, 1, 64, st, C, max_cells);
+		NH_LAUNCH(ctx, "grid_setup", k_grid_setup, 1, 64, st, C, max_cells, bp_direct ? 1u : 0u);
 		float4* fbox = ctx->fat_box;
 		uint2* kept = ctx->fat_pairs;
 		const uint32_t kept_cap = ctx->fat_pair_capacity;
@@ -1216,19 +1260,20 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_sums, max_cells / CS_TILE, 256, st, cstart, cscan_sums);
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_final, max_cells / CS_TILE, 256, st, cstart, cscan_sums, max_cells);
 		NH_LAUNCH(ctx, "cell_scatter", k_cell_scatter, nh_grid_for(C, 256, 2048), 256, st, C, keys_a, vals_a, cstart, fbox, keys_b, sbox);
-		const int fp_sub = ctx->env_fp_sub ? ctx->env_fp_sub : (C <= 16384u ? 16 : 1);
-		if (fp_sub == 4)
-			NH_LAUNCH(ctx, "find_pairs", k_find_pairs<4>, nh_grid_for((uint64_t)C * 4u, 256, 16384), 256, st, C, nbox, keys_b, sbox, cstart, large_list, fbox, kept, kept_cap);
-		else if (fp_sub == 2)
-			NH_LAUNCH(ctx, "find_pairs", k_find_pairs<2>, nh_grid_for((uint64_t)C * 2u, 256, 8192), 256, st, C, nbox, keys_b, sbox, cstart, large_list, fbox, kept, kept_cap);
-		else if (fp_sub == 16)
-			NH_LAUNCH(ctx, "find_pairs", k_find_pairs<16>, nh_grid_for((uint64_t)C * 16u, 256, 4096), 256, st, C, nbox, keys_b, sbox, cstart, large_list, fbox, kept, kept_cap);
-		else
-			NH_LAUNCH(ctx, "find_pairs", k_find_pairs<1>, nh_grid_for(C, 256, 4096), 256, st, C, nbox, keys_b, sbox, cstart, large_list, fbox, kept, kept_cap);
-		NH_LAUNCH(ctx, "large_pairs", k_large_pairs, LP_GRID, LP_THREADS, st, nbox, sbox, cstart, large_list, fbox, kept, kept_cap);
-		// this step's pairs: the kept ones whose exact AABBs overlap now (every step)
-		NH_LAUNCH(ctx, "kept_filter", k_kept_filter, nh_grid_for(kept_cap, 256, 1024), 256, st, kept, kept_cap, nbox, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters,
-		          (seeded_sort && !ctx->env_no_sort_reuse) ? 1u : 0u);
+		// (KEPT: the chain fills the kept list, k_kept_filter makes this step's pairs of it; DIRECT: the chain writes this step's pairs itself)
+		const bool many_lanes = ctx->env_fp_sub ? ctx->env_fp_sub > 1 : C <= 16384u;
+#define NH_FIND_PAIRS(SUBL, DIR, OUT, OUTCAP) NH_LAUNCH(ctx, "find_pairs", (k_find_pairs<SUBL, DIR>), nh_grid_for((uint64_t)C * SUBL, 256, 4096), 256, st, C, nbox, keys_b, sbox, cstart, large_list, fbox, OUT, OUTCAP, \
+		          coarse_parent, ctx->step_parity, bodies->idle_counters)
+		if (bp_direct) {
+			if (many_lanes) NH_FIND_PAIRS(16, true, pairs, pair_cap); else NH_FIND_PAIRS(1, true, pairs, pair_cap);
+			NH_LAUNCH(ctx, "large_pairs", (k_large_pairs<true>), LP_GRID, LP_THREADS, st, nbox, sbox, cstart, large_list, fbox, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+		} else {
+			if (many_lanes) NH_FIND_PAIRS(16, false, kept, kept_cap); else NH_FIND_PAIRS(1, false, kept, kept_cap);
+			NH_LAUNCH(ctx, "large_pairs", (k_large_pairs<false>), LP_GRID, LP_THREADS, st, nbox, sbox, cstart, large_list, fbox, kept, kept_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+			// this step's pairs: the kept ones whose exact AABBs overlap now (every step)
+			NH_LAUNCH(ctx, "kept_filter", k_kept_filter, nh_grid_for(kept_cap, 256, 1024), 256, st, kept, kept_cap, nbox, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters,
+			          (seeded_sort && !ctx->env_no_sort_reuse) ? 1u : 0u);
+		}
 		// coarse islands over the broadphase pairs (united where the pairs were emitted) + connections: only when some body is asleep (a device
 		// flag: the kernels leave at once otherwise)
 		if (!no_islands && body_connections && body_connections->count)

@@ -40,6 +40,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->env_fp_sub = getenv("NH_FP_SUB") ? atoi(getenv("NH_FP_SUB")) : 0;      // lanes per collider in the pair search (A/B: 1, 2, 4, 16; 0 = by world size)
 	ctx->env_no_sort_reuse = getenv("NH_NO_SORT_REUSE") != nullptr;      // the tag sort of the contact records runs every step even when nothing has changed (A/B, tests)
 	ctx->sort_keys_by_position = nullptr; ctx->sort_sorted_keys = nullptr; ctx->sort_sorted_idx = nullptr;
+	ctx->bp_seen_rebuilds = 0; ctx->bp_rebuild_streak = 0; ctx->bp_direct_left = 0;
 	ctx->env_no_fat = getenv("NH_NO_KEPT_PAIRS") != nullptr;      // the broadphase regroups and searches every step instead of re-using its kept pair list (A/B, tests)
 	ctx->fat_pairs = nullptr; ctx->fat_pair_capacity = 0; ctx->fat_box = nullptr; ctx->fat_collider_capacity = 0; ctx->fat_nbox = ctx->fat_nsph = 0xffffffffu;
 	ctx->env_colour_check_seeds = getenv("NH_COLOUR_CHECK_SEEDS") != nullptr;      // colours seeded from the cache go through a settle round instead of being final at once (A/B, tests)
@@ -49,6 +50,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->h_state = nullptr;
 	if (hipMalloc((void**)&ctx->d_state, sizeof(nh_DevState)) != hipSuccess) { delete ctx; return NH_ERR_HIP; }
 	if (hipHostMalloc((void**)&ctx->h_state, sizeof(nh_DevState), 0) != hipSuccess) { hipFree(ctx->d_state); delete ctx; return NH_ERR_HIP; }
+	memset(ctx->h_state, 0, sizeof(nh_DevState));
 	ctx->side = nullptr; ctx->ev_fork = nullptr; ctx->ev_join = nullptr; ctx->ev_active = nullptr; ctx->ev_gravity = nullptr; ctx->gravity_may_overlap = false;
 	if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_active, hipEventDisableTiming) != hipSuccess ||
