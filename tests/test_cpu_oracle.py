@@ -217,6 +217,25 @@ def test_library_exports_every_declared_symbol():
     assert set(engine.EXPORTS) <= set(declared)
 
 
+def test_python_mirrors_of_the_abi_structs_match_the_header(tmp_path):
+    """nudge_amd/engine.py mirrors the structs of include/nudge_hip.h with ctypes: sizes and the offsets of the last members must be what a C compiler
+    makes of the header (a field added on one side only would shift everything behind it silently)."""
+    from nudge_amd import engine as E
+    src = tmp_path / "layout.c"
+    probes = [("nh_Arena", "size", E.Arena), ("nh_ContactData", "sleeping_count", E.ContactData), ("nh_ColliderData", "spheres", E.ColliderData),
+              ("nh_BodyData", "count", E.BodyData), ("nh_BodyConnections", "count", E.BodyConnections), ("nh_ContactCache", "count", E.ContactCache),
+              ("nh_ActiveBodies", "count", E.ActiveBodies), ("nh_Counts", "sort_reuses", E.Counts), ("nh_KernelTime", "launches", E.KernelTime)]
+    body = "".join(f'  printf("%zu %zu\\n", sizeof({c}), offsetof({c}, {m}));\n' for c, m, _ in probes)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "nudge_hip.h"\nint main(void) {\n' + body + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    lines = subprocess.check_output([str(exe)], text=True).split("\n")
+    for (cname, member, mirror), line in zip(probes, lines):
+        size, off = (int(v) for v in line.split())
+        assert ctypes.sizeof(mirror) == size, (cname, ctypes.sizeof(mirror), size)
+        assert getattr(mirror, member).offset == off, (cname, member, getattr(mirror, member).offset, off)
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import torch
     from nudge_amd import engine
