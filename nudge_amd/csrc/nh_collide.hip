@@ -762,13 +762,15 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			}
 		}
 		if (SPH) {
-			// one contact at most: straight to the record's first raw slot
+			// one contact at most, ONE raw slot per sphere record (they follow the four-slot blocks of the box-box records: slot 4 n_bb + i, so that
+			// consecutive lanes write -- and k_gather_contacts reads -- consecutive 32 bytes instead of every fourth slot)
 			if (i < n) {
 				if (count) {
-					float4* dp = reinterpret_cast<float4*>(raw_data + (size_t)4 * ri);
+					const size_t slot = (size_t)4 * n_bb + i;
+					float4* dp = reinterpret_cast<float4*>(raw_data + slot);
 					dp[0] = make_float4(single.px, single.py, single.pz, single.penetration);
 					dp[1] = make_float4(single.nx, single.ny, single.nz, single.friction);
-					raw_feature[(size_t)4 * ri] = single.feature;
+					raw_feature[slot] = single.feature;
 				}
 				{ const uint64_t was = rec_key[ri]; changed |= was != key; rec_key[ri] = key; }
 				nh_Record r = { body_a, body_b, 0u, asleep ? NH_REC_SLEEPING : (uint32_t)count };
@@ -978,6 +980,7 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 	__shared__ uint32_t s_feat[4][1024];
 	__shared__ uint8_t s_own[4][1024];
 	const uint32_t nrec = st->records;
+	const uint32_t n_bb = min(st->pairs, pair_cap);
 	if (st->contacts > capacity && blockIdx.x == 0 && threadIdx.x == 0) st->error = NH_ERR_CONTACT_CAPACITY;
 	const uint32_t wave = threadIdx.x >> 6, lane = nh_lane();
 	uint32_t* src = s_src[wave];
@@ -986,6 +989,7 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 	for (uint32_t lo0 = (blockIdx.x * 4u + wave) * 64u; lo0 < nrec; lo0 += gridDim.x * 256u) {
 		const uint32_t lo = lo0 + lane;
 		uint32_t cnt = 0, start = 0, body_a = 0, body_b = 0, base4 = 0, baseo = 0;
+		bool sph_rec = false;
 		uint64_t key = 0;
 		if (lo < nrec) {
 			const uint32_t ri = rec_idx[lo];
@@ -999,7 +1003,8 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 				if (p < capacity) sleeping_pairs[p] = key; else st->error = NH_ERR_CONTACT_CAPACITY;
 			}
 			body_a = r.body_a; body_b = r.body_b;
-			base4 = 4u * ri; baseo = 4u * pair_cap + r.overflow;
+			sph_rec = ri >= n_bb;                   // (records of pairs with a sphere follow the box-box ones and own ONE raw slot each: k_narrowphase<true>)
+			base4 = sph_rec ? 4u * n_bb + (ri - n_bb) : 4u * ri; baseo = 4u * pair_cap + r.overflow;
 			// contact degree of the two bodies (body 0 is the static world): the solver's adjacency starts from these
 			// and what lets setup skip the general CSR build for a body that sits in ONE pair with the static world: its contacts are start .. start+cnt-1
 			if (cnt && start + cnt <= capacity) {
@@ -1010,7 +1015,9 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 		const uint32_t base = __shfl(start, 0);                  // lane 0 is always a valid record here
 		{
 			const uint32_t rel = start - base;
-			if (cnt && cnt <= 4) {
+			if (cnt && sph_rec) {
+				src[rel] = base4; sft[rel] = raw_feature[base4]; own[rel] = (uint8_t)lane;          // (one contact, one slot)
+			} else if (cnt && cnt <= 4) {
 				const uint4 fv = *reinterpret_cast<const uint4*>(raw_feature + base4);
 				const uint32_t f[4] = { fv.x, fv.y, fv.z, fv.w };
 #pragma unroll
