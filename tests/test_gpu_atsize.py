@@ -134,6 +134,30 @@ def test_c2_landed_window_properties():
     assert P.bits_equal(a["transforms"], b["transforms"]) and P.bits_equal(a["momentum"], b["momentum"])
 
 
+@pytest.mark.parametrize("config", ["c2", "c3"])
+def test_temporal_coherence_paths_are_bit_identical_at_size(config, monkeypatch):
+    """The broadphase's kept pair list, the re-used tag sort and the fused gravity / advance are what the bench runs.  At BASELINE's sizes they must give
+    the very bits of a world that searches the grid, sorts the records and runs the separate kernels every step -- through the fall, the landing (rebuilds,
+    key changes) and the rest (hundreds of steps on one kept list) -- and they must actually have been taken."""
+    scene = S.grid_tiles(124, side=90, seed=2, lattice_cols=11) if config == "c2" else S.grid_tiles(248, side=90, sphere_fraction=0.5, seed=3, lattice_cols=16)
+    nb = len(scene["body_transforms"])
+    a = E.World(scene, flags=E.NH_FLAG_FUSED_STEP, max_contacts=6 * nb)
+    monkeypatch.setenv("NH_NO_KEPT_PAIRS", "1"); monkeypatch.setenv("NH_NO_SORT_REUSE", "1")
+    b = E.World(scene, flags=0, max_contacts=6 * nb)
+    monkeypatch.delenv("NH_NO_KEPT_PAIRS"); monkeypatch.delenv("NH_NO_SORT_REUSE")
+    for upto in (40, 80, 200):
+        done = a.steps_done
+        a.step(upto - done); b.step(upto - done)
+        x, y = a.get_bodies(), b.get_bodies()
+        assert P.bits_equal(x["transforms"], y["transforms"]) and P.bits_equal(x["momentum"], y["momentum"]) and np.array_equal(x["idle"], y["idle"]), (config, upto)
+    ka, kb = a.get_cache(), b.get_cache()
+    assert ka["count"] == kb["count"] and np.array_equal(ka["tags"], kb["tags"]) and P.bits_equal(ka["data"]["impulse"], kb["data"]["impulse"])
+    ca, cb = a.counts(), b.counts()
+    assert cb["sort_reuses"] == 0 and cb["broadphase_rebuilds"] >= 200
+    assert ca["broadphase_rebuilds"] < 40 and ca["sort_reuses"] > 80, ca
+    a.close(); b.close()
+
+
 # ---- config 4: the ball pit -------------------------------------------------------------------------------------------------------
 def _pit_stats(scene, pos, vel, contact_bodies, penetration, wall_margin=2.0):
     """Invariants of a pit of r = 0.5 spheres: max penetration, kinetic energy per sphere, contact degree of INTERIOR spheres
