@@ -66,11 +66,14 @@ KERNEL_BYTES = {
     "cache_lookup": ("K", 12 + 28 + 16),                   # tag+feature, cache probe (tag, feature, impulse) -> impulse
     "gravity_damping": ("B", 4 + 32 + 32),
     "adjacency_simple": ("B", 4 + 4 + 4 + 1 + 8),          # degree, pair info, first contact -> class, contact list record
-    # fused one-body solver (lookup + rows + warm start + all sweeps + export), per contact: contact 32, pair 8, tag+feature 12,
-    # cache probe 12 + 16, state 16 w, impulse 16 w = 112; per body (4 contacts): class/offsets/adjacency/hint 33, transform 32,
-    # properties 16, momentum 32 r + 32 w = 145 -> 36 per contact
-    # + NH_FLAG_FUSED_STEP (what bench.py runs): the advance's outputs, transform 32 w + idle 1 r + 1 w per body = 8.5 per contact
-    "solve_one_body": ("K", 112 + 36 + 8.5),
+    # fused one-body solver (lookup + rows + warm start + all sweeps + export), priced by what the instantiation bench.py runs MOVES
+    # (k_solve_one_body<4, true, CONTIG, 1> under NH_FLAG_SINGLE_APPLY | NH_FLAG_FUSED_STEP; checked against the ISA and the PMC write side):
+    #   per contact: contact 32 r, tag 8 r, feature 4 r, cache probe (tag 8 + feature 4 + impulse 16) r, impulse 16 w               = 72 r + 16 w
+    #   per body (4 contacts): class 1, contact-list record 8, hint 4 r + 4 w, transform 32 r + 32 w, properties 16, momentum 32 r + 32 w,
+    #                          idle 1 r + 1 w                                                                      = 94 r + 69 w -> 23.5 r + 17.25 w
+    #   NOT moved in this mode: the body pair (the CONTIG instantiation never loads it), the solver state (16 B w, only kept for a further
+    #   apply call), CSR offsets / adjacency (the one-record contact list replaces them)
+    "solve_one_body": ("K", 72 + 16 + 23.5 + 17.25),       # = 128.75; main() adds the 16-byte state when the world keeps states, drops the fused advance's 8.5 when it does not fuse
     "gravity_rest": ("B", 4 + 1),                           # active list + class of every body; momentum only of bodies outside the fused solver
     "advance_rest": ("B", 4 + 1),
     "solve_one_body8": ("K", 112 + 36),
@@ -85,6 +88,12 @@ KERNEL_BYTES = {
     "update_impulses": ("G", 160 + 16 + 16),
     "write_cache": ("K", 12 + 16 + 28),
     "advance": ("B", 4 + 32 + 32 + 1 + 32 + 1),
+    # spatially blocked solver (nh_blocks.h); "S" = one sweep over all general contacts: rows 48 + local pair 4 + state 16 r + 16 w per contact,
+    # and the momentum of every general body once in, once out (64 B) -- main() turns that into bytes per contact for the scene at hand
+    "blk_sweep": ("GI", 48 + 4 + 32), "blk_warm": ("G", 48 + 4 + 32),
+    "blk_bounds": ("B", 1 + 12), "blk_body": ("B", 1 + 12 + 8), "blk_contact": ("G", 4 + 8 + 4 + 2 * 8 + 8), "blk_scatter": ("G", 4 + 4 + 4 + 4),
+    "blk_prepare": ("G", 2 * (4 + 8 + 2 * 4) + 4), "blk_gather": ("B", 8 + 64), "blk_scatter_back": ("B", 8 + 64), "blk_residual_pairs": ("G", 0),
+    "colour_seed": ("G", 4 + 16 + 8), "colour_validate": ("G", 2 * 8), "blk_reset": ("T", 0), "blk_grid": ("T", 0), "zero_u32": ("T", 0),
 }
 
 
@@ -99,7 +108,7 @@ def grid_table_entries(C):
 # timer name (nh_* launch sites) -> kernel symbol prefix in the rocprofv3 PMC export (profiles/export_pmc.py)
 PMC_KERNEL = {"solve_one_body": "k_solve_one_body<4, true, true>", "apply_static": "k_apply_static<4, true>", "narrowphase": "k_narrowphase",
               "gather_contacts": "k_gather_contacts", "find_pairs": "k_find_pairs", "radix_pass": "os_pass<unsigned long, unsigned int, true>",
-              "apply_level": "k_level_exec<false>", "write_cache": "k_write_cache", "xform_aabb": "k_xform"}
+              "apply_level": "k_level_exec<false>", "write_cache": "k_write_cache", "xform_aabb": "k_xform", "blk_sweep": "k_blk_sweep<false, true>"}
 
 
 def _pmc_file():
@@ -119,7 +128,8 @@ def pmc_traffic(kernel):
         k = ks.get(sym) or next((v for name, v in ks.items() if name.startswith(sym.rstrip(">"))), None)      # (template arguments may have grown)
     except Exception:
         return None, None
-    return (k["hbm_bytes_corrected"], os.path.basename(f)) if k else (None, None)
+    # corrected = 2 x FETCH + WRITE (an upper bound: gathers are not half-counted), raw = FETCH + WRITE (a lower bound); both are reported
+    return ((k["hbm_bytes_corrected"], k.get("hbm_bytes_raw")), os.path.basename(f)) if k else (None, None)
 
 
 def pmc_step_total():
@@ -178,7 +188,8 @@ def main():
     ap.add_argument("--tiles", type=int, default=None, help="tiles per GPU (default 124 = config 2 at one GPU, 248 = config 5's share otherwise)")
     ap.add_argument("--side", type=int, default=None)
     ap.add_argument("--scene", default="boxes", choices=["boxes", "mixed", "pit"])
-    ap.add_argument("--min-time", type=float, default=0.5, help="seconds to time at N = 1 (the K-step block is repeated from a checkpoint)")
+    ap.add_argument("--min-time", type=float, default=3.0, help="seconds to time at N = 1 (the K-step block is repeated from a checkpoint)")
+    ap.add_argument("--no-full-window", action="store_true", help="skip the steps [0, 1000) figure of SURVEY 8(d) (drop scenes, N = 1)")
     ap.add_argument("--land-cap", type=int, default=None, help="give up if the scene has not landed after this many steps")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--profile-kernels", action="store_true", help="also print the per-kernel time table (stderr)")
@@ -272,6 +283,8 @@ def main():
         t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item() > 0.5)
+
+    snap0 = w.snapshot() if (cluster is None and world == 1 and args.scene != "pit" and not args.no_full_window) else None      # step 0, for the [0, 1000) figure
 
     # ---- untimed: step until the scene has LANDED and is still awake (the configuration the metric is quoted on) ----
     if args.scene == "pit":
@@ -384,6 +397,14 @@ def main():
             # sphere contacts in default order use the 48-byte radial rows: 112 bytes less per contact than the 160-byte general row
             for name in ("rows_general", "warm_level", "apply_level", "update_impulses"):
                 KERNEL_BYTES[name] = (KERNEL_BYTES[name][0], KERNEL_BYTES[name][1] - 112)
+            # blocked sweeps: + the momentum of every (general) body once in and once out per sweep
+            for name in ("blk_sweep", "blk_warm"):
+                KERNEL_BYTES[name] = (KERNEL_BYTES[name][0], KERNEL_BYTES[name][1] + 64.0 * nb / max(G, 1.0))
+        # the one-body solver as this world runs it (see KERNEL_BYTES): + 16 B of solver state per contact when a further apply call may follow,
+        # - the fused advance's transform / idle traffic when gravity and advance are separate kernels
+        fused = bool(w.flags & E.NH_FLAG_FUSED_STEP)
+        single = fused or bool(w.flags & E.NH_FLAG_SINGLE_APPLY)
+        KERNEL_BYTES["solve_one_body"] = ("K", KERNEL_BYTES["solve_one_body"][1] + (0.0 if single else 16.0) - (0.0 if fused else 8.5))
         # whole step: sum of the per-kernel algorithmic bytes over the kernels the instrumented pass saw, against the peak
         # (a kernel launched once per colour class / level moves its share of the items per launch: priced per step, not per launch)
         alg, unpriced = 0.0, []
@@ -392,7 +413,7 @@ def main():
             if kb is None:
                 unpriced.append(name)
                 continue
-            alg += kb[1] * units[kb[0]] * (I if name == "apply_level" else 1)
+            alg += kb[1] * units[kb[0]] * (I if name == "apply_level" else 1)      # ("GI" units already carry the iterations)
         pmc_sum, pmc_src = pmc_step_total() if args.scene == "boxes" and args.tiles == 124 and world == 1 else (None, None)
         out["step_traffic"] = {"bound": "hbm", "algorithmic_bytes_per_step": alg, "achieved": alg / sec_per_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": alg / sec_per_step / 1e9 / HBM_PEAK_GBS, "unpriced_kernels": sorted(unpriced),
@@ -404,10 +425,16 @@ def main():
             n_items = units[unit_k]
             if dominant in ("apply_level", "warm_level"):
                 n_items = n_items * (I if dominant == "apply_level" else 1) / max(1.0, launches_per_step)      # one colour class per launch
+            elif dominant in ("blk_sweep", "blk_warm"):
+                n_items = n_items / max(1.0, launches_per_step)                                                  # one block colour of one sweep per launch
             bytes_per_launch = per * n_items
-            traffic, traffic_src = pmc_traffic(dominant) if args.scene == "boxes" and args.tiles == 124 and world == 1 else (None, None)
+            tr, traffic_src = pmc_traffic(dominant) if args.scene == "boxes" and args.tiles == 124 and world == 1 else (None, None)
+            traffic, traffic_raw = tr if tr else (None, None)
             out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": bytes_per_launch / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": bytes_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                               "unit": "GB/s", "frac": bytes_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw,
+                               "traffic_note": "PMC bytes per launch: traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 half-counts wide reads: an upper bound where the kernel gathers), "
+                                               "traffic_raw = FETCH_SIZE + WRITE_SIZE (lower bound)" if traffic else None,
+                               "traffic_source": traffic_src,
                                "avg_launch_ms": ms, "launches_per_step": launches_per_step,
                                "algorithmic_bytes_per_launch": bytes_per_launch, "share_of_step": dom[0] / (1e3 * dt)}
         elif dom:
@@ -420,6 +447,27 @@ def main():
                 cb = {"error": repr(e)}
             if cb:
                 out["cpu_baseline"] = cb
+        if snap0 is not None:
+            # SURVEY 8(d)'s whole-run figure: steps [0, 1000) from the initial state -- fall, landing, rest, falling asleep -- timed as one block with no host
+            # synchronisation inside; then the same 1000 steps once more, untimed, with the counters read every 10 steps for sum K_s, sum P_s
+            w.restore(snap0); barrier()
+            t0 = time.perf_counter(); advance_world(1000); barrier(); t_full = time.perf_counter() - t0
+            w.restore(snap0)
+            sum_k, sum_p, asleep_at, prev = 0.0, 0.0, None, None
+            for s0 in range(0, 1000, 10):
+                advance_world(10)
+                cc = w.counts()
+                cur = (cc["contacts"], cc["pairs"])
+                if prev is not None:
+                    sum_k += 5.0 * (prev[0] + cur[0]); sum_p += 5.0 * (prev[1] + cur[1])
+                else:
+                    sum_k += 5.0 * cur[0]; sum_p += 5.0 * cur[1]
+                prev = cur
+                if asleep_at is None and s0 > landed_at and cc["active_bodies"] < nb:
+                    asleep_at = s0 + 10
+            out["full_window"] = {"steps": "[0, 1000)", "steps_per_s": 1000.0 / t_full, "seconds": t_full, "sum_contacts": sum_k, "sum_pairs": sum_p,
+                                  "contacts_solved_per_sec": sum_k * I / t_full, "first_sleepers_by_step": asleep_at,
+                                  "note": "whole run from the initial state (free fall, landing, rest, sleep); sums by the trapezoid rule over counters read every 10 steps of an untimed replay"}
         if ktimes:
             # per-kernel milliseconds per step from the three fully instrumented landed steps (events around EVERY launch: the sum exceeds
             # ms_per_step, small kernels are inflated; the timed region only instruments the dominant kernel)

@@ -1126,6 +1126,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	// can anybody be asleep?  (counters rise by at most one per nh_advance since the nh_collide that measured them)
 	const bool no_islands = ctx->idle_bound >= 0 && (uint64_t)ctx->idle_bound + (ctx->advance_count - ctx->idle_bound_mark) < 0xffu;
 	ctx->islands_skipped = no_islands;
+	ctx->idle_unknown = false;                   // this call looks at the counters as they are now (k_collide_begin): its maximum may be adopted again
 	nh_DevState* st = ctx->d_state;
 	const uint32_t nbox = colliders->boxes.count, nsph = colliders->spheres.count;
 	const uint32_t C = nbox + nsph;

@@ -1,6 +1,7 @@
 // nh_context.hip -- context lifecycle, device counters -> host, per-kernel timing, error strings.
 #include "nh_internal.h"
 #include <stdlib.h>
+#include <string.h>
 
 extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t flags) {
 	if (!out) return NH_ERR_INVALID;
@@ -30,7 +31,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->step_parity = 0;
 	ctx->pair_capacity = 0;
 	ctx->collide_seq = 0; ctx->setup_seq = 0;
-	ctx->idle_bound = -1; ctx->advance_count = 0; ctx->collide_mark = 0; ctx->idle_bound_mark = 0; ctx->islands_skipped = false;
+	ctx->idle_bound = -1; ctx->idle_unknown = true; ctx->advance_count = 0; ctx->collide_mark = 0; ctx->idle_bound_mark = 0; ctx->islands_skipped = false;
 	// NH_SORT_CLASSIC=1: three-kernel radix passes; NH_SORT_RADIX=1: radix passes every step (no seeded bucket sort);
 	// NH_COLOUR_JP=1: Jones-Plassmann colouring rounds.  Read here once, never on the step path.
 	ctx->env_sort_classic = getenv("NH_SORT_CLASSIC") != nullptr;
@@ -46,6 +47,16 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->env_colour_check_seeds = getenv("NH_COLOUR_CHECK_SEEDS") != nullptr;      // colours seeded from the cache go through a settle round instead of being final at once (A/B, tests)
 	ctx->env_no_resident = getenv("NH_NO_RESIDENT") != nullptr;      // NH_NO_RESIDENT=1: small general sets also take the one-launch-per-level path (A/B, tests)
 	ctx->os_resident = 0;
+	// spatially blocked solver (nh_blocks.h).  NH_NO_BLOCKS=1: large general sets take the per-colour global launches (A/B, tests); NH_BLK_MIN: general
+	// contacts from which the blocked form is used; NH_BLK_TARGET: bodies per average block (tests use small values to get many blocks out of a
+	// small world); NH_BLK_CHECK=1: verify the block tables on the device every step
+	memset(&ctx->blk, 0, sizeof(ctx->blk));
+	ctx->blk.scale = 1.0f;
+	ctx->blk.disabled = getenv("NH_NO_BLOCKS") != nullptr;
+	ctx->blk.check = getenv("NH_BLK_CHECK") != nullptr;
+	ctx->blk.min_contacts = getenv("NH_BLK_MIN") ? (uint32_t)atoi(getenv("NH_BLK_MIN")) : 200000u;
+	ctx->blk.target = getenv("NH_BLK_TARGET") ? (uint32_t)atoi(getenv("NH_BLK_TARGET")) : 900u;
+	if (ctx->blk.target < 8u) ctx->blk.target = 8u;
 	ctx->d_state = nullptr;
 	ctx->h_state = nullptr;
 	if (hipMalloc((void**)&ctx->d_state, sizeof(nh_DevState)) != hipSuccess) { delete ctx; return NH_ERR_HIP; }
@@ -84,6 +95,11 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	if (ctx->sort_splitters) hipFree(ctx->sort_splitters);
 	if (ctx->sort_counts) hipFree(ctx->sort_counts);
 	if (ctx->sort_starts) hipFree(ctx->sort_starts);
+	{
+		nh_BlkBuffers& k = ctx->blk;
+		void* bufs[] = { k.brank, k.bm, k.pos_body, k.touch, k.lpair, k.ghost_list, k.blk_count, k.own_base, k.bins, k.bin_off, k.ghost_base, k.ghost_count, k.phase_list, k.scan_tmp };
+		for (void* b : bufs) if (b) hipFree(b);
+	}
 	if (ctx->d_state) hipFree(ctx->d_state);
 	if (ctx->h_state) hipHostFree(ctx->h_state);
 	delete ctx;
@@ -97,7 +113,7 @@ extern "C" int nh_set_flags(nh_context* ctx, uint32_t flags) {
 }
 extern "C" int nh_set_tag_bits(nh_context* ctx, uint32_t bits) { if (!ctx || bits < 1 || bits > 32) return NH_ERR_INVALID; ctx->tag_bits = bits; return NH_OK; }
 
-extern "C" int nh_bodies_changed(nh_context* ctx) { if (!ctx) return NH_ERR_INVALID; ctx->idle_bound = -1; return NH_OK; }
+extern "C" int nh_bodies_changed(nh_context* ctx) { if (!ctx) return NH_ERR_INVALID; ctx->idle_bound = -1; ctx->idle_unknown = true; return NH_OK; }
 
 extern "C" int nh_set_pair_capacity(nh_context* ctx, uint32_t pairs) { if (!ctx) return NH_ERR_INVALID; ctx->pair_capacity = pairs; return NH_OK; }
 
@@ -116,7 +132,8 @@ extern "C" int nh_read_counts(nh_context* ctx, nh_Counts* out) {
 	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, 27 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 	const nh_DevState* h = ctx->h_state;
-	if (ctx->collide_seq) { ctx->idle_bound = (int)h->max_idle[ctx->step_parity]; ctx->idle_bound_mark = ctx->collide_mark; }      // what the last nh_collide saw
+	// what the last nh_collide saw -- unless the counters have been rewritten since (nh_bodies_changed, nh_halo_unpack): then it describes another state
+	if (ctx->collide_seq && !ctx->idle_unknown) { ctx->idle_bound = (int)h->max_idle[ctx->step_parity]; ctx->idle_bound_mark = ctx->collide_mark; }
 	out->colliders = h->colliders; out->pairs = h->pairs + h->pairs_sph; out->contacts = h->contacts; out->sleeping_pairs = h->sleeping;
 	out->active_bodies = h->active; out->cache = h->cache; out->culled = h->culled; out->large_colliders = h->large;
 	out->general_contacts = h->general_contacts; out->levels = h->levels; out->error = h->error;

@@ -19,6 +19,26 @@
 #define NH_SORT_GRID 512                // blocks per radix-sort pass (each owns a contiguous chunk)
 #define NH_MAX_LEVELS 4096
 
+// ---- spatially blocked solver (nh_blocks.h): the block grid of this step, on the device ------------------
+#define NH_BLK_ID_BITS 15u
+#define NH_BLK_MAX_BLOCKS (1u << NH_BLK_ID_BITS)
+#define NH_BLK_MAX_COLOURS 32u
+#define NH_BLK_RADIAL 0x8000u            // in a contact's local index pair: it has a radial row (set by k_rows_general)
+struct nh_BlkGrid {
+	uint32_t bmin[3], bmax[3];        // bounds of the general bodies' centres (order-preserving uint encoding, atomicMin / Max)
+	uint32_t bodies;                  // general bodies
+	float origin[3];
+	float edge, inv_edge;             // block edge length
+	uint32_t bits[3];                 // block id = cx | cy << bits[0] | cz << (bits[0] + bits[1])
+	uint32_t nblk;                    // 1 << (bits[0] + bits[1] + bits[2]); 0 = no grid (no general body, non-finite bounds)
+	uint32_t overflow;                // some block's bodies + ghosts do not fit one workgroup's LDS (or its rank field): smaller blocks needed
+	uint32_t max_load;                // largest 1 + own + ghost count of a block
+	uint32_t ghost_cursor;            // entries of the ghost list handed out
+	uint32_t phase_count[8];          // blocks with work, by block colour (parity of the three block coordinates)
+	uint32_t check_errors;            // NH_BLK_CHECK=1: structural errors found by k_blk_check
+	uint32_t near_contacts, far_contacts;   // contacts between two blocks: solved inside a block / left to the residual launches
+};
+
 // ---- device-resident step state (one per context) ---------------------------------------------------
 struct nh_DevState {
 	// counters (zeroed at the start of nh_collide, except `cache`)
@@ -83,12 +103,34 @@ struct nh_DevState {
 	uint32_t colour_cursor;       // append cursor of the colouring's list compaction (nh_solve.hip)
 	uint32_t stale_hint;          // a body was asleep in a step for which the host had ruled that out (k_collide_begin -> k_active_write -> NH_ERR_STALE_HINT)
 	uint32_t order_conflict;      // exact-order mode: sequence number of the setup call whose closed-form schedule has a lane conflict (nh_solve.hip)
+	nh_BlkGrid blk;               // spatially blocked solver (nh_blocks.h)
 };
 
 struct nh_TimerSlot { const char* name; hipEvent_t a, b; };
 
 // what the fused one-body solver does besides solving (NH_FLAG_FUSED_STEP): bits 1 = gravity / damping on load, 2 = advance on store
 struct nh_FusedStep { float gx_dt, gy_dt, gz_dt, damping, time_step; uint32_t bits; uint8_t* idle; };
+
+// library-owned buffers of the spatially blocked solver (nh_blocks.h), grown on demand
+struct nh_BlkBuffers {
+	uint2* brank;                     // per body: block << 12 | rank in the block, position inside the block (3 x 10 bits); NH_NONE = not a general body
+	float4* bm;                       // momentum of the general bodies in block order (slot 0: the static world), 2 x float4 per body
+	uint32_t* pos_body;               // NH_BLK_CHECK=1 only: body index by block-order slot
+	uint32_t* touch;                  //   and who touched a slot in the phase being checked
+	uint32_t body_capacity;
+	uint32_t* lpair;                  // per contact position: local indices la | lb << 16 (| NH_BLK_RADIAL) into the owning block's LDS
+	uint32_t* ghost_list;             // per block: block-order slots of the neighbour bodies it borrows
+	uint32_t contact_capacity;
+	uint32_t* blk_count; uint32_t* own_base;              // NH_BLK_MAX_BLOCKS + 1 each (+ padding)
+	uint32_t* bins; uint32_t* bin_off;                    // (NH_BLK_MAX_BLOCKS + 1) x NH_BLK_MAX_COLOURS + 1: contacts by (owning block, colour); the last "block" = residual
+	uint32_t* ghost_base; uint32_t* ghost_count;          // per block
+	uint32_t* phase_list;                                 // 8 x NH_BLK_MAX_BLOCKS: blocks with work, by block colour
+	uint32_t* scan_tmp;
+	bool tables;
+	float scale;                      // block edge relative to the edge at which an average block holds `target` bodies: adapted from the largest load seen
+	uint32_t target, min_contacts;    // NH_BLK_TARGET, NH_BLK_MIN
+	bool disabled, check;             // NH_NO_BLOCKS=1, NH_BLK_CHECK=1
+};
 
 struct nh_context {
 	int device;
@@ -137,6 +179,8 @@ struct nh_context {
 	// largest counter an earlier nh_collide saw (mirrored with the step's one round trip) the host knows how soon anybody CAN be asleep:
 	// until then the island / sleeping kernels are not launched at all.  idle_bound < 0: unknown (start, nh_bodies_changed, halo unpack).
 	int idle_bound;                       // largest idle counter at the nh_collide that `idle_bound_mark` belongs to
+	bool idle_unknown;                    // idle counters were rewritten from outside (nh_bodies_changed, nh_halo_unpack) since the last nh_collide looked at them:
+	                                      // what that nh_collide measured says nothing about them (nh_read_counts must not adopt it); cleared by nh_collide
 	uint64_t advance_count, collide_mark, idle_bound_mark;     // nh_advance calls so far; their number at the last nh_collide / at the measuring one
 	bool islands_skipped;                 // the last nh_collide launched no island kernels (its prediction is checked on the device: NH_ERR_STALE_HINT)
 	// behaviour switches read ONCE from the environment by nh_create (test / A-B knobs, see nh_context.hip)
@@ -164,6 +208,7 @@ struct nh_context {
 	bool after_collide;
 	struct { bool pending, rest_pending; float gx_dt, gy_dt, gz_dt, damping, time_step; const uint32_t* active; nh_BodyMomentum* momentum; uint32_t body_count; } grav;
 	struct { bool done, rest; float time_step; const uint8_t* body_class; } adv;      // `rest`: some active body is not the fused solver's (the step's round trip told)
+	nh_BlkBuffers blk;
 };
 
 // Runs work that an earlier call deferred; every entry point that reads or writes momentum / impulses calls it first.
@@ -228,6 +273,13 @@ struct nh_ContactConstraintData {
 		nh_ContactData contacts;
 		uint32_t *cursor, *pred_a, *pred_b, *level, *slot_key, *level_hist, *level_cursor, *tmp, *tent;
 	} cont;
+	// spatially blocked solver (nh_blocks.h): the general contacts are laid out by (owning block, colour) and swept block by block in LDS
+	struct {
+		bool active, warm_pending, radial_only;
+		uint32_t L;                                   // colours
+		uint32_t phase_count[8];
+		uint32_t res_off[NH_BLK_MAX_COLOURS + 2];     // residual contacts (no block can own them) by colour: positions in the level-order arrays
+	} blk;
 };
 
 // ---- arena (host-side bump allocation over device memory, reference nudge.cpp:990-1055) ---------------

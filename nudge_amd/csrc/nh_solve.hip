@@ -1171,10 +1171,49 @@ __global__ __launch_bounds__(256) void k_colour_seed_final(nh_DevState* __restri
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
 		const uint32_t c = list[k];
 		const uint32_t old = __float_as_uint(warm[c].unused);
-		if (old >= 1u && old <= NH_MAX_LEVELS) { level[c] = old; lmax = max(lmax, old); }
+		if (old >= 1u && old <= NH_MAX_LEVELS) { level[c] = old; tent[c] = old; lmax = max(lmax, old); }      // (tent: the seed as k_colour_validate reads it)
 		else { tent[c] = 0u; ++left; }
 	}
 	block_report(st, left, lmax, 0u);
+}
+
+// The argument above holds for a cache this library wrote for this world.  The cache is caller-owned memory: one written by the reference library,
+// one with an uninitialised `unused`, a collider re-pointed to another body between two steps, or two contacts that matched the same cache entry
+// would hand two contacts of one body the same colour -- and the sweeps would then update that body's momentum concurrently.  So the seeds get ONE
+// cheap look: one lane per general body walks the body's contact list (2 G reads against the ~11 G of a settle round) for a colour held twice; of two
+// seeded contacts of a body with the same seed the one with the lower hashed priority becomes uncoloured again (decided on the immutable seeds in
+// `tent`, so the outcome does not depend on timing) and is coloured by the try / settle rounds like a new contact.
+__global__ __launch_bounds__(256) void k_colour_validate(nh_DevState* __restrict__ st, uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off,
+                                                         const uint32_t* __restrict__ adj, uint32_t* level, const uint32_t* __restrict__ tent) {
+	uint32_t demoted = 0;
+	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < nbodies; x += gridDim.x * blockDim.x) {
+		if (x == 0u || body_class[x] != NH_CLS_GENERAL) continue;
+		const uint32_t b = off[x], e = off[x + 1];
+		unsigned long long seen = 0ull;
+		bool clash = false;
+		for (uint32_t q = b; q < e; ++q) {
+			const uint32_t sc = tent[adj[q]];
+			if (!sc) continue;
+			if (sc > 64u) { clash = true; continue; }             // (more than 64 colours around one body: take the slow look)
+			const unsigned long long bit = 1ull << (sc - 1u);
+			clash |= (seen & bit) != 0ull;
+			seen |= bit;
+		}
+		if (!clash) continue;
+		for (uint32_t q = b; q < e; ++q) {
+			const uint32_t c = adj[q], sc = tent[c];
+			if (!sc) continue;
+			const uint32_t pc = colour_priority(c);
+			for (uint32_t r = b; r < e; ++r) {
+				const uint32_t m = adj[r];
+				if (m == c || tent[m] != sc) continue;
+				const uint32_t pm = colour_priority(m);
+				if (pm > pc || (pm == pc && m > c)) { if (atomicExch(&level[c], NH_UNSET) != NH_UNSET) ++demoted; break; }
+			}
+		}
+	}
+	for (int d = 32; d >= 1; d >>= 1) demoted += (uint32_t)__shfl_xor((int)demoted, d);
+	if (nh_lane() == 0u && demoted) atomicAdd(&st->unleveled, demoted);      // round 0's progress counter (block_report)
 }
 
 // the smallest colour none of c's FINISHED neighbours holds
@@ -1265,8 +1304,28 @@ __global__ __launch_bounds__(1024) void k_colour_small(nh_DevState* __restrict__
 	for (uint32_t k = tid; k < n; k += T) {
 		const uint32_t c = list[k];
 		const uint32_t old = __float_as_uint(warm[c].unused);
-		if (old >= 1u && old <= NH_MAX_LEVELS) { level[c] = old; lmax = max(lmax, old); }
+		if (old >= 1u && old <= NH_MAX_LEVELS) { level[c] = old; tent[c] = old; lmax = max(lmax, old); }
 		else { tent[c] = 0u; ++left; }
+	}
+	__syncthreads();
+	// the seeds come from caller-owned memory: of two seeded neighbours with the same seed the lower priority one is coloured again (k_colour_validate)
+	for (uint32_t k = tid; k < n; k += T) {
+		const uint32_t c = list[k], sc = tent[c];
+		if (!sc) continue;
+		const uint32_t pc = colour_priority(c);
+		const nh_BodyPair p = bodies[c];
+		bool lose = false;
+		for (int side = 0; side < 2 && !lose; ++side) {
+			const uint32_t x = side ? p.b : p.a;
+			if (!x) continue;
+			for (uint32_t q = off[x]; q < off[x + 1]; ++q) {
+				const uint32_t m = adj[q];
+				if (m == c || tent[m] != sc) continue;
+				const uint32_t pm = colour_priority(m);
+				if (pm > pc || (pm == pc && m > c)) { lose = true; break; }
+			}
+		}
+		if (lose) { level[c] = NH_UNSET; ++left; }
 	}
 	if (left) atomicAdd(&s_left, left);
 	__syncthreads();
@@ -1435,7 +1494,10 @@ __global__ __launch_bounds__(256) void k_rows_general(const nh_DevState* __restr
                                                       const nh_Contact* __restrict__ contacts, const nh_BodyPair* __restrict__ bodies,
                                                       const nh_Transform* __restrict__ xf, const nh_BodyProperties* __restrict__ props,
                                                       float4* __restrict__ rows4, size_t stride, uint2* __restrict__ gpair, uint32_t allow_radial, uint32_t static_inert,
-                                                      const uint32_t* __restrict__ level, uint32_t* __restrict__ level_has_full) {
+                                                      const uint32_t* __restrict__ level, uint32_t* __restrict__ level_has_full,
+                                                      const nh_CachedContactImpulse* __restrict__ warm_in, float4* __restrict__ gstates, uint32_t* __restrict__ lpair) {
+	// warm_in (blocked solver, nh_blocks.h): the cached impulse of every contact is copied to where its solver state will be, so that the warm start
+	// streams the same arrays as a sweep; lpair: the contact's local index pair learns whether its row is radial
 	uint32_t n = st->general_contacts;
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
 		uint32_t c = order[k];
@@ -1461,6 +1523,8 @@ __global__ __launch_bounds__(256) void k_rows_general(const nh_DevState* __restr
 			level_has_full[level[c]] = 1u;             // this level / colour class needs the kernel that knows full rows (plain store of a constant)
 		}
 		gpair[k] = make_uint2(p.a | (radial ? NH_RADIAL_BIT : 0u), p.b);
+		if (warm_in) gstates[k] = *reinterpret_cast<const float4*>(warm_in + c);
+		if (lpair && radial) lpair[k] |= NH_BLK_RADIAL;
 	}
 }
 
@@ -1478,7 +1542,7 @@ __global__ __launch_bounds__(256) void k_level_exec(const uint32_t* __restrict__
 		nh_vel a = load_vel_m(momentum, p.x), b = load_vel_m(momentum, p.y);
 		nh_state s;
 		float4 w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-		if (WARM) w = *reinterpret_cast<const float4*>(cached + order[k]);
+		if (WARM) w = cached ? *reinterpret_cast<const float4*>(cached + order[k]) : gstates[k];      // (blocked solver: the cached impulse waits in the state's place)
 		else { const float4 sv = gstates[k]; s.normal = sv.x; s.friction_x = sv.y; s.friction_y = sv.z; }
 		if (radial) {
 			nh_rowr r;
@@ -1686,6 +1750,8 @@ __global__ __launch_bounds__(256) void k_update_impulses(const nh_DevState* __re
 	}
 }
 
+#include "nh_blocks.h"
+
 // =====================================================================================================================================
 static nh_ContactImpulseData* new_impulse_data(nh_context* ctx) {
 	if (ctx->impulse_ring.empty()) { ctx->impulse_ring.resize(64, nullptr); ctx->constraint_ring.resize(64, nullptr); }
@@ -1878,6 +1944,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	d->contact_capacity = kcap; d->body_count = B; d->bodies = contacts->bodies;
 	d->contact_data = contacts->data; d->impulses = imp->data; d->general_list = general_list;
 	d->levels = 0; d->general_contacts = 0;
+	d->blk.active = false; d->blk.warm_pending = false;
 
 	// (degrees were counted by nh_collide while it laid the contacts out; their scan into CSR offsets waits until somebody needs it: ensure_csr)
 	d->csr_ready = false;
@@ -1921,6 +1988,152 @@ static void ensure_csr(nh_context* ctx, nh_ContactConstraintData* d) {
 	const uint32_t B = d->body_count;
 	nh_scan_u32(ctx, ctx->deg, d->body_off, &ctx->d_state->pad0, B + 1, d->cont.tmp, nullptr);
 	NH_LAUNCH(ctx, "adjacency_from_simple", k_adj_from_simple, nh_grid_for(B, 256, 4096), 256, B, d->body_class, d->body_off, d->simple, d->adj);
+}
+
+// ---- spatially blocked solver (nh_blocks.h): host side ---------------------------------------------------------------------------------------------
+static int blk_reserve(nh_context* ctx, uint32_t B, uint32_t kcap) {
+	nh_BlkBuffers& k = ctx->blk;
+	if (!k.tables) {
+		const size_t nb = NH_BLK_MAX_BLOCKS + 8u, nbins = (size_t)(NH_BLK_MAX_BLOCKS + 1u) * NH_BLK_MAX_COLOURS + 8u;
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.blk_count, sizeof(uint32_t) * nb));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.own_base, sizeof(uint32_t) * nb));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.bins, sizeof(uint32_t) * nbins));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.bin_off, sizeof(uint32_t) * nbins));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.ghost_base, sizeof(uint32_t) * nb));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.ghost_count, sizeof(uint32_t) * nb));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.phase_list, sizeof(uint32_t) * 8u * NH_BLK_MAX_BLOCKS));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.scan_tmp, sizeof(uint32_t) * (2u * NH_SORT_GRID + 64u)));
+		k.tables = true;
+	}
+	if (k.body_capacity < B + 1u) {
+		if (k.brank) hipFree(k.brank);
+		if (k.bm) hipFree(k.bm);
+		if (k.pos_body) hipFree(k.pos_body);
+		if (k.touch) hipFree(k.touch);
+		k.brank = nullptr; k.bm = nullptr; k.pos_body = nullptr; k.touch = nullptr; k.body_capacity = 0;
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.brank, sizeof(uint2) * (size_t)(B + 1u)));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.bm, sizeof(float4) * 2u * (size_t)(B + 1u)));
+		if (k.check) {
+			NH_HIP_CHECK(ctx, hipMalloc((void**)&k.pos_body, sizeof(uint32_t) * (size_t)(B + 1u)));
+			NH_HIP_CHECK(ctx, hipMalloc((void**)&k.touch, sizeof(uint32_t) * 2u * (size_t)(B + 1u)));
+		}
+		k.body_capacity = B + 1u;
+	}
+	if (k.contact_capacity < kcap) {
+		if (k.lpair) hipFree(k.lpair);
+		if (k.ghost_list) hipFree(k.ghost_list);
+		k.lpair = nullptr; k.ghost_list = nullptr; k.contact_capacity = 0;
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.lpair, sizeof(uint32_t) * (size_t)kcap));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.ghost_list, sizeof(uint32_t) * (size_t)kcap));
+		k.contact_capacity = kcap;
+	}
+	return NH_OK;
+}
+
+// Lays the general contacts out by (owning block, colour) and builds the per-block tables.  Leaves d->blk.active false when the blocked form does not
+// apply (the caller then takes the per-colour global launches): too few contacts, too many colours, a block that cannot be made to fit.
+static int blk_setup(nh_context* ctx, nh_ContactConstraintData* d, uint32_t G) {
+	nh_BlkBuffers& k = ctx->blk;
+	nh_DevState* st = ctx->d_state;
+	d->blk.active = false;
+	const uint32_t B = d->body_count, kcap = d->contact_capacity, L = d->levels;
+	if (k.disabled || (ctx->flags & NH_FLAG_EXACT_ORDER) || G < k.min_contacts || L < 1u || L > NH_BLK_MAX_COLOURS || !d->static_inert) return NH_OK;
+	{ int rc = blk_reserve(ctx, B, kcap); if (rc) return rc; }
+	const nh_ContactData* contacts = &d->cont.contacts;
+	const nh_BodyData* bodies = &d->bodies_at_setup;
+	uint32_t* rank = d->cont.pred_a; uint32_t* bin = d->cont.pred_b;          // (exact-order scratch: free in the default order once the colouring is done)
+	const size_t nbins = (size_t)(NH_BLK_MAX_BLOCKS + 1u) * L + 1u;
+	nh_BlkGrid* h = &ctx->h_state->blk;
+	bool ok = false;
+	for (int attempt = 0; attempt < 6 && !ok; ++attempt) {
+		NH_HIP_CHECK(ctx, hipMemsetAsync(k.blk_count, 0, sizeof(uint32_t) * (NH_BLK_MAX_BLOCKS + 8u), ctx->stream));
+		NH_HIP_CHECK(ctx, hipMemsetAsync(k.bins, 0, sizeof(uint32_t) * (nbins + 7u), ctx->stream));
+		NH_LAUNCH(ctx, "blk_reset", k_blk_reset, 1, 1, st);
+		NH_LAUNCH(ctx, "blk_bounds", k_blk_bounds, nh_grid_for(B, 256, 1024), 256, st, B, d->body_class, bodies->transforms);
+		NH_LAUNCH(ctx, "blk_grid", k_blk_grid, 1, 1, st, k.scale, (float)k.target);
+		NH_LAUNCH(ctx, "blk_body", k_blk_body, nh_grid_for(B, 256, 4096), 256, st, B, d->body_class, bodies->transforms, k.blk_count, k.brank);
+		NH_LAUNCH(ctx, "blk_contact", k_blk_contact, nh_grid_for(G, 256, 8192), 256, st, d->general_list, contacts->bodies, d->cont.level, k.brank, L, k.bins, rank, bin);
+		nh_scan_u32(ctx, k.blk_count, k.own_base, &st->pad0, NH_BLK_MAX_BLOCKS + 1u, k.scan_tmp, nullptr);
+		nh_scan_u32(ctx, k.bins, k.bin_off, &st->pad0, (uint32_t)nbins, k.scan_tmp, nullptr);
+		NH_LAUNCH(ctx, "blk_scatter", k_blk_scatter, nh_grid_for(G, 256, 8192), 256, st, d->general_list, rank, bin, k.bin_off, d->level_order);
+		NH_LAUNCH(ctx, "blk_prepare", k_blk_prepare, NH_BLK_MAX_BLOCKS, 256, st, L, k.bin_off, k.blk_count, k.own_base, d->level_order, contacts->bodies, k.brank, k.lpair,
+		          k.ghost_base, k.ghost_count, k.ghost_list, k.phase_list);
+		NH_HIP_CHECK(ctx, hipMemcpyAsync(h, &st->blk, sizeof(nh_BlkGrid), hipMemcpyDeviceToHost, ctx->stream));
+		NH_HIP_CHECK(ctx, hipMemcpyAsync(d->blk.res_off, k.bin_off + (size_t)NH_BLK_MAX_BLOCKS * L, sizeof(uint32_t) * (L + 1u), hipMemcpyDeviceToHost, ctx->stream));
+		NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+		if (!h->nblk) return NH_OK;
+		if (h->overflow) { k.scale *= 0.8f; continue; }
+		ok = true;
+		// the edge follows the largest load: room for the pile to shift, no retries
+		const float load = (float)h->max_load / (float)NH_BLK_CAP;
+		if (load > 0.90f) k.scale *= 0.97f; else if (load < 0.60f && k.scale < 4.0f) k.scale *= 1.03f;
+	}
+	if (!ok) return NH_OK;
+	for (int p = 0; p < 8; ++p) d->blk.phase_count[p] = h->phase_count[p];
+	d->blk.L = L;
+	// rows (and the cached impulses, in the solver states' place) in block order; which colours hold a full row
+	uint32_t* level_hist = d->cont.level_hist;
+	NH_LAUNCH(ctx, "zero_u32", k_zero_u32, 8, 256, level_hist, 2 * (NH_MAX_LEVELS + 2));
+	NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, d->level_order, contacts->data, contacts->bodies, bodies->transforms, bodies->properties,
+	          (float4*)d->rows, (size_t)kcap, d->gpair, 1u, 1u, d->cont.level, level_hist + (NH_MAX_LEVELS + 2), (const nh_CachedContactImpulse*)d->imp->data, d->gstates, k.lpair);
+	if (d->blk.res_off[L] > d->blk.res_off[0])
+		NH_LAUNCH(ctx, "blk_residual_pairs", k_blk_residual_pairs, nh_grid_for(d->blk.res_off[L] - d->blk.res_off[0], 256, 4096), 256, d->blk.res_off[0], d->blk.res_off[L], k.brank, k.own_base, d->gpair);
+	NH_HIP_CHECK(ctx, hipMemcpyAsync(d->level_full, level_hist + (NH_MAX_LEVELS + 2), sizeof(uint32_t) * (L + 2u), hipMemcpyDeviceToHost, ctx->stream));
+	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+	d->blk.radial_only = true;
+	for (uint32_t l = 1; l <= L; ++l) d->blk.radial_only &= d->level_full[l] == 0u;
+	if (k.check) {
+		// NH_BLK_CHECK=1 (tests): the structure the sweeps rely on, launch by launch
+		NH_LAUNCH(ctx, "blk_gather", k_blk_gather, nh_grid_for(B, 256, 4096), 256, B, k.brank, k.own_base, (const float4*)bodies->momentum, k.bm, k.pos_body);
+		for (int p = 0; p < 8; ++p) {
+			if (!d->blk.phase_count[p]) continue;
+			NH_HIP_CHECK(ctx, hipMemsetAsync(k.touch, 0, sizeof(uint32_t) * 2u * (size_t)(B + 1u), ctx->stream));
+			NH_LAUNCH(ctx, "blk_check", k_blk_check, d->blk.phase_count[p], 256, st, k.phase_list + (size_t)p * NH_BLK_MAX_BLOCKS, L, k.bin_off, k.blk_count, k.own_base, k.ghost_base,
+			          k.ghost_count, k.ghost_list, k.lpair, d->level_order, contacts->bodies, d->cont.level, k.pos_body, k.touch, k.touch + (B + 1u));
+		}
+		NH_HIP_CHECK(ctx, hipMemcpyAsync(h, &st->blk, sizeof(nh_BlkGrid), hipMemcpyDeviceToHost, ctx->stream));
+		NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+		if (h->check_errors) { fprintf(stderr, "nudge_hip: blocked solver structure check failed (%u errors)\n", h->check_errors); return NH_ERR_INVALID; }
+	}
+	d->blk.active = true;
+	d->blk.warm_pending = true;
+	return NH_OK;
+}
+
+// warm start (once per setup) and `iterations` sweeps of the blocked form: momentum into block order, per pass eight block-colour launches + the
+// residual colours, momentum back
+static void blk_run(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, bool warm, uint32_t iterations) {
+	nh_BlkBuffers& k = ctx->blk;
+	const uint32_t B = d->body_count, L = d->blk.L;
+	const uint32_t passes = (warm ? 1u : 0u) + iterations;
+	if (!passes) return;
+	const size_t stride = (size_t)d->contact_capacity;
+	NH_LAUNCH(ctx, "blk_gather", k_blk_gather, nh_grid_for(B, 256, 4096), 256, B, k.brank, k.own_base, (const float4*)bodies->momentum, k.bm, (uint32_t*)nullptr);
+	for (uint32_t pass = 0; pass < passes; ++pass) {
+		const bool w = warm && pass == 0u;
+		for (int p = 0; p < 8; ++p) {
+			const uint32_t n = d->blk.phase_count[p];
+			if (!n) continue;
+			const uint32_t* list = k.phase_list + (size_t)p * NH_BLK_MAX_BLOCKS;
+#define NH_BLK_SWEEP(NAME, W, R) NH_LAUNCH(ctx, NAME, (k_blk_sweep<W, R>), n, NH_BLK_THREADS, list, L, k.bin_off, k.blk_count, k.own_base, k.ghost_base, k.ghost_count, k.ghost_list, k.lpair, \
+			          (const float4*)d->rows, stride, d->gstates, k.bm)
+			if (w) { if (d->blk.radial_only) NH_BLK_SWEEP("blk_warm", true, true); else NH_BLK_SWEEP("blk_warm", true, false); }
+			else { if (d->blk.radial_only) NH_BLK_SWEEP("blk_sweep", false, true); else NH_BLK_SWEEP("blk_sweep", false, false); }
+#undef NH_BLK_SWEEP
+		}
+		for (uint32_t l = 0; l < L; ++l) {
+			const uint32_t b = d->blk.res_off[l], e = d->blk.res_off[l + 1];
+			if (e <= b) continue;
+			nh_BodyMomentum* bm = reinterpret_cast<nh_BodyMomentum*>(k.bm);
+			const bool full = d->level_full[l + 1u] != 0u;
+#define NH_BLK_RES(NAME, W, R) NH_LAUNCH(ctx, NAME, (k_level_exec<W, R>), nh_grid_for(e - b, 256, 8192), 256, d->level_order, b, e, d->gpair, (const nh_CachedContactImpulse*)nullptr, bm, \
+			          (const float4*)d->rows, stride, d->gstates)
+			if (w) { if (full) NH_BLK_RES("warm_level", true, false); else NH_BLK_RES("warm_level", true, true); }
+			else { if (full) NH_BLK_RES("apply_level", false, false); else NH_BLK_RES("apply_level", false, true); }
+#undef NH_BLK_RES
+		}
+	}
+	NH_LAUNCH(ctx, "blk_scatter_back", k_blk_scatter_back, nh_grid_for(B, 256, 4096), 256, B, k.brank, k.own_base, (const float4*)k.bm, (float4*)bodies->momentum);
 }
 
 static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
@@ -1976,7 +2189,8 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		    (G <= NH_RES_MAX_FULL || B <= NH_RESB_MAX_BODIES)) {
 			NH_LAUNCH(ctx, "colour_small", k_colour_small, 1, 1024, st, general_list, imp->data, contacts->bodies, d->body_off, d->adj, level, d->cont.tent, level_hist, d->level_order);
 			NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, d->level_order, contacts->data, contacts->bodies, bodies->transforms, bodies->properties,
-			          (float4*)d->rows, (size_t)kcap, d->gpair, 1u, d->static_inert ? 1u : 0u, level, level_hist + (NH_MAX_LEVELS + 2));
+			          (float4*)d->rows, (size_t)kcap, d->gpair, 1u, d->static_inert ? 1u : 0u, level, level_hist + (NH_MAX_LEVELS + 2),
+			          (const nh_CachedContactImpulse*)nullptr, (float4*)nullptr, (uint32_t*)nullptr);
 			d->levels = 0;                                  // on the device (st->levels)
 			d->resident = G <= NH_RES_MAX_FULL; d->resident_cap = NH_RES_MAX_FULL; d->resident_bodies = !d->resident;
 			if (d->resident)
@@ -2008,6 +2222,7 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 				else {
 					if (rounds == 0 && !ctx->env_colour_check_seeds) {
 						NH_LAUNCH(ctx, "colour_seed", k_colour_seed_final, nh_grid_for(G, 256, 2048), 256, st, general_list, imp->data, level, d->cont.tent);
+						NH_LAUNCH(ctx, "colour_validate", k_colour_validate, nh_grid_for(B, 256, 4096), 256, st, B, d->body_class, d->body_off, d->adj, level, d->cont.tent);
 						continue;
 					}
 					if (rounds == 0)
@@ -2030,13 +2245,17 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		}
 		if (c.levels > NH_MAX_LEVELS) return NH_ERR_INVALID;
 		d->levels = c.levels;
+		// a large set in default order: contacts owned by spatial blocks, swept in LDS block by block (nh_blocks.h)
+		rc = blk_setup(ctx, d, G);
+		if (rc) return rc;
+		if (d->blk.active) return NH_OK;
 		NH_LAUNCH(ctx, "zero_u32", k_zero_u32, 8, 256, level_hist, 2 * (NH_MAX_LEVELS + 2));       // histogram + the per-class "has a full row" flags behind it
 		NH_LAUNCH(ctx, "level_hist", k_level_hist, nh_grid_for(G, 256, 512), 256, st, general_list, level, level_hist);
 		NH_LAUNCH(ctx, "level_offsets", k_level_offsets, 1, 1024, level_hist, level_cursor);
 		NH_LAUNCH(ctx, "level_scatter", k_level_scatter, nh_grid_for(G, 256, 512), 256, st, general_list, level, level_cursor, d->level_order);
 		NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, d->level_order, contacts->data, contacts->bodies, bodies->transforms, bodies->properties,
 		          (float4*)d->rows, (size_t)kcap, d->gpair, (ctx->flags & NH_FLAG_EXACT_ORDER) ? 0u : 1u, d->static_inert ? 1u : 0u,
-		          level, level_hist + (NH_MAX_LEVELS + 2));
+		          level, level_hist + (NH_MAX_LEVELS + 2), (const nh_CachedContactImpulse*)nullptr, (float4*)nullptr, (uint32_t*)nullptr);
 		NH_HIP_CHECK(ctx, hipMemcpyAsync(d->level_off, level_hist, sizeof(uint32_t) * (d->levels + 2), hipMemcpyDeviceToHost, ctx->stream));
 		NH_HIP_CHECK(ctx, hipMemcpyAsync(d->level_full, level_hist + (NH_MAX_LEVELS + 2), sizeof(uint32_t) * (d->levels + 2), hipMemcpyDeviceToHost, ctx->stream));
 		NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -2162,6 +2381,7 @@ int nh_flush_pending(nh_context* ctx, bool keep_gravity) {
 			d->setup_pending = false;
 			int rc = first_apply(ctx, d, &d->bodies_at_setup, 0);       // zero sweeps: lookup + rows + warm start only
 			if (rc) return rc;
+			if (d->general_contacts && d->blk.active && d->blk.warm_pending) { d->blk.warm_pending = false; blk_run(ctx, d, &d->bodies_at_setup, true, 0u); }
 		}
 	}
 	// NH_FLAG_FUSED_STEP: gravity waits for the solver only across nh_read_cached_impulses / nh_setup_contact_constraints / nh_apply_impulses
@@ -2178,7 +2398,11 @@ extern "C" int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* d, c
 	ctx->pending = nullptr;
 	if (first) { int rc = first_apply(ctx, d, bodies, iterations, (ctx->flags & NH_FLAG_FUSED_STEP) != 0); if (rc) return rc; }
 	else { int rc = settle_gravity(ctx); if (rc) return rc; launch_apply_static(ctx, d, bodies, iterations, false, false); }
-	if (d->general_contacts && d->resident) {
+	if (d->general_contacts && d->blk.active) {
+		const bool warm = d->blk.warm_pending;
+		d->blk.warm_pending = false;
+		blk_run(ctx, d, bodies, warm, iterations);
+	} else if (d->general_contacts && d->resident) {
 		// small general set: one workgroup, rows in LDS for all sweeps (k_solve_resident)
 		if (iterations)
 			NH_LAUNCH(ctx, "solve_resident", k_solve_resident, 1, NH_RES_THREADS, ctx->d_state, d->cont.level_hist, d->levels, d->level_order, d->gpair, (const nh_CachedContactImpulse*)nullptr,
@@ -2255,7 +2479,7 @@ extern "C" int nh_halo_pack(nh_context* ctx, const nh_BodyData* bodies, const ui
 extern "C" int nh_halo_unpack(nh_context* ctx, const nh_BodyData* bodies, uint32_t first_slot, uint32_t count, const void* in) {
 	if (!ctx || !bodies || (count && !in) || (uint64_t)first_slot + count > bodies->count) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
-	if (count) ctx->idle_bound = -1;             // idle counters arrive from another world: nothing is known about them until the next nh_collide has looked
+	if (count) { ctx->idle_bound = -1; ctx->idle_unknown = true; }             // idle counters arrive from another world: nothing is known about them until the next nh_collide has looked
 	if (count) NH_LAUNCH(ctx, "halo_unpack", k_halo_unpack, nh_grid_for(count, 256, 1024), 256, bodies->transforms, bodies->momentum, bodies->idle_counters, first_slot, count, (const nh_HaloRecord*)in);
 	return NH_OK;
 }

@@ -36,6 +36,9 @@ POS_TOL_TILE_MAX = 2e-4 # ... with the worst body within twice that.  Union vs t
 VEL_TOL_UNION = 3e-4    # union vs tile, absolute, bodies at rest (|v| < 1)
 
 
+BENCH_FLAGS = E.NH_FLAG_SINGLE_APPLY | E.NH_FLAG_FUSED_STEP      # bench.py's World(...) flags at N = 1
+
+
 def _require_reference():
     assert refworld.available("exact"), "oracle/_ref/libnudge_ref_exact.so did not travel to this box: the at-size parity tests need it"
 
@@ -53,7 +56,7 @@ def _tiled_reference(scene, n_tiles, steps):
 
 def _union_vs_tiled_reference(scene, n_tiles, steps, sample_tiles):
     n = len(scene["body_transforms"]) - 1
-    w = E.World(scene, flags=E.NH_FLAG_SINGLE_APPLY, max_contacts=6 * n)            # the bench's mode: one host round trip per step, one apply call per step
+    w = E.World(scene, flags=BENCH_FLAGS, max_contacts=6 * n)            # exactly the flags bench.py runs: one host round trip per step, one apply call, gravity / advance fused
     w.step(steps)
     c = w.counts()
     assert c["error"] == 0
@@ -86,7 +89,7 @@ def _union_vs_tiled_reference(scene, n_tiles, steps, sample_tiles):
     # the two-part bound on sampled tiles: GPU(tile) == reference(tile) bit for bit, GPU(union) vs GPU(tile) within the bar
     for t in sample_tiles:
         sub, body_map = S.extract_tile(scene, t)
-        wt = E.World(sub, flags=E.NH_FLAG_SINGLE_APPLY)
+        wt = E.World(sub, flags=BENCH_FLAGS)
         wt.step(steps)
         tb, rb = wt.get_bodies(), worlds[t].bodies()
         wt.close()
@@ -111,6 +114,33 @@ def test_c3_two_million_mixed_1000_steps_every_tile_vs_reference():
     scene = S.grid_tiles(248, side=90, sphere_fraction=0.5, seed=3, lattice_cols=16)
     assert len(scene["body_transforms"]) - 1 == 2008800
     _union_vs_tiled_reference(scene, 248, 1000, sample_tiles=(0, 100, 247))
+
+
+@pytest.mark.parametrize("spheres", [0.0, 0.5])
+def test_union_the_reference_can_hold_is_bit_exact_in_the_bench_mode(spheres):
+    """Two tiles of 63 x 63 bodies (7938 + two ground slabs: the largest union under the reference's 8192-collider limit, nudge.cpp:3010) stepped as
+    ONE world by both sides for 1000 steps -- fall, landing, rest, sleep.  In a union a contact's batch slot depends on how many contacts precede
+    it in the world (nudge.cpp:4206-4339); that is why union-vs-TILE comparisons carry a 1e-4 bar.  Union against the SAME union has no such
+    excuse: the GPU in the bench's exact flags (default order, one apply call, fused gravity / advance, kept pair list, re-used tag sort) must give
+    the reference's bits, cache and sleeping pairs included."""
+    _require_reference()
+    scene = S.grid_tiles(2, side=63, sphere_fraction=spheres, seed=11, lattice_cols=2)
+    n = len(scene["body_transforms"]) - 1
+    assert n == 7938
+    ref = refworld.RefWorld(scene, max_contacts=6 * n)
+    w = E.World(scene, flags=BENCH_FLAGS, max_contacts=6 * n)
+    for upto in (100, 400, 1000):
+        ref.step(upto - w.steps_done); w.step(upto - w.steps_done)
+        gb, rb = w.get_bodies(), ref.bodies()
+        assert P.bits_equal(gb["transforms"]["position"], rb["transforms"]["position"]) and P.bits_equal(gb["transforms"]["rotation"], rb["transforms"]["rotation"]), upto
+        assert P.bits_equal(gb["momentum"]["velocity"], rb["momentum"]["velocity"]) and P.bits_equal(gb["momentum"]["angular_velocity"], rb["momentum"]["angular_velocity"]), upto
+        assert np.array_equal(gb["idle"], rb["idle"]), upto
+    c = w.counts()
+    assert c["error"] == 0 and c["general_contacts"] == 0
+    assert int((rb["idle"][1:] == 0xff).sum()) > 0.9 * n, "the union was meant to have gone to sleep"
+    kc, rc = w.get_cache(), ref.cache()
+    assert kc["count"] == rc["count"] and P.bits_equal(kc["data"]["impulse"], rc["data"]["impulse"])
+    w.close()
 
 
 def test_c2_landed_window_properties():
