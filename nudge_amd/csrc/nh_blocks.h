@@ -37,6 +37,15 @@
 #define NH_BLK_HASH 4096u                // ghost table of k_blk_prepare (open addressing in LDS)
 #define NH_BLK_NEAR 500                  // of 1024 per block edge: "near" = no coordinate of the two centres differs by more (12 units of slack for the quantisation)
 #define NH_BLK_RESIDUAL NH_BLK_MAX_BLOCKS
+#define NH_BLK_GROUPS 2                  // wavefront groups of a sweep workgroup that take the colour chunks in turn (below)
+#define NH_BLK_CHUNK (NH_BLK_THREADS / NH_BLK_GROUPS)      // contacts of one colour solved in one step
+#define NH_BLK_MAX_CHUNKS 96u            // steps of one block: its colours cut into chunks (a block with more is too big: smaller blocks)
+#define NH_BLK_DESC_WORDS 40u            // per (block colour, workgroup) descriptor: block, own bodies, first slot, ghosts, ghost list base, the L + 1 bin offsets
+
+// 16 bytes from a per-lane global address straight into LDS (lane-linear destination: consecutive lanes must name consecutive 16-byte pieces)
+__device__ __forceinline__ void nh_glds16(const float4* src, float4* lds_dst) {
+	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
 
 __device__ __forceinline__ uint32_t blk_slot(const uint32_t* __restrict__ own_base, uint32_t br) { return 1u + own_base[br >> NH_BLK_RANK_BITS] + (br & NH_BLK_RANK_MASK); }
 
@@ -223,9 +232,9 @@ __global__ __launch_bounds__(256) void k_blk_scatter(const nh_DevState* __restri
 __global__ __launch_bounds__(256) void k_blk_prepare(nh_DevState* __restrict__ st, uint32_t L, const uint32_t* __restrict__ bin_off, const uint32_t* __restrict__ blk_count,
                                                      const uint32_t* __restrict__ own_base, const uint32_t* __restrict__ order, const nh_BodyPair* __restrict__ bodies,
                                                      const uint2* __restrict__ brank, uint32_t* __restrict__ lpair, uint32_t* __restrict__ ghost_base, uint32_t* __restrict__ ghost_count,
-                                                     uint32_t* __restrict__ ghost_list, uint32_t* __restrict__ phase_list) {
+                                                     uint32_t* __restrict__ ghost_list, uint32_t* __restrict__ phase_list, uint32_t* __restrict__ desc) {
 	__shared__ uint32_t s_key[NH_BLK_HASH], s_val[NH_BLK_HASH];
-	__shared__ uint32_t s_n, s_base, s_fail;
+	__shared__ uint32_t s_n, s_base, s_fail, s_slot;
 	const uint32_t b = blockIdx.x, tid = threadIdx.x;
 	if (b >= st->blk.nblk) return;
 	const uint32_t r0 = bin_off[b * L], r1 = bin_off[(b + 1u) * L];
@@ -254,7 +263,9 @@ __global__ __launch_bounds__(256) void k_blk_prepare(nh_DevState* __restrict__ s
 	for (uint32_t t = tid; t < NH_BLK_HASH; t += 256u) if (s_key[t] != NH_NONE) s_val[t] = atomicAdd(&s_n, 1u);
 	__syncthreads();
 	const uint32_t n_gh = s_n;
-	const bool fits = !s_fail && 1u + n_own + n_gh <= NH_BLK_CAP;
+	uint32_t chunks = 0;                                      // (every thread counts: L is small)
+	for (uint32_t l = 0; l < L; ++l) chunks += (bin_off[b * L + l + 1u] - bin_off[b * L + l] + NH_BLK_CHUNK - 1u) / NH_BLK_CHUNK;
+	const bool fits = !s_fail && 1u + n_own + n_gh <= NH_BLK_CAP && chunks <= NH_BLK_MAX_CHUNKS;
 	if (tid == 0) {
 		atomicMax(&st->blk.max_load, 1u + n_own + n_gh);
 		if (!fits) st->blk.overflow = 1;
@@ -265,11 +276,16 @@ __global__ __launch_bounds__(256) void k_blk_prepare(nh_DevState* __restrict__ s
 			const uint32_t b0 = st->blk.bits[0], b1 = st->blk.bits[1], b2 = st->blk.bits[2];
 			const uint32_t c0 = b & ((1u << b0) - 1u), c1 = (b >> b0) & ((1u << b1) - 1u), c2 = (b >> (b0 + b1)) & ((1u << b2) - 1u);
 			const uint32_t col = (c0 & 1u) | (c1 & 1u) << 1 | (c2 & 1u) << 2;
-			phase_list[col * NH_BLK_MAX_BLOCKS + atomicAdd(&st->blk.phase_count[col], 1u)] = b;
+			const uint32_t slot = col * NH_BLK_MAX_BLOCKS + atomicAdd(&st->blk.phase_count[col], 1u);
+			phase_list[slot] = b;
+			s_slot = slot;
+			uint32_t* dsc = desc + (size_t)slot * NH_BLK_DESC_WORDS;
+			dsc[0] = b; dsc[1] = n_own; dsc[2] = 1u + own_base[b]; dsc[3] = n_gh; dsc[4] = s_base;
 		}
 	}
 	__syncthreads();
 	if (!fits) return;                                   // (the host sees the overflow flag and retries the whole setup with smaller blocks)
+	if (tid <= L) desc[(size_t)s_slot * NH_BLK_DESC_WORDS + 5u + tid] = bin_off[b * L + tid];
 	const uint32_t base = s_base;
 	for (uint32_t t = tid; t < NH_BLK_HASH; t += 256u) if (s_key[t] != NH_NONE) ghost_list[base + s_val[t]] = blk_slot(own_base, brank[s_key[t]].x);
 	for (uint32_t k = r0 + tid; k < r1; k += 256u) {
@@ -303,13 +319,17 @@ __global__ __launch_bounds__(256) void k_blk_residual_pairs(uint32_t begin, uint
 	}
 }
 
-// momentum of the general bodies, caller's array <-> block order
+// momentum of the general bodies, caller's array <-> block order.  The copy's records are (velocity, inverse mass | angular velocity, k): the inverse
+// mass rides in the first spare word like in the reference (nudge.cpp:4198; k_adj_sort put it there), the second spare word carries the body's
+// inverse inertia about x -- the scalar k of a body with isotropic inertia, which is all a radial row ever asks of it (nh_rowr_derive).
 __global__ __launch_bounds__(256) void k_blk_gather(uint32_t nbodies, const uint2* __restrict__ brank, const uint32_t* __restrict__ own_base, const float4* __restrict__ momentum4,
-                                                    float4* __restrict__ bm4, uint32_t* __restrict__ pos_body) {
+                                                    const nh_BodyProperties* __restrict__ props, float4* __restrict__ bm4, uint32_t* __restrict__ pos_body) {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) {
 		uint32_t slot = 0;
 		if (i) { const uint32_t br = brank[i].x; if (br == NH_NONE) continue; slot = blk_slot(own_base, br); }
-		bm4[2 * (size_t)slot] = momentum4[2 * (size_t)i]; bm4[2 * (size_t)slot + 1] = momentum4[2 * (size_t)i + 1];
+		float4 m1 = momentum4[2 * (size_t)i + 1];
+		m1.w = props[i].inertia_inverse[0];
+		bm4[2 * (size_t)slot] = momentum4[2 * (size_t)i]; bm4[2 * (size_t)slot + 1] = m1;
 		if (pos_body) pos_body[slot] = i;
 	}
 }
@@ -320,91 +340,152 @@ __global__ __launch_bounds__(256) void k_blk_scatter_back(uint32_t nbodies, cons
 		const uint32_t br = brank[i].x;
 		if (br == NH_NONE) continue;
 		const uint32_t slot = blk_slot(own_base, br);
-		momentum4[2 * (size_t)i] = bm4[2 * (size_t)slot]; momentum4[2 * (size_t)i + 1] = bm4[2 * (size_t)slot + 1];
+		float4 m1 = bm4[2 * (size_t)slot + 1];
+		m1.w = 0.0f;                                   // (what k_level_exec leaves in the spare word of a body it has solved)
+		momentum4[2 * (size_t)i] = bm4[2 * (size_t)slot]; momentum4[2 * (size_t)i + 1] = m1;
 	}
 }
 
 // ---- the sweep: one workgroup per block of the launch's block colour ---------------------------------------------------------------------------------
 // WARM: the warm start (nudge.cpp:4563-4632) instead of a sweep; the cached impulse of a contact sits where its solver state will (k_rows_general put it
 // there), so both kinds of launch stream the same arrays.  RADIAL_ONLY: no contact of the set has a full row (the host knows from k_rows_general's
-// flags): the kernel without the 40-float path runs at twice the occupancy.
-template<int NQ> struct nh_blk_item { float4 row[NQ]; float4 sv; uint32_t lp, k; bool valid; };
-
+// flags).
+//
+// What a contact costs per sweep: the first eight floats of its radial row (n, bias, alpha, beta, friction, effective mass; the other three follow from the
+// two bodies, nh_rowr_derive), its local index pair, three state floats in and out -- 60 bytes, streamed in block order.  A colour step by itself is a
+// dependent chain (LDS read, ~150 instructions, LDS write, barrier) with a few hundred contacts in it, far too little to keep HBM busy; what keeps it busy
+// is how far AHEAD the stream is fetched.  The workgroup's wavefronts are split into NG groups that take the colours in turn (group g: colours g, g + NG,
+// ...; a block has a few hundred contacts per colour, so a group's threads cover one), every thread keeps three contacts in flight in three register sets
+// that take turns (no copies: a copy would have to wait for the loads it moves), and so the loads of the next 2 NG colours -- about half of a block's
+// contacts -- are under way while a colour is being solved.  All loads go out unconditionally at clamped positions: a load under a divergent branch is
+// issued and awaited inside that branch.
+struct nh_blk_item { float4 r0, r1; float sx, sy, sz; uint32_t lp; };      // (position and validity follow from the colour: not kept)
 template<bool WARM, bool RADIAL_ONLY>
-__global__ __launch_bounds__(NH_BLK_THREADS) void k_blk_sweep(const uint32_t* __restrict__ phase_list, uint32_t L, const uint32_t* __restrict__ bin_off, const uint32_t* __restrict__ blk_count,
-                                                              const uint32_t* __restrict__ own_base, const uint32_t* __restrict__ ghost_base, const uint32_t* __restrict__ ghost_count,
+__global__ __launch_bounds__(NH_BLK_THREADS) __attribute__((amdgpu_waves_per_eu(RADIAL_ONLY ? 4 : 2, RADIAL_ONLY ? 4 : 2))) void k_blk_sweep(const uint32_t* __restrict__ desc, uint32_t L,
                                                               const uint32_t* __restrict__ ghost_list, const uint32_t* __restrict__ lpair, const float4* __restrict__ rows4, size_t stride,
-                                                              float4* __restrict__ gstates, float4* bm4) {
-	constexpr int NQ = RADIAL_ONLY ? 3 : 10;
+                                                              float* __restrict__ pstates, float4* bm4, unsigned long long* __restrict__ prof) {
+	// prof (NH_BLK_PROFILE=1): per workgroup four readings of the 100 MHz wall clock -- start, bodies in, colours done, momentum out
+	constexpr uint32_t NG = NH_BLK_GROUPS, T = NH_BLK_THREADS, TG = NH_BLK_CHUNK;
+	if (prof && threadIdx.x == 0) prof[4 * (size_t)blockIdx.x] = wall_clock64();
 	__shared__ float4 s_m0[NH_BLK_CAP], s_m1[NH_BLK_CAP];
-	__shared__ uint32_t s_off[NH_BLK_MAX_COLOURS + 1];
-	const uint32_t tid = threadIdx.x, T = NH_BLK_THREADS;
-	const uint32_t b = phase_list[blockIdx.x];
-	const uint32_t n_own = blk_count[b], base = 1u + own_base[b], n_gh = ghost_count[b], gb = ghost_base[b];
-	if (tid <= L) s_off[tid] = bin_off[b * L + tid];
+	__shared__ uint32_t s_desc[NH_BLK_DESC_WORDS];
+	__shared__ uint32_t s_first[64];                       // first chunk of every colour
+	__shared__ uint32_t s_cs[NH_BLK_MAX_CHUNKS + 1];       // chunk starts (positions in the block-ordered contact arrays); chunk m = [s_cs[m], s_cs[m + 1])
+	const uint32_t tid = threadIdx.x, g = tid / TG, t = tid % TG;
+	// one load brings everything the workgroup needs to know about its block (k_blk_prepare wrote it where blockIdx finds it)
+	if (tid < NH_BLK_DESC_WORDS) s_desc[tid] = desc[(size_t)blockIdx.x * NH_BLK_DESC_WORDS + tid];
 	__syncthreads();
+	const uint32_t n_own = s_desc[1], base = s_desc[2], n_gh = s_desc[3], gb = s_desc[4];
+	const uint32_t* s_off = s_desc + 5;
+	// A colour is solved in chunks of at most TG contacts, one chunk per step (the greedy colouring fills its low colours first: a block's first colours
+	// hold several hundred contacts, its last ones a handful).  Chunks of one colour need no barrier between them, but as steps of ONE pipeline they
+	// are all prefetched alike.  Chunk table: counts per colour, a wave scan, the starts.
+	if (tid < 64u) {
+		const uint32_t n = tid < L ? (s_off[tid + 1u] - s_off[tid] + TG - 1u) / TG : 0u;
+		uint32_t x = n;
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, d); if ((int)tid >= d) x += y; }
+		s_first[tid] = x - n;                              // (s_first[L] = number of chunks)
+	}
+	__syncthreads();
+	const uint32_t nch = min(s_first[L], NH_BLK_MAX_CHUNKS);
+	if (tid < L) { const uint32_t f = s_first[tid], n = s_first[tid + 1u] - f; for (uint32_t q = 0; q < n && f + q < NH_BLK_MAX_CHUNKS; ++q) s_cs[f + q] = s_off[tid] + q * TG; }
+	if (tid == L) s_cs[nch] = s_off[L];
+	__syncthreads();
+	const uint32_t last = s_off[L] > s_off[0] ? s_off[L] - 1u : s_off[0];
 
-	auto load_item = [&](uint32_t k, nh_blk_item<NQ>& it) {
-		it.k = k;
+	auto load_item = [&](uint32_t k, nh_blk_item& it) {
 		it.lp = lpair[k];
-#pragma unroll
-		for (int q = 0; q < 3; ++q) it.row[q] = rows4[(size_t)q * stride + k];
-		if (!RADIAL_ONLY && !(it.lp & NH_BLK_RADIAL)) {
-#pragma unroll
-			for (int q = 3; q < NQ; ++q) it.row[q] = rows4[(size_t)q * stride + k];
-		}
-		it.sv = gstates[k];
+		it.r0 = rows4[k];
+		it.r1 = rows4[stride + k];
+		const float* ps = pstates + 3 * (size_t)k;
+		it.sx = ps[0]; it.sy = ps[1]; it.sz = ps[2];
 	};
-	auto fetch = [&](uint32_t l, nh_blk_item<NQ>& it) {
-		const uint32_t k = s_off[l] + tid;
-		it.valid = k < s_off[l + 1];
-		if (it.valid) load_item(k, it);
+	// this thread's contact in its group's j-th chunk
+	auto fetch = [&](uint32_t j, nh_blk_item& it) {
+		const uint32_t m = j * NG + g;
+		const uint32_t mc = min(m, nch - 1u);
+		const uint32_t k = s_cs[mc] + t;
+		load_item(m < nch && k < s_cs[mc + 1u] ? k : last, it);
 	};
-	auto process = [&](const nh_blk_item<NQ>& it) {
+	auto process = [&](const nh_blk_item& it, uint32_t k) {
 		const uint32_t la = it.lp & 0xFFFu, lb = (it.lp >> 16) & 0xFFFu;
 		const float4 a0 = s_m0[la], a1 = s_m1[la], b0 = s_m0[lb], b1 = s_m1[lb];
 		nh_vel a = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w }, bb = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };
 		nh_state s;
-		if (!WARM) { s.normal = it.sv.x; s.friction_x = it.sv.y; s.friction_y = it.sv.z; }
+		if (!WARM) { s.normal = it.sx; s.friction_x = it.sy; s.friction_y = it.sz; }
 		if (RADIAL_ONLY || (it.lp & NH_BLK_RADIAL)) {
 			nh_rowr r;
-			float4* dst = reinterpret_cast<float4*>(&r);
-#pragma unroll
-			for (int q = 0; q < 3; ++q) dst[q] = it.row[q];
-			if (WARM) nh_warm_start_r(r, it.sv.x, it.sv.y, it.sv.z, a, bb, s); else nh_apply_radial(r, s, a, bb);
+			r.n_x = it.r0.x; r.n_y = it.r0.y; r.n_z = it.r0.z; r.bias = it.r0.w;
+			r.alpha = it.r1.x; r.beta = it.r1.y; r.friction = it.r1.z; r.normal_velocity_to_normal_impulse = it.r1.w; r.pad = 0.0f;
+			nh_rowr_derive(r.alpha, r.beta, a0.w, b0.w, a1.w, b1.w, r.friction_coefficient, r.c_a, r.c_b);
+			if (WARM) nh_warm_start_r(r, it.sx, it.sy, it.sz, a, bb, s); else nh_apply_radial(r, s, a, bb);
 		} else if (!RADIAL_ONLY) {
+			// a full row (boxes): chunks 2..9 fetched in place -- scenes of boxes are not what this kernel is tuned for
 			nh_row r;
 			float4* dst = reinterpret_cast<float4*>(&r);
+			dst[0] = it.r0; dst[1] = it.r1;
 #pragma unroll
-			for (int q = 0; q < NQ; ++q) dst[q] = it.row[q];
-			if (WARM) nh_warm_start(r, it.sv.x, it.sv.y, it.sv.z, a, bb, s); else nh_apply_one(r, s, a, bb);
+			for (int q = 2; q < 10; ++q) dst[q] = rows4[(size_t)q * stride + k];
+			if (WARM) nh_warm_start(r, it.sx, it.sy, it.sz, a, bb, s); else nh_apply_one(r, s, a, bb);
 		}
-		gstates[it.k] = make_float4(s.normal, s.friction_x, s.friction_y, 0.0f);
-		if (la) { s_m0[la] = make_float4(a.vx, a.vy, a.vz, a.mass_inverse); s_m1[la] = make_float4(a.wx, a.wy, a.wz, a.w_unused); }      // slot 0 is the static world: never written
-		if (lb) { s_m0[lb] = make_float4(bb.vx, bb.vy, bb.vz, bb.mass_inverse); s_m1[lb] = make_float4(bb.wx, bb.wy, bb.wz, bb.w_unused); }
+		float* ps = pstates + 3 * (size_t)k;
+		ps[0] = s.normal; ps[1] = s.friction_x; ps[2] = s.friction_y;
+		// slot 0 is the static world: never written.  The spare words (inverse mass, k) go back as they came.
+		if (la) { s_m0[la] = make_float4(a.vx, a.vy, a.vz, a0.w); s_m1[la] = make_float4(a.wx, a.wy, a.wz, a1.w); }
+		if (lb) { s_m0[lb] = make_float4(bb.vx, bb.vy, bb.vz, b0.w); s_m1[lb] = make_float4(bb.wx, bb.wy, bb.wz, b1.w); }
 	};
 
-	// the first colour's contacts are on their way while the bodies come in
-	nh_blk_item<NQ> cur, nxt;
-	fetch(0u, cur);
-	if (tid == 0) { s_m0[0] = bm4[0]; s_m1[0] = bm4[1]; }
-	for (uint32_t i = tid; i < n_own; i += T) { s_m0[1u + i] = bm4[2 * (size_t)(base + i)]; s_m1[1u + i] = bm4[2 * (size_t)(base + i) + 1]; }
-	for (uint32_t i = tid; i < n_gh; i += T) { const size_t slot = ghost_list[gb + i]; s_m0[1u + n_own + i] = bm4[2 * slot]; s_m1[1u + n_own + i] = bm4[2 * slot + 1]; }
-	__syncthreads();
-	for (uint32_t l = 0; l < L; ++l) {
-		const bool more = l + 1u < L;
-		if (more) fetch(l + 1u, nxt);
-		if (cur.valid) process(cur);
-		for (uint32_t k = s_off[l] + tid + T; k < s_off[l + 1]; k += T) {            // a colour with more contacts than threads: the rest, fetched in place
-			nh_blk_item<NQ> extra;
-			load_item(k, extra);
-			process(extra);
-		}
-		__syncthreads();
-		if (more) cur = nxt;
+	// Prologue: the block's bodies come in by LDS-direct loads (global_load_lds_dwordx4: a wave moves 64 consecutive 16-byte pieces from per-lane
+	// addresses to 1 KB of LDS, no staging registers, nothing to wait for until the barrier) -- the own bodies are contiguous in block order, a ghost's
+	// slot comes from the ghost list first (the first two per thread are asked for before anything else).  Two dependent round trips in all.
+	constexpr uint32_t UG = 2;
+	uint32_t gs[UG];
+#pragma unroll
+	for (uint32_t u = 0; u < UG; ++u) gs[u] = ghost_list[gb + min(tid + u * T, n_gh ? n_gh - 1u : 0u)];
+	nh_blk_item A, B, C;
+	fetch(0u, A);
+	fetch(1u, B);
+	if (tid == 0) { nh_glds16(bm4, &s_m0[0]); nh_glds16(bm4 + 1, &s_m1[0]); }
+	for (uint32_t i = tid; i < n_own; i += T) {
+		nh_glds16(bm4 + 2 * (size_t)(base + i), &s_m0[1u + i]);
+		nh_glds16(bm4 + 2 * (size_t)(base + i) + 1, &s_m1[1u + i]);
 	}
+#pragma unroll
+	for (uint32_t u = 0; u < UG; ++u) {
+		const uint32_t i = tid + u * T;
+		if (i < n_gh) { nh_glds16(bm4 + 2 * (size_t)gs[u], &s_m0[1u + n_own + i]); nh_glds16(bm4 + 2 * (size_t)gs[u] + 1, &s_m1[1u + n_own + i]); }
+	}
+	for (uint32_t i = tid + UG * T; i < n_gh; i += T) {
+		const size_t slot = ghost_list[gb + i];
+		nh_glds16(bm4 + 2 * slot, &s_m0[1u + n_own + i]); nh_glds16(bm4 + 2 * slot + 1, &s_m1[1u + n_own + i]);
+	}
+	__syncthreads();
+	if (prof && threadIdx.x == 0) prof[4 * (size_t)blockIdx.x + 1] = wall_clock64();
+	uint32_t j = 0;
+#define NH_BLK_STEP(CUR, FREE)                                                                                                                           \
+	{                                                                                                                                                    \
+		fetch(j + 2u, FREE);                                                                                                                             \
+		_Pragma("unroll") for (uint32_t gg = 0; gg < NG; ++gg) {                                                                                         \
+			const uint32_t m = j * NG + gg;                                                                                                              \
+			if (m < nch) {                                   /* (uniform over the workgroup) */                                                          \
+				if (g == gg) {                               /* (uniform over a wavefront)  */                                                           \
+					const uint32_t k = s_cs[m] + t;                                                                                                      \
+					if (k < s_cs[m + 1u]) process(CUR, k);                                                                                               \
+				}                                                                                                                                        \
+				__syncthreads();                                                                                                                         \
+			}                                                                                                                                            \
+		}                                                                                                                                                \
+		if (++j * NG >= nch) break;                                                                                                                      \
+	}
+	for (;;) { NH_BLK_STEP(A, C) NH_BLK_STEP(B, A) NH_BLK_STEP(C, B) }
+#undef NH_BLK_STEP
+	if (prof && threadIdx.x == 0) prof[4 * (size_t)blockIdx.x + 2] = wall_clock64();
+	// momentum out; the first ghost slots are still in registers
 	for (uint32_t i = tid; i < n_own; i += T) { bm4[2 * (size_t)(base + i)] = s_m0[1u + i]; bm4[2 * (size_t)(base + i) + 1] = s_m1[1u + i]; }
-	for (uint32_t i = tid; i < n_gh; i += T) { const size_t slot = ghost_list[gb + i]; bm4[2 * slot] = s_m0[1u + n_own + i]; bm4[2 * slot + 1] = s_m1[1u + n_own + i]; }
+#pragma unroll
+	for (uint32_t u = 0; u < UG; ++u) { const uint32_t i = tid + u * T; if (i < n_gh) { bm4[2 * (size_t)gs[u]] = s_m0[1u + n_own + i]; bm4[2 * (size_t)gs[u] + 1] = s_m1[1u + n_own + i]; } }
+	for (uint32_t i = tid + UG * T; i < n_gh; i += T) { const size_t slot = ghost_list[gb + i]; bm4[2 * slot] = s_m0[1u + n_own + i]; bm4[2 * slot + 1] = s_m1[1u + n_own + i]; }
+	if (prof && threadIdx.x == 0) prof[4 * (size_t)blockIdx.x + 3] = wall_clock64();
 }
 
 // ---- NH_BLK_CHECK=1: structural check of one block colour's launch -------------------------------------------------------------------------------------

@@ -54,6 +54,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->blk.scale = 1.0f;
 	ctx->blk.disabled = getenv("NH_NO_BLOCKS") != nullptr;
 	ctx->blk.check = getenv("NH_BLK_CHECK") != nullptr;
+	if (getenv("NH_BLK_PROFILE")) hipMalloc((void**)&ctx->blk.prof, sizeof(unsigned long long) * 4u * 8u * NH_BLK_MAX_BLOCKS);
 	ctx->blk.min_contacts = getenv("NH_BLK_MIN") ? (uint32_t)atoi(getenv("NH_BLK_MIN")) : 200000u;
 	ctx->blk.target = getenv("NH_BLK_TARGET") ? (uint32_t)atoi(getenv("NH_BLK_TARGET")) : 900u;
 	if (ctx->blk.target < 8u) ctx->blk.target = 8u;
@@ -97,7 +98,7 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	if (ctx->sort_starts) hipFree(ctx->sort_starts);
 	{
 		nh_BlkBuffers& k = ctx->blk;
-		void* bufs[] = { k.brank, k.bm, k.pos_body, k.touch, k.lpair, k.ghost_list, k.blk_count, k.own_base, k.bins, k.bin_off, k.ghost_base, k.ghost_count, k.phase_list, k.scan_tmp };
+		void* bufs[] = { k.brank, k.bm, k.pos_body, k.touch, k.lpair, k.ghost_list, k.blk_count, k.own_base, k.bins, k.bin_off, k.ghost_base, k.ghost_count, k.phase_list, k.desc, k.scan_tmp, k.prof };
 		for (void* b : bufs) if (b) hipFree(b);
 	}
 	if (ctx->d_state) hipFree(ctx->d_state);

@@ -125,11 +125,13 @@ struct nh_BlkBuffers {
 	uint32_t* bins; uint32_t* bin_off;                    // (NH_BLK_MAX_BLOCKS + 1) x NH_BLK_MAX_COLOURS + 1: contacts by (owning block, colour); the last "block" = residual
 	uint32_t* ghost_base; uint32_t* ghost_count;          // per block
 	uint32_t* phase_list;                                 // 8 x NH_BLK_MAX_BLOCKS: blocks with work, by block colour
+	uint32_t* desc;                                       // ... and what a sweep workgroup needs to know about each of them (NH_BLK_DESC_WORDS words)
 	uint32_t* scan_tmp;
 	bool tables;
 	float scale;                      // block edge relative to the edge at which an average block holds `target` bodies: adapted from the largest load seen
 	uint32_t target, min_contacts;    // NH_BLK_TARGET, NH_BLK_MIN
 	bool disabled, check;             // NH_NO_BLOCKS=1, NH_BLK_CHECK=1
+	unsigned long long* prof; uint32_t prof_calls;       // NH_BLK_PROFILE=1: wall-clock readings of the sweep workgroups (8 launches x NH_BLK_MAX_BLOCKS x 4), printed now and then
 };
 
 struct nh_context {

@@ -1495,7 +1495,7 @@ __global__ __launch_bounds__(256) void k_rows_general(const nh_DevState* __restr
                                                       const nh_Transform* __restrict__ xf, const nh_BodyProperties* __restrict__ props,
                                                       float4* __restrict__ rows4, size_t stride, uint2* __restrict__ gpair, uint32_t allow_radial, uint32_t static_inert,
                                                       const uint32_t* __restrict__ level, uint32_t* __restrict__ level_has_full,
-                                                      const nh_CachedContactImpulse* __restrict__ warm_in, float4* __restrict__ gstates, uint32_t* __restrict__ lpair) {
+                                                      const nh_CachedContactImpulse* __restrict__ warm_in, float4* __restrict__ gstates, uint32_t* __restrict__ lpair, uint32_t packed_end) {
 	// warm_in (blocked solver, nh_blocks.h): the cached impulse of every contact is copied to where its solver state will be, so that the warm start
 	// streams the same arrays as a sweep; lpair: the contact's local index pair learns whether its row is radial
 	uint32_t n = st->general_contacts;
@@ -1523,7 +1523,12 @@ __global__ __launch_bounds__(256) void k_rows_general(const nh_DevState* __restr
 			level_has_full[level[c]] = 1u;             // this level / colour class needs the kernel that knows full rows (plain store of a constant)
 		}
 		gpair[k] = make_uint2(p.a | (radial ? NH_RADIAL_BIT : 0u), p.b);
-		if (warm_in) gstates[k] = *reinterpret_cast<const float4*>(warm_in + c);
+		if (warm_in) {
+			// (contacts owned by a block, k < packed_end, keep their three state floats packed: 12 bytes each in the same memory)
+			const float4 w = *reinterpret_cast<const float4*>(warm_in + c);
+			if (k < packed_end) { float* ps = reinterpret_cast<float*>(gstates) + 3 * (size_t)k; ps[0] = w.x; ps[1] = w.y; ps[2] = w.z; }
+			else gstates[k] = w;
+		}
 		if (lpair && radial) lpair[k] |= NH_BLK_RADIAL;
 	}
 }
@@ -1534,12 +1539,14 @@ template<bool WARM, bool RADIAL_ONLY = false>
 __global__ __launch_bounds__(256) void k_level_exec(const uint32_t* __restrict__ order, uint32_t begin, uint32_t end,
                                                     const uint2* __restrict__ gpair, const nh_CachedContactImpulse* __restrict__ cached,
                                                     nh_BodyMomentum* __restrict__ momentum,
-                                                    const float4* __restrict__ rows4, size_t stride, float4* __restrict__ gstates) {
+                                                    const float4* __restrict__ rows4, size_t stride, float4* __restrict__ gstates, uint32_t keep_w = 0u) {
+	// keep_w (blocked solver: residual contacts on its block-ordered momentum copy): the spare word of a momentum record is not ours to clear
 	for (uint32_t k = begin + blockIdx.x * blockDim.x + threadIdx.x; k < end; k += gridDim.x * blockDim.x) {
 		uint2 p = gpair[k];
 		const bool radial = RADIAL_ONLY || (p.x & NH_RADIAL_BIT) != 0u;
 		p.x &= ~NH_RADIAL_BIT;
 		nh_vel a = load_vel_m(momentum, p.x), b = load_vel_m(momentum, p.y);
+		const float aw = a.w_unused, bw = b.w_unused;
 		nh_state s;
 		float4 w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		if (WARM) w = cached ? *reinterpret_cast<const float4*>(cached + order[k]) : gstates[k];      // (blocked solver: the cached impulse waits in the state's place)
@@ -1554,6 +1561,7 @@ __global__ __launch_bounds__(256) void k_level_exec(const uint32_t* __restrict__
 			if (WARM) nh_warm_start(r, w.x, w.y, w.z, a, b, s); else nh_apply_one(r, s, a, b);
 		}
 		gstates[k] = make_float4(s.normal, s.friction_x, s.friction_y, 0.0f);
+		if (keep_w) { a.w_unused = aw; b.w_unused = bw; }
 		if (p.x) store_vel_m(momentum, p.x, a);      // body 0 is the static world: never written
 		if (p.y) store_vel_m(momentum, p.y, b);
 	}
@@ -1727,13 +1735,15 @@ __global__ __launch_bounds__(NH_RESB_THREADS) void k_solve_resident_bodies(const
 
 __global__ __launch_bounds__(256) void k_update_impulses(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ order, const float4* __restrict__ rows4, size_t stride,
                                                          const float4* __restrict__ gstates, nh_CachedContactImpulse* __restrict__ out, const uint32_t* __restrict__ colour,
-                                                         const uint2* __restrict__ gpair) {
+                                                         const uint2* __restrict__ gpair, uint32_t packed_end = 0u) {
+	// packed_end (blocked solver): the states of the contacts owned by a block, k < packed_end, are packed (three floats each, same memory)
 	// colour != nullptr (default solver order): the contact's colour rides in the spare word of its cached impulse, so that the next
 	// step's colouring can start from it (k_colour_seed)
 	uint32_t n = st->general_contacts;
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-		float4 sv = gstates[k];
-		nh_state s = { sv.x, sv.y, sv.z };
+		nh_state s;
+		if (k < packed_end) { const float* ps = reinterpret_cast<const float*>(gstates) + 3 * (size_t)k; s.normal = ps[0]; s.friction_x = ps[1]; s.friction_y = ps[2]; }
+		else { const float4 sv = gstates[k]; s.normal = sv.x; s.friction_x = sv.y; s.friction_y = sv.z; }
 		float ox, oy, oz;
 		if (gpair[k].x & NH_RADIAL_BIT) {
 			nh_rowr r;
@@ -2002,6 +2012,7 @@ static int blk_reserve(nh_context* ctx, uint32_t B, uint32_t kcap) {
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.ghost_base, sizeof(uint32_t) * nb));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.ghost_count, sizeof(uint32_t) * nb));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.phase_list, sizeof(uint32_t) * 8u * NH_BLK_MAX_BLOCKS));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.desc, sizeof(uint32_t) * 8u * NH_BLK_MAX_BLOCKS * NH_BLK_DESC_WORDS));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.scan_tmp, sizeof(uint32_t) * (2u * NH_SORT_GRID + 64u)));
 		k.tables = true;
 	}
@@ -2057,7 +2068,7 @@ static int blk_setup(nh_context* ctx, nh_ContactConstraintData* d, uint32_t G) {
 		nh_scan_u32(ctx, k.bins, k.bin_off, &st->pad0, (uint32_t)nbins, k.scan_tmp, nullptr);
 		NH_LAUNCH(ctx, "blk_scatter", k_blk_scatter, nh_grid_for(G, 256, 8192), 256, st, d->general_list, rank, bin, k.bin_off, d->level_order);
 		NH_LAUNCH(ctx, "blk_prepare", k_blk_prepare, NH_BLK_MAX_BLOCKS, 256, st, L, k.bin_off, k.blk_count, k.own_base, d->level_order, contacts->bodies, k.brank, k.lpair,
-		          k.ghost_base, k.ghost_count, k.ghost_list, k.phase_list);
+		          k.ghost_base, k.ghost_count, k.ghost_list, k.phase_list, k.desc);
 		NH_HIP_CHECK(ctx, hipMemcpyAsync(h, &st->blk, sizeof(nh_BlkGrid), hipMemcpyDeviceToHost, ctx->stream));
 		NH_HIP_CHECK(ctx, hipMemcpyAsync(d->blk.res_off, k.bin_off + (size_t)NH_BLK_MAX_BLOCKS * L, sizeof(uint32_t) * (L + 1u), hipMemcpyDeviceToHost, ctx->stream));
 		NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -2075,7 +2086,7 @@ static int blk_setup(nh_context* ctx, nh_ContactConstraintData* d, uint32_t G) {
 	uint32_t* level_hist = d->cont.level_hist;
 	NH_LAUNCH(ctx, "zero_u32", k_zero_u32, 8, 256, level_hist, 2 * (NH_MAX_LEVELS + 2));
 	NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, d->level_order, contacts->data, contacts->bodies, bodies->transforms, bodies->properties,
-	          (float4*)d->rows, (size_t)kcap, d->gpair, 1u, 1u, d->cont.level, level_hist + (NH_MAX_LEVELS + 2), (const nh_CachedContactImpulse*)d->imp->data, d->gstates, k.lpair);
+	          (float4*)d->rows, (size_t)kcap, d->gpair, 1u, 1u, d->cont.level, level_hist + (NH_MAX_LEVELS + 2), (const nh_CachedContactImpulse*)d->imp->data, d->gstates, k.lpair, d->blk.res_off[0]);
 	if (d->blk.res_off[L] > d->blk.res_off[0])
 		NH_LAUNCH(ctx, "blk_residual_pairs", k_blk_residual_pairs, nh_grid_for(d->blk.res_off[L] - d->blk.res_off[0], 256, 4096), 256, d->blk.res_off[0], d->blk.res_off[L], k.brank, k.own_base, d->gpair);
 	NH_HIP_CHECK(ctx, hipMemcpyAsync(d->level_full, level_hist + (NH_MAX_LEVELS + 2), sizeof(uint32_t) * (L + 2u), hipMemcpyDeviceToHost, ctx->stream));
@@ -2084,7 +2095,7 @@ static int blk_setup(nh_context* ctx, nh_ContactConstraintData* d, uint32_t G) {
 	for (uint32_t l = 1; l <= L; ++l) d->blk.radial_only &= d->level_full[l] == 0u;
 	if (k.check) {
 		// NH_BLK_CHECK=1 (tests): the structure the sweeps rely on, launch by launch
-		NH_LAUNCH(ctx, "blk_gather", k_blk_gather, nh_grid_for(B, 256, 4096), 256, B, k.brank, k.own_base, (const float4*)bodies->momentum, k.bm, k.pos_body);
+		NH_LAUNCH(ctx, "blk_gather", k_blk_gather, nh_grid_for(B, 256, 4096), 256, B, k.brank, k.own_base, (const float4*)bodies->momentum, bodies->properties, k.bm, k.pos_body);
 		for (int p = 0; p < 8; ++p) {
 			if (!d->blk.phase_count[p]) continue;
 			NH_HIP_CHECK(ctx, hipMemsetAsync(k.touch, 0, sizeof(uint32_t) * 2u * (size_t)(B + 1u), ctx->stream));
@@ -2108,15 +2119,15 @@ static void blk_run(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyD
 	const uint32_t passes = (warm ? 1u : 0u) + iterations;
 	if (!passes) return;
 	const size_t stride = (size_t)d->contact_capacity;
-	NH_LAUNCH(ctx, "blk_gather", k_blk_gather, nh_grid_for(B, 256, 4096), 256, B, k.brank, k.own_base, (const float4*)bodies->momentum, k.bm, (uint32_t*)nullptr);
+	NH_LAUNCH(ctx, "blk_gather", k_blk_gather, nh_grid_for(B, 256, 4096), 256, B, k.brank, k.own_base, (const float4*)bodies->momentum, bodies->properties, k.bm, (uint32_t*)nullptr);
 	for (uint32_t pass = 0; pass < passes; ++pass) {
 		const bool w = warm && pass == 0u;
 		for (int p = 0; p < 8; ++p) {
 			const uint32_t n = d->blk.phase_count[p];
 			if (!n) continue;
-			const uint32_t* list = k.phase_list + (size_t)p * NH_BLK_MAX_BLOCKS;
-#define NH_BLK_SWEEP(NAME, W, R) NH_LAUNCH(ctx, NAME, (k_blk_sweep<W, R>), n, NH_BLK_THREADS, list, L, k.bin_off, k.blk_count, k.own_base, k.ghost_base, k.ghost_count, k.ghost_list, k.lpair, \
-			          (const float4*)d->rows, stride, d->gstates, k.bm)
+			const uint32_t* list = k.desc + (size_t)p * NH_BLK_MAX_BLOCKS * NH_BLK_DESC_WORDS;
+#define NH_BLK_SWEEP(NAME, W, R) NH_LAUNCH(ctx, NAME, (k_blk_sweep<W, R>), n, NH_BLK_THREADS, list, L, k.ghost_list, k.lpair, \
+			          (const float4*)d->rows, stride, reinterpret_cast<float*>(d->gstates), k.bm, (k.prof && pass + 1u == passes) ? k.prof + 4u * (size_t)p * NH_BLK_MAX_BLOCKS : (unsigned long long*)nullptr)
 			if (w) { if (d->blk.radial_only) NH_BLK_SWEEP("blk_warm", true, true); else NH_BLK_SWEEP("blk_warm", true, false); }
 			else { if (d->blk.radial_only) NH_BLK_SWEEP("blk_sweep", false, true); else NH_BLK_SWEEP("blk_sweep", false, false); }
 #undef NH_BLK_SWEEP
@@ -2127,10 +2138,30 @@ static void blk_run(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyD
 			nh_BodyMomentum* bm = reinterpret_cast<nh_BodyMomentum*>(k.bm);
 			const bool full = d->level_full[l + 1u] != 0u;
 #define NH_BLK_RES(NAME, W, R) NH_LAUNCH(ctx, NAME, (k_level_exec<W, R>), nh_grid_for(e - b, 256, 8192), 256, d->level_order, b, e, d->gpair, (const nh_CachedContactImpulse*)nullptr, bm, \
-			          (const float4*)d->rows, stride, d->gstates)
+			          (const float4*)d->rows, stride, d->gstates, 1u)
 			if (w) { if (full) NH_BLK_RES("warm_level", true, false); else NH_BLK_RES("warm_level", true, true); }
 			else { if (full) NH_BLK_RES("apply_level", false, false); else NH_BLK_RES("apply_level", false, true); }
 #undef NH_BLK_RES
+		}
+	}
+	if (k.prof && (++k.prof_calls % 64u) == 0u) {
+		// NH_BLK_PROFILE=1: the last sweep's eight launches, per workgroup: prologue / colours / epilogue in microseconds (100 MHz clock)
+		hipStreamSynchronize(ctx->stream);
+		std::vector<unsigned long long> h(4u * NH_BLK_MAX_BLOCKS);
+		for (int p = 0; p < 8; ++p) {
+			const uint32_t n = d->blk.phase_count[p];
+			if (!n) continue;
+			hipMemcpy(h.data(), k.prof + 4u * (size_t)p * NH_BLK_MAX_BLOCKS, sizeof(unsigned long long) * 4u * n, hipMemcpyDeviceToHost);
+			double s0 = 0, s1 = 0, s2 = 0, m0 = 0, m1 = 0, m2 = 0;
+			unsigned long long first = ~0ull, lastt = 0;
+			for (uint32_t i = 0; i < n; ++i) {
+				const double a = 0.01 * (double)(h[4 * i + 1] - h[4 * i]), b = 0.01 * (double)(h[4 * i + 2] - h[4 * i + 1]), c = 0.01 * (double)(h[4 * i + 3] - h[4 * i + 2]);
+				s0 += a; s1 += b; s2 += c; if (a > m0) m0 = a; if (b > m1) m1 = b; if (c > m2) m2 = c;
+				if (h[4 * i] < first) first = h[4 * i];
+				if (h[4 * i + 3] > lastt) lastt = h[4 * i + 3];
+			}
+			fprintf(stderr, "blk_profile phase %d: %u workgroups, first start to last end %.1f us; mean (max) us: prologue %.2f (%.2f), colours %.2f (%.2f), epilogue %.2f (%.2f)\n",
+			        p, n, 0.01 * (double)(lastt - first), s0 / n, m0, s1 / n, m1, s2 / n, m2);
 		}
 	}
 	NH_LAUNCH(ctx, "blk_scatter_back", k_blk_scatter_back, nh_grid_for(B, 256, 4096), 256, B, k.brank, k.own_base, (const float4*)k.bm, (float4*)bodies->momentum);
@@ -2190,7 +2221,7 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 			NH_LAUNCH(ctx, "colour_small", k_colour_small, 1, 1024, st, general_list, imp->data, contacts->bodies, d->body_off, d->adj, level, d->cont.tent, level_hist, d->level_order);
 			NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, d->level_order, contacts->data, contacts->bodies, bodies->transforms, bodies->properties,
 			          (float4*)d->rows, (size_t)kcap, d->gpair, 1u, d->static_inert ? 1u : 0u, level, level_hist + (NH_MAX_LEVELS + 2),
-			          (const nh_CachedContactImpulse*)nullptr, (float4*)nullptr, (uint32_t*)nullptr);
+			          (const nh_CachedContactImpulse*)nullptr, (float4*)nullptr, (uint32_t*)nullptr, 0u);
 			d->levels = 0;                                  // on the device (st->levels)
 			d->resident = G <= NH_RES_MAX_FULL; d->resident_cap = NH_RES_MAX_FULL; d->resident_bodies = !d->resident;
 			if (d->resident)
@@ -2255,7 +2286,7 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		NH_LAUNCH(ctx, "level_scatter", k_level_scatter, nh_grid_for(G, 256, 512), 256, st, general_list, level, level_cursor, d->level_order);
 		NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, d->level_order, contacts->data, contacts->bodies, bodies->transforms, bodies->properties,
 		          (float4*)d->rows, (size_t)kcap, d->gpair, (ctx->flags & NH_FLAG_EXACT_ORDER) ? 0u : 1u, d->static_inert ? 1u : 0u,
-		          level, level_hist + (NH_MAX_LEVELS + 2), (const nh_CachedContactImpulse*)nullptr, (float4*)nullptr, (uint32_t*)nullptr);
+		          level, level_hist + (NH_MAX_LEVELS + 2), (const nh_CachedContactImpulse*)nullptr, (float4*)nullptr, (uint32_t*)nullptr, 0u);
 		NH_HIP_CHECK(ctx, hipMemcpyAsync(d->level_off, level_hist, sizeof(uint32_t) * (d->levels + 2), hipMemcpyDeviceToHost, ctx->stream));
 		NH_HIP_CHECK(ctx, hipMemcpyAsync(d->level_full, level_hist + (NH_MAX_LEVELS + 2), sizeof(uint32_t) * (d->levels + 2), hipMemcpyDeviceToHost, ctx->stream));
 		NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -2432,7 +2463,8 @@ extern "C" int nh_update_cached_impulses(nh_context* ctx, nh_ContactConstraintDa
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	if (d->general_contacts)
 		NH_LAUNCH(ctx, "update_impulses", k_update_impulses, nh_grid_for(d->general_contacts, 256, 4096), 256, ctx->d_state, d->level_order, (const float4*)d->rows, (size_t)d->contact_capacity,
-		          (const float4*)d->gstates, imp->data, (ctx->flags & NH_FLAG_EXACT_ORDER) ? (const uint32_t*)nullptr : (const uint32_t*)d->cont.level, d->gpair);
+		          (const float4*)d->gstates, imp->data, (ctx->flags & NH_FLAG_EXACT_ORDER) ? (const uint32_t*)nullptr : (const uint32_t*)d->cont.level, d->gpair,
+		          d->blk.active ? d->blk.res_off[0] : 0u);
 	return NH_OK;
 }
 

@@ -596,9 +596,17 @@ NH_HD void nh_export_impulse1(const nh_row1& r, const nh_state& st, float& ix, f
 // never under NH_FLAG_EXACT_ORDER.  tests/test_cpu_oracle.py::test_radial_forms_agree_with_general_forms bounds the difference.
 struct nh_rowr {
 	float n_x, n_y, n_z, bias;
-	float alpha, beta, normal_velocity_to_normal_impulse, friction_coefficient;
-	float c_a, c_b, friction, pad;        // c_a = k_a * alpha, c_b = k_b * beta
+	float alpha, beta, friction, normal_velocity_to_normal_impulse;
+	float friction_coefficient, c_a, c_b, pad;        // c_a = k_a * alpha, c_b = k_b * beta: what nh_rowr_derive gives (the blocked solver, nh_blocks.h,
+	                                                  // streams only the first eight floats and recomputes these three from the two bodies)
 };
+
+// the part of a radial row that follows from alpha, beta and the two bodies' inverse mass / isotropic inverse inertia k
+NH_HD void nh_rowr_derive(float alpha, float beta, float a_mass_inverse, float b_mass_inverse, float k_a, float k_b, float& friction_coefficient, float& c_a, float& c_b) {
+	float mass_inverse = a_mass_inverse + b_mass_inverse;
+	friction_coefficient = mass_inverse + k_a * alpha * alpha + k_b * beta * beta;
+	c_a = k_a * alpha; c_b = k_b * beta;
+}
 
 // the smoothly varying tangent basis of nh_build_row (nudge.cpp:4445-4456)
 NH_HD void nh_tangents(float nx, float ny, float nz, nh_f3& u, nh_f3& v) {
@@ -634,8 +642,7 @@ NH_HD void nh_build_rowr(const nh_contact_in& c, nh_f3 apos, nh_f3 bpos, float k
 	r.bias = (-NH_BIAS_FACTOR) * nh_max(c.penetration - NH_ALLOWED_PENETRATION, 0.0f) * nvtni;
 	r.alpha = alpha; r.beta = beta;
 	r.normal_velocity_to_normal_impulse = nvtni;
-	r.friction_coefficient = mass_inverse + k_a * alpha * alpha + k_b * beta * beta;
-	r.c_a = k_a * alpha; r.c_b = k_b * beta;
+	nh_rowr_derive(alpha, beta, a_mass_inverse, b_mass_inverse, k_a, k_b, r.friction_coefficient, r.c_a, r.c_b);
 	r.friction = c.friction; r.pad = 0.0f;
 }
 

@@ -815,7 +815,7 @@ def test_garbage_colour_seeds_in_the_cache_are_caught(side):
     outs = []
     for _ in range(2):
         w = E.World(scene, flags=E.NH_FLAG_SINGLE_APPLY, max_contacts=8 * nb, max_pairs=10 * nb)
-        w.step(150)
+        w.step(350)                              # settled
         w.synchronize()
         kd = w._keep["kd"].view(w.torch.int32).view(-1, 4)
         kd[:, 3] = 1                              # "colour 1" everywhere, as an integer bit pattern
