@@ -44,9 +44,9 @@
  *      warm start; call `nh_synchronize` (or any entry point) first if you need that.
  *
  *   8. The solver consumes the contact list as nh_collide laid it out (tag order, per-body degrees, adjacency seeds).
- *      Contacts appended by the caller between nh_collide and nh_setup_contact_constraints (the reference allows that:
- *      "Custom contacts can be added here", example/main.cpp:287) are NOT picked up: edit fields of existing contacts in
- *      place (friction, penetration ...) instead, or express the constraint as impulses between nh_apply_impulses calls.
+ *      Contacts appended by the caller after nh_collide (the reference allows that: "Custom contacts can be added here",
+ *      example/main.cpp:287) are announced with `nh_append_contacts`, which merges them into that order and counts the per-body
+ *      bookkeeping again; fields of existing contacts (friction, penetration ...) may simply be edited in place.
  *      One nh_setup_contact_constraints per nh_collide (a second one returns NH_ERR_STALE_SETUP).
  *
  * Threading: one context = one HIP stream = one world at a time; no global mutable state.
@@ -203,6 +203,16 @@ int nh_last_hip_error(nh_context* ctx);
 int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_ContactData* contacts,
                const nh_BodyData* bodies, const nh_ColliderData* colliders,
                const nh_BodyConnections* body_connections, nh_Arena temporary);
+
+/* Custom contacts (example/main.cpp:287: "Custom contacts can be added here").  The caller has written `extra` complete contacts -- data, bodies,
+   tags (a_tag | b_tag << 32: any pair of tags that no collider pair produces), features -- behind the list nh_collide returned, at indices
+   [count, count + extra) of the arrays of `contacts` (device memory; without NH_FLAG_SYNC_COUNTS `count` is what nh_read_counts reports).  Call this
+   after nh_collide and before nh_read_cached_impulses: the contacts are merged into tag order (the order the reference's solver consumes,
+   nudge.cpp:4027-4044, 4172) and the per-body bookkeeping is counted again; the contact count grows by `extra` (contacts->count too under
+   NH_FLAG_SYNC_COUNTS).  `positions` (device memory, count + extra words, or NULL): where every contact of the list as the caller left it -- the
+   old ones, then the appended ones -- now sits.  `temporary`: scratch (~60 bytes per contact of capacity).  At most 65,536 contacts per call.
+   Like in the reference, contacts appended here take no part in the sleeping islands nh_collide has already formed. */
+int nh_append_contacts(nh_context* ctx, nh_ContactData* contacts, const nh_BodyData* bodies, uint32_t extra, uint32_t* positions, nh_Arena temporary);
 
 /* caller-side loop of the sample app (example/main.cpp:290-305): v -= g*dt; v,w *= 1 - dt*damping_rate */
 int nh_apply_gravity_damping(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_BodyData* bodies,

@@ -87,6 +87,7 @@ struct Session {
 	DevBuf k_tags, k_features, k_data;
 	DevBuf active;
 	DevBuf arena;
+	DevBuf positions;
 	// the step in flight
 	nh_Arena temporary = { nullptr, 0 };
 	nh_ContactData contacts = {};
@@ -96,6 +97,11 @@ struct Session {
 	std::vector<uint32_t> u32;
 	std::vector<uint64_t> u64;
 	std::vector<uint32_t> feat;
+	// contacts appended by the caller after collide() ("Custom contacts can be added here", example/main.cpp:287): the device list is merged into tag
+	// order (nh_append_contacts) while the caller's arrays keep their order; perm[i] = where the caller's contact i sits on the device
+	std::vector<uint32_t> perm;
+	std::vector<nudge::Contact> staged_contacts;
+	uint32_t host_contacts = 0;          // contacts.count as the caller sees it
 
 	void init() {
 		if (ctx) return;
@@ -141,6 +147,14 @@ inline void widen_tag(uint64_t tag, uint64_t& wide, uint32_t& feature) {
 	uint64_t hi = tag >> 32;
 	wide = (hi & 0xffffu) | (((hi >> 16) & 0xffffu) << 32);
 	feature = (uint32_t)tag;
+}
+
+// the caller may have edited contact fields in place (custom friction etc.): its array goes up again, through the permutation if contacts were appended
+void upload_contact_data(Session& s, const nudge::Contact* data, uint32_t n) {
+	if (s.perm.empty()) { upload(s.c_data, data, sizeof(nudge::Contact) * (size_t)n); return; }
+	s.staged_contacts.resize(n ? n : 1);
+	for (uint32_t i = 0; i < n; ++i) s.staged_contacts[s.perm[i]] = data[i];
+	upload(s.c_data, s.staged_contacts.data(), sizeof(nudge::Contact) * (size_t)n);
 }
 
 // opaque results: handles in the caller's arena (reference nudge.cpp:4022, 4174 allocate theirs there too)
@@ -210,6 +224,7 @@ void collide(ActiveBodies* active_bodies, ContactData* contacts, BodyData bodies
 	// outputs written in place by the reference: contacts (data, bodies, tags, count, sleeping pairs), active bodies
 	const uint32_t n = s.contacts.count;
 	contacts->count = n;
+	s.host_contacts = n; s.perm.clear();
 	download(contacts->data, s.c_data.p, sizeof(Contact) * (size_t)n);
 	s.u32.resize(2 * (size_t)n + 2); s.u64.resize((size_t)n + 1); s.feat.resize((size_t)n + 1);
 	download(s.u32.data(), s.c_bodies.p, 8 * (size_t)n);
@@ -240,9 +255,29 @@ ContactImpulseData* read_cached_impulses(ContactCache contact_cache, ContactData
 	Session& s = session();
 	std::lock_guard<std::mutex> guard(s.lock);
 	s.init();
-	if (contacts.count != s.contacts.count) die("read_cached_impulses", "contacts were added or removed since collide()");
-	// the caller may have edited contact fields in place (custom friction etc.)
-	upload(s.c_data, contacts.data, sizeof(Contact) * (size_t)contacts.count);
+	if (contacts.count < s.host_contacts) die("read_cached_impulses", "contacts were removed since collide()");
+	if (contacts.count > contacts.capacity) die("read_cached_impulses", "contacts.count exceeds contacts.capacity");
+	if (contacts.count > s.host_contacts) {
+		// custom contacts appended behind the list collide() returned (example/main.cpp:287): up they go, widened, and into tag order on the device
+		const uint32_t old = s.host_contacts, extra = contacts.count - old;
+		if (!s.perm.empty()) die("read_cached_impulses", "contacts appended twice in one step");
+		hip_check(hipMemcpy(s.c_data.as<nh_Contact>() + old, contacts.data + old, sizeof(Contact) * (size_t)extra, hipMemcpyHostToDevice), "hipMemcpy H2D");
+		s.u32.resize(2 * (size_t)extra); s.u64.resize(extra); s.feat.resize(extra);
+		for (uint32_t i = 0; i < extra; ++i) {
+			s.u32[2 * i] = contacts.bodies[old + i].a; s.u32[2 * i + 1] = contacts.bodies[old + i].b;
+			widen_tag(contacts.tags[old + i], s.u64[i], s.feat[i]);
+		}
+		hip_check(hipMemcpy(s.c_bodies.as<nh_BodyPair>() + old, s.u32.data(), 8 * (size_t)extra, hipMemcpyHostToDevice), "hipMemcpy H2D");
+		hip_check(hipMemcpy(s.c_tags.as<uint64_t>() + old, s.u64.data(), 8 * (size_t)extra, hipMemcpyHostToDevice), "hipMemcpy H2D");
+		hip_check(hipMemcpy(s.c_features.as<uint32_t>() + old, s.feat.data(), 4 * (size_t)extra, hipMemcpyHostToDevice), "hipMemcpy H2D");
+		s.positions.reserve(4 * (size_t)contacts.capacity + 16);
+		nh_BodyData db = { s.body_xf.as<nh_Transform>(), s.body_props.as<nh_BodyProperties>(), s.body_mom.as<nh_BodyMomentum>(), s.body_idle.as<uint8_t>(), s.body_count };
+		check(nh_append_contacts(s.ctx, &s.contacts, &db, extra, s.positions.as<uint32_t>(), s.temporary), "append_contacts");
+		s.perm.resize(contacts.count);
+		download(s.perm.data(), s.positions.p, 4 * (size_t)contacts.count);
+		s.host_contacts = contacts.count;
+	}
+	upload_contact_data(s, contacts.data, contacts.count);
 	const uint32_t m = contact_cache.count, cap = contact_cache.capacity;
 	s.u64.resize((size_t)m + 1); s.feat.resize((size_t)m + 1);
 	for (uint32_t i = 0; i < m; ++i) widen_tag(contact_cache.tags[i], s.u64[i], s.feat[i]);
@@ -285,9 +320,9 @@ ContactConstraintData* setup_contact_constraints(ActiveBodies active_bodies, Con
 	std::lock_guard<std::mutex> guard(s.lock);
 	ImpulseHandle* h = reinterpret_cast<ImpulseHandle*>(contact_impulses);
 	if (!h || h->magic != IMPULSE_MAGIC) die("setup_contact_constraints", "not a ContactImpulseData of this backend");
-	if (contacts.count != s.contacts.count) die("setup_contact_constraints", "contacts were added or removed since collide()");
+	if (contacts.count != s.host_contacts) die("setup_contact_constraints", "contacts were added or removed since read_cached_impulses()");
 	(void)active_bodies;
-	upload(s.c_data, contacts.data, sizeof(Contact) * (size_t)contacts.count);
+	upload_contact_data(s, contacts.data, contacts.count);
 	nh_BodyData db = device_bodies(s, bodies, true, true, true, false);      // the gravity loop has touched momentum
 	nh_ContactConstraintData* dev = nullptr;
 	check(nh_setup_contact_constraints(s.ctx, &s.active_bodies, &s.contacts, &db, h->dev, &s.temporary, &dev), "setup_contact_constraints");

@@ -1375,3 +1375,124 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	ctx->after_collide = true;
 	return NH_OK;
 }
+
+// ---- contacts appended by the caller after nh_collide -----------------------------------------------------------------------------------------------
+// The reference lets its caller append contacts between collide() and read_cached_impulses() ("Custom contacts can be added here",
+// example/main.cpp:287): they simply take part in the tag sort of read_cached_impulses (nudge.cpp:4027-4044) and everything downstream walks the
+// sorted order.  Here the list nh_collide returns is already IN tag order and carries per-body bookkeeping counted while it was laid out (degrees,
+// pair counts, first contact), so appended contacts are merged into that order and the bookkeeping is counted again -- a slow path, paid only by
+// the steps that use it: one pass over all contacts.
+__device__ __forceinline__ bool app_less(uint64_t ta, uint32_t fa, uint64_t tb, uint32_t fb) { return ta < tb || (ta == tb && fa < fb); }
+
+// rank of every appended contact among the appended ones (ties: position), and the sorted keys
+__global__ __launch_bounds__(256) void k_app_rank(const nh_DevState* __restrict__ st, uint32_t extra, const uint64_t* __restrict__ tags, const uint32_t* __restrict__ features,
+                                                  uint32_t* __restrict__ rank, uint64_t* __restrict__ skey, uint32_t* __restrict__ sfeat) {
+	const uint32_t K = st->contacts;
+	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < extra; j += gridDim.x * blockDim.x) {
+		const uint64_t t = tags[K + j]; const uint32_t f = features[K + j];
+		uint32_t r = 0;
+		for (uint32_t i = 0; i < extra; ++i) {
+			const uint64_t ti = tags[K + i]; const uint32_t fi = features[K + i];
+			r += (app_less(ti, fi, t, f) || (ti == t && fi == f && i < j)) ? 1u : 0u;
+		}
+		rank[j] = r; skey[r] = t; sfeat[r] = f;
+	}
+}
+
+// new position of every contact: an old one moves up by the appended ones that sort before it, an appended one lands behind the old ones with a key <= its own
+__global__ __launch_bounds__(256) void k_app_positions(const nh_DevState* __restrict__ st, uint32_t extra, const uint64_t* __restrict__ tags, const uint32_t* __restrict__ features,
+                                                       const uint32_t* __restrict__ rank, const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sfeat, uint32_t* __restrict__ pos) {
+	const uint32_t K = st->contacts;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < K + extra; i += gridDim.x * blockDim.x) {
+		const uint64_t t = tags[i]; const uint32_t f = features[i];
+		if (i < K) {
+			uint32_t lo = 0, hi = extra;                         // appended contacts with a key < (t, f)
+			while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (app_less(skey[mid], sfeat[mid], t, f)) lo = mid + 1u; else hi = mid; }
+			pos[i] = i + lo;
+		} else {
+			uint32_t lo = 0, hi = K;                             // old contacts with a key <= (t, f)
+			while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (!app_less(t, f, tags[mid], features[mid])) lo = mid + 1u; else hi = mid; }
+			pos[i] = rank[i - K] + lo;
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_app_copy(const nh_DevState* __restrict__ st, uint32_t extra, const nh_Contact* __restrict__ data, const nh_BodyPair* __restrict__ bodies,
+                                                  const uint64_t* __restrict__ tags, const uint32_t* __restrict__ features, float4* __restrict__ t_data, nh_BodyPair* __restrict__ t_bodies,
+                                                  uint64_t* __restrict__ t_tags, uint32_t* __restrict__ t_features) {
+	const uint32_t n = st->contacts + extra;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		t_data[2 * (size_t)i] = reinterpret_cast<const float4*>(data + i)[0]; t_data[2 * (size_t)i + 1] = reinterpret_cast<const float4*>(data + i)[1];
+		t_bodies[i] = bodies[i]; t_tags[i] = tags[i]; t_features[i] = features[i];
+	}
+}
+
+__global__ __launch_bounds__(256) void k_app_scatter(const nh_DevState* __restrict__ st, uint32_t extra, const uint32_t* __restrict__ pos, const float4* __restrict__ t_data,
+                                                     const nh_BodyPair* __restrict__ t_bodies, const uint64_t* __restrict__ t_tags, const uint32_t* __restrict__ t_features,
+                                                     nh_Contact* __restrict__ data, nh_BodyPair* __restrict__ bodies, uint64_t* __restrict__ tags, uint32_t* __restrict__ features) {
+	const uint32_t n = st->contacts + extra;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const uint32_t p = pos[i];
+		reinterpret_cast<float4*>(data + p)[0] = t_data[2 * (size_t)i]; reinterpret_cast<float4*>(data + p)[1] = t_data[2 * (size_t)i + 1];
+		bodies[p] = t_bodies[i]; tags[p] = t_tags[i]; features[p] = t_features[i];
+	}
+}
+
+// the per-body bookkeeping of k_gather_contacts, from the merged list: a run of equal tags is one collider pair
+__global__ __launch_bounds__(256) void k_app_recount(nh_DevState* __restrict__ st, uint32_t extra, const nh_BodyPair* __restrict__ bodies, const uint64_t* __restrict__ tags,
+                                                     uint32_t* __restrict__ deg, uint32_t nbodies) {
+	uint32_t* __restrict__ info = deg + 2u * (nbodies + 2u);
+	uint32_t* __restrict__ first_contact = deg + 3u * (nbodies + 2u);
+	const uint32_t n = st->contacts + extra;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		if (i > 0 && tags[i - 1] == tags[i]) continue;          // not the head of its run
+		const uint64_t t = tags[i];
+		uint32_t len = 1;
+		while (i + len < n && tags[i + len] == t) ++len;
+		const nh_BodyPair p = bodies[i];
+		if (p.a) { atomicAdd(&deg[p.a], len); atomicAdd(&info[p.a], p.b ? 0x10001u : 1u); first_contact[p.a] = i | 0x80000000u; }
+		if (p.b) { atomicAdd(&deg[p.b], len); atomicAdd(&info[p.b], p.a ? 0x10001u : 1u); first_contact[p.b] = i; }
+	}
+}
+
+__global__ void k_app_count(nh_DevState* st, uint32_t extra, uint32_t capacity) {
+	if (st->contacts + extra > capacity) st->error = NH_ERR_CONTACT_CAPACITY; else st->contacts += extra;
+}
+
+extern "C" int nh_append_contacts(nh_context* ctx, nh_ContactData* contacts, const nh_BodyData* bodies, uint32_t extra, uint32_t* positions, nh_Arena temporary) {
+	if (!ctx || !contacts || !bodies) return NH_ERR_INVALID;
+	if (!extra) return NH_OK;
+	if (extra > 65536u || extra > contacts->capacity) return NH_ERR_INVALID;      // (the appended contacts are ranked against each other by comparison: a slow path for a handful)
+	if (ctx->setup_seq == ctx->collide_seq || !ctx->deg) return NH_ERR_STALE_SETUP;      // after nh_collide, before nh_read_cached_impulses / nh_setup_contact_constraints
+	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	nh_DevState* st = ctx->d_state;
+	const uint32_t cap = contacts->capacity, B = bodies->count;
+	int err = NH_OK;
+	uint32_t* rank = nh_arena_array<uint32_t>(&temporary, extra, &err);
+	uint64_t* skey = nh_arena_array<uint64_t>(&temporary, extra, &err);
+	uint32_t* sfeat = nh_arena_array<uint32_t>(&temporary, extra, &err);
+	uint32_t* pos = positions ? positions : nh_arena_array<uint32_t>(&temporary, cap, &err);
+	float4* t_data = nh_arena_array<float4>(&temporary, 2 * (size_t)cap, &err);
+	nh_BodyPair* t_bodies = nh_arena_array<nh_BodyPair>(&temporary, cap, &err);
+	uint64_t* t_tags = nh_arena_array<uint64_t>(&temporary, cap, &err);
+	uint32_t* t_features = nh_arena_array<uint32_t>(&temporary, cap, &err);
+	if (err) return err;
+	if ((ctx->flags & NH_FLAG_SYNC_COUNTS) && (uint64_t)contacts->count + extra > cap) return NH_ERR_CONTACT_CAPACITY;
+	NH_LAUNCH(ctx, "append_rank", k_app_rank, nh_grid_for(extra, 256, 1024), 256, st, extra, contacts->tags, contacts->features, rank, skey, sfeat);
+	NH_LAUNCH(ctx, "append_positions", k_app_positions, nh_grid_for(cap, 256, 2048), 256, st, extra, contacts->tags, contacts->features, rank, skey, sfeat, pos);
+	NH_LAUNCH(ctx, "append_copy", k_app_copy, nh_grid_for(cap, 256, 2048), 256, st, extra, contacts->data, contacts->bodies, contacts->tags, contacts->features, t_data, t_bodies, t_tags, t_features);
+	NH_LAUNCH(ctx, "append_scatter", k_app_scatter, nh_grid_for(cap, 256, 2048), 256, st, extra, pos, t_data, t_bodies, t_tags, t_features, contacts->data, contacts->bodies, contacts->tags, contacts->features);
+	// degrees, pair info, first contact: counted again (the fill cursors in between stay zero)
+	NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(uint32_t) * (size_t)(B + 2u), ctx->stream));
+	NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->deg + 2u * (size_t)(B + 2u), 0, sizeof(uint32_t) * 2u * (size_t)(B + 2u), ctx->stream));
+	NH_LAUNCH(ctx, "append_recount", k_app_recount, nh_grid_for(cap, 256, 2048), 256, st, extra, contacts->bodies, contacts->tags, ctx->deg, B);
+	NH_LAUNCH(ctx, "append_count", k_app_count, 1, 1, st, extra, cap);
+	if (ctx->flags & NH_FLAG_SYNC_COUNTS) {
+		nh_Counts c;
+		int rc = nh_read_counts(ctx, &c);
+		if (rc) return rc;
+		if (c.error) return (int)c.error;
+		contacts->count = c.contacts;
+	}
+	return NH_OK;
+}

@@ -32,7 +32,7 @@ EXPORTS = [
     "nh_set_tag_bits", "nh_set_pair_capacity", "nh_bodies_changed", "nh_error_string", "nh_last_hip_error", "nh_collide", "nh_apply_gravity_damping",
     "nh_read_cached_impulses", "nh_write_cached_impulses", "nh_setup_contact_constraints", "nh_apply_impulses",
     "nh_update_cached_impulses", "nh_advance", "nh_contact_impulses_device", "nh_enable_timing", "nh_set_timing_filter", "nh_kernel_times",
-    "nh_halo_pack", "nh_halo_unpack",
+    "nh_halo_pack", "nh_halo_unpack", "nh_append_contacts",
 ]
 HALO_RECORD_BYTES = 64
 
@@ -129,6 +129,7 @@ def lib():
         L.nh_kernel_times.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int, C.c_int]
         L.nh_halo_pack.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_void_p, C.c_uint32, C.c_void_p]
         L.nh_halo_unpack.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_uint32, C.c_uint32, C.c_void_p]
+        L.nh_append_contacts.argtypes = [C.c_void_p, C.POINTER(ContactData), C.POINTER(BodyData), C.c_uint32, C.c_void_p, Arena]
         _LIB = L
     return _LIB
 
@@ -241,6 +242,23 @@ class World:
         _check(self.L, self.L.nh_collide(self.ctx, C.byref(self.active), C.byref(self.contacts), C.byref(self.bodies),
                                          C.byref(self.colliders), C.byref(self.connections), self.arena), "nh_collide")
         self._temp = Arena(self.arena.data, self.arena.size)
+
+    def append_contacts(self, data, bodies, tags, features, count=None):
+        """Custom contacts behind the list collide() returned (reference example/main.cpp:287): numpy arrays of S.CONTACT records, (n, 2) uint32
+        body pairs, uint64 tags (a_tag | b_tag << 32) and uint32 features; `count` = contacts so far (read from the device when not given)."""
+        torch = self.torch
+        n = len(tags)
+        if n == 0:
+            return
+        k = self.counts()["contacts"] if count is None else count
+        if k + n > self.max_contacts:
+            raise NudgeError("append_contacts: contact capacity")
+        for name, arr, width in (("cd", np.ascontiguousarray(data), 32), ("cb", np.ascontiguousarray(bodies, dtype=np.uint32), 8),
+                                 ("ct", np.ascontiguousarray(tags, dtype=np.uint64), 8), ("cf", np.ascontiguousarray(features, dtype=np.uint32), 4)):
+            raw = arr.view(np.uint8).reshape(-1)
+            assert raw.size == width * n, name
+            self._keep[name][width * k:width * (k + n)] = torch.from_numpy(raw.copy()).to(self.dev)
+        _check(self.L, self.L.nh_append_contacts(self.ctx, C.byref(self.contacts), C.byref(self.bodies), n, None, self.arena), "append_contacts")
 
     def gravity(self):
         p = self.params

@@ -14,6 +14,8 @@
 //   zero_iterations   never calls apply_impulses: the warm start applied by setup_contact_constraints (nudge.cpp:4563-4632) is all the solver does
 //   peek_after_setup  reads bodies.momentum right after setup_contact_constraints (folds it into the checksum): the warm start must be visible there
 //   custom_impulses   user impulses between two apply_impulses calls, the way custom constraints interleave (example/main.cpp:314-317)
+//   custom_contacts   contacts appended behind the list collide() returned ("Custom contacts can be added here", example/main.cpp:287): a soft
+//                     "shelf" that the first dynamic bodies rest against, with tags no collider pair produces
 // scene.bin: u32 header { bodies, boxes, spheres, iterations, max_contacts } + f32 { time_step, gravity, damping_rate }
 //            then Transform[bodies] BodyProperties[bodies] BodyMomentum[bodies] u8 idle[bodies]
 //            u16 box_tags[boxes] BoxCollider[boxes] Transform[boxes] u16 sphere_tags[spheres] SphereCollider[spheres] Transform[spheres]
@@ -53,7 +55,8 @@ int main(int argc, char** argv) {
 	const unsigned steps = (unsigned)atoi(argv[3]);
 	const char* mode = argc > 4 ? argv[4] : "plain";
 	const bool zero_iterations = !strcmp(mode, "zero_iterations"), peek = !strcmp(mode, "peek_after_setup"), custom = !strcmp(mode, "custom_impulses");
-	if (!zero_iterations && !peek && !custom && strcmp(mode, "plain") && strcmp(mode, "exact")) { fprintf(stderr, "replay: unknown mode %s\n", mode); return 2; }
+	const bool custom_contacts = !strcmp(mode, "custom_contacts");
+	if (!zero_iterations && !peek && !custom && !custom_contacts && strcmp(mode, "plain") && strcmp(mode, "exact")) { fprintf(stderr, "replay: unknown mode %s\n", mode); return 2; }
 	uint64_t checksum = 1469598103934665603ull;      // FNV-1a over whatever the mode looks at
 
 	nudge::BodyData bodies = {};
@@ -111,6 +114,25 @@ int main(int argc, char** argv) {
 		nudge::BodyConnections connections = {};
 		nudge::collide(&active, &contacts, bodies, colliders, connections, temporary);
 		sum_contacts += contacts.count;
+		if (custom_contacts) {
+			// "Custom contacts can be added here" (example/main.cpp:287): every one of the first dynamic bodies gets two contacts with the static world
+			// -- a floor under it at y = 3 (only while it is below) and a gentle sideways push -- tagged with collider tags nobody uses
+			for (unsigned b = 1; b < nb && b <= 12 && contacts.count + 2 <= contacts.capacity; ++b) {
+				const float* p = bodies.transforms[b].position;
+				for (unsigned k = 0; k < 2; ++k) {
+					if (k == 0 && p[1] > 3.0f) continue;
+					nudge::Contact c = {};
+					c.position[0] = p[0]; c.position[1] = k == 0 ? p[1] - 0.25f : p[1]; c.position[2] = p[2];
+					c.penetration = k == 0 ? (3.0f - p[1] < 0.2f ? 3.0f - p[1] : 0.2f) : 0.01f;
+					c.normal[0] = k == 0 ? 0.0f : 1.0f; c.normal[1] = k == 0 ? 1.0f : 0.0f; c.normal[2] = 0.0f;       // from a (the static world) towards b
+					c.friction = 0.25f;
+					const unsigned i = contacts.count++;
+					contacts.data[i] = c;
+					contacts.bodies[i].a = 0; contacts.bodies[i].b = (uint16_t)b;
+					contacts.tags[i] = ((uint64_t)(0x7000u + k) | ((uint64_t)(0x7100u + b) << 16)) << 32 | (uint64_t)(k + 1u);
+				}
+			}
+		}
 
 		// caller-side gravity and damping over the active list
 		const float damping = 1.0f - time_step * damping_rate;

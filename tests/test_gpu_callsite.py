@@ -93,6 +93,28 @@ def test_unusual_call_patterns_two_backends_bit_identical(name, mode, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,steps", [("pile256", 300), ("grid30", 220), ("mixed20", 150)])
+def test_custom_contacts_appended_after_collide_two_backends_bit_identical(name, steps, tmp_path):
+    """"Custom contacts can be added here" (example/main.cpp:287): the call site appends contacts of its own behind the list collide() returned --
+    a floor at y = 3 under the first dynamic bodies and a sideways push, with tags no collider pair produces -- and bumps contacts.count.  The
+    reference sorts them in with everybody else (nudge.cpp:4027-4044); the drop-in uploads them, nh_append_contacts merges them into the
+    device's tag order and counts the per-body bookkeeping again.  Same source file, two backends, bit-identical worlds."""
+    assert os.path.exists(CU.REPLAY_HIP), "nudge_amd/compat/_build/replay_hip missing: make -C nudge_amd/compat"
+    assert os.path.exists(CU.REPLAY_REF), "oracle/_ref/replay_ref missing: make -C oracle"
+    scene, _ = _build(name)
+    nb = CU.write_scene(str(tmp_path / "s.bin"), scene)
+    CU.run_replay(CU.REPLAY_HIP, str(tmp_path / "s.bin"), str(tmp_path / "hip.bin"), steps, extra=["custom_contacts"])
+    CU.run_replay(CU.REPLAY_REF, str(tmp_path / "s.bin"), str(tmp_path / "ref.bin"), steps, extra=["custom_contacts"])
+    CU.run_replay(CU.REPLAY_REF, str(tmp_path / "s.bin"), str(tmp_path / "plain.bin"), steps)
+    got, ref, plain = (CU.read_result(str(tmp_path / f), nb) for f in ("hip.bin", "ref.bin", "plain.bin"))
+    assert not P.bits_equal(ref["transforms"], plain["transforms"]), "the custom contacts were meant to change the outcome"
+    assert P.bits_equal(got["transforms"], ref["transforms"])
+    assert P.bits_equal(got["momentum"], ref["momentum"])
+    assert P.bits_equal(got["idle"], ref["idle"])
+    assert got["sum_contacts"] == ref["sum_contacts"] and got["last_contacts"] == ref["last_contacts"]
+
+
+@pytest.mark.gpu
 def test_reference_own_test_program_passes_on_the_gpu_backend():
     assert os.path.exists(CU.REF_TESTS_HIP), "nudge_amd/compat/_build/ref_tests_hip missing: make -C nudge_amd/compat"
     r = subprocess.run([CU.REF_TESTS_HIP], capture_output=True, text=True, timeout=1500)

@@ -829,3 +829,42 @@ def test_garbage_colour_seeds_in_the_cache_are_caught(side):
         outs.append(b)
         w.close()
     assert P.bits_equal(outs[0]["transforms"], outs[1]["transforms"]) and P.bits_equal(outs[0]["momentum"], outs[1]["momentum"])
+
+
+def test_append_contacts_through_the_resident_abi():
+    """nh_append_contacts on the device-resident boundary, default solver order, with and without NH_FLAG_SYNC_COUNTS: custom contacts that hold the
+    first dynamic boxes of a drop tile up at y = 3 (the tile's ground is at y = -10).  The two flag sets agree bit for bit, the boxes rest on their
+    custom floor, and a list that would overflow the capacity is refused."""
+    scene, _ = G.build("grid30")
+    held = np.arange(1, 9)
+
+    def run(flags):
+        w = E.World(scene, flags=flags)
+        for _ in range(260):
+            w.collide()
+            pos = w.get_bodies()["transforms"]["position"][held]
+            low = pos[:, 1] <= 3.0
+            data = np.zeros(int(low.sum()), dtype=S.CONTACT)
+            data["position"] = pos[low] - np.array([0.0, 0.25, 0.0], dtype=np.float32)
+            data["penetration"] = np.minimum(3.0 - pos[low, 1], 0.2)
+            data["normal"] = (0.0, 1.0, 0.0)
+            data["friction"] = 0.25
+            bodies = np.stack([np.zeros(int(low.sum()), np.uint32), held[low].astype(np.uint32)], axis=1)
+            tags = (np.uint64(0x70000) | ((held[low].astype(np.uint64) + np.uint64(0x71000)) << np.uint64(32)))
+            w.append_contacts(data, bodies, tags, np.ones(int(low.sum()), np.uint32))
+            w.gravity(); w.read_cache(); w.setup(); w.apply(); w.update(); w.write_cache(); w.advance()
+        assert w.counts()["error"] == 0
+        return w, w.get_bodies()
+
+    wa, a = run(FAST)
+    wb, b = run(0)
+    assert P.bits_equal(a["transforms"], b["transforms"]) and P.bits_equal(a["momentum"], b["momentum"])
+    y = a["transforms"]["position"][:, 1]
+    assert np.all(np.abs(y[held] - 3.0) < 0.1), y[held]                 # resting on the custom floor
+    assert np.all(y[9:] < -8.0)                                          # everybody else on the ground
+    wa.collide()
+    k = wa.counts()["contacts"]
+    n = wa.max_contacts - k + 1
+    with pytest.raises(E.NudgeError, match="capacity"):
+        wa.append_contacts(np.zeros(n, dtype=S.CONTACT), np.zeros((n, 2), np.uint32), np.zeros(n, np.uint64), np.zeros(n, np.uint32))
+    wa.close(); wb.close()
