@@ -27,13 +27,18 @@
 //     match an exact-math build of the reference bit for bit; the x86 approximate rsqrt/rcp of the shipped build
 //     are not reproduced (their bits are CPU-vendor specific).
 //
-// Thread model: one process-wide world at a time (the reference is re-entrant; this layer serialises on a mutex).
+// Thread model: like the reference (no global mutable state, re-entrant for disjoint worlds, one thread per world at a time): every WORLD -- identified
+// by the caller's arrays: bodies.transforms and contacts.data, which the reference API hands to every entry point that carries no opaque handle -- has
+// its own session here (device mirrors, nh_context, HIP stream, mutex); sessions are found through a small registry.  Two threads stepping two worlds
+// run concurrently; two threads inside ONE world are the caller's bug in the reference too (SURVEY 8(b) threading) and are serialised.
 #include <nudge.h>
 
 #include "../../include/nudge_hip.h"
 
 #include <hip/hip_runtime_api.h>
 
+#include <map>
+#include <memory>
 #include <mutex>
 #include <stdint.h>
 #include <stdio.h>
@@ -103,17 +108,50 @@ struct Session {
 	std::vector<nudge::Contact> staged_contacts;
 	uint32_t host_contacts = 0;          // contacts.count as the caller sees it
 
+	hipStream_t stream = nullptr;
 	void init() {
 		if (ctx) return;
 		int device = 0;
 		if (const char* s = getenv("NUDGE_HIP_DEVICE")) device = atoi(s);
-		int rc = nh_create(&ctx, device, nullptr, NH_FLAG_SYNC_COUNTS | NH_FLAG_EXACT_ORDER);
+		hip_check(hipSetDevice(device), "hipSetDevice");
+		// a stream of the world's own (a blocking one: the synchronous copies of this layer, on the legacy default stream, stay ordered with its kernels)
+		hip_check(hipStreamCreate(&stream), "hipStreamCreate");
+		int rc = nh_create(&ctx, device, stream, NH_FLAG_SYNC_COUNTS | NH_FLAG_EXACT_ORDER);
 		if (rc) die("nh_create", nh_error_string(rc));
 		nh_set_tag_bits(ctx, 16);       // the reference's collider tags are 16-bit (nudge.h:86, 93)
 	}
 };
 
-Session& session() { static Session s; return s; }
+// worlds by the caller's arrays.  The registry lock is held only while looking up / registering; a session's own lock for the duration of a call.
+struct Registry {
+	std::mutex lock;
+	std::map<const void*, Session*> by_key;
+	std::vector<std::unique_ptr<Session>> all;
+};
+Registry& registry() { static Registry r; return r; }
+
+// collide(): the world of these bodies / this contact list, created on first sight
+Session& session_of_world(const void* body_transforms, const void* contact_data) {
+	Registry& r = registry();
+	std::lock_guard<std::mutex> guard(r.lock);
+	Session* s = nullptr;
+	auto a = r.by_key.find(body_transforms);
+	if (a != r.by_key.end()) s = a->second;
+	if (!s) { auto b = r.by_key.find(contact_data); if (b != r.by_key.end()) s = b->second; }
+	if (!s) { r.all.emplace_back(new Session()); s = r.all.back().get(); }
+	if (body_transforms) r.by_key[body_transforms] = s;
+	if (contact_data) r.by_key[contact_data] = s;
+	return *s;
+}
+
+// any later entry point without an opaque handle: the world collide() registered these arrays for
+Session& session_by_key(const void* key, const char* who) {
+	Registry& r = registry();
+	std::lock_guard<std::mutex> guard(r.lock);
+	auto a = r.by_key.find(key);
+	if (a == r.by_key.end()) die(who, "these arrays belong to no world that collide() has seen");
+	return *a->second;
+}
 
 void check(int rc, const char* what) { if (rc) die(what, nh_error_string(rc)); }
 
@@ -158,8 +196,8 @@ void upload_contact_data(Session& s, const nudge::Contact* data, uint32_t n) {
 }
 
 // opaque results: handles in the caller's arena (reference nudge.cpp:4022, 4174 allocate theirs there too)
-struct ImpulseHandle { uint64_t magic; nh_ContactImpulseData* dev; };
-struct ConstraintHandle { uint64_t magic; nh_ContactConstraintData* dev; };
+struct ImpulseHandle { uint64_t magic; nh_ContactImpulseData* dev; Session* world; };
+struct ConstraintHandle { uint64_t magic; nh_ContactConstraintData* dev; Session* world; };
 const uint64_t IMPULSE_MAGIC = 0x6e68496d70756c73ull, CONSTRAINT_MAGIC = 0x6e68436f6e737472ull;
 
 void* arena_take(nudge::Arena* arena, uintptr_t size, uintptr_t alignment) {
@@ -177,7 +215,7 @@ namespace nudge {
 
 // nudge.h:134, nudge.cpp:3000-4009
 void collide(ActiveBodies* active_bodies, ContactData* contacts, BodyData bodies, ColliderData colliders, BodyConnections body_connections, Arena /*temporary: scratch is device memory*/) {
-	Session& s = session();
+	Session& s = session_of_world(bodies.transforms, contacts->data);
 	std::lock_guard<std::mutex> guard(s.lock);
 	s.init();
 	const uint32_t nbox = colliders.boxes.count, nsph = colliders.spheres.count, K = contacts->capacity;
@@ -252,7 +290,7 @@ void collide(ActiveBodies* active_bodies, ContactData* contacts, BodyData bodies
 
 // nudge.h:136, nudge.cpp:4021-4108
 ContactImpulseData* read_cached_impulses(ContactCache contact_cache, ContactData contacts, Arena* memory) {
-	Session& s = session();
+	Session& s = session_by_key(contacts.data, "read_cached_impulses");
 	std::lock_guard<std::mutex> guard(s.lock);
 	s.init();
 	if (contacts.count < s.host_contacts) die("read_cached_impulses", "contacts were removed since collide()");
@@ -290,16 +328,16 @@ ContactImpulseData* read_cached_impulses(ContactCache contact_cache, ContactData
 	nh_ContactImpulseData* dev = nullptr;
 	check(nh_read_cached_impulses(s.ctx, &dk, &s.contacts, &s.temporary, &dev), "read_cached_impulses");
 	ImpulseHandle* h = static_cast<ImpulseHandle*>(arena_take(memory, sizeof(ImpulseHandle), 16));
-	h->magic = IMPULSE_MAGIC; h->dev = dev;
+	h->magic = IMPULSE_MAGIC; h->dev = dev; h->world = &s;
 	return reinterpret_cast<ContactImpulseData*>(h);
 }
 
 // nudge.h:138, nudge.cpp:4110-4158
 void write_cached_impulses(ContactCache* contact_cache, ContactData contacts, ContactImpulseData* contact_impulses) {
-	Session& s = session();
-	std::lock_guard<std::mutex> guard(s.lock);
 	ImpulseHandle* h = reinterpret_cast<ImpulseHandle*>(contact_impulses);
 	if (!h || h->magic != IMPULSE_MAGIC) die("write_cached_impulses", "not a ContactImpulseData of this backend");
+	Session& s = *h->world;
+	std::lock_guard<std::mutex> guard(s.lock);
 	(void)contacts;
 	const uint32_t cap = contact_cache->capacity;
 	s.k_tags.reserve(8 * (size_t)cap + 16); s.k_features.reserve(4 * (size_t)cap + 16); s.k_data.reserve(16 * (size_t)cap + 16);
@@ -316,10 +354,10 @@ void write_cached_impulses(ContactCache* contact_cache, ContactData contacts, Co
 
 // nudge.h:140, nudge.cpp:4170-4638
 ContactConstraintData* setup_contact_constraints(ActiveBodies active_bodies, ContactData contacts, BodyData bodies, ContactImpulseData* contact_impulses, Arena* memory) {
-	Session& s = session();
-	std::lock_guard<std::mutex> guard(s.lock);
 	ImpulseHandle* h = reinterpret_cast<ImpulseHandle*>(contact_impulses);
 	if (!h || h->magic != IMPULSE_MAGIC) die("setup_contact_constraints", "not a ContactImpulseData of this backend");
+	Session& s = *h->world;
+	std::lock_guard<std::mutex> guard(s.lock);
 	if (contacts.count != s.host_contacts) die("setup_contact_constraints", "contacts were added or removed since read_cached_impulses()");
 	(void)active_bodies;
 	upload_contact_data(s, contacts.data, contacts.count);
@@ -331,16 +369,16 @@ ContactConstraintData* setup_contact_constraints(ActiveBodies active_bodies, Con
 	check(nh_synchronize(s.ctx), "synchronize");
 	download(bodies.momentum, s.body_mom.p, sizeof(BodyMomentum) * (size_t)bodies.count);     // warm start + unused0 (4198)
 	ConstraintHandle* c = static_cast<ConstraintHandle*>(arena_take(memory, sizeof(ConstraintHandle), 16));
-	c->magic = CONSTRAINT_MAGIC; c->dev = dev;
+	c->magic = CONSTRAINT_MAGIC; c->dev = dev; c->world = &s;
 	return reinterpret_cast<ContactConstraintData*>(c);
 }
 
 // nudge.h:142, nudge.cpp:4640-4855
 void apply_impulses(ContactConstraintData* data, BodyData bodies) {
-	Session& s = session();
-	std::lock_guard<std::mutex> guard(s.lock);
 	ConstraintHandle* c = reinterpret_cast<ConstraintHandle*>(data);
 	if (!c || c->magic != CONSTRAINT_MAGIC) die("apply_impulses", "not a ContactConstraintData of this backend");
+	Session& s = *c->world;
+	std::lock_guard<std::mutex> guard(s.lock);
 	nh_BodyData db = device_bodies(s, bodies, false, false, true, false);    // custom constraint impulses may have touched momentum
 	check(nh_apply_impulses(s.ctx, c->dev, &db, 1), "apply_impulses");
 	download(bodies.momentum, s.body_mom.p, sizeof(BodyMomentum) * (size_t)bodies.count);
@@ -348,17 +386,17 @@ void apply_impulses(ContactConstraintData* data, BodyData bodies) {
 
 // nudge.h:144, nudge.cpp:4857-4884
 void update_cached_impulses(ContactConstraintData* data, ContactImpulseData* contact_impulses) {
-	Session& s = session();
-	std::lock_guard<std::mutex> guard(s.lock);
 	ConstraintHandle* c = reinterpret_cast<ConstraintHandle*>(data);
 	ImpulseHandle* h = reinterpret_cast<ImpulseHandle*>(contact_impulses);
-	if (!c || c->magic != CONSTRAINT_MAGIC || !h || h->magic != IMPULSE_MAGIC) die("update_cached_impulses", "foreign opaque data");
+	if (!c || c->magic != CONSTRAINT_MAGIC || !h || h->magic != IMPULSE_MAGIC || c->world != h->world) die("update_cached_impulses", "foreign opaque data");
+	Session& s = *c->world;
+	std::lock_guard<std::mutex> guard(s.lock);
 	check(nh_update_cached_impulses(s.ctx, c->dev, h->dev), "update_cached_impulses");
 }
 
 // nudge.h:146, nudge.cpp:4886-4926
 void advance(ActiveBodies active_bodies, BodyData bodies, float time_step) {
-	Session& s = session();
+	Session& s = session_by_key(bodies.transforms, "advance");
 	std::lock_guard<std::mutex> guard(s.lock);
 	s.init();
 	nh_BodyData db = device_bodies(s, bodies, true, false, true, true);

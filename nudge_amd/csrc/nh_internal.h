@@ -188,6 +188,7 @@ struct nh_context {
 	// behaviour switches read ONCE from the environment by nh_create (test / A-B knobs, see nh_context.hip)
 	bool env_sort_classic, env_sort_radix, env_colour_jp, env_no_resident, env_colour_check_seeds;
 	int env_solver_waves, env_fp_sub;
+	bool os_plain_launch;                 // cooperative launches are not available here: the radix passes use plain launches bounded by os_resident
 	int os_resident;                      // co-resident workgroups of a one-kernel radix pass on THIS device (nh_util.hip), 0 = not yet asked
 	// tag sort seeded by the previous step's order (nh_util.hip): splitters persist across steps; counts / starts are scratch that must
 	// outlive nothing but is zeroed by its own kernels.  `sort_seeded`: the splitters describe the previous nh_collide of this capacity

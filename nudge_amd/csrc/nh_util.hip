@@ -332,9 +332,26 @@ static int onesweep_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* va
 	hipError_t e = hipMemsetAsync(scratch, 0, sizeof(uint32_t) * (size_t)sh.n * OS_PASS_WORDS, ctx->stream);
 	if (ctx->timing) nh_timer_end(ctx);
 	if (e != hipSuccess) ctx->last_hip_error = (int)e;
+	// The workgroups of a pass wait for each other (earlier counts, group sums): all of them MUST be resident at once.  A cooperative launch makes
+	// that the runtime's promise instead of an occupancy estimate of ours (another process or stream holding compute units cannot turn the wait
+	// into a hang); if the runtime finds the grid too large for this device it is halved -- any grid sorts correctly, workgroups then own more tiles.
+	uint32_t g = grid;
 	for (int p = 0; p < sh.n; ++p) {
 		uint32_t* c = scratch + (size_t)p * OS_PASS_WORDS;
-		NH_LAUNCH(ctx, "radix_pass", (os_pass<K, V, HAS_V>), grid, 256, kin, kout, vin, vout, d_count, c, c + (size_t)OS_MAX_GRID * 256, sh.s[p]);
+		uint32_t* c2 = c + (size_t)OS_MAX_GRID * 256;
+		int shift = sh.s[p];
+		void* args[] = { (void*)&kin, (void*)&kout, (void*)&vin, (void*)&vout, (void*)&d_count, (void*)&c, (void*)&c2, (void*)&shift };
+		if (ctx->timing) nh_timer_begin(ctx, "radix_pass");
+		hipError_t le = hipErrorUnknown;
+		while (!ctx->os_plain_launch) {
+			le = hipLaunchCooperativeKernel((const void*)os_pass<K, V, HAS_V>, dim3(g), dim3(256), args, 0, ctx->stream);
+			if (le == hipSuccess) break;
+			(void)hipGetLastError();
+			if (le == hipErrorCooperativeLaunchTooLarge && g > 16u) { g /= 2u; resident = (int)g; continue; }
+			ctx->os_plain_launch = true;           // no cooperative launches on this device / runtime: the occupancy-bounded plain launch, as before
+		}
+		if (ctx->os_plain_launch) hipLaunchKernelGGL((os_pass<K, V, HAS_V>), dim3(g), dim3(256), 0, ctx->stream, kin, kout, vin, vout, d_count, c, c2, shift);
+		if (ctx->timing) nh_timer_end(ctx);
 		K* tk = kin; kin = kout; kout = tk;
 		V* tv = vin; vin = vout; vout = tv;
 	}

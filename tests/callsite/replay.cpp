@@ -14,6 +14,8 @@
 //   zero_iterations   never calls apply_impulses: the warm start applied by setup_contact_constraints (nudge.cpp:4563-4632) is all the solver does
 //   peek_after_setup  reads bodies.momentum right after setup_contact_constraints (folds it into the checksum): the warm start must be visible there
 //   custom_impulses   user impulses between two apply_impulses calls, the way custom constraints interleave (example/main.cpp:314-317)
+//   two_worlds        the plain loop on TWO copies of the scene, each with arrays of its own, stepped by two threads at once: the reference has no global
+//                     mutable state and is re-entrant for disjoint worlds (SURVEY 8(b) threading); both worlds must end up alike (exit code 3 otherwise)
 //   custom_contacts   contacts appended behind the list collide() returned ("Custom contacts can be added here", example/main.cpp:287): a soft
 //                     "shelf" that the first dynamic bodies rest against, with tags no collider pair produces
 // scene.bin: u32 header { bodies, boxes, spheres, iterations, max_contacts } + f32 { time_step, gravity, damping_rate }
@@ -27,6 +29,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <thread>
 #include <vector>
 
 template<class T>
@@ -42,8 +45,24 @@ static void read_array(FILE* f, T* dst, size_t n) {
 	if (n && fread(dst, sizeof(T), n, f) != n) { fprintf(stderr, "replay: short scene file\n"); exit(2); }
 }
 
+static int world_main(int argc, char** argv, bool write_output, std::vector<unsigned char>* final_state);
+
 int main(int argc, char** argv) {
-	if (argc < 4) { fprintf(stderr, "usage: %s scene.bin out.bin steps\n", argv[0]); return 2; }
+	if (argc < 4) { fprintf(stderr, "usage: %s scene.bin out.bin steps [mode]\n", argv[0]); return 2; }
+	if (argc > 4 && !strcmp(argv[4], "two_worlds")) {
+		std::vector<unsigned char> a, b;
+		int rb = 0;
+		std::thread other([&] { rb = world_main(argc, argv, false, &b); });
+		const int ra = world_main(argc, argv, true, &a);
+		other.join();
+		if (ra || rb) return ra ? ra : rb;
+		if (a != b) { fprintf(stderr, "replay: the two worlds differ\n"); return 3; }
+		return 0;
+	}
+	return world_main(argc, argv, true, nullptr);
+}
+
+static int world_main(int argc, char** argv, bool write_output, std::vector<unsigned char>* final_state) {
 	FILE* f = fopen(argv[1], "rb");
 	if (!f) { perror(argv[1]); return 2; }
 	uint32_t head[5];
@@ -56,7 +75,7 @@ int main(int argc, char** argv) {
 	const char* mode = argc > 4 ? argv[4] : "plain";
 	const bool zero_iterations = !strcmp(mode, "zero_iterations"), peek = !strcmp(mode, "peek_after_setup"), custom = !strcmp(mode, "custom_impulses");
 	const bool custom_contacts = !strcmp(mode, "custom_contacts");
-	if (!zero_iterations && !peek && !custom && !custom_contacts && strcmp(mode, "plain") && strcmp(mode, "exact")) { fprintf(stderr, "replay: unknown mode %s\n", mode); return 2; }
+	if (!zero_iterations && !peek && !custom && !custom_contacts && strcmp(mode, "two_worlds") && strcmp(mode, "plain") && strcmp(mode, "exact")) { fprintf(stderr, "replay: unknown mode %s\n", mode); return 2; }
 	uint64_t checksum = 1469598103934665603ull;      // FNV-1a over whatever the mode looks at
 
 	nudge::BodyData bodies = {};
@@ -161,6 +180,14 @@ int main(int argc, char** argv) {
 	}
 	const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
+	if (final_state) {
+		const unsigned char* t = reinterpret_cast<const unsigned char*>(bodies.transforms);
+		const unsigned char* m = reinterpret_cast<const unsigned char*>(bodies.momentum);
+		final_state->assign(t, t + sizeof(nudge::Transform) * (size_t)nb);
+		final_state->insert(final_state->end(), m, m + sizeof(nudge::BodyMomentum) * (size_t)nb);
+		final_state->insert(final_state->end(), bodies.idle_counters, bodies.idle_counters + nb);
+	}
+	if (!write_output) return 0;
 	FILE* o = fopen(argv[2], "wb");
 	if (!o) { perror(argv[2]); return 2; }
 	fwrite(bodies.transforms, sizeof(nudge::Transform), nb, o);

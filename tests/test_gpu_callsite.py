@@ -115,6 +115,19 @@ def test_custom_contacts_appended_after_collide_two_backends_bit_identical(name,
 
 
 @pytest.mark.gpu
+def test_two_worlds_on_two_threads_are_independent(tmp_path):
+    """The reference keeps no global mutable state: two threads may step two disjoint worlds at once (SURVEY 8(b) threading).  The drop-in keeps
+    one session per world (found by the caller's arrays), each with its own context and stream: the call site steps two copies of a scene on
+    two threads, both must equal the single-world reference run."""
+    scene, steps = _build("pile256")
+    nb = CU.write_scene(str(tmp_path / "s.bin"), scene)
+    CU.run_replay(CU.REPLAY_HIP, str(tmp_path / "s.bin"), str(tmp_path / "hip.bin"), steps, extra=["two_worlds"])       # (exit code 3 if the two differ)
+    CU.run_replay(CU.REPLAY_REF, str(tmp_path / "s.bin"), str(tmp_path / "ref.bin"), steps)
+    got, ref = CU.read_result(str(tmp_path / "hip.bin"), nb), CU.read_result(str(tmp_path / "ref.bin"), nb)
+    assert P.bits_equal(got["transforms"], ref["transforms"]) and P.bits_equal(got["momentum"], ref["momentum"]) and P.bits_equal(got["idle"], ref["idle"])
+
+
+@pytest.mark.gpu
 def test_reference_own_test_program_passes_on_the_gpu_backend():
     assert os.path.exists(CU.REF_TESTS_HIP), "nudge_amd/compat/_build/ref_tests_hip missing: make -C nudge_amd/compat"
     r = subprocess.run([CU.REF_TESTS_HIP], capture_output=True, text=True, timeout=1500)
