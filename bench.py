@@ -260,7 +260,8 @@ def main():
     n_box_dyn = int((scene["box_transforms"]["body"] > 0).sum())
     n_sph_dyn = int((scene["sphere_transforms"]["body"] > 0).sum())
     if halo:
-        w = E.World(scene, device=device_index, flags=E.NH_FLAG_SINGLE_APPLY, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=6 * info["capacity"]["bodies"])
+        # (the partitioned step keeps the sample's call order -- the halo arrives before nh_collide -- so gravity and advance fuse into the solver here too)
+        w = E.World(scene, device=device_index, flags=E.NH_FLAG_SINGLE_APPLY | E.NH_FLAG_FUSED_STEP, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=6 * info["capacity"]["bodies"])
         cluster = PT.DistCluster(PT.Partition(w, info, epoch=16), host_staging=(backend != "nccl"))
     else:
         w = E.World(scene, device=device_index, flags=E.NH_FLAG_SINGLE_APPLY | E.NH_FLAG_FUSED_STEP, max_contacts=max(4096, (6 if args.scene != "pit" else 5) * nb),

@@ -165,7 +165,7 @@ int main(int argc, char** argv) {
 		}
 
 	nh_context* ctx = nullptr;
-	NH_OK_(nh_create(&ctx, local_rank, stream, NH_FLAG_SINGLE_APPLY));
+	NH_OK_(nh_create(&ctx, local_rank, stream, NH_FLAG_SINGLE_APPLY | NH_FLAG_FUSED_STEP));
 	uint32_t tag_bits = 1; while ((1ull << tag_bits) <= (uint64_t)n_tiles + (uint64_t)n_tiles * side * side) ++tag_bits;
 	NH_OK_(nh_set_tag_bits(ctx, tag_bits));
 	const uint32_t K = 6u * nb + 4096u;
@@ -222,8 +222,8 @@ int main(int argc, char** argv) {
 				if (n_gr) NCCL_OK(ncclRecv(in_right, (size_t)n_gr * NH_HALO_RECORD_BYTES, ncclUint8, rank + 1, comm, stream));
 			}
 			NCCL_OK(ncclGroupEnd());
-			NH_OK_(nh_halo_unpack(ctx, &bodies, 1 + n_owned, n_gl, in_left));
-			NH_OK_(nh_halo_unpack(ctx, &bodies, 1 + n_owned + n_gl, n_gr, in_right));
+			NH_OK_(nh_halo_update(ctx, &bodies, 1 + n_owned, n_gl, in_left));
+			NH_OK_(nh_halo_update(ctx, &bodies, 1 + n_owned + n_gl, n_gr, in_right));
 		}
 		// ---- the reference's sub-step on the local world (example/main.cpp:274-328) ----
 		nh_Arena temporary = arena;

@@ -249,6 +249,10 @@ int nh_advance(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_B
 #define NH_HALO_RECORD_BYTES 64
 int nh_halo_pack(nh_context* ctx, const nh_BodyData* bodies, const uint32_t* indices, uint32_t count, void* out);
 int nh_halo_unpack(nh_context* ctx, const nh_BodyData* bodies, uint32_t first_slot, uint32_t count, const void* in);
+/* nh_halo_update: nh_halo_unpack for records of the SAME bodies that already occupy those slots, as their owner stepped them since the last exchange (the
+   per-step halo; nh_halo_unpack is for slots that change hands: refresh, migration).  The difference is the library's sleep prediction (see
+   nh_bodies_changed): idle counters rise by at most one per step on the owner as they do here, so an update does not invalidate it. */
+int nh_halo_update(nh_context* ctx, const nh_BodyData* bodies, uint32_t first_slot, uint32_t count, const void* in);
 
 /* ---- introspection for tests / measurement --------------------------------------------------------- */
 /* Device pointer to the per-contact warm-start impulses of an nh_ContactImpulseData (K x 16 B, contact order). */

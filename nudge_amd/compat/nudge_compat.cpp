@@ -127,6 +127,13 @@ struct Registry {
 	std::mutex lock;
 	std::map<const void*, Session*> by_key;
 	std::vector<std::unique_ptr<Session>> all;
+	// (constructed on first use, i.e. after the HIP runtime: destroyed before it at exit -- contexts and streams go while the runtime is still alive)
+	~Registry() {
+		for (auto& s : all) {
+			if (s->ctx) { nh_destroy(s->ctx); s->ctx = nullptr; }
+			if (s->stream) { hipStreamDestroy(s->stream); s->stream = nullptr; }
+		}
+	}
 };
 Registry& registry() { static Registry r; return r; }
 

@@ -2508,10 +2508,17 @@ extern "C" int nh_halo_pack(nh_context* ctx, const nh_BodyData* bodies, const ui
 	return NH_OK;
 }
 
-extern "C" int nh_halo_unpack(nh_context* ctx, const nh_BodyData* bodies, uint32_t first_slot, uint32_t count, const void* in) {
+// nh_halo_update: the same for records of the SAME bodies that already occupy those slots, one step further on their owner (the per-step halo of a
+// partitioned world).  Their idle counters rise by at most one per step there as here, so what the last measuring nh_collide saw of them still bounds
+// them: the host's sleep prediction survives (a sleeper the prediction had ruled out is still caught on the device: NH_ERR_STALE_HINT).
+static int halo_unpack(nh_context* ctx, const nh_BodyData* bodies, uint32_t first_slot, uint32_t count, const void* in, bool same_bodies);
+extern "C" int nh_halo_update(nh_context* ctx, const nh_BodyData* bodies, uint32_t first_slot, uint32_t count, const void* in) { return halo_unpack(ctx, bodies, first_slot, count, in, true); }
+extern "C" int nh_halo_unpack(nh_context* ctx, const nh_BodyData* bodies, uint32_t first_slot, uint32_t count, const void* in) { return halo_unpack(ctx, bodies, first_slot, count, in, false); }
+
+static int halo_unpack(nh_context* ctx, const nh_BodyData* bodies, uint32_t first_slot, uint32_t count, const void* in, bool same_bodies) {
 	if (!ctx || !bodies || (count && !in) || (uint64_t)first_slot + count > bodies->count) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
-	if (count) { ctx->idle_bound = -1; ctx->idle_unknown = true; }             // idle counters arrive from another world: nothing is known about them until the next nh_collide has looked
+	if (count && !same_bodies) { ctx->idle_bound = -1; ctx->idle_unknown = true; }             // idle counters arrive from another world: nothing is known about them until the next nh_collide has looked
 	if (count) NH_LAUNCH(ctx, "halo_unpack", k_halo_unpack, nh_grid_for(count, 256, 1024), 256, bodies->transforms, bodies->momentum, bodies->idle_counters, first_slot, count, (const nh_HaloRecord*)in);
 	return NH_OK;
 }

@@ -5,6 +5,7 @@
 // own one contiguous chunk of the input, so a pass is  histogram[digit][block] -> one scan -> stable scatter.
 // Element counts live in device memory (no host round trip); kernels are launched with a fixed grid.
 #include "nh_internal.h"
+#include <mutex>
 
 #define RS_G NH_SORT_GRID
 #define RS_TILE 256
@@ -307,6 +308,8 @@ __global__ __launch_bounds__(256) void os_pass(const K* __restrict__ keys, K* __
 	}
 }
 
+static std::mutex& nh_cooperative_launch_lock() { static std::mutex m; return m; }
+
 template<typename K, typename V, bool HAS_V>
 static int onesweep_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* vals_b, const uint32_t* d_count, uint32_t capacity, uint32_t expected, uint32_t* scratch, const os_shifts& sh) {
 	K* kin = keys_a; K* kout = keys_b;
@@ -344,6 +347,9 @@ static int onesweep_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* va
 		if (ctx->timing) nh_timer_begin(ctx, "radix_pass");
 		hipError_t le = hipErrorUnknown;
 		while (!ctx->os_plain_launch) {
+			// (one cooperative launch at a time process-wide: the runtime sets up its cooperative queue on first use and two host threads racing
+			// there -- two worlds stepped by two threads -- crashed its teardown; the lock costs nothing on the one-thread path)
+			std::lock_guard<std::mutex> guard(nh_cooperative_launch_lock());
 			le = hipLaunchCooperativeKernel((const void*)os_pass<K, V, HAS_V>, dim3(g), dim3(256), args, 0, ctx->stream);
 			if (le == hipSuccess) break;
 			(void)hipGetLastError();

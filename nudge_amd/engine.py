@@ -32,7 +32,7 @@ EXPORTS = [
     "nh_set_tag_bits", "nh_set_pair_capacity", "nh_bodies_changed", "nh_error_string", "nh_last_hip_error", "nh_collide", "nh_apply_gravity_damping",
     "nh_read_cached_impulses", "nh_write_cached_impulses", "nh_setup_contact_constraints", "nh_apply_impulses",
     "nh_update_cached_impulses", "nh_advance", "nh_contact_impulses_device", "nh_enable_timing", "nh_set_timing_filter", "nh_kernel_times",
-    "nh_halo_pack", "nh_halo_unpack", "nh_append_contacts",
+    "nh_halo_pack", "nh_halo_unpack", "nh_halo_update", "nh_append_contacts",
 ]
 HALO_RECORD_BYTES = 64
 
@@ -129,6 +129,7 @@ def lib():
         L.nh_kernel_times.argtypes = [C.c_void_p, C.POINTER(KernelTime), C.c_int, C.c_int]
         L.nh_halo_pack.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_void_p, C.c_uint32, C.c_void_p]
         L.nh_halo_unpack.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_uint32, C.c_uint32, C.c_void_p]
+        L.nh_halo_update.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_uint32, C.c_uint32, C.c_void_p]
         L.nh_append_contacts.argtypes = [C.c_void_p, C.POINTER(ContactData), C.POINTER(BodyData), C.c_uint32, C.c_void_p, Arena]
         _LIB = L
     return _LIB
@@ -340,11 +341,13 @@ class World:
                                            C.c_void_p(out.data_ptr() if n else 0)), "halo_pack")
         return out
 
-    def halo_unpack(self, first_slot, records):
+    def halo_unpack(self, first_slot, records, same_bodies=False):
+        """same_bodies: the records update the bodies already in those slots (per-step halo: nh_halo_update keeps the sleep prediction)."""
         n = int(records.shape[0])
         if n:
             assert records.is_contiguous() and records.shape[1] == HALO_RECORD_BYTES
-            _check(self.L, self.L.nh_halo_unpack(self.ctx, C.byref(self.bodies), first_slot, n, C.c_void_p(records.data_ptr())), "halo_unpack")
+            fn = self.L.nh_halo_update if same_bodies else self.L.nh_halo_unpack
+            _check(self.L, fn(self.ctx, C.byref(self.bodies), first_slot, n, C.c_void_p(records.data_ptr())), "halo_unpack")
 
     # ---- state ----
     def synchronize(self):

@@ -332,7 +332,7 @@ class Partition:
             if m:
                 rec = incoming[d]
                 if hasattr(self.e, "halo_unpack"):
-                    self.e.halo_unpack(at, rec.contiguous())
+                    self.e.halo_unpack(at, rec.contiguous(), same_bodies=True)      # (the ghost lists only change at a refresh, which announces itself: set_counts)
                 else:
                     s = slice(at, at + m)
                     self.bt[s, :12] = rec[:, :12]                 # position

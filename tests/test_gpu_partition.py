@@ -16,15 +16,44 @@ from nudge_amd import scenes as S           # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-def _cluster(scene, ranks, epoch=8, **kw):
+def _cluster(scene, ranks, epoch=8, flags=0, **kw):
     x = scene["body_transforms"]["position"][1:, 0]
     cuts = [float(np.quantile(x, (r + 1) / ranks)) + 0.41 for r in range(ranks - 1)]
     parts = []
     for r in range(ranks):
         local, info = PT.split_scene(scene, cuts, r, min_extra=2048)
-        w = E.World(local, flags=0, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=8 * info["capacity"]["bodies"])
+        w = E.World(local, flags=flags, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=8 * info["capacity"]["bodies"])
         parts.append(PT.Partition(w, info, epoch=epoch, **kw))
     return PT.LocalCluster(parts), parts
+
+
+def test_partitions_in_the_bench_mode_fall_asleep_like_the_single_world():
+    """bench.py --gpus N steps every slab with NH_FLAG_SINGLE_APPLY | NH_FLAG_FUSED_STEP and the per-step halo as an UPDATE of the same bodies
+    (nh_halo_update: the host's sleep prediction survives the exchange; only a refresh, every `epoch` steps, invalidates it).  Through the fall,
+    the landing, the rest and the sleep of a drop scene cut through its tiles: the same bodies asleep as in the single world, state within the
+    partitioned bar, no NH_ERR_STALE_HINT, and the island kernels really were skipped while nobody could be asleep."""
+    scene = S.grid_tiles(4, side=30, seed=23, lattice_cols=2)
+    flags = E.NH_FLAG_SINGLE_APPLY | E.NH_FLAG_FUSED_STEP
+    cl, parts = _cluster(scene, 2, epoch=16, flags=flags)
+    single = E.World(scene, flags=flags)
+    parts[0].e.enable_timing(True)
+    cl.step(120); single.step(120)
+    names = parts[0].e.kernel_times(reset=True)
+    parts[0].e.enable_timing(False)
+    assert "uf_flatten" not in names and "active_flags" not in names, sorted(names)        # nobody can be asleep in the first 120 steps: predicted, not computed
+    assert "gravity_damping" not in names and "advance" not in names, sorted(names)       # fused into the solver
+    cl.step(480); single.step(480)
+    got, ref = cl.gather(), single.get_bodies()
+    for q in parts:
+        assert q.e.counts()["error"] == 0
+    asleep_ref = ref["idle"][1:] == 0xff
+    assert asleep_ref.mean() > 0.9, "the scene was meant to have gone to sleep"
+    assert float(((got["idle"] == 0xff) != asleep_ref).mean()) < 0.02       # (islands at the edge of falling asleep may differ by a step or two)
+    assert P.rel_err(got["transforms"]["position"], ref["transforms"]["position"][1:]).max() <= 1e-4
+    assert np.abs(got["momentum"]["velocity"] - ref["momentum"]["velocity"][1:]).max() <= 2e-4
+    for q in parts:
+        q.e.close()
+    single.close()
 
 
 @pytest.mark.parametrize("sphere_fraction", [0.0, 0.5])
