@@ -261,7 +261,7 @@ def main():
     n_sph_dyn = int((scene["sphere_transforms"]["body"] > 0).sum())
     if halo:
         # (the partitioned step keeps the sample's call order -- the halo arrives before nh_collide -- so gravity and advance fuse into the solver here too)
-        w = E.World(scene, device=device_index, flags=E.NH_FLAG_SINGLE_APPLY | E.NH_FLAG_FUSED_STEP, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=6 * info["capacity"]["bodies"])
+        w = E.World(scene, device=device_index, flags=E.NH_FLAG_SINGLE_APPLY | (0 if os.environ.get("NUDGE_BENCH_NO_FUSED") else E.NH_FLAG_FUSED_STEP), capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=6 * info["capacity"]["bodies"])
         cluster = PT.DistCluster(PT.Partition(w, info, epoch=16), host_staging=(backend != "nccl"))
     else:
         w = E.World(scene, device=device_index, flags=E.NH_FLAG_SINGLE_APPLY | E.NH_FLAG_FUSED_STEP, max_contacts=max(4096, (6 if args.scene != "pit" else 5) * nb),

@@ -46,7 +46,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->fat_pairs = nullptr; ctx->fat_pair_capacity = 0; ctx->fat_box = nullptr; ctx->fat_collider_capacity = 0; ctx->fat_nbox = ctx->fat_nsph = 0xffffffffu;
 	ctx->env_colour_check_seeds = getenv("NH_COLOUR_CHECK_SEEDS") != nullptr;      // colours seeded from the cache go through a settle round instead of being final at once (A/B, tests)
 	ctx->env_no_resident = getenv("NH_NO_RESIDENT") != nullptr;      // NH_NO_RESIDENT=1: small general sets also take the one-launch-per-level path (A/B, tests)
-	ctx->os_resident = 0; ctx->os_plain_launch = false;
+	ctx->os_resident = 0; ctx->os_plain_launch = getenv("NH_COOPERATIVE") == nullptr;      // NH_COOPERATIVE=1: the one-kernel radix passes go out as cooperative launches (nh_util.hip)
 	// spatially blocked solver (nh_blocks.h).  NH_NO_BLOCKS=1: large general sets take the per-colour global launches (A/B, tests); NH_BLK_MIN: general
 	// contacts from which the blocked form is used; NH_BLK_TARGET: bodies per average block (tests use small values to get many blocks out of a
 	// small world); NH_BLK_CHECK=1: verify the block tables on the device every step

@@ -335,9 +335,12 @@ static int onesweep_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* va
 	hipError_t e = hipMemsetAsync(scratch, 0, sizeof(uint32_t) * (size_t)sh.n * OS_PASS_WORDS, ctx->stream);
 	if (ctx->timing) nh_timer_end(ctx);
 	if (e != hipSuccess) ctx->last_hip_error = (int)e;
-	// The workgroups of a pass wait for each other (earlier counts, group sums): all of them MUST be resident at once.  A cooperative launch makes
-	// that the runtime's promise instead of an occupancy estimate of ours (another process or stream holding compute units cannot turn the wait
-	// into a hang); if the runtime finds the grid too large for this device it is halved -- any grid sorts correctly, workgroups then own more tiles.
+	// The workgroups of a pass wait for each other (earlier counts, group sums): all of them must get to run while the others spin.  The launch is
+	// bounded by 3/4 of what the occupancy query says is resident at once, and nothing this library runs beside it (side stream) ever waits for it, so
+	// workgroups that find the compute units busy with somebody else's kernels are merely late.  NH_COOPERATIVE=1 turns the bound into the runtime's
+	// promise (hipLaunchCooperativeKernel; a grid it finds too large is halved -- any grid sorts correctly).  It is not the default because of what it
+	// costs: with two processes sharing one MI355X (the N = 2 rehearsal, whose refresh re-seeds the sort every 16 steps) every cooperative launch took
+	// ~10 ms against ~0.05 ms for the plain one (profiles/r03_cooperative_launch_ab.txt).
 	uint32_t g = grid;
 	for (int p = 0; p < sh.n; ++p) {
 		uint32_t* c = scratch + (size_t)p * OS_PASS_WORDS;

@@ -40,7 +40,8 @@ def test_partitions_in_the_bench_mode_fall_asleep_like_the_single_world():
     cl.step(120); single.step(120)
     names = parts[0].e.kernel_times(reset=True)
     parts[0].e.enable_timing(False)
-    assert "uf_flatten" not in names and "active_flags" not in names, sorted(names)        # nobody can be asleep in the first 120 steps: predicted, not computed
+    # nobody can be asleep in the first 120 steps: predicted, not computed -- except in the step after a refresh (new bodies in the ghost slots)
+    assert names.get("active_flags", (0.0, 0))[1] <= 120 // 16 + 1 and names.get("uf_flatten", (0.0, 0))[1] <= 120 // 16 + 1, sorted(names)
     assert "gravity_damping" not in names and "advance" not in names, sorted(names)       # fused into the solver
     cl.step(480); single.step(480)
     got, ref = cl.gather(), single.get_bodies()
