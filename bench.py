@@ -111,9 +111,12 @@ PMC_KERNEL = {"solve_one_body": "k_solve_one_body<4, true, true>", "apply_static
               "apply_level": "k_level_exec<false>", "write_cache": "k_write_cache", "xform_aabb": "k_xform", "blk_sweep": "k_blk_sweep<false, true>"}
 
 
+PMC_SUFFIX = ""       # "_c4" for the pit: its own export (profiles/collect.sh)
+
+
 def _pmc_file():
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_traffic{PMC_SUFFIX}.json")))
     return files[-1] if files else None
 
 
@@ -429,7 +432,10 @@ def main():
             elif dominant in ("blk_sweep", "blk_warm"):
                 n_items = n_items / max(1.0, launches_per_step)                                                  # one block colour of one sweep per launch
             bytes_per_launch = per * n_items
-            tr, traffic_src = pmc_traffic(dominant) if args.scene == "boxes" and args.tiles == 124 and world == 1 else (None, None)
+            if args.scene == "pit" and args.side == 160:
+                global PMC_SUFFIX
+                PMC_SUFFIX = "_c4"
+            tr, traffic_src = pmc_traffic(dominant) if world == 1 and ((args.scene == "boxes" and args.tiles == 124) or (args.scene == "pit" and args.side == 160)) else (None, None)
             traffic, traffic_raw = tr if tr else (None, None)
             out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": bytes_per_launch / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": bytes_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw,

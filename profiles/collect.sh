@@ -4,7 +4,7 @@
 #   two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass on gfx950), one SQ wave-state pass and the one-GPU rehearsal of the N = 2 path.
 # Raw output goes to gpurun_out/<tag>/ (scratch); the summaries are exported into gpurun_out/<tag>/export/ ready to be copied to profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O/export
@@ -13,6 +13,7 @@ python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/export/${TAG}_bench_drive
 python $R/bench.py --profile-kernels > $O/export/${TAG}_bench_default.json 2> $O/export/${TAG}_bench_kernel_table.log
 python $R/bench.py --scene mixed --tiles 248 --no-cpu --profile-kernels > $O/export/${TAG}_bench_c3_mixed_2M.json 2> $O/export/${TAG}_bench_c3_kernel_table.log
 timeout 400 python $R/bench.py --scene pit --no-cpu --steps 10 --profile-kernels > $O/export/${TAG}_bench_c4_pit_4M_settled.json 2> $O/export/${TAG}_bench_c4_kernel_table.log
+NH_NO_BLOCKS=1 timeout 400 python $R/bench.py --scene pit --no-cpu --steps 10 --min-time 1 > $O/export/${TAG}_bench_c4_per_colour_launches.json 2> $O/c4_noblocks.err
 # rocprofv3: kernel trace + stats of the driver's invocation
 rocprofv3 --kernel-trace --stats -d $O/prof -o stats -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu > $O/prof_bench.json 2> $O/prof.log
 DB=$(find $O/prof -name "*.db" | head -1)
@@ -42,6 +43,21 @@ rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_V
 F=$(find $O/sq -name "*counter_collection.csv" | head -1)
 [ -n "$F" ] && python $R/profiles/export_sq.py $(dirname $F) $O/export/${TAG}_sq_wave_states.json > $O/export/${TAG}_sq_wave_states.log 2>&1
 rm -rf $O/sq $O/pmc $O/prof
+# config 4: the blocked solver's kernels -- SQ wave states, FETCH / WRITE per launch, and the per-workgroup wall-clock profile
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU --kernel-include-regex "k_blk_|k_rows_general|k_level_exec" --kernel-trace --output-format csv -d $O/sq4 -o c -- python $R/bench.py --scene pit --no-cpu --steps 3 --min-time 0 > $O/sq4_bench.json 2> $O/sq4.log
+F=$(find $O/sq4 -name "*counter_collection.csv" | head -1)
+[ -n "$F" ] && python $R/profiles/export_sq.py $(dirname $F) $O/export/${TAG}_sq_wave_states_c4.json 64 > $O/export/${TAG}_sq_wave_states_c4.log 2>&1
+for CNT in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $CNT --kernel-include-regex "k_blk_|k_rows_general|k_level_exec" --kernel-trace --output-format csv -d $O/pmc4 -o $CNT -- python $R/bench.py --scene pit --no-cpu --steps 3 --min-time 0 > $O/pmc4_$CNT.json 2> $O/pmc4_$CNT.log
+done
+F=$(find $O/pmc4 -name "FETCH_SIZE_counter_collection.csv" | head -1)
+if [ -n "$F" ]; then
+  D=$(dirname $F); W=$(find $O/pmc4 -name "WRITE_SIZE_counter_collection.csv" | head -1); [ "$(dirname $W)" != "$D" ] && cp $W $D/
+  python $R/profiles/export_pmc.py $D $O/export/${TAG}_pmc_traffic_c4.json 64 > $O/export/${TAG}_pmc_traffic_c4.log
+fi
+NH_BLK_PROFILE=1 timeout 300 python $R/bench.py --scene pit --no-cpu --steps 10 --min-time 0.3 > $O/c4_prof.json 2> $O/c4_prof.log
+grep blk_profile $O/c4_prof.log | tail -8 > $O/export/${TAG}_blocked_sweep_workgroup_profile.log
+rm -rf $O/sq4 $O/pmc4
 # N = 2 rehearsal on one GPU
 cd $R; timeout 600 tests/gpu_rehearsal_n2.sh > $O/rehearsal.out 2> $O/export/${TAG}_bench_n2_rehearsal_kernel_table.log
 grep '^{' $O/rehearsal.out | tail -1 > $O/export/${TAG}_bench_n2_rehearsal_one_gpu.json

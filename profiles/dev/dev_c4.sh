@@ -1,0 +1,6 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/c4; mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+timeout 400 python $R/bench.py --scene pit --no-cpu --steps 10 --min-time 1 --profile-kernels > $O/bench_c4.json 2> $O/bench_c4_kernels.log
+cut -c1-220 $O/bench_c4.json; head -64 $O/bench_c4_kernels.log
