@@ -335,6 +335,7 @@ def main():
     if dominant:
         w.enable_timing(True, only=dominant)
     dt, blocks, contact_sum, pair_sum, general_sum = 0.0, 0, 0.0, 0.0, 0.0
+    block_ms = []
     while True:
         if snap is not None and blocks:
             w.restore(snap)
@@ -348,6 +349,7 @@ def main():
         if c1["error"]:
             raise SystemExit(f"device error {c1['error']}")
         dt += t1 - t0
+        block_ms.append(1e3 * (t1 - t0) / args.steps)
         blocks += 1
         contact_sum += 0.5 * (c0["contacts"] + c1["contacts"])
         pair_sum += 0.5 * (c0["pairs"] + c1["pairs"])
@@ -393,7 +395,9 @@ def main():
                        "landed_after_steps": landed_at,
                        "timed_window": f"steps [{first_timed}, {first_timed + args.steps}) (landed and awake), timed {blocks}x from a device checkpoint" if snap is not None
                                        else f"steps [{first_timed}, {first_timed + args.steps}) (landed and awake)",
-                       "timed_blocks": blocks, "timed_steps": timed_steps, "timed_seconds": dt},
+                       "timed_blocks": blocks, "timed_steps": timed_steps, "timed_seconds": dt,
+                       # the same K steps block after block: how steady the clock is over the timed seconds (ms per step of the first, fastest, slowest, last block)
+                       "block_ms_per_step": {"first": block_ms[0], "min": min(block_ms), "max": max(block_ms), "last": block_ms[-1]}},
             "contacts_solved_per_sec": contacts_all * I / sec_per_step,
         }
         units = {"B": B, "C": C, "P": P, "K": K, "R": P, "G": G, "GI": G * I, "T": grid_table_entries(C)}

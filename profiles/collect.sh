@@ -15,7 +15,7 @@ python $R/bench.py --scene mixed --tiles 248 --no-cpu --profile-kernels > $O/exp
 timeout 400 python $R/bench.py --scene pit --no-cpu --steps 10 --profile-kernels > $O/export/${TAG}_bench_c4_pit_4M_settled.json 2> $O/export/${TAG}_bench_c4_kernel_table.log
 NH_NO_BLOCKS=1 timeout 400 python $R/bench.py --scene pit --no-cpu --steps 10 --min-time 1 > $O/export/${TAG}_bench_c4_per_colour_launches.json 2> $O/c4_noblocks.err
 # rocprofv3: kernel trace + stats of the driver's invocation
-rocprofv3 --kernel-trace --stats -d $O/prof -o stats -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu > $O/prof_bench.json 2> $O/prof.log
+rocprofv3 --kernel-trace --stats -d $O/prof -o stats -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-full-window > $O/prof_bench.json 2> $O/prof.log
 DB=$(find $O/prof -name "*.db" | head -1)
 if [ -n "$DB" ]; then
   python - "$O/prof_bench.json" "$DB" "$O/export/${TAG}_rocprofv3_kernel_stats.tsv" <<'PY'
@@ -31,7 +31,7 @@ PY
 fi
 # PMC passes (one block of the timed region is enough; counters serialise the kernels)
 for CNT in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $O/pmc -o $CNT -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --min-time 0 > $O/pmc_$CNT.json 2> $O/pmc_$CNT.log
+  rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $O/pmc -o $CNT -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-full-window --min-time 0 > $O/pmc_$CNT.json 2> $O/pmc_$CNT.log
 done
 F=$(find $O/pmc -name "FETCH_SIZE_counter_collection.csv" | head -1)
 if [ -n "$F" ]; then
@@ -39,7 +39,7 @@ if [ -n "$F" ]; then
   python $R/profiles/export_pmc.py $D $O/export/${TAG}_pmc_traffic.json 20 > $O/export/${TAG}_pmc_traffic.log
 fi
 # SQ wave-state counters of every kernel (where the wave cycles go: issuing, parked at s_waitcnt, stalled at issue)
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/sq -o sq -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --min-time 0 > $O/sq_bench.json 2> $O/sq.log
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/sq -o sq -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-full-window --min-time 0 > $O/sq_bench.json 2> $O/sq.log
 F=$(find $O/sq -name "*counter_collection.csv" | head -1)
 [ -n "$F" ] && python $R/profiles/export_sq.py $(dirname $F) $O/export/${TAG}_sq_wave_states.json > $O/export/${TAG}_sq_wave_states.log 2>&1
 rm -rf $O/sq $O/pmc $O/prof
