@@ -412,6 +412,22 @@ __device__ __forceinline__ void emit_kept(nh_DevState* st, uint2* __restrict__ k
 	if (ps.count > ps.cap - 64) flush_pairs(st, kept, kept_cap, ps, &st->fat_count, &st->fat_count_sph);
 }
 
+// Two sphere colliders whose boxes overlap but which cannot touch.  In a pit of spheres 40 % of the overlapping boxes belong to spheres that do not
+// touch: they would become records that hold no contact, sorted, scanned and gathered with the rest.  The search knows both boxes, and a sphere's box
+// IS the sphere (centre = middle, radius = half the edge), up to the rounding of centre -/+ radius: with a margin of ~8 ulp of the coordinates and
+// 1e-5 of the radii "surely apart" never drops a pair the narrowphase would give a contact (nudge.cpp:2495: l2 > r * r means none).  Only in the
+// DIRECT search (the kept list has to stay a superset across steps), and only between two bodies that are AWAKE: an edge with a sleeping end takes part in
+// the coarse islands and may have to be reported as a sleeping pair although its boxes merely overlap (nudge.cpp:3575-3703).
+__device__ __forceinline__ bool spheres_surely_apart(const float4& amin, const float4& amax, const float4& bmin, const float4& bmax) {
+	const float ax = 0.5f * (amin.x + amax.x), ay = 0.5f * (amin.y + amax.y), az = 0.5f * (amin.z + amax.z);
+	const float bx = 0.5f * (bmin.x + bmax.x), by = 0.5f * (bmin.y + bmax.y), bz = 0.5f * (bmin.z + bmax.z);
+	const float r = 0.5f * (amax.x - amin.x) + 0.5f * (bmax.x - bmin.x);
+	const float dx = bx - ax, dy = by - ay, dz = bz - az;
+	const float e = 1e-6f * (fabsf(ax) + fabsf(ay) + fabsf(az) + fabsf(bx) + fabsf(by) + fabsf(bz)) + 1e-5f * r;
+	const float s = r + e;
+	return dx * dx + dy * dy + dz * dz > s * s;
+}
+
 // What the grid search does with two overlapping boxes.  KEPT mode: the boxes are inflated, the pair goes to the kept list as it is.  DIRECT mode (a
 // world in which somebody leaves its box every step: keeping pairs would only add the filter pass): the boxes are the exact AABBs, and the pair --
 // unless both colliders sit on one body -- goes straight to this step's pairs, roles by Morton order, coarse islands united (emit_pair).
@@ -522,6 +538,8 @@ __global__ __launch_bounds__(256) void k_find_pairs(nh_DevState* __restrict__ st
 				if (have[k]) {
 					cb = __float_as_uint(bmax[k].w);
 					hit = aabb_overlap(amin, amax, bmin[k], bmax[k]);
+					if (DIRECT && hit && ca >= nbox && cb >= nbox && spheres_surely_apart(amin, amax, bmin[k], bmax[k]))
+						hit = islands && (idle[__float_as_uint(amin.w)] == 0xffu || idle[__float_as_uint(bmin[k].w)] == 0xffu);      // (two awake spheres that cannot touch: no pair; `islands` is null while nobody sleeps at all)
 				}
 				emit_found<DIRECT>(st, kept, kept_cap, amin, bmin[k], ca, cb, hit, ps, mscale, mmin, islands, idle);
 			}
