@@ -993,8 +993,8 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
                                                          nh_Contact* __restrict__ data, nh_BodyPair* __restrict__ bodies, uint64_t* __restrict__ tags, uint32_t* __restrict__ features, uint32_t capacity, uint32_t pair_cap,
                                                          const uint32_t* __restrict__ sleep_scan, uint64_t* __restrict__ sleeping_pairs, uint32_t* __restrict__ deg, uint32_t nbodies) {
 	__shared__ uint32_t s_src[4][1024];
-	uint32_t* __restrict__ info = deg + 2u * (nbodies + 2u);
-	uint32_t* __restrict__ first_contact = deg + 3u * (nbodies + 2u);
+	unsigned long long* __restrict__ pair_counter = reinterpret_cast<unsigned long long*>(deg + 2u * NH_DEG_STRIDE(nbodies));
+	uint32_t* __restrict__ first_contact = deg + 4u * NH_DEG_STRIDE(nbodies);
 	__shared__ uint32_t s_feat[4][1024];
 	__shared__ uint8_t s_own[4][1024];
 	const uint32_t nrec = st->records;
@@ -1025,9 +1025,11 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 			base4 = sph_rec ? 4u * n_bb + (ri - n_bb) : 4u * ri; baseo = 4u * pair_cap + r.overflow;
 			// contact degree of the two bodies (body 0 is the static world): the solver's adjacency starts from these
 			// and what lets setup skip the general CSR build for a body that sits in ONE pair with the static world: its contacts are start .. start+cnt-1
+			// ONE atomic per body and pair: degree and pair info share a 64-bit counter (two 32-bit atomics per body used to make this kernel
+			// atomic-bound in a pit of 11 M contacts); no value is asked back -- a returning atomic is a memory round trip the wave waits for
 			if (cnt && start + cnt <= capacity) {
-				if (body_a) { atomicAdd(&deg[body_a], cnt); atomicAdd(&info[body_a], body_b ? 0x10001u : 1u); first_contact[body_a] = start | 0x80000000u; }      // top bit: plays "a"
-				if (body_b) { atomicAdd(&deg[body_b], cnt); atomicAdd(&info[body_b], body_a ? 0x10001u : 1u); first_contact[body_b] = start; }
+				if (body_a) { atomicAdd(&pair_counter[body_a], (unsigned long long)cnt | ((unsigned long long)(body_b ? 0x10001u : 1u) << 32)); first_contact[body_a] = start | 0x80000000u; }      // top bit: plays "a"
+				if (body_b) { atomicAdd(&pair_counter[body_b], (unsigned long long)cnt | ((unsigned long long)(body_a ? 0x10001u : 1u) << 32)); first_contact[body_b] = start; }
 			}
 		}
 		const uint32_t base = __shfl(start, 0);                  // lane 0 is always a valid record here
@@ -1112,7 +1114,7 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 	__syncthreads();
 	if (threadIdx.x == 0) block_top[blockIdx.x] = max(max(s_top[0], s_top[1]), max(s_top[2], s_top[3]));
 	if (blockIdx.x == 0 && threadIdx.x == 0) st->any_idle[parity ^ 1u] = 0;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < 3u * (nbodies + 2u); i += gridDim.x * blockDim.x) deg[i] = 0;      // degrees, fill cursors, pair info
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < NH_DEG_WORDS(nbodies); i += gridDim.x * blockDim.x) deg[i] = 0;      // degrees, pair counters, first contacts (NH_DEG_STRIDE)
 	if (blockIdx.x != 0) return;
 	uint32_t t = threadIdx.x;
 	if (t == 0) {
@@ -1203,14 +1205,15 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 
 	hipStream_t s = ctx->stream;
 	bool drop_sort_order = ctx->env_no_sort_reuse;
-	if (ctx->deg_capacity < 4u * (B + 2u)) {
-		// library-owned, 4 x (B + 2) words: per body the contact degree, a fill cursor, the pair info (collider pairs it is in | pairs with a
+	if (ctx->deg_capacity < NH_DEG_WORDS(B)) {
+		// library-owned (layout: NH_DEG_STRIDE in nh_internal.h): per body the contact degree, the pair info (collider pairs it is in | pairs with a
 		// dynamic partner << 16) and the first contact of its last pair -- written while the contacts are laid out, consumed by setup
 		if (ctx->deg) NH_HIP_CHECK(ctx, hipFree(ctx->deg));
 		ctx->deg = nullptr; ctx->deg_capacity = 0;
-		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->deg, sizeof(uint32_t) * 4u * ((size_t)B + 2u)));
-		ctx->deg_capacity = 4u * (B + 2u);
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->deg, sizeof(uint32_t) * NH_DEG_WORDS(B)));
+		ctx->deg_capacity = (uint32_t)NH_DEG_WORDS(B);
 	}
+
 	if (ctx->sort_capacity != pair_cap) {
 		// library-owned: splitters of the seeded tag sort (they persist from one nh_collide to the next) + its bucket counters
 		if (ctx->sort_splitters) NH_HIP_CHECK(ctx, hipFree(ctx->sort_splitters));
@@ -1459,8 +1462,8 @@ __global__ __launch_bounds__(256) void k_app_scatter(const nh_DevState* __restri
 // the per-body bookkeeping of k_gather_contacts, from the merged list: a run of equal tags is one collider pair
 __global__ __launch_bounds__(256) void k_app_recount(nh_DevState* __restrict__ st, uint32_t extra, const nh_BodyPair* __restrict__ bodies, const uint64_t* __restrict__ tags,
                                                      uint32_t* __restrict__ deg, uint32_t nbodies) {
-	uint32_t* __restrict__ info = deg + 2u * (nbodies + 2u);
-	uint32_t* __restrict__ first_contact = deg + 3u * (nbodies + 2u);
+	unsigned long long* __restrict__ pair_counter = reinterpret_cast<unsigned long long*>(deg + 2u * NH_DEG_STRIDE(nbodies));
+	uint32_t* __restrict__ first_contact = deg + 4u * NH_DEG_STRIDE(nbodies);
 	const uint32_t n = st->contacts + extra;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		if (i > 0 && tags[i - 1] == tags[i]) continue;          // not the head of its run
@@ -1468,8 +1471,8 @@ __global__ __launch_bounds__(256) void k_app_recount(nh_DevState* __restrict__ s
 		uint32_t len = 1;
 		while (i + len < n && tags[i + len] == t) ++len;
 		const nh_BodyPair p = bodies[i];
-		if (p.a) { atomicAdd(&deg[p.a], len); atomicAdd(&info[p.a], p.b ? 0x10001u : 1u); first_contact[p.a] = i | 0x80000000u; }
-		if (p.b) { atomicAdd(&deg[p.b], len); atomicAdd(&info[p.b], p.a ? 0x10001u : 1u); first_contact[p.b] = i; }
+		if (p.a) { atomicAdd(&pair_counter[p.a], (unsigned long long)len | ((unsigned long long)(p.b ? 0x10001u : 1u) << 32)); first_contact[p.a] = i | 0x80000000u; }
+		if (p.b) { atomicAdd(&pair_counter[p.b], (unsigned long long)len | ((unsigned long long)(p.a ? 0x10001u : 1u) << 32)); first_contact[p.b] = i; }
 	}
 }
 
@@ -1500,9 +1503,8 @@ extern "C" int nh_append_contacts(nh_context* ctx, nh_ContactData* contacts, con
 	NH_LAUNCH(ctx, "append_positions", k_app_positions, nh_grid_for(cap, 256, 2048), 256, st, extra, contacts->tags, contacts->features, rank, skey, sfeat, pos);
 	NH_LAUNCH(ctx, "append_copy", k_app_copy, nh_grid_for(cap, 256, 2048), 256, st, extra, contacts->data, contacts->bodies, contacts->tags, contacts->features, t_data, t_bodies, t_tags, t_features);
 	NH_LAUNCH(ctx, "append_scatter", k_app_scatter, nh_grid_for(cap, 256, 2048), 256, st, extra, pos, t_data, t_bodies, t_tags, t_features, contacts->data, contacts->bodies, contacts->tags, contacts->features);
-	// degrees, pair info, first contact: counted again (the fill cursors in between stay zero)
-	NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(uint32_t) * (size_t)(B + 2u), ctx->stream));
-	NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->deg + 2u * (size_t)(B + 2u), 0, sizeof(uint32_t) * 2u * (size_t)(B + 2u), ctx->stream));
+	// degrees, pair info, first contact: counted again
+	NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(uint32_t) * NH_DEG_WORDS(B), ctx->stream));
 	NH_LAUNCH(ctx, "append_recount", k_app_recount, nh_grid_for(cap, 256, 2048), 256, st, extra, contacts->bodies, contacts->tags, ctx->deg, B);
 	NH_LAUNCH(ctx, "append_count", k_app_count, 1, 1, st, extra, cap);
 	if (ctx->flags & NH_FLAG_SYNC_COUNTS) {

@@ -323,6 +323,13 @@ void nh_timer_collect(nh_context* ctx);
 		if (e_ != hipSuccess) { (ctx)->last_hip_error = (int)e_; return NH_ERR_HIP; }            \
 	} while (0)
 
+// layout of ctx->deg (32-bit words, S = NH_DEG_STRIDE(bodies)): [0, S) contact degree per body (k_adj_simple writes it out of the counters below: the CSR
+// scan reads it); [S, 2S) fill cursors of the CSR build (zero until then); [2S, 4S) one 64-bit counter per body, bumped ONCE per collider pair while the
+// contacts are laid out: low word = contacts so far (the degree), high word = collider pairs | pairs with a dynamic partner
+// << 16; [4S, 5S) first contact of the body's last pair (| NH_FIRST_IS_A)
+#define NH_DEG_STRIDE(B) ((((size_t)(B)) + 3u) & ~(size_t)1u)
+#define NH_DEG_WORDS(B) (5u * NH_DEG_STRIDE(B))
+
 static inline uint32_t nh_grid_for(uint64_t n, uint32_t block = NH_BLOCK, uint32_t max_blocks = 4096) {
 	uint64_t g = (n + block - 1) / block;
 	if (g < 1) g = 1;

@@ -208,7 +208,7 @@ __device__ __forceinline__ uint32_t slot_key_of(uint32_t i, const uint32_t* __re
 // writes the CSR form on demand).  Everything else is left PENDING for the general k_adj_fill / k_adj_sort, which do not even start
 // when nothing is pending.
 #define NH_FIRST_IS_A 0x80000000u        // in first_contact[]: the body plays "a" in its last pair (k_gather_contacts)
-__global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st, uint32_t nbodies, const uint32_t* __restrict__ deg, const uint32_t* __restrict__ info,
+__global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st, uint32_t nbodies, uint32_t* __restrict__ deg, const unsigned long long* __restrict__ pair_counter,
                                                     const uint32_t* __restrict__ first_contact, const uint32_t* __restrict__ slot_key,
                                                     uint8_t* __restrict__ body_class, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                     uint2* __restrict__ simple) {
@@ -220,12 +220,15 @@ __global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st
 			const nh_BodyMomentum m0 = momentum[0];
 			const nh_BodyProperties p0 = props[0];
 			st->static_inert = nh_is_inert(m0.velocity, m0.angular_velocity, p0.inertia_inverse, p0.mass_inverse) ? 1u : 0u;
+			deg[0] = 0u;
 			continue;
 		}
-		const uint32_t d = deg[x];
+		const unsigned long long pc = pair_counter[x];
+		const uint32_t d = (uint32_t)pc;
+		deg[x] = d;                                 // (the degrees as an array of their own: what the CSR scan reads, ensure_csr)
 		uint32_t cls = NH_CLS_NONE;
 		if (d) {
-			const uint32_t inf = info[x];
+			const uint32_t inf = (uint32_t)(pc >> 32);
 			if ((inf & 0xFFFFu) == 1u && (inf >> 16) == 0u && d <= 8u) {
 				const uint32_t fc = first_contact[x];
 				const uint32_t f = fc & ~NH_FIRST_IS_A;
@@ -1924,7 +1927,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	nh_ContactConstraintData* d = new_constraint_data(ctx);
 	d->rows = nh_arena_array<float>(memory, (size_t)kcap * 40, &err);
 	d->states = nh_arena_array<float>(memory, (size_t)kcap * 4, &err);
-	if (!ctx->deg || ctx->deg_capacity < 4u * (B + 2u)) return NH_ERR_INVALID;      // nh_collide of this step sized and filled it
+	if (!ctx->deg || ctx->deg_capacity < NH_DEG_WORDS(B)) return NH_ERR_INVALID;      // nh_collide of this step sized and filled it
 	// one setup per collide: the fill cursors and the contact layout below belong to the last nh_collide (header note 8)
 	if (ctx->setup_seq == ctx->collide_seq) return NH_ERR_STALE_SETUP;
 	if ((ctx->flags & NH_FLAG_SYNC_COUNTS) && contacts->count != ctx->h_state->contacts) return NH_ERR_STALE_SETUP;
@@ -1936,7 +1939,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	d->level_order = nh_arena_array<uint32_t>(memory, kcap, &err);
 	d->gpair = nh_arena_array<uint2>(memory, kcap, &err);
 	d->gstates = nh_arena_array<float4>(memory, kcap, &err);
-	uint32_t* cursor = ctx->deg + (B + 2);                                          // fill cursors (zeroed by nh_collide)
+	uint32_t* cursor = ctx->deg + NH_DEG_STRIDE(B);                                   // fill cursors (zeroed by nh_collide)
 	uint32_t* pred_a = nh_arena_array<uint32_t>(memory, kcap, &err);
 	uint32_t* pred_b = nh_arena_array<uint32_t>(memory, kcap, &err);
 	uint32_t* level = nh_arena_array<uint32_t>(memory, kcap, &err);
@@ -1963,7 +1966,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 		NH_LAUNCH(ctx, "order_check", k_order_check, nh_grid_for(kcap / 8u + 16u, 256, 1024), 256, st, contacts->bodies, slot_key, seq);
 		NH_LAUNCH(ctx, "greedy_replay", k_greedy_replay, 1, 64, st, contacts->bodies, slot_key, seq, spill_ab, spill_idx, spill_cap);
 	}
-	NH_LAUNCH(ctx, "adjacency_simple", k_adj_simple, nh_grid_for(B, 256, 4096), 256, st, B, ctx->deg, ctx->deg + 2 * (size_t)(B + 2), ctx->deg + 3 * (size_t)(B + 2), slot_key,
+	NH_LAUNCH(ctx, "adjacency_simple", k_adj_simple, nh_grid_for(B, 256, 4096), 256, st, B, ctx->deg, reinterpret_cast<const unsigned long long*>(ctx->deg + 2u * NH_DEG_STRIDE(B)), ctx->deg + 4u * NH_DEG_STRIDE(B), slot_key,
 	          d->body_class, bodies->properties, bodies->momentum, d->simple);
 	if (ctx->hint_capacity < B) {
 		// library-owned, persistent across steps: per body, where its contacts started in the previous step's list (warm-start hint)
@@ -2173,7 +2176,7 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 	const nh_BodyData* bodies = &d->bodies_at_setup;
 	nh_ContactImpulseData* imp = d->imp;
 	const uint32_t kcap = d->contact_capacity, B = d->body_count;
-	uint32_t* cursor = d->cont.cursor; uint32_t* pred_a = d->cont.pred_a; uint32_t* pred_b = d->cont.pred_b; uint32_t* level = d->cont.level;
+	uint32_t* pred_a = d->cont.pred_a; uint32_t* pred_b = d->cont.pred_b; uint32_t* level = d->cont.level;
 	uint32_t* slot_key = d->cont.slot_key; uint32_t* level_hist = d->cont.level_hist; uint32_t* level_cursor = d->cont.level_cursor;
 	uint32_t* general_list = d->general_list;
 	// one round trip: body classes, whether anything sleeps, whether the general adjacency build has work
@@ -2194,7 +2197,7 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 	if (d->has_late || ctx->h_state->has_static8 || !ctx->h_state->static_inert) ensure_csr(ctx, d);
 	if (d->has_late) {
 		// bodies in several pairs or with dynamic partners (piles, pits): general CSR fill + sort + classification, then the counts again
-		NH_LAUNCH(ctx, "adjacency_fill", k_adj_fill, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, contacts->tags, d->body_off, cursor, d->adj, d->body_class);
+		NH_LAUNCH(ctx, "adjacency_fill", k_adj_fill, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, contacts->tags, d->body_off, d->cont.cursor, d->adj, d->body_class);
 		NH_LAUNCH(ctx, "adjacency_sort", k_adj_sort, nh_grid_for(B, 256, 4096), 256, st, B, contacts->bodies, d->body_off, d->adj, slot_key, d->body_class, pred_a, pred_b, bodies->properties, bodies->momentum);
 		NH_LAUNCH(ctx, "contact_class", k_contact_class, nh_grid_for(kcap, 256, 2048), 256, st, contacts->bodies, d->body_class, level, general_list, pred_a, pred_b);
 		rc = nh_read_counts(ctx, &c);
