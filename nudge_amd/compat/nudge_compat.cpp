@@ -18,8 +18,9 @@
 //
 // Deviations from the reference, all forced by the implementation underneath:
 //   * `contacts` come back in tag order (the order the reference's solver consumes) instead of emission order;
-//     between collide() and write_cached_impulses() the caller may edit contact fields in place (friction,
-//     penetration ...) but must not reorder, add or remove contacts;
+//     between collide() and read_cached_impulses() the caller may edit contact fields in place (friction,
+//     penetration ...) and append contacts of its own behind the list (example/main.cpp:287: bump contacts.count),
+//     but must not reorder or remove contacts;
 //   * capacity overflows and arena exhaustion abort with a message (reference: assert / silent overflow);
 //   * scratch does not come from the caller's Arena (it is device memory owned by this layer); only the two
 //     opaque handles are allocated from it;
