@@ -1285,10 +1285,13 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		float4* fbox = ctx->fat_box;
 		uint2* kept = ctx->fat_pairs;
 		const uint32_t kept_cap = ctx->fat_pair_capacity;
+		const bool measure_skip = ctx->env_measure_skip && ctx->collide_seq > 66u;       // NH_MEASURE_SKIP_CHAINS=1: MEASUREMENT ONLY (wrong as soon as anything moves): what the launches that leave at once cost
+		if (!measure_skip) {
 		NH_LAUNCH(ctx, "cell_keys", k_cell_keys, nh_grid_for(C, 256, 2048), 256, st, C, aabb_min, aabb_max, fbox, keys_a, vals_a, large_list, cstart);
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_sums, max_cells / CS_TILE, 256, st, cstart, cscan_sums);
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_final, max_cells / CS_TILE, 256, st, cstart, cscan_sums, max_cells);
 		NH_LAUNCH(ctx, "cell_scatter", k_cell_scatter, nh_grid_for(C, 256, 2048), 256, st, C, keys_a, vals_a, cstart, fbox, keys_b, sbox);
+		}
 		// (KEPT: the chain fills the kept list, k_kept_filter makes this step's pairs of it; DIRECT: the chain writes this step's pairs itself)
 		const bool many_lanes = ctx->env_fp_sub ? ctx->env_fp_sub > 1 : C <= 16384u;
 #define NH_FIND_PAIRS(SUBL, DIR, OUT, OUTCAP) NH_LAUNCH(ctx, "find_pairs", (k_find_pairs<SUBL, DIR>), nh_grid_for((uint64_t)C * SUBL, 256, 4096), 256, st, C, nbox, keys_b, sbox, cstart, large_list, fbox, OUT, OUTCAP, \
@@ -1297,8 +1300,10 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 			if (many_lanes) NH_FIND_PAIRS(16, true, pairs, pair_cap); else NH_FIND_PAIRS(1, true, pairs, pair_cap);
 			NH_LAUNCH(ctx, "large_pairs", (k_large_pairs<true>), LP_GRID, LP_THREADS, st, nbox, sbox, cstart, large_list, fbox, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
 		} else {
+			if (!measure_skip) {
 			if (many_lanes) NH_FIND_PAIRS(16, false, kept, kept_cap); else NH_FIND_PAIRS(1, false, kept, kept_cap);
 			NH_LAUNCH(ctx, "large_pairs", (k_large_pairs<false>), LP_GRID, LP_THREADS, st, nbox, sbox, cstart, large_list, fbox, kept, kept_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+			}
 			// this step's pairs: the kept ones whose exact AABBs overlap now (every step)
 			NH_LAUNCH(ctx, "kept_filter", k_kept_filter, nh_grid_for(kept_cap, 256, 1024), 256, st, kept, kept_cap, nbox, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters,
 			          (seeded_sort && !ctx->env_no_sort_reuse) ? 1u : 0u);
@@ -1359,6 +1364,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	const uint64_t* sorted_keys = rec_key_a;
 	const uint32_t* sorted_idx = rec_idx_a;
 	if (seeded_sort) {
+		if (!(ctx->env_measure_skip && ctx->collide_seq > 66u))
 		nh_bucket_sort_u64_u32(ctx, rec_key_a, rec_key_b, rec_idx_a, rec_idx_b, pair_cap, sort_place, key_bits, ctx->sort_sorted_keys, ctx->sort_sorted_idx);
 		sorted_keys = ctx->sort_sorted_keys; sorted_idx = ctx->sort_sorted_idx;
 	} else if (onesweep) {

@@ -42,6 +42,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->env_no_sort_reuse = getenv("NH_NO_SORT_REUSE") != nullptr;      // the tag sort of the contact records runs every step even when nothing has changed (A/B, tests)
 	ctx->sort_keys_by_position = nullptr; ctx->sort_sorted_keys = nullptr; ctx->sort_sorted_idx = nullptr;
 	ctx->bp_seen_rebuilds = 0; ctx->bp_rebuild_streak = 0; ctx->bp_direct_left = 0;
+	ctx->env_measure_skip = getenv("NH_MEASURE_SKIP_CHAINS") != nullptr;      // MEASUREMENT ONLY: from step 67 on the launches of the grid chain and the tag sort are not issued at all (wrong as soon as anything moves)
 	ctx->env_no_fat = getenv("NH_NO_KEPT_PAIRS") != nullptr;      // the broadphase regroups and searches every step instead of re-using its kept pair list (A/B, tests)
 	ctx->fat_pairs = nullptr; ctx->fat_pair_capacity = 0; ctx->fat_box = nullptr; ctx->fat_collider_capacity = 0; ctx->fat_nbox = ctx->fat_nsph = 0xffffffffu;
 	ctx->env_colour_check_seeds = getenv("NH_COLOUR_CHECK_SEEDS") != nullptr;      // colours seeded from the cache go through a settle round instead of being final at once (A/B, tests)

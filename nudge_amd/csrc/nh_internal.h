@@ -172,6 +172,7 @@ struct nh_context {
 	float4* fat_box; uint32_t fat_collider_capacity;
 	uint32_t fat_nbox, fat_nsph;          // collider counts of the last nh_collide (a change invalidates the list)
 	uint32_t bp_seen_rebuilds, bp_rebuild_streak; int bp_direct_left;      // direct search instead of the kept list while every step rebuilds it (nh_collide)
+	bool env_measure_skip;                // NH_MEASURE_SKIP_CHAINS=1: measurement only (nh_collide)
 	bool env_no_fat;                      // NH_NO_KEPT_PAIRS=1: rebuild every step (A/B, tests)
 	uint32_t step_parity;
 	uint32_t order_seq;

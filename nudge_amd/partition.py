@@ -31,6 +31,12 @@ MOMENTUM (32 B) of the listed bodies again and overwrites its ghosts' momentum w
 crosses the cut, but every sweep starts from the owners' values on both sides instead of drifting apart for a whole step
 (the per-iteration ghost exchange).  Costs I extra neighbour messages per step; off by default.
 
+Re-balancing ("move cuts when |count_r - mean| > 5 %"): at every refresh the two ranks on either side of a cut tell each other how many
+bodies they own; when the two counts differ by more than 5 % of their sum the HEAVIER one picks the new cut -- the x that hands half the difference (at most
+5 % of its bodies per refresh: the capacity slack) to its neighbour -- and sends it over; the bodies between the old cut and the new one then migrate through the
+ordinary migration of that same refresh.  Neighbour messages only (two more tiny ones per refresh, one of them only when a cut moves); a cut never moves further
+from where it started than the static colliders a rank keeps allow (`split_scene(static_margin=...)`).
+
 Restriction: a dynamic body carries exactly ONE collider (any local transform); static colliders are unrestricted.
 
 Transport is pluggable: `LocalCluster` moves tensors between partitions living in one process (tests, one GPU),
@@ -123,7 +129,7 @@ def split_scene(scene, cuts, rank, slack=0.15, min_extra=4096, static_margin=Non
         cxf[sel] = scene[prefix + "_transforms"][ci]
         tag[sel] = scene[prefix + "_tags"][ci]
     extra = max(min_extra, int(slack * n))
-    info = dict(rank=rank, ranks=len(cuts) + 1, lo=float(lo), hi=float(hi), n_owned=n - 1, kind=kk.copy(), shape=shape, cxf=cxf, tag=tag,
+    info = dict(rank=rank, ranks=len(cuts) + 1, lo=float(lo), hi=float(hi), n_owned=n - 1, cut_slack=(float("inf") if static_margin is None else 0.5 * float(static_margin)), kind=kk.copy(), shape=shape, cxf=cxf, tag=tag,
                 reach=reach[body_map].copy(), max_reach=float(reach.max()) if len(reach) else 0.0,
                 n_static_box=n_static_box, n_static_sph=n_static_sph,
                 capacity=dict(bodies=n + extra, boxes=len(local["box_tags"]) + extra, spheres=len(local["sphere_tags"]) + extra),
@@ -137,9 +143,13 @@ class Partition:
     tensors (`records(name, bytes)`), `set_counts(bodies, boxes, spheres)`, `step(n)` and `params` -- nudge_amd.engine.World
     does; the CPU tests plug the oracle in behind the same four members."""
 
-    def __init__(self, engine, info, epoch=16, speed_floor=1.0, per_iteration=False):
+    def __init__(self, engine, info, epoch=16, speed_floor=1.0, per_iteration=False, rebalance=True, balance_tolerance=0.05):
         import torch
         self.per_iteration = per_iteration
+        self.rebalance, self.balance_tolerance = rebalance, balance_tolerance
+        self.cut0 = {-1: info["lo"], +1: info["hi"]}            # where the cuts started: they may move by at most cut_slack
+        self.cut_slack = info.get("cut_slack", float("inf"))
+        self._nb_count = {}
         self.torch = torch
         self.e = engine
         self.rank, self.ranks = info["rank"], info["ranks"]
@@ -176,7 +186,7 @@ class Partition:
         self.ghost_out32 = {-1: None, +1: None}
         self.ghost_in = {-1: 0, +1: 0}             # ghost records received from the left / right neighbour
         self.steps = 0
-        self.stats = dict(refreshes=0, migrated_out=0, migrated_in=0, ghosts=0, late_bodies=0, step_bytes=0, refresh_bytes=0)
+        self.stats = dict(refreshes=0, migrated_out=0, migrated_in=0, ghosts=0, late_bodies=0, step_bytes=0, refresh_bytes=0, cut_moves=0)
 
     # ---- helpers -------------------------------------------------------------------------------------------------
     def neighbours(self):
@@ -221,6 +231,72 @@ class Partition:
         pad = t.zeros((len(idx), 4), dtype=t.uint8, device=idx.device)
         pad[:, 0] = self.bi[idx, 0]
         return t.cat([self.bt[idx][:, :12], self.bt[idx][:, 16:], self.bm[idx], pad], dim=1)
+
+    # ---- refresh: phase 0 (re-balancing the cuts) ------------------------------------------------------------------
+    def balance_pack_counts(self):
+        """One 8-byte message per neighbour: how many bodies I own."""
+        t = self.torch
+        dev = self.bt.device
+        return {d: t.tensor([self.n_owned], dtype=t.int64, device=dev).view(t.uint8).reshape(1, 8) for d in self.neighbours()}
+
+    def _moves(self, d):
+        """Does the cut towards neighbour d move this refresh, and who picks the new place?  Both sides evaluate the same rule on the same two counts."""
+        if not self.rebalance or d not in self._nb_count:
+            return None
+        mine, theirs = self.n_owned, self._nb_count[d]
+        if abs(mine - theirs) <= self.balance_tolerance * max(1, mine + theirs):
+            return None
+        return "me" if mine > theirs else "neighbour"
+
+    def balance_unpack_counts(self, incoming):
+        t = self.torch
+        self._nb_count = {d: int(incoming[d].reshape(-1).view(t.int64)[0].item()) for d in self.neighbours() if d in incoming and incoming[d].numel()}
+
+    def balance_expected(self):
+        """Rows of the second message I expect from each neighbour (1 when the neighbour is the heavier side of a cut that moves)."""
+        return {d: (1 if self._moves(d) == "neighbour" else 0) for d in self.neighbours()}
+
+    def balance_pack_cuts(self):
+        """The heavier side of an unbalanced cut picks the x that hands half the difference -- at most 5 % of its bodies -- to the neighbour."""
+        t = self.torch
+        dev = self.bt.device
+        out = {}
+        n = self.n_owned
+        x = self._x(n + 1)[1:] if n else None
+        for d in self.neighbours():
+            rec = t.zeros((0, 8), dtype=t.uint8, device=dev)
+            if self._moves(d) == "me":                     # (the neighbour expects exactly one row then, whatever comes out)
+                old = self.lo if d < 0 else self.hi
+                cut = old
+                if n > 1:
+                    k = max(1, min((n - self._nb_count[d]) // 2, int(0.05 * n), n - 1))
+                    if d < 0:          # bodies with x < new lo leave: between the k-th and the (k+1)-th smallest x
+                        a, b = t.kthvalue(x, k).values, t.kthvalue(x, k + 1).values
+                    else:              # bodies with x >= new hi leave: between the k-th and the (k+1)-th largest x
+                        a, b = t.kthvalue(x, n - k + 1).values, t.kthvalue(x, n - k).values
+                    cut = 0.5 * (float(a) + float(b))
+                    # never further from where the cut started than the static colliders this rank kept allow
+                    cut = min(max(cut, self.cut0[d] - self.cut_slack), self.cut0[d] + self.cut_slack)
+                    if not np.isfinite(cut):
+                        cut = old
+                if cut != old:
+                    if d < 0: self.lo = cut
+                    else: self.hi = cut
+                    self.stats["cut_moves"] += 1
+                rec = t.tensor([cut], dtype=t.float64, device=dev).view(t.uint8).reshape(1, 8)
+            out[d] = rec
+        return out
+
+    def balance_unpack_cuts(self, incoming):
+        t = self.torch
+        for d in self.neighbours():
+            rec = incoming.get(d)
+            if rec is not None and rec.numel():
+                cut = float(rec.reshape(-1).view(t.float64)[0].item())
+                if cut != (self.lo if d < 0 else self.hi):
+                    if d < 0: self.lo = cut
+                    else: self.hi = cut
+                    self.stats["cut_moves"] += 1
 
     # ---- refresh: phase 1 (migration) --------------------------------------------------------------------------
     def refresh_pack_migrants(self):
@@ -412,6 +488,13 @@ class LocalCluster:
     def step(self, steps=1):
         for _ in range(steps):
             if self.parts[0].needs_refresh():
+                if self.parts[0].rebalance and self.parts[0].steps > 0:
+                    ins = self._route([p.balance_pack_counts() for p in self.parts])
+                    for p, i in zip(self.parts, ins):
+                        p.balance_unpack_counts(i)
+                    ins = self._route([p.balance_pack_cuts() for p in self.parts])
+                    for p, i in zip(self.parts, ins):
+                        p.balance_unpack_cuts(i)
                 ins = self._route([p.refresh_pack_migrants() for p in self.parts])
                 for p, i in zip(self.parts, ins):
                     p.refresh_unpack_migrants(i)
@@ -496,6 +579,9 @@ class DistCluster:
         p = self.p
         for _ in range(steps):
             if p.needs_refresh():
+                if p.rebalance and p.steps > 0:
+                    p.balance_unpack_counts(self._exchange(p.balance_pack_counts(), 8, known_counts={d: 1 for d in p.neighbours()}))
+                    p.balance_unpack_cuts(self._exchange(p.balance_pack_cuts(), 8, known_counts=p.balance_expected()))
                 p.refresh_unpack_migrants(self._exchange(p.refresh_pack_migrants(), FULL_BYTES))
                 p.refresh_unpack_ghosts(self._exchange(p.refresh_pack_ghosts(), FULL_BYTES))
             else:

@@ -242,3 +242,74 @@ def test_per_iteration_exchange_under_gloo(tmp_path):
         assert len(gb) == len(ob) > 10
         assert np.array_equal(gb[:, :12], ob[:, :12]) and np.array_equal(gb[:, 16:], ob[:, 16:])          # position, rotation (not the id field)
         assert np.array_equal(z[f"ghost_bm{me}"][:, :12], z[f"out_bm{owner}"][:, :12]) and np.array_equal(z[f"ghost_bm{me}"][:, 16:28], z[f"out_bm{owner}"][:, 16:28])
+
+
+def test_cuts_rebalance_when_the_slabs_are_uneven():
+    """"rebalance by moving cuts when |count_r - mean| > 5 %".  A tile cut 75 / 25: at every refresh the heavier rank of a cut hands up to 5 % of
+    its bodies over by moving the cut (they travel through the ordinary migration), until the two counts agree within the tolerance -- and the union still is the
+    single world (bit-identical while everything is airborne: who owns a body does not show in its state)."""
+    import partition_util as PU
+    scene = _drop_scene(side=20)
+    scene["body_transforms"]["position"][1:, 1] += 30.0          # high up: airborne for the whole test
+    x = scene["body_transforms"]["position"][1:, 0]
+    cuts = [float(np.quantile(x, 0.75)) + 0.37]
+    parts = []
+    for r in range(2):
+        local, info = PT.split_scene(scene, cuts, r, min_extra=512)
+        parts.append(PT.Partition(PU.OracleEngine(local, info["capacity"]), info, epoch=2))
+    n0 = [p.n_owned for p in parts]
+    assert n0[0] > 2.5 * n0[1]
+    cl = PT.LocalCluster(parts)
+    cl.step(60)
+    n1 = [p.n_owned for p in parts]
+    assert sum(n1) == sum(n0)
+    assert abs(n1[0] - n1[1]) <= 0.05 * sum(n1) + 20, (n0, n1)
+    assert parts[0].stats["cut_moves"] > 3 and parts[0].stats["cut_moves"] == parts[1].stats["cut_moves"]
+    assert parts[0].hi == parts[1].lo
+    got, ref = cl.gather(), PU.single_world_reference(scene, 60)
+    assert np.array_equal(got["ids"], np.arange(1, len(scene["body_transforms"])))
+    assert P.bits_equal(got["transforms"]["position"], ref["transforms"]["position"][1:])
+    assert P.bits_equal(got["momentum"]["velocity"], ref["momentum"]["velocity"][1:])
+
+
+def _gloo_rebalance_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    import partition_util as PU
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = _drop_scene(side=18)
+    scene["body_transforms"]["position"][1:, 1] += 30.0
+    x = scene["body_transforms"]["position"][1:, 0]
+    cuts = [float(np.quantile(x, 0.15)) + 0.37, float(np.quantile(x, 0.85)) + 0.37]        # 15 / 70 / 15: the middle rank is heavier than both neighbours
+    local, info = PT.split_scene(scene, cuts, rank, min_extra=512)
+    part = PT.Partition(PU.OracleEngine(local, info["capacity"]), info, epoch=2)
+    cl = PT.DistCluster(part)
+    cl.step(80)
+    got = cl.gather(dst=0)
+    counts = [None] * world
+    dist.all_gather_object(counts, (part.n_owned, part.stats["cut_moves"]))
+    if rank == 0:
+        np.savez(out_path, ids=got["ids"], transforms=got["transforms"], momentum=got["momentum"], counts=np.array(counts, dtype=np.int64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_three_ranks_rebalance(tmp_path):
+    """The same over torch.distributed (gloo, three ranks): the middle rank starts with 70 % of the bodies and gives to both sides; the count and cut
+    messages are neighbour point-to-point, the second one only between ranks whose cut moves."""
+    import torch.multiprocessing as mp
+    import partition_util as PU
+    port = 29500 + (os.getpid() % 400) + 41
+    out = str(tmp_path / "rebalance.npz")
+    mp.start_processes(_gloo_rebalance_worker, args=(3, port, out), nprocs=3, join=True, start_method="spawn")
+    got = np.load(out)
+    counts = got["counts"]
+    n = counts[:, 0]
+    assert abs(n[0] - n[1]) <= 0.05 * (n[0] + n[1]) + 20 and abs(n[1] - n[2]) <= 0.05 * (n[1] + n[2]) + 20, counts
+    assert counts[1, 1] > 4
+    scene = _drop_scene(side=18)
+    scene["body_transforms"]["position"][1:, 1] += 30.0
+    ref = PU.single_world_reference(scene, 80)
+    assert np.array_equal(got["ids"], np.arange(1, len(scene["body_transforms"])))
+    assert P.bits_equal(got["transforms"]["position"], ref["transforms"]["position"][1:])
