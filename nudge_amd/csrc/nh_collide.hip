@@ -1028,8 +1028,13 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 			// ONE atomic per body and pair: degree and pair info share a 64-bit counter (two 32-bit atomics per body used to make this kernel
 			// atomic-bound in a pit of 11 M contacts); no value is asked back -- a returning atomic is a memory round trip the wave waits for
 			if (cnt && start + cnt <= capacity) {
+#if defined(NH_GATHER_32)      // A/B only: the two 32-bit atomics per body of rounds 1 and 2, on the halves of the same counter
+				if (body_a) { uint32_t* h = reinterpret_cast<uint32_t*>(&pair_counter[body_a]); atomicAdd(h, cnt); atomicAdd(h + 1, body_b ? 0x10001u : 1u); first_contact[body_a] = start | 0x80000000u; }
+				if (body_b) { uint32_t* h = reinterpret_cast<uint32_t*>(&pair_counter[body_b]); atomicAdd(h, cnt); atomicAdd(h + 1, body_a ? 0x10001u : 1u); first_contact[body_b] = start; }
+#else
 				if (body_a) { atomicAdd(&pair_counter[body_a], (unsigned long long)cnt | ((unsigned long long)(body_b ? 0x10001u : 1u) << 32)); first_contact[body_a] = start | 0x80000000u; }      // top bit: plays "a"
 				if (body_b) { atomicAdd(&pair_counter[body_b], (unsigned long long)cnt | ((unsigned long long)(body_a ? 0x10001u : 1u) << 32)); first_contact[body_b] = start; }
+#endif
 			}
 		}
 		const uint32_t base = __shfl(start, 0);                  // lane 0 is always a valid record here

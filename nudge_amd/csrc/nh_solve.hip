@@ -190,8 +190,9 @@ __global__ __launch_bounds__(256) void k_adj_fill(const nh_DevState* __restrict_
 		uint32_t len = run_length(tags, i, n);
 		if (!len) continue;
 		nh_BodyPair p = bodies[i];
-		if (p.a && body_class[p.a] == NH_CLS_PENDING) { uint32_t base = off[p.a] + atomicAdd(&cursor[p.a], len); for (uint32_t k = 0; k < len; ++k) adj[base + k] = i + k; }
-		if (p.b && body_class[p.b] == NH_CLS_PENDING) { uint32_t base = off[p.b] + atomicAdd(&cursor[p.b], len); for (uint32_t k = 0; k < len; ++k) adj[base + k] = i + k; }
+		const uint32_t ca = p.a ? body_class[p.a] : NH_CLS_NONE, cb = p.b ? body_class[p.b] : NH_CLS_NONE;      // (general bodies settled by k_adj_simple need their lists too)
+		if (ca == NH_CLS_PENDING || ca == NH_CLS_GENERAL) { uint32_t base = off[p.a] + atomicAdd(&cursor[p.a], len); for (uint32_t k = 0; k < len; ++k) adj[base + k] = i + k; }
+		if (cb == NH_CLS_PENDING || cb == NH_CLS_GENERAL) { uint32_t base = off[p.b] + atomicAdd(&cursor[p.b], len); for (uint32_t k = 0; k < len; ++k) adj[base + k] = i + k; }
 	}
 }
 
@@ -256,6 +257,13 @@ __global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st
 				if (d <= 4u) emit(std::integral_constant<int, 4>()); else emit(std::integral_constant<int, 8>());
 				cls = d <= 4u ? NH_CLS_STATIC4 : NH_CLS_STATIC8;
 				if (cls == NH_CLS_STATIC8) st->has_static8 = 1;
+			} else if (!slot_key && (inf >> 16) != 0u) {
+				// default (colour) order and a dynamic partner: a general body, settled here -- its adjacency list is filled like a pending body's
+				// (k_adj_fill) but needs neither the per-body sort by slot key nor the predecessor links of the exact order (k_adj_sort walks and
+				// sorts every list it classifies: 0.5 ms in a pit of 4 M spheres that are ALL of this kind)
+				cls = NH_CLS_GENERAL;
+				st->has_pending = 1;
+				momentum[x].unused0 = props[x].mass_inverse;         // (nudge.cpp:4198: the level-scheduled sweeps read it from there)
 			} else {
 				cls = NH_CLS_PENDING;
 				st->has_pending = 1;
