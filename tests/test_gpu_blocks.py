@@ -141,3 +141,22 @@ def test_blocked_heap_of_boxes_and_spheres_full_rows_and_residual_contacts(monke
     assert abs(landed_x - landed_z) < 0.05
     assert abs(ca["contacts"] - cc["contacts"]) < 0.1 * cc["contacts"] + 100
     a.close(); b.close(); c.close()
+
+
+def test_blocked_structure_check_on_a_million_spheres(monkeypatch):
+    """The device-side structure check (NH_BLK_CHECK=1) at the scale the blocked solver is built for: a 100^3 pit -- a million spheres, ~1000 blocks of the
+    default size, blocks that overflow while the pile collapses and are rebuilt smaller -- every step of the collapse and the first settling: every local
+    index resolves to the body its contact names, no two blocks of a launch touch one body, no block list holds two contacts of one colour on one body."""
+    scene = S.ball_pit(100, 100, 100, seed=6)
+    nb = 100 ** 3
+    w = _world(monkeypatch, scene, dict(NH_BLK_CHECK=1), max_contacts=5 * nb, max_pairs=7 * nb)
+    blocked_steps = 0
+    for upto in (100, 200, 300):
+        w.step(upto - w.steps_done)
+        c = w.counts()
+        assert c["error"] == 0, c
+        blocked_steps += int(c["general_contacts"] >= 200000)
+    assert blocked_steps >= 2, "the blocked solver was meant to have run (general contacts above its threshold)"
+    g = _gpu_pit_stats(w, scene)
+    assert g["inside"] == 1.0 and g["max_pen"] <= 0.25, g
+    w.close()
