@@ -87,14 +87,16 @@ enum {
 	NH_FLAG_SINGLE_APPLY = 4u,   /* the caller promises ONE nh_apply_impulses(..., iterations) per nh_setup_contact_constraints (the whole
 	                                iteration loop of example/main.cpp:313-318 in one call): the per-contact solver states that only a
 	                                further nh_apply_impulses call would read are then not written (16 B per contact per step); a
-	                                second call for the same setup returns NH_ERR_INVALID                                   */
+	                                second call for the same setup returns NH_ERR_INVALID.  Entry points that complete a deferred setup
+	                                before the first apply (nh_read_counts, nh_synchronize ...) keep the states: the apply after them works */
 	NH_FLAG_FUSED_STEP = 8u,     /* implies NH_FLAG_SINGLE_APPLY.  The caller promises the call order of the sample's step (example/main.cpp:286-330):
 	                                nh_collide, nh_apply_gravity_damping(dt), nh_read_cached_impulses, nh_setup_contact_constraints, one
 	                                nh_apply_impulses, nh_update_cached_impulses, nh_write_cached_impulses, nh_advance(dt), and does not touch body
 	                                state in between.  Gravity / damping and the advance of the bodies whose only contacts are with the inert
 	                                static world then happen inside their solver kernel (same arithmetic, two passes over the body state less);
 	                                every other body goes through the ordinary kernels.  Any other entry point in between settles the pending
-	                                gravity first; nh_advance with a different time step than the solver was given returns NH_ERR_INVALID   */
+	                                gravity first; nh_advance with a different time step than gravity was given returns NH_ERR_INVALID -- a broken
+	                                promise, found after the solver has moved its bodies by gravity's step: do not continue that world       */
 	NH_FLAG_EXACT_ORDER = 2u     /* solver visits contacts in the reference's greedy batch order, replayed
 	                                exactly on the device (nudge.cpp:4206-4339); default is the closed-form
 	                                round-robin order, identical whenever the greedy scheduler meets no

@@ -160,6 +160,7 @@ __global__ __launch_bounds__(64) void k_grid_setup(nh_DevState* st, uint32_t nco
 	if (!rebuild) return;
 	st->fat_margin = direct ? 0.0f : nh_kept_margin(st->cell_inv);           // (of the grid about to be replaced: what k_xform used)
 	st->fat_valid = direct ? 0u : 1u; st->fat_count = 0u; st->fat_count_sph = 0u; st->fat_rebuilds += 1u;
+	st->large = 0u;             // (counted again by k_cell_keys of this rebuild; steps that re-use the kept list keep the count of the rebuild they live on)
 	// e = largest size class (exponent << 2 | two mantissa bits) kept "small"; never let the cell underflow to denormals
 	if (e < (64 << 2)) e = 64 << 2;
 	if (e > (190 << 2)) e = 190 << 2;
@@ -1124,7 +1125,7 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 	uint32_t t = threadIdx.x;
 	if (t == 0) {
 		st->colliders = ncolliders; st->pairs = 0; st->pairs_sph = 0; st->raw_contacts = 0; st->records = 0; st->contacts = 0; st->sleeping = 0;
-		st->active = 0; st->culled = 0; st->large = 0; st->general_contacts = 0; st->levels = 0; st->error = 0;
+		st->active = 0; st->culled = 0; st->general_contacts = 0; st->levels = 0; st->error = 0;
 		st->has_other = 0; st->unleveled = 0; st->has_static8 = 0; st->has_staticN = 0; st->any_sleeping = 0; st->has_pending = 0;
 		st->sort_buckets = st->sort_buckets_next;
 		st->fat_escaped = 0; st->fat_rebuild = 0;

@@ -267,6 +267,7 @@ struct nh_ContactConstraintData {
 	// one-body path: row build + warm start are deferred into the first nh_apply_impulses (or the next call that observes
 	// momentum / impulses); `setup_pending` says they have not run yet
 	bool setup_pending;
+	bool states_kept;          // the first solver call stored its states: another nh_apply_impulses can continue (false after an applied NH_FLAG_SINGLE_APPLY call)
 	nh_ContactImpulseData* imp;
 	nh_BodyData bodies_at_setup;
 	// nh_setup_contact_constraints returns WITHOUT a host round trip; what needs the device counters (general adjacency, culling,

@@ -2336,7 +2336,7 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 
 // Solver launches for the one-body classes.  `early4_done`: the STATIC4 bodies classified by k_adj_simple have already been taken by
 // the speculative launch (only possible when body 0 is inert: that launch checks it on the device and leaves otherwise).
-static void launch_apply_static(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations, bool fused, bool early4_done) {
+static void launch_apply_static(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations, bool fused, bool early4_done, bool drop_states = false) {
 	const uint32_t B = d->body_count;
 	if (!(fused && early4_done && !d->has_late && !d->has_static8 && !d->has_staticN)) ensure_csr(ctx, d);      // (the common step launches nothing below)
 	nh_CacheView cv = { nullptr, nullptr, nullptr, nullptr, nullptr, ctx->d_state };
@@ -2348,7 +2348,7 @@ static void launch_apply_static(nh_context* ctx, nh_ContactConstraintData* d, co
 	auto go1 = [&](const char* name, auto kernel, uint32_t cls_a, uint32_t cls_b) {
 		NH_LAUNCH(ctx, name, kernel, nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
 		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, cls_a, cls_b,
-		          (fused && (ctx->flags & NH_FLAG_SINGLE_APPLY)) ? 2u : 0u, (const uint2*)nullptr, nh_FusedStep());
+		          (fused && drop_states) ? 2u : 0u, (const uint2*)nullptr, nh_FusedStep());
 	};
 	const bool late = d->has_late;
 	if (d->static_inert) {
@@ -2382,9 +2382,13 @@ static int settle_gravity(nh_context* ctx) {
 	return NH_OK;
 }
 
-// `from_apply`: called by nh_apply_impulses itself (not by the flush of a setup nobody applied): with NH_FLAG_FUSED_STEP the caller has promised
+// `applied`: called by nh_apply_impulses itself (not by the flush of a setup nobody applied): with NH_FLAG_FUSED_STEP the caller has promised
 // that this is the step's only solver call, so the bodies of the fused kernel are advanced there too
-static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations, bool from_apply = false) {
+static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations, bool applied = false) {
+	// the flush of a setup nobody applied yet keeps the solver states whatever the flags say: an nh_apply_impulses may still follow (nh_read_counts
+	// or nh_synchronize between setup and apply must not break the step)
+	const bool from_apply = applied && (ctx->flags & NH_FLAG_FUSED_STEP), drop_states = applied && (ctx->flags & NH_FLAG_SINGLE_APPLY);
+	d->states_kept = !drop_states;
 	bool early4_done = false;
 	if (!d->finish_pending) { int rc = settle_gravity(ctx); if (rc) return rc; }
 	if (d->finish_pending) {
@@ -2402,14 +2406,14 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 		}
 #define NH_SOLVE_CONTIG(NWAVES) NH_LAUNCH(ctx, "solve_one_body", (k_solve_one_body<4, true, true, NWAVES>), (B + 64u * NWAVES - 1u) / (64u * NWAVES), 64 * NWAVES, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum, \
 		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, \
-		          1u | ((ctx->flags & NH_FLAG_SINGLE_APPLY) ? 2u : 0u), d->simple, fs)
+		          1u | (drop_states ? 2u : 0u), d->simple, fs)
 		if (ctx->env_solver_waves == 4) NH_SOLVE_CONTIG(4); else if (ctx->env_solver_waves == 2) NH_SOLVE_CONTIG(2); else NH_SOLVE_CONTIG(1);
 		ctx->grav.rest_pending = gravity_here;        // everybody else's gravity: finish_setup, once the round trip has told whether there is anybody else
 		int rc = finish_setup(ctx, d);
 		if (rc) return rc;
 		early4_done = d->static_inert;          // (if body 0 is not inert the speculative launch left at once and the general kernels take everything)
 	}
-	launch_apply_static(ctx, d, bodies, iterations, true, early4_done);
+	launch_apply_static(ctx, d, bodies, iterations, true, early4_done, drop_states);
 	return NH_OK;
 }
 
@@ -2435,10 +2439,10 @@ extern "C" int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* d, c
 	if (ctx->pending && ctx->pending != d) { int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	ctx->gravity_may_overlap = false; ctx->after_collide = false;
 	const bool first = d->setup_pending;
-	if (!first && (ctx->flags & NH_FLAG_SINGLE_APPLY)) return NH_ERR_INVALID;      // the states of the first call were not kept
+	if (!first && !d->states_kept) return NH_ERR_INVALID;      // NH_FLAG_SINGLE_APPLY: the states of the first call were not kept
 	d->setup_pending = false;
 	ctx->pending = nullptr;
-	if (first) { int rc = first_apply(ctx, d, bodies, iterations, (ctx->flags & NH_FLAG_FUSED_STEP) != 0); if (rc) return rc; }
+	if (first) { int rc = first_apply(ctx, d, bodies, iterations, true); if (rc) return rc; }
 	else { int rc = settle_gravity(ctx); if (rc) return rc; launch_apply_static(ctx, d, bodies, iterations, false, false); }
 	if (d->general_contacts && d->blk.active) {
 		const bool warm = d->blk.warm_pending;

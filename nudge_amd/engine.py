@@ -297,9 +297,13 @@ class World:
             self.update()
             self.write_cache()
             self.advance()
-            self.steps_done += 1
-            if self.flags & NH_FLAG_SYNC_COUNTS:
-                self.sum_contacts += self.contacts.count
+            self.step_done()
+
+    def step_done(self):
+        """Book-keeping of one finished step; callers that drive the eight calls themselves (partition.py, per-iteration exchange) call it after advance()."""
+        self.steps_done += 1
+        if self.flags & NH_FLAG_SYNC_COUNTS:
+            self.sum_contacts += self.contacts.count
 
     # ---- checkpoint / restore of the caller-owned persistent state (bodies + contact cache), device to device ----
     def snapshot(self):

@@ -146,6 +146,10 @@ class Partition:
     def __init__(self, engine, info, epoch=16, speed_floor=1.0, per_iteration=False, rebalance=True, balance_tolerance=0.05):
         import torch
         self.per_iteration = per_iteration
+        # per-iteration exchange = one apply call per sweep with ghost momentum written in between: the engine must keep its solver states and
+        # re-read momentum every call, which NH_FLAG_SINGLE_APPLY (4) / NH_FLAG_FUSED_STEP (8) promise away
+        if per_iteration and (getattr(engine, "flags", 0) & (4 | 8)):
+            raise ValueError("per_iteration=True needs an engine without NH_FLAG_SINGLE_APPLY / NH_FLAG_FUSED_STEP")
         self.rebalance, self.balance_tolerance = rebalance, balance_tolerance
         self.cut0 = {-1: info["lo"], +1: info["hi"]}            # where the cuts started: they may move by at most cut_slack
         self.cut_slack = info.get("cut_slack", float("inf"))

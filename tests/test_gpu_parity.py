@@ -466,6 +466,36 @@ def test_fused_step_flag_changes_nothing(name, steps, flags):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("flags", [E.NH_FLAG_SINGLE_APPLY, E.NH_FLAG_FUSED_STEP])
+@pytest.mark.parametrize("name,steps", [("grid30_awake", 60), ("mixed20", 120), ("pile256", 200)])
+def test_counts_or_synchronize_between_setup_and_apply_do_not_break_the_step(name, steps, flags):
+    """nh_read_counts / nh_synchronize complete a deferred setup (header note 7).  Under NH_FLAG_SINGLE_APPLY that used to consume the setup without
+    keeping the solver states, and the apply that followed was refused; now the completion keeps them and the step gives the bits of a plain world.
+    A large collider count also has to survive the steps that re-use the kept pair list."""
+    scene, _ = G.build(name)
+    a, b = E.World(scene, flags=0), E.World(scene, flags=flags)
+    a.step(steps); b.step(steps)
+    for variant in range(3):
+        for w in (a, b):
+            w.collide(); w.gravity(); w.read_cache(); w.setup()
+            if w is b and variant == 0: assert w.counts()["error"] == 0
+            if w is b and variant == 1: w.synchronize()
+            if w is b and variant == 2: w.get_contacts()
+            w.apply(None); w.update(); w.write_cache(); w.advance()
+        x, y = a.get_bodies(), b.get_bodies()
+        assert P.bits_equal(x["transforms"], y["transforms"]) and P.bits_equal(x["momentum"], y["momentum"]) and np.array_equal(x["idle"], y["idle"]), variant
+    ca, cb = a.get_cache(), b.get_cache()
+    assert ca["count"] == cb["count"] and P.bits_equal(ca["data"]["impulse"], cb["data"]["impulse"])
+    b.step(3); a.step(3)
+    c = b.counts()
+    assert c["error"] == 0 and c["large_colliders"] == a.counts()["large_colliders"]
+    if c["sort_reuses"] or c["broadphase_rebuilds"] < b.steps_done:
+        assert c["large_colliders"] >= 1, "the ground slab is a large collider on every step, not only on rebuild steps"
+    x, y = a.get_bodies(), b.get_bodies()
+    assert P.bits_equal(x["transforms"], y["transforms"]) and P.bits_equal(x["momentum"], y["momentum"])
+    a.close(); b.close()
+
+
 def test_fused_step_survives_calls_that_break_the_promised_order():
     """Any entry point other than read / setup / apply between gravity and the solver settles the pending gravity with the ordinary kernel, a
     flush of the setup (update without apply) consumes it without advancing anybody, and nh_advance with another time step is refused."""
