@@ -30,8 +30,10 @@
 #ifndef NH_BLOCKS_H
 #define NH_BLOCKS_H
 
+#ifndef NH_BLK_CAP
 #define NH_BLK_CAP 2400u                 // momentum records in one workgroup's LDS: slot 0 = the static world, own bodies, ghosts (76.8 KB: two workgroups per CU)
 #define NH_BLK_THREADS 512
+#endif
 #define NH_BLK_RANK_BITS 12u
 #define NH_BLK_RANK_MASK ((1u << NH_BLK_RANK_BITS) - 1u)
 #define NH_BLK_HASH 4096u                // ghost table of k_blk_prepare (open addressing in LDS)

@@ -1353,7 +1353,8 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	}
 	// (nobody asleep -- known on the device, or already on the host: the active list is 1 .. B-1, written without looking at any set)
 	NH_LAUNCH(ctx, "active_write", k_active_write, nh_grid_for(B, 256, 2048), 256, st, B, root_of, set_active, flags, active_bodies->indices, active_bodies->capacity, ctx->step_parity, no_islands ? 1u : 0u, block_top, begin_grid);
-	if (ctx->side) NH_HIP_CHECK(ctx, hipEventRecord(ctx->ev_active, ctx->stream));         // (ctx->stream is the side stream inside a fork)
+	// (what a gravity call on the side stream waits for; NH_FLAG_FUSED_STEP never takes that road, and an event on the stream is a bubble of a few microseconds)
+	if (ctx->side && !(ctx->flags & NH_FLAG_FUSED_STEP)) NH_HIP_CHECK(ctx, hipEventRecord(ctx->ev_active, ctx->stream));         // (ctx->stream is the side stream inside a fork)
 	if (!no_islands) NH_LAUNCH(ctx, "filter_records", k_filter_records, nh_grid_for(pair_cap, 256, 2048), 256, st, rec, root_of, set_active, ctx->step_parity);
 	if (fork) {
 		ctx->stream = main_stream;

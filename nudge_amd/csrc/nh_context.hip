@@ -128,11 +128,8 @@ extern "C" int nh_synchronize(nh_context* ctx) {
 	return NH_OK;
 }
 
-extern "C" int nh_read_counts(nh_context* ctx, nh_Counts* out) {
-	if (!ctx || !out) return NH_ERR_INVALID;
-	{ int rc = nh_flush_pending(ctx, true); if (rc) return rc; }      // (counters only: a pending NH_FLAG_FUSED_STEP gravity stays pending)
-	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, 27 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+// the mirrored counter block -> what callers see (and the host's sleep prediction)
+void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out) {
 	const nh_DevState* h = ctx->h_state;
 	// what the last nh_collide saw -- unless the counters have been rewritten since (nh_bodies_changed, nh_halo_unpack): then it describes another state
 	if (ctx->collide_seq && !ctx->idle_unknown) { ctx->idle_bound = (int)h->max_idle[ctx->step_parity]; ctx->idle_bound_mark = ctx->collide_mark; }
@@ -140,6 +137,14 @@ extern "C" int nh_read_counts(nh_context* ctx, nh_Counts* out) {
 	out->active_bodies = h->active; out->cache = h->cache; out->culled = h->culled; out->large_colliders = h->large;
 	out->general_contacts = h->general_contacts; out->levels = h->levels; out->error = h->error;
 	out->has_other_bodies = h->has_other; out->broadphase_rebuilds = h->fat_rebuilds; out->sort_reuses = h->sort_reuses; out->unleveled = h->unleveled; out->raw_pairs = h->pairs + h->pairs_sph;
+}
+
+extern "C" int nh_read_counts(nh_context* ctx, nh_Counts* out) {
+	if (!ctx || !out) return NH_ERR_INVALID;
+	{ int rc = nh_flush_pending(ctx, true); if (rc) return rc; }      // (counters only: a pending NH_FLAG_FUSED_STEP gravity stays pending)
+	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, NH_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+	nh_counts_from_mirror(ctx, out);
 	if (ctx->timing) nh_timer_collect(ctx);
 	return NH_OK;
 }

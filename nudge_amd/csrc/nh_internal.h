@@ -217,6 +217,8 @@ struct nh_context {
 
 // Runs work that an earlier call deferred; every entry point that reads or writes momentum / impulses calls it first.
 int nh_flush_pending(nh_context* ctx, bool keep_gravity = false);
+void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out);
+#define NH_COUNTER_WORDS 27u          // leading words of nh_DevState that the host mirrors (nh_read_counts)
 
 struct nh_ContactImpulseData {
 	nh_CachedContactImpulse* data;        // K, contact (tag) order; holds the warm-start impulses once `lookup_pending` is false

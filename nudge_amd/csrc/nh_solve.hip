@@ -2159,6 +2159,7 @@ static void blk_run(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyD
 		// NH_BLK_PROFILE=1: the last sweep's eight launches, per workgroup: prologue / colours / epilogue in microseconds (100 MHz clock)
 		hipStreamSynchronize(ctx->stream);
 		std::vector<unsigned long long> h(4u * NH_BLK_MAX_BLOCKS);
+		unsigned long long prev_end = 0;
 		for (int p = 0; p < 8; ++p) {
 			const uint32_t n = d->blk.phase_count[p];
 			if (!n) continue;
@@ -2171,8 +2172,9 @@ static void blk_run(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyD
 				if (h[4 * i] < first) first = h[4 * i];
 				if (h[4 * i + 3] > lastt) lastt = h[4 * i + 3];
 			}
-			fprintf(stderr, "blk_profile phase %d: %u workgroups, first start to last end %.1f us; mean (max) us: prologue %.2f (%.2f), colours %.2f (%.2f), epilogue %.2f (%.2f)\n",
-			        p, n, 0.01 * (double)(lastt - first), s0 / n, m0, s1 / n, m1, s2 / n, m2);
+			fprintf(stderr, "blk_profile phase %d: %u workgroups, first start to last end %.1f us (%.1f us after the previous launch's last end); mean (max) us: prologue %.2f (%.2f), colours %.2f (%.2f), epilogue %.2f (%.2f)\n",
+			        p, n, 0.01 * (double)(lastt - first), prev_end ? 0.01 * (double)((long long)first - (long long)prev_end) : 0.0, s0 / n, m0, s1 / n, m1, s2 / n, m2);
+			prev_end = lastt;
 		}
 	}
 	NH_LAUNCH(ctx, "blk_scatter_back", k_blk_scatter_back, nh_grid_for(B, 256, 4096), 256, B, k.brank, k.own_base, (const float4*)k.bm, (float4*)bodies->momentum);
