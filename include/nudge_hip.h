@@ -176,6 +176,8 @@ typedef struct nh_Counts {
 	uint32_t broadphase_rebuilds; /* nh_collide calls since nh_create that regrouped the colliders and searched the grid; the others re-used the kept pair list */
 	uint32_t sort_reuses;       /* nh_collide calls since nh_create that skipped the tag sort of the contact records: every record sat where it sat the step
 	                               before, with the same key */
+	uint32_t broadphase_inserts; /* colliders that left their inflated box and were re-inserted into the kept pair list (new box, new pairs) without a rebuild,
+	                               since nh_create */
 } nh_Counts;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */

@@ -18,6 +18,10 @@
 // 1024-thread workgroups, one per CU: the scene bounds / histogram end in a handful of global atomics per WORKGROUP on the same
 // few addresses (~12 ns each, serialised), so the fewer workgroups the better.
 // inflation of the kept pair list's boxes: 1/32 of the last grid's cell (nothing is known before the first grid)
+#define NH_ESC_MAX 4096u             // colliders re-inserted per step at most (more leave their boxes: rebuild)
+#define NH_MOVED_MAX 16384u          // colliders re-inserted since the last rebuild at most (their grid entries are stale: the next leaver is tested against each of them)
+#define NH_GEN_SHIFT 24u             // kept pairs carry the generation stamps of their two colliders above the 24-bit collider index
+#define NH_GEN_INDEX 0xFFFFFFu
 __device__ __forceinline__ float nh_kept_margin(float cell_inv) { return cell_inv > 0.0f ? 0.03125f / cell_inv : 0.05f; }
 
 __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
@@ -25,7 +29,8 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
                                                const nh_Transform* __restrict__ box_xf, const nh_BoxCollider* __restrict__ box_data, const uint32_t* __restrict__ box_tags, uint32_t nbox,
                                                const nh_Transform* __restrict__ sph_xf, const nh_SphereCollider* __restrict__ sph_data, const uint32_t* __restrict__ sph_tags, uint32_t nsph,
                                                nh_xform* __restrict__ xf, float4* __restrict__ aabb_min, float4* __restrict__ aabb_max, uint32_t* __restrict__ ctag,
-                                               uint4* __restrict__ zero16, uint32_t zero16_count, const float4* __restrict__ fat_box, uint32_t direct) {
+                                               uint4* __restrict__ zero16, uint32_t zero16_count, float4* fat_box, uint32_t direct,
+                                               uint8_t* __restrict__ gen, uint32_t* __restrict__ esc_mark, uint32_t* __restrict__ esc_list, uint32_t* __restrict__ moved_list, uint32_t seq) {
 	__shared__ uint32_t hist[1024];
 	__shared__ uint32_t red[12];
 	hist[threadIdx.x] = 0;
@@ -75,14 +80,33 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 		xf[c] = w;
 		aabb_min[c] = make_float4(mnx, mny, mnz, __uint_as_float(l.body));
 		aabb_max[c] = make_float4(mxx, mxy, mxz, ext);
-		if (fat_valid) {
-			const float4 fmn = fat_box[2u * c], fmx = fat_box[2u * c + 1u];
-			escaped |= !(mnx >= fmn.x && mny >= fmn.y && mnz >= fmn.z && mxx <= fmx.x && mxy <= fmx.y && mxz <= fmx.z);       // (NaN: escaped)
-		}
 		// the inflated box a rebuild would sort and search (k_cell_keys writes it then): the grid's statistics (size class, bounds of the small
 		// ones) are taken from it; the Morton frame (lmin / lmax) is the exact AABBs' (nudge.cpp:3086-3100)
 		const float fx0 = mnx - margin, fy0 = mny - margin, fz0 = mnz - margin, fx1 = mxx + margin, fy1 = mxy + margin, fz1 = mxz + margin;
 		const float fext = fmaxf(fmaxf(fx1 - fx0, fy1 - fy0), fz1 - fz0);
+		bool out = false;
+		if (fat_valid) {
+			const float4 fmn = fat_box[2u * c], fmx = fat_box[2u * c + 1u];
+			out = !(mnx >= fmn.x && mny >= fmn.y && mnz >= fmn.z && mxx <= fmx.x && mxy <= fmx.y && mxz <= fmx.z);       // (NaN: out)
+		}
+		if (gen) {
+			// Re-insertion ("7." below): a SMALL collider that has left its box takes the candidate box as its new one right here, gets the next generation
+			// stamp (its kept pairs die) and goes on this step's list of leavers; k_reinsert finds its new pairs.  Large colliders, worn-out stamps, full
+			// lists and boxes that are no longer small for the grid end in the rebuild instead.
+			const uint32_t g = out ? gen[c] : 0u;
+			bool again = out && !(g & 0x80u) && (g & 0x7Fu) < 127u && ((__float_as_uint(fext) >> 21) & 1023u) <= guess_exp && fext == fext;
+			const uint32_t eslot = nh_wave_reserve1(&st->esc_count, again);
+			const uint32_t mslot = nh_wave_reserve1(&st->moved_count, again && (g & 0x7Fu) == 0u);
+			if (again && (eslot >= NH_ESC_MAX || ((g & 0x7Fu) == 0u && mslot >= NH_MOVED_MAX))) again = false;
+			if (again) {
+				esc_list[eslot] = c;
+				if ((g & 0x7Fu) == 0u) moved_list[mslot] = c;
+				gen[c] = (uint8_t)(g + 1u); esc_mark[c] = seq;
+				fat_box[2u * c] = make_float4(fx0, fy0, fz0, __uint_as_float(l.body)); fat_box[2u * c + 1u] = make_float4(fx1, fy1, fz1, fext);
+				out = false;
+			}
+		}
+		escaped |= out;
 		uint32_t f;
 		f = nh_float_flip(mnx); lmin[0] = min(lmin[0], f); lmax[0] = max(lmax[0], f);
 		f = nh_float_flip(mny); lmin[1] = min(lmin[1], f); lmax[1] = max(lmax[1], f);
@@ -123,7 +147,7 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 // needs -- an L2 write-back per workgroup on this multi-die part -- cost 100 us, twenty times the launch it saved.)
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return *p; }
 
-__global__ __launch_bounds__(64) void k_grid_setup(nh_DevState* st, uint32_t ncolliders, uint32_t max_cells, uint32_t direct) {
+__global__ __launch_bounds__(64) void k_grid_setup(nh_DevState* st, uint32_t ncolliders, uint32_t max_cells, uint32_t direct, uint32_t kept_cap) {
 	// small/large split: allow at most max(64, C/1024) colliders above the grid's cell size.  e = largest size class kept small =
 	// the highest class whose suffix count (colliders in classes >= e) exceeds the budget.  One wave: lane l owns classes 16l..16l+15.
 	const uint32_t budget = max(ncolliders / 1024u, 64u);
@@ -155,9 +179,15 @@ __global__ __launch_bounds__(64) void k_grid_setup(nh_DevState* st, uint32_t nco
 	// kept pair list: while it is valid and nobody has left its inflated box the grid below is not needed this step -- every kernel of the chain
 	// (k_cell_keys .. k_large_pairs) leaves at once and k_kept_filter re-tests the kept pairs; otherwise the candidate boxes k_xform just
 	// wrote become the current ones and the chain rebuilds the list from them
-	const bool rebuild = direct || st->fat_valid == 0u || st->fat_escaped != 0u;
+	// (re-insertions append to the kept list and leave dead pairs behind: when this step's -- 64 pairs per leaver allowed for -- would fill it beyond seven
+	// eighths it is rebuilt instead, which compacts it; and when more than a sixteenth of the world has left, regrouping everybody is the cheaper way)
+	const uint32_t leavers = st->esc_count;
+	const bool crowded = leavers != 0u && ((uint64_t)st->fat_count + st->fat_count_sph + 64ull * leavers > (uint64_t)kept_cap / 8u * 7u || (uint64_t)leavers * 16u > ncolliders);
+	const bool rebuild = direct || st->fat_valid == 0u || st->fat_escaped != 0u || crowded;
 	st->fat_rebuild = rebuild ? 1u : 0u;
-	if (!rebuild) return;
+	st->fat_reinsert = !rebuild && st->esc_count != 0u ? 1u : 0u;
+	if (!rebuild) { st->fat_inserts += st->esc_count; return; }
+	st->moved_count = 0u;
 	st->fat_margin = direct ? 0.0f : nh_kept_margin(st->cell_inv);           // (of the grid about to be replaced: what k_xform used)
 	st->fat_valid = direct ? 0u : 1u; st->fat_count = 0u; st->fat_count_sph = 0u; st->fat_rebuilds += 1u;
 	st->large = 0u;             // (counted again by k_cell_keys of this rebuild; steps that re-use the kept list keep the count of the rebuild they live on)
@@ -208,7 +238,7 @@ __device__ __forceinline__ int cell_coord(float x, float origin, float inv) {
 __global__ __launch_bounds__(256) void k_cell_keys(nh_DevState* __restrict__ st, uint32_t n,
                                                    const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max, float4* __restrict__ box,
                                                    uint32_t* __restrict__ keys, uint32_t* __restrict__ rank, uint32_t* __restrict__ large_list,
-                                                   uint32_t* __restrict__ cstart) {
+                                                   uint32_t* __restrict__ cstart, uint8_t* __restrict__ gen) {
 	if (!st->fat_rebuild) return;
 	// (the inflated boxes of this rebuild: box[2c] = min, body; box[2c + 1] = max, extent -- written here, read by the rest of the chain and,
 	// in the steps that re-use the kept pairs, by k_xform)
@@ -241,6 +271,7 @@ __global__ __launch_bounds__(256) void k_cell_keys(nh_DevState* __restrict__ st,
 		}
 		uint32_t slot = nh_wave_reserve1(&st->large, valid && large);
 		if (valid && large) { large_list[slot] = c; rank[c] = slot; }
+		if (valid && gen) gen[c] = large ? 0x80u : 0u;            // generation 0: the grid entry written below is this collider's box (bit 7: not in the grid)
 	}
 }
 
@@ -260,7 +291,7 @@ __global__ __launch_bounds__(256) void k_cscan_sums(const nh_DevState* __restric
 	if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-__global__ __launch_bounds__(256) void k_cscan_final(const nh_DevState* __restrict__ st, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ block_sums, uint32_t n) {
+__global__ __launch_bounds__(256) void k_cscan_final(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ block_sums, uint32_t n, uint32_t* __restrict__ out) {
 	if (!st->fat_rebuild) return;
 	__shared__ uint32_t wsum[4];
 	__shared__ uint32_t red[4];
@@ -269,7 +300,8 @@ __global__ __launch_bounds__(256) void k_cscan_final(const nh_DevState* __restri
 	for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256) ca += block_sums[i];
 	for (int d = 32; d >= 1; d >>= 1) ca += __shfl_xor(ca, d);
 	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ca;
-	uint4* p = reinterpret_cast<uint4*>(cnt + (size_t)blockIdx.x * CS_TILE + threadIdx.x * CS_PER_THREAD);
+	const uint4* p = reinterpret_cast<const uint4*>(cnt + (size_t)blockIdx.x * CS_TILE + threadIdx.x * CS_PER_THREAD);
+	uint4* po = reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * CS_TILE + threadIdx.x * CS_PER_THREAD);       // (the starts live in a table of their own: the grid outlasts the step)
 	uint4 v[CS_PER_THREAD / 4];
 	uint32_t mine = 0;
 #pragma unroll
@@ -284,9 +316,9 @@ __global__ __launch_bounds__(256) void k_cscan_final(const nh_DevState* __restri
 	for (int q = 0; q < CS_PER_THREAD / 4; ++q) {
 		uint4 o;
 		o.x = run; run += v[q].x; o.y = run; run += v[q].y; o.z = run; run += v[q].z; o.w = run; run += v[q].w;
-		p[q] = o;
+		po[q] = o;
 	}
-	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) cnt[n] = run;
+	if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) out[n] = run;
 }
 
 // cell-sorted copy of the AABBs: ONE 32-byte record per collider, sbox[2 pos] = (min.xyz, body), sbox[2 pos + 1] = (max.xyz, collider index),
@@ -319,7 +351,7 @@ __device__ __forceinline__ bool aabb_overlap(const float4& amin, const float4& a
 // reason, nudge.cpp:3705-3751): box-box pairs fill `pairs` from the front (counter st->pairs), pairs with a sphere from the back (counter
 // st->pairs_sph, slot pair_cap-1-k), so that each narrowphase launch runs ONE kind of arithmetic in all its lanes.
 #define FP_WBUF 512
-struct pair_stage { uint2* buf; uint32_t count; uint32_t cap; uint32_t nbox; };
+struct pair_stage { uint2* buf; uint32_t count; uint32_t cap; uint32_t nbox; uint32_t mask = 0xFFFFFFFFu; };      // (mask: where a staged pair carries generation stamps above its collider indices)
 
 __device__ __forceinline__ void write_staged(nh_DevState* st, uint2* pairs, uint32_t pair_cap, const pair_stage& ps, uint32_t base_bb, uint32_t base_sph) {
 	// lanes take the staged pairs 64 at a time; a pair's slot = its type's base + its rank among the staged pairs of that type
@@ -328,7 +360,7 @@ __device__ __forceinline__ void write_staged(nh_DevState* st, uint2* pairs, uint
 		const uint32_t k = k0 + nh_lane();
 		const bool on = k < ps.count;
 		const uint2 pr = on ? ps.buf[k] : make_uint2(0u, 0u);
-		const bool sph = on && (pr.x >= ps.nbox || pr.y >= ps.nbox);
+		const bool sph = on && ((pr.x & ps.mask) >= ps.nbox || (pr.y & ps.mask) >= ps.nbox);
 		const unsigned long long bs = __ballot(sph), bb = __ballot(on && !sph);
 		const unsigned long long below = (1ull << nh_lane()) - 1ull;
 		if (on) {
@@ -341,7 +373,7 @@ __device__ __forceinline__ void write_staged(nh_DevState* st, uint2* pairs, uint
 
 __device__ __forceinline__ void count_staged(const pair_stage& ps, uint32_t& n_bb, uint32_t& n_sph) {
 	uint32_t sph = 0;
-	for (uint32_t k = nh_lane(); k < ps.count; k += 64) { const uint2 pr = ps.buf[k]; sph += (pr.x >= ps.nbox || pr.y >= ps.nbox) ? 1u : 0u; }
+	for (uint32_t k = nh_lane(); k < ps.count; k += 64) { const uint2 pr = ps.buf[k]; sph += ((pr.x & ps.mask) >= ps.nbox || (pr.y & ps.mask) >= ps.nbox) ? 1u : 0u; }
 	for (int d = 32; d >= 1; d >>= 1) sph += (uint32_t)__shfl_xor((int)sph, d);
 	n_sph = sph; n_bb = ps.count - sph;
 }
@@ -625,6 +657,81 @@ __global__ __launch_bounds__(LP_THREADS) void k_large_pairs(nh_DevState* __restr
 	flush_pairs_block(st, kept, kept_cap, ps, DIRECT ? &st->pairs : &st->fat_count, DIRECT ? &st->pairs_sph : &st->fat_count_sph);
 }
 
+// ---- 7. re-insertion: the kept list survives a few colliders leaving their boxes ------------------------------------------------------------
+// A collider that has left its inflated box used to cost everybody the rebuild (regroup 1 M colliders, search, 117 us) -- one rolling ball in a world at
+// rest, every step.  Now k_xform gives a SMALL leaver a new box and the next GENERATION stamp on the spot, and this kernel finds the pairs of the new box:
+//   * a kept pair carries the stamps of its two colliders (7 bits each, above the 24-bit indices); k_kept_filter skips pairs whose stamps are not the
+//     current ones -- every old pair of the leaver dies without anybody searching for it; dead pairs stay where they are until the next rebuild;
+//   * everybody who has NOT moved since the rebuild (stamp 0) still lies in the box the kept grid sorted it by: the leaver visits the cells around its
+//     new box (min-corner cell in [c_min - 1, c_max] per axis, as k_large_pairs does) and the large list, skipping stale entries (stamp != 0);
+//   * everybody who HAS moved since (the `moved` list, at most NH_MOVED_MAX) is tested directly with its current box; two leavers of one step meet once
+//     (the lower index is taken by the higher).
+// The result is again a superset of the overlapping pairs with every pair in it once, so k_kept_filter gives exactly the pairs of a full search
+// (NH_NO_INCREMENTAL=1 and NH_NO_KEPT_PAIRS=1 must give the same bits: test_kept_pair_list_*).  One wave per leaver, lanes across the candidates.
+// Rebuilds remain for: large colliders on the move, more than NH_ESC_MAX leavers in a step (a falling scene), a full moved list, a worn-out stamp,
+// a crowded kept buffer, changed collider counts.
+__global__ __launch_bounds__(256) void k_reinsert(nh_DevState* __restrict__ st, uint32_t nbox, const float4* __restrict__ sbox, const uint32_t* __restrict__ cstart,
+                                                  const uint32_t* __restrict__ large_list, const float4* __restrict__ box, const uint8_t* __restrict__ gen,
+                                                  const uint32_t* __restrict__ esc_mark, const uint32_t* __restrict__ esc_list, const uint32_t* __restrict__ moved_list, uint32_t seq,
+                                                  uint2* __restrict__ kept, uint32_t kept_cap) {
+	if (!st->fat_reinsert) return;
+	const uint32_t ne = min(st->esc_count, NH_ESC_MAX), nm = min(st->moved_count, NH_MOVED_MAX), nlarge = st->large;
+	const float inv = st->cell_inv;
+	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
+	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
+	__shared__ uint2 wave_buf[4][FP_WBUF];
+	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u, FP_WBUF, nbox, NH_GEN_INDEX };
+	const uint32_t lane = nh_lane();
+	const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+	for (uint32_t e = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; e < ne; e += nwaves) {                // (wave-uniform)
+		const uint32_t ca = esc_list[e];
+		const float4 amin = box[2u * ca], amax = box[2u * ca + 1u];
+		const uint32_t pa = ca | (uint32_t)(gen[ca] & 0x7Fu) << NH_GEN_SHIFT;
+		// the kept grid: everybody whose box has not changed since the rebuild
+		const int x0 = min(max(cell_coord(amin.x, ox, inv) - 1, 0), nx - 1), x1 = min(max(cell_coord(amax.x, ox, inv), 0), nx - 1);
+		const int y0 = min(max(cell_coord(amin.y, oy, inv) - 1, 0), ny - 1), y1 = min(max(cell_coord(amax.y, oy, inv), 0), ny - 1);
+		const int z0 = min(max(cell_coord(amin.z, oz, inv) - 1, 0), nz - 1), z1 = min(max(cell_coord(amax.z, oz, inv), 0), nz - 1);
+		for (int cz = z0; cz <= z1; ++cz)
+			for (int cy = y0; cy <= y1; ++cy) {
+				const uint32_t row = (uint32_t)((cz * ny + cy) * nx);
+				const uint32_t j0 = cstart[row + (uint32_t)x0], jend = cstart[row + (uint32_t)x1 + 1u];
+				for (uint32_t base = j0; base < jend; base += 64u) {
+					const uint32_t cand = base + lane;
+					bool hit = false;
+					uint32_t cb = 0;
+					if (cand < jend) {
+						const float4 bmin = sbox[2u * cand], bmax = sbox[2u * cand + 1u];
+						cb = __float_as_uint(bmax.w);
+						hit = aabb_overlap(amin, amax, bmin, bmax) && (gen[cb] & 0x7Fu) == 0u;              // (a stale entry -- the leaver's own among them -- is on the moved list)
+					}
+					emit_kept(st, kept, kept_cap, pa, cb, hit, ps);
+				}
+			}
+		// the large colliders (never re-inserted: their boxes are the rebuild's)
+		for (uint32_t base = 0; base < nlarge; base += 64u) {
+			const uint32_t l = base + lane;
+			bool hit = false;
+			uint32_t cb = 0;
+			if (l < nlarge) { cb = large_list[l]; hit = aabb_overlap(amin, amax, box[2u * cb], box[2u * cb + 1u]); }
+			emit_kept(st, kept, kept_cap, pa, cb, hit, ps);
+		}
+		// everybody who has moved since the rebuild, with the box it has now
+		for (uint32_t base = 0; base < nm; base += 64u) {
+			const uint32_t m = base + lane;
+			bool hit = false;
+			uint32_t pb = 0;
+			if (m < nm) {
+				const uint32_t cb = moved_list[m];
+				const bool other_leaver = esc_mark[cb] == seq;                     // (it takes, or has taken, its own turn in this loop)
+				hit = cb != ca && !(other_leaver && cb > ca) && aabb_overlap(amin, amax, box[2u * cb], box[2u * cb + 1u]);
+				pb = cb | (uint32_t)(gen[cb] & 0x7Fu) << NH_GEN_SHIFT;
+			}
+			emit_kept(st, kept, kept_cap, pa, pb, hit, ps);
+		}
+	}
+	flush_pairs_block(st, kept, kept_cap, ps, &st->fat_count, &st->fat_count_sph);
+}
+
 // ---- 6. kept pairs -> this step's pairs ------------------------------------------------------------------------------------------------
 // Temporal coherence.  The grid search above runs on AABBs inflated by 1/32 of a cell and its result is KEPT.  As long as every collider's
 // AABB lies inside the inflated box it had then (checked by k_xform every step; a moved, resized or re-parented collider simply leaves its
@@ -642,8 +749,12 @@ __global__ __launch_bounds__(LP_THREADS) void k_large_pairs(nh_DevState* __restr
 __global__ __launch_bounds__(256) void k_kept_filter(nh_DevState* __restrict__ st, const uint2* __restrict__ kept, uint32_t kept_cap, uint32_t nbox,
                                                      const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max,
                                                      uint2* __restrict__ pairs, uint32_t pair_cap,
-                                                     uint32_t* __restrict__ coarse_parent, uint32_t parity, const uint8_t* __restrict__ idle, uint32_t allow_in_place) {
+                                                     uint32_t* __restrict__ coarse_parent, uint32_t parity, const uint8_t* __restrict__ idle, uint32_t allow_in_place,
+                                                     const uint8_t* __restrict__ gen) {
 	uint32_t* const islands = st->any_idle[parity] ? coarse_parent : nullptr;
+	// generation stamps (k_reinsert): looked at only once somebody has been re-inserted since the rebuild -- until then every stamp is 0
+	const uint32_t index_mask = gen ? NH_GEN_INDEX : 0xFFFFFFFFu;
+	const bool stamps = gen && st->moved_count != 0u;
 	// Morton frame (nudge.cpp:3096-3100): which collider of a pair plays "a" is decided by the Morton order of the AABB min corners
 	const float mscale = st->morton_scale;
 	const nh_f3 mmin = nh_make3(st->morton_min[0], st->morton_min[1], st->morton_min[2]);
@@ -668,10 +779,11 @@ __global__ __launch_bounds__(256) void k_kept_filter(nh_DevState* __restrict__ s
 		uint64_t ka = 0, kb = 0;
 		if (i < n) {
 			const uint2 pr = i < n_bb ? kept[i] : kept[kept_cap - 1u - (i - n_bb)];
-			ca = pr.x; cb = pr.y;
+			ca = pr.x & index_mask; cb = pr.y & index_mask;
 			const float4 amin = aabb_min[ca], amax = aabb_max[ca], bmin = aabb_min[cb], bmax = aabb_max[cb];
 			abody = __float_as_uint(amin.w); bbody = __float_as_uint(bmin.w);
 			hit = aabb_overlap(amin, amax, bmin, bmax) && (bbody != abody);
+			if (stamps && hit) hit = (uint32_t)(gen[ca] & 0x7Fu) == (pr.x >> NH_GEN_SHIFT) && (uint32_t)(gen[cb] & 0x7Fu) == (pr.y >> NH_GEN_SHIFT);      // (a pair of a box somebody has left since)
 			if (hit) { ka = nh_morton_of(nh_make3(amin.x, amin.y, amin.z), mscale, mmin); kb = nh_morton_of(nh_make3(bmin.x, bmin.y, bmin.z), mscale, mmin); }
 		}
 		hits += hit ? 1u : 0u;
@@ -1128,7 +1240,7 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 		st->active = 0; st->culled = 0; st->general_contacts = 0; st->levels = 0; st->error = 0;
 		st->has_other = 0; st->unleveled = 0; st->has_static8 = 0; st->has_staticN = 0; st->any_sleeping = 0; st->has_pending = 0;
 		st->sort_buckets = st->sort_buckets_next;
-		st->fat_escaped = 0; st->fat_rebuild = 0;
+		st->fat_escaped = 0; st->fat_rebuild = 0; st->esc_count = 0; st->fat_reinsert = 0;
 		st->fat_hits_prev = st->fat_hits; st->fat_hits = 0;
 		st->keys_changed = 0;
 		if (drop_sort_order) st->sort_valid = 0;
@@ -1165,12 +1277,10 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	nh_xform* xf = nh_arena_array<nh_xform>(A, C, &err);
 	float4* aabb_min = nh_arena_array<float4>(A, C, &err);
 	float4* aabb_max = nh_arena_array<float4>(A, C, &err);
-	float4* sbox = nh_arena_array<float4>(A, (size_t)2 * C, &err);         // cell-sorted AABBs, one 32-byte record per collider
 	uint32_t* ctag = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* keys_a = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* keys_b = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* vals_a = nh_arena_array<uint32_t>(A, C, &err);
-	uint32_t* large_list = nh_arena_array<uint32_t>(A, C, &err);
 	// broadphase pairs (each owns 4 raw contact slots, further contacts overflow): nh_set_pair_capacity, else half the contact capacity
 	const uint32_t pair_cap = ctx->pair_capacity ? ctx->pair_capacity : cap / 2 + 1024;
 	const bool onesweep = !ctx->env_sort_classic;                    // one kernel per radix pass (nh_util.hip); NH_SORT_CLASSIC=1: three
@@ -1276,6 +1386,34 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		drop_kept = true;
 	}
 	ctx->fat_nbox = nbox; ctx->fat_nsph = nsph;
+	// library-owned as well: the grid of the last rebuild (cell-sorted boxes, cell starts, large list) and the book-keeping of re-insertions -- a
+	// collider that leaves its box is looked up in THAT grid steps later, so none of it may live in the caller's temporary arena
+	if (ctx->grid_cells < max_cells || ctx->grid_collider_capacity < ctx->fat_collider_capacity) {
+		if (ctx->grid_sbox) NH_HIP_CHECK(ctx, hipFree(ctx->grid_sbox));
+		if (ctx->grid_cstart) NH_HIP_CHECK(ctx, hipFree(ctx->grid_cstart));
+		if (ctx->grid_large) NH_HIP_CHECK(ctx, hipFree(ctx->grid_large));
+		if (ctx->fat_gen) NH_HIP_CHECK(ctx, hipFree(ctx->fat_gen));
+		if (ctx->fat_esc_mark) NH_HIP_CHECK(ctx, hipFree(ctx->fat_esc_mark));
+		if (ctx->fat_esc_list) NH_HIP_CHECK(ctx, hipFree(ctx->fat_esc_list));
+		if (ctx->fat_moved_list) NH_HIP_CHECK(ctx, hipFree(ctx->fat_moved_list));
+		ctx->grid_sbox = nullptr; ctx->grid_cstart = nullptr; ctx->grid_large = nullptr; ctx->fat_gen = nullptr; ctx->fat_esc_mark = nullptr;
+		ctx->fat_esc_list = nullptr; ctx->fat_moved_list = nullptr; ctx->grid_cells = 0; ctx->grid_collider_capacity = 0;
+		const size_t cc = ctx->fat_collider_capacity;              // (>= C: set with the boxes above)
+		const uint32_t cells = max_cells > ctx->grid_cells ? max_cells : ctx->grid_cells;
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->grid_sbox, sizeof(float4) * 2u * cc + 64u));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->grid_cstart, sizeof(uint32_t) * ((size_t)cells + 8u)));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->grid_large, sizeof(uint32_t) * cc + 64u));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->fat_gen, cc + 64u));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->fat_esc_mark, sizeof(uint32_t) * cc + 64u));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->fat_esc_list, sizeof(uint32_t) * NH_ESC_MAX));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->fat_moved_list, sizeof(uint32_t) * NH_MOVED_MAX));
+		NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->fat_esc_mark, 0, sizeof(uint32_t) * cc + 64u, s));
+		NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->fat_gen, 0, cc + 64u, s));
+		ctx->grid_cells = cells; ctx->grid_collider_capacity = (uint32_t)cc;
+		drop_kept = true;
+	}
+	// re-insertion of colliders that leave their boxes (k_reinsert): kept-list steps only, indices that leave room for the stamps
+	const bool incremental = !bp_direct && !ctx->env_no_incremental && C < (1u << NH_GEN_SHIFT);
 	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, begin_grid, 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity, coarse_parent, coarse_active, no_islands ? 1u : 0u, block_top,
 	          drop_kept ? 1u : 0u, drop_sort_order ? 1u : 0u);
 	const bool seeded_sort = !ctx->env_sort_classic && ctx->sort_seeded && !ctx->env_sort_radix;      // (NH_SORT_RADIX=1: radix passes every step)
@@ -1284,35 +1422,41 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 1024, 256), 1024, st, bodies->transforms,
 		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
 		          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
-		          xf, aabb_min, aabb_max, ctag, reinterpret_cast<uint4*>(cstart), (max_cells + 8u) / 4u, ctx->fat_box, bp_direct ? 1u : 0u);
+		          xf, aabb_min, aabb_max, ctag, reinterpret_cast<uint4*>(cstart), (max_cells + 8u) / 4u, ctx->fat_box, bp_direct ? 1u : 0u,
+		          incremental ? ctx->fat_gen : (uint8_t*)nullptr, ctx->fat_esc_mark, ctx->fat_esc_list, ctx->fat_moved_list, ctx->collide_seq);
 		// Morton frame; and the decision whether the grid chain below runs this step or the kept pair list is re-used (its kernels are launched
 		// either way: the decision is made on the device, and a kernel that leaves at once costs two microseconds)
-		NH_LAUNCH(ctx, "grid_setup", k_grid_setup, 1, 64, st, C, max_cells, bp_direct ? 1u : 0u);
+		NH_LAUNCH(ctx, "grid_setup", k_grid_setup, 1, 64, st, C, max_cells, bp_direct ? 1u : 0u, ctx->fat_pair_capacity);
 		float4* fbox = ctx->fat_box;
+		float4* sbox = ctx->grid_sbox; uint32_t* large_list = ctx->grid_large; uint32_t* cell_start = ctx->grid_cstart;       // (cstart, in the arena: this step's cell COUNTS)
 		uint2* kept = ctx->fat_pairs;
 		const uint32_t kept_cap = ctx->fat_pair_capacity;
 		const bool measure_skip = ctx->env_measure_skip && ctx->collide_seq > 66u;       // NH_MEASURE_SKIP_CHAINS=1: MEASUREMENT ONLY (wrong as soon as anything moves): what the launches that leave at once cost
 		if (!measure_skip) {
-		NH_LAUNCH(ctx, "cell_keys", k_cell_keys, nh_grid_for(C, 256, 2048), 256, st, C, aabb_min, aabb_max, fbox, keys_a, vals_a, large_list, cstart);
+		NH_LAUNCH(ctx, "cell_keys", k_cell_keys, nh_grid_for(C, 256, 2048), 256, st, C, aabb_min, aabb_max, fbox, keys_a, vals_a, large_list, cstart, incremental ? ctx->fat_gen : (uint8_t*)nullptr);
 		NH_LAUNCH(ctx, "cell_scan", k_cscan_sums, max_cells / CS_TILE, 256, st, cstart, cscan_sums);
-		NH_LAUNCH(ctx, "cell_scan", k_cscan_final, max_cells / CS_TILE, 256, st, cstart, cscan_sums, max_cells);
-		NH_LAUNCH(ctx, "cell_scatter", k_cell_scatter, nh_grid_for(C, 256, 2048), 256, st, C, keys_a, vals_a, cstart, fbox, keys_b, sbox);
+		NH_LAUNCH(ctx, "cell_scan", k_cscan_final, max_cells / CS_TILE, 256, st, cstart, cscan_sums, max_cells, cell_start);
+		NH_LAUNCH(ctx, "cell_scatter", k_cell_scatter, nh_grid_for(C, 256, 2048), 256, st, C, keys_a, vals_a, cell_start, fbox, keys_b, sbox);
 		}
 		// (KEPT: the chain fills the kept list, k_kept_filter makes this step's pairs of it; DIRECT: the chain writes this step's pairs itself)
 		const bool many_lanes = ctx->env_fp_sub ? ctx->env_fp_sub > 1 : C <= 16384u;
-#define NH_FIND_PAIRS(SUBL, DIR, OUT, OUTCAP) NH_LAUNCH(ctx, "find_pairs", (k_find_pairs<SUBL, DIR>), nh_grid_for((uint64_t)C * SUBL, 256, 4096), 256, st, C, nbox, keys_b, sbox, cstart, large_list, fbox, OUT, OUTCAP, \
+#define NH_FIND_PAIRS(SUBL, DIR, OUT, OUTCAP) NH_LAUNCH(ctx, "find_pairs", (k_find_pairs<SUBL, DIR>), nh_grid_for((uint64_t)C * SUBL, 256, 4096), 256, st, C, nbox, keys_b, sbox, cell_start, large_list, fbox, OUT, OUTCAP, \
 		          coarse_parent, ctx->step_parity, bodies->idle_counters)
 		if (bp_direct) {
 			if (many_lanes) NH_FIND_PAIRS(16, true, pairs, pair_cap); else NH_FIND_PAIRS(1, true, pairs, pair_cap);
-			NH_LAUNCH(ctx, "large_pairs", (k_large_pairs<true>), LP_GRID, LP_THREADS, st, nbox, sbox, cstart, large_list, fbox, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+			NH_LAUNCH(ctx, "large_pairs", (k_large_pairs<true>), LP_GRID, LP_THREADS, st, nbox, sbox, cell_start, large_list, fbox, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
 		} else {
 			if (!measure_skip) {
 			if (many_lanes) NH_FIND_PAIRS(16, false, kept, kept_cap); else NH_FIND_PAIRS(1, false, kept, kept_cap);
-			NH_LAUNCH(ctx, "large_pairs", (k_large_pairs<false>), LP_GRID, LP_THREADS, st, nbox, sbox, cstart, large_list, fbox, kept, kept_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
+			NH_LAUNCH(ctx, "large_pairs", (k_large_pairs<false>), LP_GRID, LP_THREADS, st, nbox, sbox, cell_start, large_list, fbox, kept, kept_cap, coarse_parent, ctx->step_parity, bodies->idle_counters);
 			}
+			// colliders that left their boxes this step (a few: otherwise the chain above has run): new boxes, new pairs appended to the kept list
+			if (incremental)
+				NH_LAUNCH(ctx, "reinsert", k_reinsert, 256, 256, st, nbox, sbox, cell_start, large_list, fbox, ctx->fat_gen, ctx->fat_esc_mark, ctx->fat_esc_list, ctx->fat_moved_list,
+				          ctx->collide_seq, kept, kept_cap);
 			// this step's pairs: the kept ones whose exact AABBs overlap now (every step)
 			NH_LAUNCH(ctx, "kept_filter", k_kept_filter, nh_grid_for(kept_cap, 256, 1024), 256, st, kept, kept_cap, nbox, aabb_min, aabb_max, pairs, pair_cap, coarse_parent, ctx->step_parity, bodies->idle_counters,
-			          (seeded_sort && !ctx->env_no_sort_reuse) ? 1u : 0u);
+			          (seeded_sort && !ctx->env_no_sort_reuse) ? 1u : 0u, incremental ? ctx->fat_gen : (const uint8_t*)nullptr);
 		}
 		// coarse islands over the broadphase pairs (united where the pairs were emitted) + connections: only when some body is asleep (a device
 		// flag: the kernels leave at once otherwise)

@@ -45,6 +45,9 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->env_measure_skip = getenv("NH_MEASURE_SKIP_CHAINS") != nullptr;      // MEASUREMENT ONLY: from step 67 on the launches of the grid chain and the tag sort are not issued at all (wrong as soon as anything moves)
 	ctx->env_no_fat = getenv("NH_NO_KEPT_PAIRS") != nullptr;      // the broadphase regroups and searches every step instead of re-using its kept pair list (A/B, tests)
 	ctx->fat_pairs = nullptr; ctx->fat_pair_capacity = 0; ctx->fat_box = nullptr; ctx->fat_collider_capacity = 0; ctx->fat_nbox = ctx->fat_nsph = 0xffffffffu;
+	ctx->grid_sbox = nullptr; ctx->grid_skeys = nullptr; ctx->grid_cstart = nullptr; ctx->grid_large = nullptr; ctx->grid_cells = 0; ctx->grid_collider_capacity = 0;
+	ctx->fat_gen = nullptr; ctx->fat_esc_mark = nullptr; ctx->fat_esc_list = nullptr; ctx->fat_moved_list = nullptr;
+	ctx->env_no_incremental = getenv("NH_NO_INCREMENTAL") != nullptr;     // NH_NO_INCREMENTAL=1: a collider that leaves its inflated box forces a rebuild of the kept pair list (A/B, tests)
 	ctx->env_colour_check_seeds = getenv("NH_COLOUR_CHECK_SEEDS") != nullptr;      // colours seeded from the cache go through a settle round instead of being final at once (A/B, tests)
 	ctx->env_no_resident = getenv("NH_NO_RESIDENT") != nullptr;      // NH_NO_RESIDENT=1: small general sets also take the one-launch-per-level path (A/B, tests)
 	ctx->os_resident = 0; ctx->os_plain_launch = getenv("NH_COOPERATIVE") == nullptr;      // NH_COOPERATIVE=1: the one-kernel radix passes go out as cooperative launches (nh_util.hip)
@@ -91,6 +94,14 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	if (ctx->deg) hipFree(ctx->deg);
 	if (ctx->fat_pairs) hipFree(ctx->fat_pairs);
 	if (ctx->fat_box) hipFree(ctx->fat_box);
+	if (ctx->grid_sbox) hipFree(ctx->grid_sbox);
+	if (ctx->grid_skeys) hipFree(ctx->grid_skeys);
+	if (ctx->grid_cstart) hipFree(ctx->grid_cstart);
+	if (ctx->grid_large) hipFree(ctx->grid_large);
+	if (ctx->fat_gen) hipFree(ctx->fat_gen);
+	if (ctx->fat_esc_mark) hipFree(ctx->fat_esc_mark);
+	if (ctx->fat_esc_list) hipFree(ctx->fat_esc_list);
+	if (ctx->fat_moved_list) hipFree(ctx->fat_moved_list);
 	if (ctx->sort_keys_by_position) hipFree(ctx->sort_keys_by_position);
 	if (ctx->sort_sorted_keys) hipFree(ctx->sort_sorted_keys);
 	if (ctx->sort_sorted_idx) hipFree(ctx->sort_sorted_idx);
@@ -136,7 +147,7 @@ void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out) {
 	out->colliders = h->colliders; out->pairs = h->pairs + h->pairs_sph; out->contacts = h->contacts; out->sleeping_pairs = h->sleeping;
 	out->active_bodies = h->active; out->cache = h->cache; out->culled = h->culled; out->large_colliders = h->large;
 	out->general_contacts = h->general_contacts; out->levels = h->levels; out->error = h->error;
-	out->has_other_bodies = h->has_other; out->broadphase_rebuilds = h->fat_rebuilds; out->sort_reuses = h->sort_reuses; out->unleveled = h->unleveled; out->raw_pairs = h->pairs + h->pairs_sph;
+	out->has_other_bodies = h->has_other; out->broadphase_rebuilds = h->fat_rebuilds; out->sort_reuses = h->sort_reuses; out->broadphase_inserts = h->fat_inserts; out->unleveled = h->unleveled; out->raw_pairs = h->pairs + h->pairs_sph;
 }
 
 extern "C" int nh_read_counts(nh_context* ctx, nh_Counts* out) {

@@ -67,7 +67,8 @@ struct nh_DevState {
 	uint32_t max_idle[2];                 // by step parity: largest idle counter seen by this step's nh_collide (host-side sleep prediction, nh_collide)
 	uint32_t fat_rebuilds;                // broadphase rebuilds since nh_create (the steps in between re-used the kept pair list: below)
 	uint32_t sort_reuses;                 // steps since nh_create whose record sort was skipped because last step's tag order still held
-	// ---- (the 27 words above are what nh_read_counts mirrors to the host) ----
+	uint32_t fat_inserts;                 // colliders re-inserted into the kept pair list since nh_create (they left their inflated box; no rebuild)
+	// ---- (the 28 words above are what nh_read_counts mirrors to the host: NH_COUNTER_WORDS) ----
 	// Temporal coherence of the broadphase (nh_collide.hip, "kept pair list"): the grid search runs over AABBs inflated by `fat_margin` and its
 	// pairs are KEPT; while every collider's AABB stays inside its inflated box the kept list is a superset of the overlapping pairs and one filter
 	// pass (exact AABBs, exact test) replaces the whole regrouping + search.
@@ -78,6 +79,11 @@ struct nh_DevState {
 	float fat_margin;                     // inflation of the boxes a rebuild writes this step (k_grid_setup -> k_cell_keys)
 	uint32_t fat_count_sph;               // kept pairs with a sphere (they fill the kept buffer from the back; fat_count counts the box-box ones)
 	uint32_t fat_hits, fat_hits_prev;     // kept pairs that overlapped in this / the last k_kept_filter pass
+	// incremental insertion (nh_collide.hip, "7. re-insertion"): a few colliders left their boxes -- they get new boxes, their old pairs die (generation
+	// stamps) and their new pairs are appended; the grid of the last rebuild keeps serving everybody who has not moved since
+	uint32_t esc_count;                   // this step: colliders that left their box and were given a new one (k_xform)
+	uint32_t moved_count;                 // colliders re-inserted at least once since the last rebuild (their grid entry is stale: the `moved` list)
+	uint32_t fat_reinsert;                // this step: k_reinsert has work (k_grid_setup: no rebuild, esc_count > 0)
 	// sort re-use (nh_collide): this step's records sit where last step's sat and carry the same keys => last step's tag order still holds
 	uint32_t keys_changed;                // some record's key differs from the key that position had last step (k_narrowphase)
 	uint32_t records_kept, records_prev;  // records of the step the kept tag order belongs to / as saved at the start of this step
@@ -170,6 +176,11 @@ struct nh_context {
 	// kept pair list of the broadphase (library-owned, persists from one nh_collide to the next): pairs of inflated boxes, and the boxes
 	uint2* fat_pairs; uint32_t fat_pair_capacity;
 	float4* fat_box; uint32_t fat_collider_capacity;
+	// the grid of the last rebuild, kept for re-insertions: cell-sorted inflated boxes, their cell keys, cell starts, the large colliders; per collider
+	// a generation byte (bit 7: large) and the nh_collide call it last left its box in; this step's leavers, everybody who has left since the rebuild
+	float4* grid_sbox; uint32_t* grid_skeys; uint32_t* grid_cstart; uint32_t* grid_large; uint32_t grid_cells, grid_collider_capacity;
+	uint8_t* fat_gen; uint32_t* fat_esc_mark; uint32_t* fat_esc_list; uint32_t* fat_moved_list;
+	bool env_no_incremental;
 	uint32_t fat_nbox, fat_nsph;          // collider counts of the last nh_collide (a change invalidates the list)
 	uint32_t bp_seen_rebuilds, bp_rebuild_streak; int bp_direct_left;      // direct search instead of the kept list while every step rebuilds it (nh_collide)
 	bool env_measure_skip;                // NH_MEASURE_SKIP_CHAINS=1: measurement only (nh_collide)
@@ -218,7 +229,7 @@ struct nh_context {
 // Runs work that an earlier call deferred; every entry point that reads or writes momentum / impulses calls it first.
 int nh_flush_pending(nh_context* ctx, bool keep_gravity = false);
 void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out);
-#define NH_COUNTER_WORDS 27u          // leading words of nh_DevState that the host mirrors (nh_read_counts)
+#define NH_COUNTER_WORDS 28u          // leading words of nh_DevState that the host mirrors (nh_read_counts)
 
 struct nh_ContactImpulseData {
 	nh_CachedContactImpulse* data;        // K, contact (tag) order; holds the warm-start impulses once `lookup_pending` is false

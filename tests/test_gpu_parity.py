@@ -617,6 +617,55 @@ def test_kept_pair_list_survives_teleports_and_collider_edits():
         w.close()
 
 
+@pytest.mark.parametrize("name,warm", [("grid30_awake", 100), ("mixed20", 140)])
+def test_a_few_movers_are_reinserted_into_the_kept_pair_list(name, warm):
+    """A landed world in which a handful of bodies keep moving (kicked by the caller every few steps: they slide, hop onto their neighbours, fly off).  Each
+    of them leaves its inflated box again and again; the kept pair list must survive that -- the leavers get new boxes and new pairs (k_reinsert), the rest of
+    the list is untouched -- and give, step for step, the bits of a world that rebuilds the list whenever somebody leaves (NH_NO_INCREMENTAL=1) and of one that
+    searches the grid every step (NH_NO_KEPT_PAIRS=1)."""
+    import copy
+    scene, _ = G.build(name)
+    worlds = []
+    for env in (None, "NH_NO_INCREMENTAL", "NH_NO_KEPT_PAIRS"):
+        if env: os.environ[env] = "1"
+        worlds.append(E.World(copy.deepcopy(scene), flags=FAST))
+        if env: os.environ.pop(env, None)
+    for w in worlds:
+        w.step(warm)
+    nb = worlds[0].get_bodies()["momentum"].shape[0]
+    rng = np.random.default_rng(3)
+    movers = rng.choice(np.arange(1, nb), size=7, replace=False)
+    base = [w.counts() for w in worlds]
+    for rnd in range(24):
+        kick = rng.uniform(-3.0, 3.0, size=(len(movers), 3)).astype(np.float32)
+        kick[:, 1] = np.abs(kick[:, 1]) * np.float32(0.5 if rnd % 3 else 2.0)
+        for w in worlds:
+            m = w.get_bodies()["momentum"].copy()
+            m["velocity"][movers] = kick
+            w.set_bodies(momentum=m)
+            w.step(6)
+        x = worlds[0].get_bodies()
+        for k, w in enumerate(worlds[1:]):
+            y = w.get_bodies()
+            assert P.bits_equal(x["transforms"], y["transforms"]) and P.bits_equal(x["momentum"], y["momentum"]) and np.array_equal(x["idle"], y["idle"]), (name, rnd, k)
+    for w in worlds:
+        w.collide()
+    ca = worlds[0].get_contacts()
+    for w in worlds[1:]:
+        cb = w.get_contacts()
+        assert ca["count"] == cb["count"] and np.array_equal(ca["tags"], cb["tags"]) and P.bits_equal(ca["data"], cb["data"]) and np.array_equal(ca["bodies"], cb["bodies"])
+    c = [w.counts() for w in worlds]
+    steps = 24 * 6 + 1
+    inserts = c[0]["broadphase_inserts"] - base[0]["broadphase_inserts"]
+    rebuilds = [c[k]["broadphase_rebuilds"] - base[k]["broadphase_rebuilds"] for k in range(3)]
+    print(f"\n[{name}: 7 movers, {steps} steps] re-insertions {inserts}; rebuilds: incremental {rebuilds[0]}, rebuild-on-leave {rebuilds[1]}, search every step {rebuilds[2]}")
+    assert inserts > 50 and c[1]["broadphase_inserts"] == 0 and c[2]["broadphase_inserts"] == 0
+    assert rebuilds[0] * 4 < rebuilds[1], rebuilds          # (the movers force a rebuild every step or two without re-insertion)
+    assert rebuilds[2] == steps
+    for w in worlds:
+        w.close()
+
+
 @pytest.mark.parametrize("name,steps", [("grid30", 460), ("mixed20", 250), ("pile256", 600), ("stacks", 150)])
 def test_sort_reuse_changes_nothing(name, steps, monkeypatch):
     """When k_kept_filter writes the pairs in place, a contact record sits where it sat last step; when every record also has last step's key the
