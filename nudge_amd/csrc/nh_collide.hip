@@ -182,7 +182,9 @@ __global__ __launch_bounds__(64) void k_grid_setup(nh_DevState* st, uint32_t nco
 	// (re-insertions append to the kept list and leave dead pairs behind: when this step's -- 64 pairs per leaver allowed for -- would fill it beyond seven
 	// eighths it is rebuilt instead, which compacts it; and when more than a sixteenth of the world has left, regrouping everybody is the cheaper way)
 	const uint32_t leavers = st->esc_count;
-	const bool crowded = leavers != 0u && ((uint64_t)st->fat_count + st->fat_count_sph + 64ull * leavers > (uint64_t)kept_cap / 8u * 7u || (uint64_t)leavers * 16u > ncolliders);
+	// (... or when the leavers' tests against everybody who has moved since the rebuild -- quadratic -- outgrow the regrouping they stand in for)
+	const bool crowded = leavers != 0u && ((uint64_t)st->fat_count + st->fat_count_sph + 64ull * leavers > (uint64_t)kept_cap / 8u * 7u || (uint64_t)leavers * 16u > ncolliders ||
+	                                       (uint64_t)leavers * (st->moved_count + st->large) > (uint64_t)ncolliders / 2u);
 	const bool rebuild = direct || st->fat_valid == 0u || st->fat_escaped != 0u || crowded;
 	st->fat_rebuild = rebuild ? 1u : 0u;
 	st->fat_reinsert = !rebuild && st->esc_count != 0u ? 1u : 0u;
@@ -682,52 +684,63 @@ __global__ __launch_bounds__(256) void k_reinsert(nh_DevState* __restrict__ st, 
 	__shared__ uint2 wave_buf[4][FP_WBUF];
 	pair_stage ps = { wave_buf[threadIdx.x >> 6], 0u, FP_WBUF, nbox, NH_GEN_INDEX };
 	const uint32_t lane = nh_lane();
-	const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-	for (uint32_t e = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; e < ne; e += nwaves) {                // (wave-uniform)
+	const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	// (a) the kept grid: everybody whose box has not changed since the rebuild.  One wave per leaver; the rows of cells around its box are ranges of the
+	// cell-sorted list: the lanes fetch all the range ends at once, then share out the candidates of all rows together -- three dependent memory round trips
+	// per leaver whatever the number of rows (one row after the other it was thirty, and ONE leaver cost as much as the rebuild it was meant to save)
+	for (uint32_t e = wave; e < ne; e += nwaves) {                // (wave-uniform)
 		const uint32_t ca = esc_list[e];
 		const float4 amin = box[2u * ca], amax = box[2u * ca + 1u];
 		const uint32_t pa = ca | (uint32_t)(gen[ca] & 0x7Fu) << NH_GEN_SHIFT;
-		// the kept grid: everybody whose box has not changed since the rebuild
 		const int x0 = min(max(cell_coord(amin.x, ox, inv) - 1, 0), nx - 1), x1 = min(max(cell_coord(amax.x, ox, inv), 0), nx - 1);
 		const int y0 = min(max(cell_coord(amin.y, oy, inv) - 1, 0), ny - 1), y1 = min(max(cell_coord(amax.y, oy, inv), 0), ny - 1);
 		const int z0 = min(max(cell_coord(amin.z, oz, inv) - 1, 0), nz - 1), z1 = min(max(cell_coord(amax.z, oz, inv), 0), nz - 1);
-		for (int cz = z0; cz <= z1; ++cz)
-			for (int cy = y0; cy <= y1; ++cy) {
-				const uint32_t row = (uint32_t)((cz * ny + cy) * nx);
-				const uint32_t j0 = cstart[row + (uint32_t)x0], jend = cstart[row + (uint32_t)x1 + 1u];
-				for (uint32_t base = j0; base < jend; base += 64u) {
-					const uint32_t cand = base + lane;
-					bool hit = false;
-					uint32_t cb = 0;
-					if (cand < jend) {
-						const float4 bmin = sbox[2u * cand], bmax = sbox[2u * cand + 1u];
-						cb = __float_as_uint(bmax.w);
-						hit = aabb_overlap(amin, amax, bmin, bmax) && (gen[cb] & 0x7Fu) == 0u;              // (a stale entry -- the leaver's own among them -- is on the moved list)
-					}
-					emit_kept(st, kept, kept_cap, pa, cb, hit, ps);
-				}
+		const uint32_t wy = (uint32_t)(y1 - y0 + 1), nrows = min(wy * (uint32_t)(z1 - z0 + 1), 64u);        // (a small collider: at most 3 x 3 rows, 4 x 4 in the worst rounding)
+		uint32_t j0 = 0, len = 0;
+		if (lane < nrows) {
+			const uint32_t row = (uint32_t)(((z0 + (int)(lane / wy)) * ny + (y0 + (int)(lane % wy))) * nx);
+			j0 = cstart[row + (uint32_t)x0];
+			len = cstart[row + (uint32_t)x1 + 1u] - j0;
+		}
+		uint32_t incl = len;
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d); if ((int)lane >= d) incl += y; }
+		const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+		for (uint32_t base = 0; base < total; base += 64u) {
+			const uint32_t t = base + lane;
+			uint32_t cand = 0;
+			for (uint32_t r = 0; r < nrows; ++r) {
+				const uint32_t end = (uint32_t)__shfl((int)incl, (int)r), l = (uint32_t)__shfl((int)len, (int)r), first = (uint32_t)__shfl((int)j0, (int)r);
+				if (t < end && t >= end - l) cand = first + (t - (end - l));
 			}
-		// the large colliders (never re-inserted: their boxes are the rebuild's)
-		for (uint32_t base = 0; base < nlarge; base += 64u) {
-			const uint32_t l = base + lane;
 			bool hit = false;
 			uint32_t cb = 0;
-			if (l < nlarge) { cb = large_list[l]; hit = aabb_overlap(amin, amax, box[2u * cb], box[2u * cb + 1u]); }
+			if (t < total) {
+				const float4 bmin = sbox[2u * cand], bmax = sbox[2u * cand + 1u];
+				cb = __float_as_uint(bmax.w);
+				hit = aabb_overlap(amin, amax, bmin, bmax) && (gen[cb] & 0x7Fu) == 0u;              // (a stale entry -- the leaver's own among them -- is on the moved list)
+			}
 			emit_kept(st, kept, kept_cap, pa, cb, hit, ps);
 		}
-		// everybody who has moved since the rebuild, with the box it has now
-		for (uint32_t base = 0; base < nm; base += 64u) {
-			const uint32_t m = base + lane;
-			bool hit = false;
-			uint32_t pb = 0;
-			if (m < nm) {
-				const uint32_t cb = moved_list[m];
-				const bool other_leaver = esc_mark[cb] == seq;                     // (it takes, or has taken, its own turn in this loop)
-				hit = cb != ca && !(other_leaver && cb > ca) && aabb_overlap(amin, amax, box[2u * cb], box[2u * cb + 1u]);
-				pb = cb | (uint32_t)(gen[cb] & 0x7Fu) << NH_GEN_SHIFT;
-			}
-			emit_kept(st, kept, kept_cap, pa, pb, hit, ps);
+	}
+	// (b) leaver x (large colliders: never re-inserted, their boxes are the rebuild's) and leaver x (everybody who has moved since the rebuild, with the box
+	// it has now): one lane per combination, all of them spread over the launch
+	const uint32_t others = nlarge + nm;
+	const uint64_t combos = (uint64_t)ne * others, rounded = (combos + 63u) & ~63ull;
+	for (uint64_t cbase = (uint64_t)wave * 64u; cbase < rounded; cbase += (uint64_t)nwaves * 64u) {
+		const uint64_t idx = cbase + lane;
+		bool hit = false;
+		uint32_t pa = 0, pb = 0;
+		if (idx < combos) {
+			const uint32_t e = (uint32_t)(idx / others), q = (uint32_t)(idx % others);
+			const uint32_t ca = esc_list[e];
+			const uint32_t cb = q < nlarge ? large_list[q] : moved_list[q - nlarge];
+			// two leavers of one step meet once: the higher index takes the lower (both stand on the moved list)
+			const bool skip = cb == ca || (q >= nlarge && esc_mark[cb] == seq && cb > ca);
+			if (!skip) hit = aabb_overlap(box[2u * ca], box[2u * ca + 1u], box[2u * cb], box[2u * cb + 1u]);
+			pa = ca | (uint32_t)(gen[ca] & 0x7Fu) << NH_GEN_SHIFT;
+			pb = cb | (uint32_t)(gen[cb] & 0x7Fu) << NH_GEN_SHIFT;
 		}
+		emit_kept(st, kept, kept_cap, pa, pb, hit, ps);
 	}
 	flush_pairs_block(st, kept, kept_cap, ps, &st->fat_count, &st->fat_count_sph);
 }
