@@ -19,7 +19,8 @@
  *      `bodies->count` seen); the splitters and bucket counters of the tag sort (16 B per 1024 broadphase pairs of
  *      capacity); the broadphase's kept pair list (16 B per pair of pair capacity: twice the capacity in 8-byte pairs) and one
  *      inflated box per collider (32 B) -- nh_collide re-tests the kept pairs instead of searching the grid while no collider
- *      has left its box; the contact records' keys by position and the tag order of the last sort (20 B per pair of capacity) --
+ *      has left its box, and re-inserts the few that have (new box, new pairs) from the grid of its last search, which it keeps as well:
+ *      per collider 32 B of cell-sorted boxes + 9 B of book-keeping, 4 B per grid cell (4 cells per collider, 2^16 .. 2^24); the contact records' keys by position and the tag order of the last sort (20 B per pair of capacity) --
  *      the sort is skipped while no record changes its key; a side stream and two events; two small host-side rings of opaque-object descriptors.
  *   2. Indices are widened: body indices and collider tags are 32-bit (the reference packs them in 16 bits:
  *      nudge.h:68-71, 86, 93, 126 and asserts <= 8192 colliders at nudge.cpp:3010).  A contact's identity
