@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_cscan_sums(const nh_DevState* __restric
 	if (threadIdx.x == 0) block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-__global__ __launch_bounds__(256) void k_cscan_final(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ block_sums, uint32_t n, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_cscan_final(const nh_DevState* __restrict__ st, uint32_t* __restrict__ cnt, const uint32_t* __restrict__ block_sums, uint32_t n, uint32_t* __restrict__ out) {
 	if (!st->fat_rebuild) return;
 	__shared__ uint32_t wsum[4];
 	__shared__ uint32_t red[4];
@@ -302,12 +302,14 @@ __global__ __launch_bounds__(256) void k_cscan_final(const nh_DevState* __restri
 	for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256) ca += block_sums[i];
 	for (int d = 32; d >= 1; d >>= 1) ca += __shfl_xor(ca, d);
 	if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ca;
-	const uint4* p = reinterpret_cast<const uint4*>(cnt + (size_t)blockIdx.x * CS_TILE + threadIdx.x * CS_PER_THREAD);
+	uint4* p = reinterpret_cast<uint4*>(cnt + (size_t)blockIdx.x * CS_TILE + threadIdx.x * CS_PER_THREAD);
 	uint4* po = reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * CS_TILE + threadIdx.x * CS_PER_THREAD);       // (the starts live in a table of their own: the grid outlasts the step)
 	uint4 v[CS_PER_THREAD / 4];
 	uint32_t mine = 0;
 #pragma unroll
-	for (int q = 0; q < CS_PER_THREAD / 4; ++q) { v[q] = p[q]; mine += v[q].x + v[q].y + v[q].z + v[q].w; }
+	// (the counts are cleared as they are consumed: the table is the library's and starts the next rebuild clean -- clearing 4 cells per collider at the start of
+	// EVERY step, rebuild or not, was 33 MB of a landed step's 85 MB of k_xform writes at a million boxes)
+	for (int q = 0; q < CS_PER_THREAD / 4; ++q) { v[q] = p[q]; p[q] = make_uint4(0u, 0u, 0u, 0u); mine += v[q].x + v[q].y + v[q].z + v[q].w; }
 	uint32_t x = mine;
 	for (int d = 1; d < 64; d <<= 1) { uint32_t y = __shfl_up(x, d); if ((int)(threadIdx.x & 63) >= d) x += y; }
 	if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
@@ -1308,7 +1310,6 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	if (want > (1u << 24)) want = 1u << 24;
 	const uint32_t max_cells = (uint32_t)want;
 	int cell_bits = 0; while ((1ull << cell_bits) < want) ++cell_bits;
-	uint32_t* cstart = nh_arena_array<uint32_t>(A, (size_t)max_cells + 8, &err);          // per-cell counts -> starts (+ sentinel)
 	uint32_t* cscan_sums = nh_arena_array<uint32_t>(A, max_cells / CS_TILE + 8, &err);
 	const uint32_t overflow_cap = cap;
 	uint2* pairs = nh_arena_array<uint2>(A, pair_cap, &err);
@@ -1404,17 +1405,20 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	if (ctx->grid_cells < max_cells || ctx->grid_collider_capacity < ctx->fat_collider_capacity) {
 		if (ctx->grid_sbox) NH_HIP_CHECK(ctx, hipFree(ctx->grid_sbox));
 		if (ctx->grid_cstart) NH_HIP_CHECK(ctx, hipFree(ctx->grid_cstart));
+		if (ctx->grid_counts) NH_HIP_CHECK(ctx, hipFree(ctx->grid_counts));
 		if (ctx->grid_large) NH_HIP_CHECK(ctx, hipFree(ctx->grid_large));
 		if (ctx->fat_gen) NH_HIP_CHECK(ctx, hipFree(ctx->fat_gen));
 		if (ctx->fat_esc_mark) NH_HIP_CHECK(ctx, hipFree(ctx->fat_esc_mark));
 		if (ctx->fat_esc_list) NH_HIP_CHECK(ctx, hipFree(ctx->fat_esc_list));
 		if (ctx->fat_moved_list) NH_HIP_CHECK(ctx, hipFree(ctx->fat_moved_list));
-		ctx->grid_sbox = nullptr; ctx->grid_cstart = nullptr; ctx->grid_large = nullptr; ctx->fat_gen = nullptr; ctx->fat_esc_mark = nullptr;
+		ctx->grid_sbox = nullptr; ctx->grid_cstart = nullptr; ctx->grid_counts = nullptr; ctx->grid_large = nullptr; ctx->fat_gen = nullptr; ctx->fat_esc_mark = nullptr;
 		ctx->fat_esc_list = nullptr; ctx->fat_moved_list = nullptr; ctx->grid_cells = 0; ctx->grid_collider_capacity = 0;
 		const size_t cc = ctx->fat_collider_capacity;              // (>= C: set with the boxes above)
 		const uint32_t cells = max_cells > ctx->grid_cells ? max_cells : ctx->grid_cells;
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->grid_sbox, sizeof(float4) * 2u * cc + 64u));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->grid_cstart, sizeof(uint32_t) * ((size_t)cells + 8u)));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->grid_counts, sizeof(uint32_t) * ((size_t)cells + 8u)));
+		NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->grid_counts, 0, sizeof(uint32_t) * ((size_t)cells + 8u), s));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->grid_large, sizeof(uint32_t) * cc + 64u));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->fat_gen, cc + 64u));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->fat_esc_mark, sizeof(uint32_t) * cc + 64u));
@@ -1435,13 +1439,13 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 1024, 256), 1024, st, bodies->transforms,
 		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
 		          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
-		          xf, aabb_min, aabb_max, ctag, reinterpret_cast<uint4*>(cstart), (max_cells + 8u) / 4u, ctx->fat_box, bp_direct ? 1u : 0u,
+		          xf, aabb_min, aabb_max, ctag, (uint4*)nullptr, 0u, ctx->fat_box, bp_direct ? 1u : 0u,
 		          incremental ? ctx->fat_gen : (uint8_t*)nullptr, ctx->fat_esc_mark, ctx->fat_esc_list, ctx->fat_moved_list, ctx->collide_seq);
 		// Morton frame; and the decision whether the grid chain below runs this step or the kept pair list is re-used (its kernels are launched
 		// either way: the decision is made on the device, and a kernel that leaves at once costs two microseconds)
 		NH_LAUNCH(ctx, "grid_setup", k_grid_setup, 1, 64, st, C, max_cells, bp_direct ? 1u : 0u, ctx->fat_pair_capacity);
 		float4* fbox = ctx->fat_box;
-		float4* sbox = ctx->grid_sbox; uint32_t* large_list = ctx->grid_large; uint32_t* cell_start = ctx->grid_cstart;       // (cstart, in the arena: this step's cell COUNTS)
+		float4* sbox = ctx->grid_sbox; uint32_t* large_list = ctx->grid_large; uint32_t* cell_start = ctx->grid_cstart; uint32_t* cstart = ctx->grid_counts;       // (cstart: the cell COUNTS of a rebuild, all zero between rebuilds)
 		uint2* kept = ctx->fat_pairs;
 		const uint32_t kept_cap = ctx->fat_pair_capacity;
 		const bool measure_skip = ctx->env_measure_skip && ctx->collide_seq > 66u;       // NH_MEASURE_SKIP_CHAINS=1: MEASUREMENT ONLY (wrong as soon as anything moves): what the launches that leave at once cost

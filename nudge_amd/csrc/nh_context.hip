@@ -45,7 +45,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->env_measure_skip = getenv("NH_MEASURE_SKIP_CHAINS") != nullptr;      // MEASUREMENT ONLY: from step 67 on the launches of the grid chain and the tag sort are not issued at all (wrong as soon as anything moves)
 	ctx->env_no_fat = getenv("NH_NO_KEPT_PAIRS") != nullptr;      // the broadphase regroups and searches every step instead of re-using its kept pair list (A/B, tests)
 	ctx->fat_pairs = nullptr; ctx->fat_pair_capacity = 0; ctx->fat_box = nullptr; ctx->fat_collider_capacity = 0; ctx->fat_nbox = ctx->fat_nsph = 0xffffffffu;
-	ctx->grid_sbox = nullptr; ctx->grid_skeys = nullptr; ctx->grid_cstart = nullptr; ctx->grid_large = nullptr; ctx->grid_cells = 0; ctx->grid_collider_capacity = 0;
+	ctx->grid_sbox = nullptr; ctx->grid_skeys = nullptr; ctx->grid_cstart = nullptr; ctx->grid_counts = nullptr; ctx->grid_large = nullptr; ctx->grid_cells = 0; ctx->grid_collider_capacity = 0;
 	ctx->fat_gen = nullptr; ctx->fat_esc_mark = nullptr; ctx->fat_esc_list = nullptr; ctx->fat_moved_list = nullptr;
 	ctx->env_no_incremental = getenv("NH_NO_INCREMENTAL") != nullptr;     // NH_NO_INCREMENTAL=1: a collider that leaves its inflated box forces a rebuild of the kept pair list (A/B, tests)
 	ctx->env_colour_check_seeds = getenv("NH_COLOUR_CHECK_SEEDS") != nullptr;      // colours seeded from the cache go through a settle round instead of being final at once (A/B, tests)
@@ -97,6 +97,7 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	if (ctx->grid_sbox) hipFree(ctx->grid_sbox);
 	if (ctx->grid_skeys) hipFree(ctx->grid_skeys);
 	if (ctx->grid_cstart) hipFree(ctx->grid_cstart);
+	if (ctx->grid_counts) hipFree(ctx->grid_counts);
 	if (ctx->grid_large) hipFree(ctx->grid_large);
 	if (ctx->fat_gen) hipFree(ctx->fat_gen);
 	if (ctx->fat_esc_mark) hipFree(ctx->fat_esc_mark);

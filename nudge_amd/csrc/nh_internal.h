@@ -178,7 +178,7 @@ struct nh_context {
 	float4* fat_box; uint32_t fat_collider_capacity;
 	// the grid of the last rebuild, kept for re-insertions: cell-sorted inflated boxes, their cell keys, cell starts, the large colliders; per collider
 	// a generation byte (bit 7: large) and the nh_collide call it last left its box in; this step's leavers, everybody who has left since the rebuild
-	float4* grid_sbox; uint32_t* grid_skeys; uint32_t* grid_cstart; uint32_t* grid_large; uint32_t grid_cells, grid_collider_capacity;
+	float4* grid_sbox; uint32_t* grid_skeys; uint32_t* grid_cstart; uint32_t* grid_counts; uint32_t* grid_large; uint32_t grid_cells, grid_collider_capacity;
 	uint8_t* fat_gen; uint32_t* fat_esc_mark; uint32_t* fat_esc_list; uint32_t* fat_moved_list;
 	bool env_no_incremental;
 	uint32_t fat_nbox, fat_nsph;          // collider counts of the last nh_collide (a change invalidates the list)
