@@ -188,6 +188,40 @@ def test_temporal_coherence_paths_are_bit_identical_at_size(config, monkeypatch)
     a.close(); b.close()
 
 
+def test_movers_in_a_million_boxes_at_rest_are_reinserted_bit_identically(monkeypatch):
+    """The regime re-insertion into the kept pair list is for, at BASELINE's size: the 1,004,400 boxes of config 2 have landed; 300 of them are thrown across
+    their neighbours (some fly for the whole window and leave their inflated boxes on every step, some hop and land on other boxes, a few are teleported).
+    The default world re-inserts the leavers (no rebuild while they move); a world that searches the grid every step must give the very same bits."""
+    scene = S.grid_tiles(124, side=90, seed=2, lattice_cols=11)
+    nb = len(scene["body_transforms"])
+    a = E.World(scene, flags=E.NH_FLAG_FUSED_STEP, max_contacts=6 * nb)
+    monkeypatch.setenv("NH_NO_KEPT_PAIRS", "1")
+    b = E.World(scene, flags=E.NH_FLAG_FUSED_STEP, max_contacts=6 * nb)
+    monkeypatch.delenv("NH_NO_KEPT_PAIRS")
+    a.step(75); b.step(75)
+    rng = np.random.default_rng(11)
+    movers = rng.choice(np.arange(1, nb), size=300, replace=False)
+    kick = rng.uniform(-3.0, 3.0, size=(300, 3)).astype(np.float32)
+    kick[:100, 1] = 30.0; kick[100:, 1] = rng.uniform(1.0, 4.0, size=200).astype(np.float32)
+    c0 = a.counts()
+    for w in (a, b):
+        bd = w.get_bodies()
+        m = bd["momentum"].copy(); m["velocity"][movers] = kick
+        t = bd["transforms"].copy(); t["position"][movers[-5:], 1] += np.float32(1.5); t["position"][movers[-5:], 0] += np.float32(0.7)
+        w.set_bodies(transforms=t, momentum=m)
+    for upto in (20, 60, 120):
+        a.step(upto - (a.steps_done - 75)); b.step(upto - (b.steps_done - 75))
+        x, y = a.get_bodies(), b.get_bodies()
+        assert P.bits_equal(x["transforms"], y["transforms"]) and P.bits_equal(x["momentum"], y["momentum"]) and np.array_equal(x["idle"], y["idle"]), upto
+    ka, kb = a.get_cache(), b.get_cache()
+    assert ka["count"] == kb["count"] and np.array_equal(ka["tags"], kb["tags"]) and P.bits_equal(ka["data"]["impulse"], kb["data"]["impulse"])
+    ca, cb = a.counts(), b.counts()
+    assert ca["error"] == 0 and cb["error"] == 0
+    print(f"\n[1 M boxes, 300 movers, 120 steps] re-insertions {ca['broadphase_inserts'] - c0['broadphase_inserts']}, rebuilds {ca['broadphase_rebuilds'] - c0['broadphase_rebuilds']} (search every step: {cb['broadphase_rebuilds']})")
+    assert ca["broadphase_inserts"] - c0["broadphase_inserts"] > 5000 and ca["broadphase_rebuilds"] - c0["broadphase_rebuilds"] <= 6, ca
+    a.close(); b.close()
+
+
 # ---- config 4: the ball pit -------------------------------------------------------------------------------------------------------
 def _pit_stats(scene, pos, vel, contact_bodies, penetration, wall_margin=2.0):
     """Invariants of a pit of r = 0.5 spheres: max penetration, kinetic energy per sphere, contact degree of INTERIOR spheres
