@@ -42,6 +42,9 @@
 #define NH_BLK_GROUPS 2                  // wavefront groups of a sweep workgroup that take the colour chunks in turn (below)
 #define NH_BLK_CHUNK (NH_BLK_THREADS / NH_BLK_GROUPS)      // contacts of one colour solved in one step
 #define NH_BLK_MAX_CHUNKS 96u            // steps of one block: its colours cut into chunks (a block with more is too big: smaller blocks)
+#define NH_BLK_LOCAL_L 32u               // colours of the per-block colouring (k_blk_prepare_local); the descriptor holds L + 1 offsets
+#define NH_BLK_PREP_THREADS 1024         // threads of k_blk_prepare_local (a block's ~2500 contacts: two or three per thread and pass; 512 threads: 0.74 ms, 256: 1.15 ms in the pit)
+#define NH_BLK_MAX_CONTACTS 6144u        // contacts of one block the per-block colouring holds in LDS (a block with more is too big: smaller blocks)
 #define NH_BLK_DESC_WORDS 40u            // per (block colour, workgroup) descriptor: block, own bodies, first slot, ghosts, ghost list base, the L + 1 bin offsets
 
 // 16 bytes from a per-lane global address straight into LDS (lane-linear destination: consecutive lanes must name consecutive 16-byte pieces)
@@ -54,7 +57,7 @@ __device__ __forceinline__ uint32_t blk_slot(const uint32_t* __restrict__ own_ba
 __global__ void k_blk_reset(nh_DevState* st) {
 	nh_BlkGrid& g = st->blk;
 	for (int k = 0; k < 3; ++k) { g.bmin[k] = 0xffffffffu; g.bmax[k] = 0u; }
-	g.bodies = 0; g.nblk = 0; g.overflow = 0; g.max_load = 0; g.ghost_cursor = 0; g.check_errors = 0; g.near_contacts = 0; g.far_contacts = 0;
+	g.bodies = 0; g.nblk = 0; g.overflow = 0; g.max_load = 0; g.ghost_cursor = 0; g.check_errors = 0; g.near_contacts = 0; g.far_contacts = 0; g.max_colours = 0; g.too_many_colours = 0;
 	for (int k = 0; k < 8; ++k) g.phase_count[k] = 0;
 }
 
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void k_blk_contact(nh_DevState* __restrict__ s
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
 		const uint32_t c = general_list[k];
 		const nh_BodyPair p = bodies[c];
-		uint32_t l = level[c];
+		uint32_t l = level ? level[c] : 1u;          // (no colours yet: the blocks colour their own contacts, k_blk_prepare_local; L = 1)
 		if (l < 1u || l > L) { st->error = NH_ERR_INVALID; l = 1u; }
 		const uint2 ra = p.a ? brank[p.a] : make_uint2(NH_NONE, 0u), rb = p.b ? brank[p.b] : make_uint2(NH_NONE, 0u);
 		if ((p.a && ra.x == NH_NONE) || (p.b && rb.x == NH_NONE) || (!p.a && !p.b)) { st->error = NH_ERR_INVALID; rank_out[k] = 0; bin_out[k] = NH_NONE; continue; }
@@ -212,7 +215,21 @@ __global__ __launch_bounds__(256) void k_blk_contact(nh_DevState* __restrict__ s
 			else { owner = NH_BLK_RESIDUAL; ++far; }
 		}
 		const uint32_t bin = owner * L + (l - 1u);
-		rank_out[k] = atomicAdd(&bins[bin], 1u);
+		// (contacts come in tag order, which is spatial order in a generated scene: the lanes of a wave hit a handful of bins -- one atomic per bin and wave;
+		// with one bin per block, 2500 contacts each, a returning atomic per contact cost 1.9 ms in a pit of 11 M contacts)
+		uint32_t rnk = 0;
+		unsigned long long todo = __ballot(1);
+		while (todo) {
+			const int leader = __ffsll((long long)todo) - 1;
+			const uint32_t lb2 = (uint32_t)__shfl((int)bin, leader);
+			const unsigned long long same = __ballot(bin == lb2) & todo;
+			uint32_t base2 = 0;
+			if ((int)nh_lane() == leader) base2 = atomicAdd(&bins[lb2], (uint32_t)__popcll(same));
+			base2 = (uint32_t)__shfl((int)base2, leader);
+			if ((same >> nh_lane()) & 1ull) rnk = base2 + (uint32_t)__popcll(same & ((1ull << nh_lane()) - 1ull));
+			todo &= ~same;
+		}
+		rank_out[k] = rnk;
 		bin_out[k] = bin;
 	}
 	for (int d = 32; d >= 1; d >>= 1) { near += (uint32_t)__shfl_xor((int)near, d); far += (uint32_t)__shfl_xor((int)far, d); }
@@ -309,6 +326,192 @@ __global__ __launch_bounds__(256) void k_blk_prepare(nh_DevState* __restrict__ s
 			loc[side] = l;
 		}
 		lpair[k] = loc[0] | loc[1] << 16;
+	}
+}
+
+// The same with the COLOURING done here, block by block (when no contact is residual -- the usual case: every contact then lives in exactly one block, and
+// all a block needs from a colouring is that no two contacts of one colour in ITS list share a dynamic body).  The world-wide colouring this replaces
+// needs per-body adjacency lists (23 M returning atomics in a pit of 4 M spheres), a seed and a validation pass and three to five relaxation rounds with a
+// host round trip each: 2 ms of the pit's 16.  Here the block's contacts and a "colours in use" mask per local body sit in LDS:
+//   * SEEDS: a contact that was there last step brings the colour it had (it rides in the spare word of its cached impulse, as for the world-wide
+//     colouring).  Every seeded contact ORs its colour into its two bodies' masks; a body that is offered one colour twice (two contacts that were
+//     coloured in different blocks last step, or garbage in a cache the library did not write) is noted in a conflict mask, and BOTH contacts of such a
+//     clash give their seed up -- symmetric, so the outcome does not depend on who came first;
+//   * the rest (new contacts, a few per cent) by Jones-Plassmann rounds over a compacted list: every uncoloured contact bids for its two bodies with a
+//     hashed priority (atomicMin of a 64-bit value made of the contact's index in the caller's list: no arrival order in it), a contact that holds both
+//     takes the lowest colour neither body uses.
+// Then a counting sort by colour inside the block's segment (positions inside a colour are arrival order: contacts of one colour share no body, so
+// nothing depends on it), the descriptor with the NH_BLK_LOCAL_L + 1 colour offsets, and the colours written back for the next step's seeds.
+__global__ __launch_bounds__(NH_BLK_PREP_THREADS) void k_blk_prepare_local(nh_DevState* __restrict__ st, const uint32_t* __restrict__ bin_off, const uint32_t* __restrict__ blk_count,
+                                                           const uint32_t* __restrict__ own_base, const uint32_t* __restrict__ order, const nh_BodyPair* __restrict__ bodies,
+                                                           const uint2* __restrict__ brank, const nh_CachedContactImpulse* __restrict__ warm, uint32_t* __restrict__ colour_out,
+                                                           uint32_t* __restrict__ order_out, uint32_t* __restrict__ lpair, uint32_t* __restrict__ ghost_base,
+                                                           uint32_t* __restrict__ ghost_count, uint32_t* __restrict__ ghost_list, uint32_t* __restrict__ phase_list, uint32_t* __restrict__ desc) {
+	constexpr uint32_t LL = NH_BLK_LOCAL_L, LIST = 2u * (2u * NH_BLK_HASH - NH_BLK_MAX_CONTACTS);       // (16-bit entries behind the index pairs)
+	__shared__ uint32_t s_tab[2u * NH_BLK_HASH];                 // the ghost table (keys, values); afterwards the local index pairs of the block's contacts + the list of the uncoloured
+	__shared__ unsigned long long s_mask[NH_BLK_CAP];            // colours in use, per local body
+	__shared__ unsigned long long s_claim[NH_BLK_CAP];           // seed pass: colours offered twice; Jones-Plassmann rounds: the best bid
+	__shared__ uint8_t s_col[NH_BLK_MAX_CONTACTS];
+	__shared__ uint32_t s_cnt[LL + 1u], s_cur[LL];
+	__shared__ uint32_t s_n, s_base, s_fail, s_slot, s_nlist;
+	static_assert(2u * NH_BLK_HASH > NH_BLK_MAX_CONTACTS, "the index pairs reuse the ghost table");
+	uint32_t* const s_key = s_tab; uint32_t* const s_val = s_tab + NH_BLK_HASH; uint32_t* const s_lp = s_tab;
+	uint16_t* const s_list = reinterpret_cast<uint16_t*>(s_tab + NH_BLK_MAX_CONTACTS);
+	const uint32_t b = blockIdx.x, tid = threadIdx.x;
+	if (b >= st->blk.nblk) return;
+	const uint32_t r0 = bin_off[b], r1 = bin_off[b + 1u];
+	if (r0 == r1) { if (tid == 0) { ghost_base[b] = 0; ghost_count[b] = 0; } return; }
+	const uint32_t n_own = blk_count[b], nc = r1 - r0;
+	for (uint32_t t = tid; t < NH_BLK_HASH; t += NH_BLK_PREP_THREADS) s_key[t] = NH_NONE;
+	if (tid == 0) { s_n = 0; s_fail = nc > NH_BLK_MAX_CONTACTS ? 1u : 0u; s_nlist = 0; }
+	__syncthreads();
+	for (uint32_t k = r0 + tid; k < r1; k += NH_BLK_PREP_THREADS) {
+		const nh_BodyPair p = bodies[order[k]];
+#pragma unroll
+		for (int side = 0; side < 2; ++side) {
+			const uint32_t x = side ? p.b : p.a;
+			if (!x || (brank[x].x >> NH_BLK_RANK_BITS) == b) continue;
+			uint32_t h = (x * 2654435761u) >> (32 - 12);
+			bool done = false;
+			for (uint32_t probe = 0; probe < NH_BLK_HASH; ++probe) {
+				const uint32_t old = atomicCAS(&s_key[h], NH_NONE, x);
+				if (old == NH_NONE || old == x) { done = true; break; }
+				h = (h + 1u) & (NH_BLK_HASH - 1u);
+			}
+			if (!done) s_fail = 1;
+		}
+	}
+	__syncthreads();
+	for (uint32_t t = tid; t < NH_BLK_HASH; t += NH_BLK_PREP_THREADS) if (s_key[t] != NH_NONE) s_val[t] = atomicAdd(&s_n, 1u);
+	__syncthreads();
+	const uint32_t n_gh = s_n, nloc = 1u + n_own + n_gh;
+	const bool fits = !s_fail && nloc <= NH_BLK_CAP;
+	if (tid == 0) atomicMax(&st->blk.max_load, nloc);
+	if (!fits) { if (tid == 0) { st->blk.overflow = 1; ghost_base[b] = 0; ghost_count[b] = 0; } return; }             // (uniform: the host retries with smaller blocks)
+	if (tid == 0) { s_base = atomicAdd(&st->blk.ghost_cursor, n_gh); ghost_base[b] = s_base; ghost_count[b] = n_gh; }
+	__syncthreads();
+	const uint32_t base = s_base;
+	for (uint32_t t = tid; t < NH_BLK_HASH; t += NH_BLK_PREP_THREADS) if (s_key[t] != NH_NONE) ghost_list[base + s_val[t]] = blk_slot(own_base, brank[s_key[t]].x);
+	// local index pairs, parked in the output array (contact order of the segment) until the table's memory is free for them
+	for (uint32_t k = r0 + tid; k < r1; k += NH_BLK_PREP_THREADS) {
+		const nh_BodyPair p = bodies[order[k]];
+		uint32_t loc[2];
+#pragma unroll
+		for (int side = 0; side < 2; ++side) {
+			const uint32_t x = side ? p.b : p.a;
+			uint32_t l = 0;
+			if (x) {
+				const uint32_t br = brank[x].x;
+				if ((br >> NH_BLK_RANK_BITS) == b) l = 1u + (br & NH_BLK_RANK_MASK);
+				else {
+					uint32_t h = (x * 2654435761u) >> (32 - 12);
+					while (s_key[h] != x) h = (h + 1u) & (NH_BLK_HASH - 1u);
+					l = 1u + n_own + s_val[h];
+				}
+			}
+			loc[side] = l;
+		}
+		lpair[k] = loc[0] | loc[1] << 16;
+	}
+	__syncthreads();
+	for (uint32_t t = tid; t < nloc; t += NH_BLK_PREP_THREADS) { s_mask[t] = 0ull; s_claim[t] = 0ull; }
+	__syncthreads();
+	// seeds: the colour of last step, offered to both bodies
+	for (uint32_t kl = tid; kl < nc; kl += NH_BLK_PREP_THREADS) {
+		const uint32_t lp = lpair[r0 + kl], la = lp & 0xFFFFu, lb = lp >> 16;
+		s_lp[kl] = lp;
+		uint32_t seed = __float_as_uint(warm[order[r0 + kl]].unused);
+		if (seed < 1u || seed > LL) seed = 0u;
+		s_col[kl] = (uint8_t)seed;
+		if (seed) {
+			const unsigned long long bit = 1ull << (seed - 1u);
+			if (la) { const unsigned long long old = atomicOr(&s_mask[la], bit); if (old & bit) atomicOr(&s_claim[la], bit); }
+			if (lb) { const unsigned long long old = atomicOr(&s_mask[lb], bit); if (old & bit) atomicOr(&s_claim[lb], bit); }
+		}
+	}
+	__syncthreads();
+	// a colour offered twice to one body: both contacts give it up (the colour stays marked as used on that body: one colour wasted, no order in the outcome);
+	// whoever is left without a colour goes on the list
+	for (uint32_t kl = tid; kl < nc; kl += NH_BLK_PREP_THREADS) {
+		uint32_t seed = s_col[kl];
+		if (seed) {
+			const uint32_t lp = s_lp[kl], la = lp & 0xFFFFu, lb = lp >> 16;
+			const unsigned long long bit = 1ull << (seed - 1u);
+			if ((la && (s_claim[la] & bit)) || (lb && (s_claim[lb] & bit))) { seed = 0u; s_col[kl] = 0; }
+		}
+		if (!seed) { const uint32_t at = atomicAdd(&s_nlist, 1u); if (at < LIST) s_list[at] = (uint16_t)kl; }
+	}
+	__syncthreads();
+	const uint32_t nlist = s_nlist;
+	const bool listed = nlist <= LIST;                // (else: a block without seeds -- the first step -- walks all its contacts in every round)
+	const uint32_t nwalk = listed ? nlist : nc;
+	// Jones-Plassmann rounds over the uncoloured
+	for (uint32_t round = 0; round < 4096u && nwalk; ++round) {
+		for (uint32_t i = tid; i < nwalk; i += NH_BLK_PREP_THREADS) {
+			const uint32_t kl = listed ? (uint32_t)s_list[i] : i;
+			if (s_col[kl]) continue;
+			const uint32_t lp = s_lp[kl], la = lp & 0xFFFFu, lb = lp >> 16;
+			if (la) s_claim[la] = ~0ull;
+			if (lb) s_claim[lb] = ~0ull;
+		}
+		__syncthreads();
+		for (uint32_t i = tid; i < nwalk; i += NH_BLK_PREP_THREADS) {
+			const uint32_t kl = listed ? (uint32_t)s_list[i] : i;
+			if (s_col[kl]) continue;
+			const uint32_t lp = s_lp[kl], la = lp & 0xFFFFu, lb = lp >> 16, c = order[r0 + kl];
+			const unsigned long long bid = (unsigned long long)(c * 2654435761u) << 32 | c;
+			if (la) atomicMin(&s_claim[la], bid);
+			if (lb) atomicMin(&s_claim[lb], bid);
+		}
+		__syncthreads();
+		bool left = false;
+		for (uint32_t i = tid; i < nwalk; i += NH_BLK_PREP_THREADS) {
+			const uint32_t kl = listed ? (uint32_t)s_list[i] : i;
+			if (s_col[kl]) continue;
+			const uint32_t lp = s_lp[kl], la = lp & 0xFFFFu, lb = lp >> 16, c = order[r0 + kl];
+			const unsigned long long bid = (unsigned long long)(c * 2654435761u) << 32 | c;
+			if ((!la || s_claim[la] == bid) && (!lb || s_claim[lb] == bid)) {
+				const unsigned long long used = (la ? s_mask[la] : 0ull) | (lb ? s_mask[lb] : 0ull);
+				const uint32_t q = (uint32_t)__ffsll((long long)~used) - 1u;
+				if (q >= LL) { s_fail = 1; s_col[kl] = 1; }                  // (more colours than the descriptor holds: smaller blocks do not help, the caller falls back)
+				else { s_col[kl] = (uint8_t)(q + 1u); if (la) s_mask[la] |= 1ull << q; if (lb) s_mask[lb] |= 1ull << q; }
+			} else left = true;
+		}
+		if (!__syncthreads_or(left ? 1 : 0)) break;
+	}
+	// counting sort by colour inside the segment; chunks of the sweep's pipeline
+	if (tid <= LL) s_cnt[tid] = 0;
+	for (uint32_t kl = tid; kl < nc; kl += NH_BLK_PREP_THREADS) if (!s_col[kl]) { s_fail = 1; s_col[kl] = 1; }          // (the round limit: never in practice)
+	__syncthreads();
+	for (uint32_t kl = tid; kl < nc; kl += NH_BLK_PREP_THREADS) atomicAdd(&s_cnt[s_col[kl] - 1u], 1u);
+	__syncthreads();
+	if (tid == 0) {
+		uint32_t run = 0, chunks = 0, used = 0;
+		for (uint32_t c = 0; c < LL; ++c) { const uint32_t n = s_cnt[c]; s_cnt[c] = run; s_cur[c] = 0; run += n; chunks += (n + NH_BLK_CHUNK - 1u) / NH_BLK_CHUNK; if (n) used = c + 1u; }
+		s_cnt[LL] = run;
+		atomicMax(&st->blk.max_colours, used);
+		if (s_fail) st->blk.too_many_colours = 1;
+		if (chunks > NH_BLK_MAX_CHUNKS) { st->blk.overflow = 1; s_fail = 1; }
+		if (!s_fail) {
+			const uint32_t b0 = st->blk.bits[0], b1 = st->blk.bits[1], b2 = st->blk.bits[2];
+			const uint32_t c0 = b & ((1u << b0) - 1u), c1 = (b >> b0) & ((1u << b1) - 1u), c2 = (b >> (b0 + b1)) & ((1u << b2) - 1u);
+			const uint32_t col = (c0 & 1u) | (c1 & 1u) << 1 | (c2 & 1u) << 2;
+			const uint32_t slot = col * NH_BLK_MAX_BLOCKS + atomicAdd(&st->blk.phase_count[col], 1u);
+			phase_list[slot] = b;
+			s_slot = slot;
+			uint32_t* dsc = desc + (size_t)slot * NH_BLK_DESC_WORDS;
+			dsc[0] = b; dsc[1] = n_own; dsc[2] = 1u + own_base[b]; dsc[3] = n_gh; dsc[4] = base;
+		}
+	}
+	__syncthreads();
+	if (s_fail) return;
+	if (tid <= LL) desc[(size_t)s_slot * NH_BLK_DESC_WORDS + 5u + tid] = r0 + s_cnt[tid];
+	for (uint32_t kl = tid; kl < nc; kl += NH_BLK_PREP_THREADS) {
+		const uint32_t q = s_col[kl] - 1u, c = order[r0 + kl];
+		const uint32_t pos = r0 + s_cnt[q] + atomicAdd(&s_cur[q], 1u);
+		order_out[pos] = c;
+		lpair[pos] = s_lp[kl];
+		colour_out[c] = q + 1u;                        // (next step's seed: k_update_impulses puts it into the cached impulse's spare word)
 	}
 }
 
@@ -497,16 +700,19 @@ __global__ __launch_bounds__(256) void k_blk_check(nh_DevState* __restrict__ st,
                                                    const uint32_t* __restrict__ blk_count, const uint32_t* __restrict__ own_base, const uint32_t* __restrict__ ghost_base,
                                                    const uint32_t* __restrict__ ghost_count, const uint32_t* __restrict__ ghost_list, const uint32_t* __restrict__ lpair,
                                                    const uint32_t* __restrict__ order, const nh_BodyPair* __restrict__ bodies, const uint32_t* __restrict__ level,
-                                                   const uint32_t* __restrict__ pos_body, uint32_t* __restrict__ touch, uint32_t* __restrict__ colour_of_slot /* 2 x slots: scratch */) {
+                                                   const uint32_t* __restrict__ pos_body, uint32_t* __restrict__ touch, uint32_t* __restrict__ colour_of_slot /* 2 x slots: scratch */,
+                                                   const uint32_t* __restrict__ desc_phase) {
+	// (desc_phase: the blocks coloured their own contacts, k_blk_prepare_local -- the colour offsets are the descriptor's, there is no world-wide colour)
 	const uint32_t b = phase_list[blockIdx.x];
+	const uint32_t* offs = desc_phase ? desc_phase + (size_t)blockIdx.x * NH_BLK_DESC_WORDS + 5u : bin_off + (size_t)b * L;
 	const uint32_t n_own = blk_count[b], base = 1u + own_base[b], n_gh = ghost_count[b], gb = ghost_base[b];
 	uint32_t errors = 0;
 	if (1u + n_own + n_gh > NH_BLK_CAP) ++errors;
 	for (uint32_t l = 0; l < L; ++l) {
-		for (uint32_t k = bin_off[b * L + l] + threadIdx.x; k < bin_off[b * L + l + 1u]; k += blockDim.x) {
+		for (uint32_t k = offs[l] + threadIdx.x; k < offs[l + 1u]; k += blockDim.x) {
 			const uint32_t c = order[k];
 			const nh_BodyPair p = bodies[c];
-			if (level[c] != l + 1u) ++errors;
+			if (level && level[c] != l + 1u) ++errors;
 			const uint32_t lp = lpair[k];
 			const uint32_t loc[2] = { lp & 0xFFFu, (lp >> 16) & 0xFFFu };
 			for (int side = 0; side < 2; ++side) {

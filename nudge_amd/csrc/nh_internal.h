@@ -37,6 +37,7 @@ struct nh_BlkGrid {
 	uint32_t phase_count[8];          // blocks with work, by block colour (parity of the three block coordinates)
 	uint32_t check_errors;            // NH_BLK_CHECK=1: structural errors found by k_blk_check
 	uint32_t near_contacts, far_contacts;   // contacts between two blocks: solved inside a block / left to the residual launches
+	uint32_t max_colours, too_many_colours; // per-block colouring (k_blk_prepare_local): most colours a block used; some block needed more than its descriptor holds
 };
 
 // ---- device-resident step state (one per context) ---------------------------------------------------
@@ -181,6 +182,8 @@ struct nh_context {
 	float4* grid_sbox; uint32_t* grid_skeys; uint32_t* grid_cstart; uint32_t* grid_counts; uint32_t* grid_large; uint32_t grid_cells, grid_collider_capacity;
 	uint8_t* fat_gen; uint32_t* fat_esc_mark; uint32_t* fat_esc_list; uint32_t* fat_moved_list;
 	bool env_no_incremental;
+	bool env_blk_global_colours;          // NH_BLK_GLOBAL_COLOURS=1: the blocked solver takes the world-wide colouring (A/B, tests)
+	uint32_t last_general_contacts;       // general contacts of the last setup: does this step's adjacency build leave the general bodies to the per-block colouring?
 	uint32_t fat_nbox, fat_nsph;          // collider counts of the last nh_collide (a change invalidates the list)
 	uint32_t bp_seen_rebuilds, bp_rebuild_streak; int bp_direct_left;      // direct search instead of the kept list while every step rebuilds it (nh_collide)
 	bool env_measure_skip;                // NH_MEASURE_SKIP_CHAINS=1: measurement only (nh_collide)
@@ -280,6 +283,7 @@ struct nh_ContactConstraintData {
 	// one-body path: row build + warm start are deferred into the first nh_apply_impulses (or the next call that observes
 	// momentum / impulses); `setup_pending` says they have not run yet
 	bool setup_pending;
+	bool general_lists;        // the adjacency lists of the general bodies have been filled (not when the per-block colouring of the blocked solver was expected to apply)
 	bool states_kept;          // the first solver call stored its states: another nh_apply_impulses can continue (false after an applied NH_FLAG_SINGLE_APPLY call)
 	nh_ContactImpulseData* imp;
 	nh_BodyData bodies_at_setup;
@@ -294,6 +298,7 @@ struct nh_ContactConstraintData {
 	// spatially blocked solver (nh_blocks.h): the general contacts are laid out by (owning block, colour) and swept block by block in LDS
 	struct {
 		bool active, warm_pending, radial_only;
+		bool local;                           // the blocks coloured their own contacts (k_blk_prepare_local): no world-wide colour, no general adjacency lists
 		uint32_t L;                                   // colours
 		uint32_t phase_count[8];
 		uint32_t res_off[NH_BLK_MAX_COLOURS + 2];     // residual contacts (no block can own them) by colour: positions in the level-order arrays

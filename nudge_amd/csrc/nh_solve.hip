@@ -183,7 +183,9 @@ __device__ __forceinline__ uint32_t run_length(const uint64_t* __restrict__ tags
 
 // general CSR fill, only for the bodies k_adj_simple left pending (several pairs, or a dynamic partner)
 __global__ __launch_bounds__(256) void k_adj_fill(const nh_DevState* __restrict__ st, const nh_BodyPair* __restrict__ bodies, const uint64_t* __restrict__ tags, const uint32_t* __restrict__ off,
-                                                  uint32_t* __restrict__ cursor, uint32_t* __restrict__ adj, const uint8_t* __restrict__ body_class) {
+                                                  uint32_t* __restrict__ cursor, uint32_t* __restrict__ adj, const uint8_t* __restrict__ body_class, uint32_t which) {
+	// `which`: 3 = the lists of pending AND general bodies; 1 = pending bodies only (the general ones are left to the per-block colouring of the blocked
+	// solver, which needs no lists); 2 = general bodies only (the second pass when that turned out not to apply)
 	if (!st->has_pending) return;
 	uint32_t n = st->contacts;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -191,8 +193,8 @@ __global__ __launch_bounds__(256) void k_adj_fill(const nh_DevState* __restrict_
 		if (!len) continue;
 		nh_BodyPair p = bodies[i];
 		const uint32_t ca = p.a ? body_class[p.a] : NH_CLS_NONE, cb = p.b ? body_class[p.b] : NH_CLS_NONE;      // (general bodies settled by k_adj_simple need their lists too)
-		if (ca == NH_CLS_PENDING || ca == NH_CLS_GENERAL) { uint32_t base = off[p.a] + atomicAdd(&cursor[p.a], len); for (uint32_t k = 0; k < len; ++k) adj[base + k] = i + k; }
-		if (cb == NH_CLS_PENDING || cb == NH_CLS_GENERAL) { uint32_t base = off[p.b] + atomicAdd(&cursor[p.b], len); for (uint32_t k = 0; k < len; ++k) adj[base + k] = i + k; }
+		if ((ca == NH_CLS_PENDING && (which & 1u)) || (ca == NH_CLS_GENERAL && (which & 2u))) { uint32_t base = off[p.a] + atomicAdd(&cursor[p.a], len); for (uint32_t k = 0; k < len; ++k) adj[base + k] = i + k; }
+		if ((cb == NH_CLS_PENDING && (which & 1u)) || (cb == NH_CLS_GENERAL && (which & 2u))) { uint32_t base = off[p.b] + atomicAdd(&cursor[p.b], len); for (uint32_t k = 0; k < len; ++k) adj[base + k] = i + k; }
 	}
 }
 
@@ -1531,7 +1533,7 @@ __global__ __launch_bounds__(256) void k_rows_general(const nh_DevState* __restr
 			nh_row r;
 			nh_build_row(ci, apos, bpos, IA, IB, pa.w, pb.w, r);
 			store_row_soa(rows4, stride, k, r);
-			level_has_full[level[c]] = 1u;             // this level / colour class needs the kernel that knows full rows (plain store of a constant)
+			level_has_full[level ? level[c] : 1u] = 1u;             // this level / colour class needs the kernel that knows full rows (plain store of a constant; per-block colours: one flag for all)
 		}
 		gpair[k] = make_uint2(p.a | (radial ? NH_RADIAL_BIT : 0u), p.b);
 		if (warm_in) {
@@ -1965,7 +1967,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	d->contact_capacity = kcap; d->body_count = B; d->bodies = contacts->bodies;
 	d->contact_data = contacts->data; d->impulses = imp->data; d->general_list = general_list;
 	d->levels = 0; d->general_contacts = 0;
-	d->blk.active = false; d->blk.warm_pending = false;
+	d->blk.active = false; d->blk.warm_pending = false; d->blk.local = false;
 
 	// (degrees were counted by nh_collide while it laid the contacts out; their scan into CSR offsets waits until somebody needs it: ensure_csr)
 	d->csr_ready = false;
@@ -1990,7 +1992,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	d->cont.contacts = *contacts;
 	d->cont.cursor = cursor; d->cont.pred_a = pred_a; d->cont.pred_b = pred_b; d->cont.level = level; d->cont.slot_key = slot_key;
 	d->cont.level_hist = level_hist; d->cont.level_cursor = level_cursor; d->cont.tmp = tmp; d->cont.tent = tent;
-	d->has_static8 = d->has_staticN = d->has_late = false; d->static_inert = false;
+	d->has_static8 = d->has_staticN = d->has_late = false; d->static_inert = false; d->general_lists = true;
 	d->finish_pending = true;
 	d->setup_pending = true; d->imp = imp; d->bodies_at_setup = *bodies;
 	imp->consumed = true;
@@ -2054,11 +2056,13 @@ static int blk_reserve(nh_context* ctx, uint32_t B, uint32_t kcap) {
 
 // Lays the general contacts out by (owning block, colour) and builds the per-block tables.  Leaves d->blk.active false when the blocked form does not
 // apply (the caller then takes the per-colour global launches): too few contacts, too many colours, a block that cannot be made to fit.
-static int blk_setup(nh_context* ctx, nh_ContactConstraintData* d, uint32_t G) {
+static int blk_setup(nh_context* ctx, nh_ContactConstraintData* d, uint32_t G, bool local) {
 	nh_BlkBuffers& k = ctx->blk;
 	nh_DevState* st = ctx->d_state;
-	d->blk.active = false;
-	const uint32_t B = d->body_count, kcap = d->contact_capacity, L = d->levels;
+	// `local`: tried BEFORE any world-wide colouring exists -- contacts are binned by owning block only and every block colours its own (k_blk_prepare_local);
+	// gives up (not active) when some contact is residual or a block needs more colours than its descriptor holds: the caller colours world-wide and comes again
+	d->blk.active = false; d->blk.local = false;
+	const uint32_t B = d->body_count, kcap = d->contact_capacity, L = local ? 1u : d->levels;
 	if (k.disabled || (ctx->flags & NH_FLAG_EXACT_ORDER) || G < k.min_contacts || L < 1u || L > NH_BLK_MAX_COLOURS || !d->static_inert) return NH_OK;
 	{ int rc = blk_reserve(ctx, B, kcap); if (rc) return rc; }
 	const nh_ContactData* contacts = &d->cont.contacts;
@@ -2074,16 +2078,21 @@ static int blk_setup(nh_context* ctx, nh_ContactConstraintData* d, uint32_t G) {
 		NH_LAUNCH(ctx, "blk_bounds", k_blk_bounds, nh_grid_for(B, 256, 1024), 256, st, B, d->body_class, bodies->transforms);
 		NH_LAUNCH(ctx, "blk_grid", k_blk_grid, 1, 1, st, k.scale, (float)k.target);
 		NH_LAUNCH(ctx, "blk_body", k_blk_body, nh_grid_for(B, 256, 4096), 256, st, B, d->body_class, bodies->transforms, k.blk_count, k.brank);
-		NH_LAUNCH(ctx, "blk_contact", k_blk_contact, nh_grid_for(G, 256, 8192), 256, st, d->general_list, contacts->bodies, d->cont.level, k.brank, L, k.bins, rank, bin);
+		NH_LAUNCH(ctx, "blk_contact", k_blk_contact, nh_grid_for(G, 256, 8192), 256, st, d->general_list, contacts->bodies, local ? (const uint32_t*)nullptr : (const uint32_t*)d->cont.level, k.brank, L, k.bins, rank, bin);
 		nh_scan_u32(ctx, k.blk_count, k.own_base, &st->pad0, NH_BLK_MAX_BLOCKS + 1u, k.scan_tmp, nullptr);
 		nh_scan_u32(ctx, k.bins, k.bin_off, &st->pad0, (uint32_t)nbins, k.scan_tmp, nullptr);
 		NH_LAUNCH(ctx, "blk_scatter", k_blk_scatter, nh_grid_for(G, 256, 8192), 256, st, d->general_list, rank, bin, k.bin_off, d->level_order);
+		if (local)         // (the colour-sorted order goes to `rank`'s memory, free since the scatter: it becomes the setup's level order below)
+			NH_LAUNCH(ctx, "blk_prepare", k_blk_prepare_local, NH_BLK_MAX_BLOCKS, NH_BLK_PREP_THREADS, st, k.bin_off, k.blk_count, k.own_base, d->level_order, contacts->bodies, k.brank,
+			          (const nh_CachedContactImpulse*)d->imp->data, d->cont.tent /* (not `level`: a failed attempt must leave that as k_contact_class wrote it) */, rank, k.lpair, k.ghost_base, k.ghost_count, k.ghost_list, k.phase_list, k.desc);
+		else
 		NH_LAUNCH(ctx, "blk_prepare", k_blk_prepare, NH_BLK_MAX_BLOCKS, 256, st, L, k.bin_off, k.blk_count, k.own_base, d->level_order, contacts->bodies, k.brank, k.lpair,
 		          k.ghost_base, k.ghost_count, k.ghost_list, k.phase_list, k.desc);
 		NH_HIP_CHECK(ctx, hipMemcpyAsync(h, &st->blk, sizeof(nh_BlkGrid), hipMemcpyDeviceToHost, ctx->stream));
 		NH_HIP_CHECK(ctx, hipMemcpyAsync(d->blk.res_off, k.bin_off + (size_t)NH_BLK_MAX_BLOCKS * L, sizeof(uint32_t) * (L + 1u), hipMemcpyDeviceToHost, ctx->stream));
 		NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 		if (!h->nblk) return NH_OK;
+		if (local && (h->far_contacts || h->too_many_colours)) return NH_OK;         // (a contact no block can own / a block of more than 32 colours: the world-wide colouring it is)
 		if (h->overflow) { k.scale *= 0.8f; continue; }
 		ok = true;
 		// the edge follows the largest load: room for the pile to shift, no retries
@@ -2092,26 +2101,35 @@ static int blk_setup(nh_context* ctx, nh_ContactConstraintData* d, uint32_t G) {
 	}
 	if (!ok) return NH_OK;
 	for (int p = 0; p < 8; ++p) d->blk.phase_count[p] = h->phase_count[p];
-	d->blk.L = L;
+	if (k.prof && (k.prof_calls % 64u) == 63u) fprintf(stderr, "blk_profile setup: %s colouring, most colours in a block %u, largest load %u of %u, near contacts %u, residual %u\n", local ? "per-block" : "world-wide", local ? h->max_colours : L, h->max_load, NH_BLK_CAP, h->near_contacts, h->far_contacts);
+	d->blk.L = local ? NH_BLK_LOCAL_L : L;
+	d->blk.local = local;
+	if (local) {
+		// every contact is owned by a block; the order k_blk_prepare_local wrote is the setup's level order from here on
+		for (uint32_t l = 1; l <= NH_BLK_LOCAL_L; ++l) d->blk.res_off[l] = d->blk.res_off[0];
+		uint32_t* t = d->level_order; d->level_order = rank; d->cont.pred_a = t;
+	}
 	// rows (and the cached impulses, in the solver states' place) in block order; which colours hold a full row
 	uint32_t* level_hist = d->cont.level_hist;
 	NH_LAUNCH(ctx, "zero_u32", k_zero_u32, 8, 256, level_hist, 2 * (NH_MAX_LEVELS + 2));
 	NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, d->level_order, contacts->data, contacts->bodies, bodies->transforms, bodies->properties,
-	          (float4*)d->rows, (size_t)kcap, d->gpair, 1u, 1u, d->cont.level, level_hist + (NH_MAX_LEVELS + 2), (const nh_CachedContactImpulse*)d->imp->data, d->gstates, k.lpair, d->blk.res_off[0]);
+	          (float4*)d->rows, (size_t)kcap, d->gpair, 1u, 1u, local ? (const uint32_t*)nullptr : (const uint32_t*)d->cont.level, level_hist + (NH_MAX_LEVELS + 2), (const nh_CachedContactImpulse*)d->imp->data, d->gstates, k.lpair, d->blk.res_off[0]);
 	if (d->blk.res_off[L] > d->blk.res_off[0])
 		NH_LAUNCH(ctx, "blk_residual_pairs", k_blk_residual_pairs, nh_grid_for(d->blk.res_off[L] - d->blk.res_off[0], 256, 4096), 256, d->blk.res_off[0], d->blk.res_off[L], k.brank, k.own_base, d->gpair);
 	NH_HIP_CHECK(ctx, hipMemcpyAsync(d->level_full, level_hist + (NH_MAX_LEVELS + 2), sizeof(uint32_t) * (L + 2u), hipMemcpyDeviceToHost, ctx->stream));
 	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 	d->blk.radial_only = true;
 	for (uint32_t l = 1; l <= L; ++l) d->blk.radial_only &= d->level_full[l] == 0u;
+	if (local) for (uint32_t l = 2; l <= NH_BLK_LOCAL_L + 1u; ++l) d->level_full[l] = d->level_full[1];       // (one flag for all colours)
 	if (k.check) {
 		// NH_BLK_CHECK=1 (tests): the structure the sweeps rely on, launch by launch
 		NH_LAUNCH(ctx, "blk_gather", k_blk_gather, nh_grid_for(B, 256, 4096), 256, B, k.brank, k.own_base, (const float4*)bodies->momentum, bodies->properties, k.bm, k.pos_body);
 		for (int p = 0; p < 8; ++p) {
 			if (!d->blk.phase_count[p]) continue;
 			NH_HIP_CHECK(ctx, hipMemsetAsync(k.touch, 0, sizeof(uint32_t) * 2u * (size_t)(B + 1u), ctx->stream));
-			NH_LAUNCH(ctx, "blk_check", k_blk_check, d->blk.phase_count[p], 256, st, k.phase_list + (size_t)p * NH_BLK_MAX_BLOCKS, L, k.bin_off, k.blk_count, k.own_base, k.ghost_base,
-			          k.ghost_count, k.ghost_list, k.lpair, d->level_order, contacts->bodies, d->cont.level, k.pos_body, k.touch, k.touch + (B + 1u));
+			NH_LAUNCH(ctx, "blk_check", k_blk_check, d->blk.phase_count[p], 256, st, k.phase_list + (size_t)p * NH_BLK_MAX_BLOCKS, d->blk.L, k.bin_off, k.blk_count, k.own_base, k.ghost_base,
+			          k.ghost_count, k.ghost_list, k.lpair, d->level_order, contacts->bodies, local ? (const uint32_t*)nullptr : (const uint32_t*)d->cont.level, k.pos_body, k.touch, k.touch + (B + 1u),
+			          local ? (const uint32_t*)(k.desc + (size_t)p * NH_BLK_MAX_BLOCKS * NH_BLK_DESC_WORDS) : (const uint32_t*)nullptr);
 		}
 		NH_HIP_CHECK(ctx, hipMemcpyAsync(h, &st->blk, sizeof(nh_BlkGrid), hipMemcpyDeviceToHost, ctx->stream));
 		NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -2207,7 +2225,11 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 	if (d->has_late || ctx->h_state->has_static8 || !ctx->h_state->static_inert) ensure_csr(ctx, d);
 	if (d->has_late) {
 		// bodies in several pairs or with dynamic partners (piles, pits): general CSR fill + sort + classification, then the counts again
-		NH_LAUNCH(ctx, "adjacency_fill", k_adj_fill, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, contacts->tags, d->body_off, d->cont.cursor, d->adj, d->body_class);
+		// (a world that had enough general contacts for the blocked solver last step will most likely colour them block by block again: the general bodies'
+		// lists -- which only the world-wide colouring reads -- are then left out, and filled in a second pass if it comes to that)
+		const bool local_candidate = !(ctx->flags & NH_FLAG_EXACT_ORDER) && !ctx->blk.disabled && !ctx->env_blk_global_colours && ctx->last_general_contacts >= ctx->blk.min_contacts;
+		d->general_lists = !local_candidate;
+		NH_LAUNCH(ctx, "adjacency_fill", k_adj_fill, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, contacts->tags, d->body_off, d->cont.cursor, d->adj, d->body_class, local_candidate ? 1u : 3u);
 		NH_LAUNCH(ctx, "adjacency_sort", k_adj_sort, nh_grid_for(B, 256, 4096), 256, st, B, contacts->bodies, d->body_off, d->adj, slot_key, d->body_class, pred_a, pred_b, bodies->properties, bodies->momentum);
 		NH_LAUNCH(ctx, "contact_class", k_contact_class, nh_grid_for(kcap, 256, 2048), 256, st, contacts->bodies, d->body_class, level, general_list, pred_a, pred_b);
 		rc = nh_read_counts(ctx, &c);
@@ -2216,6 +2238,7 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 	}
 	run_cull(ctx, imp, c.sleeping_pairs);
 	d->general_contacts = c.general_contacts;
+	ctx->last_general_contacts = c.general_contacts;
 	d->has_static8 = ctx->h_state->has_static8 != 0;
 	d->has_staticN = ctx->h_state->has_staticN != 0;
 	d->static_inert = ctx->h_state->static_inert != 0;
@@ -2228,6 +2251,18 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 	if (c.general_contacts) {
 		const uint32_t G = c.general_contacts;
 		materialize_lookup(ctx, imp, contacts->bodies, d->body_class);
+		// a large set in default order with no contact that no block can own: the blocks colour their own contacts (nh_blocks.h, k_blk_prepare_local) --
+		// no world-wide colouring, no adjacency lists of the general bodies
+		if (!(ctx->flags & NH_FLAG_EXACT_ORDER) && !ctx->env_blk_global_colours) {
+			rc = blk_setup(ctx, d, G, true);
+			if (rc) return rc;
+			if (d->blk.active) return NH_OK;
+		}
+		if (!d->general_lists && d->has_late) {
+			// (the per-block colouring did not apply after all: the lists of the general bodies the adjacency build left out)
+			NH_LAUNCH(ctx, "adjacency_fill", k_adj_fill, nh_grid_for(kcap, 256, 4096), 256, st, contacts->bodies, contacts->tags, d->body_off, d->cont.cursor, d->adj, d->body_class, 2u);
+			d->general_lists = true;
+		}
 		// A few thousand contacts in default order: colouring and level order by ONE workgroup, no host round trip until the solver's (k_colour_small)
 		if (!(ctx->flags & NH_FLAG_EXACT_ORDER) && !ctx->env_colour_jp && !ctx->env_no_resident && !ctx->env_colour_check_seeds && G <= NH_COLOUR_SMALL_MAX &&
 		    (G <= NH_RES_MAX_FULL || B <= NH_RESB_MAX_BODIES)) {
@@ -2290,7 +2325,7 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		if (c.levels > NH_MAX_LEVELS) return NH_ERR_INVALID;
 		d->levels = c.levels;
 		// a large set in default order: contacts owned by spatial blocks, swept in LDS block by block (nh_blocks.h)
-		rc = blk_setup(ctx, d, G);
+		rc = blk_setup(ctx, d, G, false);
 		if (rc) return rc;
 		if (d->blk.active) return NH_OK;
 		NH_LAUNCH(ctx, "zero_u32", k_zero_u32, 8, 256, level_hist, 2 * (NH_MAX_LEVELS + 2));       // histogram + the per-class "has a full row" flags behind it
@@ -2480,7 +2515,7 @@ extern "C" int nh_update_cached_impulses(nh_context* ctx, nh_ContactConstraintDa
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	if (d->general_contacts)
 		NH_LAUNCH(ctx, "update_impulses", k_update_impulses, nh_grid_for(d->general_contacts, 256, 4096), 256, ctx->d_state, d->level_order, (const float4*)d->rows, (size_t)d->contact_capacity,
-		          (const float4*)d->gstates, imp->data, (ctx->flags & NH_FLAG_EXACT_ORDER) ? (const uint32_t*)nullptr : (const uint32_t*)d->cont.level, d->gpair,
+		          (const float4*)d->gstates, imp->data, (ctx->flags & NH_FLAG_EXACT_ORDER) ? (const uint32_t*)nullptr : (const uint32_t*)((d->blk.active && d->blk.local) ? d->cont.tent : d->cont.level), d->gpair,
 		          d->blk.active ? d->blk.res_off[0] : 0u);
 	return NH_OK;
 }

@@ -8,6 +8,8 @@ reference the bar is the statistical one of SURVEY 8(d) c4; what CAN be exact is
     and so do one apply call of I iterations and I calls of one;
   * NH_BLK_CHECK=1 verifies on the device, every step, that every local index resolves to the body the contact names, that no two blocks of
     a launch touch the same body and that no block list holds two contacts of one colour on one body.
+By default every block colours its own contacts (k_blk_prepare_local: no world-wide colouring, no adjacency lists of the general bodies) whenever no contact is
+residual; NH_BLK_GLOBAL_COLOURS=1 keeps the world-wide colouring.  Both are checked by the same device-side structure check.
 The knobs (read once in nh_create): NH_BLK_MIN (general contacts from which the blocked form is used; 200,000 by default), NH_BLK_TARGET (bodies
 per average block: small values make many blocks out of a small world), NH_NO_BLOCKS=1 (per-colour launches), NH_NO_RESIDENT=1 (no one-workgroup
 solvers)."""
@@ -30,7 +32,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _world(monkeypatch, scene, env, flags=E.NH_FLAG_SINGLE_APPLY, **kw):
-    keys = ("NH_BLK_MIN", "NH_BLK_TARGET", "NH_BLK_CHECK", "NH_NO_BLOCKS", "NH_NO_RESIDENT")
+    keys = ("NH_BLK_MIN", "NH_BLK_TARGET", "NH_BLK_CHECK", "NH_NO_BLOCKS", "NH_NO_RESIDENT", "NH_BLK_GLOBAL_COLOURS")
     for k in keys:
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
@@ -46,11 +48,12 @@ def _same(a, b):
 
 
 def test_one_block_is_bit_identical_to_the_per_colour_launches(monkeypatch):
-    """A 12^3 pit in ONE block: the workgroup walks colours 1..L exactly like the L launches of k_level_exec do, with the momentum in LDS
-    instead of HBM.  Same arithmetic, same order => the same bits, step after step, cache included."""
+    """A 12^3 pit in ONE block, with the world-wide colouring (NH_BLK_GLOBAL_COLOURS=1; by default a block colours its own contacts): the workgroup walks
+    colours 1..L exactly like the L launches of k_level_exec do, with the momentum in LDS instead of HBM.  Same arithmetic, same order => the same bits, step
+    after step, cache included."""
     scene = S.ball_pit(12, 12, 12, seed=21)
     nb = 12 ** 3
-    a = _world(monkeypatch, scene, dict(NH_NO_RESIDENT=1, NH_BLK_MIN=1, NH_BLK_TARGET=1000000, NH_BLK_CHECK=1), max_contacts=8 * nb, max_pairs=10 * nb)
+    a = _world(monkeypatch, scene, dict(NH_NO_RESIDENT=1, NH_BLK_MIN=1, NH_BLK_TARGET=1000000, NH_BLK_CHECK=1, NH_BLK_GLOBAL_COLOURS=1), max_contacts=8 * nb, max_pairs=10 * nb)
     b = _world(monkeypatch, scene, dict(NH_NO_RESIDENT=1, NH_NO_BLOCKS=1), max_contacts=8 * nb, max_pairs=10 * nb)
     for upto in (60, 150, 300):
         a.step(upto - a.steps_done); b.step(upto - b.steps_done)
@@ -96,10 +99,14 @@ def test_blocked_pit_against_the_reference_and_the_colour_launches(monkeypatch):
     ref = _reference_pit(20, 20, 20, 9, checkpoints)
     scene = S.ball_pit(20, 20, 20, seed=9)
     nb = 8000
-    blk = _world(monkeypatch, scene, dict(NH_BLK_MIN=1, NH_BLK_TARGET=120), max_contacts=8 * nb, max_pairs=10 * nb)
+    blk = _world(monkeypatch, scene, dict(NH_BLK_MIN=1, NH_BLK_TARGET=120, NH_BLK_CHECK=1), max_contacts=8 * nb, max_pairs=10 * nb)
+    glo = _world(monkeypatch, scene, dict(NH_BLK_MIN=1, NH_BLK_TARGET=120, NH_BLK_GLOBAL_COLOURS=1), max_contacts=8 * nb, max_pairs=10 * nb)
     col = _world(monkeypatch, scene, dict(NH_NO_BLOCKS=1), max_contacts=8 * nb, max_pairs=10 * nb)
     for s in checkpoints:
-        blk.step(s - blk.steps_done); col.step(s - col.steps_done)
+        blk.step(s - blk.steps_done); col.step(s - col.steps_done); glo.step(s - glo.steps_done)
+        assert blk.counts()["error"] == 0 and glo.counts()["error"] == 0
+        q = _gpu_pit_stats(glo, scene)
+        assert q["inside"] == 1.0 and abs(q["top"] - ref[s]["top"]) <= 0.005 * ref[s]["top"] + 0.1 and q["max_pen"] <= 1.5 * ref[s]["max_pen"] + 0.01      # (blocks with the world-wide colours)
         g, h, r = _gpu_pit_stats(blk, scene), _gpu_pit_stats(col, scene), ref[s]
         print(f"\n[pit 20^3 step {s}] blocked / colours / reference: contacts {g['contacts']} / {h['contacts']} / {int(round(r['contacts_per_sphere'] * nb))}; "
               f"max penetration {g['max_pen']:.4f} / {h['max_pen']:.4f} / {r['max_pen']:.4f}; KE/sphere {g['ke']:.3e} / {h['ke']:.3e} / {r['ke']:.3e}; "
@@ -111,7 +118,7 @@ def test_blocked_pit_against_the_reference_and_the_colour_launches(monkeypatch):
         assert abs(g["contacts"] - r["contacts_per_sphere"] * nb) <= 0.03 * r["contacts_per_sphere"] * nb + 50
         if s >= 300:
             assert abs(g["mean_degree"] - r["mean_degree"]) <= 0.05 * r["mean_degree"], (g["mean_degree"], r["mean_degree"])
-    blk.close(); col.close()
+    blk.close(); col.close(); glo.close()
 
 
 def test_blocked_heap_of_boxes_and_spheres_full_rows_and_residual_contacts(monkeypatch):
