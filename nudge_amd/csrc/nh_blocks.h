@@ -57,7 +57,7 @@ __device__ __forceinline__ uint32_t blk_slot(const uint32_t* __restrict__ own_ba
 __global__ void k_blk_reset(nh_DevState* st) {
 	nh_BlkGrid& g = st->blk;
 	for (int k = 0; k < 3; ++k) { g.bmin[k] = 0xffffffffu; g.bmax[k] = 0u; }
-	g.bodies = 0; g.nblk = 0; g.overflow = 0; g.max_load = 0; g.ghost_cursor = 0; g.check_errors = 0; g.near_contacts = 0; g.far_contacts = 0; g.max_colours = 0; g.too_many_colours = 0;
+	g.bodies = 0; g.nblk = 0; g.overflow = 0; g.max_load = 0; g.ghost_cursor = 0; g.check_errors = 0; g.near_contacts = 0; g.far_contacts = 0; g.max_colours = 0; g.too_many_colours = 0; g.max_rounds = 0; g.max_listed = 0;
 	for (int k = 0; k < 8; ++k) g.phase_count[k] = 0;
 }
 
@@ -472,12 +472,13 @@ __global__ __launch_bounds__(NH_BLK_PREP_THREADS) void k_blk_prepare_local(nh_De
 			const unsigned long long bid = (unsigned long long)(c * 2654435761u) << 32 | c;
 			if ((!la || s_claim[la] == bid) && (!lb || s_claim[lb] == bid)) {
 				const unsigned long long used = (la ? s_mask[la] : 0ull) | (lb ? s_mask[lb] : 0ull);
-				const uint32_t q = (uint32_t)__ffsll((long long)~used) - 1u;
+				const uint32_t q = (uint32_t)__ffsll((long long)~used) - 1u;           // (the LOWEST free colour: a free colour picked by hash, to even the classes out, made 22 colours of 15 and four times the clashes among the seeds)
 				if (q >= LL) { s_fail = 1; s_col[kl] = 1; }                  // (more colours than the descriptor holds: smaller blocks do not help, the caller falls back)
 				else { s_col[kl] = (uint8_t)(q + 1u); if (la) s_mask[la] |= 1ull << q; if (lb) s_mask[lb] |= 1ull << q; }
 			} else left = true;
 		}
-		if (!__syncthreads_or(left ? 1 : 0)) break;
+		if (!__syncthreads_or(left ? 1 : 0)) { if (tid == 0) { atomicMax(&st->blk.max_rounds, round + 1u); atomicMax(&st->blk.max_listed, nlist); } break; }
+		if (round == 4095u && tid == 0) atomicMax(&st->blk.max_rounds, 4096u);
 	}
 	// counting sort by colour inside the segment; chunks of the sweep's pipeline
 	if (tid <= LL) s_cnt[tid] = 0;

@@ -2092,7 +2092,10 @@ static int blk_setup(nh_context* ctx, nh_ContactConstraintData* d, uint32_t G, b
 		NH_HIP_CHECK(ctx, hipMemcpyAsync(d->blk.res_off, k.bin_off + (size_t)NH_BLK_MAX_BLOCKS * L, sizeof(uint32_t) * (L + 1u), hipMemcpyDeviceToHost, ctx->stream));
 		NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 		if (!h->nblk) return NH_OK;
-		if (local && (h->far_contacts || h->too_many_colours)) return NH_OK;         // (a contact no block can own / a block of more than 32 colours: the world-wide colouring it is)
+		if (local && (h->far_contacts || h->too_many_colours)) {
+			if (k.prof) fprintf(stderr, "blk_profile setup: per-block colouring gave up (residual %u, too many colours %u, most rounds %u, most anew %u, overflow %u)\n", h->far_contacts, h->too_many_colours, h->max_rounds, h->max_listed, h->overflow);
+			return NH_OK;
+		}         // (a contact no block can own / a block of more than 32 colours: the world-wide colouring it is)
 		if (h->overflow) { k.scale *= 0.8f; continue; }
 		ok = true;
 		// the edge follows the largest load: room for the pile to shift, no retries
@@ -2101,7 +2104,7 @@ static int blk_setup(nh_context* ctx, nh_ContactConstraintData* d, uint32_t G, b
 	}
 	if (!ok) return NH_OK;
 	for (int p = 0; p < 8; ++p) d->blk.phase_count[p] = h->phase_count[p];
-	if (k.prof && (k.prof_calls % 64u) == 63u) fprintf(stderr, "blk_profile setup: %s colouring, most colours in a block %u, largest load %u of %u, near contacts %u, residual %u\n", local ? "per-block" : "world-wide", local ? h->max_colours : L, h->max_load, NH_BLK_CAP, h->near_contacts, h->far_contacts);
+	if (k.prof && (k.prof_calls % 64u) == 63u) fprintf(stderr, "blk_profile setup: %s colouring, most colours in a block %u (most rounds %u, most contacts coloured anew %u), largest load %u of %u, near contacts %u, residual %u\n", local ? "per-block" : "world-wide", local ? h->max_colours : L, h->max_rounds, h->max_listed, h->max_load, NH_BLK_CAP, h->near_contacts, h->far_contacts);
 	d->blk.L = local ? NH_BLK_LOCAL_L : L;
 	d->blk.local = local;
 	if (local) {
