@@ -698,6 +698,7 @@ __global__ __launch_bounds__(256) void k_reinsert(nh_DevState* __restrict__ st, 
 		const int y0 = min(max(cell_coord(amin.y, oy, inv) - 1, 0), ny - 1), y1 = min(max(cell_coord(amax.y, oy, inv), 0), ny - 1);
 		const int z0 = min(max(cell_coord(amin.z, oz, inv) - 1, 0), nz - 1), z1 = min(max(cell_coord(amax.z, oz, inv), 0), nz - 1);
 		const uint32_t wy = (uint32_t)(y1 - y0 + 1), nrows = min(wy * (uint32_t)(z1 - z0 + 1), 64u);        // (a small collider: at most 3 x 3 rows, 4 x 4 in the worst rounding)
+		if (wy * (uint32_t)(z1 - z0 + 1) > 64u && lane == 0u) st->error = NH_ERR_INVALID;                     // (k_xform lets only small colliders through: never -- but never silently)
 		uint32_t j0 = 0, len = 0;
 		if (lane < nrows) {
 			const uint32_t row = (uint32_t)(((z0 + (int)(lane / wy)) * ny + (y0 + (int)(lane % wy))) * nx);
