@@ -91,8 +91,9 @@ KERNEL_BYTES = {
     # spatially blocked solver (nh_blocks.h); "S" = one sweep over all general contacts: rows 48 + local pair 4 + state 16 r + 16 w per contact,
     # and the momentum of every general body once in, once out (64 B) -- main() turns that into bytes per contact for the scene at hand
     "blk_sweep": ("GI", 48 + 4 + 32), "blk_warm": ("G", 48 + 4 + 32),
-    "blk_bounds": ("B", 1 + 12), "blk_body": ("B", 1 + 12 + 8), "blk_contact": ("G", 4 + 8 + 4 + 2 * 8 + 8), "blk_scatter": ("G", 4 + 4 + 4 + 4),
-    "blk_prepare": ("G", 2 * (4 + 8 + 2 * 4) + 4), "blk_gather": ("B", 8 + 64), "blk_scatter_back": ("B", 8 + 64), "blk_residual_pairs": ("G", 0),
+    "blk_bounds": ("B", 1 + 12), "blk_body": ("B", 1 + 12 + 8), "blk_contact": ("G", 4 + 8 + 2 * 8 + 8), "blk_scatter": ("G", 4 + 4 + 4 + 4),
+    "blk_prepare": ("G", 2 * (4 + 8 + 2 * 8) + 2 * 4 + 16 + 4 + 3 * 4),      # k_blk_prepare_local: two passes over (order, pair, two block ranks), the index pair parked and fetched, the seed, order again; order, index pair and colour out
+    "reinsert": ("T", 0), "blk_gather": ("B", 8 + 64), "blk_scatter_back": ("B", 8 + 64), "blk_residual_pairs": ("G", 0),
     "colour_seed": ("G", 4 + 16 + 8), "colour_validate": ("G", 2 * 8), "blk_reset": ("T", 0), "blk_grid": ("T", 0), "zero_u32": ("T", 0),
 }
 
