@@ -150,6 +150,34 @@ def test_blocked_heap_of_boxes_and_spheres_full_rows_and_residual_contacts(monke
     a.close(); b.close(); c.close()
 
 
+def test_blocks_colour_their_own_boxes_full_rows_without_residual(monkeypatch):
+    """A pile of 2500 equal boxes in blocks several boxes wide: no contact is residual, so every block colours its own contacts (k_blk_prepare_local) -- and
+    the rows are the full 40-float ones (boxes), the kernel with both paths.  Structure check on every step; two runs agree bit for bit; the pile lands and
+    stays above the ground like the one solved by the per-colour launches."""
+    scene = S.pile(2500, 0, seed=12, iterations=8)
+    nb = 2500
+    env = dict(NH_BLK_MIN=1, NH_BLK_TARGET=300, NH_BLK_CHECK=1, NH_NO_RESIDENT=1)
+    a = _world(monkeypatch, scene, env, max_contacts=24 * nb, max_pairs=24 * nb)
+    b = _world(monkeypatch, scene, env, max_contacts=24 * nb, max_pairs=24 * nb)
+    c = _world(monkeypatch, scene, dict(NH_NO_BLOCKS=1, NH_NO_RESIDENT=1), max_contacts=24 * nb, max_pairs=24 * nb)
+    a.step(500); b.step(500); c.step(500)
+    ca, cc = a.counts(), c.counts()
+    assert ca["error"] == 0 and cc["error"] == 0
+    x, y, z = a.get_bodies(), b.get_bodies(), c.get_bodies()
+    assert _same(x, y), "two runs of the blocked solver differ: a data race"
+    px, pz = x["transforms"]["position"][1:], z["transforms"]["position"][1:]
+    assert np.isfinite(px).all() and np.isfinite(x["momentum"]["velocity"]).all()
+    kx = float((x["momentum"]["velocity"][1:].astype(np.float64) ** 2).sum(axis=1).mean())
+    kz = float((z["momentum"]["velocity"][1:].astype(np.float64) ** 2).sum(axis=1).mean())
+    print(f"\n[2500 boxes, 500 steps] blocked (own colours) / per-colour launches: contacts {ca['contacts']} / {cc['contacts']}, general {ca['general_contacts']} / {cc['general_contacts']}, "
+          f"mean |v|^2 {kx:.3e} / {kz:.3e}, lowest centre {px[:, 1].min():.3f} / {pz[:, 1].min():.3f}, mean height {px[:, 1].mean():.3f} / {pz[:, 1].mean():.3f}")
+    assert ca["general_contacts"] > 1000
+    assert px[:, 1].min() > -10.5 and pz[:, 1].min() > -10.5            # nothing fell through the ground (top of the slab: y = -10)
+    assert abs(float(px[:, 1].mean()) - float(pz[:, 1].mean())) < 0.05 * abs(float(pz[:, 1].mean())) + 0.5
+    assert abs(ca["contacts"] - cc["contacts"]) < 0.1 * cc["contacts"] + 200
+    a.close(); b.close(); c.close()
+
+
 def test_blocked_structure_check_on_a_million_spheres(monkeypatch):
     """The device-side structure check (NH_BLK_CHECK=1) at the scale the blocked solver is built for: a 100^3 pit -- a million spheres, ~1000 blocks of the
     default size, blocks that overflow while the pile collapses and are rebuilt smaller -- every step of the collapse and the first settling: every local
