@@ -158,7 +158,8 @@ typedef struct nh_ContactImpulseData nh_ContactImpulseData;         /* nudge.h:1
 typedef struct nh_ContactConstraintData nh_ContactConstraintData;   /* nudge.h:132, opaque */
 typedef struct nh_context nh_context;
 
-/* Device-side counters of the most recent step, mirrored to the host by nh_read_counts. */
+/* Device-side counters of the most recent step, mirrored to the host by nh_read_counts.  (Fields are only ever added at the END; a caller built against an
+   older header must be recompiled: nh_read_counts fills the whole struct.) */
 typedef struct nh_Counts {
 	uint32_t colliders;         /* C */
 	uint32_t pairs;             /* P: broadphase pairs surviving the same-body / sleeping filters */
