@@ -516,6 +516,77 @@ __global__ __launch_bounds__(NH_BLK_PREP_THREADS) void k_blk_prepare_local(nh_De
 	}
 }
 
+// block-order slot -> body (the inverse of blk_slot): what a kernel that works block by block needs to find its bodies' records
+__global__ __launch_bounds__(256) void k_blk_slots(uint32_t nbodies, const uint2* __restrict__ brank, const uint32_t* __restrict__ own_base, uint32_t* __restrict__ pos_body) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) {
+		if (i == 0u) { pos_body[0] = 0u; continue; }
+		const uint32_t br = brank[i].x;
+		if (br != NH_NONE) pos_body[blk_slot(own_base, br)] = i;
+	}
+}
+
+// Rows of the contacts the blocks own, BLOCK BY BLOCK (per-block colouring only: every general contact is then owned).  k_rows_general walks the block-ordered
+// contact list with one thread per contact and gathers, per contact, the two bodies' positions and inertias from the caller's arrays: in a pit of 11 M
+// contacts it fetched 2.5 GB (PMC, raw) for 0.9 GB of distinct data.  Here one workgroup per block stages the block's bodies ONCE in LDS (position, inverse
+// mass | inverse inertia, body index: the same 32 bytes per body the sweep keeps of the momentum) and its contacts read them from there; what is left in
+// global memory per contact is its 32-byte record, its cached impulse and its place.  Same functions, same operands: the rows are the very bits
+// k_rows_general writes (NH_BLK_ROWS_GLOBAL=1 keeps that kernel: the A/B of the tests).
+struct nh_BlkPhases { uint32_t start[9]; };          // workgroups of the eight block colours, as ranges of one launch
+__global__ __launch_bounds__(NH_BLK_THREADS) void k_blk_rows(const nh_DevState* __restrict__ st, nh_BlkPhases ph, const uint32_t* __restrict__ desc_all, const uint32_t* __restrict__ ghost_list,
+                                                             const uint32_t* __restrict__ pos_body, const uint32_t* __restrict__ order, const nh_Contact* __restrict__ contacts,
+                                                             const nh_Transform* __restrict__ xf, const nh_BodyProperties* __restrict__ props, float4* __restrict__ rows4, size_t stride,
+                                                             uint2* __restrict__ gpair, uint32_t* __restrict__ level_has_full, const nh_CachedContactImpulse* __restrict__ warm_in,
+                                                             float* __restrict__ pstates, uint32_t* __restrict__ lpair) {
+	__shared__ float4 s_p[NH_BLK_CAP], s_i[NH_BLK_CAP];          // (position, inverse mass), (inverse inertia, body index)
+	__shared__ uint32_t s_desc[NH_BLK_DESC_WORDS];
+	const uint32_t tid = threadIdx.x;
+	uint32_t p = 0;
+	while (p < 7u && blockIdx.x >= ph.start[p + 1u]) ++p;
+	const uint32_t* dsc = desc_all + ((size_t)p * NH_BLK_MAX_BLOCKS + (blockIdx.x - ph.start[p])) * NH_BLK_DESC_WORDS;
+	if (tid < NH_BLK_DESC_WORDS) s_desc[tid] = dsc[tid];
+	__syncthreads();
+	const uint32_t n_own = s_desc[1], base = s_desc[2], n_gh = s_desc[3], gb = s_desc[4], nloc = 1u + n_own + n_gh;
+	const uint32_t k0 = s_desc[5], k1 = s_desc[5u + NH_BLK_LOCAL_L];
+	const bool static_inert = st->static_inert != 0u;
+	for (uint32_t j = tid; j < nloc; j += NH_BLK_THREADS) {
+		uint32_t body = 0;
+		if (j) body = pos_body[j <= n_own ? base + (j - 1u) : ghost_list[gb + (j - 1u - n_own)]];
+		const float4 t0 = reinterpret_cast<const float4*>(xf + body)[0];
+		const float4 pr = *reinterpret_cast<const float4*>(props + body);
+		s_p[j] = make_float4(t0.x, t0.y, t0.z, pr.w);
+		s_i[j] = make_float4(pr.x, pr.y, pr.z, __uint_as_float(body));
+	}
+	__syncthreads();
+	for (uint32_t k = k0 + tid; k < k1; k += NH_BLK_THREADS) {
+		const uint32_t c = order[k];
+		const nh_Contact ct = contacts[c];
+		const uint32_t lp = lpair[k], la = lp & 0xFFFu, lb = (lp >> 16) & 0xFFFu;
+		const float4 a_p = s_p[la], a_i = s_i[la], b_p = s_p[lb], b_i = s_i[lb];
+		const uint32_t body_a = __float_as_uint(a_i.w), body_b = __float_as_uint(b_i.w);
+		nh_contact_in ci = { ct.position[0], ct.position[1], ct.position[2], ct.penetration, ct.normal[0], ct.normal[1], ct.normal[2], ct.friction };
+		const nh_f3 apos = nh_make3(a_p.x, a_p.y, a_p.z), bpos = nh_make3(b_p.x, b_p.y, b_p.z);
+		const bool ia = static_inert && body_a == 0u, ib = static_inert && body_b == 0u;
+		const bool radial = nh_side_is_radial(ci.px - apos.x, ci.py - apos.y, ci.pz - apos.z, ci.nx, ci.ny, ci.nz, a_i.x, a_i.y, a_i.z, ia) &&
+		                    nh_side_is_radial(ci.px - bpos.x, ci.py - bpos.y, ci.pz - bpos.z, ci.nx, ci.ny, ci.nz, b_i.x, b_i.y, b_i.z, ib);
+		if (radial) {
+			nh_rowr r;
+			nh_build_rowr(ci, apos, bpos, a_i.x, b_i.x, a_p.w, b_p.w, ia, ib, r);
+			store_rowr_soa(rows4, stride, k, r);
+		} else {
+			nh_inertia IA = body_inertia(xf, props, body_a), IB = body_inertia(xf, props, body_b);          // (boxes: the rotation too -- from the caller's arrays)
+			nh_row r;
+			nh_build_row(ci, apos, bpos, IA, IB, a_p.w, b_p.w, r);
+			store_row_soa(rows4, stride, k, r);
+			level_has_full[1] = 1u;
+		}
+		gpair[k] = make_uint2(body_a | (radial ? NH_RADIAL_BIT : 0u), body_b);
+		const float4 w = *reinterpret_cast<const float4*>(warm_in + c);
+		float* ps = pstates + 3 * (size_t)k;
+		ps[0] = w.x; ps[1] = w.y; ps[2] = w.z;
+		if (radial) lpair[k] = lp | NH_BLK_RADIAL;
+	}
+}
+
 // residual contacts are solved by the global per-colour launches on the block-ordered momentum copy: their pairs become block-order slots
 __global__ __launch_bounds__(256) void k_blk_residual_pairs(uint32_t begin, uint32_t end, const uint2* __restrict__ brank, const uint32_t* __restrict__ own_base, uint2* __restrict__ gpair) {
 	for (uint32_t k = begin + blockIdx.x * blockDim.x + threadIdx.x; k < end; k += gridDim.x * blockDim.x) {

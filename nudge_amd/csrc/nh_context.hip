@@ -47,6 +47,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->fat_pairs = nullptr; ctx->fat_pair_capacity = 0; ctx->fat_box = nullptr; ctx->fat_collider_capacity = 0; ctx->fat_nbox = ctx->fat_nsph = 0xffffffffu;
 	ctx->grid_sbox = nullptr; ctx->grid_skeys = nullptr; ctx->grid_cstart = nullptr; ctx->grid_counts = nullptr; ctx->grid_large = nullptr; ctx->grid_cells = 0; ctx->grid_collider_capacity = 0;
 	ctx->fat_gen = nullptr; ctx->fat_esc_mark = nullptr; ctx->fat_esc_list = nullptr; ctx->fat_moved_list = nullptr;
+	ctx->env_blk_rows_global = getenv("NH_BLK_ROWS_GLOBAL") != nullptr;
 	ctx->env_blk_global_colours = getenv("NH_BLK_GLOBAL_COLOURS") != nullptr; ctx->last_general_contacts = 0;
 	ctx->env_no_incremental = getenv("NH_NO_INCREMENTAL") != nullptr;     // NH_NO_INCREMENTAL=1: a collider that leaves its inflated box forces a rebuild of the kept pair list (A/B, tests)
 	ctx->env_colour_check_seeds = getenv("NH_COLOUR_CHECK_SEEDS") != nullptr;      // colours seeded from the cache go through a settle round instead of being final at once (A/B, tests)

@@ -183,6 +183,7 @@ struct nh_context {
 	float4* grid_sbox; uint32_t* grid_skeys; uint32_t* grid_cstart; uint32_t* grid_counts; uint32_t* grid_large; uint32_t grid_cells, grid_collider_capacity;
 	uint8_t* fat_gen; uint32_t* fat_esc_mark; uint32_t* fat_esc_list; uint32_t* fat_moved_list;
 	bool env_no_incremental;
+	bool env_blk_rows_global;             // NH_BLK_ROWS_GLOBAL=1: the rows of block-owned contacts by k_rows_general (one thread per contact) instead of k_blk_rows (A/B, tests)
 	bool env_blk_global_colours;          // NH_BLK_GLOBAL_COLOURS=1: the blocked solver takes the world-wide colouring (A/B, tests)
 	uint32_t last_general_contacts;       // general contacts of the last setup: does this step's adjacency build leave the general bodies to the per-block colouring?
 	uint32_t fat_nbox, fat_nsph;          // collider counts of the last nh_collide (a change invalidates the list)

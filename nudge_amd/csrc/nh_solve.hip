@@ -2037,10 +2037,8 @@ static int blk_reserve(nh_context* ctx, uint32_t B, uint32_t kcap) {
 		k.brank = nullptr; k.bm = nullptr; k.pos_body = nullptr; k.touch = nullptr; k.body_capacity = 0;
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.brank, sizeof(uint2) * (size_t)(B + 1u)));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.bm, sizeof(float4) * 2u * (size_t)(B + 1u)));
-		if (k.check) {
-			NH_HIP_CHECK(ctx, hipMalloc((void**)&k.pos_body, sizeof(uint32_t) * (size_t)(B + 1u)));
-			NH_HIP_CHECK(ctx, hipMalloc((void**)&k.touch, sizeof(uint32_t) * 2u * (size_t)(B + 1u)));
-		}
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.pos_body, sizeof(uint32_t) * (size_t)(B + 1u)));
+		if (k.check) NH_HIP_CHECK(ctx, hipMalloc((void**)&k.touch, sizeof(uint32_t) * 2u * (size_t)(B + 1u)));
 		k.body_capacity = B + 1u;
 	}
 	if (k.contact_capacity < kcap) {
@@ -2115,6 +2113,16 @@ static int blk_setup(nh_context* ctx, nh_ContactConstraintData* d, uint32_t G, b
 	// rows (and the cached impulses, in the solver states' place) in block order; which colours hold a full row
 	uint32_t* level_hist = d->cont.level_hist;
 	NH_LAUNCH(ctx, "zero_u32", k_zero_u32, 8, 256, level_hist, 2 * (NH_MAX_LEVELS + 2));
+	if (local && !ctx->env_blk_rows_global) {
+		// one workgroup per block, the block's bodies staged in LDS (k_blk_rows): every general contact is owned by a block here
+		nh_BlkPhases ph;
+		ph.start[0] = 0;
+		for (int p = 0; p < 8; ++p) ph.start[p + 1] = ph.start[p] + d->blk.phase_count[p];
+		NH_LAUNCH(ctx, "blk_slots", k_blk_slots, nh_grid_for(B, 256, 4096), 256, B, k.brank, k.own_base, k.pos_body);
+		if (ph.start[8])
+			NH_LAUNCH(ctx, "rows_general", k_blk_rows, ph.start[8], NH_BLK_THREADS, st, ph, k.desc, k.ghost_list, k.pos_body, d->level_order, contacts->data, bodies->transforms, bodies->properties,
+			          (float4*)d->rows, (size_t)kcap, d->gpair, level_hist + (NH_MAX_LEVELS + 2), (const nh_CachedContactImpulse*)d->imp->data, reinterpret_cast<float*>(d->gstates), k.lpair);
+	} else
 	NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, d->level_order, contacts->data, contacts->bodies, bodies->transforms, bodies->properties,
 	          (float4*)d->rows, (size_t)kcap, d->gpair, 1u, 1u, local ? (const uint32_t*)nullptr : (const uint32_t*)d->cont.level, level_hist + (NH_MAX_LEVELS + 2), (const nh_CachedContactImpulse*)d->imp->data, d->gstates, k.lpair, d->blk.res_off[0]);
 	if (d->blk.res_off[L] > d->blk.res_off[0])

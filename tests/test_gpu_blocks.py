@@ -32,7 +32,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _world(monkeypatch, scene, env, flags=E.NH_FLAG_SINGLE_APPLY, **kw):
-    keys = ("NH_BLK_MIN", "NH_BLK_TARGET", "NH_BLK_CHECK", "NH_NO_BLOCKS", "NH_NO_RESIDENT", "NH_BLK_GLOBAL_COLOURS")
+    keys = ("NH_BLK_MIN", "NH_BLK_TARGET", "NH_BLK_CHECK", "NH_NO_BLOCKS", "NH_NO_RESIDENT", "NH_BLK_GLOBAL_COLOURS", "NH_BLK_ROWS_GLOBAL")
     for k in keys:
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
@@ -148,6 +148,28 @@ def test_blocked_heap_of_boxes_and_spheres_full_rows_and_residual_contacts(monke
     assert abs(landed_x - landed_z) < 0.05
     assert abs(ca["contacts"] - cc["contacts"]) < 0.1 * cc["contacts"] + 100
     a.close(); b.close(); c.close()
+
+
+@pytest.mark.parametrize("scene_name", ["pit", "boxes"])
+def test_rows_built_block_by_block_are_the_bits_of_the_per_contact_kernel(monkeypatch, scene_name):
+    """k_blk_rows (one workgroup per block, the block's bodies staged in LDS) against k_rows_general (one thread per contact, gathers from the caller's
+    arrays; NH_BLK_ROWS_GLOBAL=1): same functions on the same operands, so the worlds must agree bit for bit -- spheres (radial rows) and boxes (full rows)."""
+    if scene_name == "pit":
+        scene, nb, cap = S.ball_pit(20, 20, 20, seed=9), 8000, 8
+        env = dict(NH_BLK_MIN=1, NH_BLK_TARGET=120)
+    else:
+        scene, nb, cap = S.pile(2500, 0, seed=12, iterations=8), 2500, 24
+        env = dict(NH_BLK_MIN=1, NH_BLK_TARGET=300, NH_NO_RESIDENT=1)
+    a = _world(monkeypatch, scene, env, max_contacts=cap * nb, max_pairs=cap * nb)
+    b = _world(monkeypatch, scene, dict(env, NH_BLK_ROWS_GLOBAL=1), max_contacts=cap * nb, max_pairs=cap * nb)
+    for upto in (120, 300):
+        a.step(upto - a.steps_done); b.step(upto - b.steps_done)
+        assert a.counts()["error"] == 0 and b.counts()["error"] == 0
+        assert _same(a.get_bodies(), b.get_bodies()), (scene_name, upto)
+    ka, kb = a.get_cache(), b.get_cache()
+    assert ka["count"] == kb["count"] and np.array_equal(ka["tags"], kb["tags"]) and P.bits_equal(ka["data"]["impulse"], kb["data"]["impulse"])
+    assert a.counts()["general_contacts"] > 500
+    a.close(); b.close()
 
 
 def test_blocks_colour_their_own_boxes_full_rows_without_residual(monkeypatch):
