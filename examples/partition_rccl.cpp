@@ -95,6 +95,16 @@ int main(int argc, char** argv) {
 		}
 		NCCL_OK(ncclCommInitRank(&comm, world, id, rank));
 	}
+	// NUDGE_RCCL_LOOPBACK=1 with WORLD_SIZE=1: a one-rank communicator, and every step the halo records of the first owned bodies travel
+	// nh_halo_pack -> ncclSend(self) / ncclRecv(self) in one group -> nh_halo_update onto the SAME bodies (a no-op for the simulation: the
+	// checksum must equal the run without it).  What a one-GPU box can execute of the communication path: RCCL point-to-point on the
+	// library's stream between the two halo kernels.
+	const bool loopback = world == 1 && getenv("NUDGE_RCCL_LOOPBACK") && atoi(getenv("NUDGE_RCCL_LOOPBACK")) != 0;
+	if (loopback) {
+		ncclUniqueId id;
+		NCCL_OK(ncclGetUniqueId(&id));
+		NCCL_OK(ncclCommInitRank(&comm, 1, id, 0));
+	}
 
 	// ---- the world: cols x rows tiles of side x side boxes on a 3.0 pitch, one ground slab per tile; x-slabs cut THROUGH tiles ----
 	const float pitch = 3.0f, half = side * 1.5f + 2.0f, tile_pitch = 2.0f * half + 4.0f;
@@ -145,6 +155,8 @@ int main(int argc, char** argv) {
 			else if (x >= hi && x < hi + margin) ghost_right.push_back(b);
 		}
 	}
+	const uint32_t n_loop = loopback ? (uint32_t)(owned.size() < 4096 ? owned.size() : 4096) : 0u;
+	if (loopback) for (uint32_t i = 0; i < n_loop; ++i) send_right.push_back(1u + i);           // (consecutive slots: nh_halo_update writes a range)
 	const uint32_t n_owned = (uint32_t)owned.size(), n_gl = (uint32_t)ghost_left.size(), n_gr = (uint32_t)ghost_right.size();
 	const uint32_t nb = 1 + n_owned + n_gl + n_gr, n_static = (uint32_t)slab_xf.size(), nbox = n_static + nb - 1;
 
@@ -189,7 +201,7 @@ int main(int argc, char** argv) {
 	uint32_t* d_send_left = to_device(send_left, 1); uint32_t* d_send_right = to_device(send_right, 1);
 	void *out_left = nullptr, *out_right = nullptr, *in_left = nullptr, *in_right = nullptr;
 	HIP_OK(hipMalloc(&out_left, (size_t)NH_HALO_RECORD_BYTES * (send_left.size() + 1))); HIP_OK(hipMalloc(&out_right, (size_t)NH_HALO_RECORD_BYTES * (send_right.size() + 1)));
-	HIP_OK(hipMalloc(&in_left, (size_t)NH_HALO_RECORD_BYTES * (n_gl + 1))); HIP_OK(hipMalloc(&in_right, (size_t)NH_HALO_RECORD_BYTES * (n_gr + 1)));
+	HIP_OK(hipMalloc(&in_left, (size_t)NH_HALO_RECORD_BYTES * (n_gl + 1))); HIP_OK(hipMalloc(&in_right, (size_t)NH_HALO_RECORD_BYTES * (n_gr + n_loop + 1)));
 	if (world > 1) {
 		// both sides must agree on the list lengths: what I call my right ghosts is what my right neighbour calls its left sends
 		uint64_t mine[2] = { (uint64_t)send_left.size(), (uint64_t)send_right.size() }, theirs[2] = { 0, 0 };
@@ -225,6 +237,14 @@ int main(int argc, char** argv) {
 			NH_OK_(nh_halo_update(ctx, &bodies, 1 + n_owned, n_gl, in_left));
 			NH_OK_(nh_halo_update(ctx, &bodies, 1 + n_owned + n_gl, n_gr, in_right));
 		}
+		if (loopback && n_loop) {
+			NH_OK_(nh_halo_pack(ctx, &bodies, d_send_right, n_loop, out_right));
+			NCCL_OK(ncclGroupStart());
+			NCCL_OK(ncclSend(out_right, (size_t)n_loop * NH_HALO_RECORD_BYTES, ncclUint8, 0, comm, stream));
+			NCCL_OK(ncclRecv(in_right, (size_t)n_loop * NH_HALO_RECORD_BYTES, ncclUint8, 0, comm, stream));
+			NCCL_OK(ncclGroupEnd());
+			NH_OK_(nh_halo_update(ctx, &bodies, 1, n_loop, in_right));
+		}
 		// ---- the reference's sub-step on the local world (example/main.cpp:274-328) ----
 		nh_Arena temporary = arena;
 		NH_OK_(nh_collide(ctx, &active, &contacts, &bodies, &colliders, &connections, temporary));
@@ -255,6 +275,7 @@ int main(int argc, char** argv) {
 	}
 	printf("partition_rccl rank %d/%d: %u owned + %u ghost bodies, %u steps, last step %llu contacts (%.3f per owned+ghost body), %.1f steps/s, checksum %.6f\n",
 	       rank, world, n_owned, n_gl + n_gr, steps, (unsigned long long)sum_contacts, (double)sum_contacts / (nb - 1), steps / seconds, checksum);
+	if (loopback) printf("partition_rccl loopback: %u halo records per step through ncclSend/ncclRecv(self), %u steps\n", n_loop, steps);
 	nh_destroy(ctx);
 	if (comm) NCCL_OK(ncclCommDestroy(comm));
 	return 0;

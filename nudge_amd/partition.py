@@ -537,14 +537,39 @@ class DistCluster:
     """One partition per process; neighbour messages over torch.distributed point-to-point ops
     (backend "nccl" = RCCL over xGMI for GPU tensors, "gloo" for the CPU tests)."""
 
-    def __init__(self, partition, group=None, host_staging=False):
-        """`host_staging`: move messages through host memory (for backends without device p2p, e.g. gloo with GPU worlds)."""
+    def __init__(self, partition, group=None, host_staging=False, loopback=0):
+        """`host_staging`: move messages through host memory (for backends without device p2p, e.g. gloo with GPU worlds).
+        `loopback` = m > 0: every step this rank also sends the per-step records of its first m owned bodies to ITSELF through the same
+        point-to-point ops and writes them back onto those bodies (a no-op for the simulation) -- what a ONE-GPU box can execute of the RCCL path."""
         import torch.distributed as dist
         self.dist = dist
         self.p = partition
         self.group = group
         self.torch = partition.torch
         self.host_staging = host_staging
+        self.loopback = int(loopback)
+        self.loopback_records = 0
+
+    def _loopback(self):
+        t, dist, p = self.torch, self.dist, self.p
+        m = min(self.loopback, p.n_owned)
+        if m <= 0:
+            return
+        home = p.bt.device
+        idx = t.arange(1, 1 + m, dtype=t.int32, device=home)
+        rec = p._step_records(idx.to(t.int64), idx)
+        dev = t.device("cpu") if self.host_staging else home
+        out = rec.to(dev).contiguous()
+        back = t.empty_like(out)
+        me = dist.get_rank(self.group)
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, out, me, self.group), dist.P2POp(dist.irecv, back, me, self.group)]):
+            w.wait()
+        back = back.to(home)
+        if hasattr(p.e, "halo_unpack"):
+            p.e.halo_unpack(1, back.contiguous(), same_bodies=True)
+        else:
+            p.bt[1:1 + m, :12] = back[:, :12]; p.bt[1:1 + m, 16:] = back[:, 12:28]; p.bm[1:1 + m] = back[:, 28:60]; p.bi[1:1 + m, 0] = back[:, 60]
+        self.loopback_records += m
 
     def _exchange(self, out, widths=None, known_counts=None):
         """Sends out[d] to rank+d and returns what the neighbours sent.  Counts are exchanged first unless known."""
@@ -590,6 +615,8 @@ class DistCluster:
                 p.refresh_unpack_ghosts(self._exchange(p.refresh_pack_ghosts(), FULL_BYTES))
             else:
                 p.step_unpack(self._exchange(p.step_pack(), STEP_BYTES, known_counts={d: p.ghost_in[d] for d in p.neighbours()}))
+            if self.loopback:
+                self._loopback()
             if p.per_iteration:
                 p.step_begin()
                 for _it in range(p.iterations()):

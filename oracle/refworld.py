@@ -190,6 +190,23 @@ class RefWorld:
         return dict(count=n, tags=_view_array(v.cache_tags, np.uint64, n).copy(),
                     data=_view_array(v.cache_data, self.S.IMPULSE, n).copy())
 
+    def snapshot(self):
+        """Everything that persists from one step to the next (bodies + contact cache), copied to the host side of the caller."""
+        v = self._view()
+        n = v.cache_count
+        return dict(bodies=self.bodies(), cache_count=n, cache_tags=_view_array(v.cache_tags, np.uint64, n).copy(),
+                    cache_data=_view_array(v.cache_data, self.S.IMPULSE, n).copy())
+
+    def restore(self, snap):
+        b = snap["bodies"]
+        self.set_bodies(b["transforms"], b["momentum"], b["idle"])
+        v = self._view()
+        n = snap["cache_count"]
+        if n:
+            _view_array(v.cache_tags, np.uint64, n)[:] = snap["cache_tags"]
+            _view_array(v.cache_data, self.S.IMPULSE, n)[:] = snap["cache_data"]
+        self.L.ref_world_set_cache_count(self.h, n)
+
     def solver_order(self):
         """constraint_to_contact (batches x 8 contact indices) of the last setup (nudge.cpp:4203, 4354)."""
         nb = self.L.ref_constraint_batches(self.h)

@@ -276,7 +276,7 @@ def test_c4_column_of_160_layers_default_order_vs_reference():
     checkpoints = (150, 300, 450, 600, 800)
     ref = _reference_pit(7, 160, 7, 14, checkpoints)
     scene = S.ball_pit(7, 160, 7, seed=14)
-    w = E.World(scene, flags=E.NH_FLAG_SINGLE_APPLY, max_contacts=8 * 7840, max_pairs=10 * 7840)
+    w = E.World(scene, flags=BENCH_FLAGS, max_contacts=8 * 7840, max_pairs=10 * 7840)            # bench.py's flags (--scene pit)
     done = 0
     for s in checkpoints:
         w.step(s - done); done = s
@@ -305,7 +305,7 @@ def test_c4_four_million_sphere_pit_invariants_default_order():
     scene = S.ball_pit(160, 160, 160, seed=4)
     nb = len(scene["body_transforms"]) - 1
     assert nb == 4096000
-    w = E.World(scene, flags=E.NH_FLAG_SINGLE_APPLY, max_contacts=5 * nb, max_pairs=7 * nb)
+    w = E.World(scene, flags=BENCH_FLAGS, max_contacts=5 * nb, max_pairs=7 * nb)                 # exactly bench.py --scene pit: SINGLE_APPLY | FUSED_STEP
     done, kes, g = 0, [], None
     for s in checkpoints:
         w.step(s - done); done = s

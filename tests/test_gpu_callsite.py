@@ -167,3 +167,22 @@ def test_cpp_rccl_host_runs_a_slab_on_one_gpu():
     r = subprocess.run([CU.PARTITION_RCCL, "3", "2", "24", "90"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "3456 owned + 0 ghost bodies" in r.stdout and "(4.000 per owned+ghost body)" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_rccl_host_loopback_executes_rccl_between_the_halo_kernels():
+    """RCCL on the one GPU there is: WORLD_SIZE = 1 and NUDGE_RCCL_LOOPBACK = 1 make examples/partition_rccl.cpp create a one-rank communicator and send the
+    per-step halo records of 2304 bodies to ITSELF -- nh_halo_pack -> ncclGroupStart; ncclSend(self); ncclRecv(self); ncclGroupEnd -> nh_halo_update, all on
+    the library's stream, every step.  The records update the bodies they were packed from, so the world must come out exactly as without the exchange
+    (same checksum, four contacts per box): the communication path of the multi-GPU host has then really executed, kernels, RCCL and stream ordering."""
+    assert os.path.exists(CU.PARTITION_RCCL), "nudge_amd/partition_rccl missing: make -C nudge_amd/csrc"
+    base = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    outs = []
+    for loop in ("0", "1"):
+        r = subprocess.run([CU.PARTITION_RCCL, "2", "2", "24", "90"], capture_output=True, text=True, timeout=600, env=dict(base, NUDGE_RCCL_LOOPBACK=loop))
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "2304 owned + 0 ghost bodies" in r.stdout and "(4.000 per owned+ghost body)" in r.stdout, r.stdout
+        outs.append(r.stdout)
+    assert "loopback: 2304 halo records per step through ncclSend/ncclRecv(self), 90 steps" in outs[1], outs[1]
+    checksum = [o.split("checksum")[1].split()[0] for o in outs]
+    assert checksum[0] == checksum[1], checksum

@@ -149,3 +149,27 @@ def test_per_iteration_ghost_exchange_on_the_gpu():
         for q in parts:
             assert q.e.counts()["error"] == 0
             q.e.close()
+
+
+def test_bench_under_torchrun_with_one_rank_executes_rccl_point_to_point():
+    """`bench.py --gpus N` meets RCCL for the first time under the driver's 8-GPU run unless something executes that path earlier.  A one-GPU box can run
+    everything but the second rank: `python -m torch.distributed.run --nproc-per-node 1 bench.py --gpus 1` with NUDGE_BENCH_LOOPBACK=1 creates the
+    `nccl` (= RCCL) process group with its device id, sends the world through the partitioned code path (split_scene, Partition, DistCluster: one slab),
+    and every step moves 4096 per-step halo records pack -> batch_isend_irecv(isend to self, irecv from self) on DEVICE tensors -> nh_halo_update; the
+    barriers and the MAX / SUM all-reduces of the timing protocol run on the GPU as well.  The line must come out and carry contacts."""
+    import json
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, NUDGE_BENCH_LOOPBACK="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "2", "--tiles", "8", "--side", "45", "--no-cpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["contacts_per_step"] > 0.9 * 4 * 8 * 45 * 45, out
+    assert out["halo"]["backend"] == "nccl" and out["halo"]["loopback_records_per_step"] == 4096, out["halo"]

@@ -313,3 +313,4 @@ def test_gloo_three_ranks_rebalance(tmp_path):
     ref = PU.single_world_reference(scene, 80)
     assert np.array_equal(got["ids"], np.arange(1, len(scene["body_transforms"])))
     assert P.bits_equal(got["transforms"]["position"], ref["transforms"]["position"][1:])
+
