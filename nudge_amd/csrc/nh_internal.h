@@ -70,7 +70,13 @@ struct nh_DevState {
 	uint32_t fat_rebuilds;                // broadphase rebuilds since nh_create (the steps in between re-used the kept pair list: below)
 	uint32_t sort_reuses;                 // steps since nh_create whose record sort was skipped because last step's tag order still held
 	uint32_t fat_inserts;                 // colliders re-inserted into the kept pair list since nh_create (they left their inflated box; no rebuild)
-	// ---- (the 28 words above are what nh_read_counts mirrors to the host: NH_COUNTER_WORDS) ----
+	// "still" steps (nh_collide.hip, "9. still steps"): a step the host launched speculatively as a world whose contact layout is last step's
+	uint32_t still_fail[2];               // by step parity: this still step met something that is NOT as it was (a collider left its box, a record's key / contact count /
+	                                      // features changed, a body is asleep, body 0 not inert): every kernel after that leaves, the host replays the step in full
+	uint32_t lay_valid;                   // the kept layout (per record: first contact | count, feature words; per body: class + contact list record) describes the contact
+	                                      // list the last FULL step laid out, and that step met the conditions a still step relies on (k_gather_contacts)
+	uint32_t still_steps;                 // still steps that went through, since nh_create (statistics)
+	// ---- (the 32 words above are what nh_read_counts mirrors to the host: NH_COUNTER_WORDS) ----
 	// Temporal coherence of the broadphase (nh_collide.hip, "kept pair list"): the grid search runs over AABBs inflated by `fat_margin` and its
 	// pairs are KEPT; while every collider's AABB stays inside its inflated box the kept list is a superset of the overlapping pairs and one filter
 	// pass (exact AABBs, exact test) replaces the whole regrouping + search.
@@ -111,6 +117,9 @@ struct nh_DevState {
 	uint32_t colour_cursor;       // append cursor of the colouring's list compaction (nh_solve.hip)
 	uint32_t stale_hint;          // a body was asleep in a step for which the host had ruled that out (k_collide_begin -> k_active_write -> NH_ERR_STALE_HINT)
 	uint32_t order_conflict;      // exact-order mode: sequence number of the setup call whose closed-form schedule has a lane conflict (nh_solve.hip)
+	uint32_t lay_in_place;        // this (full) step's k_kept_filter wrote the pairs IN PLACE: a record's position is its kept pair's position
+	uint32_t still_smin[2][3], still_smax[2][3];   // by step parity: scene bounds of a still step (k_xform<true>; cleared for the next step by the step before)
+	uint32_t still_top[2];        // by step parity: largest idle counter a still step saw
 	nh_BlkGrid blk;               // spatially blocked solver (nh_blocks.h)
 };
 
@@ -234,7 +243,7 @@ struct nh_context {
 // Runs work that an earlier call deferred; every entry point that reads or writes momentum / impulses calls it first.
 int nh_flush_pending(nh_context* ctx, bool keep_gravity = false);
 void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out);
-#define NH_COUNTER_WORDS 28u          // leading words of nh_DevState that the host mirrors (nh_read_counts)
+#define NH_COUNTER_WORDS 32u          // leading words of nh_DevState that the host mirrors (nh_read_counts)
 
 struct nh_ContactImpulseData {
 	nh_CachedContactImpulse* data;        // K, contact (tag) order; holds the warm-start impulses once `lookup_pending` is false

@@ -83,10 +83,8 @@ def test_c5_sixteen_million_boxes_in_eight_partitions_vs_single_world_and_refere
     ghosts = sum(p.stats["ghosts"] for p in parts)
     assert ghosts > 0 and all(p.stats["refreshes"] >= 2 for p in parts)
 
-    # landed and at rest: 320 steps, 20 refreshes
-    steps = 320
-    cl.step(steps - 32); single.step(steps - 32)
-    got, ref = cl.gather(), single.get_bodies()
+    # landed, at rest and still awake (boxes land around steps 40-60 and fall asleep 255 quiet steps later): every box on its four contacts
+    cl.step(288 - 32); single.step(288 - 32)
     contacts = 0
     for q in parts:
         c = q.e.counts()
@@ -95,7 +93,17 @@ def test_c5_sixteen_million_boxes_in_eight_partitions_vs_single_world_and_refere
     cs = single.counts()
     assert cs["error"] == 0
     assert cs["contacts"] >= 0.95 * 4 * n and contacts >= cs["contacts"]            # (contacts of ghosts are counted on both sides)
+    # ... and asleep: 352 steps, 22 refreshes; islands, sleeping pairs and cache culling have run on every partition
+    steps = 352
+    cl.step(steps - 288); single.step(steps - 288)
+    got, ref = cl.gather(), single.get_bodies()
+    for q in parts:
+        assert q.e.counts()["error"] == 0
+    assert single.counts()["error"] == 0
     assert sum(p.n_owned for p in parts) == n
+    asleep_one = ref["idle"][1:] == 0xff
+    assert asleep_one.mean() > 0.9, "the world was meant to have gone to sleep"
+    assert float(((got["idle"] == 0xff) != asleep_one).mean()) < 0.02
     p_part, p_one = got["transforms"]["position"], ref["transforms"]["position"][1:]
     assert np.isfinite(p_part).all() and np.isfinite(p_one).all()
     e_single = P.rel_err(p_part, p_one)
@@ -126,7 +134,8 @@ def test_c5_sixteen_million_boxes_in_eight_partitions_vs_single_world_and_refere
         worst_p = max(worst_p, float(P.rel_err(p_part[ids], rb["transforms"]["position"][1:]).max()))
         worst_p1 = max(worst_p1, float(P.rel_err(p_one[ids], rb["transforms"]["position"][1:]).max()))
         worst_v = max(worst_v, float(np.abs(got["momentum"]["velocity"][ids] - rb["momentum"]["velocity"][1:]).max()))
-        assert np.array_equal(got["idle"][ids] == 0xff, rb["idle"][1:] == 0xff), f"tile {t}: different bodies asleep"
+        # (a body may fall asleep a step early or late: islands at the edge)
+        assert float(((got["idle"][ids] == 0xff) != (rb["idle"][1:] == 0xff)).mean()) < 0.02, f"tile {t}: different bodies asleep"
     errs = np.concatenate(errs)
     q9999, tile_max = float(np.quantile(errs, 0.9999)), float(errs.max())
     print(f"[c5 at size] partitions vs the tiled reference on {len(sample)} tiles ({len(cut_tiles)} cut by a slab boundary): relative to |p| max {worst_p:.3e} "
