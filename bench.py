@@ -209,7 +209,9 @@ def cpu_baseline(scene, land_steps, tiles_total, budget_s=20.0):
     usable = facts.get("affinity") or os.cpu_count() or 1
     if facts.get("cgroup_quota_cores"):
         usable = max(1, min(usable, int(math.ceil(facts["cgroup_quota_cores"]))))
-    ntiles = max(1, min(usable, tiles_total))
+    # (one point BEYOND the quota, when the affinity mask allows it: the curve must go flat there -- that is what tells a CPU quota from a slow reference)
+    over = min(facts.get("affinity") or usable, 2 * usable) if facts.get("cgroup_quota_cores") else usable
+    ntiles = max(1, min(over, tiles_total))
     worlds = []
     for t in range(ntiles):
         sub, _ = S.extract_tile(scene, t)
@@ -218,9 +220,10 @@ def cpu_baseline(scene, land_steps, tiles_total, budget_s=20.0):
     snaps = [w.snapshot() for w in worlds]
     per_tile = len(scene['body_transforms']) // max(1, tiles_total)
     points, t = [], 1
-    while t < ntiles:
+    while t < min(usable, ntiles):
         points.append(t)
         t *= 2
+    points.append(min(usable, ntiles))
     points.append(ntiles)
     if facts.get("physical_cores") and 1 < facts["physical_cores"] < ntiles and facts["physical_cores"] not in points:
         points.append(facts["physical_cores"])                                      # one thread per physical core (no SMT sharing)

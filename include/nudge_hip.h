@@ -50,6 +50,16 @@
  *      bookkeeping again; fields of existing contacts (friction, penetration ...) may simply be edited in place.
  *      One nh_setup_contact_constraints per nh_collide (a second one returns NH_ERR_STALE_SETUP).
  *
+ *   9. Still steps (NH_FLAG_FUSED_STEP without NH_FLAG_SYNC_COUNTS / NH_FLAG_EXACT_ORDER).  A world at rest on static geometry repeats itself: the same pairs, the
+ *      same contacts in the same order, the cache equal to last step's contact list.  When a step ended in that state the library launches the NEXT one
+ *      speculatively as a "still" step: three kernels (transforms + AABBs, narrowphase straight from the kept pair list into the caller's contact list, the
+ *      fused solver reading and writing the cache in place) that CHECK everything they rely on -- nobody outside its inflated box or asleep, every collider
+ *      pair with the key, contact count and feature words it had, body 0 inert -- instead of the ~30 launches that would find it out again.  A failed check is
+ *      reported with the step's one host round trip (inside nh_apply_impulses), before anything but contact data has been written, and the step is run again in
+ *      full from nh_collide's arguments: results are bit-identical to a library that never speculates (NH_NO_STILL=1), which the tests check.  Any entry point
+ *      outside the sample's call order (nh_read_counts, nh_synchronize, nh_append_contacts ...) between nh_collide and nh_apply_impulses turns the step
+ *      into a full one first, so everything it observes is what a full step produces.  nh_Counts.still_steps / still_replays count them.
+ *
  * Threading: one context = one HIP stream = one world at a time; no global mutable state.
  */
 #ifndef NUDGE_HIP_H
@@ -180,6 +190,8 @@ typedef struct nh_Counts {
 	                               before, with the same key */
 	uint32_t broadphase_inserts; /* colliders that left their inflated box and were re-inserted into the kept pair list (new box, new pairs) without a rebuild,
 	                               since nh_create */
+	uint32_t still_steps;       /* steps since nh_create that went through as STILL steps (note 9): launched as a world whose contact layout is last step's, and confirmed */
+	uint32_t still_replays;     /* ... launched as one, found otherwise (by the device or because the caller left the sample's call order) and run again in full */
 } nh_Counts;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */

@@ -24,16 +24,21 @@
 #define NH_GEN_INDEX 0xFFFFFFu
 __device__ __forceinline__ float nh_kept_margin(float cell_inv) { return cell_inv > 0.0f ? 0.03125f / cell_inv : 0.05f; }
 
+// STILL (nh_collide, "9. still steps"): the step was launched as one in which nothing changes structurally.  The kernel then only CHECKS -- a collider
+// outside its inflated box, a body asleep: the step fails (st->still_fail) and is replayed in full -- and gathers nothing a rebuild would need; it also does
+// what k_collide_begin does for a full step as far as a still step needs it (largest idle counter; next step's flags and bounds cleared).
+template<bool STILL>
 __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
                                                const nh_Transform* __restrict__ body_xf,
                                                const nh_Transform* __restrict__ box_xf, const nh_BoxCollider* __restrict__ box_data, const uint32_t* __restrict__ box_tags, uint32_t nbox,
                                                const nh_Transform* __restrict__ sph_xf, const nh_SphereCollider* __restrict__ sph_data, const uint32_t* __restrict__ sph_tags, uint32_t nsph,
                                                nh_xform* __restrict__ xf, float4* __restrict__ aabb_min, float4* __restrict__ aabb_max, uint32_t* __restrict__ ctag,
                                                uint4* __restrict__ zero16, uint32_t zero16_count, float4* fat_box, uint32_t direct,
-                                               uint8_t* __restrict__ gen, uint32_t* __restrict__ esc_mark, uint32_t* __restrict__ esc_list, uint32_t* __restrict__ moved_list, uint32_t seq) {
-	__shared__ uint32_t hist[1024];
+                                               uint8_t* __restrict__ gen, uint32_t* __restrict__ esc_mark, uint32_t* __restrict__ esc_list, uint32_t* __restrict__ moved_list, uint32_t seq,
+                                               const uint8_t* __restrict__ idle = nullptr, uint32_t nbodies = 0u, uint32_t parity = 0u) {
+	__shared__ uint32_t hist[STILL ? 1 : 1024];
 	__shared__ uint32_t red[12];
-	hist[threadIdx.x] = 0;
+	if (!STILL) hist[threadIdx.x] = 0;
 	if (threadIdx.x < 3) { red[threadIdx.x] = 0xffffffffu; red[3 + threadIdx.x] = 0u; red[6 + threadIdx.x] = 0xffffffffu; red[9 + threadIdx.x] = 0u; }
 	__syncthreads();
 	uint32_t n = nbox + nsph;
@@ -47,7 +52,28 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 	// (`direct`: this step searches the grid with the exact boxes and keeps nothing, nh_collide)
 	const bool fat_valid = st->fat_valid != 0u && !direct;
 	const float margin = direct ? 0.0f : nh_kept_margin(st->cell_inv);           // (k_grid_setup records the same value for k_cell_keys before it moves the grid)
-	bool escaped = false;
+	bool escaped = STILL && !fat_valid;
+	if (STILL) {
+		// the per-body part of k_collide_begin: nobody may be asleep (the host has ruled it out; checked), the largest idle counter for its next prediction
+		uint32_t top = 0;
+		for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x + 1u; i < nbodies; i += gridDim.x * blockDim.x) { const uint32_t cnt = idle[i]; top = max(top, cnt); escaped |= cnt == 0xffu; }
+		for (int d = 32; d >= 1; d >>= 1) top = max(top, (uint32_t)__shfl_xor((int)top, d));
+		if (threadIdx.x < 64u) red[0] = 0u;          // (reused below after the barrier; here: the workgroup's largest counter)
+		__syncthreads();
+		if (nh_lane() == 0 && top) atomicMax(&red[0], top);
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			if (red[0]) atomicMax(&st->max_idle[parity], red[0]);
+			if (blockIdx.x == 0) {
+				// what the NEXT step (the other parity) accumulates into: nobody touches it during this one
+				st->still_fail[parity ^ 1u] = 0u; st->max_idle[parity ^ 1u] = 0u;
+				for (int k = 0; k < 3; ++k) { st->still_smin[parity ^ 1u][k] = 0xffffffffu; st->still_smax[parity ^ 1u][k] = 0u; }
+			}
+		}
+		__syncthreads();
+		if (threadIdx.x < 3) { red[threadIdx.x] = 0xffffffffu; red[3 + threadIdx.x] = 0u; }
+		__syncthreads();
+	}
 	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
 		bool is_box = c < nbox;
 		nh_Transform l = is_box ? box_xf[c] : sph_xf[c - nbox];
@@ -89,7 +115,7 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 			const float4 fmn = fat_box[2u * c], fmx = fat_box[2u * c + 1u];
 			out = !(mnx >= fmn.x && mny >= fmn.y && mnz >= fmn.z && mxx <= fmx.x && mxy <= fmx.y && mxz <= fmx.z);       // (NaN: out)
 		}
-		if (gen) {
+		if (!STILL && gen) {
 			// Re-insertion ("7." below): a SMALL collider that has left its box takes the candidate box as its new one right here, gets the next generation
 			// stamp (its kept pairs die) and goes on this step's list of leavers; k_reinsert finds its new pairs.  Large colliders, worn-out stamps, full
 			// lists and boxes that are no longer small for the grid end in the rebuild instead.
@@ -112,6 +138,7 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 		f = nh_float_flip(mny); lmin[1] = min(lmin[1], f); lmax[1] = max(lmax[1], f);
 		f = nh_float_flip(mnz); lmin[2] = min(lmin[2], f); lmax[2] = max(lmax[2], f);
 		// exponent histogram: one LDS atomic per distinct exponent in the wave (usually 2-3), not one per lane
+		if (STILL) continue;
 		uint32_t ebin = (__float_as_uint(fext) >> 21) & 1023u;          // size class: exponent + two mantissa bits (quarter octaves)
 		if (ebin <= guess_exp && fext == fext) {
 			f = nh_float_flip(fx0); gmn[0] = min(gmn[0], f); gmx[0] = max(gmx[0], f);
@@ -129,9 +156,15 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 	for (int k = 0; k < 3; ++k) {
 		for (int d = 32; d >= 1; d >>= 1) {
 			lmin[k] = min(lmin[k], (uint32_t)__shfl_xor((int)lmin[k], d)); lmax[k] = max(lmax[k], (uint32_t)__shfl_xor((int)lmax[k], d));
-			gmn[k] = min(gmn[k], (uint32_t)__shfl_xor((int)gmn[k], d)); gmx[k] = max(gmx[k], (uint32_t)__shfl_xor((int)gmx[k], d));
+			if (!STILL) { gmn[k] = min(gmn[k], (uint32_t)__shfl_xor((int)gmn[k], d)); gmx[k] = max(gmx[k], (uint32_t)__shfl_xor((int)gmx[k], d)); }
 		}
-		if ((threadIdx.x & 63) == 0) { atomicMin(&red[k], lmin[k]); atomicMax(&red[3 + k], lmax[k]); atomicMin(&red[6 + k], gmn[k]); atomicMax(&red[9 + k], gmx[k]); }
+		if ((threadIdx.x & 63) == 0) { atomicMin(&red[k], lmin[k]); atomicMax(&red[3 + k], lmax[k]); if (!STILL) { atomicMin(&red[6 + k], gmn[k]); atomicMax(&red[9 + k], gmx[k]); } }
+	}
+	if (STILL) {
+		if (__ballot(escaped) != 0ull && nh_lane() == 0) st->still_fail[parity] = 1u;
+		__syncthreads();
+		if (threadIdx.x < 3) { atomicMin(&st->still_smin[parity][threadIdx.x], red[threadIdx.x]); atomicMax(&st->still_smax[parity][threadIdx.x], red[3 + threadIdx.x]); }
+		return;
 	}
 	if (__ballot(escaped) != 0ull && nh_lane() == 0) st->fat_escaped = 1u;          // (plain store of a constant)
 	__syncthreads();
@@ -783,7 +816,7 @@ __global__ __launch_bounds__(256) void k_kept_filter(nh_DevState* __restrict__ s
 	// (every workgroup derives the same decision from values nobody writes during this kernel)
 	const bool in_place = allow_in_place && !st->fat_rebuild && n <= pair_cap && (uint64_t)st->fat_hits_prev * 16u >= (uint64_t)n * 15u;
 	if (threadIdx.x == 0) s_hits = 0;
-	if (blockIdx.x == 0 && threadIdx.x == 0 && in_place) { st->pairs = n_bb; st->pairs_sph = n_sph; }
+	if (blockIdx.x == 0 && threadIdx.x == 0 && in_place) { st->pairs = n_bb; st->pairs_sph = n_sph; st->lay_in_place = 1u; }
 	__syncthreads();
 	// One reservation on the pair counters per WORKGROUP and flush (a same-address atomic costs ~12 ns, serialised: with one per wave the counters, not the
 	// memory system, set the pace): the waves stage their pairs separately but flush together, so the trip count is uniform over the workgroup
@@ -831,24 +864,48 @@ struct nh_Record { uint32_t body_a, body_b, overflow, count; };
 
 // SPH = false: the box-box pairs (front of `pairs`, records 0 .. n_bb-1); SPH = true: the pairs with a sphere (back of `pairs`, records
 // n_bb .. n_bb+n_sph-1).  Record r owns the raw contact slots 4r .. 4r+3 either way (a sphere pair uses the first one).
-template<bool SPH>
+// STILL (nh_collide, "9. still steps"): the pairs are taken straight from the KEPT list (what k_kept_filter does in place: exact AABB test, bodies,
+// stamps, roles by Morton order -- a kept pair's position is its record's), the result is COMPARED with the layout the last full step left (key by record
+// position, contact count and feature words per record: lay_start / lay_feat) and, being the same, written where it belongs in the caller's contact list --
+// data[first contact of the record + rank by feature] -- whose pair / tag / feature arrays still hold.  Anything else raises st->still_fail: no record,
+// no raw slot, no key is written, the step is replayed in full.
+template<bool SPH, bool STILL>
 __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ st, const uint2* __restrict__ pairs,
                                                      const nh_xform* __restrict__ xf, const uint32_t* __restrict__ ctag,
                                                      const nh_BoxCollider* __restrict__ box_data, const nh_SphereCollider* __restrict__ sph_data, uint32_t nbox,
                                                      nh_Contact* __restrict__ raw_data, uint32_t* __restrict__ raw_feature, uint32_t pair_cap, uint32_t overflow_cap,
                                                      uint64_t* __restrict__ rec_key, nh_Record* __restrict__ rec, uint32_t* __restrict__ rec_idx,
-                                                     const uint32_t* __restrict__ coarse_root, const uint32_t* __restrict__ coarse_active, uint32_t parity) {
+                                                     const uint32_t* __restrict__ coarse_root, const uint32_t* __restrict__ coarse_active, uint32_t parity,
+                                                     uint32_t* __restrict__ lay_start, uint4* __restrict__ lay_feat,
+                                                     // STILL only: the kept list (`pairs`) and its capacity, this step's exact AABBs, the stamps, the caller's contact list
+                                                     uint32_t kept_cap = 0u, const float4* __restrict__ aabb_min = nullptr, const float4* __restrict__ aabb_max = nullptr,
+                                                     const uint8_t* __restrict__ gen = nullptr, nh_Contact* __restrict__ data = nullptr, uint32_t capacity = 0u) {
 	// coarse islands (nudge.cpp:3500-3703): a pair whose bodies belong to a set of sleeping bodies (sets over the BROADPHASE pairs and the
 	// user's connections) never reaches the narrowphase: it becomes a sleeping pair, larger tag in the low half (3697)
-	const bool some_asleep = st->any_idle[parity] != 0;
+	const bool some_asleep = !STILL && st->any_idle[parity] != 0;
 	constexpr int NS = SPH ? 1 : 4;
 	__shared__ float4 s_c0[NS][256], s_c1[NS][256];
 	__shared__ uint32_t s_f[NS][256];
 	__shared__ uint8_t s_n[NS][64];
+	__shared__ uint32_t s_start[STILL && !SPH ? 4 : 1][64];
+	__shared__ uint8_t s_perm[STILL && !SPH ? 4 : 1][64];
 	const uint32_t n_bb = min(st->pairs, pair_cap), n_sph = min(st->pairs_sph, pair_cap - n_bb);
-	if (blockIdx.x == 0 && threadIdx.x == 0) {
+	if (!STILL && blockIdx.x == 0 && threadIdx.x == 0) {
 		st->records = n_bb + n_sph;            // (both launches write the same number: either may be the only one)
 		if ((uint64_t)st->pairs + st->pairs_sph > pair_cap) st->error = NH_ERR_PAIR_CAPACITY;
+	}
+	// STILL: Morton frame of this step (nudge.cpp:3096-3100; k_grid_setup's arithmetic) from the bounds k_xform<true> gathered; stamps as in k_kept_filter
+	float mscale = 0.0f;
+	nh_f3 mmin = nh_make3(0.0f, 0.0f, 0.0f);
+	const uint32_t index_mask = (STILL && gen) ? NH_GEN_INDEX : 0xFFFFFFFFu;
+	const bool stamps = STILL && gen && st->moved_count != 0u;
+	if (STILL) {
+		const nh_f3 smin = nh_make3(nh_float_unflip(st->still_smin[parity][0]), nh_float_unflip(st->still_smin[parity][1]), nh_float_unflip(st->still_smin[parity][2]));
+		const nh_f3 smax = nh_make3(nh_float_unflip(st->still_smax[parity][0]), nh_float_unflip(st->still_smax[parity][1]), nh_float_unflip(st->still_smax[parity][2]));
+		mscale = nh_morton_scale(smin, smax);
+		mmin = nh_make3(smin.x * mscale, smin.y * mscale, smin.z * mscale);
+		// (the layout must be the last full step's, and the kept list as long as the pair list it was written from)
+		if (blockIdx.x == 0 && threadIdx.x == 0 && (!st->lay_valid || st->fat_count != st->pairs || st->fat_count_sph != st->pairs_sph)) st->still_fail[parity] = 1u;
 	}
 	const uint32_t n = SPH ? n_sph : n_bb, first_rec = SPH ? n_bb : 0u;
 	// sort re-use (nh_collide): `rec_key` is the context's buffer of keys by record position, still holding last step's -- is every key what it was?
@@ -865,7 +922,19 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		const uint32_t ri = first_rec + i;        // record index
 		bool invalid = false;
 		if (i < n) {
-			uint2 pr = pairs[SPH ? pair_cap - 1u - i : i];
+			uint2 pr;
+			if (STILL) {
+				const uint2 kp = pairs[SPH ? kept_cap - 1u - i : i];
+				const uint32_t ca = kp.x & index_mask, cb = kp.y & index_mask;
+				const float4 amin = aabb_min[ca], amax = aabb_max[ca], bmin = aabb_min[cb], bmax = aabb_max[cb];
+				bool hit = aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != __float_as_uint(amin.w));
+				if (stamps && hit) hit = (uint32_t)(gen[ca] & 0x7Fu) == (kp.x >> NH_GEN_SHIFT) && (uint32_t)(gen[cb] & 0x7Fu) == (kp.y >> NH_GEN_SHIFT);
+				const uint64_t ka = nh_morton_of(nh_make3(amin.x, amin.y, amin.z), mscale, mmin), kb = nh_morton_of(nh_make3(bmin.x, bmin.y, bmin.z), mscale, mmin);
+				const bool a_first = (ka < kb) || (ka == kb && ca < cb);
+				pr = hit ? (a_first ? make_uint2(cb, ca) : make_uint2(ca, cb)) : make_uint2(NH_PAIR_INVALID, NH_PAIR_INVALID);       // narrowphase "a" = later in Morton order (emit_pair)
+			} else {
+				pr = pairs[SPH ? pair_cap - 1u - i : i];
+			}
 			invalid = pr.x == NH_PAIR_INVALID;       // (k_kept_filter, in-place form: a kept pair that does not overlap this step -- an empty record, key ~0)
 			if (invalid) { pr = make_uint2(0u, 0u); key = ~0ull; }
 			uint32_t a = pr.x, b = pr.y;            // a = later in Morton order
@@ -911,6 +980,20 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		if (SPH) {
 			// one contact at most, ONE raw slot per sphere record (they follow the four-slot blocks of the box-box records: slot 4 n_bb + i, so that
 			// consecutive lanes write -- and k_gather_contacts reads -- consecutive 32 bytes instead of every fourth slot)
+			if (STILL) {
+				if (i < n) {
+					const uint32_t ls = lay_start[ri];
+					const bool same = rec_key[ri] == key && (ls >> 28) == (uint32_t)count && (!count || lay_feat[ri].x == single.feature);
+					changed |= !same;
+					const uint32_t d = ls & 0x0FFFFFFFu;
+					if (same && count && d < capacity) {
+						float4* dp = reinterpret_cast<float4*>(data + d);
+						dp[0] = make_float4(single.px, single.py, single.pz, single.penetration);
+						dp[1] = make_float4(single.nx, single.ny, single.nz, single.friction);
+					}
+				}
+				continue;
+			}
 			if (i < n) {
 				if (count) {
 					const size_t slot = (size_t)4 * n_bb + i;
@@ -924,13 +1007,14 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 				if (asleep) st->any_sleeping = 1;
 				rec[ri] = r;
 				rec_idx[ri] = ri;
+				lay_feat[ri] = make_uint4(single.feature, 0u, 0u, 0u);
 			}
 			continue;
 		}
 		// more than 4 contacts per pair is the exception (askew face contacts): only those touch the global counter
-		uint32_t extra = count > 4 ? (uint32_t)(count - 4) : 0u;
+		uint32_t extra = (!STILL && count > 4) ? (uint32_t)(count - 4) : 0u;
 		uint32_t ovf = 0;
-		if (__ballot(extra != 0)) ovf = nh_wave_reserve(&st->raw_contacts, extra);
+		if (!STILL && __ballot(extra != 0)) ovf = nh_wave_reserve(&st->raw_contacts, extra);
 		// The first four contacts of a pair go to its four raw slots: the wave's 64 pairs own ONE contiguous run of 256 slots, so the
 		// lanes post their contacts to LDS and the wave writes the run with consecutive lanes on consecutive slots (a lane writing
 		// its own 128 bytes would put 64 different lines behind every store instruction).  Contacts 5+ (rare) go out directly.
@@ -942,6 +1026,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		if (i < n) {
 			if (extra && ovf + extra > overflow_cap) { st->error = NH_ERR_CONTACT_CAPACITY; count = 4; }
 			auto put = [&](int k, const nh_contact_out& o) {
+				if (STILL && k >= 4) return;
 				if (k < 4) {
 					w_c0[4u * lane + k] = make_float4(o.px, o.py, o.pz, o.penetration);
 					w_c1[4u * lane + k] = make_float4(o.nx, o.ny, o.nz, o.friction);
@@ -968,11 +1053,56 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			} else if (bb.kind == 1) {
 				put(0, bb.edge);
 			}
-			{ const uint64_t was = rec_key[ri]; changed |= was != key; rec_key[ri] = key; }
-			nh_Record r = { body_a, body_b, ovf, asleep ? NH_REC_SLEEPING : (uint32_t)count };
-			if (asleep) st->any_sleeping = 1;
-			rec[ri] = r;
-			rec_idx[ri] = ri;
+			if (!STILL) {
+				{ const uint64_t was = rec_key[ri]; changed |= was != key; rec_key[ri] = key; }
+				nh_Record r = { body_a, body_b, ovf, asleep ? NH_REC_SLEEPING : (uint32_t)count };
+				if (asleep) st->any_sleeping = 1;
+				rec[ri] = r;
+				rec_idx[ri] = ri;
+				// the record's feature words in slot order: what a still step compares its own with
+				lay_feat[ri] = make_uint4(count > 0 ? w_f[4u * lane] : 0u, count > 1 ? w_f[4u * lane + 1u] : 0u, count > 2 ? w_f[4u * lane + 2u] : 0u, count > 3 ? w_f[4u * lane + 3u] : 0u);
+			}
+		}
+		if (STILL) {
+			// same record as last step?  Then its contacts go to data[first + rank by feature] (k_gather_contacts' order: feature, ties by slot) -- through LDS, so
+			// that eight lanes write one record's 128 bytes (a lane writing its own four contacts would put 64 lines behind every store instruction)
+			uint32_t cnt_ok = 0, first = 0, perm = 0;
+			if (i < n) {
+				const uint32_t ls = lay_start[ri];
+				const uint4 fe = lay_feat[ri];
+				const uint32_t f[4] = { w_f[4u * lane], w_f[4u * lane + 1u], w_f[4u * lane + 2u], w_f[4u * lane + 3u] }, g[4] = { fe.x, fe.y, fe.z, fe.w };
+				bool same = rec_key[ri] == key && (ls >> 28) == (uint32_t)count && count <= 4;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) same = same && (k >= count || f[k] == g[k]);
+				changed |= !same;
+				if (same) { cnt_ok = (uint32_t)count; first = ls & 0x0FFFFFFFu; }
+				if (same) {
+					// slot of every rank (two bits each): the write-out below fetches a record's contacts in rank order
+#pragma unroll
+					for (int j = 0; j < 4; ++j) {
+						uint32_t r = 0;
+#pragma unroll
+						for (int q = 0; q < 4; ++q) r += (q < count && (f[q] < f[j] || (f[q] == f[j] && q < j))) ? 1u : 0u;
+						if (j < count) perm |= (uint32_t)j << (2u * r);
+					}
+				}
+			}
+			if (cnt_ok && first + cnt_ok > capacity) cnt_ok = 0;
+			w_n[lane] = (uint8_t)cnt_ok;
+			s_perm[threadIdx.x >> 6][lane] = (uint8_t)perm;
+			s_start[threadIdx.x >> 6][lane] = first;
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int r8 = 0; r8 < 8; ++r8) {
+				const uint32_t e = 64u * r8 + lane, j = e >> 3, q = (e >> 1) & 3u, half = e & 1u;
+				if (q < (uint32_t)w_n[j]) {
+					const uint32_t slot = ((uint32_t)s_perm[threadIdx.x >> 6][j] >> (2u * q)) & 3u;
+					float4* dp = reinterpret_cast<float4*>(data + s_start[threadIdx.x >> 6][j] + q);
+					dp[half] = half ? w_c1[4u * j + slot] : w_c0[4u * j + slot];
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+			continue;
 		}
 		w_n[lane] = (uint8_t)(i < n ? (count < 4 ? count : 4) : 0);
 		__builtin_amdgcn_wave_barrier();
@@ -990,6 +1120,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		}
 		__builtin_amdgcn_wave_barrier();
 	}
+	if (STILL) { if (__ballot(changed) != 0ull && nh_lane() == 0) st->still_fail[parity] = 1u; return; }
 	if (__ballot(changed) != 0ull && nh_lane() == 0) st->keys_changed = 1u;          // (plain store of a constant)
 }
 
@@ -1120,7 +1251,8 @@ __global__ __launch_bounds__(256) void k_sorted_counts(nh_DevState* __restrict__
 __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict__ st, const uint32_t* __restrict__ rec_idx, const nh_Record* __restrict__ rec, const uint64_t* __restrict__ rec_key_sorted,
                                                          const uint32_t* __restrict__ starts, const nh_Contact* __restrict__ raw_data, const uint32_t* __restrict__ raw_feature,
                                                          nh_Contact* __restrict__ data, nh_BodyPair* __restrict__ bodies, uint64_t* __restrict__ tags, uint32_t* __restrict__ features, uint32_t capacity, uint32_t pair_cap,
-                                                         const uint32_t* __restrict__ sleep_scan, uint64_t* __restrict__ sleeping_pairs, uint32_t* __restrict__ deg, uint32_t nbodies) {
+                                                         const uint32_t* __restrict__ sleep_scan, uint64_t* __restrict__ sleeping_pairs, uint32_t* __restrict__ deg, uint32_t nbodies,
+                                                         uint32_t* __restrict__ lay_start, uint32_t order_kept) {
 	__shared__ uint32_t s_src[4][1024];
 	unsigned long long* __restrict__ pair_counter = reinterpret_cast<unsigned long long*>(deg + 2u * NH_DEG_STRIDE(nbodies));
 	uint32_t* __restrict__ first_contact = deg + 4u * NH_DEG_STRIDE(nbodies);
@@ -1129,6 +1261,10 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 	const uint32_t nrec = st->records;
 	const uint32_t n_bb = min(st->pairs, pair_cap);
 	if (st->contacts > capacity && blockIdx.x == 0 && threadIdx.x == 0) st->error = NH_ERR_CONTACT_CAPACITY;
+	// The layout this launch leaves (per record: first contact | contact count << 28, below) is what a still step compares itself with and writes through:
+	// usable when a record's position is its kept pair's (k_kept_filter wrote in place), nothing sleeps, and everything fits
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+		st->lay_valid = (st->lay_in_place && order_kept && !st->any_sleeping && !st->error && st->contacts <= capacity && st->contacts < (1u << 28)) ? 1u : 0u;
 	const uint32_t wave = threadIdx.x >> 6, lane = nh_lane();
 	uint32_t* src = s_src[wave];
 	uint32_t* sft = s_feat[wave];
@@ -1149,6 +1285,7 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 				const uint32_t p = sleep_scan[lo];
 				if (p < capacity) sleeping_pairs[p] = key; else st->error = NH_ERR_CONTACT_CAPACITY;
 			}
+			lay_start[ri] = (start & 0x0FFFFFFFu) | (((r.count & NH_REC_SLEEPING) || r.count > 4u ? 15u : r.count) << 28);
 			body_a = r.body_a; body_b = r.body_b;
 			sph_rec = ri >= n_bb;                   // (records of pairs with a sphere follow the box-box ones and own ONE raw slot each: k_narrowphase<true>)
 			base4 = sph_rec ? 4u * n_bb + (ri - n_bb) : 4u * ri; baseo = 4u * pair_cap + r.overflow;
@@ -1247,7 +1384,12 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 	if (nh_lane() == 0) s_top[threadIdx.x >> 6] = top;
 	__syncthreads();
 	if (threadIdx.x == 0) block_top[blockIdx.x] = max(max(s_top[0], s_top[1]), max(s_top[2], s_top[3]));
-	if (blockIdx.x == 0 && threadIdx.x == 0) st->any_idle[parity ^ 1u] = 0;
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		st->any_idle[parity ^ 1u] = 0;
+		// (what a still step of the other parity -- the next step, if the host launches it as one -- accumulates into, and the verdict on this step's layout)
+		st->still_fail[parity ^ 1u] = 0u; st->max_idle[parity ^ 1u] = 0u; st->lay_valid = 0u; st->lay_in_place = 0u;
+		for (int k = 0; k < 3; ++k) { st->still_smin[parity ^ 1u][k] = 0xffffffffu; st->still_smax[parity ^ 1u][k] = 0u; }
+	}
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < NH_DEG_WORDS(nbodies); i += gridDim.x * blockDim.x) deg[i] = 0;      // degrees, pair counters, first contacts (NH_DEG_STRIDE)
 	if (blockIdx.x != 0) return;
 	uint32_t t = threadIdx.x;
@@ -1267,12 +1409,59 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 }
 
 // =================================================================================================================
+// ---- 9. still steps (nh_internal.h: nh_StillStep) --------------------------------------------------------------------------------------------------------
+static bool same_bodies(const nh_BodyData& a, const nh_BodyData& b) {
+	return a.transforms == b.transforms && a.properties == b.properties && a.momentum == b.momentum && a.idle_counters == b.idle_counters && a.count == b.count;
+}
+static bool same_colliders(const nh_ColliderData& a, const nh_ColliderData& b) {
+	return a.boxes.tags == b.boxes.tags && a.boxes.data == b.boxes.data && a.boxes.transforms == b.boxes.transforms && a.boxes.count == b.boxes.count &&
+	       a.spheres.tags == b.spheres.tags && a.spheres.data == b.spheres.data && a.spheres.transforms == b.spheres.transforms && a.spheres.count == b.spheres.count;
+}
+static bool same_contacts(const nh_ContactData& a, const nh_ContactData& b) {
+	return a.data == b.data && a.bodies == b.bodies && a.tags == b.tags && a.features == b.features && a.capacity == b.capacity && a.sleeping_pairs == b.sleeping_pairs;
+}
+
+static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_ContactData* contacts, const nh_BodyData* bodies, const nh_ColliderData* colliders,
+                        const nh_BodyConnections* body_connections, nh_Arena temporary, bool want_still);
+
 extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_ContactData* contacts,
                           const nh_BodyData* bodies, const nh_ColliderData* colliders,
                           const nh_BodyConnections* body_connections, nh_Arena temporary) {
 	if (!ctx || !active_bodies || !contacts || !bodies || !colliders) return NH_ERR_INVALID;
 	NH_HIP_CHECK(ctx, hipSetDevice(ctx->device));
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	nh_StillStep& ss = ctx->still;
+	ss.active = false; ss.resolved = false; ss.setup_d = nullptr;
+	// A still step?  The last step must have left everything one relies on (ok_next: decided at its round trip), the contact cache must be that step's contact
+	// list, the caller must be in the mode that promises the sample's call order, and the world must be the one the kept layout describes.
+	const bool want_still = !ss.disabled && ss.ok_next && ss.cache_ok && !ss.appended && (ctx->flags & NH_FLAG_FUSED_STEP) && !(ctx->flags & (NH_FLAG_SYNC_COUNTS | NH_FLAG_EXACT_ORDER)) &&
+	                        same_bodies(*bodies, ss.lay_bodies) && same_colliders(*colliders, ss.lay_colliders) && same_contacts(*contacts, ss.lay_contacts) &&
+	                        active_bodies->indices == ss.lay_active && active_bodies->capacity == ss.lay_active_capacity;
+	// (kept for the replay of a still step that fails, and as what the next layout belongs to)
+	ss.active_out = active_bodies; ss.contacts_out = contacts; ss.bodies = *bodies; ss.colliders = *colliders;
+	ss.has_connections = body_connections != nullptr;
+	if (body_connections) ss.connections = *body_connections;
+	ss.temporary = temporary;
+	return collide_impl(ctx, active_bodies, contacts, bodies, colliders, body_connections, temporary, want_still);
+}
+
+// A still step that has not been confirmed becomes a full one: nh_collide again, in full, with the arguments it was given -- and the adjacency kernel the still
+// setup left out, if setup has run.  Called by every entry point outside the sample's call order (nh_flush_pending) and by the solver's round trip when a check
+// failed (first_apply).  Nothing the still kernels wrote matters: contact data is rewritten, momentum / transforms / cache were not touched.
+int nh_still_collide_again(nh_context* ctx) {
+	nh_StillStep& ss = ctx->still;
+	const bool after_collide = ctx->after_collide, may_overlap = ctx->gravity_may_overlap;
+	ss.active = false; ss.resolved = false; ss.ok_next = false;
+	ss.failed++;
+	ss.replaying = true;
+	const int rc = collide_impl(ctx, ss.active_out, ss.contacts_out, &ss.bodies, &ss.colliders, ss.has_connections ? &ss.connections : nullptr, ss.temporary, false);
+	ss.replaying = false;
+	ctx->after_collide = after_collide; ctx->gravity_may_overlap = may_overlap;
+	return rc;
+}
+
+static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_ContactData* contacts, const nh_BodyData* bodies, const nh_ColliderData* colliders,
+                        const nh_BodyConnections* body_connections, nh_Arena temporary, bool want_still) {
 	ctx->adv.done = false;
 	ctx->step_parity ^= 1u;
 	ctx->collide_seq++;
@@ -1432,12 +1621,61 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	}
 	// re-insertion of colliders that leave their boxes (k_reinsert): kept-list steps only, indices that leave room for the stamps
 	const bool incremental = !bp_direct && !ctx->env_no_incremental && C < (1u << NH_GEN_SHIFT);
+	// library-owned: the layout of the contact list (nh_internal.h), per record position and per body
+	bool lay_fresh = false;
+	if (ctx->lay_capacity != pair_cap) {
+		if (ctx->lay_start) NH_HIP_CHECK(ctx, hipFree(ctx->lay_start));
+		if (ctx->lay_feat) NH_HIP_CHECK(ctx, hipFree(ctx->lay_feat));
+		ctx->lay_start = nullptr; ctx->lay_feat = nullptr; ctx->lay_capacity = 0;
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->lay_start, sizeof(uint32_t) * (size_t)pair_cap + 64u));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->lay_feat, sizeof(uint4) * (size_t)pair_cap + 64u));
+		ctx->lay_capacity = pair_cap; lay_fresh = true;
+	}
+	if (ctx->lay_body_capacity < B) {
+		if (ctx->lay_class) NH_HIP_CHECK(ctx, hipFree(ctx->lay_class));
+		if (ctx->lay_simple) NH_HIP_CHECK(ctx, hipFree(ctx->lay_simple));
+		ctx->lay_class = nullptr; ctx->lay_simple = nullptr; ctx->lay_body_capacity = 0;
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->lay_class, (size_t)B + 64u));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->lay_simple, sizeof(uint2) * (size_t)B + 64u));
+		ctx->lay_body_capacity = B; lay_fresh = true;
+	}
+	{
+		nh_StillStep& ss = ctx->still;
+		ss.lay_bodies = *bodies; ss.lay_colliders = *colliders; ss.lay_contacts = *contacts; ss.lay_active = active_bodies->indices; ss.lay_active_capacity = active_bodies->capacity;
+		ss.appended = false;
+		// ---- the still step: three launches instead of the thirty below ----
+		const bool still = want_still && no_islands && !bp_direct && !drop_kept && !drop_sort_order && !lay_fresh && !ctx->env_sort_classic && ctx->sort_seeded && !ctx->env_sort_radix &&
+		                   !ctx->env_no_sort_reuse && C != 0u;
+		if (still) {
+			nh_DevState* st = ctx->d_state;
+			NH_LAUNCH(ctx, "xform_aabb", (k_xform<true>), nh_grid_for(C > B ? C : B, 1024, 256), 1024, st, bodies->transforms,
+			          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
+			          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
+			          xf, aabb_min, aabb_max, ctag, (uint4*)nullptr, 0u, ctx->fat_box, 0u,
+			          (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, ctx->collide_seq, bodies->idle_counters, B, ctx->step_parity);
+			const uint8_t* gen = incremental ? ctx->fat_gen : (const uint8_t*)nullptr;
+			if (nbox >= 2)
+				NH_LAUNCH(ctx, "narrowphase", (k_narrowphase<false, true>), nh_grid_for(pair_cap, 256, 4096), 256, st, ctx->fat_pairs, xf, ctag,
+				          colliders->boxes.data, colliders->spheres.data, nbox, (nh_Contact*)nullptr, (uint32_t*)nullptr, pair_cap, 0u, ctx->sort_keys_by_position, (nh_Record*)nullptr, (uint32_t*)nullptr,
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->lay_start, ctx->lay_feat,
+				          ctx->fat_pair_capacity, aabb_min, aabb_max, gen, contacts->data, cap);
+			if (nsph)
+				NH_LAUNCH(ctx, "narrowphase_sph", (k_narrowphase<true, true>), nh_grid_for(pair_cap, 256, 8192), 256, st, ctx->fat_pairs, xf, ctag,
+				          colliders->boxes.data, colliders->spheres.data, nbox, (nh_Contact*)nullptr, (uint32_t*)nullptr, pair_cap, 0u, ctx->sort_keys_by_position, (nh_Record*)nullptr, (uint32_t*)nullptr,
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->lay_start, ctx->lay_feat,
+				          ctx->fat_pair_capacity, aabb_min, aabb_max, gen, contacts->data, cap);
+			ss.active = true; ss.resolved = false; ss.launched++;
+			ctx->gravity_may_overlap = false;
+			ctx->after_collide = true;
+			return NH_OK;
+		}
+	}
 	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, begin_grid, 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity, coarse_parent, coarse_active, no_islands ? 1u : 0u, block_top,
 	          drop_kept ? 1u : 0u, drop_sort_order ? 1u : 0u);
 	const bool seeded_sort = !ctx->env_sort_classic && ctx->sort_seeded && !ctx->env_sort_radix;      // (NH_SORT_RADIX=1: radix passes every step)
 	uint64_t* rec_key_a = ctx->sort_keys_by_position;
 	if (C) {
-		NH_LAUNCH(ctx, "xform_aabb", k_xform, nh_grid_for(C, 1024, 256), 1024, st, bodies->transforms,
+		NH_LAUNCH(ctx, "xform_aabb", (k_xform<false>), nh_grid_for(C, 1024, 256), 1024, st, bodies->transforms,
 		          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
 		          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
 		          xf, aabb_min, aabb_max, ctag, (uint4*)nullptr, 0u, ctx->fat_box, bp_direct ? 1u : 0u,
@@ -1485,13 +1723,13 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 		// (the host does not know the counts: a launch over a list that turns out empty costs a few microseconds, so the launch for a
 		// shape the world does not contain is skipped outright)
 		if (nbox >= 2)
-			NH_LAUNCH(ctx, "narrowphase", (k_narrowphase<false>), nh_grid_for(pair_cap, 256, 4096), 256, st, pairs, xf, ctag,
+			NH_LAUNCH(ctx, "narrowphase", (k_narrowphase<false, false>), nh_grid_for(pair_cap, 256, 4096), 256, st, pairs, xf, ctag,
 			          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a,
-			          coarse_root, coarse_active, ctx->step_parity);
+			          coarse_root, coarse_active, ctx->step_parity, ctx->lay_start, ctx->lay_feat);
 		if (nsph)
-			NH_LAUNCH(ctx, "narrowphase_sph", (k_narrowphase<true>), nh_grid_for(pair_cap, 256, 8192), 256, st, pairs, xf, ctag,
+			NH_LAUNCH(ctx, "narrowphase_sph", (k_narrowphase<true, false>), nh_grid_for(pair_cap, 256, 8192), 256, st, pairs, xf, ctag,
 			          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a,
-			          coarse_root, coarse_active, ctx->step_parity);
+			          coarse_root, coarse_active, ctx->step_parity, ctx->lay_start, ctx->lay_feat);
 	}
 	// islands over contact records (+ user connections): a chain of small kernels that the tag sort of the records does not depend
 	// on -- it runs on the side stream while the caller's stream sorts (fork here, join before k_sorted_counts)
@@ -1556,7 +1794,8 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	// contact starts and sleeping-pair slots: two scans over the sorted records in one pair of launches
 	nh_scan2_u32(ctx, rec_counts, rec_counts, &st->contacts, sleep_flags, sleep_flags, &st->sleeping, &st->records, 1, scan_tmp);
 	NH_LAUNCH(ctx, "gather_contacts", k_gather_contacts, nh_grid_for(pair_cap, 256, 8192), 256, st, sorted_idx, rec, sorted_keys, rec_counts, raw_data, raw_feature,
-	          contacts->data, contacts->bodies, contacts->tags, contacts->features, cap, pair_cap, sleep_flags, contacts->sleeping_pairs, ctx->deg, B);
+	          contacts->data, contacts->bodies, contacts->tags, contacts->features, cap, pair_cap, sleep_flags, contacts->sleeping_pairs, ctx->deg, B,
+	          ctx->lay_start, seeded_sort ? 1u : 0u);
 
 	if (ctx->flags & NH_FLAG_SYNC_COUNTS) {
 		nh_Counts c;

@@ -64,6 +64,9 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->blk.min_contacts = getenv("NH_BLK_MIN") ? (uint32_t)atoi(getenv("NH_BLK_MIN")) : 200000u;
 	ctx->blk.target = getenv("NH_BLK_TARGET") ? (uint32_t)atoi(getenv("NH_BLK_TARGET")) : 900u;
 	if (ctx->blk.target < 8u) ctx->blk.target = 8u;
+	ctx->lay_start = nullptr; ctx->lay_feat = nullptr; ctx->lay_capacity = 0; ctx->lay_class = nullptr; ctx->lay_simple = nullptr; ctx->lay_body_capacity = 0;
+	memset(&ctx->still, 0, sizeof(ctx->still));
+	ctx->still.disabled = getenv("NH_NO_STILL") != nullptr;      // NH_NO_STILL=1: no step is launched speculatively as a still step (A/B, tests)
 	ctx->d_state = nullptr;
 	ctx->h_state = nullptr;
 	if (hipMalloc((void**)&ctx->d_state, sizeof(nh_DevState)) != hipSuccess) { delete ctx; return NH_ERR_HIP; }
@@ -111,6 +114,10 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	if (ctx->sort_splitters) hipFree(ctx->sort_splitters);
 	if (ctx->sort_counts) hipFree(ctx->sort_counts);
 	if (ctx->sort_starts) hipFree(ctx->sort_starts);
+	if (ctx->lay_start) hipFree(ctx->lay_start);
+	if (ctx->lay_feat) hipFree(ctx->lay_feat);
+	if (ctx->lay_class) hipFree(ctx->lay_class);
+	if (ctx->lay_simple) hipFree(ctx->lay_simple);
 	{
 		nh_BlkBuffers& k = ctx->blk;
 		void* bufs[] = { k.brank, k.bm, k.pos_body, k.touch, k.lpair, k.ghost_list, k.blk_count, k.own_base, k.bins, k.bin_off, k.ghost_base, k.ghost_count, k.phase_list, k.desc, k.scan_tmp, k.prof };
@@ -129,7 +136,13 @@ extern "C" int nh_set_flags(nh_context* ctx, uint32_t flags) {
 }
 extern "C" int nh_set_tag_bits(nh_context* ctx, uint32_t bits) { if (!ctx || bits < 1 || bits > 32) return NH_ERR_INVALID; ctx->tag_bits = bits; return NH_OK; }
 
-extern "C" int nh_bodies_changed(nh_context* ctx) { if (!ctx) return NH_ERR_INVALID; ctx->idle_bound = -1; ctx->idle_unknown = true; return NH_OK; }
+extern "C" int nh_bodies_changed(nh_context* ctx) {
+	if (!ctx) return NH_ERR_INVALID;
+	{ int rc = nh_still_abandon(ctx); if (rc) return rc; }
+	ctx->idle_bound = -1; ctx->idle_unknown = true;
+	ctx->still.ok_next = false;                  // body records rewritten from outside: the next step looks at everything again
+	return NH_OK;
+}
 
 extern "C" int nh_set_pair_capacity(nh_context* ctx, uint32_t pairs) { if (!ctx) return NH_ERR_INVALID; ctx->pair_capacity = pairs; return NH_OK; }
 
@@ -150,6 +163,7 @@ void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out) {
 	out->colliders = h->colliders; out->pairs = h->pairs + h->pairs_sph; out->contacts = h->contacts; out->sleeping_pairs = h->sleeping;
 	out->active_bodies = h->active; out->cache = h->cache; out->culled = h->culled; out->large_colliders = h->large;
 	out->general_contacts = h->general_contacts; out->levels = h->levels; out->error = h->error;
+	out->still_steps = (uint32_t)(ctx->still.launched - ctx->still.failed - ((ctx->still.active && !ctx->still.resolved) ? 1u : 0u)); out->still_replays = (uint32_t)ctx->still.failed;
 	out->has_other_bodies = h->has_other; out->broadphase_rebuilds = h->fat_rebuilds; out->sort_reuses = h->sort_reuses; out->broadphase_inserts = h->fat_inserts; out->unleveled = h->unleveled; out->raw_pairs = h->pairs + h->pairs_sph;
 }
 
@@ -167,6 +181,8 @@ __global__ void k_set_cache_count(nh_DevState* st, uint32_t n) { st->cache = n; 
 
 extern "C" int nh_set_cache_count(nh_context* ctx, uint32_t count) {
 	if (!ctx) return NH_ERR_INVALID;
+	{ int rc = nh_still_abandon(ctx); if (rc) return rc; }
+	ctx->still.cache_ok = false;                 // the caller has put another cache in place
 	hipLaunchKernelGGL(k_set_cache_count, dim3(1), dim3(1), 0, ctx->stream, ctx->d_state, count);
 	return NH_OK;
 }

@@ -126,7 +126,7 @@ struct nh_DevState {
 struct nh_TimerSlot { const char* name; hipEvent_t a, b; };
 
 // what the fused one-body solver does besides solving (NH_FLAG_FUSED_STEP): bits 1 = gravity / damping on load, 2 = advance on store
-struct nh_FusedStep { float gx_dt, gy_dt, gz_dt, damping, time_step; uint32_t bits; uint8_t* idle; };
+struct nh_FusedStep { float gx_dt, gy_dt, gz_dt, damping, time_step; uint32_t bits; uint8_t* idle; uint32_t parity; };      // (parity: of the step, for a still step's verdict)
 
 // library-owned buffers of the spatially blocked solver (nh_blocks.h), grown on demand
 struct nh_BlkBuffers {
@@ -149,6 +149,28 @@ struct nh_BlkBuffers {
 	uint32_t target, min_contacts;    // NH_BLK_TARGET, NH_BLK_MIN
 	bool disabled, check;             // NH_NO_BLOCKS=1, NH_BLK_CHECK=1
 	unsigned long long* prof; uint32_t prof_calls;       // NH_BLK_PROFILE=1: wall-clock readings of the sweep workgroups (8 launches x NH_BLK_MAX_BLOCKS x 4), printed now and then
+};
+
+// ---- still steps (nh_collide.hip, "9. still steps") --------------------------------------------------------------------------------------------------
+// A world at rest on static geometry repeats itself: the same pairs at the same places of the kept pair list, the same contacts in the same order, every body
+// with its one contact-list record, the contact cache = last step's contact list.  Everything a step does to FIND that out again -- grid chain, pair filter,
+// tag sort, scans, contact gather, adjacency, cache merge: two dozen launches, most of them leaving at once -- is then skipped by the HOST, which launches
+// three kernels (k_xform<true>, k_narrowphase<*, true>, the solver reading and writing the cache in place); they CHECK what they rely on (nobody left its
+// inflated box or is asleep; every record has the key, contact count and feature words it had; body 0 inert) and raise st->still_fail otherwise -- after which
+// each of them leaves without having changed anything that matters, and the host, which learns of it with the step's one round trip, replays the step in full.
+struct nh_StillStep {
+	bool disabled;                  // nh option / NH_NO_STILL=1: never launch a step speculatively (A/B, tests)
+	bool ok_next;                   // the last step left a layout, body classes and a cache that a still step may rely on (decided at its round trip / end)
+	bool cache_ok;                  // the caller's contact cache IS the contact list of the last step (nh_write_cached_impulses wrote it with nothing culled)
+	const void *cache_tags, *cache_features, *cache_data; uint32_t cache_capacity;
+	bool active, resolved;          // this step was launched as a still step / ... and its round trip has confirmed it
+	bool replaying;                 // inside the replay of a failed one
+	bool appended;                  // nh_append_contacts changed the list since the layout was written
+	nh_ContactConstraintData* setup_d;      // its nh_setup_contact_constraints has run (without the adjacency kernel the replay then owes)
+	// the arguments of its nh_collide, for the replay; and the arrays the kept layout belongs to (another world in the same context: not still)
+	nh_ActiveBodies* active_out; nh_ContactData* contacts_out; nh_BodyData bodies; nh_ColliderData colliders; nh_BodyConnections connections; bool has_connections; nh_Arena temporary;
+	nh_BodyData lay_bodies; nh_ColliderData lay_colliders; nh_ContactData lay_contacts; const uint32_t* lay_active; uint32_t lay_active_capacity;
+	uint64_t launched, failed;      // statistics
 };
 
 struct nh_context {
@@ -238,10 +260,18 @@ struct nh_context {
 	struct { bool pending, rest_pending; float gx_dt, gy_dt, gz_dt, damping, time_step; const uint32_t* active; nh_BodyMomentum* momentum; uint32_t body_count; } grav;
 	struct { bool done, rest; float time_step; const uint8_t* body_class; } adv;      // `rest`: some active body is not the fused solver's (the step's round trip told)
 	nh_BlkBuffers blk;
+	// kept layout of the contact list (library-owned; written by every full step, read by still steps): per record position its first contact | count << 28
+	// and its feature words in slot order; per body its class and contact-list record (k_adj_simple)
+	uint32_t* lay_start; uint4* lay_feat; uint32_t lay_capacity;
+	uint8_t* lay_class; uint2* lay_simple; uint32_t lay_body_capacity;
+	nh_StillStep still;
 };
 
 // Runs work that an earlier call deferred; every entry point that reads or writes momentum / impulses calls it first.
-int nh_flush_pending(nh_context* ctx, bool keep_gravity = false);
+// `in_sequence`: the caller is the next call of the sample's step (gravity, read, setup, apply): a still step stays speculative across it; every other
+// entry point first turns a still step that has not been confirmed yet into a full one (nh_still_abandon)
+int nh_flush_pending(nh_context* ctx, bool keep_gravity = false, bool in_sequence = false);
+int nh_still_abandon(nh_context* ctx);
 void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out);
 #define NH_COUNTER_WORDS 32u          // leading words of nh_DevState that the host mirrors (nh_read_counts)
 

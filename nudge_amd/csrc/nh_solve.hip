@@ -844,7 +844,10 @@ __device__ __noinline__ float4 cache_search(const uint64_t* __restrict__ ctags, 
 // Four 27-float rows fit in 256 registers: two waves per SIMD (the compiler would otherwise spend 260 and run one).
 struct nh_ob_slot { float4 c0, c1, w; };      // contact (32 B), cached impulse xyz + flags in w.w (bit 0 miss, bit 1 body is "a")
 
-template<int MAXC, bool FUSED, bool CONTIG = false, int NW = 4>
+// STILL (nh_internal.h: nh_StillStep): the step was launched as one whose contact list is last step's, entry for entry.  The cache then IS that list: contact c's
+// warm start is cdata[c] -- no tags, no features, no hint, no search -- and its solved impulse goes back to cdata[c], which is all nh_write_cached_impulses
+// would have done.  If an earlier kernel of the step found the assumption broken (st->still_fail), or body 0 is not inert, the kernel leaves before touching anything.
+template<int MAXC, bool FUSED, bool CONTIG = false, int NW = 4, bool STILL = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ? 2 : 1, MAXC == 4 ? 2 : 1))) void k_solve_one_body(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
                                                         const nh_BodyPair* __restrict__ bodies, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                         float4* __restrict__ states, uint32_t iterations,
@@ -860,14 +863,24 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 	const bool keep_states = !(require_inert & 2u);
 	if (nbodies == 0u) return;
 	// (the two words of device state -- is body 0 inert, how long is the cache -- are fetched beside the first round of loads, not before it)
-	const uint32_t inert_word = (require_inert & 1u) ? cv.st->static_inert : 1u;
+	uint32_t inert_word = (require_inert & 1u) ? cv.st->static_inert : 1u;
+	if (STILL) {
+		// (every workgroup reads the same words and comes to the same verdict)
+		const nh_BodyMomentum m0 = momentum[0];
+		const nh_BodyProperties p0 = props[0];
+		const bool inert = nh_is_inert(m0.velocity, m0.angular_velocity, p0.inertia_inverse, p0.mass_inverse);
+		if (!inert && blockIdx.x == 0 && threadIdx.x == 0) const_cast<nh_DevState*>(cv.st)->still_fail[fs.parity] = 1u;
+		if (!inert || cv.st->still_fail[fs.parity]) return;
+		inert_word = 1u;
+	}
 	__shared__ nh_ob_slot s_slot[NW][64 * M];
 	__shared__ uint32_t s_cid[NW][64 * M];
 	__shared__ uint32_t s_hint[NW][64], s_first[NW][64];
 	const uint32_t wave = threadIdx.x >> 6, lane = nh_lane();
 	nh_ob_slot* slot = s_slot[wave];
 	uint32_t* scid = s_cid[wave];
-	const uint32_t m = FUSED ? cv.st->cache : 0u;
+	const uint32_t m = (FUSED && !STILL) ? cv.st->cache : 0u;
+	nh_CachedContactImpulse* const out_impulses = STILL ? const_cast<nh_CachedContactImpulse*>(cv.cdata) : impulses;
 	const uint32_t rounded = (nbodies + (64u * NW - 1u)) / (64u * NW) * (64u * NW);
 	// block-uniform trip count; the CONTIG launch covers every body with one pass (no loop: nothing is carried in registers across iterations)
 	uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -883,7 +896,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		uint2 sp = make_uint2(0u, 0u);
 		uint32_t h = NH_HINT_NONE;
 		if (CONTIG) sp = simple[xc];
-		if (FUSED) h = hint[xc];
+		if (FUSED && !STILL) h = hint[xc];
 		if (!inert_word) return;
 		const bool mine = x < nbodies && (my_class == cls_a || my_class == cls_b);
 		const uint32_t wave_x0 = x - lane;
@@ -917,7 +930,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			sc1[k] = reinterpret_cast<const float4*>(contacts + c)[1];
 			// (CONTIG: the body's role in its one pair rides in simple[x], bit 28 -- no load of the body pair)
 			sflags[k] = (!CONTIG && bodies[c].a == wave_x0 + j) ? 2u : 0u;
-			if (FUSED) {
+			if (STILL) {
+				sw[k] = *reinterpret_cast<const float4*>(cv.cdata + c);
+			} else if (FUSED) {
 				const uint32_t hj = s_hint[wave][j];
 				sguess[k] = hj != NH_HINT_NONE ? hj + (sc[k] - s_first[wave][j]) : sc[k];
 				const uint32_t g = sguess[k] < m ? sguess[k] : 0u;
@@ -950,7 +965,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			if (sc[k] != 0xFFFFFFFFu) {
 				uint32_t flags = sflags[k];
 				o.c0 = sc0[k]; o.c1 = sc1[k];
-				if (FUSED) {
+				if (STILL) {
+					o.w = make_float4(sw[k].x, sw[k].y, sw[k].z, __uint_as_float(flags));
+				} else if (FUSED) {
 					const bool hit = sguess[k] < m && sctag[k] == stag[k] && scfeat[k] == sfeat[k];
 					if (!hit) flags |= 1u;
 					o.w = hit ? make_float4(sw[k].x, sw[k].y, sw[k].z, __uint_as_float(flags)) : make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(flags));
@@ -980,7 +997,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 				nh_build_row1(ci, posx, IX, v.mass_inverse, is_a[q], r[q]);
 				if (FUSED) {
 					float wx = o.w.x, wy = o.w.y, wz = o.w.z;
-					if (flags & 1u) {
+					if (!STILL && (flags & 1u)) {
 						const float4 found = cache_search(cv.ctags, cv.cfeatures, cv.cdata, m, h != NH_HINT_NONE ? h + (cid[q] - first) : cid[q], cv.tags[cid[q]], cv.features[cid[q]]);
 						wx = found.x; wy = found.y; wz = found.z;
 					}
@@ -990,7 +1007,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 				}
 			}
 		}
-		if (FUSED && mine) hint[x] = first;          // where this body's contacts start in what becomes the next step's cache
+		if (FUSED && !STILL && mine) hint[x] = first;          // where this body's contacts start in what becomes the next step's cache
 		// (CONTIG: a body's role is one bit for all its contacts, and in most scenes the static world is always "a": when no lane of the wave
 		// has D = a the role selects drop out of the sweep)
 		if (CONTIG && __builtin_amdgcn_ballot_w64(mine && ((sp.y >> 28) & 1u) != 0) == 0) {
@@ -1029,7 +1046,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			const uint32_t c = scid[e];
 			if (c != 0xFFFFFFFFu) {
 				if (keep_states) states[c] = slot[e].c0;
-				*reinterpret_cast<float4*>(impulses + c) = slot[e].c1;
+				*reinterpret_cast<float4*>(out_impulses + c) = slot[e].c1;
 			}
 		}
 		if (mine) {
@@ -1794,7 +1811,10 @@ extern "C" int nh_apply_gravity_damping(nh_context* ctx, const nh_ActiveBodies* 
                                         float time_step, const float gravity[3], float damping_rate) {
 	if (!ctx || !active_bodies || !bodies || !gravity) return NH_ERR_INVALID;
 	const bool follows_collide = ctx->gravity_may_overlap, after_collide = ctx->after_collide;
-	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	// (a still step stays speculative across the gravity call that directly follows its nh_collide on the same arrays -- the one the solver will fuse)
+	const bool in_sequence = ctx->still.active && !ctx->still.resolved && after_collide && !ctx->pending && bodies->momentum == ctx->still.bodies.momentum &&
+	                         active_bodies->indices == ctx->still.lay_active;
+	{ int rc = nh_flush_pending(ctx, false, in_sequence); if (rc) return rc; }
 	float damping = 1.0f - time_step * damping_rate;
 	if ((ctx->flags & NH_FLAG_FUSED_STEP) && after_collide) {
 		// applied by the fused solver when it loads a body (first_apply), by k_gravity_rest for the others; any other entry point settles it first
@@ -1852,7 +1872,13 @@ static void run_cull(nh_context* ctx, nh_ContactImpulseData* d, uint32_t sleepin
 
 extern "C" int nh_read_cached_impulses(nh_context* ctx, const nh_ContactCache* cache, const nh_ContactData* contacts, nh_Arena* memory, nh_ContactImpulseData** out) {
 	if (!ctx || !cache || !contacts || !memory || !out) return NH_ERR_INVALID;
-	{ int rc = nh_flush_pending(ctx, true); if (rc) return rc; }
+	{
+		// still step: only on the cache and the contact list it was launched for
+		const nh_StillStep& ss = ctx->still;
+		const bool in_sequence = ss.active && !ss.resolved && !ctx->pending && cache->tags == ss.cache_tags && cache->features == ss.cache_features && cache->data == ss.cache_data &&
+		                         cache->capacity == ss.cache_capacity && contacts->data == ss.lay_contacts.data && contacts->tags == ss.lay_contacts.tags;
+		int rc = nh_flush_pending(ctx, true, in_sequence); if (rc) return rc;
+	}
 	const uint32_t kcap = contacts->capacity, ccap = cache->capacity;
 	int err = NH_OK;
 	ctx->ring_pos++;
@@ -1904,6 +1930,15 @@ extern "C" const nh_CachedContactImpulse* nh_contact_impulses_device(const nh_Co
 extern "C" int nh_write_cached_impulses(nh_context* ctx, nh_ContactCache* cache, const nh_ContactData* contacts, nh_ContactImpulseData* imp) {
 	if (!ctx || !cache || !contacts || !imp) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	{
+		nh_StillStep& ss = ctx->still;
+		// a still step that went through: the solver has written every contact's impulse into its cache entry, tags and features are last step's -- nothing to do
+		if (ss.active && ss.resolved && cache->data == ss.cache_data && imp->ctx == ctx && imp->consumed) return NH_OK;
+		// a full step: afterwards the cache IS this step's contact list when nothing was culled (the round trip has told) -- what the next still step relies on
+		ss.cache_ok = imp->consumed && !imp->cull_pending && !(ctx->flags & NH_FLAG_SYNC_COUNTS) && ctx->h_state->sleeping == 0u && ctx->h_state->culled == 0u &&
+		              contacts->data == ss.lay_contacts.data && contacts->tags == ss.lay_contacts.tags;
+		ss.cache_tags = cache->tags; ss.cache_features = cache->features; ss.cache_data = cache->data; ss.cache_capacity = cache->capacity;
+	}
 	if (!imp->consumed) materialize_lookup(ctx, imp);      // no setup ran on this handle: the cache is rewritten from the looked-up impulses
 	if (imp->cull_pending) {
 		nh_Counts c;
@@ -1928,7 +1963,12 @@ extern "C" int nh_write_cached_impulses(nh_context* ctx, nh_ContactCache* cache,
 extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodies* active_bodies, const nh_ContactData* contacts,
                                             const nh_BodyData* bodies, nh_ContactImpulseData* imp, nh_Arena* memory, nh_ContactConstraintData** out) {
 	if (!ctx || !contacts || !bodies || !imp || !memory || !out) return NH_ERR_INVALID;
-	{ int rc = nh_flush_pending(ctx, true); if (rc) return rc; }
+	{
+		const nh_StillStep& ss = ctx->still;
+		const bool in_sequence = ss.active && !ss.resolved && !ctx->pending && contacts->data == ss.lay_contacts.data && contacts->bodies == ss.lay_contacts.bodies &&
+		                         bodies->momentum == ss.bodies.momentum && bodies->transforms == ss.bodies.transforms && bodies->count == ss.bodies.count && imp->ctx == ctx && !imp->consumed;
+		int rc = nh_flush_pending(ctx, true, in_sequence); if (rc) return rc;
+	}
 	(void)active_bodies;
 	nh_DevState* st = ctx->d_state;
 	const uint32_t kcap = contacts->capacity;
@@ -1944,8 +1984,9 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	ctx->setup_seq = ctx->collide_seq;
 	d->body_off = nh_arena_array<uint32_t>(memory, (size_t)B + 2u, &err);           // CSR offsets (scan of the degrees nh_collide counted)
 	d->adj = nh_arena_array<uint32_t>(memory, (size_t)kcap * 2, &err);
-	d->body_class = nh_arena_array<uint8_t>(memory, B, &err);
-	d->simple = nh_arena_array<uint2>(memory, B, &err);
+	if (!ctx->lay_class || ctx->lay_body_capacity < B) return NH_ERR_INVALID;        // (sized by this step's nh_collide)
+	d->body_class = ctx->lay_class;          // library-owned: a still step reads what the last full step's k_adj_simple left here
+	d->simple = ctx->lay_simple;
 	d->level_order = nh_arena_array<uint32_t>(memory, kcap, &err);
 	d->gpair = nh_arena_array<uint2>(memory, kcap, &err);
 	d->gstates = nh_arena_array<float4>(memory, kcap, &err);
@@ -1976,6 +2017,8 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 		NH_LAUNCH(ctx, "order_check", k_order_check, nh_grid_for(kcap / 8u + 16u, 256, 1024), 256, st, contacts->bodies, slot_key, seq);
 		NH_LAUNCH(ctx, "greedy_replay", k_greedy_replay, 1, 64, st, contacts->bodies, slot_key, seq, spill_ab, spill_idx, spill_cap);
 	}
+	if (ctx->still.active && !ctx->still.resolved) ctx->still.setup_d = d;      // still step: classes and records are last step's (nh_still_abandon launches the kernel if it comes to that)
+	else
 	NH_LAUNCH(ctx, "adjacency_simple", k_adj_simple, nh_grid_for(B, 256, 4096), 256, st, B, ctx->deg, reinterpret_cast<const unsigned long long*>(ctx->deg + 2u * NH_DEG_STRIDE(B)), ctx->deg + 4u * NH_DEG_STRIDE(B), slot_key,
 	          d->body_class, bodies->properties, bodies->momentum, d->simple);
 	if (ctx->hint_capacity < B) {
@@ -2224,6 +2267,13 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 	if (rc) return rc;
 	if (c.error) return (int)c.error;
 	d->has_late = ctx->h_state->has_pending != 0;
+	{
+		// may the NEXT step be launched as a still step?  (nh_internal.h: nh_StillStep)  This step laid its contacts out in a layout a still step can write through, every
+		// dynamic body sits in one pair with an inert static world (the fused solver owns them all), nothing sleeps, nothing was culled
+		const nh_DevState* h = ctx->h_state;
+		ctx->still.ok_next = h->lay_valid && !h->has_other && h->static_inert && !h->has_pending && !h->has_static8 && !h->has_staticN && !h->any_sleeping && h->sleeping == 0u &&
+		                     h->culled == 0u && h->general_contacts == 0u && !h->error && h->contacts != 0u;
+	}
 	// NH_FLAG_FUSED_STEP: gravity / damping of the bodies the fused solver does not own, before anything else reads their momentum -- not launched
 	// at all when every body is the fused solver's (a landed drop scene)
 	ctx->adv.rest = ctx->h_state->has_other != 0 || !ctx->h_state->static_inert;
@@ -2438,6 +2488,41 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 	const bool from_apply = applied && (ctx->flags & NH_FLAG_FUSED_STEP), drop_states = applied && (ctx->flags & NH_FLAG_SINGLE_APPLY);
 	d->states_kept = !drop_states;
 	bool early4_done = false;
+	if (ctx->still.active && !ctx->still.resolved) {
+		// ---- still step: ONE launch, then the round trip that confirms it ----
+		nh_StillStep& ss = ctx->still;
+		const bool usable = applied && from_apply && drop_states && iterations != 0u && d->finish_pending && ss.setup_d == d && ctx->grav.pending && ctx->grav.momentum == bodies->momentum &&
+		                    bodies->idle_counters && bodies->momentum == ss.bodies.momentum && bodies->transforms == ss.bodies.transforms && d->imp->cdata == ss.cache_data;
+		bool confirmed = false;
+		if (usable) {
+			const uint32_t B = d->body_count;
+			nh_CacheView cv = { d->imp->tags, d->imp->features, d->imp->ctags, d->imp->cfeatures, d->imp->cdata, ctx->d_state };
+			nh_FusedStep fs = nh_FusedStep();
+			fs.gx_dt = ctx->grav.gx_dt; fs.gy_dt = ctx->grav.gy_dt; fs.gz_dt = ctx->grav.gz_dt; fs.damping = ctx->grav.damping; fs.time_step = ctx->grav.time_step;
+			fs.bits = 3u; fs.idle = bodies->idle_counters; fs.parity = ctx->step_parity;
+#define NH_SOLVE_STILL(NWAVES) NH_LAUNCH(ctx, "solve_one_body", (k_solve_one_body<4, true, true, NWAVES, true>), (B + 64u * NWAVES - 1u) / (64u * NWAVES), 64 * NWAVES, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum, \
+		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fs)
+			if (ctx->env_solver_waves == 4) NH_SOLVE_STILL(4); else if (ctx->env_solver_waves == 2) NH_SOLVE_STILL(2); else NH_SOLVE_STILL(1);
+			// the step's one round trip: did every check hold?
+			NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, NH_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+			NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+			if (ctx->timing) nh_timer_collect(ctx);
+			confirmed = ctx->h_state->still_fail[ctx->step_parity] == 0u && ctx->h_state->error == 0u;
+		}
+		if (confirmed) {
+			nh_Counts c;
+			nh_counts_from_mirror(ctx, &c);              // (the sleep prediction: largest idle counter this step saw)
+			ss.resolved = true; ss.setup_d = nullptr;
+			d->finish_pending = false; d->has_late = false; d->has_static8 = d->has_staticN = false; d->static_inert = true; d->general_contacts = 0; d->levels = 0;
+			d->imp->cull_pending = false; d->imp->lookup_pending = false;
+			ctx->last_general_contacts = 0;
+			ctx->grav.pending = false; ctx->grav.rest_pending = false;
+			ctx->adv.done = true; ctx->adv.time_step = ctx->grav.time_step; ctx->adv.body_class = d->body_class; ctx->adv.rest = false;
+			return NH_OK;
+		}
+		// not a still step after all (a check failed on the device, or the caller left the sample's order): the step again, in full
+		{ int rc = nh_still_abandon(ctx); if (rc) return rc; }
+	}
 	if (!d->finish_pending) { int rc = settle_gravity(ctx); if (rc) return rc; }
 	if (d->finish_pending) {
 		d->finish_pending = false;
@@ -2465,7 +2550,27 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 	return NH_OK;
 }
 
-int nh_flush_pending(nh_context* ctx, bool keep_gravity) {
+int nh_still_collide_again(nh_context* ctx);       // nh_collide.hip
+
+// A still step that has not been confirmed, met by anything but the next call of the sample's order (or failed on the device): the step is launched again in full.
+int nh_still_abandon(nh_context* ctx) {
+	nh_StillStep& ss = ctx->still;
+	if (!ss.active || ss.resolved || ss.replaying) return NH_OK;
+	nh_ContactConstraintData* d = ss.setup_d;
+	ss.setup_d = nullptr;
+	int rc = nh_still_collide_again(ctx);
+	if (rc) return rc;
+	if (d) {
+		// the adjacency kernel the still setup left out (default order only: still steps are not launched in exact-order mode)
+		const uint32_t B = d->body_count;
+		NH_LAUNCH(ctx, "adjacency_simple", k_adj_simple, nh_grid_for(B, 256, 4096), 256, ctx->d_state, B, ctx->deg, reinterpret_cast<const unsigned long long*>(ctx->deg + 2u * NH_DEG_STRIDE(B)),
+		          ctx->deg + 4u * NH_DEG_STRIDE(B), (const uint32_t*)nullptr, d->body_class, d->bodies_at_setup.properties, d->bodies_at_setup.momentum, d->simple);
+	}
+	return NH_OK;
+}
+
+int nh_flush_pending(nh_context* ctx, bool keep_gravity, bool in_sequence) {
+	if (!in_sequence) { int rc = nh_still_abandon(ctx); if (rc) return rc; }
 	ctx->gravity_may_overlap = false;            // some entry point other than nh_collide is enqueueing work: gravity no longer "directly follows" it
 	ctx->after_collide = false;
 	nh_ContactConstraintData* d = ctx->pending;
@@ -2485,6 +2590,7 @@ int nh_flush_pending(nh_context* ctx, bool keep_gravity) {
 extern "C" int nh_apply_impulses(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations) {
 	if (!ctx || !d || !bodies) return NH_ERR_INVALID;
 	if (ctx->pending && ctx->pending != d) { int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	if (ctx->still.active && !ctx->still.resolved && !(ctx->pending == d && d->setup_pending)) { int rc = nh_still_abandon(ctx); if (rc) return rc; }
 	ctx->gravity_may_overlap = false; ctx->after_collide = false;
 	const bool first = d->setup_pending;
 	if (!first && !d->states_kept) return NH_ERR_INVALID;      // NH_FLAG_SINGLE_APPLY: the states of the first call were not kept

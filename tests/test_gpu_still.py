@@ -1,0 +1,151 @@
+"""Still steps (include/nudge_hip.h note 9; nudge_amd/csrc/nh_internal.h: nh_StillStep) on the GPU (pytest -m gpu).
+
+A step that follows a step which left the world at rest on static geometry is launched speculatively with three kernels that check what they rely on; when a
+check fails the step is run again in full.  Whatever happens, a library that speculates must leave the same bits as one that never does (NH_NO_STILL=1), and
+as the compiled reference: these tests drive worlds through both, through the transitions in and out of the still regime and through every way of leaving the
+sample's call order in the middle of a speculative step."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import parity_util as P                      # noqa: E402
+from nudge_amd import engine as E           # noqa: E402
+from nudge_amd import scenes as S           # noqa: E402
+from oracle import refworld                 # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+BENCH_FLAGS = E.NH_FLAG_SINGLE_APPLY | E.NH_FLAG_FUSED_STEP
+
+
+def _world(scene, still, flags=BENCH_FLAGS, **kw):
+    if not still:
+        os.environ["NH_NO_STILL"] = "1"
+    try:
+        return E.World(scene, flags=flags, **kw)
+    finally:
+        os.environ.pop("NH_NO_STILL", None)
+
+
+def _same_world(a, b, what=""):
+    ba, bb = a.get_bodies(), b.get_bodies()
+    assert P.bits_equal(ba["transforms"], bb["transforms"]), f"{what}: transforms differ"
+    assert P.bits_equal(ba["momentum"], bb["momentum"]), f"{what}: momentum differs"
+    assert np.array_equal(ba["idle"], bb["idle"]), f"{what}: idle counters differ"
+    ca, cb = a.get_cache(), b.get_cache()
+    assert ca["count"] == cb["count"], f"{what}: cache count {ca['count']} vs {cb['count']}"
+    assert np.array_equal(ca["tags"], cb["tags"]) and np.array_equal(ca["features"], cb["features"]), f"{what}: cache tags differ"
+    assert P.bits_equal(ca["data"]["impulse"], cb["data"]["impulse"]), f"{what}: cached impulses differ"
+    ka, kb = a.get_contacts(), b.get_contacts()
+    assert ka["count"] == kb["count"], f"{what}: contact count"
+    assert np.array_equal(ka["tags"], kb["tags"]) and np.array_equal(ka["features"], kb["features"]) and np.array_equal(ka["bodies"], kb["bodies"]), f"{what}: contact identities differ"
+    assert P.bits_equal(ka["data"], kb["data"]), f"{what}: contact data differ"
+
+
+@pytest.mark.parametrize("sphere_fraction", [0.0, 0.5])
+def test_still_steps_leave_the_bits_of_full_steps_through_fall_rest_and_sleep(sphere_fraction):
+    """A drop scene from free fall to sleep: the speculating library against the one that never speculates, checkpoint by checkpoint, bit for bit (bodies, idle
+    counters, contacts, cache), and both against the compiled reference.  At rest nearly every step must have gone through as a still step."""
+    scene = S.grid_tiles(2, side=40, sphere_fraction=sphere_fraction, seed=31, lattice_cols=2)
+    a, b = _world(scene, True), _world(scene, False)
+    done = 0
+    for cp in (30, 70, 100, 200, 290, 330, 420):
+        a.step(cp - done); b.step(cp - done); done = cp
+        _same_world(a, b, f"step {cp}")
+    ca, cb = a.counts(), b.counts()
+    assert ca["error"] == 0 and cb["error"] == 0
+    assert cb["still_steps"] == 0 and cb["still_replays"] == 0
+    # landed by ~70, asleep from ~300: two hundred steps at rest, all but the few after a checkpoint's counts() still
+    print(f"\n[still steps, spheres {sphere_fraction}] {ca['still_steps']} still steps, {ca['still_replays']} replays of 420")
+    assert ca["still_steps"] >= 150, ca
+    if refworld.available("exact") and S.narrow_ok(scene):
+        r = refworld.RefWorld(scene, max_contacts=8 * len(scene["body_transforms"]))
+        r.step(420)
+        rb, gb = r.bodies(), a.get_bodies()
+        assert P.bits_equal(gb["transforms"], rb["transforms"]) and P.bits_equal(gb["momentum"]["velocity"], rb["momentum"]["velocity"])
+        assert np.array_equal(gb["idle"], rb["idle"])
+    a.close(); b.close()
+
+
+def test_a_kick_in_the_middle_of_rest_fails_the_checks_and_is_replayed():
+    """Bodies at rest, every step a still step; then the caller rewrites a few velocities (no nh_bodies_changed: momentum is the caller's to write).  The bodies leave
+    their inflated boxes / change their contacts a few steps later: a still step's checks fail on the device, it is replayed in full, the world goes on exactly
+    like the one that never speculates -- and returns to still steps once it is at rest again."""
+    scene = S.grid_tiles(1, side=32, seed=37)
+    a, b = _world(scene, True), _world(scene, False)
+    a.step(120); b.step(120)
+    c0 = a.counts()
+    assert c0["still_steps"] > 20, c0
+    for w in (a, b):
+        m = w.get_bodies()["momentum"]
+        m["velocity"][5::97, 1] = 4.0                    # a hop
+        m["velocity"][11::131, 0] = 1.5                  # a shove along the ground
+        w.set_bodies(momentum=m)
+    a.step(100); b.step(100)
+    _same_world(a, b, "after the kick")
+    c1 = a.counts()
+    assert c1["still_replays"] > c0["still_replays"], (c0, c1)
+    assert c1["still_steps"] > c0["still_steps"] + 10, (c0, c1)        # ... and back to still steps afterwards
+    a.close(); b.close()
+
+
+def test_leaving_the_call_order_inside_a_speculative_step():
+    """Every entry point outside collide / gravity / read / setup / apply turns an unconfirmed still step into a full one before it looks at anything: counts and
+    contacts read between nh_collide and the solver are a full step's, and the step ends in the same bits."""
+    scene = S.grid_tiles(1, side=24, seed=41)
+    a, b = _world(scene, True), _world(scene, False)
+    a.step(100); b.step(100)
+    assert a.counts()["still_steps"] > 10
+    a.step(2); b.step(2)                                   # (the step after counts() is a full one; the next is still again)
+
+    def step_with(w, hook_at):
+        w.collide()
+        if hook_at == 0: seen = (w.counts(), w.get_contacts())
+        w.gravity()
+        if hook_at == 1: seen = (w.counts(), w.get_contacts())
+        w.read_cache()
+        if hook_at == 2: seen = (w.counts(), w.get_contacts())
+        w.setup()
+        if hook_at == 3: seen = (w.counts(), w.get_contacts())
+        w.apply(); w.update(); w.write_cache(); w.advance(); w.step_done()
+        return seen
+
+    for hook_at in (0, 1, 2, 3, 0):
+        sa, sb = step_with(a, hook_at), step_with(b, hook_at)
+        assert sa[0]["contacts"] == sb[0]["contacts"] and sa[0]["pairs"] == sb[0]["pairs"] and sa[0]["active_bodies"] == sb[0]["active_bodies"]
+        assert np.array_equal(sa[1]["tags"], sb[1]["tags"]) and P.bits_equal(sa[1]["data"], sb[1]["data"])
+        _same_world(a, b, f"hook {hook_at}")
+        a.step(3); b.step(3)                               # back into the still regime before the next hook
+        _same_world(a, b, f"after hook {hook_at}")
+    ca = a.counts()
+    assert ca["still_replays"] >= 4, ca
+    a.close(); b.close()
+
+
+def test_snapshot_restore_and_set_cache_count_leave_the_still_regime():
+    """bench.py restores a device snapshot (bodies + cache) between its timed blocks: the step after must look at everything again."""
+    scene = S.grid_tiles(1, side=24, seed=43)
+    a, b = _world(scene, True), _world(scene, False)
+    a.step(90); b.step(90)
+    sa, sb = a.snapshot(), b.snapshot()
+    a.step(25); b.step(25)
+    _same_world(a, b, "before restore")
+    a.restore(sa); b.restore(sb)
+    a.step(25); b.step(25)
+    _same_world(a, b, "after restore")
+    assert a.counts()["still_steps"] > 30
+    a.close(); b.close()
+
+
+def test_still_steps_in_a_world_with_a_pile_never_start():
+    """Bodies that touch each other are not the fused solver's: no step of such a world may be launched as a still step."""
+    scene = S.pile(n_boxes=200, n_spheres=50, seed=3)
+    a, b = _world(scene, True), _world(scene, False)
+    a.step(200); b.step(200)
+    _same_world(a, b, "pile")
+    c = a.counts()
+    assert c["still_steps"] == 0 and c["still_replays"] == 0 and c["general_contacts"] > 0, c
+    a.close(); b.close()
