@@ -192,6 +192,8 @@ typedef struct nh_Counts {
 	                               since nh_create */
 	uint32_t still_steps;       /* steps since nh_create that went through as STILL steps (note 9): launched as a world whose contact layout is last step's, and confirmed */
 	uint32_t still_replays;     /* ... launched as one, found otherwise (by the device or because the caller left the sample's call order) and run again in full */
+	uint32_t still_diff[4];     /* what still steps have found changed, summed since nh_create: collider pairs with another key / another contact count / other feature words;
+	                               colliders outside their inflated box or bodies asleep (diagnostic) */
 } nh_Counts;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */
@@ -271,6 +273,67 @@ int nh_halo_unpack(nh_context* ctx, const nh_BodyData* bodies, uint32_t first_sl
    per-step halo; nh_halo_unpack is for slots that change hands: refresh, migration).  The difference is the library's sleep prediction (see
    nh_bodies_changed): idle counters rise by at most one per step on the owner as they do here, so an update does not invalidate it. */
 int nh_halo_update(nh_context* ctx, const nh_BodyData* bodies, uint32_t first_slot, uint32_t count, const void* in);
+
+/* ---- multi-GPU: one x-slab of a world per context ------------------------------------------------------------------------------------
+   The world is cut into slabs along x, one rank (process, GPU, nh_context) per slab [lo, hi).  A rank's arrays hold
+       body slot 0            the static world with the static colliders the rank keeps (front of the collider arrays),
+       slots 1 .. n_owned     the dynamic bodies whose centre lies in the slab: authoritative here,
+       the tail               GHOSTS: copies of neighbour-owned bodies that may touch something owned here (left neighbour's first),
+   and one collider per dynamic body, in body-slot order behind the static ones.  An `nh_partition` keeps the per-body collider description
+   (shape, local transform, tag, kind), the slab, and the lists of who is sent where; everything below is device work on the context's
+   stream with device-side counts -- what the host gets back are the message lengths it needs to post the messages.  TRANSPORT IS THE CALLER'S:
+   records are written to / read from caller-provided device buffers (ncclSend / ncclRecv, torch.distributed ...);
+   nudge_amd/partition.py and examples/partition_rccl.cpp are two such transports over these entry points.
+     every `epoch` steps (and at step 0), REFRESH:
+        [optional: re-balance -- nh_partition_choose_cut / nh_partition_set_cut]
+        nh_partition_pack_migrants  -> exchange -> nh_partition_unpack_migrants     (bodies whose centre left the slab change owner)
+        nh_partition_pack_ghosts    -> exchange -> nh_partition_unpack_ghosts       (owned bodies that can reach across a cut within the epoch; collider arrays rebuilt)
+     every other step:
+        nh_partition_pack_step      -> exchange -> nh_partition_unpack_step         (64-byte records of the listed bodies, fixed lengths)
+   Reference counterpart: none (the reference is single-threaded); the contact identity that makes this work is the collider TAG
+   (nudge.h:86, 93; nudge.cpp:2074-2087), which travels with a body.  A dynamic body carries exactly one collider. */
+#define NH_PARTITION_FULL_BYTES 136      /* transform 32 | properties 16 | momentum 32 | shape 16 | collider transform 32 | tag 4 | kind 1, idle 1, pad 2 */
+typedef struct nh_partition nh_partition;
+typedef struct nh_PartitionConfig {
+	uint32_t rank, ranks;
+	double lo, hi;                                      /* the slab along x; -HUGE_VAL / HUGE_VAL at the two ends */
+	uint32_t n_owned;                                   /* dynamic bodies in slots 1 .. n_owned at creation */
+	uint32_t n_static_box, n_static_sph;                /* static colliders at the front of the collider arrays (never touched) */
+	uint32_t body_capacity, box_capacity, sphere_capacity;   /* records the caller's arrays have room for */
+	uint32_t epoch;                                     /* steps between two refreshes */
+	double time_step, gravity, speed_floor;             /* how far a body can travel in an epoch: epoch dt (max(top speed, floor) + g epoch dt) */
+	double max_reach;                                   /* largest distance from a body origin to the far side of its collider, over the WHOLE world */
+	double cut_slack;                                   /* a cut never moves further than this from where it started (static colliders kept); HUGE_VAL = unlimited */
+} nh_PartitionConfig;
+typedef struct nh_PartitionInfo {
+	uint32_t n_owned, n_bodies, n_boxes, n_spheres;     /* bodies = 1 + owned + ghosts; colliders incl. the static ones */
+	uint32_t ghost_out[2], ghost_in[2];                 /* [0] left neighbour, [1] right neighbour: bodies listed for / received from it at the last refresh */
+	double lo, hi;
+	uint64_t migrated_out, migrated_in, refreshes, cut_moves;
+} nh_PartitionInfo;
+/* `bodies` / `colliders`: the rank's arrays as they are at creation (1 + n_owned bodies, static + one collider per dynamic body, Transform.body = body slot). */
+int nh_partition_create(nh_partition** out, nh_context* ctx, const nh_PartitionConfig* config, const nh_BodyData* bodies, const nh_ColliderData* colliders);
+void nh_partition_destroy(nh_partition* p);
+int nh_partition_info(nh_partition* p, nh_PartitionInfo* out);
+/* Refresh, phase 1.  pack: full records of the owned bodies whose centre is left of lo -> out_left, right of (or on) hi -> out_right (device buffers of `capacity_records`
+   records each; either may be NULL at an end of the row); counts[0..1] = records written (the call synchronises the stream once to tell).
+   unpack: the leavers are dropped (owned bodies stay in slot order), the arrivals appended, left neighbour's first; ghosts are gone until phase 2. */
+int nh_partition_pack_migrants(nh_partition* p, const nh_BodyData* bodies, void* out_left, void* out_right, uint32_t capacity_records, uint32_t counts[2]);
+int nh_partition_unpack_migrants(nh_partition* p, const nh_BodyData* bodies, const void* in_left, uint32_t n_left, const void* in_right, uint32_t n_right);
+/* Refresh, phase 2.  pack: the owned bodies within reach of a cut for the coming epoch are listed (the lists are kept for the per-step records) and their full
+   records written.  unpack: the received ghosts are installed behind the owned bodies, the collider arrays rebuilt (static ones, then one per dynamic body in
+   slot order), `bodies->count` and the collider counts of the caller's structs set, and the context told that body records changed (nh_bodies_changed). */
+int nh_partition_pack_ghosts(nh_partition* p, const nh_BodyData* bodies, void* out_left, void* out_right, uint32_t capacity_records, uint32_t counts[2]);
+int nh_partition_unpack_ghosts(nh_partition* p, nh_BodyData* bodies, nh_ColliderData* colliders, const void* in_left, uint32_t n_left, const void* in_right, uint32_t n_right);
+/* Every other step: NH_HALO_RECORD_BYTES per listed body (nh_halo_pack's record); lengths are those of the last refresh (nh_partition_info: ghost_out / ghost_in). */
+int nh_partition_pack_step(nh_partition* p, const nh_BodyData* bodies, void* out_left, void* out_right);
+int nh_partition_unpack_step(nh_partition* p, const nh_BodyData* bodies, const void* in_left, const void* in_right);
+/* Re-balancing ("move cuts when |count_r - mean| > 5 %").  The two ranks at a cut tell each other how many bodies they own (transport: caller); when the
+   counts differ by more than `tolerance` of their sum the HEAVIER side calls nh_partition_choose_cut(direction, neighbour's count) -- the x that hands half the
+   difference, at most 5 % of its bodies, to the neighbour; it moves its own cut and returns it -- and sends the value over; the lighter side calls nh_partition_set_cut.
+   The bodies in between migrate with the refresh that follows.  direction: -1 = the cut towards the left neighbour, +1 = towards the right. */
+int nh_partition_choose_cut(nh_partition* p, const nh_BodyData* bodies, int direction, uint32_t neighbour_owned, double* cut);
+int nh_partition_set_cut(nh_partition* p, int direction, double cut);
 
 /* ---- introspection for tests / measurement --------------------------------------------------------- */
 /* Device pointer to the per-contact warm-start impulses of an nh_ContactImpulseData (K x 16 B, contact order). */

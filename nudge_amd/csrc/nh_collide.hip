@@ -161,7 +161,7 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 		if ((threadIdx.x & 63) == 0) { atomicMin(&red[k], lmin[k]); atomicMax(&red[3 + k], lmax[k]); if (!STILL) { atomicMin(&red[6 + k], gmn[k]); atomicMax(&red[9 + k], gmx[k]); } }
 	}
 	if (STILL) {
-		if (__ballot(escaped) != 0ull && nh_lane() == 0) st->still_fail[parity] = 1u;
+		{ const unsigned long long esc = __ballot(escaped); if (esc != 0ull && nh_lane() == 0) { st->still_fail[parity] = 1u; atomicAdd(&st->still_diff[3], (uint32_t)__popcll(esc)); } }
 		__syncthreads();
 		if (threadIdx.x < 3) { atomicMin(&st->still_smin[parity][threadIdx.x], red[threadIdx.x]); atomicMax(&st->still_smax[parity][threadIdx.x], red[3 + threadIdx.x]); }
 		return;
@@ -983,8 +983,10 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			if (STILL) {
 				if (i < n) {
 					const uint32_t ls = lay_start[ri];
-					const bool same = rec_key[ri] == key && (ls >> 28) == (uint32_t)count && (!count || lay_feat[ri].x == single.feature);
+					const bool same_key = rec_key[ri] == key, same_count = (ls >> 28) == (uint32_t)count;
+					const bool same = same_key && same_count && (!count || lay_feat[ri].x == single.feature);
 					changed |= !same;
+					if (!same) atomicAdd(&st->still_diff[!same_key ? 0 : (!same_count ? 1 : 2)], 1u);
 					const uint32_t d = ls & 0x0FFFFFFFu;
 					if (same && count && d < capacity) {
 						float4* dp = reinterpret_cast<float4*>(data + d);
@@ -1071,10 +1073,12 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 				const uint32_t ls = lay_start[ri];
 				const uint4 fe = lay_feat[ri];
 				const uint32_t f[4] = { w_f[4u * lane], w_f[4u * lane + 1u], w_f[4u * lane + 2u], w_f[4u * lane + 3u] }, g[4] = { fe.x, fe.y, fe.z, fe.w };
-				bool same = rec_key[ri] == key && (ls >> 28) == (uint32_t)count && count <= 4;
+				const bool same_key = rec_key[ri] == key, same_count = (ls >> 28) == (uint32_t)count && count <= 4;
+				bool same = same_key && same_count;
 #pragma unroll
 				for (int k = 0; k < 4; ++k) same = same && (k >= count || f[k] == g[k]);
 				changed |= !same;
+				if (!same) atomicAdd(&st->still_diff[!same_key ? 0 : (!same_count ? 1 : 2)], 1u);            // (statistics; rare by construction)
 				if (same) { cnt_ok = (uint32_t)count; first = ls & 0x0FFFFFFFu; }
 				if (same) {
 					// slot of every rank (two bits each): the write-out below fetches a record's contacts in rank order

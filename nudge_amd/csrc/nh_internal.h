@@ -76,7 +76,8 @@ struct nh_DevState {
 	uint32_t lay_valid;                   // the kept layout (per record: first contact | count, feature words; per body: class + contact list record) describes the contact
 	                                      // list the last FULL step laid out, and that step met the conditions a still step relies on (k_gather_contacts)
 	uint32_t still_steps;                 // still steps that went through, since nh_create (statistics)
-	// ---- (the 32 words above are what nh_read_counts mirrors to the host: NH_COUNTER_WORDS) ----
+	uint32_t still_diff[4];               // why the last still step that failed did: records whose key / contact count / feature words differed, colliders outside their boxes or bodies asleep (statistics)
+	// ---- (the 36 words above are what nh_read_counts mirrors to the host: NH_COUNTER_WORDS) ----
 	// Temporal coherence of the broadphase (nh_collide.hip, "kept pair list"): the grid search runs over AABBs inflated by `fat_margin` and its
 	// pairs are KEPT; while every collider's AABB stays inside its inflated box the kept list is a superset of the overlapping pairs and one filter
 	// pass (exact AABBs, exact test) replaces the whole regrouping + search.
@@ -273,7 +274,7 @@ struct nh_context {
 int nh_flush_pending(nh_context* ctx, bool keep_gravity = false, bool in_sequence = false);
 int nh_still_abandon(nh_context* ctx);
 void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out);
-#define NH_COUNTER_WORDS 32u          // leading words of nh_DevState that the host mirrors (nh_read_counts)
+#define NH_COUNTER_WORDS 36u          // leading words of nh_DevState that the host mirrors (nh_read_counts)
 
 struct nh_ContactImpulseData {
 	nh_CachedContactImpulse* data;        // K, contact (tag) order; holds the warm-start impulses once `lookup_pending` is false

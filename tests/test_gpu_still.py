@@ -86,6 +86,8 @@ def test_a_kick_in_the_middle_of_rest_fails_the_checks_and_is_replayed():
         w.set_bodies(momentum=m)
     a.step(100); b.step(100)
     _same_world(a, b, "after the kick")
+    a.step(150); b.step(150)                               # (the kicked boxes slide and rock for a while)
+    _same_world(a, b, "at rest again")
     c1 = a.counts()
     assert c1["still_replays"] > c0["still_replays"], (c0, c1)
     assert c1["still_steps"] > c0["still_steps"] + 10, (c0, c1)        # ... and back to still steps afterwards
