@@ -859,16 +859,16 @@ __global__ __launch_bounds__(256) void k_kept_filter(nh_DevState* __restrict__ s
 // ---- 6. narrowphase -----------------------------------------------------------------------------------------
 // raw contacts are appended in arbitrary order; one record per pair that produced contacts.
 // record i belongs to pair i: its first 4 contacts sit at raw[4*i .. 4*i+3], further ones in the overflow area
-struct nh_Record { uint32_t body_a, body_b, overflow, count; };
-#define NH_REC_SLEEPING 0x80000000u
+// (struct nh_Record, NH_REC_SLEEPING: nh_internal.h -- the records are library-owned and outlive the step)
 
 // SPH = false: the box-box pairs (front of `pairs`, records 0 .. n_bb-1); SPH = true: the pairs with a sphere (back of `pairs`, records
 // n_bb .. n_bb+n_sph-1).  Record r owns the raw contact slots 4r .. 4r+3 either way (a sphere pair uses the first one).
 // STILL (nh_collide, "9. still steps"): the pairs are taken straight from the KEPT list (what k_kept_filter does in place: exact AABB test, bodies,
-// stamps, roles by Morton order -- a kept pair's position is its record's), the result is COMPARED with the layout the last full step left (key by record
-// position, contact count and feature words per record: lay_start / lay_feat) and, being the same, written where it belongs in the caller's contact list --
-// data[first contact of the record + rank by feature] -- whose pair / tag / feature arrays still hold.  Anything else raises st->still_fail: no record,
-// no raw slot, no key is written, the step is replayed in full.
+// stamps, roles by Morton order -- a kept pair's position is its record's) and the contacts go to the record's own raw slots like in a full step: a pair that
+// gains or loses a contact moves nobody else's data.  What a still step RELIES on is checked -- the record's key is what it was (tag order unchanged), at most
+// four contacts, a pair with contacts joins a dynamic body to the static world and is the one pair that body's solver lane knows (body_rec) -- and raises
+// st->still_fail otherwise: the step is replayed in full.  The record's count goes to its place in the tag order (cnt_sorted): one scan later every record
+// knows where its contacts sit in the dense list.
 template<bool SPH, bool STILL>
 __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ st, const uint2* __restrict__ pairs,
                                                      const nh_xform* __restrict__ xf, const uint32_t* __restrict__ ctag,
@@ -876,10 +876,10 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
                                                      nh_Contact* __restrict__ raw_data, uint32_t* __restrict__ raw_feature, uint32_t pair_cap, uint32_t overflow_cap,
                                                      uint64_t* __restrict__ rec_key, nh_Record* __restrict__ rec, uint32_t* __restrict__ rec_idx,
                                                      const uint32_t* __restrict__ coarse_root, const uint32_t* __restrict__ coarse_active, uint32_t parity,
-                                                     uint32_t* __restrict__ lay_start, uint4* __restrict__ lay_feat,
-                                                     // STILL only: the kept list (`pairs`) and its capacity, this step's exact AABBs, the stamps, the caller's contact list
+                                                     // STILL only: the kept list (`pairs`) and its capacity, this step's exact AABBs, the stamps, tag-order positions / counts, the bodies' records
                                                      uint32_t kept_cap = 0u, const float4* __restrict__ aabb_min = nullptr, const float4* __restrict__ aabb_max = nullptr,
-                                                     const uint8_t* __restrict__ gen = nullptr, nh_Contact* __restrict__ data = nullptr, uint32_t capacity = 0u) {
+                                                     const uint8_t* __restrict__ gen = nullptr, const uint32_t* __restrict__ lay_rank = nullptr, uint32_t* __restrict__ cnt_sorted = nullptr,
+                                                     const uint32_t* __restrict__ body_rec = nullptr) {
 	// coarse islands (nudge.cpp:3500-3703): a pair whose bodies belong to a set of sleeping bodies (sets over the BROADPHASE pairs and the
 	// user's connections) never reaches the narrowphase: it becomes a sleeping pair, larger tag in the low half (3697)
 	const bool some_asleep = !STILL && st->any_idle[parity] != 0;
@@ -887,8 +887,6 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 	__shared__ float4 s_c0[NS][256], s_c1[NS][256];
 	__shared__ uint32_t s_f[NS][256];
 	__shared__ uint8_t s_n[NS][64];
-	__shared__ uint32_t s_start[STILL && !SPH ? 4 : 1][64];
-	__shared__ uint8_t s_perm[STILL && !SPH ? 4 : 1][64];
 	const uint32_t n_bb = min(st->pairs, pair_cap), n_sph = min(st->pairs_sph, pair_cap - n_bb);
 	if (!STILL && blockIdx.x == 0 && threadIdx.x == 0) {
 		st->records = n_bb + n_sph;            // (both launches write the same number: either may be the only one)
@@ -910,6 +908,18 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 	const uint32_t n = SPH ? n_sph : n_bb, first_rec = SPH ? n_bb : 0u;
 	// sort re-use (nh_collide): `rec_key` is the context's buffer of keys by record position, still holding last step's -- is every key what it was?
 	bool changed = false;
+	// STILL: what the step relies on, per record (see above); the count goes to the record's place in the tag order
+	auto still_record = [&](uint32_t ri, uint64_t key, int count, uint32_t body_a, uint32_t body_b) {
+		const bool same_key = rec_key[ri] == key;
+		bool ok = same_key && count <= 4;
+		if (ok && count) {
+			const uint32_t dyn = body_a ? body_a : body_b;
+			ok = (body_a == 0u) != (body_b == 0u) && (body_rec[dyn] & ~NH_BODY_REC_IS_A) == ri;
+		}
+		if (!ok) { atomicAdd(&st->still_diff[!same_key ? 0 : (count > 4 ? 1 : 2)], 1u); changed = true; }          // (statistics; rare)
+		rec[ri].count = (uint32_t)count;
+		cnt_sorted[lay_rank[ri]] = (uint32_t)count;
+	};
 	uint32_t rounded = (n + 63u) & ~63u;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
 		nh_bb_result bb;
@@ -980,22 +990,6 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		if (SPH) {
 			// one contact at most, ONE raw slot per sphere record (they follow the four-slot blocks of the box-box records: slot 4 n_bb + i, so that
 			// consecutive lanes write -- and k_gather_contacts reads -- consecutive 32 bytes instead of every fourth slot)
-			if (STILL) {
-				if (i < n) {
-					const uint32_t ls = lay_start[ri];
-					const bool same_key = rec_key[ri] == key, same_count = (ls >> 28) == (uint32_t)count;
-					const bool same = same_key && same_count && (!count || lay_feat[ri].x == single.feature);
-					changed |= !same;
-					if (!same) atomicAdd(&st->still_diff[!same_key ? 0 : (!same_count ? 1 : 2)], 1u);
-					const uint32_t d = ls & 0x0FFFFFFFu;
-					if (same && count && d < capacity) {
-						float4* dp = reinterpret_cast<float4*>(data + d);
-						dp[0] = make_float4(single.px, single.py, single.pz, single.penetration);
-						dp[1] = make_float4(single.nx, single.ny, single.nz, single.friction);
-					}
-				}
-				continue;
-			}
 			if (i < n) {
 				if (count) {
 					const size_t slot = (size_t)4 * n_bb + i;
@@ -1004,12 +998,14 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 					dp[1] = make_float4(single.nx, single.ny, single.nz, single.friction);
 					raw_feature[slot] = single.feature;
 				}
+				if (STILL) still_record(ri, key, count, body_a, body_b);
+				else {
 				{ const uint64_t was = rec_key[ri]; changed |= was != key; rec_key[ri] = key; }
 				nh_Record r = { body_a, body_b, 0u, asleep ? NH_REC_SLEEPING : (uint32_t)count };
 				if (asleep) st->any_sleeping = 1;
 				rec[ri] = r;
 				rec_idx[ri] = ri;
-				lay_feat[ri] = make_uint4(single.feature, 0u, 0u, 0u);
+				}
 			}
 			continue;
 		}
@@ -1055,58 +1051,14 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			} else if (bb.kind == 1) {
 				put(0, bb.edge);
 			}
-			if (!STILL) {
+			if (STILL) still_record(ri, key, count, body_a, body_b);
+			else {
 				{ const uint64_t was = rec_key[ri]; changed |= was != key; rec_key[ri] = key; }
 				nh_Record r = { body_a, body_b, ovf, asleep ? NH_REC_SLEEPING : (uint32_t)count };
 				if (asleep) st->any_sleeping = 1;
 				rec[ri] = r;
 				rec_idx[ri] = ri;
-				// the record's feature words in slot order: what a still step compares its own with
-				lay_feat[ri] = make_uint4(count > 0 ? w_f[4u * lane] : 0u, count > 1 ? w_f[4u * lane + 1u] : 0u, count > 2 ? w_f[4u * lane + 2u] : 0u, count > 3 ? w_f[4u * lane + 3u] : 0u);
 			}
-		}
-		if (STILL) {
-			// same record as last step?  Then its contacts go to data[first + rank by feature] (k_gather_contacts' order: feature, ties by slot) -- through LDS, so
-			// that eight lanes write one record's 128 bytes (a lane writing its own four contacts would put 64 lines behind every store instruction)
-			uint32_t cnt_ok = 0, first = 0, perm = 0;
-			if (i < n) {
-				const uint32_t ls = lay_start[ri];
-				const uint4 fe = lay_feat[ri];
-				const uint32_t f[4] = { w_f[4u * lane], w_f[4u * lane + 1u], w_f[4u * lane + 2u], w_f[4u * lane + 3u] }, g[4] = { fe.x, fe.y, fe.z, fe.w };
-				const bool same_key = rec_key[ri] == key, same_count = (ls >> 28) == (uint32_t)count && count <= 4;
-				bool same = same_key && same_count;
-#pragma unroll
-				for (int k = 0; k < 4; ++k) same = same && (k >= count || f[k] == g[k]);
-				changed |= !same;
-				if (!same) atomicAdd(&st->still_diff[!same_key ? 0 : (!same_count ? 1 : 2)], 1u);            // (statistics; rare by construction)
-				if (same) { cnt_ok = (uint32_t)count; first = ls & 0x0FFFFFFFu; }
-				if (same) {
-					// slot of every rank (two bits each): the write-out below fetches a record's contacts in rank order
-#pragma unroll
-					for (int j = 0; j < 4; ++j) {
-						uint32_t r = 0;
-#pragma unroll
-						for (int q = 0; q < 4; ++q) r += (q < count && (f[q] < f[j] || (f[q] == f[j] && q < j))) ? 1u : 0u;
-						if (j < count) perm |= (uint32_t)j << (2u * r);
-					}
-				}
-			}
-			if (cnt_ok && first + cnt_ok > capacity) cnt_ok = 0;
-			w_n[lane] = (uint8_t)cnt_ok;
-			s_perm[threadIdx.x >> 6][lane] = (uint8_t)perm;
-			s_start[threadIdx.x >> 6][lane] = first;
-			__builtin_amdgcn_wave_barrier();
-#pragma unroll
-			for (int r8 = 0; r8 < 8; ++r8) {
-				const uint32_t e = 64u * r8 + lane, j = e >> 3, q = (e >> 1) & 3u, half = e & 1u;
-				if (q < (uint32_t)w_n[j]) {
-					const uint32_t slot = ((uint32_t)s_perm[threadIdx.x >> 6][j] >> (2u * q)) & 3u;
-					float4* dp = reinterpret_cast<float4*>(data + s_start[threadIdx.x >> 6][j] + q);
-					dp[half] = half ? w_c1[4u * j + slot] : w_c0[4u * j + slot];
-				}
-			}
-			__builtin_amdgcn_wave_barrier();
-			continue;
 		}
 		w_n[lane] = (uint8_t)(i < n ? (count < 4 ? count : 4) : 0);
 		__builtin_amdgcn_wave_barrier();
@@ -1235,13 +1187,15 @@ __global__ __launch_bounds__(256) void k_filter_records(nh_DevState* __restrict_
 
 // ---- 8. tag-ordered output ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sorted_counts(nh_DevState* __restrict__ st, const uint32_t* __restrict__ rec_idx, const nh_Record* __restrict__ rec,
-                                                       uint32_t* __restrict__ counts, uint32_t* __restrict__ sleep_flags, uint32_t order_kept) {
+                                                       uint32_t* __restrict__ counts, uint32_t* __restrict__ sleep_flags, uint32_t order_kept, uint32_t* __restrict__ lay_rank) {
 	uint32_t n = st->records;
 	// sort re-use: `rec_idx` is the context's kept tag order (order_kept), sorted this step or still holding from an earlier one -- either way it now
 	// belongs to the keys k_narrowphase left in the context's buffer and to this record count
 	if (blockIdx.x == 0 && threadIdx.x == 0) { st->sort_valid = order_kept; st->records_kept = n; }
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		nh_Record r = rec[rec_idx[i]];
+		const uint32_t ri = rec_idx[i];
+		nh_Record r = rec[ri];
+		lay_rank[ri] = i;                      // (where a still step puts the record's count: nh_internal.h, contact storage by slot)
 		counts[i] = r.count & ~NH_REC_SLEEPING;
 		sleep_flags[i] = (r.count & NH_REC_SLEEPING) ? 1u : 0u;
 	}
@@ -1256,7 +1210,8 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
                                                          const uint32_t* __restrict__ starts, const nh_Contact* __restrict__ raw_data, const uint32_t* __restrict__ raw_feature,
                                                          nh_Contact* __restrict__ data, nh_BodyPair* __restrict__ bodies, uint64_t* __restrict__ tags, uint32_t* __restrict__ features, uint32_t capacity, uint32_t pair_cap,
                                                          const uint32_t* __restrict__ sleep_scan, uint64_t* __restrict__ sleeping_pairs, uint32_t* __restrict__ deg, uint32_t nbodies,
-                                                         uint32_t* __restrict__ lay_start, uint32_t order_kept) {
+                                                         uint32_t* __restrict__ dense_slot, uint32_t order_kept, uint32_t view_only) {
+	// view_only: the dense list is laid out again for the caller from what still steps keep by slot (nh_still_sync_outputs): no per-body bookkeeping, no sleeping pairs
 	__shared__ uint32_t s_src[4][1024];
 	unsigned long long* __restrict__ pair_counter = reinterpret_cast<unsigned long long*>(deg + 2u * NH_DEG_STRIDE(nbodies));
 	uint32_t* __restrict__ first_contact = deg + 4u * NH_DEG_STRIDE(nbodies);
@@ -1267,7 +1222,7 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 	if (st->contacts > capacity && blockIdx.x == 0 && threadIdx.x == 0) st->error = NH_ERR_CONTACT_CAPACITY;
 	// The layout this launch leaves (per record: first contact | contact count << 28, below) is what a still step compares itself with and writes through:
 	// usable when a record's position is its kept pair's (k_kept_filter wrote in place), nothing sleeps, and everything fits
-	if (blockIdx.x == 0 && threadIdx.x == 0)
+	if (blockIdx.x == 0 && threadIdx.x == 0 && !view_only)
 		st->lay_valid = (st->lay_in_place && order_kept && !st->any_sleeping && !st->error && st->contacts <= capacity && st->contacts < (1u << 28)) ? 1u : 0u;
 	const uint32_t wave = threadIdx.x >> 6, lane = nh_lane();
 	uint32_t* src = s_src[wave];
@@ -1285,11 +1240,10 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 			cnt = (r.count & NH_REC_SLEEPING) ? 0u : (r.count > 16u ? 16u : r.count);
 			key = rec_key_sorted[lo];
 			// sleeping pairs in ascending tag order (the reference sorts them at nudge.cpp:4008): ordered compaction of the sorted records
-			if ((r.count & NH_REC_SLEEPING) && sleeping_pairs) {
+			if ((r.count & NH_REC_SLEEPING) && sleeping_pairs && !view_only) {
 				const uint32_t p = sleep_scan[lo];
 				if (p < capacity) sleeping_pairs[p] = key; else st->error = NH_ERR_CONTACT_CAPACITY;
 			}
-			lay_start[ri] = (start & 0x0FFFFFFFu) | (((r.count & NH_REC_SLEEPING) || r.count > 4u ? 15u : r.count) << 28);
 			body_a = r.body_a; body_b = r.body_b;
 			sph_rec = ri >= n_bb;                   // (records of pairs with a sphere follow the box-box ones and own ONE raw slot each: k_narrowphase<true>)
 			base4 = sph_rec ? 4u * n_bb + (ri - n_bb) : 4u * ri; baseo = 4u * pair_cap + r.overflow;
@@ -1297,7 +1251,10 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 			// and what lets setup skip the general CSR build for a body that sits in ONE pair with the static world: its contacts are start .. start+cnt-1
 			// ONE atomic per body and pair: degree and pair info share a 64-bit counter (two 32-bit atomics per body used to make this kernel
 			// atomic-bound in a pit of 11 M contacts); no value is asked back -- a returning atomic is a memory round trip the wave waits for
-			if (cnt && start + cnt <= capacity) {
+			if (cnt && start + cnt <= capacity && !view_only) {
+				// (where a body of the one-pair class finds its record and the record's place in the tag order: k_adj_simple -> body_rec / body_pos)
+				if (body_a) first_contact[body_a + NH_DEG_STRIDE(nbodies)] = lo;
+				if (body_b) first_contact[body_b + NH_DEG_STRIDE(nbodies)] = lo;
 #if defined(NH_GATHER_32)      // A/B only: the two 32-bit atomics per body of rounds 1 and 2, on the halves of the same counter
 				if (body_a) { uint32_t* h = reinterpret_cast<uint32_t*>(&pair_counter[body_a]); atomicAdd(h, cnt); atomicAdd(h + 1, body_b ? 0x10001u : 1u); first_contact[body_a] = start | 0x80000000u; }
 				if (body_b) { uint32_t* h = reinterpret_cast<uint32_t*>(&pair_counter[body_b]); atomicAdd(h, cnt); atomicAdd(h + 1, body_a ? 0x10001u : 1u); first_contact[body_b] = start; }
@@ -1356,6 +1313,7 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 				bodies[d] = bp;
 				tags[d] = (uint64_t)klo | ((uint64_t)khi << 32);
 				features[d] = sft[k];
+				dense_slot[d] = src[k];
 			}
 		}
 		__builtin_amdgcn_wave_barrier();
@@ -1400,7 +1358,7 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 	if (t == 0) {
 		st->colliders = ncolliders; st->pairs = 0; st->pairs_sph = 0; st->raw_contacts = 0; st->records = 0; st->contacts = 0; st->sleeping = 0;
 		st->active = 0; st->culled = 0; st->general_contacts = 0; st->levels = 0; st->error = 0;
-		st->has_other = 0; st->unleveled = 0; st->has_static8 = 0; st->has_staticN = 0; st->any_sleeping = 0; st->has_pending = 0;
+		st->has_other = 0; st->has_unstable = 0; st->unleveled = 0; st->has_static8 = 0; st->has_staticN = 0; st->any_sleeping = 0; st->has_pending = 0;
 		st->sort_buckets = st->sort_buckets_next;
 		st->fat_escaped = 0; st->fat_rebuild = 0; st->esc_count = 0; st->fat_reinsert = 0;
 		st->fat_hits_prev = st->fat_hits; st->fat_hits = 0;
@@ -1438,7 +1396,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	ss.active = false; ss.resolved = false; ss.setup_d = nullptr;
 	// A still step?  The last step must have left everything one relies on (ok_next: decided at its round trip), the contact cache must be that step's contact
 	// list, the caller must be in the mode that promises the sample's call order, and the world must be the one the kept layout describes.
-	const bool want_still = !ss.disabled && ss.ok_next && ss.cache_ok && !ss.appended && (ctx->flags & NH_FLAG_FUSED_STEP) && !(ctx->flags & (NH_FLAG_SYNC_COUNTS | NH_FLAG_EXACT_ORDER)) &&
+	const bool want_still = !ss.disabled && ss.ok_next && ss.cache_ok && ss.slots_current && !ss.appended && (ctx->flags & NH_FLAG_FUSED_STEP) && !(ctx->flags & (NH_FLAG_SYNC_COUNTS | NH_FLAG_EXACT_ORDER)) &&
 	                        same_bodies(*bodies, ss.lay_bodies) && same_colliders(*colliders, ss.lay_colliders) && same_contacts(*contacts, ss.lay_contacts) &&
 	                        active_bodies->indices == ss.lay_active && active_bodies->capacity == ss.lay_active_capacity;
 	// (kept for the replay of a still step that fails, and as what the next layout belongs to)
@@ -1462,6 +1420,17 @@ int nh_still_collide_again(nh_context* ctx) {
 	ss.replaying = false;
 	ctx->after_collide = after_collide; ctx->gravity_may_overlap = may_overlap;
 	return rc;
+}
+
+// The dense, tag-ordered contact list of the API laid out again from what still steps keep by slot (records, raw slots, counts and starts in tag order): the
+// same kernel a full step uses, without its per-body bookkeeping.  For whoever looks at contacts->data / bodies / tags / features after still steps.
+int nh_still_view_contacts(nh_context* ctx) {
+	const nh_ContactData& c = ctx->still.lay_contacts;
+	const uint32_t pair_cap = ctx->lay_capacity;
+	NH_LAUNCH(ctx, "gather_contacts", k_gather_contacts, nh_grid_for(pair_cap, 256, 8192), 256, ctx->d_state, ctx->sort_sorted_idx, ctx->rec, ctx->sort_sorted_keys, ctx->start_sorted,
+	          ctx->raw_data, ctx->raw_feature, c.data, c.bodies, c.tags, c.features, c.capacity, pair_cap, (const uint32_t*)nullptr, (uint64_t*)nullptr, ctx->deg, ctx->still.bodies.count,
+	          ctx->dense_slot, 1u, 1u);
+	return NH_OK;
 }
 
 static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_ContactData* contacts, const nh_BodyData* bodies, const nh_ColliderData* colliders,
@@ -1507,14 +1476,10 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 	uint32_t* cscan_sums = nh_arena_array<uint32_t>(A, max_cells / CS_TILE + 8, &err);
 	const uint32_t overflow_cap = cap;
 	uint2* pairs = nh_arena_array<uint2>(A, pair_cap, &err);
-	nh_Contact* raw_data = nh_arena_array<nh_Contact>(A, (size_t)4 * pair_cap + overflow_cap, &err);
-	uint32_t* raw_feature = nh_arena_array<uint32_t>(A, (size_t)4 * pair_cap + overflow_cap, &err);
 	uint64_t* rec_key_b = nh_arena_array<uint64_t>(A, pair_cap, &err);
 	uint32_t* rec_idx_a = nh_arena_array<uint32_t>(A, pair_cap, &err);
 	uint32_t* rec_idx_b = nh_arena_array<uint32_t>(A, pair_cap, &err);
-	nh_Record* rec = nh_arena_array<nh_Record>(A, pair_cap, &err);
 	uint2* sort_place = nh_arena_array<uint2>(A, pair_cap, &err);
-	uint32_t* rec_counts = nh_arena_array<uint32_t>(A, pair_cap + 1, &err);
 	uint32_t* sleep_flags = nh_arena_array<uint32_t>(A, pair_cap + 1, &err);
 	uint32_t* parent = nh_arena_array<uint32_t>(A, B, &err);
 	uint32_t* set_active = nh_arena_array<uint32_t>(A, B, &err);
@@ -1625,24 +1590,42 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 	}
 	// re-insertion of colliders that leave their boxes (k_reinsert): kept-list steps only, indices that leave room for the stamps
 	const bool incremental = !bp_direct && !ctx->env_no_incremental && C < (1u << NH_GEN_SHIFT);
-	// library-owned: the layout of the contact list (nh_internal.h), per record position and per body
+	// library-owned: contact storage by slot, the records, their place in the tag order, the slot cache; per body class / contact-list record / record (nh_internal.h)
 	bool lay_fresh = false;
-	if (ctx->lay_capacity != pair_cap) {
-		if (ctx->lay_start) NH_HIP_CHECK(ctx, hipFree(ctx->lay_start));
-		if (ctx->lay_feat) NH_HIP_CHECK(ctx, hipFree(ctx->lay_feat));
-		ctx->lay_start = nullptr; ctx->lay_feat = nullptr; ctx->lay_capacity = 0;
-		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->lay_start, sizeof(uint32_t) * (size_t)pair_cap + 64u));
-		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->lay_feat, sizeof(uint4) * (size_t)pair_cap + 64u));
-		ctx->lay_capacity = pair_cap; lay_fresh = true;
+	if (ctx->lay_capacity != pair_cap || ctx->lay_contact_capacity != cap) {
+		void** bufs[] = { (void**)&ctx->raw_data, (void**)&ctx->raw_feature, (void**)&ctx->rec, (void**)&ctx->lay_rank, (void**)&ctx->cnt_sorted, (void**)&ctx->start_sorted, (void**)&ctx->dense_slot,
+		                  (void**)&ctx->sc_imp, (void**)&ctx->sc_feat, (void**)&ctx->sc_count, (void**)&ctx->exp_cnt, (void**)&ctx->exp_start, (void**)&ctx->exp_scan_tmp };
+		for (void** b : bufs) { if (*b) NH_HIP_CHECK(ctx, hipFree(*b)); *b = nullptr; }
+		ctx->lay_capacity = 0; ctx->lay_contact_capacity = 0;
+		const size_t slots = (size_t)4 * pair_cap + cap, cache_slots = (size_t)5 * pair_cap + 64u;
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->raw_data, sizeof(nh_Contact) * slots));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->raw_feature, sizeof(uint32_t) * slots + 64u));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->rec, sizeof(nh_Record) * (size_t)pair_cap + 64u));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->lay_rank, sizeof(uint32_t) * (size_t)pair_cap + 64u));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->cnt_sorted, sizeof(uint32_t) * ((size_t)pair_cap + 2u)));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->start_sorted, sizeof(uint32_t) * ((size_t)pair_cap + 2u)));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->dense_slot, sizeof(uint32_t) * (size_t)cap + 64u));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sc_imp, sizeof(float4) * cache_slots));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sc_feat, sizeof(uint32_t) * cache_slots));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sc_count, sizeof(uint32_t) * (size_t)pair_cap + 64u));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->exp_cnt, sizeof(uint32_t) * ((size_t)pair_cap + 2u)));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->exp_start, sizeof(uint32_t) * ((size_t)pair_cap + 2u)));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->exp_scan_tmp, sizeof(uint32_t) * (2u * NH_SORT_GRID + 64u)));
+		ctx->raw_slots = (uint32_t)slots;
+		ctx->lay_capacity = pair_cap; ctx->lay_contact_capacity = cap; lay_fresh = true;
 	}
 	if (ctx->lay_body_capacity < B) {
-		if (ctx->lay_class) NH_HIP_CHECK(ctx, hipFree(ctx->lay_class));
-		if (ctx->lay_simple) NH_HIP_CHECK(ctx, hipFree(ctx->lay_simple));
-		ctx->lay_class = nullptr; ctx->lay_simple = nullptr; ctx->lay_body_capacity = 0;
+		void** bufs[] = { (void**)&ctx->lay_class, (void**)&ctx->lay_simple, (void**)&ctx->body_rec, (void**)&ctx->body_pos };
+		for (void** b : bufs) { if (*b) NH_HIP_CHECK(ctx, hipFree(*b)); *b = nullptr; }
+		ctx->lay_body_capacity = 0;
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->lay_class, (size_t)B + 64u));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->lay_simple, sizeof(uint2) * (size_t)B + 64u));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->body_rec, sizeof(uint32_t) * (size_t)B + 64u));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->body_pos, sizeof(uint32_t) * (size_t)B + 64u));
 		ctx->lay_body_capacity = B; lay_fresh = true;
 	}
+	nh_Contact* raw_data = ctx->raw_data; uint32_t* raw_feature = ctx->raw_feature; nh_Record* rec = ctx->rec; uint32_t* rec_counts = ctx->cnt_sorted;
+	if (lay_fresh) { ctx->still.slots_current = false; ctx->still.ok_next = false; }
 	{
 		nh_StillStep& ss = ctx->still;
 		ss.lay_bodies = *bodies; ss.lay_colliders = *colliders; ss.lay_contacts = *contacts; ss.lay_active = active_bodies->indices; ss.lay_active_capacity = active_bodies->capacity;
@@ -1660,20 +1643,23 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			const uint8_t* gen = incremental ? ctx->fat_gen : (const uint8_t*)nullptr;
 			if (nbox >= 2)
 				NH_LAUNCH(ctx, "narrowphase", (k_narrowphase<false, true>), nh_grid_for(pair_cap, 256, 4096), 256, st, ctx->fat_pairs, xf, ctag,
-				          colliders->boxes.data, colliders->spheres.data, nbox, (nh_Contact*)nullptr, (uint32_t*)nullptr, pair_cap, 0u, ctx->sort_keys_by_position, (nh_Record*)nullptr, (uint32_t*)nullptr,
-				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->lay_start, ctx->lay_feat,
-				          ctx->fat_pair_capacity, aabb_min, aabb_max, gen, contacts->data, cap);
+				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr,
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec);
 			if (nsph)
 				NH_LAUNCH(ctx, "narrowphase_sph", (k_narrowphase<true, true>), nh_grid_for(pair_cap, 256, 8192), 256, st, ctx->fat_pairs, xf, ctag,
-				          colliders->boxes.data, colliders->spheres.data, nbox, (nh_Contact*)nullptr, (uint32_t*)nullptr, pair_cap, 0u, ctx->sort_keys_by_position, (nh_Record*)nullptr, (uint32_t*)nullptr,
-				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->lay_start, ctx->lay_feat,
-				          ctx->fat_pair_capacity, aabb_min, aabb_max, gen, contacts->data, cap);
+				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr,
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec);
+			// every record's first contact in the dense (tag-ordered) list: the scan of the counts in tag order; the total is this step's contact count
+			nh_scan_u32(ctx, ctx->cnt_sorted, ctx->start_sorted, &st->records, 1, scan_tmp, &st->contacts);
 			ss.active = true; ss.resolved = false; ss.launched++;
 			ctx->gravity_may_overlap = false;
 			ctx->after_collide = true;
 			return NH_OK;
 		}
 	}
+	// a full step: the solver reads the caller's cache arrays and this nh_collide lays the dense contact list out -- whatever still steps kept by slot goes home first
+	{ int rc = nh_still_export_cache(ctx); if (rc) return rc; }
+	ctx->still.contacts_stale = false; ctx->still.slots_current = false;
 	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, begin_grid, 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity, coarse_parent, coarse_active, no_islands ? 1u : 0u, block_top,
 	          drop_kept ? 1u : 0u, drop_sort_order ? 1u : 0u);
 	const bool seeded_sort = !ctx->env_sort_classic && ctx->sort_seeded && !ctx->env_sort_radix;      // (NH_SORT_RADIX=1: radix passes every step)
@@ -1729,11 +1715,11 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 		if (nbox >= 2)
 			NH_LAUNCH(ctx, "narrowphase", (k_narrowphase<false, false>), nh_grid_for(pair_cap, 256, 4096), 256, st, pairs, xf, ctag,
 			          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a,
-			          coarse_root, coarse_active, ctx->step_parity, ctx->lay_start, ctx->lay_feat);
+			          coarse_root, coarse_active, ctx->step_parity);
 		if (nsph)
 			NH_LAUNCH(ctx, "narrowphase_sph", (k_narrowphase<true, false>), nh_grid_for(pair_cap, 256, 8192), 256, st, pairs, xf, ctag,
 			          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a,
-			          coarse_root, coarse_active, ctx->step_parity, ctx->lay_start, ctx->lay_feat);
+			          coarse_root, coarse_active, ctx->step_parity);
 	}
 	// islands over contact records (+ user connections): a chain of small kernels that the tag sort of the records does not depend
 	// on -- it runs on the side stream while the caller's stream sorts (fork here, join before k_sorted_counts)
@@ -1794,12 +1780,12 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 	if (!seeded_sort) { sorted_keys = rec_key_a; sorted_idx = rec_idx_a; }         // (the radix passes leave the result in whichever buffer they ended in)
 	if (onesweep && !seeded_sort) { nh_bucket_sort_seed(ctx, rec_key_a, pair_cap); ctx->sort_seeded = true; }
 	if (fork) NH_HIP_CHECK(ctx, hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
-	NH_LAUNCH(ctx, "sorted_counts", k_sorted_counts, nh_grid_for(pair_cap, 256, 2048), 256, st, sorted_idx, rec, rec_counts, sleep_flags, seeded_sort ? 1u : 0u);
+	NH_LAUNCH(ctx, "sorted_counts", k_sorted_counts, nh_grid_for(pair_cap, 256, 2048), 256, st, sorted_idx, rec, rec_counts, sleep_flags, seeded_sort ? 1u : 0u, ctx->lay_rank);
 	// contact starts and sleeping-pair slots: two scans over the sorted records in one pair of launches
-	nh_scan2_u32(ctx, rec_counts, rec_counts, &st->contacts, sleep_flags, sleep_flags, &st->sleeping, &st->records, 1, scan_tmp);
-	NH_LAUNCH(ctx, "gather_contacts", k_gather_contacts, nh_grid_for(pair_cap, 256, 8192), 256, st, sorted_idx, rec, sorted_keys, rec_counts, raw_data, raw_feature,
+	nh_scan2_u32(ctx, rec_counts, ctx->start_sorted, &st->contacts, sleep_flags, sleep_flags, &st->sleeping, &st->records, 1, scan_tmp);
+	NH_LAUNCH(ctx, "gather_contacts", k_gather_contacts, nh_grid_for(pair_cap, 256, 8192), 256, st, sorted_idx, rec, sorted_keys, ctx->start_sorted, raw_data, raw_feature,
 	          contacts->data, contacts->bodies, contacts->tags, contacts->features, cap, pair_cap, sleep_flags, contacts->sleeping_pairs, ctx->deg, B,
-	          ctx->lay_start, seeded_sort ? 1u : 0u);
+	          ctx->dense_slot, seeded_sort ? 1u : 0u, 0u);
 
 	if (ctx->flags & NH_FLAG_SYNC_COUNTS) {
 		nh_Counts c;
@@ -1904,6 +1890,8 @@ extern "C" int nh_append_contacts(nh_context* ctx, nh_ContactData* contacts, con
 	if (extra > 65536u || extra > contacts->capacity) return NH_ERR_INVALID;      // (the appended contacts are ranked against each other by comparison: a slow path for a handful)
 	if (ctx->setup_seq == ctx->collide_seq || !ctx->deg) return NH_ERR_STALE_SETUP;      // after nh_collide, before nh_read_cached_impulses / nh_setup_contact_constraints
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	{ int rc = nh_still_sync_outputs(ctx); if (rc) return rc; }
+	ctx->still.appended = true; ctx->still.ok_next = false;
 	nh_DevState* st = ctx->d_state;
 	const uint32_t cap = contacts->capacity, B = bodies->count;
 	int err = NH_OK;

@@ -64,7 +64,9 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->blk.min_contacts = getenv("NH_BLK_MIN") ? (uint32_t)atoi(getenv("NH_BLK_MIN")) : 200000u;
 	ctx->blk.target = getenv("NH_BLK_TARGET") ? (uint32_t)atoi(getenv("NH_BLK_TARGET")) : 900u;
 	if (ctx->blk.target < 8u) ctx->blk.target = 8u;
-	ctx->lay_start = nullptr; ctx->lay_feat = nullptr; ctx->lay_capacity = 0; ctx->lay_class = nullptr; ctx->lay_simple = nullptr; ctx->lay_body_capacity = 0;
+	ctx->raw_data = nullptr; ctx->raw_feature = nullptr; ctx->raw_slots = 0; ctx->rec = nullptr; ctx->lay_rank = nullptr; ctx->cnt_sorted = nullptr; ctx->start_sorted = nullptr; ctx->dense_slot = nullptr;
+	ctx->sc_imp = nullptr; ctx->sc_feat = nullptr; ctx->sc_count = nullptr; ctx->exp_cnt = nullptr; ctx->exp_start = nullptr; ctx->exp_scan_tmp = nullptr; ctx->lay_capacity = 0; ctx->lay_contact_capacity = 0;
+	ctx->lay_class = nullptr; ctx->lay_simple = nullptr; ctx->body_rec = nullptr; ctx->body_pos = nullptr; ctx->lay_body_capacity = 0;
 	memset(&ctx->still, 0, sizeof(ctx->still));
 	ctx->still.disabled = getenv("NH_NO_STILL") != nullptr;      // NH_NO_STILL=1: no step is launched speculatively as a still step (A/B, tests)
 	ctx->d_state = nullptr;
@@ -114,10 +116,11 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	if (ctx->sort_splitters) hipFree(ctx->sort_splitters);
 	if (ctx->sort_counts) hipFree(ctx->sort_counts);
 	if (ctx->sort_starts) hipFree(ctx->sort_starts);
-	if (ctx->lay_start) hipFree(ctx->lay_start);
-	if (ctx->lay_feat) hipFree(ctx->lay_feat);
-	if (ctx->lay_class) hipFree(ctx->lay_class);
-	if (ctx->lay_simple) hipFree(ctx->lay_simple);
+	{
+		void* bufs[] = { ctx->raw_data, ctx->raw_feature, ctx->rec, ctx->lay_rank, ctx->cnt_sorted, ctx->start_sorted, ctx->dense_slot, ctx->sc_imp, ctx->sc_feat, ctx->sc_count, ctx->exp_cnt, ctx->exp_start,
+		                 ctx->exp_scan_tmp, ctx->lay_class, ctx->lay_simple, ctx->body_rec, ctx->body_pos };
+		for (void* b : bufs) if (b) hipFree(b);
+	}
 	{
 		nh_BlkBuffers& k = ctx->blk;
 		void* bufs[] = { k.brank, k.bm, k.pos_body, k.touch, k.lpair, k.ghost_list, k.blk_count, k.own_base, k.bins, k.bin_off, k.ghost_base, k.ghost_count, k.phase_list, k.desc, k.scan_tmp, k.prof };
@@ -150,6 +153,8 @@ extern "C" int nh_synchronize(nh_context* ctx) {
 	if (!ctx) return NH_ERR_INVALID;
 	int rc = nh_flush_pending(ctx);
 	if (rc) return rc;
+	rc = nh_still_sync_outputs(ctx);         // (contacts and cache as the caller's arrays show them: note 9)
+	if (rc) return rc;
 	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 	if (ctx->timing) nh_timer_collect(ctx);
 	return NH_OK;
@@ -171,6 +176,7 @@ void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out) {
 extern "C" int nh_read_counts(nh_context* ctx, nh_Counts* out) {
 	if (!ctx || !out) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx, true); if (rc) return rc; }      // (counters only: a pending NH_FLAG_FUSED_STEP gravity stays pending)
+	{ int rc = nh_still_sync_outputs(ctx); if (rc) return rc; }
 	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, NH_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 	nh_counts_from_mirror(ctx, out);
@@ -183,7 +189,7 @@ __global__ void k_set_cache_count(nh_DevState* st, uint32_t n) { st->cache = n; 
 extern "C" int nh_set_cache_count(nh_context* ctx, uint32_t count) {
 	if (!ctx) return NH_ERR_INVALID;
 	{ int rc = nh_still_abandon(ctx); if (rc) return rc; }
-	ctx->still.cache_ok = false;                 // the caller has put another cache in place
+	ctx->still.cache_ok = false; ctx->still.slots_current = false; ctx->still.cache_stale = false;      // the caller has put another cache in place: what the slots hold is void
 	hipLaunchKernelGGL(k_set_cache_count, dim3(1), dim3(1), 0, ctx->stream, ctx->d_state, count);
 	return NH_OK;
 }

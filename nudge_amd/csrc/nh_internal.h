@@ -75,7 +75,7 @@ struct nh_DevState {
 	                                      // features changed, a body is asleep, body 0 not inert): every kernel after that leaves, the host replays the step in full
 	uint32_t lay_valid;                   // the kept layout (per record: first contact | count, feature words; per body: class + contact list record) describes the contact
 	                                      // list the last FULL step laid out, and that step met the conditions a still step relies on (k_gather_contacts)
-	uint32_t still_steps;                 // still steps that went through, since nh_create (statistics)
+	uint32_t has_unstable;                // some body with contacts is outside the class a still step's solver owns (one collider pair, with the static world, <= 4 contacts): k_adj_simple
 	uint32_t still_diff[4];               // why the last still step that failed did: records whose key / contact count / feature words differed, colliders outside their boxes or bodies asleep (statistics)
 	// ---- (the 36 words above are what nh_read_counts mirrors to the host: NH_COUNTER_WORDS) ----
 	// Temporal coherence of the broadphase (nh_collide.hip, "kept pair list"): the grid search runs over AABBs inflated by `fat_margin` and its
@@ -167,6 +167,9 @@ struct nh_StillStep {
 	bool active, resolved;          // this step was launched as a still step / ... and its round trip has confirmed it
 	bool replaying;                 // inside the replay of a failed one
 	bool appended;                  // nh_append_contacts changed the list since the layout was written
+	bool slots_current;             // the slot cache (sc_*) holds the impulses of the last step (imported at the end of a full step that allows a still one, then kept by the solver)
+	bool cache_stale, contacts_stale;   // still steps have run since the caller's cache arrays / dense contact arrays were last written
+	nh_ContactCache cache;          // the caller's cache arrays (as given to the last nh_write_cached_impulses)
 	nh_ContactConstraintData* setup_d;      // its nh_setup_contact_constraints has run (without the adjacency kernel the replay then owes)
 	// the arguments of its nh_collide, for the replay; and the arrays the kept layout belongs to (another world in the same context: not still)
 	nh_ActiveBodies* active_out; nh_ContactData* contacts_out; nh_BodyData bodies; nh_ColliderData colliders; nh_BodyConnections connections; bool has_connections; nh_Arena temporary;
@@ -261,10 +264,22 @@ struct nh_context {
 	struct { bool pending, rest_pending; float gx_dt, gy_dt, gz_dt, damping, time_step; const uint32_t* active; nh_BodyMomentum* momentum; uint32_t body_count; } grav;
 	struct { bool done, rest; float time_step; const uint8_t* body_class; } adv;      // `rest`: some active body is not the fused solver's (the step's round trip told)
 	nh_BlkBuffers blk;
-	// kept layout of the contact list (library-owned; written by every full step, read by still steps): per record position its first contact | count << 28
-	// and its feature words in slot order; per body its class and contact-list record (k_adj_simple)
-	uint32_t* lay_start; uint4* lay_feat; uint32_t lay_capacity;
-	uint8_t* lay_class; uint2* lay_simple; uint32_t lay_body_capacity;
+	// Contact storage by SLOT (library-owned; written by every step, full or still).  A collider pair of the (kept) pair list is a RECORD; record r owns the raw
+	// contact slots 4 r .. 4 r + 3 (a record of a pair with a sphere: the one slot 4 n_bb + (r - n_bb)), whatever the other records do -- so a pair that gains or
+	// loses a contact moves nobody else's data.  The dense, tag-ordered contact list of the API is a VIEW of this: record r sits at position lay_rank[r] of the tag
+	// order (kept from the last sort), its contacts start at start_sorted[lay_rank[r]] (the scan of the counts in that order) ranked by feature word.  A full step
+	// lays the view out for the caller right away (k_gather_contacts); still steps leave it to the next call that looks (nh_still_sync_outputs).
+	nh_Contact* raw_data; uint32_t* raw_feature; uint32_t raw_slots;        // 4 pair_cap + contact capacity slots (the tail: contacts 5+ of a pair, full steps only)
+	struct nh_Record* rec;                                                   // per record: the two bodies, overflow position, contact count
+	uint32_t* lay_rank;                                                      // per record: its position in the kept tag order
+	uint32_t* cnt_sorted; uint32_t* start_sorted;                            // per tag-order position: contact count, first contact (pair_cap + 1 entries)
+	uint32_t* dense_slot;                                                    // per contact of the last FULL step's list: the raw slot it came from
+	// the contact cache by slot (still steps): the solved impulse and the feature word of the contact each slot held LAST step, and how many each record had
+	float4* sc_imp; uint32_t* sc_feat; uint32_t* sc_count;
+	uint32_t* exp_cnt; uint32_t* exp_start; uint32_t* exp_scan_tmp;          // scratch of the export slots -> caller's cache (pair_cap + 2 words each; scan temporaries)
+	uint32_t lay_capacity, lay_contact_capacity;                             // pair capacity / contact capacity the arrays above were sized for
+	// per body (k_adj_simple): class, contact-list record of the full path; the record a body's contacts come from (| NH_BODY_REC_IS_A) and its tag-order position
+	uint8_t* lay_class; uint2* lay_simple; uint32_t* body_rec; uint32_t* body_pos; uint32_t lay_body_capacity;
 	nh_StillStep still;
 };
 
@@ -273,6 +288,14 @@ struct nh_context {
 // entry point first turns a still step that has not been confirmed yet into a full one (nh_still_abandon)
 int nh_flush_pending(nh_context* ctx, bool keep_gravity = false, bool in_sequence = false);
 int nh_still_abandon(nh_context* ctx);
+// The caller's view of what still steps keep by slot -- the dense contact list and the contact cache in tag order -- brought up to date (every entry point outside
+// the sample's call order calls it through nh_flush_pending: nh_read_counts, nh_synchronize, ...)
+int nh_still_sync_outputs(nh_context* ctx);
+int nh_still_export_cache(nh_context* ctx);
+#define NH_BODY_REC_NONE 0xFFFFFFFFu
+#define NH_BODY_REC_IS_A 0x80000000u
+struct nh_Record { uint32_t body_a, body_b, overflow, count; };          // one per collider pair that reached the narrowphase (nh_collide.hip)
+#define NH_REC_SLEEPING 0x80000000u
 void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out);
 #define NH_COUNTER_WORDS 36u          // leading words of nh_DevState that the host mirrors (nh_read_counts)
 
@@ -390,7 +413,7 @@ void nh_timer_collect(nh_context* ctx);
 // contacts are laid out: low word = contacts so far (the degree), high word = collider pairs | pairs with a dynamic partner
 // << 16; [4S, 5S) first contact of the body's last pair (| NH_FIRST_IS_A)
 #define NH_DEG_STRIDE(B) ((((size_t)(B)) + 3u) & ~(size_t)1u)
-#define NH_DEG_WORDS(B) (5u * NH_DEG_STRIDE(B))
+#define NH_DEG_WORDS(B) (6u * NH_DEG_STRIDE(B))       // ([5S, 6S): tag-order position of the record the first contact belongs to)
 
 static inline uint32_t nh_grid_for(uint64_t n, uint32_t block = NH_BLOCK, uint32_t max_blocks = 4096) {
 	uint64_t g = (n + block - 1) / block;

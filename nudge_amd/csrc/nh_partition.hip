@@ -383,6 +383,8 @@ extern "C" int nh_partition_unpack_step(nh_partition* p, const nh_BodyData* bodi
 	return NH_OK;
 }
 
+__global__ void k_part_set_sort_count(nh_PartDev* dv, uint32_t n) { dv->kinds[0] = n; }
+
 extern "C" int nh_partition_choose_cut(nh_partition* p, const nh_BodyData* bodies, int direction, uint32_t neighbour_owned, double* cut_out) {
 	if (!p || !bodies || !cut_out || (direction != -1 && direction != 1)) return NH_ERR_INVALID;
 	nh_context* ctx = p->ctx;
@@ -398,11 +400,30 @@ extern "C" int nh_partition_choose_cut(nh_partition* p, const nh_BodyData* bodie
 		if (k > five) k = five;
 		if (k > n - 1u) k = n - 1u;
 		if (k < 1u) k = 1u;
+		NH_LAUNCH(ctx, "part_reset", k_part_set_sort_count, 1, 1, p->d, n);
 		NP_LAUNCH("part_x_keys", k_part_x_keys, n, n + 1u, bodies->transforms, p->sort_a, p->sort_va);
-		const int in_b = nh_sort_u32_u32(ctx, p->sort_a, p->sort_b, p->sort_va, p->sort_vb, &p->d->zero, p->sort_hist, 0, 32);
-		(void)in_b;
-		return NH_ERR_INVALID;       // (replaced below: see nh_partition_choose_cut_impl)
+		const int in_b = nh_sort_u32_u32(ctx, p->sort_a, p->sort_b, p->sort_va, p->sort_vb, &p->d->kinds[0], p->sort_hist, 0, 32);
+		const uint32_t* sorted = in_b ? p->sort_b : p->sort_a;
+		// towards the left neighbour the k smallest x leave (between the k-th and the (k+1)-th smallest); towards the right one the k largest
+		const uint32_t ia = direction < 0 ? k - 1u : n - k, ib = direction < 0 ? k : n - k - 1u;
+		NH_LAUNCH(ctx, "part_kth", k_part_kth, 1, 1, sorted, ia, ib, p->d);
+		int rc = part_read_back(p);
+		if (rc) return rc;
+		cut = 0.5 * ((double)p->h->kth[0] + (double)p->h->kth[1]);
+		// never further from where the cut started than the static colliders this rank kept allow
+		const double c0 = p->cut0[direction < 0 ? 0 : 1];
+		if (cut < c0 - p->cfg.cut_slack) cut = c0 - p->cfg.cut_slack;
+		if (cut > c0 + p->cfg.cut_slack) cut = c0 + p->cfg.cut_slack;
+		if (!(cut == cut) || cut > 1e300 || cut < -1e300) cut = old;
 	}
+	if (cut != old) { if (direction < 0) p->lo = cut; else p->hi = cut; p->cut_moves++; }
 	*cut_out = cut;
+	return NH_OK;
+}
+
+extern "C" int nh_partition_set_cut(nh_partition* p, int direction, double cut) {
+	if (!p || (direction != -1 && direction != 1) || !(cut == cut)) return NH_ERR_INVALID;
+	const double old = direction < 0 ? p->lo : p->hi;
+	if (cut != old) { if (direction < 0) p->lo = cut; else p->hi = cut; p->cut_moves++; }
 	return NH_OK;
 }

@@ -214,8 +214,10 @@ __device__ __forceinline__ uint32_t slot_key_of(uint32_t i, const uint32_t* __re
 __global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st, uint32_t nbodies, uint32_t* __restrict__ deg, const unsigned long long* __restrict__ pair_counter,
                                                     const uint32_t* __restrict__ first_contact, const uint32_t* __restrict__ slot_key,
                                                     uint8_t* __restrict__ body_class, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
-                                                    uint2* __restrict__ simple) {
-	bool other = false;
+                                                    uint2* __restrict__ simple, uint32_t* __restrict__ body_rec, uint32_t* __restrict__ body_pos, const uint32_t* __restrict__ sorted_idx) {
+	// body_rec / body_pos (nh_internal.h, contact storage by slot): for a body of the one-pair class the record its contacts come from (| role) and that record's
+	// place in the tag order -- what a still step's solver lane starts from; NH_BODY_REC_NONE for a body without contacts
+	bool other = false, unstable = false;
 	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x; x < nbodies; x += gridDim.x * blockDim.x) {
 		if (x == 0) {
 			body_class[0] = 0;
@@ -255,6 +257,11 @@ __global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st
 #pragma unroll
 					for (int q = 0; q < W; ++q) if ((uint32_t)q < d) perm |= (c[q] - f) << (3 * q);
 					simple[x] = make_uint2(f, d | (perm << 4) | ((fc & NH_FIRST_IS_A) ? (1u << 28) : 0u));
+					if (body_rec) {
+						const uint32_t pos = first_contact[x + NH_DEG_STRIDE(nbodies)];
+						body_pos[x] = pos;
+						body_rec[x] = (sorted_idx ? sorted_idx[pos] : NH_BODY_REC_NONE) | ((fc & NH_FIRST_IS_A) ? NH_BODY_REC_IS_A : 0u);
+					}
 				};
 				if (d <= 4u) emit(std::integral_constant<int, 4>()); else emit(std::integral_constant<int, 8>());
 				cls = d <= 4u ? NH_CLS_STATIC4 : NH_CLS_STATIC8;
@@ -272,10 +279,13 @@ __global__ __launch_bounds__(256) void k_adj_simple(nh_DevState* __restrict__ st
 			}
 		} else {
 			momentum[x].unused0 = props[x].mass_inverse;
+			if (body_rec) { body_rec[x] = NH_BODY_REC_NONE; body_pos[x] = 0u; }
 		}
 		body_class[x] = (uint8_t)cls;
 		other |= cls != NH_CLS_STATIC4;
+		unstable |= cls != NH_CLS_STATIC4 && cls != NH_CLS_NONE;
 	}
+	if (__builtin_amdgcn_ballot_w64(unstable) != 0 && nh_lane() == 0) st->has_unstable = 1u;
 	// (one plain store per wave that has such a body: no counting)
 	if (__builtin_amdgcn_ballot_w64(other) != 0 && nh_lane() == 0) st->has_other = 1u;
 }
@@ -844,16 +854,23 @@ __device__ __noinline__ float4 cache_search(const uint64_t* __restrict__ ctags, 
 // Four 27-float rows fit in 256 registers: two waves per SIMD (the compiler would otherwise spend 260 and run one).
 struct nh_ob_slot { float4 c0, c1, w; };      // contact (32 B), cached impulse xyz + flags in w.w (bit 0 miss, bit 1 body is "a")
 
-// STILL (nh_internal.h: nh_StillStep): the step was launched as one whose contact list is last step's, entry for entry.  The cache then IS that list: contact c's
-// warm start is cdata[c] -- no tags, no features, no hint, no search -- and its solved impulse goes back to cdata[c], which is all nh_write_cached_impulses
-// would have done.  If an earlier kernel of the step found the assumption broken (st->still_fail), or body 0 is not inert, the kernel leaves before touching anything.
+// STILL (nh_internal.h: nh_StillStep, contact storage by slot).  The lane of body x starts from the body's RECORD (body_rec: the one collider pair, with the
+// static world, its contacts come from; none: the body only falls) instead of a contact-list record of the dense list: this step's contact count and first dense
+// index from the record's place in the tag order (cnt_sorted / start_sorted: the still narrowphase and one scan wrote them), its contacts and feature words from the
+// record's own raw slots, last step's feature words and solved impulses from the slot cache.  From those it derives what the full path reads from arrays: the
+// dense index of a contact (first + rank of its feature word, nudge.cpp:4027-4044), the order its contacts are solved in (slot keys of those indices,
+// nudge.cpp:4206-4339: k_adj_simple's rule), and each contact's warm start (the cached impulse with the same feature word, nudge.cpp:4057-4083 -- a pair's
+// entries can only be the pair's own).  The solved impulses and this step's feature words go back to the slot cache.  EVERY dynamic body is the kernel's: one
+// without contacts gets gravity and its advance here.  If an earlier kernel of the step raised st->still_fail, or body 0 is not inert, the kernel leaves first.
+struct nh_StillView { const uint32_t* body_rec; const uint32_t* body_pos; const uint32_t* cnt_sorted; const uint32_t* start_sorted; const uint32_t* raw_feature; uint32_t* sc_feat; uint32_t* sc_count; uint32_t pair_cap; };
+
 template<int MAXC, bool FUSED, bool CONTIG = false, int NW = 4, bool STILL = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ? 2 : 1, MAXC == 4 ? 2 : 1))) void k_solve_one_body(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
                                                         const nh_BodyPair* __restrict__ bodies, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                         float4* __restrict__ states, uint32_t iterations,
                                                         const nh_Contact* __restrict__ contacts, nh_Transform* xf, nh_CachedContactImpulse* __restrict__ impulses,
                                                         nh_CacheView cv, uint32_t* __restrict__ hint, uint32_t cls_a, uint32_t cls_b, uint32_t require_inert,
-                                                        const uint2* __restrict__ simple = nullptr, nh_FusedStep fs = nh_FusedStep()) {
+                                                        const uint2* __restrict__ simple = nullptr, nh_FusedStep fs = nh_FusedStep(), nh_StillView sv = nh_StillView()) {
 	// CONTIG: every body of the class comes from k_adj_simple (one collider pair with the static world): its contact list is the record
 	// simple[x] -- one load next to the body state instead of the dependent chain off[x] -> adj[] -> contact
 	constexpr int M = MAXC;
@@ -876,6 +893,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 	__shared__ nh_ob_slot s_slot[NW][64 * M];
 	__shared__ uint32_t s_cid[NW][64 * M];
 	__shared__ uint32_t s_hint[NW][64], s_first[NW][64];
+	__shared__ uint32_t s_wid[STILL ? NW : 1][STILL ? 64 * M : 1];       // STILL: per contact, the slot of the cache entry it warm-starts from
 	const uint32_t wave = threadIdx.x >> 6, lane = nh_lane();
 	nh_ob_slot* slot = s_slot[wave];
 	uint32_t* scid = s_cid[wave];
@@ -892,25 +910,81 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		// are in flight together -- with the body state issued behind them (it is needed only in phase B).  Loads under divergent branches are
 		// issued and awaited branch by branch: that form spent 61 % of the wave cycles parked at s_waitcnt (SQ_WAIT_ANY; now 33 %: profiles/r02_sq_wave_states.json).
 		const uint32_t xc = min(x, nbodies - 1u);
-		const uint32_t my_class = body_class[xc];
+		const uint32_t my_class = STILL ? 0u : body_class[xc];
 		uint2 sp = make_uint2(0u, 0u);
 		uint32_t h = NH_HINT_NONE;
-		if (CONTIG) sp = simple[xc];
+		if (CONTIG && !STILL) sp = simple[xc];
 		if (FUSED && !STILL) h = hint[xc];
+		uint32_t br = NH_BODY_REC_NONE, bpos = 0u;
+		if (STILL) { br = sv.body_rec[xc]; bpos = sv.body_pos[xc]; }
 		if (!inert_word) return;
-		const bool mine = x < nbodies && (my_class == cls_a || my_class == cls_b);
+		const bool mine = STILL ? (x >= 1u && x < nbodies) : (x < nbodies && (my_class == cls_a || my_class == cls_b));
 		const uint32_t wave_x0 = x - lane;
 		uint32_t b = 0, cnt = 0;
-		if (!mine) { sp = make_uint2(0u, 0u); h = NH_HINT_NONE; }
-		if (CONTIG) cnt = sp.y & 15u;
-		else if (mine) { b = off[x]; cnt = off[x + 1] - b; }
+		if (!mine) { sp = make_uint2(0u, 0u); h = NH_HINT_NONE; br = NH_BODY_REC_NONE; }
 		uint32_t cid[M];
 		uint32_t first = 0xFFFFFFFFu;
+		uint32_t still_base = 0, still_rec = 0;
+		bool still_has = false;
+		if (STILL) {
+			still_has = br != NH_BODY_REC_NONE;
+			still_rec = br & ~NH_BODY_REC_IS_A;
+			const uint32_t n_bb = min(cv.st->pairs, sv.pair_cap);
+			still_base = still_rec < n_bb ? 4u * still_rec : 4u * n_bb + (still_rec - n_bb);       // (a record of a pair with a sphere owns ONE slot, behind the box-box records' four each)
+			uint32_t start = 0, oc = 0;
+			if (still_has) { cnt = min(sv.cnt_sorted[bpos], 4u); start = sv.start_sorted[bpos]; oc = min(sv.sc_count[still_rec], 4u); }
+			uint32_t nf[M], of[M];
+#pragma unroll
+			for (int k = 0; k < M; ++k) { nf[k] = (uint32_t)k < cnt ? sv.raw_feature[still_base + k] : 0u; of[k] = (uint32_t)k < oc ? sv.sc_feat[still_base + k] : 0u; }
+			// dense index of slot k = first + rank of its feature word (ties by slot: k_gather_contacts); the order of solving = by slot key of that index, then by index
+			// (k_adj_simple's rule); the cache entry a contact starts from = last step's slot with the same feature word
+			uint32_t ci[M], key[M], slot[M];
+#pragma unroll
+			for (int k = 0; k < M; ++k) {
+				uint32_t r = 0;
+#pragma unroll
+				for (int j = 0; j < M; ++j) r += ((uint32_t)j < cnt && (nf[j] < nf[k] || (nf[j] == nf[k] && j < k))) ? 1u : 0u;
+				const bool on = (uint32_t)k < cnt;
+				ci[k] = on ? start + r : 0xFFFFFFFFu;
+				key[k] = on ? slot_key_of(ci[k], nullptr) : 0xFFFFFFFFu;
+				slot[k] = (uint32_t)k;
+			}
+#pragma unroll
+			for (int q = 1; q < M; ++q) {
+#pragma unroll
+				for (int j = q; j > 0; --j) {
+					const bool sw = (key[j] < key[j - 1]) || (key[j] == key[j - 1] && ci[j] < ci[j - 1]);
+					const uint32_t tc = sw ? ci[j - 1] : ci[j], tk = sw ? key[j - 1] : key[j], ts = sw ? slot[j - 1] : slot[j];
+					ci[j - 1] = sw ? ci[j] : ci[j - 1]; key[j - 1] = sw ? key[j] : key[j - 1]; slot[j - 1] = sw ? slot[j] : slot[j - 1];
+					ci[j] = tc; key[j] = tk; slot[j] = ts;
+				}
+			}
+#pragma unroll
+			for (int q = 0; q < M; ++q) {
+				const bool on = (uint32_t)q < cnt;
+				uint32_t f = 0, wslot = 0xFFFFFFFFu;
+#pragma unroll
+				for (int k = 0; k < M; ++k) if (slot[q] == (uint32_t)k) f = nf[k];
+#pragma unroll
+				for (int j = M - 1; j >= 0; --j) if ((uint32_t)j < oc && of[j] == f) wslot = still_base + (uint32_t)j;
+				cid[q] = on ? still_base + slot[q] : 0xFFFFFFFFu;
+				s_wid[wave][lane * M + q] = on ? wslot : 0xFFFFFFFFu;
+			}
+			// this step's feature words and count become the slot cache's (the impulses follow at the end)
+			if (still_has) {
+#pragma unroll
+				for (int k = 0; k < M; ++k) if ((uint32_t)k < cnt) sv.sc_feat[still_base + k] = nf[k];
+				sv.sc_count[still_rec] = cnt;
+			}
+		} else {
+		if (CONTIG) cnt = sp.y & 15u;
+		else if (mine) { b = off[x]; cnt = off[x + 1] - b; }
 #pragma unroll
 		for (int q = 0; q < M; ++q) {
 			if (CONTIG) cid[q] = (uint32_t)q < cnt ? sp.x + ((sp.y >> (4 + 3 * q)) & 7u) : 0xFFFFFFFFu;
 			else cid[q] = (uint32_t)q < cnt ? adj[b + q] : 0xFFFFFFFFu;
 			first = min(first, cid[q]);
+		}
 		}
 #pragma unroll
 		for (int q = 0; q < M; ++q) scid[lane * M + q] = cid[q];
@@ -931,7 +1005,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			// (CONTIG: the body's role in its one pair rides in simple[x], bit 28 -- no load of the body pair)
 			sflags[k] = (!CONTIG && bodies[c].a == wave_x0 + j) ? 2u : 0u;
 			if (STILL) {
-				sw[k] = *reinterpret_cast<const float4*>(cv.cdata + c);
+				const uint32_t wc = s_wid[wave][e];
+				const float4 wv = *reinterpret_cast<const float4*>(cv.cdata + (wc != 0xFFFFFFFFu ? wc : 0u));
+				sw[k] = wc != 0xFFFFFFFFu ? wv : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 			} else if (FUSED) {
 				const uint32_t hj = s_hint[wave][j];
 				sguess[k] = hj != NH_HINT_NONE ? hj + (sc[k] - s_first[wave][j]) : sc[k];
@@ -992,7 +1068,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			if ((uint32_t)q < cnt) {
 				const nh_ob_slot o = slot[lane * M + q];
 				const uint32_t flags = __float_as_uint(o.w.w);
-				is_a[q] = CONTIG ? ((sp.y >> 28) & 1u) != 0 : (flags & 2u) != 0;
+				is_a[q] = STILL ? (br & NH_BODY_REC_IS_A) != 0 : (CONTIG ? ((sp.y >> 28) & 1u) != 0 : (flags & 2u) != 0);
 				nh_contact_in ci = { o.c0.x, o.c0.y, o.c0.z, o.c0.w, o.c1.x, o.c1.y, o.c1.z, o.c1.w };
 				nh_build_row1(ci, posx, IX, v.mass_inverse, is_a[q], r[q]);
 				if (FUSED) {
@@ -1010,7 +1086,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		if (FUSED && !STILL && mine) hint[x] = first;          // where this body's contacts start in what becomes the next step's cache
 		// (CONTIG: a body's role is one bit for all its contacts, and in most scenes the static world is always "a": when no lane of the wave
 		// has D = a the role selects drop out of the sweep)
-		if (CONTIG && __builtin_amdgcn_ballot_w64(mine && ((sp.y >> 28) & 1u) != 0) == 0) {
+		if (CONTIG && __builtin_amdgcn_ballot_w64(mine && (STILL ? (still_has && (br & NH_BODY_REC_IS_A) != 0) : ((sp.y >> 28) & 1u) != 0)) == 0) {
 			for (uint32_t it = 0; it < iterations; ++it) {
 #pragma unroll
 				for (int q = 0; q < M; ++q)
@@ -1923,9 +1999,18 @@ extern "C" const nh_CachedContactImpulse* nh_contact_impulses_device(const nh_Co
 		// before the solver has run this holds the warm-start impulses, afterwards the solved ones: make either visible
 		if (m->ctx->pending) nh_flush_pending(m->ctx);
 		else if (!m->consumed) materialize_lookup(m->ctx, m);
+		nh_StillStep& ss = m->ctx->still;
+		if (ss.active && ss.resolved && m->consumed && m->cdata == ss.cache_data) {
+			// a still step: the solved impulses live in the slot cache; in tag order they are what the exported cache holds (nothing is culled in a still step)
+			if (nh_still_sync_outputs(m->ctx) == NH_OK)
+				hipMemcpyAsync(m->data, ss.cache.data, sizeof(nh_CachedContactImpulse) * (size_t)(m->capacity < ss.cache.capacity ? m->capacity : ss.cache.capacity), hipMemcpyDeviceToDevice, m->ctx->stream);
+		}
 	}
 	return d->data;
 }
+
+__global__ void k_cache_to_slots(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ dense_slot, const nh_CachedContactImpulse* __restrict__ imp,
+                                 const uint32_t* __restrict__ features, const nh_Record* __restrict__ rec, float4* __restrict__ sc_imp, uint32_t* __restrict__ sc_feat, uint32_t* __restrict__ sc_count);
 
 extern "C" int nh_write_cached_impulses(nh_context* ctx, nh_ContactCache* cache, const nh_ContactData* contacts, nh_ContactImpulseData* imp) {
 	if (!ctx || !cache || !contacts || !imp) return NH_ERR_INVALID;
@@ -1938,6 +2023,8 @@ extern "C" int nh_write_cached_impulses(nh_context* ctx, nh_ContactCache* cache,
 		ss.cache_ok = imp->consumed && !imp->cull_pending && !(ctx->flags & NH_FLAG_SYNC_COUNTS) && ctx->h_state->sleeping == 0u && ctx->h_state->culled == 0u &&
 		              contacts->data == ss.lay_contacts.data && contacts->tags == ss.lay_contacts.tags;
 		ss.cache_tags = cache->tags; ss.cache_features = cache->features; ss.cache_data = cache->data; ss.cache_capacity = cache->capacity;
+		ss.cache = *cache;
+		ss.slots_current = false;
 	}
 	if (!imp->consumed) materialize_lookup(ctx, imp);      // no setup ran on this handle: the cache is rewritten from the looked-up impulses
 	if (imp->cull_pending) {
@@ -1950,6 +2037,12 @@ extern "C" int nh_write_cached_impulses(nh_context* ctx, nh_ContactCache* cache,
 	NH_LAUNCH(ctx, "write_cache", k_write_cache, nh_grid_for((uint64_t)contacts->capacity + cache->capacity, 256, 4096), 256, st,
 	          contacts->tags, contacts->features, imp->data, imp->culled_tags, imp->culled_features, imp->culled_data,
 	          cache->tags, cache->features, cache->data, cache->capacity);
+	if (ctx->still.ok_next && ctx->still.cache_ok && !ctx->still.disabled && (ctx->flags & NH_FLAG_FUSED_STEP) && ctx->sort_seeded) {
+		// the next step may be a still one: the cache goes to the slots as well (solved impulse + feature word to the raw slot each contact came from)
+		NH_LAUNCH(ctx, "cache_to_slots", k_cache_to_slots, nh_grid_for(contacts->capacity, 256, 4096), 256, st, ctx->dense_slot, imp->data, contacts->features, ctx->rec,
+		          ctx->sc_imp, ctx->sc_feat, ctx->sc_count);
+		ctx->still.slots_current = true;
+	}
 	if (ctx->flags & NH_FLAG_SYNC_COUNTS) {
 		nh_Counts c;
 		int rc = nh_read_counts(ctx, &c);
@@ -2020,7 +2113,7 @@ extern "C" int nh_setup_contact_constraints(nh_context* ctx, const nh_ActiveBodi
 	if (ctx->still.active && !ctx->still.resolved) ctx->still.setup_d = d;      // still step: classes and records are last step's (nh_still_abandon launches the kernel if it comes to that)
 	else
 	NH_LAUNCH(ctx, "adjacency_simple", k_adj_simple, nh_grid_for(B, 256, 4096), 256, st, B, ctx->deg, reinterpret_cast<const unsigned long long*>(ctx->deg + 2u * NH_DEG_STRIDE(B)), ctx->deg + 4u * NH_DEG_STRIDE(B), slot_key,
-	          d->body_class, bodies->properties, bodies->momentum, d->simple);
+	          d->body_class, bodies->properties, bodies->momentum, d->simple, ctx->body_rec, ctx->body_pos, ctx->sort_seeded ? ctx->sort_sorted_idx : (const uint32_t*)nullptr);
 	if (ctx->hint_capacity < B) {
 		// library-owned, persistent across steps: per body, where its contacts started in the previous step's list (warm-start hint)
 		if (ctx->hint) NH_HIP_CHECK(ctx, hipFree(ctx->hint));
@@ -2271,8 +2364,8 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		// may the NEXT step be launched as a still step?  (nh_internal.h: nh_StillStep)  This step laid its contacts out in a layout a still step can write through, every
 		// dynamic body sits in one pair with an inert static world (the fused solver owns them all), nothing sleeps, nothing was culled
 		const nh_DevState* h = ctx->h_state;
-		ctx->still.ok_next = h->lay_valid && !h->has_other && h->static_inert && !h->has_pending && !h->has_static8 && !h->has_staticN && !h->any_sleeping && h->sleeping == 0u &&
-		                     h->culled == 0u && h->general_contacts == 0u && !h->error && h->contacts != 0u;
+		ctx->still.ok_next = h->lay_valid && !h->has_unstable && h->static_inert && !h->has_pending && !h->has_static8 && !h->has_staticN && !h->any_sleeping && h->sleeping == 0u &&
+		                     h->culled == 0u && h->general_contacts == 0u && !h->error;
 	}
 	// NH_FLAG_FUSED_STEP: gravity / damping of the bodies the fused solver does not own, before anything else reads their momentum -- not launched
 	// at all when every body is the fused solver's (a landed drop scene)
@@ -2446,7 +2539,7 @@ static void launch_apply_static(nh_context* ctx, nh_ContactConstraintData* d, co
 	auto go1 = [&](const char* name, auto kernel, uint32_t cls_a, uint32_t cls_b) {
 		NH_LAUNCH(ctx, name, kernel, nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
 		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, cls_a, cls_b,
-		          (fused && drop_states) ? 2u : 0u, (const uint2*)nullptr, nh_FusedStep());
+		          (fused && drop_states) ? 2u : 0u, (const uint2*)nullptr, nh_FusedStep(), nh_StillView());
 	};
 	const bool late = d->has_late;
 	if (d->static_inert) {
@@ -2492,16 +2585,17 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 		// ---- still step: ONE launch, then the round trip that confirms it ----
 		nh_StillStep& ss = ctx->still;
 		const bool usable = applied && from_apply && drop_states && iterations != 0u && d->finish_pending && ss.setup_d == d && ctx->grav.pending && ctx->grav.momentum == bodies->momentum &&
-		                    bodies->idle_counters && bodies->momentum == ss.bodies.momentum && bodies->transforms == ss.bodies.transforms && d->imp->cdata == ss.cache_data;
+		                    bodies->idle_counters && bodies->momentum == ss.bodies.momentum && bodies->transforms == ss.bodies.transforms && d->imp->cdata == ss.cache_data && ss.slots_current;
 		bool confirmed = false;
 		if (usable) {
 			const uint32_t B = d->body_count;
-			nh_CacheView cv = { d->imp->tags, d->imp->features, d->imp->ctags, d->imp->cfeatures, d->imp->cdata, ctx->d_state };
+			nh_CacheView cv = { nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const nh_CachedContactImpulse*>(ctx->sc_imp), ctx->d_state };
+			nh_StillView sv = { ctx->body_rec, ctx->body_pos, ctx->cnt_sorted, ctx->start_sorted, ctx->raw_feature, ctx->sc_feat, ctx->sc_count, ctx->lay_capacity };
 			nh_FusedStep fs = nh_FusedStep();
 			fs.gx_dt = ctx->grav.gx_dt; fs.gy_dt = ctx->grav.gy_dt; fs.gz_dt = ctx->grav.gz_dt; fs.damping = ctx->grav.damping; fs.time_step = ctx->grav.time_step;
 			fs.bits = 3u; fs.idle = bodies->idle_counters; fs.parity = ctx->step_parity;
 #define NH_SOLVE_STILL(NWAVES) NH_LAUNCH(ctx, "solve_one_body", (k_solve_one_body<4, true, true, NWAVES, true>), (B + 64u * NWAVES - 1u) / (64u * NWAVES), 64 * NWAVES, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum, \
-		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fs)
+		          (float4*)d->states, iterations, ctx->raw_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fs, sv)
 			if (ctx->env_solver_waves == 4) NH_SOLVE_STILL(4); else if (ctx->env_solver_waves == 2) NH_SOLVE_STILL(2); else NH_SOLVE_STILL(1);
 			// the step's one round trip: did every check hold?
 			NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, NH_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -2513,6 +2607,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 			nh_Counts c;
 			nh_counts_from_mirror(ctx, &c);              // (the sleep prediction: largest idle counter this step saw)
 			ss.resolved = true; ss.setup_d = nullptr;
+			ss.cache_stale = true; ss.contacts_stale = true;        // (the caller's cache and dense contact arrays are last written by an earlier step: nh_still_sync_outputs)
 			d->finish_pending = false; d->has_late = false; d->has_static8 = d->has_staticN = false; d->static_inert = true; d->general_contacts = 0; d->levels = 0;
 			d->imp->cull_pending = false; d->imp->lookup_pending = false;
 			ctx->last_general_contacts = 0;
@@ -2539,7 +2634,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 		}
 #define NH_SOLVE_CONTIG(NWAVES) NH_LAUNCH(ctx, "solve_one_body", (k_solve_one_body<4, true, true, NWAVES>), (B + 64u * NWAVES - 1u) / (64u * NWAVES), 64 * NWAVES, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum, \
 		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, \
-		          1u | (drop_states ? 2u : 0u), d->simple, fs)
+		          1u | (drop_states ? 2u : 0u), d->simple, fs, nh_StillView())
 		if (ctx->env_solver_waves == 4) NH_SOLVE_CONTIG(4); else if (ctx->env_solver_waves == 2) NH_SOLVE_CONTIG(2); else NH_SOLVE_CONTIG(1);
 		ctx->grav.rest_pending = gravity_here;        // everybody else's gravity: finish_setup, once the round trip has told whether there is anybody else
 		int rc = finish_setup(ctx, d);
@@ -2551,6 +2646,74 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 }
 
 int nh_still_collide_again(nh_context* ctx);       // nh_collide.hip
+int nh_still_view_contacts(nh_context* ctx);       // nh_collide.hip: the dense contact list laid out again from the slots (k_gather_contacts, view only)
+
+// ---- the contact cache between its two homes: the caller's arrays (tag order) and the slots (nh_internal.h, contact storage by slot) ------------------------
+// full step -> slots: the solved impulse and feature word of dense contact c go to the raw slot c came from (k_gather_contacts recorded it), every record's count
+__global__ __launch_bounds__(256) void k_cache_to_slots(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ dense_slot, const nh_CachedContactImpulse* __restrict__ imp,
+                                                        const uint32_t* __restrict__ features, const nh_Record* __restrict__ rec, float4* __restrict__ sc_imp, uint32_t* __restrict__ sc_feat,
+                                                        uint32_t* __restrict__ sc_count) {
+	const uint32_t n = st->contacts, nrec = st->records;
+	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+		const uint32_t slot = dense_slot[c];
+		sc_imp[slot] = *reinterpret_cast<const float4*>(imp + c);
+		sc_feat[slot] = features[c];
+	}
+	for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nrec; r += gridDim.x * blockDim.x) { const uint32_t k = rec[r].count; sc_count[r] = (k & NH_REC_SLEEPING) ? 0u : k; }
+}
+
+// slots -> the caller's cache arrays, in tag order: counts in tag order (scanned by the host's launch in between), then the entries ranked by feature word
+__global__ __launch_bounds__(256) void k_slot_counts_sorted(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ sc_count, uint32_t* __restrict__ out) {
+	const uint32_t nrec = st->records;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= nrec; i += gridDim.x * blockDim.x) out[i] = i < nrec ? min(sc_count[sorted_idx[i]], 4u) : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_slots_to_cache(nh_DevState* __restrict__ st, const uint32_t* __restrict__ sorted_idx, const uint64_t* __restrict__ sorted_keys, const uint32_t* __restrict__ cnt,
+                                                        const uint32_t* __restrict__ start, const float4* __restrict__ sc_imp, const uint32_t* __restrict__ sc_feat, uint32_t pair_cap,
+                                                        uint64_t* __restrict__ otags, uint32_t* __restrict__ ofeatures, nh_CachedContactImpulse* __restrict__ odata, uint32_t capacity) {
+	const uint32_t nrec = st->records, n_bb = min(st->pairs, pair_cap);
+	if (blockIdx.x == 0 && threadIdx.x == 0) { const uint32_t total = start[nrec]; if (total > capacity) { st->error = NH_ERR_CACHE_CAPACITY; st->cache = 0u; } else st->cache = total; }
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += gridDim.x * blockDim.x) {
+		const uint32_t k = cnt[i];
+		if (!k) continue;
+		const uint32_t ri = sorted_idx[i], base = ri < n_bb ? 4u * ri : 4u * n_bb + (ri - n_bb), first = start[i];
+		if (first + k > capacity) continue;
+		const uint64_t key = sorted_keys[i];
+		uint32_t f[4];
+		for (uint32_t j = 0; j < 4u; ++j) f[j] = j < k ? sc_feat[base + j] : 0u;
+		for (uint32_t j = 0; j < k; ++j) {
+			uint32_t r = 0;
+			for (uint32_t q = 0; q < k; ++q) r += (f[q] < f[j] || (f[q] == f[j] && q < j)) ? 1u : 0u;
+			otags[first + r] = key; ofeatures[first + r] = f[j];
+			*reinterpret_cast<float4*>(odata + first + r) = sc_imp[base + j];
+		}
+	}
+}
+
+int nh_still_export_cache(nh_context* ctx) {
+	nh_StillStep& ss = ctx->still;
+	if (!ss.cache_stale) return NH_OK;
+	ss.cache_stale = false;
+	nh_DevState* st = ctx->d_state;
+	const uint32_t P = ctx->lay_capacity;
+	// (scratch: the tag-order starts of the dense VIEW are this step's -- a failed still step may already have overwritten them -- so the cache gets its own scan;
+	// dense_slot is free between two full steps)
+	uint32_t* tmp_cnt = ctx->exp_cnt; uint32_t* tmp_start = ctx->exp_start;
+	NH_LAUNCH(ctx, "slot_counts", k_slot_counts_sorted, nh_grid_for(P, 256, 2048), 256, st, ctx->sort_sorted_idx, ctx->sc_count, tmp_cnt);
+	nh_scan_u32(ctx, tmp_cnt, tmp_start, &st->records, 1, ctx->exp_scan_tmp, nullptr);
+	NH_LAUNCH(ctx, "slots_to_cache", k_slots_to_cache, nh_grid_for(P, 256, 4096), 256, st, ctx->sort_sorted_idx, ctx->sort_sorted_keys, tmp_cnt, tmp_start, ctx->sc_imp, ctx->sc_feat, P,
+	          ss.cache.tags, ss.cache.features, ss.cache.data, ss.cache.capacity);
+	return NH_OK;
+}
+
+int nh_still_sync_outputs(nh_context* ctx) {
+	nh_StillStep& ss = ctx->still;
+	if (ss.active && !ss.resolved) return NH_OK;          // (an unconfirmed still step is abandoned by the caller first: nh_flush_pending)
+	int rc = nh_still_export_cache(ctx);
+	if (rc) return rc;
+	if (ss.contacts_stale) { ss.contacts_stale = false; rc = nh_still_view_contacts(ctx); }
+	return rc;
+}
 
 // A still step that has not been confirmed, met by anything but the next call of the sample's order (or failed on the device): the step is launched again in full.
 int nh_still_abandon(nh_context* ctx) {
@@ -2558,13 +2721,17 @@ int nh_still_abandon(nh_context* ctx) {
 	if (!ss.active || ss.resolved || ss.replaying) return NH_OK;
 	nh_ContactConstraintData* d = ss.setup_d;
 	ss.setup_d = nullptr;
-	int rc = nh_still_collide_again(ctx);
+	int rc = nh_still_export_cache(ctx);                  // (the slot cache holds the last confirmed step's impulses: the full solver reads the caller's arrays)
+	if (rc) return rc;
+	ss.contacts_stale = false;                         // (the replay lays the dense list out itself)
+	rc = nh_still_collide_again(ctx);
 	if (rc) return rc;
 	if (d) {
 		// the adjacency kernel the still setup left out (default order only: still steps are not launched in exact-order mode)
 		const uint32_t B = d->body_count;
 		NH_LAUNCH(ctx, "adjacency_simple", k_adj_simple, nh_grid_for(B, 256, 4096), 256, ctx->d_state, B, ctx->deg, reinterpret_cast<const unsigned long long*>(ctx->deg + 2u * NH_DEG_STRIDE(B)),
-		          ctx->deg + 4u * NH_DEG_STRIDE(B), (const uint32_t*)nullptr, d->body_class, d->bodies_at_setup.properties, d->bodies_at_setup.momentum, d->simple);
+		          ctx->deg + 4u * NH_DEG_STRIDE(B), (const uint32_t*)nullptr, d->body_class, d->bodies_at_setup.properties, d->bodies_at_setup.momentum, d->simple,
+		          ctx->body_rec, ctx->body_pos, ctx->sort_seeded ? ctx->sort_sorted_idx : (const uint32_t*)nullptr);
 	}
 	return NH_OK;
 }
