@@ -74,6 +74,16 @@ KERNEL_BYTES = {
     #   NOT moved in this mode: the body pair (the CONTIG instantiation never loads it), the solver state (16 B w, only kept for a further
     #   apply call), CSR offsets / adjacency (the one-record contact list replaces them)
     "solve_one_body": ("K", 72 + 16 + 23.5 + 17.25),       # = 128.75; main() adds the 16-byte state when the world keeps states, drops the fused advance's 8.5 when it does not fuse
+    # still steps (include/nudge_hip.h note 9): transforms + AABBs + the idle scan; the narrowphase straight from the kept pair list into the pairs' own raw slots;
+    # the fused solver from the slots and the slot cache
+    "xform_still": ("C", 32 + 32 + 16 + 4 + 32 + 32 + 4 + 32 + 1),      # as xform_aabb, + the inflated box it checks (32 r), the idle counter (1 r)
+    "narrowphase_still": ("P", 8 + 2 * 32 + 2 * (32 + 16 + 4) + 8 + 4 + 4 + 4 * 36 + 4 + 4),   # kept pair, 2 AABBs, 2 x (transform, shape, tag), key, tag-order position, body record -> 4 contacts x 36 B, count x 2
+    "narrowphase_sph_still": ("P", 8 + 2 * 32 + 2 * (32 + 4 + 4) + 8 + 4 + 4 + 36 + 4 + 4),
+    #   per contact: contact 32 r, cached impulse 16 r, solved impulse 16 w                                                                = 48 r + 16 w
+    #   per body (4 contacts): record 4, tag-order position 4, count 4, first contact 4, 4 feature words 16, cached feature words 16 r + 16 w, cached count 4 r + 4 w,
+    #                          transform 32 r + 32 w, properties 16, momentum 32 r + 32 w, idle 1 r + 1 w                                   = 133 r + 85 w -> 33.25 r + 21.25 w
+    "solve_still": ("K", 48 + 16 + 33.25 + 21.25),         # = 118.5
+    "slot_counts": ("R", 4 + 4 + 4), "slots_to_cache": ("K", 16 + 4 + 28), "cache_to_slots": ("K", 4 + 16 + 4 + 20),
     "gravity_rest": ("B", 4 + 1),                           # active list + class of every body; momentum only of bodies outside the fused solver
     "advance_rest": ("B", 4 + 1),
     "solve_one_body8": ("K", 112 + 36),
@@ -108,7 +118,8 @@ def grid_table_entries(C):
     return min(want, 1 << 24)
 
 # timer name (nh_* launch sites) -> kernel symbol prefix in the rocprofv3 PMC export (profiles/export_pmc.py)
-PMC_KERNEL = {"solve_one_body": "k_solve_one_body<4, true, true>", "apply_static": "k_apply_static<4, true>", "narrowphase": "k_narrowphase",
+PMC_KERNEL = {"solve_one_body": "k_solve_one_body<4, true, true, 1, false>", "solve_still": "k_solve_one_body<4, true, true, 1, true>", "narrowphase_still": "k_narrowphase<false, true>",
+              "xform_still": "k_xform<true>", "apply_static": "k_apply_static<4, true>", "narrowphase": "k_narrowphase<false, false>",
               "gather_contacts": "k_gather_contacts", "find_pairs": "k_find_pairs", "radix_pass": "os_pass<unsigned long, unsigned int, true>",
               "apply_level": "k_level_exec<false>", "write_cache": "k_write_cache", "xform_aabb": "k_xform", "blk_sweep": "k_blk_sweep<false, true>"}
 

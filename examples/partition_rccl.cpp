@@ -1,30 +1,29 @@
-// examples/partition_rccl.cpp -- C++ host for the MULTI-GPU path: one process per GPU, one x-slab of a drop-tile world per process,
-// ghost-body halo exchange every step with ncclSend / ncclRecv (RCCL over xGMI) on the records of nh_halo_pack / nh_halo_unpack.
+// examples/partition_rccl.cpp -- C++ host of the MULTI-GPU path: one x-slab of a world per rank, the slab logic behind the C ABI
+// (include/nudge_hip.h "multi-GPU": nh_partition_* -- migration, ghost listing / installation, collider rebuild, per-step halo records, cut re-balancing, all
+// kernels with device-side counts), and THIS program as the transport: RCCL point-to-point (ncclSend / ncclRecv over xGMI) between one process per GPU, or
+// device-to-device copies between several ranks held by one process on one GPU (NUDGE_LOCAL_RANKS=R: what a one-GPU box can run of it, and what the tests
+// compare with the Python host nudge_amd/partition.py bit for bit -- both are thin transports over the same entry points).
 //
-// The shape of BASELINE.json configs[4] (boxes dropping onto ground slabs): bodies never leave their slab sideways, so
-// this example keeps STATIC ghost lists and does no migration (nudge_amd/partition.py is the general host: refresh epochs, migration,
-// equal-count cuts; it talks to the same two C-ABI entry points through torch.distributed).  What it shows is the host side in the
-// reference's own language on the performance path:
-//   * every rank generates, from the same counter-based generator, the tiles that touch its slab: the bodies whose centre lies in
-//     [lo, hi) are OWNED, those within `margin` outside are GHOSTS (slots after the owned ones, ordinary bodies to the engine);
-//   * per step:  nh_halo_pack(owned bodies near a cut) -> ncclGroupStart; ncclSend / ncclRecv with both neighbours; ncclGroupEnd
-//                -> nh_halo_unpack(into the ghost slots) -> the eight calls of the reference's sub-step (example/main.cpp:274-328);
-//     everything on ONE HIP stream, no host synchronisation inside the loop, no collective on the data path;
-//   * both sides of a cut enumerate the bodies in the same (generation) order, so a message needs no index list.
-// Contacts between an owned body and a ghost are solved on both ranks and the owner's state wins at the next exchange (exact when no
-// contact crosses a cut, which is the case here: boxes only touch the ground).
+//   every `epoch` steps:  [re-balance: the two ranks at a cut exchange their body counts; the heavier one calls nh_partition_choose_cut and sends the value]
+//                         nh_partition_pack_migrants -> exchange -> nh_partition_unpack_migrants
+//                         nh_partition_pack_ghosts   -> exchange -> nh_partition_unpack_ghosts
+//   every other step:     nh_partition_pack_step     -> exchange -> nh_partition_unpack_step
+//   then the reference's sub-step on the local world (example/main.cpp:274-328): the eight calls of the C ABI.
+// No collective on the data path; per refresh one host synchronisation per rank (the message lengths), none on the other steps.
 //
-// build:  make -C nudge_amd/csrc partition_rccl            (hipcc/g++ + -lrccl -lamdhip64 -lnudge_hip)
-// run:    one process per GPU, e.g.
-//         for r in 0 1 2 3 4 5 6 7; do RANK=$r WORLD_SIZE=8 LOCAL_RANK=$r NUDGE_NCCL_ID_FILE=/tmp/nudge.id \
-//             nudge_amd/partition_rccl 16 2 90 200 & done; wait
-//         arguments: tile columns per rank, tile rows, boxes per tile side, steps
-//         WORLD_SIZE=1 runs the whole world on one GPU without any communication (what tests/test_gpu_callsite.py does).
+// The world: a scene file written by tests/partition_util.py (`--scene FILE --cuts x1,x2,... STEPS`), or the drop-tile world of BASELINE.json configs[4] from a
+// counter-based generator (`COLS_PER_RANK ROWS SIDE STEPS`: every rank generates the same world and keeps its slab).
+//
+// build:  make -C nudge_amd/csrc partition_rccl
+// run:    one process per GPU:   for r in 0 .. 7: RANK=$r WORLD_SIZE=8 LOCAL_RANK=$r NUDGE_NCCL_ID_FILE=/tmp/nudge.id nudge_amd/partition_rccl 6 46 90 200 &
+//         one GPU, three ranks:  NUDGE_LOCAL_RANKS=3 nudge_amd/partition_rccl 2 2 24 120
+//         NUDGE_RCCL_LOOPBACK=1 (WORLD_SIZE=1): the per-step records of the first bodies also travel ncclSend(self) / ncclRecv(self) -- RCCL executed on one GPU.
 #include "../include/nudge_hip.h"
 
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <math.h>
 #include <stdint.h>
@@ -39,6 +38,33 @@
 #define NH_OK_(expr) do { int rc_ = (expr); if (rc_) { fprintf(stderr, "%s: %s\n", #expr, nh_error_string(rc_)); exit(4); } } while (0)
 #define NCCL_OK(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { fprintf(stderr, "%s: %s\n", #expr, ncclGetErrorString(r_)); exit(5); } } while (0)
 
+// ---- the whole world on the host (what nudge_amd/scenes.py builds; layouts of nudge_hip.h) ----------------------------------------------------------------
+struct Scene {
+	std::vector<nh_Transform> body_xf; std::vector<nh_BodyProperties> body_props; std::vector<nh_BodyMomentum> body_mom; std::vector<uint8_t> idle;
+	std::vector<uint32_t> box_tags; std::vector<nh_BoxCollider> box_data; std::vector<nh_Transform> box_xf;
+	std::vector<uint32_t> sph_tags; std::vector<nh_SphereCollider> sph_data; std::vector<nh_Transform> sph_xf;
+	double time_step = 1.0 / 120.0, gravity = 9.82, damping_rate = 0.25;
+	uint32_t iterations = 8;
+};
+
+template<class T> static void read_vec(FILE* f, std::vector<T>& v, size_t n) { v.resize(n); if (n && fread(v.data(), sizeof(T), n, f) != n) { fprintf(stderr, "scene file truncated\n"); exit(2); } }
+
+// file layout (tests/partition_util.py: write_scene_file): "NHSC" | u32 version = 1, nb, nbox, nsph, iterations | f64 time_step, gravity, damping_rate | the ten arrays
+static Scene load_scene(const char* path) {
+	FILE* f = fopen(path, "rb");
+	if (!f) { perror(path); exit(2); }
+	char magic[4]; uint32_t head[5]; double par[3];
+	if (fread(magic, 1, 4, f) != 4 || memcmp(magic, "NHSC", 4) || fread(head, 4, 5, f) != 5 || head[0] != 1u || fread(par, 8, 3, f) != 3) { fprintf(stderr, "%s: not a scene file\n", path); exit(2); }
+	Scene s;
+	const size_t nb = head[1], nbox = head[2], nsph = head[3];
+	s.iterations = head[4]; s.time_step = par[0]; s.gravity = par[1]; s.damping_rate = par[2];
+	read_vec(f, s.body_xf, nb); read_vec(f, s.body_props, nb); read_vec(f, s.body_mom, nb); read_vec(f, s.idle, nb);
+	read_vec(f, s.box_tags, nbox); read_vec(f, s.box_data, nbox); read_vec(f, s.box_xf, nbox);
+	read_vec(f, s.sph_tags, nsph); read_vec(f, s.sph_data, nsph); read_vec(f, s.sph_xf, nsph);
+	fclose(f);
+	return s;
+}
+
 // counter-based generator (splitmix64): the same body on every rank that generates it
 static float u01(uint64_t seed, uint64_t counter) {
 	uint64_t x = seed + (counter + 1) * 0x9E3779B97F4A7C15ull;
@@ -48,11 +74,48 @@ static float u01(uint64_t seed, uint64_t counter) {
 	return (float)((double)(x >> 40) * (1.0 / 16777216.0));
 }
 
-struct Body { nh_Transform xf; nh_BodyProperties props; nh_BoxCollider box; uint32_t tag; };
+// cols x rows tiles of side x side boxes on a 3.0 pitch, one ground slab per tile (the shape of BASELINE.json configs[1] / configs[4])
+static Scene drop_tiles(int cols, int rows, int side) {
+	Scene s;
+	const uint64_t seed = 0x9E3779B97F4A7C15ull ^ 5ull;
+	const float pitch = 3.0f, half = side * 1.5f + 2.0f, tile_pitch = 2.0f * half + 4.0f;
+	const uint32_t n_tiles = (uint32_t)(cols * rows);
+	nh_Transform ident = {}; ident.rotation[3] = 1.0f;
+	s.body_xf.push_back(ident); s.body_props.push_back(nh_BodyProperties()); s.body_mom.push_back(nh_BodyMomentum()); s.idle.push_back(0);
+	for (int tz = 0; tz < rows; ++tz) for (int tx = 0; tx < cols; ++tx) {
+		nh_Transform st = ident; st.position[0] = tx * tile_pitch; st.position[1] = -20.0f; st.position[2] = tz * tile_pitch; st.body = 0;
+		nh_BoxCollider sb = { { half, 10.0f, half }, 0.0f };
+		s.box_xf.push_back(st); s.box_data.push_back(sb); s.box_tags.push_back((uint32_t)(tz * cols + tx));          // static colliders: tags 0 .. n_tiles-1
+	}
+	for (int tz = 0; tz < rows; ++tz) for (int tx = 0; tx < cols; ++tx) {
+		const float ox = tx * tile_pitch, oz = tz * tile_pitch;
+		const uint32_t tile = (uint32_t)(tz * cols + tx);
+		for (int iz = 0; iz < side; ++iz) for (int ix = 0; ix < side; ++ix) {
+			const uint64_t g = (uint64_t)tile * side * side + (uint64_t)iz * side + ix;
+			const float sx = 0.5f + 0.5f * u01(seed, 8 * g), sy = 0.5f + 0.5f * u01(seed, 8 * g + 1), sz = 0.5f + 0.5f * u01(seed, 8 * g + 2);
+			const float yaw = 0.5f * u01(seed, 8 * g + 3);
+			nh_Transform t = ident;
+			t.position[0] = ox + (ix - (side - 1) * 0.5f) * pitch + 0.2f * u01(seed, 8 * g + 4);
+			t.position[2] = oz + (iz - (side - 1) * 0.5f) * pitch + 0.2f * u01(seed, 8 * g + 5);
+			t.position[1] = -10.0f + 0.5f + 0.5f * u01(seed, 8 * g + 6) + sy;
+			t.rotation[1] = sinf(0.5f * yaw); t.rotation[3] = cosf(0.5f * yaw);
+			const float mass = 8.0f * sx * sy * sz, k = mass / 3.0f;            // add_box of the sample application (example/main.cpp:112-145)
+			nh_BodyProperties p;
+			p.mass_inverse = 1.0f / mass;
+			p.inertia_inverse[0] = 1.0f / (k * sy * sy + k * sz * sz); p.inertia_inverse[1] = 1.0f / (k * sx * sx + k * sz * sz); p.inertia_inverse[2] = 1.0f / (k * sx * sx + k * sy * sy);
+			const uint32_t body = (uint32_t)s.body_xf.size();
+			s.body_xf.push_back(t); s.body_props.push_back(p); s.body_mom.push_back(nh_BodyMomentum()); s.idle.push_back(0);
+			nh_Transform local = ident; local.body = body;
+			nh_BoxCollider b = { { sx, sy, sz }, 0.0f };
+			s.box_xf.push_back(local); s.box_data.push_back(b); s.box_tags.push_back(n_tiles + (uint32_t)g);
+		}
+	}
+	return s;
+}
 
 template<class T>
-static T* to_device(const std::vector<T>& v, size_t capacity = 0) {
-	size_t n = capacity > v.size() ? capacity : v.size();
+static T* to_device(const std::vector<T>& v, size_t capacity) {
+	const size_t n = capacity > v.size() ? capacity : v.size();
 	T* d = nullptr;
 	HIP_OK(hipMalloc((void**)&d, sizeof(T) * (n ? n : 1)));
 	HIP_OK(hipMemset(d, 0, sizeof(T) * (n ? n : 1)));
@@ -60,223 +123,331 @@ static T* to_device(const std::vector<T>& v, size_t capacity = 0) {
 	return d;
 }
 
+// ---- one rank: its slab of the scene as a device-resident world + the nh_partition that keeps it ---------------------------------------------------------
+struct Rank {
+	int rank = 0, ranks = 1;
+	nh_context* ctx = nullptr;
+	nh_partition* part = nullptr;
+	nh_BodyData bodies = {}; nh_ColliderData colliders = {}; nh_BodyConnections connections = { nullptr, 0 };
+	nh_ContactData contacts = {}; nh_ContactCache cache = {}; nh_ActiveBodies active = {}; nh_Arena arena = {};
+	uint32_t body_capacity = 0, msg_capacity = 0;
+	void* out[2] = { nullptr, nullptr }; void* in[2] = { nullptr, nullptr };          // message buffers: [0] left neighbour, [1] right neighbour
+	uint32_t out_count[2] = { 0, 0 }, in_count[2] = { 0, 0 };
+	bool has(int side) const { return side == 0 ? rank > 0 : rank + 1 < ranks; }
+};
+
+// the slab [lo, hi) of `scene` for `rank`: what nudge_amd/partition.py split_scene() builds (every static collider kept; slots in scene order)
+static void make_rank(Rank& R, const Scene& s, const std::vector<double>& cuts, int rank, int device, hipStream_t stream, uint32_t epoch, double speed_floor, double max_reach, uint32_t min_extra, double slack) {
+	R.rank = rank; R.ranks = (int)cuts.size() + 1;
+	const double lo = rank == 0 ? -HUGE_VAL : cuts[rank - 1], hi = rank + 1 == R.ranks ? HUGE_VAL : cuts[rank];
+	const size_t nb = s.body_xf.size();
+	std::vector<uint32_t> slot_of(nb, 0u);
+	std::vector<nh_Transform> xf(1, s.body_xf[0]); std::vector<nh_BodyProperties> props(1, s.body_props[0]); std::vector<nh_BodyMomentum> mom(1, s.body_mom[0]); std::vector<uint8_t> idle(1, s.idle[0]);
+	for (size_t i = 1; i < nb; ++i) {
+		const float x = s.body_xf[i].position[0];
+		if (!(x >= lo && x < hi)) continue;
+		slot_of[i] = (uint32_t)xf.size();
+		nh_Transform t = s.body_xf[i]; t.body = (uint32_t)i;                          // the global id rides in the field the engine does not use for bodies (nudge.h:36)
+		xf.push_back(t); props.push_back(s.body_props[i]); mom.push_back(s.body_mom[i]); idle.push_back(s.idle[i]);
+	}
+	const uint32_t n = (uint32_t)xf.size();
+	// colliders: the static ones, then one per owned dynamic body in SLOT order (boxes and spheres each in their own array)
+	std::vector<uint32_t> bt, stg; std::vector<nh_BoxCollider> bd; std::vector<nh_SphereCollider> sd; std::vector<nh_Transform> bx, sx;
+	for (size_t c = 0; c < s.box_xf.size(); ++c) if (s.box_xf[c].body == 0) { bt.push_back(s.box_tags[c]); bd.push_back(s.box_data[c]); bx.push_back(s.box_xf[c]); }
+	for (size_t c = 0; c < s.sph_xf.size(); ++c) if (s.sph_xf[c].body == 0) { stg.push_back(s.sph_tags[c]); sd.push_back(s.sph_data[c]); sx.push_back(s.sph_xf[c]); }
+	const uint32_t n_static_box = (uint32_t)bt.size(), n_static_sph = (uint32_t)stg.size();
+	std::vector<std::pair<uint32_t, size_t>> dyn_box, dyn_sph;          // (slot, collider)
+	for (size_t c = 0; c < s.box_xf.size(); ++c) { const uint32_t b = s.box_xf[c].body; if (b && slot_of[b]) dyn_box.push_back({ slot_of[b], c }); }
+	for (size_t c = 0; c < s.sph_xf.size(); ++c) { const uint32_t b = s.sph_xf[c].body; if (b && slot_of[b]) dyn_sph.push_back({ slot_of[b], c }); }
+	std::sort(dyn_box.begin(), dyn_box.end()); std::sort(dyn_sph.begin(), dyn_sph.end());
+	for (auto& e : dyn_box) { nh_Transform t = s.box_xf[e.second]; t.body = e.first; bt.push_back(s.box_tags[e.second]); bd.push_back(s.box_data[e.second]); bx.push_back(t); }
+	for (auto& e : dyn_sph) { nh_Transform t = s.sph_xf[e.second]; t.body = e.first; stg.push_back(s.sph_tags[e.second]); sd.push_back(s.sph_data[e.second]); sx.push_back(t); }
+	if (dyn_box.size() + dyn_sph.size() != n - 1u) { fprintf(stderr, "rank %d: a dynamic body needs exactly one collider\n", rank); exit(2); }
+	const uint32_t extra = std::max<uint32_t>(min_extra, (uint32_t)(slack * n));
+	R.body_capacity = n + extra;
+	const uint32_t box_cap = (uint32_t)bt.size() + extra, sph_cap = (uint32_t)stg.size() + extra;
+	uint32_t max_tag = 1;
+	for (uint32_t t : s.box_tags) max_tag = std::max(max_tag, t);
+	for (uint32_t t : s.sph_tags) max_tag = std::max(max_tag, t);
+	uint32_t tag_bits = 8; while (tag_bits < 32 && (1ull << tag_bits) <= max_tag) ++tag_bits;
+
+	HIP_OK(hipSetDevice(device));
+	NH_OK_(nh_create(&R.ctx, device, stream, NH_FLAG_SINGLE_APPLY | NH_FLAG_FUSED_STEP));
+	NH_OK_(nh_set_tag_bits(R.ctx, tag_bits));
+	R.bodies = { to_device(xf, R.body_capacity), to_device(props, R.body_capacity), to_device(mom, R.body_capacity), to_device(idle, R.body_capacity), n };
+	R.colliders.boxes.tags = to_device(bt, box_cap); R.colliders.boxes.data = to_device(bd, box_cap); R.colliders.boxes.transforms = to_device(bx, box_cap); R.colliders.boxes.count = (uint32_t)bt.size();
+	R.colliders.spheres.tags = to_device(stg, sph_cap); R.colliders.spheres.data = to_device(sd, sph_cap); R.colliders.spheres.transforms = to_device(sx, sph_cap); R.colliders.spheres.count = (uint32_t)stg.size();
+	const uint32_t K = 8u * R.body_capacity;
+	R.contacts.data = to_device(std::vector<nh_Contact>(), K); R.contacts.bodies = to_device(std::vector<nh_BodyPair>(), K); R.contacts.tags = to_device(std::vector<uint64_t>(), K);
+	R.contacts.features = to_device(std::vector<uint32_t>(), K); R.contacts.sleeping_pairs = to_device(std::vector<uint64_t>(), K); R.contacts.capacity = K;
+	R.cache = { to_device(std::vector<uint64_t>(), K), to_device(std::vector<uint32_t>(), K), to_device(std::vector<nh_CachedContactImpulse>(), K), K, 0 };
+	R.active = { to_device(std::vector<uint32_t>(), R.body_capacity), R.body_capacity, 0 };
+	const size_t ncol = (size_t)box_cap + sph_cap;
+	size_t cells = 1; while (cells < 4 * ncol) cells <<= 1;
+	cells = std::min<size_t>(std::max<size_t>(cells, (size_t)1 << 16), (size_t)1 << 24);
+	R.arena.size = ((size_t)64 << 20) + ncol * 200 + cells * 8 + (size_t)K * 320 + ((size_t)K / 2 + 1024) * 216 + (size_t)R.body_capacity * 64;
+	HIP_OK(hipMalloc(&R.arena.data, R.arena.size));
+	nh_PartitionConfig cfg = {};
+	cfg.rank = (uint32_t)rank; cfg.ranks = (uint32_t)R.ranks; cfg.lo = lo; cfg.hi = hi; cfg.n_owned = n - 1u; cfg.n_static_box = n_static_box; cfg.n_static_sph = n_static_sph;
+	cfg.body_capacity = R.body_capacity; cfg.box_capacity = box_cap; cfg.sphere_capacity = sph_cap; cfg.epoch = epoch;
+	cfg.time_step = s.time_step; cfg.gravity = s.gravity; cfg.speed_floor = speed_floor; cfg.max_reach = max_reach; cfg.cut_slack = HUGE_VAL;
+	NH_OK_(nh_partition_create(&R.part, R.ctx, &cfg, &R.bodies, &R.colliders));
+	R.msg_capacity = std::max<uint32_t>(4096u, R.body_capacity / 4u);
+	for (int side = 0; side < 2; ++side) {
+		HIP_OK(hipMalloc(&R.out[side], (size_t)NH_PARTITION_FULL_BYTES * R.msg_capacity)); HIP_OK(hipMalloc(&R.in[side], (size_t)NH_PARTITION_FULL_BYTES * R.msg_capacity));
+	}
+}
+
+// the reference's sub-step on a rank's local world (example/main.cpp:274-328)
+static void local_step(Rank& R, const Scene& s) {
+	const float dt = (float)s.time_step, gravity[3] = { 0.0f, (float)s.gravity, 0.0f };
+	nh_Arena temporary = R.arena;
+	NH_OK_(nh_collide(R.ctx, &R.active, &R.contacts, &R.bodies, &R.colliders, &R.connections, temporary));
+	NH_OK_(nh_apply_gravity_damping(R.ctx, &R.active, &R.bodies, dt, gravity, (float)s.damping_rate));
+	nh_ContactImpulseData* impulses = nullptr;
+	NH_OK_(nh_read_cached_impulses(R.ctx, &R.cache, &R.contacts, &temporary, &impulses));
+	nh_ContactConstraintData* constraints = nullptr;
+	NH_OK_(nh_setup_contact_constraints(R.ctx, &R.active, &R.contacts, &R.bodies, impulses, &temporary, &constraints));
+	NH_OK_(nh_apply_impulses(R.ctx, constraints, &R.bodies, s.iterations));
+	NH_OK_(nh_update_cached_impulses(R.ctx, constraints, impulses));
+	NH_OK_(nh_write_cached_impulses(R.ctx, &R.cache, &R.contacts, impulses));
+	NH_OK_(nh_advance(R.ctx, &R.active, &R.bodies, dt));
+}
+
+// ---- transport: what rank r's out[side] holds goes to its neighbour's in[1 - side].  LOCAL: device-to-device copies; RCCL: ncclSend / ncclRecv ----------
+struct Transport {
+	bool local = false;                          // several ranks in this process (one GPU)
+	ncclComm_t comm = nullptr; int rank = 0, world = 1;
+	hipStream_t stream = nullptr;
+	uint64_t* d_cnt = nullptr;                   // RCCL: 4 words on the device (out left / right, in left / right) for lengths and cut values
+};
+
+// `known`: the lengths are what the last refresh agreed on (per-step records); otherwise they travel first (one stream synchronisation)
+static void exchange(Transport& T, std::vector<Rank>& ranks, size_t record_bytes, bool known) {
+	if (T.local) {
+		for (Rank& R : ranks) for (int side = 0; side < 2; ++side) if (R.has(side)) {
+			Rank& N = ranks[R.rank + (side ? 1 : -1)];
+			N.in_count[1 - side] = R.out_count[side];
+			if (R.out_count[side]) HIP_OK(hipMemcpyAsync(N.in[1 - side], R.out[side], record_bytes * R.out_count[side], hipMemcpyDeviceToDevice, T.stream));
+		}
+		return;
+	}
+	Rank& R = ranks[0];
+	if (!known) {
+		uint64_t h[4] = { R.out_count[0], R.out_count[1], 0, 0 };
+		HIP_OK(hipMemcpyAsync(T.d_cnt, h, 16, hipMemcpyHostToDevice, T.stream));
+		NCCL_OK(ncclGroupStart());
+		for (int side = 0; side < 2; ++side) if (R.has(side)) {
+			const int peer = T.rank + (side ? 1 : -1);
+			NCCL_OK(ncclSend(T.d_cnt + side, 1, ncclUint64, peer, T.comm, T.stream)); NCCL_OK(ncclRecv(T.d_cnt + 2 + side, 1, ncclUint64, peer, T.comm, T.stream));
+		}
+		NCCL_OK(ncclGroupEnd());
+		HIP_OK(hipMemcpyAsync(h, T.d_cnt, 32, hipMemcpyDeviceToHost, T.stream));
+		HIP_OK(hipStreamSynchronize(T.stream));
+		for (int side = 0; side < 2; ++side) R.in_count[side] = R.has(side) ? (uint32_t)h[2 + side] : 0u;
+	}
+	NCCL_OK(ncclGroupStart());
+	for (int side = 0; side < 2; ++side) if (R.has(side)) {
+		const int peer = T.rank + (side ? 1 : -1);
+		if (R.out_count[side]) NCCL_OK(ncclSend(R.out[side], record_bytes * R.out_count[side], ncclUint8, peer, T.comm, T.stream));
+		if (R.in_count[side]) NCCL_OK(ncclRecv(R.in[side], record_bytes * R.in_count[side], ncclUint8, peer, T.comm, T.stream));
+	}
+	NCCL_OK(ncclGroupEnd());
+}
+
+// one number per cut and side (a body count, a new cut): out[side][k] of rank k goes to in[1 - side][neighbour].  LOCAL: plain assignment
+typedef std::vector<double> Values[2];
+static void exchange_values(Transport& T, std::vector<Rank>& ranks, Values& out, Values& in) {
+	if (T.local) {
+		for (Rank& R : ranks) for (int side = 0; side < 2; ++side) if (R.has(side)) in[1 - side][R.rank + (side ? 1 : -1)] = out[side][R.rank];
+		return;
+	}
+	Rank& R = ranks[0];
+	double h[4] = { out[0][0], out[1][0], 0.0, 0.0 };
+	HIP_OK(hipMemcpyAsync(T.d_cnt, h, 16, hipMemcpyHostToDevice, T.stream));
+	NCCL_OK(ncclGroupStart());
+	for (int side = 0; side < 2; ++side) if (R.has(side)) {
+		const int peer = T.rank + (side ? 1 : -1);
+		NCCL_OK(ncclSend(T.d_cnt + side, 1, ncclUint64, peer, T.comm, T.stream)); NCCL_OK(ncclRecv(T.d_cnt + 2 + side, 1, ncclUint64, peer, T.comm, T.stream));
+	}
+	NCCL_OK(ncclGroupEnd());
+	HIP_OK(hipMemcpyAsync(h, T.d_cnt, 32, hipMemcpyDeviceToHost, T.stream));
+	HIP_OK(hipStreamSynchronize(T.stream));
+	in[0][0] = h[2]; in[1][0] = h[3];
+}
+
 int main(int argc, char** argv) {
 	const int rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
 	const int world = getenv("WORLD_SIZE") ? atoi(getenv("WORLD_SIZE")) : 1;
 	const int local_rank = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : rank;
-	const int cols_per_rank = argc > 1 ? atoi(argv[1]) : 4, rows = argc > 2 ? atoi(argv[2]) : 2, side = argc > 3 ? atoi(argv[3]) : 90;
-	const unsigned steps = argc > 4 ? (unsigned)atoi(argv[4]) : 100;
-	const int cols = cols_per_rank * world;
-	const uint32_t iterations = 8;
-	const float time_step = 1.0f / 120.0f, gravity[3] = { 0.0f, 9.82f, 0.0f }, damping_rate = 0.25f;
-	const uint64_t seed = 0x9E3779B97F4A7C15ull ^ 5ull;
+	const int local_ranks = getenv("NUDGE_LOCAL_RANKS") ? atoi(getenv("NUDGE_LOCAL_RANKS")) : 0;
+	const char* scene_path = nullptr; const char* out_path = nullptr; const char* cuts_arg = nullptr;
+	std::vector<const char*> pos;
+	uint32_t epoch = 16, min_extra = 4096; double speed_floor = 1.0, slack = 0.15; bool rebalance = true;
+	for (int i = 1; i < argc; ++i) {
+		if (!strcmp(argv[i], "--scene") && i + 1 < argc) scene_path = argv[++i];
+		else if (!strcmp(argv[i], "--out") && i + 1 < argc) out_path = argv[++i];
+		else if (!strcmp(argv[i], "--cuts") && i + 1 < argc) cuts_arg = argv[++i];
+		else if (!strcmp(argv[i], "--epoch") && i + 1 < argc) epoch = (uint32_t)atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--speed-floor") && i + 1 < argc) speed_floor = atof(argv[++i]);
+		else if (!strcmp(argv[i], "--min-extra") && i + 1 < argc) min_extra = (uint32_t)atoi(argv[++i]);
+		else if (!strcmp(argv[i], "--slack") && i + 1 < argc) slack = atof(argv[++i]);
+		else if (!strcmp(argv[i], "--no-rebalance")) rebalance = false;
+		else pos.push_back(argv[i]);
+	}
+	const int n_ranks = local_ranks > 0 ? local_ranks : world;
+	const int cols_per_rank = pos.size() > 0 ? atoi(pos[0]) : 4, rows = pos.size() > 1 ? atoi(pos[1]) : 2, side = pos.size() > 2 ? atoi(pos[2]) : 90;
+	const unsigned steps = scene_path ? (pos.size() > 0 ? (unsigned)atoi(pos[0]) : 100u) : (pos.size() > 3 ? (unsigned)atoi(pos[3]) : 100u);
+	const bool loopback = world == 1 && local_ranks == 0 && getenv("NUDGE_RCCL_LOOPBACK") && atoi(getenv("NUDGE_RCCL_LOOPBACK")) != 0;
 
-	HIP_OK(hipSetDevice(local_rank));
+	const int device = local_ranks > 0 ? 0 : local_rank;
+	HIP_OK(hipSetDevice(device));
 	hipStream_t stream;
 	HIP_OK(hipStreamCreate(&stream));
 
-	// ---- RCCL bootstrap: rank 0 publishes the unique id through a file (one node, shared file system) ----
-	ncclComm_t comm = nullptr;
-	if (world > 1) {
-		const char* path = getenv("NUDGE_NCCL_ID_FILE") ? getenv("NUDGE_NCCL_ID_FILE") : "/tmp/nudge_partition_rccl.id";
+	// ---- RCCL bootstrap (one process per GPU): rank 0 publishes the unique id through a file (one node, shared file system) ----
+	Transport T;
+	T.stream = stream; T.rank = rank; T.world = world; T.local = local_ranks > 0;
+	if (local_ranks == 0 && (world > 1 || loopback)) {
 		ncclUniqueId id;
-		if (rank == 0) {
-			NCCL_OK(ncclGetUniqueId(&id));
-			std::string tmp = std::string(path) + ".tmp";
-			FILE* f = fopen(tmp.c_str(), "wb");
-			if (!f || fwrite(&id, sizeof(id), 1, f) != 1) { perror(path); return 2; }
-			fclose(f);
-			rename(tmp.c_str(), path);
-		} else {
-			FILE* f = nullptr;
-			for (int tries = 0; tries < 600 && !(f = fopen(path, "rb")); ++tries) usleep(100000);
-			if (!f || fread(&id, sizeof(id), 1, f) != 1) { fprintf(stderr, "rank %d: no unique id at %s\n", rank, path); return 2; }
-			fclose(f);
-		}
-		NCCL_OK(ncclCommInitRank(&comm, world, id, rank));
+		if (world > 1) {
+			const char* path = getenv("NUDGE_NCCL_ID_FILE") ? getenv("NUDGE_NCCL_ID_FILE") : "/tmp/nudge_partition_rccl.id";
+			if (rank == 0) {
+				NCCL_OK(ncclGetUniqueId(&id));
+				std::string tmp = std::string(path) + ".tmp";
+				FILE* f = fopen(tmp.c_str(), "wb");
+				if (!f || fwrite(&id, sizeof(id), 1, f) != 1) { perror(path); return 2; }
+				fclose(f);
+				rename(tmp.c_str(), path);
+			} else {
+				FILE* f = nullptr;
+				for (int tries = 0; tries < 600 && !(f = fopen(path, "rb")); ++tries) usleep(100000);
+				if (!f || fread(&id, sizeof(id), 1, f) != 1) { fprintf(stderr, "rank %d: no unique id at %s\n", rank, path); return 2; }
+				fclose(f);
+			}
+		} else NCCL_OK(ncclGetUniqueId(&id));
+		NCCL_OK(ncclCommInitRank(&T.comm, world, id, rank));
+		HIP_OK(hipMalloc((void**)&T.d_cnt, 64));
 	}
-	// NUDGE_RCCL_LOOPBACK=1 with WORLD_SIZE=1: a one-rank communicator, and every step the halo records of the first owned bodies travel
-	// nh_halo_pack -> ncclSend(self) / ncclRecv(self) in one group -> nh_halo_update onto the SAME bodies (a no-op for the simulation: the
-	// checksum must equal the run without it).  What a one-GPU box can execute of the communication path: RCCL point-to-point on the
-	// library's stream between the two halo kernels.
-	const bool loopback = world == 1 && getenv("NUDGE_RCCL_LOOPBACK") && atoi(getenv("NUDGE_RCCL_LOOPBACK")) != 0;
+
+	// ---- the world and the cuts ----
+	Scene scene = scene_path ? load_scene(scene_path) : drop_tiles(cols_per_rank * n_ranks, rows, side);
+	std::vector<double> cuts;
+	if (cuts_arg) { for (const char* p = cuts_arg; *p;) { char* e = nullptr; cuts.push_back(strtod(p, &e)); p = *e == ',' ? e + 1 : e; if (e == p) break; } }
+	else if (n_ranks > 1) {
+		// equal-count x-slabs: the quantiles of the bodies' x (+0.41: never exactly on a lattice line), like bench.py
+		std::vector<float> xs;
+		for (size_t i = 1; i < scene.body_xf.size(); ++i) xs.push_back(scene.body_xf[i].position[0]);
+		std::sort(xs.begin(), xs.end());
+		for (int r = 1; r < n_ranks; ++r) cuts.push_back((double)xs[std::min(xs.size() - 1, (size_t)((double)r / n_ranks * (xs.size() - 1)))] + 0.41);
+	}
+	if ((int)cuts.size() != n_ranks - 1) { fprintf(stderr, "%d ranks need %d cuts\n", n_ranks, n_ranks - 1); return 2; }
+	// largest reach of any body of the WHOLE world (partition.py body_reach: |collider offset| + extent, rounded to float, x 1.0001)
+	float max_reach = 0.0f;
+	for (size_t c = 0; c < scene.box_xf.size(); ++c) if (scene.box_xf[c].body) {
+		const nh_Transform& t = scene.box_xf[c]; const nh_BoxCollider& b = scene.box_data[c];
+		const double off = sqrt((double)t.position[0] * t.position[0] + (double)t.position[1] * t.position[1] + (double)t.position[2] * t.position[2]);
+		const double ext = sqrt((double)b.size[0] * b.size[0] + (double)b.size[1] * b.size[1] + (double)b.size[2] * b.size[2]);
+		max_reach = std::max(max_reach, (float)(off + ext) * 1.0001f);
+	}
+	for (size_t c = 0; c < scene.sph_xf.size(); ++c) if (scene.sph_xf[c].body) {
+		const nh_Transform& t = scene.sph_xf[c];
+		const double off = sqrt((double)t.position[0] * t.position[0] + (double)t.position[1] * t.position[1] + (double)t.position[2] * t.position[2]);
+		max_reach = std::max(max_reach, (float)(off + (double)scene.sph_data[c].radius) * 1.0001f);
+	}
+
+	std::vector<Rank> ranks(local_ranks > 0 ? local_ranks : 1);
+	for (size_t k = 0; k < ranks.size(); ++k) make_rank(ranks[k], scene, cuts, local_ranks > 0 ? (int)k : rank, device, stream, epoch, speed_floor, (double)max_reach, min_extra, slack);
+	const size_t total_bodies = scene.body_xf.size() - 1;
+
+	// NUDGE_RCCL_LOOPBACK=1: per-step records of the first owned bodies to myself through RCCL, written back onto the same bodies (a no-op for the world)
+	uint32_t n_loop = 0; uint32_t* d_loop = nullptr; void* loop_out = nullptr; void* loop_in = nullptr;
 	if (loopback) {
-		ncclUniqueId id;
-		NCCL_OK(ncclGetUniqueId(&id));
-		NCCL_OK(ncclCommInitRank(&comm, 1, id, 0));
+		nh_PartitionInfo info; NH_OK_(nh_partition_info(ranks[0].part, &info));
+		n_loop = std::min<uint32_t>(info.n_owned, 4096u);
+		std::vector<uint32_t> idx(n_loop); for (uint32_t i = 0; i < n_loop; ++i) idx[i] = 1u + i;
+		d_loop = to_device(idx, 1); HIP_OK(hipMalloc(&loop_out, (size_t)NH_HALO_RECORD_BYTES * (n_loop + 1))); HIP_OK(hipMalloc(&loop_in, (size_t)NH_HALO_RECORD_BYTES * (n_loop + 1)));
 	}
 
-	// ---- the world: cols x rows tiles of side x side boxes on a 3.0 pitch, one ground slab per tile; x-slabs cut THROUGH tiles ----
-	const float pitch = 3.0f, half = side * 1.5f + 2.0f, tile_pitch = 2.0f * half + 4.0f;
-	const float x_begin = -half, x_end = (cols - 1) * tile_pitch + half;
-	const float width = (x_end - x_begin) / world;
-	const float lo = rank == 0 ? -1e30f : x_begin + rank * width + 0.41f;           // (+0.41: never exactly on a lattice line)
-	const float hi = rank == world - 1 ? 1e30f : x_begin + (rank + 1) * width + 0.41f;
-	const float margin = 8.0f;                                                       // > 2 x the largest box diagonal + sideways drift of a drop
-
-	std::vector<Body> owned, ghost_left, ghost_right;       // ghost_left: owned by rank-1, within `margin` of my lo; ...
-	std::vector<uint32_t> send_left, send_right;           // owned slots (1-based body indices) the neighbours hold as ghosts, generation order
-	std::vector<nh_Transform> slab_xf;
-	std::vector<nh_BoxCollider> slab_box;
-	std::vector<uint32_t> slab_tags;
-	const uint32_t n_tiles = (uint32_t)(cols * rows);
-	for (int tz = 0; tz < rows; ++tz) for (int tx = 0; tx < cols; ++tx) {
-		const float ox = tx * tile_pitch, oz = tz * tile_pitch;
-		if (ox + half < lo - margin || ox - half > hi + margin) continue;        // the tile does not touch this rank
-		const uint32_t tile = (uint32_t)(tz * cols + tx);
-		nh_Transform st = {};
-		st.position[0] = ox; st.position[1] = -20.0f; st.position[2] = oz; st.body = 0; st.rotation[3] = 1.0f;
-		slab_xf.push_back(st);
-		nh_BoxCollider sb = { { half, 10.0f, half }, 0.0f };
-		slab_box.push_back(sb);
-		slab_tags.push_back(tile);                                                 // static colliders: tags 0 .. n_tiles-1
-		for (int iz = 0; iz < side; ++iz) for (int ix = 0; ix < side; ++ix) {
-			const uint64_t g = (uint64_t)tile * side * side + (uint64_t)iz * side + ix;   // global body number (0-based among the dynamic ones)
-			Body b = {};
-			const float sx = 0.5f + 0.5f * u01(seed, 8 * g), sy = 0.5f + 0.5f * u01(seed, 8 * g + 1), sz = 0.5f + 0.5f * u01(seed, 8 * g + 2);
-			const float yaw = 0.5f * u01(seed, 8 * g + 3);
-			b.xf.position[0] = ox + (ix - (side - 1) * 0.5f) * pitch + 0.2f * u01(seed, 8 * g + 4);
-			b.xf.position[2] = oz + (iz - (side - 1) * 0.5f) * pitch + 0.2f * u01(seed, 8 * g + 5);
-			b.xf.position[1] = -10.0f + 0.5f + 0.5f * u01(seed, 8 * g + 6) + sy;
-			b.xf.rotation[1] = sinf(0.5f * yaw); b.xf.rotation[3] = cosf(0.5f * yaw);
-			const float mass = 8.0f * sx * sy * sz, k = mass / 3.0f;            // add_box of the sample application (example/main.cpp:112-145)
-			b.props.mass_inverse = 1.0f / mass;
-			b.props.inertia_inverse[0] = 1.0f / (k * sy * sy + k * sz * sz);
-			b.props.inertia_inverse[1] = 1.0f / (k * sx * sx + k * sz * sz);
-			b.props.inertia_inverse[2] = 1.0f / (k * sx * sx + k * sy * sy);
-			b.box.size[0] = sx; b.box.size[1] = sy; b.box.size[2] = sz;
-			b.tag = n_tiles + (uint32_t)g;                                          // collider tag = global, identical on every rank
-			const float x = b.xf.position[0];
-			if (x >= lo && x < hi) {
-				owned.push_back(b);
-				if (x < lo + margin && rank > 0) send_left.push_back((uint32_t)owned.size());
-				if (x >= hi - margin && rank < world - 1) send_right.push_back((uint32_t)owned.size());
-			} else if (x >= lo - margin && x < lo) ghost_left.push_back(b);
-			else if (x >= hi && x < hi + margin) ghost_right.push_back(b);
-		}
-	}
-	const uint32_t n_loop = loopback ? (uint32_t)(owned.size() < 4096 ? owned.size() : 4096) : 0u;
-	if (loopback) for (uint32_t i = 0; i < n_loop; ++i) send_right.push_back(1u + i);           // (consecutive slots: nh_halo_update writes a range)
-	const uint32_t n_owned = (uint32_t)owned.size(), n_gl = (uint32_t)ghost_left.size(), n_gr = (uint32_t)ghost_right.size();
-	const uint32_t nb = 1 + n_owned + n_gl + n_gr, n_static = (uint32_t)slab_xf.size(), nbox = n_static + nb - 1;
-
-	// body 0 = the static world; then owned, then the left ghosts, then the right ghosts.  One box collider per dynamic body.
-	std::vector<nh_Transform> h_xf(nb), h_box_xf(nbox);
-	std::vector<nh_BodyProperties> h_props(nb);
-	std::vector<nh_BoxCollider> h_box(nbox);
-	std::vector<uint32_t> h_tags(nbox);
-	h_xf[0].rotation[3] = 1.0f;
-	for (uint32_t s = 0; s < n_static; ++s) { h_box_xf[s] = slab_xf[s]; h_box[s] = slab_box[s]; h_tags[s] = slab_tags[s]; }
-	uint32_t at = 1;
-	for (const std::vector<Body>* list : { &owned, &ghost_left, &ghost_right })
-		for (const Body& b : *list) {
-			h_xf[at] = b.xf; h_props[at] = b.props;
-			nh_Transform local = {}; local.rotation[3] = 1.0f; local.body = at;
-			h_box_xf[n_static + at - 1] = local; h_box[n_static + at - 1] = b.box; h_tags[n_static + at - 1] = b.tag;
-			++at;
-		}
-
-	nh_context* ctx = nullptr;
-	NH_OK_(nh_create(&ctx, local_rank, stream, NH_FLAG_SINGLE_APPLY | NH_FLAG_FUSED_STEP));
-	uint32_t tag_bits = 1; while ((1ull << tag_bits) <= (uint64_t)n_tiles + (uint64_t)n_tiles * side * side) ++tag_bits;
-	NH_OK_(nh_set_tag_bits(ctx, tag_bits));
-	const uint32_t K = 6u * nb + 4096u;
-	nh_BodyData bodies = { to_device(h_xf), to_device(h_props), to_device(std::vector<nh_BodyMomentum>(nb)), to_device(std::vector<uint8_t>(nb)), nb };
-	nh_ColliderData colliders = {};
-	colliders.boxes.tags = to_device(h_tags); colliders.boxes.data = to_device(h_box); colliders.boxes.transforms = to_device(h_box_xf); colliders.boxes.count = nbox;
-	colliders.spheres.tags = to_device(std::vector<uint32_t>(), 1); colliders.spheres.data = to_device(std::vector<nh_SphereCollider>(), 1);
-	colliders.spheres.transforms = to_device(std::vector<nh_Transform>(), 1); colliders.spheres.count = 0;
-	nh_BodyConnections connections = { nullptr, 0 };
-	nh_ContactData contacts = {};
-	contacts.data = to_device(std::vector<nh_Contact>(), K); contacts.bodies = to_device(std::vector<nh_BodyPair>(), K);
-	contacts.tags = to_device(std::vector<uint64_t>(), K); contacts.features = to_device(std::vector<uint32_t>(), K);
-	contacts.sleeping_pairs = to_device(std::vector<uint64_t>(), K); contacts.capacity = K;
-	nh_ContactCache cache = { to_device(std::vector<uint64_t>(), K), to_device(std::vector<uint32_t>(), K), to_device(std::vector<nh_CachedContactImpulse>(), K), K, 0 };
-	nh_ActiveBodies active = { to_device(std::vector<uint32_t>(), nb), nb, 0 };
-	nh_Arena arena = {};
-	arena.size = ((size_t)64 << 20) + (size_t)nbox * 200 + ((size_t)1 << 24) * 8 + (size_t)K * 320 + ((size_t)K / 2 + 1024) * 216 + (size_t)nb * 64;
-	HIP_OK(hipMalloc(&arena.data, arena.size));
-
-	// halo buffers: what I send to / receive from each neighbour (NH_HALO_RECORD_BYTES per body)
-	uint32_t* d_send_left = to_device(send_left, 1); uint32_t* d_send_right = to_device(send_right, 1);
-	void *out_left = nullptr, *out_right = nullptr, *in_left = nullptr, *in_right = nullptr;
-	HIP_OK(hipMalloc(&out_left, (size_t)NH_HALO_RECORD_BYTES * (send_left.size() + 1))); HIP_OK(hipMalloc(&out_right, (size_t)NH_HALO_RECORD_BYTES * (send_right.size() + 1)));
-	HIP_OK(hipMalloc(&in_left, (size_t)NH_HALO_RECORD_BYTES * (n_gl + 1))); HIP_OK(hipMalloc(&in_right, (size_t)NH_HALO_RECORD_BYTES * (n_gr + n_loop + 1)));
-	if (world > 1) {
-		// both sides must agree on the list lengths: what I call my right ghosts is what my right neighbour calls its left sends
-		uint64_t mine[2] = { (uint64_t)send_left.size(), (uint64_t)send_right.size() }, theirs[2] = { 0, 0 };
-		uint64_t* d_m = to_device(std::vector<uint64_t>(mine, mine + 2)); uint64_t* d_t = to_device(std::vector<uint64_t>(2));
-		NCCL_OK(ncclGroupStart());
-		if (rank > 0) { NCCL_OK(ncclSend(d_m, 1, ncclUint64, rank - 1, comm, stream)); NCCL_OK(ncclRecv(d_t, 1, ncclUint64, rank - 1, comm, stream)); }
-		if (rank < world - 1) { NCCL_OK(ncclSend(d_m + 1, 1, ncclUint64, rank + 1, comm, stream)); NCCL_OK(ncclRecv(d_t + 1, 1, ncclUint64, rank + 1, comm, stream)); }
-		NCCL_OK(ncclGroupEnd());
-		HIP_OK(hipStreamSynchronize(stream));
-		HIP_OK(hipMemcpy(theirs, d_t, sizeof(theirs), hipMemcpyDeviceToHost));
-		// the left neighbour sent me the length of ITS right list (= my left ghosts), the right neighbour that of its left list
-		if ((rank > 0 && theirs[0] != n_gl) || (rank < world - 1 && theirs[1] != n_gr)) { fprintf(stderr, "rank %d: ghost lists disagree (%llu/%u, %llu/%u)\n", rank, (unsigned long long)theirs[0], n_gl, (unsigned long long)theirs[1], n_gr); return 6; }
-	}
-
-	uint64_t sum_contacts = 0;
+	const size_t slots = T.local ? (size_t)n_ranks : (size_t)1;
+	auto at = [&](const Rank& R) { return T.local ? (size_t)R.rank : (size_t)0; };
 	HIP_OK(hipStreamSynchronize(stream));
 	auto t0 = std::chrono::steady_clock::now();
 	for (unsigned n = 0; n < steps; ++n) {
-		if (world > 1) {
-			// ---- ghost-body halo exchange: the owners' state of this step overwrites the ghosts' ----
-			NH_OK_(nh_halo_pack(ctx, &bodies, d_send_left, (uint32_t)send_left.size(), out_left));
-			NH_OK_(nh_halo_pack(ctx, &bodies, d_send_right, (uint32_t)send_right.size(), out_right));
-			NCCL_OK(ncclGroupStart());
-			if (rank > 0) {
-				if (!send_left.empty()) NCCL_OK(ncclSend(out_left, send_left.size() * NH_HALO_RECORD_BYTES, ncclUint8, rank - 1, comm, stream));
-				if (n_gl) NCCL_OK(ncclRecv(in_left, (size_t)n_gl * NH_HALO_RECORD_BYTES, ncclUint8, rank - 1, comm, stream));
+		if (n % epoch == 0 && n_ranks > 1) {
+			// ---- REFRESH ----
+			if (rebalance && n > 0) {
+				Values mine = { std::vector<double>(slots, 0.0), std::vector<double>(slots, 0.0) }, theirs = { std::vector<double>(slots, 0.0), std::vector<double>(slots, 0.0) };
+				for (Rank& R : ranks) { nh_PartitionInfo i; NH_OK_(nh_partition_info(R.part, &i)); mine[0][at(R)] = mine[1][at(R)] = (double)i.n_owned; }
+				exchange_values(T, ranks, mine, theirs);
+				// both sides of a cut evaluate the same rule on the same two counts; the heavier one picks the new place and sends it over
+				Values cut_out = { std::vector<double>(slots, NAN), std::vector<double>(slots, NAN) }, cut_in = { std::vector<double>(slots, NAN), std::vector<double>(slots, NAN) };
+				for (Rank& R : ranks) for (int side = 0; side < 2; ++side) if (R.has(side)) {
+					const double a = mine[side][at(R)], b = theirs[side][at(R)];
+					if (fabs(a - b) <= 0.05 * std::max(1.0, a + b) || a <= b) continue;
+					double cut = 0.0;
+					NH_OK_(nh_partition_choose_cut(R.part, &R.bodies, side ? +1 : -1, (uint32_t)b, &cut));
+					cut_out[side][at(R)] = cut;
+				}
+				exchange_values(T, ranks, cut_out, cut_in);
+				for (Rank& R : ranks) for (int side = 0; side < 2; ++side) if (R.has(side)) {
+					const double a = mine[side][at(R)], b = theirs[side][at(R)], cut = cut_in[side][at(R)];
+					if (fabs(a - b) > 0.05 * std::max(1.0, a + b) && a < b && cut == cut) NH_OK_(nh_partition_set_cut(R.part, side ? +1 : -1, cut));
+				}
 			}
-			if (rank < world - 1) {
-				if (!send_right.empty()) NCCL_OK(ncclSend(out_right, send_right.size() * NH_HALO_RECORD_BYTES, ncclUint8, rank + 1, comm, stream));
-				if (n_gr) NCCL_OK(ncclRecv(in_right, (size_t)n_gr * NH_HALO_RECORD_BYTES, ncclUint8, rank + 1, comm, stream));
+			for (Rank& R : ranks) NH_OK_(nh_partition_pack_migrants(R.part, &R.bodies, R.has(0) ? R.out[0] : nullptr, R.has(1) ? R.out[1] : nullptr, R.msg_capacity, R.out_count));
+			exchange(T, ranks, NH_PARTITION_FULL_BYTES, false);
+			for (Rank& R : ranks) NH_OK_(nh_partition_unpack_migrants(R.part, &R.bodies, R.in[0], R.has(0) ? R.in_count[0] : 0u, R.in[1], R.has(1) ? R.in_count[1] : 0u));
+			for (Rank& R : ranks) NH_OK_(nh_partition_pack_ghosts(R.part, &R.bodies, R.has(0) ? R.out[0] : nullptr, R.has(1) ? R.out[1] : nullptr, R.msg_capacity, R.out_count));
+			exchange(T, ranks, NH_PARTITION_FULL_BYTES, false);
+			for (Rank& R : ranks) NH_OK_(nh_partition_unpack_ghosts(R.part, &R.bodies, &R.colliders, R.in[0], R.has(0) ? R.in_count[0] : 0u, R.in[1], R.has(1) ? R.in_count[1] : 0u));
+		} else if (n_ranks > 1) {
+			// ---- the per-step halo: the owners' state of this step overwrites the ghosts' (lengths fixed since the refresh) ----
+			for (Rank& R : ranks) {
+				NH_OK_(nh_partition_pack_step(R.part, &R.bodies, R.out[0], R.out[1]));
+				nh_PartitionInfo i; NH_OK_(nh_partition_info(R.part, &i));
+				R.out_count[0] = i.ghost_out[0]; R.out_count[1] = i.ghost_out[1]; R.in_count[0] = i.ghost_in[0]; R.in_count[1] = i.ghost_in[1];
 			}
-			NCCL_OK(ncclGroupEnd());
-			NH_OK_(nh_halo_update(ctx, &bodies, 1 + n_owned, n_gl, in_left));
-			NH_OK_(nh_halo_update(ctx, &bodies, 1 + n_owned + n_gl, n_gr, in_right));
+			exchange(T, ranks, NH_HALO_RECORD_BYTES, true);
+			for (Rank& R : ranks) NH_OK_(nh_partition_unpack_step(R.part, &R.bodies, R.in[0], R.in[1]));
 		}
 		if (loopback && n_loop) {
-			NH_OK_(nh_halo_pack(ctx, &bodies, d_send_right, n_loop, out_right));
+			Rank& R = ranks[0];
+			NH_OK_(nh_halo_pack(R.ctx, &R.bodies, d_loop, n_loop, loop_out));
 			NCCL_OK(ncclGroupStart());
-			NCCL_OK(ncclSend(out_right, (size_t)n_loop * NH_HALO_RECORD_BYTES, ncclUint8, 0, comm, stream));
-			NCCL_OK(ncclRecv(in_right, (size_t)n_loop * NH_HALO_RECORD_BYTES, ncclUint8, 0, comm, stream));
+			NCCL_OK(ncclSend(loop_out, (size_t)n_loop * NH_HALO_RECORD_BYTES, ncclUint8, 0, T.comm, stream));
+			NCCL_OK(ncclRecv(loop_in, (size_t)n_loop * NH_HALO_RECORD_BYTES, ncclUint8, 0, T.comm, stream));
 			NCCL_OK(ncclGroupEnd());
-			NH_OK_(nh_halo_update(ctx, &bodies, 1, n_loop, in_right));
+			NH_OK_(nh_halo_update(R.ctx, &R.bodies, 1, n_loop, loop_in));
 		}
-		// ---- the reference's sub-step on the local world (example/main.cpp:274-328) ----
-		nh_Arena temporary = arena;
-		NH_OK_(nh_collide(ctx, &active, &contacts, &bodies, &colliders, &connections, temporary));
-		NH_OK_(nh_apply_gravity_damping(ctx, &active, &bodies, time_step, gravity, damping_rate));
-		nh_ContactImpulseData* impulses = nullptr;
-		NH_OK_(nh_read_cached_impulses(ctx, &cache, &contacts, &temporary, &impulses));
-		nh_ContactConstraintData* constraints = nullptr;
-		NH_OK_(nh_setup_contact_constraints(ctx, &active, &contacts, &bodies, impulses, &temporary, &constraints));
-		NH_OK_(nh_apply_impulses(ctx, constraints, &bodies, iterations));
-		NH_OK_(nh_update_cached_impulses(ctx, constraints, impulses));
-		NH_OK_(nh_write_cached_impulses(ctx, &cache, &contacts, impulses));
-		NH_OK_(nh_advance(ctx, &active, &bodies, time_step));
+		for (Rank& R : ranks) local_step(R, scene);
 	}
-	NH_OK_(nh_synchronize(ctx));
+	for (Rank& R : ranks) NH_OK_(nh_synchronize(R.ctx));
 	const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-	nh_Counts c;
-	NH_OK_(nh_read_counts(ctx, &c));
-	if (c.error) { fprintf(stderr, "rank %d: device error: %s\n", rank, nh_error_string((int)c.error)); return 5; }
-	sum_contacts = c.contacts;
 
-	// owned bodies must still be inside slab + margin (this example has no migration), and a position checksum for comparisons between runs
-	HIP_OK(hipMemcpy(h_xf.data(), bodies.transforms, sizeof(nh_Transform) * nb, hipMemcpyDeviceToHost));
-	double checksum = 0.0;
-	for (uint32_t i = 1; i <= n_owned; ++i) {
-		const float x = h_xf[i].position[0];
-		if (x < lo - margin * 0.5f || x > hi + margin * 0.5f) { fprintf(stderr, "rank %d: body %u left its slab (x = %g): this example does not migrate bodies\n", rank, i, x); return 7; }
-		checksum += (double)h_xf[i].position[0] + 2.0 * h_xf[i].position[1] + 3.0 * h_xf[i].position[2];
+	// ---- results: per rank a line; optionally every owned body (transform with the global id, momentum, idle) into a file the tests read ----
+	FILE* fo = out_path ? fopen(out_path, "wb") : nullptr;
+	uint64_t owned_all = 0;
+	for (Rank& R : ranks) {
+		nh_Counts c; NH_OK_(nh_read_counts(R.ctx, &c));
+		if (c.error) { fprintf(stderr, "rank %d: device error: %s\n", R.rank, nh_error_string((int)c.error)); return 5; }
+		nh_PartitionInfo info; NH_OK_(nh_partition_info(R.part, &info));
+		std::vector<nh_Transform> xf(info.n_owned + 1u); std::vector<nh_BodyMomentum> mom(info.n_owned + 1u); std::vector<uint8_t> idle(info.n_owned + 1u);
+		HIP_OK(hipMemcpy(xf.data(), R.bodies.transforms, sizeof(nh_Transform) * xf.size(), hipMemcpyDeviceToHost));
+		HIP_OK(hipMemcpy(mom.data(), R.bodies.momentum, sizeof(nh_BodyMomentum) * mom.size(), hipMemcpyDeviceToHost));
+		HIP_OK(hipMemcpy(idle.data(), R.bodies.idle_counters, idle.size(), hipMemcpyDeviceToHost));
+		double checksum = 0.0;
+		for (uint32_t i = 1; i <= info.n_owned; ++i) checksum += (double)xf[i].position[0] + 2.0 * xf[i].position[1] + 3.0 * xf[i].position[2];
+		if (fo) for (uint32_t i = 1; i <= info.n_owned; ++i) { fwrite(&xf[i], sizeof(nh_Transform), 1, fo); fwrite(&mom[i], sizeof(nh_BodyMomentum), 1, fo); fwrite(&idle[i], 1, 1, fo); }
+		owned_all += info.n_owned;
+		printf("partition_rccl rank %d/%d: %u owned + %u ghost bodies, %u steps, last step %u contacts (%.3f per owned+ghost body), %.1f steps/s, refreshes %llu, migrated out %llu in %llu, cut moves %llu, "
+		       "still steps %u, checksum %.6f\n", R.rank, n_ranks, info.n_owned, info.ghost_in[0] + info.ghost_in[1], steps, c.contacts, (double)c.contacts / std::max(1u, info.n_bodies - 1u), steps / seconds,
+		       (unsigned long long)info.refreshes, (unsigned long long)info.migrated_out, (unsigned long long)info.migrated_in, (unsigned long long)info.cut_moves, c.still_steps, checksum);
 	}
-	printf("partition_rccl rank %d/%d: %u owned + %u ghost bodies, %u steps, last step %llu contacts (%.3f per owned+ghost body), %.1f steps/s, checksum %.6f\n",
-	       rank, world, n_owned, n_gl + n_gr, steps, (unsigned long long)sum_contacts, (double)sum_contacts / (nb - 1), steps / seconds, checksum);
+	if (fo) fclose(fo);
+	if (local_ranks > 0 && owned_all != total_bodies) { fprintf(stderr, "bodies lost or duplicated: %llu owned of %zu\n", (unsigned long long)owned_all, total_bodies); return 7; }
 	if (loopback) printf("partition_rccl loopback: %u halo records per step through ncclSend/ncclRecv(self), %u steps\n", n_loop, steps);
-	nh_destroy(ctx);
-	if (comm) NCCL_OK(ncclCommDestroy(comm));
+	for (Rank& R : ranks) { nh_partition_destroy(R.part); nh_destroy(R.ctx); }
+	if (T.comm) NCCL_OK(ncclCommDestroy(T.comm));
 	return 0;
 }

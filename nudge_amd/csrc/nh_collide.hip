@@ -1635,18 +1635,18 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 		                   !ctx->env_no_sort_reuse && C != 0u;
 		if (still) {
 			nh_DevState* st = ctx->d_state;
-			NH_LAUNCH(ctx, "xform_aabb", (k_xform<true>), nh_grid_for(C > B ? C : B, 1024, 256), 1024, st, bodies->transforms,
+			NH_LAUNCH(ctx, "xform_still", (k_xform<true>), nh_grid_for(C > B ? C : B, 1024, 256), 1024, st, bodies->transforms,
 			          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
 			          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
 			          xf, aabb_min, aabb_max, ctag, (uint4*)nullptr, 0u, ctx->fat_box, 0u,
 			          (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, ctx->collide_seq, bodies->idle_counters, B, ctx->step_parity);
 			const uint8_t* gen = incremental ? ctx->fat_gen : (const uint8_t*)nullptr;
 			if (nbox >= 2)
-				NH_LAUNCH(ctx, "narrowphase", (k_narrowphase<false, true>), nh_grid_for(pair_cap, 256, 4096), 256, st, ctx->fat_pairs, xf, ctag,
+				NH_LAUNCH(ctx, "narrowphase_still", (k_narrowphase<false, true>), nh_grid_for(pair_cap, 256, 4096), 256, st, ctx->fat_pairs, xf, ctag,
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr,
 				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec);
 			if (nsph)
-				NH_LAUNCH(ctx, "narrowphase_sph", (k_narrowphase<true, true>), nh_grid_for(pair_cap, 256, 8192), 256, st, ctx->fat_pairs, xf, ctag,
+				NH_LAUNCH(ctx, "narrowphase_sph_still", (k_narrowphase<true, true>), nh_grid_for(pair_cap, 256, 8192), 256, st, ctx->fat_pairs, xf, ctag,
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr,
 				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec);
 			// every record's first contact in the dense (tag-ordered) list: the scan of the counts in tag order; the total is this step's contact count

@@ -2594,7 +2594,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 			nh_FusedStep fs = nh_FusedStep();
 			fs.gx_dt = ctx->grav.gx_dt; fs.gy_dt = ctx->grav.gy_dt; fs.gz_dt = ctx->grav.gz_dt; fs.damping = ctx->grav.damping; fs.time_step = ctx->grav.time_step;
 			fs.bits = 3u; fs.idle = bodies->idle_counters; fs.parity = ctx->step_parity;
-#define NH_SOLVE_STILL(NWAVES) NH_LAUNCH(ctx, "solve_one_body", (k_solve_one_body<4, true, true, NWAVES, true>), (B + 64u * NWAVES - 1u) / (64u * NWAVES), 64 * NWAVES, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum, \
+#define NH_SOLVE_STILL(NWAVES) NH_LAUNCH(ctx, "solve_still", (k_solve_one_body<4, true, true, NWAVES, true>), (B + 64u * NWAVES - 1u) / (64u * NWAVES), 64 * NWAVES, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum, \
 		          (float4*)d->states, iterations, ctx->raw_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fs, sv)
 			if (ctx->env_solver_waves == 4) NH_SOLVE_STILL(4); else if (ctx->env_solver_waves == 2) NH_SOLVE_STILL(2); else NH_SOLVE_STILL(1);
 			// the step's one round trip: did every check hold?

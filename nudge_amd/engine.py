@@ -82,6 +82,17 @@ class Counts(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class PartitionConfig(C.Structure):
+    _fields_ = [("rank", C.c_uint32), ("ranks", C.c_uint32), ("lo", C.c_double), ("hi", C.c_double), ("n_owned", C.c_uint32), ("n_static_box", C.c_uint32), ("n_static_sph", C.c_uint32),
+                ("body_capacity", C.c_uint32), ("box_capacity", C.c_uint32), ("sphere_capacity", C.c_uint32), ("epoch", C.c_uint32),
+                ("time_step", C.c_double), ("gravity", C.c_double), ("speed_floor", C.c_double), ("max_reach", C.c_double), ("cut_slack", C.c_double)]
+
+
+class PartitionInfo(C.Structure):
+    _fields_ = [("n_owned", C.c_uint32), ("n_bodies", C.c_uint32), ("n_boxes", C.c_uint32), ("n_spheres", C.c_uint32), ("ghost_out", C.c_uint32 * 2), ("ghost_in", C.c_uint32 * 2),
+                ("lo", C.c_double), ("hi", C.c_double), ("migrated_out", C.c_uint64), ("migrated_in", C.c_uint64), ("refreshes", C.c_uint64), ("cut_moves", C.c_uint64)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char_p), ("ms", C.c_double), ("launches", C.c_uint32), ("reserved", C.c_uint32)]
 
@@ -134,6 +145,19 @@ def lib():
         L.nh_halo_unpack.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_uint32, C.c_uint32, C.c_void_p]
         L.nh_halo_update.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_uint32, C.c_uint32, C.c_void_p]
         L.nh_append_contacts.argtypes = [C.c_void_p, C.POINTER(ContactData), C.POINTER(BodyData), C.c_uint32, C.c_void_p, Arena]
+        # multi-GPU: one x-slab per context (include/nudge_hip.h, "multi-GPU")
+        L.nh_partition_create.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(PartitionConfig), C.POINTER(BodyData), C.POINTER(ColliderData)]
+        L.nh_partition_destroy.argtypes = [C.c_void_p]
+        L.nh_partition_destroy.restype = None
+        L.nh_partition_info.argtypes = [C.c_void_p, C.POINTER(PartitionInfo)]
+        L.nh_partition_pack_migrants.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32 * 2)]
+        L.nh_partition_unpack_migrants.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.nh_partition_pack_ghosts.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32 * 2)]
+        L.nh_partition_unpack_ghosts.argtypes = [C.c_void_p, C.POINTER(BodyData), C.POINTER(ColliderData), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.nh_partition_pack_step.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_void_p, C.c_void_p]
+        L.nh_partition_unpack_step.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_void_p, C.c_void_p]
+        L.nh_partition_choose_cut.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_int, C.c_uint32, C.POINTER(C.c_double)]
+        L.nh_partition_set_cut.argtypes = [C.c_void_p, C.c_int, C.c_double]
         _LIB = L
     return _LIB
 

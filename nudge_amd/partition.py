@@ -39,6 +39,12 @@ from where it started than the static colliders a rank keeps allow (`split_scene
 
 Restriction: a dynamic body carries exactly ONE collider (any local transform); static colliders are unrestricted.
 
+WHERE THE WORK IS DONE.  On the HIP engine every operation below -- migration, ghost listing and installation, the collider rebuild, the per-step records,
+the choice of a new cut -- is a call into the C ABI (include/nudge_hip.h "multi-GPU": nh_partition_*, kernels with device-side counts in
+nudge_amd/csrc/nh_partition.hip); this class then only carries message buffers between the library and the transport, exactly like the C++ host
+examples/partition_rccl.cpp.  The torch implementation of the same operations further down is what the CPU tests run (the compiled reference as the
+engine, gloo as the transport) and what the GPU tests check the kernels against (`Partition(..., force_torch=True)`).
+
 Transport is pluggable: `LocalCluster` moves tensors between partitions living in one process (tests, one GPU),
 `DistCluster` uses torch.distributed point-to-point ops (one process per GPU).  The same `Partition` code runs in both.
 """
@@ -143,9 +149,10 @@ class Partition:
     tensors (`records(name, bytes)`), `set_counts(bodies, boxes, spheres)`, `step(n)` and `params` -- nudge_amd.engine.World
     does; the CPU tests plug the oracle in behind the same four members."""
 
-    def __init__(self, engine, info, epoch=16, speed_floor=1.0, per_iteration=False, rebalance=True, balance_tolerance=0.05):
+    def __init__(self, engine, info, epoch=16, speed_floor=1.0, per_iteration=False, rebalance=True, balance_tolerance=0.05, force_torch=False):
         import torch
         self.per_iteration = per_iteration
+        self.hip = None                       # the nh_partition handle when the engine is the HIP world (set at the end of __init__)
         # per-iteration exchange = one apply call per sweep with ghost momentum written in between: the engine must keep its solver states and
         # re-read momentum every call, which NH_FLAG_SINGLE_APPLY (4) / NH_FLAG_FUSED_STEP (8) promise away
         if per_iteration and (getattr(engine, "flags", 0) & (4 | 8)):
@@ -191,6 +198,64 @@ class Partition:
         self.ghost_in = {-1: 0, +1: 0}             # ghost records received from the left / right neighbour
         self.steps = 0
         self.stats = dict(refreshes=0, migrated_out=0, migrated_in=0, ghosts=0, late_bodies=0, step_bytes=0, refresh_bytes=0, cut_moves=0)
+        # (the per-iteration momentum exchange is a torch-side experiment on top of the lists this class keeps: it stays on the torch implementation)
+        if not force_torch and not per_iteration and hasattr(engine, "L") and hasattr(engine, "ctx") and hasattr(engine.L, "nh_partition_create"):
+            self._hip_create(info)
+
+    # ---- the HIP engine: every operation is a C-ABI call (include/nudge_hip.h "multi-GPU"); this class moves message buffers ---------------------------------
+    def _hip_create(self, info):
+        import ctypes as C
+        from . import engine as E
+        t, e = self.torch, self.e
+        cap = e.capacity
+        inf = float("inf")
+        cfg = E.PartitionConfig(self.rank, self.ranks, self.lo if self.lo > -inf else -1e308 * 10, self.hi if self.hi < inf else 1e308 * 10, self.n_owned, self.n_static_box, self.n_static_sph,
+                                cap["bodies"], cap["boxes"], cap["spheres"], self.epoch, self.dt, self.gravity, self.speed_floor, self.max_reach,
+                                self.cut_slack if self.cut_slack < inf else 1e308 * 10)
+        h = C.c_void_p()
+        E._check(e.L, e.L.nh_partition_create(C.byref(h), e.ctx, C.byref(cfg), C.byref(e.bodies), C.byref(e.colliders)), "nh_partition_create")
+        self.hip = h
+        dev = self.bt.device
+        self._msg_cap = max(4096, cap["bodies"] // 4)
+        self._full = {d: t.empty((self._msg_cap, FULL_BYTES), dtype=t.uint8, device=dev) for d in (-1, +1)}
+        self._stepbuf = {d: t.empty((0, STEP_BYTES), dtype=t.uint8, device=dev) for d in (-1, +1)}
+
+    def _hip_info(self):
+        import ctypes as C
+        from . import engine as E
+        i = E.PartitionInfo()
+        E._check(self.e.L, self.e.L.nh_partition_info(self.hip, C.byref(i)), "nh_partition_info")
+        self.n_owned = int(i.n_owned)
+        self.lo, self.hi = (float(i.lo) if self.rank > 0 else self.lo), (float(i.hi) if self.rank + 1 < self.ranks else self.hi)
+        self.stats.update(refreshes=int(i.refreshes), migrated_out=int(i.migrated_out), migrated_in=int(i.migrated_in), cut_moves=int(i.cut_moves),
+                          ghosts=int(i.ghost_in[0]) + int(i.ghost_in[1]))
+        return i
+
+    def _hip_pack(self, fn, what):
+        import ctypes as C
+        from . import engine as E
+        e = self.e
+        counts = (C.c_uint32 * 2)()
+        ptr = lambda d: C.c_void_p(self._full[d].data_ptr()) if d in self.neighbours() else C.c_void_p(0)
+        E._check(e.L, fn(self.hip, C.byref(e.bodies), ptr(-1), ptr(+1), self._msg_cap, C.byref(counts)), what)
+        return {d: self._full[d][:int(counts[0 if d < 0 else 1])] for d in self.neighbours()}
+
+    def _hip_unpack_args(self, incoming):
+        import ctypes as C
+        args = []
+        for d in (-1, +1):
+            rec = incoming.get(d) if d in self.neighbours() else None
+            m = 0 if rec is None else int(rec.shape[0])
+            if m:
+                rec = rec.contiguous()
+                incoming[d] = rec              # (keeps the buffer alive until the kernels have been enqueued behind it)
+            args += [C.c_void_p(rec.data_ptr() if m else 0), m]
+        return args
+
+    def close(self):
+        if self.hip is not None:
+            self.e.L.nh_partition_destroy(self.hip)
+            self.hip = None
 
     # ---- helpers -------------------------------------------------------------------------------------------------
     def neighbours(self):
@@ -269,7 +334,16 @@ class Partition:
         x = self._x(n + 1)[1:] if n else None
         for d in self.neighbours():
             rec = t.zeros((0, 8), dtype=t.uint8, device=dev)
-            if self._moves(d) == "me":                     # (the neighbour expects exactly one row then, whatever comes out)
+            if self._moves(d) == "me" and self.hip is not None:
+                import ctypes as C
+                from . import engine as E
+                cut = C.c_double(0.0)
+                E._check(self.e.L, self.e.L.nh_partition_choose_cut(self.hip, C.byref(self.e.bodies), d, int(self._nb_count[d]), C.byref(cut)), "nh_partition_choose_cut")
+                if d < 0: self.lo = cut.value
+                else: self.hi = cut.value
+                self._hip_info()
+                rec = t.tensor([cut.value], dtype=t.float64, device=dev).view(t.uint8).reshape(1, 8)
+            elif self._moves(d) == "me":                     # (the neighbour expects exactly one row then, whatever comes out)
                 old = self.lo if d < 0 else self.hi
                 cut = old
                 if n > 1:
@@ -297,6 +371,9 @@ class Partition:
             rec = incoming.get(d)
             if rec is not None and rec.numel():
                 cut = float(rec.reshape(-1).view(t.float64)[0].item())
+                if self.hip is not None:
+                    from . import engine as E
+                    E._check(self.e.L, self.e.L.nh_partition_set_cut(self.hip, d, cut), "nh_partition_set_cut")
                 if cut != (self.lo if d < 0 else self.hi):
                     if d < 0: self.lo = cut
                     else: self.hi = cut
@@ -304,6 +381,8 @@ class Partition:
 
     # ---- refresh: phase 1 (migration) --------------------------------------------------------------------------
     def refresh_pack_migrants(self):
+        if self.hip is not None:
+            return self._hip_pack(self.e.L.nh_partition_pack_migrants, "nh_partition_pack_migrants")
         t = self.torch
         n = self.n_owned + 1
         x = self._x(n)
@@ -320,6 +399,12 @@ class Partition:
 
     def refresh_unpack_migrants(self, incoming):
         """Drops the bodies that left, appends the ones that arrived (owned region stays contiguous from slot 1)."""
+        if self.hip is not None:
+            import ctypes as C
+            from . import engine as E
+            E._check(self.e.L, self.e.L.nh_partition_unpack_migrants(self.hip, C.byref(self.e.bodies), *self._hip_unpack_args(incoming)), "nh_partition_unpack_migrants")
+            self._hip_info()
+            return
         t = self.torch
         n = self.n_owned + 1
         keep = t.nonzero(~self._leave).flatten()          # includes slot 0
@@ -341,6 +426,12 @@ class Partition:
 
     # ---- refresh: phase 2 (ghost lists) ------------------------------------------------------------------------------
     def refresh_pack_ghosts(self):
+        if self.hip is not None:
+            out = self._hip_pack(self.e.L.nh_partition_pack_ghosts, "nh_partition_pack_ghosts")
+            dev = self.bt.device
+            for d in self.neighbours():
+                self._stepbuf[d] = self.torch.empty((out[d].shape[0], STEP_BYTES), dtype=self.torch.uint8, device=dev)
+            return out
         t = self.torch
         n = self.n_owned + 1
         x = self._x(n)
@@ -361,6 +452,16 @@ class Partition:
         return out
 
     def refresh_unpack_ghosts(self, incoming):
+        if self.hip is not None:
+            import ctypes as C
+            from . import engine as E
+            e = self.e
+            E._check(e.L, e.L.nh_partition_unpack_ghosts(self.hip, C.byref(e.bodies), C.byref(e.colliders), *self._hip_unpack_args(incoming)), "nh_partition_unpack_ghosts")
+            i = self._hip_info()
+            self.ghost_in = {-1: int(i.ghost_in[0]), +1: int(i.ghost_in[1])}
+            self.n_bodies = int(i.n_bodies)
+            e.nb, e.nbox, e.nsph = int(i.n_bodies), int(i.n_boxes), int(i.n_spheres)         # (the C call has set the counts of the engine's structs and told the context)
+            return
         at = self.n_owned + 1
         for d in (-1, +1):
             rec = incoming.get(d) if d in self.neighbours() else None
@@ -398,6 +499,15 @@ class Partition:
 
     # ---- every step ---------------------------------------------------------------------------------------------------
     def step_pack(self):
+        if self.hip is not None:
+            import ctypes as C
+            from . import engine as E
+            e = self.e
+            ptr = lambda d: C.c_void_p(self._stepbuf[d].data_ptr()) if d in self.neighbours() and self._stepbuf[d].shape[0] else C.c_void_p(0)
+            E._check(e.L, e.L.nh_partition_pack_step(self.hip, C.byref(e.bodies), ptr(-1), ptr(+1)), "nh_partition_pack_step")
+            out = {d: self._stepbuf[d] for d in self.neighbours()}
+            self.stats["step_bytes"] += sum(int(r.numel()) for r in out.values())
+            return out
         out = {}
         for d in self.neighbours():
             rec = self._step_records(self.ghost_out[d], self.ghost_out32[d])
@@ -406,6 +516,14 @@ class Partition:
         return out
 
     def step_unpack(self, incoming):
+        if self.hip is not None:
+            import ctypes as C
+            from . import engine as E
+            e = self.e
+            recs = {d: (incoming[d].contiguous() if self.ghost_in[d] else None) for d in (-1, +1)}
+            ptr = lambda d: C.c_void_p(recs[d].data_ptr()) if recs[d] is not None else C.c_void_p(0)
+            E._check(e.L, e.L.nh_partition_unpack_step(self.hip, C.byref(e.bodies), ptr(-1), ptr(+1)), "nh_partition_unpack_step")
+            return
         at = self.n_owned + 1
         for d in (-1, +1):
             m = self.ghost_in[d]

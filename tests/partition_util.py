@@ -122,3 +122,27 @@ def single_world_reference(scene, steps):
     w = refworld.RefWorld(scene)
     w.step(steps)
     return w.bodies()
+
+
+# ---- the scene as a file for the C++ host (examples/partition_rccl.cpp: load_scene) and its result file -----------------------------------------------------
+def write_scene_file(scene, path):
+    """'NHSC' | u32 version = 1, nb, nbox, nsph, iterations | f64 time_step, gravity, damping_rate | body transforms, properties, momentum, idle counters,
+    box tags (u32), data, transforms, sphere tags (u32), data, transforms -- the record layouts of include/nudge_hip.h."""
+    p = scene["params"]
+    with open(path, "wb") as f:
+        f.write(b"NHSC")
+        f.write(np.array([1, len(scene["body_transforms"]), len(scene["box_tags"]), len(scene["sphere_tags"]), int(p["iterations"])], dtype=np.uint32).tobytes())
+        f.write(np.array([p["time_step"], p["gravity"], p["damping_rate"]], dtype=np.float64).tobytes())
+        for k in ("body_transforms", "body_properties", "body_momentum", "idle_counters"):
+            f.write(np.ascontiguousarray(scene[k]).tobytes())
+        f.write(np.ascontiguousarray(scene["box_tags"], dtype=np.uint32).tobytes()); f.write(np.ascontiguousarray(scene["box_data"]).tobytes()); f.write(np.ascontiguousarray(scene["box_transforms"]).tobytes())
+        f.write(np.ascontiguousarray(scene["sphere_tags"], dtype=np.uint32).tobytes()); f.write(np.ascontiguousarray(scene["sphere_data"]).tobytes()); f.write(np.ascontiguousarray(scene["sphere_transforms"]).tobytes())
+
+
+def read_owned_file(path):
+    """What partition_rccl --out writes: per owned body its transform (the global id in `body`), momentum and idle counter; returned sorted by id like gather()."""
+    rec = np.dtype([("xf", S.TRANSFORM), ("mom", S.MOMENTUM), ("idle", np.uint8)])
+    a = np.fromfile(path, dtype=rec)
+    order = np.argsort(a["xf"]["body"], kind="stable")
+    a = a[order]
+    return dict(ids=a["xf"]["body"].astype(np.int64), transforms=a["xf"].copy(), momentum=a["mom"].copy(), idle=a["idle"].copy())

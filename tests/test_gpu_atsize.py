@@ -184,7 +184,8 @@ def test_temporal_coherence_paths_are_bit_identical_at_size(config, monkeypatch)
     assert ka["count"] == kb["count"] and np.array_equal(ka["tags"], kb["tags"]) and P.bits_equal(ka["data"]["impulse"], kb["data"]["impulse"])
     ca, cb = a.counts(), b.counts()
     assert cb["sort_reuses"] == 0 and cb["broadphase_rebuilds"] >= 200
-    assert ca["broadphase_rebuilds"] < 40 and ca["sort_reuses"] > 80, ca
+    # (a step either re-uses the tag order of the sort before it, or -- at rest -- is a still step that does not even ask: include/nudge_hip.h note 9)
+    assert ca["broadphase_rebuilds"] < 40 and ca["sort_reuses"] + ca["still_steps"] > 80 and ca["still_steps"] > 60, ca
     a.close(); b.close()
 
 

@@ -186,3 +186,45 @@ def test_cpp_rccl_host_loopback_executes_rccl_between_the_halo_kernels():
     assert "loopback: 2304 halo records per step through ncclSend/ncclRecv(self), 90 steps" in outs[1], outs[1]
     checksum = [o.split("checksum")[1].split()[0] for o in outs]
     assert checksum[0] == checksum[1], checksum
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sphere_fraction", [0.0, 0.5])
+def test_cpp_partition_host_matches_the_python_host_bit_for_bit(tmp_path, sphere_fraction):
+    """examples/partition_rccl.cpp with NUDGE_LOCAL_RANKS=3 (three ranks of the C++ host in one process on one GPU, device-to-device copies as the transport) and
+    nudge_amd/partition.py's LocalCluster are two hosts over the SAME C-ABI entry points (nh_partition_*): on one scene cut through its tiles, same epoch, same
+    capacities, they must leave the same owned bodies bit for bit -- through refreshes, per-step halos, landing and rest -- which also pins the C++ host's refresh /
+    migration / re-balancing logic, none of which a one-rank run executes."""
+    import numpy as np
+    import partition_util as PU
+    import parity_util as P
+    from nudge_amd import engine as E, partition as PT, scenes as S
+    assert os.path.exists(CU.PARTITION_RCCL), "nudge_amd/partition_rccl missing: make -C nudge_amd/csrc"
+    scene = S.grid_tiles(6, side=24, sphere_fraction=sphere_fraction, seed=33, lattice_cols=3)
+    x = scene["body_transforms"]["position"][1:, 0]
+    cuts = [float(np.quantile(x, 0.30)) + 0.41, float(np.quantile(x, 0.72)) + 0.41]          # uneven on purpose: the re-balancing moves them
+    steps = 150
+    scene_file, out_file = str(tmp_path / "scene.bin"), str(tmp_path / "owned.bin")
+    PU.write_scene_file(scene, scene_file)
+    env = dict(os.environ, NUDGE_LOCAL_RANKS="3", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([CU.PARTITION_RCCL, "--scene", scene_file, "--cuts", ",".join(repr(c) for c in cuts), "--out", out_file, "--min-extra", "2048", str(steps)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = PU.read_owned_file(out_file)
+    parts = []
+    for rk in range(3):
+        local, info = PT.split_scene(scene, cuts, rk, min_extra=2048)
+        w = E.World(local, flags=E.NH_FLAG_SINGLE_APPLY | E.NH_FLAG_FUSED_STEP, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=8 * info["capacity"]["bodies"])
+        parts.append(PT.Partition(w, info, epoch=16))
+        assert parts[-1].hip is not None
+    cl = PT.LocalCluster(parts)
+    cl.step(steps)
+    ref = cl.gather()
+    assert np.array_equal(got["ids"], ref["ids"]) and np.array_equal(got["ids"], np.arange(1, len(scene["body_transforms"])))
+    assert P.bits_equal(got["transforms"]["position"], ref["transforms"]["position"]) and P.bits_equal(got["transforms"]["rotation"], ref["transforms"]["rotation"])
+    assert P.bits_equal(got["momentum"]["velocity"], ref["momentum"]["velocity"]) and P.bits_equal(got["momentum"]["angular_velocity"], ref["momentum"]["angular_velocity"])
+    assert np.array_equal(got["idle"], ref["idle"])
+    moves = sum(p.stats["cut_moves"] for p in parts)
+    assert moves > 0 and f"cut moves" in r.stdout, (moves, r.stdout)
+    for q in parts:
+        q.close(); q.e.close()

@@ -173,3 +173,78 @@ def test_bench_under_torchrun_with_one_rank_executes_rccl_point_to_point():
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["contacts_per_step"] > 0.9 * 4 * 8 * 45 * 45, out
     assert out["halo"]["backend"] == "nccl" and out["halo"]["loopback_records_per_step"] == 4096, out["halo"]
+
+
+def _two_clusters(scene, ranks, epoch, flags, **kw):
+    """The same scene cut the same way twice: partitions driven by the C ABI (nh_partition_*: kernels) and by the torch implementation of the same operations."""
+    x = scene["body_transforms"]["position"][1:, 0]
+    cuts = [float(np.quantile(x, (r + 1) / ranks)) + 0.41 for r in range(ranks - 1)]
+    out = []
+    for force_torch in (False, True):
+        parts = []
+        for r in range(ranks):
+            local, info = PT.split_scene(scene, cuts, r, min_extra=2048)
+            w = E.World(local, flags=flags, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=8 * info["capacity"]["bodies"])
+            parts.append(PT.Partition(w, info, epoch=epoch, force_torch=force_torch, **kw))
+        assert all((p.hip is not None) == (not force_torch) for p in parts)
+        out.append((PT.LocalCluster(parts), parts))
+    return out
+
+
+@pytest.mark.parametrize("sphere_fraction", [0.0, 0.5])
+def test_partition_kernels_behind_the_c_abi_match_the_torch_implementation(sphere_fraction):
+    """nh_partition_* (include/nudge_hip.h "multi-GPU": migration, ghost listing / installation, collider rebuild, per-step records as HIP kernels with device-side
+    counts) against the torch implementation of the same operations in nudge_amd/partition.py, on a drop scene cut through its tiles in the bench's mode: the same
+    ghost counts at every refresh, and the owned bodies bit for bit over fall, landing, rest and sleep."""
+    scene = S.grid_tiles(6, side=30, sphere_fraction=sphere_fraction, seed=27, lattice_cols=3)
+    flags = E.NH_FLAG_SINGLE_APPLY | E.NH_FLAG_FUSED_STEP
+    (ca, pa), (cb, pb) = _two_clusters(scene, 3, 16, flags)
+    done = 0
+    for upto in (1, 17, 60, 150, 340):
+        ca.step(upto - done); cb.step(upto - done); done = upto
+        ga, gb = ca.gather(), cb.gather()
+        assert np.array_equal(ga["ids"], gb["ids"]) and np.array_equal(ga["ids"], np.arange(1, len(scene["body_transforms"])))
+        assert P.bits_equal(ga["transforms"]["position"], gb["transforms"]["position"]) and P.bits_equal(ga["transforms"]["rotation"], gb["transforms"]["rotation"]), upto
+        assert P.bits_equal(ga["momentum"]["velocity"], gb["momentum"]["velocity"]) and np.array_equal(ga["idle"], gb["idle"]), upto
+        for x, y in zip(pa, pb):
+            # (who is listed as a ghost may differ for a body exactly at the margin: reach and top speed are rounded differently by torch.norm and by the kernels)
+            assert x.n_owned == y.n_owned and abs(x.stats["ghosts"] - y.stats["ghosts"]) <= 4, (upto, x.stats, y.stats)
+    assert sum(p.stats["ghosts"] for p in pa) > 0 and pa[0].stats["refreshes"] >= 20
+    for q in pa + pb:
+        assert q.e.counts()["error"] == 0
+        q.close() if hasattr(q, "close") else None
+        q.e.close()
+
+
+def test_migration_and_cut_rebalancing_through_the_c_abi():
+    """Bodies flying sideways across the cuts change owner through nh_partition_pack_migrants / unpack_migrants; a lopsided split is re-balanced through
+    nh_partition_choose_cut / set_cut (a device-side sort picks the new cut).  Same owners, same cuts, same bits as the torch implementation."""
+    scene = S.grid_tiles(2, side=32, seed=29, lattice_cols=2)
+    scene["body_momentum"]["velocity"][1:, 0] = 10.0          # 2.5 units (most of a pitch) in 30 steps, all airborne
+    x = scene["body_transforms"]["position"][1:, 0]
+    cuts = [float(np.quantile(x, 0.2)) + 0.41, float(np.quantile(x, 0.8)) + 0.41]       # 20 % | 60 % | 20 %: the middle rank hands bodies to both sides
+    clusters = []
+    for force_torch in (False, True):
+        parts = []
+        for r in range(3):
+            local, info = PT.split_scene(scene, cuts, r, min_extra=4096, slack=1.0)
+            w = E.World(local, flags=0, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=8 * info["capacity"]["bodies"])
+            parts.append(PT.Partition(w, info, epoch=4, speed_floor=12.0, force_torch=force_torch))
+        clusters.append((PT.LocalCluster(parts), parts))
+    (ca, pa), (cb, pb) = clusters
+    ca.step(30); cb.step(30)
+    ga, gb = ca.gather(), cb.gather()
+    assert np.array_equal(ga["ids"], np.arange(1, len(scene["body_transforms"]))) and np.array_equal(ga["ids"], gb["ids"])
+    assert P.bits_equal(ga["transforms"]["position"], gb["transforms"]["position"]) and P.bits_equal(ga["momentum"]["velocity"], gb["momentum"]["velocity"])
+    for xp, yp in zip(pa, pb):
+        assert xp.n_owned == yp.n_owned and xp.lo == yp.lo and xp.hi == yp.hi, ((xp.n_owned, xp.lo, xp.hi), (yp.n_owned, yp.lo, yp.hi))
+    assert sum(p.stats["migrated_out"] for p in pa) > 0 and sum(p.stats["cut_moves"] for p in pa) > 0
+    assert sum(p.stats["migrated_out"] for p in pa) == sum(p.stats["migrated_out"] for p in pb)
+    single = E.World(scene, flags=0)
+    single.step(30)
+    ref = single.get_bodies()
+    assert P.bits_equal(ga["transforms"]["position"], ref["transforms"]["position"][1:])          # airborne: the partitioned world IS the single one
+    for q in pa + pb:
+        q.close()
+        q.e.close()
+    single.close()
