@@ -215,6 +215,12 @@ int nh_set_tag_bits(nh_context* ctx, uint32_t bits);        /* collider tags are
    arena too, nudge.cpp:3473): dense scenes hold more overlapping pairs than contacts (a settled ball pit: 1.7 x), so size it from
    the collider count there.  Overflow is reported as NH_ERR_PAIR_CAPACITY. */
 int nh_set_pair_capacity(nh_context* ctx, uint32_t pairs);
+/* Diagnostic switches for A/B runs and tests -- none is needed in production, each selects an older, slower or more talkative path; the library never reads the
+   environment.  Names (value 0 / 1 unless noted): "no_still", "no_kept_pairs", "no_incremental", "no_sort_reuse", "sort_classic", "sort_radix", "bucket_tile" (n),
+   "bucket_target" (n), "colour_jp", "colour_check_seeds", "no_resident", "solver_waves" (1, 2, 4), "fp_sub" (0, 1, 2, 4, 16), "cooperative", "no_blocks", "blk_check",
+   "blk_min" (n), "blk_target" (n), "blk_rows_global", "blk_global_colours", "blk_profile".  Unknown name: NH_ERR_INVALID.  Call right after nh_create.
+   (nudge_amd/engine.py maps environment variables NH_<NAME> onto these calls for its tests: a convenience of that host, not of the library.) */
+int nh_set_option(nh_context* ctx, const char* name, int value);
 const char* nh_error_string(int code);
 int nh_last_hip_error(nh_context* ctx);
 
@@ -273,6 +279,19 @@ int nh_halo_unpack(nh_context* ctx, const nh_BodyData* bodies, uint32_t first_sl
    per-step halo; nh_halo_unpack is for slots that change hands: refresh, migration).  The difference is the library's sleep prediction (see
    nh_bodies_changed): idle counters rise by at most one per step on the owner as they do here, so an update does not invalidate it. */
 int nh_halo_update(nh_context* ctx, const nh_BodyData* bodies, uint32_t first_slot, uint32_t count, const void* in);
+
+/* ---- the sample's sub-step loop as ONE entry point (example/main.cpp:274-328: simulate()) ---------------------------------------------------------------------
+   nh_step(ctx, args, steps) = `steps` times  nh_collide, nh_apply_gravity_damping, nh_read_cached_impulses, nh_setup_contact_constraints, nh_apply_impulses(iterations),
+   nh_update_cached_impulses, nh_write_cached_impulses, nh_advance  on the arrays of `args` (scratch and the two opaque objects come out of `arena`, reset every step like
+   the sample does, example/main.cpp:282).  Same results as the eight calls made by the caller -- bit for bit -- with two savings: one crossing of the ABI instead of
+   eight per step, and, because the library drives the call order itself, the host round trip of a still step (note 9) is taken one step LATE, so that neither the host nor
+   the GPU waits for the other inside the loop.  Every step is confirmed when the call returns.  Custom contacts / user impulses between the calls need the eight calls. */
+typedef struct nh_StepArgs {
+	nh_ActiveBodies* active_bodies; nh_ContactData* contacts; const nh_BodyData* bodies; const nh_ColliderData* colliders; const nh_BodyConnections* body_connections;
+	nh_ContactCache* contact_cache; nh_Arena arena;
+	float time_step; float gravity[3]; float damping_rate; uint32_t iterations;
+} nh_StepArgs;
+int nh_step(nh_context* ctx, const nh_StepArgs* args, uint32_t steps);
 
 /* ---- multi-GPU: one x-slab of a world per context ------------------------------------------------------------------------------------
    The world is cut into slabs along x, one rank (process, GPU, nh_context) per slab [lo, hi).  A rank's arrays hold

@@ -110,9 +110,12 @@ struct Session {
 	uint32_t host_contacts = 0;          // contacts.count as the caller sees it
 
 	hipStream_t stream = nullptr;
+	int device = 0;
+	// every entry point, after taking the session's lock: the world's device is the calling thread's current one (a world first seen by another thread would
+	// otherwise get its mirrors on whatever device THIS thread happens to have current)
+	void bind() { init(); hip_check(hipSetDevice(device), "hipSetDevice"); }
 	void init() {
 		if (ctx) return;
-		int device = 0;
 		if (const char* s = getenv("NUDGE_HIP_DEVICE")) device = atoi(s);
 		hip_check(hipSetDevice(device), "hipSetDevice");
 		// a stream of the world's own (a blocking one: the synchronous copies of this layer, on the legacy default stream, stay ordered with its kernels)
@@ -157,11 +160,39 @@ Session& session_by_key(const void* key, const char* who) {
 	Registry& r = registry();
 	std::lock_guard<std::mutex> guard(r.lock);
 	auto a = r.by_key.find(key);
-	if (a == r.by_key.end()) die(who, "these arrays belong to no world that collide() has seen");
-	return *a->second;
+	if (a != r.by_key.end()) return *a->second;
+	// the reference has no call order: advance() or read_cached_impulses() on arrays collide() has not seen yet simply start a world
+	(void)who;
+	r.all.emplace_back(new Session());
+	Session* s = r.all.back().get();
+	if (key) r.by_key[key] = s;
+	return *s;
 }
 
 void check(int rc, const char* what) { if (rc) die(what, nh_error_string(rc)); }
+
+// The caller is done with a world (its arrays are about to be freed or re-used): the session found through either array goes, with its device mirrors, context
+// and stream.  Without this call sessions live until the process ends (the reference has nothing to release, so an unmodified call site never tells).
+void release_world(const void* key) {
+	Registry& r = registry();
+	std::lock_guard<std::mutex> guard(r.lock);
+	auto a = r.by_key.find(key);
+	if (a == r.by_key.end()) return;
+	Session* s = a->second;
+	for (auto it = r.by_key.begin(); it != r.by_key.end();) { if (it->second == s) it = r.by_key.erase(it); else ++it; }
+	for (auto it = r.all.begin(); it != r.all.end(); ++it) if (it->get() == s) {
+		{
+			std::lock_guard<std::mutex> g2(s->lock);
+			if (s->ctx) { hipSetDevice(s->device); nh_destroy(s->ctx); s->ctx = nullptr; }
+			if (s->stream) { hipStreamDestroy(s->stream); s->stream = nullptr; }
+			DevBuf* bufs[] = { &s->body_xf, &s->body_props, &s->body_mom, &s->body_idle, &s->box_tags, &s->box_data, &s->box_xf, &s->sph_tags, &s->sph_data, &s->sph_xf, &s->connections,
+			                   &s->c_data, &s->c_bodies, &s->c_tags, &s->c_features, &s->c_sleeping, &s->k_tags, &s->k_features, &s->k_data, &s->active, &s->arena, &s->positions };
+			for (DevBuf* b : bufs) if (b->p) { hipFree(b->p); b->p = nullptr; b->cap = 0; }
+		}
+		r.all.erase(it);
+		break;
+	}
+}
 
 nh_BodyData device_bodies(Session& s, const nudge::BodyData& b, bool xf, bool props, bool mom, bool idle) {
 	if (xf) upload(s.body_xf, b.transforms, sizeof(nudge::Transform) * b.count);
@@ -225,7 +256,7 @@ namespace nudge {
 void collide(ActiveBodies* active_bodies, ContactData* contacts, BodyData bodies, ColliderData colliders, BodyConnections body_connections, Arena /*temporary: scratch is device memory*/) {
 	Session& s = session_of_world(bodies.transforms, contacts->data);
 	std::lock_guard<std::mutex> guard(s.lock);
-	s.init();
+	s.bind();
 	const uint32_t nbox = colliders.boxes.count, nsph = colliders.spheres.count, K = contacts->capacity;
 
 	nh_BodyData db = device_bodies(s, bodies, true, false, false, true);
@@ -300,7 +331,7 @@ void collide(ActiveBodies* active_bodies, ContactData* contacts, BodyData bodies
 ContactImpulseData* read_cached_impulses(ContactCache contact_cache, ContactData contacts, Arena* memory) {
 	Session& s = session_by_key(contacts.data, "read_cached_impulses");
 	std::lock_guard<std::mutex> guard(s.lock);
-	s.init();
+	s.bind();
 	if (contacts.count < s.host_contacts) die("read_cached_impulses", "contacts were removed since collide()");
 	if (contacts.count > contacts.capacity) die("read_cached_impulses", "contacts.count exceeds contacts.capacity");
 	if (contacts.count > s.host_contacts) {
@@ -346,6 +377,7 @@ void write_cached_impulses(ContactCache* contact_cache, ContactData contacts, Co
 	if (!h || h->magic != IMPULSE_MAGIC) die("write_cached_impulses", "not a ContactImpulseData of this backend");
 	Session& s = *h->world;
 	std::lock_guard<std::mutex> guard(s.lock);
+	s.bind();
 	(void)contacts;
 	const uint32_t cap = contact_cache->capacity;
 	s.k_tags.reserve(8 * (size_t)cap + 16); s.k_features.reserve(4 * (size_t)cap + 16); s.k_data.reserve(16 * (size_t)cap + 16);
@@ -366,6 +398,7 @@ ContactConstraintData* setup_contact_constraints(ActiveBodies active_bodies, Con
 	if (!h || h->magic != IMPULSE_MAGIC) die("setup_contact_constraints", "not a ContactImpulseData of this backend");
 	Session& s = *h->world;
 	std::lock_guard<std::mutex> guard(s.lock);
+	s.bind();
 	if (contacts.count != s.host_contacts) die("setup_contact_constraints", "contacts were added or removed since read_cached_impulses()");
 	(void)active_bodies;
 	upload_contact_data(s, contacts.data, contacts.count);
@@ -387,6 +420,7 @@ void apply_impulses(ContactConstraintData* data, BodyData bodies) {
 	if (!c || c->magic != CONSTRAINT_MAGIC) die("apply_impulses", "not a ContactConstraintData of this backend");
 	Session& s = *c->world;
 	std::lock_guard<std::mutex> guard(s.lock);
+	s.bind();
 	nh_BodyData db = device_bodies(s, bodies, false, false, true, false);    // custom constraint impulses may have touched momentum
 	check(nh_apply_impulses(s.ctx, c->dev, &db, 1), "apply_impulses");
 	download(bodies.momentum, s.body_mom.p, sizeof(BodyMomentum) * (size_t)bodies.count);
@@ -399,6 +433,7 @@ void update_cached_impulses(ContactConstraintData* data, ContactImpulseData* con
 	if (!c || c->magic != CONSTRAINT_MAGIC || !h || h->magic != IMPULSE_MAGIC || c->world != h->world) die("update_cached_impulses", "foreign opaque data");
 	Session& s = *c->world;
 	std::lock_guard<std::mutex> guard(s.lock);
+	s.bind();
 	check(nh_update_cached_impulses(s.ctx, c->dev, h->dev), "update_cached_impulses");
 }
 
@@ -406,7 +441,7 @@ void update_cached_impulses(ContactConstraintData* data, ContactImpulseData* con
 void advance(ActiveBodies active_bodies, BodyData bodies, float time_step) {
 	Session& s = session_by_key(bodies.transforms, "advance");
 	std::lock_guard<std::mutex> guard(s.lock);
-	s.init();
+	s.bind();
 	nh_BodyData db = device_bodies(s, bodies, true, false, true, true);
 	// the active list is the one collide() produced (still on the device); the host copy must not have been edited
 	if (active_bodies.count != s.active_bodies.count) die("advance", "active_bodies were edited since collide()");
@@ -417,3 +452,7 @@ void advance(ActiveBodies active_bodies, BodyData bodies, float time_step) {
 }
 
 }  // namespace nudge
+
+// Optional, for adopters that create and destroy worlds: nudge_hip_release_world(bodies.transforms) (or contacts.data) frees everything the GPU backend holds for
+// the world these arrays belong to.  Declared in INTEGRATION.md; the reference API itself has no such call.
+extern "C" void nudge_hip_release_world(const void* body_transforms_or_contact_data) { release_world(body_transforms_or_contact_data); }

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 			if (red[0]) atomicMax(&st->max_idle[parity], red[0]);
 			if (blockIdx.x == 0) {
 				// what the NEXT step (the other parity) accumulates into: nobody touches it during this one
-				st->still_fail[parity ^ 1u] = 0u; st->max_idle[parity ^ 1u] = 0u;
+				st->max_idle[parity ^ 1u] = 0u;
 				for (int k = 0; k < 3; ++k) { st->still_smin[parity ^ 1u][k] = 0xffffffffu; st->still_smax[parity ^ 1u][k] = 0u; }
 			}
 		}
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 		if ((threadIdx.x & 63) == 0) { atomicMin(&red[k], lmin[k]); atomicMax(&red[3 + k], lmax[k]); if (!STILL) { atomicMin(&red[6 + k], gmn[k]); atomicMax(&red[9 + k], gmx[k]); } }
 	}
 	if (STILL) {
-		{ const unsigned long long esc = __ballot(escaped); if (esc != 0ull && nh_lane() == 0) { st->still_fail[parity] = 1u; atomicAdd(&st->still_diff[3], (uint32_t)__popcll(esc)); } }
+		{ const unsigned long long esc = __ballot(escaped); if (esc != 0ull && nh_lane() == 0) { atomicMax(&st->still_failed_seq, seq); atomicAdd(&st->still_diff[3], (uint32_t)__popcll(esc)); } }
 		__syncthreads();
 		if (threadIdx.x < 3) { atomicMin(&st->still_smin[parity][threadIdx.x], red[threadIdx.x]); atomicMax(&st->still_smax[parity][threadIdx.x], red[3 + threadIdx.x]); }
 		return;
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
                                                      // STILL only: the kept list (`pairs`) and its capacity, this step's exact AABBs, the stamps, tag-order positions / counts, the bodies' records
                                                      uint32_t kept_cap = 0u, const float4* __restrict__ aabb_min = nullptr, const float4* __restrict__ aabb_max = nullptr,
                                                      const uint8_t* __restrict__ gen = nullptr, const uint32_t* __restrict__ lay_rank = nullptr, uint32_t* __restrict__ cnt_sorted = nullptr,
-                                                     const uint32_t* __restrict__ body_rec = nullptr) {
+                                                     const uint32_t* __restrict__ body_rec = nullptr, uint32_t seq = 0u) {
 	// coarse islands (nudge.cpp:3500-3703): a pair whose bodies belong to a set of sleeping bodies (sets over the BROADPHASE pairs and the
 	// user's connections) never reaches the narrowphase: it becomes a sleeping pair, larger tag in the low half (3697)
 	const bool some_asleep = !STILL && st->any_idle[parity] != 0;
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		mscale = nh_morton_scale(smin, smax);
 		mmin = nh_make3(smin.x * mscale, smin.y * mscale, smin.z * mscale);
 		// (the layout must be the last full step's, and the kept list as long as the pair list it was written from)
-		if (blockIdx.x == 0 && threadIdx.x == 0 && (!st->lay_valid || st->fat_count != st->pairs || st->fat_count_sph != st->pairs_sph)) st->still_fail[parity] = 1u;
+		if (blockIdx.x == 0 && threadIdx.x == 0 && (!st->lay_valid || st->fat_count != st->pairs || st->fat_count_sph != st->pairs_sph)) atomicMax(&st->still_failed_seq, seq);
 	}
 	const uint32_t n = SPH ? n_sph : n_bb, first_rec = SPH ? n_bb : 0u;
 	// sort re-use (nh_collide): `rec_key` is the context's buffer of keys by record position, still holding last step's -- is every key what it was?
@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		}
 		__builtin_amdgcn_wave_barrier();
 	}
-	if (STILL) { if (__ballot(changed) != 0ull && nh_lane() == 0) st->still_fail[parity] = 1u; return; }
+	if (STILL) { if (__ballot(changed) != 0ull && nh_lane() == 0) atomicMax(&st->still_failed_seq, seq); return; }
 	if (__ballot(changed) != 0ull && nh_lane() == 0) st->keys_changed = 1u;          // (plain store of a constant)
 }
 
@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		st->any_idle[parity ^ 1u] = 0;
 		// (what a still step of the other parity -- the next step, if the host launches it as one -- accumulates into, and the verdict on this step's layout)
-		st->still_fail[parity ^ 1u] = 0u; st->max_idle[parity ^ 1u] = 0u; st->lay_valid = 0u; st->lay_in_place = 0u;
+		st->max_idle[parity ^ 1u] = 0u; st->lay_valid = 0u; st->lay_in_place = 0u;
 		for (int k = 0; k < 3; ++k) { st->still_smin[parity ^ 1u][k] = 0xffffffffu; st->still_smax[parity ^ 1u][k] = 0u; }
 	}
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < NH_DEG_WORDS(nbodies); i += gridDim.x * blockDim.x) deg[i] = 0;      // degrees, pair counters, first contacts (NH_DEG_STRIDE)
@@ -1644,11 +1644,11 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			if (nbox >= 2)
 				NH_LAUNCH(ctx, "narrowphase_still", (k_narrowphase<false, true>), nh_grid_for(pair_cap, 256, 4096), 256, st, ctx->fat_pairs, xf, ctag,
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr,
-				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec);
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq);
 			if (nsph)
 				NH_LAUNCH(ctx, "narrowphase_sph_still", (k_narrowphase<true, true>), nh_grid_for(pair_cap, 256, 8192), 256, st, ctx->fat_pairs, xf, ctag,
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr,
-				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec);
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq);
 			// every record's first contact in the dense (tag-ordered) list: the scan of the counts in tag order; the total is this step's contact count
 			nh_scan_u32(ctx, ctx->cnt_sorted, ctx->start_sorted, &st->records, 1, scan_tmp, &st->contacts);
 			ss.active = true; ss.resolved = false; ss.launched++;
@@ -1657,7 +1657,9 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			return NH_OK;
 		}
 	}
-	// a full step: the solver reads the caller's cache arrays and this nh_collide lays the dense contact list out -- whatever still steps kept by slot goes home first
+	// a full step.  (nh_step: a still step whose verdict has not been looked at yet must have happened before anything is built on it)
+	if (ctx->still.verdict.pending && nh_still_verdict_now(ctx)) return NH_INTERNAL_STILL_FAILED;
+	// The solver reads the caller's cache arrays and this nh_collide lays the dense contact list out -- whatever still steps kept by slot goes home first
 	{ int rc = nh_still_export_cache(ctx); if (rc) return rc; }
 	ctx->still.contacts_stale = false; ctx->still.slots_current = false;
 	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, begin_grid, 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity, coarse_parent, coarse_active, no_islands ? 1u : 0u, block_top,
@@ -1810,9 +1812,11 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 __device__ __forceinline__ bool app_less(uint64_t ta, uint32_t fa, uint64_t tb, uint32_t fb) { return ta < tb || (ta == tb && fa < fb); }
 
 // rank of every appended contact among the appended ones (ties: position), and the sorted keys
+// (every k_app_* kernel leaves at once when the merged list would not fit the caller's arrays: k_app_count reports NH_ERR_CONTACT_CAPACITY and nothing is written out of bounds)
 __global__ __launch_bounds__(256) void k_app_rank(const nh_DevState* __restrict__ st, uint32_t extra, const uint64_t* __restrict__ tags, const uint32_t* __restrict__ features,
-                                                  uint32_t* __restrict__ rank, uint64_t* __restrict__ skey, uint32_t* __restrict__ sfeat) {
+                                                  uint32_t* __restrict__ rank, uint64_t* __restrict__ skey, uint32_t* __restrict__ sfeat, uint32_t capacity) {
 	const uint32_t K = st->contacts;
+	if ((uint64_t)K + extra > capacity) return;
 	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < extra; j += gridDim.x * blockDim.x) {
 		const uint64_t t = tags[K + j]; const uint32_t f = features[K + j];
 		uint32_t r = 0;
@@ -1826,8 +1830,9 @@ __global__ __launch_bounds__(256) void k_app_rank(const nh_DevState* __restrict_
 
 // new position of every contact: an old one moves up by the appended ones that sort before it, an appended one lands behind the old ones with a key <= its own
 __global__ __launch_bounds__(256) void k_app_positions(const nh_DevState* __restrict__ st, uint32_t extra, const uint64_t* __restrict__ tags, const uint32_t* __restrict__ features,
-                                                       const uint32_t* __restrict__ rank, const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sfeat, uint32_t* __restrict__ pos) {
+                                                       const uint32_t* __restrict__ rank, const uint64_t* __restrict__ skey, const uint32_t* __restrict__ sfeat, uint32_t* __restrict__ pos, uint32_t capacity) {
 	const uint32_t K = st->contacts;
+	if ((uint64_t)K + extra > capacity) return;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < K + extra; i += gridDim.x * blockDim.x) {
 		const uint64_t t = tags[i]; const uint32_t f = features[i];
 		if (i < K) {
@@ -1844,7 +1849,8 @@ __global__ __launch_bounds__(256) void k_app_positions(const nh_DevState* __rest
 
 __global__ __launch_bounds__(256) void k_app_copy(const nh_DevState* __restrict__ st, uint32_t extra, const nh_Contact* __restrict__ data, const nh_BodyPair* __restrict__ bodies,
                                                   const uint64_t* __restrict__ tags, const uint32_t* __restrict__ features, float4* __restrict__ t_data, nh_BodyPair* __restrict__ t_bodies,
-                                                  uint64_t* __restrict__ t_tags, uint32_t* __restrict__ t_features) {
+                                                  uint64_t* __restrict__ t_tags, uint32_t* __restrict__ t_features, uint32_t capacity) {
+	if ((uint64_t)st->contacts + extra > capacity) return;
 	const uint32_t n = st->contacts + extra;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		t_data[2 * (size_t)i] = reinterpret_cast<const float4*>(data + i)[0]; t_data[2 * (size_t)i + 1] = reinterpret_cast<const float4*>(data + i)[1];
@@ -1854,7 +1860,8 @@ __global__ __launch_bounds__(256) void k_app_copy(const nh_DevState* __restrict_
 
 __global__ __launch_bounds__(256) void k_app_scatter(const nh_DevState* __restrict__ st, uint32_t extra, const uint32_t* __restrict__ pos, const float4* __restrict__ t_data,
                                                      const nh_BodyPair* __restrict__ t_bodies, const uint64_t* __restrict__ t_tags, const uint32_t* __restrict__ t_features,
-                                                     nh_Contact* __restrict__ data, nh_BodyPair* __restrict__ bodies, uint64_t* __restrict__ tags, uint32_t* __restrict__ features) {
+                                                     nh_Contact* __restrict__ data, nh_BodyPair* __restrict__ bodies, uint64_t* __restrict__ tags, uint32_t* __restrict__ features, uint32_t capacity) {
+	if ((uint64_t)st->contacts + extra > capacity) return;
 	const uint32_t n = st->contacts + extra;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const uint32_t p = pos[i];
@@ -1863,18 +1870,20 @@ __global__ __launch_bounds__(256) void k_app_scatter(const nh_DevState* __restri
 	}
 }
 
-// the per-body bookkeeping of k_gather_contacts, from the merged list: a run of equal tags is one collider pair
+// the per-body bookkeeping of k_gather_contacts, from the merged list: a run of equal tags AND equal bodies is one collider pair (appended contacts may share a tag --
+// the reference only sorts by it -- while naming different bodies: each such stretch is a pair of its own for its two bodies)
 __global__ __launch_bounds__(256) void k_app_recount(nh_DevState* __restrict__ st, uint32_t extra, const nh_BodyPair* __restrict__ bodies, const uint64_t* __restrict__ tags,
-                                                     uint32_t* __restrict__ deg, uint32_t nbodies) {
+                                                     uint32_t* __restrict__ deg, uint32_t nbodies, uint32_t capacity) {
+	if ((uint64_t)st->contacts + extra > capacity) return;
 	unsigned long long* __restrict__ pair_counter = reinterpret_cast<unsigned long long*>(deg + 2u * NH_DEG_STRIDE(nbodies));
 	uint32_t* __restrict__ first_contact = deg + 4u * NH_DEG_STRIDE(nbodies);
 	const uint32_t n = st->contacts + extra;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		if (i > 0 && tags[i - 1] == tags[i]) continue;          // not the head of its run
+		const nh_BodyPair p = bodies[i];
+		if (i > 0 && tags[i - 1] == tags[i] && bodies[i - 1].a == p.a && bodies[i - 1].b == p.b) continue;          // not the head of its run
 		const uint64_t t = tags[i];
 		uint32_t len = 1;
-		while (i + len < n && tags[i + len] == t) ++len;
-		const nh_BodyPair p = bodies[i];
+		while (i + len < n && tags[i + len] == t && bodies[i + len].a == p.a && bodies[i + len].b == p.b) ++len;
 		if (p.a) { atomicAdd(&pair_counter[p.a], (unsigned long long)len | ((unsigned long long)(p.b ? 0x10001u : 1u) << 32)); first_contact[p.a] = i | 0x80000000u; }
 		if (p.b) { atomicAdd(&pair_counter[p.b], (unsigned long long)len | ((unsigned long long)(p.a ? 0x10001u : 1u) << 32)); first_contact[p.b] = i; }
 	}
@@ -1905,13 +1914,13 @@ extern "C" int nh_append_contacts(nh_context* ctx, nh_ContactData* contacts, con
 	uint32_t* t_features = nh_arena_array<uint32_t>(&temporary, cap, &err);
 	if (err) return err;
 	if ((ctx->flags & NH_FLAG_SYNC_COUNTS) && (uint64_t)contacts->count + extra > cap) return NH_ERR_CONTACT_CAPACITY;
-	NH_LAUNCH(ctx, "append_rank", k_app_rank, nh_grid_for(extra, 256, 1024), 256, st, extra, contacts->tags, contacts->features, rank, skey, sfeat);
-	NH_LAUNCH(ctx, "append_positions", k_app_positions, nh_grid_for(cap, 256, 2048), 256, st, extra, contacts->tags, contacts->features, rank, skey, sfeat, pos);
-	NH_LAUNCH(ctx, "append_copy", k_app_copy, nh_grid_for(cap, 256, 2048), 256, st, extra, contacts->data, contacts->bodies, contacts->tags, contacts->features, t_data, t_bodies, t_tags, t_features);
-	NH_LAUNCH(ctx, "append_scatter", k_app_scatter, nh_grid_for(cap, 256, 2048), 256, st, extra, pos, t_data, t_bodies, t_tags, t_features, contacts->data, contacts->bodies, contacts->tags, contacts->features);
+	NH_LAUNCH(ctx, "append_rank", k_app_rank, nh_grid_for(extra, 256, 1024), 256, st, extra, contacts->tags, contacts->features, rank, skey, sfeat, cap);
+	NH_LAUNCH(ctx, "append_positions", k_app_positions, nh_grid_for(cap, 256, 2048), 256, st, extra, contacts->tags, contacts->features, rank, skey, sfeat, pos, cap);
+	NH_LAUNCH(ctx, "append_copy", k_app_copy, nh_grid_for(cap, 256, 2048), 256, st, extra, contacts->data, contacts->bodies, contacts->tags, contacts->features, t_data, t_bodies, t_tags, t_features, cap);
+	NH_LAUNCH(ctx, "append_scatter", k_app_scatter, nh_grid_for(cap, 256, 2048), 256, st, extra, pos, t_data, t_bodies, t_tags, t_features, contacts->data, contacts->bodies, contacts->tags, contacts->features, cap);
 	// degrees, pair info, first contact: counted again
 	NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->deg, 0, sizeof(uint32_t) * NH_DEG_WORDS(B), ctx->stream));
-	NH_LAUNCH(ctx, "append_recount", k_app_recount, nh_grid_for(cap, 256, 2048), 256, st, extra, contacts->bodies, contacts->tags, ctx->deg, B);
+	NH_LAUNCH(ctx, "append_recount", k_app_recount, nh_grid_for(cap, 256, 2048), 256, st, extra, contacts->bodies, contacts->tags, ctx->deg, B, cap);
 	NH_LAUNCH(ctx, "append_count", k_app_count, 1, 1, st, extra, cap);
 	if (ctx->flags & NH_FLAG_SYNC_COUNTS) {
 		nh_Counts c;

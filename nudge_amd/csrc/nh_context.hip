@@ -26,49 +26,37 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->deg_capacity = 0;
 	ctx->order_seq = 0;
 	ctx->sort_splitters = nullptr; ctx->sort_counts = nullptr; ctx->sort_starts = nullptr; ctx->sort_capacity = 0; ctx->sort_seeded = false;
-	{ const char* e = getenv("NH_BUCKET_TILE"); ctx->sort_tile = e ? (uint32_t)atoi(e) : 0u; }
-	{ const char* e = getenv("NH_BUCKET_TARGET"); ctx->sort_target = e ? (uint32_t)atoi(e) : 0u; }
 	ctx->step_parity = 0;
 	ctx->pair_capacity = 0;
 	ctx->collide_seq = 0; ctx->setup_seq = 0;
 	ctx->idle_bound = -1; ctx->idle_unknown = true; ctx->advance_count = 0; ctx->collide_mark = 0; ctx->idle_bound_mark = 0; ctx->islands_skipped = false;
-	// NH_SORT_CLASSIC=1: three-kernel radix passes; NH_SORT_RADIX=1: radix passes every step (no seeded bucket sort);
-	// NH_COLOUR_JP=1: Jones-Plassmann colouring rounds.  Read here once, never on the step path.
-	ctx->env_sort_classic = getenv("NH_SORT_CLASSIC") != nullptr;
-	ctx->env_sort_radix = getenv("NH_SORT_RADIX") != nullptr;
-	ctx->env_colour_jp = getenv("NH_COLOUR_JP") != nullptr;
-	ctx->env_solver_waves = getenv("NH_SOLVER_WAVES") ? atoi(getenv("NH_SOLVER_WAVES")) : 1;      // wavefronts per workgroup of the fused solver (A/B: 1, 2, 4)
-	ctx->env_fp_sub = getenv("NH_FP_SUB") ? atoi(getenv("NH_FP_SUB")) : 0;      // lanes per collider in the pair search (A/B: 1, 2, 4, 16; 0 = by world size)
-	ctx->env_no_sort_reuse = getenv("NH_NO_SORT_REUSE") != nullptr;      // the tag sort of the contact records runs every step even when nothing has changed (A/B, tests)
+	// Behaviour switches (A/B runs, tests): defaults here, changed through nh_set_option -- the library itself never reads the environment
+	ctx->sort_tile = 0u; ctx->sort_target = 0u;
+	ctx->env_sort_classic = false; ctx->env_sort_radix = false; ctx->env_colour_jp = false;
+	ctx->env_solver_waves = 1; ctx->env_fp_sub = 0;
+	ctx->env_no_sort_reuse = false;
 	ctx->sort_keys_by_position = nullptr; ctx->sort_sorted_keys = nullptr; ctx->sort_sorted_idx = nullptr;
 	ctx->bp_seen_rebuilds = 0; ctx->bp_rebuild_streak = 0; ctx->bp_direct_left = 0;
-	ctx->env_measure_skip = getenv("NH_MEASURE_SKIP_CHAINS") != nullptr;      // MEASUREMENT ONLY: from step 67 on the launches of the grid chain and the tag sort are not issued at all (wrong as soon as anything moves)
-	ctx->env_no_fat = getenv("NH_NO_KEPT_PAIRS") != nullptr;      // the broadphase regroups and searches every step instead of re-using its kept pair list (A/B, tests)
+	ctx->env_measure_skip = false;
+	ctx->env_no_fat = false;
 	ctx->fat_pairs = nullptr; ctx->fat_pair_capacity = 0; ctx->fat_box = nullptr; ctx->fat_collider_capacity = 0; ctx->fat_nbox = ctx->fat_nsph = 0xffffffffu;
 	ctx->grid_sbox = nullptr; ctx->grid_skeys = nullptr; ctx->grid_cstart = nullptr; ctx->grid_counts = nullptr; ctx->grid_large = nullptr; ctx->grid_cells = 0; ctx->grid_collider_capacity = 0;
 	ctx->fat_gen = nullptr; ctx->fat_esc_mark = nullptr; ctx->fat_esc_list = nullptr; ctx->fat_moved_list = nullptr;
-	ctx->env_blk_rows_global = getenv("NH_BLK_ROWS_GLOBAL") != nullptr;
-	ctx->env_blk_global_colours = getenv("NH_BLK_GLOBAL_COLOURS") != nullptr; ctx->last_general_contacts = 0;
-	ctx->env_no_incremental = getenv("NH_NO_INCREMENTAL") != nullptr;     // NH_NO_INCREMENTAL=1: a collider that leaves its inflated box forces a rebuild of the kept pair list (A/B, tests)
-	ctx->env_colour_check_seeds = getenv("NH_COLOUR_CHECK_SEEDS") != nullptr;      // colours seeded from the cache go through a settle round instead of being final at once (A/B, tests)
-	ctx->env_no_resident = getenv("NH_NO_RESIDENT") != nullptr;      // NH_NO_RESIDENT=1: small general sets also take the one-launch-per-level path (A/B, tests)
-	ctx->os_resident = 0; ctx->os_plain_launch = getenv("NH_COOPERATIVE") == nullptr;      // NH_COOPERATIVE=1: the one-kernel radix passes go out as cooperative launches (nh_util.hip)
-	// spatially blocked solver (nh_blocks.h).  NH_NO_BLOCKS=1: large general sets take the per-colour global launches (A/B, tests); NH_BLK_MIN: general
-	// contacts from which the blocked form is used; NH_BLK_TARGET: bodies per average block (tests use small values to get many blocks out of a
-	// small world); NH_BLK_CHECK=1: verify the block tables on the device every step
+	ctx->env_blk_rows_global = false;
+	ctx->env_blk_global_colours = false; ctx->last_general_contacts = 0;
+	ctx->env_no_incremental = false;
+	ctx->env_colour_check_seeds = false;
+	ctx->env_no_resident = false;
+	ctx->os_resident = 0; ctx->os_plain_launch = true;
 	memset(&ctx->blk, 0, sizeof(ctx->blk));
 	ctx->blk.scale = 1.0f;
-	ctx->blk.disabled = getenv("NH_NO_BLOCKS") != nullptr;
-	ctx->blk.check = getenv("NH_BLK_CHECK") != nullptr;
-	if (getenv("NH_BLK_PROFILE")) hipMalloc((void**)&ctx->blk.prof, sizeof(unsigned long long) * 4u * 8u * NH_BLK_MAX_BLOCKS);
-	ctx->blk.min_contacts = getenv("NH_BLK_MIN") ? (uint32_t)atoi(getenv("NH_BLK_MIN")) : 200000u;
-	ctx->blk.target = getenv("NH_BLK_TARGET") ? (uint32_t)atoi(getenv("NH_BLK_TARGET")) : 900u;
-	if (ctx->blk.target < 8u) ctx->blk.target = 8u;
+	ctx->blk.disabled = false; ctx->blk.check = false;
+	ctx->blk.min_contacts = 200000u;
+	ctx->blk.target = 900u;
 	ctx->raw_data = nullptr; ctx->raw_feature = nullptr; ctx->raw_slots = 0; ctx->rec = nullptr; ctx->lay_rank = nullptr; ctx->cnt_sorted = nullptr; ctx->start_sorted = nullptr; ctx->dense_slot = nullptr;
 	ctx->sc_imp = nullptr; ctx->sc_feat = nullptr; ctx->sc_count = nullptr; ctx->exp_cnt = nullptr; ctx->exp_start = nullptr; ctx->exp_scan_tmp = nullptr; ctx->lay_capacity = 0; ctx->lay_contact_capacity = 0;
 	ctx->lay_class = nullptr; ctx->lay_simple = nullptr; ctx->body_rec = nullptr; ctx->body_pos = nullptr; ctx->lay_body_capacity = 0;
 	memset(&ctx->still, 0, sizeof(ctx->still));
-	ctx->still.disabled = getenv("NH_NO_STILL") != nullptr;      // NH_NO_STILL=1: no step is launched speculatively as a still step (A/B, tests)
 	ctx->d_state = nullptr;
 	ctx->h_state = nullptr;
 	if (hipMalloc((void**)&ctx->d_state, sizeof(nh_DevState)) != hipSuccess) { delete ctx; return NH_ERR_HIP; }
@@ -116,6 +104,7 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	if (ctx->sort_splitters) hipFree(ctx->sort_splitters);
 	if (ctx->sort_counts) hipFree(ctx->sort_counts);
 	if (ctx->sort_starts) hipFree(ctx->sort_starts);
+	for (int k = 0; k < 2; ++k) { if (ctx->still.h_ring[k]) hipHostFree(ctx->still.h_ring[k]); if (ctx->still.ev_ring[k]) hipEventDestroy(ctx->still.ev_ring[k]); }
 	{
 		void* bufs[] = { ctx->raw_data, ctx->raw_feature, ctx->rec, ctx->lay_rank, ctx->cnt_sorted, ctx->start_sorted, ctx->dense_slot, ctx->sc_imp, ctx->sc_feat, ctx->sc_count, ctx->exp_cnt, ctx->exp_start,
 		                 ctx->exp_scan_tmp, ctx->lay_class, ctx->lay_simple, ctx->body_rec, ctx->body_pos };
@@ -137,6 +126,43 @@ extern "C" int nh_set_flags(nh_context* ctx, uint32_t flags) {
 	ctx->flags = (flags & NH_FLAG_FUSED_STEP) ? (flags | NH_FLAG_SINGLE_APPLY) : flags;
 	return NH_OK;
 }
+// Diagnostic switches (include/nudge_hip.h: nh_set_option).  None is needed in production: each selects an older, slower or more talkative path for A/B runs and
+// tests.  Call right after nh_create (a switch changed between two steps takes effect at the next nh_collide; buffers already sized are kept).
+extern "C" int nh_set_option(nh_context* ctx, const char* name, int value) {
+	if (!ctx || !name) return NH_ERR_INVALID;
+	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	const std::string n(name);
+	const bool on = value != 0;
+	if (n == "no_still") ctx->still.disabled = on;                        // no step is launched speculatively as a still step (note 9)
+	else if (n == "sort_classic") ctx->env_sort_classic = on;             // three-kernel radix passes
+	else if (n == "sort_radix") ctx->env_sort_radix = on;                 // radix passes every step (no seeded bucket sort)
+	else if (n == "no_sort_reuse") ctx->env_no_sort_reuse = on;           // the tag sort of the contact records runs every step even when nothing has changed
+	else if (n == "bucket_tile") ctx->sort_tile = (uint32_t)value;
+	else if (n == "bucket_target") ctx->sort_target = (uint32_t)value;
+	else if (n == "colour_jp") ctx->env_colour_jp = on;                   // Jones-Plassmann colouring rounds
+	else if (n == "colour_check_seeds") ctx->env_colour_check_seeds = on; // colours seeded from the cache go through a settle round instead of being final at once
+	else if (n == "solver_waves") ctx->env_solver_waves = value;          // wavefronts per workgroup of the fused solver (1, 2, 4)
+	else if (n == "fp_sub") ctx->env_fp_sub = value;                      // lanes per collider in the pair search (1, 2, 4, 16; 0 = by world size)
+	else if (n == "no_kept_pairs") ctx->env_no_fat = on;                  // the broadphase regroups and searches every step instead of re-using its kept pair list
+	else if (n == "no_incremental") ctx->env_no_incremental = on;         // a collider that leaves its inflated box forces a rebuild of the kept pair list
+	else if (n == "no_resident") ctx->env_no_resident = on;               // small general sets also take the one-launch-per-level path
+	else if (n == "cooperative") ctx->os_plain_launch = !on;              // the one-kernel radix passes go out as cooperative launches (nh_util.hip)
+	else if (n == "no_blocks") ctx->blk.disabled = on;                    // large general sets take the per-colour global launches instead of the blocked solver
+	else if (n == "blk_check") ctx->blk.check = on;                       // verify the block tables on the device every step
+	else if (n == "blk_min") ctx->blk.min_contacts = (uint32_t)value;     // general contacts from which the blocked form is used
+	else if (n == "blk_target") ctx->blk.target = value < 8 ? 8u : (uint32_t)value;      // bodies per average block
+	else if (n == "blk_rows_global") ctx->env_blk_rows_global = on;       // rows of block-owned contacts by k_rows_general
+	else if (n == "blk_global_colours") ctx->env_blk_global_colours = on; // the blocked solver takes the world-wide colouring
+	else if (n == "blk_profile") {                                         // wall-clock readings of the sweep workgroups, printed now and then
+		if (on && !ctx->blk.prof) NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->blk.prof, sizeof(unsigned long long) * 4u * 8u * NH_BLK_MAX_BLOCKS));
+	}
+#if defined(NH_MEASURE)
+	else if (n == "measure_skip_chains") ctx->env_measure_skip = on;      // MEASUREMENT BUILDS ONLY (-DNH_MEASURE): wrong as soon as anything moves
+#endif
+	else return NH_ERR_INVALID;
+	return NH_OK;
+}
+
 extern "C" int nh_set_tag_bits(nh_context* ctx, uint32_t bits) { if (!ctx || bits < 1 || bits > 32) return NH_ERR_INVALID; ctx->tag_bits = bits; return NH_OK; }
 
 extern "C" int nh_bodies_changed(nh_context* ctx) {

@@ -71,8 +71,11 @@ struct nh_DevState {
 	uint32_t sort_reuses;                 // steps since nh_create whose record sort was skipped because last step's tag order still held
 	uint32_t fat_inserts;                 // colliders re-inserted into the kept pair list since nh_create (they left their inflated box; no rebuild)
 	// "still" steps (nh_collide.hip, "9. still steps"): a step the host launched speculatively as a world whose contact layout is last step's
-	uint32_t still_fail[2];               // by step parity: this still step met something that is NOT as it was (a collider left its box, a record's key / contact count /
-	                                      // features changed, a body is asleep, body 0 not inert): every kernel after that leaves, the host replays the step in full
+	uint32_t still_failed_seq;            // the latest still step (its nh_collide's sequence number) that met something that is NOT as it was -- a collider left its box, a body is
+	                                      // asleep, a collider pair changed its key or has more than four contacts or a partner the solver lane does not know, body 0 not inert:
+	                                      // the solver of that step, and of every still step launched behind it before the host has looked, leaves without touching anything;
+	                                      // the host replays from that step in full.  Only ever raised (atomicMax): no clearing, no window in which a verdict can be lost
+	uint32_t still_pad;
 	uint32_t lay_valid;                   // the kept layout (per record: first contact | count, feature words; per body: class + contact list record) describes the contact
 	                                      // list the last FULL step laid out, and that step met the conditions a still step relies on (k_gather_contacts)
 	uint32_t has_unstable;                // some body with contacts is outside the class a still step's solver owns (one collider pair, with the static world, <= 4 contacts): k_adj_simple
@@ -127,7 +130,8 @@ struct nh_DevState {
 struct nh_TimerSlot { const char* name; hipEvent_t a, b; };
 
 // what the fused one-body solver does besides solving (NH_FLAG_FUSED_STEP): bits 1 = gravity / damping on load, 2 = advance on store
-struct nh_FusedStep { float gx_dt, gy_dt, gz_dt, damping, time_step; uint32_t bits; uint8_t* idle; uint32_t parity; };      // (parity: of the step, for a still step's verdict)
+struct nh_FusedStep { float gx_dt, gy_dt, gz_dt, damping, time_step; uint32_t bits; uint8_t* idle; uint32_t seq, guard_seq; };      // (still steps: this step's sequence number; the
+                                                                                                                                    // oldest still step whose verdict the host has not seen)
 
 // library-owned buffers of the spatially blocked solver (nh_blocks.h), grown on demand
 struct nh_BlkBuffers {
@@ -170,6 +174,12 @@ struct nh_StillStep {
 	bool slots_current;             // the slot cache (sc_*) holds the impulses of the last step (imported at the end of a full step that allows a still one, then kept by the solver)
 	bool cache_stale, contacts_stale;   // still steps have run since the caller's cache arrays / dense contact arrays were last written
 	nh_ContactCache cache;          // the caller's cache arrays (as given to the last nh_write_cached_impulses)
+	// nh_step drives the sample's loop itself, so it can look at a still step's verdict ONE STEP LATE: the host never waits for the GPU inside the loop (the copy of the
+	// counters it looks at has long landed), and the GPU never waits for the host.  A still step that failed did nothing, nor did the one launched behind it (their
+	// solvers compare st->still_failed_seq with `guard`): nh_step runs both again, the first in full.
+	bool pipelined;                 // inside nh_step
+	struct { bool pending; uint32_t seq, parity; int slot; uint64_t collide_mark; } verdict;      // the still step whose counters the host has not looked at yet
+	nh_DevState* h_ring[2]; hipEvent_t ev_ring[2];      // pinned landing places of the counter copies, and when they have landed
 	nh_ContactConstraintData* setup_d;      // its nh_setup_contact_constraints has run (without the adjacency kernel the replay then owes)
 	// the arguments of its nh_collide, for the replay; and the arrays the kept layout belongs to (another world in the same context: not still)
 	nh_ActiveBodies* active_out; nh_ContactData* contacts_out; nh_BodyData bodies; nh_ColliderData colliders; nh_BodyConnections connections; bool has_connections; nh_Arena temporary;
@@ -292,6 +302,8 @@ int nh_still_abandon(nh_context* ctx);
 // the sample's call order calls it through nh_flush_pending: nh_read_counts, nh_synchronize, ...)
 int nh_still_sync_outputs(nh_context* ctx);
 int nh_still_export_cache(nh_context* ctx);
+int nh_still_verdict_now(nh_context* ctx);            // nh_step: the pending verdict of the last still step, waited for: 0 = it happened, 1 = it did not
+#define NH_INTERNAL_STILL_FAILED (-1000)      // (never leaves the library) first_apply -> nh_step: the still step before this one failed, run both again
 #define NH_BODY_REC_NONE 0xFFFFFFFFu
 #define NH_BODY_REC_IS_A 0x80000000u
 struct nh_Record { uint32_t body_a, body_b, overflow, count; };          // one per collider pair that reached the narrowphase (nh_collide.hip)

@@ -173,11 +173,13 @@ __global__ __launch_bounds__(256) void k_zero_u32(uint32_t* __restrict__ p, uint
 
 // Contacts of one collider pair are contiguous in tag order: the first lane of each run does the pair's bookkeeping
 // (one atomic per pair and body instead of one per contact).
-__device__ __forceinline__ uint32_t run_length(const uint64_t* __restrict__ tags, uint32_t i, uint32_t n) {
-	if (i > 0 && tags[i - 1] == tags[i]) return 0;           // not the head of its run
+// (a run = equal tags AND equal bodies: contacts appended by the caller may share a tag between different body pairs, nh_append_contacts)
+__device__ __forceinline__ uint32_t run_length(const uint64_t* __restrict__ tags, const nh_BodyPair* __restrict__ bodies, uint32_t i, uint32_t n) {
+	const nh_BodyPair p = bodies[i];
+	if (i > 0 && tags[i - 1] == tags[i] && bodies[i - 1].a == p.a && bodies[i - 1].b == p.b) return 0;           // not the head of its run
 	uint64_t t = tags[i];
 	uint32_t len = 1;
-	while (i + len < n && tags[i + len] == t) ++len;
+	while (i + len < n && tags[i + len] == t && bodies[i + len].a == p.a && bodies[i + len].b == p.b) ++len;
 	return len;
 }
 
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256) void k_adj_fill(const nh_DevState* __restrict_
 	if (!st->has_pending) return;
 	uint32_t n = st->contacts;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		uint32_t len = run_length(tags, i, n);
+		uint32_t len = run_length(tags, bodies, i, n);
 		if (!len) continue;
 		nh_BodyPair p = bodies[i];
 		const uint32_t ca = p.a ? body_class[p.a] : NH_CLS_NONE, cb = p.b ? body_class[p.b] : NH_CLS_NONE;      // (general bodies settled by k_adj_simple need their lists too)
@@ -886,8 +888,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		const nh_BodyMomentum m0 = momentum[0];
 		const nh_BodyProperties p0 = props[0];
 		const bool inert = nh_is_inert(m0.velocity, m0.angular_velocity, p0.inertia_inverse, p0.mass_inverse);
-		if (!inert && blockIdx.x == 0 && threadIdx.x == 0) const_cast<nh_DevState*>(cv.st)->still_fail[fs.parity] = 1u;
-		if (!inert || cv.st->still_fail[fs.parity]) return;
+		if (!inert && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&const_cast<nh_DevState*>(cv.st)->still_failed_seq, fs.seq);
+		if (!inert || cv.st->still_failed_seq >= fs.guard_seq) return;
 		inert_word = 1u;
 	}
 	__shared__ nh_ob_slot s_slot[NW][64 * M];
@@ -2593,19 +2595,37 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 			nh_StillView sv = { ctx->body_rec, ctx->body_pos, ctx->cnt_sorted, ctx->start_sorted, ctx->raw_feature, ctx->sc_feat, ctx->sc_count, ctx->lay_capacity };
 			nh_FusedStep fs = nh_FusedStep();
 			fs.gx_dt = ctx->grav.gx_dt; fs.gy_dt = ctx->grav.gy_dt; fs.gz_dt = ctx->grav.gz_dt; fs.damping = ctx->grav.damping; fs.time_step = ctx->grav.time_step;
-			fs.bits = 3u; fs.idle = bodies->idle_counters; fs.parity = ctx->step_parity;
+			fs.bits = 3u; fs.idle = bodies->idle_counters; fs.seq = ctx->collide_seq;
+			fs.guard_seq = ss.verdict.pending ? ss.verdict.seq : ctx->collide_seq;          // (a solver behind an unconfirmed still step leaves when THAT one failed)
 #define NH_SOLVE_STILL(NWAVES) NH_LAUNCH(ctx, "solve_still", (k_solve_one_body<4, true, true, NWAVES, true>), (B + 64u * NWAVES - 1u) / (64u * NWAVES), 64 * NWAVES, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum, \
 		          (float4*)d->states, iterations, ctx->raw_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fs, sv)
 			if (ctx->env_solver_waves == 4) NH_SOLVE_STILL(4); else if (ctx->env_solver_waves == 2) NH_SOLVE_STILL(2); else NH_SOLVE_STILL(1);
-			// the step's one round trip: did every check hold?
-			NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, NH_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-			NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-			if (ctx->timing) nh_timer_collect(ctx);
-			confirmed = ctx->h_state->still_fail[ctx->step_parity] == 0u && ctx->h_state->error == 0u;
+			if (ss.pipelined && ss.h_ring[0]) {
+				// nh_step: first the verdict of the still step BEFORE this one (its counters landed long ago) ...
+				if (ss.verdict.pending) {
+					NH_HIP_CHECK(ctx, hipEventSynchronize(ss.ev_ring[ss.verdict.slot]));
+					const nh_DevState* h = ss.h_ring[ss.verdict.slot];
+					if (h->still_failed_seq >= ss.verdict.seq || h->error) return NH_INTERNAL_STILL_FAILED;       // (nh_step cleans up and runs both steps again)
+					memcpy(ctx->h_state, h, NH_COUNTER_WORDS * sizeof(uint32_t));
+					if (!ctx->idle_unknown) { ctx->idle_bound = (int)h->max_idle[ss.verdict.parity]; ctx->idle_bound_mark = ss.verdict.collide_mark; }
+					ss.verdict.pending = false;
+				}
+				// ... then this step's counters on their way, to be looked at by the next step
+				const int slot = (int)(ctx->collide_seq & 1u);
+				NH_HIP_CHECK(ctx, hipMemcpyAsync(ss.h_ring[slot], ctx->d_state, NH_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+				NH_HIP_CHECK(ctx, hipEventRecord(ss.ev_ring[slot], ctx->stream));
+				ss.verdict.pending = true; ss.verdict.seq = ctx->collide_seq; ss.verdict.parity = ctx->step_parity; ss.verdict.slot = slot; ss.verdict.collide_mark = ctx->collide_mark;
+				confirmed = true;          // (until the next step says otherwise)
+			} else {
+				// the step's one round trip: did every check hold?
+				NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, NH_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+				NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+				if (ctx->timing) nh_timer_collect(ctx);
+				confirmed = ctx->h_state->still_failed_seq < ctx->collide_seq && ctx->h_state->error == 0u;
+				if (confirmed) { nh_Counts c; nh_counts_from_mirror(ctx, &c); }              // (the sleep prediction: largest idle counter this step saw)
+			}
 		}
 		if (confirmed) {
-			nh_Counts c;
-			nh_counts_from_mirror(ctx, &c);              // (the sleep prediction: largest idle counter this step saw)
 			ss.resolved = true; ss.setup_d = nullptr;
 			ss.cache_stale = true; ss.contacts_stale = true;        // (the caller's cache and dense contact arrays are last written by an earlier step: nh_still_sync_outputs)
 			d->finish_pending = false; d->has_late = false; d->has_static8 = d->has_staticN = false; d->static_inert = true; d->general_contacts = 0; d->levels = 0;
@@ -2857,4 +2877,83 @@ static int halo_unpack(nh_context* ctx, const nh_BodyData* bodies, uint32_t firs
 	if (count && !same_bodies) { ctx->idle_bound = -1; ctx->idle_unknown = true; }             // idle counters arrive from another world: nothing is known about them until the next nh_collide has looked
 	if (count) NH_LAUNCH(ctx, "halo_unpack", k_halo_unpack, nh_grid_for(count, 256, 1024), 256, bodies->transforms, bodies->momentum, bodies->idle_counters, first_slot, count, (const nh_HaloRecord*)in);
 	return NH_OK;
+}
+
+// ---- nh_step: the sample's sub-step loop (example/main.cpp:274-328) as one entry point ----------------------------------------------------------------------
+// The eight calls, `steps` times.  Besides sparing the caller eight crossings of the ABI per step, the library -- driving the call order itself -- may look at a still
+// step's verdict one step late (nh_internal.h: nh_StillStep::pipelined), so that neither the host nor the GPU ever waits for the other inside the loop; a failed
+// still step and the one launched behind it (both did nothing) are simply run again.  On return every step is confirmed.
+int nh_still_verdict_now(nh_context* ctx) {
+	// the pending verdict, waited for: 0 confirmed, 1 failed
+	nh_StillStep& ss = ctx->still;
+	if (!ss.verdict.pending) return 0;
+	if (hipEventSynchronize(ss.ev_ring[ss.verdict.slot]) != hipSuccess) return 1;
+	const nh_DevState* h = ss.h_ring[ss.verdict.slot];
+	ss.verdict.pending = false;
+	if (h->still_failed_seq >= ss.verdict.seq || h->error) return 1;
+	memcpy(ctx->h_state, h, NH_COUNTER_WORDS * sizeof(uint32_t));
+	if (!ctx->idle_unknown) { ctx->idle_bound = (int)h->max_idle[ss.verdict.parity]; ctx->idle_bound_mark = ss.verdict.collide_mark; }
+	return 0;
+}
+
+// after a failed still step: nothing of it (or of the step launched behind it) has happened; the next nh_collide is a full one
+static int still_forget_failed(nh_context* ctx, bool advanced, uint32_t voided) {
+	nh_StillStep& ss = ctx->still;
+	ss.verdict.pending = false;
+	ss.active = false; ss.resolved = false; ss.setup_d = nullptr; ss.ok_next = false;
+	ss.failed += voided;                               // (still steps launched that did not happen: the failed one, and the one launched behind it if it got that far)
+	ctx->pending = nullptr;
+	ctx->grav.pending = false; ctx->grav.rest_pending = false; ctx->adv.done = false;
+	ctx->after_collide = false; ctx->gravity_may_overlap = false;
+	if (advanced && ctx->advance_count) ctx->advance_count--;          // (the failed step's nh_advance was counted: the sleep prediction counts real ones)
+	return nh_still_export_cache(ctx);                                 // (the slot cache holds the last step that DID happen: the full solver reads the caller's arrays)
+}
+
+extern "C" int nh_step(nh_context* ctx, const nh_StepArgs* a, uint32_t steps) {
+	if (!ctx || !a || !a->active_bodies || !a->contacts || !a->bodies || !a->colliders || !a->contact_cache) return NH_ERR_INVALID;
+	NH_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+	nh_StillStep& ss = ctx->still;
+	if (!ss.h_ring[0]) {
+		for (int k = 0; k < 2; ++k) {
+			if (hipHostMalloc((void**)&ss.h_ring[k], sizeof(nh_DevState), 0) != hipSuccess || hipEventCreateWithFlags(&ss.ev_ring[k], hipEventDisableTiming) != hipSuccess) { ss.h_ring[0] = nullptr; break; }
+			memset(ss.h_ring[k], 0, sizeof(nh_DevState));
+		}
+	}
+	ss.pipelined = ss.h_ring[0] != nullptr && (ctx->flags & NH_FLAG_FUSED_STEP) && !(ctx->flags & (NH_FLAG_SYNC_COUNTS | NH_FLAG_EXACT_ORDER)) && !ss.disabled && !ctx->timing;
+	ss.verdict.pending = false;
+	int result = NH_OK;
+	uint32_t i = 0;
+	while (i < steps || ss.verdict.pending) {
+		if (i >= steps) {
+			// the last step's verdict, waited for; a failure sends the loop back one step
+			if (nh_still_verdict_now(ctx) == 0) break;
+			{ int rc = still_forget_failed(ctx, true, 1u); if (rc) { result = rc; break; } }
+			i -= 1;
+			continue;
+		}
+		int rc;
+		nh_Arena temporary = a->arena;
+		nh_ContactImpulseData* imp = nullptr;
+		nh_ContactConstraintData* con = nullptr;
+		if ((rc = nh_collide(ctx, a->active_bodies, a->contacts, a->bodies, a->colliders, a->body_connections, temporary)) ||
+		    (rc = nh_apply_gravity_damping(ctx, a->active_bodies, a->bodies, a->time_step, a->gravity, a->damping_rate)) ||
+		    (rc = nh_read_cached_impulses(ctx, a->contact_cache, a->contacts, &temporary, &imp)) ||
+		    (rc = nh_setup_contact_constraints(ctx, a->active_bodies, a->contacts, a->bodies, imp, &temporary, &con)) ||
+		    (rc = nh_apply_impulses(ctx, con, a->bodies, a->iterations))) {
+			if (rc == NH_INTERNAL_STILL_FAILED && i > 0) {
+				// the still step before this one failed: neither it nor this one has happened
+				{ int rc2 = still_forget_failed(ctx, true, ctx->still.active ? 2u : 1u); if (rc2) { result = rc2; break; } }
+				i -= 1;
+				continue;
+			}
+			result = rc == NH_INTERNAL_STILL_FAILED ? NH_ERR_INVALID : rc;
+			break;
+		}
+		if ((rc = nh_update_cached_impulses(ctx, con, imp)) || (rc = nh_write_cached_impulses(ctx, a->contact_cache, a->contacts, imp)) ||
+		    (rc = nh_advance(ctx, a->active_bodies, a->bodies, a->time_step))) { result = rc; break; }
+		++i;
+	}
+	ss.pipelined = false;
+	if (result && ss.verdict.pending) { hipEventSynchronize(ss.ev_ring[ss.verdict.slot]); ss.verdict.pending = false; }
+	return result;
 }

@@ -146,7 +146,8 @@ static int sort_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* vals_b
 #define OS_MAX_PASSES 8
 #define OS_READY 0x80000000u
 #define OS_VALUE_MASK 0x7FFFFFFFu
-#define OS_PASS_WORDS ((OS_MAX_GRID + OS_MAX_GRID / OS_GROUP) * 256)
+#define OS_PASS_WORDS ((OS_MAX_GRID + OS_MAX_GRID / OS_GROUP + 2) * 256)      // ... | digit histogram of the whole input [256] | ticket counter (+ padding) [256]
+#define OS_HIST_OFFSET ((OS_MAX_GRID / OS_GROUP) * 256)                      // (from the group sums)
 
 // a pass descriptor: digit = ((key >> s0) & (2^b0 - 1)) | ((key >> s1) << b0) & 255 -- s0 | b0 << 8 | s1 << 16.  b0 = 8 is the plain
 // byte at s0; b0 < 8 glues the top bits of one key field to the low bits of the next (nh_onesweep_u64_u32_two_fields)
@@ -205,6 +206,26 @@ __device__ __forceinline__ void os_rank_tile(const K (&key)[OS_KPT], uint32_t ti
 	}
 }
 
+// Digit histograms of the whole input for every pass of a sort, in one read of the keys (a pass permutes the keys, its histogram does not care).  With the totals
+// known up front a pass only ever waits for workgroups that STARTED BEFORE it (its chunk index is a ticket drawn at start, below): no workgroup depends on one that may
+// not be resident yet, so the launch needs no co-residency guarantee -- neither an occupancy bound nor a cooperative launch -- to be free of deadlock.
+template<typename K>
+__global__ __launch_bounds__(256) void os_hist(const K* __restrict__ keys, const uint32_t* __restrict__ d_n, uint32_t* __restrict__ scratch, os_shifts sh) {
+	__shared__ uint32_t h[OS_MAX_PASSES][256];
+	for (int p = 0; p < sh.n; ++p) h[p][threadIdx.x] = 0;
+	__syncthreads();
+	const uint32_t n = *d_n;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const K key = keys[i];
+		for (int p = 0; p < sh.n; ++p) atomicAdd(&h[p][os_digit<K>(key, sh.s[p])], 1u);
+	}
+	__syncthreads();
+	for (int p = 0; p < sh.n; ++p) {
+		const uint32_t c = h[p][threadIdx.x];
+		if (c) atomicAdd(scratch + (size_t)p * OS_PASS_WORDS + (size_t)OS_MAX_GRID * 256 + OS_HIST_OFFSET + threadIdx.x, c);
+	}
+}
+
 template<typename K, typename V, bool HAS_V>
 __global__ __launch_bounds__(256) void os_pass(const K* __restrict__ keys, K* __restrict__ keys_out, const V* __restrict__ vals, V* __restrict__ vals_out,
                                                const uint32_t* __restrict__ d_n, uint32_t* __restrict__ counts, uint32_t* __restrict__ group_sum, int shift) {
@@ -216,7 +237,12 @@ __global__ __launch_bounds__(256) void os_pass(const K* __restrict__ keys, K* __
 	const uint32_t ntiles = (n + OS_TILE - 1) / OS_TILE;
 	const uint32_t m = (ntiles + gridDim.x - 1) / gridDim.x;               // tiles per workgroup (1 up to 2 M keys)
 	const uint32_t nwg = m ? (ntiles + m - 1) / m : 0;                       // workgroups that own a chunk
-	const uint32_t w = blockIdx.x;
+	// the chunk a workgroup owns is a TICKET drawn when it starts, not its block index: whoever holds a lower ticket is already running (or done), whatever order the
+	// hardware dispatches blocks in
+	__shared__ uint32_t s_ticket;
+	if (threadIdx.x == 0) s_ticket = atomicAdd(group_sum + OS_HIST_OFFSET + 256, 1u);
+	__syncthreads();
+	const uint32_t w = s_ticket;
 	if (w >= nwg) return;
 	const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t first_tile = w * m, last_tile = min(first_tile + m, ntiles);
@@ -253,7 +279,8 @@ __global__ __launch_bounds__(256) void os_pass(const K* __restrict__ keys, K* __
 		if ((w % OS_GROUP) == OS_GROUP - 1 || w == nwg - 1)
 			__hip_atomic_store(group_sum + (size_t)group * 256 + d, OS_READY | (in_group + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		const uint32_t before_groups = os_sum_published(group_sum + d, group, 256);
-		const uint32_t total = before_groups + os_sum_published(group_sum + (size_t)group * 256 + d, ngroups - group, 256);
+		(void)ngroups;
+		const uint32_t total = group_sum[OS_HIST_OFFSET + d];          // (os_hist: the whole input's count of this digit -- nobody waits for a LATER workgroup)
 		// digit base: exclusive scan of the 256 digit totals
 		uint32_t x = total;
 		for (int k = 1; k < 64; k <<= 1) { uint32_t y = __shfl_up(x, k); if ((int)lane >= k) x += y; }
@@ -335,7 +362,10 @@ static int onesweep_impl(nh_context* ctx, K* keys_a, K* keys_b, V* vals_a, V* va
 	hipError_t e = hipMemsetAsync(scratch, 0, sizeof(uint32_t) * (size_t)sh.n * OS_PASS_WORDS, ctx->stream);
 	if (ctx->timing) nh_timer_end(ctx);
 	if (e != hipSuccess) ctx->last_hip_error = (int)e;
-	// The workgroups of a pass wait for each other (earlier counts, group sums): all of them must get to run while the others spin.  The launch is
+	// digit totals of every pass, up front (os_hist): a pass then only waits for workgroups holding LOWER tickets, which are running or done -- no deadlock whatever
+	// else shares the device; the occupancy bound below is about speed (spinning workgroups that crowd out the ones they wait for), no longer about correctness
+	NH_LAUNCH(ctx, "radix_hist", (os_hist<K>), (uint32_t)(cap_tiles < 512 ? cap_tiles : 512), 256, (const K*)kin, d_count, scratch, sh);
+	// (history) The workgroups of a pass used to wait for each other in both directions (earlier counts, group sums of ALL groups): all of them had to be resident.  The launch is
 	// bounded by 3/4 of what the occupancy query says is resident at once, and nothing this library runs beside it (side stream) ever waits for it, so
 	// workgroups that find the compute units busy with somebody else's kernels are merely late.  NH_COOPERATIVE=1 turns the bound into the runtime's
 	// promise (hipLaunchCooperativeKernel; a grid it finds too large is halved -- any grid sorts correctly).  It is not the default because of what it

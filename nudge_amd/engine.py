@@ -29,10 +29,10 @@ NH_FLAG_FUSED_STEP = 8
 
 EXPORTS = [
     "nh_create", "nh_destroy", "nh_set_flags", "nh_synchronize", "nh_read_counts", "nh_set_cache_count",
-    "nh_set_tag_bits", "nh_set_pair_capacity", "nh_bodies_changed", "nh_error_string", "nh_last_hip_error", "nh_collide", "nh_apply_gravity_damping",
+    "nh_set_tag_bits", "nh_set_pair_capacity", "nh_set_option", "nh_bodies_changed", "nh_error_string", "nh_last_hip_error", "nh_collide", "nh_apply_gravity_damping",
     "nh_read_cached_impulses", "nh_write_cached_impulses", "nh_setup_contact_constraints", "nh_apply_impulses",
     "nh_update_cached_impulses", "nh_advance", "nh_contact_impulses_device", "nh_enable_timing", "nh_set_timing_filter", "nh_kernel_times",
-    "nh_halo_pack", "nh_halo_unpack", "nh_halo_update", "nh_append_contacts",
+    "nh_halo_pack", "nh_halo_unpack", "nh_halo_update", "nh_append_contacts", "nh_step",
     "nh_partition_create", "nh_partition_destroy", "nh_partition_info", "nh_partition_pack_migrants", "nh_partition_unpack_migrants", "nh_partition_pack_ghosts",
     "nh_partition_unpack_ghosts", "nh_partition_pack_step", "nh_partition_unpack_step", "nh_partition_choose_cut", "nh_partition_set_cut",
 ]
@@ -82,6 +82,12 @@ class Counts(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class StepArgs(C.Structure):
+    _fields_ = [("active_bodies", C.POINTER(ActiveBodies)), ("contacts", C.POINTER(ContactData)), ("bodies", C.POINTER(BodyData)), ("colliders", C.POINTER(ColliderData)),
+                ("body_connections", C.POINTER(BodyConnections)), ("contact_cache", C.POINTER(ContactCache)), ("arena", Arena),
+                ("time_step", C.c_float), ("gravity", C.c_float * 3), ("damping_rate", C.c_float), ("iterations", C.c_uint32)]
+
+
 class PartitionConfig(C.Structure):
     _fields_ = [("rank", C.c_uint32), ("ranks", C.c_uint32), ("lo", C.c_double), ("hi", C.c_double), ("n_owned", C.c_uint32), ("n_static_box", C.c_uint32), ("n_static_sph", C.c_uint32),
                 ("body_capacity", C.c_uint32), ("box_capacity", C.c_uint32), ("sphere_capacity", C.c_uint32), ("epoch", C.c_uint32),
@@ -119,6 +125,8 @@ def lib():
         L.nh_set_tag_bits.argtypes = [C.c_void_p, C.c_uint32]
         L.nh_set_pair_capacity.argtypes = [C.c_void_p, C.c_uint32]
         L.nh_bodies_changed.argtypes = [C.c_void_p]
+        L.nh_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        L.nh_step.argtypes = [C.c_void_p, C.POINTER(StepArgs), C.c_uint32]
         L.nh_synchronize.argtypes = [C.c_void_p]
         L.nh_read_counts.argtypes = [C.c_void_p, C.POINTER(Counts)]
         L.nh_set_cache_count.argtypes = [C.c_void_p, C.c_uint32]
@@ -240,6 +248,15 @@ class World:
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         _check(self.L, self.L.nh_create(C.byref(self.ctx), device, C.c_void_p(stream), flags), "nh_create")
         self.flags = flags
+        # A/B switches for tests and dev scripts: environment variables NH_<NAME>=<int> become nh_set_option(name, value) calls HERE -- the library itself never
+        # reads the environment (include/nudge_hip.h: nh_set_option)
+        for key, val in sorted(os.environ.items()):
+            if key.startswith("NH_") and key not in ("NH_GATHER_32",):
+                try:
+                    num = int(val)
+                except ValueError:
+                    num = 1
+                _check(self.L, self.L.nh_set_option(self.ctx, key[3:].lower().encode(), num), f"nh_set_option({key})")
         if tag_bits is None:
             mt = 1
             for k in ("box_tags", "sphere_tags"):
@@ -315,6 +332,15 @@ class World:
         _check(self.L, self.L.nh_advance(self.ctx, C.byref(self.active), C.byref(self.bodies), dt), "advance")
 
     def step(self, steps=1, iterations=None):
+        """`steps` sub-steps of the sample's loop (example/main.cpp:274-328).  Worlds that do not ask for host-visible counts go through nh_step -- the eight calls made
+        by the library itself, one crossing of the ABI for all the steps; the others (NH_FLAG_SYNC_COUNTS: `sum_contacts` is kept per step) make the eight calls here."""
+        if steps > 0 and not (self.flags & NH_FLAG_SYNC_COUNTS) and not getattr(self, "eight_calls", False):
+            p = self.params
+            args = StepArgs(C.pointer(self.active), C.pointer(self.contacts), C.pointer(self.bodies), C.pointer(self.colliders), C.pointer(self.connections), C.pointer(self.cache), self.arena,
+                            p["time_step"], (C.c_float * 3)(0.0, p["gravity"], 0.0), p["damping_rate"], p["iterations"] if iterations is None else iterations)
+            _check(self.L, self.L.nh_step(self.ctx, C.byref(args), steps), "nh_step")
+            self.steps_done += steps
+            return
         for _ in range(steps):
             self.collide()
             self.gravity()

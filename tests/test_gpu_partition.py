@@ -129,7 +129,7 @@ def test_per_iteration_ghost_exchange_on_the_gpu():
         for r in range(2):
             local, info = PT.split_scene(scene, [0.3], r, min_extra=2048)
             w = E.World(local, flags=0, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=16 * info["capacity"]["bodies"])
-            parts.append(PT.Partition(w, info, epoch=8, per_iteration=per_iteration))
+            parts.append(PT.Partition(w, info, epoch=8, per_iteration=per_iteration, force_torch=True))      # (this test reads the torch-side ghost lists of both modes)
         cl = PT.LocalCluster(parts)
         cl.step(12)
         worst = 0.0

@@ -151,3 +151,27 @@ def test_still_steps_in_a_world_with_a_pile_never_start():
     c = a.counts()
     assert c["still_steps"] == 0 and c["still_replays"] == 0 and c["general_contacts"] > 0, c
     a.close(); b.close()
+
+
+def test_nh_step_with_late_verdicts_matches_the_eight_calls():
+    """nh_step makes the eight calls itself and looks at a still step's verdict one step LATE (no host / GPU wait inside the loop); a failed still step and the one
+    launched behind it did nothing and are run again.  Against a host that makes the eight calls itself (verdict inside every step) and one that never speculates: the
+    same bits through rest, a kick that fails checks in the middle of a long nh_step call, and the return to rest; step counts add up."""
+    scene = S.grid_tiles(1, side=32, seed=47)
+    a, b, c = _world(scene, True), _world(scene, True), _world(scene, False)
+    b.eight_calls = True
+    for w in (a, b, c):
+        w.step(110)
+    _same_world(a, b, "rest: nh_step vs eight calls"); _same_world(a, c, "rest: nh_step vs no speculation")
+    for w in (a, b, c):
+        m = w.get_bodies()["momentum"]
+        m["velocity"][7::89, 1] = 3.0
+        m["velocity"][3::101, 2] = -1.2
+        w.set_bodies(momentum=m)
+    c0 = a.counts()
+    a.step(260); b.step(260); c.step(260)                      # ONE nh_step call of 260 steps on `a`: hops, landings, slides, rest again
+    _same_world(a, b, "kick: nh_step vs eight calls"); _same_world(a, c, "kick: nh_step vs no speculation")
+    ca, cb = a.counts(), b.counts()
+    assert ca["still_replays"] > c0["still_replays"] and ca["still_steps"] > c0["still_steps"] + 50, (c0, ca)
+    assert ca["error"] == 0 and cb["error"] == 0
+    a.close(); b.close(); c.close()
