@@ -66,7 +66,7 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 			if (red[0]) atomicMax(&st->max_idle[parity], red[0]);
 			if (blockIdx.x == 0) {
 				// what the NEXT step (the other parity) accumulates into: nobody touches it during this one
-				st->max_idle[parity ^ 1u] = 0u;
+				st->max_idle[parity ^ 1u] = 0u; st->delta_count[parity ^ 1u] = 0u; st->delta_overflow[parity ^ 1u] = 0u;
 				for (int k = 0; k < 3; ++k) { st->still_smin[parity ^ 1u][k] = 0xffffffffu; st->still_smax[parity ^ 1u][k] = 0u; }
 			}
 		}
@@ -879,7 +879,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
                                                      // STILL only: the kept list (`pairs`) and its capacity, this step's exact AABBs, the stamps, tag-order positions / counts, the bodies' records
                                                      uint32_t kept_cap = 0u, const float4* __restrict__ aabb_min = nullptr, const float4* __restrict__ aabb_max = nullptr,
                                                      const uint8_t* __restrict__ gen = nullptr, const uint32_t* __restrict__ lay_rank = nullptr, uint32_t* __restrict__ cnt_sorted = nullptr,
-                                                     const uint32_t* __restrict__ body_rec = nullptr, uint32_t seq = 0u) {
+                                                     const uint32_t* __restrict__ body_rec = nullptr, uint32_t seq = 0u, int2* __restrict__ delta = nullptr) {
 	// coarse islands (nudge.cpp:3500-3703): a pair whose bodies belong to a set of sleeping bodies (sets over the BROADPHASE pairs and the
 	// user's connections) never reaches the narrowphase: it becomes a sleeping pair, larger tag in the low half (3697)
 	const bool some_asleep = !STILL && st->any_idle[parity] != 0;
@@ -918,7 +918,17 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		}
 		if (!ok) { atomicAdd(&st->still_diff[!same_key ? 0 : (count > 4 ? 1 : 2)], 1u); changed = true; }          // (statistics; rare)
 		rec[ri].count = (uint32_t)count;
-		cnt_sorted[lay_rank[ri]] = (uint32_t)count;
+		// the record's count in its place of the tag order; a CHANGE is listed (position, difference): the solver lanes shift their first contact by the changes before
+		// them -- a handful per step in a world at rest -- instead of the whole order being scanned again.  Too many for the list: the scan runs (delta_overflow)
+		const uint32_t pos = lay_rank[ri], old = cnt_sorted[pos];
+		if (old != (uint32_t)count) {
+			cnt_sorted[pos] = (uint32_t)count;
+			if (!st->delta_overflow[parity]) {
+				const uint32_t k = atomicAdd(&st->delta_count[parity], 1u);
+				if (k < NH_DELTA_MAX) delta[parity * NH_DELTA_MAX + k] = make_int2((int)pos, count - (int)old);
+				else st->delta_overflow[parity] = 1u;
+			}
+		}
 	};
 	uint32_t rounded = (n + 63u) & ~63u;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
@@ -1264,7 +1274,10 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 #endif
 			}
 		}
-		const uint32_t base = __shfl(start, 0);                  // lane 0 is always a valid record here
+		// (first output slot of the wave's records: the smallest start among those that HAVE contacts -- a record without any may carry a start that still steps
+		// have not kept up to date, nh_internal.h "contact storage by slot")
+		uint32_t base = cnt ? start : 0xFFFFFFFFu;
+		for (int d = 32; d >= 1; d >>= 1) base = min(base, (uint32_t)__shfl_xor((int)base, d));
 		{
 			const uint32_t rel = start - base;
 			if (cnt && sph_rec) {
@@ -1294,7 +1307,7 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 				}
 			}
 		}
-		uint32_t total = (lo < nrec) ? (start - base + cnt) : 0u;
+		uint32_t total = (lo < nrec && cnt) ? (start - base + cnt) : 0u;
 		for (int d = 32; d >= 1; d >>= 1) total = max(total, (uint32_t)__shfl_xor((int)total, d));
 		__builtin_amdgcn_wave_barrier();
 		for (uint32_t k0 = 0; k0 < total; k0 += 64) {           // wave-uniform: every lane takes part in the shuffles
@@ -1349,7 +1362,7 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		st->any_idle[parity ^ 1u] = 0;
 		// (what a still step of the other parity -- the next step, if the host launches it as one -- accumulates into, and the verdict on this step's layout)
-		st->max_idle[parity ^ 1u] = 0u; st->lay_valid = 0u; st->lay_in_place = 0u;
+		st->max_idle[parity ^ 1u] = 0u; st->lay_valid = 0u; st->lay_in_place = 0u; st->delta_count[parity ^ 1u] = 0u; st->delta_overflow[parity ^ 1u] = 0u;
 		for (int k = 0; k < 3; ++k) { st->still_smin[parity ^ 1u][k] = 0xffffffffu; st->still_smax[parity ^ 1u][k] = 0u; }
 	}
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < NH_DEG_WORDS(nbodies); i += gridDim.x * blockDim.x) deg[i] = 0;      // degrees, pair counters, first contacts (NH_DEG_STRIDE)
@@ -1594,7 +1607,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 	bool lay_fresh = false;
 	if (ctx->lay_capacity != pair_cap || ctx->lay_contact_capacity != cap) {
 		void** bufs[] = { (void**)&ctx->raw_data, (void**)&ctx->raw_feature, (void**)&ctx->rec, (void**)&ctx->lay_rank, (void**)&ctx->cnt_sorted, (void**)&ctx->start_sorted, (void**)&ctx->dense_slot,
-		                  (void**)&ctx->sc_imp, (void**)&ctx->sc_feat, (void**)&ctx->sc_count, (void**)&ctx->exp_cnt, (void**)&ctx->exp_start, (void**)&ctx->exp_scan_tmp };
+		                  (void**)&ctx->sc_imp, (void**)&ctx->sc_feat, (void**)&ctx->sc_count, (void**)&ctx->exp_cnt, (void**)&ctx->exp_start, (void**)&ctx->exp_scan_tmp, (void**)&ctx->still_delta };
 		for (void** b : bufs) { if (*b) NH_HIP_CHECK(ctx, hipFree(*b)); *b = nullptr; }
 		ctx->lay_capacity = 0; ctx->lay_contact_capacity = 0;
 		const size_t slots = (size_t)4 * pair_cap + cap, cache_slots = (size_t)5 * pair_cap + 64u;
@@ -1611,6 +1624,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->exp_cnt, sizeof(uint32_t) * ((size_t)pair_cap + 2u)));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->exp_start, sizeof(uint32_t) * ((size_t)pair_cap + 2u)));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->exp_scan_tmp, sizeof(uint32_t) * (2u * NH_SORT_GRID + 64u)));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->still_delta, sizeof(int2) * 2u * NH_DELTA_MAX));
 		ctx->raw_slots = (uint32_t)slots;
 		ctx->lay_capacity = pair_cap; ctx->lay_contact_capacity = cap; lay_fresh = true;
 	}
@@ -1644,13 +1658,14 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			if (nbox >= 2)
 				NH_LAUNCH(ctx, "narrowphase_still", (k_narrowphase<false, true>), nh_grid_for(pair_cap, 256, 4096), 256, st, ctx->fat_pairs, xf, ctag,
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr,
-				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq);
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta);
 			if (nsph)
 				NH_LAUNCH(ctx, "narrowphase_sph_still", (k_narrowphase<true, true>), nh_grid_for(pair_cap, 256, 8192), 256, st, ctx->fat_pairs, xf, ctag,
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr,
-				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq);
-			// every record's first contact in the dense (tag-ordered) list: the scan of the counts in tag order; the total is this step's contact count
-			nh_scan_u32(ctx, ctx->cnt_sorted, ctx->start_sorted, &st->records, 1, scan_tmp, &st->contacts);
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta);
+			// every record's first contact in the dense (tag-ordered) list = the scan of the counts in tag order: kept from step to step, shifted by the listed changes
+			// (only when more pairs changed their count than the list holds: the two launches leave at once otherwise; the solver keeps the total)
+			nh_scan_u32(ctx, ctx->cnt_sorted, ctx->start_sorted, &st->records, 1, scan_tmp, nullptr, &st->delta_overflow[ctx->step_parity]);
 			ss.active = true; ss.resolved = false; ss.launched++;
 			ctx->gravity_may_overlap = false;
 			ctx->after_collide = true;

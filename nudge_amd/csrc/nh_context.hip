@@ -54,7 +54,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->blk.min_contacts = 200000u;
 	ctx->blk.target = 900u;
 	ctx->raw_data = nullptr; ctx->raw_feature = nullptr; ctx->raw_slots = 0; ctx->rec = nullptr; ctx->lay_rank = nullptr; ctx->cnt_sorted = nullptr; ctx->start_sorted = nullptr; ctx->dense_slot = nullptr;
-	ctx->sc_imp = nullptr; ctx->sc_feat = nullptr; ctx->sc_count = nullptr; ctx->exp_cnt = nullptr; ctx->exp_start = nullptr; ctx->exp_scan_tmp = nullptr; ctx->lay_capacity = 0; ctx->lay_contact_capacity = 0;
+	ctx->sc_imp = nullptr; ctx->sc_feat = nullptr; ctx->sc_count = nullptr; ctx->exp_cnt = nullptr; ctx->exp_start = nullptr; ctx->exp_scan_tmp = nullptr; ctx->still_delta = nullptr; ctx->lay_capacity = 0; ctx->lay_contact_capacity = 0;
 	ctx->lay_class = nullptr; ctx->lay_simple = nullptr; ctx->body_rec = nullptr; ctx->body_pos = nullptr; ctx->lay_body_capacity = 0;
 	memset(&ctx->still, 0, sizeof(ctx->still));
 	ctx->d_state = nullptr;
@@ -107,7 +107,7 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	for (int k = 0; k < 2; ++k) { if (ctx->still.h_ring[k]) hipHostFree(ctx->still.h_ring[k]); if (ctx->still.ev_ring[k]) hipEventDestroy(ctx->still.ev_ring[k]); }
 	{
 		void* bufs[] = { ctx->raw_data, ctx->raw_feature, ctx->rec, ctx->lay_rank, ctx->cnt_sorted, ctx->start_sorted, ctx->dense_slot, ctx->sc_imp, ctx->sc_feat, ctx->sc_count, ctx->exp_cnt, ctx->exp_start,
-		                 ctx->exp_scan_tmp, ctx->lay_class, ctx->lay_simple, ctx->body_rec, ctx->body_pos };
+		                 ctx->exp_scan_tmp, ctx->still_delta, ctx->lay_class, ctx->lay_simple, ctx->body_rec, ctx->body_pos };
 		for (void* b : bufs) if (b) hipFree(b);
 	}
 	{

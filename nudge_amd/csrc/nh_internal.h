@@ -122,6 +122,8 @@ struct nh_DevState {
 	uint32_t stale_hint;          // a body was asleep in a step for which the host had ruled that out (k_collide_begin -> k_active_write -> NH_ERR_STALE_HINT)
 	uint32_t order_conflict;      // exact-order mode: sequence number of the setup call whose closed-form schedule has a lane conflict (nh_solve.hip)
 	uint32_t lay_in_place;        // this (full) step's k_kept_filter wrote the pairs IN PLACE: a record's position is its kept pair's position
+	uint32_t delta_count[2], delta_overflow[2];   // by step parity: collider pairs whose contact count changed in this still step (their tag-order position and the change are listed
+	                                              // in nh_context::still_delta; more than NH_DELTA_MAX of them: the counts are scanned again instead)
 	uint32_t still_smin[2][3], still_smax[2][3];   // by step parity: scene bounds of a still step (k_xform<true>; cleared for the next step by the step before)
 	uint32_t still_top[2];        // by step parity: largest idle counter a still step saw
 	nh_BlkGrid blk;               // spatially blocked solver (nh_blocks.h)
@@ -286,6 +288,7 @@ struct nh_context {
 	uint32_t* dense_slot;                                                    // per contact of the last FULL step's list: the raw slot it came from
 	// the contact cache by slot (still steps): the solved impulse and the feature word of the contact each slot held LAST step, and how many each record had
 	float4* sc_imp; uint32_t* sc_feat; uint32_t* sc_count;
+	int2* still_delta;                                                       // 2 x NH_DELTA_MAX: (tag-order position, change of the contact count) of this still step, by step parity
 	uint32_t* exp_cnt; uint32_t* exp_start; uint32_t* exp_scan_tmp;          // scratch of the export slots -> caller's cache (pair_cap + 2 words each; scan temporaries)
 	uint32_t lay_capacity, lay_contact_capacity;                             // pair capacity / contact capacity the arrays above were sized for
 	// per body (k_adj_simple): class, contact-list record of the full path; the record a body's contacts come from (| NH_BODY_REC_IS_A) and its tag-order position
@@ -304,6 +307,7 @@ int nh_still_sync_outputs(nh_context* ctx);
 int nh_still_export_cache(nh_context* ctx);
 int nh_still_verdict_now(nh_context* ctx);            // nh_step: the pending verdict of the last still step, waited for: 0 = it happened, 1 = it did not
 #define NH_INTERNAL_STILL_FAILED (-1000)      // (never leaves the library) first_apply -> nh_step: the still step before this one failed, run both again
+#define NH_DELTA_MAX 256u
 #define NH_BODY_REC_NONE 0xFFFFFFFFu
 #define NH_BODY_REC_IS_A 0x80000000u
 struct nh_Record { uint32_t body_a, body_b, overflow, count; };          // one per collider pair that reached the narrowphase (nh_collide.hip)

@@ -864,7 +864,8 @@ struct nh_ob_slot { float4 c0, c1, w; };      // contact (32 B), cached impulse 
 // nudge.cpp:4206-4339: k_adj_simple's rule), and each contact's warm start (the cached impulse with the same feature word, nudge.cpp:4057-4083 -- a pair's
 // entries can only be the pair's own).  The solved impulses and this step's feature words go back to the slot cache.  EVERY dynamic body is the kernel's: one
 // without contacts gets gravity and its advance here.  If an earlier kernel of the step raised st->still_fail, or body 0 is not inert, the kernel leaves first.
-struct nh_StillView { const uint32_t* body_rec; const uint32_t* body_pos; const uint32_t* cnt_sorted; const uint32_t* start_sorted; const uint32_t* raw_feature; uint32_t* sc_feat; uint32_t* sc_count; uint32_t pair_cap; };
+struct nh_StillView { const uint32_t* body_rec; const uint32_t* body_pos; const uint32_t* cnt_sorted; uint32_t* start_sorted; const uint32_t* raw_feature; uint32_t* sc_feat; uint32_t* sc_count; uint32_t pair_cap;
+                     const int2* delta; uint32_t parity; };
 
 template<int MAXC, bool FUSED, bool CONTIG = false, int NW = 4, bool STILL = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ? 2 : 1, MAXC == 4 ? 2 : 1))) void k_solve_one_body(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
@@ -896,6 +897,24 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 	__shared__ uint32_t s_cid[NW][64 * M];
 	__shared__ uint32_t s_hint[NW][64], s_first[NW][64];
 	__shared__ uint32_t s_wid[STILL ? NW : 1][STILL ? 64 * M : 1];       // STILL: per contact, the slot of the cache entry it warm-starts from
+	__shared__ int2 s_delta[STILL ? NH_DELTA_MAX : 1];                   // STILL: this step's changes of contact counts (tag-order position, difference)
+	uint32_t n_delta = 0;
+	if (STILL) {
+		// The first contact of every record in the dense list is kept from step to step (start_sorted); the records whose count changed this step are listed, and a lane
+		// shifts its record's start by the changes BEFORE it in the tag order.  (More changes than the list holds: the scan has run instead, nothing to shift.)
+		n_delta = cv.st->delta_overflow[sv.parity] ? 0u : min(cv.st->delta_count[sv.parity], NH_DELTA_MAX);
+		for (uint32_t k = threadIdx.x; k < n_delta; k += blockDim.x) s_delta[k] = sv.delta[sv.parity * NH_DELTA_MAX + k];
+		if (blockIdx.x == 0 && threadIdx.x == 0) {
+			// the contact count of the step = the total behind the last record: kept like the starts
+			const uint32_t nrec = cv.st->records;
+			int shift = 0;
+			for (uint32_t k = 0; k < n_delta; ++k) shift += sv.delta[sv.parity * NH_DELTA_MAX + k].y;
+			const uint32_t total = sv.start_sorted[nrec] + (uint32_t)shift;
+			if (shift) sv.start_sorted[nrec] = total;
+			const_cast<nh_DevState*>(cv.st)->contacts = total;
+		}
+		__syncthreads();
+	}
 	const uint32_t wave = threadIdx.x >> 6, lane = nh_lane();
 	nh_ob_slot* slot = s_slot[wave];
 	uint32_t* scid = s_cid[wave];
@@ -934,7 +953,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			const uint32_t n_bb = min(cv.st->pairs, sv.pair_cap);
 			still_base = still_rec < n_bb ? 4u * still_rec : 4u * n_bb + (still_rec - n_bb);       // (a record of a pair with a sphere owns ONE slot, behind the box-box records' four each)
 			uint32_t start = 0, oc = 0;
-			if (still_has) { cnt = min(sv.cnt_sorted[bpos], 4u); start = sv.start_sorted[bpos]; oc = min(sv.sc_count[still_rec], 4u); }
+			if (still_has) {
+				cnt = min(sv.cnt_sorted[bpos], 4u); start = sv.start_sorted[bpos]; oc = min(sv.sc_count[still_rec], 4u);
+				int shift = 0;
+				for (uint32_t k = 0; k < n_delta; ++k) shift += (uint32_t)s_delta[k].x < bpos ? s_delta[k].y : 0;
+				if (shift) { start += (uint32_t)shift; sv.start_sorted[bpos] = start; }
+			}
 			uint32_t nf[M], of[M];
 #pragma unroll
 			for (int k = 0; k < M; ++k) { nf[k] = (uint32_t)k < cnt ? sv.raw_feature[still_base + k] : 0u; of[k] = (uint32_t)k < oc ? sv.sc_feat[still_base + k] : 0u; }
@@ -2592,7 +2616,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 		if (usable) {
 			const uint32_t B = d->body_count;
 			nh_CacheView cv = { nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const nh_CachedContactImpulse*>(ctx->sc_imp), ctx->d_state };
-			nh_StillView sv = { ctx->body_rec, ctx->body_pos, ctx->cnt_sorted, ctx->start_sorted, ctx->raw_feature, ctx->sc_feat, ctx->sc_count, ctx->lay_capacity };
+			nh_StillView sv = { ctx->body_rec, ctx->body_pos, ctx->cnt_sorted, ctx->start_sorted, ctx->raw_feature, ctx->sc_feat, ctx->sc_count, ctx->lay_capacity, ctx->still_delta, ctx->step_parity };
 			nh_FusedStep fs = nh_FusedStep();
 			fs.gx_dt = ctx->grav.gx_dt; fs.gy_dt = ctx->grav.gy_dt; fs.gz_dt = ctx->grav.gz_dt; fs.damping = ctx->grav.damping; fs.time_step = ctx->grav.time_step;
 			fs.bits = 3u; fs.idle = bodies->idle_counters; fs.seq = ctx->collide_seq;
