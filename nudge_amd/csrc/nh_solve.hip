@@ -864,11 +864,14 @@ struct nh_ob_slot { float4 c0, c1, w; };      // contact (32 B), cached impulse 
 // nudge.cpp:4206-4339: k_adj_simple's rule), and each contact's warm start (the cached impulse with the same feature word, nudge.cpp:4057-4083 -- a pair's
 // entries can only be the pair's own).  The solved impulses and this step's feature words go back to the slot cache.  EVERY dynamic body is the kernel's: one
 // without contacts gets gravity and its advance here.  If an earlier kernel of the step raised st->still_fail, or body 0 is not inert, the kernel leaves first.
+#ifndef NH_SOLVER_WPE
+#define NH_SOLVER_WPE 2          // wavefronts per SIMD the four-contact solver is compiled for (A/B: -DNH_SOLVER_WPE=3)
+#endif
 struct nh_StillView { const uint32_t* body_rec; const uint32_t* body_pos; const uint32_t* cnt_sorted; uint32_t* start_sorted; const uint32_t* raw_feature; uint32_t* sc_feat; uint32_t* sc_count; uint32_t pair_cap;
                      const int2* delta; uint32_t parity; };
 
 template<int MAXC, bool FUSED, bool CONTIG = false, int NW = 4, bool STILL = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ? 2 : 1, MAXC == 4 ? 2 : 1))) void k_solve_one_body(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ? NH_SOLVER_WPE : 1, MAXC == 4 ? NH_SOLVER_WPE : 1))) void k_solve_one_body(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
                                                         const nh_BodyPair* __restrict__ bodies, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                         float4* __restrict__ states, uint32_t iterations,
                                                         const nh_Contact* __restrict__ contacts, nh_Transform* xf, nh_CachedContactImpulse* __restrict__ impulses,
