@@ -162,10 +162,16 @@ static void make_rank(Rank& R, const Scene& s, const std::vector<double>& cuts, 
 	std::sort(dyn_box.begin(), dyn_box.end()); std::sort(dyn_sph.begin(), dyn_sph.end());
 	for (auto& e : dyn_box) { nh_Transform t = s.box_xf[e.second]; t.body = e.first; bt.push_back(s.box_tags[e.second]); bd.push_back(s.box_data[e.second]); bx.push_back(t); }
 	for (auto& e : dyn_sph) { nh_Transform t = s.sph_xf[e.second]; t.body = e.first; stg.push_back(s.sph_tags[e.second]); sd.push_back(s.sph_data[e.second]); sx.push_back(t); }
-	if (dyn_box.size() + dyn_sph.size() != n - 1u) { fprintf(stderr, "rank %d: a dynamic body needs exactly one collider\n", rank); exit(2); }
+	{
+		// a dynamic body carries up to NH_PARTITION_MAX_COLLIDERS colliders (compound bodies travel with all of them)
+		std::vector<uint8_t> per_body(n, 0);
+		for (auto& e : dyn_box) per_body[e.first]++;
+		for (auto& e : dyn_sph) per_body[e.first]++;
+		for (uint32_t b = 1; b < n; ++b) if (per_body[b] > NH_PARTITION_MAX_COLLIDERS) { fprintf(stderr, "rank %d: a dynamic body carries at most %d colliders\n", rank, NH_PARTITION_MAX_COLLIDERS); exit(2); }
+	}
 	const uint32_t extra = std::max<uint32_t>(min_extra, (uint32_t)(slack * n));
 	R.body_capacity = n + extra;
-	const uint32_t box_cap = (uint32_t)bt.size() + extra, sph_cap = (uint32_t)stg.size() + extra;
+	const uint32_t box_cap = (uint32_t)bt.size() + NH_PARTITION_MAX_COLLIDERS * extra, sph_cap = (uint32_t)stg.size() + NH_PARTITION_MAX_COLLIDERS * extra;
 	uint32_t max_tag = 1;
 	for (uint32_t t : s.box_tags) max_tag = std::max(max_tag, t);
 	for (uint32_t t : s.sph_tags) max_tag = std::max(max_tag, t);

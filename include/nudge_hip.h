@@ -310,8 +310,10 @@ int nh_step(nh_context* ctx, const nh_StepArgs* args, uint32_t steps);
      every other step:
         nh_partition_pack_step      -> exchange -> nh_partition_unpack_step         (64-byte records of the listed bodies, fixed lengths)
    Reference counterpart: none (the reference is single-threaded); the contact identity that makes this work is the collider TAG
-   (nudge.h:86, 93; nudge.cpp:2074-2087), which travels with a body.  A dynamic body carries exactly one collider. */
-#define NH_PARTITION_FULL_BYTES 136      /* transform 32 | properties 16 | momentum 32 | shape 16 | collider transform 32 | tag 4 | kind 1, idle 1, pad 2 */
+   (nudge.h:86, 93; nudge.cpp:2074-2087), which travels with a body.  A dynamic body carries up to NH_PARTITION_MAX_COLLIDERS colliders (compound bodies); in the
+   collider arrays the colliders of dynamic bodies stand in body-slot order, a body's own adjacent (boxes in the box array, spheres in the sphere array). */
+#define NH_PARTITION_MAX_COLLIDERS 4     /* colliders a dynamic body may carry across ranks (compound bodies, nudge.cpp:3023-3025, 3058-3060): its boxes, then its spheres */
+#define NH_PARTITION_FULL_BYTES 308      /* transform 32 | properties 16 | momentum 32 | 4 x (shape 16 | collider transform 32 | tag 4 | pad 4) | boxes 1, spheres 1, idle 1, pad 1 */
 typedef struct nh_partition nh_partition;
 typedef struct nh_PartitionConfig {
 	uint32_t rank, ranks;
@@ -330,7 +332,7 @@ typedef struct nh_PartitionInfo {
 	double lo, hi;
 	uint64_t migrated_out, migrated_in, refreshes, cut_moves;
 } nh_PartitionInfo;
-/* `bodies` / `colliders`: the rank's arrays as they are at creation (1 + n_owned bodies, static + one collider per dynamic body, Transform.body = body slot). */
+/* `bodies` / `colliders`: the rank's arrays as they are at creation (1 + n_owned bodies; the static colliders, then the dynamic bodies' in slot order, Transform.body = slot). */
 int nh_partition_create(nh_partition** out, nh_context* ctx, const nh_PartitionConfig* config, const nh_BodyData* bodies, const nh_ColliderData* colliders);
 void nh_partition_destroy(nh_partition* p);
 int nh_partition_info(nh_partition* p, nh_PartitionInfo* out);

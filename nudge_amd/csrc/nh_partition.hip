@@ -18,8 +18,11 @@ struct nh_PartDev {
 	uint32_t error;
 };
 
-struct nh_FullRecord { nh_Transform xf; nh_BodyProperties props; nh_BodyMomentum momentum; float shape[4]; nh_Transform cxf; uint32_t tag; uint8_t kind, idle, pad0, pad1; };
-static_assert(sizeof(nh_FullRecord) == NH_PARTITION_FULL_BYTES, "full record layout");
+// what travels with a body: its state and up to NH_PARTITION_MAX_COLLIDERS colliders (boxes first, then spheres), each as shape | local transform | tag
+struct nh_PartCollider { float shape[4]; nh_Transform cxf; uint32_t tag; uint32_t pad; };      // 56 B
+struct nh_FullRecord { nh_Transform xf; nh_BodyProperties props; nh_BodyMomentum momentum; nh_PartCollider col[NH_PARTITION_MAX_COLLIDERS]; uint8_t nbox, nsph, idle, pad; };
+static_assert(sizeof(nh_PartCollider) == 56 && sizeof(nh_FullRecord) == NH_PARTITION_FULL_BYTES, "full record layout");
+#define NP_MAXC NH_PARTITION_MAX_COLLIDERS
 
 struct nh_partition {
 	nh_context* ctx;
@@ -28,8 +31,8 @@ struct nh_partition {
 	uint32_t n_owned, n_bodies, n_boxes, n_spheres;
 	uint32_t ghost_out[2], ghost_in[2];
 	uint64_t migrated_out, migrated_in, refreshes, cut_moves;
-	// body-parallel description of the one collider a dynamic body carries (device, body_capacity entries)
-	float4* shape; nh_Transform* cxf; uint32_t* tag; uint8_t* kind; float* reach;
+	// body-parallel description of the colliders a dynamic body carries (device, body_capacity entries; NP_MAXC collider slots per body: its boxes first, then its spheres)
+	float4* shape; nh_Transform* cxf; uint32_t* tag; uint8_t* nbx; uint8_t* nsp; float* reach;
 	// lists of the owned slots sent to the left / right neighbour every step (written by pack_ghosts)
 	uint32_t* list[2];
 	// scratch: two flag / scan arrays of body_capacity + 1 words, scan temporaries, sort buffers, a staging copy of the body records for the compaction
@@ -41,26 +44,44 @@ struct nh_partition {
 
 #define NP_CHECK(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (ctx)->last_hip_error = (int)e_; return NH_ERR_HIP; } } while (0)
 
+// the body-parallel collider description as the kernels see it: body i's colliders sit at [NP_MAXC i, NP_MAXC i + nbx[i] + nsp[i]): boxes, then spheres
+struct nh_PartCols { float4* shape; nh_Transform* cxf; uint32_t* tag; uint8_t* nbx; uint8_t* nsp; float* reach; };
+
 // ---- kernels ------------------------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float np_reach(const nh_Transform& c, const float4& s, uint32_t kind) {
+__device__ __forceinline__ float np_reach(const nh_Transform& c, const float4& s, bool box) {
 	const float off = sqrtf(c.position[0] * c.position[0] + c.position[1] * c.position[1] + c.position[2] * c.position[2]);
-	const float ext = kind == 0u ? sqrtf(s.x * s.x + s.y * s.y + s.z * s.z) : s.x;
+	const float ext = box ? sqrtf(s.x * s.x + s.y * s.y + s.z * s.z) : s.x;
 	return (off + ext) * 1.0001f;
 }
+__device__ __forceinline__ float np_body_reach(const nh_PartCols& pc, uint32_t b) {
+	const uint32_t nb = pc.nbx[b], ns = pc.nsp[b];
+	float r = 0.0f;
+	for (uint32_t c = 0; c < nb + ns && c < NP_MAXC; ++c) r = fmaxf(r, np_reach(pc.cxf[(size_t)NP_MAXC * b + c], pc.shape[(size_t)NP_MAXC * b + c], c < nb));
+	return r;
+}
 
-// creation: the collider arrays (static ones first, then one per dynamic body with Transform.body = slot) -> the body-parallel description
+// creation: the collider arrays (static ones first, then the dynamic bodies' in body-slot order, a body's colliders adjacent, Transform.body = slot) -> the
+// body-parallel description.  A collider's place among its body's = the run of colliders of that body just before it (boxes: from 0; spheres: behind the boxes).
 __global__ __launch_bounds__(256) void k_part_adopt(uint32_t n_static, uint32_t n, uint32_t which, const uint32_t* __restrict__ tags, const void* __restrict__ data, const nh_Transform* __restrict__ xf,
-                                                    uint32_t body_capacity, float4* __restrict__ shape, nh_Transform* __restrict__ cxf, uint32_t* __restrict__ tag, uint8_t* __restrict__ kind,
-                                                    float* __restrict__ reach, nh_PartDev* dv) {
+                                                    uint32_t body_capacity, nh_PartCols pc, nh_PartDev* dv) {
 	for (uint32_t c = n_static + blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
 		const nh_Transform t = xf[c];
 		const uint32_t b = t.body;
 		if (b == 0u || b >= body_capacity) { dv->error = NH_ERR_INVALID; continue; }
+		uint32_t rank = 0;
+		while (rank < NP_MAXC && c - rank > n_static && xf[c - rank - 1u].body == b) ++rank;
+		const bool last = c + 1u >= n || xf[c + 1u].body != b;
+		const uint32_t at = (which == 0u ? 0u : (uint32_t)pc.nbx[b]) + rank;          // (spheres are adopted by a second launch: the box count is final by then)
+		if (at >= NP_MAXC) { dv->error = NH_ERR_INVALID; continue; }
 		float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		if (which == 0u) { const nh_BoxCollider bc = reinterpret_cast<const nh_BoxCollider*>(data)[c]; s = make_float4(bc.size[0], bc.size[1], bc.size[2], bc.unused); }
 		else s.x = reinterpret_cast<const nh_SphereCollider*>(data)[c].radius;
-		shape[b] = s; cxf[b] = t; tag[b] = tags[c]; kind[b] = (uint8_t)which; reach[b] = np_reach(t, s, which);
+		pc.shape[(size_t)NP_MAXC * b + at] = s; pc.cxf[(size_t)NP_MAXC * b + at] = t; pc.tag[(size_t)NP_MAXC * b + at] = tags[c];
+		if (last) { if (which == 0u) pc.nbx[b] = (uint8_t)(rank + 1u); else pc.nsp[b] = (uint8_t)(rank + 1u); }
 	}
+}
+__global__ __launch_bounds__(256) void k_part_reaches(uint32_t n, nh_PartCols pc) {
+	for (uint32_t b = 1u + blockIdx.x * blockDim.x + threadIdx.x; b < n; b += gridDim.x * blockDim.x) pc.reach[b] = np_body_reach(pc, b);
 }
 
 // refresh phase 1: who leaves (x < lo: to the left; x >= hi: to the right).  flags are scanned in place afterwards
@@ -77,26 +98,32 @@ __global__ __launch_bounds__(256) void k_part_flag_leavers(uint32_t n, const nh_
 	}
 }
 
-__device__ __forceinline__ nh_FullRecord np_full(uint32_t i, const nh_Transform* bt, const nh_BodyProperties* bp, const nh_BodyMomentum* bm, const uint8_t* bi,
-                                                  const float4* shape, const nh_Transform* cxf, const uint32_t* tag, const uint8_t* kind) {
+__device__ __forceinline__ nh_FullRecord np_full(uint32_t i, const nh_Transform* bt, const nh_BodyProperties* bp, const nh_BodyMomentum* bm, const uint8_t* bi, const nh_PartCols& pc) {
 	nh_FullRecord r;
 	r.xf = bt[i]; r.props = bp[i]; r.momentum = bm[i];
-	const float4 s = shape[i];
-	r.shape[0] = s.x; r.shape[1] = s.y; r.shape[2] = s.z; r.shape[3] = s.w;
-	r.cxf = cxf[i]; r.tag = tag[i]; r.kind = kind[i]; r.idle = bi[i]; r.pad0 = 0; r.pad1 = 0;
+	r.nbox = pc.nbx[i]; r.nsph = pc.nsp[i]; r.idle = bi[i]; r.pad = 0;
+	for (uint32_t c = 0; c < NP_MAXC; ++c) {
+		nh_PartCollider k;
+		memset(&k, 0, sizeof(k));
+		if (c < (uint32_t)r.nbox + r.nsph) {
+			const float4 s = pc.shape[(size_t)NP_MAXC * i + c];
+			k.shape[0] = s.x; k.shape[1] = s.y; k.shape[2] = s.z; k.shape[3] = s.w;
+			k.cxf = pc.cxf[(size_t)NP_MAXC * i + c]; k.tag = pc.tag[(size_t)NP_MAXC * i + c];
+		}
+		r.col[c] = k;
+	}
 	return r;
 }
 
 // ordered compaction of the flagged bodies' full records (sl / sr: the exclusive scans of the flags, n + 1 entries); optionally the slot lists too
 __global__ __launch_bounds__(256) void k_part_pack_full(uint32_t n, const uint32_t* __restrict__ sl, const uint32_t* __restrict__ sr, uint32_t capacity,
                                                         const nh_Transform* __restrict__ bt, const nh_BodyProperties* __restrict__ bp, const nh_BodyMomentum* __restrict__ bm, const uint8_t* __restrict__ bi,
-                                                        const float4* __restrict__ shape, const nh_Transform* __restrict__ cxf, const uint32_t* __restrict__ tag, const uint8_t* __restrict__ kind,
-                                                        nh_FullRecord* __restrict__ out_l, nh_FullRecord* __restrict__ out_r, uint32_t* __restrict__ list_l, uint32_t* __restrict__ list_r, nh_PartDev* dv) {
+                                                        nh_PartCols pc, nh_FullRecord* __restrict__ out_l, nh_FullRecord* __restrict__ out_r, uint32_t* __restrict__ list_l, uint32_t* __restrict__ list_r, nh_PartDev* dv) {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const uint32_t pl = sl[i], pr = sr[i];
 		const bool l = sl[i + 1] != pl, r = sr[i + 1] != pr;
 		if (!l && !r) continue;
-		const nh_FullRecord rec = np_full(i, bt, bp, bm, bi, shape, cxf, tag, kind);
+		const nh_FullRecord rec = np_full(i, bt, bp, bm, bi, pc);
 		if (l) { if (pl < capacity && out_l) out_l[pl] = rec; else dv->error = NH_ERR_INVALID; if (list_l) list_l[pl] = i; }
 		if (r) { if (pr < capacity && out_r) out_r[pr] = rec; else dv->error = NH_ERR_INVALID; if (list_r) list_r[pr] = i; }
 	}
@@ -105,25 +132,27 @@ __global__ __launch_bounds__(256) void k_part_pack_full(uint32_t n, const uint32
 // the bodies that stay, in slot order, into the staging buffer (keep position = i - leavers before i); then back
 __global__ __launch_bounds__(256) void k_part_stage_kept(uint32_t n, const uint32_t* __restrict__ sl, const uint32_t* __restrict__ sr,
                                                          const nh_Transform* __restrict__ bt, const nh_BodyProperties* __restrict__ bp, const nh_BodyMomentum* __restrict__ bm, const uint8_t* __restrict__ bi,
-                                                         const float4* __restrict__ shape, const nh_Transform* __restrict__ cxf, const uint32_t* __restrict__ tag, const uint8_t* __restrict__ kind,
-                                                         nh_FullRecord* __restrict__ stage) {
+                                                         nh_PartCols pc, nh_FullRecord* __restrict__ stage) {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const uint32_t pl = sl[i], pr = sr[i];
 		if (sl[i + 1] != pl || sr[i + 1] != pr) continue;
-		stage[i - pl - pr] = np_full(i, bt, bp, bm, bi, shape, cxf, tag, kind);
+		stage[i - pl - pr] = np_full(i, bt, bp, bm, bi, pc);
 	}
 }
 
-// full records -> body slots [at, at + m): the world's arrays and the body-parallel description (reach follows from the collider)
+// full records -> body slots [at, at + m): the world's arrays and the body-parallel description (reach follows from the colliders)
 __global__ __launch_bounds__(256) void k_part_install(uint32_t at, uint32_t m, const nh_FullRecord* __restrict__ in,
-                                                      nh_Transform* __restrict__ bt, nh_BodyProperties* __restrict__ bp, nh_BodyMomentum* __restrict__ bm, uint8_t* __restrict__ bi,
-                                                      float4* __restrict__ shape, nh_Transform* __restrict__ cxf, uint32_t* __restrict__ tag, uint8_t* __restrict__ kind, float* __restrict__ reach) {
+                                                      nh_Transform* __restrict__ bt, nh_BodyProperties* __restrict__ bp, nh_BodyMomentum* __restrict__ bm, uint8_t* __restrict__ bi, nh_PartCols pc) {
 	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < m; k += gridDim.x * blockDim.x) {
 		const nh_FullRecord r = in[k];
 		const uint32_t i = at + k;
 		bt[i] = r.xf; bp[i] = r.props; bm[i] = r.momentum; bi[i] = r.idle;
-		const float4 s = make_float4(r.shape[0], r.shape[1], r.shape[2], r.shape[3]);
-		shape[i] = s; cxf[i] = r.cxf; tag[i] = r.tag; kind[i] = r.kind; reach[i] = np_reach(r.cxf, s, r.kind);
+		pc.nbx[i] = r.nbox; pc.nsp[i] = r.nsph;
+		for (uint32_t c = 0; c < NP_MAXC; ++c) {
+			pc.shape[(size_t)NP_MAXC * i + c] = make_float4(r.col[c].shape[0], r.col[c].shape[1], r.col[c].shape[2], r.col[c].shape[3]);
+			pc.cxf[(size_t)NP_MAXC * i + c] = r.col[c].cxf; pc.tag[(size_t)NP_MAXC * i + c] = r.col[c].tag;
+		}
+		pc.reach[i] = np_body_reach(pc, i);
 	}
 }
 
@@ -161,34 +190,35 @@ __global__ __launch_bounds__(256) void k_part_flag_ghosts(uint32_t n, const nh_T
 	}
 }
 
-// collider rebuild: flags by kind over the dynamic bodies, then the ordered write behind the static colliders
-__global__ __launch_bounds__(256) void k_part_flag_kinds(uint32_t n, const uint8_t* __restrict__ kind, uint32_t* __restrict__ f0, uint32_t* __restrict__ f1) {
+// collider rebuild: how many boxes / spheres every dynamic body carries (scanned by the host's launch in between), then the ordered write behind the static colliders
+__global__ __launch_bounds__(256) void k_part_flag_kinds(uint32_t n, const uint8_t* __restrict__ nbx, const uint8_t* __restrict__ nsp, uint32_t* __restrict__ f0, uint32_t* __restrict__ f1) {
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) {
-		const uint32_t k = (i >= 1u && i < n) ? kind[i] : 255u;
-		f0[i] = k == 0u ? 1u : 0u; f1[i] = k == 1u ? 1u : 0u;
+		const bool body = i >= 1u && i < n;
+		f0[i] = body ? (uint32_t)nbx[i] : 0u; f1[i] = body ? (uint32_t)nsp[i] : 0u;
 	}
 }
 
-__global__ __launch_bounds__(256) void k_part_write_colliders(uint32_t n, const uint32_t* __restrict__ s0, const uint32_t* __restrict__ s1, const uint8_t* __restrict__ kind,
-                                                              const float4* __restrict__ shape, const nh_Transform* __restrict__ cxf, const uint32_t* __restrict__ tag,
+__global__ __launch_bounds__(256) void k_part_write_colliders(uint32_t n, const uint32_t* __restrict__ s0, const uint32_t* __restrict__ s1, nh_PartCols pc,
                                                               uint32_t n_static_box, uint32_t box_capacity, uint32_t* __restrict__ xt, nh_BoxCollider* __restrict__ xd, nh_Transform* __restrict__ xx,
                                                               uint32_t n_static_sph, uint32_t sph_capacity, uint32_t* __restrict__ st, nh_SphereCollider* __restrict__ sd, nh_Transform* __restrict__ sx,
                                                               nh_PartDev* dv) {
 	for (uint32_t i = 1u + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		const uint32_t k = kind[i];
-		nh_Transform t = cxf[i];
-		t.body = i;                                  // Transform.body of a collider = its body's slot (nudge.h:36)
-		const float4 s = shape[i];
-		if (k == 0u) {
-			const uint32_t c = n_static_box + s0[i];
-			if (c >= box_capacity) { dv->error = NH_ERR_INVALID; continue; }
-			nh_BoxCollider b = { { s.x, s.y, s.z }, s.w };
-			xt[c] = tag[i]; xd[c] = b; xx[c] = t;
-		} else if (k == 1u) {
-			const uint32_t c = n_static_sph + s1[i];
-			if (c >= sph_capacity) { dv->error = NH_ERR_INVALID; continue; }
-			nh_SphereCollider sp = { s.x };
-			st[c] = tag[i]; sd[c] = sp; sx[c] = t;
+		const uint32_t nb = pc.nbx[i], ns = pc.nsp[i];
+		for (uint32_t k = 0; k < nb + ns && k < NP_MAXC; ++k) {
+			nh_Transform t = pc.cxf[(size_t)NP_MAXC * i + k];
+			t.body = i;                                  // Transform.body of a collider = its body's slot (nudge.h:36)
+			const float4 s = pc.shape[(size_t)NP_MAXC * i + k];
+			if (k < nb) {
+				const uint32_t c = n_static_box + s0[i] + k;
+				if (c >= box_capacity) { dv->error = NH_ERR_INVALID; continue; }
+				nh_BoxCollider b = { { s.x, s.y, s.z }, s.w };
+				xt[c] = pc.tag[(size_t)NP_MAXC * i + k]; xd[c] = b; xx[c] = t;
+			} else {
+				const uint32_t c = n_static_sph + s1[i] + (k - nb);
+				if (c >= sph_capacity) { dv->error = NH_ERR_INVALID; continue; }
+				nh_SphereCollider sp = { s.x };
+				st[c] = pc.tag[(size_t)NP_MAXC * i + k]; sd[c] = sp; sx[c] = t;
+			}
 		}
 	}
 }
@@ -201,6 +231,7 @@ __global__ void k_part_kth(const uint32_t* __restrict__ sorted, uint32_t ka, uin
 __global__ void k_part_reset(nh_PartDev* dv) { dv->count[0] = dv->count[1] = 0u; dv->kinds[0] = dv->kinds[1] = 0u; dv->vmax_bits = 0u; dv->zero = 0u; }
 
 // ---- host ----------------------------------------------------------------------------------------------------------------------------------------------
+static nh_PartCols part_cols(const nh_partition* p) { nh_PartCols pc = { p->shape, p->cxf, p->tag, p->nbx, p->nsp, p->reach }; return pc; }
 static int part_read_back(nh_partition* p) {
 	nh_context* ctx = p->ctx;
 	NP_CHECK(ctx, hipMemcpyAsync(p->h, p->d, sizeof(nh_PartDev), hipMemcpyDeviceToHost, ctx->stream));
@@ -212,7 +243,6 @@ extern "C" int nh_partition_create(nh_partition** out, nh_context* ctx, const nh
 	if (!out || !ctx || !cfg || !bodies || !colliders) return NH_ERR_INVALID;
 	if (cfg->body_capacity < cfg->n_owned + 1u || bodies->count != cfg->n_owned + 1u || cfg->ranks == 0u || cfg->rank >= cfg->ranks || cfg->epoch == 0u) return NH_ERR_INVALID;
 	if (colliders->boxes.count < cfg->n_static_box || colliders->spheres.count < cfg->n_static_sph) return NH_ERR_INVALID;
-	if ((uint64_t)(colliders->boxes.count - cfg->n_static_box) + (colliders->spheres.count - cfg->n_static_sph) != cfg->n_owned) return NH_ERR_INVALID;      // one collider per dynamic body
 	NP_CHECK(ctx, hipSetDevice(ctx->device));
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	nh_partition* p = new nh_partition();
@@ -221,8 +251,9 @@ extern "C" int nh_partition_create(nh_partition** out, nh_context* ctx, const nh
 	p->n_owned = cfg->n_owned; p->n_bodies = cfg->n_owned + 1u; p->n_boxes = colliders->boxes.count; p->n_spheres = colliders->spheres.count;
 	const size_t cap = cfg->body_capacity;
 	const size_t sort_words = 256u * NH_SORT_GRID + 512u;
-	bool ok = hipMalloc((void**)&p->shape, sizeof(float4) * cap) == hipSuccess && hipMalloc((void**)&p->cxf, sizeof(nh_Transform) * cap) == hipSuccess &&
-	          hipMalloc((void**)&p->tag, sizeof(uint32_t) * cap) == hipSuccess && hipMalloc((void**)&p->kind, cap + 64u) == hipSuccess && hipMalloc((void**)&p->reach, sizeof(float) * cap) == hipSuccess &&
+	bool ok = hipMalloc((void**)&p->shape, sizeof(float4) * cap * NP_MAXC) == hipSuccess && hipMalloc((void**)&p->cxf, sizeof(nh_Transform) * cap * NP_MAXC) == hipSuccess &&
+	          hipMalloc((void**)&p->tag, sizeof(uint32_t) * cap * NP_MAXC) == hipSuccess && hipMalloc((void**)&p->nbx, cap + 64u) == hipSuccess && hipMalloc((void**)&p->nsp, cap + 64u) == hipSuccess &&
+	          hipMalloc((void**)&p->reach, sizeof(float) * cap) == hipSuccess &&
 	          hipMalloc((void**)&p->list[0], sizeof(uint32_t) * cap) == hipSuccess && hipMalloc((void**)&p->list[1], sizeof(uint32_t) * cap) == hipSuccess &&
 	          hipMalloc((void**)&p->flag[0], sizeof(uint32_t) * (cap + 2u)) == hipSuccess && hipMalloc((void**)&p->flag[1], sizeof(uint32_t) * (cap + 2u)) == hipSuccess &&
 	          hipMalloc((void**)&p->scan_tmp, sizeof(uint32_t) * (2u * NH_SORT_GRID + 64u)) == hipSuccess &&
@@ -234,18 +265,20 @@ extern "C" int nh_partition_create(nh_partition** out, nh_context* ctx, const nh
 	if (!ok) { nh_partition_destroy(p); return NH_ERR_HIP; }
 	hipStream_t s = ctx->stream;
 	hipMemsetAsync(p->d, 0, sizeof(nh_PartDev), s);
-	hipMemsetAsync(p->kind, 0xFF, cap, s);
+	hipMemsetAsync(p->nbx, 0, cap, s); hipMemsetAsync(p->nsp, 0, cap, s);
 	hipMemsetAsync(p->reach, 0, sizeof(float) * cap, s);
-	hipMemsetAsync(p->shape, 0, sizeof(float4) * cap, s);
-	hipMemsetAsync(p->cxf, 0, sizeof(nh_Transform) * cap, s);
-	hipMemsetAsync(p->tag, 0, sizeof(uint32_t) * cap, s);
+	hipMemsetAsync(p->shape, 0, sizeof(float4) * cap * NP_MAXC, s);
+	hipMemsetAsync(p->cxf, 0, sizeof(nh_Transform) * cap * NP_MAXC, s);
+	hipMemsetAsync(p->tag, 0, sizeof(uint32_t) * cap * NP_MAXC, s);
 	const uint32_t nbx = colliders->boxes.count, nsp = colliders->spheres.count;
+	// (boxes first: a body's spheres go behind its boxes, so the box counts must be final when the spheres are adopted -- two launches on one stream)
 	if (nbx > cfg->n_static_box)
 		hipLaunchKernelGGL(k_part_adopt, dim3(nh_grid_for(nbx - cfg->n_static_box, 256, 2048)), dim3(256), 0, s, cfg->n_static_box, nbx, 0u, colliders->boxes.tags, (const void*)colliders->boxes.data,
-		                   colliders->boxes.transforms, cfg->body_capacity, p->shape, p->cxf, p->tag, p->kind, p->reach, p->d);
+		                   colliders->boxes.transforms, cfg->body_capacity, part_cols(p), p->d);
 	if (nsp > cfg->n_static_sph)
 		hipLaunchKernelGGL(k_part_adopt, dim3(nh_grid_for(nsp - cfg->n_static_sph, 256, 2048)), dim3(256), 0, s, cfg->n_static_sph, nsp, 1u, colliders->spheres.tags, (const void*)colliders->spheres.data,
-		                   colliders->spheres.transforms, cfg->body_capacity, p->shape, p->cxf, p->tag, p->kind, p->reach, p->d);
+		                   colliders->spheres.transforms, cfg->body_capacity, part_cols(p), p->d);
+	hipLaunchKernelGGL(k_part_reaches, dim3(nh_grid_for(p->n_bodies, 256, 2048)), dim3(256), 0, s, p->n_bodies, part_cols(p));
 	int rc = part_read_back(p);
 	if (rc) { nh_partition_destroy(p); return rc; }
 	*out = p;
@@ -256,7 +289,7 @@ extern "C" void nh_partition_destroy(nh_partition* p) {
 	if (!p) return;
 	hipSetDevice(p->ctx->device);
 	hipStreamSynchronize(p->ctx->stream);
-	void* bufs[] = { p->shape, p->cxf, p->tag, p->kind, p->reach, p->list[0], p->list[1], p->flag[0], p->flag[1], p->scan_tmp, p->sort_a, p->sort_b, p->sort_va, p->sort_vb, p->sort_hist, p->stage, p->d };
+	void* bufs[] = { p->shape, p->cxf, p->tag, p->nbx, p->nsp, p->reach, p->list[0], p->list[1], p->flag[0], p->flag[1], p->scan_tmp, p->sort_a, p->sort_b, p->sort_va, p->sort_vb, p->sort_hist, p->stage, p->d };
 	for (void* b : bufs) if (b) hipFree(b);
 	if (p->h) hipHostFree(p->h);
 	delete p;
@@ -284,7 +317,7 @@ extern "C" int nh_partition_pack_migrants(nh_partition* p, const nh_BodyData* bo
 	NP_LAUNCH("part_flag_leavers", k_part_flag_leavers, n, n, bodies->transforms, (float)p->lo, (float)p->hi, has_left ? 1u : 0u, has_right ? 1u : 0u, p->flag[0], p->flag[1]);
 	nh_scan2_u32(ctx, p->flag[0], p->flag[0], &p->d->count[0], p->flag[1], p->flag[1], &p->d->count[1], &p->d->zero, n + 1u, p->scan_tmp);
 	NP_LAUNCH("part_pack_full", k_part_pack_full, n, n, p->flag[0], p->flag[1], capacity_records, bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters,
-	          p->shape, p->cxf, p->tag, p->kind, (nh_FullRecord*)out_left, (nh_FullRecord*)out_right, (uint32_t*)nullptr, (uint32_t*)nullptr, p->d);
+	          part_cols(p), (nh_FullRecord*)out_left, (nh_FullRecord*)out_right, (uint32_t*)nullptr, (uint32_t*)nullptr, p->d);
 	int rc = part_read_back(p);
 	if (rc) return rc;
 	counts[0] = p->h->count[0]; counts[1] = p->h->count[1];
@@ -303,12 +336,12 @@ extern "C" int nh_partition_unpack_migrants(nh_partition* p, const nh_BodyData* 
 	if ((uint64_t)keep + n_left + n_right > p->cfg.body_capacity) return NH_ERR_INVALID;
 	if (left) {
 		// the bodies that stay keep their order: through the staging buffer (a gather in place would read slots another lane has already overwritten)
-		NP_LAUNCH("part_stage_kept", k_part_stage_kept, n, n, p->flag[0], p->flag[1], bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters, p->shape, p->cxf, p->tag, p->kind, p->stage);
-		NP_LAUNCH("part_install", k_part_install, keep, 0u, keep, p->stage, bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters, p->shape, p->cxf, p->tag, p->kind, p->reach);
+		NP_LAUNCH("part_stage_kept", k_part_stage_kept, n, n, p->flag[0], p->flag[1], bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters, part_cols(p), p->stage);
+		NP_LAUNCH("part_install", k_part_install, keep, 0u, keep, p->stage, bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters, part_cols(p));
 	}
 	uint32_t at = keep;
-	if (n_left) { NP_LAUNCH("part_install", k_part_install, n_left, at, n_left, (const nh_FullRecord*)in_left, bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters, p->shape, p->cxf, p->tag, p->kind, p->reach); at += n_left; }
-	if (n_right) { NP_LAUNCH("part_install", k_part_install, n_right, at, n_right, (const nh_FullRecord*)in_right, bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters, p->shape, p->cxf, p->tag, p->kind, p->reach); at += n_right; }
+	if (n_left) { NP_LAUNCH("part_install", k_part_install, n_left, at, n_left, (const nh_FullRecord*)in_left, bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters, part_cols(p)); at += n_left; }
+	if (n_right) { NP_LAUNCH("part_install", k_part_install, n_right, at, n_right, (const nh_FullRecord*)in_right, bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters, part_cols(p)); at += n_right; }
 	p->n_owned = at - 1u;
 	p->n_bodies = at;                       // (ghosts are gone until nh_partition_unpack_ghosts)
 	p->ghost_in[0] = p->ghost_in[1] = 0u;
@@ -330,7 +363,7 @@ extern "C" int nh_partition_pack_ghosts(nh_partition* p, const nh_BodyData* bodi
 	          p->cfg.max_reach, epoch_dt, p->cfg.speed_floor, fabs(p->cfg.gravity) * epoch_dt, p->d, p->flag[0], p->flag[1]);
 	nh_scan2_u32(ctx, p->flag[0], p->flag[0], &p->d->count[0], p->flag[1], p->flag[1], &p->d->count[1], &p->d->zero, n + 1u, p->scan_tmp);
 	NP_LAUNCH("part_pack_full", k_part_pack_full, n, n, p->flag[0], p->flag[1], capacity_records, bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters,
-	          p->shape, p->cxf, p->tag, p->kind, (nh_FullRecord*)out_left, (nh_FullRecord*)out_right, p->list[0], p->list[1], p->d);
+	          part_cols(p), (nh_FullRecord*)out_left, (nh_FullRecord*)out_right, p->list[0], p->list[1], p->d);
 	int rc = part_read_back(p);
 	if (rc) return rc;
 	counts[0] = p->h->count[0]; counts[1] = p->h->count[1];
@@ -346,20 +379,19 @@ extern "C" int nh_partition_unpack_ghosts(nh_partition* p, nh_BodyData* bodies, 
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	uint32_t at = p->n_owned + 1u;
 	if ((uint64_t)at + n_left + n_right > p->cfg.body_capacity) return NH_ERR_INVALID;
-	if (n_left) { NP_LAUNCH("part_install", k_part_install, n_left, at, n_left, (const nh_FullRecord*)in_left, bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters, p->shape, p->cxf, p->tag, p->kind, p->reach); at += n_left; }
-	if (n_right) { NP_LAUNCH("part_install", k_part_install, n_right, at, n_right, (const nh_FullRecord*)in_right, bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters, p->shape, p->cxf, p->tag, p->kind, p->reach); at += n_right; }
+	if (n_left) { NP_LAUNCH("part_install", k_part_install, n_left, at, n_left, (const nh_FullRecord*)in_left, bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters, part_cols(p)); at += n_left; }
+	if (n_right) { NP_LAUNCH("part_install", k_part_install, n_right, at, n_right, (const nh_FullRecord*)in_right, bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters, part_cols(p)); at += n_right; }
 	p->ghost_in[0] = n_left; p->ghost_in[1] = n_right;
 	p->n_bodies = at;
 	// colliders: the static ones stay, then one per dynamic body slot (owned, then ghosts) -- boxes and spheres each compacted in slot order
 	NH_LAUNCH(ctx, "part_reset", k_part_reset, 1, 1, p->d);
-	NP_LAUNCH("part_flag_kinds", k_part_flag_kinds, at, at, p->kind, p->flag[0], p->flag[1]);
+	NP_LAUNCH("part_flag_kinds", k_part_flag_kinds, at, at, p->nbx, p->nsp, p->flag[0], p->flag[1]);
 	nh_scan2_u32(ctx, p->flag[0], p->flag[0], &p->d->kinds[0], p->flag[1], p->flag[1], &p->d->kinds[1], &p->d->zero, at + 1u, p->scan_tmp);
-	NP_LAUNCH("part_write_colliders", k_part_write_colliders, at, at, p->flag[0], p->flag[1], p->kind, p->shape, p->cxf, p->tag,
+	NP_LAUNCH("part_write_colliders", k_part_write_colliders, at, at, p->flag[0], p->flag[1], part_cols(p),
 	          p->cfg.n_static_box, p->cfg.box_capacity, colliders->boxes.tags, colliders->boxes.data, colliders->boxes.transforms,
 	          p->cfg.n_static_sph, p->cfg.sphere_capacity, colliders->spheres.tags, colliders->spheres.data, colliders->spheres.transforms, p->d);
 	int rc = part_read_back(p);
 	if (rc) return rc;
-	if (p->h->kinds[0] + p->h->kinds[1] != at - 1u) return NH_ERR_INVALID;            // a dynamic body without a collider of its own
 	p->n_boxes = p->cfg.n_static_box + p->h->kinds[0]; p->n_spheres = p->cfg.n_static_sph + p->h->kinds[1];
 	if (p->n_boxes > p->cfg.box_capacity || p->n_spheres > p->cfg.sphere_capacity) return NH_ERR_INVALID;
 	bodies->count = at; colliders->boxes.count = p->n_boxes; colliders->spheres.count = p->n_spheres;

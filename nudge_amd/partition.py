@@ -37,7 +37,8 @@ bodies they own; when the two counts differ by more than 5 % of their sum the HE
 ordinary migration of that same refresh.  Neighbour messages only (two more tiny ones per refresh, one of them only when a cut moves); a cut never moves further
 from where it started than the static colliders a rank keeps allow (`split_scene(static_margin=...)`).
 
-Restriction: a dynamic body carries exactly ONE collider (any local transform); static colliders are unrestricted.
+A dynamic body carries up to MAX_COLLIDERS colliders (compound bodies: nudge.cpp:3023-3025, 3058-3060), any local transforms; they travel with it in its
+record, boxes first, then spheres.  Static colliders are unrestricted.
 
 WHERE THE WORK IS DONE.  On the HIP engine every operation below -- migration, ghost listing and installation, the collider rebuild, the per-step records,
 the choice of a new cut -- is a call into the C ABI (include/nudge_hip.h "multi-GPU": nh_partition_*, kernels with device-side counts in
@@ -54,30 +55,36 @@ import numpy as np
 
 from . import scenes as S
 
-FULL_BYTES = 32 + 16 + 32 + 16 + 32 + 4 + 4        # transform, properties, momentum, shape, collider transform, tag, (kind, idle)
+MAX_COLLIDERS = 4                                 # colliders a dynamic body may carry across ranks (include/nudge_hip.h: NH_PARTITION_MAX_COLLIDERS)
+COLLIDER_BYTES = 16 + 32 + 4 + 4                  # shape, collider transform, tag, pad
+FULL_BYTES = 32 + 16 + 32 + MAX_COLLIDERS * COLLIDER_BYTES + 4      # transform, properties, momentum, the colliders (boxes first, then spheres), (boxes, spheres, idle, pad)
 STEP_BYTES = 64                                   # position 12, rotation 16, momentum 32, idle 1 + pad (nh_halo_pack's record)
 
 
-def body_reach(scene):
-    """Per dynamic body: distance from the body origin to the farthest point of its collider; raises unless every
-    dynamic body has exactly one collider.  Returns (kind[B], collider_index[B], reach[B]) with kind 0 box / 1 sphere."""
+def body_colliders(scene):
+    """Per dynamic body its colliders, boxes first (scene order), then spheres: (nbx[B], nsp[B], index[B, 4] into the scene's box / sphere arrays, reach[B]) with
+    reach = distance from the body origin to the farthest point of any of its colliders.  Raises when a body carries more than MAX_COLLIDERS."""
     nb = len(scene["body_transforms"])
-    kind = np.full(nb, 255, dtype=np.uint8)
-    cidx = np.zeros(nb, dtype=np.int64)
+    counts, index = [], np.zeros((nb, MAX_COLLIDERS), dtype=np.int64)
     reach = np.zeros(nb, dtype=np.float32)
+    base = np.zeros(nb, dtype=np.int64)
     for k, (xf, data) in enumerate(((scene["box_transforms"], scene["box_data"]), (scene["sphere_transforms"], scene["sphere_data"]))):
         body = xf["body"].astype(np.int64)
         dyn = np.flatnonzero(body > 0)
-        if len(dyn) and (kind[body[dyn]] != 255).any() or len(np.unique(body[dyn])) != len(dyn):
-            raise ValueError("partitioned worlds need exactly one collider per dynamic body")
-        kind[body[dyn]] = k
-        cidx[body[dyn]] = dyn
-        off = np.linalg.norm(xf["position"][dyn].astype(np.float64), axis=1)
-        ext = np.linalg.norm(data["size"][dyn].astype(np.float64), axis=1) if k == 0 else data["radius"][dyn].astype(np.float64)
-        reach[body[dyn]] = (off + ext).astype(np.float32) * np.float32(1.0001)
-    if (kind[1:] == 255).any():
-        raise ValueError("partitioned worlds need exactly one collider per dynamic body")
-    return kind, cidx, reach
+        order = dyn[np.argsort(body[dyn], kind="stable")]               # grouped by body, scene order inside a body
+        b = body[order]
+        cnt = np.bincount(b, minlength=nb)
+        first = np.cumsum(cnt) - cnt
+        within = np.arange(len(order)) - first[b]
+        if len(order) and (base[b] + within >= MAX_COLLIDERS).any():
+            raise ValueError(f"partitioned worlds: a dynamic body carries at most {MAX_COLLIDERS} colliders")
+        index[b, base[b] + within] = order
+        off = np.linalg.norm(xf["position"][order].astype(np.float64), axis=1)
+        ext = np.linalg.norm(data["size"][order].astype(np.float64), axis=1) if k == 0 else data["radius"][order].astype(np.float64)
+        np.maximum.at(reach, b, (off + ext).astype(np.float32) * np.float32(1.0001))
+        counts.append(cnt.astype(np.uint8))
+        base = base + cnt
+    return counts[0], counts[1], index, reach
 
 
 def split_scene(scene, cuts, rank, slack=0.15, min_extra=4096, static_margin=None):
@@ -86,7 +93,7 @@ def split_scene(scene, cuts, rank, slack=0.15, min_extra=4096, static_margin=Non
     `static_margin`: keep only the static colliders whose x-extent comes within this distance of the rank's slab or of a
     neighbour's (bodies only ever arrive from a neighbour, and they bring the ground they stand on into reach one slab at a
     time) -- None keeps all of them (small scenes); a rank of the 16 M-box world holds ~500 of the 1984 ground slabs."""
-    kind, cidx, reach = body_reach(scene)
+    nbx, nsp, cidx, reach = body_colliders(scene)
     x = scene["body_transforms"]["position"][:, 0]
     lo = -np.inf if rank == 0 else cuts[rank - 1]
     hi = np.inf if rank == len(cuts) else cuts[rank]
@@ -111,34 +118,41 @@ def split_scene(scene, cuts, rank, slack=0.15, min_extra=4096, static_margin=Non
             lo2 = -np.inf if rank <= 1 else cuts[rank - 2]
             hi2 = np.inf if rank + 1 >= len(cuts) else cuts[rank + 1]
             static = static[(cx + ext >= lo2 - static_margin) & (cx - ext <= hi2 + static_margin)]
-        dyn_local = np.flatnonzero(kind[body_map[1:]] == k) + 1             # local body slots with a collider of this kind
-        sel = np.concatenate([static, cidx[body_map[dyn_local]]]).astype(np.int64)
+        # the dynamic bodies' colliders of this kind in local slot order, a body's own adjacent (what nh_partition_create and the collider rebuild expect / produce)
+        cnt = (nbx if k == 0 else nsp)[body_map].astype(np.int64)
+        cnt[0] = 0
+        slot = np.repeat(np.arange(n), cnt)
+        within = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt) + (0 if k == 0 else nbx[body_map].astype(np.int64)[slot])
+        sel = np.concatenate([static, cidx[body_map[slot], within]]).astype(np.int64)
         t = xf[sel].copy()
-        t["body"][len(static):] = dyn_local.astype(np.uint32)
+        t["body"][len(static):] = slot.astype(np.uint32)
         return scene[prefix + "_tags"][sel].astype(np.uint32), scene[prefix + "_data"][sel].copy(), t, len(static)
 
     local["box_tags"], local["box_data"], local["box_transforms"], n_static_box = pick("box", 0)
     local["sphere_tags"], local["sphere_data"], local["sphere_transforms"], n_static_sph = pick("sphere", 1)
 
-    # body-parallel collider description (what travels with a body)
-    shape = np.zeros((n, 4), dtype=np.float32)
-    cxf = np.zeros(n, dtype=S.TRANSFORM)
-    tag = np.zeros(n, dtype=np.uint32)
-    kk = kind[body_map]
-    for k, prefix in ((0, "box"), (1, "sphere")):
-        sel = np.flatnonzero(kk[1:] == k) + 1
-        ci = cidx[body_map[sel]]
-        if k == 0:
-            shape[sel, :3] = scene["box_data"]["size"][ci]
-        else:
-            shape[sel, 0] = scene["sphere_data"]["radius"][ci]
-        cxf[sel] = scene[prefix + "_transforms"][ci]
-        tag[sel] = scene[prefix + "_tags"][ci]
+    # body-parallel collider description (what travels with a body): per body MAX_COLLIDERS slots, its boxes first, then its spheres
+    shape = np.zeros((n, MAX_COLLIDERS, 4), dtype=np.float32)
+    cxf = np.zeros((n, MAX_COLLIDERS), dtype=S.TRANSFORM)
+    tag = np.zeros((n, MAX_COLLIDERS), dtype=np.uint32)
+    lb, ls = nbx[body_map].copy(), nsp[body_map].copy()
+    lb[0] = ls[0] = 0
+    for c in range(MAX_COLLIDERS):
+        isb = np.flatnonzero(c < lb)
+        ci = cidx[body_map[isb], c]
+        shape[isb, c, :3] = scene["box_data"]["size"][ci]; shape[isb, c, 3] = scene["box_data"]["unused"][ci]
+        cxf[isb, c] = scene["box_transforms"][ci]; tag[isb, c] = scene["box_tags"][ci]
+        iss = np.flatnonzero((c >= lb) & (c < lb.astype(np.int64) + ls))
+        ci = cidx[body_map[iss], c]
+        shape[iss, c, 0] = scene["sphere_data"]["radius"][ci]
+        cxf[iss, c] = scene["sphere_transforms"][ci]; tag[iss, c] = scene["sphere_tags"][ci]
     extra = max(min_extra, int(slack * n))
-    info = dict(rank=rank, ranks=len(cuts) + 1, lo=float(lo), hi=float(hi), n_owned=n - 1, cut_slack=(float("inf") if static_margin is None else 0.5 * float(static_margin)), kind=kk.copy(), shape=shape, cxf=cxf, tag=tag,
+    info = dict(rank=rank, ranks=len(cuts) + 1, lo=float(lo), hi=float(hi), n_owned=n - 1, cut_slack=(float("inf") if static_margin is None else 0.5 * float(static_margin)), nbx=lb, nsp=ls, shape=shape, cxf=cxf, tag=tag,
                 reach=reach[body_map].copy(), max_reach=float(reach.max()) if len(reach) else 0.0,
                 n_static_box=n_static_box, n_static_sph=n_static_sph,
-                capacity=dict(bodies=n + extra, boxes=len(local["box_tags"]) + extra, spheres=len(local["sphere_tags"]) + extra),
+                # (room for `extra` more bodies, with as many colliders each as the world's busiest body carries)
+                capacity=dict(bodies=n + extra, boxes=len(local["box_tags"]) + extra * max(1, int(nbx.max()) if len(nbx) else 1),
+                              spheres=len(local["sphere_tags"]) + extra * max(1, int(nsp.max()) if len(nsp) else 1)),
                 tag_bits=max(8, int(max(int(scene["box_tags"].max()) if len(scene["box_tags"]) else 1,
                                         int(scene["sphere_tags"].max()) if len(scene["sphere_tags"]) else 1)).bit_length()))
     return local, info
@@ -185,12 +199,14 @@ class Partition:
             t[:n] = torch.from_numpy(raw.copy()).to(dev)
             return t
 
-        # body-parallel collider description + reach
-        self.shape = dev_rec(info["shape"], 16)
-        self.cxf = dev_rec(info["cxf"], 32)
-        self.tag = dev_rec(info["tag"], 4)
-        self.kind = torch.zeros(cap, dtype=torch.uint8, device=dev)
-        self.kind[:n] = torch.from_numpy(info["kind"].copy()).to(dev)
+        # body-parallel collider description + reach: MAX_COLLIDERS slots per body (its boxes first, then its spheres)
+        self.shape = dev_rec(info["shape"], MAX_COLLIDERS * 16).view(cap, MAX_COLLIDERS, 16)
+        self.cxf = dev_rec(info["cxf"], MAX_COLLIDERS * 32).view(cap, MAX_COLLIDERS, 32)
+        self.tag = dev_rec(info["tag"], MAX_COLLIDERS * 4).view(cap, MAX_COLLIDERS, 4)
+        self.nbx = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        self.nbx[:n] = torch.from_numpy(info["nbx"].astype(np.uint8).copy()).to(dev)
+        self.nsp = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        self.nsp[:n] = torch.from_numpy(info["nsp"].astype(np.uint8).copy()).to(dev)
         self.reach = torch.zeros(cap, dtype=torch.float32, device=dev)
         self.reach[:n] = torch.from_numpy(info["reach"].copy()).to(dev)
         self.ghost_out = {-1: None, +1: None}      # owned slots sent to the left / right neighbour every step
@@ -268,29 +284,45 @@ class Partition:
         return self._f32(self.bt[:n])[:, 0]
 
     def _full(self, idx):
-        """Full records of the given body slots: [len, FULL_BYTES] uint8."""
+        """Full records of the given body slots: [len, FULL_BYTES] uint8 (the layout of nh_FullRecord, nudge_amd/csrc/nh_partition.hip)."""
         t = self.torch
-        meta = t.zeros((len(idx), 4), dtype=t.uint8, device=idx.device)
-        meta[:, 0] = self.kind[idx]
-        meta[:, 1] = self.bi[idx, 0]
-        return t.cat([self.bt[idx], self.bp[idx], self.bm[idx], self.shape[idx], self.cxf[idx], self.tag[idx], meta], dim=1)
+        m = len(idx)
+        pad = t.zeros((m, 4), dtype=t.uint8, device=idx.device)
+        tail = t.zeros((m, 4), dtype=t.uint8, device=idx.device)
+        tail[:, 0] = self.nbx[idx]
+        tail[:, 1] = self.nsp[idx]
+        tail[:, 2] = self.bi[idx, 0]
+        parts = [self.bt[idx], self.bp[idx], self.bm[idx]]
+        for c in range(MAX_COLLIDERS):
+            parts += [self.shape[idx, c], self.cxf[idx, c], self.tag[idx, c], pad]
+        return t.cat(parts + [tail], dim=1)
 
     def _install_full(self, rec, at):
         """Writes full records into body slots [at, at + len)."""
+        t = self.torch
         m = rec.shape[0]
         s = slice(at, at + m)
         o = 0
-        for dst, w in ((self.bt, 32), (self.bp, 16), (self.bm, 32), (self.shape, 16), (self.cxf, 32), (self.tag, 4)):
+        for dst, w in ((self.bt, 32), (self.bp, 16), (self.bm, 32)):
             dst[s] = rec[:, o:o + w]
             o += w
-        self.kind[s] = rec[:, o]
-        self.bi[s, 0] = rec[:, o + 1]
-        # reach is a function of the collider: |local offset| + extent
-        t = self.torch
-        off = self._f32(self.cxf[s])[:, :3].norm(dim=1)
-        sh = self._f32(self.shape[s])
-        ext = t.where(self.kind[s] == 0, sh[:, :3].norm(dim=1), sh[:, 0])
-        self.reach[s] = (off + ext) * 1.0001
+        for c in range(MAX_COLLIDERS):
+            self.shape[s, c] = rec[:, o:o + 16]
+            self.cxf[s, c] = rec[:, o + 16:o + 48]
+            self.tag[s, c] = rec[:, o + 48:o + 52]
+            o += COLLIDER_BYTES
+        self.nbx[s] = rec[:, o]
+        self.nsp[s] = rec[:, o + 1]
+        self.bi[s, 0] = rec[:, o + 2]
+        # reach is a function of the colliders: the largest |local offset| + extent
+        nb, ns = self.nbx[s].to(t.int64), self.nsp[s].to(t.int64)
+        reach = t.zeros(m, dtype=t.float32, device=rec.device)
+        for c in range(MAX_COLLIDERS):
+            off = self._f32(self.cxf[s, c].contiguous())[:, :3].norm(dim=1)
+            sh = self._f32(self.shape[s, c].contiguous())
+            ext = t.where(c < nb, sh[:, :3].norm(dim=1), sh[:, 0])
+            reach = t.where(c < nb + ns, t.maximum(reach, (off + ext) * 1.0001), reach)
+        self.reach[s] = reach
 
     def _step_records(self, idx, idx32=None):
         """Per-step records [len, 64] of the given body slots: the engine's HIP kernel when it has one (nh_halo_pack), else torch ops."""
@@ -409,10 +441,8 @@ class Partition:
         n = self.n_owned + 1
         keep = t.nonzero(~self._leave).flatten()          # includes slot 0
         if keep.numel() != n:
-            for arr in (self.bt, self.bp, self.bm, self.bi, self.shape, self.cxf, self.tag):
+            for arr in (self.bt, self.bp, self.bm, self.bi, self.shape, self.cxf, self.tag, self.nbx, self.nsp, self.reach):
                 arr[:keep.numel()] = arr[keep]
-            self.kind[:keep.numel()] = self.kind[keep]
-            self.reach[:keep.numel()] = self.reach[keep]
         at = int(keep.numel())
         for d in self.neighbours():
             rec = incoming.get(d)
@@ -478,22 +508,25 @@ class Partition:
         self.stats["ghosts"] = self.ghost_in[-1] + self.ghost_in[+1]
 
     def _rebuild_colliders(self):
-        """Collider arrays = static colliders, then one collider per dynamic body slot (owned, then ghosts)."""
+        """Collider arrays = static colliders, then the dynamic bodies' in slot order (owned, then ghosts), a body's own adjacent."""
         t = self.torch
         n = self.n_bodies
-        kind = self.kind[:n]
-        slots = t.arange(n, device=kind.device)
+        dev = self.bt.device
+        nb, ns = self.nbx[:n].to(t.int64).clone(), self.nsp[:n].to(t.int64).clone()
+        nb[0] = 0; ns[0] = 0
         counts = []
-        for k, (tags, data, xf, n_static, width) in enumerate(((self.xt, self.xd, self.xx, self.n_static_box, 16), (self.st, self.sd, self.sx, self.n_static_sph, 4))):
-            idx = t.nonzero((kind == k) & (slots > 0)).flatten()
-            m = int(idx.numel())
+        for k, (tags, data, xf, n_static, width, cnt, base) in enumerate(((self.xt, self.xd, self.xx, self.n_static_box, 16, nb, t.zeros_like(nb)),
+                                                                          (self.st, self.sd, self.sx, self.n_static_sph, 4, ns, nb))):
+            m = int(cnt.sum())
             if n_static + m > tags.shape[0]:
                 raise RuntimeError("partition: collider capacity exceeded")
+            slot = t.repeat_interleave(t.arange(n, device=dev), cnt)
+            within = t.arange(m, device=dev) - t.repeat_interleave(t.cumsum(cnt, 0) - cnt, cnt) + base[slot]
             s = slice(n_static, n_static + m)
-            tags[s] = self.tag[idx]
-            data[s] = self.shape[idx][:, :width]
-            xf[s] = self.cxf[idx]
-            xf[s].view(t.int32)[:, 3] = idx.to(t.int32)               # Transform.body = local body slot (nudge.h:36)
+            tags[s] = self.tag[slot, within]
+            data[s] = self.shape[slot, within][:, :width]
+            xf[s] = self.cxf[slot, within]
+            xf[s].view(t.int32)[:, 3] = slot.to(t.int32)               # Transform.body = local body slot (nudge.h:36)
             counts.append(n_static + m)
         self.e.set_counts(n, counts[0], counts[1])
 

@@ -189,7 +189,7 @@ def test_cpp_rccl_host_loopback_executes_rccl_between_the_halo_kernels():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sphere_fraction", [0.0, 0.5])
+@pytest.mark.parametrize("sphere_fraction", [0.0, 0.5, "compound"])
 def test_cpp_partition_host_matches_the_python_host_bit_for_bit(tmp_path, sphere_fraction):
     """examples/partition_rccl.cpp with NUDGE_LOCAL_RANKS=3 (three ranks of the C++ host in one process on one GPU, device-to-device copies as the transport) and
     nudge_amd/partition.py's LocalCluster are two hosts over the SAME C-ABI entry points (nh_partition_*): on one scene cut through its tiles, same epoch, same
@@ -200,7 +200,11 @@ def test_cpp_partition_host_matches_the_python_host_bit_for_bit(tmp_path, sphere
     import parity_util as P
     from nudge_amd import engine as E, partition as PT, scenes as S
     assert os.path.exists(CU.PARTITION_RCCL), "nudge_amd/partition_rccl missing: make -C nudge_amd/csrc"
-    scene = S.grid_tiles(6, side=24, sphere_fraction=sphere_fraction, seed=33, lattice_cols=3)
+    if sphere_fraction == "compound":
+        scene = S.compound(n_bodies=300, seed=6)             # two boxes and a sphere per body: the records carry all three, the collider arrays are rebuilt with a body's own adjacent
+        scene["body_momentum"]["velocity"][1::4, 0] = 5.0
+    else:
+        scene = S.grid_tiles(6, side=24, sphere_fraction=sphere_fraction, seed=33, lattice_cols=3)
     x = scene["body_transforms"]["position"][1:, 0]
     cuts = [float(np.quantile(x, 0.30)) + 0.41, float(np.quantile(x, 0.72)) + 0.41]          # uneven on purpose: the re-balancing moves them
     steps = 150
@@ -226,5 +230,7 @@ def test_cpp_partition_host_matches_the_python_host_bit_for_bit(tmp_path, sphere
     assert np.array_equal(got["idle"], ref["idle"])
     moves = sum(p.stats["cut_moves"] for p in parts)
     assert moves > 0 and f"cut moves" in r.stdout, (moves, r.stdout)
+    if sphere_fraction == "compound":
+        assert sum(p.stats["migrated_out"] for p in parts) > 0
     for q in parts:
         q.close(); q.e.close()

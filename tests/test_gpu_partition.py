@@ -248,3 +248,40 @@ def test_migration_and_cut_rebalancing_through_the_c_abi():
         q.close()
         q.e.close()
     single.close()
+
+
+def test_compound_bodies_across_a_cut_on_the_gpu():
+    """Compound bodies (two boxes and a sphere each, local transforms: nudge.cpp:3023-3025, 3058-3060) in a world cut in two: ghost and migration records carry all
+    three colliders, through the C ABI (nh_partition_*) and through the torch implementation alike -- same owners, same bits -- and while nothing touches, the
+    partitioned world IS the single world; landed (contacts across the cut are solved on both ranks) it stays close to it."""
+    scene = S.compound(n_bodies=240, seed=6)
+    scene["body_momentum"]["velocity"][1::3, 0] = 6.0
+    x = scene["body_transforms"]["position"][1:, 0]
+    cuts = [float(np.quantile(x, 0.5)) + 0.13]
+    clusters = []
+    for force_torch in (False, True):
+        parts = []
+        for r in range(2):
+            local, info = PT.split_scene(scene, cuts, r, min_extra=1024)
+            w = E.World(local, flags=0, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=16 * info["capacity"]["bodies"], max_pairs=16 * info["capacity"]["bodies"])
+            parts.append(PT.Partition(w, info, epoch=4, speed_floor=8.0, force_torch=force_torch))
+        clusters.append((PT.LocalCluster(parts), parts))
+    (ca, pa), (cb, pb) = clusters
+    single = E.World(scene, flags=0)
+    ca.step(20); cb.step(20); single.step(20)
+    ga, gb, ref = ca.gather(), cb.gather(), single.get_bodies()
+    assert np.array_equal(ga["ids"], np.arange(1, len(scene["body_transforms"]))) and np.array_equal(ga["ids"], gb["ids"])
+    assert P.bits_equal(ga["transforms"]["position"], gb["transforms"]["position"]) and P.bits_equal(ga["transforms"]["rotation"], gb["transforms"]["rotation"])
+    assert P.bits_equal(ga["transforms"]["position"], ref["transforms"]["position"][1:]) and P.bits_equal(ga["transforms"]["rotation"], ref["transforms"]["rotation"][1:])
+    assert pa[0].stats["migrated_out"] > 0 and sum(p.stats["ghosts"] for p in pa) > 0
+    for xp, yp in zip(pa, pb):
+        assert xp.n_owned == yp.n_owned
+    ca.step(130); cb.step(130); single.step(130)
+    ga, gb, ref = ca.gather(), cb.gather(), single.get_bodies()
+    assert P.bits_equal(ga["transforms"]["position"], gb["transforms"]["position"]) and P.bits_equal(ga["momentum"]["velocity"], gb["momentum"]["velocity"])
+    assert np.isfinite(ga["transforms"]["position"]).all()
+    assert P.rel_err(ga["transforms"]["position"], ref["transforms"]["position"][1:]).max() <= 5e-2
+    for q in pa + pb:
+        assert q.e.counts()["error"] == 0
+        q.close(); q.e.close()
+    single.close()
