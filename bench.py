@@ -44,6 +44,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+EPOCH = 32                     # steps between two refreshes of the partitioned world (migration, ghost lists): nudge_amd/partition.py
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
 C2_BODIES = 1004400
 
@@ -378,7 +379,7 @@ def main():
         scene, info = PT.split_scene(g, cuts, rank, static_margin=64.0)
         del g, gx
         sharding = (f"{world} x-slabs of one {total}-tile world ({total * args.side * args.side:,} bodies), ghost halo exchange every step "
-                    f"({'RCCL' if backend == 'nccl' else backend} p2p), refresh + migration every 16 steps")
+                    f"({'RCCL' if backend == 'nccl' else backend} p2p), refresh + migration every {EPOCH} steps")
     elif args.scene in ("boxes", "mixed"):
         # every rank owns its own lattice of independent tiles (different seed per rank)
         scene = S.grid_tiles(args.tiles, side=args.side, sphere_fraction=sphere_fraction, seed=(2 if args.scene == "boxes" else 3) + 1000 * rank,
@@ -400,7 +401,7 @@ def main():
     if halo:
         # (the partitioned step keeps the sample's call order -- the halo arrives before nh_collide -- so gravity and advance fuse into the solver here too)
         w = E.World(scene, device=device_index, flags=E.NH_FLAG_SINGLE_APPLY | (0 if os.environ.get("NUDGE_BENCH_NO_FUSED") else E.NH_FLAG_FUSED_STEP), capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=6 * info["capacity"]["bodies"])
-        cluster = PT.DistCluster(PT.Partition(w, info, epoch=16), host_staging=(backend != "nccl"), loopback=4096 if loopback else 0)
+        cluster = PT.DistCluster(PT.Partition(w, info, epoch=EPOCH), host_staging=(backend != "nccl"), loopback=4096 if loopback else 0)
     else:
         w = E.World(scene, device=device_index, flags=E.NH_FLAG_SINGLE_APPLY | E.NH_FLAG_FUSED_STEP, max_contacts=max(4096, (6 if args.scene != "pit" else 5) * nb),
                     max_pairs=None if args.scene != "pit" else 7 * nb)

@@ -336,8 +336,11 @@ class World:
         by the library itself, one crossing of the ABI for all the steps; the others (NH_FLAG_SYNC_COUNTS: `sum_contacts` is kept per step) make the eight calls here."""
         if steps > 0 and not (self.flags & NH_FLAG_SYNC_COUNTS) and not getattr(self, "eight_calls", False):
             p = self.params
-            args = StepArgs(C.pointer(self.active), C.pointer(self.contacts), C.pointer(self.bodies), C.pointer(self.colliders), C.pointer(self.connections), C.pointer(self.cache), self.arena,
-                            p["time_step"], (C.c_float * 3)(0.0, p["gravity"], 0.0), p["damping_rate"], p["iterations"] if iterations is None else iterations)
+            it = p["iterations"] if iterations is None else iterations
+            args = getattr(self, "_step_args", None)
+            if args is None or args.iterations != it:          # (the structs it points to are this object's own: counts changed by set_counts are seen through the pointers)
+                args = self._step_args = StepArgs(C.pointer(self.active), C.pointer(self.contacts), C.pointer(self.bodies), C.pointer(self.colliders), C.pointer(self.connections),
+                                                  C.pointer(self.cache), self.arena, p["time_step"], (C.c_float * 3)(0.0, p["gravity"], 0.0), p["damping_rate"], it)
             _check(self.L, self.L.nh_step(self.ctx, C.byref(args), steps), "nh_step")
             self.steps_done += steps
             return

@@ -700,6 +700,28 @@ class DistCluster:
         self.host_staging = host_staging
         self.loopback = int(loopback)
         self.loopback_records = 0
+        self._step_plan = None              # per-step exchange of a HIP partition: send / receive buffers and the P2P ops, built once per refresh
+
+    def _fast_step_exchange(self):
+        """The per-step halo of a partition on the C ABI, device tensors, lengths fixed since the last refresh: the message buffers and the list of point-to-point ops
+        are built once per refresh; a step is pack (one C call), batch_isend_irecv on the prepared ops, unpack (one C call)."""
+        t, dist, p = self.torch, self.dist, self.p
+        if self._step_plan is None or self._step_plan[0] != p.stats["refreshes"]:
+            home = p.bt.device
+            ins = {d: t.empty((p.ghost_in[d], STEP_BYTES), dtype=t.uint8, device=home) for d in p.neighbours()}
+            ops = []
+            for d in p.neighbours():
+                if p._stepbuf[d].shape[0]:
+                    ops.append(dist.P2POp(dist.isend, p._stepbuf[d], p.rank + d, self.group))
+                if p.ghost_in[d]:
+                    ops.append(dist.P2POp(dist.irecv, ins[d], p.rank + d, self.group))
+            self._step_plan = (p.stats["refreshes"], ins, ops)
+        _, ins, ops = self._step_plan
+        p.step_pack()
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        p.step_unpack(ins)
 
     def _loopback(self):
         t, dist, p = self.torch, self.dist, self.p
@@ -764,6 +786,8 @@ class DistCluster:
                     p.balance_unpack_cuts(self._exchange(p.balance_pack_cuts(), 8, known_counts=p.balance_expected()))
                 p.refresh_unpack_migrants(self._exchange(p.refresh_pack_migrants(), FULL_BYTES))
                 p.refresh_unpack_ghosts(self._exchange(p.refresh_pack_ghosts(), FULL_BYTES))
+            elif p.hip is not None and not self.host_staging:
+                self._fast_step_exchange()
             else:
                 p.step_unpack(self._exchange(p.step_pack(), STEP_BYTES, known_counts={d: p.ghost_in[d] for d in p.neighbours()}))
             if self.loopback:
