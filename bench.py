@@ -402,6 +402,10 @@ def main():
         # (the partitioned step keeps the sample's call order -- the halo arrives before nh_collide -- so gravity and advance fuse into the solver here too)
         w = E.World(scene, device=device_index, flags=E.NH_FLAG_SINGLE_APPLY | (0 if os.environ.get("NUDGE_BENCH_NO_FUSED") else E.NH_FLAG_FUSED_STEP), capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=6 * info["capacity"]["bodies"])
         cluster = PT.DistCluster(PT.Partition(w, info, epoch=EPOCH), host_staging=(backend != "nccl"), loopback=4096 if loopback else 0)
+        # the per-step halo driven by the library over its own RCCL communicator (pack, ncclSend / ncclRecv, unpack in one C call); checked with a pattern exchange
+        # under a time-out and agreed on by all ranks -- any doubt keeps the torch.distributed point-to-point transport (NUDGE_BENCH_RCCL_DIRECT=0 forces that)
+        if backend == "nccl" and os.environ.get("NUDGE_BENCH_RCCL_DIRECT", "1") != "0":
+            cluster.use_rccl_direct(device_index, loopback=loopback)
     else:
         w = E.World(scene, device=device_index, flags=E.NH_FLAG_SINGLE_APPLY | E.NH_FLAG_FUSED_STEP, max_contacts=max(4096, (6 if args.scene != "pit" else 5) * nb),
                     max_pairs=None if args.scene != "pit" else 7 * nb)
@@ -664,7 +668,7 @@ def main():
                 out["speedup_vs_single_gpu_same_world"] = value / one["value"]
         if cluster is not None:
             st = cluster.p.stats
-            out["halo"] = {"backend": backend, "loopback_records_per_step": (cluster.loopback_records / max(1, cluster.p.steps)) if loopback else None,
+            out["halo"] = {"backend": backend, "per_step_transport": ("library-driven RCCL (nh_partition_exchange_step)" if cluster.direct else f"torch.distributed point-to-point ({cluster.direct_why or 'not asked'})"), "loopback_records_per_step": (cluster.loopback_records / max(1, cluster.p.steps)) if loopback else None,
                            "ghost_bodies_rank0": st["ghosts"], "refreshes": st["refreshes"], "migrated_out_rank0": st["migrated_out"],
                            "bytes_sent_per_step_rank0": st["step_bytes"] / max(1, cluster.p.steps)}
         print(json.dumps(out))

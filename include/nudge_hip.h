@@ -349,6 +349,16 @@ int nh_partition_unpack_ghosts(nh_partition* p, nh_BodyData* bodies, nh_Collider
 /* Every other step: NH_HALO_RECORD_BYTES per listed body (nh_halo_pack's record); lengths are those of the last refresh (nh_partition_info: ghost_out / ghost_in). */
 int nh_partition_pack_step(nh_partition* p, const nh_BodyData* bodies, void* out_left, void* out_right);
 int nh_partition_unpack_step(nh_partition* p, const nh_BodyData* bodies, const void* in_left, const void* in_right);
+/* The per-step halo driven by the library: nh_partition_exchange_step = pack -> ncclGroupStart; ncclSend / ncclRecv with both neighbours; ncclGroupEnd -> unpack, all
+   enqueued on the context's stream in ONE call (the host's share of a step shrinks to two calls: this one and nh_step).  The library does not link RCCL: the host hands
+   it an ncclComm_t of the world's ranks and the addresses of ncclGroupStart / ncclGroupEnd / ncclSend / ncclRecv of the RCCL library its process has loaded
+   (nh_partition_set_transport; left_peer / right_peer: communicator ranks of the neighbours, -1 = none).  nh_partition_transport_check sends a pattern to both peers and
+   receives theirs in one group (a peer equal to the own rank: a loop-back on one GPU); with enqueue_only the host polls the stream itself -- a neighbour that never answers must not hang
+   it -- and fetches the verdict with nh_partition_transport_result. */
+int nh_partition_set_transport(nh_partition* p, void* comm, void* group_start, void* group_end, void* send, void* recv, int left_peer, int right_peer);
+int nh_partition_exchange_step(nh_partition* p, const nh_BodyData* bodies);
+int nh_partition_transport_check(nh_partition* p, uint32_t bytes, int enqueue_only);
+int nh_partition_transport_result(nh_partition* p);
 /* Re-balancing ("move cuts when |count_r - mean| > 5 %").  The two ranks at a cut tell each other how many bodies they own (transport: caller); when the
    counts differ by more than `tolerance` of their sum the HEAVIER side calls nh_partition_choose_cut(direction, neighbour's count) -- the x that hands half the
    difference, at most 5 % of its bodies, to the neighbour; it moves its own cut and returns it -- and sends the value over; the lighter side calls nh_partition_set_cut.

@@ -40,6 +40,11 @@ struct nh_partition {
 	nh_FullRecord* stage;
 	nh_PartDev* d; nh_PartDev* h;
 	bool leavers_flagged;
+	// optional transport for the PER-STEP halo (nh_partition_set_transport): an RCCL communicator and the five RCCL entry points, handed in by the host as plain
+	// pointers -- the library neither links nor loads RCCL itself, it calls what the host's process has already loaded
+	struct { void* comm; int (*group_start)(void); int (*group_end)(void);
+	         int (*send)(const void*, size_t, int, int, void*, hipStream_t); int (*recv)(void*, size_t, int, int, void*, hipStream_t); int peer[2]; } rccl;
+	void* step_out[2]; void* step_in[2]; uint32_t step_cap[2][2];      // message buffers of the per-step halo, [side][out / in], grown at refreshes
 };
 
 #define NP_CHECK(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (ctx)->last_hip_error = (int)e_; return NH_ERR_HIP; } } while (0)
@@ -289,6 +294,7 @@ extern "C" void nh_partition_destroy(nh_partition* p) {
 	if (!p) return;
 	hipSetDevice(p->ctx->device);
 	hipStreamSynchronize(p->ctx->stream);
+	for (int side = 0; side < 2; ++side) { if (p->step_out[side]) hipFree(p->step_out[side]); if (p->step_in[side]) hipFree(p->step_in[side]); }
 	void* bufs[] = { p->shape, p->cxf, p->tag, p->nbx, p->nsp, p->reach, p->list[0], p->list[1], p->flag[0], p->flag[1], p->scan_tmp, p->sort_a, p->sort_b, p->sort_va, p->sort_vb, p->sort_hist, p->stage, p->d };
 	for (void* b : bufs) if (b) hipFree(b);
 	if (p->h) hipHostFree(p->h);
@@ -459,3 +465,78 @@ extern "C" int nh_partition_set_cut(nh_partition* p, int direction, double cut) 
 	if (cut != old) { if (direction < 0) p->lo = cut; else p->hi = cut; p->cut_moves++; }
 	return NH_OK;
 }
+
+// ---- the per-step halo through RCCL, driven from here (one call per step instead of pack / host-side transport / unpack) -------------------------------------
+// `comm`: an ncclComm_t of the ranks of this world, in rank order; the four functions: ncclGroupStart, ncclGroupEnd, ncclSend, ncclRecv of the RCCL library the
+// host process has loaded (plain pointers: nothing of RCCL is linked into or loaded by libnudge_hip.so).  left_peer / right_peer: the communicator ranks of the two
+// neighbours (-1: none).
+extern "C" int nh_partition_set_transport(nh_partition* p, void* comm, void* group_start, void* group_end, void* send, void* recv, int left_peer, int right_peer) {
+	if (!p) return NH_ERR_INVALID;
+	if (comm && (!group_start || !group_end || !send || !recv)) return NH_ERR_INVALID;
+	p->rccl.comm = comm;
+	p->rccl.group_start = reinterpret_cast<int (*)(void)>(group_start); p->rccl.group_end = reinterpret_cast<int (*)(void)>(group_end);
+	p->rccl.send = reinterpret_cast<int (*)(const void*, size_t, int, int, void*, hipStream_t)>(send);
+	p->rccl.recv = reinterpret_cast<int (*)(void*, size_t, int, int, void*, hipStream_t)>(recv);
+	p->rccl.peer[0] = left_peer; p->rccl.peer[1] = right_peer;
+	return NH_OK;
+}
+
+static int part_step_buffer(nh_partition* p, int side, int io, uint32_t records) {
+	if (p->step_cap[side][io] >= records && (io ? p->step_in[side] : p->step_out[side])) return NH_OK;
+	void** buf = io ? &p->step_in[side] : &p->step_out[side];
+	if (*buf) { hipStreamSynchronize(p->ctx->stream); hipFree(*buf); *buf = nullptr; }
+	const uint32_t cap = records + records / 4u + 256u;
+	if (hipMalloc(buf, (size_t)cap * NH_HALO_RECORD_BYTES) != hipSuccess) return NH_ERR_HIP;
+	p->step_cap[side][io] = cap;
+	return NH_OK;
+}
+
+// pack -> ncclGroupStart; ncclSend / ncclRecv with both neighbours; ncclGroupEnd -> unpack, all on the context's stream, lengths those of the last refresh
+extern "C" int nh_partition_exchange_step(nh_partition* p, const nh_BodyData* bodies) {
+	if (!p || !bodies || !p->rccl.comm) return NH_ERR_INVALID;
+	nh_context* ctx = p->ctx;
+	NP_CHECK(ctx, hipSetDevice(ctx->device));
+	for (int side = 0; side < 2; ++side) {
+		if (p->ghost_out[side]) { int rc = part_step_buffer(p, side, 0, p->ghost_out[side]); if (rc) return rc; }
+		if (p->ghost_in[side]) { int rc = part_step_buffer(p, side, 1, p->ghost_in[side]); if (rc) return rc; }
+	}
+	{ int rc = nh_partition_pack_step(p, bodies, p->step_out[0], p->step_out[1]); if (rc) return rc; }
+	if (p->rccl.group_start()) return NH_ERR_HIP;
+	for (int side = 0; side < 2; ++side) {
+		const int peer = p->rccl.peer[side];
+		if (peer < 0) continue;
+		if (p->ghost_out[side] && p->rccl.send(p->step_out[side], (size_t)p->ghost_out[side] * NH_HALO_RECORD_BYTES, 1 /* ncclUint8 */, peer, p->rccl.comm, ctx->stream)) return NH_ERR_HIP;
+		if (p->ghost_in[side] && p->rccl.recv(p->step_in[side], (size_t)p->ghost_in[side] * NH_HALO_RECORD_BYTES, 1, peer, p->rccl.comm, ctx->stream)) return NH_ERR_HIP;
+	}
+	if (p->rccl.group_end()) return NH_ERR_HIP;
+	return nh_partition_unpack_step(p, bodies, p->step_in[0], p->step_in[1]);
+}
+
+// transport check: `bytes` of a pattern to both peers and from both (a peer equal to this rank: a loop-back) through the functions handed in, one group; 0 = what
+// came back is what each peer sent (the pattern carries the sender's rank).  Synchronises the stream; the host decides what a time-out is (it can poll an event instead: see bench.py).
+__global__ void k_part_pattern(uint32_t* buf, uint32_t n, uint32_t rank) { for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) buf[i] = (rank << 24) ^ (i * 2654435761u); }
+__global__ void k_part_pattern_check(const uint32_t* buf, uint32_t n, uint32_t rank, nh_PartDev* dv) { for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) if (buf[i] != ((rank << 24) ^ (i * 2654435761u))) dv->error = NH_ERR_INVALID; }
+extern "C" int nh_partition_transport_check(nh_partition* p, uint32_t bytes, int enqueue_only) {
+	if (!p || !p->rccl.comm || bytes < 4u) return NH_ERR_INVALID;
+	nh_context* ctx = p->ctx;
+	NP_CHECK(ctx, hipSetDevice(ctx->device));
+	const uint32_t records = (bytes + NH_HALO_RECORD_BYTES - 1u) / NH_HALO_RECORD_BYTES, words = bytes / 4u;
+	for (int side = 0; side < 2; ++side) if (p->rccl.peer[side] >= 0) {
+		{ int rc = part_step_buffer(p, side, 0, records); if (rc) return rc; }
+		{ int rc = part_step_buffer(p, side, 1, records); if (rc) return rc; }
+	}
+	hipLaunchKernelGGL(k_part_reset, dim3(1), dim3(1), 0, ctx->stream, p->d);
+	for (int side = 0; side < 2; ++side) if (p->rccl.peer[side] >= 0)
+		hipLaunchKernelGGL(k_part_pattern, dim3(64), dim3(256), 0, ctx->stream, (uint32_t*)p->step_out[side], words, p->cfg.rank);
+	if (p->rccl.group_start()) return NH_ERR_HIP;
+	for (int side = 0; side < 2; ++side) if (p->rccl.peer[side] >= 0) {
+		if (p->rccl.send(p->step_out[side], (size_t)words * 4u, 1, p->rccl.peer[side], p->rccl.comm, ctx->stream)) return NH_ERR_HIP;
+		if (p->rccl.recv(p->step_in[side], (size_t)words * 4u, 1, p->rccl.peer[side], p->rccl.comm, ctx->stream)) return NH_ERR_HIP;
+	}
+	if (p->rccl.group_end()) return NH_ERR_HIP;
+	for (int side = 0; side < 2; ++side) if (p->rccl.peer[side] >= 0)
+		hipLaunchKernelGGL(k_part_pattern_check, dim3(64), dim3(256), 0, ctx->stream, (const uint32_t*)p->step_in[side], words, (uint32_t)p->rccl.peer[side], p->d);
+	if (enqueue_only) return NH_OK;            // (the caller polls the stream and then calls nh_partition_transport_result)
+	return part_read_back(p);
+}
+extern "C" int nh_partition_transport_result(nh_partition* p) { return p ? part_read_back(p) : NH_ERR_INVALID; }

@@ -35,6 +35,7 @@ EXPORTS = [
     "nh_halo_pack", "nh_halo_unpack", "nh_halo_update", "nh_append_contacts", "nh_step",
     "nh_partition_create", "nh_partition_destroy", "nh_partition_info", "nh_partition_pack_migrants", "nh_partition_unpack_migrants", "nh_partition_pack_ghosts",
     "nh_partition_unpack_ghosts", "nh_partition_pack_step", "nh_partition_unpack_step", "nh_partition_choose_cut", "nh_partition_set_cut",
+    "nh_partition_set_transport", "nh_partition_exchange_step", "nh_partition_transport_check", "nh_partition_transport_result",
 ]
 HALO_RECORD_BYTES = 64
 
@@ -166,6 +167,10 @@ def lib():
         L.nh_partition_unpack_step.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_void_p, C.c_void_p]
         L.nh_partition_choose_cut.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_int, C.c_uint32, C.POINTER(C.c_double)]
         L.nh_partition_set_cut.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        L.nh_partition_set_transport.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.nh_partition_exchange_step.argtypes = [C.c_void_p, C.POINTER(BodyData)]
+        L.nh_partition_transport_check.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+        L.nh_partition_transport_result.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 

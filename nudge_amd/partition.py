@@ -461,6 +461,7 @@ class Partition:
             dev = self.bt.device
             for d in self.neighbours():
                 self._stepbuf[d] = self.torch.empty((out[d].shape[0], STEP_BYTES), dtype=self.torch.uint8, device=dev)
+            self._ghost_out_total = sum(int(out[d].shape[0]) for d in self.neighbours())
             return out
         t = self.torch
         n = self.n_owned + 1
@@ -684,6 +685,87 @@ class LocalCluster:
                     momentum=np.concatenate([q[2] for q in parts])[order], idle=np.concatenate([q[3] for q in parts])[order])
 
 
+class RcclDirect:
+    """An RCCL communicator of this job's ranks created through ctypes on the RCCL library the process has ALREADY loaded (torch's), for the library-driven per-step
+    halo (include/nudge_hip.h: nh_partition_set_transport / nh_partition_exchange_step): the unique id travels over torch.distributed, the four entry points the
+    library calls are handed to it as plain addresses.  Everything here may fail (no RCCL library found, a rank that does not answer): `ok` then stays False and the
+    caller keeps the torch.distributed transport."""
+
+    def __init__(self, dist, group, device, timeout_s=60.0):
+        import ctypes as C
+        self.ok, self.why, self.comm, self.lib = False, "", None, None
+        try:
+            import torch
+            path = None
+            try:
+                for line in open("/proc/self/maps"):
+                    if "librccl" in line:
+                        path = line.split()[-1]
+                        break
+            except OSError:
+                pass
+            self.lib = C.CDLL(path or "librccl.so")
+            self.path = path or "librccl.so"
+
+            class UniqueId(C.Structure):
+                _fields_ = [("internal", C.c_char * 128)]
+            self.lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+            self.lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+            uid = UniqueId()
+            if rank == 0:
+                rc = self.lib.ncclGetUniqueId(C.byref(uid))
+                if rc:
+                    raise RuntimeError(f"ncclGetUniqueId: {rc}")
+            red = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+            t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone().to(red)
+            dist.broadcast(t, src=0, group=group)
+            C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+            torch.cuda.set_device(device)
+            comm = C.c_void_p()
+            rc = self.lib.ncclCommInitRank(C.byref(comm), world, uid, rank)
+            if rc:
+                raise RuntimeError(f"ncclCommInitRank: {rc}")
+            self.comm, self.rank, self.world = comm, rank, world
+            self.fn = [C.cast(getattr(self.lib, n), C.c_void_p) for n in ("ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv")]
+            self.ok = True
+        except Exception as e:          # noqa: BLE001 -- any failure means "use the torch transport"
+            self.why = repr(e)
+
+    def attach(self, partition, loopback=False, timeout_s=60.0):
+        """Hands communicator and entry points to the partition's library object and checks both neighbours with a pattern exchange, polled with a time-out so that a
+        neighbour that never answers cannot hang the job.  Returns True when the library-driven exchange may be used."""
+        import time
+        import ctypes as C
+        from . import engine as E
+        p = partition
+        if not self.ok or p.hip is None:
+            return False
+        left = p.rank - 1 if p.rank > 0 else -1
+        right = p.rank + 1 if p.rank + 1 < p.ranks else (self.rank if loopback else -1)
+        L = p.e.L
+        if L.nh_partition_set_transport(p.hip, self.comm, *self.fn, left, right):
+            return False
+        if left < 0 and right < 0:
+            return True
+        if L.nh_partition_transport_check(p.hip, 1 << 16, 1):
+            L.nh_partition_set_transport(p.hip, None, None, None, None, None, -1, -1)
+            return False
+        stream = p.torch.cuda.current_stream(p.bt.device)
+        t0 = time.time()
+        while not stream.query():
+            if time.time() - t0 > timeout_s:
+                self.why = "transport check timed out"
+                L.nh_partition_set_transport(p.hip, None, None, None, None, None, -1, -1)
+                return False
+            time.sleep(0.001)
+        if L.nh_partition_transport_result(p.hip):
+            self.why = "transport check: wrong data"
+            L.nh_partition_set_transport(p.hip, None, None, None, None, None, -1, -1)
+            return False
+        return True
+
+
 class DistCluster:
     """One partition per process; neighbour messages over torch.distributed point-to-point ops
     (backend "nccl" = RCCL over xGMI for GPU tensors, "gloo" for the CPU tests)."""
@@ -701,6 +783,24 @@ class DistCluster:
         self.loopback = int(loopback)
         self.loopback_records = 0
         self._step_plan = None              # per-step exchange of a HIP partition: send / receive buffers and the P2P ops, built once per refresh
+        self.direct = False                 # the per-step halo is driven by the library over its own RCCL communicator (use_rccl_direct)
+        self.direct_why = ""
+
+    def use_rccl_direct(self, device, loopback=False):
+        """Per-step halo through nh_partition_exchange_step (pack, ncclSend / ncclRecv, unpack in ONE library call) instead of torch.distributed point-to-point ops: the
+        host's share of a step shrinks to two C calls.  Every rank must end up with the same answer, so the outcome is agreed on with an all-reduce; any doubt -> False."""
+        t, dist, p = self.torch, self.dist, self.p
+        r = RcclDirect(dist, self.group, device)
+        ok = r.attach(p, loopback=loopback)
+        red = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        flag = t.tensor([1.0 if ok else 0.0], device=red)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        self.direct = bool(flag.item() > 0.5)
+        self.direct_why = r.why
+        self._rccl = r                      # (keeps library and communicator alive)
+        if not self.direct and ok:
+            p.e.L.nh_partition_set_transport(p.hip, None, None, None, None, None, -1, -1)
+        return self.direct
 
     def _fast_step_exchange(self):
         """The per-step halo of a partition on the C ABI, device tensors, lengths fixed since the last refresh: the message buffers and the list of point-to-point ops
@@ -729,19 +829,33 @@ class DistCluster:
         if m <= 0:
             return
         home = p.bt.device
-        idx = t.arange(1, 1 + m, dtype=t.int32, device=home)
-        rec = p._step_records(idx.to(t.int64), idx)
-        dev = t.device("cpu") if self.host_staging else home
-        out = rec.to(dev).contiguous()
-        back = t.empty_like(out)
-        me = dist.get_rank(self.group)
-        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, out, me, self.group), dist.P2POp(dist.irecv, back, me, self.group)]):
-            w.wait()
-        back = back.to(home)
-        if hasattr(p.e, "halo_unpack"):
-            p.e.halo_unpack(1, back.contiguous(), same_bodies=True)
+        plan = getattr(self, "_loop_plan", None)
+        if plan is None or plan[0] != m:
+            # (buffers and ops built once, like the per-step exchange with real neighbours: _fast_step_exchange)
+            idx = t.arange(1, 1 + m, dtype=t.int32, device=home)
+            dev = t.device("cpu") if self.host_staging else home
+            out = t.empty((m, STEP_BYTES), dtype=t.uint8, device=home)
+            back = t.empty((m, STEP_BYTES), dtype=t.uint8, device=dev)
+            me = dist.get_rank(self.group)
+            stage = out if not self.host_staging else t.empty((m, STEP_BYTES), dtype=t.uint8, device=dev)
+            ops = [dist.P2POp(dist.isend, stage, me, self.group), dist.P2POp(dist.irecv, back, me, self.group)]
+            plan = self._loop_plan = (m, idx, out, stage, back, ops)
+        _, idx, out, stage, back, ops = plan
+        if hasattr(p.e, "L") and hasattr(p.e, "ctx"):
+            import ctypes as C
+            from . import engine as E
+            E._check(p.e.L, p.e.L.nh_halo_pack(p.e.ctx, C.byref(p.e.bodies), C.c_void_p(idx.data_ptr()), m, C.c_void_p(out.data_ptr())), "halo_pack")
         else:
-            p.bt[1:1 + m, :12] = back[:, :12]; p.bt[1:1 + m, 16:] = back[:, 12:28]; p.bm[1:1 + m] = back[:, 28:60]; p.bi[1:1 + m, 0] = back[:, 60]
+            out.copy_(p._step_records(idx.to(t.int64), idx))
+        if self.host_staging:
+            stage.copy_(out)
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        rec = back.to(home) if self.host_staging else back
+        if hasattr(p.e, "halo_unpack"):
+            p.e.halo_unpack(1, rec, same_bodies=True)
+        else:
+            p.bt[1:1 + m, :12] = rec[:, :12]; p.bt[1:1 + m, 16:] = rec[:, 12:28]; p.bm[1:1 + m] = rec[:, 28:60]; p.bi[1:1 + m, 0] = rec[:, 60]
         self.loopback_records += m
 
     def _exchange(self, out, widths=None, known_counts=None):
@@ -786,6 +900,11 @@ class DistCluster:
                     p.balance_unpack_cuts(self._exchange(p.balance_pack_cuts(), 8, known_counts=p.balance_expected()))
                 p.refresh_unpack_migrants(self._exchange(p.refresh_pack_migrants(), FULL_BYTES))
                 p.refresh_unpack_ghosts(self._exchange(p.refresh_pack_ghosts(), FULL_BYTES))
+            elif self.direct:
+                import ctypes as C
+                from . import engine as E
+                E._check(p.e.L, p.e.L.nh_partition_exchange_step(p.hip, C.byref(p.e.bodies)), "nh_partition_exchange_step")
+                p.stats["step_bytes"] += STEP_BYTES * getattr(p, "_ghost_out_total", 0)
             elif p.hip is not None and not self.host_staging:
                 self._fast_step_exchange()
             else:

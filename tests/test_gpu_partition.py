@@ -173,6 +173,9 @@ def test_bench_under_torchrun_with_one_rank_executes_rccl_point_to_point():
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["contacts_per_step"] > 0.9 * 4 * 8 * 45 * 45, out
     assert out["halo"]["backend"] == "nccl" and out["halo"]["loopback_records_per_step"] == 4096, out["halo"]
+    # ... and the library-driven transport: an RCCL communicator of its own created through ctypes on the RCCL library torch has loaded, ncclGroupStart / ncclSend /
+    # ncclRecv / ncclGroupEnd called by libnudge_hip.so through the addresses it was handed, checked with a pattern sent to this same rank
+    assert out["halo"]["per_step_transport"].startswith("library-driven RCCL"), out["halo"]
 
 
 def _two_clusters(scene, ranks, epoch, flags, **kw):
