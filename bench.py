@@ -401,7 +401,7 @@ def main():
     if halo:
         # (the partitioned step keeps the sample's call order -- the halo arrives before nh_collide -- so gravity and advance fuse into the solver here too)
         w = E.World(scene, device=device_index, flags=E.NH_FLAG_SINGLE_APPLY | (0 if os.environ.get("NUDGE_BENCH_NO_FUSED") else E.NH_FLAG_FUSED_STEP), capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=6 * info["capacity"]["bodies"])
-        cluster = PT.DistCluster(PT.Partition(w, info, epoch=EPOCH), host_staging=(backend != "nccl"), loopback=4096 if loopback else 0)
+        cluster = PT.DistCluster(PT.Partition(w, info, epoch=EPOCH), host_staging=(backend != "nccl"), loopback=int(os.environ.get("NUDGE_BENCH_LOOPBACK_RECORDS", "4096")) if loopback else 0)
         # the per-step halo driven by the library over its own RCCL communicator (pack, ncclSend / ncclRecv, unpack in one C call); checked with a pattern exchange
         # under a time-out and agreed on by all ranks -- any doubt keeps the torch.distributed point-to-point transport (NUDGE_BENCH_RCCL_DIRECT=0 forces that)
         if backend == "nccl" and os.environ.get("NUDGE_BENCH_RCCL_DIRECT", "1") != "0":
