@@ -50,15 +50,20 @@
  *      bookkeeping again; fields of existing contacts (friction, penetration ...) may simply be edited in place.
  *      One nh_setup_contact_constraints per nh_collide (a second one returns NH_ERR_STALE_SETUP).
  *
- *   9. Still steps (NH_FLAG_FUSED_STEP without NH_FLAG_SYNC_COUNTS / NH_FLAG_EXACT_ORDER).  A world at rest on static geometry repeats itself: the same pairs, the
- *      same contacts in the same order, the cache equal to last step's contact list.  When a step ended in that state the library launches the NEXT one
- *      speculatively as a "still" step: three kernels (transforms + AABBs, narrowphase straight from the kept pair list into the caller's contact list, the
- *      fused solver reading and writing the cache in place) that CHECK everything they rely on -- nobody outside its inflated box or asleep, every collider
- *      pair with the key, contact count and feature words it had, body 0 inert -- instead of the ~30 launches that would find it out again.  A failed check is
- *      reported with the step's one host round trip (inside nh_apply_impulses), before anything but contact data has been written, and the step is run again in
- *      full from nh_collide's arguments: results are bit-identical to a library that never speculates (NH_NO_STILL=1), which the tests check.  Any entry point
- *      outside the sample's call order (nh_read_counts, nh_synchronize, nh_append_contacts ...) between nh_collide and nh_apply_impulses turns the step
- *      into a full one first, so everything it observes is what a full step produces.  nh_Counts.still_steps / still_replays count them.
+ *   9. Still steps (NH_FLAG_FUSED_STEP without NH_FLAG_SYNC_COUNTS / NH_FLAG_EXACT_ORDER).  A world at rest on static geometry repeats itself: the same pairs at
+ *      the same places of the kept pair list, the same tag order, nearly the same contacts.  When a step ended in that state the library launches the NEXT one
+ *      speculatively as a "still" step: transforms + AABBs, the narrowphase straight from the kept pair list into the pairs' own contact slots (library-owned),
+ *      the fused solver reading those slots and a slot-indexed copy of the warm-start cache -- three kernels that CHECK everything they rely on (nobody outside
+ *      its inflated box or asleep, every collider pair with the key it had, at most four contacts per body, all of them against the inert static world) instead
+ *      of the ~25 launches that would find it out again.  A pair that gains or loses a contact is listed and the places of the contacts behind it shift (the
+ *      solver order of nudge.cpp:4206-4339 is a function of a contact's dense tag-order index, which stays exact).  A failed check is reported with the step's
+ *      one host round trip before anything irreversible has been written, and the step is run again in full from nh_collide's arguments: results are
+ *      bit-identical to a library that never speculates (option "no_still"), which the tests check.
+ *      The caller's dense contact list (contacts->data / bodies / tags / features) and contact cache are VIEWS of the slots under this regime: they are
+ *      brought up to date by every entry point that lets the caller observe them -- nh_read_counts, nh_synchronize, nh_append_contacts, and any step that
+ *      does not qualify -- not by every step.  Call nh_synchronize before reading them from the device yourself.  Any entry point outside the sample's
+ *      call order between nh_collide and nh_apply_impulses turns a still step into a full one first, so everything it observes is what a full step
+ *      produces.  nh_Counts.still_steps / still_replays count them.
  *
  * Threading: one context = one HIP stream = one world at a time; no global mutable state.
  */
