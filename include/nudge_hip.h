@@ -370,6 +370,13 @@ int nh_partition_transport_result(nh_partition* p);
    The bodies in between migrate with the refresh that follows.  direction: -1 = the cut towards the left neighbour, +1 = towards the right. */
 int nh_partition_choose_cut(nh_partition* p, const nh_BodyData* bodies, int direction, uint32_t neighbour_owned, double* cut);
 int nh_partition_set_cut(nh_partition* p, int direction, double cut);
+/* One owner per contact that crosses a cut (SURVEY 8(e) "determinism rule": the contact is owned by the rank owning the body with the larger collider tag, mirroring the
+   a > b canonicalisation of nudge.cpp:2074-2087 / 2131-2132).  With first_ghost > 0 the bodies [first_ghost, count) of the context's world are ghosts and nh_collide makes
+   contacts only for collider pairs this rank owns: a pair with the static world belongs to its dynamic body, a pair of two dynamic bodies to the body whose collider has the
+   larger tag -- if that body is a ghost here, the pair yields no contact on this rank (the rank that owns the body solves it).  The host returns what the solver did to the
+   ghosts (momentum after a sweep minus before) to their owners and refreshes the ghosts from the owners after every nh_apply_impulses(..., 1): nudge_amd/partition.py
+   `Partition(per_iteration=True, single_owner=True)`.  0 switches the rule off.  Still steps (note 9) are not launched while it is on. */
+int nh_set_first_ghost_body(nh_context* ctx, uint32_t first_ghost);
 
 /* ---- introspection for tests / measurement --------------------------------------------------------- */
 /* Device pointer to the per-contact warm-start impulses of an nh_ContactImpulseData (K x 16 B, contact order). */

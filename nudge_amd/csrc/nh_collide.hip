@@ -876,6 +876,8 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
                                                      nh_Contact* __restrict__ raw_data, uint32_t* __restrict__ raw_feature, uint32_t pair_cap, uint32_t overflow_cap,
                                                      uint64_t* __restrict__ rec_key, nh_Record* __restrict__ rec, uint32_t* __restrict__ rec_idx,
                                                      const uint32_t* __restrict__ coarse_root, const uint32_t* __restrict__ coarse_active, uint32_t parity,
+                                                     // contact ownership of a partitioned world (nh_set_first_ghost_body): bodies >= first_ghost are ghosts; 0 = off
+                                                     uint32_t first_ghost,
                                                      // STILL only: the kept list (`pairs`) and its capacity, this step's exact AABBs, the stamps, tag-order positions / counts, the bodies' records
                                                      uint32_t kept_cap = 0u, const float4* __restrict__ aabb_min = nullptr, const float4* __restrict__ aabb_max = nullptr,
                                                      const uint8_t* __restrict__ gen = nullptr, const uint32_t* __restrict__ lay_rank = nullptr, uint32_t* __restrict__ cnt_sorted = nullptr,
@@ -995,6 +997,14 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 				count = nh_box_sphere(sz.size, sph_data[sp - nbox].radius, A, B, &single);
 				key = (uint64_t)ctag[bx] | ((uint64_t)ctag[sp] << 32);
 				body_a = A.body; body_b = B.body;
+			}
+			// one owner per contact in a partitioned world ("contact owned by the rank owning the body with the larger collider tag", the a > b
+			// canonicalisation of nudge.cpp:2074-2087): a pair with the static world belongs to its dynamic body, a pair of two dynamic bodies to the body of
+			// the collider with the larger tag; a pair whose owner is a ghost here is solved by the rank that owns that body and makes no contact on this one
+			if (!STILL && first_ghost && count) {
+				const uint32_t ba = xf[a].body, bb2 = xf[b].body;
+				const uint32_t owner = ba == 0u ? bb2 : (bb2 == 0u ? ba : (ctag[a] > ctag[b] ? ba : bb2));
+				if (owner >= first_ghost) { count = 0; bb.kind = 0; }
 			}
 		}
 		if (SPH) {
@@ -1409,7 +1419,7 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	ss.active = false; ss.resolved = false; ss.setup_d = nullptr;
 	// A still step?  The last step must have left everything one relies on (ok_next: decided at its round trip), the contact cache must be that step's contact
 	// list, the caller must be in the mode that promises the sample's call order, and the world must be the one the kept layout describes.
-	const bool want_still = !ss.disabled && ss.ok_next && ss.cache_ok && ss.slots_current && !ss.appended && (ctx->flags & NH_FLAG_FUSED_STEP) && !(ctx->flags & (NH_FLAG_SYNC_COUNTS | NH_FLAG_EXACT_ORDER)) &&
+	const bool want_still = !ss.disabled && !ctx->first_ghost && ss.ok_next && ss.cache_ok && ss.slots_current && !ss.appended && (ctx->flags & NH_FLAG_FUSED_STEP) && !(ctx->flags & (NH_FLAG_SYNC_COUNTS | NH_FLAG_EXACT_ORDER)) &&
 	                        same_bodies(*bodies, ss.lay_bodies) && same_colliders(*colliders, ss.lay_colliders) && same_contacts(*contacts, ss.lay_contacts) &&
 	                        active_bodies->indices == ss.lay_active && active_bodies->capacity == ss.lay_active_capacity;
 	// (kept for the replay of a still step that fails, and as what the next layout belongs to)
@@ -1658,11 +1668,11 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			if (nbox >= 2)
 				NH_LAUNCH(ctx, "narrowphase_still", (k_narrowphase<false, true>), nh_grid_for(pair_cap, 256, 4096), 256, st, ctx->fat_pairs, xf, ctag,
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr,
-				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta);
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta);
 			if (nsph)
 				NH_LAUNCH(ctx, "narrowphase_sph_still", (k_narrowphase<true, true>), nh_grid_for(pair_cap, 256, 8192), 256, st, ctx->fat_pairs, xf, ctag,
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr,
-				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta);
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta);
 			// every record's first contact in the dense (tag-ordered) list = the scan of the counts in tag order: kept from step to step, shifted by the listed changes
 			// (only when more pairs changed their count than the list holds: the two launches leave at once otherwise; the solver keeps the total)
 			nh_scan_u32(ctx, ctx->cnt_sorted, ctx->start_sorted, &st->records, 1, scan_tmp, nullptr, &st->delta_overflow[ctx->step_parity]);
@@ -1732,11 +1742,11 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 		if (nbox >= 2)
 			NH_LAUNCH(ctx, "narrowphase", (k_narrowphase<false, false>), nh_grid_for(pair_cap, 256, 4096), 256, st, pairs, xf, ctag,
 			          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a,
-			          coarse_root, coarse_active, ctx->step_parity);
+			          coarse_root, coarse_active, ctx->step_parity, ctx->first_ghost);
 		if (nsph)
 			NH_LAUNCH(ctx, "narrowphase_sph", (k_narrowphase<true, false>), nh_grid_for(pair_cap, 256, 8192), 256, st, pairs, xf, ctag,
 			          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, overflow_cap, rec_key_a, rec, rec_idx_a,
-			          coarse_root, coarse_active, ctx->step_parity);
+			          coarse_root, coarse_active, ctx->step_parity, ctx->first_ghost);
 	}
 	// islands over contact records (+ user connections): a chain of small kernels that the tag sort of the records does not depend
 	// on -- it runs on the side stream while the caller's stream sorts (fork here, join before k_sorted_counts)

@@ -57,6 +57,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->sc_imp = nullptr; ctx->sc_feat = nullptr; ctx->sc_count = nullptr; ctx->exp_cnt = nullptr; ctx->exp_start = nullptr; ctx->exp_scan_tmp = nullptr; ctx->still_delta = nullptr; ctx->lay_capacity = 0; ctx->lay_contact_capacity = 0;
 	ctx->lay_class = nullptr; ctx->lay_simple = nullptr; ctx->body_rec = nullptr; ctx->body_pos = nullptr; ctx->lay_body_capacity = 0;
 	memset(&ctx->still, 0, sizeof(ctx->still));
+	ctx->first_ghost = 0;
 	ctx->d_state = nullptr;
 	ctx->h_state = nullptr;
 	if (hipMalloc((void**)&ctx->d_state, sizeof(nh_DevState)) != hipSuccess) { delete ctx; return NH_ERR_HIP; }
@@ -128,6 +129,13 @@ extern "C" int nh_set_flags(nh_context* ctx, uint32_t flags) {
 }
 // Diagnostic switches (include/nudge_hip.h: nh_set_option).  None is needed in production: each selects an older, slower or more talkative path for A/B runs and
 // tests.  Call right after nh_create (a switch changed between two steps takes effect at the next nh_collide; buffers already sized are kept).
+extern "C" int nh_set_first_ghost_body(nh_context* ctx, uint32_t first_ghost) {
+	if (!ctx) return NH_ERR_INVALID;
+	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	ctx->first_ghost = first_ghost;          // (still steps are not launched while the rule is on: nh_collide)
+	return NH_OK;
+}
+
 extern "C" int nh_set_option(nh_context* ctx, const char* name, int value) {
 	if (!ctx || !name) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }

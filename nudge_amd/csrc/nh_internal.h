@@ -294,6 +294,7 @@ struct nh_context {
 	// per body (k_adj_simple): class, contact-list record of the full path; the record a body's contacts come from (| NH_BODY_REC_IS_A) and its tag-order position
 	uint8_t* lay_class; uint2* lay_simple; uint32_t* body_rec; uint32_t* body_pos; uint32_t lay_body_capacity;
 	nh_StillStep still;
+	uint32_t first_ghost;          // nh_set_first_ghost_body: bodies >= first_ghost are ghosts of a partitioned world (0 = no ownership rule)
 };
 
 // Runs work that an earlier call deferred; every entry point that reads or writes momentum / impulses calls it first.

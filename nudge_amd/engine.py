@@ -35,7 +35,7 @@ EXPORTS = [
     "nh_halo_pack", "nh_halo_unpack", "nh_halo_update", "nh_append_contacts", "nh_step",
     "nh_partition_create", "nh_partition_destroy", "nh_partition_info", "nh_partition_pack_migrants", "nh_partition_unpack_migrants", "nh_partition_pack_ghosts",
     "nh_partition_unpack_ghosts", "nh_partition_pack_step", "nh_partition_unpack_step", "nh_partition_choose_cut", "nh_partition_set_cut",
-    "nh_partition_set_transport", "nh_partition_exchange_step", "nh_partition_transport_check", "nh_partition_transport_result",
+    "nh_partition_set_transport", "nh_partition_exchange_step", "nh_partition_transport_check", "nh_partition_transport_result", "nh_set_first_ghost_body",
 ]
 HALO_RECORD_BYTES = 64
 
@@ -171,6 +171,7 @@ def lib():
         L.nh_partition_exchange_step.argtypes = [C.c_void_p, C.POINTER(BodyData)]
         L.nh_partition_transport_check.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
         L.nh_partition_transport_result.argtypes = [C.c_void_p]
+        L.nh_set_first_ghost_body.argtypes = [C.c_void_p, C.c_uint32]
         _LIB = L
     return _LIB
 
@@ -390,6 +391,10 @@ class World:
         self.bodies.count = bodies
         self.colliders.boxes.count = boxes
         self.colliders.spheres.count = spheres
+
+    def set_first_ghost(self, first_ghost):
+        """Contact ownership of a partitioned world (include/nudge_hip.h: nh_set_first_ghost_body): bodies >= first_ghost are ghosts; 0 = off."""
+        _check(self.L, self.L.nh_set_first_ghost_body(self.ctx, int(first_ghost)), "nh_set_first_ghost_body")
 
     def records(self, name, record_bytes):
         """Device tensor behind one caller-owned array, as [capacity, record_bytes] uint8 (no copy)."""

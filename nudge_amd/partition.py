@@ -31,6 +31,17 @@ MOMENTUM (32 B) of the listed bodies again and overwrites its ghosts' momentum w
 crosses the cut, but every sweep starts from the owners' values on both sides instead of drifting apart for a whole step
 (the per-iteration ghost exchange).  Costs I extra neighbour messages per step; off by default.
 
+`Partition(..., per_iteration=True, single_owner=True)` -- SURVEY 8(e)'s determinism rule: ONE owner per contact.  A contact with the static world belongs to the
+rank of its dynamic body; a contact of two dynamic bodies to the rank owning the body whose collider has the LARGER tag (the a > b canonicalisation of
+nudge.cpp:2074-2087 / 2131-2132); the engine makes no contact for a pair it does not own (include/nudge_hip.h: nh_set_first_ghost_body; on the reference engine of the
+CPU tests the list is filtered between collide and read_cached_impulses).  So the contact lists of the ranks are disjoint and together are the single world's list.
+A ghost is then moved only by the contacts owned here, and what they did to it -- momentum now minus momentum at the last exchange, 32 B per ghost -- goes back to
+the ghost's owner, which adds it; after that the owners' momentum goes out to the ghosts as before.  Even ranks sweep first, their results travel, then odd ranks
+sweep (two exchanges per solver iteration): every contact of the world is then visited once per iteration with everything before it applied, i.e. one Gauss-Seidel
+sweep in rank-parity order -- like the engine's colour order a different order than the reference's, same fixed point.  (Both parities sweeping at once would be a
+Jacobi step between ranks: a plank held from both sides of a cut gets both supports' full correction and overshoots.)  The warm-start cache of a contact lives on
+its owner; when a migration changes the owner the contact starts cold once.
+
 Re-balancing ("move cuts when |count_r - mean| > 5 %"): at every refresh the two ranks on either side of a cut tell each other how many
 bodies they own; when the two counts differ by more than 5 % of their sum the HEAVIER one picks the new cut -- the x that hands half the difference (at most
 5 % of its bodies per refresh: the capacity slack) to its neighbour -- and sends it over; the bodies between the old cut and the new one then migrate through the
@@ -163,9 +174,16 @@ class Partition:
     tensors (`records(name, bytes)`), `set_counts(bodies, boxes, spheres)`, `step(n)` and `params` -- nudge_amd.engine.World
     does; the CPU tests plug the oracle in behind the same four members."""
 
-    def __init__(self, engine, info, epoch=16, speed_floor=1.0, per_iteration=False, rebalance=True, balance_tolerance=0.05, force_torch=False):
+    def __init__(self, engine, info, epoch=16, speed_floor=1.0, per_iteration=False, rebalance=True, balance_tolerance=0.05, force_torch=False, single_owner=False):
         import torch
         self.per_iteration = per_iteration
+        # one owner per contact that crosses a cut (module docstring): needs the per-iteration exchange, and an engine that can drop the contacts it does not own
+        if single_owner and not per_iteration:
+            raise ValueError("single_owner=True needs per_iteration=True")
+        if single_owner and not hasattr(engine, "set_first_ghost"):
+            raise ValueError("single_owner=True needs an engine with set_first_ghost()")
+        self.single_owner = single_owner
+        self._ghost_ref = None
         self.hip = None                       # the nh_partition handle when the engine is the HIP world (set at the end of __init__)
         # per-iteration exchange = one apply call per sweep with ghost momentum written in between: the engine must keep its solver states and
         # re-read momentum every call, which NH_FLAG_SINGLE_APPLY (4) / NH_FLAG_FUSED_STEP (8) promise away
@@ -580,7 +598,47 @@ class Partition:
     # ---- per-iteration mode: the step in phases, ghost momentum refreshed after every sweep ---------------------------
     def step_begin(self):
         e = self.e
-        e.collide(); e.gravity(); e.read_cache(); e.setup()
+        if self.single_owner:
+            e.set_first_ghost(self.n_owned + 1)
+        e.collide(); e.gravity(); e.read_cache()
+        if self.single_owner:
+            self.delta_mark()                     # (the warm start inside setup() already moves the ghosts of the contacts owned here)
+        e.setup()
+        if self.single_owner and hasattr(e, "synchronize"):
+            e.synchronize()                       # (the HIP engine may defer the warm start into the first apply call, header note 7: it has to be in the momentum the deltas are taken from)
+
+    # ---- single ownership: what the solver did to a ghost goes back to the ghost's owner ----------------------------------------------
+    def _ghost_span(self):
+        at = self.n_owned + 1
+        return at, at + self.ghost_in[-1] + self.ghost_in[+1]
+
+    def delta_mark(self):
+        a, b = self._ghost_span()
+        self._ghost_ref = self.bm[a:b].clone()
+
+    def delta_pack(self):
+        """Per neighbour: momentum of its bodies' ghosts here now minus at the last delta_mark() (8 floats per ghost, in the order of the neighbour's list)."""
+        t = self.torch
+        a, b = self._ghost_span()
+        d = self.bm[a:b].contiguous().view(t.float32) - self._ghost_ref.contiguous().view(t.float32)
+        d[:, 3] = 0.0; d[:, 7] = 0.0              # (the two spare words of a momentum record are the engine's: the inverse mass rides there during a solve, nudge.cpp:4358)
+        out, m = {}, self.ghost_in[-1]
+        for dirn, part in ((-1, d[:m]), (+1, d[m:])):
+            if dirn in self.neighbours():
+                out[dirn] = part.contiguous().view(t.uint8)
+                self.stats["step_bytes"] += int(out[dirn].numel())
+        return out
+
+    def delta_unpack(self, incoming):
+        """Adds the neighbours' deltas to the bodies listed for them (ghost_out[d] is the order the neighbour holds their ghosts in)."""
+        t = self.torch
+        bmf = self.bm.view(t.float32)
+        for d in self.neighbours():
+            idx = self.ghost_out[d]
+            if idx is not None and len(idx):
+                bmf.index_add_(0, idx.long(), incoming[d].contiguous().view(t.float32).to(bmf.device))
+        if hasattr(self.e, "momentum_written"):
+            self.e.momentum_written()
 
     def sweep(self):
         self.e.apply(1)
@@ -662,14 +720,34 @@ class LocalCluster:
                 for p, i in zip(self.parts, ins):
                     p.step_unpack(i)
             if self.parts[0].per_iteration:
-                for p in self.parts:
-                    p.step_begin()
-                for _it in range(self.parts[0].iterations()):
-                    for p in self.parts:
-                        p.sweep()
+                def exchange():
+                    if self.parts[0].single_owner:          # ghost deltas to their owners first: the momentum sent back below includes them
+                        ins = self._route([p.delta_pack() for p in self.parts])
+                        for p, i in zip(self.parts, ins):
+                            p.delta_unpack(i)
                     ins = self._route([p.momentum_pack() for p in self.parts])
                     for p, i in zip(self.parts, ins):
                         p.momentum_unpack(i)
+                    if self.parts[0].single_owner:
+                        for p in self.parts:
+                            p.delta_mark()
+                for p in self.parts:
+                    p.step_begin()
+                if self.parts[0].single_owner:
+                    exchange()                              # (the warm start)
+                for _it in range(self.parts[0].iterations()):
+                    if self.parts[0].single_owner:
+                        # even ranks sweep, their results travel, odd ranks sweep: with one owner per contact that IS one Gauss-Seidel sweep over all contacts of the
+                        # world (module docstring); sweeping both parities at once would be a Jacobi step between the ranks, which overshoots on a body held from both sides
+                        for phase in (0, 1):
+                            for p in self.parts:
+                                if p.rank % 2 == phase:
+                                    p.sweep()
+                            exchange()
+                    else:
+                        for p in self.parts:
+                            p.sweep()
+                        exchange()
                 for p in self.parts:
                     p.step_end()
             else:
@@ -912,10 +990,24 @@ class DistCluster:
             if self.loopback:
                 self._loopback()
             if p.per_iteration:
-                p.step_begin()
-                for _it in range(p.iterations()):
-                    p.sweep()
+                def exchange():
+                    if p.single_owner:
+                        p.delta_unpack(self._exchange(p.delta_pack(), 32, known_counts={d: int(len(p.ghost_out[d])) if p.ghost_out[d] is not None else 0 for d in p.neighbours()}))
                     p.momentum_unpack(self._exchange(p.momentum_pack(), 32, known_counts={d: p.ghost_in[d] for d in p.neighbours()}))
+                    if p.single_owner:
+                        p.delta_mark()
+                p.step_begin()
+                if p.single_owner:
+                    exchange()
+                for _it in range(p.iterations()):
+                    if p.single_owner:
+                        for phase in (0, 1):          # (see LocalCluster.step)
+                            if p.rank % 2 == phase:
+                                p.sweep()
+                            exchange()
+                    else:
+                        p.sweep()
+                        exchange()
                 p.step_end()
             else:
                 p.local_step()

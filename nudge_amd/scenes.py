@@ -162,6 +162,28 @@ def pile(n_boxes=256, n_spheres=0, seed=1, iterations=4):
     return _assemble((st, ssz), (bt, bsz, bp), (spt, r, sp), params, name=f"pile{n_boxes}+{n_spheres}")
 
 
+def bridge(layers=2, iterations=8):
+    """Bodies held from both sides of the plane x = 0: per layer two unit cubes at x = -1.25 / +1.25 and a plank (half extents 1.6, 0.5, 1) lying across them with its
+    centre at x = 0.1, layer on layer, starting at rest on the ground.  Cut at x = 0 every plank has one support on each side: the test scene of contact ownership
+    across a cut (nudge_amd/partition.py: single_owner)."""
+    f = np.float32
+    st = _identity_transforms(1)
+    st["position"][0] = (0.0, -20.0, 0.0)
+    ssz = np.array([[400.0, 10.0, 400.0]], dtype=f)
+    pos, size, y = [], [], -9.0
+    for _ in range(layers):
+        pos += [(-1.25, y, 0.0), (1.25, y, 0.0), (0.1, y + 1.5, 0.0)]
+        size += [(1.0, 1.0, 1.0), (1.0, 1.0, 1.0), (1.6, 0.5, 1.0)]
+        y += 3.0
+    n = len(pos)
+    bt = _identity_transforms(n)
+    bt["position"][:] = np.array(pos, dtype=f)
+    bsz = np.array(size, dtype=f)
+    bp = _box_properties(bsz[:, 0].copy(), bsz[:, 1].copy(), bsz[:, 2].copy())
+    params = dict(DEFAULT_PARAMS, iterations=iterations)
+    return _assemble((st, ssz), (bt, bsz, bp), (_identity_transforms(0), np.zeros(0, f), _sphere_properties(np.zeros(0, f))), params, name=f"bridge{layers}")
+
+
 def grid_tiles(n_tiles=1, side=90, sphere_fraction=0.0, seed=2, iterations=8, lattice_cols=None):
     """Configs 2/3/5: `n_tiles` independent single-layer drop tiles.  Per tile one static ground slab
     (half-extents (side*1.5+2, 10, side*1.5+2), top at y=-10) and side*side bodies on a 3.0 pitch:

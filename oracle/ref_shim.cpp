@@ -182,6 +182,8 @@ void ref_world_set_counts(RefWorld* w, uint32_t bodies, uint32_t boxes, uint32_t
 }
 
 void ref_world_set_cache_count(RefWorld* w, uint32_t n) { w->cache.count = n; }
+// (the reference lets the caller edit the contact list between collide and read_cached_impulses, example/main.cpp:287: a caller that REMOVES contacts shortens it)
+void ref_world_set_contact_count(RefWorld* w, uint32_t n) { w->contacts.count = n; }
 
 void ref_world_view(RefWorld* w, RefWorldView* v) {
 	v->body_transforms = w->bodies.transforms;

@@ -42,6 +42,8 @@ def lib(variant="exact"):
     L.ref_world_destroy.argtypes = [C.c_void_p]
     L.ref_world_set_counts.argtypes = [C.c_void_p] + [C.c_uint32] * 4
     L.ref_world_set_cache_count.argtypes = [C.c_void_p, C.c_uint32]
+    if hasattr(L, "ref_world_set_contact_count"):
+        L.ref_world_set_contact_count.argtypes = [C.c_void_p, C.c_uint32]
     L.ref_world_view.argtypes = [C.c_void_p, C.POINTER(_View)]
     L.ref_set_ftz.argtypes = [C.c_int]
     L.ref_variant.restype = C.c_char_p
@@ -144,6 +146,27 @@ class RefWorld:
     def gravity(self):
         p = self.params
         self.L.ref_stage_gravity(self.h, p["time_step"], p["gravity"], p["damping_rate"])
+    def keep_owned_contacts(self, first_ghost):
+        """Between collide() and read_cache(): drops the contacts a rank of a partitioned world does not own (include/nudge_hip.h: nh_set_first_ghost_body -- a contact
+        with the static world belongs to its dynamic body, a contact of two dynamic bodies to the body whose collider has the larger tag; bodies >= first_ghost are ghosts).
+        The list stays in the reference's order."""
+        v = self._view()
+        n = v.contact_count
+        if n == 0:
+            return 0
+        ab = _view_array(v.contact_bodies, np.uint16, 2 * n).reshape(-1, 2)
+        tags = _view_array(v.contact_tags, np.uint64, n)
+        data = _view_array(v.contact_data, self.S.CONTACT, n)
+        a, b = ab[:, 0].astype(np.int64), ab[:, 1].astype(np.int64)
+        ta, tb = (tags >> np.uint64(32)) & np.uint64(0xffff), (tags >> np.uint64(48)) & np.uint64(0xffff)
+        owner = np.where(a == 0, b, np.where(b == 0, a, np.where(ta > tb, a, b)))
+        keep = np.flatnonzero(owner < first_ghost)
+        m = len(keep)
+        if m < n:
+            ab[:m] = ab[keep].copy(); tags[:m] = tags[keep].copy(); data[:m] = data[keep].copy()
+            self.L.ref_world_set_contact_count(self.h, m)
+        return n - m
+
     def read_cache(self): self.L.ref_stage_read_cache(self.h)
     def setup(self): self.L.ref_stage_setup(self.h)
     def apply(self, iterations=None):

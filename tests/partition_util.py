@@ -53,8 +53,18 @@ class OracleEngine:
         self._phase = True
         self.step(1, only_upload=True)
 
-    def collide(self): self._upload(); self.ref.collide()
-    def gravity(self): self.ref.gravity()
+    def set_first_ghost(self, first_ghost):
+        """Contact ownership (include/nudge_hip.h: nh_set_first_ghost_body), on the reference: the contacts this rank does not own are removed from the list between
+        collide and read_cached_impulses (example/main.cpp:287 is where the reference lets its caller edit the list)."""
+        self.first_ghost = int(first_ghost)
+
+    def collide(self):
+        self._upload(); self.ref.collide()
+        if getattr(self, "first_ghost", 0):
+            self.dropped_contacts = self.ref.keep_owned_contacts(self.first_ghost)
+    def gravity(self):
+        self.ref.gravity()
+        self._download(momentum_only=True)          # (single ownership measures what the solver does to a ghost from here)
     def read_cache(self): self.ref.read_cache()
 
     def setup(self):

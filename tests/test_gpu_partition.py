@@ -290,3 +290,52 @@ def test_compound_bodies_across_a_cut_on_the_gpu():
         assert q.e.counts()["error"] == 0
         q.close(); q.e.close()
     single.close()
+
+
+def test_single_owner_of_cross_cut_contacts_on_the_gpu_is_the_reference_engine_bit_for_bit():
+    """SURVEY 8(e) "determinism rule" on the HIP engine (nh_set_first_ghost_body: nh_collide makes contacts only for the collider pairs a rank owns) under
+    Partition(per_iteration=True, single_owner=True): ghost deltas back to the owners, owners' momentum out to the ghosts, even ranks sweeping before odd ones.
+    The same two-rank cluster stepped with the compiled reference as every rank's engine (its contact list filtered by the same rule between collide and
+    read_cached_impulses) leaves the same bits -- planks lying across the cut, and a heap forming across it; the contact lists of the two ranks are disjoint and
+    together are the single world's."""
+    import partition_util as PU
+    from oracle import refworld
+    assert refworld.available("exact")
+
+    def low_pile():
+        scene = S.pile(n_boxes=120, n_spheres=0, seed=3)
+        scene["body_transforms"]["position"][1:, 1] *= 0.08
+        scene["body_transforms"]["position"][1:, 1] += 1.0
+        return scene
+
+    for scene, cut, checkpoints in ((S.bridge(3), 0.0, (4, 30, 90)), (low_pile(), 0.3, (20, 50, 80))):
+        gpu, cpu = [], []
+        for r in range(2):
+            local, info = PT.split_scene(scene, [cut], r, min_extra=512)
+            w = E.World(local, flags=E.NH_FLAG_EXACT_ORDER, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=16 * info["capacity"]["bodies"])
+            gpu.append(PT.Partition(w, info, epoch=8, per_iteration=True, single_owner=True))
+            cpu.append(PT.Partition(PU.OracleEngine(local, info["capacity"]), info, epoch=8, per_iteration=True, single_owner=True))
+        cg, cc = PT.LocalCluster(gpu), PT.LocalCluster(cpu)
+        done = 0
+        for k in checkpoints:
+            cg.step(k - done); cc.step(k - done); done = k
+            a, b = cg.gather(), cc.gather()
+            assert np.array_equal(a["ids"], b["ids"])
+            assert P.bits_equal(a["transforms"]["position"], b["transforms"]["position"]) and P.bits_equal(a["transforms"]["rotation"], b["transforms"]["rotation"]), f"{scene['name']} step {k}"
+            assert P.bits_equal(a["momentum"]["velocity"], b["momentum"]["velocity"]) and P.bits_equal(a["momentum"]["angular_velocity"], b["momentum"]["angular_velocity"]), f"{scene['name']} step {k}"
+            lists = [q.e.get_contacts() for q in gpu]
+            kept_gpu = sum(c["count"] for c in lists)
+            kept_cpu = sum(q.e.ref.contacts()["count"] for q in cpu)
+            assert kept_gpu == kept_cpu > 0
+            if k == 4:
+                # disjoint and complete: the two lists together are the single world's, while the worlds still agree (tests/test_partition_cpu.py does the same on the reference)
+                single = E.World(scene, flags=E.NH_FLAG_EXACT_ORDER)
+                single.step(4)
+                c1 = single.get_contacts()
+                key = lambda c: np.sort(np.stack([c["tags"], c["features"].astype(np.uint64)], axis=1).view(np.dtype([("t", np.uint64), ("f", np.uint64)])).ravel(), order=("t", "f"))   # noqa: E731
+                mine = np.sort(np.concatenate([key(c) for c in lists]), order=("t", "f"))
+                assert len(mine) == c1["count"] > 20 and np.array_equal(mine, key(c1))
+                single.close()
+        for q in gpu:
+            assert q.e.counts()["error"] == 0
+            q.e.close()

@@ -166,13 +166,13 @@ def _ghost_deviation(parts):
     return worst, n
 
 
-def _pile_cluster(per_iteration):
+def _pile_cluster(per_iteration, single_owner=False):
     import partition_util as PU
     scene = _low_pile()
     parts = []
     for r in range(2):
         local, info = PT.split_scene(scene, [0.3], r, min_extra=512)
-        parts.append(PT.Partition(PU.OracleEngine(local, info["capacity"]), info, epoch=8, per_iteration=per_iteration))
+        parts.append(PT.Partition(PU.OracleEngine(local, info["capacity"]), info, epoch=8, per_iteration=per_iteration, single_owner=single_owner))
     return scene, PT.LocalCluster(parts), parts
 
 
@@ -203,6 +203,96 @@ def test_per_iteration_exchange_keeps_ghosts_equal_to_their_owners():
     ref = PU.single_world_reference(_low_pile(), 80)
     top = ref["transforms"]["position"][1:, 1].max()
     assert abs(tall - top) < 1.5 and abs(tall_step - top) < 1.5, (tall, tall_step, top)
+
+
+def _bridge_cluster(single_owner, layers=3):
+    import partition_util as PU
+    scene = S.bridge(layers)
+    parts = []
+    for r in range(2):
+        local, info = PT.split_scene(scene, [0.0], r, min_extra=64)
+        parts.append(PT.Partition(PU.OracleEngine(local, info["capacity"]), info, epoch=8, per_iteration=True, single_owner=single_owner))
+    return scene, PT.LocalCluster(parts), parts
+
+
+def test_single_owner_every_contact_is_solved_by_exactly_one_rank():
+    """SURVEY 8(e) "determinism rule": a contact is owned by the rank owning the body with the larger collider tag (the a > b canonicalisation of nudge.cpp:2074-2087);
+    a contact with the static world by its dynamic body's rank.  Planks lying across the cut on a support on either side: the contact lists of the two ranks are
+    disjoint and together ARE the single world's list; what the owner's solver does to a ghost flows back to the ghost's owner after every sweep (even ranks sweep,
+    then odd ranks: one Gauss-Seidel sweep over all contacts of the world), and the stack stays where the single world's stays."""
+    import partition_util as PU
+    scene, cl, parts = _bridge_cluster(True)
+    ref = refworld.RefWorld(scene, max_contacts=1024)
+    cl.step(4); ref.step(4)                                   # (the stack starts at rest and sinks into contact layer by layer: 8 more contacts per step so far)
+    mine = np.sort(np.concatenate([p.e.ref.contacts()["tags"] for p in parts]))
+    assert len(mine) == ref.contacts()["count"] > 20 and np.array_equal(mine, np.sort(ref.contacts()["tags"]))
+    assert all(p.e.dropped_contacts > 0 for p in parts)
+    # ... and without the rule the two ranks hold the cross-cut contacts twice
+    _, cl2, parts2 = _bridge_cluster(False)
+    cl2.step(4)
+    assert sum(p.e.ref.contacts()["count"] for p in parts2) > len(mine)
+    worst, done = 0.0, 4
+    for k in (20, 100, 300):
+        cl.step(k - done); ref.step(k - done); done = k
+        dev, n = _ghost_deviation(parts)
+        assert dev == 0.0 and n >= 3                         # a ghost IS its owner after every step
+        got, rb = cl.gather(), ref.bodies()
+        worst = max(worst, float(np.abs(got["transforms"]["position"] - rb["transforms"]["position"][1:]).max()))
+        assert float(np.abs(got["momentum"]["velocity"] - rb["momentum"]["velocity"][1:]).max()) < 0.1
+    assert worst < 2e-2, worst                               # (a different Gauss-Seidel order than the reference's: within 1 % of a box, not equal)
+
+
+def test_single_owner_heap_across_the_cut_matches_the_single_world():
+    """The heap of the per-iteration test with one owner per contact: finite, every ghost equal to its owner every step, and as close to the single world as the
+    both-ranks-solve form is (a heap is chaotic: height and kinetic energy are what can be compared)."""
+    import partition_util as PU
+    scene, cl, parts = _pile_cluster(True, single_owner=True)
+    cl.step(12)
+    for _ in range(68):
+        cl.step(1)
+        dev, n = _ghost_deviation(parts)
+        assert dev == 0.0 and n > 20
+    got = cl.gather()
+    ref = PU.single_world_reference(_low_pile(), 80)
+    assert np.isfinite(got["transforms"]["position"]).all()
+    assert abs(got["transforms"]["position"][:, 1].max() - ref["transforms"]["position"][1:, 1].max()) < 1.5
+    ke = lambda m: float((m["velocity"].astype(np.float64) ** 2).sum())          # noqa: E731
+    assert abs(ke(got["momentum"]) - ke(ref["momentum"][1:])) < 0.05 * ke(ref["momentum"][1:])
+    e = np.abs(got["transforms"]["position"] - ref["transforms"]["position"][1:]).max(axis=1)
+    assert float(np.median(e)) < 0.2, float(np.median(e))
+    assert sum(p.e.dropped_contacts for p in parts) > 0
+
+
+def _gloo_bridge_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+    import partition_util as PU
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = S.bridge(3)
+    local, info = PT.split_scene(scene, [0.0], rank, min_extra=64)
+    part = PT.Partition(PU.OracleEngine(local, info["capacity"]), info, epoch=8, per_iteration=True, single_owner=True)
+    cl = PT.DistCluster(part)
+    cl.step(60)
+    got = cl.gather(dst=0)
+    if rank == 0:
+        np.savez(out_path, position=got["transforms"]["position"], rotation=got["transforms"]["rotation"], velocity=got["momentum"]["velocity"], ids=got["ids"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_single_owner_under_gloo_is_the_in_process_run(tmp_path):
+    """Two processes, deltas and momentum as torch.distributed point-to-point messages (two phases per sweep): the same bits as the in-process cluster."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "bridge.npz")
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_bridge_worker, args=(2, port, out), nprocs=2, join=True)
+    z = np.load(out)
+    _, cl, _parts = _bridge_cluster(True)
+    cl.step(60)
+    got = cl.gather()
+    assert np.array_equal(z["ids"], got["ids"])
+    assert P.bits_equal(z["position"], got["transforms"]["position"]) and P.bits_equal(z["rotation"], got["transforms"]["rotation"]) and P.bits_equal(z["velocity"], got["momentum"]["velocity"])
 
 
 def _gloo_pile_worker(rank, world, port, out_path):
