@@ -1419,7 +1419,9 @@ extern "C" int nh_collide(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Co
 	ss.active = false; ss.resolved = false; ss.setup_d = nullptr;
 	// A still step?  The last step must have left everything one relies on (ok_next: decided at its round trip), the contact cache must be that step's contact
 	// list, the caller must be in the mode that promises the sample's call order, and the world must be the one the kept layout describes.
-	const bool want_still = !ss.disabled && !ctx->first_ghost && ss.ok_next && ss.cache_ok && ss.slots_current && !ss.appended && (ctx->flags & NH_FLAG_FUSED_STEP) && !(ctx->flags & (NH_FLAG_SYNC_COUNTS | NH_FLAG_EXACT_ORDER)) &&
+	const bool held = ss.hold != 0u;          // (back-off after failed still steps: nh_internal.h)
+	if (held) ss.hold--;
+	const bool want_still = !held && !ss.disabled && !ctx->first_ghost && ss.ok_next && ss.cache_ok && ss.slots_current && !ss.appended && (ctx->flags & NH_FLAG_FUSED_STEP) && !(ctx->flags & (NH_FLAG_SYNC_COUNTS | NH_FLAG_EXACT_ORDER)) &&
 	                        same_bodies(*bodies, ss.lay_bodies) && same_colliders(*colliders, ss.lay_colliders) && same_contacts(*contacts, ss.lay_contacts) &&
 	                        active_bodies->indices == ss.lay_active && active_bodies->capacity == ss.lay_active_capacity;
 	// (kept for the replay of a still step that fails, and as what the next layout belongs to)
@@ -1437,7 +1439,7 @@ int nh_still_collide_again(nh_context* ctx) {
 	nh_StillStep& ss = ctx->still;
 	const bool after_collide = ctx->after_collide, may_overlap = ctx->gravity_may_overlap;
 	ss.active = false; ss.resolved = false; ss.ok_next = false;
-	ss.failed++;
+	ss.failed++; ss.note_failure();
 	ss.replaying = true;
 	const int rc = collide_impl(ctx, ss.active_out, ss.contacts_out, &ss.bodies, &ss.colliders, ss.has_connections ? &ss.connections : nullptr, ss.temporary, false);
 	ss.replaying = false;

@@ -187,6 +187,12 @@ struct nh_StillStep {
 	nh_ActiveBodies* active_out; nh_ContactData* contacts_out; nh_BodyData bodies; nh_ColliderData colliders; nh_BodyConnections connections; bool has_connections; nh_Arena temporary;
 	nh_BodyData lay_bodies; nh_ColliderData lay_colliders; nh_ContactData lay_contacts; const uint32_t* lay_active; uint32_t lay_active_capacity;
 	uint64_t launched, failed;      // statistics
+	// back-off: a world in which something keeps moving (a body in the air leaves its inflated box every step) fails every still step it is offered; after the k-th
+	// failure in a row the next 2^k - 1 steps (at most 63) are not offered as still steps.  Sixteen confirmed still steps in a row forget the failures.
+	uint32_t hold, fail_level, good_run;
+	uint32_t seen_inserts, seen_rebuilds;          // re-insertion / rebuild counters at the last full step's round trip (finish_setup: did anybody leave its box in that step?)
+	void note_failure() { hold = (1u << fail_level) - 1u; if (fail_level < 6u) ++fail_level; good_run = 0; }
+	void note_confirmed() { if (++good_run >= 16u) fail_level = 0; }
 };
 
 struct nh_context {

@@ -2395,6 +2395,10 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		const nh_DevState* h = ctx->h_state;
 		ctx->still.ok_next = h->lay_valid && !h->has_unstable && h->static_inert && !h->has_pending && !h->has_static8 && !h->has_staticN && !h->any_sleeping && h->sleeping == 0u &&
 		                     h->culled == 0u && h->general_contacts == 0u && !h->error;
+		// ... and nobody moved: a collider that left its inflated box in THIS step (re-inserted, or the kept list rebuilt) will most likely leave it again in the next
+		// one -- a body in the air does on every step -- and a still step that fails costs two steps' worth of launches
+		if (h->fat_inserts != ctx->still.seen_inserts || h->fat_rebuilds != ctx->still.seen_rebuilds) ctx->still.ok_next = false;
+		ctx->still.seen_inserts = h->fat_inserts; ctx->still.seen_rebuilds = h->fat_rebuilds;
 	}
 	// NH_FLAG_FUSED_STEP: gravity / damping of the bodies the fused solver does not own, before anything else reads their momentum -- not launched
 	// at all when every body is the fused solver's (a landed drop scene)
@@ -2653,7 +2657,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 			}
 		}
 		if (confirmed) {
-			ss.resolved = true; ss.setup_d = nullptr;
+			ss.resolved = true; ss.setup_d = nullptr; ss.note_confirmed();
 			ss.cache_stale = true; ss.contacts_stale = true;        // (the caller's cache and dense contact arrays are last written by an earlier step: nh_still_sync_outputs)
 			d->finish_pending = false; d->has_late = false; d->has_static8 = d->has_staticN = false; d->static_inert = true; d->general_contacts = 0; d->levels = 0;
 			d->imp->cull_pending = false; d->imp->lookup_pending = false;
@@ -2928,6 +2932,7 @@ static int still_forget_failed(nh_context* ctx, bool advanced, uint32_t voided) 
 	nh_StillStep& ss = ctx->still;
 	ss.verdict.pending = false;
 	ss.active = false; ss.resolved = false; ss.setup_d = nullptr; ss.ok_next = false;
+	ss.note_failure();
 	ss.failed += voided;                               // (still steps launched that did not happen: the failed one, and the one launched behind it if it got that far)
 	ctx->pending = nullptr;
 	ctx->grav.pending = false; ctx->grav.rest_pending = false; ctx->adv.done = false;

@@ -22,10 +22,10 @@ print(f"{nb - 1:,} boxes in {tiles} tiles, landed and awake; steps/s over 96 ste
 _w = E.World(scene, flags=flags); _w.step(200); _w.synchronize(); _w.close()          # (clocks and allocator warm before the first measured world)
 for mode in ("hop", "fly"):
     print(f"--- {mode}: " + ("K boxes kicked every 12 steps" if mode == "hop" else "K boxes thrown up once, in the air throughout"))
-    print("movers | re-insertion (default) | rebuild on leave (NH_NO_INCREMENTAL=1) | search every step (NH_NO_KEPT_PAIRS=1)")
+    print("movers | re-insertion + still steps (default) | no still steps (NH_NO_STILL=1) | rebuild on leave (NH_NO_INCREMENTAL=1) | search every step (NH_NO_KEPT_PAIRS=1)")
     for K in ((0, 1, 16, 256, 2048) if mode == "hop" else (1, 16, 256, 2048)):
         row, detail = [], []
-        for env in (None, "NH_NO_INCREMENTAL", "NH_NO_KEPT_PAIRS"):
+        for env in (None, "NH_NO_STILL", "NH_NO_INCREMENTAL", "NH_NO_KEPT_PAIRS"):
             if env: os.environ[env] = "1"
             w = E.World(scene, flags=flags)
             if env: os.environ.pop(env, None)
@@ -48,6 +48,7 @@ for mode in ("hop", "fly"):
             c1 = w.counts()
             assert c1["error"] == 0
             row.append(8 * 12 / t)
-            detail.append(f"{c1['broadphase_rebuilds'] - c0['broadphase_rebuilds']} rebuilds, {c1['broadphase_inserts'] - c0['broadphase_inserts']} re-insertions")
+            detail.append(f"{c1['broadphase_rebuilds'] - c0['broadphase_rebuilds']} rebuilds, {c1['broadphase_inserts'] - c0['broadphase_inserts']} re-insertions"
+                          + (f", {c1['still_steps'] - c0['still_steps']} still steps, {c1['still_replays'] - c0['still_replays']} replayed" if env is None else ""))
             w.close()
-        print(f"{K:6d} | {row[0]:8.1f} ({detail[0]}) | {row[1]:8.1f} ({detail[1]}) | {row[2]:8.1f} ({detail[2]})", flush=True)
+        print(f"{K:6d} | {row[0]:8.1f} ({detail[0]}) | {row[1]:8.1f} ({detail[1]}) | {row[2]:8.1f} ({detail[2]}) | {row[3]:8.1f} ({detail[3]})", flush=True)
