@@ -102,9 +102,9 @@ KERNEL_BYTES = {
     "update_impulses": ("G", 160 + 16 + 16),
     "write_cache": ("K", 12 + 16 + 28),
     "advance": ("B", 4 + 32 + 32 + 1 + 32 + 1),
-    # spatially blocked solver (nh_blocks.h): per contact and sweep 60 B streamed in block order; and the momentum of every general body once in, once
-    # out (2 x 32 B; ghost copies a block borrows are NOT counted: the count is not mirrored to the host, so this is a lower bound) -- main() turns
-    # that into bytes per contact for the scene at hand
+    # spatially blocked solver (nh_blocks.h): per contact and sweep 60 B streamed in block order; and per sweep every momentum record a block holds once in, once
+    # out (2 x 32 B): the general bodies as their block's own + the ghost copies the blocks borrow (nh_Counts.blk_bodies / blk_ghosts) -- main() turns that into
+    # bytes per contact for the scene at hand
     "blk_sweep": ("GI", 32 + 4 + 24), "blk_warm": ("G", 32 + 4 + 24),   # nh_blocks.h (k_blk_sweep): first 8 row floats, local index pair, 3 state floats in + out = 60 B
     "blk_bounds": ("B", 1 + 12), "blk_body": ("B", 1 + 12 + 8), "blk_contact": ("G", 4 + 8 + 2 * 8 + 8), "blk_scatter": ("G", 4 + 4 + 4 + 4),
     "blk_prepare": ("G", 2 * (4 + 8 + 2 * 8) + 2 * 4 + 16 + 4 + 3 * 4),      # k_blk_prepare_local: two passes over (order, pair, two block ranks), the index pair parked and fetched, the seed, order again; order, index pair and colour out
@@ -561,9 +561,11 @@ def main():
             # sphere contacts in default order use the 48-byte radial rows: 112 bytes less per contact than the 160-byte general row
             for name in ("rows_general", "warm_level", "apply_level", "update_impulses"):
                 KERNEL_BYTES[name] = (KERNEL_BYTES[name][0], KERNEL_BYTES[name][1] - 112)
-            # blocked sweeps: + the momentum of every (general) body once in and once out per sweep
+            # blocked sweeps: + the momentum records a sweep loads and stores -- every general body once as its block's own, and once more per block that borrows it as a
+            # ghost (nh_Counts.blk_bodies + blk_ghosts of the last timed step: the block tables are rebuilt every step)
+            blk_records = float(c1.get("blk_bodies", 0) + c1.get("blk_ghosts", 0)) or float(nb)
             for name in ("blk_sweep", "blk_warm"):
-                KERNEL_BYTES[name] = (KERNEL_BYTES[name][0], KERNEL_BYTES[name][1] + 64.0 * nb / max(G, 1.0))
+                KERNEL_BYTES[name] = (KERNEL_BYTES[name][0], KERNEL_BYTES[name][1] + 64.0 * blk_records / max(G, 1.0))
         # the one-body solver as this world runs it (see KERNEL_BYTES): + 16 B of solver state per contact when a further apply call may follow,
         # - the fused advance's transform / idle traffic when gravity and advance are separate kernels
         fused = bool(w.flags & E.NH_FLAG_FUSED_STEP)

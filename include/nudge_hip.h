@@ -199,6 +199,8 @@ typedef struct nh_Counts {
 	uint32_t still_replays;     /* ... launched as one, found otherwise (by the device or because the caller left the sample's call order) and run again in full */
 	uint32_t still_diff[4];     /* what still steps have found changed, summed since nh_create: collider pairs with another key / another contact count / other feature words;
 	                               colliders outside their inflated box or bodies asleep (diagnostic) */
+	uint32_t blk_blocks, blk_bodies, blk_ghosts;   /* the blocked solver's tables of the last step that built them (large general sets): blocks of the grid, general bodies binned,
+	                               ghost copies borrowed by blocks (a sweep loads and stores blk_bodies + blk_ghosts momentum records); diagnostic / measurement */
 } nh_Counts;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */

@@ -204,6 +204,7 @@ void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out) {
 	out->general_contacts = h->general_contacts; out->levels = h->levels; out->error = h->error;
 	out->still_steps = (uint32_t)(ctx->still.launched - ctx->still.failed - ((ctx->still.active && !ctx->still.resolved) ? 1u : 0u)); out->still_replays = (uint32_t)ctx->still.failed;
 	for (int k = 0; k < 4; ++k) out->still_diff[k] = h->still_diff[k];
+	out->blk_blocks = h->blk.nblk; out->blk_bodies = h->blk.bodies; out->blk_ghosts = h->blk.ghost_cursor;
 	out->has_other_bodies = h->has_other; out->broadphase_rebuilds = h->fat_rebuilds; out->sort_reuses = h->sort_reuses; out->broadphase_inserts = h->fat_inserts; out->unleveled = h->unleveled; out->raw_pairs = h->pairs + h->pairs_sph;
 }
 
