@@ -201,6 +201,7 @@ typedef struct nh_Counts {
 	                               colliders outside their inflated box or bodies asleep (diagnostic) */
 	uint32_t blk_blocks, blk_bodies, blk_ghosts;   /* the blocked solver's tables of the last step that built them (large general sets): blocks of the grid, general bodies binned,
 	                               ghost copies borrowed by blocks (a sweep loads and stores blk_bodies + blk_ghosts momentum records); diagnostic / measurement */
+	uint32_t asleep_steps;      /* steps since nh_create that nh_step found to be steps of a world in which every body is asleep and nothing has changed: done without a launch */
 } nh_Counts;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */
@@ -225,7 +226,7 @@ int nh_set_pair_capacity(nh_context* ctx, uint32_t pairs);
 /* Diagnostic switches for A/B runs and tests -- none is needed in production, each selects an older, slower or more talkative path; the library never reads the
    environment.  Names (value 0 / 1 unless noted): "no_still", "no_kept_pairs", "no_incremental", "no_sort_reuse", "sort_classic", "sort_radix", "bucket_tile" (n),
    "bucket_target" (n), "colour_jp", "colour_check_seeds", "no_resident", "solver_waves" (1, 2, 4), "fp_sub" (0, 1, 2, 4, 16), "cooperative", "no_blocks", "blk_check",
-   "blk_min" (n), "blk_target" (n), "blk_rows_global", "blk_global_colours", "blk_profile".  Unknown name: NH_ERR_INVALID.  Call right after nh_create.
+   "blk_min" (n), "blk_target" (n), "blk_rows_global", "blk_global_colours", "blk_profile", "no_asleep".  Unknown name: NH_ERR_INVALID.  Call right after nh_create.
    (nudge_amd/engine.py maps environment variables NH_<NAME> onto these calls for its tests: a convenience of that host, not of the library.) */
 int nh_set_option(nh_context* ctx, const char* name, int value);
 const char* nh_error_string(int code);
@@ -292,7 +293,11 @@ int nh_halo_update(nh_context* ctx, const nh_BodyData* bodies, uint32_t first_sl
    nh_update_cached_impulses, nh_write_cached_impulses, nh_advance  on the arrays of `args` (scratch and the two opaque objects come out of `arena`, reset every step like
    the sample does, example/main.cpp:282).  Same results as the eight calls made by the caller -- bit for bit -- with two savings: one crossing of the ABI instead of
    eight per step, and, because the library drives the call order itself, the host round trip of a still step (note 9) is taken one step LATE, so that neither the host nor
-   the GPU waits for the other inside the loop.  Every step is confirmed when the call returns.  Custom contacts / user impulses between the calls need the eight calls. */
+   the GPU waits for the other inside the loop.  Every step is confirmed when the call returns.  Custom contacts / user impulses between the calls need the eight calls.
+   A world in which EVERY body is asleep is a fixed point of the step (no active body, no contact, every overlapping pair a sleeping pair, the cache kept aside and
+   written back as it was: nudge.cpp:3669-3703, 4064-4101, 4896-4898).  Once two full steps in a row have shown that, nh_step checks once per call -- one kernel: every
+   collider's world AABB and tag what they were, every body still asleep -- that nothing the caller owns has changed, and takes the steps of the call as done
+   (nh_Counts.asleep_steps); anything else runs them in full.  Results are those of a library that never does this (option "no_asleep"), which the tests check. */
 typedef struct nh_StepArgs {
 	nh_ActiveBodies* active_bodies; nh_ContactData* contacts; const nh_BodyData* bodies; const nh_ColliderData* colliders; const nh_BodyConnections* body_connections;
 	nh_ContactCache* contact_cache; nh_Arena arena;

@@ -1100,6 +1100,83 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 	if (__ballot(changed) != 0ull && nh_lane() == 0) st->keys_changed = 1u;          // (plain store of a constant)
 }
 
+// Asleep steps (nh_internal.h: nh_AsleepState): is every collider's world AABB (k_xform's arithmetic, bit for bit) and tag what it was when the world was found asleep,
+// and every body still asleep?  One lane per collider / body; any difference raises st->asleep_failed.
+__global__ __launch_bounds__(256) void k_asleep_check(nh_DevState* __restrict__ st, const nh_Transform* __restrict__ body_xf, const uint8_t* __restrict__ idle, uint32_t nbodies,
+                                                      const nh_Transform* __restrict__ box_xf, const nh_BoxCollider* __restrict__ box_data, const uint32_t* __restrict__ box_tags, uint32_t nbox,
+                                                      const nh_Transform* __restrict__ sph_xf, const nh_SphereCollider* __restrict__ sph_data, const uint32_t* __restrict__ sph_tags, uint32_t nsph,
+                                                      const float4* __restrict__ was_min, const float4* __restrict__ was_max, const uint32_t* __restrict__ was_tag) {
+	bool differs = false;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x + 1u; i < nbodies; i += gridDim.x * blockDim.x) differs |= idle[i] != 0xffu;
+	const uint32_t n = nbox + nsph;
+	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+		const bool is_box = c < nbox;
+		const nh_Transform l = is_box ? box_xf[c] : sph_xf[c - nbox];
+		if (l.body >= nbodies) { differs = true; continue; }
+		const nh_Transform b = body_xf[l.body];
+		const nh_quat bq = { b.rotation[0], b.rotation[1], b.rotation[2], b.rotation[3] };
+		const nh_quat lq = { l.rotation[0], l.rotation[1], l.rotation[2], l.rotation[3] };
+		const nh_f3 p = nh_rotate(bq, nh_make3(l.position[0], l.position[1], l.position[2])) + nh_make3(b.position[0], b.position[1], b.position[2]);
+		const nh_quat q = nh_qmul(bq, lq);
+		float sx, sy, sz;
+		uint32_t tag;
+		if (is_box) {
+			const nh_m33 m = nh_matrix(q);
+			const nh_BoxCollider bc = box_data[c];
+			const nh_f3 c0 = m.c0 * bc.size[0], c1 = m.c1 * bc.size[1], c2 = m.c2 * bc.size[2];
+			sx = fabsf(c0.x) + fabsf(c1.x) + fabsf(c2.x);
+			sy = fabsf(c0.y) + fabsf(c1.y) + fabsf(c2.y);
+			sz = fabsf(c0.z) + fabsf(c1.z) + fabsf(c2.z);
+			tag = box_tags[c];
+		} else {
+			sx = sy = sz = sph_data[c - nbox].radius;
+			tag = sph_tags[c - nbox];
+		}
+		const float4 mn = was_min[c], mx = was_max[c];
+		const float mnx = p.x - sx, mny = p.y - sy, mnz = p.z - sz, mxx = p.x + sx, mxy = p.y + sy, mxz = p.z + sz;
+		differs |= __float_as_uint(mnx) != __float_as_uint(mn.x) || __float_as_uint(mny) != __float_as_uint(mn.y) || __float_as_uint(mnz) != __float_as_uint(mn.z) ||
+		           __float_as_uint(mxx) != __float_as_uint(mx.x) || __float_as_uint(mxy) != __float_as_uint(mx.y) || __float_as_uint(mxz) != __float_as_uint(mx.z) ||
+		           __float_as_uint(mn.w) != l.body || tag != was_tag[c];
+	}
+	if (__ballot(differs) != 0ull && nh_lane() == 0) st->asleep_failed = 1u;          // (plain store of a constant)
+}
+
+// The one check of an nh_step call on a world that went to sleep (nh_solve.hip: nh_step): 0 = nothing has changed, 1 = something has, < 0 = error code.
+int nh_asleep_verify(nh_context* ctx, const nh_BodyData* bodies, const nh_ColliderData* colliders) {
+	nh_AsleepState& as = ctx->asleep;
+	const uint32_t C = colliders->boxes.count + colliders->spheres.count;
+	if (C != as.C || bodies->count != as.B || !as.aabb_min || !bodies->idle_counters) return 1;
+	NH_HIP_CHECK(ctx, hipMemsetAsync(&ctx->d_state->asleep_failed, 0, sizeof(uint32_t), ctx->stream));
+	NH_LAUNCH(ctx, "asleep_check", k_asleep_check, nh_grid_for(C > bodies->count ? C : bodies->count, 256, 4096), 256, ctx->d_state, bodies->transforms, bodies->idle_counters, bodies->count,
+	          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, colliders->boxes.count,
+	          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, colliders->spheres.count, as.aabb_min, as.aabb_max, as.tags);
+	uint32_t failed = 1u;
+	NH_HIP_CHECK(ctx, hipMemcpyAsync(&failed, &ctx->d_state->asleep_failed, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+	return failed ? 1 : 0;
+}
+
+// ... and the copies it compares with: this step's world AABBs and tags (the caller's arena still holds them), taken when the second all-asleep step in a row ends
+int nh_asleep_remember(nh_context* ctx) {
+	nh_AsleepState& as = ctx->asleep;
+	const uint32_t C = as.last_C;
+	if (!C || !as.last_aabb_min) return 1;
+	if (as.capacity < C) {
+		void** bufs[] = { (void**)&as.aabb_min, (void**)&as.aabb_max, (void**)&as.tags };
+		for (void** b : bufs) { if (*b) NH_HIP_CHECK(ctx, hipFree(*b)); *b = nullptr; }
+		as.capacity = 0;
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&as.aabb_min, sizeof(float4) * (size_t)C));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&as.aabb_max, sizeof(float4) * (size_t)C));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&as.tags, sizeof(uint32_t) * (size_t)C));
+		as.capacity = C;
+	}
+	NH_HIP_CHECK(ctx, hipMemcpyAsync(as.aabb_min, as.last_aabb_min, sizeof(float4) * (size_t)C, hipMemcpyDeviceToDevice, ctx->stream));
+	NH_HIP_CHECK(ctx, hipMemcpyAsync(as.aabb_max, as.last_aabb_max, sizeof(float4) * (size_t)C, hipMemcpyDeviceToDevice, ctx->stream));
+	NH_HIP_CHECK(ctx, hipMemcpyAsync(as.tags, as.last_ctag, sizeof(uint32_t) * (size_t)C, hipMemcpyDeviceToDevice, ctx->stream));
+	as.C = C;
+	return 0;
+}
+
 // ---- 7. islands (lock-free union-find), active bodies, sleeping -------------------------------------------
 // find with path halving: every visited node is re-pointed at its grandparent (an ancestor stays an ancestor whatever other
 // lanes do, and parent[x] <= x is preserved), so the long chains of one big island (ball pit) collapse as they are walked
@@ -1481,6 +1558,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 	float4* aabb_min = nh_arena_array<float4>(A, C, &err);
 	float4* aabb_max = nh_arena_array<float4>(A, C, &err);
 	uint32_t* ctag = nh_arena_array<uint32_t>(A, C, &err);
+	ctx->asleep.last_aabb_min = aabb_min; ctx->asleep.last_aabb_max = aabb_max; ctx->asleep.last_ctag = ctag; ctx->asleep.last_C = C;          // (nh_asleep_remember)
 	uint32_t* keys_a = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* keys_b = nh_arena_array<uint32_t>(A, C, &err);
 	uint32_t* vals_a = nh_arena_array<uint32_t>(A, C, &err);

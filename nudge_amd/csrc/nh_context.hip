@@ -11,6 +11,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	nh_context* ctx = new nh_context();
 	ctx->device = device;
 	ctx->stream = (hipStream_t)stream;
+	ctx->asleep.streak = 0;
 	ctx->flags = (flags & NH_FLAG_FUSED_STEP) ? (flags | NH_FLAG_SINGLE_APPLY) : flags;
 	ctx->after_collide = false; ctx->grav.pending = false; ctx->grav.rest_pending = false; ctx->adv.done = false; ctx->adv.rest = true;
 	ctx->tag_bits = 32;
@@ -58,6 +59,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->lay_class = nullptr; ctx->lay_simple = nullptr; ctx->body_rec = nullptr; ctx->body_pos = nullptr; ctx->lay_body_capacity = 0;
 	memset(&ctx->still, 0, sizeof(ctx->still));
 	ctx->first_ghost = 0;
+	memset(&ctx->asleep, 0, sizeof(ctx->asleep));
 	ctx->d_state = nullptr;
 	ctx->h_state = nullptr;
 	if (hipMalloc((void**)&ctx->d_state, sizeof(nh_DevState)) != hipSuccess) { delete ctx; return NH_ERR_HIP; }
@@ -86,6 +88,9 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
 	if (ctx->ev_active) hipEventDestroy(ctx->ev_active);
 	if (ctx->ev_gravity) hipEventDestroy(ctx->ev_gravity);
+	if (ctx->asleep.aabb_min) hipFree(ctx->asleep.aabb_min);
+	if (ctx->asleep.aabb_max) hipFree(ctx->asleep.aabb_max);
+	if (ctx->asleep.tags) hipFree(ctx->asleep.tags);
 	if (ctx->hint) hipFree(ctx->hint);
 	if (ctx->deg) hipFree(ctx->deg);
 	if (ctx->fat_pairs) hipFree(ctx->fat_pairs);
@@ -124,6 +129,7 @@ extern "C" void nh_destroy(nh_context* ctx) {
 extern "C" int nh_set_flags(nh_context* ctx, uint32_t flags) {
 	if (!ctx) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	ctx->asleep.streak = 0;
 	ctx->flags = (flags & NH_FLAG_FUSED_STEP) ? (flags | NH_FLAG_SINGLE_APPLY) : flags;
 	return NH_OK;
 }
@@ -132,6 +138,7 @@ extern "C" int nh_set_flags(nh_context* ctx, uint32_t flags) {
 extern "C" int nh_set_first_ghost_body(nh_context* ctx, uint32_t first_ghost) {
 	if (!ctx) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	ctx->asleep.streak = 0;
 	ctx->first_ghost = first_ghost;          // (still steps are not launched while the rule is on: nh_collide)
 	return NH_OK;
 }
@@ -141,7 +148,9 @@ extern "C" int nh_set_option(nh_context* ctx, const char* name, int value) {
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
 	const std::string n(name);
 	const bool on = value != 0;
-	if (n == "no_still") ctx->still.disabled = on;                        // no step is launched speculatively as a still step (note 9)
+	ctx->asleep.streak = 0;
+	if (n == "no_asleep") ctx->asleep.disabled = on;                      // nh_step runs every step of a world that is asleep in full (nh_internal.h: nh_AsleepState)
+	else if (n == "no_still") ctx->still.disabled = on;                        // no step is launched speculatively as a still step (note 9)
 	else if (n == "sort_classic") ctx->env_sort_classic = on;             // three-kernel radix passes
 	else if (n == "sort_radix") ctx->env_sort_radix = on;                 // radix passes every step (no seeded bucket sort)
 	else if (n == "no_sort_reuse") ctx->env_no_sort_reuse = on;           // the tag sort of the contact records runs every step even when nothing has changed
@@ -177,6 +186,7 @@ extern "C" int nh_bodies_changed(nh_context* ctx) {
 	if (!ctx) return NH_ERR_INVALID;
 	{ int rc = nh_still_abandon(ctx); if (rc) return rc; }
 	ctx->idle_bound = -1; ctx->idle_unknown = true;
+	ctx->asleep.streak = 0;
 	ctx->still.ok_next = false;                  // body records rewritten from outside: the next step looks at everything again
 	return NH_OK;
 }
@@ -204,6 +214,7 @@ void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out) {
 	out->general_contacts = h->general_contacts; out->levels = h->levels; out->error = h->error;
 	out->still_steps = (uint32_t)(ctx->still.launched - ctx->still.failed - ((ctx->still.active && !ctx->still.resolved) ? 1u : 0u)); out->still_replays = (uint32_t)ctx->still.failed;
 	for (int k = 0; k < 4; ++k) out->still_diff[k] = h->still_diff[k];
+	out->asleep_steps = (uint32_t)ctx->asleep.steps;
 	out->blk_blocks = h->blk.nblk; out->blk_bodies = h->blk.bodies; out->blk_ghosts = h->blk.ghost_cursor;
 	out->has_other_bodies = h->has_other; out->broadphase_rebuilds = h->fat_rebuilds; out->sort_reuses = h->sort_reuses; out->broadphase_inserts = h->fat_inserts; out->unleveled = h->unleveled; out->raw_pairs = h->pairs + h->pairs_sph;
 }
@@ -224,6 +235,7 @@ __global__ void k_set_cache_count(nh_DevState* st, uint32_t n) { st->cache = n; 
 extern "C" int nh_set_cache_count(nh_context* ctx, uint32_t count) {
 	if (!ctx) return NH_ERR_INVALID;
 	{ int rc = nh_still_abandon(ctx); if (rc) return rc; }
+	ctx->asleep.streak = 0;
 	ctx->still.cache_ok = false; ctx->still.slots_current = false; ctx->still.cache_stale = false;      // the caller has put another cache in place: what the slots hold is void
 	hipLaunchKernelGGL(k_set_cache_count, dim3(1), dim3(1), 0, ctx->stream, ctx->d_state, count);
 	return NH_OK;

@@ -125,6 +125,7 @@ struct nh_DevState {
 	uint32_t delta_count[2], delta_overflow[2];   // by step parity: collider pairs whose contact count changed in this still step (their tag-order position and the change are listed
 	                                              // in nh_context::still_delta; more than NH_DELTA_MAX of them: the counts are scanned again instead)
 	uint32_t still_smin[2][3], still_smax[2][3];   // by step parity: scene bounds of a still step (k_xform<true>; cleared for the next step by the step before)
+	uint32_t asleep_failed;                // k_asleep_check (nh_step, asleep steps): something is not what it was when the world went to sleep
 	uint32_t still_top[2];        // by step parity: largest idle counter a still step saw
 	nh_BlkGrid blk;               // spatially blocked solver (nh_blocks.h)
 };
@@ -193,6 +194,22 @@ struct nh_StillStep {
 	uint32_t seen_inserts, seen_rebuilds;          // re-insertion / rebuild counters at the last full step's round trip (finish_setup: did anybody leave its box in that step?)
 	void note_failure() { hold = (1u << fail_level) - 1u; if (fail_level < 6u) ++fail_level; good_run = 0; }
 	void note_confirmed() { if (++good_run >= 16u) fail_level = 0; }
+};
+
+// ASLEEP STEPS (nh_step only).  A world in which every body is asleep is a fixed point of the step: no active body, no contact, every overlapping pair a sleeping pair,
+// the cache kept aside and written back as it was (nudge.cpp:3669-3703, 4064-4101, 4896-4898) -- the step reads everything and changes nothing.  When two full steps in
+// a row have shown exactly that (their round trips: nobody active, no contact, the same pair / sleeping-pair / cache counts as the step before) the library
+// keeps a copy of the colliders' world AABBs and tags; nh_step then verifies ONCE per call, with one kernel, that all of them are what they were and that every body is
+// still asleep (the only things a caller could have changed between two calls without telling: nh_bodies_changed and friends end the regime themselves) -- and, if so,
+// the steps of that call are done: nothing inside the library can wake a world nobody is awake in.  Anything else runs the steps in full.
+struct nh_AsleepState {
+	bool disabled;                   // option "no_asleep"
+	uint32_t streak;                 // full steps in a row that were all-asleep fixed points
+	uint32_t prev_pairs, prev_sleeping, prev_cache;
+	float4 *aabb_min, *aabb_max; uint32_t* tags; uint32_t capacity;          // library-owned copies (world AABBs and tags of the step that made the streak 2)
+	uint32_t C, B;                   // colliders / bodies of that step
+	const float4 *last_aabb_min, *last_aabb_max; const uint32_t* last_ctag; uint32_t last_C;     // this step's arrays in the caller's arena (nh_collide)
+	uint64_t steps;                  // statistics
 };
 
 struct nh_context {
@@ -300,6 +317,7 @@ struct nh_context {
 	// per body (k_adj_simple): class, contact-list record of the full path; the record a body's contacts come from (| NH_BODY_REC_IS_A) and its tag-order position
 	uint8_t* lay_class; uint2* lay_simple; uint32_t* body_rec; uint32_t* body_pos; uint32_t lay_body_capacity;
 	nh_StillStep still;
+	nh_AsleepState asleep;
 	uint32_t first_ghost;          // nh_set_first_ghost_body: bodies >= first_ghost are ghosts of a partitioned world (0 = no ownership rule)
 };
 

@@ -16,6 +16,7 @@
 //     levels run one after the other, contacts inside a level are independent.  Executing levels in order
 //     is exactly the sequential Gauss-Seidel sweep in slot order.
 #include "nh_internal.h"
+int nh_asleep_remember(nh_context* ctx);            // nh_collide.hip (asleep steps: nh_internal.h)
 #include <type_traits>
 #include "nh_solver.h"
 
@@ -2399,6 +2400,17 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		// one -- a body in the air does on every step -- and a still step that fails costs two steps' worth of launches
 		if (h->fat_inserts != ctx->still.seen_inserts || h->fat_rebuilds != ctx->still.seen_rebuilds) ctx->still.ok_next = false;
 		ctx->still.seen_inserts = h->fat_inserts; ctx->still.seen_rebuilds = h->fat_rebuilds;
+		// asleep steps (nh_internal.h: nh_AsleepState): was this step the fixed point of a world in which every body is asleep -- nobody active, no contact, every cache
+		// entry kept aside -- and the second one in a row with the same counts?  Then nh_step may take the steps that follow as done (after its own check)
+		nh_AsleepState& as = ctx->asleep;
+		const uint32_t pairs_now = h->pairs + h->pairs_sph;
+		// (the cache: entries of sleeping pairs are kept aside and written back, nudge.cpp:4064-4101, by kernels that run after this round trip -- what shows here is that
+		//  the count the LAST step left is the count it found, i.e. nothing but kept-aside entries was in it)
+		const bool fixed_point = h->active == 0u && h->contacts == 0u && h->general_contacts == 0u && !h->error && h->sleeping != 0u && !ctx->first_ghost;
+		if (fixed_point && as.streak && as.prev_pairs == pairs_now && as.prev_sleeping == h->sleeping && as.prev_cache == h->cache) as.streak++;
+		else as.streak = fixed_point ? 1u : 0u;
+		as.prev_pairs = pairs_now; as.prev_sleeping = h->sleeping; as.prev_cache = h->cache;
+		if (as.streak == 2u && !as.disabled) { as.B = d->body_count; if (nh_asleep_remember(ctx)) as.streak = 0; }
 	}
 	// NH_FLAG_FUSED_STEP: gravity / damping of the bodies the fused solver does not own, before anything else reads their momentum -- not launched
 	// at all when every body is the fused solver's (a landed drop scene)
@@ -2697,6 +2709,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 }
 
 int nh_still_collide_again(nh_context* ctx);       // nh_collide.hip
+int nh_asleep_verify(nh_context* ctx, const nh_BodyData* bodies, const nh_ColliderData* colliders);      // nh_collide.hip
 int nh_still_view_contacts(nh_context* ctx);       // nh_collide.hip: the dense contact list laid out again from the slots (k_gather_contacts, view only)
 
 // ---- the contact cache between its two homes: the caller's arrays (tag order) and the slots (nh_internal.h, contact storage by slot) ------------------------
@@ -2941,6 +2954,14 @@ static int still_forget_failed(nh_context* ctx, bool advanced, uint32_t voided) 
 	return nh_still_export_cache(ctx);                                 // (the slot cache holds the last step that DID happen: the full solver reads the caller's arrays)
 }
 
+static bool same_bodies_arrays(const nh_BodyData& a, const nh_BodyData& b) {
+	return a.transforms == b.transforms && a.properties == b.properties && a.momentum == b.momentum && a.idle_counters == b.idle_counters && a.count == b.count;
+}
+static bool same_collider_arrays(const nh_ColliderData& a, const nh_ColliderData& b) {
+	return a.boxes.tags == b.boxes.tags && a.boxes.data == b.boxes.data && a.boxes.transforms == b.boxes.transforms && a.boxes.count == b.boxes.count &&
+	       a.spheres.tags == b.spheres.tags && a.spheres.data == b.spheres.data && a.spheres.transforms == b.spheres.transforms && a.spheres.count == b.spheres.count;
+}
+
 extern "C" int nh_step(nh_context* ctx, const nh_StepArgs* a, uint32_t steps) {
 	if (!ctx || !a || !a->active_bodies || !a->contacts || !a->bodies || !a->colliders || !a->contact_cache) return NH_ERR_INVALID;
 	NH_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -2962,6 +2983,16 @@ extern "C" int nh_step(nh_context* ctx, const nh_StepArgs* a, uint32_t steps) {
 			{ int rc = still_forget_failed(ctx, true, 1u); if (rc) { result = rc; break; } }
 			i -= 1;
 			continue;
+		}
+		// A world asleep (nh_internal.h: nh_AsleepState): two full steps in a row were its fixed point.  ONE check per call that nothing the caller owns has changed since
+		// -- and the remaining steps of this call are done: nothing inside the library wakes a world in which nobody is awake.
+		if (ctx->asleep.streak >= 2u && !ctx->asleep.disabled && !ss.verdict.pending && !ctx->pending && (ctx->flags & NH_FLAG_FUSED_STEP) && !(ctx->flags & NH_FLAG_SYNC_COUNTS) && !ctx->timing &&
+		    same_bodies_arrays(*a->bodies, ss.lay_bodies) && same_collider_arrays(*a->colliders, ss.lay_colliders) && a->contacts->data == ss.lay_contacts.data && a->contacts->tags == ss.lay_contacts.tags &&
+		    a->contacts->sleeping_pairs == ss.lay_contacts.sleeping_pairs && a->active_bodies->indices == ss.lay_active && a->contact_cache->data == ss.cache_data && a->contact_cache->tags == ss.cache_tags && a->contact_cache->features == ss.cache_features) {
+			const int v = nh_asleep_verify(ctx, a->bodies, a->colliders);
+			if (v < 0) { result = -v; break; }
+			if (v == 0) { ctx->asleep.steps += steps - i; i = steps; continue; }
+			ctx->asleep.streak = 0;
 		}
 		int rc;
 		nh_Arena temporary = a->arena;

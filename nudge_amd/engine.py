@@ -78,7 +78,7 @@ class Counts(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("colliders", "pairs", "contacts", "sleeping_pairs", "active_bodies", "cache", "culled",
                                           "large_colliders", "general_contacts", "levels", "error", "has_other_bodies", "unleveled", "raw_pairs", "broadphase_rebuilds", "sort_reuses", "broadphase_inserts",
                                           "still_steps", "still_replays", "still_diff_key", "still_diff_count", "still_diff_feature", "still_diff_escape",
-                                          "blk_blocks", "blk_bodies", "blk_ghosts")]
+                                          "blk_blocks", "blk_bodies", "blk_ghosts", "asleep_steps")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

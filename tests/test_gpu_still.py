@@ -175,3 +175,90 @@ def test_nh_step_with_late_verdicts_matches_the_eight_calls():
     assert ca["still_replays"] > c0["still_replays"] and ca["still_steps"] > c0["still_steps"] + 50, (c0, ca)
     assert ca["error"] == 0 and cb["error"] == 0
     a.close(); b.close(); c.close()
+
+
+# ---- asleep steps (nudge_amd/csrc/nh_internal.h: nh_AsleepState): nh_step on a world in which every body is asleep ---------------------------------------------
+def _plain_world(scene, **kw):
+    """Neither still steps nor asleep steps: every step in full."""
+    os.environ["NH_NO_STILL"] = "1"; os.environ["NH_NO_ASLEEP"] = "1"
+    try:
+        return E.World(scene, flags=BENCH_FLAGS, **kw)
+    finally:
+        os.environ.pop("NH_NO_STILL", None); os.environ.pop("NH_NO_ASLEEP", None)
+
+
+def _same_asleep_world(a, b, what=""):
+    _same_world(a, b, what)
+    ka, kb = a.get_contacts(), b.get_contacts()
+    assert np.array_equal(ka["sleeping_pairs"], kb["sleeping_pairs"]), f"{what}: sleeping pairs differ"
+    assert np.array_equal(a.get_active(), b.get_active()), f"{what}: active bodies differ"
+    ca, cb = a.counts(), b.counts()
+    for k in ("contacts", "sleeping_pairs", "active_bodies", "cache", "pairs", "error"):
+        assert ca[k] == cb[k], f"{what}: counter {k}: {ca[k]} vs {cb[k]}"
+
+
+def test_asleep_steps_change_nothing_and_leave_what_full_steps_leave():
+    """A drop scene falls asleep around step 300.  From then on a full step reads everything and changes nothing (no active body, no contact, every pair a sleeping
+    pair, the cache kept aside and written back: nudge.cpp:3669-3703, 4064-4101); nh_step checks once per call that nothing the caller owns has changed and takes the
+    steps as done.  Against a library that runs every step in full: bodies, idle counters, contacts, sleeping pairs, active list, cache and counters bit for bit --
+    through single-step calls, long calls, counts() in between; and against the compiled reference."""
+    scene = S.grid_tiles(2, side=40, sphere_fraction=0.5, seed=53, lattice_cols=2)
+    a, b = _world(scene, True), _plain_world(scene)
+    done = 0
+    for cp in (280, 330, 331, 332, 340, 500, 501, 900):
+        a.step(cp - done); b.step(cp - done); done = cp
+        _same_asleep_world(a, b, f"step {cp}")
+    ca = a.counts()
+    print(f"\n[asleep steps] {ca['asleep_steps']} of {done} steps taken as done ({ca['still_steps']} still steps)")
+    assert ca["active_bodies"] == 0 and ca["contacts"] == 0 and ca["sleeping_pairs"] > 0
+    assert ca["asleep_steps"] >= 500, ca
+    assert b.counts()["asleep_steps"] == 0
+    if refworld.available("exact") and S.narrow_ok(scene):
+        r = refworld.RefWorld(scene, max_contacts=8 * len(scene["body_transforms"]))
+        r.step(done)
+        rb, gb = r.bodies(), a.get_bodies()
+        assert P.bits_equal(gb["transforms"], rb["transforms"]) and np.array_equal(gb["idle"], rb["idle"])
+    a.close(); b.close()
+
+
+def test_whatever_the_caller_changes_while_the_world_sleeps_is_seen():
+    """Between two nh_step calls the caller may do anything to its arrays.  Told (nh_bodies_changed: idle counters rewritten) or untold (a sleeping body teleported, a
+    static collider moved, a collider's tag rewritten): the next call runs its steps in full and ends where the library that never skips ends."""
+    scene = S.grid_tiles(1, side=24, seed=59)
+    a, b = _world(scene, True), _plain_world(scene)
+    a.step(400); b.step(400)
+    a.step(20); b.step(20)
+    c0 = a.counts()
+    assert c0["active_bodies"] == 0 and c0["asleep_steps"] > 0
+    # (1) a sleeping body is put somewhere else, nobody is told: it stays asleep (nudge.cpp:3669-3672), its overlaps -- the sleeping pairs -- are others
+    for w in (a, b):
+        t = w.get_bodies()["transforms"]
+        t["position"][7] += np.float32(1.25)
+        w.set_bodies(transforms=t)
+    a.step(5); b.step(5)
+    _same_asleep_world(a, b, "teleported sleeper")
+    a.step(40); b.step(40)
+    _same_asleep_world(a, b, "teleported sleeper, later")
+    c1 = a.counts()
+    assert c1["asleep_steps"] - c0["asleep_steps"] < 45 and c1["asleep_steps"] > c0["asleep_steps"]          # (seen, and asleep steps again afterwards)
+    # (2) the ground is moved up a little under everybody (static collider 0), untold
+    for w in (a, b):
+        bx = w.records("xx", 32)
+        raw = np.frombuffer(bx[:1].cpu().numpy().tobytes(), dtype=S.TRANSFORM).copy()
+        raw["position"][0, 1] += np.float32(0.01)
+        bx[:1] = w.torch.from_numpy(raw.view(np.uint8).reshape(1, 32).copy()).to(bx.device)
+    a.step(3); b.step(3)
+    _same_asleep_world(a, b, "moved ground")
+    # (3) somebody is woken up and thrown: the world goes through contact, rest and sleep again
+    for w in (a, b):
+        bd = w.get_bodies()
+        idle, m = bd["idle"].copy(), bd["momentum"].copy()
+        idle[5::41] = 0
+        m["velocity"][5::41, 1] = 3.0
+        w.set_bodies(momentum=m, idle=idle)
+    for cp in (30, 200, 420, 470):
+        a.step(cp if cp == 30 else cp - prev); b.step(cp if cp == 30 else cp - prev); prev = cp
+        _same_asleep_world(a, b, f"woken, step {cp}")
+    c2 = a.counts()
+    assert c2["active_bodies"] == 0 and c2["asleep_steps"] > c1["asleep_steps"]
+    a.close(); b.close()
