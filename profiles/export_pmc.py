@@ -16,6 +16,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         name = row["Kernel_Name"].split("(")[0].replace("void ", "")
         per[name].append(float(row["Counter_Value"]))
     vals[c] = per
+# launches per step over the whole profiled run: k_xform (either instantiation) runs exactly once per step
+steps = sum(len(v) for n, v in vals["FETCH_SIZE"].items() if n.startswith("k_xform")) or 1
 res = {}
 for name in vals["FETCH_SIZE"]:
     f = vals["FETCH_SIZE"][name][-last:]
@@ -24,8 +26,10 @@ for name in vals["FETCH_SIZE"]:
         continue
     fr = sum(f) / len(f) * 1024.0
     wr = sum(w) / len(w) * 1024.0
-    res[name] = {"fetch_bytes_raw": fr, "write_bytes": wr, "hbm_bytes_raw": fr + wr, "hbm_bytes_corrected": 2 * fr + wr, "dispatches_averaged": len(f)}
-json.dump({"note": "bytes per launch, mean of the last dispatches (landed, awake steps of the 1M-box scene); corrected = 2*FETCH + WRITE (gfx950 half-count of wide reads)",
+    res[name] = {"fetch_bytes_raw": fr, "write_bytes": wr, "hbm_bytes_raw": fr + wr, "hbm_bytes_corrected": 2 * fr + wr, "dispatches_averaged": len(f),
+                 "launches_per_step": len(vals["FETCH_SIZE"][name]) / steps}
+json.dump({"note": "bytes per launch, mean of the last dispatches (landed, awake steps of the 1M-box scene); corrected = 2*FETCH + WRITE (gfx950 half-count of wide reads); "
+                   "launches_per_step = this kernel's dispatches / steps over the whole profiled run (landing included)",
            "kernels": res}, open(out, "w"), indent=1)
 for k, v in sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes_corrected"])[:14]:
     print(f"{k:28s} fetch {v['fetch_bytes_raw']/1e6:8.1f} MB  write {v['write_bytes']/1e6:8.1f} MB  corrected {v['hbm_bytes_corrected']/1e6:8.1f} MB")
