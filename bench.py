@@ -565,6 +565,7 @@ def main():
             # blocked sweeps: + the momentum records a sweep loads and stores -- every general body once as its block's own, and once more per block that borrows it as a
             # ghost (nh_Counts.blk_bodies + blk_ghosts of the last timed step: the block tables are rebuilt every step)
             blk_records = float(c1.get("blk_bodies", 0) + c1.get("blk_ghosts", 0)) or float(nb)
+            out["config"]["blocked_solver"] = {"blocks": c1.get("blk_blocks"), "bodies_binned": c1.get("blk_bodies"), "ghost_copies": c1.get("blk_ghosts")}
             for name in ("blk_sweep", "blk_warm"):
                 KERNEL_BYTES[name] = (KERNEL_BYTES[name][0], KERNEL_BYTES[name][1] + 64.0 * blk_records / max(G, 1.0))
         # the one-body solver as this world runs it (see KERNEL_BYTES): + 16 B of solver state per contact when a further apply call may follow,
@@ -601,7 +602,8 @@ def main():
             if args.scene == "pit" and args.side == 160:
                 global PMC_SUFFIX
                 PMC_SUFFIX = "_c4"
-            tr, traffic_src = pmc_traffic(dominant) if world == 1 and ((args.scene == "boxes" and args.tiles == 124) or (args.scene == "pit" and args.side == 160)) else (None, None)
+            comparable = world == 1 and ((args.scene == "boxes" and args.tiles == 124) or (args.scene == "pit" and args.side == 160)) and not any(k.startswith("NH_") for k in os.environ)
+            tr, traffic_src = pmc_traffic(dominant) if comparable else (None, None)          # (the committed PMC export describes the default paths of exactly these two scenes)
             traffic, traffic_raw = tr if tr else (None, None)
             out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": bytes_per_launch / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": bytes_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw,
