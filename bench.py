@@ -637,7 +637,9 @@ def main():
             # SURVEY 8(d)'s whole-run figure: steps [0, 1000) from the initial state -- fall, landing, rest, falling asleep -- timed as one block with no host
             # synchronisation inside; then the same 1000 steps once more, untimed, with the counters read every 10 steps for sum K_s, sum P_s
             w.restore(snap0); barrier()
+            cf0 = w.counts()
             t0 = time.perf_counter(); advance_world(1000); barrier(); t_full = time.perf_counter() - t0
+            cf1 = w.counts()
             w.restore(snap0)
             sum_k, sum_p, asleep_at, prev = 0.0, 0.0, None, None
             for s0 in range(0, 1000, 10):
@@ -653,6 +655,9 @@ def main():
                     asleep_at = s0 + 10
             out["full_window"] = {"steps": "[0, 1000)", "steps_per_s": 1000.0 / t_full, "seconds": t_full, "sum_contacts": sum_k, "sum_pairs": sum_p,
                                   "contacts_solved_per_sec": sum_k * I / t_full, "first_sleepers_by_step": asleep_at,
+                                  # how the 1000 steps went through (include/nudge_hip.h: note 9, nh_step): as still steps of a world at rest; as steps of a world in which every
+                                  # body is asleep and nothing has changed (a fixed point of the step: taken as done after one check); the rest in full
+                                  "still_steps": cf1.get("still_steps", 0) - cf0.get("still_steps", 0), "asleep_steps": cf1.get("asleep_steps", 0) - cf0.get("asleep_steps", 0),
                                   "note": "whole run from the initial state (free fall, landing, rest, sleep); sums by the trapezoid rule over counters read every 10 steps of an untimed replay"}
         if ktimes:
             # per-kernel milliseconds per step from the three fully instrumented landed steps (events around EVERY launch: the sum exceeds
