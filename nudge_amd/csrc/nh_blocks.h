@@ -52,6 +52,21 @@ __device__ __forceinline__ void nh_glds16(const float4* src, float4* lds_dst) {
 	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// ... the same with system scope (sc0 sc1): the line is fetched from memory whatever this XCD's L2 holds -- for data another workgroup of the SAME launch has
+// written with system-scope stores (chained sweeps below; MI355X: the L2s of the eight XCDs are not coherent with each other)
+__device__ __forceinline__ void nh_glds16_sys(const float4* src, float4* lds_dst) {
+	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 17);
+}
+typedef float nh_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nh_store16_sys(float4* dst, float4 v) {
+	const nh_v4f w = { v.x, v.y, v.z, v.w };
+	asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(dst), "v"(w) : "memory");
+}
+#define NH_BLK_NBR_WORDS 28u             // chained sweeps: per task the number of tasks it waits for, then up to 26 of them (+ padding)
+#define NH_BLK_CHAIN_PASSES 64u
+struct nh_BlkPhases { uint32_t start[9]; };          // workgroups of the eight block colours, as ranges of one launch
+struct nh_BlkChain { nh_BlkPhases ph; const uint32_t* nbr; uint32_t* done; uint32_t* ticket; uint32_t tag; uint32_t* error; };
+
 __device__ __forceinline__ uint32_t blk_slot(const uint32_t* __restrict__ own_base, uint32_t br) { return 1u + own_base[br >> NH_BLK_RANK_BITS] + (br & NH_BLK_RANK_MASK); }
 
 __global__ void k_blk_reset(nh_DevState* st) {
@@ -531,7 +546,6 @@ __global__ __launch_bounds__(256) void k_blk_slots(uint32_t nbodies, const uint2
 // mass | inverse inertia, body index: the same 32 bytes per body the sweep keeps of the momentum) and its contacts read them from there; what is left in
 // global memory per contact is its 32-byte record, its cached impulse and its place.  Same functions, same operands: the rows are the very bits
 // k_rows_general writes (NH_BLK_ROWS_GLOBAL=1 keeps that kernel: the A/B of the tests).
-struct nh_BlkPhases { uint32_t start[9]; };          // workgroups of the eight block colours, as ranges of one launch
 __global__ __launch_bounds__(NH_BLK_THREADS) void k_blk_rows(const nh_DevState* __restrict__ st, nh_BlkPhases ph, const uint32_t* __restrict__ desc_all, const uint32_t* __restrict__ ghost_list,
                                                              const uint32_t* __restrict__ pos_body, const uint32_t* __restrict__ order, const nh_Contact* __restrict__ contacts,
                                                              const nh_Transform* __restrict__ xf, const nh_BodyProperties* __restrict__ props, float4* __restrict__ rows4, size_t stride,
@@ -636,21 +650,67 @@ __global__ __launch_bounds__(256) void k_blk_scatter_back(uint32_t nbodies, cons
 // that take turns (no copies: a copy would have to wait for the loads it moves), and so the loads of the next 2 NG colours -- about half of a block's
 // contacts -- are under way while a colour is being solved.  All loads go out unconditionally at clamped positions: a load under a divergent branch is
 // issued and awaited inside that branch.
+// chained sweeps: task t = the t-th (block colour, block) in launch order.  Which task is a block's, and which tasks of EARLIER colours touch bodies it touches
+// (any of its 26 neighbours in the grid that has work: a block borrows ghosts only from neighbours, and only neighbours borrow from it)
+__global__ __launch_bounds__(256) void k_blk_chain_slots(nh_BlkPhases ph, const uint32_t* __restrict__ phase_list, uint32_t* __restrict__ slot_of_block) {
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= ph.start[8]) return;
+	int p = 0;
+	while (p < 7 && t >= ph.start[p + 1]) ++p;
+	slot_of_block[phase_list[(size_t)p * NH_BLK_MAX_BLOCKS + (t - ph.start[p])]] = t;
+}
+__global__ __launch_bounds__(256) void k_blk_chain_nbr(const nh_DevState* __restrict__ st, nh_BlkPhases ph, const uint32_t* __restrict__ phase_list, const uint32_t* __restrict__ slot_of_block,
+                                                       uint32_t* __restrict__ nbr, uint32_t* __restrict__ done) {
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	if (t >= ph.start[8]) return;
+	int p = 0;
+	while (p < 7 && t >= ph.start[p + 1]) ++p;
+	const uint32_t b = phase_list[(size_t)p * NH_BLK_MAX_BLOCKS + (t - ph.start[p])];
+	const uint32_t b0 = st->blk.bits[0], b1 = st->blk.bits[1], b2 = st->blk.bits[2];
+	const int d0 = 1 << b0, d1 = 1 << b1, d2 = 1 << b2;
+	const int c0 = (int)(b & (uint32_t)(d0 - 1)), c1 = (int)((b >> b0) & (uint32_t)(d1 - 1)), c2 = (int)((b >> (b0 + b1)) & (uint32_t)(d2 - 1));
+	uint32_t n = 0;
+	for (int z = -1; z <= 1; ++z) for (int y = -1; y <= 1; ++y) for (int x = -1; x <= 1; ++x) {
+		if (!x && !y && !z) continue;
+		const int q0 = c0 + x, q1 = c1 + y, q2 = c2 + z;
+		if (q0 < 0 || q0 >= d0 || q1 < 0 || q1 >= d1 || q2 < 0 || q2 >= d2) continue;
+		const uint32_t s = slot_of_block[(uint32_t)q0 | (uint32_t)q1 << b0 | (uint32_t)q2 << (b0 + b1)];
+		if (s != NH_NONE && s < ph.start[p]) nbr[(size_t)t * NH_BLK_NBR_WORDS + 1u + n++] = s;          // (an earlier colour: its task of this pass comes first)
+	}
+	nbr[(size_t)t * NH_BLK_NBR_WORDS] = n;
+	done[t] = 0u;
+}
+
 struct nh_blk_item { float4 r0, r1; float sx, sy, sz; uint32_t lp; };      // (position and validity follow from the colour: not kept)
-template<bool WARM, bool RADIAL_ONLY>
+template<bool WARM, bool RADIAL_ONLY, bool CHAIN = false>
 __global__ __launch_bounds__(NH_BLK_THREADS) __attribute__((amdgpu_waves_per_eu(RADIAL_ONLY ? 4 : 2, RADIAL_ONLY ? 4 : 2))) void k_blk_sweep(const uint32_t* __restrict__ desc, uint32_t L,
                                                               const uint32_t* __restrict__ ghost_list, const uint32_t* __restrict__ lpair, const float4* __restrict__ rows4, size_t stride,
-                                                              float* __restrict__ pstates, float4* bm4, unsigned long long* __restrict__ prof) {
+                                                              float* __restrict__ pstates, float4* bm4, unsigned long long* __restrict__ prof, nh_BlkChain chain = nh_BlkChain()) {
 	// prof (NH_BLK_PROFILE=1): per workgroup four readings of the 100 MHz wall clock -- start, bodies in, colours done, momentum out
 	constexpr uint32_t NG = NH_BLK_GROUPS, T = NH_BLK_THREADS, TG = NH_BLK_CHUNK;
-	if (prof && threadIdx.x == 0) prof[4 * (size_t)blockIdx.x] = wall_clock64();
+	const unsigned long long t_start = prof ? wall_clock64() : 0ull;
 	__shared__ float4 s_m0[NH_BLK_CAP], s_m1[NH_BLK_CAP];
 	__shared__ uint32_t s_desc[NH_BLK_DESC_WORDS];
 	__shared__ uint32_t s_first[64];                       // first chunk of every colour
 	__shared__ uint32_t s_cs[NH_BLK_MAX_CHUNKS + 1];       // chunk starts (positions in the block-ordered contact arrays); chunk m = [s_cs[m], s_cs[m + 1])
 	const uint32_t tid = threadIdx.x, g = tid / TG, t = tid % TG;
-	// one load brings everything the workgroup needs to know about its block (k_blk_prepare wrote it where blockIdx finds it)
-	if (tid < NH_BLK_DESC_WORDS) s_desc[tid] = desc[(size_t)blockIdx.x * NH_BLK_DESC_WORDS + tid];
+	// CHAIN: all eight block colours in one launch.  The workgroup's task is the next ticket (tickets go out in the order workgroups START, so every task this one
+	// may have to wait for below is running or done: no deadlock whatever the residency); `desc` = the descriptors of all colours
+	uint32_t task = blockIdx.x;
+	size_t pidx = blockIdx.x;          // (where the profile readings of this workgroup go)
+	if (CHAIN) {
+		__shared__ uint32_t s_task;
+		if (tid == 0) s_task = atomicAdd(chain.ticket, 1u);
+		__syncthreads();
+		task = s_task;
+		int p = 0;
+		while (p < 7 && task >= chain.ph.start[p + 1]) ++p;
+		desc += (size_t)p * NH_BLK_MAX_BLOCKS * NH_BLK_DESC_WORDS + (size_t)(task - chain.ph.start[p]) * NH_BLK_DESC_WORDS;
+		pidx = (size_t)p * NH_BLK_MAX_BLOCKS + (task - chain.ph.start[p]);
+	} else desc += (size_t)blockIdx.x * NH_BLK_DESC_WORDS;
+	if (prof && threadIdx.x == 0) prof[4 * pidx] = t_start;
+	// one load brings everything the workgroup needs to know about its block (k_blk_prepare wrote it where the task finds it)
+	if (tid < NH_BLK_DESC_WORDS) s_desc[tid] = desc[tid];
 	__syncthreads();
 	const uint32_t n_own = s_desc[1], base = s_desc[2], n_gh = s_desc[3], gb = s_desc[4];
 	const uint32_t* s_off = s_desc + 5;
@@ -722,22 +782,37 @@ __global__ __launch_bounds__(NH_BLK_THREADS) __attribute__((amdgpu_waves_per_eu(
 	nh_blk_item A, B, C;
 	fetch(0u, A);
 	fetch(1u, B);
-	if (tid == 0) { nh_glds16(bm4, &s_m0[0]); nh_glds16(bm4 + 1, &s_m1[0]); }
-	for (uint32_t i = tid; i < n_own; i += T) {
-		nh_glds16(bm4 + 2 * (size_t)(base + i), &s_m0[1u + i]);
-		nh_glds16(bm4 + 2 * (size_t)(base + i) + 1, &s_m1[1u + i]);
+	if (CHAIN) {
+		// wait for the tasks of earlier colours that touch this block's bodies (k_blk_chain_nbr): they publish their momentum with system-scope stores and then
+		// their pass tag; the spin is bounded -- a tag that never comes is an error, not a hang
+		if (tid < 64u) {
+			const uint32_t* mine = chain.nbr + (size_t)task * NH_BLK_NBR_WORDS;
+			const uint32_t cnt = mine[0];
+			if (tid < cnt) {
+				const uint32_t other = mine[1u + tid];
+				uint32_t spins = 0;
+				while (__hip_atomic_load(&chain.done[other], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != chain.tag) {
+					__builtin_amdgcn_s_sleep(8);
+					if (++spins > 4000000u) { *chain.error = NH_ERR_INVALID; break; }
+				}
+			}
+		}
+		__syncthreads();
 	}
+	auto body_in = [&](size_t slot, uint32_t at) {
+		if (CHAIN) { nh_glds16_sys(bm4 + 2 * slot, &s_m0[at]); nh_glds16_sys(bm4 + 2 * slot + 1, &s_m1[at]); }
+		else { nh_glds16(bm4 + 2 * slot, &s_m0[at]); nh_glds16(bm4 + 2 * slot + 1, &s_m1[at]); }
+	};
+	if (tid == 0) { nh_glds16(bm4, &s_m0[0]); nh_glds16(bm4 + 1, &s_m1[0]); }
+	for (uint32_t i = tid; i < n_own; i += T) body_in((size_t)(base + i), 1u + i);
 #pragma unroll
 	for (uint32_t u = 0; u < UG; ++u) {
 		const uint32_t i = tid + u * T;
-		if (i < n_gh) { nh_glds16(bm4 + 2 * (size_t)gs[u], &s_m0[1u + n_own + i]); nh_glds16(bm4 + 2 * (size_t)gs[u] + 1, &s_m1[1u + n_own + i]); }
+		if (i < n_gh) body_in((size_t)gs[u], 1u + n_own + i);
 	}
-	for (uint32_t i = tid + UG * T; i < n_gh; i += T) {
-		const size_t slot = ghost_list[gb + i];
-		nh_glds16(bm4 + 2 * slot, &s_m0[1u + n_own + i]); nh_glds16(bm4 + 2 * slot + 1, &s_m1[1u + n_own + i]);
-	}
+	for (uint32_t i = tid + UG * T; i < n_gh; i += T) body_in((size_t)ghost_list[gb + i], 1u + n_own + i);
 	__syncthreads();
-	if (prof && threadIdx.x == 0) prof[4 * (size_t)blockIdx.x + 1] = wall_clock64();
+	if (prof && threadIdx.x == 0) prof[4 * pidx + 1] = wall_clock64();
 	uint32_t j = 0;
 #define NH_BLK_STEP(CUR, FREE)                                                                                                                           \
 	{                                                                                                                                                    \
@@ -756,13 +831,23 @@ __global__ __launch_bounds__(NH_BLK_THREADS) __attribute__((amdgpu_waves_per_eu(
 	}
 	for (;;) { NH_BLK_STEP(A, C) NH_BLK_STEP(B, A) NH_BLK_STEP(C, B) }
 #undef NH_BLK_STEP
-	if (prof && threadIdx.x == 0) prof[4 * (size_t)blockIdx.x + 2] = wall_clock64();
+	if (prof && threadIdx.x == 0) prof[4 * pidx + 2] = wall_clock64();
 	// momentum out; the first ghost slots are still in registers
-	for (uint32_t i = tid; i < n_own; i += T) { bm4[2 * (size_t)(base + i)] = s_m0[1u + i]; bm4[2 * (size_t)(base + i) + 1] = s_m1[1u + i]; }
+	auto body_out = [&](size_t slot, uint32_t at) {
+		if (CHAIN) { nh_store16_sys(bm4 + 2 * slot, s_m0[at]); nh_store16_sys(bm4 + 2 * slot + 1, s_m1[at]); }
+		else { bm4[2 * slot] = s_m0[at]; bm4[2 * slot + 1] = s_m1[at]; }
+	};
+	for (uint32_t i = tid; i < n_own; i += T) body_out((size_t)(base + i), 1u + i);
 #pragma unroll
-	for (uint32_t u = 0; u < UG; ++u) { const uint32_t i = tid + u * T; if (i < n_gh) { bm4[2 * (size_t)gs[u]] = s_m0[1u + n_own + i]; bm4[2 * (size_t)gs[u] + 1] = s_m1[1u + n_own + i]; } }
-	for (uint32_t i = tid + UG * T; i < n_gh; i += T) { const size_t slot = ghost_list[gb + i]; bm4[2 * slot] = s_m0[1u + n_own + i]; bm4[2 * slot + 1] = s_m1[1u + n_own + i]; }
-	if (prof && threadIdx.x == 0) prof[4 * (size_t)blockIdx.x + 3] = wall_clock64();
+	for (uint32_t u = 0; u < UG; ++u) { const uint32_t i = tid + u * T; if (i < n_gh) body_out((size_t)gs[u], 1u + n_own + i); }
+	for (uint32_t i = tid + UG * T; i < n_gh; i += T) body_out((size_t)ghost_list[gb + i], 1u + n_own + i);
+	if (CHAIN) {
+		// published: every store of the workgroup has left, then the tag (system scope, like the stores)
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (tid == 0) __hip_atomic_store(&chain.done[task], chain.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+	if (prof && threadIdx.x == 0) prof[4 * pidx + 3] = wall_clock64();
 }
 
 // ---- NH_BLK_CHECK=1: structural check of one block colour's launch -------------------------------------------------------------------------------------

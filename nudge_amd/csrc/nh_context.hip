@@ -52,6 +52,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	memset(&ctx->blk, 0, sizeof(ctx->blk));
 	ctx->blk.scale = 1.0f;
 	ctx->blk.disabled = false; ctx->blk.check = false;
+	ctx->blk.chain = true;
 	ctx->blk.min_contacts = 200000u;
 	ctx->blk.target = 900u;
 	ctx->raw_data = nullptr; ctx->raw_feature = nullptr; ctx->raw_slots = 0; ctx->rec = nullptr; ctx->lay_rank = nullptr; ctx->cnt_sorted = nullptr; ctx->start_sorted = nullptr; ctx->dense_slot = nullptr;
@@ -118,7 +119,7 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	}
 	{
 		nh_BlkBuffers& k = ctx->blk;
-		void* bufs[] = { k.brank, k.bm, k.pos_body, k.touch, k.lpair, k.ghost_list, k.blk_count, k.own_base, k.bins, k.bin_off, k.ghost_base, k.ghost_count, k.phase_list, k.desc, k.scan_tmp, k.prof };
+		void* bufs[] = { k.brank, k.bm, k.pos_body, k.touch, k.lpair, k.ghost_list, k.blk_count, k.own_base, k.bins, k.bin_off, k.ghost_base, k.ghost_count, k.phase_list, k.desc, k.scan_tmp, k.prof, k.chain_slot, k.chain_nbr, k.chain_done, k.chain_ticket };
 		for (void* b : bufs) if (b) hipFree(b);
 	}
 	if (ctx->d_state) hipFree(ctx->d_state);
@@ -170,6 +171,7 @@ extern "C" int nh_set_option(nh_context* ctx, const char* name, int value) {
 	else if (n == "blk_target") ctx->blk.target = value < 8 ? 8u : (uint32_t)value;      // bodies per average block
 	else if (n == "blk_rows_global") ctx->env_blk_rows_global = on;       // rows of block-owned contacts by k_rows_general
 	else if (n == "blk_global_colours") ctx->env_blk_global_colours = on; // the blocked solver takes the world-wide colouring
+	else if (n == "no_blk_chain") ctx->blk.chain = !on;                   // blocked solver: eight launches per pass (one per block colour) instead of one launch with neighbour-to-neighbour waits
 	else if (n == "blk_profile") {                                         // wall-clock readings of the sweep workgroups, printed now and then
 		if (on && !ctx->blk.prof) NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->blk.prof, sizeof(unsigned long long) * 4u * 8u * NH_BLK_MAX_BLOCKS));
 	}

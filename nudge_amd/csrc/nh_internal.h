@@ -156,6 +156,9 @@ struct nh_BlkBuffers {
 	float scale;                      // block edge relative to the edge at which an average block holds `target` bodies: adapted from the largest load seen
 	uint32_t target, min_contacts;    // NH_BLK_TARGET, NH_BLK_MIN
 	bool disabled, check;             // NH_NO_BLOCKS=1, NH_BLK_CHECK=1
+	// chained sweeps (option "blk_chain", nh_blocks.h: k_blk_sweep<.., CHAIN>): the eight block colours of a pass as ONE launch; a workgroup draws its task from a
+	// ticket counter in (colour, block) order and waits only for the neighbour blocks of earlier colours -- no launch-wide tail between two colours
+	bool chain; uint32_t* chain_slot; uint32_t* chain_nbr; uint32_t* chain_done; uint32_t* chain_ticket;      // block -> task; per task: count + tasks it waits for; per task: last pass done; per pass: ticket counter
 	unsigned long long* prof; uint32_t prof_calls;       // NH_BLK_PROFILE=1: wall-clock readings of the sweep workgroups (8 launches x NH_BLK_MAX_BLOCKS x 4), printed now and then
 };
 
@@ -407,6 +410,7 @@ struct nh_ContactConstraintData {
 		bool local;                           // the blocks coloured their own contacts (k_blk_prepare_local): no world-wide colour, no general adjacency lists
 		uint32_t L;                                   // colours
 		uint32_t phase_count[8];
+		bool chain; uint32_t chain_pass;              // chained sweeps usable for this setup (tables built, no residual contacts); passes launched so far
 		uint32_t res_off[NH_BLK_MAX_COLOURS + 2];     // residual contacts (no block can own them) by colour: positions in the level-order arrays
 	} blk;
 };

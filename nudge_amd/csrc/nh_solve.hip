@@ -2193,6 +2193,10 @@ static int blk_reserve(nh_context* ctx, uint32_t B, uint32_t kcap) {
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.phase_list, sizeof(uint32_t) * 8u * NH_BLK_MAX_BLOCKS));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.desc, sizeof(uint32_t) * 8u * NH_BLK_MAX_BLOCKS * NH_BLK_DESC_WORDS));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.scan_tmp, sizeof(uint32_t) * (2u * NH_SORT_GRID + 64u)));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.chain_slot, sizeof(uint32_t) * nb));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.chain_nbr, sizeof(uint32_t) * nb * NH_BLK_NBR_WORDS));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.chain_done, sizeof(uint32_t) * nb));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&k.chain_ticket, sizeof(uint32_t) * NH_BLK_CHAIN_PASSES));
 		k.tables = true;
 	}
 	if (k.body_capacity < B + 1u) {
@@ -2312,6 +2316,20 @@ static int blk_setup(nh_context* ctx, nh_ContactConstraintData* d, uint32_t G, b
 		NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 		if (h->check_errors) { fprintf(stderr, "nudge_hip: blocked solver structure check failed (%u errors)\n", h->check_errors); return NH_ERR_INVALID; }
 	}
+	// chained sweeps (option "blk_chain"): which task is a block's, which tasks of earlier colours it waits for; tags and tickets start over
+	d->blk.chain = false; d->blk.chain_pass = 0;
+	if (k.chain && local && d->blk.res_off[d->blk.L] == d->blk.res_off[0]) {
+		nh_BlkPhases ph;
+		ph.start[0] = 0;
+		for (int p = 0; p < 8; ++p) ph.start[p + 1] = ph.start[p] + d->blk.phase_count[p];
+		if (ph.start[8]) {
+			NH_HIP_CHECK(ctx, hipMemsetAsync(k.chain_slot, 0xff, sizeof(uint32_t) * NH_BLK_MAX_BLOCKS, ctx->stream));
+			NH_HIP_CHECK(ctx, hipMemsetAsync(k.chain_ticket, 0, sizeof(uint32_t) * NH_BLK_CHAIN_PASSES, ctx->stream));
+			NH_LAUNCH(ctx, "blk_chain_slots", k_blk_chain_slots, (ph.start[8] + 255u) / 256u, 256, ph, k.phase_list, k.chain_slot);
+			NH_LAUNCH(ctx, "blk_chain_nbr", k_blk_chain_nbr, (ph.start[8] + 255u) / 256u, 256, st, ph, k.phase_list, k.chain_slot, k.chain_nbr, k.chain_done);
+			d->blk.chain = true;
+		}
+	}
 	d->blk.active = true;
 	d->blk.warm_pending = true;
 	return NH_OK;
@@ -2328,6 +2346,20 @@ static void blk_run(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyD
 	NH_LAUNCH(ctx, "blk_gather", k_blk_gather, nh_grid_for(B, 256, 4096), 256, B, k.brank, k.own_base, (const float4*)bodies->momentum, bodies->properties, k.bm, (uint32_t*)nullptr);
 	for (uint32_t pass = 0; pass < passes; ++pass) {
 		const bool w = warm && pass == 0u;
+		if (d->blk.chain && d->blk.chain_pass < NH_BLK_CHAIN_PASSES) {
+			// one launch for the eight block colours of this pass
+			nh_BlkChain ch;
+			ch.ph.start[0] = 0;
+			for (int p = 0; p < 8; ++p) ch.ph.start[p + 1] = ch.ph.start[p] + d->blk.phase_count[p];
+			ch.nbr = k.chain_nbr; ch.done = k.chain_done; ch.ticket = k.chain_ticket + d->blk.chain_pass; ch.tag = ++d->blk.chain_pass; ch.error = &ctx->d_state->error;
+			unsigned long long* pr = (k.prof && pass + 1u == passes) ? k.prof : (unsigned long long*)nullptr;
+#define NH_BLK_CHAINED(NAME, W, R) NH_LAUNCH(ctx, NAME, (k_blk_sweep<W, R, true>), ch.ph.start[8], NH_BLK_THREADS, k.desc, L, k.ghost_list, k.lpair, \
+			          (const float4*)d->rows, stride, reinterpret_cast<float*>(d->gstates), k.bm, pr, ch)
+			if (w) { if (d->blk.radial_only) NH_BLK_CHAINED("blk_warm", true, true); else NH_BLK_CHAINED("blk_warm", true, false); }
+			else { if (d->blk.radial_only) NH_BLK_CHAINED("blk_sweep", false, true); else NH_BLK_CHAINED("blk_sweep", false, false); }
+#undef NH_BLK_CHAINED
+			continue;
+		}
 		for (int p = 0; p < 8; ++p) {
 			const uint32_t n = d->blk.phase_count[p];
 			if (!n) continue;

@@ -32,7 +32,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _world(monkeypatch, scene, env, flags=E.NH_FLAG_SINGLE_APPLY, **kw):
-    keys = ("NH_BLK_MIN", "NH_BLK_TARGET", "NH_BLK_CHECK", "NH_NO_BLOCKS", "NH_NO_RESIDENT", "NH_BLK_GLOBAL_COLOURS", "NH_BLK_ROWS_GLOBAL")
+    keys = ("NH_BLK_MIN", "NH_BLK_TARGET", "NH_BLK_CHECK", "NH_NO_BLOCKS", "NH_NO_RESIDENT", "NH_BLK_GLOBAL_COLOURS", "NH_BLK_ROWS_GLOBAL", "NH_NO_BLK_CHAIN")
     for k in keys:
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
@@ -88,6 +88,34 @@ def test_many_blocks_structure_determinism_and_call_pattern(monkeypatch, target)
     x, y, z = a.get_bodies(), b.get_bodies(), c.get_bodies()
     assert _same(x, y), "two runs of the blocked solver differ: a data race"
     assert _same(x, z), "16 x apply(1) differs from apply(16)"
+    a.close(); b.close(); c.close()
+
+
+@pytest.mark.parametrize("target", [40, 300])
+def test_chained_sweeps_are_the_bits_of_the_eight_launches(monkeypatch, target):
+    """The default sweep (option no_blk_chain switches it off): the eight block colours of a pass as ONE launch -- a workgroup draws its (colour, block) task from a ticket counter and waits only for the
+    neighbour blocks of earlier colours, which publish their momentum with system-scope stores (nh_blocks.h: k_blk_sweep<.., CHAIN>).  Same blocks, same colour
+    order inside and between the blocks => the bits of the eight launches, step after step, with the structure check on; 16 x apply(1) included."""
+    scene = S.ball_pit(20, 20, 20, seed=9)
+    nb = 8000
+    env = dict(NH_BLK_MIN=1, NH_BLK_TARGET=target, NH_BLK_CHECK=1)
+    a = _world(monkeypatch, scene, env, max_contacts=8 * nb, max_pairs=10 * nb)
+    b = _world(monkeypatch, scene, dict(env, NH_NO_BLK_CHAIN=1), max_contacts=8 * nb, max_pairs=10 * nb)
+    c = _world(monkeypatch, scene, env, flags=0, max_contacts=8 * nb, max_pairs=10 * nb)
+    for upto in (60, 200, 330):
+        a.step(upto - a.steps_done); b.step(upto - b.steps_done)
+        assert a.counts()["error"] == 0 and b.counts()["error"] == 0
+        assert _same(a.get_bodies(), b.get_bodies()), f"chained sweeps differ from the eight launches at step {upto}"
+        ca, cb = a.get_cache(), b.get_cache()
+        assert ca["count"] == cb["count"] and P.bits_equal(ca["data"]["impulse"], cb["data"]["impulse"])
+    for _ in range(330):
+        c.collide(); c.gravity(); c.read_cache(); c.setup()
+        for _ in range(16):
+            c.apply(1)
+        c.update(); c.write_cache(); c.advance()
+    assert c.counts()["error"] == 0
+    assert _same(a.get_bodies(), c.get_bodies()), "chained: 16 x apply(1) differs from apply(16)"
+    assert a.counts()["general_contacts"] > 15000
     a.close(); b.close(); c.close()
 
 
