@@ -67,6 +67,26 @@ __device__ __forceinline__ void nh_store16_sys(float4* dst, float4 v) {
 struct nh_BlkPhases { uint32_t start[9]; };          // workgroups of the eight block colours, as ranges of one launch
 struct nh_BlkChain { nh_BlkPhases ph; const uint32_t* nbr; uint32_t* done; uint32_t* ticket; uint32_t tag; uint32_t* error; };
 
+// Places at per-key counters for the lanes of a wave (`valid` lanes; `key` = index of the counter): lanes with the same key find each other by ballots, and then ALL
+// group leaders ask for their group's places at once -- one memory round trip per call, not one per distinct key in the wave (a returning atomic is a round trip the
+// wave waits for; contacts and bodies arrive in spatial order, so a wave meets a handful of keys)
+__device__ __forceinline__ uint32_t nh_wave_places(uint32_t* __restrict__ counters, bool valid, uint32_t key) {
+	const uint32_t lane = nh_lane();
+	uint32_t leader = lane, before = 0, group = 0;
+	unsigned long long todo = __ballot(valid);
+	while (todo) {
+		const int first = __ffsll((long long)todo) - 1;
+		const uint32_t k = (uint32_t)__shfl((int)key, first);
+		const unsigned long long same = __ballot(valid && key == k) & todo;
+		if ((same >> lane) & 1ull) { leader = (uint32_t)first; before = (uint32_t)__popcll(same & ((1ull << lane) - 1ull)); group = (uint32_t)__popcll(same); }
+		todo &= ~same;
+	}
+	uint32_t base = 0;
+	if (valid && leader == lane) base = atomicAdd(&counters[key], group);
+	base = (uint32_t)__shfl((int)base, (int)leader);
+	return base + before;
+}
+
 __device__ __forceinline__ uint32_t blk_slot(const uint32_t* __restrict__ own_base, uint32_t br) { return 1u + own_base[br >> NH_BLK_RANK_BITS] + (br & NH_BLK_RANK_MASK); }
 
 __global__ void k_blk_reset(nh_DevState* st) {
@@ -157,7 +177,6 @@ __global__ __launch_bounds__(256) void k_blk_body(nh_DevState* __restrict__ st, 
 	const float inv = st->blk.inv_edge * 1024.0f;
 	const uint32_t bits[3] = { st->blk.bits[0], st->blk.bits[1], st->blk.bits[2] };
 	const uint32_t rounded = (nbodies + 63u) & ~63u;
-	const uint32_t lane = nh_lane();
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
 		const bool general = i >= 1u && i < nbodies && body_class[i] == NH_CLS_GENERAL;
 		uint32_t blk = 0, frac = 0;
@@ -175,18 +194,7 @@ __global__ __launch_bounds__(256) void k_blk_body(nh_DevState* __restrict__ st, 
 				shift += bits[k];
 			}
 		}
-		uint32_t rank = 0;
-		unsigned long long todo = __ballot(general);
-		while (todo) {
-			const int leader = __ffsll((long long)todo) - 1;
-			const uint32_t lb = (uint32_t)__shfl((int)blk, leader);
-			const unsigned long long same = __ballot(general && blk == lb) & todo;
-			uint32_t base = 0;
-			if ((int)lane == leader) base = atomicAdd(&blk_count[lb], (uint32_t)__popcll(same));
-			base = (uint32_t)__shfl((int)base, leader);
-			if ((same >> lane) & 1ull) rank = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-			todo &= ~same;
-		}
+		uint32_t rank = nh_wave_places(blk_count, general, blk);
 		if (general) {
 			if (rank >= NH_BLK_RANK_MASK) { st->blk.overflow = 1; rank = NH_BLK_RANK_MASK; }
 			brank[i] = make_uint2(blk << NH_BLK_RANK_BITS | rank, frac);
@@ -232,18 +240,7 @@ __global__ __launch_bounds__(256) void k_blk_contact(nh_DevState* __restrict__ s
 		const uint32_t bin = owner * L + (l - 1u);
 		// (contacts come in tag order, which is spatial order in a generated scene: the lanes of a wave hit a handful of bins -- one atomic per bin and wave;
 		// with one bin per block, 2500 contacts each, a returning atomic per contact cost 1.9 ms in a pit of 11 M contacts)
-		uint32_t rnk = 0;
-		unsigned long long todo = __ballot(1);
-		while (todo) {
-			const int leader = __ffsll((long long)todo) - 1;
-			const uint32_t lb2 = (uint32_t)__shfl((int)bin, leader);
-			const unsigned long long same = __ballot(bin == lb2) & todo;
-			uint32_t base2 = 0;
-			if ((int)nh_lane() == leader) base2 = atomicAdd(&bins[lb2], (uint32_t)__popcll(same));
-			base2 = (uint32_t)__shfl((int)base2, leader);
-			if ((same >> nh_lane()) & 1ull) rnk = base2 + (uint32_t)__popcll(same & ((1ull << nh_lane()) - 1ull));
-			todo &= ~same;
-		}
+		const uint32_t rnk = nh_wave_places(bins, true, bin);
 		rank_out[k] = rnk;
 		bin_out[k] = bin;
 	}
