@@ -707,7 +707,10 @@ __global__ __launch_bounds__(NH_BLK_THREADS) __attribute__((amdgpu_waves_per_eu(
 	} else desc += (size_t)blockIdx.x * NH_BLK_DESC_WORDS;
 	if (prof && threadIdx.x == 0) prof[4 * pidx] = t_start;
 	// one load brings everything the workgroup needs to know about its block (k_blk_prepare wrote it where the task finds it)
+	// (CHAIN: and, in the same round trip, the list of tasks it has to wait for)
+	__shared__ uint32_t s_nbr[NH_BLK_NBR_WORDS];
 	if (tid < NH_BLK_DESC_WORDS) s_desc[tid] = desc[tid];
+	if (CHAIN && tid >= 64u && tid < 64u + NH_BLK_NBR_WORDS) s_nbr[tid - 64u] = chain.nbr[(size_t)task * NH_BLK_NBR_WORDS + (tid - 64u)];
 	__syncthreads();
 	const uint32_t n_own = s_desc[1], base = s_desc[2], n_gh = s_desc[3], gb = s_desc[4];
 	const uint32_t* s_off = s_desc + 5;
@@ -783,10 +786,9 @@ __global__ __launch_bounds__(NH_BLK_THREADS) __attribute__((amdgpu_waves_per_eu(
 		// wait for the tasks of earlier colours that touch this block's bodies (k_blk_chain_nbr): they publish their momentum with system-scope stores and then
 		// their pass tag; the spin is bounded -- a tag that never comes is an error, not a hang
 		if (tid < 64u) {
-			const uint32_t* mine = chain.nbr + (size_t)task * NH_BLK_NBR_WORDS;
-			const uint32_t cnt = mine[0];
+			const uint32_t cnt = s_nbr[0];
 			if (tid < cnt) {
-				const uint32_t other = mine[1u + tid];
+				const uint32_t other = s_nbr[1u + tid];
 				uint32_t spins = 0;
 				while (__hip_atomic_load(&chain.done[other], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != chain.tag) {
 					__builtin_amdgcn_s_sleep(8);
