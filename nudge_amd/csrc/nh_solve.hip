@@ -900,7 +900,6 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 	__shared__ nh_ob_slot s_slot[NW][64 * M];
 	__shared__ uint32_t s_cid[NW][64 * M];
 	__shared__ uint32_t s_hint[NW][64], s_first[NW][64];
-	__shared__ uint32_t s_wid[STILL ? NW : 1][STILL ? 64 * M : 1];       // STILL: per contact, the slot of the cache entry it warm-starts from
 	__shared__ int2 s_delta[STILL ? NH_DELTA_MAX : 1];                   // STILL: this step's changes of contact counts (tag-order position, difference)
 	uint32_t n_delta = 0;
 	if (STILL) {
@@ -951,61 +950,25 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		uint32_t first = 0xFFFFFFFFu;
 		uint32_t still_base = 0, still_rec = 0;
 		bool still_has = false;
+		// STILL: two memory round trips, like the full form -- (1) the body's record and tag-order position (above); (2) EVERYTHING else at once: the record's count,
+		// start and cached count, the feature words of its four slots (this step's and the cached ones), the four contacts and the four cached impulses IN SLOT ORDER
+		// (the wave-cooperative loads below), the body state.  Which slot is solved when, and which cached impulse it starts from, is worked out afterwards in
+		// registers -- the version that first read counts, then features, then sorted, then fetched the contacts in solve order waited for four dependent round trips
+		uint32_t st_start = 0, st_cnt = 0, st_oc = 0;
+		uint32_t nf[M], of[M];
+		uint32_t sl[M], jm[M];          // solve order -> slot of the contact, slot of the cached impulse it starts from (0xFFFFFFFF: none)
+#pragma unroll
+		for (int k = 0; k < M; ++k) { nf[k] = 0u; of[k] = 0u; sl[k] = (uint32_t)k; jm[k] = 0xFFFFFFFFu; }
 		if (STILL) {
 			still_has = br != NH_BODY_REC_NONE;
-			still_rec = br & ~NH_BODY_REC_IS_A;
+			still_rec = still_has ? (br & ~NH_BODY_REC_IS_A) : 0u;
 			const uint32_t n_bb = min(cv.st->pairs, sv.pair_cap);
 			still_base = still_rec < n_bb ? 4u * still_rec : 4u * n_bb + (still_rec - n_bb);       // (a record of a pair with a sphere owns ONE slot, behind the box-box records' four each)
-			uint32_t start = 0, oc = 0;
-			if (still_has) {
-				cnt = min(sv.cnt_sorted[bpos], 4u); start = sv.start_sorted[bpos]; oc = min(sv.sc_count[still_rec], 4u);
-				int shift = 0;
-				for (uint32_t k = 0; k < n_delta; ++k) shift += (uint32_t)s_delta[k].x < bpos ? s_delta[k].y : 0;
-				if (shift) { start += (uint32_t)shift; sv.start_sorted[bpos] = start; }
-			}
-			uint32_t nf[M], of[M];
+			const uint32_t bp = still_has ? bpos : 0u;
+			st_cnt = sv.cnt_sorted[bp]; st_start = sv.start_sorted[bp]; st_oc = sv.sc_count[still_rec];
 #pragma unroll
-			for (int k = 0; k < M; ++k) { nf[k] = (uint32_t)k < cnt ? sv.raw_feature[still_base + k] : 0u; of[k] = (uint32_t)k < oc ? sv.sc_feat[still_base + k] : 0u; }
-			// dense index of slot k = first + rank of its feature word (ties by slot: k_gather_contacts); the order of solving = by slot key of that index, then by index
-			// (k_adj_simple's rule); the cache entry a contact starts from = last step's slot with the same feature word
-			uint32_t ci[M], key[M], slot[M];
-#pragma unroll
-			for (int k = 0; k < M; ++k) {
-				uint32_t r = 0;
-#pragma unroll
-				for (int j = 0; j < M; ++j) r += ((uint32_t)j < cnt && (nf[j] < nf[k] || (nf[j] == nf[k] && j < k))) ? 1u : 0u;
-				const bool on = (uint32_t)k < cnt;
-				ci[k] = on ? start + r : 0xFFFFFFFFu;
-				key[k] = on ? slot_key_of(ci[k], nullptr) : 0xFFFFFFFFu;
-				slot[k] = (uint32_t)k;
-			}
-#pragma unroll
-			for (int q = 1; q < M; ++q) {
-#pragma unroll
-				for (int j = q; j > 0; --j) {
-					const bool sw = (key[j] < key[j - 1]) || (key[j] == key[j - 1] && ci[j] < ci[j - 1]);
-					const uint32_t tc = sw ? ci[j - 1] : ci[j], tk = sw ? key[j - 1] : key[j], ts = sw ? slot[j - 1] : slot[j];
-					ci[j - 1] = sw ? ci[j] : ci[j - 1]; key[j - 1] = sw ? key[j] : key[j - 1]; slot[j - 1] = sw ? slot[j] : slot[j - 1];
-					ci[j] = tc; key[j] = tk; slot[j] = ts;
-				}
-			}
-#pragma unroll
-			for (int q = 0; q < M; ++q) {
-				const bool on = (uint32_t)q < cnt;
-				uint32_t f = 0, wslot = 0xFFFFFFFFu;
-#pragma unroll
-				for (int k = 0; k < M; ++k) if (slot[q] == (uint32_t)k) f = nf[k];
-#pragma unroll
-				for (int j = M - 1; j >= 0; --j) if ((uint32_t)j < oc && of[j] == f) wslot = still_base + (uint32_t)j;
-				cid[q] = on ? still_base + slot[q] : 0xFFFFFFFFu;
-				s_wid[wave][lane * M + q] = on ? wslot : 0xFFFFFFFFu;
-			}
-			// this step's feature words and count become the slot cache's (the impulses follow at the end)
-			if (still_has) {
-#pragma unroll
-				for (int k = 0; k < M; ++k) if ((uint32_t)k < cnt) sv.sc_feat[still_base + k] = nf[k];
-				sv.sc_count[still_rec] = cnt;
-			}
+			for (int k = 0; k < M; ++k) { nf[k] = sv.raw_feature[still_base + k]; of[k] = sv.sc_feat[still_base + k]; }
+			s_first[wave][lane] = still_has ? still_base : 0xFFFFFFFFu;          // (where the wave-cooperative loads find this body's four slots)
 		} else {
 		if (CONTIG) cnt = sp.y & 15u;
 		else if (mine) { b = off[x]; cnt = off[x + 1] - b; }
@@ -1016,9 +979,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			first = min(first, cid[q]);
 		}
 		}
+		if (!STILL) {
 #pragma unroll
-		for (int q = 0; q < M; ++q) scid[lane * M + q] = cid[q];
-		s_hint[wave][lane] = h; s_first[wave][lane] = first;
+			for (int q = 0; q < M; ++q) scid[lane * M + q] = cid[q];
+			s_hint[wave][lane] = h; s_first[wave][lane] = first;
+		}
 		__builtin_amdgcn_wave_barrier();
 		// phase A: the wave fetches the per-contact records slot by slot; all loads first, then the comparisons
 		uint32_t sc[M], sflags[M];
@@ -1028,16 +993,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 #pragma unroll
 		for (int k = 0; k < M; ++k) {
 			const uint32_t e = 64u * k + lane, j = e / M;
-			sc[k] = scid[e];
+			if (STILL) { const uint32_t bj = s_first[wave][j]; sc[k] = bj != 0xFFFFFFFFu ? bj + (e - j * M) : 0xFFFFFFFFu; }          // (slot e mod M of body j's record)
+			else sc[k] = scid[e];
 			const uint32_t c = sc[k] != 0xFFFFFFFFu ? sc[k] : 0u;
 			sc0[k] = reinterpret_cast<const float4*>(contacts + c)[0];
 			sc1[k] = reinterpret_cast<const float4*>(contacts + c)[1];
 			// (CONTIG: the body's role in its one pair rides in simple[x], bit 28 -- no load of the body pair)
 			sflags[k] = (!CONTIG && bodies[c].a == wave_x0 + j) ? 2u : 0u;
 			if (STILL) {
-				const uint32_t wc = s_wid[wave][e];
-				const float4 wv = *reinterpret_cast<const float4*>(cv.cdata + (wc != 0xFFFFFFFFu ? wc : 0u));
-				sw[k] = wc != 0xFFFFFFFFu ? wv : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+				sw[k] = *reinterpret_cast<const float4*>(cv.cdata + c);          // (the impulse cached in the SAME slot; matched to a contact by feature word below)
 			} else if (FUSED) {
 				const uint32_t hj = s_hint[wave][j];
 				sguess[k] = hj != NH_HINT_NONE ? hj + (sc[k] - s_first[wave][j]) : sc[k];
@@ -1083,6 +1047,58 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			}
 			slot[e] = o;
 		}
+		if (STILL) {
+			uint32_t oc = 0;
+			if (still_has) {
+				cnt = min(st_cnt, 4u); oc = min(st_oc, 4u);
+				uint32_t start = st_start;
+				int shift = 0;
+				for (uint32_t k = 0; k < n_delta; ++k) shift += (uint32_t)s_delta[k].x < bpos ? s_delta[k].y : 0;
+				if (shift) { start += (uint32_t)shift; sv.start_sorted[bpos] = start; }
+				st_start = start;
+			}
+			// dense index of slot k = first + rank of its feature word (ties by slot: k_gather_contacts); the order of solving = by slot key of that index, then by index
+			// (k_adj_simple's rule); the cache entry a contact starts from = last step's slot with the same feature word
+			uint32_t ci[M], key[M];
+#pragma unroll
+			for (int k = 0; k < M; ++k) {
+				uint32_t r = 0;
+#pragma unroll
+				for (int j = 0; j < M; ++j) r += ((uint32_t)j < cnt && (uint32_t)k < cnt && (nf[j] < nf[k] || (nf[j] == nf[k] && j < k))) ? 1u : 0u;
+				const bool on = (uint32_t)k < cnt;
+				ci[k] = on ? st_start + r : 0xFFFFFFFFu;
+				key[k] = on ? slot_key_of(ci[k], nullptr) : 0xFFFFFFFFu;
+				sl[k] = (uint32_t)k;
+			}
+#pragma unroll
+			for (int q = 1; q < M; ++q) {
+#pragma unroll
+				for (int j = q; j > 0; --j) {
+					const bool sw2 = (key[j] < key[j - 1]) || (key[j] == key[j - 1] && ci[j] < ci[j - 1]);
+					const uint32_t tc = sw2 ? ci[j - 1] : ci[j], tk = sw2 ? key[j - 1] : key[j], ts = sw2 ? sl[j - 1] : sl[j];
+					ci[j - 1] = sw2 ? ci[j] : ci[j - 1]; key[j - 1] = sw2 ? key[j] : key[j - 1]; sl[j - 1] = sw2 ? sl[j] : sl[j - 1];
+					ci[j] = tc; key[j] = tk; sl[j] = ts;
+				}
+			}
+#pragma unroll
+			for (int q = 0; q < M; ++q) {
+				const bool on = (uint32_t)q < cnt;
+				uint32_t f = 0, wj = 0xFFFFFFFFu;
+#pragma unroll
+				for (int k = 0; k < M; ++k) if (sl[q] == (uint32_t)k) f = nf[k];
+#pragma unroll
+				for (int j = M - 1; j >= 0; --j) if ((uint32_t)j < oc && of[j] == f) wj = (uint32_t)j;
+				jm[q] = on ? wj : 0xFFFFFFFFu;
+				cid[q] = on ? still_base + sl[q] : 0xFFFFFFFFu;
+				scid[lane * M + q] = cid[q];          // (where the results go: read by the wave after the barrier before the result stores)
+			}
+			// this step's feature words and count become the slot cache's (the impulses follow at the end)
+			if (still_has) {
+#pragma unroll
+				for (int k = 0; k < M; ++k) if ((uint32_t)k < cnt) sv.sc_feat[still_base + k] = nf[k];
+				sv.sc_count[still_rec] = cnt;
+			}
+		}
 		__builtin_amdgcn_wave_barrier();
 		nh_vel v = { m0.x, m0.y, m0.z, pr.w, m1.x, m1.y, m1.z, m1.w };
 		const nh_quat qx = { t1.x, t1.y, t1.z, t1.w };
@@ -1096,13 +1112,18 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		for (int q = 0; q < M; ++q) {
 			is_a[q] = false;
 			if ((uint32_t)q < cnt) {
-				const nh_ob_slot o = slot[lane * M + q];
-				const uint32_t flags = __float_as_uint(o.w.w);
+				const nh_ob_slot o = slot[lane * M + (STILL ? sl[q] : (uint32_t)q)];
+				const uint32_t flags = STILL ? 0u : __float_as_uint(o.w.w);
 				is_a[q] = STILL ? (br & NH_BODY_REC_IS_A) != 0 : (CONTIG ? ((sp.y >> 28) & 1u) != 0 : (flags & 2u) != 0);
 				nh_contact_in ci = { o.c0.x, o.c0.y, o.c0.z, o.c0.w, o.c1.x, o.c1.y, o.c1.z, o.c1.w };
 				nh_build_row1(ci, posx, IX, v.mass_inverse, is_a[q], r[q]);
 				if (FUSED) {
 					float wx = o.w.x, wy = o.w.y, wz = o.w.z;
+					if (STILL) {
+						const float4 wv = slot[lane * M + (jm[q] != 0xFFFFFFFFu ? jm[q] : 0u)].w;
+						const bool hit = jm[q] != 0xFFFFFFFFu;
+						wx = hit ? wv.x : 0.0f; wy = hit ? wv.y : 0.0f; wz = hit ? wv.z : 0.0f;
+					}
 					if (!STILL && (flags & 1u)) {
 						const float4 found = cache_search(cv.ctags, cv.cfeatures, cv.cdata, m, h != NH_HINT_NONE ? h + (cid[q] - first) : cid[q], cv.tags[cid[q]], cv.features[cid[q]]);
 						wx = found.x; wy = found.y; wz = found.z;
