@@ -889,6 +889,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 	__shared__ float4 s_c0[NS][256], s_c1[NS][256];
 	__shared__ uint32_t s_f[NS][256];
 	__shared__ uint8_t s_n[NS][64];
+	__shared__ uint32_t s_pre[STILL ? 3 : 1][STILL ? 256 : 1];          // STILL: the record's old key and tag-order position, fetched with everything else
 	const uint32_t n_bb = min(st->pairs, pair_cap), n_sph = min(st->pairs_sph, pair_cap - n_bb);
 	if (!STILL && blockIdx.x == 0 && threadIdx.x == 0) {
 		st->records = n_bb + n_sph;            // (both launches write the same number: either may be the only one)
@@ -911,8 +912,8 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 	// sort re-use (nh_collide): `rec_key` is the context's buffer of keys by record position, still holding last step's -- is every key what it was?
 	bool changed = false;
 	// STILL: what the step relies on, per record (see above); the count goes to the record's place in the tag order
-	auto still_record = [&](uint32_t ri, uint64_t key, int count, uint32_t body_a, uint32_t body_b) {
-		const bool same_key = rec_key[ri] == key;
+	auto still_record = [&](uint32_t ri, uint64_t key, int count, uint32_t body_a, uint32_t body_b, uint64_t was_key, uint32_t pos) {
+		const bool same_key = was_key == key;
 		bool ok = same_key && count <= 4;
 		if (ok && count) {
 			const uint32_t dyn = body_a ? body_a : body_b;
@@ -922,7 +923,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		rec[ri].count = (uint32_t)count;
 		// the record's count in its place of the tag order; a CHANGE is listed (position, difference): the solver lanes shift their first contact by the changes before
 		// them -- a handful per step in a world at rest -- instead of the whole order being scanned again.  Too many for the list: the scan runs (delta_overflow)
-		const uint32_t pos = lay_rank[ri], old = cnt_sorted[pos];
+		const uint32_t old = cnt_sorted[pos];
 		if (old != (uint32_t)count) {
 			cnt_sorted[pos] = (uint32_t)count;
 			if (!st->delta_overflow[parity]) {
@@ -943,12 +944,28 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		bool asleep = false;
 		const uint32_t ri = first_rec + i;        // record index
 		bool invalid = false;
+		// STILL: everything a pair needs goes out in ONE round trip behind the pair itself -- both boxes, both world transforms, shapes and tags, the record's old key and
+		// tag-order position -- and which of the two is "a" is a register select afterwards (fetching the transforms only once the roles were known, and the key and the
+		// position only when the contacts were done, made four dependent round trips of it)
+		nh_xform XA = nh_xform(), XB = nh_xform();
+		uint32_t TA = 0, TB = 0, CB = 0;
+		nh_BoxCollider SA = nh_BoxCollider(), SB = nh_BoxCollider();
+		float RA = 0.0f, RB = 0.0f;
+		auto XF = [&](uint32_t c) -> nh_xform { if (STILL) return c == CB ? XB : XA; return xf[c]; };
+		auto TAG = [&](uint32_t c) -> uint32_t { if (STILL) return c == CB ? TB : TA; return ctag[c]; };
+		auto BOX = [&](uint32_t c) -> nh_BoxCollider { if (STILL) return c == CB ? SB : SA; return box_data[c]; };
+		auto RAD = [&](uint32_t c) -> float { if (STILL) return c == CB ? RB : RA; return sph_data[c - nbox].radius; };
 		if (i < n) {
 			uint2 pr;
 			if (STILL) {
 				const uint2 kp = pairs[SPH ? kept_cap - 1u - i : i];
 				const uint32_t ca = kp.x & index_mask, cb = kp.y & index_mask;
 				const float4 amin = aabb_min[ca], amax = aabb_max[ca], bmin = aabb_min[cb], bmax = aabb_max[cb];
+				XA = xf[ca]; XB = xf[cb]; TA = ctag[ca]; TB = ctag[cb]; CB = cb;
+				SA = box_data[ca < nbox ? ca : 0u]; SB = box_data[cb < nbox ? cb : 0u];
+				if (SPH) { RA = sph_data[ca >= nbox ? ca - nbox : 0u].radius; RB = sph_data[cb >= nbox ? cb - nbox : 0u].radius; }
+				// (parked in LDS across the contact computation: three more live registers there are three more spilled ones)
+				{ const uint64_t pk = rec_key[ri]; s_pre[0][threadIdx.x] = (uint32_t)pk; s_pre[1][threadIdx.x] = (uint32_t)(pk >> 32); s_pre[2][threadIdx.x] = lay_rank[ri]; }
 				bool hit = aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != __float_as_uint(amin.w));
 				if (stamps && hit) hit = (uint32_t)(gen[ca] & 0x7Fu) == (kp.x >> NH_GEN_SHIFT) && (uint32_t)(gen[cb] & 0x7Fu) == (kp.y >> NH_GEN_SHIFT);
 				const uint64_t ka = nh_morton_of(nh_make3(amin.x, amin.y, amin.z), mscale, mmin), kb = nh_morton_of(nh_make3(bmin.x, bmin.y, bmin.z), mscale, mmin);
@@ -975,9 +992,9 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			}
 			if (coarse_asleep) {
 			} else if (!SPH) {
-				nh_xform A = xf[a], B = xf[b];
-				nh_BoxCollider sa = box_data[a], sb = box_data[b];
-				uint32_t ta = ctag[a], tb = ctag[b];
+				nh_xform A = XF(a), B = XF(b);
+				nh_BoxCollider sa = BOX(a), sb = BOX(b);
+				uint32_t ta = TAG(a), tb = TAG(b);
 				nh_box_box_eval(A, B, sa.size, sb.size, ta, tb, bb);
 				count = nh_bb_count(bb);
 				key = (uint64_t)(bb.swapped ? tb : ta) | ((uint64_t)(bb.swapped ? ta : tb) << 32);
@@ -985,17 +1002,17 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 				body_b = bb.swapped ? A.body : B.body;
 			} else if (a_sph && b_sph) {
 				// sphere-sphere: first = earlier in Morton order = pair.y (nudge.cpp:3775-3776)
-				nh_xform A = xf[b], B = xf[a];
-				count = nh_sphere_sphere(sph_data[b - nbox].radius, sph_data[a - nbox].radius, A, B, &single);
-				key = (uint64_t)ctag[b] | ((uint64_t)ctag[a] << 32);
+				nh_xform A = XF(b), B = XF(a);
+				count = nh_sphere_sphere(RAD(b), RAD(a), A, B, &single);
+				key = (uint64_t)TAG(b) | ((uint64_t)TAG(a) << 32);
 				body_a = A.body; body_b = B.body;
 			} else {
 				// box-sphere: box is always "a" (nudge.cpp:3746-3751, 3759-3768)
 				uint32_t bx = a_sph ? b : a, sp = a_sph ? a : b;
-				nh_xform A = xf[bx], B = xf[sp];
-				nh_BoxCollider sz = box_data[bx];
-				count = nh_box_sphere(sz.size, sph_data[sp - nbox].radius, A, B, &single);
-				key = (uint64_t)ctag[bx] | ((uint64_t)ctag[sp] << 32);
+				nh_xform A = XF(bx), B = XF(sp);
+				nh_BoxCollider sz = BOX(bx);
+				count = nh_box_sphere(sz.size, RAD(sp), A, B, &single);
+				key = (uint64_t)TAG(bx) | ((uint64_t)TAG(sp) << 32);
 				body_a = A.body; body_b = B.body;
 			}
 			// one owner per contact in a partitioned world ("contact owned by the rank owning the body with the larger collider tag", the a > b
@@ -1018,7 +1035,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 					dp[1] = make_float4(single.nx, single.ny, single.nz, single.friction);
 					raw_feature[slot] = single.feature;
 				}
-				if (STILL) still_record(ri, key, count, body_a, body_b);
+				if (STILL) still_record(ri, key, count, body_a, body_b, (uint64_t)s_pre[0][threadIdx.x] | ((uint64_t)s_pre[1][threadIdx.x] << 32), s_pre[2][threadIdx.x]);
 				else {
 				{ const uint64_t was = rec_key[ri]; changed |= was != key; rec_key[ri] = key; }
 				nh_Record r = { body_a, body_b, 0u, asleep ? NH_REC_SLEEPING : (uint32_t)count };
@@ -1071,7 +1088,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			} else if (bb.kind == 1) {
 				put(0, bb.edge);
 			}
-			if (STILL) still_record(ri, key, count, body_a, body_b);
+			if (STILL) still_record(ri, key, count, body_a, body_b, (uint64_t)s_pre[0][threadIdx.x] | ((uint64_t)s_pre[1][threadIdx.x] << 32), s_pre[2][threadIdx.x]);
 			else {
 				{ const uint64_t was = rec_key[ri]; changed |= was != key; rec_key[ri] = key; }
 				nh_Record r = { body_a, body_b, ovf, asleep ? NH_REC_SLEEPING : (uint32_t)count };
