@@ -922,14 +922,14 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		if (!ok) { atomicAdd(&st->still_diff[!same_key ? 0 : (count > 4 ? 1 : 2)], 1u); changed = true; }          // (statistics; rare)
 		rec[ri].count = (uint32_t)count;
 		// the record's count in its place of the tag order; a CHANGE is listed (position, difference): the solver lanes shift their first contact by the changes before
-		// them -- a handful per step in a world at rest -- instead of the whole order being scanned again.  Too many for the list: the scan runs (delta_overflow)
+		// them -- a handful per step in a world at rest -- instead of the whole order being scanned again.  Too many for the list: the step fails (delta_overflow)
 		const uint32_t old = cnt_sorted[pos];
 		if (old != (uint32_t)count) {
 			cnt_sorted[pos] = (uint32_t)count;
 			if (!st->delta_overflow[parity]) {
 				const uint32_t k = atomicAdd(&st->delta_count[parity], 1u);
 				if (k < NH_DELTA_MAX) delta[parity * NH_DELTA_MAX + k] = make_int2((int)pos, count - (int)old);
-				else st->delta_overflow[parity] = 1u;
+				else { st->delta_overflow[parity] = 1u; atomicMax(&st->still_failed_seq, seq); }          // (more changes than the list holds: not a still step -- the full step lays the list out again)
 			}
 		}
 	};
@@ -1771,8 +1771,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr,
 				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta);
 			// every record's first contact in the dense (tag-ordered) list = the scan of the counts in tag order: kept from step to step, shifted by the listed changes
-			// (only when more pairs changed their count than the list holds: the two launches leave at once otherwise; the solver keeps the total)
-			nh_scan_u32(ctx, ctx->cnt_sorted, ctx->start_sorted, &st->records, 1, scan_tmp, nullptr, &st->delta_overflow[ctx->step_parity]);
+			// (the solver keeps the total; more pairs changing their count than the list holds fail the step: k_narrowphase)
 			ss.active = true; ss.resolved = false; ss.launched++;
 			ctx->gravity_may_overlap = false;
 			ctx->after_collide = true;
