@@ -881,7 +881,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
                                                      // STILL only: the kept list (`pairs`) and its capacity, this step's exact AABBs, the stamps, tag-order positions / counts, the bodies' records
                                                      uint32_t kept_cap = 0u, const float4* __restrict__ aabb_min = nullptr, const float4* __restrict__ aabb_max = nullptr,
                                                      const uint8_t* __restrict__ gen = nullptr, const uint32_t* __restrict__ lay_rank = nullptr, uint32_t* __restrict__ cnt_sorted = nullptr,
-                                                     const uint32_t* __restrict__ body_rec = nullptr, uint32_t seq = 0u, int2* __restrict__ delta = nullptr) {
+                                                     const uint32_t* __restrict__ body_rec = nullptr, uint32_t seq = 0u, int2* __restrict__ delta = nullptr, uint32_t delta_scan = 0u) {
 	// coarse islands (nudge.cpp:3500-3703): a pair whose bodies belong to a set of sleeping bodies (sets over the BROADPHASE pairs and the
 	// user's connections) never reaches the narrowphase: it becomes a sleeping pair, larger tag in the low half (3697)
 	const bool some_asleep = !STILL && st->any_idle[parity] != 0;
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			if (!st->delta_overflow[parity]) {
 				const uint32_t k = atomicAdd(&st->delta_count[parity], 1u);
 				if (k < NH_DELTA_MAX) delta[parity * NH_DELTA_MAX + k] = make_int2((int)pos, count - (int)old);
-				else { st->delta_overflow[parity] = 1u; atomicMax(&st->still_failed_seq, seq); }          // (more changes than the list holds: not a still step -- the full step lays the list out again)
+				else { st->delta_overflow[parity] = 1u; if (!delta_scan) atomicMax(&st->still_failed_seq, seq); }          // (more changes than the list holds: the scan runs -- large worlds, where the host has launched it -- or this is not a still step)
 			}
 		}
 	};
@@ -1762,16 +1762,19 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			          xf, aabb_min, aabb_max, ctag, (uint4*)nullptr, 0u, ctx->fat_box, 0u,
 			          (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, ctx->collide_seq, bodies->idle_counters, B, ctx->step_parity);
 			const uint8_t* gen = incremental ? ctx->fat_gen : (const uint8_t*)nullptr;
+			const bool delta_scan = C > (2u << 20);
 			if (nbox >= 2)
 				NH_LAUNCH(ctx, "narrowphase_still", (k_narrowphase<false, true>), nh_grid_for(pair_cap, 256, 4096), 256, st, ctx->fat_pairs, xf, ctag,
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr,
-				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta);
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u);
 			if (nsph)
 				NH_LAUNCH(ctx, "narrowphase_sph_still", (k_narrowphase<true, true>), nh_grid_for(pair_cap, 256, 8192), 256, st, ctx->fat_pairs, xf, ctag,
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr,
-				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta);
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u);
 			// every record's first contact in the dense (tag-ordered) list = the scan of the counts in tag order: kept from step to step, shifted by the listed changes
-			// (the solver keeps the total; more pairs changing their count than the list holds fail the step: k_narrowphase)
+			// (the solver keeps the total).  More pairs changing their count than the list holds: a world of up to two million colliders fails the step (a handful change
+			// per million and step at rest); a larger one runs the scan instead -- two launches that leave at once otherwise, nothing next to its step
+			if (delta_scan) nh_scan_u32(ctx, ctx->cnt_sorted, ctx->start_sorted, &st->records, 1, scan_tmp, nullptr, &st->delta_overflow[ctx->step_parity]);
 			ss.active = true; ss.resolved = false; ss.launched++;
 			ctx->gravity_may_overlap = false;
 			ctx->after_collide = true;
