@@ -910,10 +910,12 @@ def test_garbage_colour_seeds_in_the_cache_are_caught(side):
     assert P.bits_equal(outs[0]["transforms"], outs[1]["transforms"]) and P.bits_equal(outs[0]["momentum"], outs[1]["momentum"])
 
 
-def test_append_contacts_through_the_resident_abi():
+@pytest.mark.parametrize("shared_tag", [False, True])
+def test_append_contacts_through_the_resident_abi(shared_tag):
     """nh_append_contacts on the device-resident boundary, default solver order, with and without NH_FLAG_SYNC_COUNTS: custom contacts that push the
     first dynamic boxes of a drop tile towards y = 3 (the tile's ground is at y = -10).  The two flag sets agree bit for bit, the pushed boxes end up
-    well above everybody else, and a list that would overflow the capacity is refused."""
+    well above everybody else, and a list that would overflow the capacity is refused.  `shared_tag`: all appended contacts carry ONE tag (the reference only
+    sorts by tag and accepts that): the per-body bookkeeping must still be counted per body pair -- every held box is pushed, not only the first of the run."""
     scene, _ = G.build("grid30")
     held = np.arange(1, 9)
 
@@ -930,7 +932,10 @@ def test_append_contacts_through_the_resident_abi():
             data["friction"] = 0.25
             bodies = np.stack([np.zeros(int(low.sum()), np.uint32), held[low].astype(np.uint32)], axis=1)
             tags = (np.uint64(0x70000) | ((held[low].astype(np.uint64) + np.uint64(0x71000)) << np.uint64(32)))
-            w.append_contacts(data, bodies, tags, np.ones(int(low.sum()), np.uint32))
+            feats = np.ones(int(low.sum()), np.uint32)
+            if shared_tag:
+                tags[:] = np.uint64(0x70000) | (np.uint64(0x71000) << np.uint64(32)); feats = held[low].astype(np.uint32)
+            w.append_contacts(data, bodies, tags, feats)
             w.gravity(); w.read_cache(); w.setup(); w.apply(); w.update(); w.write_cache(); w.advance()
         assert w.counts()["error"] == 0
         return w, w.get_bodies()
