@@ -41,7 +41,7 @@ static T* to_device(const std::vector<T>& v, size_t capacity = 0) {
 }
 
 int main(int argc, char** argv) {
-	if (argc < 4) { fprintf(stderr, "usage: %s scene.bin out.bin steps [exact]\n", argv[0]); return 2; }
+	if (argc < 4) { fprintf(stderr, "usage: %s scene.bin out.bin steps [exact | step]\n", argv[0]); return 2; }
 	FILE* f = fopen(argv[1], "rb");
 	if (!f) { perror(argv[1]); return 2; }
 	std::vector<uint32_t> head = read_array<uint32_t>(f, 5);
@@ -51,6 +51,8 @@ int main(int argc, char** argv) {
 	const float gravity[3] = { 0.0f, par[1], 0.0f };
 	const unsigned steps = (unsigned)atoi(argv[3]);
 	const bool exact = argc > 4 && !strcmp(argv[4], "exact");
+	// "step": the whole loop as ONE call of nh_step under NH_FLAG_FUSED_STEP (the sample's call order promised): still steps, late verdicts, asleep steps
+	const bool one_call = argc > 4 && !strcmp(argv[4], "step");
 
 	// host copies in the file's (reference) layouts; tags widen to 32 bits
 	std::vector<nh_Transform> h_xf = read_array<nh_Transform>(f, nb);
@@ -70,7 +72,7 @@ int main(int argc, char** argv) {
 	hipStream_t stream;
 	HIP_OK(hipStreamCreate(&stream));
 	nh_context* ctx = nullptr;
-	NH_OK_(nh_create(&ctx, 0, stream, exact ? NH_FLAG_EXACT_ORDER : 0u));
+	NH_OK_(nh_create(&ctx, 0, stream, exact ? NH_FLAG_EXACT_ORDER : (one_call ? NH_FLAG_FUSED_STEP : 0u)));
 	NH_OK_(nh_set_tag_bits(ctx, 16));
 
 	// caller-owned arrays, now in HBM (the library never allocates them)
@@ -92,7 +94,14 @@ int main(int argc, char** argv) {
 	uint64_t sum_contacts = 0;
 	HIP_OK(hipStreamSynchronize(stream));
 	auto t0 = std::chrono::steady_clock::now();
-	for (unsigned n = 0; n < steps; ++n) {
+	if (one_call) {
+		nh_StepArgs args = {};
+		args.active_bodies = &active; args.contacts = &contacts; args.bodies = &bodies; args.colliders = &colliders; args.body_connections = &connections;
+		args.contact_cache = &cache; args.arena = arena; args.time_step = time_step; args.damping_rate = damping_rate; args.iterations = iterations;
+		args.gravity[0] = gravity[0]; args.gravity[1] = gravity[1]; args.gravity[2] = gravity[2];
+		NH_OK_(nh_step(ctx, &args, steps));
+	}
+	for (unsigned n = 0; n < (one_call ? 0u : steps); ++n) {
 		nh_Arena temporary = arena;                                   // same scratch every sub-step (example/main.cpp:282)
 		NH_OK_(nh_collide(ctx, &active, &contacts, &bodies, &colliders, &connections, temporary));
 		NH_OK_(nh_apply_gravity_damping(ctx, &active, &bodies, time_step, gravity, damping_rate));

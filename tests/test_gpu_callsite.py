@@ -157,6 +157,26 @@ def test_cpp_host_on_the_resident_abi_matches_reference(name, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cpp_host_with_one_nh_step_call_matches_reference(tmp_path):
+    """The same C++ host making ONE call: nh_step(ctx, &args, steps) under NH_FLAG_FUSED_STEP -- the library drives the sample's loop itself (still steps with late
+    verdicts while the boxes rest, the steps of the world asleep taken as done).  A drop tile through fall, rest and sleep: the reference's bits."""
+    assert os.path.exists(CU.RESIDENT_REPLAY), "nudge_amd/resident_replay missing: make -C nudge_amd/csrc"
+    scene, _ = G.build("grid30")
+    steps = 420
+    nb = CU.write_scene(str(tmp_path / "s.bin"), scene)
+    CU.run_replay(CU.RESIDENT_REPLAY, str(tmp_path / "s.bin"), str(tmp_path / "gpu.bin"), steps, extra=["step"])
+    got = CU.read_result(str(tmp_path / "gpu.bin"), nb)
+    assert refworld.available("exact")
+    w = refworld.RefWorld(scene)
+    w.step(steps)
+    b = w.bodies()
+    assert P.bits_equal(got["transforms"], b["transforms"])
+    assert P.bits_equal(got["momentum"], b["momentum"])
+    assert P.bits_equal(got["idle"], b["idle"])
+    assert (b["idle"][1:] == 0xff).all(), "the tile was meant to be asleep at the end"
+
+
+@pytest.mark.gpu
 def test_cpp_rccl_host_runs_a_slab_on_one_gpu():
     """examples/partition_rccl.cpp (C++ host of the multi-GPU path: x-slabs, ghost halo exchange with ncclSend / ncclRecv on the records of
     nh_halo_pack / nh_halo_unpack) with WORLD_SIZE = 1: the whole world is one slab, nothing is exchanged -- what a one-GPU box can check is that the
