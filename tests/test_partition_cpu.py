@@ -263,6 +263,32 @@ def test_single_owner_heap_across_the_cut_matches_the_single_world():
     assert sum(p.e.dropped_contacts for p in parts) > 0
 
 
+def test_single_owner_three_ranks_a_plank_owned_in_the_middle():
+    """Three slabs: every plank lies in the middle rank and rests on a cube in the left rank and a cube in the right one -- its two supports are contacts across two
+    different cuts, owned by whoever owns the larger tag, and the middle rank (odd) sweeps after both of its neighbours (even).  Lists disjoint and complete, ghosts
+    equal to their owners after every step, the stack where the single world's is."""
+    import partition_util as PU
+    scene = S.bridge(3)
+    parts = []
+    for r in range(3):
+        local, info = PT.split_scene(scene, [-0.6, 0.6], r, min_extra=64)
+        parts.append(PT.Partition(PU.OracleEngine(local, info["capacity"]), info, epoch=8, per_iteration=True, single_owner=True))
+    assert [p.n_owned for p in parts] == [3, 3, 3]
+    cl = PT.LocalCluster(parts)
+    ref = refworld.RefWorld(scene, max_contacts=1024)
+    cl.step(4); ref.step(4)
+    mine = np.sort(np.concatenate([p.e.ref.contacts()["tags"] for p in parts]))
+    assert len(mine) == ref.contacts()["count"] > 20 and np.array_equal(mine, np.sort(ref.contacts()["tags"]))
+    done, worst = 4, 0.0
+    for k in (20, 100, 300):
+        cl.step(k - done); ref.step(k - done); done = k
+        dev, n = _ghost_deviation(parts)
+        assert dev == 0.0 and n >= 6
+        got, rb = cl.gather(), ref.bodies()
+        worst = max(worst, float(np.abs(got["transforms"]["position"] - rb["transforms"]["position"][1:]).max()))
+    assert worst < 2e-2, worst
+
+
 def _gloo_bridge_worker(rank, world, port, out_path):
     import torch.distributed as dist
     import partition_util as PU
