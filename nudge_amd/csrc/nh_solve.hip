@@ -2791,18 +2791,24 @@ __global__ __launch_bounds__(256) void k_slots_to_cache(nh_DevState* __restrict_
 	const uint32_t nrec = st->records, n_bb = min(st->pairs, pair_cap);
 	if (blockIdx.x == 0 && threadIdx.x == 0) { const uint32_t total = start[nrec]; if (total > capacity) { st->error = NH_ERR_CACHE_CAPACITY; st->cache = 0u; } else st->cache = total; }
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nrec; i += gridDim.x * blockDim.x) {
-		const uint32_t k = cnt[i];
-		if (!k) continue;
-		const uint32_t ri = sorted_idx[i], base = ri < n_bb ? 4u * ri : 4u * n_bb + (ri - n_bb), first = start[i];
-		if (first + k > capacity) continue;
+		// two dependent round trips: the record's place and count, then its four slots' feature words and impulses at once (a record of a pair with a sphere owns one
+		// slot: the other three loads fall into the neighbours' slots and are not used)
+		const uint32_t k = min(cnt[i], 4u), ri = sorted_idx[i], first = start[i];
 		const uint64_t key = sorted_keys[i];
-		uint32_t f[4];
-		for (uint32_t j = 0; j < 4u; ++j) f[j] = j < k ? sc_feat[base + j] : 0u;
-		for (uint32_t j = 0; j < k; ++j) {
-			uint32_t r = 0;
-			for (uint32_t q = 0; q < k; ++q) r += (f[q] < f[j] || (f[q] == f[j] && q < j)) ? 1u : 0u;
-			otags[first + r] = key; ofeatures[first + r] = f[j];
-			*reinterpret_cast<float4*>(odata + first + r) = sc_imp[base + j];
+		const uint32_t base = ri < n_bb ? 4u * ri : 4u * n_bb + (ri - n_bb);
+		uint32_t f[4]; float4 w[4];
+#pragma unroll
+		for (int j = 0; j < 4; ++j) { f[j] = sc_feat[base + j]; w[j] = sc_imp[base + j]; }
+		if (!k || first + k > capacity) continue;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			if ((uint32_t)j < k) {
+				uint32_t r = 0;
+#pragma unroll
+				for (int q = 0; q < 4; ++q) r += ((uint32_t)q < k && (f[q] < f[j] || (f[q] == f[j] && q < j))) ? 1u : 0u;
+				otags[first + r] = key; ofeatures[first + r] = f[j];
+				*reinterpret_cast<float4*>(odata + first + r) = w[j];
+			}
 		}
 	}
 }
