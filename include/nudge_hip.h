@@ -60,8 +60,10 @@
  *      one host round trip before anything irreversible has been written, and the step is run again in full from nh_collide's arguments: results are
  *      bit-identical to a library that never speculates (option "no_still"), which the tests check.
  *      The caller's dense contact list (contacts->data / bodies / tags / features) and contact cache are VIEWS of the slots under this regime: they are
- *      brought up to date by every entry point that lets the caller observe them -- nh_read_counts, nh_synchronize, nh_append_contacts, and any step that
- *      does not qualify -- not by every step.  Call nh_synchronize before reading them from the device yourself.  Any entry point outside the sample's
+ *      brought up to date by nh_export_views (what: NH_VIEW_CONTACTS, NH_VIEW_CACHE), by nh_append_contacts, and by any step that does not qualify -- not by
+ *      every step, and not by the cheap observers: nh_read_counts returns the counters and nh_synchronize waits for the stream, neither exports anything (the
+ *      sample reads active_bodies.count every sub-step, example/main.cpp:293: that must not cost two passes over the contacts).  Call nh_export_views and then
+ *      nh_synchronize before reading the arrays from the device yourself.  Any entry point outside the sample's
  *      call order between nh_collide and nh_apply_impulses turns a still step into a full one first, so everything it observes is what a full step
  *      produces.  nh_Counts.still_steps / still_replays count them.
  *
@@ -209,8 +211,14 @@ typedef struct nh_Counts {
 int nh_create(nh_context** out, int device, void* stream, uint32_t flags);
 void nh_destroy(nh_context* ctx);
 int nh_set_flags(nh_context* ctx, uint32_t flags);
-int nh_synchronize(nh_context* ctx);
-int nh_read_counts(nh_context* ctx, nh_Counts* out);        /* synchronises the stream */
+int nh_synchronize(nh_context* ctx);                         /* completes deferred work and waits for the stream; exports no view (note 9) */
+int nh_read_counts(nh_context* ctx, nh_Counts* out);        /* synchronises the stream; exports no view (note 9) */
+/* The caller's views of what still steps keep by slot (note 9), brought up to date on the context's stream: NH_VIEW_CONTACTS = contacts->data / bodies / tags /
+   features in tag order, NH_VIEW_CACHE = the nh_ContactCache arrays (tags, features, data; nh_Counts.cache).  A no-op (two host-side flag tests) when the arrays
+   are current -- after a full step they always are.  Replaces the reference's implicit guarantee that both arrays are current when collide() /
+   write_cached_impulses() return (nudge.cpp:4009, 4158) for callers that read them from the device themselves. */
+enum { NH_VIEW_CONTACTS = 1u, NH_VIEW_CACHE = 2u, NH_VIEW_ALL = 3u };
+int nh_export_views(nh_context* ctx, uint32_t what);
 int nh_set_cache_count(nh_context* ctx, uint32_t count);    /* restore a checkpointed ContactCache */
 /* Tell the library that the caller has written `idle_counters` itself (initial upload excepted: a fresh context assumes nothing).  The
    library predicts on the host when a body can first be asleep -- counters rise by at most one per nh_advance -- and launches none of the
@@ -226,7 +234,7 @@ int nh_set_pair_capacity(nh_context* ctx, uint32_t pairs);
 /* Diagnostic switches for A/B runs and tests -- none is needed in production, each selects an older, slower or more talkative path; the library never reads the
    environment.  Names (value 0 / 1 unless noted): "no_still", "no_kept_pairs", "no_incremental", "no_sort_reuse", "sort_classic", "sort_radix", "bucket_tile" (n),
    "bucket_target" (n), "colour_jp", "colour_check_seeds", "no_resident", "solver_waves" (1, 2, 4), "fp_sub" (0, 1, 2, 4, 16), "cooperative", "no_blocks", "blk_check",
-   "blk_min" (n), "blk_target" (n), "blk_rows_global", "blk_global_colours", "blk_profile", "no_asleep", "no_blk_chain".  Unknown name: NH_ERR_INVALID.  Call right after nh_create.
+   "blk_min" (n), "blk_target" (n), "blk_rows_global", "blk_global_colours", "blk_profile", "no_asleep", "no_blk_chain", "no_local_still".  Unknown name: NH_ERR_INVALID.  Call right after nh_create.
    (nudge_amd/engine.py maps environment variables NH_<NAME> onto these calls for its tests: a convenience of that host, not of the library.) */
 int nh_set_option(nh_context* ctx, const char* name, int value);
 const char* nh_error_string(int code);

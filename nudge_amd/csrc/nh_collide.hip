@@ -66,8 +66,9 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 			if (red[0]) atomicMax(&st->max_idle[parity], red[0]);
 			if (blockIdx.x == 0) {
 				// what the NEXT step (the other parity) accumulates into: nobody touches it during this one
-				st->max_idle[parity ^ 1u] = 0u; st->delta_count[parity ^ 1u] = 0u; st->delta_overflow[parity ^ 1u] = 0u;
+				st->max_idle[parity ^ 1u] = 0u; st->delta_count[parity ^ 1u] = 0u; st->delta_overflow[parity ^ 1u] = 0u; st->still_esc[parity ^ 1u] = 0u;
 				for (int k = 0; k < 3; ++k) { st->still_smin[parity ^ 1u][k] = 0xffffffffu; st->still_smax[parity ^ 1u][k] = 0u; }
+				st->still_fat0 = st->fat_count + st->fat_count_sph;          // (nobody appends to the kept list while this kernel runs: k_reinsert's verdict needs a value that stands still)
 			}
 		}
 		__syncthreads();
@@ -115,13 +116,14 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 			const float4 fmn = fat_box[2u * c], fmx = fat_box[2u * c + 1u];
 			out = !(mnx >= fmn.x && mny >= fmn.y && mnz >= fmn.z && mxx <= fmx.x && mxy <= fmx.y && mxz <= fmx.z);       // (NaN: out)
 		}
-		if (!STILL && gen) {
+		if (gen) {
 			// Re-insertion ("7." below): a SMALL collider that has left its box takes the candidate box as its new one right here, gets the next generation
 			// stamp (its kept pairs die) and goes on this step's list of leavers; k_reinsert finds its new pairs.  Large colliders, worn-out stamps, full
 			// lists and boxes that are no longer small for the grid end in the rebuild instead.
+			// (STILL with stamps = a still step in MOVERS form, nh_internal.h "LOCAL speculation": the same, counted by step parity; whoever cannot be re-inserted fails the step)
 			const uint32_t g = out ? gen[c] : 0u;
 			bool again = out && !(g & 0x80u) && (g & 0x7Fu) < 127u && ((__float_as_uint(fext) >> 21) & 1023u) <= guess_exp && fext == fext;
-			const uint32_t eslot = nh_wave_reserve1(&st->esc_count, again);
+			const uint32_t eslot = nh_wave_reserve1(STILL ? &st->still_esc[parity] : &st->esc_count, again);
 			const uint32_t mslot = nh_wave_reserve1(&st->moved_count, again && (g & 0x7Fu) == 0u);
 			if (again && (eslot >= NH_ESC_MAX || ((g & 0x7Fu) == 0u && mslot >= NH_MOVED_MAX))) again = false;
 			if (again) {
@@ -710,9 +712,22 @@ __global__ __launch_bounds__(LP_THREADS) void k_large_pairs(nh_DevState* __restr
 __global__ __launch_bounds__(256) void k_reinsert(nh_DevState* __restrict__ st, uint32_t nbox, const float4* __restrict__ sbox, const uint32_t* __restrict__ cstart,
                                                   const uint32_t* __restrict__ large_list, const float4* __restrict__ box, const uint8_t* __restrict__ gen,
                                                   const uint32_t* __restrict__ esc_mark, const uint32_t* __restrict__ esc_list, const uint32_t* __restrict__ moved_list, uint32_t seq,
-                                                  uint2* __restrict__ kept, uint32_t kept_cap) {
-	if (!st->fat_reinsert) return;
-	const uint32_t ne = min(st->esc_count, NH_ESC_MAX), nm = min(st->moved_count, NH_MOVED_MAX), nlarge = st->large;
+                                                  uint2* __restrict__ kept, uint32_t kept_cap, uint32_t still = 0u, uint32_t parity = 0u, uint32_t ncolliders = 0u) {
+	// `still`: launched by a still step in MOVERS form (nh_internal.h, "LOCAL speculation") behind k_xform<true>, which has re-boxed this step's leavers: there is no
+	// k_grid_setup in a still step, so k_grid_setup's verdict is taken here, by every workgroup from words nobody writes meanwhile.  The boxes HAVE changed: when
+	// the leavers cannot be re-inserted (too many for the kept buffer or for the quadratic tests) the kept list is void (fat_valid = 0: the replay rebuilds it)
+	uint32_t leavers = still ? st->still_esc[parity] : st->esc_count;
+	if (still) {
+		if (!leavers) return;
+		const bool crowded = (uint64_t)st->still_fat0 + 64ull * leavers > (uint64_t)kept_cap / 8u * 7u || (uint64_t)leavers * 16u > ncolliders ||
+		                     (uint64_t)leavers * (st->moved_count + st->large) > (uint64_t)ncolliders / 2u;
+		if (crowded) {
+			if (blockIdx.x == 0 && threadIdx.x == 0) { st->fat_valid = 0u; atomicMax(&st->still_failed_seq, seq); atomicAdd(&st->still_diff[3], 1u); }
+			return;
+		}
+		if (blockIdx.x == 0 && threadIdx.x == 0) st->fat_inserts += min(leavers, NH_ESC_MAX);
+	} else if (!st->fat_reinsert) return;
+	const uint32_t ne = min(leavers, NH_ESC_MAX), nm = min(st->moved_count, NH_MOVED_MAX), nlarge = st->large;
 	const float inv = st->cell_inv;
 	const float ox = st->origin[0], oy = st->origin[1], oz = st->origin[2];
 	const int nx = (int)st->dims[0], ny = (int)st->dims[1], nz = (int)st->dims[2];
@@ -905,15 +920,29 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		const nh_f3 smax = nh_make3(nh_float_unflip(st->still_smax[parity][0]), nh_float_unflip(st->still_smax[parity][1]), nh_float_unflip(st->still_smax[parity][2]));
 		mscale = nh_morton_scale(smin, smax);
 		mmin = nh_make3(smin.x * mscale, smin.y * mscale, smin.z * mscale);
-		// (the layout must be the last full step's, and the kept list as long as the pair list it was written from)
-		if (blockIdx.x == 0 && threadIdx.x == 0 && (!st->lay_valid || st->fat_count != st->pairs || st->fat_count_sph != st->pairs_sph)) atomicMax(&st->still_failed_seq, seq);
+		// (the layout must be the last full step's, and the kept list at least as long as the pair list it was written from: what lies behind are pairs APPENDED by
+		// still steps in movers form since -- below)
+		if (blockIdx.x == 0 && threadIdx.x == 0 && (!st->lay_valid || st->fat_count < st->pairs || st->fat_count_sph < st->pairs_sph)) atomicMax(&st->still_failed_seq, seq);
 	}
 	const uint32_t n = SPH ? n_sph : n_bb, first_rec = SPH ? n_bb : 0u;
+	// STILL, LOCAL speculation (nh_internal.h): kept pairs behind the layout's -- appended by k_reinsert for colliders that left their boxes in a still step -- have no
+	// record, no raw slots and no place in the tag order.  They are evaluated like the others (exact boxes, stamps, roles, contact arithmetic); as long as none of them
+	// yields a CONTACT they are what a full step would file as records without contacts, which nothing downstream looks at; the first contact fails the step, and the
+	// full step that follows gives every kept pair its record again.
+	uint32_t n_app = 0;
+	if (STILL) {
+		const uint32_t k_bb = min(st->fat_count, kept_cap), k_sph = min(st->fat_count_sph, kept_cap - k_bb);
+		const uint32_t kc = SPH ? k_sph : k_bb;
+		n_app = kc > n ? kc - n : 0u;
+	}
 	// sort re-use (nh_collide): `rec_key` is the context's buffer of keys by record position, still holding last step's -- is every key what it was?
 	bool changed = false;
 	// STILL: what the step relies on, per record (see above); the count goes to the record's place in the tag order
-	auto still_record = [&](uint32_t ri, uint64_t key, int count, uint32_t body_a, uint32_t body_b, uint64_t was_key, uint32_t pos) {
-		const bool same_key = was_key == key;
+	auto still_record = [&](uint32_t ri, uint64_t key, int count, uint32_t body_a, uint32_t body_b, uint64_t was_key, uint32_t pos, bool vanished) {
+		// (`vanished`: the kept pair is dead -- a collider of it has been re-boxed since, stamps -- or its exact boxes do not overlap this step: a record without
+		// contacts wherever the full step's sort would put it, so its old place serves; the key it had stays on file, and if the pair overlaps again with that key
+		// it is the same record in the same place)
+		const bool same_key = was_key == key || vanished;
 		bool ok = same_key && count <= 4;
 		if (ok && count) {
 			const uint32_t dyn = body_a ? body_a : body_b;
@@ -933,8 +962,9 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			}
 		}
 	};
-	uint32_t rounded = (n + 63u) & ~63u;
+	uint32_t rounded = (n + n_app + 63u) & ~63u;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
+		const bool live = i < n, app = STILL && !live && i < n + n_app;
 		nh_bb_result bb;
 		bb.kind = 0; bb.mask = 0;
 		nh_contact_out single;          // sphere paths produce at most one contact
@@ -955,7 +985,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		auto TAG = [&](uint32_t c) -> uint32_t { if (STILL) return c == CB ? TB : TA; return ctag[c]; };
 		auto BOX = [&](uint32_t c) -> nh_BoxCollider { if (STILL) return c == CB ? SB : SA; return box_data[c]; };
 		auto RAD = [&](uint32_t c) -> float { if (STILL) return c == CB ? RB : RA; return sph_data[c - nbox].radius; };
-		if (i < n) {
+		if (live || app) {
 			uint2 pr;
 			if (STILL) {
 				const uint2 kp = pairs[SPH ? kept_cap - 1u - i : i];
@@ -965,7 +995,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 				SA = box_data[ca < nbox ? ca : 0u]; SB = box_data[cb < nbox ? cb : 0u];
 				if (SPH) { RA = sph_data[ca >= nbox ? ca - nbox : 0u].radius; RB = sph_data[cb >= nbox ? cb - nbox : 0u].radius; }
 				// (parked in LDS across the contact computation: three more live registers there are three more spilled ones)
-				{ const uint64_t pk = rec_key[ri]; s_pre[0][threadIdx.x] = (uint32_t)pk; s_pre[1][threadIdx.x] = (uint32_t)(pk >> 32); s_pre[2][threadIdx.x] = lay_rank[ri]; }
+				if (live) { const uint64_t pk = rec_key[ri]; s_pre[0][threadIdx.x] = (uint32_t)pk; s_pre[1][threadIdx.x] = (uint32_t)(pk >> 32); s_pre[2][threadIdx.x] = lay_rank[ri]; }
 				bool hit = aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != __float_as_uint(amin.w));
 				if (stamps && hit) hit = (uint32_t)(gen[ca] & 0x7Fu) == (kp.x >> NH_GEN_SHIFT) && (uint32_t)(gen[cb] & 0x7Fu) == (kp.y >> NH_GEN_SHIFT);
 				const uint64_t ka = nh_morton_of(nh_make3(amin.x, amin.y, amin.z), mscale, mmin), kb = nh_morton_of(nh_make3(bmin.x, bmin.y, bmin.z), mscale, mmin);
@@ -1023,11 +1053,13 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 				const uint32_t owner = ba == 0u ? bb2 : (bb2 == 0u ? ba : (ctag[a] > ctag[b] ? ba : bb2));
 				if (owner >= first_ghost) { count = 0; bb.kind = 0; }
 			}
+			// (an appended pair -- no record -- may overlap, but a contact of it belongs to a layout only a full step can make)
+			if (app) { if (count) { changed = true; atomicAdd(&st->still_diff[1], 1u); } count = 0; bb.kind = 0; bb.mask = 0; }
 		}
 		if (SPH) {
 			// one contact at most, ONE raw slot per sphere record (they follow the four-slot blocks of the box-box records: slot 4 n_bb + i, so that
 			// consecutive lanes write -- and k_gather_contacts reads -- consecutive 32 bytes instead of every fourth slot)
-			if (i < n) {
+			if (live) {
 				if (count) {
 					const size_t slot = (size_t)4 * n_bb + i;
 					float4* dp = reinterpret_cast<float4*>(raw_data + slot);
@@ -1035,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 					dp[1] = make_float4(single.nx, single.ny, single.nz, single.friction);
 					raw_feature[slot] = single.feature;
 				}
-				if (STILL) still_record(ri, key, count, body_a, body_b, (uint64_t)s_pre[0][threadIdx.x] | ((uint64_t)s_pre[1][threadIdx.x] << 32), s_pre[2][threadIdx.x]);
+				if (STILL) still_record(ri, key, count, body_a, body_b, (uint64_t)s_pre[0][threadIdx.x] | ((uint64_t)s_pre[1][threadIdx.x] << 32), s_pre[2][threadIdx.x], invalid);
 				else {
 				{ const uint64_t was = rec_key[ri]; changed |= was != key; rec_key[ri] = key; }
 				nh_Record r = { body_a, body_b, 0u, asleep ? NH_REC_SLEEPING : (uint32_t)count };
@@ -1058,7 +1090,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		uint32_t* w_f = s_f[threadIdx.x >> 6];
 		uint8_t* w_n = s_n[threadIdx.x >> 6];
 		const uint32_t lane = nh_lane();
-		if (i < n) {
+		if (live) {
 			if (extra && ovf + extra > overflow_cap) { st->error = NH_ERR_CONTACT_CAPACITY; count = 4; }
 			auto put = [&](int k, const nh_contact_out& o) {
 				if (STILL && k >= 4) return;
@@ -1088,7 +1120,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			} else if (bb.kind == 1) {
 				put(0, bb.edge);
 			}
-			if (STILL) still_record(ri, key, count, body_a, body_b, (uint64_t)s_pre[0][threadIdx.x] | ((uint64_t)s_pre[1][threadIdx.x] << 32), s_pre[2][threadIdx.x]);
+			if (STILL) still_record(ri, key, count, body_a, body_b, (uint64_t)s_pre[0][threadIdx.x] | ((uint64_t)s_pre[1][threadIdx.x] << 32), s_pre[2][threadIdx.x], invalid);
 			else {
 				{ const uint64_t was = rec_key[ri]; changed |= was != key; rec_key[ri] = key; }
 				nh_Record r = { body_a, body_b, ovf, asleep ? NH_REC_SLEEPING : (uint32_t)count };
@@ -1097,7 +1129,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 				rec_idx[ri] = ri;
 			}
 		}
-		w_n[lane] = (uint8_t)(i < n ? (count < 4 ? count : 4) : 0);
+		w_n[lane] = (uint8_t)(live ? (count < 4 ? count : 4) : 0);
 		__builtin_amdgcn_wave_barrier();
 		{
 			const size_t run = (size_t)4 * (ri - lane);            // first raw slot of the wave's pairs
@@ -1466,7 +1498,7 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		st->any_idle[parity ^ 1u] = 0;
 		// (what a still step of the other parity -- the next step, if the host launches it as one -- accumulates into, and the verdict on this step's layout)
-		st->max_idle[parity ^ 1u] = 0u; st->lay_valid = 0u; st->lay_in_place = 0u; st->delta_count[parity ^ 1u] = 0u; st->delta_overflow[parity ^ 1u] = 0u;
+		st->max_idle[parity ^ 1u] = 0u; st->lay_valid = 0u; st->lay_in_place = 0u; st->delta_count[parity ^ 1u] = 0u; st->delta_overflow[parity ^ 1u] = 0u; st->still_esc[parity ^ 1u] = 0u;
 		for (int k = 0; k < 3; ++k) { st->still_smin[parity ^ 1u][k] = 0xffffffffu; st->still_smax[parity ^ 1u][k] = 0u; }
 	}
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < NH_DEG_WORDS(nbodies); i += gridDim.x * blockDim.x) deg[i] = 0;      // degrees, pair counters, first contacts (NH_DEG_STRIDE)
@@ -1756,11 +1788,18 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 		                   !ctx->env_no_sort_reuse && C != 0u;
 		if (still) {
 			nh_DevState* st = ctx->d_state;
+			// MOVERS form (nh_internal.h, "LOCAL speculation"): while somebody has been leaving its inflated box lately, the step re-boxes its leavers and re-inserts them
+			// into the kept list itself (one more launch, which leaves at once in a step nobody moves in); otherwise a leaver fails the step, and the full step that
+			// re-inserts it switches this on
+			const bool movers = incremental && !ss.no_local && ss.movers_left != 0u;
 			NH_LAUNCH(ctx, "xform_still", (k_xform<true>), nh_grid_for(C > B ? C : B, 1024, 256), 1024, st, bodies->transforms,
 			          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
 			          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
 			          xf, aabb_min, aabb_max, ctag, (uint4*)nullptr, 0u, ctx->fat_box, 0u,
-			          (uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, ctx->collide_seq, bodies->idle_counters, B, ctx->step_parity);
+			          movers ? ctx->fat_gen : (uint8_t*)nullptr, ctx->fat_esc_mark, ctx->fat_esc_list, ctx->fat_moved_list, ctx->collide_seq, bodies->idle_counters, B, ctx->step_parity);
+			if (movers)
+				NH_LAUNCH(ctx, "reinsert_still", k_reinsert, 256, 256, st, nbox, ctx->grid_sbox, ctx->grid_cstart, ctx->grid_large, ctx->fat_box, ctx->fat_gen, ctx->fat_esc_mark, ctx->fat_esc_list,
+				          ctx->fat_moved_list, ctx->collide_seq, ctx->fat_pairs, ctx->fat_pair_capacity, 1u, ctx->step_parity, C);
 			const uint8_t* gen = incremental ? ctx->fat_gen : (const uint8_t*)nullptr;
 			const bool delta_scan = C > (2u << 20);
 			if (nbox >= 2)

@@ -151,6 +151,7 @@ extern "C" int nh_set_option(nh_context* ctx, const char* name, int value) {
 	const bool on = value != 0;
 	ctx->asleep.streak = 0;
 	if (n == "no_asleep") ctx->asleep.disabled = on;                      // nh_step runs every step of a world that is asleep in full (nh_internal.h: nh_AsleepState)
+	else if (n == "no_local_still") ctx->still.no_local = on;                  // a collider that leaves its inflated box fails a still step as a whole (round 4's behaviour; nh_internal.h "LOCAL speculation")
 	else if (n == "no_still") ctx->still.disabled = on;                        // no step is launched speculatively as a still step (note 9)
 	else if (n == "sort_classic") ctx->env_sort_classic = on;             // three-kernel radix passes
 	else if (n == "sort_radix") ctx->env_sort_radix = on;                 // radix passes every step (no seeded bucket sort)
@@ -199,8 +200,7 @@ extern "C" int nh_synchronize(nh_context* ctx) {
 	if (!ctx) return NH_ERR_INVALID;
 	int rc = nh_flush_pending(ctx);
 	if (rc) return rc;
-	rc = nh_still_sync_outputs(ctx);         // (contacts and cache as the caller's arrays show them: note 9)
-	if (rc) return rc;
+	// (waits only: the views of note 9 are exported by nh_export_views -- a caller that synchronises every step must not pay two passes over the contacts for it)
 	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 	if (ctx->timing) nh_timer_collect(ctx);
 	return NH_OK;
@@ -213,6 +213,9 @@ void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out) {
 	if (ctx->collide_seq && !ctx->idle_unknown) { ctx->idle_bound = (int)h->max_idle[ctx->step_parity]; ctx->idle_bound_mark = ctx->collide_mark; }
 	out->colliders = h->colliders; out->pairs = h->pairs + h->pairs_sph; out->contacts = h->contacts; out->sleeping_pairs = h->sleeping;
 	out->active_bodies = h->active; out->cache = h->cache; out->culled = h->culled; out->large_colliders = h->large;
+	// (still steps, note 9: the cache IS the contact list of the last step -- nothing is culled in a still step -- and its count is written to the device only by the
+	// export of the view: until then the step's contact count stands for it)
+	if (ctx->still.cache_stale) out->cache = h->contacts;
 	out->general_contacts = h->general_contacts; out->levels = h->levels; out->error = h->error;
 	out->still_steps = (uint32_t)(ctx->still.launched - ctx->still.failed - ((ctx->still.active && !ctx->still.resolved) ? 1u : 0u)); out->still_replays = (uint32_t)ctx->still.failed;
 	for (int k = 0; k < 4; ++k) out->still_diff[k] = h->still_diff[k];
@@ -223,8 +226,7 @@ void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out) {
 
 extern "C" int nh_read_counts(nh_context* ctx, nh_Counts* out) {
 	if (!ctx || !out) return NH_ERR_INVALID;
-	{ int rc = nh_flush_pending(ctx, true); if (rc) return rc; }      // (counters only: a pending NH_FLAG_FUSED_STEP gravity stays pending)
-	{ int rc = nh_still_sync_outputs(ctx); if (rc) return rc; }
+	{ int rc = nh_flush_pending(ctx, true); if (rc) return rc; }      // (counters only: a pending NH_FLAG_FUSED_STEP gravity stays pending; no view is exported, note 9)
 	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, NH_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 	nh_counts_from_mirror(ctx, out);

@@ -127,6 +127,10 @@ struct nh_DevState {
 	uint32_t still_smin[2][3], still_smax[2][3];   // by step parity: scene bounds of a still step (k_xform<true>; cleared for the next step by the step before)
 	uint32_t asleep_failed;                // k_asleep_check (nh_step, asleep steps): something is not what it was when the world went to sleep
 	uint32_t still_top[2];        // by step parity: largest idle counter a still step saw
+	// still steps with movers (nh_collide.hip, "9. still steps", LOCAL speculation): colliders that left their inflated boxes in a still step are given new boxes and
+	// re-inserted into the kept pair list by the step itself (k_xform<true> with stamps, k_reinsert in still mode) instead of failing it
+	uint32_t still_esc[2];        // by step parity: colliders a still step re-boxed (the esc_count of a full step; cleared for the next step by the step before)
+	uint32_t still_fat0;          // kept pairs (both kinds) when this still step began: what k_reinsert's "crowded" verdict is taken from (the list grows while it runs)
 	nh_BlkGrid blk;               // spatially blocked solver (nh_blocks.h)
 };
 
@@ -194,7 +198,13 @@ struct nh_StillStep {
 	// back-off: a world in which something keeps moving (a body in the air leaves its inflated box every step) fails every still step it is offered; after the k-th
 	// failure in a row the next 2^k - 1 steps (at most 63) are not offered as still steps.  Sixteen confirmed still steps in a row forget the failures.
 	uint32_t hold, fail_level, good_run;
-	uint32_t seen_inserts, seen_rebuilds;          // re-insertion / rebuild counters at the last full step's round trip (finish_setup: did anybody leave its box in that step?)
+	uint32_t seen_inserts, seen_rebuilds;          // re-insertion / rebuild counters at the last round trip (finish_setup, a still step's verdict: did anybody leave its box in that step?)
+	// LOCAL speculation (round 5).  A still step used to fail as a whole when ONE collider left its inflated box: a world of a million boxes at rest paid the full
+	// step for a single box in the air (-42 %).  While somebody has been leaving boxes lately (`movers_left` steps to go: renewed by every round trip that shows a
+	// re-insertion) still steps are launched in MOVERS form: k_xform<true> re-boxes the leavers like a full step's does, k_reinsert appends their new pairs to the
+	// kept list, and the still narrowphase takes a kept pair that has died (stamps) or no longer overlaps as a record without contacts, and the appended pairs as
+	// pairs without a record that must not produce a contact -- a landing is still a full step.  Option "no_local_still": the round-4 behaviour.
+	bool no_local; uint32_t movers_left;
 	void note_failure() { hold = (1u << fail_level) - 1u; if (fail_level < 6u) ++fail_level; good_run = 0; }
 	void note_confirmed() { if (++good_run >= 16u) fail_level = 0; }
 };
@@ -330,8 +340,8 @@ struct nh_context {
 int nh_flush_pending(nh_context* ctx, bool keep_gravity = false, bool in_sequence = false);
 int nh_still_abandon(nh_context* ctx);
 // The caller's view of what still steps keep by slot -- the dense contact list and the contact cache in tag order -- brought up to date (every entry point outside
-// the sample's call order calls it through nh_flush_pending: nh_read_counts, nh_synchronize, ...)
-int nh_still_sync_outputs(nh_context* ctx);
+// the sample's call order that hands the arrays to the caller: nh_export_views, nh_append_contacts, nh_contact_impulses_device -- NOT nh_read_counts / nh_synchronize)
+int nh_still_sync_outputs(nh_context* ctx, uint32_t what = 3u /* NH_VIEW_ALL */);
 int nh_still_export_cache(nh_context* ctx);
 int nh_still_verdict_now(nh_context* ctx);            // nh_step: the pending verdict of the last still step, waited for: 0 = it happened, 1 = it did not
 #define NH_INTERNAL_STILL_FAILED (-1000)      // (never leaves the library) first_apply -> nh_step: the still step before this one failed, run both again

@@ -2053,7 +2053,7 @@ extern "C" const nh_CachedContactImpulse* nh_contact_impulses_device(const nh_Co
 		nh_StillStep& ss = m->ctx->still;
 		if (ss.active && ss.resolved && m->consumed && m->cdata == ss.cache_data) {
 			// a still step: the solved impulses live in the slot cache; in tag order they are what the exported cache holds (nothing is culled in a still step)
-			if (nh_still_sync_outputs(m->ctx) == NH_OK)
+			if (nh_still_sync_outputs(m->ctx, NH_VIEW_CACHE) == NH_OK)
 				hipMemcpyAsync(m->data, ss.cache.data, sizeof(nh_CachedContactImpulse) * (size_t)(m->capacity < ss.cache.capacity ? m->capacity : ss.cache.capacity), hipMemcpyDeviceToDevice, m->ctx->stream);
 		}
 	}
@@ -2428,6 +2428,15 @@ static void blk_run(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyD
 	NH_LAUNCH(ctx, "blk_scatter_back", k_blk_scatter_back, nh_grid_for(B, 256, 4096), 256, B, k.brank, k.own_base, (const float4*)k.bm, (float4*)bodies->momentum);
 }
 
+// LOCAL speculation (nh_internal.h): every round trip -- a full step's, a still step's verdict -- tells whether somebody left its inflated box in that step; the
+// movers form of the still step stays on for 64 steps after the last one who did
+static void still_note_movers(nh_context* ctx, const nh_DevState* h) {
+	nh_StillStep& ss = ctx->still;
+	if (h->fat_inserts != ss.seen_inserts) ss.movers_left = 64u;
+	else if (ss.movers_left) ss.movers_left--;
+	ss.seen_inserts = h->fat_inserts; ss.seen_rebuilds = h->fat_rebuilds;
+}
+
 static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 	nh_DevState* st = ctx->d_state;
 	const nh_ContactData* contacts = &d->cont.contacts;
@@ -2451,8 +2460,11 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		                     h->culled == 0u && h->general_contacts == 0u && !h->error;
 		// ... and nobody moved: a collider that left its inflated box in THIS step (re-inserted, or the kept list rebuilt) will most likely leave it again in the next
 		// one -- a body in the air does on every step -- and a still step that fails costs two steps' worth of launches
-		if (h->fat_inserts != ctx->still.seen_inserts || h->fat_rebuilds != ctx->still.seen_rebuilds) ctx->still.ok_next = false;
-		ctx->still.seen_inserts = h->fat_inserts; ctx->still.seen_rebuilds = h->fat_rebuilds;
+		// (LOCAL speculation, nh_internal.h: a still step in movers form re-inserts its own leavers -- then only a REBUILD of the kept list, which also voids the
+		// layout, rules the next step out; a re-insertion switches the movers form on for the steps that follow)
+		const bool local = !ctx->still.no_local && !ctx->env_no_incremental && !ctx->env_no_fat;
+		if ((h->fat_inserts != ctx->still.seen_inserts && !local) || h->fat_rebuilds != ctx->still.seen_rebuilds) ctx->still.ok_next = false;
+		still_note_movers(ctx, h);
 		// asleep steps (nh_internal.h: nh_AsleepState): was this step the fixed point of a world in which every body is asleep -- nobody active, no contact, every cache
 		// entry kept aside -- and the second one in a row with the same counts?  Then nh_step may take the steps that follow as done (after its own check)
 		nh_AsleepState& as = ctx->asleep;
@@ -2705,6 +2717,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 					memcpy(ctx->h_state, h, NH_COUNTER_WORDS * sizeof(uint32_t));
 					if (!ctx->idle_unknown) { ctx->idle_bound = (int)h->max_idle[ss.verdict.parity]; ctx->idle_bound_mark = ss.verdict.collide_mark; }
 					ss.verdict.pending = false;
+					still_note_movers(ctx, h);
 				}
 				// ... then this step's counters on their way, to be looked at by the next step
 				const int slot = (int)(ctx->collide_seq & 1u);
@@ -2718,7 +2731,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 				NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 				if (ctx->timing) nh_timer_collect(ctx);
 				confirmed = ctx->h_state->still_failed_seq < ctx->collide_seq && ctx->h_state->error == 0u;
-				if (confirmed) { nh_Counts c; nh_counts_from_mirror(ctx, &c); }              // (the sleep prediction: largest idle counter this step saw)
+				if (confirmed) { nh_Counts c; nh_counts_from_mirror(ctx, &c); still_note_movers(ctx, ctx->h_state); }              // (the sleep prediction: largest idle counter this step saw)
 			}
 		}
 		if (confirmed) {
@@ -2829,13 +2842,21 @@ int nh_still_export_cache(nh_context* ctx) {
 	return NH_OK;
 }
 
-int nh_still_sync_outputs(nh_context* ctx) {
+int nh_still_sync_outputs(nh_context* ctx, uint32_t what) {
 	nh_StillStep& ss = ctx->still;
 	if (ss.active && !ss.resolved) return NH_OK;          // (an unconfirmed still step is abandoned by the caller first: nh_flush_pending)
-	int rc = nh_still_export_cache(ctx);
+	int rc = NH_OK;
+	if (what & NH_VIEW_CACHE) rc = nh_still_export_cache(ctx);
 	if (rc) return rc;
-	if (ss.contacts_stale) { ss.contacts_stale = false; rc = nh_still_view_contacts(ctx); }
+	if ((what & NH_VIEW_CONTACTS) && ss.contacts_stale) { ss.contacts_stale = false; rc = nh_still_view_contacts(ctx); }
 	return rc;
+}
+
+extern "C" int nh_export_views(nh_context* ctx, uint32_t what) {
+	if (!ctx || (what & ~(uint32_t)NH_VIEW_ALL)) return NH_ERR_INVALID;
+	NH_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+	{ int rc = nh_flush_pending(ctx, true); if (rc) return rc; }
+	return nh_still_sync_outputs(ctx, what);
 }
 
 // A still step that has not been confirmed, met by anything but the next call of the sample's order (or failed on the device): the step is launched again in full.
@@ -2996,6 +3017,7 @@ int nh_still_verdict_now(nh_context* ctx) {
 	if (h->still_failed_seq >= ss.verdict.seq || h->error) return 1;
 	memcpy(ctx->h_state, h, NH_COUNTER_WORDS * sizeof(uint32_t));
 	if (!ctx->idle_unknown) { ctx->idle_bound = (int)h->max_idle[ss.verdict.parity]; ctx->idle_bound_mark = ss.verdict.collide_mark; }
+	still_note_movers(ctx, h);
 	return 0;
 }
 

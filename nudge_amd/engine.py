@@ -12,6 +12,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import warnings
 
 import numpy as np
 
@@ -26,9 +27,14 @@ NH_FLAG_SYNC_COUNTS = 1
 NH_FLAG_EXACT_ORDER = 2
 NH_FLAG_SINGLE_APPLY = 4
 NH_FLAG_FUSED_STEP = 8
+NH_VIEW_CONTACTS, NH_VIEW_CACHE, NH_VIEW_ALL = 1, 2, 3
+# environment variables NH_<NAME> that World() forwards to nh_set_option (tests and dev scripts; include/nudge_hip.h lists what each does)
+OPTION_NAMES = ("no_still", "no_kept_pairs", "no_incremental", "no_sort_reuse", "sort_classic", "sort_radix", "bucket_tile", "bucket_target", "colour_jp",
+                "colour_check_seeds", "no_resident", "solver_waves", "fp_sub", "cooperative", "no_blocks", "blk_check", "blk_min", "blk_target", "blk_rows_global",
+                "blk_global_colours", "blk_profile", "no_asleep", "no_blk_chain", "no_local_still", "measure_skip_chains")
 
 EXPORTS = [
-    "nh_create", "nh_destroy", "nh_set_flags", "nh_synchronize", "nh_read_counts", "nh_set_cache_count",
+    "nh_create", "nh_destroy", "nh_set_flags", "nh_synchronize", "nh_read_counts", "nh_export_views", "nh_set_cache_count",
     "nh_set_tag_bits", "nh_set_pair_capacity", "nh_set_option", "nh_bodies_changed", "nh_error_string", "nh_last_hip_error", "nh_collide", "nh_apply_gravity_damping",
     "nh_read_cached_impulses", "nh_write_cached_impulses", "nh_setup_contact_constraints", "nh_apply_impulses",
     "nh_update_cached_impulses", "nh_advance", "nh_contact_impulses_device", "nh_enable_timing", "nh_set_timing_filter", "nh_kernel_times",
@@ -131,6 +137,7 @@ def lib():
         L.nh_step.argtypes = [C.c_void_p, C.POINTER(StepArgs), C.c_uint32]
         L.nh_synchronize.argtypes = [C.c_void_p]
         L.nh_read_counts.argtypes = [C.c_void_p, C.POINTER(Counts)]
+        L.nh_export_views.argtypes = [C.c_void_p, C.c_uint32]
         L.nh_set_cache_count.argtypes = [C.c_void_p, C.c_uint32]
         L.nh_error_string.argtypes = [C.c_int]
         L.nh_error_string.restype = C.c_char_p
@@ -258,12 +265,20 @@ class World:
         # A/B switches for tests and dev scripts: environment variables NH_<NAME>=<int> become nh_set_option(name, value) calls HERE -- the library itself never
         # reads the environment (include/nudge_hip.h: nh_set_option)
         for key, val in sorted(os.environ.items()):
-            if key.startswith("NH_") and key not in ("NH_GATHER_32",):
-                try:
-                    num = int(val)
-                except ValueError:
-                    num = 1
-                _check(self.L, self.L.nh_set_option(self.ctx, key[3:].lower().encode(), num), f"nh_set_option({key})")
+            if not key.startswith("NH_"):
+                continue
+            name = key[3:].lower()
+            if name not in OPTION_NAMES:           # (a stale or unrelated NH_* variable must not keep a world from being created)
+                if name not in ("gather_32",):
+                    warnings.warn(f"nudge_amd: environment variable {key} names no library option; ignored")
+                continue
+            try:
+                num = int(val)
+            except ValueError:
+                num = 1
+            rc = self.L.nh_set_option(self.ctx, name.encode(), num)
+            if rc:                                 # (e.g. measure_skip_chains on a build without -DNH_MEASURE)
+                warnings.warn(f"nudge_amd: nh_set_option({name}, {num}) refused: {self.L.nh_error_string(rc).decode()}")
         if tag_bits is None:
             mt = 1
             for k in ("box_tags", "sphere_tags"):
@@ -344,10 +359,10 @@ class World:
         if steps > 0 and not (self.flags & NH_FLAG_SYNC_COUNTS) and not getattr(self, "eight_calls", False):
             p = self.params
             it = p["iterations"] if iterations is None else iterations
-            args = getattr(self, "_step_args", None)
-            if args is None or args.iterations != it:          # (the structs it points to are this object's own: counts changed by set_counts are seen through the pointers)
-                args = self._step_args = StepArgs(C.pointer(self.active), C.pointer(self.contacts), C.pointer(self.bodies), C.pointer(self.colliders), C.pointer(self.connections),
-                                                  C.pointer(self.cache), self.arena, p["time_step"], (C.c_float * 3)(0.0, p["gravity"], 0.0), p["damping_rate"], it)
+            # (rebuilt every call -- a dozen host-side stores -- so that a changed time step, gravity or damping is never ignored; the structs it points to are this
+            # object's own: counts changed by set_counts are seen through the pointers)
+            args = self._step_args = StepArgs(C.pointer(self.active), C.pointer(self.contacts), C.pointer(self.bodies), C.pointer(self.colliders), C.pointer(self.connections),
+                                              C.pointer(self.cache), self.arena, p["time_step"], (C.c_float * 3)(0.0, p["gravity"], 0.0), p["damping_rate"], it)
             _check(self.L, self.L.nh_step(self.ctx, C.byref(args), steps), "nh_step")
             self.steps_done += steps
             return
@@ -372,6 +387,7 @@ class World:
     def snapshot(self):
         """Everything that persists from one step to the next on the caller's side (nudge.h: BodyData transforms / momentum / idle
         counters and the ContactCache), cloned on the device."""
+        self.export_views(NH_VIEW_CACHE)
         c = self.counts()
         return dict(cache_count=c["cache"], arrays={k: self._keep[k].clone() for k in ("bt", "bm", "bi", "kt", "kf", "kd")})
 
@@ -424,6 +440,10 @@ class World:
     def synchronize(self):
         _check(self.L, self.L.nh_synchronize(self.ctx), "synchronize")
 
+    def export_views(self, what=NH_VIEW_ALL):
+        """The dense contact list / the contact cache in the caller's arrays brought up to date after still steps (include/nudge_hip.h note 9)."""
+        _check(self.L, self.L.nh_export_views(self.ctx, what), "export_views")
+
     def counts(self):
         c = Counts()
         _check(self.L, self.L.nh_read_counts(self.ctx, C.byref(c)), "read_counts")
@@ -449,6 +469,7 @@ class World:
             self.L.nh_bodies_changed(self.ctx)
 
     def get_contacts(self):
+        self.export_views(NH_VIEW_CONTACTS)
         c = self.counts()
         n, ns = c["contacts"], c["sleeping_pairs"]
         return dict(count=n, data=self._down("cd", S.CONTACT, n), bodies=self._down("cb", np.uint32, 2 * n).reshape(-1, 2),
@@ -460,11 +481,15 @@ class World:
         return self._down("ai", np.uint32, c["active_bodies"])
 
     def get_cache(self):
+        self.export_views(NH_VIEW_CACHE)
         c = self.counts()
         n = c["cache"]
         return dict(count=n, tags=self._down("kt", np.uint64, n), features=self._down("kf", np.uint32, n), data=self._down("kd", S.IMPULSE, n))
 
     def get_contact_impulses(self):
+        if not self._imp:
+            raise NudgeError("get_contact_impulses: no nh_ContactImpulseData handle -- step() went through nh_step, which keeps the handles inside the library; "
+                             "set world.eight_calls = True (or call the eight entry points) to look at the per-contact impulses of a step")
         c = self.counts()
         n = c["contacts"]
         ptr = self.L.nh_contact_impulses_device(self._imp)

@@ -14,7 +14,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nudge_amd import scenes as S   # noqa: E402
 from nudge_amd import engine as E   # noqa: E402
 
-tiles = int(sys.argv[1]) if len(sys.argv) > 1 else 124
+quick = "--quick" in sys.argv          # (round 5) three columns: local speculation (default), global speculation (NH_NO_LOCAL_STILL=1, round 4), none (NH_NO_STILL=1)
+argv = [x for x in sys.argv[1:] if not x.startswith("--")]
+tiles = int(argv[0]) if argv else 124
 scene = S.grid_tiles(tiles, side=90, seed=2)
 nb = len(scene["body_transforms"])
 flags = E.NH_FLAG_SINGLE_APPLY | E.NH_FLAG_FUSED_STEP
@@ -22,10 +24,11 @@ print(f"{nb - 1:,} boxes in {tiles} tiles, landed and awake; steps/s over 96 ste
 _w = E.World(scene, flags=flags); _w.step(200); _w.synchronize(); _w.close()          # (clocks and allocator warm before the first measured world)
 for mode in ("hop", "fly"):
     print(f"--- {mode}: " + ("K boxes kicked every 12 steps" if mode == "hop" else "K boxes thrown up once, in the air throughout"))
-    print("movers | re-insertion + still steps (default) | no still steps (NH_NO_STILL=1) | rebuild on leave (NH_NO_INCREMENTAL=1) | search every step (NH_NO_KEPT_PAIRS=1)")
+    columns = (None, "NH_NO_LOCAL_STILL", "NH_NO_STILL") if quick else (None, "NH_NO_LOCAL_STILL", "NH_NO_STILL", "NH_NO_INCREMENTAL", "NH_NO_KEPT_PAIRS")
+    print("movers | " + " | ".join("default (still steps re-insert their own leavers)" if e is None else e + "=1" for e in columns))
     for K in ((0, 1, 16, 256, 2048) if mode == "hop" else (1, 16, 256, 2048)):
         row, detail = [], []
-        for env in (None, "NH_NO_STILL", "NH_NO_INCREMENTAL", "NH_NO_KEPT_PAIRS"):
+        for env in columns:
             if env: os.environ[env] = "1"
             w = E.World(scene, flags=flags)
             if env: os.environ.pop(env, None)
@@ -49,6 +52,6 @@ for mode in ("hop", "fly"):
             assert c1["error"] == 0
             row.append(8 * 12 / t)
             detail.append(f"{c1['broadphase_rebuilds'] - c0['broadphase_rebuilds']} rebuilds, {c1['broadphase_inserts'] - c0['broadphase_inserts']} re-insertions"
-                          + (f", {c1['still_steps'] - c0['still_steps']} still steps, {c1['still_replays'] - c0['still_replays']} replayed" if env is None else ""))
+                          + (f", {c1['still_steps'] - c0['still_steps']} still steps, {c1['still_replays'] - c0['still_replays']} replayed" if env in (None, "NH_NO_LOCAL_STILL") else ""))
             w.close()
-        print(f"{K:6d} | {row[0]:8.1f} ({detail[0]}) | {row[1]:8.1f} ({detail[1]}) | {row[2]:8.1f} ({detail[2]}) | {row[3]:8.1f} ({detail[3]})", flush=True)
+        print(f"{K:6d} | " + " | ".join(f"{r:8.1f} ({d})" for r, d in zip(row, detail)), flush=True)

@@ -21,13 +21,15 @@ pytestmark = pytest.mark.gpu
 BENCH_FLAGS = E.NH_FLAG_SINGLE_APPLY | E.NH_FLAG_FUSED_STEP
 
 
-def _world(scene, still, flags=BENCH_FLAGS, **kw):
-    if not still:
-        os.environ["NH_NO_STILL"] = "1"
+def _world(scene, still, flags=BENCH_FLAGS, env=(), **kw):
+    names = list(env) + ([] if still else ["NH_NO_STILL"])
+    for k in names:
+        os.environ[k] = "1"
     try:
         return E.World(scene, flags=flags, **kw)
     finally:
-        os.environ.pop("NH_NO_STILL", None)
+        for k in names:
+            os.environ.pop(k, None)
 
 
 def _same_world(a, b, what=""):
@@ -175,6 +177,100 @@ def test_nh_step_with_late_verdicts_matches_the_eight_calls():
     assert ca["still_replays"] > c0["still_replays"] and ca["still_steps"] > c0["still_steps"] + 50, (c0, ca)
     assert ca["error"] == 0 and cb["error"] == 0
     a.close(); b.close(); c.close()
+
+
+# ---- LOCAL speculation (nudge_amd/csrc/nh_internal.h: nh_StillStep, "LOCAL speculation"): movers in a world at rest ---------------------------------------------------
+def _throw(worlds, idx, vy, lateral=0.0, seed=0):
+    rng = np.random.default_rng(seed)
+    kick = rng.uniform(-lateral, lateral, size=(len(idx), 3)).astype(np.float32) if lateral else np.zeros((len(idx), 3), np.float32)
+    kick[:, 1] = vy
+    for w in worlds:
+        m = w.get_bodies()["momentum"].copy()
+        m["velocity"][idx] = kick
+        w.set_bodies(momentum=m)
+
+
+@pytest.mark.parametrize("sphere_fraction", [0.0, 0.5])
+def test_bodies_in_the_air_do_not_cost_the_world_its_still_steps(sphere_fraction):
+    """A landed world in which a few bodies are thrown high up: every one of them leaves its inflated box on every step.  Round 4 failed each such still step as a whole
+    (and then stopped offering them); now the step re-boxes and re-inserts its leavers itself (movers form) and the pairs they leave behind are records without
+    contacts.  The bits must be those of a library that never speculates AND of one that speculates the old way (NH_NO_LOCAL_STILL=1), checkpoint by checkpoint --
+    bodies, idle counters, contacts, cache -- and nearly every step must have gone through as a still step."""
+    scene = S.grid_tiles(2, side=32, sphere_fraction=sphere_fraction, seed=61, lattice_cols=2)
+    nb = len(scene["body_transforms"])
+    a, b, c = _world(scene, True), _world(scene, False), _world(scene, True, env=["NH_NO_LOCAL_STILL"])
+    for w in (a, b, c):
+        w.step(120)
+    _same_world(a, b, "rest")
+    idx = np.arange(5, nb, 137)
+    _throw((a, b, c), idx, 30.0, lateral=1.0, seed=7)           # 6 s in the air: far longer than the test
+    c0, k0 = a.counts(), c.counts()
+    done = 0
+    for cp in (1, 2, 3, 10, 40, 41, 120, 200):
+        for w in (a, b, c):
+            w.step(cp - done)
+        done = cp
+        _same_world(a, b, f"flying, step {cp}: local speculation vs none")
+        _same_world(c, b, f"flying, step {cp}: global speculation vs none")
+    ca, kc = a.counts(), c.counts()
+    print(f"\n[movers, spheres {sphere_fraction}] {len(idx)} bodies in the air for {done} steps: still steps {ca['still_steps'] - c0['still_steps']} (replays {ca['still_replays'] - c0['still_replays']}, "
+          f"re-insertions {ca['broadphase_inserts'] - c0['broadphase_inserts']}); without local speculation {kc['still_steps'] - k0['still_steps']} (replays {kc['still_replays'] - k0['still_replays']})")
+    assert ca["error"] == 0
+    assert ca["broadphase_inserts"] > c0["broadphase_inserts"] + done // 2, (c0, ca)          # (they really did leave their boxes)
+    assert ca["still_steps"] - c0["still_steps"] >= done - 30, (c0, ca)                      # (a few full steps: the first leave, the checkpoints' views)
+    assert kc["still_steps"] - k0["still_steps"] <= done // 2, (k0, kc)                      # (what it used to be)
+    a.close(); b.close(); c.close()
+
+
+def test_hops_landings_and_slides_through_local_speculation():
+    """Short hops: bodies leave their boxes, are in the air for a few dozen steps above their neighbours' boxes (appended pairs that overlap but must not touch), land -- a
+    full step: a contact of a pair without a record -- slide, and come to rest.  nh_step with late verdicts, the eight calls and a library that never speculates end in
+    the same bits at every checkpoint."""
+    scene = S.grid_tiles(1, side=40, seed=67)
+    nb = len(scene["body_transforms"])
+    a, b, c = _world(scene, True), _world(scene, True), _world(scene, False)
+    b.eight_calls = True
+    for w in (a, b, c):
+        w.step(110)
+    idx = np.arange(3, nb, 53)
+    c0 = a.counts()
+    for rnd in range(2):                                                  # (the world stays awake: 110 + 2 x 80 steps)
+        _throw((a, b, c), idx, 2.5, lateral=3.0, seed=11 + rnd)          # (tests/gpu_movers_rates.py "hop")
+        at = 0
+        for more in (5, 25, 50):
+            for w in (a, b, c):
+                w.step(more)
+            at += more
+            _same_world(a, c, f"hop {rnd}, step {at}: nh_step vs no speculation")
+            _same_world(b, c, f"hop {rnd}, step {at}: eight calls vs no speculation")
+    ca = a.counts()
+    print(f"\n[hops] still steps {ca['still_steps'] - c0['still_steps']} of {2 * 80}, replays {ca['still_replays'] - c0['still_replays']}, re-insertions {ca['broadphase_inserts'] - c0['broadphase_inserts']}")
+    assert ca["error"] == 0 and ca["active_bodies"] == nb - 1
+    # (31 bodies hopping across their neighbours: the steps in which one of them touches another body -- a contact the fused solver does not own -- are full steps)
+    assert ca["still_steps"] - c0["still_steps"] >= 40, (c0, ca)
+    a.close(); b.close(); c.close()
+
+
+def test_counts_and_synchronize_every_step_export_nothing_and_views_are_the_bits_of_a_full_step():
+    """The sample reads active_bodies.count every sub-step (example/main.cpp:293).  nh_read_counts / nh_synchronize are cheap observers: they keep the world in the
+    still regime and export no view; the dense contact list and the cache a caller gets AFTERWARDS (nh_export_views) are the bits of a library that never speculates."""
+    scene = S.grid_tiles(1, side=32, seed=71)
+    a, b = _world(scene, True), _world(scene, False)
+    a.step(100); b.step(100)
+    c0 = a.counts()
+    for _ in range(40):
+        a.step(1); b.step(1)
+        ca, cb = a.counts(), b.counts()
+        a.synchronize()
+        for k in ("contacts", "active_bodies", "cache", "sleeping_pairs", "error"):
+            assert ca[k] == cb[k], (k, ca[k], cb[k])
+    c1 = a.counts()
+    assert c1["still_steps"] - c0["still_steps"] >= 38, (c0, c1)
+    _same_world(a, b, "views after forty observed steps")
+    a.step(5); b.step(5)
+    assert a.counts()["still_steps"] - c1["still_steps"] >= 4          # (exporting the views did not end the regime either)
+    _same_world(a, b, "and again")
+    a.close(); b.close()
 
 
 # ---- asleep steps (nudge_amd/csrc/nh_internal.h: nh_AsleepState): nh_step on a world in which every body is asleep ---------------------------------------------
