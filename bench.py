@@ -33,6 +33,7 @@ The JSON line also carries
                   the same workload, all cores and one core (rank 0, N = 1 only).
 """
 import argparse
+import glob
 import json
 import math
 import os
@@ -151,6 +152,40 @@ def pmc_traffic(kernel):
         return None, None
     # corrected = 2 x FETCH + WRITE (an upper bound: gathers are not half-counted), raw = FETCH + WRITE (a lower bound); both are reported
     return ((k["hbm_bytes_corrected"], k.get("hbm_bytes_raw")), os.path.basename(f)) if k else (None, None)
+
+
+# ---- VALU issue ceiling (round 5; VERDICT r4 "a compute ceiling for the dominant kernel") --------------------------------------------------------------------------
+# Measured on an MI355X with tools/valu_rate.hip (profiles/r05_valu_rate.log), wave64 fp32 instructions per microsecond and SIMD:
+#   independent instructions, two or more waves per SIMD: 810 (the SIMD's issue limit);
+#   ONE dependent chain per wave: 247 with one wave per SIMD, 470 with two, 655 with three, 768 with four.
+# The fused one-body solver is a dependent chain (Gauss-Seidel inside a body, in the reference's operation order) at two waves per SIMD.
+VALU_PEAK_PER_US_PER_SIMD = 810.0
+VALU_DEPENDENT_PER_US_PER_WAVE = 247.0
+SIMDS = 256 * 4
+
+
+def valu_ceiling(kernel, launch_ms, waves_per_simd=2):
+    """VALU instructions per wave of `kernel` from the newest committed SQ export (SQ_INSTS_VALU / SQ_WAVES, profiles/export_sq.py) against what the SIMDs can issue."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_sq_wave_states.json")))
+    sym = PMC_KERNEL.get(kernel)
+    if not files or not sym or not launch_ms:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(sym)
+        per_wave, waves = k["valu_instructions_per_wave"], k["counters_per_launch"]["SQ_WAVES"]
+    except Exception:
+        return None
+    rate = per_wave * waves / SIMDS / (launch_ms * 1e3)          # wave-instructions per microsecond and SIMD
+    return {"valu_instructions_per_wave": per_wave, "waves_per_launch": waves, "achieved_wave_instr_per_us_per_simd": rate,
+            "peak_wave_instr_per_us_per_simd": VALU_PEAK_PER_US_PER_SIMD, "valu_frac": rate / VALU_PEAK_PER_US_PER_SIMD,
+            "dependent_chain_rate_at_this_occupancy": VALU_DEPENDENT_PER_US_PER_WAVE * waves_per_simd,
+            "frac_of_dependent_chain_rate": rate / (VALU_DEPENDENT_PER_US_PER_WAVE * waves_per_simd), "waves_per_simd": waves_per_simd,
+            "sq_share_of_wave_cycles": {key: k.get(key + "_share_of_wave_cycles") for key in ("active", "valu", "parked_at_waitcnt", "issue_stall")},
+            "source": [os.path.basename(files[-1]), "profiles/r05_valu_rate.log (tools/valu_rate.hip)"],
+            "note": "the kernel issues its VALU instructions at the rate two waves with one dependency chain each reach on this SIMD (frac_of_dependent_chain_rate ~ 1), 0.61 of what "
+                    "the SIMD issues when fed independent FMAs (valu_frac): not HBM-bound (roofline.frac).  A third wave per SIMD was built (168 VGPRs, 12,288 B LDS; resident: "
+                    "SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE 1.49 x) and every wave then ran 1.55 x slower -- 170 us against 153: for THIS instruction stream two waves already take "
+                    "all the SIMD gives (profiles/r05_solver_three_waves_ab.log, tools/experiments/solver_three_waves.py)"}
 
 
 def pmc_step_total():
@@ -455,8 +490,21 @@ def main():
     w.synchronize()
     first_timed = landed_at + args.warmup
 
-    # ---- one fully instrumented pass over 3 landed steps: per-kernel table, dominant kernel (state restored afterwards at N = 1) ----
-    snap = w.snapshot() if cluster is None else None
+    # ---- one fully instrumented pass over 3 landed steps: per-kernel table, dominant kernel (state restored afterwards) ----
+    # N > 1 (round 5): every rank checkpoints ITS OWN bodies (owned + ghosts) and contact cache on its device; a block is restored from it on all ranks between two
+    # barriers.  Membership (who owns what, who is whose ghost) is not part of the checkpoint -- in the landed drop scene it does not change -- and the partition's step
+    # counter runs on across blocks, so the refresh every `EPOCH` steps falls INSIDE timed blocks at its true duty cycle instead of inside or outside one 20-step window by chance.
+    snap = w.snapshot() if (cluster is None or args.scene == "boxes") else None
+    owned0 = cluster.p.n_owned if cluster is not None else None
+
+    def restore_block(b):
+        """Back to the checkpoint.  A partition's ghosts are not part of it (which bodies a neighbour lists changes from refresh to refresh with the top speeds): the
+        restored step counter makes the untimed head step of the block a REFRESH, which installs the ghosts of the restored owners; the counter then continues from a
+        phase that walks through the epoch block by block, so that over the timed blocks a refresh falls inside a block at its true rate (K / EPOCH per block)."""
+        w.restore(snap)
+        if cluster is not None:
+            cluster.p.steps = EPOCH * 4096
+
     w.enable_timing(True)
     advance_world(3)
     w.synchronize()
@@ -467,9 +515,9 @@ def main():
         tot = sum(v[0] for v in ktimes.values())
         for k, (ms, n) in sorted(ktimes.items(), key=lambda kv: -kv[1][0]):
             print(f"  {k:24s} {ms / 3:9.4f} ms/step  {n / 3:6.1f} launches/step  {100 * ms / tot:5.1f} %", file=sys.stderr)
-    if snap is not None:
+    if snap is not None and cluster is None:
         w.restore(snap)
-    else:
+    elif snap is None:
         first_timed += 3
 
     # ---- timed region: blocks of exactly K steps between barrier + synchronize; only the dominant kernel carries events ----
@@ -477,20 +525,31 @@ def main():
         w.enable_timing(True, only=dominant)
     dt, blocks, contact_sum, pair_sum, general_sum = 0.0, 0, 0.0, 0.0, 0.0
     block_ms = []
+    timed_acc = [0.0, 0, 0.0, 0]          # inside the timed blocks only: seconds in refreshes, refreshes, seconds enqueueing per-step halos, per-step halos
     while True:
-        if snap is not None and blocks:
-            w.restore(snap)
+        if snap is not None and cluster is not None and not all_ranks(cluster.p.n_owned == owned0):
+            snap = None          # (a body changed owner: the checkpoint no longer describes this rank's slots -- no more restores, the blocks timed so far stand)
+            if blocks:
+                break
+        if snap is not None and (blocks or cluster is not None):
+            restore_block(blocks)
         if snap is not None:
             # one UNTIMED step at the head of every block: restoring a checkpoint (an artefact of this measurement: it rewrites body state and cache from outside) makes
             # the library look at everything again for one step, which a world stepping through its landed window never does.  Every block -- the first one too --
             # therefore times the same K steps, the ones after that step.
             advance_world(1)
+            if cluster is not None:
+                cluster.p.steps = EPOCH * 4096 + 1 + (blocks * args.steps) % EPOCH
         c0 = w.counts()
         barrier()
+        if cluster is not None:
+            acc0 = (cluster.t_refresh, cluster.n_refresh, cluster.t_halo, cluster.n_halo)
         t0 = time.perf_counter()
         advance_world(args.steps)
         barrier()
         t1 = time.perf_counter()
+        if cluster is not None:
+            timed_acc = [a + (b - c) for a, b, c in zip(timed_acc, (cluster.t_refresh, cluster.n_refresh, cluster.t_halo, cluster.n_halo), acc0)]
         c1 = w.counts()
         if c1["error"]:
             raise SystemExit(f"device error {c1['error']}")
@@ -500,7 +559,7 @@ def main():
         contact_sum += 0.5 * (c0["contacts"] + c1["contacts"])
         pair_sum += 0.5 * (c0["pairs"] + c1["pairs"])
         general_sum += 0.5 * (c0["general_contacts"] + c1["general_contacts"])
-        if snap is None or dt >= args.min_time or blocks >= 5000:
+        if snap is None or all_ranks(dt >= args.min_time) or blocks >= 5000:          # (N > 1: every rank leaves after the same block)
             break
     dom = w.kernel_times(reset=True).get(dominant) if dominant else None
     w.enable_timing(False)
@@ -518,7 +577,12 @@ def main():
     timed_steps = blocks * args.steps
     K, P, G = contact_sum / blocks, pair_sum / blocks, general_sum / blocks
 
+    per_rank = None
     if use_dist:
+        mine = torch.tensor([dt] + [float(v) for v in timed_acc], dtype=torch.float64, device=red_dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [[float(v) for v in e.tolist()] for e in every]
         tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -616,6 +680,13 @@ def main():
                                "pricing_check": (None if not traffic else ("ok" if bytes_per_launch <= 1.02 * traffic else "ALGORITHMIC BYTES EXCEED THE PMC UPPER BOUND: frac overstated")),
                                "avg_launch_note": "avg_launch_ms: HIP events around this kernel only, during the timed region (neighbouring kernels overlap its head and tail); "
                                                   "kernel_ms_per_step: 3 separate steps with events around EVERY launch (each kernel alone on the GPU)"}
+            # `bound` stays "hbm": achieved / peak above are the HBM roofline the metric is defined on.  What actually limits a kernel of dependent fp32 arithmetic is
+            # said next to it: its VALU issue rate against the SIMD's limit and against the rate of one dependency chain per wave (valu_ceiling)
+            vc = valu_ceiling(dominant, ms) if dominant in ("solve_still", "solve_one_body") else None
+            if vc:
+                out["roofline"]["valu"] = vc
+                out["roofline"]["limited_by"] = "VALU dependent-issue latency (see roofline.valu): neither HBM bandwidth nor the SIMD issue limit"
+
         elif dom:
             out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                                "avg_launch_ms": dom[0] / dom[1]}
@@ -679,11 +750,17 @@ def main():
             if one and abs(one["bodies"] - bodies_all) <= 0.01 * bodies_all:
                 out["single_gpu_same_world"] = one
                 out["speedup_vs_single_gpu_same_world"] = value / one["value"]
+        if per_rank:
+            # what every rank measured for the same blocks (the line's time is the slowest rank's): wall time per step; the refreshes that fell into the timed blocks
+            # and what one cost the host (its own device synchronisations included); host time to enqueue the per-step halo (pack, RCCL group, unpack -- no wait)
+            out["per_rank"] = [{"rank": r, "ms_per_step": 1e3 * e[0] / timed_steps, "refreshes_in_timed_blocks": int(e[2]), "refresh_ms": (1e3 * e[1] / e[2]) if e[2] else None,
+                                "halo_enqueue_us_per_step": (1e6 * e[3] / e[4]) if e[4] else None} for r, e in enumerate(per_rank)]
         if cluster is not None:
             st = cluster.p.stats
-            out["halo"] = {"backend": backend, "per_step_transport": ("library-driven RCCL (nh_partition_exchange_step)" if cluster.direct else f"torch.distributed point-to-point ({cluster.direct_why or 'not asked'})"), "loopback_records_per_step": (cluster.loopback_records / max(1, cluster.p.steps)) if loopback else None,
+            out["halo"] = {"backend": backend, "per_step_transport": ("library-driven RCCL (nh_partition_exchange_step)" if cluster.direct else f"torch.distributed point-to-point ({cluster.direct_why or 'not asked'})"), "loopback_records_per_step": (cluster.loopback_records / max(1, getattr(cluster, "loopback_steps", 0))) if loopback else None,
                            "ghost_bodies_rank0": st["ghosts"], "refreshes": st["refreshes"], "migrated_out_rank0": st["migrated_out"],
-                           "bytes_sent_per_step_rank0": st["step_bytes"] / max(1, cluster.p.steps)}
+                           "bytes_sent_per_step_rank0": st["step_bytes"] / max(1, cluster.p.steps % (EPOCH * 4096) if cluster.p.steps >= EPOCH * 4096 else cluster.p.steps),
+                           "loopback_bytes_per_step_through_rccl": (64.0 * cluster.loopback_records / max(1, cluster.loopback_steps)) if (loopback and getattr(cluster, "loopback_steps", 0)) else None}
         print(json.dumps(out))
     w.close()
     if use_dist:

@@ -401,6 +401,13 @@ int main(int argc, char** argv) {
 					if (fabs(a - b) > 0.05 * std::max(1.0, a + b) && a < b && cut == cut) NH_OK_(nh_partition_set_cut(R.part, side ? +1 : -1, cut));
 				}
 			}
+			{
+				// top speeds across the cuts: a cut's ghost margin must cover the fastest body on EITHER of its sides (include/nudge_hip.h: nh_partition_top_speed)
+				Values mine = { std::vector<double>(slots, 0.0), std::vector<double>(slots, 0.0) }, theirs = { std::vector<double>(slots, 0.0), std::vector<double>(slots, 0.0) };
+				for (Rank& R : ranks) { double v = 0.0; NH_OK_(nh_partition_top_speed(R.part, &R.bodies, &v)); mine[0][at(R)] = mine[1][at(R)] = v; }
+				exchange_values(T, ranks, mine, theirs);
+				for (Rank& R : ranks) NH_OK_(nh_partition_set_peer_speeds(R.part, R.has(0) ? theirs[0][at(R)] : 0.0, R.has(1) ? theirs[1][at(R)] : 0.0));
+			}
 			for (Rank& R : ranks) NH_OK_(nh_partition_pack_migrants(R.part, &R.bodies, R.has(0) ? R.out[0] : nullptr, R.has(1) ? R.out[1] : nullptr, R.msg_capacity, R.out_count));
 			exchange(T, ranks, NH_PARTITION_FULL_BYTES, false);
 			for (Rank& R : ranks) NH_OK_(nh_partition_unpack_migrants(R.part, &R.bodies, R.in[0], R.has(0) ? R.in_count[0] : 0u, R.in[1], R.has(1) ? R.in_count[1] : 0u));

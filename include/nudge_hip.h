@@ -361,6 +361,13 @@ int nh_partition_info(nh_partition* p, nh_PartitionInfo* out);
    unpack: the leavers are dropped (owned bodies stay in slot order), the arrivals appended, left neighbour's first; ghosts are gone until phase 2. */
 int nh_partition_pack_migrants(nh_partition* p, const nh_BodyData* bodies, void* out_left, void* out_right, uint32_t capacity_records, uint32_t counts[2]);
 int nh_partition_unpack_migrants(nh_partition* p, const nh_BodyData* bodies, const void* in_left, uint32_t n_left, const void* in_right, uint32_t n_right);
+/* Between the two phases -- or before phase 1, with its counts -- the ranks at a cut tell each other their TOP SPEED: a cut's ghost margin is reach + 2 x (how far anything
+   on EITHER side travels in an epoch), so it must know the fastest body of the neighbour too (a fast body owned there reaches a slow one here that this rank would
+   otherwise never list for it).  nh_partition_top_speed: the largest |velocity| among the bodies this rank owns now (call it BEFORE nh_partition_pack_migrants: a body that
+   migrates in this refresh then counts on both sides); nh_partition_set_peer_speeds: what the left / right neighbour reported (NAN or <= 0: none).  Both are consumed by the
+   next nh_partition_pack_ghosts; a host that never calls them gets margins from this rank's own top speed and `speed_floor` alone -- safe only when the floor bounds the world. */
+int nh_partition_top_speed(nh_partition* p, const nh_BodyData* bodies, double* out);
+int nh_partition_set_peer_speeds(nh_partition* p, double left, double right);
 /* Refresh, phase 2.  pack: the owned bodies within reach of a cut for the coming epoch are listed (the lists are kept for the per-step records) and their full
    records written.  unpack: the received ghosts are installed behind the owned bodies, the collider arrays rebuilt (static ones, then one per dynamic body in
    slot order), `bodies->count` and the collider counts of the caller's structs set, and the context told that body records changed (nh_bodies_changed). */
@@ -375,6 +382,8 @@ int nh_partition_unpack_step(nh_partition* p, const nh_BodyData* bodies, const v
    (nh_partition_set_transport; left_peer / right_peer: communicator ranks of the neighbours, -1 = none).  nh_partition_transport_check sends a pattern to both peers and
    receives theirs in one group (a peer equal to the own rank: a loop-back on one GPU); with enqueue_only the host polls the stream itself -- a neighbour that never answers must not hang
    it -- and fetches the verdict with nh_partition_transport_result. */
+/* (nh_partition_transport_check may re-size the message buffers: after an enqueue_only check call nh_partition_transport_result BEFORE the next exchange or check.
+   An RCCL call that fails makes the exchange return NH_ERR_HIP with the group closed; nh_last_hip_error then holds the ncclResult_t, negated.) */
 int nh_partition_set_transport(nh_partition* p, void* comm, void* group_start, void* group_end, void* send, void* recv, int left_peer, int right_peer);
 int nh_partition_exchange_step(nh_partition* p, const nh_BodyData* bodies);
 int nh_partition_transport_check(nh_partition* p, uint32_t bytes, int enqueue_only);

@@ -1206,9 +1206,20 @@ int nh_asleep_verify(nh_context* ctx, const nh_BodyData* bodies, const nh_Collid
 }
 
 // ... and the copies it compares with: this step's world AABBs and tags (the caller's arena still holds them), taken when the second all-asleep step in a row ends
+// (round-4 advisor finding: the copy used to be taken in finish_setup, inside nh_apply_impulses, out of nh_collide's scratch -- memory of the by-value arena that
+// nh_read_cached_impulses and nh_setup_contact_constraints had long handed out again; valid only because nothing happened to write there in a world asleep.  Now the
+// copy is enqueued by nh_collide itself, right behind k_xform, in the steps that can become the second of the streak; finish_setup only adopts it)
 int nh_asleep_remember(nh_context* ctx) {
 	nh_AsleepState& as = ctx->asleep;
+	if (!as.snap_C || as.snap_seq != ctx->collide_seq || as.snap_C != as.last_C) return 1;
+	as.C = as.snap_C;
+	return 0;
+}
+
+static int asleep_snapshot(nh_context* ctx) {
+	nh_AsleepState& as = ctx->asleep;
 	const uint32_t C = as.last_C;
+	as.snap_C = 0;
 	if (!C || !as.last_aabb_min) return 1;
 	if (as.capacity < C) {
 		void** bufs[] = { (void**)&as.aabb_min, (void**)&as.aabb_max, (void**)&as.tags };
@@ -1222,7 +1233,7 @@ int nh_asleep_remember(nh_context* ctx) {
 	NH_HIP_CHECK(ctx, hipMemcpyAsync(as.aabb_min, as.last_aabb_min, sizeof(float4) * (size_t)C, hipMemcpyDeviceToDevice, ctx->stream));
 	NH_HIP_CHECK(ctx, hipMemcpyAsync(as.aabb_max, as.last_aabb_max, sizeof(float4) * (size_t)C, hipMemcpyDeviceToDevice, ctx->stream));
 	NH_HIP_CHECK(ctx, hipMemcpyAsync(as.tags, as.last_ctag, sizeof(uint32_t) * (size_t)C, hipMemcpyDeviceToDevice, ctx->stream));
-	as.C = C;
+	as.snap_C = C; as.snap_seq = ctx->collide_seq;
 	return 0;
 }
 
@@ -1835,6 +1846,8 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 		          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
 		          xf, aabb_min, aabb_max, ctag, (uint4*)nullptr, 0u, ctx->fat_box, bp_direct ? 1u : 0u,
 		          incremental ? ctx->fat_gen : (uint8_t*)nullptr, ctx->fat_esc_mark, ctx->fat_esc_list, ctx->fat_moved_list, ctx->collide_seq);
+		// (asleep steps, nh_internal.h: this step may turn out to be the second fixed point in a row -- its boxes and tags are kept while they are still where k_xform put them)
+		if (ctx->asleep.streak >= 1u && !ctx->asleep.disabled) (void)asleep_snapshot(ctx);
 		// Morton frame; and the decision whether the grid chain below runs this step or the kept pair list is re-used (its kernels are launched
 		// either way: the decision is made on the device, and a kernel that leaves at once costs two microseconds)
 		NH_LAUNCH(ctx, "grid_setup", k_grid_setup, 1, 64, st, C, max_cells, bp_direct ? 1u : 0u, ctx->fat_pair_capacity);

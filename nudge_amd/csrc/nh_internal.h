@@ -190,6 +190,7 @@ struct nh_StillStep {
 	bool pipelined;                 // inside nh_step
 	struct { bool pending; uint32_t seq, parity; int slot; uint64_t collide_mark; } verdict;      // the still step whose counters the host has not looked at yet
 	nh_DevState* h_ring[2]; hipEvent_t ev_ring[2];      // pinned landing places of the counter copies, and when they have landed
+	bool ring_failed;                                    // ... could not be created: nh_step looks at every verdict inside its step
 	nh_ContactConstraintData* setup_d;      // its nh_setup_contact_constraints has run (without the adjacency kernel the replay then owes)
 	// the arguments of its nh_collide, for the replay; and the arrays the kept layout belongs to (another world in the same context: not still)
 	nh_ActiveBodies* active_out; nh_ContactData* contacts_out; nh_BodyData bodies; nh_ColliderData colliders; nh_BodyConnections connections; bool has_connections; nh_Arena temporary;
@@ -221,6 +222,7 @@ struct nh_AsleepState {
 	uint32_t prev_pairs, prev_sleeping, prev_cache;
 	float4 *aabb_min, *aabb_max; uint32_t* tags; uint32_t capacity;          // library-owned copies (world AABBs and tags of the step that made the streak 2)
 	uint32_t C, B;                   // colliders / bodies of that step
+	uint32_t snap_C, snap_seq;       // what the copies hold right now: colliders and the nh_collide call (collide_seq) they were taken in (0: nothing)
 	const float4 *last_aabb_min, *last_aabb_max; const uint32_t* last_ctag; uint32_t last_C;     // this step's arrays in the caller's arena (nh_collide)
 	uint64_t steps;                  // statistics
 };

@@ -45,6 +45,9 @@ struct nh_partition {
 	struct { void* comm; int (*group_start)(void); int (*group_end)(void);
 	         int (*send)(const void*, size_t, int, int, void*, hipStream_t); int (*recv)(void*, size_t, int, int, void*, hipStream_t); int peer[2]; } rccl;
 	void* step_out[2]; void* step_in[2]; uint32_t step_cap[2][2];      // message buffers of the per-step halo, [side][out / in], grown at refreshes
+	// the ghost margin of a cut covers how far bodies on BOTH its sides travel in an epoch: this rank's top speed before migration (nh_partition_top_speed) and what
+	// the two neighbours reported (nh_partition_set_peer_speeds); consumed by the next nh_partition_pack_ghosts
+	double speed_pre, peer_speed[2];
 };
 
 #define NP_CHECK(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (ctx)->last_hip_error = (int)e_; return NH_ERR_HIP; } } while (0)
@@ -177,19 +180,23 @@ __global__ __launch_bounds__(256) void k_part_vmax(uint32_t n, const nh_BodyMome
 }
 
 // ... who can reach across a cut within the coming epoch: distance to the cut < reach + max reach of anybody + 2 x (how far anything travels in an epoch)
+// (`2 x drift` bounds the approach of the TWO bodies of a pair across the cut, so the speed must be the top speed on both sides of THAT cut: this rank's -- now, and
+// before this refresh's migration took its fastest body away -- and the neighbour's, which the host hands in (speed_left / speed_right; round-4 advisor finding: with
+// this rank's own speed only, a fast body owned by the neighbour reached a slow body here that nobody had listed for it, and tunnelled through until the next refresh))
 __global__ __launch_bounds__(256) void k_part_flag_ghosts(uint32_t n, const nh_Transform* __restrict__ bt, const float* __restrict__ reach, float lo, float hi, uint32_t has_left, uint32_t has_right,
                                                           double max_reach, double epoch_dt, double speed_floor, double gravity_epoch_dt, const nh_PartDev* __restrict__ dv,
-                                                          uint32_t* __restrict__ fl, uint32_t* __restrict__ fr) {
-	const double vmax = (double)__uint_as_float(dv->vmax_bits);
-	const double drift = epoch_dt * ((vmax > speed_floor ? vmax : speed_floor) + gravity_epoch_dt);
-	const float extra = (float)(max_reach + 2.0 * drift);
+                                                          uint32_t* __restrict__ fl, uint32_t* __restrict__ fr, double speed_pre, double speed_left, double speed_right) {
+	double own = (double)__uint_as_float(dv->vmax_bits);
+	if (speed_pre > own) own = speed_pre;
+	if (speed_floor > own) own = speed_floor;
+	const double vl = speed_left > own ? speed_left : own, vr = speed_right > own ? speed_right : own;
+	const float extra_l = (float)(max_reach + 2.0 * epoch_dt * (vl + gravity_epoch_dt)), extra_r = (float)(max_reach + 2.0 * epoch_dt * (vr + gravity_epoch_dt));
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += gridDim.x * blockDim.x) {
 		uint32_t l = 0u, r = 0u;
 		if (i >= 1u && i < n) {
 			const float x = bt[i].position[0];
-			const float margin = reach[i] + extra;
-			l = (has_left && x - margin < lo) ? 1u : 0u;
-			r = (has_right && x + margin >= hi) ? 1u : 0u;
+			l = (has_left && x - (reach[i] + extra_l) < lo) ? 1u : 0u;
+			r = (has_right && x + (reach[i] + extra_r) >= hi) ? 1u : 0u;
 		}
 		fl[i] = l; fr[i] = r;
 	}
@@ -355,6 +362,31 @@ extern "C" int nh_partition_unpack_migrants(nh_partition* p, const nh_BodyData* 
 	return NH_OK;
 }
 
+// Top speed of the bodies this rank owns NOW (call it before nh_partition_pack_migrants): one kernel and the call's host synchronisation.  The host sends the value to
+// both neighbours (with the migrant counts, say) and hands theirs to nh_partition_set_peer_speeds before nh_partition_pack_ghosts.
+extern "C" int nh_partition_top_speed(nh_partition* p, const nh_BodyData* bodies, double* out) {
+	if (!p || !bodies || !out) return NH_ERR_INVALID;
+	nh_context* ctx = p->ctx;
+	NP_CHECK(ctx, hipSetDevice(ctx->device));
+	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	const uint32_t n = p->n_owned + 1u;
+	NH_LAUNCH(ctx, "part_reset", k_part_reset, 1, 1, p->d);
+	NH_LAUNCH(ctx, "part_vmax", k_part_vmax, nh_grid_for(n, 256, 1024), 256, n, bodies->momentum, p->d);
+	int rc = part_read_back(p);
+	if (rc) return rc;
+	float v; memcpy(&v, &p->h->vmax_bits, sizeof(v));
+	p->speed_pre = (double)v;
+	*out = p->speed_pre;
+	return NH_OK;
+}
+
+extern "C" int nh_partition_set_peer_speeds(nh_partition* p, double left, double right) {
+	if (!p) return NH_ERR_INVALID;
+	p->peer_speed[0] = left == left && left > 0.0 ? left : 0.0;          // (NaN / negative: no neighbour, or none reported)
+	p->peer_speed[1] = right == right && right > 0.0 ? right : 0.0;
+	return NH_OK;
+}
+
 extern "C" int nh_partition_pack_ghosts(nh_partition* p, const nh_BodyData* bodies, void* out_left, void* out_right, uint32_t capacity_records, uint32_t counts[2]) {
 	if (!p || !bodies || !counts) return NH_ERR_INVALID;
 	nh_context* ctx = p->ctx;
@@ -366,7 +398,8 @@ extern "C" int nh_partition_pack_ghosts(nh_partition* p, const nh_BodyData* bodi
 	NH_LAUNCH(ctx, "part_reset", k_part_reset, 1, 1, p->d);
 	NH_LAUNCH(ctx, "part_vmax", k_part_vmax, nh_grid_for(n, 256, 1024), 256, n, bodies->momentum, p->d);
 	NP_LAUNCH("part_flag_ghosts", k_part_flag_ghosts, n, n, bodies->transforms, p->reach, (float)p->lo, (float)p->hi, has_left ? 1u : 0u, has_right ? 1u : 0u,
-	          p->cfg.max_reach, epoch_dt, p->cfg.speed_floor, fabs(p->cfg.gravity) * epoch_dt, p->d, p->flag[0], p->flag[1]);
+	          p->cfg.max_reach, epoch_dt, p->cfg.speed_floor, fabs(p->cfg.gravity) * epoch_dt, p->d, p->flag[0], p->flag[1], p->speed_pre, p->peer_speed[0], p->peer_speed[1]);
+	p->speed_pre = 0.0; p->peer_speed[0] = p->peer_speed[1] = 0.0;          // (consumed: the next refresh measures and exchanges again)
 	nh_scan2_u32(ctx, p->flag[0], p->flag[0], &p->d->count[0], p->flag[1], p->flag[1], &p->d->count[1], &p->d->zero, n + 1u, p->scan_tmp);
 	NP_LAUNCH("part_pack_full", k_part_pack_full, n, n, p->flag[0], p->flag[1], capacity_records, bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters,
 	          part_cols(p), (nh_FullRecord*)out_left, (nh_FullRecord*)out_right, p->list[0], p->list[1], p->d);
@@ -501,14 +534,18 @@ extern "C" int nh_partition_exchange_step(nh_partition* p, const nh_BodyData* bo
 		if (p->ghost_in[side]) { int rc = part_step_buffer(p, side, 1, p->ghost_in[side]); if (rc) return rc; }
 	}
 	{ int rc = nh_partition_pack_step(p, bodies, p->step_out[0], p->step_out[1]); if (rc) return rc; }
-	if (p->rccl.group_start()) return NH_ERR_HIP;
-	for (int side = 0; side < 2; ++side) {
+	// (an error inside the group still closes it: a group left open on this thread would swallow every later collective of the communicator; the first RCCL result
+	// that was not ncclSuccess is kept in nh_last_hip_error, negated so that it cannot be taken for a hipError_t)
+	int nccl_rc = p->rccl.group_start();
+	if (nccl_rc) { ctx->last_hip_error = -nccl_rc; return NH_ERR_HIP; }
+	for (int side = 0; side < 2 && !nccl_rc; ++side) {
 		const int peer = p->rccl.peer[side];
 		if (peer < 0) continue;
-		if (p->ghost_out[side] && p->rccl.send(p->step_out[side], (size_t)p->ghost_out[side] * NH_HALO_RECORD_BYTES, 1 /* ncclUint8 */, peer, p->rccl.comm, ctx->stream)) return NH_ERR_HIP;
-		if (p->ghost_in[side] && p->rccl.recv(p->step_in[side], (size_t)p->ghost_in[side] * NH_HALO_RECORD_BYTES, 1, peer, p->rccl.comm, ctx->stream)) return NH_ERR_HIP;
+		if (p->ghost_out[side]) nccl_rc = p->rccl.send(p->step_out[side], (size_t)p->ghost_out[side] * NH_HALO_RECORD_BYTES, 1 /* ncclUint8 */, peer, p->rccl.comm, ctx->stream);
+		if (!nccl_rc && p->ghost_in[side]) nccl_rc = p->rccl.recv(p->step_in[side], (size_t)p->ghost_in[side] * NH_HALO_RECORD_BYTES, 1, peer, p->rccl.comm, ctx->stream);
 	}
-	if (p->rccl.group_end()) return NH_ERR_HIP;
+	{ const int end_rc = p->rccl.group_end(); if (!nccl_rc) nccl_rc = end_rc; }
+	if (nccl_rc) { ctx->last_hip_error = -nccl_rc; return NH_ERR_HIP; }
 	return nh_partition_unpack_step(p, bodies, p->step_in[0], p->step_in[1]);
 }
 
@@ -528,12 +565,14 @@ extern "C" int nh_partition_transport_check(nh_partition* p, uint32_t bytes, int
 	hipLaunchKernelGGL(k_part_reset, dim3(1), dim3(1), 0, ctx->stream, p->d);
 	for (int side = 0; side < 2; ++side) if (p->rccl.peer[side] >= 0)
 		hipLaunchKernelGGL(k_part_pattern, dim3(64), dim3(256), 0, ctx->stream, (uint32_t*)p->step_out[side], words, p->cfg.rank);
-	if (p->rccl.group_start()) return NH_ERR_HIP;
-	for (int side = 0; side < 2; ++side) if (p->rccl.peer[side] >= 0) {
-		if (p->rccl.send(p->step_out[side], (size_t)words * 4u, 1, p->rccl.peer[side], p->rccl.comm, ctx->stream)) return NH_ERR_HIP;
-		if (p->rccl.recv(p->step_in[side], (size_t)words * 4u, 1, p->rccl.peer[side], p->rccl.comm, ctx->stream)) return NH_ERR_HIP;
+	int nccl_rc = p->rccl.group_start();
+	if (nccl_rc) { ctx->last_hip_error = -nccl_rc; return NH_ERR_HIP; }
+	for (int side = 0; side < 2 && !nccl_rc; ++side) if (p->rccl.peer[side] >= 0) {
+		nccl_rc = p->rccl.send(p->step_out[side], (size_t)words * 4u, 1, p->rccl.peer[side], p->rccl.comm, ctx->stream);
+		if (!nccl_rc) nccl_rc = p->rccl.recv(p->step_in[side], (size_t)words * 4u, 1, p->rccl.peer[side], p->rccl.comm, ctx->stream);
 	}
-	if (p->rccl.group_end()) return NH_ERR_HIP;
+	{ const int end_rc = p->rccl.group_end(); if (!nccl_rc) nccl_rc = end_rc; }          // (closed whatever happened inside: see nh_partition_exchange_step)
+	if (nccl_rc) { ctx->last_hip_error = -nccl_rc; return NH_ERR_HIP; }
 	for (int side = 0; side < 2; ++side) if (p->rccl.peer[side] >= 0)
 		hipLaunchKernelGGL(k_part_pattern_check, dim3(64), dim3(256), 0, ctx->stream, (const uint32_t*)p->step_in[side], words, (uint32_t)p->rccl.peer[side], p->d);
 	if (enqueue_only) return NH_OK;            // (the caller polls the stream and then calls nh_partition_transport_result)

@@ -3047,10 +3047,17 @@ extern "C" int nh_step(nh_context* ctx, const nh_StepArgs* a, uint32_t steps) {
 	if (!ctx || !a || !a->active_bodies || !a->contacts || !a->bodies || !a->colliders || !a->contact_cache) return NH_ERR_INVALID;
 	NH_HIP_CHECK(ctx, hipSetDevice(ctx->device));
 	nh_StillStep& ss = ctx->still;
-	if (!ss.h_ring[0]) {
+	if (!ss.h_ring[0] && !ss.ring_failed) {
 		for (int k = 0; k < 2; ++k) {
-			if (hipHostMalloc((void**)&ss.h_ring[k], sizeof(nh_DevState), 0) != hipSuccess || hipEventCreateWithFlags(&ss.ev_ring[k], hipEventDisableTiming) != hipSuccess) { ss.h_ring[0] = nullptr; break; }
+			if (hipHostMalloc((void**)&ss.h_ring[k], sizeof(nh_DevState), 0) != hipSuccess || hipEventCreateWithFlags(&ss.ev_ring[k], hipEventDisableTiming) != hipSuccess) { ss.ring_failed = true; break; }
 			memset(ss.h_ring[k], 0, sizeof(nh_DevState));
+		}
+		if (ss.ring_failed) {
+			// whatever was created goes back, both slots end empty, and the loop runs with the verdict inside every step from now on (no retry per call)
+			for (int k = 0; k < 2; ++k) {
+				if (ss.h_ring[k]) { (void)hipHostFree(ss.h_ring[k]); ss.h_ring[k] = nullptr; }
+				if (ss.ev_ring[k]) { (void)hipEventDestroy(ss.ev_ring[k]); ss.ev_ring[k] = nullptr; }
+			}
 		}
 	}
 	ss.pipelined = ss.h_ring[0] != nullptr && (ctx->flags & NH_FLAG_FUSED_STEP) && !(ctx->flags & (NH_FLAG_SYNC_COUNTS | NH_FLAG_EXACT_ORDER)) && !ss.disabled && !ctx->timing;

@@ -429,6 +429,32 @@ class Partition:
                     else: self.hi = cut
                     self.stats["cut_moves"] += 1
 
+    # ---- refresh: top speeds across the cuts ---------------------------------------------------------------------
+    # A cut's ghost margin is reach + 2 x drift: the two bodies of a cross-cut pair approach each other from BOTH sides, so the drift must come from the top speed on
+    # both sides of that cut -- mine (now: before this refresh's migration) and the neighbour's.  One 8-byte message per neighbour, like the body counts.
+    # (Round-4 advisor finding: with a rank's own top speed only, a fast body owned by the neighbour reached slow bodies here that this rank had never listed for it and
+    # tunnelled through them until the next refresh.  tests/test_partition_cpu.py::test_a_fast_body_from_the_neighbour_finds_its_ghosts)
+    def speed_pack(self):
+        t = self.torch
+        if self.hip is not None:
+            import ctypes as C
+            from . import engine as E
+            v = C.c_double(0.0)
+            E._check(self.e.L, self.e.L.nh_partition_top_speed(self.hip, C.byref(self.e.bodies), C.byref(v)), "nh_partition_top_speed")
+            self._speed_pre = float(v.value)
+        else:
+            n = self.n_owned + 1
+            self._speed_pre = float(self._f32(self.bm[:n])[1:, :3].norm(dim=1).max()) if n > 1 else 0.0
+        dev = self.bt.device
+        return {d: t.tensor([self._speed_pre], dtype=t.float64, device=dev).view(t.uint8).reshape(1, 8) for d in self.neighbours()}
+
+    def speed_unpack(self, incoming):
+        t = self.torch
+        self._peer_speed = {d: float(incoming[d].reshape(-1).view(t.float64)[0].item()) for d in self.neighbours() if d in incoming and incoming[d].numel()}
+        if self.hip is not None:
+            from . import engine as E
+            E._check(self.e.L, self.e.L.nh_partition_set_peer_speeds(self.hip, self._peer_speed.get(-1, 0.0), self._peer_speed.get(+1, 0.0)), "nh_partition_set_peer_speeds")
+
     # ---- refresh: phase 1 (migration) --------------------------------------------------------------------------
     def refresh_pack_migrants(self):
         if self.hip is not None:
@@ -486,12 +512,17 @@ class Partition:
         x = self._x(n)
         v = self._f32(self.bm[:n])[:, :3].norm(dim=1)
         vmax = float(v[1:].max()) if n > 1 else 0.0
-        # how far anything can travel in one epoch: current top speed + free-fall gain, never below the floor
-        drift = self.epoch * self.dt * (max(vmax, self.speed_floor) + self.gravity * self.epoch * self.dt)
-        margin = self.reach[:n] + (self.max_reach + 2.0 * drift)
+        # how far anything can travel in one epoch: top speed on BOTH sides of the cut (speed_pack / speed_unpack) + free-fall gain, never below the floor
+        own_speed = max(vmax, getattr(self, "_speed_pre", 0.0), self.speed_floor)
+        peers = getattr(self, "_peer_speed", {})
+        self._speed_pre, self._peer_speed = 0.0, {}
         own = t.arange(n, device=x.device) > 0
         out = {}
+        drift = 0.0
         for d in self.neighbours():
+            drift_d = self.epoch * self.dt * (max(own_speed, peers.get(d, 0.0)) + self.gravity * self.epoch * self.dt)
+            drift = max(drift, drift_d)
+            margin = self.reach[:n] + (self.max_reach + 2.0 * drift_d)
             m = own & ((x - margin < self.lo) if d < 0 else (x + margin >= self.hi))
             idx = t.nonzero(m).flatten()
             self.ghost_out[d] = idx
@@ -709,6 +740,9 @@ class LocalCluster:
                     ins = self._route([p.balance_pack_cuts() for p in self.parts])
                     for p, i in zip(self.parts, ins):
                         p.balance_unpack_cuts(i)
+                ins = self._route([p.speed_pack() for p in self.parts])
+                for p, i in zip(self.parts, ins):
+                    p.speed_unpack(i)
                 ins = self._route([p.refresh_pack_migrants() for p in self.parts])
                 for p, i in zip(self.parts, ins):
                     p.refresh_unpack_migrants(i)
@@ -935,6 +969,7 @@ class DistCluster:
         else:
             p.bt[1:1 + m, :12] = rec[:, :12]; p.bt[1:1 + m, 16:] = rec[:, 12:28]; p.bm[1:1 + m] = rec[:, 28:60]; p.bi[1:1 + m, 0] = rec[:, 60]
         self.loopback_records += m
+        self.loopback_steps = getattr(self, "loopback_steps", 0) + 1
 
     def _exchange(self, out, widths=None, known_counts=None):
         """Sends out[d] to rank+d and returns what the neighbours sent.  Counts are exchanged first unless known."""
@@ -969,13 +1004,20 @@ class DistCluster:
             ins = {d: r.to(home) for d, r in ins.items()}
         return ins
 
+    # host-side accounting for bench.py (wall time of the refreshes, their own synchronisations included; host time to ENQUEUE a per-step halo)
+    t_refresh = 0.0; n_refresh = 0; t_halo = 0.0; n_halo = 0
+
     def step(self, steps=1):
+        import time
         p = self.p
         for _ in range(steps):
-            if p.needs_refresh():
+            t_0 = time.perf_counter()
+            refreshing = p.needs_refresh()
+            if refreshing:
                 if p.rebalance and p.steps > 0:
                     p.balance_unpack_counts(self._exchange(p.balance_pack_counts(), 8, known_counts={d: 1 for d in p.neighbours()}))
                     p.balance_unpack_cuts(self._exchange(p.balance_pack_cuts(), 8, known_counts=p.balance_expected()))
+                p.speed_unpack(self._exchange(p.speed_pack(), 8, known_counts={d: 1 for d in p.neighbours()}))
                 p.refresh_unpack_migrants(self._exchange(p.refresh_pack_migrants(), FULL_BYTES))
                 p.refresh_unpack_ghosts(self._exchange(p.refresh_pack_ghosts(), FULL_BYTES))
             elif self.direct:
@@ -987,6 +1029,10 @@ class DistCluster:
                 self._fast_step_exchange()
             else:
                 p.step_unpack(self._exchange(p.step_pack(), STEP_BYTES, known_counts={d: p.ghost_in[d] for d in p.neighbours()}))
+            if refreshing:
+                self.t_refresh += time.perf_counter() - t_0; self.n_refresh += 1
+            else:
+                self.t_halo += time.perf_counter() - t_0; self.n_halo += 1
             if self.loopback:
                 self._loopback()
             if p.per_iteration:

@@ -143,6 +143,36 @@ def test_union_the_reference_can_hold_is_bit_exact_in_the_bench_mode(spheres):
     w.close()
 
 
+def test_c2_exact_order_equals_bench_flags_at_size():
+    """Pins the CLOSED-FORM solver order at the size the metric is quoted on.  The bench runs the default order -- batch(i) = (i >> 7) * 16 + (i & 15),
+    what the reference's greedy scheduler (nudge.cpp:4206-4339) produces when it meets no lane conflict.  NH_FLAG_EXACT_ORDER checks every step for a conflict and
+    replays the scheduler if there is one.  1,004,400 boxes, 300 steps -- free fall, landing, rest -- in the bench's flags and under NH_FLAG_EXACT_ORDER: the same bits
+    (bodies, idle counters, contacts, cache), nothing on the general path.  What remains un-pinned at size is then ONLY the reference's own union-versus-tile effect
+    (the bars above)."""
+    scene = S.grid_tiles(124, side=90, seed=2, lattice_cols=11)
+    n = len(scene["body_transforms"]) - 1
+    assert n == 1004400
+    a = E.World(scene, flags=BENCH_FLAGS, max_contacts=6 * n)
+    b = E.World(scene, flags=E.NH_FLAG_EXACT_ORDER, max_contacts=6 * n)
+    done = 0
+    for cp in (40, 70, 150, 300):
+        a.step(cp - done); b.step(cp - done); done = cp
+        ba, bb = a.get_bodies(), b.get_bodies()
+        assert P.bits_equal(ba["transforms"], bb["transforms"]) and P.bits_equal(ba["momentum"], bb["momentum"]) and np.array_equal(ba["idle"], bb["idle"]), f"step {cp}: bodies differ"
+        ca, cb = a.counts(), b.counts()
+        assert ca["error"] == 0 and cb["error"] == 0
+        assert ca["general_contacts"] == 0 and cb["general_contacts"] == 0, (ca["general_contacts"], cb["general_contacts"])
+        assert ca["contacts"] == cb["contacts"]
+    ka, kb = a.get_contacts(), b.get_contacts()
+    assert np.array_equal(ka["tags"], kb["tags"]) and np.array_equal(ka["features"], kb["features"]) and P.bits_equal(ka["data"], kb["data"])
+    xa, xb = a.get_cache(), b.get_cache()
+    assert xa["count"] == xb["count"] and np.array_equal(xa["tags"], xb["tags"]) and np.array_equal(xa["features"], xb["features"])
+    # (the cached impulse's fourth word: zero under NH_FLAG_EXACT_ORDER, the colour of the last sweep in default order -- include/nudge_hip.h; the impulses are the bits)
+    assert P.bits_equal(xa["data"]["impulse"], xb["data"]["impulse"])
+    assert a.counts()["still_steps"] > 150          # (the bench's flags went through the still regime on the way)
+    a.close(); b.close()
+
+
 def test_c2_landed_window_properties():
     """The window the bench times: every box rests on 4 face contacts, everybody awake, nothing on the general path, two runs agree
     bit for bit."""

@@ -457,3 +457,38 @@ def test_compound_bodies_travel_across_the_cut_with_all_their_colliders():
     assert np.isfinite(got["transforms"]["position"]).all()
     # landed on each other across the cut: contacts that cross it are solved on both ranks (the overlapping-subdomain sweep of the module docstring): close, not equal
     assert P.rel_err(got["transforms"]["position"], ref["transforms"]["position"][1:]).max() <= 5e-2
+
+
+def test_a_fast_body_from_the_neighbour_finds_its_ghosts():
+    """Round-4 advisor finding.  The ghost margin of a cut is reach + 2 x (how far anything travels in an epoch); each rank used to take "anything" from ITS OWN bodies.
+    A projectile owned by the left rank (60 units/s, the floor is 0.5) flies along an empty lane towards a box at rest 8 units behind the cut: the right rank -- whose own
+    bodies are at rest -- listed only what lay within 5 units of the cut, so the left rank never saw the box, built no contact, and its projectile went through.  Now the
+    ranks at a cut tell each other their top speeds (speed_pack / speed_unpack; nh_partition_top_speed / nh_partition_set_peer_speeds behind the C ABI)."""
+    import partition_util as PU
+    scene = _drop_scene(side=12)
+    scene["params"] = dict(scene["params"], gravity=0.0)                      # nothing falls: everybody floats at rest where it starts
+    pos = scene["body_transforms"]["position"]
+    x, z = pos[1:, 0], pos[1:, 2]
+    cut = float(np.quantile(x, 0.5)) + 0.37
+    lane = float(z.min()) - 6.0                                                # an empty lane beside the lattice
+    proj = 1 + int(np.argmin(x))                                               # a body of the left rank ...
+    targ = 1 + int(np.argmax(x))                                               # ... and one of the right rank
+    y = float(pos[proj, 1])
+    pos[proj] = (cut - 20.0, y, lane)
+    pos[targ] = (cut + 8.0, y, lane)
+    scene["body_momentum"]["velocity"][proj] = (60.0, 0.0, 0.0)
+    parts = []
+    for r in range(2):
+        local, info = PT.split_scene(scene, [cut], r, min_extra=512)
+        parts.append(PT.Partition(PU.OracleEngine(local, info["capacity"]), info, epoch=32, speed_floor=0.5, rebalance=False))
+    cl = PT.LocalCluster(parts)
+    steps = 80                                                                 # impact around step 52: in the second epoch, before the projectile changes owner
+    cl.step(steps)
+    got, ref = cl.gather(), PU.single_world_reference(scene, steps)
+    gp, rp = got["transforms"]["position"], ref["transforms"]["position"][got["ids"]]
+    ip, it = int(np.flatnonzero(got["ids"] == proj)[0]), int(np.flatnonzero(got["ids"] == targ)[0])
+    free_flight = cut - 20.0 + 60.0 * steps / 120.0
+    assert rp[ip, 0] < free_flight - 3.0, "the scene is meant to have the projectile hit the target"
+    # (a contact between an owned body and a ghost is solved on both ranks and the owner's result survives: close to the single world, not bit-identical)
+    assert abs(gp[ip, 0] - rp[ip, 0]) < 0.5 and abs(gp[it, 0] - rp[it, 0]) < 0.5, (gp[ip], rp[ip], gp[it], rp[it], free_flight)
+    assert np.abs(gp - rp).max() < 0.5
