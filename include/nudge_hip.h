@@ -217,7 +217,7 @@ int nh_read_counts(nh_context* ctx, nh_Counts* out);        /* synchronises the 
    features in tag order, NH_VIEW_CACHE = the nh_ContactCache arrays (tags, features, data; nh_Counts.cache).  A no-op (two host-side flag tests) when the arrays
    are current -- after a full step they always are.  Replaces the reference's implicit guarantee that both arrays are current when collide() /
    write_cached_impulses() return (nudge.cpp:4009, 4158) for callers that read them from the device themselves. */
-enum { NH_VIEW_CONTACTS = 1u, NH_VIEW_CACHE = 2u, NH_VIEW_ALL = 3u };
+enum { NH_VIEW_CONTACTS = 1u /* + contacts->sleeping_pairs */, NH_VIEW_CACHE = 2u, NH_VIEW_ACTIVE = 4u /* active_bodies->indices */, NH_VIEW_ALL = 7u };
 int nh_export_views(nh_context* ctx, uint32_t what);
 int nh_set_cache_count(nh_context* ctx, uint32_t count);    /* restore a checkpointed ContactCache */
 /* Tell the library that the caller has written `idle_counters` itself (initial upload excepted: a fresh context assumes nothing).  The

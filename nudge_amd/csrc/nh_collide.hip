@@ -35,9 +35,12 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
                                                nh_xform* __restrict__ xf, float4* __restrict__ aabb_min, float4* __restrict__ aabb_max, uint32_t* __restrict__ ctag,
                                                uint4* __restrict__ zero16, uint32_t zero16_count, float4* fat_box, uint32_t direct,
                                                uint8_t* __restrict__ gen, uint32_t* __restrict__ esc_mark, uint32_t* __restrict__ esc_list, uint32_t* __restrict__ moved_list, uint32_t seq,
-                                               const uint8_t* __restrict__ idle = nullptr, uint32_t nbodies = 0u, uint32_t parity = 0u) {
+                                               const uint8_t* __restrict__ idle = nullptr, uint32_t nbodies = 0u, uint32_t parity = 0u, uint8_t* __restrict__ awake_out = nullptr) {
+	// `awake_out` (STILL): SLEEPERS form (nh_internal.h) -- a body asleep does not fail the step; it is counted, noted (awake_out[i]: the active list is a view of it) and
+	// its colliders carry the mark in aabb_max.w, where the still narrowphase finds it without another memory round trip
 	__shared__ uint32_t hist[STILL ? 1 : 1024];
 	__shared__ uint32_t red[12];
+	__shared__ uint32_t s_asleep;
 	if (!STILL) hist[threadIdx.x] = 0;
 	if (threadIdx.x < 3) { red[threadIdx.x] = 0xffffffffu; red[3 + threadIdx.x] = 0u; red[6 + threadIdx.x] = 0xffffffffu; red[9 + threadIdx.x] = 0u; }
 	__syncthreads();
@@ -55,18 +58,25 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 	bool escaped = STILL && !fat_valid;
 	if (STILL) {
 		// the per-body part of k_collide_begin: nobody may be asleep (the host has ruled it out; checked), the largest idle counter for its next prediction
-		uint32_t top = 0;
-		for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x + 1u; i < nbodies; i += gridDim.x * blockDim.x) { const uint32_t cnt = idle[i]; top = max(top, cnt); escaped |= cnt == 0xffu; }
-		for (int d = 32; d >= 1; d >>= 1) top = max(top, (uint32_t)__shfl_xor((int)top, d));
-		if (threadIdx.x < 64u) red[0] = 0u;          // (reused below after the barrier; here: the workgroup's largest counter)
+		uint32_t top = 0, nas = 0;
+		for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x + 1u; i < nbodies; i += gridDim.x * blockDim.x) {
+			const uint32_t cnt = idle[i]; top = max(top, cnt);
+			if (awake_out) { awake_out[i] = cnt == 0xffu ? (uint8_t)0 : (uint8_t)1; nas += cnt == 0xffu ? 1u : 0u; }
+			else escaped |= cnt == 0xffu;
+		}
+		for (int d = 32; d >= 1; d >>= 1) { top = max(top, (uint32_t)__shfl_xor((int)top, d)); nas += (uint32_t)__shfl_xor((int)nas, d); }
+		if (threadIdx.x < 64u) { red[0] = 0u; s_asleep = 0u; }          // (red[0] reused below after the barrier; here: the workgroup's largest counter)
 		__syncthreads();
 		if (nh_lane() == 0 && top) atomicMax(&red[0], top);
+		if (nh_lane() == 0 && nas) atomicAdd(&s_asleep, nas);
 		__syncthreads();
 		if (threadIdx.x == 0) {
 			if (red[0]) atomicMax(&st->max_idle[parity], red[0]);
+			if (s_asleep) atomicAdd(&st->still_asleep[parity], s_asleep);
 			if (blockIdx.x == 0) {
 				// what the NEXT step (the other parity) accumulates into: nobody touches it during this one
 				st->max_idle[parity ^ 1u] = 0u; st->delta_count[parity ^ 1u] = 0u; st->delta_overflow[parity ^ 1u] = 0u; st->still_esc[parity ^ 1u] = 0u;
+				st->still_asleep[parity ^ 1u] = 0u; st->still_sleeping[parity ^ 1u] = 0u; st->still_culled[parity ^ 1u] = 0u;
 				for (int k = 0; k < 3; ++k) { st->still_smin[parity ^ 1u][k] = 0xffffffffu; st->still_smax[parity ^ 1u][k] = 0u; }
 				st->still_fat0 = st->fat_count + st->fat_count_sph;          // (nobody appends to the kept list while this kernel runs: k_reinsert's verdict needs a value that stands still)
 			}
@@ -106,7 +116,9 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 		float ext = fmaxf(fmaxf(mxx - mnx, mxy - mny), mxz - mnz);
 		xf[c] = w;
 		aabb_min[c] = make_float4(mnx, mny, mnz, __uint_as_float(l.body));
-		aabb_max[c] = make_float4(mxx, mxy, mxz, ext);
+		// (STILL: nobody reads the extent; the fourth word says whether the collider's body is asleep -- sleepers form)
+		if (STILL) aabb_max[c] = make_float4(mxx, mxy, mxz, __uint_as_float((awake_out && l.body && idle[l.body] == 0xffu) ? 1u : 0u));
+		else aabb_max[c] = make_float4(mxx, mxy, mxz, ext);
 		// the inflated box a rebuild would sort and search (k_cell_keys writes it then): the grid's statistics (size class, bounds of the small
 		// ones) are taken from it; the Morton frame (lmin / lmax) is the exact AABBs' (nudge.cpp:3086-3100)
 		const float fx0 = mnx - margin, fy0 = mny - margin, fz0 = mnz - margin, fx1 = mxx + margin, fy1 = mxy + margin, fz1 = mxz + margin;
@@ -896,7 +908,9 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
                                                      // STILL only: the kept list (`pairs`) and its capacity, this step's exact AABBs, the stamps, tag-order positions / counts, the bodies' records
                                                      uint32_t kept_cap = 0u, const float4* __restrict__ aabb_min = nullptr, const float4* __restrict__ aabb_max = nullptr,
                                                      const uint8_t* __restrict__ gen = nullptr, const uint32_t* __restrict__ lay_rank = nullptr, uint32_t* __restrict__ cnt_sorted = nullptr,
-                                                     const uint32_t* __restrict__ body_rec = nullptr, uint32_t seq = 0u, int2* __restrict__ delta = nullptr, uint32_t delta_scan = 0u) {
+                                                     const uint32_t* __restrict__ body_rec = nullptr, uint32_t seq = 0u, int2* __restrict__ delta = nullptr, uint32_t delta_scan = 0u,
+                                                     // STILL, sleepers form (nh_internal.h): the slot cache's per-record counts (entries kept aside for a sleeping pair); nullptr = nobody can be asleep
+                                                     uint32_t* __restrict__ sc_count = nullptr) {
 	// coarse islands (nudge.cpp:3500-3703): a pair whose bodies belong to a set of sleeping bodies (sets over the BROADPHASE pairs and the
 	// user's connections) never reaches the narrowphase: it becomes a sleeping pair, larger tag in the low half (3697)
 	const bool some_asleep = !STILL && st->any_idle[parity] != 0;
@@ -938,7 +952,17 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 	// sort re-use (nh_collide): `rec_key` is the context's buffer of keys by record position, still holding last step's -- is every key what it was?
 	bool changed = false;
 	// STILL: what the step relies on, per record (see above); the count goes to the record's place in the tag order
-	auto still_record = [&](uint32_t ri, uint64_t key, int count, uint32_t body_a, uint32_t body_b, uint64_t was_key, uint32_t pos, bool vanished) {
+	uint32_t n_sleeping = 0, n_culled = 0;          // sleepers form: this lane's sleeping pairs and the cache entries kept aside for them
+	auto still_record = [&](uint32_t ri, uint64_t key, int count, uint32_t body_a, uint32_t body_b, uint64_t was_key, uint32_t pos, bool vanished, bool sleeping = false) {
+		if (sleeping) {
+			// A pair of a sleeping body with the static world: a sleeping pair (nudge.cpp:3669-3703) -- no contact, the pair's word (`key`: larger tag low, 3697) in the
+			// list of sleeping pairs, and its cached impulses kept aside (4064-4101) when the cache's tag -- the contact key on file -- IS that word; otherwise they are
+			// gone, as in the reference.  From now on the record carries the pair's word (the tag order on file no longer matches the keys: a full step sorts again).
+			vanished = true; count = 0;
+			if (was_key != key) { if (sc_count[ri]) sc_count[ri] = 0u; rec_key[ri] = key; st->sort_valid = 0u; }
+			else n_culled += min(sc_count[ri], 4u);
+			n_sleeping += 1u;
+		}
 		// (`vanished`: the kept pair is dead -- a collider of it has been re-boxed since, stamps -- or its exact boxes do not overlap this step: a record without
 		// contacts wherever the full step's sort would put it, so its old place serves; the key it had stays on file, and if the pair overlaps again with that key
 		// it is the same record in the same place)
@@ -949,7 +973,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			ok = (body_a == 0u) != (body_b == 0u) && (body_rec[dyn] & ~NH_BODY_REC_IS_A) == ri;
 		}
 		if (!ok) { atomicAdd(&st->still_diff[!same_key ? 0 : (count > 4 ? 1 : 2)], 1u); changed = true; }          // (statistics; rare)
-		rec[ri].count = (uint32_t)count;
+		rec[ri].count = sleeping ? NH_REC_SLEEPING : (uint32_t)count;
 		// the record's count in its place of the tag order; a CHANGE is listed (position, difference): the solver lanes shift their first contact by the changes before
 		// them -- a handful per step in a world at rest -- instead of the whole order being scanned again.  Too many for the list: the step fails (delta_overflow)
 		const uint32_t old = cnt_sorted[pos];
@@ -973,7 +997,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		uint32_t body_a = 0, body_b = 0;
 		bool asleep = false;
 		const uint32_t ri = first_rec + i;        // record index
-		bool invalid = false;
+		bool invalid = false, sleeper_pair = false;
 		// STILL: everything a pair needs goes out in ONE round trip behind the pair itself -- both boxes, both world transforms, shapes and tags, the record's old key and
 		// tag-order position -- and which of the two is "a" is a register select afterwards (fetching the transforms only once the roles were known, and the key and the
 		// position only when the contacts were done, made four dependent round trips of it)
@@ -998,6 +1022,12 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 				if (live) { const uint64_t pk = rec_key[ri]; s_pre[0][threadIdx.x] = (uint32_t)pk; s_pre[1][threadIdx.x] = (uint32_t)(pk >> 32); s_pre[2][threadIdx.x] = lay_rank[ri]; }
 				bool hit = aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != __float_as_uint(amin.w));
 				if (stamps && hit) hit = (uint32_t)(gen[ca] & 0x7Fu) == (kp.x >> NH_GEN_SHIFT) && (uint32_t)(gen[cb] & 0x7Fu) == (kp.y >> NH_GEN_SHIFT);
+				// sleepers form: k_xform<true> marked the colliders of sleeping bodies (aabb_max.w).  With the static world: a sleeping pair.  Two dynamic bodies with a
+				// sleeping end, or a pair nobody has a record for: the body's set holds more than itself -- not this step's business
+				if (sc_count && hit && (__float_as_uint(amax.w) | __float_as_uint(bmax.w)) != 0u) {
+					if (app || (__float_as_uint(amin.w) != 0u && __float_as_uint(bmin.w) != 0u)) { changed = true; atomicAdd(&st->still_diff[3], 1u); }
+					else sleeper_pair = true;
+				}
 				const uint64_t ka = nh_morton_of(nh_make3(amin.x, amin.y, amin.z), mscale, mmin), kb = nh_morton_of(nh_make3(bmin.x, bmin.y, bmin.z), mscale, mmin);
 				const bool a_first = (ka < kb) || (ka == kb && ca < cb);
 				pr = hit ? (a_first ? make_uint2(cb, ca) : make_uint2(ca, cb)) : make_uint2(NH_PAIR_INVALID, NH_PAIR_INVALID);       // narrowphase "a" = later in Morton order (emit_pair)
@@ -1008,7 +1038,8 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			if (invalid) { pr = make_uint2(0u, 0u); key = ~0ull; }
 			uint32_t a = pr.x, b = pr.y;            // a = later in Morton order
 			bool a_sph = a >= nbox, b_sph = b >= nbox;
-			bool coarse_asleep = invalid;
+			bool coarse_asleep = invalid || sleeper_pair;
+			if (STILL && sleeper_pair) { const uint32_t ta = TAG(a), tb = TAG(b); key = ta > tb ? ((uint64_t)ta | ((uint64_t)tb << 32)) : ((uint64_t)tb | ((uint64_t)ta << 32)); }
 			if (some_asleep && !invalid) {
 				const uint32_t ba = xf[a].body, bb2 = xf[b].body;
 				const uint32_t set = coarse_root[ba ? ba : bb2];            // sets[a] | sets[b] with sets[0] = 0 (nudge.cpp:3687)
@@ -1067,7 +1098,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 					dp[1] = make_float4(single.nx, single.ny, single.nz, single.friction);
 					raw_feature[slot] = single.feature;
 				}
-				if (STILL) still_record(ri, key, count, body_a, body_b, (uint64_t)s_pre[0][threadIdx.x] | ((uint64_t)s_pre[1][threadIdx.x] << 32), s_pre[2][threadIdx.x], invalid);
+				if (STILL) still_record(ri, key, count, body_a, body_b, (uint64_t)s_pre[0][threadIdx.x] | ((uint64_t)s_pre[1][threadIdx.x] << 32), s_pre[2][threadIdx.x], invalid, sleeper_pair);
 				else {
 				{ const uint64_t was = rec_key[ri]; changed |= was != key; rec_key[ri] = key; }
 				nh_Record r = { body_a, body_b, 0u, asleep ? NH_REC_SLEEPING : (uint32_t)count };
@@ -1120,7 +1151,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			} else if (bb.kind == 1) {
 				put(0, bb.edge);
 			}
-			if (STILL) still_record(ri, key, count, body_a, body_b, (uint64_t)s_pre[0][threadIdx.x] | ((uint64_t)s_pre[1][threadIdx.x] << 32), s_pre[2][threadIdx.x], invalid);
+			if (STILL) still_record(ri, key, count, body_a, body_b, (uint64_t)s_pre[0][threadIdx.x] | ((uint64_t)s_pre[1][threadIdx.x] << 32), s_pre[2][threadIdx.x], invalid, sleeper_pair);
 			else {
 				{ const uint64_t was = rec_key[ri]; changed |= was != key; rec_key[ri] = key; }
 				nh_Record r = { body_a, body_b, ovf, asleep ? NH_REC_SLEEPING : (uint32_t)count };
@@ -1145,7 +1176,20 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		}
 		__builtin_amdgcn_wave_barrier();
 	}
-	if (STILL) { if (__ballot(changed) != 0ull && nh_lane() == 0) atomicMax(&st->still_failed_seq, seq); return; }
+	if (STILL) {
+		if (__ballot(changed) != 0ull && nh_lane() == 0) atomicMax(&st->still_failed_seq, seq);
+		if (sc_count) {
+			// sleepers form: the step's sleeping pairs and kept-aside cache entries, one pair of atomics per workgroup that saw any
+			__shared__ uint32_t s_sl[2];
+			if (threadIdx.x < 2u) s_sl[threadIdx.x] = 0u;
+			__syncthreads();
+			for (int d = 32; d >= 1; d >>= 1) { n_sleeping += (uint32_t)__shfl_xor((int)n_sleeping, d); n_culled += (uint32_t)__shfl_xor((int)n_culled, d); }
+			if (nh_lane() == 0 && n_sleeping) { atomicAdd(&s_sl[0], n_sleeping); atomicAdd(&s_sl[1], n_culled); }
+			__syncthreads();
+			if (threadIdx.x == 0 && s_sl[0]) { atomicAdd(&st->still_sleeping[parity], s_sl[0]); if (s_sl[1]) atomicAdd(&st->still_culled[parity], s_sl[1]); }
+		}
+		return;
+	}
 	if (__ballot(changed) != 0ull && nh_lane() == 0) st->keys_changed = 1u;          // (plain store of a constant)
 }
 
@@ -1380,7 +1424,8 @@ __global__ __launch_bounds__(256) void k_gather_contacts(nh_DevState* __restrict
 	// The layout this launch leaves (per record: first contact | contact count << 28, below) is what a still step compares itself with and writes through:
 	// usable when a record's position is its kept pair's (k_kept_filter wrote in place), nothing sleeps, and everything fits
 	if (blockIdx.x == 0 && threadIdx.x == 0 && !view_only)
-		st->lay_valid = (st->lay_in_place && order_kept && !st->any_sleeping && !st->error && st->contacts <= capacity && st->contacts < (1u << 28)) ? 1u : 0u;
+		// (records of sleeping pairs are part of a usable layout since round 5 -- whether a step with sleepers may follow is the host's call: finish_setup)
+		st->lay_valid = (st->lay_in_place && order_kept && !st->error && st->contacts <= capacity && st->contacts < (1u << 28)) ? 1u : 0u;
 	const uint32_t wave = threadIdx.x >> 6, lane = nh_lane();
 	uint32_t* src = s_src[wave];
 	uint32_t* sft = s_feat[wave];
@@ -1510,6 +1555,7 @@ __global__ __launch_bounds__(256) void k_collide_begin(nh_DevState* st, uint32_t
 		st->any_idle[parity ^ 1u] = 0;
 		// (what a still step of the other parity -- the next step, if the host launches it as one -- accumulates into, and the verdict on this step's layout)
 		st->max_idle[parity ^ 1u] = 0u; st->lay_valid = 0u; st->lay_in_place = 0u; st->delta_count[parity ^ 1u] = 0u; st->delta_overflow[parity ^ 1u] = 0u; st->still_esc[parity ^ 1u] = 0u;
+		st->still_asleep[parity ^ 1u] = 0u; st->still_sleeping[parity ^ 1u] = 0u; st->still_culled[parity ^ 1u] = 0u;
 		for (int k = 0; k < 3; ++k) { st->still_smin[parity ^ 1u][k] = 0xffffffffu; st->still_smax[parity ^ 1u][k] = 0u; }
 	}
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < NH_DEG_WORDS(nbodies); i += gridDim.x * blockDim.x) deg[i] = 0;      // degrees, pair counters, first contacts (NH_DEG_STRIDE)
@@ -1795,9 +1841,21 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 		ss.lay_bodies = *bodies; ss.lay_colliders = *colliders; ss.lay_contacts = *contacts; ss.lay_active = active_bodies->indices; ss.lay_active_capacity = active_bodies->capacity;
 		ss.appended = false;
 		// ---- the still step: three launches instead of the thirty below ----
-		const bool still = want_still && no_islands && !bp_direct && !drop_kept && !drop_sort_order && !lay_fresh && !ctx->env_sort_classic && ctx->sort_seeded && !ctx->env_sort_radix &&
+		// SLEEPERS form (nh_internal.h): somebody may be asleep (the host cannot rule it out) -- bodies asleep in sets of their own are the step's business, without
+		// user connections (they join sets: nudge.cpp:3511-3575) and with the per-body notes the views are made of
+		const bool may_sleep = !no_islands;
+		const bool sleepers_ok = !ss.no_local && !(body_connections && body_connections->count);
+		if (may_sleep && sleepers_ok && ctx->still_awake_capacity < B) {
+			if (ctx->still_awake) NH_HIP_CHECK(ctx, hipFree(ctx->still_awake));
+			ctx->still_awake = nullptr; ctx->still_awake_capacity = 0;
+			NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->still_awake, (size_t)B + 64u));
+			ctx->still_awake_capacity = B;
+		}
+		const bool still = want_still && (no_islands || sleepers_ok) && !bp_direct && !drop_kept && !drop_sort_order && !lay_fresh && !ctx->env_sort_classic && ctx->sort_seeded && !ctx->env_sort_radix &&
 		                   !ctx->env_no_sort_reuse && C != 0u;
 		if (still) {
+			const bool sleepers = may_sleep;
+			ss.sleepers = sleepers;
 			nh_DevState* st = ctx->d_state;
 			// MOVERS form (nh_internal.h, "LOCAL speculation"): while somebody has been leaving its inflated box lately, the step re-boxes its leavers and re-inserts them
 			// into the kept list itself (one more launch, which leaves at once in a step nobody moves in); otherwise a leaver fails the step, and the full step that
@@ -1807,20 +1865,22 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
 			          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
 			          xf, aabb_min, aabb_max, ctag, (uint4*)nullptr, 0u, ctx->fat_box, 0u,
-			          movers ? ctx->fat_gen : (uint8_t*)nullptr, ctx->fat_esc_mark, ctx->fat_esc_list, ctx->fat_moved_list, ctx->collide_seq, bodies->idle_counters, B, ctx->step_parity);
+			          movers ? ctx->fat_gen : (uint8_t*)nullptr, ctx->fat_esc_mark, ctx->fat_esc_list, ctx->fat_moved_list, ctx->collide_seq, bodies->idle_counters, B, ctx->step_parity,
+			          sleepers ? ctx->still_awake : (uint8_t*)nullptr);
 			if (movers)
 				NH_LAUNCH(ctx, "reinsert_still", k_reinsert, 256, 256, st, nbox, ctx->grid_sbox, ctx->grid_cstart, ctx->grid_large, ctx->fat_box, ctx->fat_gen, ctx->fat_esc_mark, ctx->fat_esc_list,
 				          ctx->fat_moved_list, ctx->collide_seq, ctx->fat_pairs, ctx->fat_pair_capacity, 1u, ctx->step_parity, C);
 			const uint8_t* gen = incremental ? ctx->fat_gen : (const uint8_t*)nullptr;
-			const bool delta_scan = C > (2u << 20);
+			const bool delta_scan = C > (2u << 20) || sleepers;          // (a world dozing off changes thousands of contact counts per step: the scan, not the list)
+			uint32_t* const sc_count = sleepers ? ctx->sc_count : (uint32_t*)nullptr;
 			if (nbox >= 2)
 				NH_LAUNCH(ctx, "narrowphase_still", (k_narrowphase<false, true>), nh_grid_for(pair_cap, 256, 4096), 256, st, ctx->fat_pairs, xf, ctag,
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr,
-				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u);
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, sc_count);
 			if (nsph)
 				NH_LAUNCH(ctx, "narrowphase_sph_still", (k_narrowphase<true, true>), nh_grid_for(pair_cap, 256, 8192), 256, st, ctx->fat_pairs, xf, ctag,
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr,
-				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u);
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, sc_count);
 			// every record's first contact in the dense (tag-ordered) list = the scan of the counts in tag order: kept from step to step, shifted by the listed changes
 			// (the solver keeps the total).  More pairs changing their count than the list holds: a world of up to two million colliders fails the step (a handful change
 			// per million and step at rest); a larger one runs the scan instead -- two launches that leave at once otherwise, nothing next to its step
@@ -1835,7 +1895,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 	if (ctx->still.verdict.pending && nh_still_verdict_now(ctx)) return NH_INTERNAL_STILL_FAILED;
 	// The solver reads the caller's cache arrays and this nh_collide lays the dense contact list out -- whatever still steps kept by slot goes home first
 	{ int rc = nh_still_export_cache(ctx); if (rc) return rc; }
-	ctx->still.contacts_stale = false; ctx->still.slots_current = false;
+	ctx->still.contacts_stale = false; ctx->still.slots_current = false; ctx->still.views_sleepers = false;          // (a full step writes the contact list, the sleeping pairs and the active list itself)
 	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, begin_grid, 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity, coarse_parent, coarse_active, no_islands ? 1u : 0u, block_top,
 	          drop_kept ? 1u : 0u, drop_sort_order ? 1u : 0u);
 	const bool seeded_sort = !ctx->env_sort_classic && ctx->sort_seeded && !ctx->env_sort_radix;      // (NH_SORT_RADIX=1: radix passes every step)

@@ -57,6 +57,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->blk.target = 900u;
 	ctx->raw_data = nullptr; ctx->raw_feature = nullptr; ctx->raw_slots = 0; ctx->rec = nullptr; ctx->lay_rank = nullptr; ctx->cnt_sorted = nullptr; ctx->start_sorted = nullptr; ctx->dense_slot = nullptr;
 	ctx->sc_imp = nullptr; ctx->sc_feat = nullptr; ctx->sc_count = nullptr; ctx->exp_cnt = nullptr; ctx->exp_start = nullptr; ctx->exp_scan_tmp = nullptr; ctx->still_delta = nullptr; ctx->lay_capacity = 0; ctx->lay_contact_capacity = 0;
+	ctx->still_awake = nullptr; ctx->still_awake_capacity = 0; ctx->exp_sleep_a = nullptr; ctx->exp_sleep_b = nullptr; ctx->exp_sleep_hist = nullptr; ctx->exp_flags = nullptr; ctx->exp_sleep_capacity = 0; ctx->exp_flags_capacity = 0;
 	ctx->lay_class = nullptr; ctx->lay_simple = nullptr; ctx->body_rec = nullptr; ctx->body_pos = nullptr; ctx->lay_body_capacity = 0;
 	memset(&ctx->still, 0, sizeof(ctx->still));
 	ctx->first_ghost = 0;
@@ -114,7 +115,7 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	for (int k = 0; k < 2; ++k) { if (ctx->still.h_ring[k]) hipHostFree(ctx->still.h_ring[k]); if (ctx->still.ev_ring[k]) hipEventDestroy(ctx->still.ev_ring[k]); }
 	{
 		void* bufs[] = { ctx->raw_data, ctx->raw_feature, ctx->rec, ctx->lay_rank, ctx->cnt_sorted, ctx->start_sorted, ctx->dense_slot, ctx->sc_imp, ctx->sc_feat, ctx->sc_count, ctx->exp_cnt, ctx->exp_start,
-		                 ctx->exp_scan_tmp, ctx->still_delta, ctx->lay_class, ctx->lay_simple, ctx->body_rec, ctx->body_pos };
+		                 ctx->exp_scan_tmp, ctx->still_delta, ctx->lay_class, ctx->lay_simple, ctx->body_rec, ctx->body_pos, ctx->still_awake, ctx->exp_sleep_a, ctx->exp_sleep_b, ctx->exp_sleep_hist, ctx->exp_flags };
 		for (void* b : bufs) if (b) hipFree(b);
 	}
 	{
@@ -215,7 +216,7 @@ void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out) {
 	out->active_bodies = h->active; out->cache = h->cache; out->culled = h->culled; out->large_colliders = h->large;
 	// (still steps, note 9: the cache IS the contact list of the last step -- nothing is culled in a still step -- and its count is written to the device only by the
 	// export of the view: until then the step's contact count stands for it)
-	if (ctx->still.cache_stale) out->cache = h->contacts;
+	if (ctx->still.cache_stale) out->cache = h->contacts + h->culled;          // (+ the entries kept aside for sleeping pairs: a step in sleepers form)
 	out->general_contacts = h->general_contacts; out->levels = h->levels; out->error = h->error;
 	out->still_steps = (uint32_t)(ctx->still.launched - ctx->still.failed - ((ctx->still.active && !ctx->still.resolved) ? 1u : 0u)); out->still_replays = (uint32_t)ctx->still.failed;
 	for (int k = 0; k < 4; ++k) out->still_diff[k] = h->still_diff[k];

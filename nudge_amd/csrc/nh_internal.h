@@ -131,6 +131,9 @@ struct nh_DevState {
 	// re-inserted into the kept pair list by the step itself (k_xform<true> with stamps, k_reinsert in still mode) instead of failing it
 	uint32_t still_esc[2];        // by step parity: colliders a still step re-boxed (the esc_count of a full step; cleared for the next step by the step before)
 	uint32_t still_fat0;          // kept pairs (both kinds) when this still step began: what k_reinsert's "crowded" verdict is taken from (the list grows while it runs)
+	// still steps with SLEEPERS (nh_collide.hip, "9. still steps", LOCAL speculation): by step parity, what a still step in sleepers form counted -- bodies asleep, their
+	// collider pairs (the step's sleeping pairs), the cache entries kept aside for them; the solver turns them into the step's counters (active / sleeping / culled)
+	uint32_t still_asleep[2], still_sleeping[2], still_culled[2];
 	nh_BlkGrid blk;               // spatially blocked solver (nh_blocks.h)
 };
 
@@ -206,6 +209,16 @@ struct nh_StillStep {
 	// kept list, and the still narrowphase takes a kept pair that has died (stamps) or no longer overlaps as a record without contacts, and the appended pairs as
 	// pairs without a record that must not produce a contact -- a landing is still a full step.  Option "no_local_still": the round-4 behaviour.
 	bool no_local; uint32_t movers_left;
+	// SLEEPERS form (round 5).  Still steps needed everybody awake, asleep steps everybody asleep; a world in which SOME bodies sleep paid full steps (~40 launches).  The
+	// reference's rule is per set (nudge.cpp:3575-3703): a body whose AABB overlaps no other dynamic body's forms a set of its own, asleep exactly when its idle counter
+	// is saturated; its pairs with the static world become sleeping pairs (larger tag low, 3697), it is not active (no gravity, no advance), and its cached impulses are
+	// kept aside and written back (4064-4101) when the cache tag equals the sleeping pair's word.  All of that is local to the body: in sleepers form k_xform<true> marks
+	// the colliders of sleeping bodies (and counts them), the still narrowphase files their pairs as sleeping records without contacts -- an overlapping pair of two
+	// DYNAMIC bodies with a sleeping end means a set of more than one body: the step fails, a full step sorts it out -- and the solver leaves sleeping bodies alone.
+	// Active list and sleeping pairs are VIEWS like the contact list (nh_export_views).
+	bool sleepers;                  // this still step was launched in sleepers form
+	bool views_sleepers;            // sleepers-form still steps have run since the caller's active list / sleeping pairs were last written by a full step
+	bool sleep_pairs_current, active_current;       // ... and those two views have been exported since the last such step
 	void note_failure() { hold = (1u << fail_level) - 1u; if (fail_level < 6u) ++fail_level; good_run = 0; }
 	void note_confirmed() { if (++good_run >= 16u) fail_level = 0; }
 };
@@ -326,6 +339,8 @@ struct nh_context {
 	uint32_t* dense_slot;                                                    // per contact of the last FULL step's list: the raw slot it came from
 	// the contact cache by slot (still steps): the solved impulse and the feature word of the contact each slot held LAST step, and how many each record had
 	float4* sc_imp; uint32_t* sc_feat; uint32_t* sc_count;
+	uint8_t* still_awake; uint32_t still_awake_capacity;                     // per body: awake at the last sleepers-form still step's nh_collide (the active list is a view of it)
+	uint64_t* exp_sleep_a; uint64_t* exp_sleep_b; uint32_t* exp_sleep_hist; uint32_t* exp_flags; uint32_t exp_sleep_capacity, exp_flags_capacity;      // scratch of the view exports (on demand)
 	int2* still_delta;                                                       // 2 x NH_DELTA_MAX: (tag-order position, change of the contact count) of this still step, by step parity
 	uint32_t* exp_cnt; uint32_t* exp_start; uint32_t* exp_scan_tmp;          // scratch of the export slots -> caller's cache (pair_cap + 2 words each; scan temporaries)
 	uint32_t lay_capacity, lay_contact_capacity;                             // pair capacity / contact capacity the arrays above were sized for
@@ -343,7 +358,7 @@ int nh_flush_pending(nh_context* ctx, bool keep_gravity = false, bool in_sequenc
 int nh_still_abandon(nh_context* ctx);
 // The caller's view of what still steps keep by slot -- the dense contact list and the contact cache in tag order -- brought up to date (every entry point outside
 // the sample's call order that hands the arrays to the caller: nh_export_views, nh_append_contacts, nh_contact_impulses_device -- NOT nh_read_counts / nh_synchronize)
-int nh_still_sync_outputs(nh_context* ctx, uint32_t what = 3u /* NH_VIEW_ALL */);
+int nh_still_sync_outputs(nh_context* ctx, uint32_t what = 7u /* NH_VIEW_ALL */);
 int nh_still_export_cache(nh_context* ctx);
 int nh_still_verdict_now(nh_context* ctx);            // nh_step: the pending verdict of the last still step, waited for: 0 = it happened, 1 = it did not
 #define NH_INTERNAL_STILL_FAILED (-1000)      // (never leaves the library) first_apply -> nh_step: the still step before this one failed, run both again

@@ -914,7 +914,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			for (uint32_t k = 0; k < n_delta; ++k) shift += sv.delta[sv.parity * NH_DELTA_MAX + k].y;
 			const uint32_t total = sv.start_sorted[nrec] + (uint32_t)shift;
 			if (shift) sv.start_sorted[nrec] = total;
-			const_cast<nh_DevState*>(cv.st)->contacts = total;
+			nh_DevState* const stw = const_cast<nh_DevState*>(cv.st);
+			stw->contacts = total;
+			// (sleepers form, nh_internal.h: what k_xform<true> and the still narrowphase counted becomes the step's counters; all zero when nobody sleeps)
+			stw->active = (nbodies - 1u) - min(stw->still_asleep[sv.parity], nbodies - 1u); stw->sleeping = stw->still_sleeping[sv.parity]; stw->culled = stw->still_culled[sv.parity];
 		}
 		__syncthreads();
 	}
@@ -939,10 +942,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		uint32_t h = NH_HINT_NONE;
 		if (CONTIG && !STILL) sp = simple[xc];
 		if (FUSED && !STILL) h = hint[xc];
-		uint32_t br = NH_BODY_REC_NONE, bpos = 0u;
-		if (STILL) { br = sv.body_rec[xc]; bpos = sv.body_pos[xc]; }
+		uint32_t br = NH_BODY_REC_NONE, bpos = 0u, idle0 = 0u;
+		if (STILL) { br = sv.body_rec[xc]; bpos = sv.body_pos[xc]; if (CONTIG && (fs.bits & 2u)) idle0 = fs.idle[xc]; }
 		if (!inert_word) return;
-		const bool mine = STILL ? (x >= 1u && x < nbodies) : (x < nbodies && (my_class == cls_a || my_class == cls_b));
+		// (STILL: a body asleep -- only a step in sleepers form gets this far with one -- is nobody's: no gravity, no contacts, no advance, nothing stored; nudge.cpp:3669-3703, 4896-4898)
+		const bool mine = STILL ? (x >= 1u && x < nbodies && idle0 != 0xffu) : (x < nbodies && (my_class == cls_a || my_class == cls_b));
 		const uint32_t wave_x0 = x - lane;
 		uint32_t b = 0, cnt = 0;
 		if (!mine) { sp = make_uint2(0u, 0u); h = NH_HINT_NONE; br = NH_BODY_REC_NONE; }
@@ -1020,7 +1024,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			m0 = reinterpret_cast<const float4*>(momentum + x)[0]; m1 = reinterpret_cast<const float4*>(momentum + x)[1];
 			pr = *reinterpret_cast<const float4*>(props + x);
 			t0 = reinterpret_cast<const float4*>(xf + x)[0]; t1 = reinterpret_cast<const float4*>(xf + x)[1];
-			if (CONTIG && (fs.bits & 2u)) idle_early = fs.idle[x];
+			if (CONTIG && (fs.bits & 2u)) idle_early = STILL ? idle0 : fs.idle[x];
 			if (CONTIG && (fs.bits & 1u)) {          // NH_FLAG_FUSED_STEP: gravity / damping (k_gravity) on the way in
 				float vel[3] = { m0.x, m0.y, m0.z }, ang[3] = { m1.x, m1.y, m1.z };
 				nh_gravity_damping(vel, ang, fs.gx_dt, fs.gy_dt, fs.gz_dt, fs.damping);
@@ -2063,6 +2067,10 @@ extern "C" const nh_CachedContactImpulse* nh_contact_impulses_device(const nh_Co
 __global__ void k_cache_to_slots(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ dense_slot, const nh_CachedContactImpulse* __restrict__ imp,
                                  const uint32_t* __restrict__ features, const nh_Record* __restrict__ rec, float4* __restrict__ sc_imp, uint32_t* __restrict__ sc_feat, uint32_t* __restrict__ sc_count);
 
+__global__ void k_culled_to_slots(const nh_DevState* __restrict__ st, const uint64_t* __restrict__ ctags, const uint32_t* __restrict__ cfeatures,
+                                  const nh_CachedContactImpulse* __restrict__ cdata, const uint64_t* __restrict__ sorted_keys, const uint32_t* __restrict__ sorted_idx,
+                                  const nh_Record* __restrict__ rec, uint32_t pair_cap, float4* __restrict__ sc_imp, uint32_t* __restrict__ sc_feat, uint32_t* __restrict__ sc_count);
+
 extern "C" int nh_write_cached_impulses(nh_context* ctx, nh_ContactCache* cache, const nh_ContactData* contacts, nh_ContactImpulseData* imp) {
 	if (!ctx || !cache || !contacts || !imp) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
@@ -2071,7 +2079,8 @@ extern "C" int nh_write_cached_impulses(nh_context* ctx, nh_ContactCache* cache,
 		// a still step that went through: the solver has written every contact's impulse into its cache entry, tags and features are last step's -- nothing to do
 		if (ss.active && ss.resolved && cache->data == ss.cache_data && imp->ctx == ctx && imp->consumed) return NH_OK;
 		// a full step: afterwards the cache IS this step's contact list when nothing was culled (the round trip has told) -- what the next still step relies on
-		ss.cache_ok = imp->consumed && !imp->cull_pending && !(ctx->flags & NH_FLAG_SYNC_COUNTS) && ctx->h_state->sleeping == 0u && ctx->h_state->culled == 0u &&
+		// (sleepers form: entries kept aside for sleeping pairs are part of such a cache -- they go to the slots of their records below)
+		ss.cache_ok = imp->consumed && !imp->cull_pending && !(ctx->flags & NH_FLAG_SYNC_COUNTS) && ((ctx->h_state->sleeping == 0u && ctx->h_state->culled == 0u) || !ss.no_local) &&
 		              contacts->data == ss.lay_contacts.data && contacts->tags == ss.lay_contacts.tags;
 		ss.cache_tags = cache->tags; ss.cache_features = cache->features; ss.cache_data = cache->data; ss.cache_capacity = cache->capacity;
 		ss.cache = *cache;
@@ -2092,6 +2101,11 @@ extern "C" int nh_write_cached_impulses(nh_context* ctx, nh_ContactCache* cache,
 		// the next step may be a still one: the cache goes to the slots as well (solved impulse + feature word to the raw slot each contact came from)
 		NH_LAUNCH(ctx, "cache_to_slots", k_cache_to_slots, nh_grid_for(contacts->capacity, 256, 4096), 256, st, ctx->dense_slot, imp->data, contacts->features, ctx->rec,
 		          ctx->sc_imp, ctx->sc_feat, ctx->sc_count);
+		// (the entries kept aside for sleeping pairs, nudge.cpp:4064-4101: to the slots of the pairs' records -- a step in sleepers form keeps them there)
+		// (the host's mirror knows the step's sleeping pairs from the round trip; how many entries were kept aside is counted on the device after it: the kernel reads that)
+		if (ctx->h_state->sleeping)
+			NH_LAUNCH(ctx, "culled_to_slots", k_culled_to_slots, nh_grid_for(imp->culled_capacity, 256, 2048), 256, st, imp->culled_tags, imp->culled_features, imp->culled_data, ctx->sort_sorted_keys,
+			          ctx->sort_sorted_idx, ctx->rec, ctx->lay_capacity, ctx->sc_imp, ctx->sc_feat, ctx->sc_count);
 		ctx->still.slots_current = true;
 	}
 	if (ctx->flags & NH_FLAG_SYNC_COUNTS) {
@@ -2432,6 +2446,8 @@ static void blk_run(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyD
 // movers form of the still step stays on for 64 steps after the last one who did
 static void still_note_movers(nh_context* ctx, const nh_DevState* h) {
 	nh_StillStep& ss = ctx->still;
+	// (a still step in sleepers form that found NOBODY awake: the next step is a full one -- two of those in a row start the asleep steps, which cost nothing)
+	if (ss.sleepers && h->active == 0u) ss.ok_next = false;
 	if (h->fat_inserts != ss.seen_inserts) ss.movers_left = 64u;
 	else if (ss.movers_left) ss.movers_left--;
 	ss.seen_inserts = h->fat_inserts; ss.seen_rebuilds = h->fat_rebuilds;
@@ -2456,8 +2472,12 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		// may the NEXT step be launched as a still step?  (nh_internal.h: nh_StillStep)  This step laid its contacts out in a layout a still step can write through, every
 		// dynamic body sits in one pair with an inert static world (the fused solver owns them all), nothing sleeps, nothing was culled
 		const nh_DevState* h = ctx->h_state;
-		ctx->still.ok_next = h->lay_valid && !h->has_unstable && h->static_inert && !h->has_pending && !h->has_static8 && !h->has_staticN && !h->any_sleeping && h->sleeping == 0u &&
-		                     h->culled == 0u && h->general_contacts == 0u && !h->error;
+		// (SLEEPERS form, nh_internal.h: sleeping pairs and kept-aside cache entries no longer rule the next step out -- as long as somebody is awake; a world in which
+		// nobody is belongs to the asleep steps below, which need full steps to get going)
+		const bool sleepers_ok = !ctx->still.no_local;
+		const bool nobody_sleeps = !h->any_sleeping && h->sleeping == 0u && h->culled == 0u;
+		ctx->still.ok_next = h->lay_valid && !h->has_unstable && h->static_inert && !h->has_pending && !h->has_static8 && !h->has_staticN && (nobody_sleeps || (sleepers_ok && h->active != 0u)) &&
+		                     h->general_contacts == 0u && !h->error;
 		// ... and nobody moved: a collider that left its inflated box in THIS step (re-inserted, or the kept list rebuilt) will most likely leave it again in the next
 		// one -- a body in the air does on every step -- and a still step that fails costs two steps' worth of launches
 		// (LOCAL speculation, nh_internal.h: a still step in movers form re-inserts its own leavers -- then only a REBUILD of the kept list, which also voids the
@@ -2737,6 +2757,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 		if (confirmed) {
 			ss.resolved = true; ss.setup_d = nullptr; ss.note_confirmed();
 			ss.cache_stale = true; ss.contacts_stale = true;        // (the caller's cache and dense contact arrays are last written by an earlier step: nh_still_sync_outputs)
+			if (ss.sleepers) { ss.views_sleepers = true; ss.sleep_pairs_current = false; ss.active_current = false; }            // (... and so are its active list and sleeping pairs)
 			d->finish_pending = false; d->has_late = false; d->has_static8 = d->has_staticN = false; d->static_inert = true; d->general_contacts = 0; d->levels = 0;
 			d->imp->cull_pending = false; d->imp->lookup_pending = false;
 			ctx->last_general_contacts = 0;
@@ -2792,6 +2813,31 @@ __global__ __launch_bounds__(256) void k_cache_to_slots(const nh_DevState* __res
 	for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < nrec; r += gridDim.x * blockDim.x) { const uint32_t k = rec[r].count; sc_count[r] = (k & NH_REC_SLEEPING) ? 0u : k; }
 }
 
+// entries kept aside for sleeping pairs (the culled arrays of this step's nh_ContactImpulseData: tag order, st->culled of them) -> the slots of the pairs' records.  A
+// record is found by its key -- a sleeping record's key is the pair's word, which is what the cache tag equals for every entry that was kept (k_cull_flags) -- in the
+// tag order of the layout; an entry's place among its record's slots is its place in the run of equal tags (the entries are ranked by feature word, like the slots' export)
+__global__ __launch_bounds__(256) void k_culled_to_slots(const nh_DevState* __restrict__ st, const uint64_t* __restrict__ ctags, const uint32_t* __restrict__ cfeatures,
+                                                         const nh_CachedContactImpulse* __restrict__ cdata, const uint64_t* __restrict__ sorted_keys, const uint32_t* __restrict__ sorted_idx,
+                                                         const nh_Record* __restrict__ rec, uint32_t pair_cap, float4* __restrict__ sc_imp, uint32_t* __restrict__ sc_feat, uint32_t* __restrict__ sc_count) {
+	const uint32_t n = st->culled, nrec = st->records, n_bb = min(st->pairs, pair_cap);
+	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+		const uint64_t t = ctags[j];
+		uint32_t k = 0;                                   // place in the run of equal tags
+		while (k < 4u && j > k && ctags[j - 1u - k] == t) ++k;
+		uint32_t lo = 0, hi = nrec;
+		while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sorted_keys[mid] < t) lo = mid + 1u; else hi = mid; }
+		if (lo >= nrec || sorted_keys[lo] != t) continue;
+		const uint32_t ri = sorted_idx[lo];
+		if (!(rec[ri].count & NH_REC_SLEEPING)) continue;
+		const bool sph = ri >= n_bb;
+		if (k >= (sph ? 1u : 4u)) continue;
+		const uint32_t base = sph ? 4u * n_bb + (ri - n_bb) : 4u * ri;
+		sc_imp[base + k] = *reinterpret_cast<const float4*>(cdata + j);
+		sc_feat[base + k] = cfeatures[j];
+		if (j + 1u >= n || ctags[j + 1u] != t) sc_count[ri] = k + 1u;          // (the last entry of the run knows how many there are)
+	}
+}
+
 // slots -> the caller's cache arrays, in tag order: counts in tag order (scanned by the host's launch in between), then the entries ranked by feature word
 __global__ __launch_bounds__(256) void k_slot_counts_sorted(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ sc_count, uint32_t* __restrict__ out) {
 	const uint32_t nrec = st->records;
@@ -2842,18 +2888,83 @@ int nh_still_export_cache(nh_context* ctx) {
 	return NH_OK;
 }
 
+// ---- views of a world with sleepers (nh_internal.h, "SLEEPERS form"): the list of sleeping pairs and the active list, as a full step would have written them -------
+__global__ __launch_bounds__(256) void k_view_sleep_keys(const nh_DevState* __restrict__ st, const nh_Record* __restrict__ rec, const uint64_t* __restrict__ rec_key, uint64_t* __restrict__ out) {
+	const uint32_t n = st->records;
+	for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) out[r] = (rec[r].count & NH_REC_SLEEPING) ? rec_key[r] : ~0ull;      // (a sleeping record carries the pair's word)
+}
+__global__ __launch_bounds__(256) void k_view_sleep_copy(nh_DevState* __restrict__ st, const uint64_t* __restrict__ sorted, uint64_t* __restrict__ out, uint32_t capacity) {
+	const uint32_t n = st->sleeping;
+	if (n > capacity) { if (blockIdx.x == 0 && threadIdx.x == 0) st->error = NH_ERR_CONTACT_CAPACITY; return; }
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = sorted[i];
+}
+__global__ __launch_bounds__(256) void k_view_awake_flags(const uint8_t* __restrict__ awake, uint32_t nbodies, uint32_t* __restrict__ flags) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= nbodies; i += gridDim.x * blockDim.x) flags[i] = (i >= 1u && i < nbodies && awake[i]) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_view_active_write(nh_DevState* __restrict__ st, const uint8_t* __restrict__ awake, const uint32_t* __restrict__ scan, uint32_t nbodies,
+                                                           uint32_t* __restrict__ indices, uint32_t capacity) {
+	for (uint32_t i = 1u + blockIdx.x * blockDim.x + threadIdx.x; i < nbodies; i += gridDim.x * blockDim.x) {
+		if (!awake[i]) continue;
+		const uint32_t at = scan[i];
+		if (at < capacity) indices[at] = i; else st->error = NH_ERR_ACTIVE_CAPACITY;
+	}
+}
+
+static int still_view_sleepers(nh_context* ctx, uint32_t what) {
+	nh_StillStep& ss = ctx->still;
+	nh_DevState* st = ctx->d_state;
+	if (what & NH_VIEW_CONTACTS) {
+		// sleeping pairs in ascending order (nudge.cpp:4008): the words of the sleeping records, sorted -- every other record sorts behind them
+		const uint32_t P = ctx->lay_capacity;
+		if (ss.lay_contacts.sleeping_pairs) {
+			if (ctx->exp_sleep_capacity < P) {
+				void** bufs[] = { (void**)&ctx->exp_sleep_a, (void**)&ctx->exp_sleep_b, (void**)&ctx->exp_sleep_hist };
+				for (void** b : bufs) { if (*b) NH_HIP_CHECK(ctx, hipFree(*b)); *b = nullptr; }
+				ctx->exp_sleep_capacity = 0;
+				NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->exp_sleep_a, sizeof(uint64_t) * (size_t)P + 64u));
+				NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->exp_sleep_b, sizeof(uint64_t) * (size_t)P + 64u));
+				NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->exp_sleep_hist, sizeof(uint32_t) * (256u * NH_SORT_GRID + 512u)));
+				ctx->exp_sleep_capacity = P;
+			}
+			NH_LAUNCH(ctx, "view_sleep_keys", k_view_sleep_keys, nh_grid_for(P, 256, 2048), 256, st, ctx->rec, ctx->sort_keys_by_position, ctx->exp_sleep_a);
+			uint64_t* a = ctx->exp_sleep_a; uint64_t* b = ctx->exp_sleep_b;
+			int bits = (int)ctx->tag_bits; if (bits < 1) bits = 1; if (bits > 32) bits = 32;
+			const int top = ((bits + 7) / 8) * 8;
+			if (nh_sort_u64(ctx, a, b, &st->records, ctx->exp_sleep_hist, 0, top)) { uint64_t* t = a; a = b; b = t; }
+			if (nh_sort_u64(ctx, a, b, &st->records, ctx->exp_sleep_hist, 32, 32 + top)) { uint64_t* t = a; a = b; b = t; }
+			NH_LAUNCH(ctx, "view_sleep_copy", k_view_sleep_copy, nh_grid_for(P, 256, 1024), 256, st, a, ss.lay_contacts.sleeping_pairs, ss.lay_contacts.capacity);
+		}
+	}
+	if ((what & NH_VIEW_ACTIVE) && ss.lay_active && ctx->still_awake) {
+		const uint32_t B = ss.lay_bodies.count;
+		if (ctx->exp_flags_capacity < B + 2u) {
+			if (ctx->exp_flags) NH_HIP_CHECK(ctx, hipFree(ctx->exp_flags));
+			ctx->exp_flags = nullptr; ctx->exp_flags_capacity = 0;
+			NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->exp_flags, sizeof(uint32_t) * ((size_t)B + 66u)));
+			ctx->exp_flags_capacity = B + 2u;
+		}
+		NH_LAUNCH(ctx, "view_awake_flags", k_view_awake_flags, nh_grid_for(B, 256, 2048), 256, ctx->still_awake, B, ctx->exp_flags);
+		nh_scan_u32(ctx, ctx->exp_flags, ctx->exp_flags, &st->pad0 /* always 0 */, B, ctx->exp_scan_tmp, nullptr);
+		NH_LAUNCH(ctx, "view_active_write", k_view_active_write, nh_grid_for(B, 256, 2048), 256, st, ctx->still_awake, ctx->exp_flags, B, const_cast<uint32_t*>(ss.lay_active), ss.lay_active_capacity);
+	}
+	return NH_OK;
+}
+
 int nh_still_sync_outputs(nh_context* ctx, uint32_t what) {
 	nh_StillStep& ss = ctx->still;
 	if (ss.active && !ss.resolved) return NH_OK;          // (an unconfirmed still step is abandoned by the caller first: nh_flush_pending)
 	int rc = NH_OK;
 	if (what & NH_VIEW_CACHE) rc = nh_still_export_cache(ctx);
 	if (rc) return rc;
-	if ((what & NH_VIEW_CONTACTS) && ss.contacts_stale) { ss.contacts_stale = false; rc = nh_still_view_contacts(ctx); }
+	if ((what & NH_VIEW_CONTACTS) && ss.contacts_stale) { ss.contacts_stale = false; rc = nh_still_view_contacts(ctx); if (!rc && ss.views_sleepers) rc = still_view_sleepers(ctx, NH_VIEW_CONTACTS); ss.sleep_pairs_current = true; }
+	else if ((what & NH_VIEW_CONTACTS) && ss.views_sleepers && !ss.sleep_pairs_current) { rc = still_view_sleepers(ctx, NH_VIEW_CONTACTS); ss.sleep_pairs_current = true; }
+	if (rc) return rc;
+	if ((what & NH_VIEW_ACTIVE) && ss.views_sleepers && !ss.active_current) { rc = still_view_sleepers(ctx, NH_VIEW_ACTIVE); ss.active_current = true; }
 	return rc;
 }
 
 extern "C" int nh_export_views(nh_context* ctx, uint32_t what) {
-	if (!ctx || (what & ~(uint32_t)NH_VIEW_ALL)) return NH_ERR_INVALID;
+	if (!ctx || (what & ~(uint32_t)NH_VIEW_ALL)) return NH_ERR_INVALID;          // (NH_VIEW_ALL = contacts | cache | active)
 	NH_HIP_CHECK(ctx, hipSetDevice(ctx->device));
 	{ int rc = nh_flush_pending(ctx, true); if (rc) return rc; }
 	return nh_still_sync_outputs(ctx, what);

@@ -27,7 +27,7 @@ NH_FLAG_SYNC_COUNTS = 1
 NH_FLAG_EXACT_ORDER = 2
 NH_FLAG_SINGLE_APPLY = 4
 NH_FLAG_FUSED_STEP = 8
-NH_VIEW_CONTACTS, NH_VIEW_CACHE, NH_VIEW_ALL = 1, 2, 3
+NH_VIEW_CONTACTS, NH_VIEW_CACHE, NH_VIEW_ACTIVE, NH_VIEW_ALL = 1, 2, 4, 7
 # environment variables NH_<NAME> that World() forwards to nh_set_option (tests and dev scripts; include/nudge_hip.h lists what each does)
 OPTION_NAMES = ("no_still", "no_kept_pairs", "no_incremental", "no_sort_reuse", "sort_classic", "sort_radix", "bucket_tile", "bucket_target", "colour_jp",
                 "colour_check_seeds", "no_resident", "solver_waves", "fp_sub", "cooperative", "no_blocks", "blk_check", "blk_min", "blk_target", "blk_rows_global",
@@ -479,6 +479,7 @@ class World:
                     sleeping_pairs=self._down("cs", np.uint64, ns))
 
     def get_active(self):
+        self.export_views(NH_VIEW_ACTIVE)
         c = self.counts()
         return self._down("ai", np.uint32, c["active_bodies"])
 

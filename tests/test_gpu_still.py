@@ -273,6 +273,73 @@ def test_counts_and_synchronize_every_step_export_nothing_and_views_are_the_bits
     a.close(); b.close()
 
 
+def _same_sleepy_world(a, b, what=""):
+    """Bodies, cache, contacts (_same_world) + what a world with sleepers adds: sleeping pairs, active list, the counters a caller sees."""
+    _same_world(a, b, what)
+    ka, kb = a.get_contacts(), b.get_contacts()
+    assert np.array_equal(ka["sleeping_pairs"], kb["sleeping_pairs"]), f"{what}: sleeping pairs differ ({len(ka['sleeping_pairs'])} vs {len(kb['sleeping_pairs'])})"
+    assert np.array_equal(a.get_active(), b.get_active()), f"{what}: active bodies differ"
+    ca, cb = a.counts(), b.counts()
+    for k in ("contacts", "sleeping_pairs", "active_bodies", "cache", "error"):
+        assert ca[k] == cb[k], f"{what}: counter {k}: {ca[k]} vs {cb[k]}"
+
+
+@pytest.mark.parametrize("sphere_fraction", [0.0, 0.5])
+def test_a_world_that_is_partly_asleep_takes_still_steps(sphere_fraction):
+    """SLEEPERS form.  Two tiles fall asleep; the caller wakes one of them (idle counters rewritten, nh_bodies_changed).  For the next ~250 steps half the world is awake
+    and at rest, half asleep: round 4 ran every one of those steps in full (still steps needed everybody awake, asleep steps everybody asleep).  Now they are still
+    steps in which the sleepers' pairs are sleeping pairs, their cache entries stay aside and their bodies are left alone -- bit-identical to a library that runs
+    every step in full (bodies, idle counters, contacts, sleeping pairs, active list, cache, counters), through the second dozing-off and into the asleep steps."""
+    scene = S.grid_tiles(2, side=32, sphere_fraction=sphere_fraction, seed=73, lattice_cols=2)
+    nb = len(scene["body_transforms"])
+    a, b = _world(scene, True), _plain_world(scene)
+    a.step(420); b.step(420)
+    _same_sleepy_world(a, b, "asleep")
+    assert a.counts()["active_bodies"] == 0
+    tile0 = np.flatnonzero(scene["body_transforms"]["position"][:, 0] < np.median(scene["body_transforms"]["position"][1:, 0]))
+    tile0 = tile0[tile0 > 0]
+    for w in (a, b):
+        idle = w.get_bodies()["idle"].copy()
+        idle[tile0] = 0
+        w.set_bodies(idle=idle)
+    c0 = a.counts()
+    done = 0
+    for cp in (1, 2, 3, 10, 60, 61, 150, 240, 252, 254, 255, 256, 257, 258, 262, 270, 300, 330):
+        a.step(cp - done); b.step(cp - done); done = cp
+        _same_sleepy_world(a, b, f"half awake, step {cp}")
+        if cp == 150:
+            cm = a.counts()
+            assert 0 < cm["active_bodies"] < nb - 1 and cm["sleeping_pairs"] > 0 and cm["contacts"] > 0, cm
+            still_mid = cm["still_steps"] - c0["still_steps"]
+    c1 = a.counts()
+    print(f"\n[sleepers, spheres {sphere_fraction}] half the world asleep: {still_mid} of the first 150 steps were still steps; {c1['still_steps'] - c0['still_steps']} still + {c1['asleep_steps'] - c0['asleep_steps']} asleep of {done}, replays {c1['still_replays'] - c0['still_replays']}")
+    assert still_mid >= 120, (c0, cm)
+    assert c1["active_bodies"] == 0 and c1["asleep_steps"] > c0["asleep_steps"]          # (everybody asleep again: the asleep steps took over)
+    assert b.counts()["still_steps"] == 0
+    a.close(); b.close()
+
+
+def test_a_sleeper_next_to_an_awake_body_is_not_the_still_steps_business():
+    """A sleeping body whose AABB overlaps an awake dynamic body's belongs to a set of more than one body (nudge.cpp:3575-3650): whether it sleeps is not local.  Such a
+    step must fail as a still step and be run in full -- the world ends in the bits of the library that never speculates."""
+    scene = S.grid_tiles(1, side=24, seed=79)
+    nb = len(scene["body_transforms"])
+    a, b = _world(scene, True), _plain_world(scene)
+    a.step(420); b.step(420)
+    for w in (a, b):
+        bd = w.get_bodies()
+        idle, t = bd["idle"].copy(), bd["transforms"].copy()
+        idle[5::7] = 0                                             # every seventh body awake ...
+        j = 5 + 7 * 3
+        t["position"][j] = t["position"][j + 1] + np.float32([0.4, 2.2, 0.0])          # ... and one of them put right above its sleeping neighbour: it falls onto it
+        w.set_bodies(transforms=t, idle=idle)
+    done = 0
+    for cp in (1, 5, 30, 80, 200):
+        a.step(cp - done); b.step(cp - done); done = cp
+        _same_sleepy_world(a, b, f"sleeper with an awake neighbour, step {cp}")
+    a.close(); b.close()
+
+
 # ---- asleep steps (nudge_amd/csrc/nh_internal.h: nh_AsleepState): nh_step on a world in which every body is asleep ---------------------------------------------
 def _plain_world(scene, **kw):
     """Neither still steps nor asleep steps: every step in full."""
