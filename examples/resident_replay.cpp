@@ -91,6 +91,15 @@ int main(int argc, char** argv) {
 	arena.size = ((size_t)64 << 20) + (size_t)(nbox + nsph) * 200 + ((size_t)1 << 22) * 8 + (size_t)K * 420 + (size_t)nb * 64;
 	HIP_OK(hipMalloc(&arena.data, arena.size));
 
+	// A viewer's feed (example/main.cpp:176-272 draws from bodies.transforms after simulate()): NUDGE_STREAM_EVERY=N puts the transforms of every N-th sub-step into a
+	// pinned host ring while the world goes on (include/nudge_hip.h: nh_stream_state); a render thread would poll nh_stream_latest and draw ring[slot]
+	const unsigned stream_every = getenv("NUDGE_STREAM_EVERY") ? (unsigned)atoi(getenv("NUDGE_STREAM_EVERY")) : 0u;
+	void* ring = nullptr;
+	if (stream_every) {
+		HIP_OK(hipHostMalloc(&ring, sizeof(nh_Transform) * (size_t)nb * 4u, 0));
+		NH_OK_(nh_stream_state(ctx, &bodies, nb, ring, 4u, stream_every));
+	}
+
 	uint64_t sum_contacts = 0;
 	HIP_OK(hipStreamSynchronize(stream));
 	auto t0 = std::chrono::steady_clock::now();
@@ -122,6 +131,15 @@ int main(int argc, char** argv) {
 	double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 	nh_Counts c;
 	NH_OK_(nh_read_counts(ctx, &c));
+	if (stream_every) {
+		nh_StreamInfo si;
+		NH_OK_(nh_stream_latest(ctx, &si));
+		const nh_Transform* frame = static_cast<const nh_Transform*>(ring) + (size_t)si.slot * nb;
+		printf("resident_replay: state stream: %llu frames (%llu dropped), newest landed: sub-step %llu in slot %u, body 1 at (%.3f, %.3f, %.3f)\n", (unsigned long long)si.frames,
+		       (unsigned long long)si.dropped, (unsigned long long)si.step, si.slot, si.valid && nb > 1 ? frame[1].position[0] : 0.0f, si.valid && nb > 1 ? frame[1].position[1] : 0.0f,
+		       si.valid && nb > 1 ? frame[1].position[2] : 0.0f);
+		NH_OK_(nh_stream_state(ctx, nullptr, 0, nullptr, 0, 0));
+	}
 
 	HIP_OK(hipMemcpy(h_xf.data(), bodies.transforms, sizeof(nh_Transform) * nb, hipMemcpyDeviceToHost));
 	HIP_OK(hipMemcpy(h_mom.data(), bodies.momentum, sizeof(nh_BodyMomentum) * nb, hipMemcpyDeviceToHost));

@@ -313,6 +313,18 @@ typedef struct nh_StepArgs {
 } nh_StepArgs;
 int nh_step(nh_context* ctx, const nh_StepArgs* args, uint32_t steps);
 
+/* ---- state streaming: the GL-free viewer hook (the sample redraws from bodies.transforms after simulate(), example/main.cpp:176-272, 330) -------------------------
+   A viewer, a recorder or a network peer wants body transforms on the HOST every few steps without stopping the world.  nh_stream_state arms that: every `every`-th
+   nh_advance (the end of a sub-step, whoever drives the eight calls) the transforms of the first `count` bodies are copied device-to-device into a library-owned staging
+   buffer on the context's stream (tens of microseconds at a million bodies, ordered behind the step that produced them) and from there, on the library's side stream,
+   into slot (frame mod slots) of the caller's ring -- the world's stream never waits for the host link.  A frame whose predecessor is still on its way to the host is
+   dropped, not queued (nh_StreamInfo.dropped).  Ring layout: `slots` frames of count x sizeof(nh_Transform) bytes, back to back; give it pinned memory (hipHostMalloc)
+   or the copies are staged by the runtime.  nh_stream_latest: the newest frame that has LANDED (never blocks): its slot, and the number of nh_advance calls (since
+   nh_stream_state) it shows.  every = 0 disarms.  Reference counterpart: none needed -- its arrays are host memory. */
+typedef struct nh_StreamInfo { uint32_t slot; uint32_t valid; uint64_t step; uint64_t frames, dropped; } nh_StreamInfo;
+int nh_stream_state(nh_context* ctx, const nh_BodyData* bodies, uint32_t count, void* host_ring, uint32_t slots, uint32_t every);
+int nh_stream_latest(nh_context* ctx, nh_StreamInfo* out);
+
 /* ---- multi-GPU: one x-slab of a world per context ------------------------------------------------------------------------------------
    The world is cut into slabs along x, one rank (process, GPU, nh_context) per slab [lo, hi).  A rank's arrays hold
        body slot 0            the static world with the static colliders the rank keeps (front of the collider arrays),

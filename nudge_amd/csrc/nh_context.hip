@@ -62,6 +62,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	memset(&ctx->still, 0, sizeof(ctx->still));
 	ctx->first_ghost = 0;
 	memset(&ctx->asleep, 0, sizeof(ctx->asleep));
+	memset(&ctx->stream_state, 0, sizeof(ctx->stream_state)); ctx->stream_state.last_slot = -1;
 	ctx->d_state = nullptr;
 	ctx->h_state = nullptr;
 	if (hipMalloc((void**)&ctx->d_state, sizeof(nh_DevState)) != hipSuccess) { delete ctx; return NH_ERR_HIP; }
@@ -90,6 +91,12 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
 	if (ctx->ev_active) hipEventDestroy(ctx->ev_active);
 	if (ctx->ev_gravity) hipEventDestroy(ctx->ev_gravity);
+	{
+		nh_StateStream& ss = ctx->stream_state;
+		if (ss.stage) hipFree(ss.stage);
+		if (ss.staged) hipEventDestroy(ss.staged);
+		for (int k = 0; k < NH_STREAM_MAX_SLOTS; ++k) if (ss.landed[k]) hipEventDestroy(ss.landed[k]);
+	}
 	if (ctx->asleep.aabb_min) hipFree(ctx->asleep.aabb_min);
 	if (ctx->asleep.aabb_max) hipFree(ctx->asleep.aabb_max);
 	if (ctx->asleep.tags) hipFree(ctx->asleep.tags);
@@ -243,6 +250,63 @@ extern "C" int nh_set_cache_count(nh_context* ctx, uint32_t count) {
 	ctx->asleep.streak = 0;
 	ctx->still.cache_ok = false; ctx->still.slots_current = false; ctx->still.cache_stale = false;      // the caller has put another cache in place: what the slots hold is void
 	hipLaunchKernelGGL(k_set_cache_count, dim3(1), dim3(1), 0, ctx->stream, ctx->d_state, count);
+	return NH_OK;
+}
+
+// ---- state streaming (include/nudge_hip.h: nh_stream_state) ---------------------------------------------------------------------------------------------------
+extern "C" int nh_stream_state(nh_context* ctx, const nh_BodyData* bodies, uint32_t count, void* host_ring, uint32_t slots, uint32_t every) {
+	if (!ctx) return NH_ERR_INVALID;
+	NH_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+	nh_StateStream& ss = ctx->stream_state;
+	// (frames still on their way belong to the old ring: wait for them before the ring changes hands)
+	if (ctx->side) NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->side));
+	for (int k = 0; k < NH_STREAM_MAX_SLOTS; ++k) { ss.in_flight[k] = false; ss.slot_frame[k] = 0; ss.slot_step[k] = 0; }
+	ss.every = 0; ss.last_slot = -1; ss.advances = 0; ss.frames = 0; ss.dropped = 0;
+	if (every == 0u) return NH_OK;
+	if (!bodies || !bodies->transforms || !host_ring || count == 0u || count > bodies->count || slots == 0u || slots > NH_STREAM_MAX_SLOTS || !ctx->side) return NH_ERR_INVALID;
+	if (ss.stage_capacity < count) {
+		if (ss.stage) NH_HIP_CHECK(ctx, hipFree(ss.stage));
+		ss.stage = nullptr; ss.stage_capacity = 0;
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ss.stage, sizeof(nh_Transform) * (size_t)count));
+		ss.stage_capacity = count;
+	}
+	if (!ss.staged) NH_HIP_CHECK(ctx, hipEventCreateWithFlags(&ss.staged, hipEventDisableTiming));
+	for (uint32_t k = 0; k < slots; ++k) if (!ss.landed[k]) NH_HIP_CHECK(ctx, hipEventCreateWithFlags(&ss.landed[k], hipEventDisableTiming));
+	ss.src = bodies->transforms; ss.count = count; ss.ring = static_cast<char*>(host_ring); ss.slots = slots; ss.every = every;
+	return NH_OK;
+}
+
+int nh_stream_after_advance(nh_context* ctx) {
+	nh_StateStream& ss = ctx->stream_state;
+	if (!ss.every) return NH_OK;
+	ss.advances++;
+	if (ss.advances % ss.every) return NH_OK;
+	const uint32_t slot = (uint32_t)(ss.frames % ss.slots);
+	// one staging buffer: the frame before this one must have left it (and a slot is rewritten only when its last frame has landed) -- otherwise this frame is dropped
+	const int prev = ss.last_slot;
+	if ((prev >= 0 && ss.in_flight[prev] && hipEventQuery(ss.landed[prev]) != hipSuccess) || (ss.in_flight[slot] && hipEventQuery(ss.landed[slot]) != hipSuccess)) { ss.dropped++; return NH_OK; }
+	const size_t bytes = sizeof(nh_Transform) * (size_t)ss.count;
+	NH_HIP_CHECK(ctx, hipMemcpyAsync(ss.stage, ss.src, bytes, hipMemcpyDeviceToDevice, ctx->stream));          // (behind the step's last kernel on the world's stream)
+	NH_HIP_CHECK(ctx, hipEventRecord(ss.staged, ctx->stream));
+	NH_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->side, ss.staged, 0));
+	NH_HIP_CHECK(ctx, hipMemcpyAsync(ss.ring + (size_t)slot * bytes, ss.stage, bytes, hipMemcpyDeviceToHost, ctx->side));
+	NH_HIP_CHECK(ctx, hipEventRecord(ss.landed[slot], ctx->side));
+	// (the next DEVICE copy into the staging buffer must not overtake this frame's way out: the world's stream waits for `landed` only if it gets there first --
+	// which the in-flight test above has just ruled out for the frames that follow)
+	ss.in_flight[slot] = true; ss.slot_step[slot] = ss.advances; ss.last_slot = (int)slot; ss.frames++; ss.slot_frame[slot] = ss.frames;
+	return NH_OK;
+}
+
+extern "C" int nh_stream_latest(nh_context* ctx, nh_StreamInfo* out) {
+	if (!ctx || !out) return NH_ERR_INVALID;
+	nh_StateStream& ss = ctx->stream_state;
+	out->slot = 0; out->valid = 0; out->step = 0; out->frames = ss.frames; out->dropped = ss.dropped;
+	uint64_t best = 0;          // (frames are numbered from 1 in the order they were taken: the newest that has landed)
+	for (uint32_t k = 0; k < ss.slots; ++k) {
+		if (ss.slot_frame[k] == 0) continue;
+		if (ss.in_flight[k]) { if (hipEventQuery(ss.landed[k]) != hipSuccess) continue; ss.in_flight[k] = false; }
+		if (ss.slot_frame[k] > best) { best = ss.slot_frame[k]; out->slot = k; out->valid = 1; out->step = ss.slot_step[k]; }
+	}
 	return NH_OK;
 }
 

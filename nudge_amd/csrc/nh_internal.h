@@ -240,6 +240,16 @@ struct nh_AsleepState {
 	uint64_t steps;                  // statistics
 };
 
+// state streaming (include/nudge_hip.h: nh_stream_state)
+#define NH_STREAM_MAX_SLOTS 16
+struct nh_StateStream {
+	uint32_t every, slots, count; const nh_Transform* src; char* ring;
+	nh_Transform* stage; uint32_t stage_capacity;                 // device staging copy (the world goes on while the frame travels)
+	hipEvent_t staged, landed[NH_STREAM_MAX_SLOTS]; bool in_flight[NH_STREAM_MAX_SLOTS];
+	uint64_t slot_step[NH_STREAM_MAX_SLOTS], slot_frame[NH_STREAM_MAX_SLOTS];
+	uint64_t advances, frames, dropped; int last_slot;
+};
+
 struct nh_context {
 	int device;
 	hipStream_t stream;
@@ -349,7 +359,9 @@ struct nh_context {
 	nh_StillStep still;
 	nh_AsleepState asleep;
 	uint32_t first_ghost;          // nh_set_first_ghost_body: bodies >= first_ghost are ghosts of a partitioned world (0 = no ownership rule)
+	nh_StateStream stream_state;
 };
+int nh_stream_after_advance(nh_context* ctx);          // nh_advance -> state streaming
 
 // Runs work that an earlier call deferred; every entry point that reads or writes momentum / impulses calls it first.
 // `in_sequence`: the caller is the next call of the sample's step (gravity, read, setup, apply): a still step stays speculative across it; every other

@@ -1981,11 +1981,11 @@ extern "C" int nh_advance(nh_context* ctx, const nh_ActiveBodies* active_bodies,
 		if (ctx->adv.rest)
 			NH_LAUNCH(ctx, "advance_rest", k_advance_rest, nh_grid_for(bodies->count, 256, 2048), 256, ctx->d_state, active_bodies->indices, ctx->adv.body_class, bodies->transforms,
 			          bodies->momentum, bodies->idle_counters, time_step);
-		return NH_OK;
+		return ctx->stream_state.every ? nh_stream_after_advance(ctx) : NH_OK;
 	}
 	NH_LAUNCH(ctx, "advance", k_advance, nh_grid_for(bodies->count, 256, 2048), 256, ctx->d_state, active_bodies->indices, bodies->transforms,
 	          bodies->momentum, bodies->idle_counters, time_step);
-	return NH_OK;
+	return ctx->stream_state.every ? nh_stream_after_advance(ctx) : NH_OK;
 }
 
 // cached impulses of sleeping pairs are kept aside (nudge.cpp:4064-4101); skipped entirely when nothing sleeps (culled = 0 since nh_collide)
@@ -3143,6 +3143,7 @@ static int still_forget_failed(nh_context* ctx, bool advanced, uint32_t voided) 
 	ctx->grav.pending = false; ctx->grav.rest_pending = false; ctx->adv.done = false;
 	ctx->after_collide = false; ctx->gravity_may_overlap = false;
 	if (advanced && ctx->advance_count) ctx->advance_count--;          // (the failed step's nh_advance was counted: the sleep prediction counts real ones)
+	if (advanced && ctx->stream_state.every && ctx->stream_state.advances) ctx->stream_state.advances--;      // (... and so does the state stream: a frame taken there shows the state BEFORE that step, under the number the step run again will give its own)
 	return nh_still_export_cache(ctx);                                 // (the slot cache holds the last step that DID happen: the full solver reads the caller's arrays)
 }
 
@@ -3190,7 +3191,7 @@ extern "C" int nh_step(nh_context* ctx, const nh_StepArgs* a, uint32_t steps) {
 		    a->contacts->sleeping_pairs == ss.lay_contacts.sleeping_pairs && a->active_bodies->indices == ss.lay_active && a->contact_cache->data == ss.cache_data && a->contact_cache->tags == ss.cache_tags && a->contact_cache->features == ss.cache_features) {
 			const int v = nh_asleep_verify(ctx, a->bodies, a->colliders);
 			if (v < 0) { result = -v; break; }
-			if (v == 0) { ctx->asleep.steps += steps - i; i = steps; continue; }
+			if (v == 0) { ctx->asleep.steps += steps - i; if (ctx->stream_state.every) ctx->stream_state.advances += steps - i; i = steps; continue; }          // (no frames: nothing moves)
 			ctx->asleep.streak = 0;
 		}
 		int rc;

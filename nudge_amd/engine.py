@@ -38,7 +38,7 @@ EXPORTS = [
     "nh_set_tag_bits", "nh_set_pair_capacity", "nh_set_option", "nh_bodies_changed", "nh_error_string", "nh_last_hip_error", "nh_collide", "nh_apply_gravity_damping",
     "nh_read_cached_impulses", "nh_write_cached_impulses", "nh_setup_contact_constraints", "nh_apply_impulses",
     "nh_update_cached_impulses", "nh_advance", "nh_contact_impulses_device", "nh_enable_timing", "nh_set_timing_filter", "nh_kernel_times",
-    "nh_halo_pack", "nh_halo_unpack", "nh_halo_update", "nh_append_contacts", "nh_step",
+    "nh_halo_pack", "nh_halo_unpack", "nh_halo_update", "nh_append_contacts", "nh_step", "nh_stream_state", "nh_stream_latest",
     "nh_partition_create", "nh_partition_destroy", "nh_partition_info", "nh_partition_pack_migrants", "nh_partition_unpack_migrants", "nh_partition_pack_ghosts",
     "nh_partition_top_speed", "nh_partition_set_peer_speeds", "nh_partition_unpack_ghosts", "nh_partition_pack_step", "nh_partition_unpack_step", "nh_partition_choose_cut", "nh_partition_set_cut",
     "nh_partition_set_transport", "nh_partition_exchange_step", "nh_partition_transport_check", "nh_partition_transport_result", "nh_set_first_ghost_body",
@@ -138,6 +138,8 @@ def lib():
         L.nh_synchronize.argtypes = [C.c_void_p]
         L.nh_read_counts.argtypes = [C.c_void_p, C.POINTER(Counts)]
         L.nh_export_views.argtypes = [C.c_void_p, C.c_uint32]
+        L.nh_stream_state.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
+        L.nh_stream_latest.argtypes = [C.c_void_p, C.POINTER(StreamInfo)]
         L.nh_set_cache_count.argtypes = [C.c_void_p, C.c_uint32]
         L.nh_error_string.argtypes = [C.c_int]
         L.nh_error_string.restype = C.c_char_p
@@ -188,6 +190,10 @@ def lib():
 
 class NudgeError(RuntimeError):
     pass
+
+
+class StreamInfo(C.Structure):
+    _fields_ = [("slot", C.c_uint32), ("valid", C.c_uint32), ("step", C.c_uint64), ("frames", C.c_uint64), ("dropped", C.c_uint64)]
 
 
 def _check(L, rc, what):
@@ -499,6 +505,27 @@ class World:
         off = ptr - self.arena_t.data_ptr()
         raw = self.arena_t[off:off + 16 * n].cpu().numpy().tobytes()
         return np.frombuffer(raw, dtype=S.IMPULSE, count=n).copy()
+
+    # ---- state streaming (include/nudge_hip.h: nh_stream_state): body transforms into a pinned host ring every `every` steps, without stopping the world ----
+    def stream_state(self, every, slots=4, count=None):
+        torch = self.torch
+        n = self.nb if count is None else count
+        if every:
+            self._stream_ring = torch.zeros((slots, n * 32), dtype=torch.uint8).pin_memory()
+            self._stream_count = n
+            _check(self.L, self.L.nh_stream_state(self.ctx, C.byref(self.bodies), n, C.c_void_p(self._stream_ring.data_ptr()), slots, every), "nh_stream_state")
+        else:
+            _check(self.L, self.L.nh_stream_state(self.ctx, None, 0, None, 0, 0), "nh_stream_state")
+
+    def stream_latest(self):
+        """(step, transforms) of the newest frame that has landed in the ring, or None; plus the stream's counters."""
+        info = StreamInfo()
+        _check(self.L, self.L.nh_stream_latest(self.ctx, C.byref(info)), "nh_stream_latest")
+        stats = dict(frames=int(info.frames), dropped=int(info.dropped))
+        if not info.valid:
+            return None, stats
+        raw = self._stream_ring[info.slot].numpy().tobytes()
+        return (int(info.step), np.frombuffer(raw, dtype=S.TRANSFORM, count=self._stream_count).copy()), stats
 
     # ---- measurement ----
     def enable_timing(self, on=True, only=None):

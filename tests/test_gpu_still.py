@@ -425,3 +425,32 @@ def test_whatever_the_caller_changes_while_the_world_sleeps_is_seen():
     c2 = a.counts()
     assert c2["active_bodies"] == 0 and c2["asleep_steps"] > c1["asleep_steps"]
     a.close(); b.close()
+
+
+# ---- state streaming (include/nudge_hip.h: nh_stream_state): the GL-free viewer hook ------------------------------------------------------------------------------
+def test_state_stream_delivers_the_transforms_of_the_steps_it_names():
+    """Every 5th sub-step the body transforms travel into a pinned host ring without the world waiting for them.  Whatever frame `nh_stream_latest` hands out must be
+    the transforms a second world has after exactly that many steps -- through full steps (fall, landing), still steps and the asleep steps (which take no frames:
+    nothing moves) -- and the world itself must end in the bits of one that streams nothing."""
+    scene = S.grid_tiles(1, side=24, seed=83)
+    a, b, ref = _world(scene, True), _world(scene, True), _world(scene, True)
+    a.stream_state(every=5, slots=4)
+    done, seen = 0, 0
+    for more in (7, 30, 33, 60, 41, 200, 120):
+        a.step(more); b.step(more); done += more
+        a.synchronize()
+        frame, stats = a.stream_latest()
+        assert frame is not None, stats
+        step, xf = frame
+        assert step % 5 == 0 and step <= done, (step, done, stats)
+        if step > seen:
+            ref.step(step - seen); seen = step
+            assert P.bits_equal(xf, ref.get_bodies()["transforms"]), f"frame of step {step} (world at {done})"
+    _same_world(a, b, "a world that streams its state against one that does not")
+    frame, stats = a.stream_latest()
+    print(f"\n[state stream] {stats['frames']} frames, {stats['dropped']} dropped over {done} steps")
+    assert stats["frames"] >= 40
+    a.stream_state(every=0)
+    a.step(10); b.step(10)
+    _same_world(a, b, "after disarming")
+    a.close(); b.close(); ref.close()
