@@ -137,7 +137,8 @@ struct Rank {
 };
 
 // the slab [lo, hi) of `scene` for `rank`: what nudge_amd/partition.py split_scene() builds (every static collider kept; slots in scene order)
-static void make_rank(Rank& R, const Scene& s, const std::vector<double>& cuts, int rank, int device, hipStream_t stream, uint32_t epoch, double speed_floor, double max_reach, uint32_t min_extra, double slack) {
+static void make_rank(Rank& R, const Scene& s, const std::vector<double>& cuts, int rank, int device, hipStream_t stream, uint32_t epoch, double speed_floor, double max_reach, uint32_t min_extra, double slack,
+                      uint32_t context_flags = NH_FLAG_SINGLE_APPLY | NH_FLAG_FUSED_STEP) {
 	R.rank = rank; R.ranks = (int)cuts.size() + 1;
 	const double lo = rank == 0 ? -HUGE_VAL : cuts[rank - 1], hi = rank + 1 == R.ranks ? HUGE_VAL : cuts[rank];
 	const size_t nb = s.body_xf.size();
@@ -178,7 +179,7 @@ static void make_rank(Rank& R, const Scene& s, const std::vector<double>& cuts, 
 	uint32_t tag_bits = 8; while (tag_bits < 32 && (1ull << tag_bits) <= max_tag) ++tag_bits;
 
 	HIP_OK(hipSetDevice(device));
-	NH_OK_(nh_create(&R.ctx, device, stream, NH_FLAG_SINGLE_APPLY | NH_FLAG_FUSED_STEP));
+	NH_OK_(nh_create(&R.ctx, device, stream, context_flags));
 	NH_OK_(nh_set_tag_bits(R.ctx, tag_bits));
 	R.bodies = { to_device(xf, R.body_capacity), to_device(props, R.body_capacity), to_device(mom, R.body_capacity), to_device(idle, R.body_capacity), n };
 	R.colliders.boxes.tags = to_device(bt, box_cap); R.colliders.boxes.data = to_device(bd, box_cap); R.colliders.boxes.transforms = to_device(bx, box_cap); R.colliders.boxes.count = (uint32_t)bt.size();
@@ -289,7 +290,7 @@ int main(int argc, char** argv) {
 	const int local_ranks = getenv("NUDGE_LOCAL_RANKS") ? atoi(getenv("NUDGE_LOCAL_RANKS")) : 0;
 	const char* scene_path = nullptr; const char* out_path = nullptr; const char* cuts_arg = nullptr;
 	std::vector<const char*> pos;
-	uint32_t epoch = 16, min_extra = 4096; double speed_floor = 1.0, slack = 0.15; bool rebalance = true;
+	uint32_t epoch = 16, min_extra = 4096; double speed_floor = 1.0, slack = 0.15; bool rebalance = true, single_owner = false;
 	for (int i = 1; i < argc; ++i) {
 		if (!strcmp(argv[i], "--scene") && i + 1 < argc) scene_path = argv[++i];
 		else if (!strcmp(argv[i], "--out") && i + 1 < argc) out_path = argv[++i];
@@ -299,6 +300,7 @@ int main(int argc, char** argv) {
 		else if (!strcmp(argv[i], "--min-extra") && i + 1 < argc) min_extra = (uint32_t)atoi(argv[++i]);
 		else if (!strcmp(argv[i], "--slack") && i + 1 < argc) slack = atof(argv[++i]);
 		else if (!strcmp(argv[i], "--no-rebalance")) rebalance = false;
+		else if (!strcmp(argv[i], "--single-owner")) single_owner = true;
 		else pos.push_back(argv[i]);
 	}
 	const int n_ranks = local_ranks > 0 ? local_ranks : world;
@@ -363,7 +365,9 @@ int main(int argc, char** argv) {
 	}
 
 	std::vector<Rank> ranks(local_ranks > 0 ? local_ranks : 1);
-	for (size_t k = 0; k < ranks.size(); ++k) make_rank(ranks[k], scene, cuts, local_ranks > 0 ? (int)k : rank, device, stream, epoch, speed_floor, (double)max_reach, min_extra, slack);
+	// (--single-owner: one nh_apply_impulses call per solver iteration, in the reference's solver order -- neither promise of the fused flags holds)
+	for (size_t k = 0; k < ranks.size(); ++k) make_rank(ranks[k], scene, cuts, local_ranks > 0 ? (int)k : rank, device, stream, epoch, speed_floor, (double)max_reach, min_extra, slack,
+	                                                    single_owner ? (uint32_t)NH_FLAG_EXACT_ORDER : (uint32_t)(NH_FLAG_SINGLE_APPLY | NH_FLAG_FUSED_STEP));
 	const size_t total_bodies = scene.body_xf.size() - 1;
 
 	// NUDGE_RCCL_LOOPBACK=1: per-step records of the first owned bodies to myself through RCCL, written back onto the same bodies (a no-op for the world)
@@ -433,7 +437,51 @@ int main(int argc, char** argv) {
 			NCCL_OK(ncclGroupEnd());
 			NH_OK_(nh_halo_update(R.ctx, &R.bodies, 1, n_loop, loop_in));
 		}
-		for (Rank& R : ranks) local_step(R, scene);
+		if (!single_owner) { for (Rank& R : ranks) local_step(R, scene); continue; }
+		// ---- single ownership of contacts that cross a cut (include/nudge_hip.h: nh_set_first_ghost_body and the per-iteration exchange) ----
+		// EXCHANGE: what a rank's sweeps did to its ghosts goes back to their owners, the owners' momentum goes out to the ghosts, the ghosts are marked
+		auto exchange_iteration = [&]() {
+			for (Rank& R : ranks) {
+				nh_PartitionInfo i; NH_OK_(nh_partition_info(R.part, &i));
+				NH_OK_(nh_partition_pack_deltas(R.part, &R.bodies, R.out[0], R.out[1]));
+				R.out_count[0] = i.ghost_in[0]; R.out_count[1] = i.ghost_in[1]; R.in_count[0] = i.ghost_out[0]; R.in_count[1] = i.ghost_out[1];
+			}
+			exchange(T, ranks, sizeof(nh_BodyMomentum), true);
+			for (Rank& R : ranks) NH_OK_(nh_partition_unpack_deltas(R.part, &R.bodies, R.in[0], R.in[1]));
+			for (Rank& R : ranks) {
+				nh_PartitionInfo i; NH_OK_(nh_partition_info(R.part, &i));
+				NH_OK_(nh_partition_pack_momentum(R.part, &R.bodies, R.out[0], R.out[1]));
+				R.out_count[0] = i.ghost_out[0]; R.out_count[1] = i.ghost_out[1]; R.in_count[0] = i.ghost_in[0]; R.in_count[1] = i.ghost_in[1];
+			}
+			exchange(T, ranks, sizeof(nh_BodyMomentum), true);
+			for (Rank& R : ranks) { NH_OK_(nh_partition_unpack_momentum(R.part, &R.bodies, R.in[0], R.in[1])); NH_OK_(nh_partition_mark_ghosts(R.part, &R.bodies)); }
+		};
+		const float dt = (float)scene.time_step, gravity[3] = { 0.0f, (float)scene.gravity, 0.0f };
+		std::vector<nh_ContactImpulseData*> impulses(ranks.size(), nullptr);
+		std::vector<nh_ContactConstraintData*> constraints(ranks.size(), nullptr);
+		for (size_t k = 0; k < ranks.size(); ++k) {
+			Rank& R = ranks[k];
+			nh_PartitionInfo i; NH_OK_(nh_partition_info(R.part, &i));
+			NH_OK_(nh_set_first_ghost_body(R.ctx, i.n_owned + 1u));
+			nh_Arena temporary = R.arena;
+			NH_OK_(nh_collide(R.ctx, &R.active, &R.contacts, &R.bodies, &R.colliders, &R.connections, temporary));
+			NH_OK_(nh_apply_gravity_damping(R.ctx, &R.active, &R.bodies, dt, gravity, (float)scene.damping_rate));
+			NH_OK_(nh_read_cached_impulses(R.ctx, &R.cache, &R.contacts, &temporary, &impulses[k]));
+			NH_OK_(nh_partition_mark_ghosts(R.part, &R.bodies));          // (the warm start inside setup already moves the ghosts of the contacts owned here)
+			NH_OK_(nh_setup_contact_constraints(R.ctx, &R.active, &R.contacts, &R.bodies, impulses[k], &temporary, &constraints[k]));
+		}
+		exchange_iteration();
+		for (uint32_t it = 0; it < scene.iterations; ++it)
+			for (int phase = 0; phase < 2; ++phase) {          // even ranks sweep, results travel, odd ranks sweep: one Gauss-Seidel sweep of the world in rank-parity order
+				for (size_t k = 0; k < ranks.size(); ++k) if (ranks[k].rank % 2 == phase) NH_OK_(nh_apply_impulses(ranks[k].ctx, constraints[k], &ranks[k].bodies, 1u));
+				exchange_iteration();
+			}
+		for (size_t k = 0; k < ranks.size(); ++k) {
+			Rank& R = ranks[k];
+			NH_OK_(nh_update_cached_impulses(R.ctx, constraints[k], impulses[k]));
+			NH_OK_(nh_write_cached_impulses(R.ctx, &R.cache, &R.contacts, impulses[k]));
+			NH_OK_(nh_advance(R.ctx, &R.active, &R.bodies, dt));
+		}
 	}
 	for (Rank& R : ranks) NH_OK_(nh_synchronize(R.ctx));
 	const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

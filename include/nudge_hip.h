@@ -413,6 +413,20 @@ int nh_partition_set_cut(nh_partition* p, int direction, double cut);
    ghosts (momentum after a sweep minus before) to their owners and refreshes the ghosts from the owners after every nh_apply_impulses(..., 1): nudge_amd/partition.py
    `Partition(per_iteration=True, single_owner=True)`.  0 switches the rule off.  Still steps (note 9) are not launched while it is on. */
 int nh_set_first_ghost_body(nh_context* ctx, uint32_t first_ghost);
+/* ... and the per-iteration exchange that goes with it, behind the C ABI (round 5; the torch form in nudge_amd/partition.py is kept as the independent check).  Records are
+   the 32-byte nh_BodyMomentum; lengths are the ghost lists of the last refresh (nh_partition_info: a rank SENDS ghost_in[side] deltas and ghost_out[side] momentum records
+   to the neighbour on that side and receives the other number), in the neighbour's list order.  One step of a rank (examples/partition_rccl.cpp --single-owner):
+       nh_set_first_ghost_body(n_owned + 1); nh_collide; gravity; nh_read_cached_impulses; nh_partition_mark_ghosts; nh_setup_contact_constraints; EXCHANGE;
+       iterations x { even ranks: nh_apply_impulses(.., 1); EXCHANGE; odd ranks: nh_apply_impulses(.., 1); EXCHANGE }; update; write; advance
+       EXCHANGE = pack_deltas -> transport -> unpack_deltas (owners add what the neighbours' sweeps did to their bodies); pack_momentum -> transport -> unpack_momentum
+                  (ghosts take their owners' momentum); mark_ghosts -- or nh_partition_exchange_iteration, which does all of it over the transport of nh_partition_set_transport.
+   Every call first completes deferred work (note 7), so the warm start is in the momentum the records are taken from. */
+int nh_partition_mark_ghosts(nh_partition* p, const nh_BodyData* bodies);
+int nh_partition_pack_deltas(nh_partition* p, const nh_BodyData* bodies, void* out_left, void* out_right);
+int nh_partition_unpack_deltas(nh_partition* p, const nh_BodyData* bodies, const void* in_left, const void* in_right);
+int nh_partition_pack_momentum(nh_partition* p, const nh_BodyData* bodies, void* out_left, void* out_right);
+int nh_partition_unpack_momentum(nh_partition* p, const nh_BodyData* bodies, const void* in_left, const void* in_right);
+int nh_partition_exchange_iteration(nh_partition* p, const nh_BodyData* bodies);
 
 /* ---- introspection for tests / measurement --------------------------------------------------------- */
 /* Device pointer to the per-contact warm-start impulses of an nh_ContactImpulseData (K x 16 B, contact order). */

@@ -896,7 +896,10 @@ __global__ __launch_bounds__(256) void k_kept_filter(nh_DevState* __restrict__ s
 // four contacts, a pair with contacts joins a dynamic body to the static world and is the one pair that body's solver lane knows (body_rec) -- and raises
 // st->still_fail otherwise: the step is replayed in full.  The record's count goes to its place in the tag order (cnt_sorted): one scan later every record
 // knows where its contacts sit in the dense list.
-template<bool SPH, bool STILL>
+// LOCAL (STILL only; nh_internal.h, "LOCAL speculation"): the form that knows appended pairs (movers) and sleeping bodies (sleepers).  A world in which nobody has left
+// its box lately and nobody can be asleep -- the bench's steady state -- runs the LOCAL = false instantiation: the loop of round 4 (rocprofv3: 91 us at 1 M boxes; the
+// one form with everything in it, measured first: 100.6)
+template<bool SPH, bool STILL, bool LOCAL = false>
 __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ st, const uint2* __restrict__ pairs,
                                                      const nh_xform* __restrict__ xf, const uint32_t* __restrict__ ctag,
                                                      const nh_BoxCollider* __restrict__ box_data, const nh_SphereCollider* __restrict__ sph_data, uint32_t nbox,
@@ -936,7 +939,9 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		mmin = nh_make3(smin.x * mscale, smin.y * mscale, smin.z * mscale);
 		// (the layout must be the last full step's, and the kept list at least as long as the pair list it was written from: what lies behind are pairs APPENDED by
 		// still steps in movers form since -- below)
-		if (blockIdx.x == 0 && threadIdx.x == 0 && (!st->lay_valid || st->fat_count < st->pairs || st->fat_count_sph < st->pairs_sph)) atomicMax(&st->still_failed_seq, seq);
+		// (LOCAL = false: the host launches this form only when no still step in movers form has appended a pair since the layout was written -- checked all the same)
+		if (blockIdx.x == 0 && threadIdx.x == 0 && (!st->lay_valid || (LOCAL ? (st->fat_count < st->pairs || st->fat_count_sph < st->pairs_sph) : (st->fat_count != st->pairs || st->fat_count_sph != st->pairs_sph))))
+			atomicMax(&st->still_failed_seq, seq);
 	}
 	const uint32_t n = SPH ? n_sph : n_bb, first_rec = SPH ? n_bb : 0u;
 	// STILL, LOCAL speculation (nh_internal.h): kept pairs behind the layout's -- appended by k_reinsert for colliders that left their boxes in a still step -- have no
@@ -944,7 +949,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 	// yields a CONTACT they are what a full step would file as records without contacts, which nothing downstream looks at; the first contact fails the step, and the
 	// full step that follows gives every kept pair its record again.
 	uint32_t n_app = 0;
-	if (STILL) {
+	if (STILL && LOCAL) {
 		const uint32_t k_bb = min(st->fat_count, kept_cap), k_sph = min(st->fat_count_sph, kept_cap - k_bb);
 		const uint32_t kc = SPH ? k_sph : k_bb;
 		n_app = kc > n ? kc - n : 0u;
@@ -954,7 +959,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 	// STILL: what the step relies on, per record (see above); the count goes to the record's place in the tag order
 	uint32_t n_sleeping = 0, n_culled = 0;          // sleepers form: this lane's sleeping pairs and the cache entries kept aside for them
 	auto still_record = [&](uint32_t ri, uint64_t key, int count, uint32_t body_a, uint32_t body_b, uint64_t was_key, uint32_t pos, bool vanished, bool sleeping = false) {
-		if (sleeping) {
+		if (LOCAL && sleeping) {
 			// A pair of a sleeping body with the static world: a sleeping pair (nudge.cpp:3669-3703) -- no contact, the pair's word (`key`: larger tag low, 3697) in the
 			// list of sleeping pairs, and its cached impulses kept aside (4064-4101) when the cache's tag -- the contact key on file -- IS that word; otherwise they are
 			// gone, as in the reference.  From now on the record carries the pair's word (the tag order on file no longer matches the keys: a full step sorts again).
@@ -973,7 +978,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			ok = (body_a == 0u) != (body_b == 0u) && (body_rec[dyn] & ~NH_BODY_REC_IS_A) == ri;
 		}
 		if (!ok) { atomicAdd(&st->still_diff[!same_key ? 0 : (count > 4 ? 1 : 2)], 1u); changed = true; }          // (statistics; rare)
-		rec[ri].count = sleeping ? NH_REC_SLEEPING : (uint32_t)count;
+		rec[ri].count = (LOCAL && sleeping) ? NH_REC_SLEEPING : (uint32_t)count;
 		// the record's count in its place of the tag order; a CHANGE is listed (position, difference): the solver lanes shift their first contact by the changes before
 		// them -- a handful per step in a world at rest -- instead of the whole order being scanned again.  Too many for the list: the step fails (delta_overflow)
 		const uint32_t old = cnt_sorted[pos];
@@ -988,7 +993,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 	};
 	uint32_t rounded = (n + n_app + 63u) & ~63u;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rounded; i += gridDim.x * blockDim.x) {
-		const bool live = i < n, app = STILL && !live && i < n + n_app;
+		const bool live = i < n, app = STILL && LOCAL && !live && i < n + n_app;
 		nh_bb_result bb;
 		bb.kind = 0; bb.mask = 0;
 		nh_contact_out single;          // sphere paths produce at most one contact
@@ -1024,7 +1029,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 				if (stamps && hit) hit = (uint32_t)(gen[ca] & 0x7Fu) == (kp.x >> NH_GEN_SHIFT) && (uint32_t)(gen[cb] & 0x7Fu) == (kp.y >> NH_GEN_SHIFT);
 				// sleepers form: k_xform<true> marked the colliders of sleeping bodies (aabb_max.w).  With the static world: a sleeping pair.  Two dynamic bodies with a
 				// sleeping end, or a pair nobody has a record for: the body's set holds more than itself -- not this step's business
-				if (sc_count && hit && (__float_as_uint(amax.w) | __float_as_uint(bmax.w)) != 0u) {
+				if (LOCAL && sc_count && hit && (__float_as_uint(amax.w) | __float_as_uint(bmax.w)) != 0u) {
 					if (app || (__float_as_uint(amin.w) != 0u && __float_as_uint(bmin.w) != 0u)) { changed = true; atomicAdd(&st->still_diff[3], 1u); }
 					else sleeper_pair = true;
 				}
@@ -1039,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			uint32_t a = pr.x, b = pr.y;            // a = later in Morton order
 			bool a_sph = a >= nbox, b_sph = b >= nbox;
 			bool coarse_asleep = invalid || sleeper_pair;
-			if (STILL && sleeper_pair) { const uint32_t ta = TAG(a), tb = TAG(b); key = ta > tb ? ((uint64_t)ta | ((uint64_t)tb << 32)) : ((uint64_t)tb | ((uint64_t)ta << 32)); }
+			if (STILL && LOCAL && sleeper_pair) { const uint32_t ta = TAG(a), tb = TAG(b); key = ta > tb ? ((uint64_t)ta | ((uint64_t)tb << 32)) : ((uint64_t)tb | ((uint64_t)ta << 32)); }
 			if (some_asleep && !invalid) {
 				const uint32_t ba = xf[a].body, bb2 = xf[b].body;
 				const uint32_t set = coarse_root[ba ? ba : bb2];            // sets[a] | sets[b] with sets[0] = 0 (nudge.cpp:3687)
@@ -1085,7 +1090,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 				if (owner >= first_ghost) { count = 0; bb.kind = 0; }
 			}
 			// (an appended pair -- no record -- may overlap, but a contact of it belongs to a layout only a full step can make)
-			if (app) { if (count) { changed = true; atomicAdd(&st->still_diff[1], 1u); } count = 0; bb.kind = 0; bb.mask = 0; }
+			if (LOCAL && app) { if (count) { changed = true; atomicAdd(&st->still_diff[1], 1u); } count = 0; bb.kind = 0; bb.mask = 0; }
 		}
 		if (SPH) {
 			// one contact at most, ONE raw slot per sphere record (they follow the four-slot blocks of the box-box records: slot 4 n_bb + i, so that
@@ -1178,7 +1183,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 	}
 	if (STILL) {
 		if (__ballot(changed) != 0ull && nh_lane() == 0) atomicMax(&st->still_failed_seq, seq);
-		if (sc_count) {
+		if (LOCAL && sc_count) {
 			// sleepers form: the step's sleeping pairs and kept-aside cache entries, one pair of atomics per workgroup that saw any
 			__shared__ uint32_t s_sl[2];
 			if (threadIdx.x < 2u) s_sl[threadIdx.x] = 0u;
@@ -1873,14 +1878,18 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			const uint8_t* gen = incremental ? ctx->fat_gen : (const uint8_t*)nullptr;
 			const bool delta_scan = C > (2u << 20) || sleepers;          // (a world dozing off changes thousands of contact counts per step: the scan, not the list)
 			uint32_t* const sc_count = sleepers ? ctx->sc_count : (uint32_t*)nullptr;
-			if (nbox >= 2)
-				NH_LAUNCH(ctx, "narrowphase_still", (k_narrowphase<false, true>), nh_grid_for(pair_cap, 256, 4096), 256, st, ctx->fat_pairs, xf, ctag,
-				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr,
-				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, sc_count);
-			if (nsph)
-				NH_LAUNCH(ctx, "narrowphase_sph_still", (k_narrowphase<true, true>), nh_grid_for(pair_cap, 256, 8192), 256, st, ctx->fat_pairs, xf, ctag,
-				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr,
-				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, sc_count);
+			// (the LOCAL form of the narrowphase -- appended pairs, sleeping bodies -- only where it can matter: this step or an earlier one since the layout ran in movers
+			// form, or somebody may be asleep)
+			if (movers) ss.appended_pairs = true;
+			const bool local = sleepers || ss.appended_pairs;
+#define NH_NARROW_STILL(SPHERES, NAME, GRIDMAX) do { if (local) NH_LAUNCH(ctx, NAME, (k_narrowphase<SPHERES, true, true>), nh_grid_for(pair_cap, 256, GRIDMAX), 256, st, ctx->fat_pairs, xf, ctag, \
+				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr, \
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, sc_count); \
+				else NH_LAUNCH(ctx, NAME, (k_narrowphase<SPHERES, true, false>), nh_grid_for(pair_cap, 256, GRIDMAX), 256, st, ctx->fat_pairs, xf, ctag, \
+				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr, \
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, (uint32_t*)nullptr); } while (0)
+			if (nbox >= 2) NH_NARROW_STILL(false, "narrowphase_still", 4096);
+			if (nsph) NH_NARROW_STILL(true, "narrowphase_sph_still", 8192);
 			// every record's first contact in the dense (tag-ordered) list = the scan of the counts in tag order: kept from step to step, shifted by the listed changes
 			// (the solver keeps the total).  More pairs changing their count than the list holds: a world of up to two million colliders fails the step (a handful change
 			// per million and step at rest); a larger one runs the scan instead -- two launches that leave at once otherwise, nothing next to its step
@@ -1895,7 +1904,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 	if (ctx->still.verdict.pending && nh_still_verdict_now(ctx)) return NH_INTERNAL_STILL_FAILED;
 	// The solver reads the caller's cache arrays and this nh_collide lays the dense contact list out -- whatever still steps kept by slot goes home first
 	{ int rc = nh_still_export_cache(ctx); if (rc) return rc; }
-	ctx->still.contacts_stale = false; ctx->still.slots_current = false; ctx->still.views_sleepers = false;          // (a full step writes the contact list, the sleeping pairs and the active list itself)
+	ctx->still.contacts_stale = false; ctx->still.slots_current = false; ctx->still.views_sleepers = false; ctx->still.appended_pairs = false;          // (a full step writes the contact list, the sleeping pairs and the active list itself)
 	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, begin_grid, 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity, coarse_parent, coarse_active, no_islands ? 1u : 0u, block_top,
 	          drop_kept ? 1u : 0u, drop_sort_order ? 1u : 0u);
 	const bool seeded_sort = !ctx->env_sort_classic && ctx->sort_seeded && !ctx->env_sort_radix;      // (NH_SORT_RADIX=1: radix passes every step)

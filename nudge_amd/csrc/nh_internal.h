@@ -209,6 +209,7 @@ struct nh_StillStep {
 	// kept list, and the still narrowphase takes a kept pair that has died (stamps) or no longer overlaps as a record without contacts, and the appended pairs as
 	// pairs without a record that must not produce a contact -- a landing is still a full step.  Option "no_local_still": the round-4 behaviour.
 	bool no_local; uint32_t movers_left;
+	bool appended_pairs;            // a still step in movers form has run since the last full step: the kept list may be longer than the layout (the narrowphase's LOCAL form is needed)
 	// SLEEPERS form (round 5).  Still steps needed everybody awake, asleep steps everybody asleep; a world in which SOME bodies sleep paid full steps (~40 launches).  The
 	// reference's rule is per set (nudge.cpp:3575-3703): a body whose AABB overlaps no other dynamic body's forms a set of its own, asleep exactly when its idle counter
 	// is saturated; its pairs with the static world become sleeping pairs (larger tag low, 3697), it is not active (no gravity, no advance), and its cached impulses are

@@ -48,6 +48,8 @@ struct nh_partition {
 	// the ghost margin of a cut covers how far bodies on BOTH its sides travel in an epoch: this rank's top speed before migration (nh_partition_top_speed) and what
 	// the two neighbours reported (nh_partition_set_peer_speeds); consumed by the next nh_partition_pack_ghosts
 	double speed_pre, peer_speed[2];
+	// single ownership of contacts that cross a cut (nh_set_first_ghost_body): the ghosts' momentum as it was at the last nh_partition_mark_ghosts (2 x float4 per ghost)
+	float4* ghost_ref; uint32_t ghost_ref_capacity;
 };
 
 #define NP_CHECK(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (ctx)->last_hip_error = (int)e_; return NH_ERR_HIP; } } while (0)
@@ -302,7 +304,7 @@ extern "C" void nh_partition_destroy(nh_partition* p) {
 	hipSetDevice(p->ctx->device);
 	hipStreamSynchronize(p->ctx->stream);
 	for (int side = 0; side < 2; ++side) { if (p->step_out[side]) hipFree(p->step_out[side]); if (p->step_in[side]) hipFree(p->step_in[side]); }
-	void* bufs[] = { p->shape, p->cxf, p->tag, p->nbx, p->nsp, p->reach, p->list[0], p->list[1], p->flag[0], p->flag[1], p->scan_tmp, p->sort_a, p->sort_b, p->sort_va, p->sort_vb, p->sort_hist, p->stage, p->d };
+	void* bufs[] = { p->shape, p->cxf, p->tag, p->nbx, p->nsp, p->reach, p->list[0], p->list[1], p->flag[0], p->flag[1], p->scan_tmp, p->sort_a, p->sort_b, p->sort_va, p->sort_vb, p->sort_hist, p->stage, p->d, p->ghost_ref };
 	for (void* b : bufs) if (b) hipFree(b);
 	if (p->h) hipHostFree(p->h);
 	delete p;
@@ -522,6 +524,151 @@ static int part_step_buffer(nh_partition* p, int side, int io, uint32_t records)
 	if (hipMalloc(buf, (size_t)cap * NH_HALO_RECORD_BYTES) != hipSuccess) return NH_ERR_HIP;
 	p->step_cap[side][io] = cap;
 	return NH_OK;
+}
+
+// ---- single ownership of contacts that cross a cut: the per-iteration exchange (include/nudge_hip.h; round 5: behind the C ABI) -------------------------------------------
+// With nh_set_first_ghost_body a contact is solved by ONE rank (the owner of the body with the larger collider tag: nudge.cpp:2074-2087, 2131-2132), so a sweep here
+// moves ghosts -- bodies another rank owns.  After every sweep (and after the warm start) what it did to them goes home: delta = momentum now - momentum at the last
+// mark, added to the owner's record; then the owners' momentum goes out to their ghosts again and is marked.  All 32-byte momentum records; lengths are the ghost
+// lists of the last refresh, in the neighbour's list order.  Same arithmetic as nudge_amd/partition.py's torch form (delta_pack / delta_unpack / momentum_pack /
+// momentum_unpack / delta_mark), which stays as the independent check.
+__global__ __launch_bounds__(256) void k_part_mark(uint32_t n, uint32_t at, const nh_BodyMomentum* __restrict__ bm, float4* __restrict__ ref) {
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		const float4* m = reinterpret_cast<const float4*>(bm + at + k);
+		ref[2u * k] = m[0]; ref[2u * k + 1u] = m[1];
+	}
+}
+__global__ __launch_bounds__(256) void k_part_pack_delta(uint32_t n, uint32_t at, uint32_t ref_at, const nh_BodyMomentum* __restrict__ bm, const float4* __restrict__ ref, float4* __restrict__ out) {
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		const float4* m = reinterpret_cast<const float4*>(bm + at + k);
+		const float4 a0 = m[0], a1 = m[1], r0 = ref[2u * (ref_at + k)], r1 = ref[2u * (ref_at + k) + 1u];
+		// (the two spare words of a momentum record are the engine's -- the inverse mass rides there during a solve, nudge.cpp:4358 -- and never travel)
+		out[2u * k] = make_float4(a0.x - r0.x, a0.y - r0.y, a0.z - r0.z, 0.0f);
+		out[2u * k + 1u] = make_float4(a1.x - r1.x, a1.y - r1.y, a1.z - r1.z, 0.0f);
+	}
+}
+__global__ __launch_bounds__(256) void k_part_add_delta(uint32_t n, const uint32_t* __restrict__ list, nh_BodyMomentum* __restrict__ bm, const float4* __restrict__ in) {
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		float4* m = reinterpret_cast<float4*>(bm + list[k]);
+		const float4 d0 = in[2u * k], d1 = in[2u * k + 1u];
+		float4 a0 = m[0], a1 = m[1];
+		a0.x += d0.x; a0.y += d0.y; a0.z += d0.z; a0.w += d0.w; a1.x += d1.x; a1.y += d1.y; a1.z += d1.z; a1.w += d1.w;          // (all eight words, like index_add_: the spare ones get + 0)
+		m[0] = a0; m[1] = a1;
+	}
+}
+__global__ __launch_bounds__(256) void k_part_pack_mom(uint32_t n, const uint32_t* __restrict__ list, const nh_BodyMomentum* __restrict__ bm, float4* __restrict__ out) {
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		const float4* m = reinterpret_cast<const float4*>(bm + list[k]);
+		out[2u * k] = m[0]; out[2u * k + 1u] = m[1];
+	}
+}
+__global__ __launch_bounds__(256) void k_part_unpack_mom(uint32_t n, uint32_t at, nh_BodyMomentum* __restrict__ bm, const float4* __restrict__ in) {
+	for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+		float4* m = reinterpret_cast<float4*>(bm + at + k);
+		m[0] = in[2u * k]; m[1] = in[2u * k + 1u];
+	}
+}
+
+static int part_iteration_enter(nh_partition* p, const nh_BodyData* bodies) {
+	if (!p || !bodies || !bodies->momentum) return NH_ERR_INVALID;
+	nh_context* ctx = p->ctx;
+	NP_CHECK(ctx, hipSetDevice(ctx->device));
+	// (a deferred setup -- rows, warm start: header note 7 -- has to be in the momentum the records are taken from)
+	return nh_flush_pending(ctx);
+}
+
+extern "C" int nh_partition_mark_ghosts(nh_partition* p, const nh_BodyData* bodies) {
+	{ int rc = part_iteration_enter(p, bodies); if (rc) return rc; }
+	nh_context* ctx = p->ctx;
+	const uint32_t n = p->ghost_in[0] + p->ghost_in[1];
+	if (p->ghost_ref_capacity < n) {
+		if (p->ghost_ref) { NP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); NP_CHECK(ctx, hipFree(p->ghost_ref)); }
+		p->ghost_ref = nullptr; p->ghost_ref_capacity = 0;
+		const uint32_t cap = n + n / 4u + 256u;
+		NP_CHECK(ctx, hipMalloc((void**)&p->ghost_ref, sizeof(float4) * 2u * (size_t)cap));
+		p->ghost_ref_capacity = cap;
+	}
+	if (n) NP_LAUNCH("part_mark", k_part_mark, n, n, p->n_owned + 1u, bodies->momentum, p->ghost_ref);
+	return NH_OK;
+}
+
+extern "C" int nh_partition_pack_deltas(nh_partition* p, const nh_BodyData* bodies, void* out_left, void* out_right) {
+	{ int rc = part_iteration_enter(p, bodies); if (rc) return rc; }
+	nh_context* ctx = p->ctx;
+	if (p->ghost_ref_capacity < p->ghost_in[0] + p->ghost_in[1]) return NH_ERR_INVALID;          // (no mark since the ghosts changed)
+	uint32_t at = p->n_owned + 1u, ref_at = 0u;
+	void* out[2] = { out_left, out_right };
+	for (int side = 0; side < 2; ++side) {
+		const uint32_t n = p->ghost_in[side];
+		if (n) { if (!out[side]) return NH_ERR_INVALID; NP_LAUNCH("part_pack_delta", k_part_pack_delta, n, n, at, ref_at, bodies->momentum, p->ghost_ref, (float4*)out[side]); }
+		at += n; ref_at += n;
+	}
+	return NH_OK;
+}
+
+extern "C" int nh_partition_unpack_deltas(nh_partition* p, const nh_BodyData* bodies, const void* in_left, const void* in_right) {
+	{ int rc = part_iteration_enter(p, bodies); if (rc) return rc; }
+	nh_context* ctx = p->ctx;
+	const void* in[2] = { in_left, in_right };
+	for (int side = 0; side < 2; ++side) {          // (left neighbour's first, then the right one's: a body listed for both gets the two sums in this order)
+		const uint32_t n = p->ghost_out[side];
+		if (n) { if (!in[side]) return NH_ERR_INVALID; NP_LAUNCH("part_add_delta", k_part_add_delta, n, n, p->list[side], bodies->momentum, (const float4*)in[side]); }
+	}
+	return NH_OK;
+}
+
+extern "C" int nh_partition_pack_momentum(nh_partition* p, const nh_BodyData* bodies, void* out_left, void* out_right) {
+	{ int rc = part_iteration_enter(p, bodies); if (rc) return rc; }
+	nh_context* ctx = p->ctx;
+	void* out[2] = { out_left, out_right };
+	for (int side = 0; side < 2; ++side) {
+		const uint32_t n = p->ghost_out[side];
+		if (n) { if (!out[side]) return NH_ERR_INVALID; NP_LAUNCH("part_pack_mom", k_part_pack_mom, n, n, p->list[side], bodies->momentum, (float4*)out[side]); }
+	}
+	return NH_OK;
+}
+
+extern "C" int nh_partition_unpack_momentum(nh_partition* p, const nh_BodyData* bodies, const void* in_left, const void* in_right) {
+	{ int rc = part_iteration_enter(p, bodies); if (rc) return rc; }
+	nh_context* ctx = p->ctx;
+	const void* in[2] = { in_left, in_right };
+	uint32_t at = p->n_owned + 1u;
+	for (int side = 0; side < 2; ++side) {
+		const uint32_t n = p->ghost_in[side];
+		if (n) { if (!in[side]) return NH_ERR_INVALID; NP_LAUNCH("part_unpack_mom", k_part_unpack_mom, n, n, at, bodies->momentum, (const float4*)in[side]); }
+		at += n;
+	}
+	return NH_OK;
+}
+
+static int part_step_buffer(nh_partition* p, int side, int io, uint32_t records);
+// The whole exchange of one solver iteration driven by the library over the transport of nh_partition_set_transport, in ONE call: deltas of the ghosts back to their
+// owners, the owners' momentum out to the ghosts, the ghosts marked -- two RCCL groups on the context's stream, no host synchronisation.
+extern "C" int nh_partition_exchange_iteration(nh_partition* p, const nh_BodyData* bodies) {
+	if (!p || !bodies || !p->rccl.comm) return NH_ERR_INVALID;
+	nh_context* ctx = p->ctx;
+	for (int side = 0; side < 2; ++side) {
+		const uint32_t most = p->ghost_out[side] > p->ghost_in[side] ? p->ghost_out[side] : p->ghost_in[side];
+		if (most) { int rc = part_step_buffer(p, side, 0, most); if (rc) return rc; rc = part_step_buffer(p, side, 1, most); if (rc) return rc; }
+	}
+	for (int pass = 0; pass < 2; ++pass) {
+		// pass 0: deltas -- this rank sends what it did to the neighbour's bodies (its ghosts from that side) and receives what the neighbour did to the bodies listed for it;
+		// pass 1: momentum -- the listed bodies go out, the ghosts come in
+		{ int rc = pass == 0 ? nh_partition_pack_deltas(p, bodies, p->step_out[0], p->step_out[1]) : nh_partition_pack_momentum(p, bodies, p->step_out[0], p->step_out[1]); if (rc) return rc; }
+		int nccl_rc = p->rccl.group_start();
+		if (nccl_rc) { ctx->last_hip_error = -nccl_rc; return NH_ERR_HIP; }
+		for (int side = 0; side < 2 && !nccl_rc; ++side) {
+			const int peer = p->rccl.peer[side];
+			if (peer < 0) continue;
+			const uint32_t n_out = pass == 0 ? p->ghost_in[side] : p->ghost_out[side], n_in = pass == 0 ? p->ghost_out[side] : p->ghost_in[side];
+			if (n_out) nccl_rc = p->rccl.send(p->step_out[side], (size_t)n_out * 32u, 1 /* ncclUint8 */, peer, p->rccl.comm, ctx->stream);
+			if (!nccl_rc && n_in) nccl_rc = p->rccl.recv(p->step_in[side], (size_t)n_in * 32u, 1, peer, p->rccl.comm, ctx->stream);
+		}
+		{ const int end_rc = p->rccl.group_end(); if (!nccl_rc) nccl_rc = end_rc; }
+		if (nccl_rc) { ctx->last_hip_error = -nccl_rc; return NH_ERR_HIP; }
+		{ int rc = pass == 0 ? nh_partition_unpack_deltas(p, bodies, p->step_in[0], p->step_in[1]) : nh_partition_unpack_momentum(p, bodies, p->step_in[0], p->step_in[1]); if (rc) return rc; }
+	}
+	return nh_partition_mark_ghosts(p, bodies);
 }
 
 // pack -> ncclGroupStart; ncclSend / ncclRecv with both neighbours; ncclGroupEnd -> unpack, all on the context's stream, lengths those of the last refresh

@@ -943,7 +943,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		if (CONTIG && !STILL) sp = simple[xc];
 		if (FUSED && !STILL) h = hint[xc];
 		uint32_t br = NH_BODY_REC_NONE, bpos = 0u, idle0 = 0u;
-		if (STILL) { br = sv.body_rec[xc]; bpos = sv.body_pos[xc]; if (CONTIG && (fs.bits & 2u)) idle0 = fs.idle[xc]; }
+		if (STILL) { br = sv.body_rec[xc]; bpos = sv.body_pos[xc]; if (CONTIG && (fs.bits & 4u)) idle0 = fs.idle[xc]; }          // (bit 2 of fs.bits: sleepers form -- somebody may be asleep)
 		if (!inert_word) return;
 		// (STILL: a body asleep -- only a step in sleepers form gets this far with one -- is nobody's: no gravity, no contacts, no advance, nothing stored; nudge.cpp:3669-3703, 4896-4898)
 		const bool mine = STILL ? (x >= 1u && x < nbodies && idle0 != 0xffu) : (x < nbodies && (my_class == cls_a || my_class == cls_b));
@@ -1024,7 +1024,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			m0 = reinterpret_cast<const float4*>(momentum + x)[0]; m1 = reinterpret_cast<const float4*>(momentum + x)[1];
 			pr = *reinterpret_cast<const float4*>(props + x);
 			t0 = reinterpret_cast<const float4*>(xf + x)[0]; t1 = reinterpret_cast<const float4*>(xf + x)[1];
-			if (CONTIG && (fs.bits & 2u)) idle_early = STILL ? idle0 : fs.idle[x];
+			if (CONTIG && (fs.bits & 2u)) idle_early = (STILL && (fs.bits & 4u)) ? idle0 : fs.idle[x];
 			if (CONTIG && (fs.bits & 1u)) {          // NH_FLAG_FUSED_STEP: gravity / damping (k_gravity) on the way in
 				float vel[3] = { m0.x, m0.y, m0.z }, ang[3] = { m1.x, m1.y, m1.z };
 				nh_gravity_damping(vel, ang, fs.gx_dt, fs.gy_dt, fs.gz_dt, fs.damping);
@@ -2723,7 +2723,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 			nh_StillView sv = { ctx->body_rec, ctx->body_pos, ctx->cnt_sorted, ctx->start_sorted, ctx->raw_feature, ctx->sc_feat, ctx->sc_count, ctx->lay_capacity, ctx->still_delta, ctx->step_parity };
 			nh_FusedStep fs = nh_FusedStep();
 			fs.gx_dt = ctx->grav.gx_dt; fs.gy_dt = ctx->grav.gy_dt; fs.gz_dt = ctx->grav.gz_dt; fs.damping = ctx->grav.damping; fs.time_step = ctx->grav.time_step;
-			fs.bits = 3u; fs.idle = bodies->idle_counters; fs.seq = ctx->collide_seq;
+			fs.bits = 3u | (ss.sleepers ? 4u : 0u); fs.idle = bodies->idle_counters; fs.seq = ctx->collide_seq;
 			fs.guard_seq = ss.verdict.pending ? ss.verdict.seq : ctx->collide_seq;          // (a solver behind an unconfirmed still step leaves when THAT one failed)
 #define NH_SOLVE_STILL(NWAVES) NH_LAUNCH(ctx, "solve_still", (k_solve_one_body<4, true, true, NWAVES, true>), (B + 64u * NWAVES - 1u) / (64u * NWAVES), 64 * NWAVES, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum, \
 		          (float4*)d->states, iterations, ctx->raw_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fs, sv)

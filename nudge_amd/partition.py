@@ -232,8 +232,10 @@ class Partition:
         self.ghost_in = {-1: 0, +1: 0}             # ghost records received from the left / right neighbour
         self.steps = 0
         self.stats = dict(refreshes=0, migrated_out=0, migrated_in=0, ghosts=0, late_bodies=0, step_bytes=0, refresh_bytes=0, cut_moves=0)
-        # (the per-iteration momentum exchange is a torch-side experiment on top of the lists this class keeps: it stays on the torch implementation)
-        if not force_torch and not per_iteration and hasattr(engine, "L") and hasattr(engine, "ctx") and hasattr(engine.L, "nh_partition_create"):
+        # (round 5: the per-iteration exchange of single ownership is behind the C ABI too -- nh_partition_mark_ghosts / pack_deltas / ... -- so the HIP engine takes the
+        # C-ABI path in every mode; force_torch=True keeps the torch implementation, the independent check)
+        self.force_torch = force_torch
+        if not force_torch and hasattr(engine, "L") and hasattr(engine, "ctx") and hasattr(engine.L, "nh_partition_create"):
             self._hip_create(info)
 
     # ---- the HIP engine: every operation is a C-ABI call (include/nudge_hip.h "multi-GPU"); this class moves message buffers ---------------------------------
@@ -643,12 +645,46 @@ class Partition:
         at = self.n_owned + 1
         return at, at + self.ghost_in[-1] + self.ghost_in[+1]
 
+    # (round 5: behind the C ABI -- nh_partition_mark_ghosts / pack_deltas / unpack_deltas / pack_momentum / unpack_momentum -- when the engine is the HIP world; the
+    # torch form below is the same arithmetic and stays as the independent check: Partition(force_torch=True), and the reference-engine clusters of the tests)
+    def _hip_iter(self):
+        return self.hip is not None and not self.force_torch
+
+    def _hip_pair(self, fn, what, sizes, incoming=None):
+        """One of the four pack / unpack entry points: `sizes` records of 32 bytes per side; returns {d: tensor} for a pack."""
+        import ctypes as C
+        from . import engine as E
+        t = self.torch
+        dev = self.bt.device
+        bufs = {}
+        for d in (-1, +1):
+            if incoming is None:
+                bufs[d] = t.empty((sizes[d], 32), dtype=t.uint8, device=dev) if d in self.neighbours() else None
+            else:
+                r = incoming.get(d) if d in self.neighbours() else None
+                bufs[d] = r.contiguous().to(dev) if (r is not None and sizes[d]) else None
+                if bufs[d] is not None:
+                    assert bufs[d].numel() == 32 * sizes[d], (what, d, bufs[d].shape, sizes[d])
+        ptr = lambda d: C.c_void_p(bufs[d].data_ptr() if (bufs[d] is not None and bufs[d].numel()) else 0)      # noqa: E731
+        E._check(self.e.L, fn(self.hip, C.byref(self.e.bodies), ptr(-1), ptr(+1)), what)
+        self._iter_keep = bufs                   # (the kernels are enqueued: keep the message tensors alive until the next call)
+        return {d: b for d, b in bufs.items() if b is not None} if incoming is None else None
+
     def delta_mark(self):
+        if self._hip_iter():
+            import ctypes as C
+            from . import engine as E
+            E._check(self.e.L, self.e.L.nh_partition_mark_ghosts(self.hip, C.byref(self.e.bodies)), "nh_partition_mark_ghosts")
+            return
         a, b = self._ghost_span()
         self._ghost_ref = self.bm[a:b].clone()
 
     def delta_pack(self):
         """Per neighbour: momentum of its bodies' ghosts here now minus at the last delta_mark() (8 floats per ghost, in the order of the neighbour's list)."""
+        if self._hip_iter():
+            out = self._hip_pair(self.e.L.nh_partition_pack_deltas, "nh_partition_pack_deltas", {d: self.ghost_in[d] for d in (-1, +1)})
+            self.stats["step_bytes"] += sum(int(v.numel()) for v in out.values())
+            return out
         t = self.torch
         a, b = self._ghost_span()
         d = self.bm[a:b].contiguous().view(t.float32) - self._ghost_ref.contiguous().view(t.float32)
@@ -662,6 +698,9 @@ class Partition:
 
     def delta_unpack(self, incoming):
         """Adds the neighbours' deltas to the bodies listed for them (ghost_out[d] is the order the neighbour holds their ghosts in)."""
+        if self._hip_iter():
+            self._hip_pair(self.e.L.nh_partition_unpack_deltas, "nh_partition_unpack_deltas", {d: (len(self.ghost_out[d]) if self.ghost_out.get(d) is not None else self._ghost_out_n(d)) for d in (-1, +1)}, incoming)
+            return
         t = self.torch
         bmf = self.bm.view(t.float32)
         for d in self.neighbours():
@@ -674,7 +713,18 @@ class Partition:
     def sweep(self):
         self.e.apply(1)
 
+    def _ghost_out_n(self, d):
+        """How many of my bodies are listed for neighbour d (the HIP partition keeps the lists on the device: nh_partition_info)."""
+        if self.hip is not None:
+            i = self._hip_info()
+            return int(i.ghost_out[0 if d < 0 else 1])
+        return int(len(self.ghost_out[d])) if self.ghost_out.get(d) is not None else 0
+
     def momentum_pack(self):
+        if self._hip_iter():
+            out = self._hip_pair(self.e.L.nh_partition_pack_momentum, "nh_partition_pack_momentum", {d: self._ghost_out_n(d) for d in (-1, +1)})
+            self.stats["step_bytes"] += sum(int(v.numel()) for v in out.values())
+            return out
         out = {}
         for d in self.neighbours():
             rec = self.bm[self.ghost_out[d]]
@@ -683,6 +733,9 @@ class Partition:
         return out
 
     def momentum_unpack(self, incoming):
+        if self._hip_iter():
+            self._hip_pair(self.e.L.nh_partition_unpack_momentum, "nh_partition_unpack_momentum", {d: self.ghost_in[d] for d in (-1, +1)}, incoming)
+            return
         at = self.n_owned + 1
         for d in (-1, +1):
             m = self.ghost_in[d]
@@ -1038,7 +1091,7 @@ class DistCluster:
             if p.per_iteration:
                 def exchange():
                     if p.single_owner:
-                        p.delta_unpack(self._exchange(p.delta_pack(), 32, known_counts={d: int(len(p.ghost_out[d])) if p.ghost_out[d] is not None else 0 for d in p.neighbours()}))
+                        p.delta_unpack(self._exchange(p.delta_pack(), 32, known_counts={d: p._ghost_out_n(d) for d in p.neighbours()}))
                     p.momentum_unpack(self._exchange(p.momentum_pack(), 32, known_counts={d: p.ghost_in[d] for d in p.neighbours()}))
                     if p.single_owner:
                         p.delta_mark()

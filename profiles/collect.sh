@@ -4,7 +4,7 @@
 #   two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass on gfx950), one SQ wave-state pass and the one-GPU rehearsal of the N = 2 path.
 # Raw output goes to gpurun_out/<tag>/ (scratch); the summaries are exported into gpurun_out/<tag>/export/ ready to be copied to profiles/.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O/export
@@ -17,7 +17,7 @@ timeout 400 python $R/bench.py --scene pit --no-cpu --steps 10 --profile-kernels
 python $R/bench.py --gpus 1 --tiles 1984 --steps 20 --warmup 5 --profile-kernels > $O/export/${TAG}_bench_c5_single_gpu_16M.json 2> $O/export/${TAG}_bench_c5_single_gpu_16M_kernel_table.log
 python $R/bench.py --gpus 1 --tiles 248 --steps 20 --warmup 5 --no-cpu --no-full-window > $O/export/${TAG}_bench_248_tiles_single_gpu.json 2> $O/bench_248.err
 # the partitioned code path with ONE rank under torch.distributed.run, backend nccl: the library-driven RCCL transport checked by a loop-back, per-step host cost of the path
-NUDGE_BENCH_LOOPBACK=1 NUDGE_BENCH_LOOPBACK_RECORDS=0 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 $R/bench.py --gpus 1 --steps 100 --warmup 5 --tiles 248 --no-cpu 2> $O/loop.err | grep "^{" > $O/export/${TAG}_bench_one_rank_partition_path_rccl.json
+NUDGE_BENCH_LOOPBACK=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 $R/bench.py --gpus 1 --steps 100 --warmup 5 --tiles 248 --no-cpu 2> $O/loop.err | grep "^{" > $O/export/${TAG}_bench_one_rank_partition_path_rccl.json
 NH_NO_BLOCKS=1 timeout 400 python $R/bench.py --scene pit --no-cpu --steps 10 --min-time 1 > $O/export/${TAG}_bench_c4_per_colour_launches.json 2> $O/c4_noblocks.err
 # rocprofv3: kernel trace + stats of the driver's invocation
 rocprofv3 --kernel-trace --stats -d $O/prof -o stats -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-full-window > $O/prof_bench.json 2> $O/prof.log

@@ -254,3 +254,47 @@ def test_cpp_partition_host_matches_the_python_host_bit_for_bit(tmp_path, sphere
         assert sum(p.stats["migrated_out"] for p in parts) > 0
     for q in parts:
         q.close(); q.e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["planks", "heap"])
+def test_cpp_partition_host_with_single_ownership_matches_the_python_host_bit_for_bit(tmp_path, which):
+    """examples/partition_rccl.cpp --single-owner: the C++ host drives the contact-ownership rule of SURVEY 8(e) (nudge.cpp:2074-2087, 2131-2132) and its per-iteration
+    exchange entirely through the C ABI -- nh_set_first_ghost_body, nh_partition_mark_ghosts / pack_deltas / unpack_deltas / pack_momentum / unpack_momentum, one
+    nh_apply_impulses(.., 1) per iteration and rank parity.  Two ranks in one process on one GPU against nudge_amd/partition.py's LocalCluster over the same entry points
+    (which tests/test_gpu_partition.py pins to the reference engine bit for bit): planks lying across the cut, a heap forming across it."""
+    import numpy as np
+    import partition_util as PU
+    import parity_util as P
+    from nudge_amd import engine as E, partition as PT, scenes as S
+    assert os.path.exists(CU.PARTITION_RCCL), "nudge_amd/partition_rccl missing: make -C nudge_amd/csrc"
+    if which == "planks":
+        scene, cut, steps = S.bridge(3), 0.0, 90
+    else:
+        scene = S.pile(n_boxes=120, n_spheres=0, seed=3)
+        scene["body_transforms"]["position"][1:, 1] *= 0.08
+        scene["body_transforms"]["position"][1:, 1] += 1.0
+        cut, steps = 0.3, 80
+    scene_file, out_file = str(tmp_path / "scene.bin"), str(tmp_path / "owned.bin")
+    PU.write_scene_file(scene, scene_file)
+    env = dict(os.environ, NUDGE_LOCAL_RANKS="2", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([CU.PARTITION_RCCL, "--scene", scene_file, "--cuts", repr(cut), "--out", out_file, "--min-extra", "512", "--epoch", "8", "--single-owner", str(steps)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = PU.read_owned_file(out_file)
+    parts = []
+    for rk in range(2):
+        local, info = PT.split_scene(scene, [cut], rk, min_extra=512)
+        w = E.World(local, flags=E.NH_FLAG_EXACT_ORDER, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=16 * info["capacity"]["bodies"])
+        parts.append(PT.Partition(w, info, epoch=8, per_iteration=True, single_owner=True))
+        assert parts[-1].hip is not None
+    cl = PT.LocalCluster(parts)
+    cl.step(steps)
+    ref = cl.gather()
+    assert np.array_equal(got["ids"], ref["ids"]) and np.array_equal(got["ids"], np.arange(1, len(scene["body_transforms"])))
+    assert P.bits_equal(got["transforms"]["position"], ref["transforms"]["position"]) and P.bits_equal(got["transforms"]["rotation"], ref["transforms"]["rotation"])
+    assert P.bits_equal(got["momentum"]["velocity"], ref["momentum"]["velocity"]) and P.bits_equal(got["momentum"]["angular_velocity"], ref["momentum"]["angular_velocity"])
+    assert sum(p.stats["ghosts"] for p in parts) > 0
+    for q in parts:
+        assert q.e.counts()["error"] == 0
+        q.close(); q.e.close()

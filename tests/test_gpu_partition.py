@@ -292,7 +292,8 @@ def test_compound_bodies_across_a_cut_on_the_gpu():
     single.close()
 
 
-def test_single_owner_of_cross_cut_contacts_on_the_gpu_is_the_reference_engine_bit_for_bit():
+@pytest.mark.parametrize("force_torch", [False, True])
+def test_single_owner_of_cross_cut_contacts_on_the_gpu_is_the_reference_engine_bit_for_bit(force_torch):
     """SURVEY 8(e) "determinism rule" on the HIP engine (nh_set_first_ghost_body: nh_collide makes contacts only for the collider pairs a rank owns) under
     Partition(per_iteration=True, single_owner=True): ghost deltas back to the owners, owners' momentum out to the ghosts, even ranks sweeping before odd ones.
     The same two-rank cluster stepped with the compiled reference as every rank's engine (its contact list filtered by the same rule between collide and
@@ -313,7 +314,10 @@ def test_single_owner_of_cross_cut_contacts_on_the_gpu_is_the_reference_engine_b
         for r in range(2):
             local, info = PT.split_scene(scene, [cut], r, min_extra=512)
             w = E.World(local, flags=E.NH_FLAG_EXACT_ORDER, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=16 * info["capacity"]["bodies"])
-            gpu.append(PT.Partition(w, info, epoch=8, per_iteration=True, single_owner=True))
+            # (force_torch=False, round 5: mark / deltas / momentum through nh_partition_mark_ghosts, pack_deltas, unpack_deltas, pack_momentum, unpack_momentum and
+            # the refresh through nh_partition_*; True: the torch implementation of all of it -- both against the reference-engine cluster)
+            gpu.append(PT.Partition(w, info, epoch=8, per_iteration=True, single_owner=True, force_torch=force_torch))
+            assert (gpu[-1].hip is None) == force_torch
             cpu.append(PT.Partition(PU.OracleEngine(local, info["capacity"]), info, epoch=8, per_iteration=True, single_owner=True))
         cg, cc = PT.LocalCluster(gpu), PT.LocalCluster(cpu)
         done = 0

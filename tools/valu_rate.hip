@@ -39,6 +39,69 @@ __global__ __launch_bounds__(64) void k_chain(float* out, unsigned long long* cy
 }
 
 static size_t g_lds = 0;          // dynamic LDS per 64-thread workgroup (0: none): what LDS footprint still lets `waves_per_simd` waves share a SIMD?
+// the same for other instructions of the solver's mix (static counts in the still solver: 3520 v_mul_f32, 1520 v_add_f32, 1248 v_fmac_f32, 908 v_fma_f32, 720 v_sub_f32,
+// 860 v_cndmask_b32): OP 0 v_mul_f32 (VOP2), 1 v_add_f32 (VOP2), 2 v_fmac_f32 (VOP2, accumulates into its destination), 3 v_cndmask_b32 (VOP2 reading VCC), 4 v_fma_f32 with
+// three DIFFERENT source registers besides the chain (VOP3), 5 an alternation mul / add / fmac / fma like the sweep's
+template<int CHAINS, int OP>
+__global__ __launch_bounds__(64) void k_mix(float* out, unsigned long long* cycles, int iters, float a, float b) {
+	float x[CHAINS], y[CHAINS];
+#pragma unroll
+	for (int c = 0; c < CHAINS; ++c) { x[c] = (float)threadIdx.x * 1e-3f + c; y[c] = 1.0f + c; }
+	float a2 = a * 1.0001f, b2 = b * 0.5f;
+	unsigned long long smask = __ballot(a > b);
+	asm volatile("v_cmp_gt_f32 vcc, %0, %1" :: "v"(a), "v"(b) : "vcc");
+	for (int it = 0; it < iters; ++it) {
+#pragma unroll
+		for (int u = 0; u < 32; ++u) {
+#pragma unroll
+			for (int c = 0; c < CHAINS; ++c) {
+				if (OP == 0) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[c]) : "v"(a));
+				else if (OP == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[c]) : "v"(b));
+				else if (OP == 2) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(b));
+				else if (OP == 3) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[c]) : "v"(a));
+				else if (OP == 6) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x[c]) : "v"(a));
+				else if (OP == 7) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a), "s"(smask));
+				else if (OP == 8) asm volatile("v_max_f32 %0, %0, %1" : "+v"(x[c]) : "v"(b));
+				else if (OP == 9) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(x[c]) : "v"(y[c]), "v"(a));
+				else if (OP == 10) { asm volatile("v_cmp_gt_f32 vcc, %0, %1" :: "v"(x[c]), "v"(b) : "vcc"); asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x[c]) : "v"(a) : "vcc"); }
+				else if (OP == 11) asm volatile("v_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(x[c]) : "v"(a), "v"(b));
+				else if (OP == 4) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[c]) : "v"((u & 1) ? a : a2), "v"((u & 2) ? b : b2));
+				else {
+					if ((u & 3) == 0) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[c]) : "v"(a));
+					else if ((u & 3) == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[c]) : "v"(b));
+					else if ((u & 3) == 2) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(x[c]) : "v"(a), "v"(y[c]));
+					else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a2), "v"(b2));
+				}
+			}
+		}
+	}
+	float s = 0.0f;
+#pragma unroll
+	for (int c = 0; c < CHAINS; ++c) s += x[c];
+	out[blockIdx.x * 64 + threadIdx.x] = s;
+	if (threadIdx.x == 0) cycles[blockIdx.x] = 0;
+}
+
+template<int CHAINS, int OP>
+static void run_mix(int waves_per_simd, int iters) {
+	static const char* names[] = { "v_mul_f32   ", "v_add_f32   ", "v_fmac_f32  ", "v_cndmask   ", "v_fma 3 src ", "mul/add/fmac/fma", "v_cndmask_e32 vcc", "v_cndmask_e64 sgpr", "v_max_f32   ", "v_bfi_b32   ",
+	                               "v_cmp + v_cndmask (2 instr)", "v_cndmask_e32, no dependence" };
+	const int simds = 256 * 4, blocks = simds * waves_per_simd;
+	float* out; unsigned long long* cyc;
+	hipMalloc((void**)&out, sizeof(float) * 64 * blocks); hipMalloc((void**)&cyc, sizeof(unsigned long long) * blocks);
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	hipLaunchKernelGGL((k_mix<CHAINS, OP>), dim3(blocks), dim3(64), 0, 0, out, cyc, 16, 1.0000001f, 1e-7f);
+	hipDeviceSynchronize();
+	hipEventRecord(e0, 0);
+	hipLaunchKernelGGL((k_mix<CHAINS, OP>), dim3(blocks), dim3(64), 0, 0, out, cyc, iters, 1.0000001f, 1e-7f);
+	hipEventRecord(e1, 0);
+	hipDeviceSynchronize();
+	float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+	const double n = (double)iters * 32.0 * CHAINS, us = ms * 1e3;
+	printf("%s chains %d  waves/SIMD %d : %8.1f us  -> %7.1f wave-instr per us per SIMD\n", names[OP], CHAINS, waves_per_simd, us, n * waves_per_simd / us);
+	hipFree(out); hipFree(cyc);
+}
+
 template<int CHAINS, bool PACKED>
 static void run(int waves_per_simd, int iters) {
 	const int simds = 256 * 4, blocks = simds * waves_per_simd;
@@ -73,6 +136,11 @@ int main() {
 	for (int w : { 1, 2, 4 }) run<8, false>(w, iters / 2);
 	for (int w : { 1, 2, 4 }) run<1, true>(w, iters);
 	for (int w : { 1, 2, 4 }) run<4, true>(w, iters);
+	// other instructions of the solver's mix: issue limit (8 chains, 2 waves) and dependent rate (1 chain, 2 and 3 waves)
+	run_mix<8, 0>(2, iters / 2); run_mix<8, 1>(2, iters / 2); run_mix<8, 2>(2, iters / 2); run_mix<8, 3>(2, iters / 8); run_mix<8, 4>(2, iters / 2); run_mix<8, 5>(2, iters / 2);
+	run_mix<8, 6>(2, iters / 8); run_mix<8, 7>(2, iters / 8); run_mix<8, 8>(2, iters / 2); run_mix<8, 9>(2, iters / 2); run_mix<8, 10>(2, iters / 8); run_mix<8, 11>(2, iters / 8); run_mix<1, 6>(2, iters / 8); run_mix<1, 11>(1, iters / 8);
+	run_mix<1, 0>(2, iters); run_mix<1, 2>(2, iters); run_mix<1, 5>(2, iters); run_mix<1, 5>(3, iters); run_mix<1, 5>(4, iters);
+	run_mix<2, 5>(2, iters); run_mix<4, 5>(2, iters);
 	// LDS footprint against residency: three waves per SIMD = 12 workgroups of one wave per CU
 	for (size_t lds : { (size_t)12288, (size_t)13312, (size_t)13568, (size_t)13824, (size_t)15616 }) {
 		g_lds = lds;
