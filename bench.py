@@ -162,6 +162,14 @@ def pmc_traffic(kernel):
 VALU_PEAK_PER_US_PER_SIMD = 810.0
 VALU_DEPENDENT_PER_US_PER_WAVE = 247.0
 SIMDS = 256 * 4
+# ... and by instruction (same log; 8 independent chains, two waves per SIMD): what ONE wave-instruction costs the SIMD's VALU pipe, in microseconds
+VALU_COST_US = {"mul_add_sub_fmac": 1 / 950.0,          # v_mul / v_add / v_sub / v_fmac _f32 (VOP2): 927-984 per us
+                "fma_vop3": 1 / 826.0,                  # v_fma_f32 and other three-operand encodings
+                "mov_minmax_cmp_select": 1 / 560.0,     # v_mov_b32 594, v_max_f32 551, v_bfi_b32 535, v_cndmask_b32 with an SGPR mask 545, v_cmp -> vcc / sgpr 580
+                "rcp_rsq": 1 / 287.0,                   # v_rcp_f32 284, v_rsq_f32 290
+                "select_through_vcc": 1 / 148.0 - 1 / 583.0}      # v_cmp + v_cndmask_b32_e32 reading VCC: 148 pairs per us (the v_cmp is counted above)
+# one sweep of the still solver over a body's four contacts (ISA of k_solve_one_body<4,true,true,1,true>, the loop the landed boxes take: 388 VALU instructions)
+SWEEP_MIX = {"mul_add_sub_fmac": 260, "fma_vop3": 40, "mov_minmax_cmp_select": 64, "rcp_rsq": 12, "select_through_vcc": 12}
 
 
 def valu_ceiling(kernel, launch_ms, waves_per_simd=2):
@@ -176,16 +184,27 @@ def valu_ceiling(kernel, launch_ms, waves_per_simd=2):
     except Exception:
         return None
     rate = per_wave * waves / SIMDS / (launch_ms * 1e3)          # wave-instructions per microsecond and SIMD
-    return {"valu_instructions_per_wave": per_wave, "waves_per_launch": waves, "achieved_wave_instr_per_us_per_simd": rate,
+    # what the instructions cost the VALU pipe, by the measured price of each kind (the sweep's mix stands for the whole kernel: 63 % of its instructions)
+    sweep_us = sum(SWEEP_MIX[k] * VALU_COST_US[k] for k in SWEEP_MIX)
+    per_instr_us = sweep_us / sum(SWEEP_MIX.values())
+    wave_life_us = launch_ms * 1e3 / (waves / (SIMDS * waves_per_simd))
+    parked = k.get("parked_at_waitcnt_share_of_wave_cycles") or 0.0
+    busy_kernel = waves_per_simd * per_wave * per_instr_us / wave_life_us
+    busy_compute_phase = busy_kernel / max(1e-9, 1.0 - parked)
+    return {"valu_pipe_busy_by_instruction_prices": busy_kernel, "valu_pipe_busy_while_the_waves_compute": busy_compute_phase,
+            "price_model": {"sweep_mix": SWEEP_MIX, "us_of_pipe_per_wave_instruction": VALU_COST_US, "pipe_us_per_sweep_and_wave": sweep_us,
+                            "note": "busy = waves per SIMD x instructions per wave x mean price / wave lifetime; 'while the waves compute' divides by the share of the wave's "
+                                    "cycles NOT parked at s_waitcnt (SQ) -- the memory phases at the head and tail of a wave, during which its SIMD partner is mostly parked too"},"valu_instructions_per_wave": per_wave, "waves_per_launch": waves, "achieved_wave_instr_per_us_per_simd": rate,
             "peak_wave_instr_per_us_per_simd": VALU_PEAK_PER_US_PER_SIMD, "valu_frac": rate / VALU_PEAK_PER_US_PER_SIMD,
             "dependent_chain_rate_at_this_occupancy": VALU_DEPENDENT_PER_US_PER_WAVE * waves_per_simd,
             "frac_of_dependent_chain_rate": rate / (VALU_DEPENDENT_PER_US_PER_WAVE * waves_per_simd), "waves_per_simd": waves_per_simd,
             "sq_share_of_wave_cycles": {key: k.get(key + "_share_of_wave_cycles") for key in ("active", "valu", "parked_at_waitcnt", "issue_stall")},
             "source": [os.path.basename(files[-1]), "profiles/r05_valu_rate.log (tools/valu_rate.hip)"],
-            "note": "the kernel issues its VALU instructions at the rate two waves with one dependency chain each reach on this SIMD (frac_of_dependent_chain_rate ~ 1), 0.61 of what "
-                    "the SIMD issues when fed independent FMAs (valu_frac): not HBM-bound (roofline.frac).  A third wave per SIMD was built (168 VGPRs, 12,288 B LDS; resident: "
-                    "SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE 1.49 x) and every wave then ran 1.55 x slower -- 170 us against 153: for THIS instruction stream two waves already take "
-                    "all the SIMD gives (profiles/r05_solver_three_waves_ab.log, tools/experiments/solver_three_waves.py)"}
+            "note": "0.61 of what the SIMD issues when fed independent FMAs (valu_frac) -- but this kernel's instructions are not FMAs: priced one by one (mov / min / max / "
+                    "compare / select at 1.7 x a multiply, rcp / rsq at 3.3 x, a select through VCC at 6 x) two waves keep the VALU pipe ~0.7 busy over the whole kernel and "
+                    "~1.0 while they compute (valu_pipe_busy_*): the sweeps are VALU-THROUGHPUT bound, the rest of the time both waves of a SIMD sit in their memory phases.  "
+                    "Consistent with the experiment: a third wave per SIMD (168 VGPRs, 12,288 B LDS; resident by PMC, 1.49 x SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE) made every wave "
+                    "1.55 x slower -- 170 us against 153 (profiles/r05_solver_three_waves_ab.log, tools/experiments/solver_three_waves.py).  Not HBM-bound (roofline.frac)"}
 
 
 def pmc_step_total():
@@ -663,11 +682,13 @@ def main():
             elif dominant in ("blk_sweep", "blk_warm"):
                 n_items = n_items / max(1.0, launches_per_step)                                                  # one block colour of one sweep per launch
             bytes_per_launch = per * n_items
-            if args.scene == "pit" and args.side == 160:
-                global PMC_SUFFIX
-                PMC_SUFFIX = "_c4"
-            comparable = world == 1 and ((args.scene == "boxes" and args.tiles == 124) or (args.scene == "pit" and args.side == 160)) and not any(k.startswith("NH_") for k in os.environ)
-            tr, traffic_src = pmc_traffic(dominant) if comparable else (None, None)          # (the committed PMC export describes the default paths of exactly these two scenes)
+            # (one committed PMC export per configuration of profiles/collect.sh: c2 -- no suffix --, c3, c4, and the 16 M-box world of config 5 on one GPU)
+            global PMC_SUFFIX
+            which = {("boxes", 124): "", ("mixed", 248): "_c3", ("boxes", 1984): "_c5"}.get((args.scene, args.tiles)) if args.scene != "pit" else ("_c4" if args.side == 160 else None)
+            comparable = world == 1 and which is not None and not any(k.startswith("NH_") for k in os.environ)
+            if comparable:
+                PMC_SUFFIX = which
+            tr, traffic_src = pmc_traffic(dominant) if comparable else (None, None)          # (the committed PMC exports describe the default paths of exactly these scenes)
             traffic, traffic_raw = tr if tr else (None, None)
             out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": bytes_per_launch / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": bytes_per_launch / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw,
@@ -682,10 +703,10 @@ def main():
                                                   "kernel_ms_per_step: 3 separate steps with events around EVERY launch (each kernel alone on the GPU)"}
             # `bound` stays "hbm": achieved / peak above are the HBM roofline the metric is defined on.  What actually limits a kernel of dependent fp32 arithmetic is
             # said next to it: its VALU issue rate against the SIMD's limit and against the rate of one dependency chain per wave (valu_ceiling)
-            vc = valu_ceiling(dominant, ms) if dominant in ("solve_still", "solve_one_body") else None
+            vc = valu_ceiling(dominant, ms) if (dominant in ("solve_still", "solve_one_body") and comparable and which == "") else None          # (the SQ export describes c2's launches)
             if vc:
                 out["roofline"]["valu"] = vc
-                out["roofline"]["limited_by"] = "VALU dependent-issue latency (see roofline.valu): neither HBM bandwidth nor the SIMD issue limit"
+                out["roofline"]["limited_by"] = "VALU throughput of the sweeps at this kernel's instruction mix (roofline.valu), not HBM bandwidth"
 
         elif dom:
             out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,

@@ -11,7 +11,7 @@ mkdir -p $O/export
 cd /tmp; export TMPDIR=/tmp
 python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/export/${TAG}_bench_driver_invocation.json 2> $O/bench_driver.err
 python $R/bench.py --profile-kernels > $O/export/${TAG}_bench_default.json 2> $O/export/${TAG}_bench_kernel_table.log
-python $R/bench.py --scene mixed --tiles 248 --no-cpu --profile-kernels > $O/export/${TAG}_bench_c3_mixed_2M.json 2> $O/export/${TAG}_bench_c3_kernel_table.log
+python $R/bench.py --scene mixed --tiles 248 --profile-kernels > $O/export/${TAG}_bench_c3_mixed_2M.json 2> $O/export/${TAG}_bench_c3_kernel_table.log
 timeout 400 python $R/bench.py --scene pit --no-cpu --steps 10 --profile-kernels > $O/export/${TAG}_bench_c4_pit_4M_settled.json 2> $O/export/${TAG}_bench_c4_kernel_table.log
 # config 5 as ONE world on one GPU (the denominator of ">= 6 x single-GPU throughput at 8 GPUs") and one rank's load (248 tiles) alone on the GPU
 python $R/bench.py --gpus 1 --tiles 1984 --steps 20 --warmup 5 --profile-kernels > $O/export/${TAG}_bench_c5_single_gpu_16M.json 2> $O/export/${TAG}_bench_c5_single_gpu_16M_kernel_table.log
@@ -43,6 +43,19 @@ if [ -n "$F" ]; then
   D=$(dirname $F); W=$(find $O/pmc -name "WRITE_SIZE_counter_collection.csv" | head -1); [ "$(dirname $W)" != "$D" ] && cp $W $D/
   python $R/profiles/export_pmc.py $D $O/export/${TAG}_pmc_traffic.json 20 > $O/export/${TAG}_pmc_traffic.log
 fi
+# the same two PMC passes for config 3 (2 M mixed) and for the 16 M-box world of config 5 on one GPU: their bench lines read these exports for roofline.traffic
+for CFG in "c3 --scene mixed --tiles 248" "c5 --tiles 1984"; do
+  set -- $CFG; NAME=$1; shift
+  for CNT in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $O/pmc_$NAME -o $CNT -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-full-window --min-time 0 "$@" > $O/pmc_${NAME}_$CNT.json 2> $O/pmc_${NAME}_$CNT.log
+  done
+  F=$(find $O/pmc_$NAME -name "FETCH_SIZE_counter_collection.csv" | head -1)
+  if [ -n "$F" ]; then
+    D=$(dirname $F); W=$(find $O/pmc_$NAME -name "WRITE_SIZE_counter_collection.csv" | head -1); [ "$(dirname $W)" != "$D" ] && cp $W $D/
+    python $R/profiles/export_pmc.py $D $O/export/${TAG}_pmc_traffic_$NAME.json 20 > $O/export/${TAG}_pmc_traffic_$NAME.log
+  fi
+  rm -rf $O/pmc_$NAME
+done
 # SQ wave-state counters of every kernel (where the wave cycles go: issuing, parked at s_waitcnt, stalled at issue)
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/sq -o sq -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-full-window --min-time 0 > $O/sq_bench.json 2> $O/sq.log
 F=$(find $O/sq -name "*counter_collection.csv" | head -1)

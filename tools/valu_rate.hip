@@ -65,6 +65,13 @@ __global__ __launch_bounds__(64) void k_mix(float* out, unsigned long long* cycl
 				else if (OP == 9) asm volatile("v_bfi_b32 %0, %1, %2, %0" : "+v"(x[c]) : "v"(y[c]), "v"(a));
 				else if (OP == 10) { asm volatile("v_cmp_gt_f32 vcc, %0, %1" :: "v"(x[c]), "v"(b) : "vcc"); asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x[c]) : "v"(a) : "vcc"); }
 				else if (OP == 11) asm volatile("v_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(x[c]) : "v"(a), "v"(b));
+				else if (OP == 12) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[c]));
+				else if (OP == 13) asm volatile("v_rsq_f32 %0, %0" : "+v"(x[c]));
+				else if (OP == 14) asm volatile("v_cmp_gt_f32 vcc, %0, %1" :: "v"(x[c]), "v"(b) : "vcc");
+				else if (OP == 15) asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(smask) : "v"(x[c]), "v"(b));
+				else if (OP == 16) { asm volatile("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(smask) : "v"(x[c]), "v"(b)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x[c]) : "v"(a), "s"(smask)); }
+				else if (OP == 17) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x[c]) : "v"(b));
+				else if (OP == 18) asm volatile("v_mov_b32 %0, %1" : "=v"(x[c]) : "v"(y[c]));
 				else if (OP == 4) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[c]) : "v"((u & 1) ? a : a2), "v"((u & 2) ? b : b2));
 				else {
 					if ((u & 3) == 0) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x[c]) : "v"(a));
@@ -85,7 +92,8 @@ __global__ __launch_bounds__(64) void k_mix(float* out, unsigned long long* cycl
 template<int CHAINS, int OP>
 static void run_mix(int waves_per_simd, int iters) {
 	static const char* names[] = { "v_mul_f32   ", "v_add_f32   ", "v_fmac_f32  ", "v_cndmask   ", "v_fma 3 src ", "mul/add/fmac/fma", "v_cndmask_e32 vcc", "v_cndmask_e64 sgpr", "v_max_f32   ", "v_bfi_b32   ",
-	                               "v_cmp + v_cndmask (2 instr)", "v_cndmask_e32, no dependence" };
+	                               "v_cmp + v_cndmask (2 instr)", "v_cndmask_e32, no dependence", "v_rcp_f32   ", "v_rsq_f32   ", "v_cmp -> vcc", "v_cmp_e64 -> sgpr", "v_cmp_e64 + v_cndmask_e64 via sgpr (2 instr)",
+	                               "v_sub_f32   ", "v_mov_b32   " };
 	const int simds = 256 * 4, blocks = simds * waves_per_simd;
 	float* out; unsigned long long* cyc;
 	hipMalloc((void**)&out, sizeof(float) * 64 * blocks); hipMalloc((void**)&cyc, sizeof(unsigned long long) * blocks);
@@ -139,6 +147,8 @@ int main() {
 	// other instructions of the solver's mix: issue limit (8 chains, 2 waves) and dependent rate (1 chain, 2 and 3 waves)
 	run_mix<8, 0>(2, iters / 2); run_mix<8, 1>(2, iters / 2); run_mix<8, 2>(2, iters / 2); run_mix<8, 3>(2, iters / 8); run_mix<8, 4>(2, iters / 2); run_mix<8, 5>(2, iters / 2);
 	run_mix<8, 6>(2, iters / 8); run_mix<8, 7>(2, iters / 8); run_mix<8, 8>(2, iters / 2); run_mix<8, 9>(2, iters / 2); run_mix<8, 10>(2, iters / 8); run_mix<8, 11>(2, iters / 8); run_mix<1, 6>(2, iters / 8); run_mix<1, 11>(1, iters / 8);
+	run_mix<8, 12>(2, iters / 4); run_mix<8, 13>(2, iters / 4); run_mix<8, 14>(2, iters / 4); run_mix<8, 15>(2, iters / 4); run_mix<8, 16>(2, iters / 4); run_mix<8, 17>(2, iters / 2); run_mix<8, 18>(2, iters / 2);
+	run_mix<1, 12>(2, iters / 4); run_mix<1, 16>(2, iters / 4);
 	run_mix<1, 0>(2, iters); run_mix<1, 2>(2, iters); run_mix<1, 5>(2, iters); run_mix<1, 5>(3, iters); run_mix<1, 5>(4, iters);
 	run_mix<2, 5>(2, iters); run_mix<4, 5>(2, iters);
 	// LDS footprint against residency: three waves per SIMD = 12 workgroups of one wave per CU
