@@ -2443,12 +2443,12 @@ static void blk_run(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyD
 }
 
 // LOCAL speculation (nh_internal.h): every round trip -- a full step's, a still step's verdict -- tells whether somebody left its inflated box in that step; the
-// movers form of the still step stays on for 64 steps after the last one who did
+// movers form of the still step stays on for 16 steps after the last one who did
 static void still_note_movers(nh_context* ctx, const nh_DevState* h) {
 	nh_StillStep& ss = ctx->still;
 	// (a still step in sleepers form that found NOBODY awake: the next step is a full one -- two of those in a row start the asleep steps, which cost nothing)
 	if (ss.sleepers && h->active == 0u) ss.ok_next = false;
-	if (h->fat_inserts != ss.seen_inserts) ss.movers_left = 64u;
+	if (h->fat_inserts != ss.seen_inserts) ss.movers_left = 16u;
 	else if (ss.movers_left) ss.movers_left--;
 	ss.seen_inserts = h->fat_inserts; ss.seen_rebuilds = h->fat_rebuilds;
 }
@@ -3172,7 +3172,10 @@ extern "C" int nh_step(nh_context* ctx, const nh_StepArgs* a, uint32_t steps) {
 			}
 		}
 	}
-	ss.pipelined = ss.h_ring[0] != nullptr && (ctx->flags & NH_FLAG_FUSED_STEP) && !(ctx->flags & (NH_FLAG_SYNC_COUNTS | NH_FLAG_EXACT_ORDER)) && !ss.disabled && !ctx->timing;
+	// (per-kernel timing of EVERY launch collects its events at the step's round trip; timing restricted to one kernel -- nh_set_timing_filter: two events per step, what
+	// bench.py keeps on during its timed region -- leaves the loop as it is: the events are collected when the call's last verdict has been waited for)
+	ss.pipelined = ss.h_ring[0] != nullptr && (ctx->flags & NH_FLAG_FUSED_STEP) && !(ctx->flags & (NH_FLAG_SYNC_COUNTS | NH_FLAG_EXACT_ORDER)) && !ss.disabled &&
+	               !(ctx->timing && ctx->timing_filter.empty());
 	ss.verdict.pending = false;
 	int result = NH_OK;
 	uint32_t i = 0;
