@@ -433,7 +433,8 @@ int nh_partition_exchange_iteration(nh_partition* p, const nh_BodyData* bodies);
 const nh_CachedContactImpulse* nh_contact_impulses_device(const nh_ContactImpulseData* d);
 /* Per-kernel device time of the last step, measured with HIP events on the context's stream when timing is on. */
 int nh_enable_timing(nh_context* ctx, int on);
-/* Restrict timing to kernels whose name equals `name` (NULL or "" = all): two events per step instead of hundreds. */
+/* Restrict timing to kernels whose name equals `name` (NULL or "" = all): two events per step instead of hundreds.  (With timing of ALL kernels on, nh_step looks at every
+   still step's verdict inside the step -- the events are collected at that round trip; restricted to one kernel it keeps its late verdicts and collects at the end of the call.) */
 int nh_set_timing_filter(nh_context* ctx, const char* name);
 /* Writes up to `cap` (name, milliseconds, launches) triples accumulated since the last reset; returns the number. */
 typedef struct nh_KernelTime { const char* name; double ms; uint32_t launches; uint32_t reserved; } nh_KernelTime;

@@ -173,6 +173,49 @@ def test_c2_exact_order_equals_bench_flags_at_size():
     a.close(); b.close()
 
 
+def test_c2_half_asleep_and_movers_at_size_are_the_bits_of_full_steps(monkeypatch):
+    """Local speculation at the size the metric is quoted on: 1,004,400 boxes fall asleep; the caller wakes the left half (idle counters rewritten) and throws 64 of the
+    woken boxes into the air.  For 120 steps the world is half asleep with bodies in flight -- still steps in sleepers AND movers form -- against a library that runs every
+    step in full (no still steps, no asleep steps): bodies, idle counters, contacts, sleeping pairs, active list, cache and counters bit for bit."""
+    scene = S.grid_tiles(124, side=90, seed=2, lattice_cols=11)
+    n = len(scene["body_transforms"]) - 1
+    a = E.World(scene, flags=BENCH_FLAGS, max_contacts=6 * n)
+    monkeypatch.setenv("NH_NO_STILL", "1"); monkeypatch.setenv("NH_NO_ASLEEP", "1")
+    b = E.World(scene, flags=BENCH_FLAGS, max_contacts=6 * n)
+    monkeypatch.delenv("NH_NO_STILL"); monkeypatch.delenv("NH_NO_ASLEEP")
+    a.step(400); b.step(400)
+    assert a.counts()["active_bodies"] == 0 and b.counts()["active_bodies"] == 0
+    order = np.argsort(scene["body_transforms"]["position"][1:, 0], kind="stable") + 1
+    woken = order[: n // 2]
+    rng = np.random.default_rng(9)
+    fliers = rng.choice(woken, size=64, replace=False)
+    for w in (a, b):
+        bd = w.get_bodies()
+        idle, m = bd["idle"].copy(), bd["momentum"].copy()
+        idle[woken] = 0
+        m["velocity"][fliers, 1] = 25.0
+        w.set_bodies(momentum=m, idle=idle)
+    c0 = a.counts()
+    done = 0
+    for cp in (1, 2, 30, 120):
+        a.step(cp - done); b.step(cp - done); done = cp
+        ba, bb = a.get_bodies(), b.get_bodies()
+        assert P.bits_equal(ba["transforms"], bb["transforms"]) and P.bits_equal(ba["momentum"], bb["momentum"]) and np.array_equal(ba["idle"], bb["idle"]), f"step {cp}: bodies differ"
+        ca, cb = a.counts(), b.counts()
+        for k in ("contacts", "sleeping_pairs", "active_bodies", "cache", "error"):
+            assert ca[k] == cb[k], (cp, k, ca[k], cb[k])
+    ka, kb = a.get_contacts(), b.get_contacts()
+    assert np.array_equal(ka["tags"], kb["tags"]) and np.array_equal(ka["features"], kb["features"]) and P.bits_equal(ka["data"], kb["data"])
+    assert np.array_equal(ka["sleeping_pairs"], kb["sleeping_pairs"]) and len(ka["sleeping_pairs"]) >= n // 2 - 1
+    assert np.array_equal(a.get_active(), b.get_active())
+    xa, xb = a.get_cache(), b.get_cache()
+    assert xa["count"] == xb["count"] and np.array_equal(xa["tags"], xb["tags"]) and np.array_equal(xa["features"], xb["features"]) and P.bits_equal(xa["data"]["impulse"], xb["data"]["impulse"])
+    c1 = a.counts()
+    print(f"\n[c2 half asleep + 64 fliers] {c1['still_steps'] - c0['still_steps']} still steps of {done} ({c1['still_replays'] - c0['still_replays']} replayed), {c1['broadphase_inserts'] - c0['broadphase_inserts']} re-insertions")
+    assert c1["still_steps"] - c0["still_steps"] >= 100 and c1["broadphase_inserts"] > c0["broadphase_inserts"]
+    a.close(); b.close()
+
+
 def test_c2_landed_window_properties():
     """The window the bench times: every box rests on 4 face contacts, everybody awake, nothing on the general path, two runs agree
     bit for bit."""
