@@ -721,10 +721,35 @@ __global__ __launch_bounds__(LP_THREADS) void k_large_pairs(nh_DevState* __restr
 // (NH_NO_INCREMENTAL=1 and NH_NO_KEPT_PAIRS=1 must give the same bits: test_kept_pair_list_*).  One wave per leaver, lanes across the candidates.
 // Rebuilds remain for: large colliders on the move, more than NH_ESC_MAX leavers in a step (a falling scene), a full moved list, a worn-out stamp,
 // a crowded kept buffer, changed collider counts.
+// A leaver's OLD pair with the collider its body's contacts come from (still mode only; nh_internal.h "LOCAL speculation").  Re-boxing kills every kept pair of the
+// leaver (stamps) and the search appends the pairs of the new box -- a body that hops and comes down on the ground it left would so lose the RECORD of that pair (its
+// place in the tag order, its slots, the body's body_rec) and get an appended pair without one: the landing would need a full step.  But the layout knows that pair:
+// body_rec[body] is its record, a record's position is its kept pair's (in-place layout).  When the new box still overlaps that partner's box, the old pair is
+// re-stamped where it stands instead of a new one being appended: same pair set, and the record lives on -- empty while the body is in the air, with contacts again
+// when it lands.
+struct nh_OldPair { uint32_t partner, kpos; uint2 kp; bool leaver_is_x; };
+__device__ __forceinline__ nh_OldPair nh_old_pair_of(const nh_DevState* __restrict__ st, uint32_t ca, const float4* __restrict__ box, const uint32_t* __restrict__ body_rec,
+                                                     const uint2* __restrict__ kept, uint32_t kept_cap, uint32_t pair_cap) {
+	nh_OldPair o = { 0xFFFFFFFFu, 0u, make_uint2(0u, 0u), false };
+	if (!body_rec || !st->lay_valid || !st->lay_in_place) return o;
+	const uint32_t body = __float_as_uint(box[2u * ca].w);
+	if (!body) return o;
+	const uint32_t br = body_rec[body];
+	if (br == NH_BODY_REC_NONE) return o;
+	const uint32_t r = br & ~NH_BODY_REC_IS_A, n_bb = min(st->pairs, pair_cap), n_sph = min(st->pairs_sph, pair_cap - n_bb);
+	if (r >= n_bb + n_sph) return o;
+	o.kpos = r < n_bb ? r : kept_cap - 1u - (r - n_bb);
+	o.kp = kept[o.kpos];
+	const uint32_t x = o.kp.x & NH_GEN_INDEX, y = o.kp.y & NH_GEN_INDEX;
+	if (x == ca) { o.partner = y; o.leaver_is_x = true; } else if (y == ca) { o.partner = x; o.leaver_is_x = false; }
+	return o;
+}
+
 __global__ __launch_bounds__(256) void k_reinsert(nh_DevState* __restrict__ st, uint32_t nbox, const float4* __restrict__ sbox, const uint32_t* __restrict__ cstart,
                                                   const uint32_t* __restrict__ large_list, const float4* __restrict__ box, const uint8_t* __restrict__ gen,
                                                   const uint32_t* __restrict__ esc_mark, const uint32_t* __restrict__ esc_list, const uint32_t* __restrict__ moved_list, uint32_t seq,
-                                                  uint2* __restrict__ kept, uint32_t kept_cap, uint32_t still = 0u, uint32_t parity = 0u, uint32_t ncolliders = 0u) {
+                                                  uint2* __restrict__ kept, uint32_t kept_cap, uint32_t still = 0u, uint32_t parity = 0u, uint32_t ncolliders = 0u,
+                                                  const uint32_t* __restrict__ body_rec = nullptr, uint32_t pair_cap = 0u) {
 	// `still`: launched by a still step in MOVERS form (nh_internal.h, "LOCAL speculation") behind k_xform<true>, which has re-boxed this step's leavers: there is no
 	// k_grid_setup in a still step, so k_grid_setup's verdict is taken here, by every workgroup from words nobody writes meanwhile.  The boxes HAVE changed: when
 	// the leavers cannot be re-inserted (too many for the kept buffer or for the quadratic tests) the kept list is void (fat_valid = 0: the replay rebuilds it)
@@ -754,6 +779,8 @@ __global__ __launch_bounds__(256) void k_reinsert(nh_DevState* __restrict__ st, 
 		const uint32_t ca = esc_list[e];
 		const float4 amin = box[2u * ca], amax = box[2u * ca + 1u];
 		const uint32_t pa = ca | (uint32_t)(gen[ca] & 0x7Fu) << NH_GEN_SHIFT;
+		const nh_OldPair old = still ? nh_old_pair_of(st, ca, box, body_rec, kept, kept_cap, pair_cap) : nh_OldPair{ 0xFFFFFFFFu, 0u, make_uint2(0u, 0u), false };      // (wave-uniform)
+		bool revived = false;
 		const int x0 = min(max(cell_coord(amin.x, ox, inv) - 1, 0), nx - 1), x1 = min(max(cell_coord(amax.x, ox, inv), 0), nx - 1);
 		const int y0 = min(max(cell_coord(amin.y, oy, inv) - 1, 0), ny - 1), y1 = min(max(cell_coord(amax.y, oy, inv), 0), ny - 1);
 		const int z0 = min(max(cell_coord(amin.z, oz, inv) - 1, 0), nz - 1), z1 = min(max(cell_coord(amax.z, oz, inv), 0), nz - 1);
@@ -781,9 +808,11 @@ __global__ __launch_bounds__(256) void k_reinsert(nh_DevState* __restrict__ st, 
 				const float4 bmin = sbox[2u * cand], bmax = sbox[2u * cand + 1u];
 				cb = __float_as_uint(bmax.w);
 				hit = aabb_overlap(amin, amax, bmin, bmax) && (gen[cb] & 0x7Fu) == 0u;              // (a stale entry -- the leaver's own among them -- is on the moved list)
+				if (hit && cb == old.partner) { hit = false; revived = true; }                      // (the pair the body's record belongs to: re-stamped below, not appended)
 			}
 			emit_kept(st, kept, kept_cap, pa, cb, hit, ps);
 		}
+		if (__ballot(revived) != 0ull && lane == 0u) kept[old.kpos] = old.leaver_is_x ? make_uint2(pa, old.kp.y) : make_uint2(old.kp.x, pa);
 	}
 	// (b) leaver x (large colliders: never re-inserted, their boxes are the rebuild's) and leaver x (everybody who has moved since the rebuild, with the box
 	// it has now): one lane per combination, all of them spread over the launch
@@ -802,6 +831,15 @@ __global__ __launch_bounds__(256) void k_reinsert(nh_DevState* __restrict__ st, 
 			if (!skip) hit = aabb_overlap(box[2u * ca], box[2u * ca + 1u], box[2u * cb], box[2u * cb + 1u]);
 			pa = ca | (uint32_t)(gen[ca] & 0x7Fu) << NH_GEN_SHIFT;
 			pb = cb | (uint32_t)(gen[cb] & 0x7Fu) << NH_GEN_SHIFT;
+			if (hit && still) {
+				// (the ground a hopping body comes back to is a LARGE collider: this is where its old pair is found again -- see nh_old_pair_of; one lane per combination,
+				// so this lane is the only one that can hold it)
+				const nh_OldPair old = nh_old_pair_of(st, ca, box, body_rec, kept, kept_cap, pair_cap);
+				if (cb == old.partner) {
+					hit = false;
+					kept[old.kpos] = old.leaver_is_x ? make_uint2(pa, (old.kp.y & NH_GEN_INDEX) | (pb & ~NH_GEN_INDEX)) : make_uint2((old.kp.x & NH_GEN_INDEX) | (pb & ~NH_GEN_INDEX), pa);
+				}
+			}
 		}
 		emit_kept(st, kept, kept_cap, pa, pb, hit, ps);
 	}
@@ -1874,7 +1912,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			          sleepers ? ctx->still_awake : (uint8_t*)nullptr);
 			if (movers)
 				NH_LAUNCH(ctx, "reinsert_still", k_reinsert, 256, 256, st, nbox, ctx->grid_sbox, ctx->grid_cstart, ctx->grid_large, ctx->fat_box, ctx->fat_gen, ctx->fat_esc_mark, ctx->fat_esc_list,
-				          ctx->fat_moved_list, ctx->collide_seq, ctx->fat_pairs, ctx->fat_pair_capacity, 1u, ctx->step_parity, C);
+				          ctx->fat_moved_list, ctx->collide_seq, ctx->fat_pairs, ctx->fat_pair_capacity, 1u, ctx->step_parity, C, ctx->body_rec, pair_cap);
 			const uint8_t* gen = incremental ? ctx->fat_gen : (const uint8_t*)nullptr;
 			const bool delta_scan = C > (2u << 20) || sleepers;          // (a world dozing off changes thousands of contact counts per step: the scan, not the list)
 			uint32_t* const sc_count = sleepers ? ctx->sc_count : (uint32_t*)nullptr;

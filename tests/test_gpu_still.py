@@ -222,6 +222,31 @@ def test_bodies_in_the_air_do_not_cost_the_world_its_still_steps(sphere_fraction
     a.close(); b.close(); c.close()
 
 
+def test_a_body_that_comes_back_to_the_ground_it_left_keeps_its_record():
+    """A body thrown straight up leaves its inflated box (re-boxed: its kept pairs die) and comes down on the same ground a second later.  Its pair with that ground is
+    re-stamped where it stands instead of being appended anew (k_reinsert, still mode: nh_old_pair_of), so the record -- tag-order place, slots, body_rec -- lives on, empty
+    while the body is in the air: take-off, flight AND landing are still steps.  Bit-identical to a library that never speculates at every checkpoint."""
+    scene = S.grid_tiles(1, side=32, seed=89)
+    nb = len(scene["body_transforms"])
+    a, b = _world(scene, True), _world(scene, False)
+    a.step(120); b.step(120)
+    idx = np.arange(9, nb, 101)
+    _throw((a, b), idx, 5.0)                                  # 1.0 s = 122 steps in the air, straight up and down
+    c0 = a.counts()
+    done = 0
+    for cp in (1, 20, 60, 110, 125, 128, 131, 135, 145, 170, 230):
+        a.step(cp - done); b.step(cp - done); done = cp
+        _same_world(a, b, f"up and down, step {cp}")
+    ca = a.counts()
+    print(f"\n[up and down] {len(idx)} bodies: still steps {ca['still_steps'] - c0['still_steps']} of {done}, replays {ca['still_replays'] - c0['still_replays']}, "
+          f"re-insertions {ca['broadphase_inserts'] - c0['broadphase_inserts']}")
+    # (the bodies that flew are back on the ground, four contacts each; the rest of the world has meanwhile fallen asleep -- still steps in sleepers form)
+    assert ca["error"] == 0 and ca["contacts"] == b.counts()["contacts"] and ca["contacts"] >= 4 * len(idx) - 4
+    assert ca["broadphase_inserts"] > c0["broadphase_inserts"]
+    assert ca["still_steps"] - c0["still_steps"] >= done - 40, (c0, ca)
+    a.close(); b.close()
+
+
 def test_hops_landings_and_slides_through_local_speculation():
     """Short hops: bodies leave their boxes, are in the air for a few dozen steps above their neighbours' boxes (appended pairs that overlap but must not touch), land -- a
     full step: a contact of a pair without a record -- slide, and come to rest.  nh_step with late verdicts, the eight calls and a library that never speculates end in
