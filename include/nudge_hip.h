@@ -59,8 +59,13 @@
  *      solver order of nudge.cpp:4206-4339 is a function of a contact's dense tag-order index, which stays exact).  A failed check is reported with the step's
  *      one host round trip before anything irreversible has been written, and the step is run again in full from nh_collide's arguments: results are
  *      bit-identical to a library that never speculates (option "no_still"), which the tests check.
- *      The caller's dense contact list (contacts->data / bodies / tags / features) and contact cache are VIEWS of the slots under this regime: they are
- *      brought up to date by nh_export_views (what: NH_VIEW_CONTACTS, NH_VIEW_CACHE), by nh_append_contacts, and by any step that does not qualify -- not by
+ *      Since round 5 two of those checks no longer fail the step (LOCAL speculation; option "no_local_still" restores them): a small collider outside its inflated box is
+ *      given a new box and re-inserted into the kept pair list by the step itself (its pair with the ground it left keeps its record: taking off, flying and coming down
+ *      again are still steps), and a body asleep in a set of its own (no overlapping AABB of another dynamic body, no user connections in the world) is left alone -- its
+ *      pairs are sleeping pairs, its cached impulses are kept aside by the reference's rule (nudge.cpp:3669-3703, 4064-4101).  What still ends in a full step: a first
+ *      contact with a collider the body was not resting on, two dynamic bodies touching, sets of several bodies with a sleeper among them, a rebuild of the kept list.
+ *      The caller's dense contact list (contacts->data / bodies / tags / features, contacts->sleeping_pairs), active list and contact cache are VIEWS under this regime: they are
+ *      brought up to date by nh_export_views (what: NH_VIEW_CONTACTS, NH_VIEW_CACHE, NH_VIEW_ACTIVE), by nh_append_contacts, and by any step that does not qualify -- not by
  *      every step, and not by the cheap observers: nh_read_counts returns the counters and nh_synchronize waits for the stream, neither exports anything (the
  *      sample reads active_bodies.count every sub-step, example/main.cpp:293: that must not cost two passes over the contacts).  Call nh_export_views and then
  *      nh_synchronize before reading the arrays from the device yourself.  Any entry point outside the sample's
