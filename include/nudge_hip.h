@@ -209,6 +209,8 @@ typedef struct nh_Counts {
 	uint32_t blk_blocks, blk_bodies, blk_ghosts;   /* the blocked solver's tables of the last step that built them (large general sets): blocks of the grid, general bodies binned,
 	                               ghost copies borrowed by blocks (a sweep loads and stores blk_bodies + blk_ghosts momentum records); diagnostic / measurement */
 	uint32_t asleep_steps;      /* steps since nh_create that nh_step found to be steps of a world in which every body is asleep and nothing has changed: done without a launch */
+	uint32_t ahead_steps;       /* still steps (launched, since nh_create) that started at the narrowphase: the solver of the sub-step before them, inside the same nh_step call, had
+	                               already written their colliders' world transforms and boxes (note 9, "xform ahead") */
 } nh_Counts;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */
@@ -239,7 +241,7 @@ int nh_set_pair_capacity(nh_context* ctx, uint32_t pairs);
 /* Diagnostic switches for A/B runs and tests -- none is needed in production, each selects an older, slower or more talkative path; the library never reads the
    environment.  Names (value 0 / 1 unless noted): "no_still", "no_kept_pairs", "no_incremental", "no_sort_reuse", "sort_classic", "sort_radix", "bucket_tile" (n),
    "bucket_target" (n), "colour_jp", "colour_check_seeds", "no_resident", "solver_waves" (1, 2, 4), "fp_sub" (0, 1, 2, 4, 16), "cooperative", "no_blocks", "blk_check",
-   "blk_min" (n), "blk_target" (n), "blk_rows_global", "blk_global_colours", "blk_profile", "no_asleep", "no_blk_chain", "no_local_still".  Unknown name: NH_ERR_INVALID.  Call right after nh_create.
+   "blk_min" (n), "blk_target" (n), "blk_rows_global", "blk_global_colours", "blk_profile", "no_asleep", "no_blk_chain", "no_local_still", "no_xform_ahead".  Unknown name: NH_ERR_INVALID.  Call right after nh_create.
    (nudge_amd/engine.py maps environment variables NH_<NAME> onto these calls for its tests: a convenience of that host, not of the library.) */
 int nh_set_option(nh_context* ctx, const char* name, int value);
 const char* nh_error_string(int code);

@@ -47,10 +47,7 @@
 #define NH_BLK_MAX_CONTACTS 6144u        // contacts of one block the per-block colouring holds in LDS (a block with more is too big: smaller blocks)
 #define NH_BLK_DESC_WORDS 40u            // per (block colour, workgroup) descriptor: block, own bodies, first slot, ghosts, ghost list base, the L + 1 bin offsets
 
-// 16 bytes from a per-lane global address straight into LDS (lane-linear destination: consecutive lanes must name consecutive 16-byte pieces)
-__device__ __forceinline__ void nh_glds16(const float4* src, float4* lds_dst) {
-	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
+// (nh_glds16 -- 16 bytes from a per-lane global address straight into LDS: nh_internal.h)
 
 // ... the same with system scope (sc0 sc1): the line is fetched from memory whatever this XCD's L2 holds -- for data another workgroup of the SAME launch has
 // written with system-scope stores (chained sweeps below; MI355X: the L2s of the eight XCDs are not coherent with each other)

@@ -81,6 +81,8 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 				st->still_fat0 = st->fat_count + st->fat_count_sph;          // (nobody appends to the kept list while this kernel runs: k_reinsert's verdict needs a value that stands still)
 			}
 		}
+		// (xform ahead, nh_internal.h: what this step's solver may gather for the next step)
+		if (blockIdx.x == 0 && threadIdx.x < NH_AHEAD_PARTS * 8u) (&st->ahead_part[parity ^ 1u][0][0])[threadIdx.x] = (threadIdx.x & 7u) < 3u ? 0xffffffffu : 0u;
 		__syncthreads();
 		if (threadIdx.x < 3) { red[threadIdx.x] = 0xffffffffu; red[3 + threadIdx.x] = 0u; }
 		__syncthreads();
@@ -951,7 +953,25 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
                                                      const uint8_t* __restrict__ gen = nullptr, const uint32_t* __restrict__ lay_rank = nullptr, uint32_t* __restrict__ cnt_sorted = nullptr,
                                                      const uint32_t* __restrict__ body_rec = nullptr, uint32_t seq = 0u, int2* __restrict__ delta = nullptr, uint32_t delta_scan = 0u,
                                                      // STILL, sleepers form (nh_internal.h): the slot cache's per-record counts (entries kept aside for a sleeping pair); nullptr = nobody can be asleep
-                                                     uint32_t* __restrict__ sc_count = nullptr) {
+                                                     uint32_t* __restrict__ sc_count = nullptr,
+                                                     // STILL, plain form: no k_xform<true> has run this step -- the last step's solver did its work (nh_internal.h: xform ahead)
+                                                     uint32_t ahead = 0u) {
+	if (STILL && !LOCAL && ahead) {
+		// what k_xform<true> does for the step after this one (nobody touches the other parity's words during this step: the solver that gathers into them comes later)
+		if (blockIdx.x == 0 && threadIdx.x == 0) {
+			st->max_idle[parity ^ 1u] = 0u; st->delta_count[parity ^ 1u] = 0u; st->delta_overflow[parity ^ 1u] = 0u; st->still_esc[parity ^ 1u] = 0u;
+			st->still_asleep[parity ^ 1u] = 0u; st->still_sleeping[parity ^ 1u] = 0u; st->still_culled[parity ^ 1u] = 0u;
+			for (int k = 0; k < 3; ++k) { st->still_smin[parity ^ 1u][k] = 0xffffffffu; st->still_smax[parity ^ 1u][k] = 0u; }
+			st->still_fat0 = st->fat_count + st->fat_count_sph;
+		}
+		if (blockIdx.x == 0) for (uint32_t k = threadIdx.x; k < NH_AHEAD_PARTS * 8u; k += blockDim.x) (&st->ahead_part[parity ^ 1u][0][0])[k] = (k & 7u) < 3u ? 0xffffffffu : 0u;
+		// ... and what it would have found: a collider outside its inflated box, a body asleep (the solver lane that advanced the body saw it), a world the lanes cannot
+		// stand in for k_xform in -- this step has not happened (every workgroup reads the same words and comes to the same verdict)
+		if (st->ahead_failed_seq >= seq || st->ahead_multi != 0u) {
+			if (blockIdx.x == 0 && threadIdx.x == 0) { atomicMax(&st->still_failed_seq, seq); atomicAdd(&st->still_diff[3], 1u); }
+			return;
+		}
+	}
 	// coarse islands (nudge.cpp:3500-3703): a pair whose bodies belong to a set of sleeping bodies (sets over the BROADPHASE pairs and the
 	// user's connections) never reaches the narrowphase: it becomes a sleeping pair, larger tag in the low half (3697)
 	const bool some_asleep = !STILL && st->any_idle[parity] != 0;
@@ -968,13 +988,40 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 	// STILL: Morton frame of this step (nudge.cpp:3096-3100; k_grid_setup's arithmetic) from the bounds k_xform<true> gathered; stamps as in k_kept_filter
 	float mscale = 0.0f;
 	nh_f3 mmin = nh_make3(0.0f, 0.0f, 0.0f);
+	uint32_t fr_min[3] = { 0u, 0u, 0u }, fr_max[3] = { 0u, 0u, 0u }, fr_top = 0u;
+	uint32_t i_first = 0u;
+	uint2 kp_first = make_uint2(0u, 0u);
+	auto still_frame = [&]() {
+		if (!LOCAL && ahead) {
+			for (int k = 0; k < 3; ++k)
+				for (int d = 32; d >= 1; d >>= 1) { fr_min[k] = min(fr_min[k], (uint32_t)__shfl_xor((int)fr_min[k], d)); fr_max[k] = max(fr_max[k], (uint32_t)__shfl_xor((int)fr_max[k], d)); }
+			for (int d = 32; d >= 1; d >>= 1) fr_top = max(fr_top, (uint32_t)__shfl_xor((int)fr_top, d));
+			// (the first wave files the result where a step with a k_xform<true> of its own would have it: the host's mirror, the sleep prediction)
+			if (blockIdx.x == 0 && threadIdx.x == 0) {
+				for (int k = 0; k < 3; ++k) { st->still_smin[parity][k] = fr_min[k]; st->still_smax[parity][k] = fr_max[k]; }
+				st->max_idle[parity] = fr_top;
+			}
+		}
+		const nh_f3 smin = nh_make3(nh_float_unflip(fr_min[0]), nh_float_unflip(fr_min[1]), nh_float_unflip(fr_min[2]));
+		const nh_f3 smax = nh_make3(nh_float_unflip(fr_max[0]), nh_float_unflip(fr_max[1]), nh_float_unflip(fr_max[2]));
+		mscale = nh_morton_scale(smin, smax);
+		mmin = nh_make3(smin.x * mscale, smin.y * mscale, smin.z * mscale);
+	};
 	const uint32_t index_mask = (STILL && gen) ? NH_GEN_INDEX : 0xFFFFFFFFu;
 	const bool stamps = STILL && gen && st->moved_count != 0u;
 	if (STILL) {
-		const nh_f3 smin = nh_make3(nh_float_unflip(st->still_smin[parity][0]), nh_float_unflip(st->still_smin[parity][1]), nh_float_unflip(st->still_smin[parity][2]));
-		const nh_f3 smax = nh_make3(nh_float_unflip(st->still_smax[parity][0]), nh_float_unflip(st->still_smax[parity][1]), nh_float_unflip(st->still_smax[parity][2]));
-		mscale = nh_morton_scale(smin, smax);
-		mmin = nh_make3(smin.x * mscale, smin.y * mscale, smin.z * mscale);
+		for (int k = 0; k < 3; ++k) { fr_min[k] = st->still_smin[parity][k]; fr_max[k] = st->still_smax[parity][k]; }
+		if (!LOCAL && ahead) {
+			// the bounds (and the largest idle counter) the last step's solver lanes gathered in NH_AHEAD_PARTS places, the static world's share beside them: asked for
+			// here, put together by every wave for itself (still_frame) once its lanes' first kept pairs are on their way as well
+			const uint32_t* part = &st->ahead_part[parity][nh_lane() & (NH_AHEAD_PARTS - 1u)][0];
+			fr_top = part[6];
+			for (int k = 0; k < 3; ++k) { fr_min[k] = min(part[k], st->still_static_min[k]); fr_max[k] = max(part[3 + k], st->still_static_max[k]); }
+		}
+		// (every lane's FIRST kept pair is asked for before the frame is put together: the wave waits once for both)
+		i_first = blockIdx.x * blockDim.x + threadIdx.x;
+		{ const uint32_t ic = min(i_first, kept_cap - 1u); kp_first = pairs[SPH ? kept_cap - 1u - ic : ic]; }
+		still_frame();
 		// (the layout must be the last full step's, and the kept list at least as long as the pair list it was written from: what lies behind are pairs APPENDED by
 		// still steps in movers form since -- below)
 		// (LOCAL = false: the host launches this form only when no still step in movers form has appended a pair since the layout was written -- checked all the same)
@@ -1055,7 +1102,8 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		if (live || app) {
 			uint2 pr;
 			if (STILL) {
-				const uint2 kp = pairs[SPH ? kept_cap - 1u - i : i];
+				uint2 kp = kp_first;
+				if (i != i_first) kp = pairs[SPH ? kept_cap - 1u - i : i];
 				const uint32_t ca = kp.x & index_mask, cb = kp.y & index_mask;
 				const float4 amin = aabb_min[ca], amax = aabb_max[ca], bmin = aabb_min[cb], bmax = aabb_max[cb];
 				XA = xf[ca]; XB = xf[cb]; TA = ctag[ca]; TB = ctag[cb]; CB = cb;
@@ -1234,6 +1282,43 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		return;
 	}
 	if (__ballot(changed) != 0ull && nh_lane() == 0) st->keys_changed = 1u;          // (plain store of a constant)
+}
+
+// XFORM AHEAD (nh_internal.h: nh_StillStep).  Once per nh_step call, behind the k_xform<true> of its first plain still step: which collider a body's solver lane
+// transforms for the next step (body_col, cleared to NH_NONE by the host), whether every dynamic body has at most one (st->ahead_multi), and the scene bounds of the
+// colliders no lane owns -- the static world's (body 0), which nothing moves inside the call.
+__global__ __launch_bounds__(256) void k_ahead_map(nh_DevState* __restrict__ st, const float4* __restrict__ aabb_min, uint32_t n, uint32_t* __restrict__ body_col) {
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		st->ahead_multi = 0u;
+		for (int k = 0; k < 3; ++k) { st->still_static_min[k] = 0xffffffffu; st->still_static_max[k] = 0u; }
+	}
+	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+		const uint32_t b = __float_as_uint(aabb_min[c].w);
+		if (b) body_col[b] = c;          // (several colliders of one body: any of them wins, k_ahead_check sees the others)
+	}
+}
+__global__ __launch_bounds__(256) void k_ahead_check(nh_DevState* __restrict__ st, const float4* __restrict__ aabb_min, uint32_t n, const uint32_t* __restrict__ body_col) {
+	__shared__ uint32_t red[6];
+	if (threadIdx.x < 3) { red[threadIdx.x] = 0xffffffffu; red[3 + threadIdx.x] = 0u; }
+	__syncthreads();
+	uint32_t lmin[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, lmax[3] = { 0, 0, 0 };
+	bool multi = false;
+	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+		const float4 mn = aabb_min[c];
+		const uint32_t b = __float_as_uint(mn.w);
+		if (b) { multi |= body_col[b] != c; continue; }
+		uint32_t f;
+		f = nh_float_flip(mn.x); lmin[0] = min(lmin[0], f); lmax[0] = max(lmax[0], f);
+		f = nh_float_flip(mn.y); lmin[1] = min(lmin[1], f); lmax[1] = max(lmax[1], f);
+		f = nh_float_flip(mn.z); lmin[2] = min(lmin[2], f); lmax[2] = max(lmax[2], f);
+	}
+	if (__ballot(multi) != 0ull && nh_lane() == 0) st->ahead_multi = 1u;          // (plain store of a constant)
+	for (int k = 0; k < 3; ++k) {
+		for (int d = 32; d >= 1; d >>= 1) { lmin[k] = min(lmin[k], (uint32_t)__shfl_xor((int)lmin[k], d)); lmax[k] = max(lmax[k], (uint32_t)__shfl_xor((int)lmax[k], d)); }
+		if ((threadIdx.x & 63) == 0) { atomicMin(&red[k], lmin[k]); atomicMax(&red[3 + k], lmax[k]); }
+	}
+	__syncthreads();
+	if (threadIdx.x < 3 && red[threadIdx.x] <= red[3 + threadIdx.x]) { atomicMin(&st->still_static_min[threadIdx.x], red[threadIdx.x]); atomicMax(&st->still_static_max[threadIdx.x], red[3 + threadIdx.x]); }
 }
 
 // Asleep steps (nh_internal.h: nh_AsleepState): is every collider's world AABB (k_xform's arithmetic, bit for bit) and tag what it was when the world was found asleep,
@@ -1881,6 +1966,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 	if (lay_fresh) { ctx->still.slots_current = false; ctx->still.ok_next = false; }
 	{
 		nh_StillStep& ss = ctx->still;
+		if (!same_colliders(*colliders, ss.lay_colliders)) ss.ahead_world_bad = false;          // (other colliders: whether bodies carry several of them is found out again)
 		ss.lay_bodies = *bodies; ss.lay_colliders = *colliders; ss.lay_contacts = *contacts; ss.lay_active = active_bodies->indices; ss.lay_active_capacity = active_bodies->capacity;
 		ss.appended = false;
 		// ---- the still step: three launches instead of the thirty below ----
@@ -1904,12 +1990,44 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			// into the kept list itself (one more launch, which leaves at once in a step nobody moves in); otherwise a leaver fails the step, and the full step that
 			// re-inserts it switches this on
 			const bool movers = incremental && !ss.no_local && ss.movers_left != 0u;
+			// (the colliders' world transforms, boxes and tags of a still step live in buffers of the library's own: nh_internal.h, xform ahead)
+			if (ctx->own_capacity < C) {
+				void** bufs[] = { (void**)&ctx->own_xf, (void**)&ctx->own_aabb_min, (void**)&ctx->own_aabb_max, (void**)&ctx->own_ctag };
+				for (void** b : bufs) { if (*b) NH_HIP_CHECK(ctx, hipFree(*b)); *b = nullptr; }
+				ctx->own_capacity = 0;
+				NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->own_xf, sizeof(nh_xform) * (size_t)C + 64u));
+				NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->own_aabb_min, sizeof(float4) * (size_t)C + 64u));
+				NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->own_aabb_max, sizeof(float4) * (size_t)C + 64u));
+				NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->own_ctag, sizeof(uint32_t) * (size_t)C + 64u));
+				ctx->own_capacity = C; ss.ahead_ready = false;
+			}
+			xf = ctx->own_xf; aabb_min = ctx->own_aabb_min; aabb_max = ctx->own_aabb_max; ctag = ctx->own_ctag;
+			// XFORM AHEAD: the solver of the step before this one -- same nh_step call, plain form -- has written all of that for the dynamic bodies' colliders; this step
+			// starts at the narrowphase
+			const bool plain = !movers && !sleepers && !ss.appended_pairs && (nbox >= 2 || nsph != 0u);
+			const bool ahead_step = plain && ss.ahead_ready && !ss.no_ahead;
+			ss.ahead_ready = false; ss.ahead_plain = plain;
+			if (ahead_step) ss.ahead_steps++;
+			else
 			NH_LAUNCH(ctx, "xform_still", (k_xform<true>), nh_grid_for(C > B ? C : B, 1024, 256), 1024, st, bodies->transforms,
 			          colliders->boxes.transforms, colliders->boxes.data, colliders->boxes.tags, nbox,
 			          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
 			          xf, aabb_min, aabb_max, ctag, (uint4*)nullptr, 0u, ctx->fat_box, 0u,
 			          movers ? ctx->fat_gen : (uint8_t*)nullptr, ctx->fat_esc_mark, ctx->fat_esc_list, ctx->fat_moved_list, ctx->collide_seq, bodies->idle_counters, B, ctx->step_parity,
 			          sleepers ? ctx->still_awake : (uint8_t*)nullptr);
+			if (!ahead_step && plain && ss.more_steps && !ss.no_ahead && !ss.ahead_world_bad && !ss.ahead_map_ok && bodies->idle_counters) {
+				// (once per nh_step call: which collider each body's lane stands in for, and the static world's share of the scene bounds)
+				if (ctx->body_col_capacity < B) {
+					if (ctx->body_col) NH_HIP_CHECK(ctx, hipFree(ctx->body_col));
+					ctx->body_col = nullptr; ctx->body_col_capacity = 0;
+					NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->body_col, sizeof(uint32_t) * (size_t)B + 64u));
+					ctx->body_col_capacity = B;
+				}
+				NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->body_col, 0xff, sizeof(uint32_t) * (size_t)B, ctx->stream));
+				NH_LAUNCH(ctx, "ahead_map", k_ahead_map, nh_grid_for(C, 256, 2048), 256, st, aabb_min, C, ctx->body_col);
+				NH_LAUNCH(ctx, "ahead_check", k_ahead_check, nh_grid_for(C, 256, 1024), 256, st, aabb_min, C, ctx->body_col);
+				ss.ahead_map_ok = true;
+			}
 			if (movers)
 				NH_LAUNCH(ctx, "reinsert_still", k_reinsert, 256, 256, st, nbox, ctx->grid_sbox, ctx->grid_cstart, ctx->grid_large, ctx->fat_box, ctx->fat_gen, ctx->fat_esc_mark, ctx->fat_esc_list,
 				          ctx->fat_moved_list, ctx->collide_seq, ctx->fat_pairs, ctx->fat_pair_capacity, 1u, ctx->step_parity, C, ctx->body_rec, pair_cap);
@@ -1925,7 +2043,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, sc_count); \
 				else NH_LAUNCH(ctx, NAME, (k_narrowphase<SPHERES, true, false>), nh_grid_for(pair_cap, 256, GRIDMAX), 256, st, ctx->fat_pairs, xf, ctag, \
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr, \
-				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, (uint32_t*)nullptr); } while (0)
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, (uint32_t*)nullptr, ahead_step ? 1u : 0u); } while (0)
 			if (nbox >= 2) NH_NARROW_STILL(false, "narrowphase_still", 4096);
 			if (nsph) NH_NARROW_STILL(true, "narrowphase_sph_still", 8192);
 			// every record's first contact in the dense (tag-ordered) list = the scan of the counts in tag order: kept from step to step, shifted by the listed changes
@@ -1942,6 +2060,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 	if (ctx->still.verdict.pending && nh_still_verdict_now(ctx)) return NH_INTERNAL_STILL_FAILED;
 	// The solver reads the caller's cache arrays and this nh_collide lays the dense contact list out -- whatever still steps kept by slot goes home first
 	{ int rc = nh_still_export_cache(ctx); if (rc) return rc; }
+	ctx->still.ahead_ready = false; ctx->still.ahead_plain = false;
 	ctx->still.contacts_stale = false; ctx->still.slots_current = false; ctx->still.views_sleepers = false; ctx->still.appended_pairs = false;          // (a full step writes the contact list, the sleeping pairs and the active list itself)
 	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, begin_grid, 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity, coarse_parent, coarse_active, no_islands ? 1u : 0u, block_top,
 	          drop_kept ? 1u : 0u, drop_sort_order ? 1u : 0u);

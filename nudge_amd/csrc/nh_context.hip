@@ -57,12 +57,14 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->blk.target = 900u;
 	ctx->raw_data = nullptr; ctx->raw_feature = nullptr; ctx->raw_slots = 0; ctx->rec = nullptr; ctx->lay_rank = nullptr; ctx->cnt_sorted = nullptr; ctx->start_sorted = nullptr; ctx->dense_slot = nullptr;
 	ctx->sc_imp = nullptr; ctx->sc_feat = nullptr; ctx->sc_count = nullptr; ctx->exp_cnt = nullptr; ctx->exp_start = nullptr; ctx->exp_scan_tmp = nullptr; ctx->still_delta = nullptr; ctx->lay_capacity = 0; ctx->lay_contact_capacity = 0;
+	ctx->own_xf = nullptr; ctx->own_aabb_min = nullptr; ctx->own_aabb_max = nullptr; ctx->own_ctag = nullptr; ctx->own_capacity = 0; ctx->body_col = nullptr; ctx->body_col_capacity = 0;
 	ctx->still_awake = nullptr; ctx->still_awake_capacity = 0; ctx->exp_sleep_a = nullptr; ctx->exp_sleep_b = nullptr; ctx->exp_sleep_hist = nullptr; ctx->exp_flags = nullptr; ctx->exp_sleep_capacity = 0; ctx->exp_flags_capacity = 0;
 	ctx->lay_class = nullptr; ctx->lay_simple = nullptr; ctx->body_rec = nullptr; ctx->body_pos = nullptr; ctx->lay_body_capacity = 0;
 	memset(&ctx->still, 0, sizeof(ctx->still));
 	ctx->first_ghost = 0;
 	memset(&ctx->asleep, 0, sizeof(ctx->asleep));
 	memset(&ctx->stream_state, 0, sizeof(ctx->stream_state)); ctx->stream_state.last_slot = -1;
+	{ int cus = 0; ctx->cu_count = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && cus > 0) ? cus : 256; }
 	ctx->d_state = nullptr;
 	ctx->h_state = nullptr;
 	if (hipMalloc((void**)&ctx->d_state, sizeof(nh_DevState)) != hipSuccess) { delete ctx; return NH_ERR_HIP; }
@@ -122,7 +124,8 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	for (int k = 0; k < 2; ++k) { if (ctx->still.h_ring[k]) hipHostFree(ctx->still.h_ring[k]); if (ctx->still.ev_ring[k]) hipEventDestroy(ctx->still.ev_ring[k]); }
 	{
 		void* bufs[] = { ctx->raw_data, ctx->raw_feature, ctx->rec, ctx->lay_rank, ctx->cnt_sorted, ctx->start_sorted, ctx->dense_slot, ctx->sc_imp, ctx->sc_feat, ctx->sc_count, ctx->exp_cnt, ctx->exp_start,
-		                 ctx->exp_scan_tmp, ctx->still_delta, ctx->lay_class, ctx->lay_simple, ctx->body_rec, ctx->body_pos, ctx->still_awake, ctx->exp_sleep_a, ctx->exp_sleep_b, ctx->exp_sleep_hist, ctx->exp_flags };
+		                 ctx->exp_scan_tmp, ctx->still_delta, ctx->lay_class, ctx->lay_simple, ctx->body_rec, ctx->body_pos, ctx->still_awake, ctx->exp_sleep_a, ctx->exp_sleep_b, ctx->exp_sleep_hist, ctx->exp_flags,
+		                 ctx->own_xf, ctx->own_aabb_min, ctx->own_aabb_max, ctx->own_ctag, ctx->body_col };
 		for (void* b : bufs) if (b) hipFree(b);
 	}
 	{
@@ -159,6 +162,7 @@ extern "C" int nh_set_option(nh_context* ctx, const char* name, int value) {
 	const bool on = value != 0;
 	ctx->asleep.streak = 0;
 	if (n == "no_asleep") ctx->asleep.disabled = on;                      // nh_step runs every step of a world that is asleep in full (nh_internal.h: nh_AsleepState)
+	else if (n == "no_xform_ahead") ctx->still.no_ahead = on;                  // every still step launches k_xform<true> itself (nh_internal.h: xform ahead)
 	else if (n == "no_local_still") ctx->still.no_local = on;                  // a collider that leaves its inflated box fails a still step as a whole (round 4's behaviour; nh_internal.h "LOCAL speculation")
 	else if (n == "no_still") ctx->still.disabled = on;                        // no step is launched speculatively as a still step (note 9)
 	else if (n == "sort_classic") ctx->env_sort_classic = on;             // three-kernel radix passes
@@ -227,7 +231,7 @@ void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out) {
 	out->general_contacts = h->general_contacts; out->levels = h->levels; out->error = h->error;
 	out->still_steps = (uint32_t)(ctx->still.launched - ctx->still.failed - ((ctx->still.active && !ctx->still.resolved) ? 1u : 0u)); out->still_replays = (uint32_t)ctx->still.failed;
 	for (int k = 0; k < 4; ++k) out->still_diff[k] = h->still_diff[k];
-	out->asleep_steps = (uint32_t)ctx->asleep.steps;
+	out->asleep_steps = (uint32_t)ctx->asleep.steps; out->ahead_steps = (uint32_t)ctx->still.ahead_steps;
 	out->blk_blocks = h->blk.nblk; out->blk_bodies = h->blk.bodies; out->blk_ghosts = h->blk.ghost_cursor;
 	out->has_other_bodies = h->has_other; out->broadphase_rebuilds = h->fat_rebuilds; out->sort_reuses = h->sort_reuses; out->broadphase_inserts = h->fat_inserts; out->unleveled = h->unleveled; out->raw_pairs = h->pairs + h->pairs_sph;
 }

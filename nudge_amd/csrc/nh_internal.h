@@ -75,7 +75,7 @@ struct nh_DevState {
 	                                      // asleep, a collider pair changed its key or has more than four contacts or a partner the solver lane does not know, body 0 not inert:
 	                                      // the solver of that step, and of every still step launched behind it before the host has looked, leaves without touching anything;
 	                                      // the host replays from that step in full.  Only ever raised (atomicMax): no clearing, no window in which a verdict can be lost
-	uint32_t still_pad;
+	uint32_t ahead_multi;                 // k_ahead_check ("xform ahead", nh_StillStep): some body carries more than one collider -- its solver lane cannot stand in for k_xform<true>
 	uint32_t lay_valid;                   // the kept layout (per record: first contact | count, feature words; per body: class + contact list record) describes the contact
 	                                      // list the last FULL step laid out, and that step met the conditions a still step relies on (k_gather_contacts)
 	uint32_t has_unstable;                // some body with contacts is outside the class a still step's solver owns (one collider pair, with the static world, <= 4 contacts): k_adj_simple
@@ -134,12 +134,25 @@ struct nh_DevState {
 	// still steps with SLEEPERS (nh_collide.hip, "9. still steps", LOCAL speculation): by step parity, what a still step in sleepers form counted -- bodies asleep, their
 	// collider pairs (the step's sleeping pairs), the cache entries kept aside for them; the solver turns them into the step's counters (active / sleeping / culled)
 	uint32_t still_asleep[2], still_sleeping[2], still_culled[2];
+	// XFORM AHEAD (nh_StillStep): a still step's solver has done the NEXT step's k_xform<true> for its body's collider -- what it found (a collider outside its inflated box,
+	// a body whose idle counter is saturated) fails that next step, not its own: the sequence number of the step it fails; and the part of the scene bounds no solver lane
+	// owns (the static world's colliders)
+	uint32_t ahead_failed_seq;
+	uint32_t still_static_min[3], still_static_max[3];
+	// ... and what the lanes gathered for the next step, by step parity: NH_AHEAD_PARTS partial results (min corner bounds 0-2 / 3-5, largest idle counter 6) that the
+	// waves of the solver spread their atomics over -- 16 K waves on ONE address would queue for 12 ns each; the next step's narrowphase reduces them
+	uint32_t ahead_part[2][64][8];
 	nh_BlkGrid blk;               // spatially blocked solver (nh_blocks.h)
 };
 
 struct nh_TimerSlot { const char* name; hipEvent_t a, b; };
 
 // what the fused one-body solver does besides solving (NH_FLAG_FUSED_STEP): bits 1 = gravity / damping on load, 2 = advance on store
+#define NH_AHEAD_PARTS 64u
+struct nh_xform;
+// what a solver lane needs to do the next step's k_xform<true> for its body's collider (nh_StillStep: xform ahead)
+struct nh_AheadView { const uint32_t* body_col; const nh_Transform* box_xf; const nh_BoxCollider* box_data; const nh_Transform* sph_xf; const nh_SphereCollider* sph_data; uint32_t nbox;
+                      nh_xform* xf; float4* aabb_min; float4* aabb_max; const float4* fat_box; };
 struct nh_FusedStep { float gx_dt, gy_dt, gz_dt, damping, time_step; uint32_t bits; uint8_t* idle; uint32_t seq, guard_seq; };      // (still steps: this step's sequence number; the
                                                                                                                                     // oldest still step whose verdict the host has not seen)
 
@@ -209,6 +222,21 @@ struct nh_StillStep {
 	// kept list, and the still narrowphase takes a kept pair that has died (stamps) or no longer overlaps as a record without contacts, and the appended pairs as
 	// pairs without a record that must not produce a contact -- a landing is still a full step.  Option "no_local_still": the round-4 behaviour.
 	bool no_local; uint32_t movers_left;
+	// XFORM AHEAD (round 5, verdict 2c).  k_xform<true> was 40 of a still step's 300 us at a million boxes, and cannot be folded into the narrowphase that follows it:
+	// which collider of a pair plays "a" depends on the scene bounds of THIS step (nudge.cpp:3086-3100), a reduction over every collider.  But every dynamic body of a
+	// still step has a solver lane that has just advanced it (NH_FLAG_FUSED_STEP) -- and between two sub-steps of ONE nh_step call the caller cannot touch anything.  So
+	// the lane does the next step's k_xform for the body's one collider while the transform is still in registers: world transform, AABB, the test against the inflated
+	// box, the bounds, the largest idle counter.  The next step then starts at the narrowphase (two launches instead of three); what the lane found wanting fails THAT
+	// step (st->ahead_failed_seq), which is run again in full like any failed still step.  Only in the plain form (nobody moving, nobody able to sleep), only for worlds
+	// whose dynamic bodies carry one collider each (checked once per call: k_ahead_map / k_ahead_check), only while another sub-step of the same call follows.
+	// Option "no_xform_ahead": every still step launches k_xform<true> (A/B, tests).
+	bool no_ahead;                  // option
+	bool more_steps;                // nh_step: another sub-step of this call follows the one being launched
+	bool ahead_map_ok;              // the body -> collider map was built in this nh_step call (the caller cannot have changed the colliders since)
+	bool ahead_world_bad;           // ... and showed a body with several colliders (st->ahead_multi, seen at a round trip): not offered again until the colliders change
+	bool ahead_plain;               // the still step being launched is in the plain form and has a narrowphase launch
+	bool ahead_ready;               // the solver of the LAST step launched did this step's transforms: the next nh_collide of this call may skip k_xform<true>
+	uint64_t ahead_steps;           // statistics: still steps that started at the narrowphase
 	bool appended_pairs;            // a still step in movers form has run since the last full step: the kept list may be longer than the layout (the narrowphase's LOCAL form is needed)
 	// SLEEPERS form (round 5).  Still steps needed everybody awake, asleep steps everybody asleep; a world in which SOME bodies sleep paid full steps (~40 launches).  The
 	// reference's rule is per set (nudge.cpp:3575-3703): a body whose AABB overlaps no other dynamic body's forms a set of its own, asleep exactly when its idle counter
@@ -253,6 +281,7 @@ struct nh_StateStream {
 
 struct nh_context {
 	int device;
+	int cu_count;                  // compute units of the device (persistent launches size themselves by it)
 	hipStream_t stream;
 	uint32_t flags;
 	uint32_t tag_bits;
@@ -350,6 +379,10 @@ struct nh_context {
 	uint32_t* dense_slot;                                                    // per contact of the last FULL step's list: the raw slot it came from
 	// the contact cache by slot (still steps): the solved impulse and the feature word of the contact each slot held LAST step, and how many each record had
 	float4* sc_imp; uint32_t* sc_feat; uint32_t* sc_count;
+	// still steps keep their colliders' world transforms, AABBs and tags in buffers of the library's own (a full step's live in the caller's arena): with xform ahead
+	// (nh_StillStep) they are written by one step's solver and read by the next step's narrowphase; and the body -> collider map those solver lanes go by
+	struct nh_xform* own_xf; float4* own_aabb_min; float4* own_aabb_max; uint32_t* own_ctag; uint32_t own_capacity;
+	uint32_t* body_col; uint32_t body_col_capacity;
 	uint8_t* still_awake; uint32_t still_awake_capacity;                     // per body: awake at the last sleepers-form still step's nh_collide (the active list is a view of it)
 	uint64_t* exp_sleep_a; uint64_t* exp_sleep_b; uint32_t* exp_sleep_hist; uint32_t* exp_flags; uint32_t exp_sleep_capacity, exp_flags_capacity;      // scratch of the view exports (on demand)
 	int2* still_delta;                                                       // 2 x NH_DELTA_MAX: (tag-order position, change of the contact count) of this still step, by step parity
@@ -543,6 +576,10 @@ void nh_copy_back_u32(nh_context* ctx, const uint32_t* src, uint32_t* dst, const
 #if defined(__HIPCC__)
 __device__ __forceinline__ unsigned nh_lane() { return __lane_id(); }
 
+// 16 bytes from a per-lane global address straight into LDS (lane-linear destination: consecutive lanes must name consecutive 16-byte pieces)
+__device__ __forceinline__ void nh_glds16(const float4* src, float4* lds_dst) {
+	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
 __device__ __forceinline__ uint32_t nh_float_flip(float f) {
 	uint32_t u = __float_as_uint(f);
 	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);

@@ -871,13 +871,16 @@ struct nh_ob_slot { float4 c0, c1, w; };      // contact (32 B), cached impulse 
 struct nh_StillView { const uint32_t* body_rec; const uint32_t* body_pos; const uint32_t* cnt_sorted; uint32_t* start_sorted; const uint32_t* raw_feature; uint32_t* sc_feat; uint32_t* sc_count; uint32_t pair_cap;
                      const int2* delta; uint32_t parity; };
 
-template<int MAXC, bool FUSED, bool CONTIG = false, int NW = 4, bool STILL = false>
+// AHEAD (STILL, plain form; nh_internal.h: xform ahead): the lane that has advanced its body also does the NEXT step's k_xform<true> for the body's one collider -- world
+// transform, AABB, the test against the inflated box, scene bounds, largest idle counter -- with k_xform's own arithmetic (nh_collide.hip: k_xform, k_asleep_check).
+template<int MAXC, bool FUSED, bool CONTIG = false, int NW = 4, bool STILL = false, bool AHEAD = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ? NH_SOLVER_WPE : 1, MAXC == 4 ? NH_SOLVER_WPE : 1))) void k_solve_one_body(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
                                                         const nh_BodyPair* __restrict__ bodies, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                         float4* __restrict__ states, uint32_t iterations,
                                                         const nh_Contact* __restrict__ contacts, nh_Transform* xf, nh_CachedContactImpulse* __restrict__ impulses,
                                                         nh_CacheView cv, uint32_t* __restrict__ hint, uint32_t cls_a, uint32_t cls_b, uint32_t require_inert,
-                                                        const uint2* __restrict__ simple = nullptr, nh_FusedStep fs = nh_FusedStep(), nh_StillView sv = nh_StillView()) {
+                                                        const uint2* __restrict__ simple = nullptr, nh_FusedStep fs = nh_FusedStep(), nh_StillView sv = nh_StillView(),
+                                                        nh_AheadView av = nh_AheadView()) {
 	// CONTIG: every body of the class comes from k_adj_simple (one collider pair with the static world): its contact list is the record
 	// simple[x] -- one load next to the body state instead of the dependent chain off[x] -> adj[] -> contact
 	constexpr int M = MAXC;
@@ -901,6 +904,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 	__shared__ uint32_t s_cid[NW][64 * M];
 	__shared__ uint32_t s_hint[NW][64], s_first[NW][64];
 	__shared__ int2 s_delta[STILL ? NH_DELTA_MAX : 1];                   // STILL: this step's changes of contact counts (tag-order position, difference)
+	// AHEAD: the body's collider (fetched with the first round of loads).  What the lane needs of it -- local transform, size, inflated box: 80 bytes -- is asked for when
+	// the rows have been built and delivered straight to LDS while the sweeps run: no register holds it, and the wave's contact slots (s_slot: nobody looks at them
+	// between the row build and the results) are where it lands
+	__shared__ uint32_t s_col[AHEAD ? NW : 1][AHEAD ? 64 : 1];
 	uint32_t n_delta = 0;
 	if (STILL) {
 		// The first contact of every record in the dense list is kept from step to step (start_sorted); the records whose count changed this step are listed, and a lane
@@ -944,6 +951,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		if (FUSED && !STILL) h = hint[xc];
 		uint32_t br = NH_BODY_REC_NONE, bpos = 0u, idle0 = 0u;
 		if (STILL) { br = sv.body_rec[xc]; bpos = sv.body_pos[xc]; if (CONTIG && (fs.bits & 4u)) idle0 = fs.idle[xc]; }          // (bit 2 of fs.bits: sleepers form -- somebody may be asleep)
+		uint32_t col = 0xFFFFFFFFu;
+		if (AHEAD) col = av.body_col[xc];
 		if (!inert_word) return;
 		// (STILL: a body asleep -- only a step in sleepers form gets this far with one -- is nobody's: no gravity, no contacts, no advance, nothing stored; nudge.cpp:3669-3703, 4896-4898)
 		const bool mine = STILL ? (x >= 1u && x < nbodies && idle0 != 0xffu) : (x < nbodies && (my_class == cls_a || my_class == cls_b));
@@ -988,6 +997,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			for (int q = 0; q < M; ++q) scid[lane * M + q] = cid[q];
 			s_hint[wave][lane] = h; s_first[wave][lane] = first;
 		}
+		if (AHEAD) { if (!mine) col = 0xFFFFFFFFu; s_col[wave][lane] = col; }
 		__builtin_amdgcn_wave_barrier();
 		// phase A: the wave fetches the per-contact records slot by slot; all loads first, then the comparisons
 		uint32_t sc[M], sflags[M];
@@ -1141,6 +1151,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		if (FUSED && !STILL && mine) hint[x] = first;          // where this body's contacts start in what becomes the next step's cache
 		// (CONTIG: a body's role is one bit for all its contacts, and in most scenes the static world is always "a": when no lane of the wave
 		// has D = a the role selects drop out of the sweep)
+		float4* const s_ah = reinterpret_cast<float4*>(slot);          // AHEAD: piece k of lane l at s_ah[64 k + l]
+		float ah_rad = 0.0f;
+		if (AHEAD) {
+			__builtin_amdgcn_wave_barrier();          // (every lane has read its slots)
+			const uint32_t c0 = s_col[wave][lane];
+			const uint32_t cc = c0 != 0xFFFFFFFFu ? c0 : 0u;          // (unconditional loads at a clamped index, like everything else here)
+			const bool is_box = cc < av.nbox;
+			const float4* lp = reinterpret_cast<const float4*>(is_box ? av.box_xf + cc : av.sph_xf + (cc - av.nbox));
+			const float4* sp4 = is_box ? reinterpret_cast<const float4*>(av.box_data + cc) : lp;          // (a sphere's radius -- four bytes -- comes by register)
+			if (!is_box) ah_rad = av.sph_data[cc - av.nbox].radius;
+			nh_glds16(lp, &s_ah[lane]); nh_glds16(lp + 1, &s_ah[64u + lane]);
+			nh_glds16(av.fat_box + 2u * (size_t)cc, &s_ah[128u + lane]); nh_glds16(av.fat_box + 2u * (size_t)cc + 1u, &s_ah[192u + lane]);
+			nh_glds16(sp4, &s_ah[256u + lane]);
+		}
 		if (CONTIG && __builtin_amdgcn_ballot_w64(mine && (STILL ? (still_has && (br & NH_BODY_REC_IS_A) != 0) : ((sp.y >> 28) & 1u) != 0)) == 0) {
 			for (uint32_t it = 0; it < iterations; ++it) {
 #pragma unroll
@@ -1158,6 +1182,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		float4 a0 = make_float4(0, 0, 0, 0), a1 = a0;
 		uint32_t idle_in = 0;
 		const bool advance_here = CONTIG && (fs.bits & 2u) && mine;
+		// (AHEAD: the collider's 80 bytes out of LDS before the results take their place there and before any store is issued -- a wait for the loads that brought them
+		// must not turn into a wait for this wave's stores)
+		float4 ah_l0 = make_float4(0, 0, 0, 0), ah_l1 = ah_l0, ah_fmn = ah_l0, ah_fmx = ah_l0, ah_sz = ah_l0;
+		uint32_t ah_col = 0xFFFFFFFFu;
+		if (AHEAD) {
+			ah_col = s_col[wave][lane];
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the five loads issued before the sweeps: nothing else of this wave is in flight)
+			ah_l0 = s_ah[lane]; ah_l1 = s_ah[64u + lane]; ah_fmn = s_ah[128u + lane]; ah_fmx = s_ah[192u + lane]; ah_sz = s_ah[256u + lane];
+		}
 		if (advance_here) { a0 = t0; a1 = t1; idle_in = idle_early; }
 		// results: state + exported impulse (update_cached_impulses, nudge.cpp:4872-4882) per contact, written by the wave slot by slot
 		__builtin_amdgcn_wave_barrier();
@@ -1184,12 +1217,69 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			reinterpret_cast<float4*>(momentum + x)[0] = make_float4(v.vx, v.vy, v.vz, v.mass_inverse);
 			reinterpret_cast<float4*>(momentum + x)[1] = make_float4(v.wx, v.wy, v.wz, v.w_unused);
 		}
+		// AHEAD: what this lane's collider contributes to the next step's scene bounds (min corner, order-preserving encoding), the body's new idle counter, and whether
+		// the next step would have failed in its k_xform<true> (collider outside its inflated box; body asleep)
+		uint32_t nmin[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, nmax[3] = { 0u, 0u, 0u }, ntop = 0u;
+		bool nfail = false;
 		if (advance_here) {
 			float pos[3] = { a0.x, a0.y, a0.z }, rot[4] = { a1.x, a1.y, a1.z, a1.w };
 			const float vel[3] = { v.vx, v.vy, v.vz }, ang[3] = { v.wx, v.wy, v.wz };
-			fs.idle[x] = nh_advance_body(pos, rot, vel, ang, (uint8_t)idle_in, fs.time_step);
+			const uint8_t idle_out = nh_advance_body(pos, rot, vel, ang, (uint8_t)idle_in, fs.time_step);
+			fs.idle[x] = idle_out;
 			reinterpret_cast<float4*>(xf + x)[0] = make_float4(pos[0], pos[1], pos[2], a0.w);
 			reinterpret_cast<float4*>(xf + x)[1] = make_float4(rot[0], rot[1], rot[2], rot[3]);
+			if (AHEAD) {
+				ntop = idle_out; nfail = idle_out == 0xffu;
+				const uint32_t c = ah_col;
+				if (c != 0xFFFFFFFFu) {
+					const bool is_box = c < av.nbox;
+					const float4 l0 = ah_l0, l1 = ah_l1, fmn = ah_fmn, fmx = ah_fmx;
+					float4 sz = ah_sz;
+					if (!is_box) sz.x = ah_rad;
+					// Transform * Transform (nudge.cpp:1165-1175), |R| * size (3027-3037): k_xform's lines
+					const nh_quat bq = { rot[0], rot[1], rot[2], rot[3] };
+					const nh_quat lq = { l1.x, l1.y, l1.z, l1.w };
+					const nh_f3 p = nh_rotate(bq, nh_make3(l0.x, l0.y, l0.z)) + nh_make3(pos[0], pos[1], pos[2]);
+					const nh_quat q = nh_qmul(bq, lq);
+					float sx, sy, sz2;
+					if (is_box) {
+						const nh_m33 m = nh_matrix(q);
+						const nh_f3 c0 = m.c0 * sz.x, c1 = m.c1 * sz.y, c2 = m.c2 * sz.z;
+						sx = fabsf(c0.x) + fabsf(c1.x) + fabsf(c2.x);
+						sy = fabsf(c0.y) + fabsf(c1.y) + fabsf(c2.y);
+						sz2 = fabsf(c0.z) + fabsf(c1.z) + fabsf(c2.z);
+					} else {
+						sx = sy = sz2 = sz.x;
+					}
+					const float mnx = p.x - sx, mny = p.y - sy, mnz = p.z - sz2, mxx = p.x + sx, mxy = p.y + sy, mxz = p.z + sz2;
+					float4* const wx = reinterpret_cast<float4*>(av.xf) + 2u * (size_t)c;
+					wx[0] = make_float4(p.x, p.y, p.z, l0.w);          // (l0.w: the collider's body -- this one)
+					wx[1] = make_float4(q.x, q.y, q.z, q.s);
+					av.aabb_min[c] = make_float4(mnx, mny, mnz, l0.w);
+					av.aabb_max[c] = make_float4(mxx, mxy, mxz, __uint_as_float(0u));          // (plain form: nobody asleep)
+					nfail |= !(mnx >= fmn.x && mny >= fmn.y && mnz >= fmn.z && mxx <= fmx.x && mxy <= fmx.y && mxz <= fmx.z);       // (NaN: out)
+					nmin[0] = nmax[0] = nh_float_flip(mnx); nmin[1] = nmax[1] = nh_float_flip(mny); nmin[2] = nmax[2] = nh_float_flip(mnz);
+				}
+			}
+		}
+		if (AHEAD) {
+			// the wave's share goes to the NEXT step's words (the other parity; cleared by this step's k_xform<true> or, in a step that had none, by its narrowphase)
+			nh_DevState* const stw = const_cast<nh_DevState*>(cv.st);
+			const uint32_t np = sv.parity ^ 1u;
+#pragma unroll
+			for (int k = 0; k < 3; ++k) {
+				for (int d = 32; d >= 1; d >>= 1) { nmin[k] = min(nmin[k], (uint32_t)__shfl_xor((int)nmin[k], d)); nmax[k] = max(nmax[k], (uint32_t)__shfl_xor((int)nmax[k], d)); }
+			}
+			for (int d = 32; d >= 1; d >>= 1) ntop = max(ntop, (uint32_t)__shfl_xor((int)ntop, d));
+			const unsigned long long bad = __ballot(nfail);
+			// (NH_AHEAD_PARTS places, results not awaited: a wave neither queues behind sixteen thousand others on one address nor waits for an answer; the next
+			// step's narrowphase puts the places together, with the static world's share)
+			uint32_t* const part = &stw->ahead_part[np][(blockIdx.x * NW + wave) & (NH_AHEAD_PARTS - 1u)][0];
+			const uint32_t mine_min = lane == 0u ? nmin[0] : (lane == 1u ? nmin[1] : nmin[2]);
+			const uint32_t mine_max = lane == 3u ? nmax[0] : (lane == 4u ? nmax[1] : (lane == 5u ? nmax[2] : ntop));
+			if (lane < 3u) atomicMin(&part[lane], mine_min);
+			else if (lane < 7u) atomicMax(&part[lane], mine_max);
+			else if (lane == 7u && bad != 0ull) atomicMax(&stw->ahead_failed_seq, fs.seq + 1u);
 		}
 		__builtin_amdgcn_wave_barrier();
 		if (CONTIG) break;
@@ -2448,6 +2538,7 @@ static void still_note_movers(nh_context* ctx, const nh_DevState* h) {
 	nh_StillStep& ss = ctx->still;
 	// (a still step in sleepers form that found NOBODY awake: the next step is a full one -- two of those in a row start the asleep steps, which cost nothing)
 	if (ss.sleepers && h->active == 0u) ss.ok_next = false;
+	if (h->ahead_multi) ss.ahead_world_bad = true;          // (xform ahead: some body carries several colliders -- k_ahead_check; the step that relied on the map has failed itself)
 	if (h->fat_inserts != ss.seen_inserts) ss.movers_left = 16u;
 	else if (ss.movers_left) ss.movers_left--;
 	ss.seen_inserts = h->fat_inserts; ss.seen_rebuilds = h->fat_rebuilds;
@@ -2669,7 +2760,7 @@ static void launch_apply_static(nh_context* ctx, nh_ContactConstraintData* d, co
 	auto go1 = [&](const char* name, auto kernel, uint32_t cls_a, uint32_t cls_b) {
 		NH_LAUNCH(ctx, name, kernel, nh_grid_for(B, 256, 8192), 256, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
 		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, cls_a, cls_b,
-		          (fused && drop_states) ? 2u : 0u, (const uint2*)nullptr, nh_FusedStep(), nh_StillView());
+		          (fused && drop_states) ? 2u : 0u, (const uint2*)nullptr, nh_FusedStep(), nh_StillView(), nh_AheadView());
 	};
 	const bool late = d->has_late;
 	if (d->static_inert) {
@@ -2726,8 +2817,19 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 			fs.bits = 3u | (ss.sleepers ? 4u : 0u); fs.idle = bodies->idle_counters; fs.seq = ctx->collide_seq;
 			fs.guard_seq = ss.verdict.pending ? ss.verdict.seq : ctx->collide_seq;          // (a solver behind an unconfirmed still step leaves when THAT one failed)
 #define NH_SOLVE_STILL(NWAVES) NH_LAUNCH(ctx, "solve_still", (k_solve_one_body<4, true, true, NWAVES, true>), (B + 64u * NWAVES - 1u) / (64u * NWAVES), 64 * NWAVES, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum, \
-		          (float4*)d->states, iterations, ctx->raw_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fs, sv)
+		          (float4*)d->states, iterations, ctx->raw_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fs, sv, nh_AheadView())
+			// XFORM AHEAD (nh_internal.h): another sub-step of this nh_step call follows, the step is in the plain form and every dynamic body has its one collider on the
+			// map -- the lanes do the next step's k_xform<true> on their way out
+			const bool ahead = ss.ahead_plain && ss.more_steps && ss.ahead_map_ok && !ss.no_ahead && !ss.ahead_world_bad && ctx->env_solver_waves != 4 && ctx->env_solver_waves != 2 &&
+			                   ctx->own_xf && ctx->body_col && ctx->body_col_capacity >= B;
+			if (ahead) {
+				const nh_ColliderData& cd = ss.colliders;
+				nh_AheadView av = { ctx->body_col, cd.boxes.transforms, cd.boxes.data, cd.spheres.transforms, cd.spheres.data, cd.boxes.count, ctx->own_xf, ctx->own_aabb_min, ctx->own_aabb_max, ctx->fat_box };
+				NH_LAUNCH(ctx, "solve_still", (k_solve_one_body<4, true, true, 1, true, true>), (B + 63u) / 64u, 64, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
+				          (float4*)d->states, iterations, ctx->raw_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fs, sv, av);
+			} else
 			if (ctx->env_solver_waves == 4) NH_SOLVE_STILL(4); else if (ctx->env_solver_waves == 2) NH_SOLVE_STILL(2); else NH_SOLVE_STILL(1);
+			ss.ahead_ready = ahead;
 			if (ss.pipelined && ss.h_ring[0]) {
 				// nh_step: first the verdict of the still step BEFORE this one (its counters landed long ago) ...
 				if (ss.verdict.pending) {
@@ -2784,7 +2886,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 		}
 #define NH_SOLVE_CONTIG(NWAVES) NH_LAUNCH(ctx, "solve_one_body", (k_solve_one_body<4, true, true, NWAVES>), (B + 64u * NWAVES - 1u) / (64u * NWAVES), 64 * NWAVES, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum, \
 		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, \
-		          1u | (drop_states ? 2u : 0u), d->simple, fs, nh_StillView())
+		          1u | (drop_states ? 2u : 0u), d->simple, fs, nh_StillView(), nh_AheadView())
 		if (ctx->env_solver_waves == 4) NH_SOLVE_CONTIG(4); else if (ctx->env_solver_waves == 2) NH_SOLVE_CONTIG(2); else NH_SOLVE_CONTIG(1);
 		ctx->grav.rest_pending = gravity_here;        // everybody else's gravity: finish_setup, once the round trip has told whether there is anybody else
 		int rc = finish_setup(ctx, d);
@@ -3136,7 +3238,7 @@ int nh_still_verdict_now(nh_context* ctx) {
 static int still_forget_failed(nh_context* ctx, bool advanced, uint32_t voided) {
 	nh_StillStep& ss = ctx->still;
 	ss.verdict.pending = false;
-	ss.active = false; ss.resolved = false; ss.setup_d = nullptr; ss.ok_next = false;
+	ss.active = false; ss.resolved = false; ss.setup_d = nullptr; ss.ok_next = false; ss.ahead_ready = false;
 	ss.note_failure();
 	ss.failed += voided;                               // (still steps launched that did not happen: the failed one, and the one launched behind it if it got that far)
 	ctx->pending = nullptr;
@@ -3177,6 +3279,7 @@ extern "C" int nh_step(nh_context* ctx, const nh_StepArgs* a, uint32_t steps) {
 	ss.pipelined = ss.h_ring[0] != nullptr && (ctx->flags & NH_FLAG_FUSED_STEP) && !(ctx->flags & (NH_FLAG_SYNC_COUNTS | NH_FLAG_EXACT_ORDER)) && !ss.disabled &&
 	               !(ctx->timing && ctx->timing_filter.empty());
 	ss.verdict.pending = false;
+	ss.ahead_map_ok = false; ss.ahead_ready = false;          // (xform ahead, nh_internal.h: nothing carries over from another call -- the caller may have changed anything in between)
 	int result = NH_OK;
 	uint32_t i = 0;
 	while (i < steps || ss.verdict.pending) {
@@ -3198,6 +3301,7 @@ extern "C" int nh_step(nh_context* ctx, const nh_StepArgs* a, uint32_t steps) {
 			ctx->asleep.streak = 0;
 		}
 		int rc;
+		ss.more_steps = i + 1u < steps;
 		nh_Arena temporary = a->arena;
 		nh_ContactImpulseData* imp = nullptr;
 		nh_ContactConstraintData* con = nullptr;
@@ -3219,7 +3323,7 @@ extern "C" int nh_step(nh_context* ctx, const nh_StepArgs* a, uint32_t steps) {
 		    (rc = nh_advance(ctx, a->active_bodies, a->bodies, a->time_step))) { result = rc; break; }
 		++i;
 	}
-	ss.pipelined = false;
+	ss.pipelined = false; ss.more_steps = false; ss.ahead_ready = false; ss.ahead_map_ok = false;
 	if (result && ss.verdict.pending) { hipEventSynchronize(ss.ev_ring[ss.verdict.slot]); ss.verdict.pending = false; }
 	return result;
 }

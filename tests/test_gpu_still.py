@@ -479,3 +479,64 @@ def test_state_stream_delivers_the_transforms_of_the_steps_it_names():
     a.step(10); b.step(10)
     _same_world(a, b, "after disarming")
     a.close(); b.close(); ref.close()
+
+
+@pytest.mark.parametrize("sphere_fraction", [0.0, 0.5])
+def test_xform_ahead_leaves_the_bits_of_steps_that_transform_themselves(sphere_fraction):
+    """Inside one nh_step call a plain still step's solver does the next step's k_xform<true> (nh_internal.h: xform ahead): that step starts at the narrowphase.  Against
+    the same library with the option off, and against the one that never speculates, checkpoint by checkpoint: through rest (most steps ahead), through a hop and a
+    shove (a collider outside its inflated box is seen by the solver lane that advanced it and fails the NEXT step), through falling asleep (the saturated idle
+    counter likewise), and with calls of every length -- one step (never ahead), two, many."""
+    scene = S.grid_tiles(2, side=36, sphere_fraction=sphere_fraction, seed=53, lattice_cols=2)
+    a, b, c = _world(scene, True), _world(scene, True, env=["NH_NO_XFORM_AHEAD"]), _world(scene, False)
+    done = 0
+    for cp in (90, 91, 93, 120, 121, 160):
+        for w in (a, b, c):
+            w.step(cp - done)
+        done = cp
+        _same_world(a, b, f"step {cp} (ahead vs not)"); _same_world(a, c, f"step {cp} (ahead vs never speculating)")
+    c0 = a.counts()
+    assert c0["ahead_steps"] >= 40, c0
+    assert b.counts()["ahead_steps"] == 0 and b.counts()["still_steps"] >= 40
+    for w in (a, b, c):
+        m = w.get_bodies()["momentum"]
+        m["velocity"][7::89, 1] = 3.0
+        m["velocity"][13::101, 2] = 1.0
+        w.set_bodies(momentum=m)
+    for cp in (200, 260, 330, 420, 520):
+        for w in (a, b, c):
+            w.step(cp - done)
+        done = cp
+        _same_world(a, b, f"step {cp} (ahead vs not)"); _same_world(a, c, f"step {cp} (ahead vs never speculating)")
+    c1 = a.counts()
+    print(f"\n[xform ahead, spheres {sphere_fraction}] {c1['ahead_steps']} of {c1['still_steps']} still steps started at the narrowphase; replays {c1['still_replays']} (without: {b.counts()['still_replays']})")
+    # (after the kick the still steps are in movers form, then -- the idle counters of everybody else near saturation -- in sleepers form: few plain ones)
+    assert c1["error"] == 0 and c1["ahead_steps"] > c0["ahead_steps"] and c1["still_replays"] > c0["still_replays"], (c0, c1)
+    a.close(); b.close(); c.close()
+
+
+def test_xform_ahead_is_refused_for_bodies_with_several_colliders():
+    """A solver lane stands in for k_xform<true> for ONE collider.  Some boxes carry a second collider high above them (it touches nothing: the bodies stay in the class
+    still steps own): the map check sees it on the device, the step that relied on the map fails itself, the host stops offering -- and every bit is what the library
+    with the option off leaves."""
+    scene = S.grid_tiles(1, side=20, seed=59)
+    n = len(scene["body_transforms"]) - 1
+    owners = np.arange(1, n + 1, dtype=np.uint32)[3::7]
+    sph_t = np.zeros(len(owners), dtype=scene["sphere_transforms"].dtype)
+    sph_t["rotation"][:, 3] = 1.0
+    sph_t["position"][:, 1] = 2.5
+    sph_t["body"] = owners
+    sph_d = np.zeros(len(owners), dtype=scene["sphere_data"].dtype)
+    sph_d["radius"] = 0.25
+    first_tag = int(scene["box_tags"].max()) + 1
+    scene.update(sphere_transforms=sph_t, sphere_data=sph_d, sphere_tags=np.arange(first_tag, first_tag + len(owners), dtype=np.uint32))
+    a, b = _world(scene, True), _world(scene, True, env=["NH_NO_XFORM_AHEAD"])
+    done = 0
+    for cp in (100, 140, 141, 200):
+        a.step(cp - done); b.step(cp - done); done = cp
+        _same_world(a, b, f"step {cp}")
+    ca, cb = a.counts(), b.counts()
+    print(f"\n[xform ahead refused] ahead steps {ca['ahead_steps']}, still steps {ca['still_steps']} (option off: {cb['still_steps']}), replays {ca['still_replays']} / {cb['still_replays']}")
+    assert ca["error"] == 0 and ca["still_steps"] >= 80
+    assert ca["ahead_steps"] <= 4 and ca["still_replays"] <= cb["still_replays"] + 4, (ca, cb)
+    a.close(); b.close()
