@@ -124,12 +124,13 @@ def grid_table_entries(C):
     return min(want, 1 << 24)
 
 # timer name (nh_* launch sites) -> kernel symbol prefix in the rocprofv3 PMC export (profiles/export_pmc.py)
-PMC_KERNEL = {"solve_one_body": "k_solve_one_body<4, true, true, 1, false>", "solve_still": "k_solve_one_body<4, true, true, 1, true>", "narrowphase_still": "k_narrowphase<false, true>",
+PMC_KERNEL = {"solve_one_body": "k_solve_one_body<4, true, true, 1, false>", "solve_still": "k_solve_one_body<4, true, true, 1, true, true>", "narrowphase_still": "k_narrowphase<false, true>",
               "xform_still": "k_xform<true>", "apply_static": "k_apply_static<4, true>", "narrowphase": "k_narrowphase<false, false>",
               "gather_contacts": "k_gather_contacts", "find_pairs": "k_find_pairs", "radix_pass": "os_pass<unsigned long, unsigned int, true>",
               "apply_level": "k_level_exec<false>", "write_cache": "k_write_cache", "xform_aabb": "k_xform", "blk_sweep": "k_blk_sweep<false, true>"}
 
 
+AHEAD_BYTES_PER_BODY = 4 + 32 + 16 + 32 + 32 + 32       # xform ahead (main): what a still solver lane moves for the next step's k_xform<true>
 PMC_SUFFIX = ""       # "_c4" for the pit: its own export (profiles/collect.sh)
 
 
@@ -543,6 +544,7 @@ def main():
     if dominant:
         w.enable_timing(True, only=dominant)
     dt, blocks, contact_sum, pair_sum, general_sum = 0.0, 0, 0.0, 0.0, 0.0
+    ahead_sum = 0          # timed steps that started at the narrowphase: the step before them did their k_xform<true> inside its solver (include/nudge_hip.h note 9, xform ahead)
     block_ms = []
     timed_acc = [0.0, 0, 0.0, 0]          # inside the timed blocks only: seconds in refreshes, refreshes, seconds enqueueing per-step halos, per-step halos
     while True:
@@ -578,6 +580,7 @@ def main():
         contact_sum += 0.5 * (c0["contacts"] + c1["contacts"])
         pair_sum += 0.5 * (c0["pairs"] + c1["pairs"])
         general_sum += 0.5 * (c0["general_contacts"] + c1["general_contacts"])
+        ahead_sum += c1.get("ahead_steps", 0) - c0.get("ahead_steps", 0)
         if snap is None or all_ranks(dt >= args.min_time) or blocks >= 5000:          # (N > 1: every rank leaves after the same block)
             break
     dom = w.kernel_times(reset=True).get(dominant) if dominant else None
@@ -656,6 +659,15 @@ def main():
         fused = bool(w.flags & E.NH_FLAG_FUSED_STEP)
         single = fused or bool(w.flags & E.NH_FLAG_SINGLE_APPLY)
         KERNEL_BYTES["solve_one_body"] = ("K", KERNEL_BYTES["solve_one_body"][1] + (0.0 if single else 16.0) - (0.0 if fused else 8.5))
+        # the still solver with XFORM AHEAD: in `ahead_frac` of its launches every lane also does the next step's k_xform<true> for its body's collider -- collider index
+        # 4 r, local transform 32 r, size 16 r, inflated box 32 r, world transform 32 w, AABB 32 w = 148 B per body (the body's own transform is in registers already:
+        # 37 B less than k_xform<true> moves per collider) -- priced per contact for the scene at hand
+        ahead_frac = min(1.0, ahead_sum / float(timed_steps)) if timed_steps else 0.0
+        if ahead_frac > 0.0 and K > 0:
+            KERNEL_BYTES["solve_still"] = ("K", KERNEL_BYTES["solve_still"][1] + AHEAD_BYTES_PER_BODY * ahead_frac * nb / K)
+        out["config"]["xform_ahead"] = {"timed_steps_started_at_the_narrowphase": ahead_sum, "share_of_timed_steps": ahead_frac,
+                                        "bytes_per_body_added_to_solve_still": AHEAD_BYTES_PER_BODY,
+                                        "note": "a plain still step's solver does the next sub-step's world transforms / AABBs / box test / scene bounds (nh_step, note 9): that step has no k_xform<true>"}
         # whole step: sum of the per-kernel algorithmic bytes over the kernels the instrumented pass saw, against the peak
         # (a kernel launched once per colour class / level moves its share of the items per launch: priced per step, not per launch)
         # A kernel the instrumented pass (3 steps, one synchronisation at its end) saw less than once per step runs once per SYNCHRONISATION, not per step: the views

@@ -64,6 +64,11 @@
  *      again are still steps), and a body asleep in a set of its own (no overlapping AABB of another dynamic body, no user connections in the world) is left alone -- its
  *      pairs are sleeping pairs, its cached impulses are kept aside by the reference's rule (nudge.cpp:3669-3703, 4064-4101).  What still ends in a full step: a first
  *      contact with a collider the body was not resting on, two dynamic bodies touching, sets of several bodies with a sleeper among them, a rebuild of the kept list.
+ *      Inside ONE nh_step call -- where the caller cannot touch anything between two sub-steps -- a still step in which nobody moves and nobody can be asleep also does
+ *      the next sub-step's first kernel ("xform ahead"; option "no_xform_ahead"): the solver lane that has just advanced a body writes its collider's world transform
+ *      and AABB, tests it against the inflated box and gathers the scene bounds, so that the next sub-step starts at the narrowphase; what the lane finds wanting fails
+ *      THAT sub-step, which is run again in full.  Only for worlds whose dynamic bodies carry one collider each (checked on the device once per call).
+ *      nh_Counts.ahead_steps counts the sub-steps that started that way.
  *      The caller's dense contact list (contacts->data / bodies / tags / features, contacts->sleeping_pairs), active list and contact cache are VIEWS under this regime: they are
  *      brought up to date by nh_export_views (what: NH_VIEW_CONTACTS, NH_VIEW_CACHE, NH_VIEW_ACTIVE), by nh_append_contacts, and by any step that does not qualify -- not by
  *      every step, and not by the cheap observers: nh_read_counts returns the counters and nh_synchronize waits for the stream, neither exports anything (the

@@ -1020,7 +1020,11 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		}
 		// (every lane's FIRST kept pair is asked for before the frame is put together: the wave waits once for both)
 		i_first = blockIdx.x * blockDim.x + threadIdx.x;
+#ifndef NH_NO_PAIR_PREFETCH
 		{ const uint32_t ic = min(i_first, kept_cap - 1u); kp_first = pairs[SPH ? kept_cap - 1u - ic : ic]; }
+#else
+		i_first = 0xFFFFFFFFu;
+#endif
 		still_frame();
 		// (the layout must be the last full step's, and the kept list at least as long as the pair list it was written from: what lies behind are pairs APPENDED by
 		// still steps in movers form since -- below)
