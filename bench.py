@@ -88,6 +88,7 @@ KERNEL_BYTES = {
     #   per body (4 contacts): record 4, tag-order position 4, count 4, first contact 4, 4 feature words 16, cached feature words 16 r + 16 w, cached count 4 r + 4 w,
     #                          transform 32 r + 32 w, properties 16, momentum 32 r + 32 w, idle 1 r + 1 w                                   = 133 r + 85 w -> 33.25 r + 21.25 w
     "solve_still": ("K", 48 + 16 + 33.25 + 21.25),         # = 118.5
+    "ahead_map": ("C", 16 + 4), "ahead_check": ("C", 16 + 4),      # once per nh_step call (xform ahead): AABB min + body of every collider -> body's collider / several colliders? + the static world's bounds
     "asleep_check": ("C", 32 + 32 + 16 + 4 + 32 + 32 + 4 + 1),   # nh_step on a world asleep: local + body transform, shape, tag, the remembered AABB and tag, the idle counter
     "slot_counts": ("R", 4 + 4 + 4), "slots_to_cache": ("K", 16 + 4 + 28), "cache_to_slots": ("K", 4 + 16 + 4 + 20),
     "gravity_rest": ("B", 4 + 1),                           # active list + class of every body; momentum only of bodies outside the fused solver
