@@ -202,11 +202,13 @@ def valu_ceiling(kernel, launch_ms, waves_per_simd=2):
             "frac_of_dependent_chain_rate": rate / (VALU_DEPENDENT_PER_US_PER_WAVE * waves_per_simd), "waves_per_simd": waves_per_simd,
             "sq_share_of_wave_cycles": {key: k.get(key + "_share_of_wave_cycles") for key in ("active", "valu", "parked_at_waitcnt", "issue_stall")},
             "source": [os.path.basename(files[-1]), "profiles/r05_valu_rate.log (tools/valu_rate.hip)"],
-            "note": "0.61 of what the SIMD issues when fed independent FMAs (valu_frac) -- but this kernel's instructions are not FMAs: priced one by one (mov / min / max / "
-                    "compare / select at 1.7 x a multiply, rcp / rsq at 3.3 x, a select through VCC at 6 x) two waves keep the VALU pipe ~0.7 busy over the whole kernel and "
-                    "~1.0 while they compute (valu_pipe_busy_*): the sweeps are VALU-THROUGHPUT bound, the rest of the time both waves of a SIMD sit in their memory phases.  "
-                    "Consistent with the experiment: a third wave per SIMD (168 VGPRs, 12,288 B LDS; resident by PMC, 1.49 x SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE) made every wave "
-                    "1.55 x slower -- 170 us against 153 (profiles/r05_solver_three_waves_ab.log, tools/experiments/solver_three_waves.py).  Not HBM-bound (roofline.frac)"}
+            "note": "valu_frac: of what the SIMD issues when fed independent FMAs -- but this kernel's instructions are not FMAs: priced one by one (mov / min / max / "
+                    "compare / select at 1.7 x a multiply, rcp / rsq at 3.3 x, a select through VCC at 6 x) two waves keep the VALU pipe about two thirds busy over the whole "
+                    "kernel and ~1.0 in the cycles in which they are not parked at s_waitcnt (valu_pipe_busy_*).  Two experiments say what the rest is NOT: a third wave per "
+                    "SIMD (168 VGPRs, 12,288 B LDS; resident by PMC) made every wave 1.55 x slower -- 170 us against 153 (profiles/r05_solver_three_waves_ab.log, "
+                    "tools/experiments/solver_three_waves.py); and the same two waves with EVERY load prefetched under the previous group's sweeps (persistent waves, LDS-direct "
+                    "loads: tools/experiments/solver_pipelined.py) take 177 us against 171 -- not latency either.  What is left is two throughputs that overlap imperfectly: "
+                    "the VALU pipe at this instruction mix and 2.7 - 4.0 TB/s (PMC) moved in 16- and 32-byte pieces (DESIGN.md 7.3)"}
 
 
 def pmc_step_total():
@@ -719,7 +721,7 @@ def main():
             vc = valu_ceiling(dominant, ms) if (dominant in ("solve_still", "solve_one_body") and comparable and which == "") else None          # (the SQ export describes c2's launches)
             if vc:
                 out["roofline"]["valu"] = vc
-                out["roofline"]["limited_by"] = "VALU throughput of the sweeps at this kernel's instruction mix (roofline.valu), not HBM bandwidth"
+                out["roofline"]["limited_by"] = "VALU throughput at this kernel's instruction mix (roofline.valu: the pipe is ~1.0 busy while the waves compute, two thirds of the kernel) next to the bytes it moves in 16- and 32-byte pieces; neither more waves nor prefetching helps (DESIGN.md 7.3)"
 
         elif dom:
             out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
