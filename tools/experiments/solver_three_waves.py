@@ -5,7 +5,8 @@ What it changes: (1) a row's second tangent v = u x n is recomputed at every use
 exchange slots in LDS -- 12,288 bytes per one-wave workgroup, which is what lets TWELVE of them share a CU (tools/valu_rate.hip: 13,312 bytes do not fit twelve
 times): the first-slot / solve-order tables travel by shuffle, the delta list is read with uniform loads; (4) amdgpu_waves_per_eu(3): 168 VGPRs, 96 bytes of scratch.
 Result on an MI355X (profiles/r05_solver_three_waves_ab.log): solve_still 153 us (two waves, as shipped) -> 158 us with (1)-(3) at two waves -> 170 us at three waves.
-Bit-identical in every variant (tests/test_gpu_still.py, tests/test_gpu_parity.py)."""
+Bit-identical in every variant (tests/test_gpu_still.py, tests/test_gpu_parity.py).
+Applies to nh_solve.hip as of commit d5fd6d4 (before the solver learnt to do the next step's transforms): tools/build_variant.sh three "" d5fd6d4 with NH_VARIANT_PATCH set."""
 import sys
 s = open(sys.argv[1]).read()
 def rep(old, new, count=1):
