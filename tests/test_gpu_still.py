@@ -540,3 +540,33 @@ def test_xform_ahead_is_refused_for_bodies_with_several_colliders():
     assert ca["error"] == 0 and ca["still_steps"] >= 80
     assert ca["ahead_steps"] <= 4 and ca["still_replays"] <= cb["still_replays"] + 4, (ca, cb)
     a.close(); b.close()
+
+
+def test_xform_ahead_in_a_world_of_spheres_on_one_slab():
+    """One static box and nothing but spheres: the still narrowphase has no box-box launch (the sphere launch clears, reduces and checks for the step), every solver lane's
+    collider is a sphere.  With and without the option, and against the library that never speculates."""
+    f = np.float32
+    n = 30 * 30
+    st = S._identity_transforms(1)
+    st["position"][0] = (0.0, -20.0, 0.0)
+    ssz = np.array([[60.0, 10.0, 60.0]], dtype=np.float32)
+    d = S._draws(0x9E3779B97F4A7C15 ^ 61, n)
+    spt = S._identity_transforms(n)
+    spt["position"][:, 0] = (np.arange(n) % 30).astype(np.float32) * f(3.0) - f(43.5) + d[:, 4] * f(0.2)
+    spt["position"][:, 2] = (np.arange(n) // 30).astype(np.float32) * f(3.0) - f(43.5) + d[:, 5] * f(0.2)
+    radius = (d[:, 0] * f(0.5) + f(0.5)).astype(np.float32)
+    spt["position"][:, 1] = f(-10.0) + radius + d[:, 6] * f(0.5) + f(0.5)
+    empty = S._identity_transforms(0)
+    scene = S._assemble((st, ssz), (empty, np.zeros((0, 3), np.float32), np.zeros(0, S.PROPERTIES)), (spt, radius, S._sphere_properties(radius)),
+                        dict(S.DEFAULT_PARAMS, iterations=8), name="spheres900")
+    a, b, c = _world(scene, True), _world(scene, True, env=["NH_NO_XFORM_AHEAD"]), _world(scene, False)
+    done = 0
+    for cp in (80, 81, 120, 200, 320, 450):
+        for w in (a, b, c):
+            w.step(cp - done)
+        done = cp
+        _same_world(a, b, f"step {cp} (ahead vs not)"); _same_world(a, c, f"step {cp} (ahead vs never speculating)")
+    ca = a.counts()
+    print(f"\n[xform ahead, spheres only] {ca['ahead_steps']} of {ca['still_steps']} still steps started at the narrowphase; replays {ca['still_replays']}")
+    assert ca["error"] == 0 and ca["ahead_steps"] >= 60, ca
+    a.close(); b.close(); c.close()
