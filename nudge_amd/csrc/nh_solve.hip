@@ -960,7 +960,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		uint32_t b = 0, cnt = 0;
 		// (a wave none of whose 64 bodies is of the kernel's classes -- a ball pit, where four million bodies are the blocked solver's and a handful sit alone on the
 		// floor -- goes straight to its next 64: the second round of loads is the expensive one)
-		if (!CONTIG && !STILL && __builtin_amdgcn_ballot_w64(mine) == 0ull) { x += gridDim.x * blockDim.x; continue; }
+		if (!STILL && __builtin_amdgcn_ballot_w64(mine) == 0ull) { if (CONTIG) break; x += gridDim.x * blockDim.x; continue; }
 		if (!mine) { sp = make_uint2(0u, 0u); h = NH_HINT_NONE; br = NH_BODY_REC_NONE; }
 		uint32_t cid[M];
 		uint32_t first = 0xFFFFFFFFu;
