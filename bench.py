@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- steps/s and contacts solved/s of the stepping hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU.  Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (the driver's way) the ranks are the launcher's; started
+plainly, `python bench.py --gpus N` re-executes itself under that launcher with N ranks (self_launch).  It refuses when the node shows fewer than N devices or when a
+launcher's WORLD_SIZE disagrees with --gpus: no line ever reports fewer GPUs than were asked for.  `--dry-launch` proves the launch alone (gloo, no GPU).
 
 A "step" is one full pass of the hot path (collide -> gravity -> read cache -> setup -> apply x I -> update ->
 write cache -> advance, reference example/main.cpp:274-328) over one world resident in HBM.
@@ -372,6 +376,50 @@ def committed_single_gpu_16M():
         return None
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n, dry):
+    """Re-executes this command line under `python -m torch.distributed.run` with n ranks on this node (one per GPU) and never returns.  Refuses when the node
+    shows fewer than n devices -- except for --dry-launch, which touches no GPU -- so `--gpus 8` can never come back as a one-GPU number."""
+    if not dry and os.environ.get("NUDGE_BENCH_ONE_DEVICE", "0") != "1":
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            raise SystemExit(f"bench.py --gpus {n}: {have} HIP device(s) visible on this node -- refusing to run (nothing is measured on fewer GPUs than asked for)")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execvpe(sys.executable, cmd, env)
+
+
+def dry_launch(rank, world):
+    """--dry-launch: the ranks of this invocation find each other (gloo, CPU) and rank 0 prints what it saw.  The launch path of `--gpus N` without a GPU."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.zeros(world, dtype=torch.int64)
+        t[rank] = 1 + int(os.environ.get("LOCAL_RANK", "0"))
+        dist.all_reduce(t)
+        seen, locals_ = int((t > 0).sum()), [int(v) - 1 for v in t.tolist()]
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen, locals_ = 1, [0]
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_seen": seen, "local_ranks": locals_,
+                          "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "environment"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -385,16 +433,29 @@ def main():
     ap.add_argument("--land-cap", type=int, default=None, help="give up if the scene has not landed after this many steps")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--profile-kernels", action="store_true", help="also print the per-kernel time table (stderr)")
+    ap.add_argument("--dry-launch", action="store_true", help="only prove the launch: every rank joins a gloo group, rank 0 prints how many ranks it saw (no GPU needed)")
     args = ap.parse_args()
 
-    import torch
+    # ---- launch: `python bench.py --gpus N` with no torch.distributed.run around it starts its own N ranks (missing 1: it used to step ONE GPU and
+    # print n_gpus 1).  A launcher that did set the environment must agree with --gpus; nothing here ever measures fewer GPUs than it was asked for.
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and not launched:
+        self_launch(args.gpus, args.dry_launch)          # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to measure {world} rank(s) under the name of {args.gpus}")
+    if args.dry_launch:
+        return dry_launch(rank, world)
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device")
+    if os.environ.get("NUDGE_BENCH_ONE_DEVICE", "0") != "1" and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} HIP device(s) visible: refusing (one rank per GPU; NUDGE_BENCH_ONE_DEVICE=1 is the one-GPU rehearsal)")
     # NUDGE_BENCH_BACKEND=gloo + NUDGE_BENCH_ONE_DEVICE=1: rehearsal of the N > 1 path on a box with ONE GPU (all ranks share
     # cuda:0, halo messages staged through the host).  The driver's runs use neither: one rank per GPU over RCCL.
     backend = os.environ.get("NUDGE_BENCH_BACKEND", "nccl")
@@ -684,9 +745,16 @@ def main():
             weight = 1.0 if launches >= 3 else 1.0 / args.steps
             alg += weight * kb[1] * units[kb[0]] * (I if name == "apply_level" else 1)      # ("GI" units already carry the iterations)
         pmc_sum, pmc_src = pmc_step_total() if args.scene == "boxes" and args.tiles == 124 and world == 1 else (None, None)
+        pmc_frac = (pmc_sum / sec_per_step / 1e9 / HBM_PEAK_GBS) if pmc_sum else None
+        pmc_refused = None
+        if pmc_frac is not None and pmc_frac > 1.0:
+            # more bytes per second than the chip can move: the export's launches_per_step are wrong (round 5 counted steps by k_xform dispatches, which xform ahead
+            # removed from most steps) -- an impossible figure is not printed
+            pmc_refused = f"{pmc_src}: {pmc_sum:.4g} B per step would be {pmc_frac:.2f} x the HBM peak -- the export's step count is wrong; figure withheld"
+            pmc_sum, pmc_frac = None, None
         out["step_traffic"] = {"bound": "hbm", "algorithmic_bytes_per_step": alg, "achieved": alg / sec_per_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": alg / sec_per_step / 1e9 / HBM_PEAK_GBS, "unpriced_kernels": sorted(unpriced),
-                               "pmc_bytes_per_step": pmc_sum, "pmc_frac": (pmc_sum / sec_per_step / 1e9 / HBM_PEAK_GBS) if pmc_sum else None, "pmc_source": pmc_src}
+                               "pmc_bytes_per_step": pmc_sum, "pmc_frac": pmc_frac, "pmc_source": pmc_src, "pmc_refused": pmc_refused}
         if dom and dominant in KERNEL_BYTES and units.get(KERNEL_BYTES[dominant][0]) is not None:
             unit_k, per = KERNEL_BYTES[dominant]
             launches_per_step = dom[1] / timed_steps
@@ -795,7 +863,8 @@ def main():
             st = cluster.p.stats
             out["halo"] = {"backend": backend, "per_step_transport": ("library-driven RCCL (nh_partition_exchange_step)" if cluster.direct else f"torch.distributed point-to-point ({cluster.direct_why or 'not asked'})"), "loopback_records_per_step": (cluster.loopback_records / max(1, getattr(cluster, "loopback_steps", 0))) if loopback else None,
                            "ghost_bodies_rank0": st["ghosts"], "refreshes": st["refreshes"], "migrated_out_rank0": st["migrated_out"],
-                           "bytes_sent_per_step_rank0": st["step_bytes"] / max(1, cluster.p.steps % (EPOCH * 4096) if cluster.p.steps >= EPOCH * 4096 else cluster.p.steps),
+                           # (bytes and steps over the same window: every step this partition ever took -- `p.steps` is the epoch clock the timed blocks rewind)
+                           "bytes_sent_per_step_rank0": st["step_bytes"] / max(1, st["steps_total"]),
                            "loopback_bytes_per_step_through_rccl": (64.0 * cluster.loopback_records / max(1, cluster.loopback_steps)) if (loopback and getattr(cluster, "loopback_steps", 0)) else None}
         print(json.dumps(out))
     w.close()

@@ -231,7 +231,8 @@ class Partition:
         self.ghost_out32 = {-1: None, +1: None}
         self.ghost_in = {-1: 0, +1: 0}             # ghost records received from the left / right neighbour
         self.steps = 0
-        self.stats = dict(refreshes=0, migrated_out=0, migrated_in=0, ghosts=0, late_bodies=0, step_bytes=0, refresh_bytes=0, cut_moves=0)
+        # steps_total: every step ever taken (`steps` is the epoch clock, which bench.py rewinds before each timed block -- it cannot be the divisor of step_bytes)
+        self.stats = dict(refreshes=0, migrated_out=0, migrated_in=0, ghosts=0, late_bodies=0, step_bytes=0, refresh_bytes=0, cut_moves=0, steps_total=0)
         # (round 5: the per-iteration exchange of single ownership is behind the C ABI too -- nh_partition_mark_ghosts / pack_deltas / ... -- so the HIP engine takes the
         # C-ABI path in every mode; force_torch=True keeps the torch implementation, the independent check)
         self.force_torch = force_torch
@@ -627,6 +628,7 @@ class Partition:
     def local_step(self):
         self.e.step(1)
         self.steps += 1
+        self.stats["steps_total"] += 1
 
     # ---- per-iteration mode: the step in phases, ghost momentum refreshed after every sweep ---------------------------
     def step_begin(self):
@@ -751,6 +753,7 @@ class Partition:
         if hasattr(e, "step_done"):
             e.step_done()
         self.steps += 1
+        self.stats["steps_total"] += 1
 
     def iterations(self):
         return int(self.e.params["iterations"])
