@@ -73,7 +73,8 @@
  *      brought up to date by nh_export_views (what: NH_VIEW_CONTACTS, NH_VIEW_CACHE, NH_VIEW_ACTIVE), by nh_append_contacts, and by any step that does not qualify -- not by
  *      every step, and not by the cheap observers: nh_read_counts returns the counters and nh_synchronize waits for the stream, neither exports anything (the
  *      sample reads active_bodies.count every sub-step, example/main.cpp:293: that must not cost two passes over the contacts).  Call nh_export_views and then
- *      nh_synchronize before reading the arrays from the device yourself.  Any entry point outside the sample's
+ *      nh_synchronize before reading the arrays from the device yourself.  (BREAKING for hosts written against rounds 1-4, where nh_synchronize / nh_read_counts
+ *      exported the views: nh_set_option(ctx, "sync_exports_views", 1) restores that contract at its old price; INTEGRATION.md.)  Any entry point outside the sample's
  *      call order between nh_collide and nh_apply_impulses turns a still step into a full one first, so everything it observes is what a full step
  *      produces.  nh_Counts.still_steps / still_replays count them.
  *

@@ -955,7 +955,9 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
                                                      // STILL, sleepers form (nh_internal.h): the slot cache's per-record counts (entries kept aside for a sleeping pair); nullptr = nobody can be asleep
                                                      uint32_t* __restrict__ sc_count = nullptr,
                                                      // STILL, plain form: no k_xform<true> has run this step -- the last step's solver did its work (nh_internal.h: xform ahead)
-                                                     uint32_t ahead = 0u) {
+                                                     uint32_t ahead = 0u,
+                                                     // STILL, sleepers form: where a dropped slot-cache count is noted until the step's verdict is in (nh_internal.h: sc_undo)
+                                                     uint64_t* __restrict__ sc_undo = nullptr) {
 	if (STILL && !LOCAL && ahead) {
 		// what k_xform<true> does for the step after this one (nobody touches the other parity's words during this step: the solver that gathers into them comes later)
 		if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1053,7 +1055,9 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			// list of sleeping pairs, and its cached impulses kept aside (4064-4101) when the cache's tag -- the contact key on file -- IS that word; otherwise they are
 			// gone, as in the reference.  From now on the record carries the pair's word (the tag order on file no longer matches the keys: a full step sorts again).
 			vanished = true; count = 0;
-			if (was_key != key) { if (sc_count[ri]) sc_count[ri] = 0u; rec_key[ri] = key; st->sort_valid = 0u; }
+			// (the drop happens before the step's verdict is known: the old count is noted under this step's number and comes back if the step did not happen --
+			// nh_still_undo_drops.  The key on file needs no such care: a replay compares every key with this buffer and sorts again where they differ, and sort_valid = 0 asks for that anyway)
+			if (was_key != key) { const uint32_t oc = sc_count[ri]; if (oc) { sc_undo[ri] = ((uint64_t)seq << 32) | oc; sc_count[ri] = 0u; } rec_key[ri] = key; st->sort_valid = 0u; }
 			else n_culled += min(sc_count[ri], 4u);
 			n_sleeping += 1u;
 		}
@@ -1935,7 +1939,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 	bool lay_fresh = false;
 	if (ctx->lay_capacity != pair_cap || ctx->lay_contact_capacity != cap) {
 		void** bufs[] = { (void**)&ctx->raw_data, (void**)&ctx->raw_feature, (void**)&ctx->rec, (void**)&ctx->lay_rank, (void**)&ctx->cnt_sorted, (void**)&ctx->start_sorted, (void**)&ctx->dense_slot,
-		                  (void**)&ctx->sc_imp, (void**)&ctx->sc_feat, (void**)&ctx->sc_count, (void**)&ctx->exp_cnt, (void**)&ctx->exp_start, (void**)&ctx->exp_scan_tmp, (void**)&ctx->still_delta };
+		                  (void**)&ctx->sc_imp, (void**)&ctx->sc_feat, (void**)&ctx->sc_count, (void**)&ctx->sc_undo, (void**)&ctx->exp_cnt, (void**)&ctx->exp_start, (void**)&ctx->exp_scan_tmp, (void**)&ctx->still_delta };
 		for (void** b : bufs) { if (*b) NH_HIP_CHECK(ctx, hipFree(*b)); *b = nullptr; }
 		ctx->lay_capacity = 0; ctx->lay_contact_capacity = 0;
 		const size_t slots = (size_t)4 * pair_cap + cap, cache_slots = (size_t)5 * pair_cap + 64u;
@@ -1949,6 +1953,9 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sc_imp, sizeof(float4) * cache_slots));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sc_feat, sizeof(uint32_t) * cache_slots));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sc_count, sizeof(uint32_t) * (size_t)pair_cap + 64u));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sc_undo, sizeof(uint64_t) * (size_t)pair_cap + 64u));
+		NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->sc_undo, 0, sizeof(uint64_t) * (size_t)pair_cap + 64u, s));
+		ctx->still.undo_dirty = false;
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->exp_cnt, sizeof(uint32_t) * ((size_t)pair_cap + 2u)));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->exp_start, sizeof(uint32_t) * ((size_t)pair_cap + 2u)));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->exp_scan_tmp, sizeof(uint32_t) * (2u * NH_SORT_GRID + 64u)));
@@ -2038,13 +2045,14 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			const uint8_t* gen = incremental ? ctx->fat_gen : (const uint8_t*)nullptr;
 			const bool delta_scan = C > (2u << 20) || sleepers;          // (a world dozing off changes thousands of contact counts per step: the scan, not the list)
 			uint32_t* const sc_count = sleepers ? ctx->sc_count : (uint32_t*)nullptr;
+			if (sleepers) ss.undo_dirty = true;
 			// (the LOCAL form of the narrowphase -- appended pairs, sleeping bodies -- only where it can matter: this step or an earlier one since the layout ran in movers
 			// form, or somebody may be asleep)
 			if (movers) ss.appended_pairs = true;
 			const bool local = sleepers || ss.appended_pairs;
 #define NH_NARROW_STILL(SPHERES, NAME, GRIDMAX) do { if (local) NH_LAUNCH(ctx, NAME, (k_narrowphase<SPHERES, true, true>), nh_grid_for(pair_cap, 256, GRIDMAX), 256, st, ctx->fat_pairs, xf, ctag, \
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr, \
-				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, sc_count); \
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, sc_count, 0u, ctx->sc_undo); \
 				else NH_LAUNCH(ctx, NAME, (k_narrowphase<SPHERES, true, false>), nh_grid_for(pair_cap, 256, GRIDMAX), 256, st, ctx->fat_pairs, xf, ctag, \
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr, \
 				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, (uint32_t*)nullptr, ahead_step ? 1u : 0u); } while (0)

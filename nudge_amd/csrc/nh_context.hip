@@ -43,7 +43,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->fat_pairs = nullptr; ctx->fat_pair_capacity = 0; ctx->fat_box = nullptr; ctx->fat_collider_capacity = 0; ctx->fat_nbox = ctx->fat_nsph = 0xffffffffu;
 	ctx->grid_sbox = nullptr; ctx->grid_skeys = nullptr; ctx->grid_cstart = nullptr; ctx->grid_counts = nullptr; ctx->grid_large = nullptr; ctx->grid_cells = 0; ctx->grid_collider_capacity = 0;
 	ctx->fat_gen = nullptr; ctx->fat_esc_mark = nullptr; ctx->fat_esc_list = nullptr; ctx->fat_moved_list = nullptr;
-	ctx->env_blk_rows_global = false;
+	ctx->env_blk_rows_global = false; ctx->sync_exports_views = false;
 	ctx->env_blk_global_colours = false; ctx->last_general_contacts = 0;
 	ctx->env_no_incremental = false;
 	ctx->env_colour_check_seeds = false;
@@ -56,7 +56,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->blk.min_contacts = 200000u;
 	ctx->blk.target = 900u;
 	ctx->raw_data = nullptr; ctx->raw_feature = nullptr; ctx->raw_slots = 0; ctx->rec = nullptr; ctx->lay_rank = nullptr; ctx->cnt_sorted = nullptr; ctx->start_sorted = nullptr; ctx->dense_slot = nullptr;
-	ctx->sc_imp = nullptr; ctx->sc_feat = nullptr; ctx->sc_count = nullptr; ctx->exp_cnt = nullptr; ctx->exp_start = nullptr; ctx->exp_scan_tmp = nullptr; ctx->still_delta = nullptr; ctx->lay_capacity = 0; ctx->lay_contact_capacity = 0;
+	ctx->sc_imp = nullptr; ctx->sc_feat = nullptr; ctx->sc_count = nullptr; ctx->sc_undo = nullptr; ctx->exp_cnt = nullptr; ctx->exp_start = nullptr; ctx->exp_scan_tmp = nullptr; ctx->still_delta = nullptr; ctx->lay_capacity = 0; ctx->lay_contact_capacity = 0;
 	ctx->own_xf = nullptr; ctx->own_aabb_min = nullptr; ctx->own_aabb_max = nullptr; ctx->own_ctag = nullptr; ctx->own_capacity = 0; ctx->body_col = nullptr; ctx->body_col_capacity = 0;
 	ctx->still_awake = nullptr; ctx->still_awake_capacity = 0; ctx->exp_sleep_a = nullptr; ctx->exp_sleep_b = nullptr; ctx->exp_sleep_hist = nullptr; ctx->exp_flags = nullptr; ctx->exp_sleep_capacity = 0; ctx->exp_flags_capacity = 0;
 	ctx->lay_class = nullptr; ctx->lay_simple = nullptr; ctx->body_rec = nullptr; ctx->body_pos = nullptr; ctx->lay_body_capacity = 0;
@@ -123,7 +123,7 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	if (ctx->sort_starts) hipFree(ctx->sort_starts);
 	for (int k = 0; k < 2; ++k) { if (ctx->still.h_ring[k]) hipHostFree(ctx->still.h_ring[k]); if (ctx->still.ev_ring[k]) hipEventDestroy(ctx->still.ev_ring[k]); }
 	{
-		void* bufs[] = { ctx->raw_data, ctx->raw_feature, ctx->rec, ctx->lay_rank, ctx->cnt_sorted, ctx->start_sorted, ctx->dense_slot, ctx->sc_imp, ctx->sc_feat, ctx->sc_count, ctx->exp_cnt, ctx->exp_start,
+		void* bufs[] = { ctx->raw_data, ctx->raw_feature, ctx->rec, ctx->lay_rank, ctx->cnt_sorted, ctx->start_sorted, ctx->dense_slot, ctx->sc_imp, ctx->sc_feat, ctx->sc_count, ctx->sc_undo, ctx->exp_cnt, ctx->exp_start,
 		                 ctx->exp_scan_tmp, ctx->still_delta, ctx->lay_class, ctx->lay_simple, ctx->body_rec, ctx->body_pos, ctx->still_awake, ctx->exp_sleep_a, ctx->exp_sleep_b, ctx->exp_sleep_hist, ctx->exp_flags,
 		                 ctx->own_xf, ctx->own_aabb_min, ctx->own_aabb_max, ctx->own_ctag, ctx->body_col };
 		for (void* b : bufs) if (b) hipFree(b);
@@ -162,6 +162,7 @@ extern "C" int nh_set_option(nh_context* ctx, const char* name, int value) {
 	const bool on = value != 0;
 	ctx->asleep.streak = 0;
 	if (n == "no_asleep") ctx->asleep.disabled = on;                      // nh_step runs every step of a world that is asleep in full (nh_internal.h: nh_AsleepState)
+	else if (n == "sync_exports_views") ctx->sync_exports_views = on;          // legacy observers: nh_synchronize / nh_read_counts end with nh_export_views(NH_VIEW_ALL) like they did before round 5 (note 9)
 	else if (n == "no_xform_ahead") ctx->still.no_ahead = on;                  // every still step launches k_xform<true> itself (nh_internal.h: xform ahead)
 	else if (n == "no_local_still") ctx->still.no_local = on;                  // a collider that leaves its inflated box fails a still step as a whole (round 4's behaviour; nh_internal.h "LOCAL speculation")
 	else if (n == "no_still") ctx->still.disabled = on;                        // no step is launched speculatively as a still step (note 9)
@@ -212,7 +213,9 @@ extern "C" int nh_synchronize(nh_context* ctx) {
 	if (!ctx) return NH_ERR_INVALID;
 	int rc = nh_flush_pending(ctx);
 	if (rc) return rc;
-	// (waits only: the views of note 9 are exported by nh_export_views -- a caller that synchronises every step must not pay two passes over the contacts for it)
+	// (waits only: the views of note 9 are exported by nh_export_views -- a caller that synchronises every step must not pay two passes over the contacts for it;
+	// option "sync_exports_views" restores the older contract for hosts written against it)
+	if (ctx->sync_exports_views) { rc = nh_still_sync_outputs(ctx, NH_VIEW_ALL); if (rc) return rc; }
 	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 	if (ctx->timing) nh_timer_collect(ctx);
 	return NH_OK;
@@ -239,6 +242,7 @@ void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out) {
 extern "C" int nh_read_counts(nh_context* ctx, nh_Counts* out) {
 	if (!ctx || !out) return NH_ERR_INVALID;
 	{ int rc = nh_flush_pending(ctx, true); if (rc) return rc; }      // (counters only: a pending NH_FLAG_FUSED_STEP gravity stays pending; no view is exported, note 9)
+	if (ctx->sync_exports_views) { int rc = nh_still_sync_outputs(ctx, NH_VIEW_ALL); if (rc) return rc; }
 	NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, NH_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 	nh_counts_from_mirror(ctx, out);
@@ -299,6 +303,17 @@ int nh_stream_after_advance(nh_context* ctx) {
 	// which the in-flight test above has just ruled out for the frames that follow)
 	ss.in_flight[slot] = true; ss.slot_step[slot] = ss.advances; ss.last_slot = (int)slot; ss.frames++; ss.slot_frame[slot] = ss.frames;
 	return NH_OK;
+}
+
+// The last nh_advance counted did not happen (a still step that failed: nh_solve.hip, still_forget_failed).  Its solver left the world as it was, so a frame taken behind
+// it shows the state BEFORE the step under the number the replayed step will give its own frame: the frame is withdrawn -- nh_stream_latest no longer names it -- while
+// the slot stays marked in flight until its copy has landed (it must not be rewritten under the copy).
+void nh_stream_void_advance(nh_context* ctx) {
+	nh_StateStream& ss = ctx->stream_state;
+	if (!ss.every || !ss.advances) return;
+	for (uint32_t k = 0; k < ss.slots; ++k)
+		if (ss.slot_frame[k] != 0 && ss.slot_step[k] == ss.advances) { ss.slot_frame[k] = 0; ss.slot_step[k] = 0; }
+	ss.advances--;
 }
 
 extern "C" int nh_stream_latest(nh_context* ctx, nh_StreamInfo* out) {

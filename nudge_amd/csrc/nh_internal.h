@@ -212,6 +212,8 @@ struct nh_StillStep {
 	nh_ActiveBodies* active_out; nh_ContactData* contacts_out; nh_BodyData bodies; nh_ColliderData colliders; nh_BodyConnections connections; bool has_connections; nh_Arena temporary;
 	nh_BodyData lay_bodies; nh_ColliderData lay_colliders; nh_ContactData lay_contacts; const uint32_t* lay_active; uint32_t lay_active_capacity;
 	uint64_t launched, failed;      // statistics
+	uint32_t confirmed_seq;         // collide_seq of the newest still step whose verdict was "confirmed" (every drop noted in ctx->sc_undo under a later number is undone on failure)
+	bool undo_dirty;                // a narrowphase in sleepers form has run since sc_undo was last swept
 	// back-off: a world in which something keeps moving (a body in the air leaves its inflated box every step) fails every still step it is offered; after the k-th
 	// failure in a row the next 2^k - 1 steps (at most 63) are not offered as still steps.  Sixteen confirmed still steps in a row forget the failures.
 	uint32_t hold, fail_level, good_run;
@@ -321,6 +323,7 @@ struct nh_context {
 	float4* grid_sbox; uint32_t* grid_skeys; uint32_t* grid_cstart; uint32_t* grid_counts; uint32_t* grid_large; uint32_t grid_cells, grid_collider_capacity;
 	uint8_t* fat_gen; uint32_t* fat_esc_mark; uint32_t* fat_esc_list; uint32_t* fat_moved_list;
 	bool env_no_incremental;
+	bool sync_exports_views;              // option "sync_exports_views": nh_synchronize / nh_read_counts also bring the caller's contact list, cache and active list up to date (the contract before round 5)
 	bool env_blk_rows_global;             // NH_BLK_ROWS_GLOBAL=1: the rows of block-owned contacts by k_rows_general (one thread per contact) instead of k_blk_rows (A/B, tests)
 	bool env_blk_global_colours;          // NH_BLK_GLOBAL_COLOURS=1: the blocked solver takes the world-wide colouring (A/B, tests)
 	uint32_t last_general_contacts;       // general contacts of the last setup: does this step's adjacency build leave the general bodies to the per-block colouring?
@@ -379,6 +382,10 @@ struct nh_context {
 	uint32_t* dense_slot;                                                    // per contact of the last FULL step's list: the raw slot it came from
 	// the contact cache by slot (still steps): the solved impulse and the feature word of the contact each slot held LAST step, and how many each record had
 	float4* sc_imp; uint32_t* sc_feat; uint32_t* sc_count;
+	// sleepers form: a still step's narrowphase DROPS the slot cache's entries of a pair it files as sleeping under another word than the contact key on file (the
+	// reference's quirk, nudge.cpp:4064-4101) before the step's verdict is known.  What it dropped is noted here -- (step sequence number << 32) | old count, by record --
+	// and put back when that step turns out not to have happened (nh_still_undo_drops): a replay must find the cache of the last step that DID happen
+	uint64_t* sc_undo;
 	// still steps keep their colliders' world transforms, AABBs and tags in buffers of the library's own (a full step's live in the caller's arena): with xform ahead
 	// (nh_StillStep) they are written by one step's solver and read by the next step's narrowphase; and the body -> collider map those solver lanes go by
 	struct nh_xform* own_xf; float4* own_aabb_min; float4* own_aabb_max; uint32_t* own_ctag; uint32_t own_capacity;
@@ -406,6 +413,8 @@ int nh_still_abandon(nh_context* ctx);
 // the sample's call order that hands the arrays to the caller: nh_export_views, nh_append_contacts, nh_contact_impulses_device -- NOT nh_read_counts / nh_synchronize)
 int nh_still_sync_outputs(nh_context* ctx, uint32_t what = 7u /* NH_VIEW_ALL */);
 int nh_still_export_cache(nh_context* ctx);
+int nh_still_undo_drops(nh_context* ctx);
+void nh_stream_void_advance(nh_context* ctx);
 int nh_still_verdict_now(nh_context* ctx);            // nh_step: the pending verdict of the last still step, waited for: 0 = it happened, 1 = it did not
 #define NH_INTERNAL_STILL_FAILED (-1000)      // (never leaves the library) first_apply -> nh_step: the still step before this one failed, run both again
 #define NH_DELTA_MAX 256u

@@ -50,6 +50,9 @@ struct nh_partition {
 	double speed_pre, peer_speed[2];
 	// single ownership of contacts that cross a cut (nh_set_first_ghost_body): the ghosts' momentum as it was at the last nh_partition_mark_ghosts (2 x float4 per ghost)
 	float4* ghost_ref; uint32_t ghost_ref_capacity;
+	// ... and WHICH ghost set that mark belongs to: nh_partition_unpack_ghosts starts a new generation, the mark adopts it, nh_partition_pack_deltas insists on it
+	// (a refresh that changes the ghost set without outgrowing the buffer used to pass the capacity test and pack deltas against other bodies' references)
+	uint64_t ghost_generation, ghost_ref_generation;
 };
 
 #define NP_CHECK(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (ctx)->last_hip_error = (int)e_; return NH_ERR_HIP; } } while (0)
@@ -359,7 +362,7 @@ extern "C" int nh_partition_unpack_migrants(nh_partition* p, const nh_BodyData* 
 	if (n_right) { NP_LAUNCH("part_install", k_part_install, n_right, at, n_right, (const nh_FullRecord*)in_right, bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters, part_cols(p)); at += n_right; }
 	p->n_owned = at - 1u;
 	p->n_bodies = at;                       // (ghosts are gone until nh_partition_unpack_ghosts)
-	p->ghost_in[0] = p->ghost_in[1] = 0u;
+	p->ghost_in[0] = p->ghost_in[1] = 0u; p->ghost_generation++;
 	p->migrated_in += n_left + n_right;
 	return NH_OK;
 }
@@ -423,6 +426,7 @@ extern "C" int nh_partition_unpack_ghosts(nh_partition* p, nh_BodyData* bodies, 
 	if (n_left) { NP_LAUNCH("part_install", k_part_install, n_left, at, n_left, (const nh_FullRecord*)in_left, bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters, part_cols(p)); at += n_left; }
 	if (n_right) { NP_LAUNCH("part_install", k_part_install, n_right, at, n_right, (const nh_FullRecord*)in_right, bodies->transforms, bodies->properties, bodies->momentum, bodies->idle_counters, part_cols(p)); at += n_right; }
 	p->ghost_in[0] = n_left; p->ghost_in[1] = n_right;
+	p->ghost_generation++;          // (whatever nh_partition_mark_ghosts noted belongs to the ghosts that were here before)
 	p->n_bodies = at;
 	// colliders: the static ones stay, then one per dynamic body slot (owned, then ghosts) -- boxes and spheres each compacted in slot order
 	NH_LAUNCH(ctx, "part_reset", k_part_reset, 1, 1, p->d);
@@ -589,13 +593,15 @@ extern "C" int nh_partition_mark_ghosts(nh_partition* p, const nh_BodyData* bodi
 		p->ghost_ref_capacity = cap;
 	}
 	if (n) NP_LAUNCH("part_mark", k_part_mark, n, n, p->n_owned + 1u, bodies->momentum, p->ghost_ref);
+	p->ghost_ref_generation = p->ghost_generation;
 	return NH_OK;
 }
 
 extern "C" int nh_partition_pack_deltas(nh_partition* p, const nh_BodyData* bodies, void* out_left, void* out_right) {
 	{ int rc = part_iteration_enter(p, bodies); if (rc) return rc; }
 	nh_context* ctx = p->ctx;
-	if (p->ghost_ref_capacity < p->ghost_in[0] + p->ghost_in[1]) return NH_ERR_INVALID;          // (no mark since the ghosts changed)
+	// (no mark since the ghosts changed: the references on file are other bodies' momenta)
+	if (p->ghost_ref_capacity < p->ghost_in[0] + p->ghost_in[1] || p->ghost_ref_generation != p->ghost_generation) return NH_ERR_INVALID;
 	uint32_t at = p->n_owned + 1u, ref_at = 0u;
 	void* out[2] = { out_left, out_right };
 	for (int side = 0; side < 2; ++side) {

@@ -2839,6 +2839,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 					NH_HIP_CHECK(ctx, hipEventSynchronize(ss.ev_ring[ss.verdict.slot]));
 					const nh_DevState* h = ss.h_ring[ss.verdict.slot];
 					if (h->still_failed_seq >= ss.verdict.seq || h->error) return NH_INTERNAL_STILL_FAILED;       // (nh_step cleans up and runs both steps again)
+					ss.confirmed_seq = ss.verdict.seq;
 					memcpy(ctx->h_state, h, NH_COUNTER_WORDS * sizeof(uint32_t));
 					if (!ctx->idle_unknown) { ctx->idle_bound = (int)h->max_idle[ss.verdict.parity]; ctx->idle_bound_mark = ss.verdict.collide_mark; }
 					ss.verdict.pending = false;
@@ -2856,6 +2857,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 				NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
 				if (ctx->timing) nh_timer_collect(ctx);
 				confirmed = ctx->h_state->still_failed_seq < ctx->collide_seq && ctx->h_state->error == 0u;
+				if (confirmed) ss.confirmed_seq = ctx->collide_seq;
 				if (confirmed) { nh_Counts c; nh_counts_from_mirror(ctx, &c); still_note_movers(ctx, ctx->h_state); }              // (the sleep prediction: largest idle counter this step saw)
 			}
 		}
@@ -2977,6 +2979,26 @@ __global__ __launch_bounds__(256) void k_slots_to_cache(nh_DevState* __restrict_
 	}
 }
 
+// Sleepers form: the slot-cache counts a still narrowphase dropped in a step that did not happen (nh_internal.h: sc_undo) come back.  Called wherever a still step is
+// given up -- failed on the device (still_forget_failed), or left by the caller between its nh_collide and its solver (nh_still_abandon) -- BEFORE the slot cache goes
+// home to the caller's arrays, which is what the full replay warm-starts from.  Notes of confirmed steps (numbers <= confirmed_seq) are simply cleared.
+__global__ __launch_bounds__(256) void k_sleep_undo(uint64_t* __restrict__ sc_undo, uint32_t* __restrict__ sc_count, uint32_t n, uint32_t confirmed_seq) {
+	for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+		const uint64_t u = sc_undo[r];
+		if (u == 0ull) continue;
+		if ((uint32_t)(u >> 32) > confirmed_seq) sc_count[r] = (uint32_t)u;
+		sc_undo[r] = 0ull;
+	}
+}
+
+int nh_still_undo_drops(nh_context* ctx) {
+	nh_StillStep& ss = ctx->still;
+	if (!ss.undo_dirty || !ctx->sc_undo || !ctx->lay_capacity) return NH_OK;
+	ss.undo_dirty = false;
+	NH_LAUNCH(ctx, "sleep_undo", k_sleep_undo, nh_grid_for(ctx->lay_capacity, 256, 2048), 256, ctx->sc_undo, ctx->sc_count, ctx->lay_capacity, ss.confirmed_seq);
+	return NH_OK;
+}
+
 int nh_still_export_cache(nh_context* ctx) {
 	nh_StillStep& ss = ctx->still;
 	if (!ss.cache_stale) return NH_OK;
@@ -3081,7 +3103,9 @@ int nh_still_abandon(nh_context* ctx) {
 	if (!ss.active || ss.resolved || ss.replaying) return NH_OK;
 	nh_ContactConstraintData* d = ss.setup_d;
 	ss.setup_d = nullptr;
-	int rc = nh_still_export_cache(ctx);                  // (the slot cache holds the last confirmed step's impulses: the full solver reads the caller's arrays)
+	int rc = nh_still_undo_drops(ctx);                    // (what this step's narrowphase dropped from the slot cache in sleepers form comes back first)
+	if (rc) return rc;
+	rc = nh_still_export_cache(ctx);                      // (the slot cache holds the last confirmed step's impulses: the full solver reads the caller's arrays)
 	if (rc) return rc;
 	ss.contacts_stale = false;                         // (the replay lays the dense list out itself)
 	rc = nh_still_collide_again(ctx);
@@ -3231,6 +3255,7 @@ int nh_still_verdict_now(nh_context* ctx) {
 	const nh_DevState* h = ss.h_ring[ss.verdict.slot];
 	ss.verdict.pending = false;
 	if (h->still_failed_seq >= ss.verdict.seq || h->error) return 1;
+	ss.confirmed_seq = ss.verdict.seq;
 	memcpy(ctx->h_state, h, NH_COUNTER_WORDS * sizeof(uint32_t));
 	if (!ctx->idle_unknown) { ctx->idle_bound = (int)h->max_idle[ss.verdict.parity]; ctx->idle_bound_mark = ss.verdict.collide_mark; }
 	still_note_movers(ctx, h);
@@ -3248,7 +3273,8 @@ static int still_forget_failed(nh_context* ctx, bool advanced, uint32_t voided) 
 	ctx->grav.pending = false; ctx->grav.rest_pending = false; ctx->adv.done = false;
 	ctx->after_collide = false; ctx->gravity_may_overlap = false;
 	if (advanced && ctx->advance_count) ctx->advance_count--;          // (the failed step's nh_advance was counted: the sleep prediction counts real ones)
-	if (advanced && ctx->stream_state.every && ctx->stream_state.advances) ctx->stream_state.advances--;      // (... and so does the state stream: a frame taken there shows the state BEFORE that step, under the number the step run again will give its own)
+	if (advanced) nh_stream_void_advance(ctx);          // (... and so does the state stream; a frame taken at that nh_advance shows the state BEFORE the step: it is withdrawn)
+	{ int rc = nh_still_undo_drops(ctx); if (rc) return rc; }          // (sleepers form: slot-cache counts the voided steps' narrowphases dropped)
 	return nh_still_export_cache(ctx);                                 // (the slot cache holds the last step that DID happen: the full solver reads the caller's arrays)
 }
 

@@ -343,3 +343,31 @@ def test_single_owner_of_cross_cut_contacts_on_the_gpu_is_the_reference_engine_b
         for q in gpu:
             assert q.e.counts()["error"] == 0
             q.e.close()
+
+
+def test_deltas_against_a_mark_of_other_ghosts_are_refused():
+    """Advisor (round 5, low).  nh_partition_pack_deltas packs `momentum now - momentum at the last nh_partition_mark_ghosts` per ghost.  A refresh replaces the ghost
+    set; a host that forgets to mark again used to be caught only when the new set outgrew the reference buffer -- otherwise the deltas were taken against OTHER
+    bodies' momenta and added on the owner rank without an error.  Now every nh_partition_unpack_ghosts (and every migration) starts a generation the mark has to match."""
+    scene = S.bridge(3)
+    gpu = []
+    for r in range(2):
+        local, info = PT.split_scene(scene, [0.0], r, min_extra=512)
+        w = E.World(local, flags=E.NH_FLAG_EXACT_ORDER, capacity=info["capacity"], tag_bits=info["tag_bits"], max_contacts=16 * info["capacity"]["bodies"])
+        gpu.append(PT.Partition(w, info, epoch=8, per_iteration=True, single_owner=True))
+    cg = PT.LocalCluster(gpu)
+    cg.step(3)                                   # (refresh at step 0, marks and deltas every iteration since: all in order)
+    q = gpu[0]
+    assert q.hip is not None and sum(q.ghost_in.values()) > 0
+    q.delta_pack()                               # a mark is on file for these ghosts: fine
+    # a refresh of the ghost set behind the host's back: the same records installed again -- same count, so the reference buffer is large enough
+    outs = [p.refresh_pack_ghosts() for p in gpu]
+    routed = cg._route(outs)
+    for p, inc in zip(gpu, routed):
+        p.refresh_unpack_ghosts(inc)
+    with pytest.raises(E.NudgeError, match="nh_partition_pack_deltas"):
+        q.delta_pack()
+    q.delta_mark()
+    q.delta_pack()                               # marked again: accepted
+    for p in gpu:
+        p.e.close()

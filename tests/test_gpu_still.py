@@ -309,6 +309,26 @@ def _same_sleepy_world(a, b, what=""):
         assert ca[k] == cb[k], f"{what}: counter {k}: {ca[k]} vs {cb[k]}"
 
 
+def test_the_legacy_option_makes_synchronize_export_the_views():
+    """Hosts written against rounds 1-4 read the contact list / cache / active list from the device after nh_synchronize.  Since round 5 the cheap observers export
+    nothing (above); nh_set_option("sync_exports_views", 1) restores the old contract: the caller's arrays, read WITHOUT nh_export_views, are a full step's bits."""
+    from nudge_amd import engine as EE
+    scene = S.grid_tiles(1, side=24, seed=71)
+    a, b = _world(scene, True, env=("NH_SYNC_EXPORTS_VIEWS",)), _world(scene, False)
+    a.step(100); b.step(100)
+    c0 = a.counts()
+    a.step(12); b.step(12)
+    a.synchronize()
+    n = b.counts()["contacts"]
+    kb = b.get_contacts()
+    assert a.counts()["still_steps"] - c0["still_steps"] >= 10
+    # (the raw device arrays of world a, no nh_export_views call: World._down copies what is there)
+    assert P.bits_equal(a._down("cd", EE.S.CONTACT, n), kb["data"]) and np.array_equal(a._down("ct", np.uint64, n), kb["tags"]) and np.array_equal(a._down("cf", np.uint32, n), kb["features"])
+    cb = b.get_cache()
+    assert np.array_equal(a._down("kt", np.uint64, cb["count"]), cb["tags"]) and P.bits_equal(a._down("kd", EE.S.IMPULSE, cb["count"])["impulse"], cb["data"]["impulse"])
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("sphere_fraction", [0.0, 0.5])
 def test_a_world_that_is_partly_asleep_takes_still_steps(sphere_fraction):
     """SLEEPERS form.  Two tiles fall asleep; the caller wakes one of them (idle counters rewritten, nh_bodies_changed).  For the next ~250 steps half the world is awake
@@ -362,6 +382,52 @@ def test_a_sleeper_next_to_an_awake_body_is_not_the_still_steps_business():
     for cp in (1, 5, 30, 80, 200):
         a.step(cp - done); b.step(cp - done); done = cp
         _same_sleepy_world(a, b, f"sleeper with an awake neighbour, step {cp}")
+    a.close(); b.close()
+
+
+def test_a_drop_from_the_slot_cache_in_a_step_that_fails_is_undone():
+    """Advisor (round 5, medium).  In sleepers form the still narrowphase files the pair of a sleeping body with the static world as a sleeping pair and, when the
+    pair's word differs from the contact key on file (a sphere on a slab whose tag is the smaller one: nudge.cpp:4064-4101 drops those cache entries), zeroes the slot
+    cache's count of that record -- BEFORE the step's verdict is known.  Here sphere B's idle counter saturates after a run of confirmed still steps (so the caller's
+    cache is stale and will be rebuilt from the slots) while an awake sphere A rests beside it with overlapping AABBs and no contact: {A, B} is a set with an awake
+    body, the still step must fail, and the full replay keeps B awake and warm-starts its contact from the cache.  The drop must not have happened."""
+    scene = S.grid_tiles(1, side=4, sphere_fraction=0.5, seed=83)
+    a, b = _world(scene, True), _plain_world(scene)
+    a.step(150); b.step(150)
+
+    sph_body = scene["sphere_transforms"]["body"]
+    rad = scene["sphere_data"]["radius"]
+    pos0 = scene["body_transforms"]["position"]
+    # B: the sphere nearest the (+x, -z) corner of the lattice; A: the sphere farthest from it, put diagonally OUTSIDE the lattice next to B
+    corner = np.float32([pos0[1:, 0].max(), 0.0, pos0[1:, 2].min()])
+    d2 = ((pos0[sph_body][:, [0, 2]] - corner[[0, 2]]) ** 2).sum(axis=1)
+    kb, ka = int(np.argmin(d2)), int(np.argmax(d2))
+    B, A = int(sph_body[kb]), int(sph_body[ka])
+    gap = np.float32(0.8) * (rad[ka] + rad[kb])
+    for w in (a, b):
+        bd = w.get_bodies()
+        t, m, idle = bd["transforms"].copy(), bd["momentum"].copy(), bd["idle"].copy()
+        t["position"][A] = t["position"][B] + np.float32([gap, 0.0, -gap])
+        t["position"][A][1] = np.float32(-10.0) + rad[ka]
+        m["velocity"][A] = 0; m["angular_velocity"][A] = 0
+        idle[:] = 0
+        w.set_bodies(transforms=t, momentum=m, idle=idle)
+    a.step(40); b.step(40)
+    _same_sleepy_world(a, b, "A moved next to B")
+    for w in (a, b):
+        idle = w.get_bodies()["idle"].copy()
+        idle[:] = 0
+        idle[B] = 0xff - 12
+        w.set_bodies(idle=idle)
+    c0 = a.counts()
+    done = 0
+    for cp in (8, 11, 12, 13, 14, 16, 20, 40):
+        a.step(cp - done); b.step(cp - done); done = cp
+        _same_sleepy_world(a, b, f"B saturates beside an awake A, step {cp}")
+    c1 = a.counts()
+    print(f"\n[undo] still steps {c1['still_steps'] - c0['still_steps']}, replays {c1['still_replays'] - c0['still_replays']}, idle[B] = {a.get_bodies()['idle'][B]}")
+    assert c1["still_steps"] - c0["still_steps"] >= 6 and c1["still_replays"] > c0["still_replays"]          # (confirmed still steps first, then the failing one)
+    assert a.get_bodies()["idle"][B] == 0xff and c1["active_bodies"] == len(scene["body_transforms"]) - 1     # B's counter is saturated and B is awake all the same
     a.close(); b.close()
 
 
