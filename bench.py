@@ -92,6 +92,14 @@ KERNEL_BYTES = {
     #   per body (4 contacts): record 4, tag-order position 4, count 4, first contact 4, 4 feature words 16, cached feature words 16 r + 16 w, cached count 4 r + 4 w,
     #                          transform 32 r + 32 w, properties 16, momentum 32 r + 32 w, idle 1 r + 1 w                                   = 133 r + 85 w -> 33.25 r + 21.25 w
     "solve_still": ("K", 48 + 16 + 33.25 + 21.25),         # = 118.5
+    # the ONE-KERNEL still step (nh_fused.hip), per dynamic body with four contacts -- what the lane MOVES (the static partner's transform / box / shape are shared by the
+    # ~8100 bodies of a tile: cache hits, not priced):
+    #   position table 16 r; own collider: box 32 + world transform 32 + tag 4 + shape 16 r; record: key 8, count 4, start 4, cached count 4 r + 4 w, cached feature words
+    #   16 r + 16 w, cached impulses 64 r, solved impulses 64 w; body: momentum 32 r + 32 w, properties 16 r, transform 32 r + 32 w, idle 1 r + 1 w; next step's transforms
+    #   (xform ahead): local transform 32 + size 16 + inflated box 32 r, world transform 32 + box 32 w                                                       = 574 B
+    #   a sphere body (one contact): 16 + 16 instead of 64 + 64 impulse bytes, 4 + 4 instead of 16 + 16 feature bytes                                        = 454 B
+    # NO contact ever reaches HBM: the two-kernel form writes 4 x 36 B per pair and reads them back (narrowphase_still 352 + solve_still 4 x 118.5 + 148 = 974 B per box body)
+    "still_fused": ("B", 574.0), "fused_map": ("R", 4 + 8 + 16 + 16), "fused_copy_static": ("T", 0), "fused_copy_bodies": ("B", 2 * 65),
     "ahead_map": ("C", 16 + 4), "ahead_check": ("C", 16 + 4),      # once per nh_step call (xform ahead): AABB min + body of every collider -> body's collider / several colliders? + the static world's bounds
     "asleep_check": ("C", 32 + 32 + 16 + 4 + 32 + 32 + 4 + 1),   # nh_step on a world asleep: local + body transform, shape, tag, the remembered AABB and tag, the idle counter
     "slot_counts": ("R", 4 + 4 + 4), "slots_to_cache": ("K", 16 + 4 + 28), "cache_to_slots": ("K", 4 + 16 + 4 + 20),
@@ -129,7 +137,7 @@ def grid_table_entries(C):
     return min(want, 1 << 24)
 
 # timer name (nh_* launch sites) -> kernel symbol prefix in the rocprofv3 PMC export (profiles/export_pmc.py)
-PMC_KERNEL = {"solve_one_body": "k_solve_one_body<4, true, true, 1, false>", "solve_still": "k_solve_one_body<4, true, true, 1, true, true>", "narrowphase_still": "k_narrowphase<false, true>",
+PMC_KERNEL = {"still_fused": "k_still_fused", "solve_one_body": "k_solve_one_body<4, true, true, 1, false>", "solve_still": "k_solve_one_body<4, true, true, 1, true, true>", "narrowphase_still": "k_narrowphase<false, true>",
               "xform_still": "k_xform<true>", "apply_static": "k_apply_static<4, true>", "narrowphase": "k_narrowphase<false, false>",
               "gather_contacts": "k_gather_contacts", "find_pairs": "k_find_pairs", "radix_pass": "os_pass<unsigned long, unsigned int, true>",
               "apply_level": "k_level_exec<false>", "write_cache": "k_write_cache", "xform_aabb": "k_xform", "blk_sweep": "k_blk_sweep<false, true>"}
@@ -595,6 +603,15 @@ def main():
     ktimes = w.kernel_times(reset=True)
     w.enable_timing(False)
     dominant = max(ktimes.items(), key=lambda kv: kv[1][0])[0] if ktimes else None
+    # (per-kernel timing of EVERY launch keeps the library out of its pipelined loop, where the steady step is ONE launch -- the one-kernel still step, nh_fused.hip: a probe
+    # of a few untimed steps tells whether that is what the timed region will run; its events then go around that kernel)
+    fused_probe = 0
+    if cluster is None and snap is not None and dominant in ("solve_still", "narrowphase_still"):
+        w.restore(snap); w.step(1)
+        cp0 = w.counts(); w.step(12); cp1 = w.counts()
+        fused_probe = cp1.get("fused_steps", 0) - cp0.get("fused_steps", 0)
+        if fused_probe >= 6:
+            dominant = "still_fused"
     if args.profile_kernels and rank == 0:
         tot = sum(v[0] for v in ktimes.values())
         for k, (ms, n) in sorted(ktimes.items(), key=lambda kv: -kv[1][0]):
@@ -608,6 +625,7 @@ def main():
     if dominant:
         w.enable_timing(True, only=dominant)
     dt, blocks, contact_sum, pair_sum, general_sum = 0.0, 0, 0.0, 0.0, 0.0
+    fused_sum = 0          # timed steps that were ONE launch (nh_fused.hip)
     ahead_sum = 0          # timed steps that started at the narrowphase: the step before them did their k_xform<true> inside its solver (include/nudge_hip.h note 9, xform ahead)
     block_ms = []
     timed_acc = [0.0, 0, 0.0, 0]          # inside the timed blocks only: seconds in refreshes, refreshes, seconds enqueueing per-step halos, per-step halos
@@ -645,6 +663,7 @@ def main():
         pair_sum += 0.5 * (c0["pairs"] + c1["pairs"])
         general_sum += 0.5 * (c0["general_contacts"] + c1["general_contacts"])
         ahead_sum += c1.get("ahead_steps", 0) - c0.get("ahead_steps", 0)
+        fused_sum += c1.get("fused_steps", 0) - c0.get("fused_steps", 0)
         if snap is None or all_ranks(dt >= args.min_time) or blocks >= 5000:          # (N > 1: every rank leaves after the same block)
             break
     dom = w.kernel_times(reset=True).get(dominant) if dominant else None
@@ -729,6 +748,13 @@ def main():
         ahead_frac = min(1.0, ahead_sum / float(timed_steps)) if timed_steps else 0.0
         if ahead_frac > 0.0 and K > 0:
             KERNEL_BYTES["solve_still"] = ("K", KERNEL_BYTES["solve_still"][1] + AHEAD_BYTES_PER_BODY * ahead_frac * nb / K)
+        fused_frac = min(1.0, fused_sum / float(timed_steps)) if timed_steps else 0.0
+        # the one-kernel still step, priced for the scene at hand: per dynamic box body 574 B, per dynamic sphere body 454 B (KERNEL_BYTES), per body of the world
+        if n_box_dyn + n_sph_dyn:
+            KERNEL_BYTES["still_fused"] = ("B", (574.0 * n_box_dyn + 454.0 * n_sph_dyn) / float(nb + 1))
+        out["config"]["fused_still"] = {"timed_steps_that_were_one_launch": fused_sum, "share_of_timed_steps": fused_frac,
+                                        "note": "a plain still step that starts at the narrowphase and is not the last sub-step of its nh_step call is ONE launch (nh_fused.hip): the lane that solves "
+                                                "a body evaluates the body's kept pair itself; fused steps come in pairs (body state is written out of place), the sub-steps a call begins and ends with are the two- / three-launch form"}
         out["config"]["xform_ahead"] = {"timed_steps_started_at_the_narrowphase": ahead_sum, "share_of_timed_steps": ahead_frac,
                                         "bytes_per_body_added_to_solve_still": AHEAD_BYTES_PER_BODY,
                                         "note": "a plain still step's solver does the next sub-step's world transforms / AABBs / box test / scene bounds (nh_step, note 9): that step has no k_xform<true>"}
@@ -744,6 +770,9 @@ def main():
                 continue
             weight = 1.0 if launches >= 3 else 1.0 / args.steps
             alg += weight * kb[1] * units[kb[0]] * (I if name == "apply_level" else 1)      # ("GI" units already carry the iterations)
+        if fused_frac > 0.0:
+            # `alg` so far prices the launches of the instrumented pass, which never fuses: the timed steps were `fused_frac` one-launch steps and the rest as priced
+            alg = fused_frac * KERNEL_BYTES["still_fused"][1] * units["B"] + (1.0 - fused_frac) * alg
         pmc_sum, pmc_src = pmc_step_total() if args.scene == "boxes" and args.tiles == 124 and world == 1 else (None, None)
         pmc_frac = (pmc_sum / sec_per_step / 1e9 / HBM_PEAK_GBS) if pmc_sum else None
         pmc_refused = None
@@ -786,7 +815,7 @@ def main():
                                                   "kernel_ms_per_step: 3 separate steps with events around EVERY launch (each kernel alone on the GPU)"}
             # `bound` stays "hbm": achieved / peak above are the HBM roofline the metric is defined on.  What actually limits a kernel of dependent fp32 arithmetic is
             # said next to it: its VALU issue rate against the SIMD's limit and against the rate of one dependency chain per wave (valu_ceiling)
-            vc = valu_ceiling(dominant, ms) if (dominant in ("solve_still", "solve_one_body") and comparable and which == "") else None          # (the SQ export describes c2's launches)
+            vc = valu_ceiling(dominant, ms) if (dominant in ("solve_still", "solve_one_body", "still_fused") and comparable and which == "") else None          # (the SQ export describes c2's launches)
             if vc:
                 out["roofline"]["valu"] = vc
                 out["roofline"]["limited_by"] = "VALU throughput at this kernel's instruction mix (roofline.valu: the pipe is ~1.0 busy while the waves compute, two thirds of the kernel) next to the bytes it moves in 16- and 32-byte pieces; neither more waves nor prefetching helps (DESIGN.md 7.3)"

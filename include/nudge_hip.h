@@ -217,6 +217,7 @@ typedef struct nh_Counts {
 	uint32_t asleep_steps;      /* steps since nh_create that nh_step found to be steps of a world in which every body is asleep and nothing has changed: done without a launch */
 	uint32_t ahead_steps;       /* still steps (launched, since nh_create) that started at the narrowphase: the solver of the sub-step before them, inside the same nh_step call, had
 	                               already written their colliders' world transforms and boxes (note 9, "xform ahead") */
+	uint32_t fused_steps;       /* ... and that went through as ONE launch (note 9, "one-kernel still step"): the lane that solves a body evaluated the body's collider pair itself */
 } nh_Counts;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */

@@ -20,8 +20,7 @@
 // inflation of the kept pair list's boxes: 1/32 of the last grid's cell (nothing is known before the first grid)
 #define NH_ESC_MAX 4096u             // colliders re-inserted per step at most (more leave their boxes: rebuild)
 #define NH_MOVED_MAX 16384u          // colliders re-inserted since the last rebuild at most (their grid entries are stale: the next leaver is tested against each of them)
-#define NH_GEN_SHIFT 24u             // kept pairs carry the generation stamps of their two colliders above the 24-bit collider index
-#define NH_GEN_INDEX 0xFFFFFFu
+// (NH_GEN_SHIFT / NH_GEN_INDEX -- kept pairs carry the generation stamps of their two colliders above the 24-bit collider index: nh_internal.h)
 __device__ __forceinline__ float nh_kept_margin(float cell_inv) { return cell_inv > 0.0f ? 0.03125f / cell_inv : 0.05f; }
 
 // STILL (nh_collide, "9. still steps"): the step was launched as one in which nothing changes structurally.  The kernel then only CHECKS -- a collider
@@ -392,10 +391,7 @@ __global__ __launch_bounds__(256) void k_cell_scatter(const nh_DevState* __restr
 	}
 }
 
-__device__ __forceinline__ bool aabb_overlap(const float4& amin, const float4& amax, const float4& bmin, const float4& bmax) {
-	// strict overlap, nudge.cpp:3306-3308
-	return (bmax.x > amin.x) && (amax.x > bmin.x) && (bmax.y > amin.y) && (amax.y > bmin.y) && (bmax.z > amin.z) && (amax.z > bmin.z);
-}
+__device__ __forceinline__ bool aabb_overlap(const float4& amin, const float4& amax, const float4& bmin, const float4& bmax) { return nh_aabb_overlap(amin, amax, bmin, bmax); }
 
 // Pair emission.  A single global counter takes ~12 ns per atomic (same-address atomics serialise in L2), so
 // one atomic per wave per hit-iteration would cost more than the search itself: every wave stages its pairs in
@@ -1962,6 +1958,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->still_delta, sizeof(int2) * 2u * NH_DELTA_MAX));
 		ctx->raw_slots = (uint32_t)slots;
 		ctx->lay_capacity = pair_cap; ctx->lay_contact_capacity = cap; lay_fresh = true;
+		ctx->fused.map_valid = false;
 	}
 	if (ctx->lay_body_capacity < B) {
 		void** bufs[] = { (void**)&ctx->lay_class, (void**)&ctx->lay_simple, (void**)&ctx->body_rec, (void**)&ctx->body_pos };
@@ -2018,6 +2015,18 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			const bool plain = !movers && !sleepers && !ss.appended_pairs && (nbox >= 2 || nsph != 0u);
 			const bool ahead_step = plain && ss.ahead_ready && !ss.no_ahead;
 			ss.ahead_ready = false; ss.ahead_plain = plain;
+			// THE ONE-KERNEL STILL STEP (nh_fused.hip): a plain step that starts at the narrowphase, inside nh_step with late verdicts, and is not the call's last -- nothing is
+			// launched here; the solver call launches k_still_fused, which evaluates every kept pair in the lane that solves its body
+			const bool fused = ahead_step && ss.pipelined && ss.more_steps && nh_fused_wanted(ctx, B, C, ss.steps_left);
+			ss.fused = fused;
+			if (movers) ctx->fused.map_valid = false;          // (re-stamped and appended pairs: the position table describes another kept list)
+			if (!fused && ctx->fused.cur != 0u) {
+				// the bodies live in the shadow arrays (an odd run of fused steps) and this step works in place: the run's last verdict first -- a failed step's output
+				// must not be copied over the state it has to be replayed from -- then the bodies go home
+				if (ss.verdict.pending && nh_still_verdict_now(ctx)) return NH_INTERNAL_STILL_FAILED;
+				{ int rc = nh_fused_come_home(ctx); if (rc) return rc; }
+			}
+			if (!ahead_step) ctx->fused.statics_copied = false;          // (k_xform<true> rewrites the current set of collider buffers, the static world's entries included)
 			if (ahead_step) ss.ahead_steps++;
 			else
 			NH_LAUNCH(ctx, "xform_still", (k_xform<true>), nh_grid_for(C > B ? C : B, 1024, 256), 1024, st, bodies->transforms,
@@ -2056,12 +2065,14 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 				else NH_LAUNCH(ctx, NAME, (k_narrowphase<SPHERES, true, false>), nh_grid_for(pair_cap, 256, GRIDMAX), 256, st, ctx->fat_pairs, xf, ctag, \
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr, \
 				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, (uint32_t*)nullptr, ahead_step ? 1u : 0u); } while (0)
+			if (!fused) {
 			if (nbox >= 2) NH_NARROW_STILL(false, "narrowphase_still", 4096);
 			if (nsph) NH_NARROW_STILL(true, "narrowphase_sph_still", 8192);
+			}
 			// every record's first contact in the dense (tag-ordered) list = the scan of the counts in tag order: kept from step to step, shifted by the listed changes
 			// (the solver keeps the total).  More pairs changing their count than the list holds: a world of up to two million colliders fails the step (a handful change
 			// per million and step at rest); a larger one runs the scan instead -- two launches that leave at once otherwise, nothing next to its step
-			if (delta_scan) nh_scan_u32(ctx, ctx->cnt_sorted, ctx->start_sorted, &st->records, 1, scan_tmp, nullptr, &st->delta_overflow[ctx->step_parity]);
+			if (delta_scan && !fused) nh_scan_u32(ctx, ctx->cnt_sorted, ctx->start_sorted, &st->records, 1, scan_tmp, nullptr, &st->delta_overflow[ctx->step_parity]);
 			ss.active = true; ss.resolved = false; ss.launched++;
 			ctx->gravity_may_overlap = false;
 			ctx->after_collide = true;
@@ -2070,6 +2081,8 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 	}
 	// a full step.  (nh_step: a still step whose verdict has not been looked at yet must have happened before anything is built on it)
 	if (ctx->still.verdict.pending && nh_still_verdict_now(ctx)) return NH_INTERNAL_STILL_FAILED;
+	ctx->still.fused = false; ctx->fused.map_valid = false; ctx->fused.statics_copied = false;
+	{ int rc = nh_fused_come_home(ctx); if (rc) return rc; }          // (every fused step before this one is confirmed: the bodies it left in the shadow arrays go home)
 	// The solver reads the caller's cache arrays and this nh_collide lays the dense contact list out -- whatever still steps kept by slot goes home first
 	{ int rc = nh_still_export_cache(ctx); if (rc) return rc; }
 	ctx->still.ahead_ready = false; ctx->still.ahead_plain = false;

@@ -189,6 +189,25 @@ struct nh_BlkBuffers {
 // three kernels (k_xform<true>, k_narrowphase<*, true>, the solver reading and writing the cache in place); they CHECK what they rely on (nobody left its
 // inflated box or is asleep; every record has the key, contact count and feature words it had; body 0 inert) and raise st->still_fail otherwise -- after which
 // each of them leaves without having changed anything that matters, and the host, which learns of it with the step's one round trip, replays the step in full.
+// THE ONE-KERNEL STILL STEP (round 6; nh_fused.hip).  A plain still step that starts at the narrowphase (xform ahead) and is not the last sub-step of its nh_step call
+// is ONE launch: the lane that solves a body evaluates the body's one kept pair itself and keeps the contacts on chip.  The kernel reads body state, slot cache and
+// collider transforms from one set of buffers and writes the other (a check that fails in one wave must find the world as it was, although other waves have long
+// advanced their bodies): `cur` says where the BODY state lives -- 0: the caller's arrays, 1: the shadow arrays below -- while the library-owned buffers simply
+// change names with their twins (ctx->sc_* / own_* always name the current ones).  Fused steps come in pairs, so a call ends in the caller's arrays.
+struct nh_FusedState {
+	bool enabled;                   // option "fused_still" (OFF by default: measured slower than the two launches it replaces -- nh_fused.hip)
+	uint32_t debug_fail_in;         // option "fused_fail_in" (tests): the n-th fused launch from now fails itself after its waves have written
+	uint32_t cur;                   // which set holds the body state
+	uint32_t unconfirmed;           // fused launches whose verdict the host has not seen (each changed the sets over: a failure changes them back)
+	uint64_t steps, homecomings;    // statistics: fused steps that happened; copies of the shadow arrays back into the caller's outside the pairing
+	unsigned long long* seg; uint32_t seg_words; bool seg_clean[2];          // segment sums of the look-back, by step parity (nh_fused.hip)
+	uint4* fz; unsigned long long* status; bool map_valid; uint32_t map_records;      // per tag-order position: record, body, colliders (k_fused_map); the look-back words
+	bool statics_copied;            // the static world's collider transforms / boxes are in both sets (since the last k_xform<true>)
+	float4* sc_imp_alt; uint32_t* sc_feat_alt; uint32_t* sc_count_alt; uint32_t pair_capacity;
+	struct nh_xform* own_xf_alt; float4* own_aabb_min_alt; float4* own_aabb_max_alt; uint32_t collider_capacity;
+	nh_Transform* shadow_xf; nh_BodyMomentum* shadow_mom; uint8_t* shadow_idle; uint32_t body_capacity;
+};
+
 struct nh_StillStep {
 	bool disabled;                  // nh option / NH_NO_STILL=1: never launch a step speculatively (A/B, tests)
 	bool ok_next;                   // the last step left a layout, body classes and a cache that a still step may rely on (decided at its round trip / end)
@@ -212,6 +231,9 @@ struct nh_StillStep {
 	nh_ActiveBodies* active_out; nh_ContactData* contacts_out; nh_BodyData bodies; nh_ColliderData colliders; nh_BodyConnections connections; bool has_connections; nh_Arena temporary;
 	nh_BodyData lay_bodies; nh_ColliderData lay_colliders; nh_ContactData lay_contacts; const uint32_t* lay_active; uint32_t lay_active_capacity;
 	uint64_t launched, failed;      // statistics
+	bool fused;                     // the still step being launched is a fused one (nh_FusedState): nh_collide launched nothing, the solver call launches k_still_fused
+	bool verdict_fused;             // ... and so was the step whose verdict is pending
+	uint32_t steps_left;            // nh_step: sub-steps of this call behind the one being launched
 	uint32_t confirmed_seq;         // collide_seq of the newest still step whose verdict was "confirmed" (every drop noted in ctx->sc_undo under a later number is undone on failure)
 	bool undo_dirty;                // a narrowphase in sleepers form has run since sc_undo was last swept
 	// back-off: a world in which something keeps moving (a body in the air leaves its inflated box every step) fails every still step it is offered; after the k-th
@@ -398,6 +420,7 @@ struct nh_context {
 	// per body (k_adj_simple): class, contact-list record of the full path; the record a body's contacts come from (| NH_BODY_REC_IS_A) and its tag-order position
 	uint8_t* lay_class; uint2* lay_simple; uint32_t* body_rec; uint32_t* body_pos; uint32_t lay_body_capacity;
 	nh_StillStep still;
+	nh_FusedState fused;
 	nh_AsleepState asleep;
 	uint32_t first_ghost;          // nh_set_first_ghost_body: bodies >= first_ghost are ghosts of a partitioned world (0 = no ownership rule)
 	nh_StateStream stream_state;
@@ -414,10 +437,18 @@ int nh_still_abandon(nh_context* ctx);
 int nh_still_sync_outputs(nh_context* ctx, uint32_t what = 7u /* NH_VIEW_ALL */);
 int nh_still_export_cache(nh_context* ctx);
 int nh_still_undo_drops(nh_context* ctx);
+// nh_fused.hip
+bool nh_fused_wanted(nh_context* ctx, uint32_t B, uint32_t C, uint32_t steps_left);
+int nh_fused_launch(nh_context* ctx, const nh_BodyData* bodies, uint32_t iterations, uint32_t guard_seq);
+int nh_fused_come_home(nh_context* ctx);
+void nh_fused_void_last(nh_context* ctx, uint32_t launches);
+void nh_fused_free(nh_context* ctx);
 void nh_stream_void_advance(nh_context* ctx);
 int nh_still_verdict_now(nh_context* ctx);            // nh_step: the pending verdict of the last still step, waited for: 0 = it happened, 1 = it did not
 #define NH_INTERNAL_STILL_FAILED (-1000)      // (never leaves the library) first_apply -> nh_step: the still step before this one failed, run both again
 #define NH_DELTA_MAX 256u
+#define NH_GEN_SHIFT 24u             // kept pairs carry the generation stamps of their two colliders above the 24-bit collider index (nh_collide.hip, "7. re-insertion")
+#define NH_GEN_INDEX 0xFFFFFFu
 #define NH_BODY_REC_NONE 0xFFFFFFFFu
 #define NH_BODY_REC_IS_A 0x80000000u
 struct nh_Record { uint32_t body_a, body_b, overflow, count; };          // one per collider pair that reached the narrowphase (nh_collide.hip)
@@ -588,6 +619,10 @@ __device__ __forceinline__ unsigned nh_lane() { return __lane_id(); }
 // 16 bytes from a per-lane global address straight into LDS (lane-linear destination: consecutive lanes must name consecutive 16-byte pieces)
 __device__ __forceinline__ void nh_glds16(const float4* src, float4* lds_dst) {
 	__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+__device__ __forceinline__ bool nh_aabb_overlap(const float4& amin, const float4& amax, const float4& bmin, const float4& bmax) {
+	// strict overlap, nudge.cpp:3306-3308
+	return (bmax.x > amin.x) && (amax.x > bmin.x) && (bmax.y > amin.y) && (amax.y > bmin.y) && (bmax.z > amin.z) && (amax.z > bmin.z);
 }
 __device__ __forceinline__ uint32_t nh_float_flip(float f) {
 	uint32_t u = __float_as_uint(f);

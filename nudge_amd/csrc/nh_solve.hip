@@ -2825,14 +2825,18 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 			// map -- the lanes do the next step's k_xform<true> on their way out
 			const bool ahead = ss.ahead_plain && ss.more_steps && ss.ahead_map_ok && !ss.no_ahead && !ss.ahead_world_bad && ctx->env_solver_waves != 4 && ctx->env_solver_waves != 2 &&
 			                   ctx->own_xf && ctx->body_col && ctx->body_col_capacity >= B;
-			if (ahead) {
+			if (ss.fused) {
+				// ONE launch for the whole step (nh_fused.hip): pair evaluation, solver, advance and the next sub-step's transforms
+				int rc = nh_fused_launch(ctx, bodies, iterations, fs.guard_seq);
+				if (rc) return rc;
+			} else if (ahead) {
 				const nh_ColliderData& cd = ss.colliders;
 				nh_AheadView av = { ctx->body_col, cd.boxes.transforms, cd.boxes.data, cd.spheres.transforms, cd.spheres.data, cd.boxes.count, ctx->own_xf, ctx->own_aabb_min, ctx->own_aabb_max, ctx->fat_box };
 				NH_LAUNCH(ctx, "solve_still", (k_solve_one_body<4, true, true, 1, true, true>), (B + 63u) / 64u, 64, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
 				          (float4*)d->states, iterations, ctx->raw_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fs, sv, av);
 			} else
 			if (ctx->env_solver_waves == 4) NH_SOLVE_STILL(4); else if (ctx->env_solver_waves == 2) NH_SOLVE_STILL(2); else NH_SOLVE_STILL(1);
-			ss.ahead_ready = ahead;
+			ss.ahead_ready = ahead || ss.fused;
 			if (ss.pipelined && ss.h_ring[0]) {
 				// nh_step: first the verdict of the still step BEFORE this one (its counters landed long ago) ...
 				if (ss.verdict.pending) {
@@ -2840,6 +2844,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 					const nh_DevState* h = ss.h_ring[ss.verdict.slot];
 					if (h->still_failed_seq >= ss.verdict.seq || h->error) return NH_INTERNAL_STILL_FAILED;       // (nh_step cleans up and runs both steps again)
 					ss.confirmed_seq = ss.verdict.seq;
+					if (ss.verdict_fused && ctx->fused.unconfirmed) ctx->fused.unconfirmed--;
 					memcpy(ctx->h_state, h, NH_COUNTER_WORDS * sizeof(uint32_t));
 					if (!ctx->idle_unknown) { ctx->idle_bound = (int)h->max_idle[ss.verdict.parity]; ctx->idle_bound_mark = ss.verdict.collide_mark; }
 					ss.verdict.pending = false;
@@ -2850,6 +2855,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 				NH_HIP_CHECK(ctx, hipMemcpyAsync(ss.h_ring[slot], ctx->d_state, NH_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 				NH_HIP_CHECK(ctx, hipEventRecord(ss.ev_ring[slot], ctx->stream));
 				ss.verdict.pending = true; ss.verdict.seq = ctx->collide_seq; ss.verdict.parity = ctx->step_parity; ss.verdict.slot = slot; ss.verdict.collide_mark = ctx->collide_mark;
+				ss.verdict_fused = ss.fused;
 				confirmed = true;          // (until the next step says otherwise)
 			} else {
 				// the step's one round trip: did every check hold?
@@ -3256,6 +3262,7 @@ int nh_still_verdict_now(nh_context* ctx) {
 	ss.verdict.pending = false;
 	if (h->still_failed_seq >= ss.verdict.seq || h->error) return 1;
 	ss.confirmed_seq = ss.verdict.seq;
+	if (ss.verdict_fused && ctx->fused.unconfirmed) ctx->fused.unconfirmed--;
 	memcpy(ctx->h_state, h, NH_COUNTER_WORDS * sizeof(uint32_t));
 	if (!ctx->idle_unknown) { ctx->idle_bound = (int)h->max_idle[ss.verdict.parity]; ctx->idle_bound_mark = ss.verdict.collide_mark; }
 	still_note_movers(ctx, h);
@@ -3273,6 +3280,11 @@ static int still_forget_failed(nh_context* ctx, bool advanced, uint32_t voided) 
 	ctx->grav.pending = false; ctx->grav.rest_pending = false; ctx->adv.done = false;
 	ctx->after_collide = false; ctx->gravity_may_overlap = false;
 	if (advanced && ctx->advance_count) ctx->advance_count--;          // (the failed step's nh_advance was counted: the sleep prediction counts real ones)
+	// fused launches among the voided steps (nh_fused.hip) wrote into the OTHER set of buffers: the sets change back, and if the state they were given lives in the
+	// shadow arrays it goes home -- the replay is a full step, in place
+	nh_fused_void_last(ctx, ctx->fused.unconfirmed);
+	ss.fused = false; ss.verdict_fused = false;
+	{ int rc = nh_fused_come_home(ctx); if (rc) return rc; }
 	if (advanced) nh_stream_void_advance(ctx);          // (... and so does the state stream; a frame taken at that nh_advance shows the state BEFORE the step: it is withdrawn)
 	{ int rc = nh_still_undo_drops(ctx); if (rc) return rc; }          // (sleepers form: slot-cache counts the voided steps' narrowphases dropped)
 	return nh_still_export_cache(ctx);                                 // (the slot cache holds the last step that DID happen: the full solver reads the caller's arrays)
@@ -3330,7 +3342,7 @@ extern "C" int nh_step(nh_context* ctx, const nh_StepArgs* a, uint32_t steps) {
 			ctx->asleep.streak = 0;
 		}
 		int rc;
-		ss.more_steps = i + 1u < steps;
+		ss.more_steps = i + 1u < steps; ss.steps_left = steps - 1u - i;
 		nh_Arena temporary = a->arena;
 		nh_ContactImpulseData* imp = nullptr;
 		nh_ContactConstraintData* con = nullptr;
@@ -3352,7 +3364,10 @@ extern "C" int nh_step(nh_context* ctx, const nh_StepArgs* a, uint32_t steps) {
 		    (rc = nh_advance(ctx, a->active_bodies, a->bodies, a->time_step))) { result = rc; break; }
 		++i;
 	}
-	ss.pipelined = false; ss.more_steps = false; ss.ahead_ready = false; ss.ahead_map_ok = false;
+	ss.pipelined = false; ss.more_steps = false; ss.ahead_ready = false; ss.ahead_map_ok = false; ss.steps_left = 0u; ss.fused = false;
 	if (result && ss.verdict.pending) { hipEventSynchronize(ss.ev_ring[ss.verdict.slot]); ss.verdict.pending = false; }
+	// (fused steps are launched in pairs and every verdict of the call is in: the bodies are in the caller's arrays -- unless the call ends in an error)
+	if (ctx->fused.cur != 0u) { ctx->fused.unconfirmed = 0u; int rc = nh_fused_come_home(ctx); if (rc && !result) result = rc; }
+	ctx->fused.unconfirmed = 0u;
 	return result;
 }

@@ -31,7 +31,7 @@ NH_VIEW_CONTACTS, NH_VIEW_CACHE, NH_VIEW_ACTIVE, NH_VIEW_ALL = 1, 2, 4, 7
 # environment variables NH_<NAME> that World() forwards to nh_set_option (tests and dev scripts; include/nudge_hip.h lists what each does)
 OPTION_NAMES = ("no_still", "no_kept_pairs", "no_incremental", "no_sort_reuse", "sort_classic", "sort_radix", "bucket_tile", "bucket_target", "colour_jp",
                 "colour_check_seeds", "no_resident", "solver_waves", "fp_sub", "cooperative", "no_blocks", "blk_check", "blk_min", "blk_target", "blk_rows_global",
-                "blk_global_colours", "blk_profile", "no_asleep", "no_blk_chain", "no_local_still", "no_xform_ahead", "measure_skip_chains", "sync_exports_views")
+                "blk_global_colours", "blk_profile", "no_asleep", "no_blk_chain", "no_local_still", "no_xform_ahead", "measure_skip_chains", "sync_exports_views", "fused_still", "fused_fail_in")
 
 EXPORTS = [
     "nh_create", "nh_destroy", "nh_set_flags", "nh_synchronize", "nh_read_counts", "nh_export_views", "nh_set_cache_count",
@@ -85,7 +85,7 @@ class Counts(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("colliders", "pairs", "contacts", "sleeping_pairs", "active_bodies", "cache", "culled",
                                           "large_colliders", "general_contacts", "levels", "error", "has_other_bodies", "unleveled", "raw_pairs", "broadphase_rebuilds", "sort_reuses", "broadphase_inserts",
                                           "still_steps", "still_replays", "still_diff_key", "still_diff_count", "still_diff_feature", "still_diff_escape",
-                                          "blk_blocks", "blk_bodies", "blk_ghosts", "asleep_steps", "ahead_steps")]
+                                          "blk_blocks", "blk_bodies", "blk_ghosts", "asleep_steps", "ahead_steps", "fused_steps")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -471,6 +471,10 @@ class World:
         self.synchronize()
         return dict(transforms=self._down("bt", S.TRANSFORM, self.nb), momentum=self._down("bm", S.MOMENTUM, self.nb),
                     idle=self._down("bi", np.uint8, self.nb))
+
+    def set_option(self, name, value=1):
+        """nh_set_option on the live world (tests, A/B): include/nudge_hip.h lists the names."""
+        _check(self.L, self.L.nh_set_option(self.ctx, name.encode(), int(value)), f"nh_set_option({name})")
 
     def set_bodies(self, transforms=None, momentum=None, idle=None):
         torch = self.torch
