@@ -100,6 +100,7 @@ KERNEL_BYTES = {
     #   a sphere body (one contact): 16 + 16 instead of 64 + 64 impulse bytes, 4 + 4 instead of 16 + 16 feature bytes                                        = 454 B
     # NO contact ever reaches HBM: the two-kernel form writes 4 x 36 B per pair and reads them back (narrowphase_still 352 + solve_still 4 x 118.5 + 148 = 974 B per box body)
     "still_fused": ("B", 574.0), "fused_map": ("R", 4 + 8 + 16 + 16), "fused_copy_static": ("T", 0), "fused_copy_bodies": ("B", 2 * 65),
+    "pair_begin": ("T", 0), "pair_owned": ("B", 4),
     "ahead_map": ("C", 16 + 4), "ahead_check": ("C", 16 + 4),      # once per nh_step call (xform ahead): AABB min + body of every collider -> body's collider / several colliders? + the static world's bounds
     "asleep_check": ("C", 32 + 32 + 16 + 4 + 32 + 32 + 4 + 1),   # nh_step on a world asleep: local + body transform, shape, tag, the remembered AABB and tag, the idle counter
     "slot_counts": ("R", 4 + 4 + 4), "slots_to_cache": ("K", 16 + 4 + 28), "cache_to_slots": ("K", 4 + 16 + 4 + 20),
@@ -144,6 +145,10 @@ PMC_KERNEL = {"still_fused": "k_still_fused", "solve_one_body": "k_solve_one_bod
 
 
 AHEAD_BYTES_PER_BODY = 4 + 32 + 16 + 32 + 32 + 32       # xform ahead (main): what a still solver lane moves for the next step's k_xform<true>
+# pair ahead (main): what the lane moves MORE to evaluate its body's own kept pair for the next step -- the pair 8 r, the key on file 8 r, two tags 8 r, the record's count 4 w,
+# per contact 32 + 4 w (the static partner's transform / box / shape: shared by the ~8100 bodies of a tile, cache hits) -- priced per body with its contacts for the scene at hand
+PAIR_BYTES_PER_BODY = 8 + 8 + 8 + 4
+PAIR_BYTES_PER_CONTACT = 36
 PMC_SUFFIX = ""       # "_c4" for the pit: its own export (profiles/collect.sh)
 
 
@@ -626,6 +631,7 @@ def main():
         w.enable_timing(True, only=dominant)
     dt, blocks, contact_sum, pair_sum, general_sum = 0.0, 0, 0.0, 0.0, 0.0
     fused_sum = 0          # timed steps that were ONE launch (nh_fused.hip)
+    pairstep_sum = 0       # timed steps that started at the solver (pair ahead)
     ahead_sum = 0          # timed steps that started at the narrowphase: the step before them did their k_xform<true> inside its solver (include/nudge_hip.h note 9, xform ahead)
     block_ms = []
     timed_acc = [0.0, 0, 0.0, 0]          # inside the timed blocks only: seconds in refreshes, refreshes, seconds enqueueing per-step halos, per-step halos
@@ -664,6 +670,7 @@ def main():
         general_sum += 0.5 * (c0["general_contacts"] + c1["general_contacts"])
         ahead_sum += c1.get("ahead_steps", 0) - c0.get("ahead_steps", 0)
         fused_sum += c1.get("fused_steps", 0) - c0.get("fused_steps", 0)
+        pairstep_sum += c1.get("pair_steps", 0) - c0.get("pair_steps", 0)
         if snap is None or all_ranks(dt >= args.min_time) or blocks >= 5000:          # (N > 1: every rank leaves after the same block)
             break
     dom = w.kernel_times(reset=True).get(dominant) if dominant else None
@@ -748,6 +755,14 @@ def main():
         ahead_frac = min(1.0, ahead_sum / float(timed_steps)) if timed_steps else 0.0
         if ahead_frac > 0.0 and K > 0:
             KERNEL_BYTES["solve_still"] = ("K", KERNEL_BYTES["solve_still"][1] + AHEAD_BYTES_PER_BODY * ahead_frac * nb / K)
+        # PAIR AHEAD: in `pair_frac` of the timed steps the narrowphase was not launched at all -- the solver lanes of the step before had evaluated every body's own pair
+        # (their launches carry the extra bytes: the launches that DID the evaluation are as many as the steps that profited, one step earlier)
+        pair_frac = min(1.0, pairstep_sum / float(timed_steps)) if timed_steps else 0.0
+        if pair_frac > 0.0 and K > 0:
+            KERNEL_BYTES["solve_still"] = ("K", KERNEL_BYTES["solve_still"][1] + pair_frac * (PAIR_BYTES_PER_BODY * nb / K + PAIR_BYTES_PER_CONTACT))
+        out["config"]["pair_ahead"] = {"timed_steps_started_at_the_solver": pairstep_sum, "share_of_timed_steps": pair_frac,
+                                       "bytes_added_to_solve_still": {"per_body": PAIR_BYTES_PER_BODY, "per_contact": PAIR_BYTES_PER_CONTACT},
+                                       "note": "a plain still step's solver lane also evaluates its body's own kept pair for the next sub-step (nh_step, note 9): that step is ONE solver launch behind a one-workgroup prologue"}
         fused_frac = min(1.0, fused_sum / float(timed_steps)) if timed_steps else 0.0
         # the one-kernel still step, priced for the scene at hand: per dynamic box body 574 B, per dynamic sphere body 454 B (KERNEL_BYTES), per body of the world
         if n_box_dyn + n_sph_dyn:
@@ -769,6 +784,12 @@ def main():
                 unpriced.append(name)
                 continue
             weight = 1.0 if launches >= 3 else 1.0 / args.steps
+            # (the instrumented pass runs outside the pipelined loop: every still step there launches k_xform<true> and the narrowphase -- the timed steps did so only
+            # when they did not start further down the chain)
+            if name == "xform_still":
+                weight *= max(0.0, 1.0 - ahead_frac)
+            elif name in ("narrowphase_still", "narrowphase_sph_still"):
+                weight *= max(0.0, 1.0 - pair_frac)
             alg += weight * kb[1] * units[kb[0]] * (I if name == "apply_level" else 1)      # ("GI" units already carry the iterations)
         if fused_frac > 0.0:
             # `alg` so far prices the launches of the instrumented pass, which never fuses: the timed steps were `fused_frac` one-launch steps and the rest as priced

@@ -217,7 +217,12 @@ typedef struct nh_Counts {
 	uint32_t asleep_steps;      /* steps since nh_create that nh_step found to be steps of a world in which every body is asleep and nothing has changed: done without a launch */
 	uint32_t ahead_steps;       /* still steps (launched, since nh_create) that started at the narrowphase: the solver of the sub-step before them, inside the same nh_step call, had
 	                               already written their colliders' world transforms and boxes (note 9, "xform ahead") */
-	uint32_t fused_steps;       /* ... and that went through as ONE launch (note 9, "one-kernel still step"): the lane that solves a body evaluated the body's collider pair itself */
+	uint32_t fused_steps;       /* ... and that went through as ONE out-of-place launch with a look-back (option "fused_still", off by default: measured slower) */
+	uint32_t pair_steps;        /* still steps that started at the SOLVER: the solver lanes of the sub-step before them had evaluated every body's own collider pair for them as well
+	                               (note 9, "pair ahead") -- a step of ONE launch behind a one-workgroup prologue */
+	uint32_t pair_diag[4];      /* why such steps were refused, summed since nh_create: which collider plays "a" could not be told without the next scene frame / the record was not the
+	                               lane's to evaluate (another key, a fifth contact, a partner that is not the static world) / the next frame's cells came out too large / some kept pair
+	                               belongs to no body (diagnostic) */
 } nh_Counts;
 
 /* ---- lifecycle ---------------------------------------------------------------------------------- */

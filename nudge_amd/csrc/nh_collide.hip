@@ -1325,6 +1325,120 @@ __global__ __launch_bounds__(256) void k_ahead_check(nh_DevState* __restrict__ s
 	if (threadIdx.x < 3 && red[threadIdx.x] <= red[3 + threadIdx.x]) { atomicMin(&st->still_static_min[threadIdx.x], red[threadIdx.x]); atomicMax(&st->still_static_max[threadIdx.x], red[3 + threadIdx.x]); }
 }
 
+// PAIR AHEAD (nh_internal.h: nh_StillStep).  Once per layout: which kept pairs are NO body's contact-list record -- two neighbours whose inflated boxes overlap, a body
+// hovering above ground it does not touch yet.  k_pair_mark stamps every record that is some body's own; k_pair_list lists the others (st->pair_unowned, cleared by
+// k_ahead_map).  The solver lanes evaluate their bodies' own pairs for the next step; k_pair_begin evaluates the listed ones.
+__global__ __launch_bounds__(256) void k_pair_mark(const uint32_t* __restrict__ body_rec, uint32_t nbodies, uint32_t* __restrict__ mark, uint32_t stamp) {
+	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x + 1u; x < nbodies; x += gridDim.x * blockDim.x) {
+		const uint32_t br = body_rec[x];
+		if (br != NH_BODY_REC_NONE) mark[br & ~NH_BODY_REC_IS_A] = stamp;
+	}
+}
+__global__ __launch_bounds__(256) void k_pair_list(nh_DevState* __restrict__ st, const uint32_t* __restrict__ mark, uint32_t stamp, uint32_t* __restrict__ list, uint32_t cap) {
+	const uint32_t n = st->records;
+	for (uint32_t r0 = blockIdx.x * blockDim.x; r0 < n; r0 += gridDim.x * blockDim.x) {
+		const uint32_t r = r0 + threadIdx.x;
+		const bool mine = r < n && mark[r] != stamp;
+		const uint32_t slot = nh_wave_reserve1(&st->pair_unowned, mine);
+		if (mine && slot < cap) list[slot] = r;
+	}
+}
+
+// A still step whose pairs the LAST step's solver lanes have evaluated starts at the solver; this small launch does first what the narrowphase used to do besides: the
+// checks that concern the step as a whole, the scene frame of the step filed where a k_xform<true> would have put it (the host's mirror, the sleep prediction), the other
+// parity's words cleared for what this step's lanes gather (first workgroup) -- one check of its own: the lanes decided which collider of a pair plays "a" with the LAST
+// frame's cells as their yardstick (k_solve_one_body<.., PAIR>), so this step's cells must not be much larger -- and the kept pairs that are NO body's own (k_pair_list),
+// evaluated like k_narrowphase<*, true, false> evaluates them: a record nobody's lane solves must stay without contacts and keep its key, or this is not a still step.
+__global__ __launch_bounds__(256) void k_pair_begin(nh_DevState* __restrict__ st, uint32_t parity, uint32_t seq, const uint32_t* __restrict__ list, uint32_t list_cap,
+                                                    const uint2* __restrict__ kept, uint32_t kept_cap, uint32_t pair_cap, const uint8_t* __restrict__ gen,
+                                                    const nh_xform* __restrict__ xf, const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max, const uint32_t* __restrict__ ctag,
+                                                    const nh_BoxCollider* __restrict__ box_data, const nh_SphereCollider* __restrict__ sph_data, uint32_t nbox,
+                                                    const uint64_t* __restrict__ rec_key, nh_Record* __restrict__ rec) {
+	const uint32_t lane = nh_lane();
+	uint32_t fr_min[3], fr_max[3], fr_top;
+	{
+		const uint32_t* part = &st->ahead_part[parity][lane & (NH_AHEAD_PARTS - 1u)][0];
+		fr_top = part[6];
+		for (int k = 0; k < 3; ++k) { fr_min[k] = min(part[k], st->still_static_min[k]); fr_max[k] = max(part[3 + k], st->still_static_max[k]); }
+	}
+	for (int k = 0; k < 3; ++k)
+		for (int d = 32; d >= 1; d >>= 1) { fr_min[k] = min(fr_min[k], (uint32_t)__shfl_xor((int)fr_min[k], d)); fr_max[k] = max(fr_max[k], (uint32_t)__shfl_xor((int)fr_max[k], d)); }
+	for (int d = 32; d >= 1; d >>= 1) fr_top = max(fr_top, (uint32_t)__shfl_xor((int)fr_top, d));
+	const nh_f3 smin = nh_make3(nh_float_unflip(fr_min[0]), nh_float_unflip(fr_min[1]), nh_float_unflip(fr_min[2]));
+	const nh_f3 smax = nh_make3(nh_float_unflip(fr_max[0]), nh_float_unflip(fr_max[1]), nh_float_unflip(fr_max[2]));
+	const float mscale = nh_morton_scale(smin, smax);
+	const nh_f3 mmin = nh_make3(smin.x * mscale, smin.y * mscale, smin.z * mscale);
+	const uint32_t n_list = st->pair_unowned;
+	if (blockIdx.x == 0 && threadIdx.x < 64u) {
+		const uint32_t op = parity ^ 1u;
+		const float scale_was = nh_morton_scale(nh_make3(nh_float_unflip(st->still_smin[op][0]), nh_float_unflip(st->still_smin[op][1]), nh_float_unflip(st->still_smin[op][2])),
+		                                        nh_make3(nh_float_unflip(st->still_smax[op][0]), nh_float_unflip(st->still_smax[op][1]), nh_float_unflip(st->still_smax[op][2])));
+		const bool bad = st->ahead_failed_seq >= seq || st->ahead_multi != 0u || !st->lay_valid || st->fat_count != st->pairs || st->fat_count_sph != st->pairs_sph ||
+		                 n_list > list_cap || !(mscale >= 0.75f * scale_was);
+		__builtin_amdgcn_wave_barrier();
+		if (lane == 0) {
+			if (bad) { atomicMax(&st->still_failed_seq, seq); atomicAdd(&st->still_diff[3], 1u); }
+			if (!(mscale >= 0.75f * scale_was)) atomicAdd(&st->pair_diag[2], 1u);
+			if (n_list > list_cap) atomicAdd(&st->pair_diag[3], 1u);
+			for (int k = 0; k < 3; ++k) { st->still_smin[parity][k] = fr_min[k]; st->still_smax[parity][k] = fr_max[k]; }
+			st->max_idle[parity] = fr_top;
+			// what k_xform<true> does for the step after this one
+			st->max_idle[op] = 0u; st->delta_count[op] = 0u; st->delta_overflow[op] = 0u; st->still_esc[op] = 0u;
+			st->still_asleep[op] = 0u; st->still_sleeping[op] = 0u; st->still_culled[op] = 0u;
+			for (int k = 0; k < 3; ++k) { st->still_smin[op][k] = 0xffffffffu; st->still_smax[op][k] = 0u; }
+			st->still_fat0 = st->fat_count + st->fat_count_sph;
+		}
+		for (uint32_t k = lane; k < NH_AHEAD_PARTS * 8u; k += 64u) (&st->ahead_part[op][0][0])[k] = (k & 7u) < 3u ? 0xffffffffu : 0u;
+	}
+	// ---- the kept pairs that are nobody's: exact boxes, stamps, roles by Morton order, contact arithmetic -- and the verdict: no contact, the key on file ----
+	const uint32_t n_bb = min(st->pairs, pair_cap);
+	const uint32_t index_mask = gen ? NH_GEN_INDEX : 0xFFFFFFFFu;
+	const bool stamps = gen && st->moved_count != 0u;
+	bool changed = false;
+	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < min(n_list, list_cap); j += gridDim.x * blockDim.x) {
+		const uint32_t r = list[j];
+		const uint2 kp = r < n_bb ? kept[r] : kept[kept_cap - 1u - (r - n_bb)];
+		const uint32_t ca = kp.x & index_mask, cb = kp.y & index_mask;
+		const float4 amin = aabb_min[ca], amax = aabb_max[ca], bmin = aabb_min[cb], bmax = aabb_max[cb];
+		bool hit = aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != __float_as_uint(amin.w));
+		if (stamps && hit) hit = (uint32_t)(gen[ca] & 0x7Fu) == (kp.x >> NH_GEN_SHIFT) && (uint32_t)(gen[cb] & 0x7Fu) == (kp.y >> NH_GEN_SHIFT);
+		int count = 0;
+		uint64_t key = ~0ull;
+		if (hit) {
+			const uint64_t ka = nh_morton_of(nh_make3(amin.x, amin.y, amin.z), mscale, mmin), kb = nh_morton_of(nh_make3(bmin.x, bmin.y, bmin.z), mscale, mmin);
+			const bool a_first = (ka < kb) || (ka == kb && ca < cb);
+			const uint32_t a = a_first ? cb : ca, b = a_first ? ca : cb;          // narrowphase "a" = later in Morton order (emit_pair)
+			const nh_xform A = xf[a], B = xf[b];
+			const uint32_t ta = ctag[a], tb = ctag[b];
+			const bool a_sph = a >= nbox, b_sph = b >= nbox;
+			if (!a_sph && !b_sph) {
+				const nh_BoxCollider sa = box_data[a], sb = box_data[b];
+				nh_bb_result bb;
+				bb.kind = 0; bb.mask = 0;
+				nh_box_box_eval(A, B, sa.size, sb.size, ta, tb, bb);
+				count = nh_bb_count(bb);
+				key = (uint64_t)(bb.swapped ? tb : ta) | ((uint64_t)(bb.swapped ? ta : tb) << 32);
+			} else if (a_sph && b_sph) {
+				nh_contact_out single;
+				count = nh_sphere_sphere(sph_data[b - nbox].radius, sph_data[a - nbox].radius, B, A, &single);
+				key = (uint64_t)tb | ((uint64_t)ta << 32);
+			} else {
+				nh_contact_out single;
+				const uint32_t bx = a_sph ? b : a, sp = a_sph ? a : b;
+				const nh_BoxCollider sz = box_data[bx];
+				count = nh_box_sphere(sz.size, sph_data[sp - nbox].radius, a_sph ? B : A, a_sph ? A : B, &single);
+				key = (uint64_t)(a_sph ? tb : ta) | ((uint64_t)(a_sph ? ta : tb) << 32);
+			}
+		}
+		// (still_record for a record no lane owns: the same key -- or the pair gone -- and no contact; its count on file is 0 and stays 0)
+		const uint64_t was_key = rec_key[r];
+		const bool ok = (was_key == key || !hit) && count == 0;
+		if (!ok) { changed = true; atomicAdd(&st->still_diff[was_key != key && hit ? 0 : 2], 1u); }
+		rec[r].count = 0u;
+	}
+	if (__ballot(changed) != 0ull && lane == 0) atomicMax(&st->still_failed_seq, seq);
+}
+
 // Asleep steps (nh_internal.h: nh_AsleepState): is every collider's world AABB (k_xform's arithmetic, bit for bit) and tag what it was when the world was found asleep,
 // and every body still asleep?  One lane per collider / body; any difference raises st->asleep_failed.
 __global__ __launch_bounds__(256) void k_asleep_check(nh_DevState* __restrict__ st, const nh_Transform* __restrict__ body_xf, const uint8_t* __restrict__ idle, uint32_t nbodies,
@@ -1935,7 +2049,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 	bool lay_fresh = false;
 	if (ctx->lay_capacity != pair_cap || ctx->lay_contact_capacity != cap) {
 		void** bufs[] = { (void**)&ctx->raw_data, (void**)&ctx->raw_feature, (void**)&ctx->rec, (void**)&ctx->lay_rank, (void**)&ctx->cnt_sorted, (void**)&ctx->start_sorted, (void**)&ctx->dense_slot,
-		                  (void**)&ctx->sc_imp, (void**)&ctx->sc_feat, (void**)&ctx->sc_count, (void**)&ctx->sc_undo, (void**)&ctx->exp_cnt, (void**)&ctx->exp_start, (void**)&ctx->exp_scan_tmp, (void**)&ctx->still_delta };
+		                  (void**)&ctx->sc_imp, (void**)&ctx->sc_feat, (void**)&ctx->sc_count, (void**)&ctx->sc_undo, (void**)&ctx->pair_mark, (void**)&ctx->pair_list, (void**)&ctx->exp_cnt, (void**)&ctx->exp_start, (void**)&ctx->exp_scan_tmp, (void**)&ctx->still_delta };
 		for (void** b : bufs) { if (*b) NH_HIP_CHECK(ctx, hipFree(*b)); *b = nullptr; }
 		ctx->lay_capacity = 0; ctx->lay_contact_capacity = 0;
 		const size_t slots = (size_t)4 * pair_cap + cap, cache_slots = (size_t)5 * pair_cap + 64u;
@@ -1952,6 +2066,10 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->sc_undo, sizeof(uint64_t) * (size_t)pair_cap + 64u));
 		NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->sc_undo, 0, sizeof(uint64_t) * (size_t)pair_cap + 64u, s));
 		ctx->still.undo_dirty = false;
+		ctx->pair_list_capacity = pair_cap / 8u + 1024u;
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->pair_mark, sizeof(uint32_t) * (size_t)pair_cap + 64u));
+		NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->pair_mark, 0, sizeof(uint32_t) * (size_t)pair_cap + 64u, s));
+		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->pair_list, sizeof(uint32_t) * (size_t)ctx->pair_list_capacity));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->exp_cnt, sizeof(uint32_t) * ((size_t)pair_cap + 2u)));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->exp_start, sizeof(uint32_t) * ((size_t)pair_cap + 2u)));
 		NH_HIP_CHECK(ctx, hipMalloc((void**)&ctx->exp_scan_tmp, sizeof(uint32_t) * (2u * NH_SORT_GRID + 64u)));
@@ -2026,6 +2144,10 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 				if (ss.verdict.pending && nh_still_verdict_now(ctx)) return NH_INTERNAL_STILL_FAILED;
 				{ int rc = nh_fused_come_home(ctx); if (rc) return rc; }
 			}
+			// PAIR AHEAD (nh_internal.h): the last step's solver lanes evaluated this step's pairs too -- this step starts at the solver, behind one wave of bookkeeping
+			const bool pair_step = ahead_step && ss.pair_ready && !fused && !ss.no_pair;
+			ss.pair_ready = false; ss.pair_step = pair_step;
+			if (pair_step) ss.pair_steps++;
 			if (!ahead_step) ctx->fused.statics_copied = false;          // (k_xform<true> rewrites the current set of collider buffers, the static world's entries included)
 			if (ahead_step) ss.ahead_steps++;
 			else
@@ -2046,6 +2168,13 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 				NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->body_col, 0xff, sizeof(uint32_t) * (size_t)B, ctx->stream));
 				NH_LAUNCH(ctx, "ahead_map", k_ahead_map, nh_grid_for(C, 256, 2048), 256, st, aabb_min, C, ctx->body_col);
 				NH_LAUNCH(ctx, "ahead_check", k_ahead_check, nh_grid_for(C, 256, 1024), 256, st, aabb_min, C, ctx->body_col);
+				if (ss.pair_owned_seq == 0u && !ss.no_pair && ctx->pair_mark) {
+					// (pair ahead: the kept pairs that are no body's own, listed once per layout)
+					NH_HIP_CHECK(ctx, hipMemsetAsync(&st->pair_unowned, 0, sizeof(uint32_t), ctx->stream));
+					NH_LAUNCH(ctx, "pair_mark", k_pair_mark, nh_grid_for(B, 256, 2048), 256, ctx->body_rec, B, ctx->pair_mark, ctx->collide_seq);
+					NH_LAUNCH(ctx, "pair_list", k_pair_list, nh_grid_for(pair_cap, 256, 2048), 256, st, ctx->pair_mark, ctx->collide_seq, ctx->pair_list, ctx->pair_list_capacity);
+					ss.pair_owned_seq = ctx->collide_seq;
+				}
 				ss.ahead_map_ok = true;
 			}
 			if (movers)
@@ -2065,14 +2194,16 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 				else NH_LAUNCH(ctx, NAME, (k_narrowphase<SPHERES, true, false>), nh_grid_for(pair_cap, 256, GRIDMAX), 256, st, ctx->fat_pairs, xf, ctag, \
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr, \
 				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, (uint32_t*)nullptr, ahead_step ? 1u : 0u); } while (0)
-			if (!fused) {
+			if (pair_step) NH_LAUNCH(ctx, "pair_begin", k_pair_begin, 32, 256, st, ctx->step_parity, ctx->collide_seq, ctx->pair_list, ctx->pair_list_capacity, ctx->fat_pairs, ctx->fat_pair_capacity, pair_cap, gen,
+			                         xf, aabb_min, aabb_max, ctag, colliders->boxes.data, colliders->spheres.data, nbox, ctx->sort_keys_by_position, rec);
+			else if (!fused) {
 			if (nbox >= 2) NH_NARROW_STILL(false, "narrowphase_still", 4096);
 			if (nsph) NH_NARROW_STILL(true, "narrowphase_sph_still", 8192);
 			}
 			// every record's first contact in the dense (tag-ordered) list = the scan of the counts in tag order: kept from step to step, shifted by the listed changes
 			// (the solver keeps the total).  More pairs changing their count than the list holds: a world of up to two million colliders fails the step (a handful change
 			// per million and step at rest); a larger one runs the scan instead -- two launches that leave at once otherwise, nothing next to its step
-			if (delta_scan && !fused) nh_scan_u32(ctx, ctx->cnt_sorted, ctx->start_sorted, &st->records, 1, scan_tmp, nullptr, &st->delta_overflow[ctx->step_parity]);
+			if (delta_scan && !fused && !pair_step) nh_scan_u32(ctx, ctx->cnt_sorted, ctx->start_sorted, &st->records, 1, scan_tmp, nullptr, &st->delta_overflow[ctx->step_parity]);
 			ss.active = true; ss.resolved = false; ss.launched++;
 			ctx->gravity_may_overlap = false;
 			ctx->after_collide = true;
@@ -2082,6 +2213,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 	// a full step.  (nh_step: a still step whose verdict has not been looked at yet must have happened before anything is built on it)
 	if (ctx->still.verdict.pending && nh_still_verdict_now(ctx)) return NH_INTERNAL_STILL_FAILED;
 	ctx->still.fused = false; ctx->fused.map_valid = false; ctx->fused.statics_copied = false;
+	ctx->still.pair_ready = false; ctx->still.pair_step = false; ctx->still.pair_world_bad = false; ctx->still.pair_world_ok = false; ctx->still.pair_owned_seq = 0u;          // (another layout: whether every kept pair is some body's own is found out again)
 	{ int rc = nh_fused_come_home(ctx); if (rc) return rc; }          // (every fused step before this one is confirmed: the bodies it left in the shadow arrays go home)
 	// The solver reads the caller's cache arrays and this nh_collide lays the dense contact list out -- whatever still steps kept by slot goes home first
 	{ int rc = nh_still_export_cache(ctx); if (rc) return rc; }

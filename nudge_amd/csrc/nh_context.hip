@@ -56,7 +56,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->blk.min_contacts = 200000u;
 	ctx->blk.target = 900u;
 	ctx->raw_data = nullptr; ctx->raw_feature = nullptr; ctx->raw_slots = 0; ctx->rec = nullptr; ctx->lay_rank = nullptr; ctx->cnt_sorted = nullptr; ctx->start_sorted = nullptr; ctx->dense_slot = nullptr;
-	ctx->sc_imp = nullptr; ctx->sc_feat = nullptr; ctx->sc_count = nullptr; ctx->sc_undo = nullptr; ctx->exp_cnt = nullptr; ctx->exp_start = nullptr; ctx->exp_scan_tmp = nullptr; ctx->still_delta = nullptr; ctx->lay_capacity = 0; ctx->lay_contact_capacity = 0;
+	ctx->sc_imp = nullptr; ctx->sc_feat = nullptr; ctx->sc_count = nullptr; ctx->sc_undo = nullptr; ctx->pair_mark = nullptr; ctx->pair_list = nullptr; ctx->pair_list_capacity = 0; ctx->exp_cnt = nullptr; ctx->exp_start = nullptr; ctx->exp_scan_tmp = nullptr; ctx->still_delta = nullptr; ctx->lay_capacity = 0; ctx->lay_contact_capacity = 0;
 	ctx->own_xf = nullptr; ctx->own_aabb_min = nullptr; ctx->own_aabb_max = nullptr; ctx->own_ctag = nullptr; ctx->own_capacity = 0; ctx->body_col = nullptr; ctx->body_col_capacity = 0;
 	ctx->still_awake = nullptr; ctx->still_awake_capacity = 0; ctx->exp_sleep_a = nullptr; ctx->exp_sleep_b = nullptr; ctx->exp_sleep_hist = nullptr; ctx->exp_flags = nullptr; ctx->exp_sleep_capacity = 0; ctx->exp_flags_capacity = 0;
 	ctx->lay_class = nullptr; ctx->lay_simple = nullptr; ctx->body_rec = nullptr; ctx->body_pos = nullptr; ctx->lay_body_capacity = 0;
@@ -125,7 +125,7 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	for (int k = 0; k < 2; ++k) { if (ctx->still.h_ring[k]) hipHostFree(ctx->still.h_ring[k]); if (ctx->still.ev_ring[k]) hipEventDestroy(ctx->still.ev_ring[k]); }
 	nh_fused_free(ctx);
 	{
-		void* bufs[] = { ctx->raw_data, ctx->raw_feature, ctx->rec, ctx->lay_rank, ctx->cnt_sorted, ctx->start_sorted, ctx->dense_slot, ctx->sc_imp, ctx->sc_feat, ctx->sc_count, ctx->sc_undo, ctx->exp_cnt, ctx->exp_start,
+		void* bufs[] = { ctx->raw_data, ctx->raw_feature, ctx->rec, ctx->lay_rank, ctx->cnt_sorted, ctx->start_sorted, ctx->dense_slot, ctx->sc_imp, ctx->sc_feat, ctx->sc_count, ctx->sc_undo, ctx->pair_mark, ctx->pair_list, ctx->exp_cnt, ctx->exp_start,
 		                 ctx->exp_scan_tmp, ctx->still_delta, ctx->lay_class, ctx->lay_simple, ctx->body_rec, ctx->body_pos, ctx->still_awake, ctx->exp_sleep_a, ctx->exp_sleep_b, ctx->exp_sleep_hist, ctx->exp_flags,
 		                 ctx->own_xf, ctx->own_aabb_min, ctx->own_aabb_max, ctx->own_ctag, ctx->body_col };
 		for (void* b : bufs) if (b) hipFree(b);
@@ -167,6 +167,7 @@ extern "C" int nh_set_option(nh_context* ctx, const char* name, int value) {
 	else if (n == "sync_exports_views") ctx->sync_exports_views = on;          // legacy observers: nh_synchronize / nh_read_counts end with nh_export_views(NH_VIEW_ALL) like they did before round 5 (note 9)
 	else if (n == "fused_fail_in") ctx->fused.debug_fail_in = (uint32_t)value;   // TEST HOOK: the value-th fused launch from now raises the failure flag at its very end (rollback exercised on purpose)
 	else if (n == "fused_still") ctx->fused.enabled = on;                      // plain still steps inside nh_step as ONE out-of-place kernel with a look-back (nh_fused.hip): bit-exact, measured SLOWER, off by default
+	else if (n == "no_pair_ahead") ctx->still.no_pair = on;                    // every still step launches its narrowphase (nh_internal.h: pair ahead; A/B, tests)
 	else if (n == "no_xform_ahead") ctx->still.no_ahead = on;                  // every still step launches k_xform<true> itself (nh_internal.h: xform ahead)
 	else if (n == "no_local_still") ctx->still.no_local = on;                  // a collider that leaves its inflated box fails a still step as a whole (round 4's behaviour; nh_internal.h "LOCAL speculation")
 	else if (n == "no_still") ctx->still.disabled = on;                        // no step is launched speculatively as a still step (note 9)
@@ -238,7 +239,8 @@ void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out) {
 	out->general_contacts = h->general_contacts; out->levels = h->levels; out->error = h->error;
 	out->still_steps = (uint32_t)(ctx->still.launched - ctx->still.failed - ((ctx->still.active && !ctx->still.resolved) ? 1u : 0u)); out->still_replays = (uint32_t)ctx->still.failed;
 	for (int k = 0; k < 4; ++k) out->still_diff[k] = h->still_diff[k];
-	out->asleep_steps = (uint32_t)ctx->asleep.steps; out->ahead_steps = (uint32_t)ctx->still.ahead_steps; out->fused_steps = (uint32_t)ctx->fused.steps;
+	out->asleep_steps = (uint32_t)ctx->asleep.steps; out->ahead_steps = (uint32_t)ctx->still.ahead_steps; out->fused_steps = (uint32_t)ctx->fused.steps; out->pair_steps = (uint32_t)ctx->still.pair_steps;
+	for (int k = 0; k < 4; ++k) out->pair_diag[k] = h->pair_diag[k];
 	out->blk_blocks = h->blk.nblk; out->blk_bodies = h->blk.bodies; out->blk_ghosts = h->blk.ghost_cursor;
 	out->has_other_bodies = h->has_other; out->broadphase_rebuilds = h->fat_rebuilds; out->sort_reuses = h->sort_reuses; out->broadphase_inserts = h->fat_inserts; out->unleveled = h->unleveled; out->raw_pairs = h->pairs + h->pairs_sph;
 }

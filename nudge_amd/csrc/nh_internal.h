@@ -80,7 +80,11 @@ struct nh_DevState {
 	                                      // list the last FULL step laid out, and that step met the conditions a still step relies on (k_gather_contacts)
 	uint32_t has_unstable;                // some body with contacts is outside the class a still step's solver owns (one collider pair, with the static world, <= 4 contacts): k_adj_simple
 	uint32_t still_diff[4];               // why the last still step that failed did: records whose key / contact count / feature words differed, colliders outside their boxes or bodies asleep (statistics)
-	// ---- (the 36 words above are what nh_read_counts mirrors to the host: NH_COUNTER_WORDS) ----
+	uint32_t pair_unowned;                // k_pair_list ("pair ahead", nh_StillStep): kept pairs that are NO body's contact-list record (two neighbours whose inflated boxes overlap, a body
+	                                      // hovering above ground it does not touch yet): no solver lane evaluates them -- they are listed, and k_pair_begin does (more than the list holds: no pair ahead)
+	uint32_t pair_diag[4];                // why pair-ahead steps were refused, summed since nh_create: roles undecidable / record not the lane's to evaluate (key, count, partner) /
+	                                      // the next frame's cells too large / a kept pair that is nobody's (statistics)
+	// ---- (the 41 words above are what nh_read_counts mirrors to the host: NH_COUNTER_WORDS) ----
 	// Temporal coherence of the broadphase (nh_collide.hip, "kept pair list"): the grid search runs over AABBs inflated by `fat_margin` and its
 	// pairs are KEPT; while every collider's AABB stays inside its inflated box the kept list is a superset of the overlapping pairs and one filter
 	// pass (exact AABBs, exact test) replaces the whole regrouping + search.
@@ -152,7 +156,11 @@ struct nh_TimerSlot { const char* name; hipEvent_t a, b; };
 struct nh_xform;
 // what a solver lane needs to do the next step's k_xform<true> for its body's collider (nh_StillStep: xform ahead)
 struct nh_AheadView { const uint32_t* body_col; const nh_Transform* box_xf; const nh_BoxCollider* box_data; const nh_Transform* sph_xf; const nh_SphereCollider* sph_data; uint32_t nbox;
-                      nh_xform* xf; float4* aabb_min; float4* aabb_max; const float4* fat_box; };
+                      nh_xform* xf; float4* aabb_min; float4* aabb_max; const float4* fat_box;
+                      // PAIR AHEAD (nh_StillStep): what the lane needs to evaluate its body's own kept pair for the next sub-step -- the kept list, the keys on file, the stamps and
+                      // tags -- and where the result goes: the record's raw contact slots, its count in the tag order, the next step's list of count changes
+                      const uint2* kept; uint32_t kept_cap, pair_cap; const uint64_t* rec_key; const uint32_t* ctag; const uint8_t* gen;
+                      struct nh_Record* rec; nh_Contact* raw_data; uint32_t* raw_feature; uint32_t* cnt_sorted; int2* delta; uint32_t unowned_cap; };
 struct nh_FusedStep { float gx_dt, gy_dt, gz_dt, damping, time_step; uint32_t bits; uint8_t* idle; uint32_t seq, guard_seq; };      // (still steps: this step's sequence number; the
                                                                                                                                     // oldest still step whose verdict the host has not seen)
 
@@ -231,6 +239,23 @@ struct nh_StillStep {
 	nh_ActiveBodies* active_out; nh_ContactData* contacts_out; nh_BodyData bodies; nh_ColliderData colliders; nh_BodyConnections connections; bool has_connections; nh_Arena temporary;
 	nh_BodyData lay_bodies; nh_ColliderData lay_colliders; nh_ContactData lay_contacts; const uint32_t* lay_active; uint32_t lay_active_capacity;
 	uint64_t launched, failed;      // statistics
+	// PAIR AHEAD (round 6).  With xform ahead a plain still step was two launches: the narrowphase over the kept pairs and the solver.  In the world this form runs in nearly
+	// every kept pair is some dynamic body's ONE pair with the static world (the few that are nobody's are listed once per layout: k_pair_list) -- so the solver lane that has just advanced a body and
+	// written its collider's new world transform and box (xform ahead) goes on and evaluates that pair for the NEXT sub-step too (nh_box_box_eval & co. on what it holds in
+	// registers + the static partner's transform, box and shape): the contacts go to the record's raw slots, the count to its place in the tag order, a change of the count
+	// to the next step's list -- exactly what that step's narrowphase would have written.  The next sub-step is then ONE launch of the solver behind a small
+	// prologue (k_pair_begin: the words the narrowphase's first wave used to clear, file and check, and the listed pairs that are nobody's, evaluated the old way).  No wave waits for another; nothing is written out of place: what
+	// the lane finds wanting (another key, a fifth contact, a partner that is not where the rule below needs it) fails the NEXT step before it starts, like a leaver.
+	// Which collider of a pair plays "a" is decided by the Morton order of the AABB min corners in the NEXT step's scene frame (nudge.cpp:3086-3100), which no lane knows;
+	// but when one corner is <= the other in all three coordinates and clearly less in one (two quantisation cells of THIS step's frame), it comes first in the Morton
+	// order of ANY frame whose cells are not much larger -- k_pair_begin checks that the next frame's are not (scale >= 3/4 of this one's).  A box on a slab always is.
+	bool pair_ready;                // the solver of the LAST step launched evaluated the pairs of this one: the next nh_collide of this call launches k_pair_begin instead of the narrowphase
+	bool pair_step;                 // the still step being launched started at the solver (statistics below)
+	bool no_pair;                   // option "no_pair_ahead"
+	uint32_t pair_owned_seq;        // the nh_collide (collide_seq) in which the kept pairs that are nobody's were last listed; 0: the list is void (a full step has laid the records out again)
+	bool pair_world_bad;            // a round trip showed more such pairs than the list holds: not offered until the next full step
+	bool pair_world_ok;             // ... a round trip showed the list complete (for the layout it was made from): only then are the lanes asked to evaluate their pairs
+	uint64_t pair_steps;            // statistics: still steps that were ONE solver launch (+ its one-workgroup prologue)
 	bool fused;                     // the still step being launched is a fused one (nh_FusedState): nh_collide launched nothing, the solver call launches k_still_fused
 	bool verdict_fused;             // ... and so was the step whose verdict is pending
 	uint32_t steps_left;            // nh_step: sub-steps of this call behind the one being launched
@@ -412,6 +437,7 @@ struct nh_context {
 	// (nh_StillStep) they are written by one step's solver and read by the next step's narrowphase; and the body -> collider map those solver lanes go by
 	struct nh_xform* own_xf; float4* own_aabb_min; float4* own_aabb_max; uint32_t* own_ctag; uint32_t own_capacity;
 	uint32_t* body_col; uint32_t body_col_capacity;
+	uint32_t* pair_mark; uint32_t* pair_list; uint32_t pair_list_capacity;      // pair ahead: per record the stamp of the listing that found it some body's own; the records that are nobody's
 	uint8_t* still_awake; uint32_t still_awake_capacity;                     // per body: awake at the last sleepers-form still step's nh_collide (the active list is a view of it)
 	uint64_t* exp_sleep_a; uint64_t* exp_sleep_b; uint32_t* exp_sleep_hist; uint32_t* exp_flags; uint32_t exp_sleep_capacity, exp_flags_capacity;      // scratch of the view exports (on demand)
 	int2* still_delta;                                                       // 2 x NH_DELTA_MAX: (tag-order position, change of the contact count) of this still step, by step parity
@@ -454,7 +480,7 @@ int nh_still_verdict_now(nh_context* ctx);            // nh_step: the pending ve
 struct nh_Record { uint32_t body_a, body_b, overflow, count; };          // one per collider pair that reached the narrowphase (nh_collide.hip)
 #define NH_REC_SLEEPING 0x80000000u
 void nh_counts_from_mirror(nh_context* ctx, nh_Counts* out);
-#define NH_COUNTER_WORDS 36u          // leading words of nh_DevState that the host mirrors (nh_read_counts)
+#define NH_COUNTER_WORDS 41u          // leading words of nh_DevState that the host mirrors (nh_read_counts)
 
 struct nh_ContactImpulseData {
 	nh_CachedContactImpulse* data;        // K, contact (tag) order; holds the warm-start impulses once `lookup_pending` is false

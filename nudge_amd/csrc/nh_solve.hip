@@ -19,6 +19,7 @@
 int nh_asleep_remember(nh_context* ctx);            // nh_collide.hip (asleep steps: nh_internal.h)
 #include <type_traits>
 #include "nh_solver.h"
+#include "nh_narrowphase.h"          // (PAIR AHEAD: the still solver's lanes evaluate their bodies' own collider pairs for the next sub-step)
 
 #define NH_NONE 0xFFFFFFFFu
 // body classes: the one-body fast path by contact count (<= 4, <= 8, more) or the level-scheduled path
@@ -873,7 +874,9 @@ struct nh_StillView { const uint32_t* body_rec; const uint32_t* body_pos; const 
 
 // AHEAD (STILL, plain form; nh_internal.h: xform ahead): the lane that has advanced its body also does the NEXT step's k_xform<true> for the body's one collider -- world
 // transform, AABB, the test against the inflated box, scene bounds, largest idle counter -- with k_xform's own arithmetic (nh_collide.hip: k_xform, k_asleep_check).
-template<int MAXC, bool FUSED, bool CONTIG = false, int NW = 4, bool STILL = false, bool AHEAD = false>
+// PAIR (AHEAD only; nh_internal.h: pair ahead): ... and the next step's NARROWPHASE for the body's one kept pair, from what the lane holds in registers and the static
+// partner's transform, box and shape: contacts into the record's raw slots, count into its place in the tag order, a change of the count onto the next step's list.
+template<int MAXC, bool FUSED, bool CONTIG = false, int NW = 4, bool STILL = false, bool AHEAD = false, bool PAIR = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ? NH_SOLVER_WPE : 1, MAXC == 4 ? NH_SOLVER_WPE : 1))) void k_solve_one_body(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
                                                         const nh_BodyPair* __restrict__ bodies, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                         float4* __restrict__ states, uint32_t iterations,
@@ -908,6 +911,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 	// the rows have been built and delivered straight to LDS while the sweeps run: no register holds it, and the wave's contact slots (s_slot: nobody looks at them
 	// between the row build and the results) are where it lands
 	__shared__ uint32_t s_col[AHEAD ? NW : 1][AHEAD ? 64 : 1];
+	__shared__ uint32_t s_pk[PAIR ? NW : 1][PAIR ? 4 : 1][PAIR ? 64 : 1];          // PAIR: the body's kept pair (2 words) and the record's key on file (2), fetched with the first round of loads
 	uint32_t n_delta = 0;
 	if (STILL) {
 		// The first contact of every record in the dense list is kept from step to step (start_sorted); the records whose count changed this step are listed, and a lane
@@ -982,6 +986,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			still_base = still_rec < n_bb ? 4u * still_rec : 4u * n_bb + (still_rec - n_bb);       // (a record of a pair with a sphere owns ONE slot, behind the box-box records' four each)
 			const uint32_t bp = still_has ? bpos : 0u;
 			st_cnt = sv.cnt_sorted[bp]; st_start = sv.start_sorted[bp]; st_oc = sv.sc_count[still_rec];
+			if (PAIR) {
+				const uint2 kp = still_rec < n_bb ? av.kept[still_rec] : av.kept[av.kept_cap - 1u - (still_rec - n_bb)];
+				const uint64_t pk = av.rec_key[still_rec];
+				s_pk[wave][0][lane] = kp.x; s_pk[wave][1][lane] = kp.y; s_pk[wave][2][lane] = (uint32_t)pk; s_pk[wave][3][lane] = (uint32_t)(pk >> 32);
+			}
 #pragma unroll
 			for (int k = 0; k < M; ++k) { nf[k] = sv.raw_feature[still_base + k]; of[k] = sv.sc_feat[still_base + k]; }
 			s_first[wave][lane] = still_has ? still_base : 0xFFFFFFFFu;          // (where the wave-cooperative loads find this body's four slots)
@@ -1152,6 +1161,24 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			}
 		}
 		if (FUSED && !STILL && mine) hint[x] = first;          // where this body's contacts start in what becomes the next step's cache
+		// PAIR: the static partner of the body's one kept pair -- its world transform, box, shape and tag (this call's k_xform<true> wrote them; nothing moves it) -- asked
+		// for before the sweeps (nobody waits for it), used when the body's own collider has its new transform
+		nh_xform pp_x = nh_xform();
+		float4 pp_min = make_float4(0, 0, 0, 0), pp_max = pp_min, pp_shape = pp_min;
+		uint32_t pp_tag = 0, pp_own_tag = 0, pp_partner = 0xFFFFFFFFu, pp_bits = 0;          // pp_bits: 1 = evaluate, 2 = the pair is dead (stamps), 4 = the record is not a pair of the body's collider
+		if (PAIR && CONTIG && (fs.bits & 2u) && mine && still_has && s_col[wave][lane] != 0xFFFFFFFFu) {
+			const uint32_t ah_col = s_col[wave][lane];
+			const uint32_t kx = s_pk[wave][0][lane], ky = s_pk[wave][1][lane];
+			const uint32_t index_mask = av.gen ? NH_GEN_INDEX : 0xFFFFFFFFu;
+			const uint32_t ca = kx & index_mask, cb = ky & index_mask;
+			pp_partner = ca == ah_col ? cb : ca;
+			pp_bits = 1u | ((ca != ah_col && cb != ah_col) ? 4u : 0u);
+			if (av.gen && cv.st->moved_count != 0u && !((uint32_t)(av.gen[ca] & 0x7Fu) == (kx >> NH_GEN_SHIFT) && (uint32_t)(av.gen[cb] & 0x7Fu) == (ky >> NH_GEN_SHIFT))) pp_bits |= 2u;
+			pp_x = av.xf[pp_partner]; pp_min = av.aabb_min[pp_partner]; pp_max = av.aabb_max[pp_partner];
+			if (pp_partner < av.nbox) pp_shape = *reinterpret_cast<const float4*>(av.box_data + pp_partner);
+			else pp_shape.x = av.sph_data[pp_partner - av.nbox].radius;
+			pp_tag = av.ctag[pp_partner]; pp_own_tag = av.ctag[ah_col];
+		}
 		// (CONTIG: a body's role is one bit for all its contacts, and in most scenes the static world is always "a": when no lane of the wave
 		// has D = a the role selects drop out of the sweep)
 		float4* const s_ah = reinterpret_cast<float4*>(slot);          // AHEAD: piece k of lane l at s_ah[64 k + l]
@@ -1224,6 +1251,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		// the next step would have failed in its k_xform<true> (collider outside its inflated box; body asleep)
 		uint32_t nmin[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, nmax[3] = { 0u, 0u, 0u }, ntop = 0u;
 		bool nfail = false;
+		int pp_count = 0;
+		float pair_scale = 0.0f;
+		if (PAIR) {
+			__builtin_amdgcn_wave_barrier();          // (every lane of the wave has read where the results went)
+#pragma unroll
+			for (int k = 0; k < M; ++k) scid[lane * M + k] = 0xFFFFFFFFu;          // (where the next step's contacts go: nowhere, unless the lane says so below)
+			// the Morton scale of THIS step's scene frame (nudge.cpp:3096-3099): the yardstick of the role rule below
+			const nh_DevState* const sp = cv.st;
+			const nh_f3 smin = nh_make3(nh_float_unflip(sp->still_smin[sv.parity][0]), nh_float_unflip(sp->still_smin[sv.parity][1]), nh_float_unflip(sp->still_smin[sv.parity][2]));
+			const nh_f3 smax = nh_make3(nh_float_unflip(sp->still_smax[sv.parity][0]), nh_float_unflip(sp->still_smax[sv.parity][1]), nh_float_unflip(sp->still_smax[sv.parity][2]));
+			pair_scale = nh_morton_scale(smin, smax);
+			// more kept pairs that are nobody's than their list holds (k_pair_list): somebody would go unevaluated -- the next step is not this form's
+			if (sp->pair_unowned > av.unowned_cap) nfail = true;
+		}
 		if (advance_here) {
 			float pos[3] = { a0.x, a0.y, a0.z }, rot[4] = { a1.x, a1.y, a1.z, a1.w };
 			const float vel[3] = { v.vx, v.vy, v.vz }, ang[3] = { v.wx, v.wy, v.wz };
@@ -1262,6 +1303,110 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 					av.aabb_max[c] = make_float4(mxx, mxy, mxz, __uint_as_float(0u));          // (plain form: nobody asleep)
 					nfail |= !(mnx >= fmn.x && mny >= fmn.y && mnz >= fmn.z && mxx <= fmx.x && mxy <= fmx.y && mxz <= fmx.z);       // (NaN: out)
 					nmin[0] = nmax[0] = nh_float_flip(mnx); nmin[1] = nmax[1] = nh_float_flip(mny); nmin[2] = nmax[2] = nh_float_flip(mnz);
+					if (PAIR && (pp_bits & 1u)) {
+						// ---- the NEXT step's narrowphase for this body's pair (k_narrowphase<*, true, false>: exact boxes, stamps, roles, contact arithmetic, still_record) ----
+						const float4 omin = make_float4(mnx, mny, mnz, l0.w), omax = make_float4(mxx, mxy, mxz, 0.0f);
+						nh_xform OX; OX.px = p.x; OX.py = p.y; OX.pz = p.z; OX.body = __float_as_uint(l0.w); OX.qx = q.x; OX.qy = q.y; OX.qz = q.z; OX.qs = q.s;
+						const bool hit = nh_aabb_overlap(omin, omax, pp_min, pp_max) && __float_as_uint(pp_min.w) != OX.body && !(pp_bits & 2u);
+						// roles: "a" = the collider LATER in the Morton order of the AABB min corners in the next step's scene frame -- decided without that frame when one corner is
+						// <= the other in every coordinate and two cells of THIS step's frame less in one (k_pair_begin checks the next frame's cells against this one's)
+						const float ddx = mnx - pp_min.x, ddy = mny - pp_min.y, ddz = mnz - pp_min.z;
+						const float far = 2.0f;
+						const bool partner_first = ddx >= 0.0f && ddy >= 0.0f && ddz >= 0.0f && fmaxf(fmaxf(ddx, ddy), ddz) * pair_scale >= far;
+						const bool own_first = ddx <= 0.0f && ddy <= 0.0f && ddz <= 0.0f && fmaxf(fmaxf(-ddx, -ddy), -ddz) * pair_scale >= far;
+						bool pfail = (pp_bits & 4u) != 0u || (hit && !partner_first && !own_first) || __float_as_uint(pp_min.w) != 0u;          // (a partner that is not the static world: not this lane's to decide)
+						if (pfail) atomicAdd(&const_cast<nh_DevState*>(cv.st)->pair_diag[(hit && !partner_first && !own_first) ? 0 : 1], 1u);
+						uint64_t key = ~0ull;
+						uint32_t body_a = 0, body_b = 0;
+						nh_bb_result bb;
+						bb.kind = 0; bb.mask = 0;
+						nh_contact_out single;
+						single.px = single.py = single.pz = single.penetration = single.nx = single.ny = single.nz = 0.0f; single.friction = 0.5f; single.feature = 0u;
+						if (hit && !pfail) {
+							const bool a_is_own = partner_first;          // (the partner comes first in Morton order: the body's collider is the later one)
+							const nh_xform A = a_is_own ? OX : pp_x, B = a_is_own ? pp_x : OX;
+							const uint32_t ta = a_is_own ? pp_own_tag : pp_tag, tb = a_is_own ? pp_tag : pp_own_tag;
+							const bool own_sph = !is_box, par_sph = pp_partner >= av.nbox;
+							const bool a_sph = a_is_own ? own_sph : par_sph, b_sph = a_is_own ? par_sph : own_sph;
+							const float own_size[3] = { sz.x, sz.y, sz.z }, par_size[3] = { pp_shape.x, pp_shape.y, pp_shape.z };
+							const float ra = a_is_own ? sz.x : pp_shape.x, rb = a_is_own ? pp_shape.x : sz.x;          // (radii, where the collider is a sphere)
+							if (!a_sph && !b_sph) {
+								nh_box_box_eval(A, B, a_is_own ? own_size : par_size, a_is_own ? par_size : own_size, ta, tb, bb);
+								pp_count = nh_bb_count(bb);
+								key = (uint64_t)(bb.swapped ? tb : ta) | ((uint64_t)(bb.swapped ? ta : tb) << 32);
+								body_a = bb.swapped ? B.body : A.body; body_b = bb.swapped ? A.body : B.body;
+							} else if (a_sph && b_sph) {
+								// sphere-sphere: first = earlier in Morton order = pair.y (nudge.cpp:3775-3776)
+								pp_count = nh_sphere_sphere(rb, ra, B, A, &single);
+								key = (uint64_t)tb | ((uint64_t)ta << 32);
+								body_a = B.body; body_b = A.body;
+							} else {
+								// box-sphere: box is always "a" (nudge.cpp:3746-3751, 3759-3768)
+								const nh_xform BX = a_sph ? B : A, SP = a_sph ? A : B;
+								const bool box_is_own = a_sph ? !a_is_own : a_is_own;
+								pp_count = nh_box_sphere(box_is_own ? own_size : par_size, a_sph ? ra : rb, BX, SP, &single);
+								key = (uint64_t)(a_sph ? tb : ta) | ((uint64_t)(a_sph ? ta : tb) << 32);
+								body_a = BX.body; body_b = SP.body;
+							}
+						}
+						// what the next still step relies on, per record (still_record)
+						{
+							const uint64_t was_key = (uint64_t)s_pk[wave][2][lane] | ((uint64_t)s_pk[wave][3][lane] << 32);
+							const bool vanished = !hit;
+							const bool same_key = was_key == key || vanished;
+							bool ok = same_key && pp_count <= 4;
+							if (ok && pp_count) ok = (body_a == 0u) != (body_b == 0u);
+							if (!ok) { pfail = true; pp_count = 0; bb.kind = 0; atomicAdd(&const_cast<nh_DevState*>(cv.st)->pair_diag[1], 1u); }
+						}
+						nfail |= pfail;
+						// the contacts: staged in the wave's slots (free by now), written out by the wave below
+						if (pp_count) {
+							nh_ob_slot* const stage = slot + lane * M;
+							if (bb.kind == 2) {
+								int k = 0;
+#pragma unroll
+								for (int index = 0; index < 16; ++index) {
+									if (((bb.mask >> index) & 1u) && k < pp_count && k < M) {
+										nh_contact_out o;
+										nh_bb_contact(bb, index, bb.lx[index], bb.ly[index], bb.lz[index], bb.penetration[index], bb.tags[index], o);
+										stage[k].c0 = make_float4(o.px, o.py, o.pz, o.penetration); stage[k].c1 = make_float4(o.nx, o.ny, o.nz, o.friction); stage[k].w.x = __uint_as_float(o.feature);
+										scid[lane * M + k] = still_base + (uint32_t)k;
+										++k;
+									}
+								}
+							} else {
+								const nh_contact_out o = bb.kind == 1 ? bb.edge : single;
+								stage[0].c0 = make_float4(o.px, o.py, o.pz, o.penetration); stage[0].c1 = make_float4(o.nx, o.ny, o.nz, o.friction); stage[0].w.x = __uint_as_float(o.feature);
+								scid[lane * M] = still_base;
+							}
+						}
+						// the record's count, in the record and in its place of the tag order; a CHANGE goes onto the next step's list (k_narrowphase: still_record)
+						av.rec[still_rec].count = (uint32_t)pp_count;
+						if (st_cnt != (uint32_t)pp_count) {
+							nh_DevState* const stw = const_cast<nh_DevState*>(cv.st);
+							const uint32_t np2 = sv.parity ^ 1u;
+							av.cnt_sorted[bpos] = (uint32_t)pp_count;
+							if (!stw->delta_overflow[np2]) {
+								const uint32_t k = atomicAdd(&stw->delta_count[np2], 1u);
+								if (k < NH_DELTA_MAX) av.delta[np2 * NH_DELTA_MAX + k] = make_int2((int)bpos, pp_count - (int)st_cnt);
+								else { stw->delta_overflow[np2] = 1u; nfail = true; }          // (more changes than the list holds: the next step is not this form's)
+							}
+						}
+					}
+				}
+			}
+		}
+		if (PAIR) {
+			// the next step's contacts out to the records' raw slots, by the wave (consecutive lanes on consecutive slots wherever the records are consecutive)
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int k = 0; k < M; ++k) {
+				const uint32_t e = 64u * k + lane;
+				const uint32_t c = scid[e];
+				if (c != 0xFFFFFFFFu) {
+					float4* dp = reinterpret_cast<float4*>(av.raw_data + c);
+					dp[0] = slot[e].c0; dp[1] = slot[e].c1;
+					av.raw_feature[c] = __float_as_uint(slot[e].w.x);
 				}
 			}
 		}
@@ -2537,10 +2682,15 @@ static void blk_run(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyD
 
 // LOCAL speculation (nh_internal.h): every round trip -- a full step's, a still step's verdict -- tells whether somebody left its inflated box in that step; the
 // movers form of the still step stays on for 16 steps after the last one who did
-static void still_note_movers(nh_context* ctx, const nh_DevState* h) {
+static void still_note_movers(nh_context* ctx, const nh_DevState* h, uint32_t seq = 0u) {          // `seq`: the nh_collide the counters belong to (0: a full step's round trip)
 	nh_StillStep& ss = ctx->still;
 	// (a still step in sleepers form that found NOBODY awake: the next step is a full one -- two of those in a row start the asleep steps, which cost nothing)
 	if (ss.sleepers && h->active == 0u) ss.ok_next = false;
+#ifdef NH_DEBUG_PAIR
+	fprintf(stderr, "[pair] verdict: map_ok %d unowned %u records %u pairs %u+%u world_bad %d ok %d ready %d\n", (int)ss.ahead_map_ok, h->pair_unowned, h->records, h->pairs, h->pairs_sph, (int)ss.pair_world_bad, (int)ss.pair_world_ok, (int)ss.pair_ready);
+#endif
+	// (... counted by k_pair_owned in the nh_collide numbered pair_owned_seq: counters of an earlier step, or of a full step -- which voids the count -- say nothing)
+	if (ss.pair_owned_seq != 0u && seq >= ss.pair_owned_seq) { if (h->pair_unowned > ctx->pair_list_capacity) ss.pair_world_bad = true; else ss.pair_world_ok = true; }         // (pair ahead: some kept pair is nobody's -- k_pair_owned; the step that relied on it has failed itself)
 	if (h->ahead_multi) ss.ahead_world_bad = true;          // (xform ahead: some body carries several colliders -- k_ahead_check; the step that relied on the map has failed itself)
 	if (h->fat_inserts != ss.seen_inserts) ss.movers_left = 16u;
 	else if (ss.movers_left) ss.movers_left--;
@@ -2799,6 +2949,7 @@ static int settle_gravity(nh_context* ctx) {
 
 // `applied`: called by nh_apply_impulses itself (not by the flush of a setup nobody applied): with NH_FLAG_FUSED_STEP the caller has promised
 // that this is the step's only solver call, so the bodies of the fused kernel are advanced there too
+static inline bool cd_count_over(const nh_ColliderData& cd) { return (uint64_t)cd.boxes.count + cd.spheres.count >= (1ull << 31); }
 static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_BodyData* bodies, uint32_t iterations, bool applied = false) {
 	// the flush of a setup nobody applied yet keeps the solver states whatever the flags say: an nh_apply_impulses may still follow (nh_read_counts
 	// or nh_synchronize between setup and apply must not break the step)
@@ -2825,18 +2976,29 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 			// map -- the lanes do the next step's k_xform<true> on their way out
 			const bool ahead = ss.ahead_plain && ss.more_steps && ss.ahead_map_ok && !ss.no_ahead && !ss.ahead_world_bad && ctx->env_solver_waves != 4 && ctx->env_solver_waves != 2 &&
 			                   ctx->own_xf && ctx->body_col && ctx->body_col_capacity >= B;
+			// PAIR AHEAD (nh_internal.h): ... and the next sub-step's narrowphase for the body's own pair -- that sub-step then starts at the solver
+			const bool pair = ahead && !ss.fused && !ss.no_pair && !ss.pair_world_bad && ss.pair_owned_seq != 0u && ctx->pair_list && ctx->fat_pairs && ctx->own_ctag && !(cd_count_over(ss.colliders));
 			if (ss.fused) {
 				// ONE launch for the whole step (nh_fused.hip): pair evaluation, solver, advance and the next sub-step's transforms
 				int rc = nh_fused_launch(ctx, bodies, iterations, fs.guard_seq);
 				if (rc) return rc;
 			} else if (ahead) {
 				const nh_ColliderData& cd = ss.colliders;
-				nh_AheadView av = { ctx->body_col, cd.boxes.transforms, cd.boxes.data, cd.spheres.transforms, cd.spheres.data, cd.boxes.count, ctx->own_xf, ctx->own_aabb_min, ctx->own_aabb_max, ctx->fat_box };
+				const uint32_t C = cd.boxes.count + cd.spheres.count;
+				const uint8_t* gen = (C < (1u << NH_GEN_SHIFT) && !ctx->env_no_incremental) ? ctx->fat_gen : (const uint8_t*)nullptr;
+				nh_AheadView av = { ctx->body_col, cd.boxes.transforms, cd.boxes.data, cd.spheres.transforms, cd.spheres.data, cd.boxes.count, ctx->own_xf, ctx->own_aabb_min, ctx->own_aabb_max, ctx->fat_box,
+				                    ctx->fat_pairs, ctx->fat_pair_capacity, ctx->lay_capacity, ctx->sort_keys_by_position, ctx->own_ctag, gen,
+				                    ctx->rec, ctx->raw_data, ctx->raw_feature, ctx->cnt_sorted, ctx->still_delta, ctx->pair_list_capacity };
+				if (pair)
+				NH_LAUNCH(ctx, "solve_still", (k_solve_one_body<4, true, true, 1, true, true, true>), (B + 63u) / 64u, 64, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
+				          (float4*)d->states, iterations, ctx->raw_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fs, sv, av);
+				else
 				NH_LAUNCH(ctx, "solve_still", (k_solve_one_body<4, true, true, 1, true, true>), (B + 63u) / 64u, 64, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
 				          (float4*)d->states, iterations, ctx->raw_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fs, sv, av);
 			} else
 			if (ctx->env_solver_waves == 4) NH_SOLVE_STILL(4); else if (ctx->env_solver_waves == 2) NH_SOLVE_STILL(2); else NH_SOLVE_STILL(1);
 			ss.ahead_ready = ahead || ss.fused;
+			ss.pair_ready = pair && !ss.fused;
 			if (ss.pipelined && ss.h_ring[0]) {
 				// nh_step: first the verdict of the still step BEFORE this one (its counters landed long ago) ...
 				if (ss.verdict.pending) {
@@ -2848,7 +3010,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 					memcpy(ctx->h_state, h, NH_COUNTER_WORDS * sizeof(uint32_t));
 					if (!ctx->idle_unknown) { ctx->idle_bound = (int)h->max_idle[ss.verdict.parity]; ctx->idle_bound_mark = ss.verdict.collide_mark; }
 					ss.verdict.pending = false;
-					still_note_movers(ctx, h);
+					still_note_movers(ctx, h, ss.verdict.seq);
 				}
 				// ... then this step's counters on their way, to be looked at by the next step
 				const int slot = (int)(ctx->collide_seq & 1u);
@@ -2864,7 +3026,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 				if (ctx->timing) nh_timer_collect(ctx);
 				confirmed = ctx->h_state->still_failed_seq < ctx->collide_seq && ctx->h_state->error == 0u;
 				if (confirmed) ss.confirmed_seq = ctx->collide_seq;
-				if (confirmed) { nh_Counts c; nh_counts_from_mirror(ctx, &c); still_note_movers(ctx, ctx->h_state); }              // (the sleep prediction: largest idle counter this step saw)
+				if (confirmed) { nh_Counts c; nh_counts_from_mirror(ctx, &c); still_note_movers(ctx, ctx->h_state, ctx->collide_seq); }              // (the sleep prediction: largest idle counter this step saw)
 			}
 		}
 		if (confirmed) {
@@ -3265,7 +3427,7 @@ int nh_still_verdict_now(nh_context* ctx) {
 	if (ss.verdict_fused && ctx->fused.unconfirmed) ctx->fused.unconfirmed--;
 	memcpy(ctx->h_state, h, NH_COUNTER_WORDS * sizeof(uint32_t));
 	if (!ctx->idle_unknown) { ctx->idle_bound = (int)h->max_idle[ss.verdict.parity]; ctx->idle_bound_mark = ss.verdict.collide_mark; }
-	still_note_movers(ctx, h);
+	still_note_movers(ctx, h, ss.verdict.seq);
 	return 0;
 }
 

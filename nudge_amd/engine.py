@@ -31,7 +31,7 @@ NH_VIEW_CONTACTS, NH_VIEW_CACHE, NH_VIEW_ACTIVE, NH_VIEW_ALL = 1, 2, 4, 7
 # environment variables NH_<NAME> that World() forwards to nh_set_option (tests and dev scripts; include/nudge_hip.h lists what each does)
 OPTION_NAMES = ("no_still", "no_kept_pairs", "no_incremental", "no_sort_reuse", "sort_classic", "sort_radix", "bucket_tile", "bucket_target", "colour_jp",
                 "colour_check_seeds", "no_resident", "solver_waves", "fp_sub", "cooperative", "no_blocks", "blk_check", "blk_min", "blk_target", "blk_rows_global",
-                "blk_global_colours", "blk_profile", "no_asleep", "no_blk_chain", "no_local_still", "no_xform_ahead", "measure_skip_chains", "sync_exports_views", "fused_still", "fused_fail_in")
+                "blk_global_colours", "blk_profile", "no_asleep", "no_blk_chain", "no_local_still", "no_xform_ahead", "measure_skip_chains", "sync_exports_views", "fused_still", "fused_fail_in", "no_pair_ahead")
 
 EXPORTS = [
     "nh_create", "nh_destroy", "nh_set_flags", "nh_synchronize", "nh_read_counts", "nh_export_views", "nh_set_cache_count",
@@ -85,7 +85,7 @@ class Counts(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("colliders", "pairs", "contacts", "sleeping_pairs", "active_bodies", "cache", "culled",
                                           "large_colliders", "general_contacts", "levels", "error", "has_other_bodies", "unleveled", "raw_pairs", "broadphase_rebuilds", "sort_reuses", "broadphase_inserts",
                                           "still_steps", "still_replays", "still_diff_key", "still_diff_count", "still_diff_feature", "still_diff_escape",
-                                          "blk_blocks", "blk_bodies", "blk_ghosts", "asleep_steps", "ahead_steps", "fused_steps")]
+                                          "blk_blocks", "blk_bodies", "blk_ghosts", "asleep_steps", "ahead_steps", "fused_steps", "pair_steps", "pair_diag_roles", "pair_diag_record", "pair_diag_scale", "pair_diag_owned")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -645,6 +645,63 @@ def test_xform_ahead_in_a_world_of_spheres_on_one_slab():
     a.close(); b.close(); c.close()
 
 
+# ---- pair ahead (nudge_amd/csrc/nh_internal.h: nh_StillStep) -------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sphere_fraction", [0.0, 0.5])
+def test_pair_ahead_leaves_the_bits_of_steps_that_run_their_narrowphase(sphere_fraction):
+    """Inside one nh_step call the solver lane that has advanced a body and written its collider's new transform (xform ahead) also evaluates the body's one kept pair for
+    the NEXT sub-step: contacts into the record's raw slots, count into its place in the tag order, a change onto the next step's list.  That sub-step is the solver alone
+    behind a one-workgroup prologue.  Against the same library with the option off and against the one that never speculates, checkpoint by checkpoint: calls of every
+    length, rest, a hop and a shove (the lanes see the leaver: the next step fails before it starts), falling asleep; the views a caller exports at the end of a call are
+    the last step's (its contacts were written by the step before it)."""
+    scene = S.grid_tiles(2, side=36, sphere_fraction=sphere_fraction, seed=63, lattice_cols=2)
+    a, b, c = _world(scene, True), _world(scene, True, env=["NH_NO_PAIR_AHEAD"]), _world(scene, False)
+    done = 0
+    for cp in (90, 91, 93, 96, 100, 105, 111, 118, 126, 160, 161, 163, 200):
+        for w in (a, b, c):
+            w.step(cp - done)
+        done = cp
+        _same_world(a, b, f"step {cp} (pair ahead vs narrowphase launched)"); _same_world(a, c, f"step {cp} (pair ahead vs never speculating)")
+    c0 = a.counts()
+    assert c0["pair_steps"] >= 40, c0
+    assert b.counts()["pair_steps"] == 0 and b.counts()["ahead_steps"] >= 40
+    for w in (a, b, c):
+        m = w.get_bodies()["momentum"]
+        m["velocity"][7::89, 1] = 3.0
+        m["velocity"][13::101, 2] = 1.0
+        w.set_bodies(momentum=m)
+    for cp in (240, 300, 370, 460, 560):
+        for w in (a, b, c):
+            w.step(cp - done)
+        done = cp
+        _same_world(a, b, f"step {cp} (pair ahead vs narrowphase launched)"); _same_world(a, c, f"step {cp} (pair ahead vs never speculating)")
+    c1 = a.counts()
+    print(f"\n[pair ahead, spheres {sphere_fraction}] {c1['pair_steps']} pair of {c1['ahead_steps']} ahead of {c1['still_steps']} still steps; replays {c1['still_replays']} (narrowphase launched: {b.counts()['still_replays']})")
+    assert c1["error"] == 0 and c1["pair_steps"] > c0["pair_steps"], (c0, c1)
+    a.close(); b.close(); c.close()
+
+
+def test_pair_ahead_with_kept_pairs_that_are_nobodys():
+    """Boxes that start high above the slab land later than their neighbours: while one hovers inside its inflated box's reach of the ground, its kept pair has no contact
+    and is no body's contact-list record -- no solver lane evaluates it.  Such pairs are listed once per layout (k_pair_list) and evaluated by the step's prologue
+    (k_pair_begin) the way the narrowphase did; the step in which one of them yields a contact fails and is run in full: the landing is seen, bit for bit."""
+    scene = S.grid_tiles(1, side=28, seed=65)
+    high = np.arange(1, len(scene["body_transforms"]))[5::37]
+    scene["body_transforms"]["position"][high, 1] += 14.0
+    for k in ("box_transforms",):
+        pass
+    a, b, c = _world(scene, True), _world(scene, True, env=["NH_NO_PAIR_AHEAD"]), _world(scene, False)
+    done = 0
+    for cp in (60, 90, 120, 150, 200, 260, 320):
+        for w in (a, b, c):
+            w.step(cp - done)
+        done = cp
+        _same_world(a, b, f"step {cp} (pair ahead vs narrowphase launched)"); _same_world(a, c, f"step {cp} (pair ahead vs never speculating)")
+    ca, cb = a.counts(), b.counts()
+    print(f"\n[pair ahead, late landers] pair {ca['pair_steps']} of {ca['ahead_steps']} ahead of {ca['still_steps']} still; replays {ca['still_replays']} / {cb['still_replays']}")
+    assert ca["error"] == 0 and ca["still_replays"] <= cb["still_replays"] + 8, (ca, cb)
+    a.close(); b.close(); c.close()
+
+
 # ---- the one-kernel still step with a look-back (nudge_amd/csrc/nh_fused.hip; option "fused_still", off by default: bit-exact but measured slower, DESIGN 5.3) -------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("sphere_fraction", [0.0, 0.5])
 def test_fused_still_steps_leave_the_bits_of_the_two_kernel_form(sphere_fraction):
