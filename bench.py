@@ -539,6 +539,8 @@ def main():
         # under a time-out and agreed on by all ranks -- any doubt keeps the torch.distributed point-to-point transport (NUDGE_BENCH_RCCL_DIRECT=0 forces that)
         if backend == "nccl" and os.environ.get("NUDGE_BENCH_RCCL_DIRECT", "1") != "0":
             cluster.use_rccl_direct(device_index, loopback=loopback)
+        # (the sub-steps between two refreshes in ONE library call -- nh_partition_step -- whenever the transport is the library's; NUDGE_BENCH_MULTI_STEP=0: one call per sub-step, round 5's way)
+        cluster.multi_step = os.environ.get("NUDGE_BENCH_MULTI_STEP", "1") != "0"
     else:
         w = E.World(scene, device=device_index, flags=E.NH_FLAG_SINGLE_APPLY | E.NH_FLAG_FUSED_STEP, max_contacts=max(4096, (6 if args.scene != "pit" else 5) * nb),
                     max_pairs=None if args.scene != "pit" else 7 * nb)
@@ -911,7 +913,7 @@ def main():
                                 "halo_enqueue_us_per_step": (1e6 * e[3] / e[4]) if e[4] else None} for r, e in enumerate(per_rank)]
         if cluster is not None:
             st = cluster.p.stats
-            out["halo"] = {"backend": backend, "per_step_transport": ("library-driven RCCL (nh_partition_exchange_step)" if cluster.direct else f"torch.distributed point-to-point ({cluster.direct_why or 'not asked'})"), "loopback_records_per_step": (cluster.loopback_records / max(1, getattr(cluster, "loopback_steps", 0))) if loopback else None,
+            out["halo"] = {"backend": backend, "per_step_transport": (("library-driven RCCL inside nh_partition_step (all sub-steps between two refreshes in one call)" if cluster.multi_step else "library-driven RCCL (nh_partition_exchange_step), one call per sub-step") if cluster.direct else f"torch.distributed point-to-point ({cluster.direct_why or 'not asked'})"), "loopback_records_per_step": (cluster.loopback_records / max(1, getattr(cluster, "loopback_steps", 0))) if loopback else None,
                            "ghost_bodies_rank0": st["ghosts"], "refreshes": st["refreshes"], "migrated_out_rank0": st["migrated_out"],
                            # (bytes and steps over the same window: every step this partition ever took -- `p.steps` is the epoch clock the timed blocks rewind)
                            "bytes_sent_per_step_rank0": st["step_bytes"] / max(1, st["steps_total"]),

@@ -417,6 +417,13 @@ int nh_partition_unpack_step(nh_partition* p, const nh_BodyData* bodies, const v
    An RCCL call that fails makes the exchange return NH_ERR_HIP with the group closed; nh_last_hip_error then holds the ncclResult_t, negated.) */
 int nh_partition_set_transport(nh_partition* p, void* comm, void* group_start, void* group_end, void* send, void* recv, int left_peer, int right_peer);
 int nh_partition_exchange_step(nh_partition* p, const nh_BodyData* bodies);
+/* K sub-steps of a slab in ONE call (the loop example/main.cpp:274-328 runs for a partitioned world: halo exchange, then the eight calls, K times): nh_step with the per-step
+   exchange enqueued by the library between two sub-steps over the transport of nh_partition_set_transport (needed as soon as there is a ghost on either side).  The
+   chain of still steps (note 9: xform ahead, pair ahead) runs through such a call for the OWNED bodies; ghosts' colliders are transformed and their pairs evaluated when
+   the halo has arrived.  `exchange_first`: the first sub-step is preceded by a per-step exchange too (0 right after a refresh, which has just installed the ghosts).
+   `loopback_records` (rehearsal on one rank): that many owned bodies' records also travel through the transport to this same rank every sub-step.  K must not reach past
+   the next refresh: migration and ghost lists are the host's (nh_partition_pack_migrants ...). */
+int nh_partition_step(nh_partition* p, const nh_StepArgs* args, uint32_t steps, uint32_t exchange_first, uint32_t loopback_records);
 int nh_partition_transport_check(nh_partition* p, uint32_t bytes, int enqueue_only);
 int nh_partition_transport_result(nh_partition* p);
 /* Re-balancing ("move cuts when |count_r - mean| > 5 %").  The two ranks at a cut tell each other how many bodies they own (transport: caller); when the

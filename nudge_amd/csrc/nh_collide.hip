@@ -1328,6 +1328,7 @@ __global__ __launch_bounds__(256) void k_ahead_check(nh_DevState* __restrict__ s
 // PAIR AHEAD (nh_internal.h: nh_StillStep).  Once per layout: which kept pairs are NO body's contact-list record -- two neighbours whose inflated boxes overlap, a body
 // hovering above ground it does not touch yet.  k_pair_mark stamps every record that is some body's own; k_pair_list lists the others (st->pair_unowned, cleared by
 // k_ahead_map).  The solver lanes evaluate their bodies' own pairs for the next step; k_pair_begin evaluates the listed ones.
+// (`nbodies`: in a partitioned world stepped through nh_partition_step only the OWNED bodies -- a ghost's lane does not evaluate its pair, the ghost arrives anew every step)
 __global__ __launch_bounds__(256) void k_pair_mark(const uint32_t* __restrict__ body_rec, uint32_t nbodies, uint32_t* __restrict__ mark, uint32_t stamp) {
 	for (uint32_t x = blockIdx.x * blockDim.x + threadIdx.x + 1u; x < nbodies; x += gridDim.x * blockDim.x) {
 		const uint32_t br = body_rec[x];
@@ -1353,7 +1354,9 @@ __global__ __launch_bounds__(256) void k_pair_begin(nh_DevState* __restrict__ st
                                                     const uint2* __restrict__ kept, uint32_t kept_cap, uint32_t pair_cap, const uint8_t* __restrict__ gen,
                                                     const nh_xform* __restrict__ xf, const float4* __restrict__ aabb_min, const float4* __restrict__ aabb_max, const uint32_t* __restrict__ ctag,
                                                     const nh_BoxCollider* __restrict__ box_data, const nh_SphereCollider* __restrict__ sph_data, uint32_t nbox,
-                                                    const uint64_t* __restrict__ rec_key, nh_Record* __restrict__ rec) {
+                                                    const uint64_t* __restrict__ rec_key, nh_Record* __restrict__ rec,
+                                                    const uint32_t* __restrict__ lay_rank, uint32_t* __restrict__ cnt_sorted, const uint32_t* __restrict__ body_rec, int2* __restrict__ delta,
+                                                    nh_Contact* __restrict__ raw_data, uint32_t* __restrict__ raw_feature) {
 	const uint32_t lane = nh_lane();
 	uint32_t fr_min[3], fr_max[3], fr_top;
 	{
@@ -1404,6 +1407,11 @@ __global__ __launch_bounds__(256) void k_pair_begin(nh_DevState* __restrict__ st
 		if (stamps && hit) hit = (uint32_t)(gen[ca] & 0x7Fu) == (kp.x >> NH_GEN_SHIFT) && (uint32_t)(gen[cb] & 0x7Fu) == (kp.y >> NH_GEN_SHIFT);
 		int count = 0;
 		uint64_t key = ~0ull;
+		uint32_t body_a = 0, body_b = 0;
+		nh_bb_result bb;
+		bb.kind = 0; bb.mask = 0;
+		nh_contact_out single;
+		single.px = single.py = single.pz = single.penetration = single.nx = single.ny = single.nz = 0.0f; single.friction = 0.5f; single.feature = 0u;
 		if (hit) {
 			const uint64_t ka = nh_morton_of(nh_make3(amin.x, amin.y, amin.z), mscale, mmin), kb = nh_morton_of(nh_make3(bmin.x, bmin.y, bmin.z), mscale, mmin);
 			const bool a_first = (ka < kb) || (ka == kb && ca < cb);
@@ -1413,28 +1421,65 @@ __global__ __launch_bounds__(256) void k_pair_begin(nh_DevState* __restrict__ st
 			const bool a_sph = a >= nbox, b_sph = b >= nbox;
 			if (!a_sph && !b_sph) {
 				const nh_BoxCollider sa = box_data[a], sb = box_data[b];
-				nh_bb_result bb;
-				bb.kind = 0; bb.mask = 0;
 				nh_box_box_eval(A, B, sa.size, sb.size, ta, tb, bb);
 				count = nh_bb_count(bb);
 				key = (uint64_t)(bb.swapped ? tb : ta) | ((uint64_t)(bb.swapped ? ta : tb) << 32);
+				body_a = bb.swapped ? B.body : A.body; body_b = bb.swapped ? A.body : B.body;
 			} else if (a_sph && b_sph) {
-				nh_contact_out single;
 				count = nh_sphere_sphere(sph_data[b - nbox].radius, sph_data[a - nbox].radius, B, A, &single);
 				key = (uint64_t)tb | ((uint64_t)ta << 32);
+				body_a = B.body; body_b = A.body;
 			} else {
-				nh_contact_out single;
 				const uint32_t bx = a_sph ? b : a, sp = a_sph ? a : b;
 				const nh_BoxCollider sz = box_data[bx];
-				count = nh_box_sphere(sz.size, sph_data[sp - nbox].radius, a_sph ? B : A, a_sph ? A : B, &single);
+				const nh_xform BX = a_sph ? B : A, SP = a_sph ? A : B;
+				count = nh_box_sphere(sz.size, sph_data[sp - nbox].radius, BX, SP, &single);
 				key = (uint64_t)(a_sph ? tb : ta) | ((uint64_t)(a_sph ? ta : tb) << 32);
+				body_a = BX.body; body_b = SP.body;
 			}
 		}
-		// (still_record for a record no lane owns: the same key -- or the pair gone -- and no contact; its count on file is 0 and stays 0)
+		// still_record (k_narrowphase): the key on file -- or the pair gone --, at most four contacts, and a pair WITH contacts joins a dynamic body to the static world and
+		// is that body's own record (a ghost's, in a partitioned world: its lane solves it, this launch evaluates it)
 		const uint64_t was_key = rec_key[r];
-		const bool ok = (was_key == key || !hit) && count == 0;
-		if (!ok) { changed = true; atomicAdd(&st->still_diff[was_key != key && hit ? 0 : 2], 1u); }
-		rec[r].count = 0u;
+		const uint32_t pos = lay_rank[r];
+		bool ok = (was_key == key || !hit) && count <= 4;
+		if (ok && count) {
+			const uint32_t dyn = body_a ? body_a : body_b;
+			ok = (body_a == 0u) != (body_b == 0u) && (body_rec[dyn] & ~NH_BODY_REC_IS_A) == r;
+		}
+		if (!ok) { changed = true; atomicAdd(&st->still_diff[(was_key != key && hit) ? 0 : (count > 4 ? 1 : 2)], 1u); count = 0; }
+		else if (count) {
+			const size_t base = r < n_bb ? (size_t)4 * r : (size_t)4 * n_bb + (r - n_bb);
+			if (bb.kind == 2) {
+				int k = 0;
+#pragma unroll
+				for (int index = 0; index < 16; ++index) {
+					if (((bb.mask >> index) & 1u) && k < count) {
+						nh_contact_out o;
+						nh_bb_contact(bb, index, bb.lx[index], bb.ly[index], bb.lz[index], bb.penetration[index], bb.tags[index], o);
+						float4* dp = reinterpret_cast<float4*>(raw_data + base + k);
+						dp[0] = make_float4(o.px, o.py, o.pz, o.penetration); dp[1] = make_float4(o.nx, o.ny, o.nz, o.friction);
+						raw_feature[base + k] = o.feature;
+						++k;
+					}
+				}
+			} else {
+				const nh_contact_out o = bb.kind == 1 ? bb.edge : single;
+				float4* dp = reinterpret_cast<float4*>(raw_data + base);
+				dp[0] = make_float4(o.px, o.py, o.pz, o.penetration); dp[1] = make_float4(o.nx, o.ny, o.nz, o.friction);
+				raw_feature[base] = o.feature;
+			}
+		}
+		rec[r].count = (uint32_t)count;
+		const uint32_t old = cnt_sorted[pos];
+		if (old != (uint32_t)count) {
+			cnt_sorted[pos] = (uint32_t)count;
+			if (!st->delta_overflow[parity]) {
+				const uint32_t k = atomicAdd(&st->delta_count[parity], 1u);
+				if (k < NH_DELTA_MAX) delta[parity * NH_DELTA_MAX + k] = make_int2((int)pos, count - (int)old);
+				else { st->delta_overflow[parity] = 1u; changed = true; }
+			}
+		}
 	}
 	if (__ballot(changed) != 0ull && lane == 0) atomicMax(&st->still_failed_seq, seq);
 }
@@ -2171,7 +2216,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 				if (ss.pair_owned_seq == 0u && !ss.no_pair && ctx->pair_mark) {
 					// (pair ahead: the kept pairs that are no body's own, listed once per layout)
 					NH_HIP_CHECK(ctx, hipMemsetAsync(&st->pair_unowned, 0, sizeof(uint32_t), ctx->stream));
-					NH_LAUNCH(ctx, "pair_mark", k_pair_mark, nh_grid_for(B, 256, 2048), 256, ctx->body_rec, B, ctx->pair_mark, ctx->collide_seq);
+					NH_LAUNCH(ctx, "pair_mark", k_pair_mark, nh_grid_for(B, 256, 2048), 256, ctx->body_rec, (ctx->halo_ghost_first && ctx->halo_ghost_first < B) ? ctx->halo_ghost_first : B, ctx->pair_mark, ctx->collide_seq);
 					NH_LAUNCH(ctx, "pair_list", k_pair_list, nh_grid_for(pair_cap, 256, 2048), 256, st, ctx->pair_mark, ctx->collide_seq, ctx->pair_list, ctx->pair_list_capacity);
 					ss.pair_owned_seq = ctx->collide_seq;
 				}
@@ -2195,7 +2240,8 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr, \
 				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, (uint32_t*)nullptr, ahead_step ? 1u : 0u); } while (0)
 			if (pair_step) NH_LAUNCH(ctx, "pair_begin", k_pair_begin, 32, 256, st, ctx->step_parity, ctx->collide_seq, ctx->pair_list, ctx->pair_list_capacity, ctx->fat_pairs, ctx->fat_pair_capacity, pair_cap, gen,
-			                         xf, aabb_min, aabb_max, ctag, colliders->boxes.data, colliders->spheres.data, nbox, ctx->sort_keys_by_position, rec);
+			                         xf, aabb_min, aabb_max, ctag, colliders->boxes.data, colliders->spheres.data, nbox, ctx->sort_keys_by_position, rec,
+			                         ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->still_delta, raw_data, raw_feature);
 			else if (!fused) {
 			if (nbox >= 2) NH_NARROW_STILL(false, "narrowphase_still", 4096);
 			if (nsph) NH_NARROW_STILL(true, "narrowphase_sph_still", 8192);

@@ -62,6 +62,7 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	ctx->lay_class = nullptr; ctx->lay_simple = nullptr; ctx->body_rec = nullptr; ctx->body_pos = nullptr; ctx->lay_body_capacity = 0;
 	memset(&ctx->still, 0, sizeof(ctx->still));
 	memset(&ctx->fused, 0, sizeof(ctx->fused));
+	ctx->step_hook = nullptr; ctx->step_hook_user = nullptr; ctx->halo_ghost_first = 0u;
 	ctx->first_ghost = 0;
 	memset(&ctx->asleep, 0, sizeof(ctx->asleep));
 	memset(&ctx->stream_state, 0, sizeof(ctx->stream_state)); ctx->stream_state.last_slot = -1;

@@ -161,7 +161,9 @@ struct nh_AheadView { const uint32_t* body_col; const nh_Transform* box_xf; cons
                       // tags -- and where the result goes: the record's raw contact slots, its count in the tag order, the next step's list of count changes
                       const uint2* kept; uint32_t kept_cap, pair_cap; const uint64_t* rec_key; const uint32_t* ctag; const uint8_t* gen;
                       struct nh_Record* rec; nh_Contact* raw_data; uint32_t* raw_feature; uint32_t* cnt_sorted; int2* delta; uint32_t unowned_cap; };
-struct nh_FusedStep { float gx_dt, gy_dt, gz_dt, damping, time_step; uint32_t bits; uint8_t* idle; uint32_t seq, guard_seq; };      // (still steps: this step's sequence number; the
+struct nh_FusedStep { float gx_dt, gy_dt, gz_dt, damping, time_step; uint32_t bits; uint8_t* idle; uint32_t seq, guard_seq;
+                      uint32_t ghost_first; };      // (nh_partition_step: bodies from here on are ghosts -- their lanes solve and advance them but leave the next step's transforms and pairs alone: the ghost arrives anew)
+//      // (still steps: this step's sequence number; the
                                                                                                                                     // oldest still step whose verdict the host has not seen)
 
 // library-owned buffers of the spatially blocked solver (nh_blocks.h), grown on demand
@@ -447,6 +449,9 @@ struct nh_context {
 	uint8_t* lay_class; uint2* lay_simple; uint32_t* body_rec; uint32_t* body_pos; uint32_t lay_body_capacity;
 	nh_StillStep still;
 	nh_FusedState fused;
+	// nh_partition_step (nh_partition.hip): K sub-steps of a slab in one nh_step call -- before every sub-step's nh_collide the library calls the hook, which enqueues the
+	// per-step halo exchange (and, for a step that starts further down the chain, the ghosts' transforms); halo_ghost_first: the first ghost body while such a call runs
+	int (*step_hook)(nh_context* ctx, void* user, uint32_t sub_step); void* step_hook_user; uint32_t halo_ghost_first;
 	nh_AsleepState asleep;
 	uint32_t first_ghost;          // nh_set_first_ghost_body: bodies >= first_ghost are ghosts of a partitioned world (0 = no ownership rule)
 	nh_StateStream stream_state;

@@ -6,6 +6,7 @@
 // Order of things in a rank's arrays: body 0 (static world) | owned bodies, slots 1 .. n_owned | ghosts from the left neighbour | ghosts from the right one;
 // colliders: the static ones the rank keeps | one per dynamic body, in slot order (boxes and spheres each in their own array).
 #include "nh_internal.h"
+#include "nh_math.h"
 #include <math.h>
 #include <string.h>
 
@@ -53,6 +54,9 @@ struct nh_partition {
 	// ... and WHICH ghost set that mark belongs to: nh_partition_unpack_ghosts starts a new generation, the mark adopts it, nh_partition_pack_deltas insists on it
 	// (a refresh that changes the ghost set without outgrowing the buffer used to pass the capacity test and pack deltas against other bodies' references)
 	uint64_t ghost_generation, ghost_ref_generation;
+	// nh_partition_step: the arrays of the call in progress (the hook needs them), whether its first sub-step is preceded by a per-step exchange, loop-back records (one-rank rehearsal)
+	const nh_StepArgs* step_args; uint32_t step_exchange_first, step_loopback;
+	void* loop_out; void* loop_in; uint32_t* loop_idx; uint32_t loop_cap;
 };
 
 #define NP_CHECK(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (ctx)->last_hip_error = (int)e_; return NH_ERR_HIP; } } while (0)
@@ -307,7 +311,8 @@ extern "C" void nh_partition_destroy(nh_partition* p) {
 	hipSetDevice(p->ctx->device);
 	hipStreamSynchronize(p->ctx->stream);
 	for (int side = 0; side < 2; ++side) { if (p->step_out[side]) hipFree(p->step_out[side]); if (p->step_in[side]) hipFree(p->step_in[side]); }
-	void* bufs[] = { p->shape, p->cxf, p->tag, p->nbx, p->nsp, p->reach, p->list[0], p->list[1], p->flag[0], p->flag[1], p->scan_tmp, p->sort_a, p->sort_b, p->sort_va, p->sort_vb, p->sort_hist, p->stage, p->d, p->ghost_ref };
+	void* bufs[] = { p->shape, p->cxf, p->tag, p->nbx, p->nsp, p->reach, p->list[0], p->list[1], p->flag[0], p->flag[1], p->scan_tmp, p->sort_a, p->sort_b, p->sort_va, p->sort_vb, p->sort_hist, p->stage, p->d, p->ghost_ref,
+	                 p->loop_out, p->loop_in, p->loop_idx };
 	for (void* b : bufs) if (b) hipFree(b);
 	if (p->h) hipHostFree(p->h);
 	delete p;
@@ -700,6 +705,136 @@ extern "C" int nh_partition_exchange_step(nh_partition* p, const nh_BodyData* bo
 	{ const int end_rc = p->rccl.group_end(); if (!nccl_rc) nccl_rc = end_rc; }
 	if (nccl_rc) { ctx->last_hip_error = -nccl_rc; return NH_ERR_HIP; }
 	return nh_partition_unpack_step(p, bodies, p->step_in[0], p->step_in[1]);
+}
+
+// ---- nh_partition_step: K sub-steps of a slab in ONE library call (round 6) ---------------------------------------------------------------------
+// The sample's loop (example/main.cpp:274-328) for a partitioned world: before every sub-step the ghosts take their owners' state (nh_partition_exchange_step), then the
+// eight calls.  Driven from the host one sub-step at a time the world never got past the first link of the chain of still steps: every step launched k_xform<true> and
+// its narrowphase.  Inside one nh_step call -- the exchange enqueued by the library between two sub-steps, through the hook below -- a step's solver lanes do the next
+// step's transforms and pairs for the OWNED bodies (xform ahead, pair ahead).  GHOSTS are different: what a rank computes for a ghost is not what its owner computes
+// (the order in which a body's contacts are solved depends on the contact's index in the RANK's dense list, nudge.cpp:4206-4339), and the owner's state is what
+// arrives.  So a ghost's lane leaves the next step alone (nh_FusedStep::ghost_first); when the halo has been unpacked k_xform_ghosts does k_xform<true>'s work for the
+// ghosts' colliders -- world transform, box, the test against the inflated box, scene bounds, idle counters -- and the records whose body is a ghost are on the list
+// k_pair_begin evaluates (k_pair_mark marks owned bodies' records only).  Verdicts are looked at inside every step: what goes out to a neighbour is a step that happened.
+__global__ __launch_bounds__(256) void k_xform_ghosts(nh_DevState* __restrict__ st, uint32_t first, uint32_t nbodies, const nh_Transform* __restrict__ body_xf, const uint8_t* __restrict__ idle,
+                                                      const uint8_t* __restrict__ nbx, const uint8_t* __restrict__ nsp, const uint32_t* __restrict__ s0, const uint32_t* __restrict__ s1,
+                                                      uint32_t n_static_box, uint32_t n_static_sph, uint32_t nbox,
+                                                      const nh_Transform* __restrict__ box_xf, const nh_BoxCollider* __restrict__ box_data, const nh_Transform* __restrict__ sph_xf, const nh_SphereCollider* __restrict__ sph_data,
+                                                      float4* __restrict__ xf, float4* __restrict__ aabb_min, float4* __restrict__ aabb_max, const float4* __restrict__ fat_box,
+                                                      uint32_t parity_next, uint32_t seq_next) {
+	uint32_t lmin[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, lmax[3] = { 0u, 0u, 0u }, top = 0u;
+	bool fail = false;
+	for (uint32_t b = first + blockIdx.x * blockDim.x + threadIdx.x; b < nbodies; b += gridDim.x * blockDim.x) {
+		const uint32_t cnt = idle[b];
+		top = max(top, cnt); fail |= cnt == 0xffu;
+		const nh_Transform bt = body_xf[b];
+		const nh_quat bq = { bt.rotation[0], bt.rotation[1], bt.rotation[2], bt.rotation[3] };
+		const uint32_t nb = nbx[b], ns = nsp[b];
+		for (uint32_t k = 0; k < nb + ns; ++k) {
+			const bool is_box = k < nb;
+			const uint32_t c = is_box ? n_static_box + s0[b] + k : nbox + n_static_sph + s1[b] + (k - nb);
+			const nh_Transform l = is_box ? box_xf[c] : sph_xf[c - nbox];
+			// Transform * Transform (nudge.cpp:1165-1175), |R| * size (3027-3037): k_xform's lines
+			const nh_quat lq = { l.rotation[0], l.rotation[1], l.rotation[2], l.rotation[3] };
+			const nh_f3 p = nh_rotate(bq, nh_make3(l.position[0], l.position[1], l.position[2])) + nh_make3(bt.position[0], bt.position[1], bt.position[2]);
+			const nh_quat q = nh_qmul(bq, lq);
+			float sx, sy, sz;
+			if (is_box) {
+				const nh_m33 m = nh_matrix(q);
+				const nh_BoxCollider bc = box_data[c];
+				const nh_f3 c0 = m.c0 * bc.size[0], c1 = m.c1 * bc.size[1], c2 = m.c2 * bc.size[2];
+				sx = fabsf(c0.x) + fabsf(c1.x) + fabsf(c2.x);
+				sy = fabsf(c0.y) + fabsf(c1.y) + fabsf(c2.y);
+				sz = fabsf(c0.z) + fabsf(c1.z) + fabsf(c2.z);
+			} else {
+				sx = sy = sz = sph_data[c - nbox].radius;
+			}
+			const float mnx = p.x - sx, mny = p.y - sy, mnz = p.z - sz, mxx = p.x + sx, mxy = p.y + sy, mxz = p.z + sz;
+			xf[2u * (size_t)c] = make_float4(p.x, p.y, p.z, __uint_as_float(l.body));
+			xf[2u * (size_t)c + 1u] = make_float4(q.x, q.y, q.z, q.s);
+			aabb_min[c] = make_float4(mnx, mny, mnz, __uint_as_float(l.body));
+			aabb_max[c] = make_float4(mxx, mxy, mxz, __uint_as_float(0u));
+			const float4 fmn = fat_box[2u * (size_t)c], fmx = fat_box[2u * (size_t)c + 1u];
+			fail |= !(mnx >= fmn.x && mny >= fmn.y && mnz >= fmn.z && mxx <= fmx.x && mxy <= fmx.y && mxz <= fmx.z);       // (NaN: out)
+			uint32_t f;
+			f = nh_float_flip(mnx); lmin[0] = min(lmin[0], f); lmax[0] = max(lmax[0], f);
+			f = nh_float_flip(mny); lmin[1] = min(lmin[1], f); lmax[1] = max(lmax[1], f);
+			f = nh_float_flip(mnz); lmin[2] = min(lmin[2], f); lmax[2] = max(lmax[2], f);
+		}
+	}
+	for (int k = 0; k < 3; ++k)
+		for (int d = 32; d >= 1; d >>= 1) { lmin[k] = min(lmin[k], (uint32_t)__shfl_xor((int)lmin[k], d)); lmax[k] = max(lmax[k], (uint32_t)__shfl_xor((int)lmax[k], d)); }
+	for (int d = 32; d >= 1; d >>= 1) top = max(top, (uint32_t)__shfl_xor((int)top, d));
+	const unsigned long long bad = __ballot(fail);
+	if (nh_lane() == 0) {
+		// (into the places the solver lanes gather in: the step's first launch puts them together -- nh_solve.hip, AHEAD)
+		uint32_t* const part = &st->ahead_part[parity_next][(blockIdx.x * 4u + (threadIdx.x >> 6)) & (NH_AHEAD_PARTS - 1u)][0];
+		for (int k = 0; k < 3; ++k) { if (lmin[k] != 0xffffffffu) atomicMin(&part[k], lmin[k]); if (lmax[k]) atomicMax(&part[3 + k], lmax[k]); }
+		if (top) atomicMax(&part[6], top);
+		if (bad) atomicMax(&st->ahead_failed_seq, seq_next);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_part_iota(uint32_t* idx, uint32_t n) { for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) idx[i] = i + 1u; }
+
+static int part_step_hook(nh_context* ctx, void* user, uint32_t sub_step) {
+	nh_partition* p = static_cast<nh_partition*>(user);
+	const nh_BodyData* bodies = p->step_args->bodies;
+	const nh_ColliderData* cd = p->step_args->colliders;
+	// what the step before this one left for it (xform ahead): known BEFORE the exchange's entry points run -- they complete deferred work and look like a caller from outside
+	const bool ahead = ctx->still.ahead_ready, pair = ctx->still.pair_ready;
+	if (sub_step > 0u || p->step_exchange_first) {
+		if (p->ghost_out[0] | p->ghost_out[1] | p->ghost_in[0] | p->ghost_in[1]) { int rc = nh_partition_exchange_step(p, bodies); if (rc) return rc; }
+		if (p->step_loopback && p->rccl.comm) {
+			// one-rank rehearsal: the first `step_loopback` owned bodies' records through the transport to this same rank and back onto themselves (the same bits)
+			const uint32_t m = p->step_loopback < p->n_owned ? p->step_loopback : p->n_owned;
+			if (p->loop_cap < m) {
+				if (p->loop_out) { NP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(p->loop_out); (void)hipFree(p->loop_in); (void)hipFree(p->loop_idx); }
+				p->loop_out = p->loop_in = nullptr; p->loop_idx = nullptr; p->loop_cap = 0;
+				NP_CHECK(ctx, hipMalloc(&p->loop_out, (size_t)m * NH_HALO_RECORD_BYTES)); NP_CHECK(ctx, hipMalloc(&p->loop_in, (size_t)m * NH_HALO_RECORD_BYTES));
+				NP_CHECK(ctx, hipMalloc((void**)&p->loop_idx, sizeof(uint32_t) * (size_t)m));
+				hipLaunchKernelGGL(k_part_iota, dim3(nh_grid_for(m, 256, 256)), dim3(256), 0, ctx->stream, p->loop_idx, m);
+				p->loop_cap = m;
+			}
+			{ int rc = nh_halo_pack(ctx, bodies, p->loop_idx, m, p->loop_out); if (rc) return rc; }
+			int nccl_rc = p->rccl.group_start();
+			if (nccl_rc) { ctx->last_hip_error = -nccl_rc; return NH_ERR_HIP; }
+			const int self_peer = p->rccl.peer[1] >= 0 ? p->rccl.peer[1] : (int)p->cfg.rank;          // (the rehearsal's "right neighbour" is this rank itself: RcclDirect.attach(loopback))
+			nccl_rc = p->rccl.send(p->loop_out, (size_t)m * NH_HALO_RECORD_BYTES, 1, self_peer, p->rccl.comm, ctx->stream);
+			if (!nccl_rc) nccl_rc = p->rccl.recv(p->loop_in, (size_t)m * NH_HALO_RECORD_BYTES, 1, self_peer, p->rccl.comm, ctx->stream);
+			{ const int end_rc = p->rccl.group_end(); if (!nccl_rc) nccl_rc = end_rc; }
+			if (nccl_rc) { ctx->last_hip_error = -nccl_rc; return NH_ERR_HIP; }
+			{ int rc = nh_halo_update(ctx, bodies, 1u, m, p->loop_in); if (rc) return rc; }
+		}
+	}
+	// the entry points above are "a caller from outside" to the still-step machinery; the chain of steps goes on all the same: nothing but the ghosts (and, in the
+	// rehearsal, bodies that got their own bits back) has changed
+	ctx->still.ahead_ready = ahead; ctx->still.pair_ready = pair;
+	const uint32_t n_ghost = p->ghost_in[0] + p->ghost_in[1];
+	if (ahead && n_ghost && ctx->own_xf) {
+		const uint32_t first = p->n_owned + 1u;
+		NH_LAUNCH(ctx, "xform_ghosts", k_xform_ghosts, nh_grid_for(n_ghost, 256, 256), 256, ctx->d_state, first, bodies->count, bodies->transforms, bodies->idle_counters,
+		          p->nbx, p->nsp, p->flag[0], p->flag[1], p->cfg.n_static_box, p->cfg.n_static_sph, cd->boxes.count,
+		          cd->boxes.transforms, cd->boxes.data, cd->spheres.transforms, cd->spheres.data,
+		          reinterpret_cast<float4*>(ctx->own_xf), ctx->own_aabb_min, ctx->own_aabb_max, ctx->fat_box, ctx->step_parity ^ 1u, ctx->collide_seq + 1u);
+	}
+	return NH_OK;
+}
+
+extern "C" int nh_partition_step(nh_partition* p, const nh_StepArgs* args, uint32_t steps, uint32_t exchange_first, uint32_t loopback_records) {
+	if (!p || !args || !args->bodies || !args->colliders) return NH_ERR_INVALID;
+	nh_context* ctx = p->ctx;
+	NP_CHECK(ctx, hipSetDevice(ctx->device));
+	const bool needs_transport = (p->ghost_out[0] | p->ghost_out[1] | p->ghost_in[0] | p->ghost_in[1] | loopback_records) != 0u;
+	if (needs_transport && !p->rccl.comm) return NH_ERR_INVALID;          // (the library enqueues the exchange itself: nh_partition_set_transport first)
+	if (args->bodies->count != p->n_bodies) return NH_ERR_INVALID;
+	p->step_args = args; p->step_exchange_first = exchange_first; p->step_loopback = loopback_records;
+	ctx->step_hook = part_step_hook; ctx->step_hook_user = p;
+	ctx->halo_ghost_first = (p->ghost_in[0] + p->ghost_in[1]) ? p->n_owned + 1u : 0u;
+	const int rc = nh_step(ctx, args, steps);
+	ctx->step_hook = nullptr; ctx->step_hook_user = nullptr; ctx->halo_ghost_first = 0u;
+	p->step_args = nullptr;
+	return rc;
 }
 
 // transport check: `bytes` of a pattern to both peers and from both (a peer equal to this rank: a loop-back) through the functions handed in, one group; 0 = what

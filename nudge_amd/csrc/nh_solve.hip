@@ -1009,7 +1009,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			for (int q = 0; q < M; ++q) scid[lane * M + q] = cid[q];
 			s_hint[wave][lane] = h; s_first[wave][lane] = first;
 		}
-		if (AHEAD) { if (!mine) col = 0xFFFFFFFFu; s_col[wave][lane] = col; }
+		// (nh_partition_step: a ghost's lane solves and advances it -- an owned body may rest on it -- but its transforms and pair for the next step come with the next halo)
+		const bool ghost_lane = AHEAD && fs.ghost_first != 0u && x >= fs.ghost_first;
+		if (AHEAD) { if (!mine || ghost_lane) col = 0xFFFFFFFFu; s_col[wave][lane] = col; }
 		__builtin_amdgcn_wave_barrier();
 		// phase A: the wave fetches the per-contact records slot by slot; all loads first, then the comparisons
 		uint32_t sc[M], sflags[M];
@@ -1272,7 +1274,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			fs.idle[x] = idle_out;
 			reinterpret_cast<float4*>(xf + x)[0] = make_float4(pos[0], pos[1], pos[2], a0.w);
 			reinterpret_cast<float4*>(xf + x)[1] = make_float4(rot[0], rot[1], rot[2], rot[3]);
-			if (AHEAD) {
+			if (AHEAD && !ghost_lane) {
 				ntop = idle_out; nfail = idle_out == 0xffu;
 				const uint32_t c = ah_col;
 				if (c != 0xFFFFFFFFu) {
@@ -2969,6 +2971,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 			nh_FusedStep fs = nh_FusedStep();
 			fs.gx_dt = ctx->grav.gx_dt; fs.gy_dt = ctx->grav.gy_dt; fs.gz_dt = ctx->grav.gz_dt; fs.damping = ctx->grav.damping; fs.time_step = ctx->grav.time_step;
 			fs.bits = 3u | (ss.sleepers ? 4u : 0u); fs.idle = bodies->idle_counters; fs.seq = ctx->collide_seq;
+			fs.ghost_first = ctx->halo_ghost_first;
 			fs.guard_seq = ss.verdict.pending ? ss.verdict.seq : ctx->collide_seq;          // (a solver behind an unconfirmed still step leaves when THAT one failed)
 #define NH_SOLVE_STILL(NWAVES) NH_LAUNCH(ctx, "solve_still", (k_solve_one_body<4, true, true, NWAVES, true>), (B + 64u * NWAVES - 1u) / (64u * NWAVES), 64 * NWAVES, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum, \
 		          (float4*)d->states, iterations, ctx->raw_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fs, sv, nh_AheadView())
@@ -3480,7 +3483,8 @@ extern "C" int nh_step(nh_context* ctx, const nh_StepArgs* a, uint32_t steps) {
 	// (per-kernel timing of EVERY launch collects its events at the step's round trip; timing restricted to one kernel -- nh_set_timing_filter: two events per step, what
 	// bench.py keeps on during its timed region -- leaves the loop as it is: the events are collected when the call's last verdict has been waited for)
 	ss.pipelined = ss.h_ring[0] != nullptr && (ctx->flags & NH_FLAG_FUSED_STEP) && !(ctx->flags & (NH_FLAG_SYNC_COUNTS | NH_FLAG_EXACT_ORDER)) && !ss.disabled &&
-	               !(ctx->timing && ctx->timing_filter.empty());
+	               !(ctx->timing && ctx->timing_filter.empty()) &&
+	               !ctx->step_hook;          // (nh_partition_step: what a step sends to the neighbours must be a step that HAPPENED -- its verdict is looked at inside the step)
 	ss.verdict.pending = false;
 	ss.ahead_map_ok = false; ss.ahead_ready = false;          // (xform ahead, nh_internal.h: nothing carries over from another call -- the caller may have changed anything in between)
 	int result = NH_OK;
@@ -3504,6 +3508,7 @@ extern "C" int nh_step(nh_context* ctx, const nh_StepArgs* a, uint32_t steps) {
 			ctx->asleep.streak = 0;
 		}
 		int rc;
+		if (ctx->step_hook && (rc = ctx->step_hook(ctx, ctx->step_hook_user, i))) { result = rc; break; }
 		ss.more_steps = i + 1u < steps; ss.steps_left = steps - 1u - i;
 		nh_Arena temporary = a->arena;
 		nh_ContactImpulseData* imp = nullptr;

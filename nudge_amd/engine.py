@@ -42,7 +42,7 @@ EXPORTS = [
     "nh_partition_create", "nh_partition_destroy", "nh_partition_info", "nh_partition_pack_migrants", "nh_partition_unpack_migrants", "nh_partition_pack_ghosts",
     "nh_partition_top_speed", "nh_partition_set_peer_speeds", "nh_partition_mark_ghosts", "nh_partition_pack_deltas", "nh_partition_unpack_deltas",
     "nh_partition_pack_momentum", "nh_partition_unpack_momentum", "nh_partition_exchange_iteration", "nh_partition_unpack_ghosts", "nh_partition_pack_step", "nh_partition_unpack_step", "nh_partition_choose_cut", "nh_partition_set_cut",
-    "nh_partition_set_transport", "nh_partition_exchange_step", "nh_partition_transport_check", "nh_partition_transport_result", "nh_set_first_ghost_body",
+    "nh_partition_set_transport", "nh_partition_exchange_step", "nh_partition_step", "nh_partition_transport_check", "nh_partition_transport_result", "nh_set_first_ghost_body",
 ]
 HALO_RECORD_BYTES = 64
 
@@ -186,6 +186,7 @@ def lib():
         L.nh_partition_set_cut.argtypes = [C.c_void_p, C.c_int, C.c_double]
         L.nh_partition_set_transport.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.nh_partition_exchange_step.argtypes = [C.c_void_p, C.POINTER(BodyData)]
+        L.nh_partition_step.argtypes = [C.c_void_p, C.POINTER(StepArgs), C.c_uint32, C.c_uint32, C.c_uint32]
         L.nh_partition_transport_check.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
         L.nh_partition_transport_result.argtypes = [C.c_void_p]
         L.nh_set_first_ghost_body.argtypes = [C.c_void_p, C.c_uint32]
@@ -389,6 +390,16 @@ class World:
             self.write_cache()
             self.advance()
             self.step_done()
+
+    def partition_step(self, partition, steps, exchange_first, loopback_records=0, iterations=None):
+        """`steps` sub-steps of a partitioned world in ONE library call (nh_partition_step): the per-step halo exchange is enqueued by the library between two sub-steps
+        over the transport of nh_partition_set_transport; the chain of still steps runs through the call."""
+        p = self.params
+        it = p["iterations"] if iterations is None else iterations
+        args = self._step_args = StepArgs(C.pointer(self.active), C.pointer(self.contacts), C.pointer(self.bodies), C.pointer(self.colliders), C.pointer(self.connections),
+                                          C.pointer(self.cache), self.arena, p["time_step"], (C.c_float * 3)(0.0, p["gravity"], 0.0), p["damping_rate"], it)
+        _check(self.L, self.L.nh_partition_step(partition, C.byref(args), steps, 1 if exchange_first else 0, loopback_records), "nh_partition_step")
+        self.steps_done += steps
 
     def step_done(self):
         """Book-keeping of one finished step; callers that drive the eight calls themselves (partition.py, per-iteration exchange) call it after advance()."""

@@ -630,6 +630,16 @@ class Partition:
         self.steps += 1
         self.stats["steps_total"] += 1
 
+    def library_steps(self, n, exchange_first, loopback_records=0):
+        """n sub-steps in ONE library call (nh_partition_step): per-step halo exchanges enqueued by the library over its own transport between them.  Must not reach past
+        the next refresh (the caller's business)."""
+        self.e.partition_step(self.hip, n, exchange_first, loopback_records)
+        if exchange_first:
+            self.stats["step_bytes"] += STEP_BYTES * getattr(self, "_ghost_out_total", 0)
+        self.stats["step_bytes"] += STEP_BYTES * getattr(self, "_ghost_out_total", 0) * (n - 1)
+        self.steps += n
+        self.stats["steps_total"] += n
+
     # ---- per-iteration mode: the step in phases, ghost momentum refreshed after every sweep ---------------------------
     def step_begin(self):
         e = self.e
@@ -1062,20 +1072,44 @@ class DistCluster:
 
     # host-side accounting for bench.py (wall time of the refreshes, their own synchronisations included; host time to ENQUEUE a per-step halo)
     t_refresh = 0.0; n_refresh = 0; t_halo = 0.0; n_halo = 0
+    multi_step = True          # with the library-driven transport: the sub-steps between two refreshes in ONE call (nh_partition_step); False: one call per sub-step (round 5)
+
+    def _refresh(self):
+        p = self.p
+        if p.rebalance and p.steps > 0:
+            p.balance_unpack_counts(self._exchange(p.balance_pack_counts(), 8, known_counts={d: 1 for d in p.neighbours()}))
+            p.balance_unpack_cuts(self._exchange(p.balance_pack_cuts(), 8, known_counts=p.balance_expected()))
+        p.speed_unpack(self._exchange(p.speed_pack(), 8, known_counts={d: 1 for d in p.neighbours()}))
+        p.refresh_unpack_migrants(self._exchange(p.refresh_pack_migrants(), FULL_BYTES))
+        p.refresh_unpack_ghosts(self._exchange(p.refresh_pack_ghosts(), FULL_BYTES))
 
     def step(self, steps=1):
         import time
         p = self.p
+        if self.direct and self.multi_step and not p.per_iteration and p.hip is not None and hasattr(p.e, "partition_step"):
+            # the library drives the sub-steps between two refreshes itself (nh_partition_step): refresh (host), then one call for the steps up to the next one
+            left = steps
+            while left > 0:
+                t_0 = time.perf_counter()
+                refreshing = p.needs_refresh()
+                if refreshing:
+                    self._refresh()
+                    self.t_refresh += time.perf_counter() - t_0; self.n_refresh += 1
+                n = min(left, p.epoch - (p.steps % p.epoch))
+                t_1 = time.perf_counter()
+                lb = min(self.loopback, p.n_owned) if self.loopback else 0
+                p.library_steps(n, exchange_first=not refreshing, loopback_records=lb)
+                self.t_halo += time.perf_counter() - t_1; self.n_halo += n
+                if lb:
+                    self.loopback_records += lb * (n if not refreshing else n - 1)
+                    self.loopback_steps = getattr(self, "loopback_steps", 0) + n
+                left -= n
+            return
         for _ in range(steps):
             t_0 = time.perf_counter()
             refreshing = p.needs_refresh()
             if refreshing:
-                if p.rebalance and p.steps > 0:
-                    p.balance_unpack_counts(self._exchange(p.balance_pack_counts(), 8, known_counts={d: 1 for d in p.neighbours()}))
-                    p.balance_unpack_cuts(self._exchange(p.balance_pack_cuts(), 8, known_counts=p.balance_expected()))
-                p.speed_unpack(self._exchange(p.speed_pack(), 8, known_counts={d: 1 for d in p.neighbours()}))
-                p.refresh_unpack_migrants(self._exchange(p.refresh_pack_migrants(), FULL_BYTES))
-                p.refresh_unpack_ghosts(self._exchange(p.refresh_pack_ghosts(), FULL_BYTES))
+                self._refresh()
             elif self.direct:
                 import ctypes as C
                 from . import engine as E

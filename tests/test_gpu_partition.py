@@ -172,7 +172,9 @@ def test_bench_under_torchrun_with_one_rank_executes_rccl_point_to_point():
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["contacts_per_step"] > 0.9 * 4 * 8 * 45 * 45, out
-    assert out["halo"]["backend"] == "nccl" and out["halo"]["loopback_records_per_step"] == 4096, out["halo"]
+    # (inside nh_partition_step the sub-step right after a refresh has no per-step exchange: 31 of 32 sub-steps carry the 4096 records)
+    assert out["halo"]["backend"] == "nccl" and 0.9 * 4096 <= out["halo"]["loopback_records_per_step"] <= 4096, out["halo"]
+    assert "nh_partition_step" in out["halo"]["per_step_transport"], out["halo"]
     # ... and the library-driven transport: an RCCL communicator of its own created through ctypes on the RCCL library torch has loaded, ncclGroupStart / ncclSend /
     # ncclRecv / ncclGroupEnd called by libnudge_hip.so through the addresses it was handed, checked with a pattern sent to this same rank
     assert out["halo"]["per_step_transport"].startswith("library-driven RCCL"), out["halo"]
@@ -370,4 +372,63 @@ def test_deltas_against_a_mark_of_other_ghosts_are_refused():
     q.delta_mark()
     q.delta_pack()                               # marked again: accepted
     for p in gpu:
+        p.e.close()
+
+
+def test_sub_steps_in_one_library_call_with_ghosts_arriving_through_the_transport():
+    """nh_partition_step (round 6): K sub-steps of a slab in ONE library call, the per-step halo enqueued by the library between them.  The chain of still steps (xform
+    ahead, pair ahead) then runs through a partitioned world -- for the OWNED bodies; what a rank computes for a ghost is not what its owner computes, so ghosts' lanes
+    leave the next step alone, k_xform_ghosts transforms their colliders when the halo has arrived and k_pair_begin evaluates their pairs.
+    One GPU cannot hold two RCCL ranks, so the neighbour is a RECORDING: a two-partition cluster stepped one sub-step at a time (round 5's way) records what partition 1
+    sends to partition 0 every step; a second, identical cluster then steps its partition 0 ALONE through nh_partition_step with a transport whose `recv` plays the
+    recording back (hipMemcpyAsync on the library's stream) -- bit for bit the owned bodies of the first cluster's partition 0, and the chain did run."""
+    import ctypes as C
+    BENCH = E.NH_FLAG_SINGLE_APPLY | E.NH_FLAG_FUSED_STEP
+    scene = S.grid_tiles(2, side=24, seed=91, lattice_cols=2)
+    c1, p1 = _cluster(scene, 2, epoch=64, flags=BENCH)
+    c2, p2 = _cluster(scene, 2, epoch=64, flags=BENCH)
+    c1.step(100); c2.step(100)          # landed and at rest; refreshes at steps 0 and 64, the next one at 128
+    recorded = []
+    orig = p1[1].step_pack
+
+    def recording_pack():
+        out = orig()
+        recorded.append(out[-1].clone())
+        return out
+    p1[1].step_pack = recording_pack
+    K = 24
+    c1.step(K)
+    assert len(recorded) == K and p1[0].ghost_in[+1] > 0 and recorded[0].shape[0] == p1[0].ghost_in[+1]
+    # partition 0 of the second cluster, alone, through the library's own loop
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    played = [0]
+    GROUP = C.CFUNCTYPE(C.c_int)
+    XFER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+    group = GROUP(lambda: 0)
+    send = XFER(lambda buf, count, dtype, peer, comm, stream: 0)
+
+    def recv_fn(buf, count, dtype, peer, comm, stream):
+        msg = recorded[played[0]]
+        played[0] += 1
+        assert count == msg.numel()
+        return hip.hipMemcpyAsync(buf, msg.data_ptr(), count, 3, stream)          # hipMemcpyDeviceToDevice, on the library's stream
+    recv = XFER(recv_fn)
+    q = p2[0]
+    L = q.e.L
+    L.nh_partition_set_transport.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int]
+    E._check(L, L.nh_partition_set_transport(q.hip, C.c_void_p(1), C.cast(group, C.c_void_p), C.cast(group, C.c_void_p), C.cast(send, C.c_void_p), C.cast(recv, C.c_void_p), -1, 1), "set_transport")
+    c0 = q.e.counts()
+    q.library_steps(K, exchange_first=True)
+    cb = q.e.counts()
+    assert played[0] == K
+    a, b = p1[0].owned_state(), q.owned_state()
+    assert np.array_equal(a[0], b[0])
+    assert P.bits_equal(a[1], b[1]), "transforms of the owned bodies differ"
+    assert P.bits_equal(a[2], b[2]), "momentum of the owned bodies differs"
+    assert np.array_equal(a[3], b[3])
+    print(f"\n[nh_partition_step] {K} sub-steps in one call with {q.ghost_in[+1]} ghosts: still {cb['still_steps'] - c0['still_steps']}, ahead {cb['ahead_steps'] - c0['ahead_steps']}, pair {cb['pair_steps'] - c0['pair_steps']}, replays {cb['still_replays'] - c0['still_replays']}")
+    assert cb["error"] == 0 and cb["ahead_steps"] - c0["ahead_steps"] >= K - 4 and cb["pair_steps"] - c0["pair_steps"] >= K - 6, (c0, cb)
+    L.nh_partition_set_transport(q.hip, None, None, None, None, None, -1, -1)
+    for p in p1 + p2:
         p.e.close()
