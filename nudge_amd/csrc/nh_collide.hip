@@ -11,6 +11,8 @@
 // the few large ones (ground slabs); union-find runs lock-free with atomicCAS hooking.
 #include "nh_internal.h"
 #include "nh_narrowphase.h"
+#include <type_traits>
+#include "nh_solver.h"          // (nh_is_inert: k_pair_begin checks body 0 for the step it opens)
 #include <stdlib.h>
 
 // ---- 1. world transforms, AABBs, bounds, extent histogram ---------------------------------------------
@@ -1356,7 +1358,8 @@ __global__ __launch_bounds__(256) void k_pair_begin(nh_DevState* __restrict__ st
                                                     const nh_BoxCollider* __restrict__ box_data, const nh_SphereCollider* __restrict__ sph_data, uint32_t nbox,
                                                     const uint64_t* __restrict__ rec_key, nh_Record* __restrict__ rec,
                                                     const uint32_t* __restrict__ lay_rank, uint32_t* __restrict__ cnt_sorted, const uint32_t* __restrict__ body_rec, int2* __restrict__ delta,
-                                                    nh_Contact* __restrict__ raw_data, uint32_t* __restrict__ raw_feature) {
+                                                    nh_Contact* __restrict__ raw_data, uint32_t* __restrict__ raw_feature,
+                                                    const nh_BodyMomentum* __restrict__ momentum, const nh_BodyProperties* __restrict__ props) {
 	const uint32_t lane = nh_lane();
 	uint32_t fr_min[3], fr_max[3], fr_top;
 	{
@@ -1376,8 +1379,12 @@ __global__ __launch_bounds__(256) void k_pair_begin(nh_DevState* __restrict__ st
 		const uint32_t op = parity ^ 1u;
 		const float scale_was = nh_morton_scale(nh_make3(nh_float_unflip(st->still_smin[op][0]), nh_float_unflip(st->still_smin[op][1]), nh_float_unflip(st->still_smin[op][2])),
 		                                        nh_make3(nh_float_unflip(st->still_smax[op][0]), nh_float_unflip(st->still_smax[op][1]), nh_float_unflip(st->still_smax[op][2])));
+		// (body 0 inert: the solver checks it too -- here so that the step's verdict is complete when this launch ends, nh_StillStep::early_verdict)
+		const nh_BodyMomentum m0 = momentum[0];
+		const nh_BodyProperties p0 = props[0];
+		const bool inert = nh_is_inert(m0.velocity, m0.angular_velocity, p0.inertia_inverse, p0.mass_inverse);
 		const bool bad = st->ahead_failed_seq >= seq || st->ahead_multi != 0u || !st->lay_valid || st->fat_count != st->pairs || st->fat_count_sph != st->pairs_sph ||
-		                 n_list > list_cap || !(mscale >= 0.75f * scale_was);
+		                 n_list > list_cap || !(mscale >= 0.75f * scale_was) || !inert;
 		__builtin_amdgcn_wave_barrier();
 		if (lane == 0) {
 			if (bad) { atomicMax(&st->still_failed_seq, seq); atomicAdd(&st->still_diff[3], 1u); }
@@ -2191,7 +2198,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			}
 			// PAIR AHEAD (nh_internal.h): the last step's solver lanes evaluated this step's pairs too -- this step starts at the solver, behind one wave of bookkeeping
 			const bool pair_step = ahead_step && ss.pair_ready && !fused && !ss.no_pair;
-			ss.pair_ready = false; ss.pair_step = pair_step;
+			ss.pair_ready = false; ss.pair_step = pair_step; ss.early_verdict = false;
 			if (pair_step) ss.pair_steps++;
 			if (!ahead_step) ctx->fused.statics_copied = false;          // (k_xform<true> rewrites the current set of collider buffers, the static world's entries included)
 			if (ahead_step) ss.ahead_steps++;
@@ -2239,9 +2246,17 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 				else NH_LAUNCH(ctx, NAME, (k_narrowphase<SPHERES, true, false>), nh_grid_for(pair_cap, 256, GRIDMAX), 256, st, ctx->fat_pairs, xf, ctag, \
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr, \
 				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, (uint32_t*)nullptr, ahead_step ? 1u : 0u); } while (0)
-			if (pair_step) NH_LAUNCH(ctx, "pair_begin", k_pair_begin, 32, 256, st, ctx->step_parity, ctx->collide_seq, ctx->pair_list, ctx->pair_list_capacity, ctx->fat_pairs, ctx->fat_pair_capacity, pair_cap, gen,
+			if (pair_step) {
+			NH_LAUNCH(ctx, "pair_begin", k_pair_begin, 32, 256, st, ctx->step_parity, ctx->collide_seq, ctx->pair_list, ctx->pair_list_capacity, ctx->fat_pairs, ctx->fat_pair_capacity, pair_cap, gen,
 			                         xf, aabb_min, aabb_max, ctag, colliders->boxes.data, colliders->spheres.data, nbox, ctx->sort_keys_by_position, rec,
-			                         ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->still_delta, raw_data, raw_feature);
+			                         ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->still_delta, raw_data, raw_feature, bodies->momentum, bodies->properties);
+			ss.early_verdict = false;
+			if (ctx->step_hook && !ss.pipelined && ss.h_ring[0] && !ctx->timing) {
+				NH_HIP_CHECK(ctx, hipMemcpyAsync(ss.h_ring[0], st, NH_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+				NH_HIP_CHECK(ctx, hipEventRecord(ss.ev_ring[0], ctx->stream));
+				ss.early_verdict = true;
+			}
+			}
 			else if (!fused) {
 			if (nbox >= 2) NH_NARROW_STILL(false, "narrowphase_still", 4096);
 			if (nsph) NH_NARROW_STILL(true, "narrowphase_sph_still", 8192);
@@ -2259,7 +2274,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 	// a full step.  (nh_step: a still step whose verdict has not been looked at yet must have happened before anything is built on it)
 	if (ctx->still.verdict.pending && nh_still_verdict_now(ctx)) return NH_INTERNAL_STILL_FAILED;
 	ctx->still.fused = false; ctx->fused.map_valid = false; ctx->fused.statics_copied = false;
-	ctx->still.pair_ready = false; ctx->still.pair_step = false; ctx->still.pair_world_bad = false; ctx->still.pair_world_ok = false; ctx->still.pair_owned_seq = 0u;          // (another layout: whether every kept pair is some body's own is found out again)
+	ctx->still.pair_ready = false; ctx->still.pair_step = false; ctx->still.early_verdict = false; ctx->still.pair_world_bad = false; ctx->still.pair_world_ok = false; ctx->still.pair_owned_seq = 0u;          // (another layout: whether every kept pair is some body's own is found out again)
 	{ int rc = nh_fused_come_home(ctx); if (rc) return rc; }          // (every fused step before this one is confirmed: the bodies it left in the shadow arrays go home)
 	// The solver reads the caller's cache arrays and this nh_collide lays the dense contact list out -- whatever still steps kept by slot goes home first
 	{ int rc = nh_still_export_cache(ctx); if (rc) return rc; }

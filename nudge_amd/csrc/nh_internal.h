@@ -251,6 +251,7 @@ struct nh_StillStep {
 	// Which collider of a pair plays "a" is decided by the Morton order of the AABB min corners in the NEXT step's scene frame (nudge.cpp:3086-3100), which no lane knows;
 	// but when one corner is <= the other in all three coordinates and clearly less in one (two quantisation cells of THIS step's frame), it comes first in the Morton
 	// order of ANY frame whose cells are not much larger -- k_pair_begin checks that the next frame's are not (scale >= 3/4 of this one's).  A box on a slab always is.
+	bool early_verdict;             // nh_partition_step, pair step: the counters behind k_pair_begin are on their way to h_ring[0] -- the step's verdict, ahead of its solver
 	bool pair_ready;                // the solver of the LAST step launched evaluated the pairs of this one: the next nh_collide of this call launches k_pair_begin instead of the narrowphase
 	bool pair_step;                 // the still step being launched started at the solver (statistics below)
 	bool no_pair;                   // option "no_pair_ahead"

@@ -3022,6 +3022,22 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 				ss.verdict.pending = true; ss.verdict.seq = ctx->collide_seq; ss.verdict.parity = ctx->step_parity; ss.verdict.slot = slot; ss.verdict.collide_mark = ctx->collide_mark;
 				ss.verdict_fused = ss.fused;
 				confirmed = true;          // (until the next step says otherwise)
+			} else if (ss.early_verdict) {
+				// nh_partition_step, a step that started at the solver: everything such a step can fail on is checked by its PROLOGUE (k_pair_begin: the step-wide words,
+				// body 0, the pairs that are nobody's or a ghost's -- the lanes' checks belong to the NEXT step), whose counters nh_collide sent on their way before this
+				// solver was launched.  The host waits for THAT copy -- the solver runs on -- so the next sub-step's halo and launches queue up behind it: no bubble
+				ss.early_verdict = false;
+				NH_HIP_CHECK(ctx, hipEventSynchronize(ss.ev_ring[0]));
+				const nh_DevState* h = ss.h_ring[0];
+				confirmed = h->still_failed_seq < ctx->collide_seq && h->error == 0u;
+				if (confirmed) {
+					ss.confirmed_seq = ctx->collide_seq;
+					memcpy(ctx->h_state, h, NH_COUNTER_WORDS * sizeof(uint32_t));
+					if (!ctx->idle_unknown) { ctx->idle_bound = (int)h->max_idle[ctx->step_parity]; ctx->idle_bound_mark = ctx->collide_mark; }
+					still_note_movers(ctx, h, ctx->collide_seq);
+				} else {
+					NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));          // (the solver has left at once; the replay starts from a quiet stream like every other)
+				}
 			} else {
 				// the step's one round trip: did every check hold?
 				NH_HIP_CHECK(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, NH_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
