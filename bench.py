@@ -910,7 +910,9 @@ def main():
             # what every rank measured for the same blocks (the line's time is the slowest rank's): wall time per step; the refreshes that fell into the timed blocks
             # and what one cost the host (its own device synchronisations included); host time to enqueue the per-step halo (pack, RCCL group, unpack -- no wait)
             out["per_rank"] = [{"rank": r, "ms_per_step": 1e3 * e[0] / timed_steps, "refreshes_in_timed_blocks": int(e[2]), "refresh_ms": (1e3 * e[1] / e[2]) if e[2] else None,
-                                "halo_enqueue_us_per_step": (1e6 * e[3] / e[4]) if e[4] else None} for r, e in enumerate(per_rank)]
+                                # (with nh_partition_step the halo is enqueued by the library inside the call that also steps: there is no host time of its own to report)
+                                "halo_enqueue_us_per_step": ((1e6 * e[3] / e[4]) if e[4] else None) if not (cluster is not None and cluster.direct and cluster.multi_step) else None}
+                               for r, e in enumerate(per_rank)]
         if cluster is not None:
             st = cluster.p.stats
             out["halo"] = {"backend": backend, "per_step_transport": (("library-driven RCCL inside nh_partition_step (all sub-steps between two refreshes in one call)" if cluster.multi_step else "library-driven RCCL (nh_partition_exchange_step), one call per sub-step") if cluster.direct else f"torch.distributed point-to-point ({cluster.direct_why or 'not asked'})"), "loopback_records_per_step": (cluster.loopback_records / max(1, getattr(cluster, "loopback_steps", 0))) if loopback else None,

@@ -290,7 +290,7 @@ int main(int argc, char** argv) {
 	const int local_ranks = getenv("NUDGE_LOCAL_RANKS") ? atoi(getenv("NUDGE_LOCAL_RANKS")) : 0;
 	const char* scene_path = nullptr; const char* out_path = nullptr; const char* cuts_arg = nullptr;
 	std::vector<const char*> pos;
-	uint32_t epoch = 16, min_extra = 4096; double speed_floor = 1.0, slack = 0.15; bool rebalance = true, single_owner = false;
+	uint32_t epoch = 16, min_extra = 4096; double speed_floor = 1.0, slack = 0.15; bool rebalance = true, single_owner = false, library_steps = false;
 	for (int i = 1; i < argc; ++i) {
 		if (!strcmp(argv[i], "--scene") && i + 1 < argc) scene_path = argv[++i];
 		else if (!strcmp(argv[i], "--out") && i + 1 < argc) out_path = argv[++i];
@@ -301,6 +301,7 @@ int main(int argc, char** argv) {
 		else if (!strcmp(argv[i], "--slack") && i + 1 < argc) slack = atof(argv[++i]);
 		else if (!strcmp(argv[i], "--no-rebalance")) rebalance = false;
 		else if (!strcmp(argv[i], "--single-owner")) single_owner = true;
+		else if (!strcmp(argv[i], "--library-steps")) library_steps = true;          // the sub-steps between two refreshes in ONE call: nh_partition_step (RCCL transport handed to the library)
 		else pos.push_back(argv[i]);
 	}
 	const int n_ranks = local_ranks > 0 ? local_ranks : world;
@@ -379,6 +380,13 @@ int main(int argc, char** argv) {
 		d_loop = to_device(idx, 1); HIP_OK(hipMalloc(&loop_out, (size_t)NH_HALO_RECORD_BYTES * (n_loop + 1))); HIP_OK(hipMalloc(&loop_in, (size_t)NH_HALO_RECORD_BYTES * (n_loop + 1)));
 	}
 
+	// --library-steps: the communicator and the four RCCL entry points go to the library (it links no RCCL), neighbours by communicator rank; a one-rank rehearsal names itself
+	const bool use_library_steps = library_steps && !T.local && !single_owner && T.comm != nullptr;
+	if (library_steps && !use_library_steps) { fprintf(stderr, "--library-steps needs the RCCL transport (one rank per process) and not --single-owner\n"); return 2; }
+	if (use_library_steps)
+		for (Rank& R : ranks)
+			NH_OK_(nh_partition_set_transport(R.part, T.comm, (void*)&ncclGroupStart, (void*)&ncclGroupEnd, (void*)&ncclSend, (void*)&ncclRecv,
+			                                  R.rank > 0 ? R.rank - 1 : -1, R.rank + 1 < n_ranks ? R.rank + 1 : (loopback ? R.rank : -1)));
 	const size_t slots = T.local ? (size_t)n_ranks : (size_t)1;
 	auto at = [&](const Rank& R) { return T.local ? (size_t)R.rank : (size_t)0; };
 	HIP_OK(hipStreamSynchronize(stream));
@@ -418,7 +426,7 @@ int main(int argc, char** argv) {
 			for (Rank& R : ranks) NH_OK_(nh_partition_pack_ghosts(R.part, &R.bodies, R.has(0) ? R.out[0] : nullptr, R.has(1) ? R.out[1] : nullptr, R.msg_capacity, R.out_count));
 			exchange(T, ranks, NH_PARTITION_FULL_BYTES, false);
 			for (Rank& R : ranks) NH_OK_(nh_partition_unpack_ghosts(R.part, &R.bodies, &R.colliders, R.in[0], R.has(0) ? R.in_count[0] : 0u, R.in[1], R.has(1) ? R.in_count[1] : 0u));
-		} else if (n_ranks > 1) {
+		} else if (n_ranks > 1 && !use_library_steps) {
 			// ---- the per-step halo: the owners' state of this step overwrites the ghosts' (lengths fixed since the refresh) ----
 			for (Rank& R : ranks) {
 				NH_OK_(nh_partition_pack_step(R.part, &R.bodies, R.out[0], R.out[1]));
@@ -427,6 +435,21 @@ int main(int argc, char** argv) {
 			}
 			exchange(T, ranks, NH_HALO_RECORD_BYTES, true);
 			for (Rank& R : ranks) NH_OK_(nh_partition_unpack_step(R.part, &R.bodies, R.in[0], R.in[1]));
+		}
+		if (use_library_steps) {
+			// ---- the sub-steps up to the next refresh in ONE library call: nh_partition_step enqueues the per-step halo (pack, ncclSend / ncclRecv, unpack, the ghosts'
+			// transforms) between two sub-steps itself, so the chain of still steps -- xform ahead, pair ahead -- runs through the partitioned world (include/nudge_hip.h)
+			const unsigned k = n_ranks > 1 ? std::min<unsigned>(steps - n, epoch - n % epoch) : steps - n;
+			const float dt = (float)scene.time_step;
+			for (Rank& R : ranks) {
+				nh_StepArgs a;
+				memset(&a, 0, sizeof(a));
+				a.active_bodies = &R.active; a.contacts = &R.contacts; a.bodies = &R.bodies; a.colliders = &R.colliders; a.body_connections = &R.connections; a.contact_cache = &R.cache;
+				a.arena = R.arena; a.time_step = dt; a.gravity[0] = 0.0f; a.gravity[1] = (float)scene.gravity; a.gravity[2] = 0.0f; a.damping_rate = (float)scene.damping_rate; a.iterations = scene.iterations;
+				NH_OK_(nh_partition_step(R.part, &a, k, (n_ranks == 1 || n % epoch != 0) ? 1u : 0u, loopback ? n_loop : 0u));
+			}
+			n += k - 1u;
+			continue;
 		}
 		if (loopback && n_loop) {
 			Rank& R = ranks[0];
@@ -507,7 +530,7 @@ int main(int argc, char** argv) {
 	}
 	if (fo) fclose(fo);
 	if (local_ranks > 0 && owned_all != total_bodies) { fprintf(stderr, "bodies lost or duplicated: %llu owned of %zu\n", (unsigned long long)owned_all, total_bodies); return 7; }
-	if (loopback) printf("partition_rccl loopback: %u halo records per step through ncclSend/ncclRecv(self), %u steps\n", n_loop, steps);
+	if (loopback) printf("partition_rccl loopback: %u halo records per step through ncclSend/ncclRecv(self), %u steps%s\n", n_loop, steps, use_library_steps ? " (inside nh_partition_step)" : "");
 	for (Rank& R : ranks) { nh_partition_destroy(R.part); nh_destroy(R.ctx); }
 	if (T.comm) NCCL_OK(ncclCommDestroy(T.comm));
 	return 0;

@@ -206,6 +206,14 @@ def test_cpp_rccl_host_loopback_executes_rccl_between_the_halo_kernels():
     assert "loopback: 2304 halo records per step through ncclSend/ncclRecv(self), 90 steps" in outs[1], outs[1]
     checksum = [o.split("checksum")[1].split()[0] for o in outs]
     assert checksum[0] == checksum[1], checksum
+    # ... and the same through nh_partition_step (round 6): the host hands communicator and entry points to the library, which runs all 90 sub-steps in ONE call and
+    # enqueues the exchange between them itself -- same world, and the chain of still steps (one launch per step) ran through it
+    r = subprocess.run([CU.PARTITION_RCCL, "--library-steps", "2", "2", "24", "90"], capture_output=True, text=True, timeout=600, env=dict(base, NUDGE_RCCL_LOOPBACK="1"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "2304 owned + 0 ghost bodies" in r.stdout and "(4.000 per owned+ghost body)" in r.stdout and "(inside nh_partition_step)" in r.stdout, r.stdout
+    assert r.stdout.split("checksum")[1].split()[0] == checksum[0], (r.stdout, checksum)
+    still = [int(o.split("still steps")[1].split(",")[0]) for o in (outs[1], r.stdout)]
+    assert still[1] >= still[0] - 2, still
 
 
 @pytest.mark.gpu
