@@ -138,7 +138,7 @@ def grid_table_entries(C):
     return min(want, 1 << 24)
 
 # timer name (nh_* launch sites) -> kernel symbol prefix in the rocprofv3 PMC export (profiles/export_pmc.py)
-PMC_KERNEL = {"still_fused": "k_still_fused", "solve_one_body": "k_solve_one_body<4, true, true, 1, false>", "solve_still": "k_solve_one_body<4, true, true, 1, true, true>", "narrowphase_still": "k_narrowphase<false, true>",
+PMC_KERNEL = {"still_fused": "k_still_fused", "solve_one_body": "k_solve_one_body<4, true, true, 1, false>", "solve_still": "k_solve_one_body<4, true, true, 1, true, true, true>", "narrowphase_still": "k_narrowphase<false, true>",
               "xform_still": "k_xform<true>", "apply_static": "k_apply_static<4, true>", "narrowphase": "k_narrowphase<false, false>",
               "gather_contacts": "k_gather_contacts", "find_pairs": "k_find_pairs", "radix_pass": "os_pass<unsigned long, unsigned int, true>",
               "apply_level": "k_level_exec<false>", "write_cache": "k_write_cache", "xform_aabb": "k_xform", "blk_sweep": "k_blk_sweep<false, true>"}
