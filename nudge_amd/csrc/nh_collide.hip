@@ -21,6 +21,12 @@
 // few addresses (~12 ns each, serialised), so the fewer workgroups the better.
 // inflation of the kept pair list's boxes: 1/32 of the last grid's cell (nothing is known before the first grid)
 #define NH_ESC_MAX 4096u             // colliders re-inserted per step at most (more leave their boxes: rebuild)
+// leaver x (moved + large) box tests a step may spend before regrouping everybody is the cheaper way.  One lane per combination, 64 K lanes: sixteen tests per collider of the
+// world cost what a fifth of a rebuild costs (4.4 M tests for 2048 boxes in the air over a million at rest: ~20 us against ~250 us -- and a rebuild voids the layout the still
+// steps live on; rounds 3-5 allowed half a test per collider, which sent exactly that world into a rebuild on 84 of 96 steps)
+// (... and when a thirty-second of the world has been re-inserted since the last rebuild -- stale grid entries, dead pairs in the kept list, a layout that is no longer "in place" --
+// regrouping everybody IS the cheaper way: the old half-a-test rule did that by accident for small worlds in which everybody had moved once)
+#define NH_REINSERT_COMBOS(ncolliders) ((uint64_t)(ncolliders) * 16u)
 #define NH_MOVED_MAX 16384u          // colliders re-inserted since the last rebuild at most (their grid entries are stale: the next leaver is tested against each of them)
 // (NH_GEN_SHIFT / NH_GEN_INDEX -- kept pairs carry the generation stamps of their two colliders above the 24-bit collider index: nh_internal.h)
 __device__ __forceinline__ float nh_kept_margin(float cell_inv) { return cell_inv > 0.0f ? 0.03125f / cell_inv : 0.05f; }
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(64) void k_grid_setup(nh_DevState* st, uint32_t nco
 	const uint32_t leavers = st->esc_count;
 	// (... or when the leavers' tests against everybody who has moved since the rebuild -- quadratic -- outgrow the regrouping they stand in for)
 	const bool crowded = leavers != 0u && ((uint64_t)st->fat_count + st->fat_count_sph + 64ull * leavers > (uint64_t)kept_cap / 8u * 7u || (uint64_t)leavers * 16u > ncolliders ||
-	                                       (uint64_t)leavers * (st->moved_count + st->large) > (uint64_t)ncolliders / 2u);
+	                                       (uint64_t)leavers * (st->moved_count + st->large) > NH_REINSERT_COMBOS(ncolliders) || (uint64_t)st->moved_count * 32u > ncolliders);
 	const bool rebuild = direct || st->fat_valid == 0u || st->fat_escaped != 0u || crowded;
 	st->fat_rebuild = rebuild ? 1u : 0u;
 	st->fat_reinsert = !rebuild && st->esc_count != 0u ? 1u : 0u;
@@ -757,7 +763,7 @@ __global__ __launch_bounds__(256) void k_reinsert(nh_DevState* __restrict__ st, 
 	if (still) {
 		if (!leavers) return;
 		const bool crowded = (uint64_t)st->still_fat0 + 64ull * leavers > (uint64_t)kept_cap / 8u * 7u || (uint64_t)leavers * 16u > ncolliders ||
-		                     (uint64_t)leavers * (st->moved_count + st->large) > (uint64_t)ncolliders / 2u;
+		                     (uint64_t)leavers * (st->moved_count + st->large) > NH_REINSERT_COMBOS(ncolliders) || (uint64_t)st->moved_count * 32u > ncolliders;
 		if (crowded) {
 			if (blockIdx.x == 0 && threadIdx.x == 0) { st->fat_valid = 0u; atomicMax(&st->still_failed_seq, seq); atomicAdd(&st->still_diff[3], 1u); }
 			return;
@@ -1359,7 +1365,7 @@ __global__ __launch_bounds__(256) void k_pair_begin(nh_DevState* __restrict__ st
                                                     const uint64_t* __restrict__ rec_key, nh_Record* __restrict__ rec,
                                                     const uint32_t* __restrict__ lay_rank, uint32_t* __restrict__ cnt_sorted, const uint32_t* __restrict__ body_rec, int2* __restrict__ delta,
                                                     nh_Contact* __restrict__ raw_data, uint32_t* __restrict__ raw_feature,
-                                                    const nh_BodyMomentum* __restrict__ momentum, const nh_BodyProperties* __restrict__ props) {
+                                                    const nh_BodyMomentum* __restrict__ momentum, const nh_BodyProperties* __restrict__ props, uint32_t delta_scan) {
 	const uint32_t lane = nh_lane();
 	uint32_t fr_min[3], fr_max[3], fr_top;
 	{
@@ -1484,7 +1490,7 @@ __global__ __launch_bounds__(256) void k_pair_begin(nh_DevState* __restrict__ st
 			if (!st->delta_overflow[parity]) {
 				const uint32_t k = atomicAdd(&st->delta_count[parity], 1u);
 				if (k < NH_DELTA_MAX) delta[parity * NH_DELTA_MAX + k] = make_int2((int)pos, count - (int)old);
-				else { st->delta_overflow[parity] = 1u; changed = true; }
+				else { st->delta_overflow[parity] = 1u; if (!delta_scan) changed = true; }
 			}
 		}
 	}
@@ -2249,7 +2255,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			if (pair_step) {
 			NH_LAUNCH(ctx, "pair_begin", k_pair_begin, 32, 256, st, ctx->step_parity, ctx->collide_seq, ctx->pair_list, ctx->pair_list_capacity, ctx->fat_pairs, ctx->fat_pair_capacity, pair_cap, gen,
 			                         xf, aabb_min, aabb_max, ctag, colliders->boxes.data, colliders->spheres.data, nbox, ctx->sort_keys_by_position, rec,
-			                         ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->still_delta, raw_data, raw_feature, bodies->momentum, bodies->properties);
+			                         ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->still_delta, raw_data, raw_feature, bodies->momentum, bodies->properties, delta_scan ? 1u : 0u);
 			ss.early_verdict = false;
 			if (ctx->step_hook && !ss.pipelined && ss.h_ring[0] && !ctx->timing) {
 				NH_HIP_CHECK(ctx, hipMemcpyAsync(ss.h_ring[0], st, NH_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -2264,7 +2270,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			// every record's first contact in the dense (tag-ordered) list = the scan of the counts in tag order: kept from step to step, shifted by the listed changes
 			// (the solver keeps the total).  More pairs changing their count than the list holds: a world of up to two million colliders fails the step (a handful change
 			// per million and step at rest); a larger one runs the scan instead -- two launches that leave at once otherwise, nothing next to its step
-			if (delta_scan && !fused && !pair_step) nh_scan_u32(ctx, ctx->cnt_sorted, ctx->start_sorted, &st->records, 1, scan_tmp, nullptr, &st->delta_overflow[ctx->step_parity]);
+			if (delta_scan && !fused) nh_scan_u32(ctx, ctx->cnt_sorted, ctx->start_sorted, &st->records, 1, scan_tmp, nullptr, &st->delta_overflow[ctx->step_parity]);
 			ss.active = true; ss.resolved = false; ss.launched++;
 			ctx->gravity_may_overlap = false;
 			ctx->after_collide = true;

@@ -160,7 +160,7 @@ struct nh_AheadView { const uint32_t* body_col; const nh_Transform* box_xf; cons
                       // PAIR AHEAD (nh_StillStep): what the lane needs to evaluate its body's own kept pair for the next sub-step -- the kept list, the keys on file, the stamps and
                       // tags -- and where the result goes: the record's raw contact slots, its count in the tag order, the next step's list of count changes
                       const uint2* kept; uint32_t kept_cap, pair_cap; const uint64_t* rec_key; const uint32_t* ctag; const uint8_t* gen;
-                      struct nh_Record* rec; nh_Contact* raw_data; uint32_t* raw_feature; uint32_t* cnt_sorted; int2* delta; uint32_t unowned_cap; };
+                      struct nh_Record* rec; nh_Contact* raw_data; uint32_t* raw_feature; uint32_t* cnt_sorted; int2* delta; uint32_t unowned_cap, delta_scan; };
 struct nh_FusedStep { float gx_dt, gy_dt, gz_dt, damping, time_step; uint32_t bits; uint8_t* idle; uint32_t seq, guard_seq;
                       uint32_t ghost_first; };      // (nh_partition_step: bodies from here on are ghosts -- their lanes solve and advance them but leave the next step's transforms and pairs alone: the ghost arrives anew)
 //      // (still steps: this step's sequence number; the

@@ -1391,7 +1391,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 							if (!stw->delta_overflow[np2]) {
 								const uint32_t k = atomicAdd(&stw->delta_count[np2], 1u);
 								if (k < NH_DELTA_MAX) av.delta[np2 * NH_DELTA_MAX + k] = make_int2((int)bpos, pp_count - (int)st_cnt);
-								else { stw->delta_overflow[np2] = 1u; nfail = true; }          // (more changes than the list holds: the next step is not this form's)
+								else { stw->delta_overflow[np2] = 1u; if (!av.delta_scan) nfail = true; }          // (more changes than the list holds: the next step scans the counts again -- large worlds, where the host launches the scan -- or is not this form's)
 							}
 						}
 					}
@@ -2991,7 +2991,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 				const uint8_t* gen = (C < (1u << NH_GEN_SHIFT) && !ctx->env_no_incremental) ? ctx->fat_gen : (const uint8_t*)nullptr;
 				nh_AheadView av = { ctx->body_col, cd.boxes.transforms, cd.boxes.data, cd.spheres.transforms, cd.spheres.data, cd.boxes.count, ctx->own_xf, ctx->own_aabb_min, ctx->own_aabb_max, ctx->fat_box,
 				                    ctx->fat_pairs, ctx->fat_pair_capacity, ctx->lay_capacity, ctx->sort_keys_by_position, ctx->own_ctag, gen,
-				                    ctx->rec, ctx->raw_data, ctx->raw_feature, ctx->cnt_sorted, ctx->still_delta, ctx->pair_list_capacity };
+				                    ctx->rec, ctx->raw_data, ctx->raw_feature, ctx->cnt_sorted, ctx->still_delta, ctx->pair_list_capacity, C > (2u << 20) ? 1u : 0u };
 				if (pair)
 				NH_LAUNCH(ctx, "solve_still", (k_solve_one_body<4, true, true, 1, true, true, true>), (B + 63u) / 64u, 64, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
 				          (float4*)d->states, iterations, ctx->raw_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fs, sv, av);
