@@ -162,7 +162,8 @@ struct nh_AheadView { const uint32_t* body_col; const nh_Transform* box_xf; cons
                       const uint2* kept; uint32_t kept_cap, pair_cap; const uint64_t* rec_key; const uint32_t* ctag; const uint8_t* gen;
                       struct nh_Record* rec; nh_Contact* raw_data; uint32_t* raw_feature; uint32_t* cnt_sorted; int2* delta; uint32_t unowned_cap, delta_scan; };
 struct nh_FusedStep { float gx_dt, gy_dt, gz_dt, damping, time_step; uint32_t bits; uint8_t* idle; uint32_t seq, guard_seq;
-                      uint32_t ghost_first; };      // (nh_partition_step: bodies from here on are ghosts -- their lanes solve and advance them but leave the next step's transforms and pairs alone: the ghost arrives anew)
+                      uint32_t ghost_first;
+                      uint32_t* host_counters; };      // (nh_step, late verdicts: where the launch's first thread leaves the step's counters for the host -- pinned memory; nullptr: the host copies them itself)      // (nh_partition_step: bodies from here on are ghosts -- their lanes solve and advance them but leave the next step's transforms and pairs alone: the ghost arrives anew)
 //      // (still steps: this step's sequence number; the
                                                                                                                                     // oldest still step whose verdict the host has not seen)
 

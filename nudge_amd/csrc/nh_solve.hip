@@ -900,7 +900,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		const nh_BodyProperties p0 = props[0];
 		const bool inert = nh_is_inert(m0.velocity, m0.angular_velocity, p0.inertia_inverse, p0.mass_inverse);
 		if (!inert && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&const_cast<nh_DevState*>(cv.st)->still_failed_seq, fs.seq);
-		if (!inert || cv.st->still_failed_seq >= fs.guard_seq) return;
+		if (!inert || cv.st->still_failed_seq >= fs.guard_seq) {
+			// (the verdict the host is waiting for: see below)
+			if (fs.host_counters && blockIdx.x == 0 && threadIdx.x == 0) {
+				const volatile uint32_t* src = reinterpret_cast<const volatile uint32_t*>(cv.st);
+#pragma unroll
+				for (uint32_t k = 0; k < NH_COUNTER_WORDS; ++k) fs.host_counters[k] = src[k];
+			}
+			return;
+		}
 		inert_word = 1u;
 	}
 	__shared__ nh_ob_slot s_slot[NW][64 * M];
@@ -929,6 +937,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			stw->contacts = total;
 			// (sleepers form, nh_internal.h: what k_xform<true> and the still narrowphase counted becomes the step's counters; all zero when nobody sleeps)
 			stw->active = (nbodies - 1u) - min(stw->still_asleep[sv.parity], nbodies - 1u); stw->sleeping = stw->still_sleeping[sv.parity]; stw->culled = stw->still_culled[sv.parity];
+			// nh_step with late verdicts: everything a still step can fail on has been decided before this launch (k_xform<true>, the narrowphase or k_pair_begin) or at its
+			// top (body 0) -- what the lanes find wanting fails the NEXT step -- so the step's counters are final here, and this thread leaves them where the host will look
+			// (pinned memory, visible when the launch has ended: the host waits for the event behind it).  The copy the runtime made instead cost 6 us of stream time per step.
+			if (fs.host_counters) {
+				const volatile uint32_t* src = reinterpret_cast<const volatile uint32_t*>(cv.st);
+#pragma unroll
+				for (uint32_t k = 0; k < NH_COUNTER_WORDS; ++k) fs.host_counters[k] = src[k];
+			}
 		}
 		__syncthreads();
 	}
@@ -2972,6 +2988,9 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 			fs.gx_dt = ctx->grav.gx_dt; fs.gy_dt = ctx->grav.gy_dt; fs.gz_dt = ctx->grav.gz_dt; fs.damping = ctx->grav.damping; fs.time_step = ctx->grav.time_step;
 			fs.bits = 3u | (ss.sleepers ? 4u : 0u); fs.idle = bodies->idle_counters; fs.seq = ctx->collide_seq;
 			fs.ghost_first = ctx->halo_ghost_first;
+			// (late verdicts: the solver's first thread writes the step's counters into the pinned ring slot itself -- not the fused look-back kernel, which keeps the copy)
+			const bool self_report = ss.pipelined && ss.h_ring[0] && !ss.fused;
+			fs.host_counters = self_report ? reinterpret_cast<uint32_t*>(ss.h_ring[ctx->collide_seq & 1u]) : nullptr;
 			fs.guard_seq = ss.verdict.pending ? ss.verdict.seq : ctx->collide_seq;          // (a solver behind an unconfirmed still step leaves when THAT one failed)
 #define NH_SOLVE_STILL(NWAVES) NH_LAUNCH(ctx, "solve_still", (k_solve_one_body<4, true, true, NWAVES, true>), (B + 64u * NWAVES - 1u) / (64u * NWAVES), 64 * NWAVES, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum, \
 		          (float4*)d->states, iterations, ctx->raw_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fs, sv, nh_AheadView())
@@ -3017,7 +3036,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 				}
 				// ... then this step's counters on their way, to be looked at by the next step
 				const int slot = (int)(ctx->collide_seq & 1u);
-				NH_HIP_CHECK(ctx, hipMemcpyAsync(ss.h_ring[slot], ctx->d_state, NH_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+				if (!self_report) NH_HIP_CHECK(ctx, hipMemcpyAsync(ss.h_ring[slot], ctx->d_state, NH_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 				NH_HIP_CHECK(ctx, hipEventRecord(ss.ev_ring[slot], ctx->stream));
 				ss.verdict.pending = true; ss.verdict.seq = ctx->collide_seq; ss.verdict.parity = ctx->step_parity; ss.verdict.slot = slot; ss.verdict.collide_mark = ctx->collide_mark;
 				ss.verdict_fused = ss.fused;
@@ -3515,7 +3534,8 @@ extern "C" int nh_step(nh_context* ctx, const nh_StepArgs* a, uint32_t steps) {
 		}
 		// A world asleep (nh_internal.h: nh_AsleepState): two full steps in a row were its fixed point.  ONE check per call that nothing the caller owns has changed since
 		// -- and the remaining steps of this call are done: nothing inside the library wakes a world in which nobody is awake.
-		if (ctx->asleep.streak >= 2u && !ctx->asleep.disabled && !ss.verdict.pending && !ctx->pending && (ctx->flags & NH_FLAG_FUSED_STEP) && !(ctx->flags & NH_FLAG_SYNC_COUNTS) && !ctx->timing &&
+		// (never inside nh_partition_step: the neighbours expect this rank's halo before every sub-step, whether anything moves here or not)
+		if (ctx->asleep.streak >= 2u && !ctx->asleep.disabled && !ctx->step_hook && !ss.verdict.pending && !ctx->pending && (ctx->flags & NH_FLAG_FUSED_STEP) && !(ctx->flags & NH_FLAG_SYNC_COUNTS) && !ctx->timing &&
 		    same_bodies_arrays(*a->bodies, ss.lay_bodies) && same_collider_arrays(*a->colliders, ss.lay_colliders) && a->contacts->data == ss.lay_contacts.data && a->contacts->tags == ss.lay_contacts.tags &&
 		    a->contacts->sleeping_pairs == ss.lay_contacts.sleeping_pairs && a->active_bodies->indices == ss.lay_active && a->contact_cache->data == ss.cache_data && a->contact_cache->tags == ss.cache_tags && a->contact_cache->features == ss.cache_features) {
 			const int v = nh_asleep_verify(ctx, a->bodies, a->colliders);
