@@ -12,6 +12,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nudge_amd import scenes as S   # noqa: E402
 from nudge_amd import engine as E   # noqa: E402
 
+table = "--table" in sys.argv          # (per-kernel times of 20 extra steps of the default column, each kernel alone on the GPU)
+if table: sys.argv.remove("--table")
 tiles = int(sys.argv[1]) if len(sys.argv) > 1 else 124
 scene = S.grid_tiles(tiles, side=90, seed=2, lattice_cols=11 if tiles == 124 else None)
 nb = len(scene["body_transforms"])
@@ -38,6 +40,11 @@ for frac in (0.5, 0.1, 0.9):
         c1 = w.counts()
         assert c1["error"] == 0 and 0 < c1["active_bodies"] < nb - 1, c1
         row.append(200 / t)
+        if table and env is None:
+            w.enable_timing(True); w.step(20); w.synchronize()
+            kt = w.kernel_times()
+            print(f"  [{frac:.0%} awake, per step] " + ", ".join(f"{k} {ms / 20 * 1e3:.1f} us x{n / 20:.1f}" for k, (ms, n) in sorted(kt.items(), key=lambda x: -x[1][0])[:12]), flush=True)
+            w.enable_timing(False)
         detail.append(f"{c1['active_bodies']:,} active, {c1['sleeping_pairs']:,} sleeping pairs, {c1['still_steps'] - c0['still_steps']} still steps, {c1['still_replays'] - c0['still_replays']} replayed")
         w.close()
     print(f"{frac:4.0%} | " + " | ".join(f"{r:8.1f} ({d})" for r, d in zip(row, detail)), flush=True)

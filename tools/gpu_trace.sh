@@ -1,8 +1,8 @@
 #!/bin/bash
-# kernel trace of the driver line: per-kernel calls / average durations
+# kernel trace of the driver line (or of `bench.py <arguments>`): per-kernel calls / average durations
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/trace -o t -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-full-window --min-time 1 > $R/gpurun_out/trace_bench.json 2> $R/gpurun_out/trace.log
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/trace -o t -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-full-window --min-time 1 "$@" > $R/gpurun_out/trace_bench.json 2> $R/gpurun_out/trace.log
 DB=$(find $R/gpurun_out/trace -name "*.db" | head -1)
 python - "$DB" <<'PY'
 import sqlite3, sys
