@@ -42,7 +42,12 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
                                                nh_xform* __restrict__ xf, float4* __restrict__ aabb_min, float4* __restrict__ aabb_max, uint32_t* __restrict__ ctag,
                                                uint4* __restrict__ zero16, uint32_t zero16_count, float4* fat_box, uint32_t direct,
                                                uint8_t* __restrict__ gen, uint32_t* __restrict__ esc_mark, uint32_t* __restrict__ esc_list, uint32_t* __restrict__ moved_list, uint32_t seq,
-                                               const uint8_t* __restrict__ idle = nullptr, uint32_t nbodies = 0u, uint32_t parity = 0u, uint8_t* __restrict__ awake_out = nullptr) {
+                                               const uint8_t* __restrict__ idle = nullptr, uint32_t nbodies = 0u, uint32_t parity = 0u, uint8_t* __restrict__ awake_out = nullptr,
+                                               // STILL, sleepers form, a sub-step of an nh_step call that is not its first: a collider whose body is asleep now and carried the
+                                               // mark when the sub-step before this one wrote these arrays has not moved in between (nobody advances a sleeping body, and the
+                                               // caller cannot touch anything inside a call): its world transform, AABB, tag and mark stand -- only its share of the scene bounds
+                                               // is taken (from the AABB on file).  What an asleep collider costs is 37 bytes instead of 217
+                                               uint32_t skip_asleep = 0u) {
 	// `awake_out` (STILL): SLEEPERS form (nh_internal.h) -- a body asleep does not fail the step; it is counted, noted (awake_out[i]: the active list is a view of it) and
 	// its colliders carry the mark in aabb_max.w, where the still narrowphase finds it without another memory round trip
 	__shared__ uint32_t hist[STILL ? 1 : 1024];
@@ -88,6 +93,8 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 				st->still_fat0 = st->fat_count + st->fat_count_sph;          // (nobody appends to the kept list while this kernel runs: k_reinsert's verdict needs a value that stands still)
 			}
 		}
+		// (sleepers form: where THIS step's narrowphase counts its sleeping pairs)
+		if (awake_out && blockIdx.x == 0 && threadIdx.x < NH_SLEEP_PARTS * 2u) (&st->sleep_part[parity][0][0])[threadIdx.x] = 0u;
 		// (xform ahead, nh_internal.h: what this step's solver may gather for the next step)
 		if (blockIdx.x == 0 && threadIdx.x < NH_AHEAD_PARTS * 8u) (&st->ahead_part[parity ^ 1u][0][0])[threadIdx.x] = (threadIdx.x & 7u) < 3u ? 0xffffffffu : 0u;
 		__syncthreads();
@@ -95,6 +102,17 @@ __global__ __launch_bounds__(1024) void k_xform(nh_DevState* __restrict__ st,
 		__syncthreads();
 	}
 	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+		if (STILL && skip_asleep) {
+			const float4 omin = aabb_min[c];
+			const uint32_t omark = reinterpret_cast<const uint32_t*>(aabb_max)[4u * (size_t)c + 3u], ob = __float_as_uint(omin.w);
+			if (omark == 1u && ob != 0u && ob < nbodies && idle[ob] == 0xffu) {
+				uint32_t f;
+				f = nh_float_flip(omin.x); lmin[0] = min(lmin[0], f); lmax[0] = max(lmax[0], f);
+				f = nh_float_flip(omin.y); lmin[1] = min(lmin[1], f); lmax[1] = max(lmax[1], f);
+				f = nh_float_flip(omin.z); lmin[2] = min(lmin[2], f); lmax[2] = max(lmax[2], f);
+				continue;
+			}
+		}
 		bool is_box = c < nbox;
 		nh_Transform l = is_box ? box_xf[c] : sph_xf[c - nbox];
 		nh_Transform b = body_xf[l.body];
@@ -961,7 +979,10 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
                                                      // STILL, plain form: no k_xform<true> has run this step -- the last step's solver did its work (nh_internal.h: xform ahead)
                                                      uint32_t ahead = 0u,
                                                      // STILL, sleepers form: where a dropped slot-cache count is noted until the step's verdict is in (nh_internal.h: sc_undo)
-                                                     uint64_t* __restrict__ sc_undo = nullptr) {
+                                                     uint64_t* __restrict__ sc_undo = nullptr,
+                                                     // STILL, sleepers form: a record that WAS a sleeping pair when the step before wrote it and whose two ends are the static world or
+                                                     // asleep now is what it was -- counted, nothing else fetched (30 bytes per pair instead of 230)
+                                                     uint32_t quick_sleepers = 0u) {
 	if (STILL && !LOCAL && ahead) {
 		// what k_xform<true> does for the step after this one (nobody touches the other parity's words during this step: the solver that gathers into them comes later)
 		if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1111,7 +1132,20 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 		auto TAG = [&](uint32_t c) -> uint32_t { if (STILL) return c == CB ? TB : TA; return ctag[c]; };
 		auto BOX = [&](uint32_t c) -> nh_BoxCollider { if (STILL) return c == CB ? SB : SA; return box_data[c]; };
 		auto RAD = [&](uint32_t c) -> float { if (STILL) return c == CB ? RB : RA; return sph_data[c - nbox].radius; };
-		if (live || app) {
+		bool quick = false;
+		if (STILL && LOCAL && quick_sleepers && sc_count && live) {
+			uint2 kp = kp_first;
+			if (i != i_first) kp = pairs[SPH ? kept_cap - 1u - i : i];
+			const uint32_t ca = kp.x & index_mask, cb = kp.y & index_mask;
+			const uint32_t* const mx = reinterpret_cast<const uint32_t*>(aabb_max); const uint32_t* const mn = reinterpret_cast<const uint32_t*>(aabb_min);
+			const uint32_t ma = mx[4u * (size_t)ca + 3u], mb = mx[4u * (size_t)cb + 3u], ba = mn[4u * (size_t)ca + 3u], bb2 = mn[4u * (size_t)cb + 3u];
+			const uint32_t rc = reinterpret_cast<const uint32_t*>(rec)[4u * (size_t)ri + 3u];
+			const uint32_t oc = sc_count[ri];
+			// (both ends the static world or marked asleep -- one of them marked: the other end of a sleeping record is the static world)
+			quick = rc == NH_REC_SLEEPING && (ma | mb) == 1u && (ba == 0u || ma == 1u) && (bb2 == 0u || mb == 1u);
+			if (quick) { n_sleeping += 1u; n_culled += min(oc, 4u); }
+		}
+		if ((live && !quick) || app) {
 			uint2 pr;
 			if (STILL) {
 				uint2 kp = kp_first;
@@ -1201,7 +1235,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 					dp[1] = make_float4(single.nx, single.ny, single.nz, single.friction);
 					raw_feature[slot] = single.feature;
 				}
-				if (STILL) still_record(ri, key, count, body_a, body_b, (uint64_t)s_pre[0][threadIdx.x] | ((uint64_t)s_pre[1][threadIdx.x] << 32), s_pre[2][threadIdx.x], invalid, sleeper_pair);
+				if (STILL) { if (!quick) still_record(ri, key, count, body_a, body_b, (uint64_t)s_pre[0][threadIdx.x] | ((uint64_t)s_pre[1][threadIdx.x] << 32), s_pre[2][threadIdx.x], invalid, sleeper_pair); }
 				else {
 				{ const uint64_t was = rec_key[ri]; changed |= was != key; rec_key[ri] = key; }
 				nh_Record r = { body_a, body_b, 0u, asleep ? NH_REC_SLEEPING : (uint32_t)count };
@@ -1254,7 +1288,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			} else if (bb.kind == 1) {
 				put(0, bb.edge);
 			}
-			if (STILL) still_record(ri, key, count, body_a, body_b, (uint64_t)s_pre[0][threadIdx.x] | ((uint64_t)s_pre[1][threadIdx.x] << 32), s_pre[2][threadIdx.x], invalid, sleeper_pair);
+			if (STILL) { if (!quick) still_record(ri, key, count, body_a, body_b, (uint64_t)s_pre[0][threadIdx.x] | ((uint64_t)s_pre[1][threadIdx.x] << 32), s_pre[2][threadIdx.x], invalid, sleeper_pair); }
 			else {
 				{ const uint64_t was = rec_key[ri]; changed |= was != key; rec_key[ri] = key; }
 				nh_Record r = { body_a, body_b, ovf, asleep ? NH_REC_SLEEPING : (uint32_t)count };
@@ -1289,7 +1323,7 @@ __global__ __launch_bounds__(256) void k_narrowphase(nh_DevState* __restrict__ s
 			for (int d = 32; d >= 1; d >>= 1) { n_sleeping += (uint32_t)__shfl_xor((int)n_sleeping, d); n_culled += (uint32_t)__shfl_xor((int)n_culled, d); }
 			if (nh_lane() == 0 && n_sleeping) { atomicAdd(&s_sl[0], n_sleeping); atomicAdd(&s_sl[1], n_culled); }
 			__syncthreads();
-			if (threadIdx.x == 0 && s_sl[0]) { atomicAdd(&st->still_sleeping[parity], s_sl[0]); if (s_sl[1]) atomicAdd(&st->still_culled[parity], s_sl[1]); }
+			if (threadIdx.x == 0 && s_sl[0]) { uint32_t* const part = &st->sleep_part[parity][blockIdx.x & (NH_SLEEP_PARTS - 1u)][0]; atomicAdd(&part[0], s_sl[0]); if (s_sl[1]) atomicAdd(&part[1], s_sl[1]); }
 		}
 		return;
 	}
@@ -2214,7 +2248,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			          colliders->spheres.transforms, colliders->spheres.data, colliders->spheres.tags, nsph,
 			          xf, aabb_min, aabb_max, ctag, (uint4*)nullptr, 0u, ctx->fat_box, 0u,
 			          movers ? ctx->fat_gen : (uint8_t*)nullptr, ctx->fat_esc_mark, ctx->fat_esc_list, ctx->fat_moved_list, ctx->collide_seq, bodies->idle_counters, B, ctx->step_parity,
-			          sleepers ? ctx->still_awake : (uint8_t*)nullptr);
+			          sleepers ? ctx->still_awake : (uint8_t*)nullptr, (sleepers && ss.substep > 0u && !ctx->step_hook && !ss.no_sleeper_skip) ? 1u : 0u);          // (the narrowphase's `sleeper_skip` below)
 			if (!ahead_step && plain && ss.more_steps && !ss.no_ahead && !ss.ahead_world_bad && !ss.ahead_map_ok && bodies->idle_counters) {
 				// (once per nh_step call: which collider each body's lane stands in for, and the static world's share of the scene bounds)
 				if (ctx->body_col_capacity < B) {
@@ -2246,9 +2280,11 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			// form, or somebody may be asleep)
 			if (movers) ss.appended_pairs = true;
 			const bool local = sleepers || ss.appended_pairs;
+			// (sleepers form inside an nh_step call, not its first sub-step: what was asleep when the sub-step before this one looked and is asleep now has not moved)
+			const uint32_t sleeper_skip = (sleepers && ss.substep > 0u && !ctx->step_hook && !ss.no_sleeper_skip) ? 1u : 0u;
 #define NH_NARROW_STILL(SPHERES, NAME, GRIDMAX) do { if (local) NH_LAUNCH(ctx, NAME, (k_narrowphase<SPHERES, true, true>), nh_grid_for(pair_cap, 256, GRIDMAX), 256, st, ctx->fat_pairs, xf, ctag, \
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr, \
-				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, sc_count, 0u, ctx->sc_undo); \
+				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, sc_count, 0u, ctx->sc_undo, sleeper_skip); \
 				else NH_LAUNCH(ctx, NAME, (k_narrowphase<SPHERES, true, false>), nh_grid_for(pair_cap, 256, GRIDMAX), 256, st, ctx->fat_pairs, xf, ctag, \
 				          colliders->boxes.data, colliders->spheres.data, nbox, raw_data, raw_feature, pair_cap, 0u, ctx->sort_keys_by_position, rec, (uint32_t*)nullptr, \
 				          (const uint32_t*)nullptr, (const uint32_t*)nullptr, ctx->step_parity, 0u, ctx->fat_pair_capacity, aabb_min, aabb_max, gen, ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->collide_seq, ctx->still_delta, delta_scan ? 1u : 0u, (uint32_t*)nullptr, ahead_step ? 1u : 0u); } while (0)

@@ -138,6 +138,9 @@ struct nh_DevState {
 	// still steps with SLEEPERS (nh_collide.hip, "9. still steps", LOCAL speculation): by step parity, what a still step in sleepers form counted -- bodies asleep, their
 	// collider pairs (the step's sleeping pairs), the cache entries kept aside for them; the solver turns them into the step's counters (active / sleeping / culled)
 	uint32_t still_asleep[2], still_sleeping[2], still_culled[2];
+	// (the narrowphase's share -- sleeping pairs, entries kept aside -- arrives in NH_SLEEP_PARTS places per parity: four thousand workgroups on ONE address queued for
+	//  12 ns each, 90 us of a launch that had 10 us of work; cleared by the sleepers-form k_xform<true> of the same step, summed by the solver's first thread)
+	uint32_t sleep_part[2][64][2];
 	// XFORM AHEAD (nh_StillStep): a still step's solver has done the NEXT step's k_xform<true> for its body's collider -- what it found (a collider outside its inflated box,
 	// a body whose idle counter is saturated) fails that next step, not its own: the sequence number of the step it fails; and the part of the scene bounds no solver lane
 	// owns (the static world's colliders)
@@ -153,6 +156,7 @@ struct nh_TimerSlot { const char* name; hipEvent_t a, b; };
 
 // what the fused one-body solver does besides solving (NH_FLAG_FUSED_STEP): bits 1 = gravity / damping on load, 2 = advance on store
 #define NH_AHEAD_PARTS 64u
+#define NH_SLEEP_PARTS 64u
 struct nh_xform;
 // what a solver lane needs to do the next step's k_xform<true> for its body's collider (nh_StillStep: xform ahead)
 struct nh_AheadView { const uint32_t* body_col; const nh_Transform* box_xf; const nh_BoxCollider* box_data; const nh_Transform* sph_xf; const nh_SphereCollider* sph_data; uint32_t nbox;
@@ -299,6 +303,8 @@ struct nh_StillStep {
 	// DYNAMIC bodies with a sleeping end means a set of more than one body: the step fails, a full step sorts it out -- and the solver leaves sleeping bodies alone.
 	// Active list and sleeping pairs are VIEWS like the contact list (nh_export_views).
 	bool sleepers;                  // this still step was launched in sleepers form
+	uint32_t substep;               // nh_step: index of the sub-step being launched within its call (0: the first, or a step driven through the stage calls)
+	bool no_sleeper_skip;           // option "no_sleeper_skip": the sleepers form does everything for every collider / pair / wave, asleep or not (A/B, tests)
 	bool views_sleepers;            // sleepers-form still steps have run since the caller's active list / sleeping pairs were last written by a full step
 	bool sleep_pairs_current, active_current;       // ... and those two views have been exported since the last such step
 	void note_failure() { hold = (1u << fail_level) - 1u; if (fail_level < 6u) ++fail_level; good_run = 0; }

@@ -936,7 +936,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			nh_DevState* const stw = const_cast<nh_DevState*>(cv.st);
 			stw->contacts = total;
 			// (sleepers form, nh_internal.h: what k_xform<true> and the still narrowphase counted becomes the step's counters; all zero when nobody sleeps)
-			stw->active = (nbodies - 1u) - min(stw->still_asleep[sv.parity], nbodies - 1u); stw->sleeping = stw->still_sleeping[sv.parity]; stw->culled = stw->still_culled[sv.parity];
+			uint32_t n_sleeping = stw->still_sleeping[sv.parity], n_culled = stw->still_culled[sv.parity];
+			if (fs.bits & 4u) {          // (sleepers form: the narrowphase's share, nh_internal.h: sleep_part)
+				for (uint32_t k = 0; k < NH_SLEEP_PARTS; ++k) { n_sleeping += stw->sleep_part[sv.parity][k][0]; n_culled += stw->sleep_part[sv.parity][k][1]; }
+			}
+			stw->active = (nbodies - 1u) - min(stw->still_asleep[sv.parity], nbodies - 1u); stw->sleeping = n_sleeping; stw->culled = n_culled;
 			// nh_step with late verdicts: everything a still step can fail on has been decided before this launch (k_xform<true>, the narrowphase or k_pair_begin) or at its
 			// top (body 0) -- what the lanes find wanting fails the NEXT step -- so the step's counters are final here, and this thread leaves them where the host will look
 			// (pinned memory, visible when the launch has ended: the host waits for the event behind it).  The copy the runtime made instead cost 6 us of stream time per step.
@@ -981,6 +985,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		// (a wave none of whose 64 bodies is of the kernel's classes -- a ball pit, where four million bodies are the blocked solver's and a handful sit alone on the
 		// floor -- goes straight to its next 64: the second round of loads is the expensive one)
 		if (!STILL && __builtin_amdgcn_ballot_w64(mine) == 0ull) { if (CONTIG) break; x += gridDim.x * blockDim.x; continue; }
+		// (STILL, sleepers form: a wave all of whose bodies are asleep has nothing to fetch, solve, advance or store)
+		if (STILL && !AHEAD && CONTIG && (fs.bits & 8u) && __builtin_amdgcn_ballot_w64(mine) == 0ull) break;
 		if (!mine) { sp = make_uint2(0u, 0u); h = NH_HINT_NONE; br = NH_BODY_REC_NONE; }
 		uint32_t cid[M];
 		uint32_t first = 0xFFFFFFFFu;
@@ -2986,7 +2992,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 			nh_StillView sv = { ctx->body_rec, ctx->body_pos, ctx->cnt_sorted, ctx->start_sorted, ctx->raw_feature, ctx->sc_feat, ctx->sc_count, ctx->lay_capacity, ctx->still_delta, ctx->step_parity };
 			nh_FusedStep fs = nh_FusedStep();
 			fs.gx_dt = ctx->grav.gx_dt; fs.gy_dt = ctx->grav.gy_dt; fs.gz_dt = ctx->grav.gz_dt; fs.damping = ctx->grav.damping; fs.time_step = ctx->grav.time_step;
-			fs.bits = 3u | (ss.sleepers ? 4u : 0u); fs.idle = bodies->idle_counters; fs.seq = ctx->collide_seq;
+			fs.bits = 3u | (ss.sleepers ? 4u : 0u) | ((ss.sleepers && !ss.no_sleeper_skip) ? 8u : 0u); fs.idle = bodies->idle_counters; fs.seq = ctx->collide_seq;          // (bit 3: waves of sleeping bodies leave at once)
 			fs.ghost_first = ctx->halo_ghost_first;
 			// (late verdicts: the solver's first thread writes the step's counters into the pinned ring slot itself -- not the fused look-back kernel, which keeps the copy)
 			const bool self_report = ss.pipelined && ss.h_ring[0] && !ss.fused;
@@ -3545,7 +3551,7 @@ extern "C" int nh_step(nh_context* ctx, const nh_StepArgs* a, uint32_t steps) {
 		}
 		int rc;
 		if (ctx->step_hook && (rc = ctx->step_hook(ctx, ctx->step_hook_user, i))) { result = rc; break; }
-		ss.more_steps = i + 1u < steps; ss.steps_left = steps - 1u - i;
+		ss.more_steps = i + 1u < steps; ss.steps_left = steps - 1u - i; ss.substep = i;
 		nh_Arena temporary = a->arena;
 		nh_ContactImpulseData* imp = nullptr;
 		nh_ContactConstraintData* con = nullptr;
@@ -3567,7 +3573,7 @@ extern "C" int nh_step(nh_context* ctx, const nh_StepArgs* a, uint32_t steps) {
 		    (rc = nh_advance(ctx, a->active_bodies, a->bodies, a->time_step))) { result = rc; break; }
 		++i;
 	}
-	ss.pipelined = false; ss.more_steps = false; ss.ahead_ready = false; ss.ahead_map_ok = false; ss.steps_left = 0u; ss.fused = false;
+	ss.pipelined = false; ss.more_steps = false; ss.ahead_ready = false; ss.ahead_map_ok = false; ss.steps_left = 0u; ss.fused = false; ss.substep = 0u;
 	if (result && ss.verdict.pending) { hipEventSynchronize(ss.ev_ring[ss.verdict.slot]); ss.verdict.pending = false; }
 	// (fused steps are launched in pairs and every verdict of the call is in: the bodies are in the caller's arrays -- unless the call ends in an error)
 	if (ctx->fused.cur != 0u) { ctx->fused.unconfirmed = 0u; int rc = nh_fused_come_home(ctx); if (rc && !result) result = rc; }
