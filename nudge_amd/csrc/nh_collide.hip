@@ -425,7 +425,9 @@ __device__ __forceinline__ bool aabb_overlap(const float4& amin, const float4& a
 // The pair list is split BY SHAPE as it is emitted (the reference partitions its pairs by type before the narrowphase for the same
 // reason, nudge.cpp:3705-3751): box-box pairs fill `pairs` from the front (counter st->pairs), pairs with a sphere from the back (counter
 // st->pairs_sph, slot pair_cap-1-k), so that each narrowphase launch runs ONE kind of arithmetic in all its lanes.
+#ifndef FP_WBUF
 #define FP_WBUF 512
+#endif
 struct pair_stage { uint2* buf; uint32_t count; uint32_t cap; uint32_t nbox; uint32_t mask = 0xFFFFFFFFu; };      // (mask: where a staged pair carries generation stamps above its collider indices)
 
 __device__ __forceinline__ void write_staged(nh_DevState* st, uint2* pairs, uint32_t pair_cap, const pair_stage& ps, uint32_t base_bb, uint32_t base_sph) {

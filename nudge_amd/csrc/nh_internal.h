@@ -36,7 +36,7 @@ struct nh_BlkGrid {
 	uint32_t ghost_cursor;            // entries of the ghost list handed out
 	uint32_t phase_count[8];          // blocks with work, by block colour (parity of the three block coordinates)
 	uint32_t check_errors;            // NH_BLK_CHECK=1: structural errors found by k_blk_check
-	uint32_t near_contacts, far_contacts;   // contacts between two blocks: solved inside a block / left to the residual launches
+	uint32_t near_contacts, far_contacts;   // contacts between two blocks left to the residual launches (far; `near` -- solved inside a block -- is no longer counted)
 	uint32_t max_colours, too_many_colours; // per-block colouring (k_blk_prepare_local): most colours a block used; some block needed more than its descriptor holds
 	uint32_t max_rounds, max_listed;        // ... most Jones-Plassmann rounds a block took, most contacts a block had to colour anew (statistics)
 };

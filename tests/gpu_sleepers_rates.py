@@ -14,6 +14,9 @@ from nudge_amd import engine as E   # noqa: E402
 
 table = "--table" in sys.argv          # (per-kernel times of 20 extra steps of the default column, each kernel alone on the GPU)
 if table: sys.argv.remove("--table")
+only = None          # --only 0.5: that fraction, default library only (for a rocprofv3 run)
+if "--only" in sys.argv:
+    k = sys.argv.index("--only"); only = float(sys.argv[k + 1]); del sys.argv[k:k + 2]
 tiles = int(sys.argv[1]) if len(sys.argv) > 1 else 124
 scene = S.grid_tiles(tiles, side=90, seed=2, lattice_cols=11 if tiles == 124 else None)
 nb = len(scene["body_transforms"])
@@ -22,9 +25,9 @@ flags = E.NH_FLAG_SINGLE_APPLY | E.NH_FLAG_FUSED_STEP
 print(f"{nb - 1:,} boxes in {tiles} tiles; the world asleep, then the boxes of K tiles woken; steps/s over 200 steps")
 print("tiles awake | default (sleepers form) | NH_NO_LOCAL_STILL=1 | NH_NO_STILL=1")
 order = np.argsort(scene["body_transforms"]["position"][1:, 0], kind="stable") + 1
-for frac in (0.5, 0.1, 0.9):
+for frac in ((only,) if only else (0.5, 0.1, 0.9)):
     row, detail = [], []
-    for env in (None, "NH_NO_LOCAL_STILL", "NH_NO_STILL"):
+    for env in ((None,) if only else (None, "NH_NO_LOCAL_STILL", "NH_NO_STILL")):
         if env: os.environ[env] = "1"
         w = E.World(scene, flags=flags, max_contacts=6 * nb)
         if env: os.environ.pop(env, None)
