@@ -1713,12 +1713,29 @@ __global__ __launch_bounds__(256) void k_colour_settle(nh_DevState* __restrict__
 // grid kernels (colour_pick / colour_loses), so the colouring is the same proper, deterministic one.  Writes st->levels, the level offsets and the
 // "level has a full row" flags' zero state where k_level_offsets / k_zero_u32 would.
 #define NH_COLOUR_SMALL_MAX 8192u
+#define NH_COLOUR_STAGE_WORDS 28672u
 __global__ __launch_bounds__(1024) void k_colour_small(nh_DevState* __restrict__ st, const uint32_t* __restrict__ list, const nh_CachedContactImpulse* __restrict__ warm,
                                                        const nh_BodyPair* __restrict__ bodies, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
-                                                       uint32_t* level, uint32_t* tent, uint32_t* __restrict__ hist /* 2 x (NH_MAX_LEVELS + 2) */, uint32_t* __restrict__ order) {
+                                                       uint32_t* level_g, uint32_t* tent_g, uint32_t* __restrict__ hist /* 2 x (NH_MAX_LEVELS + 2) */, uint32_t* __restrict__ order,
+                                                       uint32_t nbodies) {
 	__shared__ uint32_t s_hist[NH_MAX_LEVELS + 2];
 	__shared__ uint32_t s_left, s_max, s_wsum[16];
+	// STAGED: the walks below -- for every contact the lists of its two bodies, for every entry the neighbour's colour -- are chains of dependent loads, a dozen entries
+	// long; out of L2 every link is most of a microsecond and the kernel 126 us of the sample pile's 780.  When the world is small enough the colours, the picks, the list
+	// offsets and the lists themselves are copied to LDS first (112 KB) and the same code walks them there
+	__shared__ uint32_t s_stage[NH_COLOUR_STAGE_WORDS];
 	const uint32_t n = min(st->general_contacts, NH_COLOUR_SMALL_MAX), T = 1024u, tid = threadIdx.x;
+	const uint32_t nc = st->contacts, nb1 = nbodies + 1u, na = nbodies ? off[nbodies] : 0u;
+	const bool staged = nbodies != 0u && (unsigned long long)2u * nc + nb1 + na <= (unsigned long long)NH_COLOUR_STAGE_WORDS;          // (the same for every thread)
+	uint32_t* level = level_g; uint32_t* tent = tent_g;
+	if (staged) {
+		level = s_stage; tent = s_stage + nc;
+		uint32_t* const s_off = s_stage + 2u * nc; uint32_t* const s_adj = s_off + nb1;
+		for (uint32_t i = tid; i < nc; i += T) level[i] = level_g[i];          // (tent: written for every listed contact below before anybody reads it)
+		for (uint32_t i = tid; i < nb1; i += T) s_off[i] = off[i];
+		for (uint32_t i = tid; i < na; i += T) s_adj[i] = adj[i];
+		off = s_off; adj = s_adj;
+	}
 	if (tid == 0) { s_left = 0; s_max = 0; }
 	for (uint32_t l = tid; l < NH_MAX_LEVELS + 2; l += T) { s_hist[l] = 0; hist[NH_MAX_LEVELS + 2 + l] = 0; }
 	__syncthreads();
@@ -1789,7 +1806,7 @@ __global__ __launch_bounds__(1024) void k_colour_small(nh_DevState* __restrict__
 	for (uint32_t w = 0; w < (tid >> 6); ++w) run += s_wsum[w];
 	for (uint32_t i = 0; i < per; ++i) if (base + i < NH_MAX_LEVELS + 2) { const uint32_t v = s_hist[base + i]; hist[base + i] = run; s_hist[base + i] = run; run += v; }
 	__syncthreads();
-	for (uint32_t k = tid; k < n; k += T) { const uint32_t c = list[k]; const uint32_t l = level[c]; if (l <= NH_MAX_LEVELS) order[atomicAdd(&s_hist[l], 1u)] = c; }
+	for (uint32_t k = tid; k < n; k += T) { const uint32_t c = list[k]; const uint32_t l = level[c]; if (l <= NH_MAX_LEVELS) order[atomicAdd(&s_hist[l], 1u)] = c; if (staged) level_g[c] = l; }
 }
 
 // the contacts of `list` that are still uncoloured, in any order (a round's outcome does not depend on who looks at which contact).
@@ -2818,7 +2835,7 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 		// A few thousand contacts in default order: colouring and level order by ONE workgroup, no host round trip until the solver's (k_colour_small)
 		if (!(ctx->flags & NH_FLAG_EXACT_ORDER) && !ctx->env_colour_jp && !ctx->env_no_resident && !ctx->env_colour_check_seeds && G <= NH_COLOUR_SMALL_MAX &&
 		    (G <= NH_RES_MAX_FULL || B <= NH_RESB_MAX_BODIES)) {
-			NH_LAUNCH(ctx, "colour_small", k_colour_small, 1, 1024, st, general_list, imp->data, contacts->bodies, d->body_off, d->adj, level, d->cont.tent, level_hist, d->level_order);
+			NH_LAUNCH(ctx, "colour_small", k_colour_small, 1, 1024, st, general_list, imp->data, contacts->bodies, d->body_off, d->adj, level, d->cont.tent, level_hist, d->level_order, B);
 			NH_LAUNCH(ctx, "rows_general", k_rows_general, nh_grid_for(G, 256, 4096), 256, st, d->level_order, contacts->data, contacts->bodies, bodies->transforms, bodies->properties,
 			          (float4*)d->rows, (size_t)kcap, d->gpair, 1u, d->static_inert ? 1u : 0u, level, level_hist + (NH_MAX_LEVELS + 2),
 			          (const nh_CachedContactImpulse*)nullptr, (float4*)nullptr, (uint32_t*)nullptr, 0u);
