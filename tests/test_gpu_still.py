@@ -364,6 +364,45 @@ def test_a_world_that_is_partly_asleep_takes_still_steps(sphere_fraction):
     a.close(); b.close()
 
 
+def test_what_the_sleepers_form_skips_changes_nothing():
+    """Round 6.  Inside one nh_step call, from its second sub-step on, a still step in sleepers form takes an asleep collider's bounds from the AABB on file, counts a record
+    that was a sleeping pair and still has both ends static or asleep without fetching anything else, and lets solver waves of sleeping bodies leave at once; the sleeping
+    pairs are counted in 64 places.  Calls of every length (a one-step call never skips), a body woken by the caller between two calls, the second dozing-off: the same bits
+    as the library with the option off and as the one that runs every step in full."""
+    scene = S.grid_tiles(2, side=32, sphere_fraction=0.5, seed=75, lattice_cols=2)
+    nb = len(scene["body_transforms"])
+    a, b, c = _world(scene, True), _world(scene, True, env=["NH_NO_SLEEPER_SKIP"]), _plain_world(scene)
+    for w in (a, b, c):
+        w.step(420)
+    _same_sleepy_world(a, c, "asleep"); _same_sleepy_world(a, b, "asleep (option off)")
+    order = np.argsort(scene["body_transforms"]["position"][1:, 0], kind="stable") + 1
+    for w in (a, b, c):
+        idle = w.get_bodies()["idle"].copy()
+        idle[order[: (nb - 1) // 3]] = 0
+        w.set_bodies(idle=idle)
+    c0 = a.counts()
+    done = 0
+    for cp in (1, 2, 3, 5, 9, 40, 41, 120):
+        for w in (a, b, c):
+            w.step(cp - done)
+        done = cp
+        _same_sleepy_world(a, c, f"a third awake, step {cp}"); _same_sleepy_world(a, b, f"a third awake, step {cp} (option off)")
+    # the caller wakes a few sleepers between two calls (idle counters rewritten: the library is told)
+    for w in (a, b, c):
+        idle = w.get_bodies()["idle"].copy()
+        idle[order[-40:]] = 0
+        w.set_bodies(idle=idle)
+    for cp in (121, 125, 180, 240, 262, 300, 380, 400):
+        for w in (a, b, c):
+            w.step(cp - done)
+        done = cp
+        _same_sleepy_world(a, c, f"more woken, step {cp}"); _same_sleepy_world(a, b, f"more woken, step {cp} (option off)")
+    c1 = a.counts()
+    print(f"\n[sleeper skip] {c1['still_steps'] - c0['still_steps']} still + {c1['asleep_steps'] - c0['asleep_steps']} asleep steps of {done}; replays {c1['still_replays'] - c0['still_replays']}")
+    assert c1["error"] == 0 and c1["still_steps"] - c0["still_steps"] >= 150, (c0, c1)
+    a.close(); b.close(); c.close()
+
+
 def test_a_sleeper_next_to_an_awake_body_is_not_the_still_steps_business():
     """A sleeping body whose AABB overlaps an awake dynamic body's belongs to a set of more than one body (nudge.cpp:3575-3650): whether it sleeps is not local.  Such a
     step must fail as a still step and be run in full -- the world ends in the bits of the library that never speculates."""
