@@ -916,7 +916,7 @@ def main():
         if cluster is not None:
             st = cluster.p.stats
             out["halo"] = {"backend": backend, "per_step_transport": (("library-driven RCCL inside nh_partition_step (all sub-steps between two refreshes in one call)" if cluster.multi_step else "library-driven RCCL (nh_partition_exchange_step), one call per sub-step") if cluster.direct else f"torch.distributed point-to-point ({cluster.direct_why or 'not asked'})"), "loopback_records_per_step": (cluster.loopback_records / max(1, getattr(cluster, "loopback_steps", 0))) if loopback else None,
-                           "ghost_bodies_rank0": st["ghosts"], "refreshes": st["refreshes"], "migrated_out_rank0": st["migrated_out"],
+                           "ghost_bodies_rank0": st["ghosts"], "refreshes": st["refreshes"], "quiet_refreshes": getattr(cluster, "quiet_refreshes", 0), "migrated_out_rank0": st["migrated_out"],
                            # (bytes and steps over the same window: every step this partition ever took -- `p.steps` is the epoch clock the timed blocks rewind)
                            "bytes_sent_per_step_rank0": st["step_bytes"] / max(1, st["steps_total"]),
                            "loopback_bytes_per_step_through_rccl": (64.0 * cluster.loopback_records / max(1, cluster.loopback_steps)) if (loopback and getattr(cluster, "loopback_steps", 0)) else None}

@@ -383,6 +383,7 @@ typedef struct nh_PartitionInfo {
 	uint32_t ghost_out[2], ghost_in[2];                 /* [0] left neighbour, [1] right neighbour: bodies listed for / received from it at the last refresh */
 	double lo, hi;
 	uint64_t migrated_out, migrated_in, refreshes, cut_moves;
+	uint64_t quiet_refreshes;                           /* refreshes this rank found it did not need (nh_partition_refresh_is_quiet said 1) */
 } nh_PartitionInfo;
 /* `bodies` / `colliders`: the rank's arrays as they are at creation (1 + n_owned bodies; the static colliders, then the dynamic bodies' in slot order, Transform.body = slot). */
 int nh_partition_create(nh_partition** out, nh_context* ctx, const nh_PartitionConfig* config, const nh_BodyData* bodies, const nh_ColliderData* colliders);
@@ -399,6 +400,11 @@ int nh_partition_unpack_migrants(nh_partition* p, const nh_BodyData* bodies, con
    migrates in this refresh then counts on both sides); nh_partition_set_peer_speeds: what the left / right neighbour reported (NAN or <= 0: none).  Both are consumed by the
    next nh_partition_pack_ghosts; a host that never calls them gets margins from this rank's own top speed and `speed_floor` alone -- safe only when the floor bounds the world. */
 int nh_partition_top_speed(nh_partition* p, const nh_BodyData* bodies, double* out);
+/* A QUIET refresh (round 6): *quiet = 1 when a refresh would change nothing on this rank -- no owned body has crossed a cut, and the bodies within reach of a cut (at the
+   speeds of nh_partition_top_speed / nh_partition_set_peer_speeds: call those first; nothing is consumed) are exactly the ones listed for the neighbours at the last
+   refresh, in the same order.  When EVERY rank of the job says so the host may skip the refresh and exchange a per-step halo instead (nudge_amd/partition.py does, with an
+   all-reduce of the answers): the still steps of a world at rest then run through the epoch boundary.  Never 1 before the first refresh.  One stream synchronisation. */
+int nh_partition_refresh_is_quiet(nh_partition* p, const nh_BodyData* bodies, int* quiet);
 int nh_partition_set_peer_speeds(nh_partition* p, double left, double right);
 /* Refresh, phase 2.  pack: the owned bodies within reach of a cut for the coming epoch are listed (the lists are kept for the per-step records) and their full
    records written.  unpack: the received ghosts are installed behind the owned bodies, the collider arrays rebuilt (static ones, then one per dynamic body in

@@ -31,7 +31,7 @@ struct nh_partition {
 	double lo, hi, cut0[2];
 	uint32_t n_owned, n_bodies, n_boxes, n_spheres;
 	uint32_t ghost_out[2], ghost_in[2];
-	uint64_t migrated_out, migrated_in, refreshes, cut_moves;
+	uint64_t migrated_out, migrated_in, refreshes, cut_moves, quiet_refreshes;
 	// body-parallel description of the colliders a dynamic body carries (device, body_capacity entries; NP_MAXC collider slots per body: its boxes first, then its spheres)
 	float4* shape; nh_Transform* cxf; uint32_t* tag; uint8_t* nbx; uint8_t* nsp; float* reach;
 	// lists of the owned slots sent to the left / right neighbour every step (written by pack_ghosts)
@@ -323,7 +323,7 @@ extern "C" int nh_partition_info(nh_partition* p, nh_PartitionInfo* out) {
 	out->n_owned = p->n_owned; out->n_bodies = p->n_bodies; out->n_boxes = p->n_boxes; out->n_spheres = p->n_spheres;
 	out->ghost_out[0] = p->ghost_out[0]; out->ghost_out[1] = p->ghost_out[1]; out->ghost_in[0] = p->ghost_in[0]; out->ghost_in[1] = p->ghost_in[1];
 	out->lo = p->lo; out->hi = p->hi;
-	out->migrated_out = p->migrated_out; out->migrated_in = p->migrated_in; out->refreshes = p->refreshes; out->cut_moves = p->cut_moves;
+	out->migrated_out = p->migrated_out; out->migrated_in = p->migrated_in; out->refreshes = p->refreshes; out->cut_moves = p->cut_moves; out->quiet_refreshes = p->quiet_refreshes;
 	return NH_OK;
 }
 
@@ -394,6 +394,57 @@ extern "C" int nh_partition_set_peer_speeds(nh_partition* p, double left, double
 	if (!p) return NH_ERR_INVALID;
 	p->peer_speed[0] = left == left && left > 0.0 ? left : 0.0;          // (NaN / negative: no neighbour, or none reported)
 	p->peer_speed[1] = right == right && right > 0.0 ? right : 0.0;
+	return NH_OK;
+}
+
+// A QUIET refresh (round 6).  A refresh re-decides who leaves and who is a ghost, ships full records, appends the ghosts again, rebuilds the collider arrays and tells the
+// context that its bodies have changed -- the next sub-step is a full step, the one after it a still step that starts from the transforms.  In a world at rest nothing of
+// that changes anything: nobody has crossed a cut, and the bodies within reach of a cut (at the speeds measured NOW: nh_partition_top_speed / nh_partition_set_peer_speeds
+// first, like before nh_partition_pack_ghosts -- nothing is consumed here) are exactly the ones on this rank's lists, in the same order.  Then the neighbours hold the
+// right ghosts already and a per-step exchange is all this boundary needs.  One kernel chain and one read-back; `quiet` = 1 says so for THIS rank -- the host skips the
+// refresh only when every rank of the job says so (a rank that refreshes re-orders what it sends).
+__global__ __launch_bounds__(256) void k_part_sum_flags(uint32_t n, const uint32_t* __restrict__ f0, const uint32_t* __restrict__ f1, uint32_t* out0, uint32_t* out1) {
+	uint32_t a = 0, b = 0;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { a += f0[i]; b += f1[i]; }
+	for (int d = 32; d >= 1; d >>= 1) { a += (uint32_t)__shfl_xor((int)a, d); b += (uint32_t)__shfl_xor((int)b, d); }
+	if ((threadIdx.x & 63u) == 0u) { if (a) atomicAdd(out0, a); if (b) atomicAdd(out1, b); }
+}
+__global__ __launch_bounds__(256) void k_part_lists_flagged(const uint32_t* __restrict__ list0, uint32_t n0, const uint32_t* __restrict__ list1, uint32_t n1, uint32_t n,
+                                                            const uint32_t* __restrict__ f0, const uint32_t* __restrict__ f1, uint32_t* __restrict__ misses) {
+	uint32_t m = 0;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1; i += gridDim.x * blockDim.x) {
+		const uint32_t b = i < n0 ? list0[i] : list1[i - n0];
+		m += (b >= 1u && b < n && (i < n0 ? f0[b] : f1[b]) != 0u) ? 0u : 1u;
+	}
+	for (int d = 32; d >= 1; d >>= 1) m += (uint32_t)__shfl_xor((int)m, d);
+	if ((threadIdx.x & 63u) == 0u && m) atomicAdd(misses, m);
+}
+extern "C" int nh_partition_refresh_is_quiet(nh_partition* p, const nh_BodyData* bodies, int* quiet) {
+	if (!p || !bodies || !quiet) return NH_ERR_INVALID;
+	*quiet = 0;
+	nh_context* ctx = p->ctx;
+	NP_CHECK(ctx, hipSetDevice(ctx->device));
+	if (p->refreshes == 0u || p->leavers_flagged) return NH_OK;          // (nothing to compare with yet: the first refresh installs ghosts and colliders)
+	{ int rc = nh_flush_pending(ctx); if (rc) return rc; }
+	const uint32_t n = p->n_owned + 1u;
+	const uint32_t has_left = p->cfg.rank > 0u, has_right = p->cfg.rank + 1u < p->cfg.ranks;
+	const double epoch_dt = (double)p->cfg.epoch * p->cfg.time_step;
+	NH_LAUNCH(ctx, "part_reset", k_part_reset, 1, 1, p->d);
+	NH_LAUNCH(ctx, "part_vmax", k_part_vmax, nh_grid_for(n, 256, 1024), 256, n, bodies->momentum, p->d);
+	// (1) nobody leaves: count[0] = bodies beyond either cut
+	NP_LAUNCH("part_flag_leavers", k_part_flag_leavers, n, n, bodies->transforms, (float)p->lo, (float)p->hi, has_left, has_right, p->flag[0], p->flag[1]);
+	NH_LAUNCH(ctx, "part_sum_flags", k_part_sum_flags, nh_grid_for(n, 256, 256), 256, n, p->flag[0], p->flag[1], &p->d->count[0], &p->d->count[0]);
+	// (2) the bodies within reach of a cut are the listed ones: as many (kinds[0 / 1]), and every listed one among them (count[1] = listed bodies that are not)
+	NP_LAUNCH("part_flag_ghosts", k_part_flag_ghosts, n, n, bodies->transforms, p->reach, (float)p->lo, (float)p->hi, has_left, has_right,
+	          p->cfg.max_reach, epoch_dt, p->cfg.speed_floor, fabs(p->cfg.gravity) * epoch_dt, p->d, p->flag[0], p->flag[1], p->speed_pre, p->peer_speed[0], p->peer_speed[1]);
+	NH_LAUNCH(ctx, "part_sum_flags", k_part_sum_flags, nh_grid_for(n, 256, 256), 256, n, p->flag[0], p->flag[1], &p->d->kinds[0], &p->d->kinds[1]);
+	if (p->ghost_out[0] + p->ghost_out[1])
+		NH_LAUNCH(ctx, "part_lists_flagged", k_part_lists_flagged, nh_grid_for(p->ghost_out[0] + p->ghost_out[1], 256, 256), 256, p->list[0], p->ghost_out[0], p->list[1], p->ghost_out[1], n,
+		          p->flag[0], p->flag[1], &p->d->count[1]);
+	int rc = part_read_back(p);
+	if (rc) return rc;
+	*quiet = (p->h->count[0] == 0u && p->h->count[1] == 0u && p->h->kinds[0] == p->ghost_out[0] && p->h->kinds[1] == p->ghost_out[1]) ? 1 : 0;
+	if (*quiet) p->quiet_refreshes++;
 	return NH_OK;
 }
 

@@ -40,7 +40,7 @@ EXPORTS = [
     "nh_update_cached_impulses", "nh_advance", "nh_contact_impulses_device", "nh_enable_timing", "nh_set_timing_filter", "nh_kernel_times",
     "nh_halo_pack", "nh_halo_unpack", "nh_halo_update", "nh_append_contacts", "nh_step", "nh_stream_state", "nh_stream_latest",
     "nh_partition_create", "nh_partition_destroy", "nh_partition_info", "nh_partition_pack_migrants", "nh_partition_unpack_migrants", "nh_partition_pack_ghosts",
-    "nh_partition_top_speed", "nh_partition_set_peer_speeds", "nh_partition_mark_ghosts", "nh_partition_pack_deltas", "nh_partition_unpack_deltas",
+    "nh_partition_top_speed", "nh_partition_set_peer_speeds", "nh_partition_refresh_is_quiet", "nh_partition_mark_ghosts", "nh_partition_pack_deltas", "nh_partition_unpack_deltas",
     "nh_partition_pack_momentum", "nh_partition_unpack_momentum", "nh_partition_exchange_iteration", "nh_partition_unpack_ghosts", "nh_partition_pack_step", "nh_partition_unpack_step", "nh_partition_choose_cut", "nh_partition_set_cut",
     "nh_partition_set_transport", "nh_partition_exchange_step", "nh_partition_step", "nh_partition_transport_check", "nh_partition_transport_result", "nh_set_first_ghost_body",
 ]
@@ -105,7 +105,7 @@ class PartitionConfig(C.Structure):
 
 class PartitionInfo(C.Structure):
     _fields_ = [("n_owned", C.c_uint32), ("n_bodies", C.c_uint32), ("n_boxes", C.c_uint32), ("n_spheres", C.c_uint32), ("ghost_out", C.c_uint32 * 2), ("ghost_in", C.c_uint32 * 2),
-                ("lo", C.c_double), ("hi", C.c_double), ("migrated_out", C.c_uint64), ("migrated_in", C.c_uint64), ("refreshes", C.c_uint64), ("cut_moves", C.c_uint64)]
+                ("lo", C.c_double), ("hi", C.c_double), ("migrated_out", C.c_uint64), ("migrated_in", C.c_uint64), ("refreshes", C.c_uint64), ("cut_moves", C.c_uint64), ("quiet_refreshes", C.c_uint64)]
 
 
 class KernelTime(C.Structure):
@@ -176,6 +176,7 @@ def lib():
         L.nh_partition_unpack_ghosts.argtypes = [C.c_void_p, C.POINTER(BodyData), C.POINTER(ColliderData), C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         L.nh_partition_top_speed.argtypes = [C.c_void_p, C.POINTER(BodyData), C.POINTER(C.c_double)]
         L.nh_partition_set_peer_speeds.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.nh_partition_refresh_is_quiet.argtypes = [C.c_void_p, C.POINTER(BodyData), C.POINTER(C.c_int)]
         L.nh_partition_pack_step.argtypes = [C.c_void_p, C.POINTER(BodyData), C.c_void_p, C.c_void_p]
         L.nh_partition_mark_ghosts.argtypes = [C.c_void_p, C.POINTER(BodyData)]
         L.nh_partition_exchange_iteration.argtypes = [C.c_void_p, C.POINTER(BodyData)]

@@ -458,6 +458,41 @@ class Partition:
             from . import engine as E
             E._check(self.e.L, self.e.L.nh_partition_set_peer_speeds(self.hip, self._peer_speed.get(-1, 0.0), self._peer_speed.get(+1, 0.0)), "nh_partition_set_peer_speeds")
 
+    # ---- refresh: is it needed at all?  (round 6) ---------------------------------------------------------------
+    quiet_refresh = True          # (class switch for A/B and tests: False = every epoch boundary is a refresh, as in rounds 3-5)
+
+    def refresh_is_quiet(self):
+        """Would a refresh change nothing on this rank?  No owned body beyond a cut, and the bodies within reach of a cut -- at the speeds just exchanged (speed_pack /
+        speed_unpack first; nothing is consumed) -- exactly the ones listed for the neighbours at the last refresh, in the same order.  The clusters skip the refresh only
+        when EVERY rank says so: the epoch boundary is then a per-step exchange like any other sub-step, and a world at rest stays in its still steps."""
+        if not self.quiet_refresh or self.steps == 0 or self.per_iteration:
+            return False
+        if self.hip is not None:
+            import ctypes as C
+            from . import engine as E
+            q = C.c_int(0)
+            E._check(self.e.L, self.e.L.nh_partition_refresh_is_quiet(self.hip, C.byref(self.e.bodies), C.byref(q)), "nh_partition_refresh_is_quiet")
+            return bool(q.value)
+        t = self.torch
+        n = self.n_owned + 1
+        x = self._x(n)
+        own = t.arange(n, device=x.device) > 0
+        for d in self.neighbours():
+            if bool((own & ((x < self.lo) if d < 0 else (x >= self.hi))).any()):
+                return False
+        v = self._f32(self.bm[:n])[:, :3].norm(dim=1)
+        vmax = float(v[1:].max()) if n > 1 else 0.0
+        own_speed = max(vmax, getattr(self, "_speed_pre", 0.0), self.speed_floor)
+        peers = getattr(self, "_peer_speed", {})
+        for d in self.neighbours():
+            drift_d = self.epoch * self.dt * (max(own_speed, peers.get(d, 0.0)) + self.gravity * self.epoch * self.dt)
+            margin = self.reach[:n] + (self.max_reach + 2.0 * drift_d)
+            idx = t.nonzero(own & ((x - margin < self.lo) if d < 0 else (x + margin >= self.hi))).flatten()
+            old = self.ghost_out.get(d)
+            if old is None or idx.shape != old.shape or not bool((idx == old).all()):
+                return False
+        return True
+
     # ---- refresh: phase 1 (migration) --------------------------------------------------------------------------
     def refresh_pack_migrants(self):
         if self.hip is not None:
@@ -809,13 +844,20 @@ class LocalCluster:
                 ins = self._route([p.speed_pack() for p in self.parts])
                 for p, i in zip(self.parts, ins):
                     p.speed_unpack(i)
-                ins = self._route([p.refresh_pack_migrants() for p in self.parts])
-                for p, i in zip(self.parts, ins):
-                    p.refresh_unpack_migrants(i)
-                ins = self._route([p.refresh_pack_ghosts() for p in self.parts])
-                for p, i in zip(self.parts, ins):
-                    p.refresh_unpack_ghosts(i)
+                # (a QUIET refresh -- nobody has crossed a cut, every ghost list would come out as it is, on EVERY partition -- is a per-step exchange)
+                refreshed = not all([p.refresh_is_quiet() for p in self.parts])
+                if refreshed:
+                    ins = self._route([p.refresh_pack_migrants() for p in self.parts])
+                    for p, i in zip(self.parts, ins):
+                        p.refresh_unpack_migrants(i)
+                    ins = self._route([p.refresh_pack_ghosts() for p in self.parts])
+                    for p, i in zip(self.parts, ins):
+                        p.refresh_unpack_ghosts(i)
+                else:
+                    self.quiet_refreshes = getattr(self, "quiet_refreshes", 0) + 1
             else:
+                refreshed = False
+            if not refreshed:
                 ins = self._route([p.step_pack() for p in self.parts])
                 for p, i in zip(self.parts, ins):
                     p.step_unpack(i)
@@ -1080,8 +1122,18 @@ class DistCluster:
             p.balance_unpack_counts(self._exchange(p.balance_pack_counts(), 8, known_counts={d: 1 for d in p.neighbours()}))
             p.balance_unpack_cuts(self._exchange(p.balance_pack_cuts(), 8, known_counts=p.balance_expected()))
         p.speed_unpack(self._exchange(p.speed_pack(), 8, known_counts={d: 1 for d in p.neighbours()}))
+        # a QUIET refresh (Partition.refresh_is_quiet): every rank of the job must say so -- one all-reduce of one word -- and the epoch boundary is a per-step exchange
+        if p.quiet_refresh and not p.per_iteration:
+            t, dist = self.torch, self.dist
+            red = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+            flag = t.tensor([1.0 if p.refresh_is_quiet() else 0.0], device=red)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            if flag.item() > 0.5:
+                self.quiet_refreshes = getattr(self, "quiet_refreshes", 0) + 1
+                return False
         p.refresh_unpack_migrants(self._exchange(p.refresh_pack_migrants(), FULL_BYTES))
         p.refresh_unpack_ghosts(self._exchange(p.refresh_pack_ghosts(), FULL_BYTES))
+        return True
 
     def step(self, steps=1):
         import time
@@ -1093,7 +1145,7 @@ class DistCluster:
                 t_0 = time.perf_counter()
                 refreshing = p.needs_refresh()
                 if refreshing:
-                    self._refresh()
+                    refreshing = self._refresh()          # (False: a quiet one -- the boundary is a per-step exchange inside the library call below)
                     self.t_refresh += time.perf_counter() - t_0; self.n_refresh += 1
                 n = min(left, p.epoch - (p.steps % p.epoch))
                 t_1 = time.perf_counter()
@@ -1108,8 +1160,11 @@ class DistCluster:
         for _ in range(steps):
             t_0 = time.perf_counter()
             refreshing = p.needs_refresh()
+            boundary = refreshing
             if refreshing:
-                self._refresh()
+                refreshing = self._refresh()
+            if refreshing:
+                pass
             elif self.direct:
                 import ctypes as C
                 from . import engine as E
@@ -1119,7 +1174,7 @@ class DistCluster:
                 self._fast_step_exchange()
             else:
                 p.step_unpack(self._exchange(p.step_pack(), STEP_BYTES, known_counts={d: p.ghost_in[d] for d in p.neighbours()}))
-            if refreshing:
+            if boundary:
                 self.t_refresh += time.perf_counter() - t_0; self.n_refresh += 1
             else:
                 self.t_halo += time.perf_counter() - t_0; self.n_halo += 1

@@ -214,7 +214,9 @@ def test_partition_kernels_behind_the_c_abi_match_the_torch_implementation(spher
         for x, y in zip(pa, pb):
             # (who is listed as a ghost may differ for a body exactly at the margin: reach and top speed are rounded differently by torch.norm and by the kernels)
             assert x.n_owned == y.n_owned and abs(x.stats["ghosts"] - y.stats["ghosts"]) <= 4, (upto, x.stats, y.stats)
-    assert sum(p.stats["ghosts"] for p in pa) > 0 and pa[0].stats["refreshes"] >= 20
+    # (round 6: a boundary at which nothing would change is a per-step exchange -- both clusters must skip the same ones)
+    assert getattr(ca, "quiet_refreshes", 0) == getattr(cb, "quiet_refreshes", 0) >= 3, (getattr(ca, "quiet_refreshes", 0), getattr(cb, "quiet_refreshes", 0))
+    assert sum(p.stats["ghosts"] for p in pa) > 0 and pa[0].stats["refreshes"] + getattr(ca, "quiet_refreshes", 0) >= 20
     for q in pa + pb:
         assert q.e.counts()["error"] == 0
         q.close() if hasattr(q, "close") else None
@@ -387,6 +389,8 @@ def test_sub_steps_in_one_library_call_with_ghosts_arriving_through_the_transpor
     scene = S.grid_tiles(2, side=24, seed=91, lattice_cols=2)
     c1, p1 = _cluster(scene, 2, epoch=64, flags=BENCH)
     c2, p2 = _cluster(scene, 2, epoch=64, flags=BENCH)
+    for p in p1 + p2:
+        p.quiet_refresh = False          # (this test's timeline counts on the refresh at step 64 -- its full step ends the back-off of the landing; quiet refreshes: the tests above)
     c1.step(100); c2.step(100)          # landed and at rest; refreshes at steps 0 and 64, the next one at 128
     recorded = []
     orig = p1[1].step_pack

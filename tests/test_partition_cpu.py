@@ -62,6 +62,73 @@ def test_partitions_in_one_process_match_single_world(ranks, sphere_fraction):
     _check_against_single_world(scene, cl.gather(), steps)
 
 
+def _run_local(scene, ranks, steps, quiet, epoch=8):
+    import partition_util as PU
+    cuts = _cuts_through(scene, ranks)
+    parts = []
+    for r in range(ranks):
+        local, info = PT.split_scene(scene, cuts, r, min_extra=512)
+        p = PT.Partition(PU.OracleEngine(local, info["capacity"]), info, epoch=epoch)
+        p.quiet_refresh = quiet
+        parts.append(p)
+    cl = PT.LocalCluster(parts)
+    cl.step(steps)
+    return cl, parts
+
+
+def test_a_quiet_refresh_is_skipped_and_changes_nothing():
+    """Round 6.  At an epoch boundary at which no body has crossed a cut and every ghost list would come out as it is -- on every partition -- the refresh is a per-step
+    exchange (Partition.refresh_is_quiet).  A world that falls, lands and rests: the boundaries at which nothing would change are skipped; the union is what it is
+    with every boundary a refresh, bit for bit."""
+    scene = _drop_scene()
+    steps = 240
+    cl_q, parts_q = _run_local(scene, 2, steps, True)
+    cl_r, parts_r = _run_local(scene, 2, steps, False)
+    a, b = cl_q.gather(), cl_r.gather()
+    assert np.array_equal(a["ids"], b["ids"])
+    for k in ("transforms", "momentum"):
+        assert a[k].tobytes() == b[k].tobytes(), k
+    assert np.array_equal(a["idle"], b["idle"])
+    skipped = getattr(cl_q, "quiet_refreshes", 0)
+    assert skipped >= 5 and getattr(cl_r, "quiet_refreshes", 0) == 0, skipped
+    assert parts_q[0].stats["refreshes"] + skipped == parts_r[0].stats["refreshes"], (parts_q[0].stats["refreshes"], skipped, parts_r[0].stats["refreshes"])
+    assert parts_q[0].stats["refreshes"] >= 1          # (the first one installs the ghosts; boundaries with migrants or growing lists: test_bodies_migrate_across_the_cut, which runs with the switch on)
+
+
+def _gloo_quiet_worker(rank, world, port, steps, out_path):
+    import torch.distributed as dist
+    import partition_util as PU
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scene = _drop_scene()
+    cuts = _cuts_through(scene, world)
+    local, info = PT.split_scene(scene, cuts, rank, min_extra=512)
+    part = PT.Partition(PU.OracleEngine(local, info["capacity"]), info, epoch=8)
+    cl = PT.DistCluster(part)
+    cl.step(steps)
+    got = cl.gather(dst=0)
+    if rank == 0:
+        np.savez(out_path, ids=got["ids"], transforms=got["transforms"], momentum=got["momentum"], idle=got["idle"], quiet=np.int64(getattr(cl, "quiet_refreshes", 0)),
+                 refreshes=np.int64(part.stats["refreshes"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_quiet_refreshes_under_gloo_are_the_in_process_run(tmp_path):
+    """Two gloo ranks agree on every boundary with one all-reduce: the same refreshes skipped as in one process, the same bits."""
+    import torch.multiprocessing as mp
+    steps = 240
+    out = str(tmp_path / "quiet.npz")
+    port = 29500 + (os.getpid() % 2000) + 41
+    mp.spawn(_gloo_quiet_worker, args=(2, port, steps, out), nprocs=2, join=True)
+    z = np.load(out)
+    cl, parts = _run_local(_drop_scene(), 2, steps, True)
+    g = cl.gather()
+    assert np.array_equal(z["ids"], g["ids"]) and z["transforms"].tobytes() == g["transforms"].tobytes() and z["momentum"].tobytes() == g["momentum"].tobytes()
+    assert int(z["quiet"]) == getattr(cl, "quiet_refreshes", 0) >= 5 and int(z["refreshes"]) == parts[0].stats["refreshes"]
+
+
 def test_bodies_migrate_across_the_cut():
     """A layer flying sideways: bodies cross the cut, change owner (first ghost, then owned), and while nothing has landed
     yet the union is BIT-identical to the single world; after the sliding impact the slot-order effect (see above,
