@@ -167,7 +167,11 @@ struct nh_AheadView { const uint32_t* body_col; const nh_Transform* box_xf; cons
                       struct nh_Record* rec; nh_Contact* raw_data; uint32_t* raw_feature; uint32_t* cnt_sorted; int2* delta; uint32_t unowned_cap, delta_scan; };
 struct nh_FusedStep { float gx_dt, gy_dt, gz_dt, damping, time_step; uint32_t bits; uint8_t* idle; uint32_t seq, guard_seq;
                       uint32_t ghost_first;
-                      uint32_t* host_counters; };      // (nh_step, late verdicts: where the launch's first thread leaves the step's counters for the host -- pinned memory; nullptr: the host copies them itself)      // (nh_partition_step: bodies from here on are ghosts -- their lanes solve and advance them but leave the next step's transforms and pairs alone: the ghost arrives anew)
+                      uint32_t* host_counters;
+                      // HALO SPLIT (nh_partition_step, round 6): the solver of a pair step as TWO launches on two streams -- the bodies a neighbour waits for (listed for it, its
+                      // ghosts here, the rehearsal's loop-back records: `xlist`, *xcount of them, part = 1) and everybody else (part = 2: `xskip` marks the listed ones) -- so that
+                      // the halo of the next sub-step travels while the interior is still being solved
+                      uint32_t part; const uint32_t* xlist; const uint32_t* xcount; const uint8_t* xskip; };      // (nh_step, late verdicts: where the launch's first thread leaves the step's counters for the host -- pinned memory; nullptr: the host copies them itself)      // (nh_partition_step: bodies from here on are ghosts -- their lanes solve and advance them but leave the next step's transforms and pairs alone: the ghost arrives anew)
 //      // (still steps: this step's sequence number; the
                                                                                                                                     // oldest still step whose verdict the host has not seen)
 
@@ -460,6 +464,13 @@ struct nh_context {
 	// nh_partition_step (nh_partition.hip): K sub-steps of a slab in one nh_step call -- before every sub-step's nh_collide the library calls the hook, which enqueues the
 	// per-step halo exchange (and, for a step that starts further down the chain, the ghosts' transforms); halo_ghost_first: the first ghost body while such a call runs
 	int (*step_hook)(nh_context* ctx, void* user, uint32_t sub_step); void* step_hook_user; uint32_t halo_ghost_first;
+	// HALO SPLIT (nh_partition_step; nh_FusedStep::part): armed by the partition for the duration of a call -- the boundary bodies' list / count / mask, the second stream, and
+	// what to enqueue on it once a pair step's verdict is in (the next sub-step's exchange: it then travels beside the interior's solver).  `launched`: this step's solver went
+	// out in two parts
+	struct { bool armed, launched; hipStream_t stream; const uint32_t* list; const uint32_t* count; const uint8_t* mask; uint32_t bound;
+	         int (*after_verdict)(nh_context* ctx, void* user); void* user; } halo_split;
+	bool halo_overlap;             // option "halo_overlap" (OFF by default: bit-exact, and no faster in the one-rank rehearsal -- profiles/r06_halo_split_ab.log): nh_partition_step sends the
+	                               // next sub-step's halo beside the interior's solver instead of between two sub-steps
 	nh_AsleepState asleep;
 	uint32_t first_ghost;          // nh_set_first_ghost_body: bodies >= first_ghost are ghosts of a partitioned world (0 = no ownership rule)
 	nh_StateStream stream_state;
@@ -642,6 +653,8 @@ void nh_bucket_sort_seed(nh_context* ctx, const uint64_t* sorted_keys, uint32_t 
 // Exclusive scan of `in[0..n)` into `out` (may alias); n read from *d_count (+ `extra` elements);
 // the grand total is also stored to *d_total if non-null.  `tmp` needs 2 * NH_SORT_GRID words.
 // If `d_enable` is given and *d_enable == 0 the scan is skipped on the device (the total is reported as 0).
+void nh_halo_pack_on(hipStream_t stream, const nh_BodyData* bodies, const uint32_t* indices, uint32_t count, void* out);          // nh_solve.hip
+void nh_halo_update_on(hipStream_t stream, const nh_BodyData* bodies, uint32_t first_slot, uint32_t count, const void* in);
 void nh_scan_u32(nh_context* ctx, const uint32_t* in, uint32_t* out, const uint32_t* d_count, uint32_t extra,
                  uint32_t* tmp, uint32_t* d_total, const uint32_t* d_enable = nullptr);
 // the same for two arrays of equal length in one pair of launches

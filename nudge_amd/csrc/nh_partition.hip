@@ -57,6 +57,12 @@ struct nh_partition {
 	// nh_partition_step: the arrays of the call in progress (the hook needs them), whether its first sub-step is preceded by a per-step exchange, loop-back records (one-rank rehearsal)
 	const nh_StepArgs* step_args; uint32_t step_exchange_first, step_loopback;
 	void* loop_out; void* loop_in; uint32_t* loop_idx; uint32_t loop_cap;
+	// HALO SPLIT (round 6): the bodies a neighbour waits for -- listed for it, its ghosts here, the rehearsal's loop-back records -- are solved by a
+	// launch of their own on `split_stream`; once the step's verdict is in, the NEXT sub-step's exchange is enqueued behind them and travels beside the interior's solver
+	// (nh_internal.h: nh_FusedStep::part).  `exchanged_ahead`: the hook of the next sub-step finds its halo in place and only joins the streams
+	hipStream_t split_stream; hipEvent_t split_done; uint32_t* split_list; uint32_t* split_count; uint8_t* split_mask; uint32_t split_list_cap, split_mask_cap;
+	bool exchanged_ahead, no_overlap;
+	uint64_t overlapped_exchanges;
 };
 
 #define NP_CHECK(ctx, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (ctx)->last_hip_error = (int)e_; return NH_ERR_HIP; } } while (0)
@@ -312,8 +318,10 @@ extern "C" void nh_partition_destroy(nh_partition* p) {
 	hipStreamSynchronize(p->ctx->stream);
 	for (int side = 0; side < 2; ++side) { if (p->step_out[side]) hipFree(p->step_out[side]); if (p->step_in[side]) hipFree(p->step_in[side]); }
 	void* bufs[] = { p->shape, p->cxf, p->tag, p->nbx, p->nsp, p->reach, p->list[0], p->list[1], p->flag[0], p->flag[1], p->scan_tmp, p->sort_a, p->sort_b, p->sort_va, p->sort_vb, p->sort_hist, p->stage, p->d, p->ghost_ref,
-	                 p->loop_out, p->loop_in, p->loop_idx };
+	                 p->loop_out, p->loop_in, p->loop_idx, p->split_list, p->split_count, p->split_mask };
 	for (void* b : bufs) if (b) hipFree(b);
+	if (p->split_stream) { hipStreamSynchronize(p->split_stream); hipStreamDestroy(p->split_stream); }
+	if (p->split_done) hipEventDestroy(p->split_done);
 	if (p->h) hipHostFree(p->h);
 	delete p;
 }
@@ -828,10 +836,134 @@ __global__ __launch_bounds__(256) void k_xform_ghosts(nh_DevState* __restrict__ 
 
 __global__ __launch_bounds__(256) void k_part_iota(uint32_t* idx, uint32_t n) { for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) idx[i] = i + 1u; }
 
+static int part_loop_buffers(nh_partition* p, uint32_t m) {
+	nh_context* ctx = p->ctx;
+	if (p->loop_cap >= m) return NH_OK;
+	if (p->loop_out) { NP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); if (p->split_stream) NP_CHECK(ctx, hipStreamSynchronize(p->split_stream)); (void)hipFree(p->loop_out); (void)hipFree(p->loop_in); (void)hipFree(p->loop_idx); }
+	p->loop_out = p->loop_in = nullptr; p->loop_idx = nullptr; p->loop_cap = 0;
+	NP_CHECK(ctx, hipMalloc(&p->loop_out, (size_t)m * NH_HALO_RECORD_BYTES)); NP_CHECK(ctx, hipMalloc(&p->loop_in, (size_t)m * NH_HALO_RECORD_BYTES));
+	NP_CHECK(ctx, hipMalloc((void**)&p->loop_idx, sizeof(uint32_t) * (size_t)m));
+	hipLaunchKernelGGL(k_part_iota, dim3(nh_grid_for(m, 256, 256)), dim3(256), 0, ctx->stream, p->loop_idx, m);
+	p->loop_cap = m;
+	return NH_OK;
+}
+
+// ---- HALO SPLIT (round 6; nh_internal.h: nh_FusedStep::part; option "halo_overlap", OFF by default) ---------------------------------------------
+// (Built, bit-exact through the recording transport and the c5 world, and in the one-rank rehearsal -- 4096 records per sub-step to this rank and back through RCCL -- no
+// faster than the exchange between two sub-steps: 0.535-0.538 against 0.529-0.534 ms per 2 M bodies, profiles/r06_halo_split_ab.log.  On one GPU there is no link latency
+// to hide, and 25 us of pack / RCCL / unpack are what two more launches and a second stream cost.  Kept for a node where the exchange crosses xGMI.)
+// The exchange used to sit BETWEEN two solver launches: pack -> RCCL -> unpack -> the ghosts' transforms, ~30 us in which the GPU did nothing else.  A pair step's solver
+// now goes out in two parts behind the step's prologue: the bodies a neighbour waits for (listed for it, its ghosts here, the rehearsal's loop-back records) on a second
+// stream, everybody else on the context's.  When the verdict is in -- the step happened -- the NEXT sub-step's exchange is enqueued behind the boundary launch and travels
+// beside the interior's solver; the next sub-step's hook only joins the two streams.  Nothing an interior lane touches is touched by the exchange (a one-body lane reads
+// and writes its own body, collider and record), and a ghost's lane has finished before its owner's state lands on it.
+__global__ __launch_bounds__(256) void k_part_mark_list(const uint32_t* __restrict__ list, uint32_t n, uint32_t nbodies, uint8_t* __restrict__ mask) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const uint32_t b = list[i]; if (b >= 1u && b < nbodies) mask[b] = 1; }
+}
+__global__ __launch_bounds__(256) void k_part_mark_range(uint32_t first, uint32_t n, uint32_t nbodies, uint8_t* __restrict__ mask) {
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) if (first + i < nbodies) mask[first + i] = 1;
+}
+__global__ __launch_bounds__(256) void k_part_mask_to_list(const uint8_t* __restrict__ mask, uint32_t nbodies, uint32_t* __restrict__ list, uint32_t cap, uint32_t* __restrict__ count) {
+	for (uint32_t b = 1u + blockIdx.x * blockDim.x + threadIdx.x; b < nbodies; b += gridDim.x * blockDim.x)
+		if (mask[b]) { const uint32_t k = atomicAdd(count, 1u); if (k < cap) list[k] = b; }
+}
+static int part_after_verdict(nh_context* ctx, void* user);
+static int part_arm_split(nh_partition* p, uint32_t loopback) {
+	nh_context* ctx = p->ctx;
+	ctx->halo_split.armed = false; ctx->halo_split.launched = false; p->exchanged_ahead = false;
+	if (!ctx->halo_overlap || !p->rccl.comm || !(ctx->flags & NH_FLAG_FUSED_STEP)) return NH_OK;
+	const uint32_t m = loopback ? (loopback < p->n_owned ? loopback : p->n_owned) : 0u;
+	const uint32_t n_ghost = p->ghost_in[0] + p->ghost_in[1];
+	const uint32_t bound = m + p->ghost_out[0] + p->ghost_out[1] + n_ghost;
+	if (!bound) return NH_OK;
+	if (!p->split_stream) { NP_CHECK(ctx, hipStreamCreateWithFlags(&p->split_stream, hipStreamNonBlocking)); NP_CHECK(ctx, hipEventCreateWithFlags(&p->split_done, hipEventDisableTiming)); }
+	if (p->split_mask_cap < p->n_bodies || p->split_list_cap < bound || !p->split_count) {
+		NP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); NP_CHECK(ctx, hipStreamSynchronize(p->split_stream));
+		if (p->split_mask) (void)hipFree(p->split_mask); if (p->split_list) (void)hipFree(p->split_list);
+		p->split_mask = nullptr; p->split_list = nullptr; p->split_mask_cap = p->split_list_cap = 0;
+		NP_CHECK(ctx, hipMalloc((void**)&p->split_mask, (size_t)p->cfg.body_capacity + 64u)); p->split_mask_cap = p->cfg.body_capacity;
+		NP_CHECK(ctx, hipMalloc((void**)&p->split_list, sizeof(uint32_t) * ((size_t)bound + bound / 2u + 64u))); p->split_list_cap = bound + bound / 2u;
+		if (!p->split_count) NP_CHECK(ctx, hipMalloc((void**)&p->split_count, 64));
+	}
+	if (m) { int rc = part_loop_buffers(p, m); if (rc) return rc; }
+	for (int side = 0; side < 2; ++side) {
+		if (p->ghost_out[side]) { int rc = part_step_buffer(p, side, 0, p->ghost_out[side]); if (rc) return rc; }
+		if (p->ghost_in[side]) { int rc = part_step_buffer(p, side, 1, p->ghost_in[side]); if (rc) return rc; }
+	}
+	NP_CHECK(ctx, hipMemsetAsync(p->split_mask, 0, p->n_bodies, ctx->stream));
+	NP_CHECK(ctx, hipMemsetAsync(p->split_count, 0, sizeof(uint32_t), ctx->stream));
+	if (m) hipLaunchKernelGGL(k_part_mark_range, dim3(nh_grid_for(m, 256, 256)), dim3(256), 0, ctx->stream, 1u, m, p->n_bodies, p->split_mask);
+	for (int side = 0; side < 2; ++side) if (p->ghost_out[side])
+		hipLaunchKernelGGL(k_part_mark_list, dim3(nh_grid_for(p->ghost_out[side], 256, 256)), dim3(256), 0, ctx->stream, p->list[side], p->ghost_out[side], p->n_bodies, p->split_mask);
+	if (n_ghost) hipLaunchKernelGGL(k_part_mark_range, dim3(nh_grid_for(n_ghost, 256, 256)), dim3(256), 0, ctx->stream, p->n_owned + 1u, n_ghost, p->n_bodies, p->split_mask);
+	hipLaunchKernelGGL(k_part_mask_to_list, dim3(nh_grid_for(p->n_bodies, 256, 1024)), dim3(256), 0, ctx->stream, p->split_mask, p->n_bodies, p->split_list, p->split_list_cap, p->split_count);
+	ctx->halo_split.stream = p->split_stream; ctx->halo_split.list = p->split_list; ctx->halo_split.count = p->split_count; ctx->halo_split.mask = p->split_mask; ctx->halo_split.bound = bound;
+	ctx->halo_split.after_verdict = part_after_verdict; ctx->halo_split.user = p;
+	ctx->halo_split.armed = true;
+	return NH_OK;
+}
+
+static void part_xform_ghosts(nh_partition* p, hipStream_t stream) {
+	nh_context* ctx = p->ctx;
+	const nh_BodyData* bodies = p->step_args->bodies;
+	const nh_ColliderData* cd = p->step_args->colliders;
+	const uint32_t n_ghost = p->ghost_in[0] + p->ghost_in[1], first = p->n_owned + 1u;
+	hipLaunchKernelGGL(k_xform_ghosts, dim3(nh_grid_for(n_ghost, 256, 256)), dim3(256), 0, stream, ctx->d_state, first, bodies->count, bodies->transforms, bodies->idle_counters,
+	                   p->nbx, p->nsp, p->flag[0], p->flag[1], p->cfg.n_static_box, p->cfg.n_static_sph, cd->boxes.count,
+	                   cd->boxes.transforms, cd->boxes.data, cd->spheres.transforms, cd->spheres.data,
+	                   reinterpret_cast<float4*>(ctx->own_xf), ctx->own_aabb_min, ctx->own_aabb_max, ctx->fat_box, ctx->step_parity ^ 1u, ctx->collide_seq + 1u);
+}
+
+// the verdict of a pair step whose solver went out in two parts is in, and it is "happened": the next sub-step's exchange, behind the boundary launch on its stream
+static int part_after_verdict(nh_context* ctx, void* user) {
+	nh_partition* p = static_cast<nh_partition*>(user);
+	const nh_BodyData* bodies = p->step_args->bodies;
+	hipStream_t s = p->split_stream;
+	const uint32_t m = p->step_loopback ? (p->step_loopback < p->n_owned ? p->step_loopback : p->n_owned) : 0u;
+	const uint32_t n_ghost = p->ghost_in[0] + p->ghost_in[1];
+	int nccl_rc = 0;
+	if (p->ghost_out[0] | p->ghost_out[1] | n_ghost) {
+		for (int side = 0; side < 2; ++side) nh_halo_pack_on(s, bodies, p->list[side], p->ghost_out[side], p->step_out[side]);
+		nccl_rc = p->rccl.group_start();
+		if (nccl_rc) { ctx->last_hip_error = -nccl_rc; return NH_ERR_HIP; }
+		for (int side = 0; side < 2 && !nccl_rc; ++side) {
+			const int peer = p->rccl.peer[side];
+			if (peer < 0) continue;
+			if (p->ghost_out[side]) nccl_rc = p->rccl.send(p->step_out[side], (size_t)p->ghost_out[side] * NH_HALO_RECORD_BYTES, 1, peer, p->rccl.comm, s);
+			if (!nccl_rc && p->ghost_in[side]) nccl_rc = p->rccl.recv(p->step_in[side], (size_t)p->ghost_in[side] * NH_HALO_RECORD_BYTES, 1, peer, p->rccl.comm, s);
+		}
+		{ const int end_rc = p->rccl.group_end(); if (!nccl_rc) nccl_rc = end_rc; }
+		if (nccl_rc) { ctx->last_hip_error = -nccl_rc; return NH_ERR_HIP; }
+		uint32_t at = p->n_owned + 1u;
+		nh_halo_update_on(s, bodies, at, p->ghost_in[0], p->step_in[0]); at += p->ghost_in[0];
+		nh_halo_update_on(s, bodies, at, p->ghost_in[1], p->step_in[1]);
+	}
+	if (m) {
+		nh_halo_pack_on(s, bodies, p->loop_idx, m, p->loop_out);
+		nccl_rc = p->rccl.group_start();
+		if (nccl_rc) { ctx->last_hip_error = -nccl_rc; return NH_ERR_HIP; }
+		const int self_peer = p->rccl.peer[1] >= 0 ? p->rccl.peer[1] : (int)p->cfg.rank;
+		nccl_rc = p->rccl.send(p->loop_out, (size_t)m * NH_HALO_RECORD_BYTES, 1, self_peer, p->rccl.comm, s);
+		if (!nccl_rc) nccl_rc = p->rccl.recv(p->loop_in, (size_t)m * NH_HALO_RECORD_BYTES, 1, self_peer, p->rccl.comm, s);
+		{ const int end_rc = p->rccl.group_end(); if (!nccl_rc) nccl_rc = end_rc; }
+		if (nccl_rc) { ctx->last_hip_error = -nccl_rc; return NH_ERR_HIP; }
+		nh_halo_update_on(s, bodies, 1u, m, p->loop_in);
+	}
+	if (ctx->still.ahead_ready && n_ghost && ctx->own_xf) part_xform_ghosts(p, s);
+	NP_CHECK(ctx, hipEventRecord(p->split_done, s));
+	p->exchanged_ahead = true; p->overlapped_exchanges++;
+	return NH_OK;
+}
+
 static int part_step_hook(nh_context* ctx, void* user, uint32_t sub_step) {
 	nh_partition* p = static_cast<nh_partition*>(user);
 	const nh_BodyData* bodies = p->step_args->bodies;
-	const nh_ColliderData* cd = p->step_args->colliders;
+	if (p->exchanged_ahead) {
+		// (halo split: this sub-step's halo left while the last one's interior was being solved -- the context's stream waits for it to have landed, that is all)
+		p->exchanged_ahead = false;
+		NP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, p->split_done, 0));
+		return NH_OK;
+	}
 	// what the step before this one left for it (xform ahead): known BEFORE the exchange's entry points run -- they complete deferred work and look like a caller from outside
 	const bool ahead = ctx->still.ahead_ready, pair = ctx->still.pair_ready;
 	if (sub_step > 0u || p->step_exchange_first) {
@@ -839,14 +971,7 @@ static int part_step_hook(nh_context* ctx, void* user, uint32_t sub_step) {
 		if (p->step_loopback && p->rccl.comm) {
 			// one-rank rehearsal: the first `step_loopback` owned bodies' records through the transport to this same rank and back onto themselves (the same bits)
 			const uint32_t m = p->step_loopback < p->n_owned ? p->step_loopback : p->n_owned;
-			if (p->loop_cap < m) {
-				if (p->loop_out) { NP_CHECK(ctx, hipStreamSynchronize(ctx->stream)); (void)hipFree(p->loop_out); (void)hipFree(p->loop_in); (void)hipFree(p->loop_idx); }
-				p->loop_out = p->loop_in = nullptr; p->loop_idx = nullptr; p->loop_cap = 0;
-				NP_CHECK(ctx, hipMalloc(&p->loop_out, (size_t)m * NH_HALO_RECORD_BYTES)); NP_CHECK(ctx, hipMalloc(&p->loop_in, (size_t)m * NH_HALO_RECORD_BYTES));
-				NP_CHECK(ctx, hipMalloc((void**)&p->loop_idx, sizeof(uint32_t) * (size_t)m));
-				hipLaunchKernelGGL(k_part_iota, dim3(nh_grid_for(m, 256, 256)), dim3(256), 0, ctx->stream, p->loop_idx, m);
-				p->loop_cap = m;
-			}
+			{ int rc = part_loop_buffers(p, m); if (rc) return rc; }
 			{ int rc = nh_halo_pack(ctx, bodies, p->loop_idx, m, p->loop_out); if (rc) return rc; }
 			int nccl_rc = p->rccl.group_start();
 			if (nccl_rc) { ctx->last_hip_error = -nccl_rc; return NH_ERR_HIP; }
@@ -862,13 +987,7 @@ static int part_step_hook(nh_context* ctx, void* user, uint32_t sub_step) {
 	// rehearsal, bodies that got their own bits back) has changed
 	ctx->still.ahead_ready = ahead; ctx->still.pair_ready = pair;
 	const uint32_t n_ghost = p->ghost_in[0] + p->ghost_in[1];
-	if (ahead && n_ghost && ctx->own_xf) {
-		const uint32_t first = p->n_owned + 1u;
-		NH_LAUNCH(ctx, "xform_ghosts", k_xform_ghosts, nh_grid_for(n_ghost, 256, 256), 256, ctx->d_state, first, bodies->count, bodies->transforms, bodies->idle_counters,
-		          p->nbx, p->nsp, p->flag[0], p->flag[1], p->cfg.n_static_box, p->cfg.n_static_sph, cd->boxes.count,
-		          cd->boxes.transforms, cd->boxes.data, cd->spheres.transforms, cd->spheres.data,
-		          reinterpret_cast<float4*>(ctx->own_xf), ctx->own_aabb_min, ctx->own_aabb_max, ctx->fat_box, ctx->step_parity ^ 1u, ctx->collide_seq + 1u);
-	}
+	if (ahead && n_ghost && ctx->own_xf) part_xform_ghosts(p, ctx->stream);
 	return NH_OK;
 }
 
@@ -882,8 +1001,14 @@ extern "C" int nh_partition_step(nh_partition* p, const nh_StepArgs* args, uint3
 	p->step_args = args; p->step_exchange_first = exchange_first; p->step_loopback = loopback_records;
 	ctx->step_hook = part_step_hook; ctx->step_hook_user = p;
 	ctx->halo_ghost_first = (p->ghost_in[0] + p->ghost_in[1]) ? p->n_owned + 1u : 0u;
+	{ int rc = part_arm_split(p, loopback_records); if (rc) { ctx->step_hook = nullptr; ctx->step_hook_user = nullptr; ctx->halo_ghost_first = 0u; p->step_args = nullptr; return rc; } }
 	const int rc = nh_step(ctx, args, steps);
 	ctx->step_hook = nullptr; ctx->step_hook_user = nullptr; ctx->halo_ghost_first = 0u;
+	if (ctx->halo_split.armed) {
+		// (the call's last sub-step is never split; an exchange still in flight here belongs to a call that ended in an error)
+		if (p->exchanged_ahead || ctx->halo_split.launched) { (void)hipStreamSynchronize(p->split_stream); p->exchanged_ahead = false; }
+		ctx->halo_split.armed = false; ctx->halo_split.launched = false;
+	}
 	p->step_args = nullptr;
 	return rc;
 }

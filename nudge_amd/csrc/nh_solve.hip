@@ -876,7 +876,7 @@ struct nh_StillView { const uint32_t* body_rec; const uint32_t* body_pos; const 
 // transform, AABB, the test against the inflated box, scene bounds, largest idle counter -- with k_xform's own arithmetic (nh_collide.hip: k_xform, k_asleep_check).
 // PAIR (AHEAD only; nh_internal.h: pair ahead): ... and the next step's NARROWPHASE for the body's one kept pair, from what the lane holds in registers and the static
 // partner's transform, box and shape: contacts into the record's raw slots, count into its place in the tag order, a change of the count onto the next step's list.
-template<int MAXC, bool FUSED, bool CONTIG = false, int NW = 4, bool STILL = false, bool AHEAD = false, bool PAIR = false>
+template<int MAXC, bool FUSED, bool CONTIG = false, int NW = 4, bool STILL = false, bool AHEAD = false, bool PAIR = false, bool PART = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC == 4 ? NH_SOLVER_WPE : 1, MAXC == 4 ? NH_SOLVER_WPE : 1))) void k_solve_one_body(uint32_t nbodies, const uint8_t* __restrict__ body_class, const uint32_t* __restrict__ off, const uint32_t* __restrict__ adj,
                                                         const nh_BodyPair* __restrict__ bodies, const nh_BodyProperties* __restrict__ props, nh_BodyMomentum* __restrict__ momentum,
                                                         float4* __restrict__ states, uint32_t iterations,
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		if (!inert && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&const_cast<nh_DevState*>(cv.st)->still_failed_seq, fs.seq);
 		if (!inert || cv.st->still_failed_seq >= fs.guard_seq) {
 			// (the verdict the host is waiting for: see below)
-			if (fs.host_counters && blockIdx.x == 0 && threadIdx.x == 0) {
+			if (fs.host_counters && blockIdx.x == 0 && threadIdx.x == 0 && !(PART && fs.part == 1u)) {
 				const volatile uint32_t* src = reinterpret_cast<const volatile uint32_t*>(cv.st);
 #pragma unroll
 				for (uint32_t k = 0; k < NH_COUNTER_WORDS; ++k) fs.host_counters[k] = src[k];
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		// shifts its record's start by the changes BEFORE it in the tag order.  (More changes than the list holds: the scan has run instead, nothing to shift.)
 		n_delta = cv.st->delta_overflow[sv.parity] ? 0u : min(cv.st->delta_count[sv.parity], NH_DELTA_MAX);
 		for (uint32_t k = threadIdx.x; k < n_delta; k += blockDim.x) s_delta[k] = sv.delta[sv.parity * NH_DELTA_MAX + k];
-		if (blockIdx.x == 0 && threadIdx.x == 0) {
+		if (blockIdx.x == 0 && threadIdx.x == 0 && !(PART && fs.part == 1u)) {          // (halo split: the interior launch does what a step does once)
 			// the contact count of the step = the total behind the last record: kept like the starts
 			const uint32_t nrec = cv.st->records;
 			int shift = 0;
@@ -960,7 +960,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 	const uint32_t rounded = (nbodies + (64u * NW - 1u)) / (64u * NW) * (64u * NW);
 	// block-uniform trip count; the CONTIG launch covers every body with one pass (no loop: nothing is carried in registers across iterations)
 	uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-	if (x >= rounded) return;
+	if (PART && fs.part == 1u) {
+		// (the listed bodies, in whatever order the list was made: a lane is a body wherever it sits; lanes behind the list's end stand on the static world, nobody's)
+		const uint32_t cnt_listed = *fs.xcount;
+		x = x < cnt_listed ? fs.xlist[x] : 0u;
+	}
+	else if (x >= rounded) return;
 	do {
 		// Two memory round trips per body, not one per dependent step: (1) class, contact-list record and cache hint -- unconditional loads at a
 		// clamped index, a few bytes wasted on bodies of other classes; (2) everything per contact for all slots at once -- contact, tag, feature,
@@ -979,7 +984,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		if (AHEAD) col = av.body_col[xc];
 		if (!inert_word) return;
 		// (STILL: a body asleep -- only a step in sleepers form gets this far with one -- is nobody's: no gravity, no contacts, no advance, nothing stored; nudge.cpp:3669-3703, 4896-4898)
-		const bool mine = STILL ? (x >= 1u && x < nbodies && idle0 != 0xffu) : (x < nbodies && (my_class == cls_a || my_class == cls_b));
+		bool mine = STILL ? (x >= 1u && x < nbodies && idle0 != 0xffu) : (x < nbodies && (my_class == cls_a || my_class == cls_b));
+		if (PART && fs.part == 2u && fs.xskip[xc] != 0u) mine = false;          // (solved by the boundary launch)
 		const uint32_t wave_x0 = x - lane;
 		uint32_t b = 0, cnt = 0;
 		// (a wave none of whose 64 bodies is of the kernel's classes -- a ball pit, where four million bodies are the blocked solver's and a handful sit alone on the
@@ -3019,6 +3025,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 		          (float4*)d->states, iterations, ctx->raw_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fs, sv, nh_AheadView())
 			// XFORM AHEAD (nh_internal.h): another sub-step of this nh_step call follows, the step is in the plain form and every dynamic body has its one collider on the
 			// map -- the lanes do the next step's k_xform<true> on their way out
+			ctx->halo_split.launched = false;          // (this step's solver has not gone out in two parts yet)
 			const bool ahead = ss.ahead_plain && ss.more_steps && ss.ahead_map_ok && !ss.no_ahead && !ss.ahead_world_bad && ctx->env_solver_waves != 4 && ctx->env_solver_waves != 2 &&
 			                   ctx->own_xf && ctx->body_col && ctx->body_col_capacity >= B;
 			// PAIR AHEAD (nh_internal.h): ... and the next sub-step's narrowphase for the body's own pair -- that sub-step then starts at the solver
@@ -3034,7 +3041,21 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 				nh_AheadView av = { ctx->body_col, cd.boxes.transforms, cd.boxes.data, cd.spheres.transforms, cd.spheres.data, cd.boxes.count, ctx->own_xf, ctx->own_aabb_min, ctx->own_aabb_max, ctx->fat_box,
 				                    ctx->fat_pairs, ctx->fat_pair_capacity, ctx->lay_capacity, ctx->sort_keys_by_position, ctx->own_ctag, gen,
 				                    ctx->rec, ctx->raw_data, ctx->raw_feature, ctx->cnt_sorted, ctx->still_delta, ctx->pair_list_capacity, C > (2u << 20) ? 1u : 0u };
-				if (pair)
+				// HALO SPLIT (nh_partition_step): the bodies the neighbours wait for on a second stream, behind the step's prologue like the interior -- the exchange of the NEXT
+				// sub-step is enqueued behind them once the verdict is in (below) and travels while the interior is being solved
+				const bool split = pair && ctx->halo_split.armed && ss.early_verdict && ss.steps_left > 0u && !ctx->timing && ctx->halo_split.bound != 0u;
+				if (split) {
+					nh_FusedStep fi = fs, fb = fs;
+					fi.part = 2u; fi.xskip = ctx->halo_split.mask;
+					fb.part = 1u; fb.xlist = ctx->halo_split.list; fb.xcount = ctx->halo_split.count; fb.host_counters = nullptr;
+					NH_LAUNCH(ctx, "solve_still", (k_solve_one_body<4, true, true, 1, true, true, true, true>), (B + 63u) / 64u, 64, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
+					          (float4*)d->states, iterations, ctx->raw_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fi, sv, av);
+					NH_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->halo_split.stream, ss.ev_ring[0], 0));          // (the counters' copy behind k_pair_begin: the prologue has run)
+					hipLaunchKernelGGL((k_solve_one_body<4, true, true, 1, true, true, true, true>), dim3((ctx->halo_split.bound + 63u) / 64u), dim3(64), 0, ctx->halo_split.stream,
+					                   B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
+					                   (float4*)d->states, iterations, ctx->raw_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fb, sv, av);
+					ctx->halo_split.launched = true;
+				} else if (pair)
 				NH_LAUNCH(ctx, "solve_still", (k_solve_one_body<4, true, true, 1, true, true, true>), (B + 63u) / 64u, 64, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum,
 				          (float4*)d->states, iterations, ctx->raw_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, 2u, d->simple, fs, sv, av);
 				else
@@ -3077,8 +3098,11 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 					memcpy(ctx->h_state, h, NH_COUNTER_WORDS * sizeof(uint32_t));
 					if (!ctx->idle_unknown) { ctx->idle_bound = (int)h->max_idle[ctx->step_parity]; ctx->idle_bound_mark = ctx->collide_mark; }
 					still_note_movers(ctx, h, ctx->collide_seq);
+					// (halo split: the step happened -- what the neighbours get of it may leave now, behind the boundary launch on its stream)
+					if (ctx->halo_split.launched && ctx->halo_split.after_verdict) { int rc = ctx->halo_split.after_verdict(ctx, ctx->halo_split.user); if (rc) return rc; }
 				} else {
 					NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));          // (the solver has left at once; the replay starts from a quiet stream like every other)
+					if (ctx->halo_split.launched) { NH_HIP_CHECK(ctx, hipStreamSynchronize(ctx->halo_split.stream)); ctx->halo_split.launched = false; }
 				}
 			} else {
 				// the step's one round trip: did every check hold?
@@ -3470,6 +3494,14 @@ static int halo_unpack(nh_context* ctx, const nh_BodyData* bodies, uint32_t firs
 	if (count && !same_bodies) { ctx->idle_bound = -1; ctx->idle_unknown = true; }             // idle counters arrive from another world: nothing is known about them until the next nh_collide has looked
 	if (count) NH_LAUNCH(ctx, "halo_unpack", k_halo_unpack, nh_grid_for(count, 256, 1024), 256, bodies->transforms, bodies->momentum, bodies->idle_counters, first_slot, count, (const nh_HaloRecord*)in);
 	return NH_OK;
+}
+
+// (the two kernels on a stream of the caller's choice, nothing completed, nothing noted: nh_partition_step's exchange beside the interior's solver -- halo split)
+void nh_halo_pack_on(hipStream_t stream, const nh_BodyData* bodies, const uint32_t* indices, uint32_t count, void* out) {
+	if (count) hipLaunchKernelGGL(k_halo_pack, dim3(nh_grid_for(count, 256, 1024)), dim3(256), 0, stream, bodies->transforms, bodies->momentum, bodies->idle_counters, indices, count, (nh_HaloRecord*)out);
+}
+void nh_halo_update_on(hipStream_t stream, const nh_BodyData* bodies, uint32_t first_slot, uint32_t count, const void* in) {
+	if (count) hipLaunchKernelGGL(k_halo_unpack, dim3(nh_grid_for(count, 256, 1024)), dim3(256), 0, stream, bodies->transforms, bodies->momentum, bodies->idle_counters, first_slot, count, (const nh_HaloRecord*)in);
 }
 
 // ---- nh_step: the sample's sub-step loop (example/main.cpp:274-328) as one entry point ----------------------------------------------------------------------

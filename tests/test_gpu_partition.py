@@ -377,7 +377,8 @@ def test_deltas_against_a_mark_of_other_ghosts_are_refused():
         p.e.close()
 
 
-def test_sub_steps_in_one_library_call_with_ghosts_arriving_through_the_transport():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_sub_steps_in_one_library_call_with_ghosts_arriving_through_the_transport(overlap):
     """nh_partition_step (round 6): K sub-steps of a slab in ONE library call, the per-step halo enqueued by the library between them.  The chain of still steps (xform
     ahead, pair ahead) then runs through a partitioned world -- for the OWNED bodies; what a rank computes for a ghost is not what its owner computes, so ghosts' lanes
     leave the next step alone, k_xform_ghosts transforms their colliders when the halo has arrived and k_pair_begin evaluates their pairs.
@@ -413,12 +414,16 @@ def test_sub_steps_in_one_library_call_with_ghosts_arriving_through_the_transpor
     send = XFER(lambda buf, count, dtype, peer, comm, stream: 0)
 
     def recv_fn(buf, count, dtype, peer, comm, stream):
-        msg = recorded[played[0]]
         played[0] += 1
+        msg = recorded[played[0] - 1]
         assert count == msg.numel()
         return hip.hipMemcpyAsync(buf, msg.data_ptr(), count, 3, stream)          # hipMemcpyDeviceToDevice, on the library's stream
     recv = XFER(recv_fn)
     q = p2[0]
+    # (overlap: option "halo_overlap" -- the solver of a pair step in two launches, the bodies the neighbour waits for on a second stream and the next sub-step's halo behind
+    # them, beside the interior's solver: the same recording, one message per sub-step, the same bits)
+    if overlap:
+        q.e.set_option("halo_overlap", 1)
     L = q.e.L
     L.nh_partition_set_transport.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int]
     E._check(L, L.nh_partition_set_transport(q.hip, C.c_void_p(1), C.cast(group, C.c_void_p), C.cast(group, C.c_void_p), C.cast(send, C.c_void_p), C.cast(recv, C.c_void_p), -1, 1), "set_transport")
