@@ -72,6 +72,9 @@ extern "C" int nh_create(nh_context** out, int device, void* stream, uint32_t fl
 	if (hipMalloc((void**)&ctx->d_state, sizeof(nh_DevState)) != hipSuccess) { delete ctx; return NH_ERR_HIP; }
 	if (hipHostMalloc((void**)&ctx->h_state, sizeof(nh_DevState), 0) != hipSuccess) { hipFree(ctx->d_state); delete ctx; return NH_ERR_HIP; }
 	memset(ctx->h_state, 0, sizeof(nh_DevState));
+	ctx->h_early = nullptr; ctx->no_early_counts = false; ctx->early_reads = 0; ctx->early_fallbacks = 0;
+	if (hipHostMalloc((void**)&ctx->h_early, sizeof(uint32_t) * (NH_COUNTER_WORDS + 16u), 0) != hipSuccess) { ctx->h_early = nullptr; (void)hipGetLastError(); }
+	else memset(ctx->h_early, 0, sizeof(uint32_t) * (NH_COUNTER_WORDS + 16u));
 	ctx->side = nullptr; ctx->ev_fork = nullptr; ctx->ev_join = nullptr; ctx->ev_active = nullptr; ctx->ev_gravity = nullptr; ctx->gravity_may_overlap = false;
 	if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
 	    hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_active, hipEventDisableTiming) != hipSuccess ||
@@ -138,6 +141,7 @@ extern "C" void nh_destroy(nh_context* ctx) {
 	}
 	if (ctx->d_state) hipFree(ctx->d_state);
 	if (ctx->h_state) hipHostFree(ctx->h_state);
+	if (ctx->h_early) hipHostFree(ctx->h_early);
 	delete ctx;
 }
 
@@ -168,6 +172,7 @@ extern "C" int nh_set_option(nh_context* ctx, const char* name, int value) {
 	else if (n == "sync_exports_views") ctx->sync_exports_views = on;          // legacy observers: nh_synchronize / nh_read_counts end with nh_export_views(NH_VIEW_ALL) like they did before round 5 (note 9)
 	else if (n == "fused_fail_in") ctx->fused.debug_fail_in = (uint32_t)value;   // TEST HOOK: the value-th fused launch from now raises the failure flag at its very end (rollback exercised on purpose)
 	else if (n == "fused_still") ctx->fused.enabled = on;                      // plain still steps inside nh_step as ONE out-of-place kernel with a look-back (nh_fused.hip): bit-exact, measured SLOWER, off by default
+	else if (n == "no_early_counts") ctx->no_early_counts = on;                // a full step's counters by a copy behind its solver, not by the solver's first thread (nh_internal.h: early counters; A/B, tests)
 	else if (n == "no_sleeper_skip") ctx->still.no_sleeper_skip = on;          // the sleepers form of a still step does all its work for sleeping bodies too (nh_internal.h; A/B, tests)
 	else if (n == "halo_overlap") ctx->halo_overlap = on;                      // nh_partition_step: the next sub-step's halo beside the interior's solver, on a second stream (nh_internal.h: halo split; measured: no gain on one GPU)
 	else if (n == "no_pair_ahead") ctx->still.no_pair = on;                    // every still step launches its narrowphase (nh_internal.h: pair ahead; A/B, tests)

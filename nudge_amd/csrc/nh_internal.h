@@ -350,6 +350,12 @@ struct nh_context {
 	uint32_t tag_bits;
 	nh_DevState* d_state;
 	nh_DevState* h_state;          // pinned mirror
+	// EARLY COUNTERS (round 6): a full step's counters are final when its one-body solver STARTS (nothing in that kernel writes them), so the launch's first thread leaves
+	// them in this pinned block -- NH_COUNTER_WORDS words, then the nh_collide number as the word that says "complete" -- and the host, polling that word, has them
+	// while the solver runs: what it launches next queues up behind the solver instead of behind a copy and a wake-up on an idle GPU (26 us of a 550 us step).
+	uint32_t* h_early;             // pinned, NH_COUNTER_WORDS + 16 words; nullptr: could not be had, the host copies
+	bool no_early_counts;          // option "no_early_counts" (A/B, tests): the copy behind the solver, as before
+	uint64_t early_reads, early_fallbacks;      // round trips answered by the solver's first thread / by the copy after all (the stream ran dry without the word)
 	int last_hip_error;
 	// timing
 	bool timing;
@@ -539,6 +545,7 @@ struct nh_ContactConstraintData {
 	uint32_t level_off[NH_MAX_LEVELS + 2];// host copy of level offsets
 	uint32_t level_full[NH_MAX_LEVELS + 2];// host copy: the level / colour class holds a full (40-float) row, not only radial ones
 	uint32_t levels;
+	uint32_t early_seq;                   // early counters (nh_context::h_early): the one-body launch of this setup leaves the step's counters for the host under this number; 0: it does not
 	uint32_t general_contacts;
 	uint32_t contact_capacity;
 	uint32_t body_count;

@@ -18,6 +18,8 @@
 #include "nh_internal.h"
 int nh_asleep_remember(nh_context* ctx);            // nh_collide.hip (asleep steps: nh_internal.h)
 #include <type_traits>
+#include <atomic>
+#include <string.h>
 #include "nh_solver.h"
 #include "nh_narrowphase.h"          // (PAIR AHEAD: the still solver's lanes evaluate their bodies' own collider pairs for the next sub-step)
 
@@ -951,6 +953,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 			}
 		}
 		__syncthreads();
+	}
+	if (!STILL && fs.host_counters && blockIdx.x == 0 && threadIdx.x == 0) {
+		// EARLY COUNTERS (nh_internal.h): nothing in a full step's one-body solver writes the step's counters -- they are final as this launch starts.  Its first thread leaves them
+		// in the host's pinned block, then the nh_collide number behind them (a release at system scope: whoever sees the number sees the words); the host polls that word
+		const volatile uint32_t* src = reinterpret_cast<const volatile uint32_t*>(cv.st);
+#pragma unroll
+		for (uint32_t k = 0; k < NH_COUNTER_WORDS; ++k) fs.host_counters[k] = src[k];
+		__threadfence_system();
+		__hip_atomic_store(fs.host_counters + NH_COUNTER_WORDS, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 	const uint32_t wave = threadIdx.x >> 6, lane = nh_lane();
 	nh_ob_slot* slot = s_slot[wave];
@@ -2744,6 +2755,29 @@ static void still_note_movers(nh_context* ctx, const nh_DevState* h, uint32_t se
 	ss.seen_inserts = h->fat_inserts; ss.seen_rebuilds = h->fat_rebuilds;
 }
 
+// EARLY COUNTERS (nh_internal.h): the counters the launch numbered `seq` left in the pinned block as it started.  The host polls the word behind them; should the stream run dry
+// without it (a launch that never happened) the ordinary copy answers instead -- nothing can hang here that could not hang in hipStreamSynchronize
+static int read_counts_early(nh_context* ctx, nh_Counts* out, uint32_t seq) {
+	volatile uint32_t* const flag = ctx->h_early + NH_COUNTER_WORDS;
+	bool seen = false;
+	for (uint32_t spins = 0; ; ++spins) {
+		if (*flag == seq) { seen = true; break; }
+		if ((spins & 255u) == 255u) {
+			const hipError_t q = hipStreamQuery(ctx->stream);
+			if (q == hipSuccess) { seen = *flag == seq; break; }          // (everything enqueued has run: the word is there, or the launch was not)
+			if (q != hipErrorNotReady) { ctx->last_hip_error = (int)q; return NH_ERR_HIP; }
+		}
+		__builtin_ia32_pause();
+	}
+	if (!seen) { ctx->early_fallbacks++; return nh_read_counts(ctx, out); }
+	ctx->gravity_may_overlap = false; ctx->after_collide = false;          // (as nh_read_counts leaves them)
+	std::atomic_thread_fence(std::memory_order_acquire);
+	memcpy(ctx->h_state, ctx->h_early, NH_COUNTER_WORDS * sizeof(uint32_t));
+	ctx->early_reads++;
+	nh_counts_from_mirror(ctx, out);
+	return NH_OK;
+}
+
 static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 	nh_DevState* st = ctx->d_state;
 	const nh_ContactData* contacts = &d->cont.contacts;
@@ -2754,8 +2788,10 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 	uint32_t* slot_key = d->cont.slot_key; uint32_t* level_hist = d->cont.level_hist; uint32_t* level_cursor = d->cont.level_cursor;
 	uint32_t* general_list = d->general_list;
 	// one round trip: body classes, whether anything sleeps, whether the general adjacency build has work
+	// (early counters, nh_internal.h: the speculative one-body launch before this call has them on their way to the host as it STARTS -- the solver runs on while the host reads)
 	nh_Counts c;
-	int rc = nh_read_counts(ctx, &c);
+	int rc = d->early_seq ? read_counts_early(ctx, &c, d->early_seq) : nh_read_counts(ctx, &c);
+	d->early_seq = 0u;
 	if (rc) return rc;
 	if (c.error) return (int)c.error;
 	d->has_late = ctx->h_state->has_pending != 0;
@@ -3145,6 +3181,12 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 #define NH_SOLVE_CONTIG(NWAVES) NH_LAUNCH(ctx, "solve_one_body", (k_solve_one_body<4, true, true, NWAVES>), (B + 64u * NWAVES - 1u) / (64u * NWAVES), 64 * NWAVES, B, d->body_class, d->body_off, d->adj, d->bodies, bodies->properties, bodies->momentum, \
 		          (float4*)d->states, iterations, d->contact_data, bodies->transforms, d->impulses, cv, ctx->hint, NH_CLS_STATIC4, NH_CLS_STATIC4, \
 		          1u | (drop_states ? 2u : 0u), d->simple, fs, nh_StillView(), nh_AheadView())
+		// (early counters: not with EVERY launch timed -- the events of a step are collected at its round trip, when they must have happened; timing restricted to one kernel, what
+		// bench.py keeps on, collects at nh_kernel_times -- and not under the legacy observer contract, whose round trips do more than read)
+		d->early_seq = 0u;
+		if (ctx->h_early && !ctx->no_early_counts && B != 0u && !(ctx->timing && ctx->timing_filter.empty()) && !ctx->sync_exports_views && !(ctx->flags & NH_FLAG_SYNC_COUNTS)) {
+			fs.host_counters = ctx->h_early; fs.seq = ctx->collide_seq; d->early_seq = ctx->collide_seq;
+		}
 		if (ctx->env_solver_waves == 4) NH_SOLVE_CONTIG(4); else if (ctx->env_solver_waves == 2) NH_SOLVE_CONTIG(2); else NH_SOLVE_CONTIG(1);
 		ctx->grav.rest_pending = gravity_here;        // everybody else's gravity: finish_setup, once the round trip has told whether there is anybody else
 		int rc = finish_setup(ctx, d);

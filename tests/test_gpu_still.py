@@ -403,6 +403,29 @@ def test_what_the_sleepers_form_skips_changes_nothing():
     a.close(); b.close(); c.close()
 
 
+def test_early_counters_change_nothing():
+    """Round 6.  A full step's counters are final when its one-body solver starts; the launch's first thread leaves them in pinned memory and the host, polling, reads them
+    while the solver runs (nh_internal.h: early counters) instead of copying them behind it.  Which of the two the host does must not show anywhere: a drop scene through
+    fall, rest and sleep in full steps, a pile (general contacts: the round trips after the first stay copies) and the speculating default, each against the same
+    library with option no_early_counts -- bodies, idle counters, contacts, cache, counters bit for bit, in calls of one and of many steps."""
+    for scene, cps in ((S.grid_tiles(2, side=32, sphere_fraction=0.5, seed=83, lattice_cols=2), (1, 2, 30, 60, 61, 100, 200, 330, 420)),
+                       (S.pile(n_boxes=300, n_spheres=60, seed=9, iterations=8), (1, 2, 3, 40, 41, 120))):
+        a, b = _plain_world(scene), _plain_world(scene)
+        b.set_option("no_early_counts", 1)
+        c, d = _world(scene, True), _world(scene, True, env=["NH_NO_EARLY_COUNTS"])
+        done = 0
+        for cp in cps:
+            for w in (a, b, c, d):
+                w.step(cp - done)
+            done = cp
+            _same_sleepy_world(a, b, f"{scene['name']} full steps, step {cp}")
+            _same_sleepy_world(c, d, f"{scene['name']} default, step {cp}")
+            _same_sleepy_world(a, c, f"{scene['name']} default against full steps, step {cp}")
+        assert a.counts()["error"] == 0
+        for w in (a, b, c, d):
+            w.close()
+
+
 def test_a_sleeper_next_to_an_awake_body_is_not_the_still_steps_business():
     """A sleeping body whose AABB overlaps an awake dynamic body's belongs to a set of more than one body (nudge.cpp:3575-3650): whether it sleeps is not local.  Such a
     step must fail as a still step and be run in full -- the world ends in the bits of the library that never speculates."""
