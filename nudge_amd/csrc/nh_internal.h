@@ -242,7 +242,7 @@ struct nh_StillStep {
 	// counters it looks at has long landed), and the GPU never waits for the host.  A still step that failed did nothing, nor did the one launched behind it (their
 	// solvers compare st->still_failed_seq with `guard`): nh_step runs both again, the first in full.
 	bool pipelined;                 // inside nh_step
-	struct { bool pending; uint32_t seq, parity; int slot; uint64_t collide_mark; } verdict;      // the still step whose counters the host has not looked at yet
+	struct { bool pending; uint32_t seq, parity; int slot; uint64_t collide_mark; bool self_report; } verdict;      // the still step whose counters the host has not looked at yet (self_report: the solver's first thread left them in the ring slot, its number behind them -- the host may poll for that word instead of waiting for the launch to END: early counters)
 	nh_DevState* h_ring[2]; hipEvent_t ev_ring[2];      // pinned landing places of the counter copies, and when they have landed
 	bool ring_failed;                                    // ... could not be created: nh_step looks at every verdict inside its step
 	nh_ContactConstraintData* setup_d;      // its nh_setup_contact_constraints has run (without the adjacency kernel the replay then owes)

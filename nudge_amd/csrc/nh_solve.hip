@@ -908,6 +908,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 				const volatile uint32_t* src = reinterpret_cast<const volatile uint32_t*>(cv.st);
 #pragma unroll
 				for (uint32_t k = 0; k < NH_COUNTER_WORDS; ++k) fs.host_counters[k] = src[k];
+				__threadfence_system();
+				__hip_atomic_store(fs.host_counters + NH_COUNTER_WORDS, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);          // (early counters: the word the host may poll for)
 			}
 			return;
 		}
@@ -950,6 +952,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 				const volatile uint32_t* src = reinterpret_cast<const volatile uint32_t*>(cv.st);
 #pragma unroll
 				for (uint32_t k = 0; k < NH_COUNTER_WORDS; ++k) fs.host_counters[k] = src[k];
+				// (early counters: ... and this step's number behind them, released at system scope -- the host that waits for the LAST verdict of an nh_step call polls for
+				// it and returns while this launch runs: the caller's next call queues up behind it instead of behind a wake-up)
+				__threadfence_system();
+				__hip_atomic_store(fs.host_counters + NH_COUNTER_WORDS, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 			}
 		}
 		__syncthreads();
@@ -3119,6 +3125,7 @@ static int first_apply(nh_context* ctx, nh_ContactConstraintData* d, const nh_Bo
 				if (!self_report) NH_HIP_CHECK(ctx, hipMemcpyAsync(ss.h_ring[slot], ctx->d_state, NH_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 				NH_HIP_CHECK(ctx, hipEventRecord(ss.ev_ring[slot], ctx->stream));
 				ss.verdict.pending = true; ss.verdict.seq = ctx->collide_seq; ss.verdict.parity = ctx->step_parity; ss.verdict.slot = slot; ss.verdict.collide_mark = ctx->collide_mark;
+				ss.verdict.self_report = self_report && !ctx->halo_split.launched;
 				ss.verdict_fused = ss.fused;
 				confirmed = true;          // (until the next step says otherwise)
 			} else if (ss.early_verdict) {
@@ -3554,8 +3561,20 @@ int nh_still_verdict_now(nh_context* ctx) {
 	// the pending verdict, waited for: 0 confirmed, 1 failed
 	nh_StillStep& ss = ctx->still;
 	if (!ss.verdict.pending) return 0;
-	if (hipEventSynchronize(ss.ev_ring[ss.verdict.slot]) != hipSuccess) return 1;
 	const nh_DevState* h = ss.h_ring[ss.verdict.slot];
+	bool seen = false;
+	if (ss.verdict.self_report && !ctx->no_early_counts && !(ctx->timing && ctx->timing_filter.empty())) {
+		// early counters (nh_internal.h): the step's solver left counters and number in the ring slot as it STARTED -- everything a still step can fail on was decided by
+		// then -- so the call's last verdict does not wait for the launch to end (the event is the fallback: a launch that never ran writes no number)
+		volatile const uint32_t* const flag = reinterpret_cast<volatile const uint32_t*>(h) + NH_COUNTER_WORDS;
+		for (uint32_t spins = 0; ; ++spins) {
+			if (*flag == ss.verdict.seq) { seen = true; break; }
+			if ((spins & 255u) == 255u && hipEventQuery(ss.ev_ring[ss.verdict.slot]) != hipErrorNotReady) break;
+			__builtin_ia32_pause();
+		}
+		if (seen) { std::atomic_thread_fence(std::memory_order_acquire); ctx->early_reads++; }
+	}
+	if (!seen && hipEventSynchronize(ss.ev_ring[ss.verdict.slot]) != hipSuccess) return 1;
 	ss.verdict.pending = false;
 	if (h->still_failed_seq >= ss.verdict.seq || h->error) return 1;
 	ss.confirmed_seq = ss.verdict.seq;
