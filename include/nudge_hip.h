@@ -254,7 +254,7 @@ int nh_set_pair_capacity(nh_context* ctx, uint32_t pairs);
    environment.  Names (value 0 / 1 unless noted): "no_still", "no_kept_pairs", "no_incremental", "no_sort_reuse", "sort_classic", "sort_radix", "bucket_tile" (n),
    "bucket_target" (n), "colour_jp", "colour_check_seeds", "no_resident", "solver_waves" (1, 2, 4), "fp_sub" (0, 1, 2, 4, 16), "cooperative", "no_blocks", "blk_check",
    "blk_min" (n), "blk_target" (n), "blk_rows_global", "blk_global_colours", "blk_profile", "no_asleep", "no_blk_chain", "no_local_still", "no_xform_ahead",
-   "no_pair_ahead", "no_sleeper_skip", "no_early_counts", "halo_overlap" (1 = on), "fused_still", "fused_fail_in" (n: test hook), "sync_exports_views".  Unknown name: NH_ERR_INVALID.  Call right after nh_create.
+   "no_pair_ahead", "no_sleeper_skip", "no_sleeper_ahead", "no_early_counts", "halo_overlap" (1 = on), "fused_still", "fused_fail_in" (n: test hook), "sync_exports_views".  Unknown name: NH_ERR_INVALID.  Call right after nh_create.
    (nudge_amd/engine.py maps environment variables NH_<NAME> onto these calls for its tests: a convenience of that host, not of the library.) */
 int nh_set_option(nh_context* ctx, const char* name, int value);
 const char* nh_error_string(int code);

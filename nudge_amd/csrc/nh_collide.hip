@@ -1345,7 +1345,8 @@ __global__ __launch_bounds__(256) void k_ahead_map(nh_DevState* __restrict__ st,
 		if (b) body_col[b] = c;          // (several colliders of one body: any of them wins, k_ahead_check sees the others)
 	}
 }
-__global__ __launch_bounds__(256) void k_ahead_check(nh_DevState* __restrict__ st, const float4* __restrict__ aabb_min, uint32_t n, const uint32_t* __restrict__ body_col) {
+// (`idle`: sleepers ahead -- a collider of a body asleep is nobody's lane's either: its share is taken here, with the static world's, while the sleeping set stands still)
+__global__ __launch_bounds__(256) void k_ahead_check(nh_DevState* __restrict__ st, const float4* __restrict__ aabb_min, uint32_t n, const uint32_t* __restrict__ body_col, const uint8_t* __restrict__ idle = nullptr) {
 	__shared__ uint32_t red[6];
 	if (threadIdx.x < 3) { red[threadIdx.x] = 0xffffffffu; red[3 + threadIdx.x] = 0u; }
 	__syncthreads();
@@ -1354,7 +1355,7 @@ __global__ __launch_bounds__(256) void k_ahead_check(nh_DevState* __restrict__ s
 	for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
 		const float4 mn = aabb_min[c];
 		const uint32_t b = __float_as_uint(mn.w);
-		if (b) { multi |= body_col[b] != c; continue; }
+		if (b) { multi |= body_col[b] != c; if (!(idle && idle[b] == 0xffu)) continue; }
 		uint32_t f;
 		f = nh_float_flip(mn.x); lmin[0] = min(lmin[0], f); lmax[0] = max(lmax[0], f);
 		f = nh_float_flip(mn.y); lmin[1] = min(lmin[1], f); lmax[1] = max(lmax[1], f);
@@ -1379,11 +1380,13 @@ __global__ __launch_bounds__(256) void k_pair_mark(const uint32_t* __restrict__ 
 		if (br != NH_BODY_REC_NONE) mark[br & ~NH_BODY_REC_IS_A] = stamp;
 	}
 }
-__global__ __launch_bounds__(256) void k_pair_list(nh_DevState* __restrict__ st, const uint32_t* __restrict__ mark, uint32_t stamp, uint32_t* __restrict__ list, uint32_t cap) {
+// (`rec`: a world with sleepers -- the record of a sleeping pair is nobody's either, a sleeping body has no contact-list record, but nobody has to evaluate it: it stays what it is
+// while its body sleeps, and a body that wakes does so in a full step, after which the list is made again)
+__global__ __launch_bounds__(256) void k_pair_list(nh_DevState* __restrict__ st, const uint32_t* __restrict__ mark, uint32_t stamp, uint32_t* __restrict__ list, uint32_t cap, const nh_Record* __restrict__ rec = nullptr) {
 	const uint32_t n = st->records;
 	for (uint32_t r0 = blockIdx.x * blockDim.x; r0 < n; r0 += gridDim.x * blockDim.x) {
 		const uint32_t r = r0 + threadIdx.x;
-		const bool mine = r < n && mark[r] != stamp;
+		const bool mine = r < n && mark[r] != stamp && !(rec && rec[r].count == NH_REC_SLEEPING);
 		const uint32_t slot = nh_wave_reserve1(&st->pair_unowned, mine);
 		if (mine && slot < cap) list[slot] = r;
 	}
@@ -1401,7 +1404,9 @@ __global__ __launch_bounds__(256) void k_pair_begin(nh_DevState* __restrict__ st
                                                     const uint64_t* __restrict__ rec_key, nh_Record* __restrict__ rec,
                                                     const uint32_t* __restrict__ lay_rank, uint32_t* __restrict__ cnt_sorted, const uint32_t* __restrict__ body_rec, int2* __restrict__ delta,
                                                     nh_Contact* __restrict__ raw_data, uint32_t* __restrict__ raw_feature,
-                                                    const nh_BodyMomentum* __restrict__ momentum, const nh_BodyProperties* __restrict__ props, uint32_t delta_scan) {
+                                                    const nh_BodyMomentum* __restrict__ momentum, const nh_BodyProperties* __restrict__ props, uint32_t delta_scan,
+                                                    // sleepers ahead (nh_internal.h): the number of bodies of a world with sleepers in it -- the step's sleeper counts are the last step's
+                                                    uint32_t sleepers_bodies = 0u) {
 	const uint32_t lane = nh_lane();
 	uint32_t fr_min[3], fr_max[3], fr_top;
 	{
@@ -1433,7 +1438,15 @@ __global__ __launch_bounds__(256) void k_pair_begin(nh_DevState* __restrict__ st
 			if (!(mscale >= 0.75f * scale_was)) atomicAdd(&st->pair_diag[2], 1u);
 			if (n_list > list_cap) atomicAdd(&st->pair_diag[3], 1u);
 			for (int k = 0; k < 3; ++k) { st->still_smin[parity][k] = fr_min[k]; st->still_smax[parity][k] = fr_max[k]; }
-			st->max_idle[parity] = fr_top;
+			uint32_t top = fr_top;
+			if (sleepers_bodies) {
+				// (nobody fell asleep or woke since the last step -- that step's lanes would have failed this one: k_solve_one_body<.., AHEAD> -- so what a k_xform<true> and a
+				// narrowphase in sleepers form would count now is what they counted then; the solver's first thread turns the parity words into the step's counters)
+				const uint32_t asleep = (sleepers_bodies - 1u) - min(st->active, sleepers_bodies - 1u);
+				st->still_asleep[parity] = asleep; st->still_sleeping[parity] = st->sleeping; st->still_culled[parity] = st->culled;
+				if (asleep) top = 0xffu;
+			}
+			st->max_idle[parity] = top;
 			// what k_xform<true> does for the step after this one
 			st->max_idle[op] = 0u; st->delta_count[op] = 0u; st->delta_overflow[op] = 0u; st->still_esc[op] = 0u;
 			st->still_asleep[op] = 0u; st->still_sleeping[op] = 0u; st->still_culled[op] = 0u;
@@ -1441,6 +1454,7 @@ __global__ __launch_bounds__(256) void k_pair_begin(nh_DevState* __restrict__ st
 			st->still_fat0 = st->fat_count + st->fat_count_sph;
 		}
 		for (uint32_t k = lane; k < NH_AHEAD_PARTS * 8u; k += 64u) (&st->ahead_part[op][0][0])[k] = (k & 7u) < 3u ? 0xffffffffu : 0u;
+		if (sleepers_bodies) for (uint32_t k = lane; k < NH_SLEEP_PARTS * 2u; k += 64u) (&st->sleep_part[parity][0][0])[k] = 0u;          // (no narrowphase adds to them in such a step)
 	}
 	// ---- the kept pairs that are nobody's: exact boxes, stamps, roles by Morton order, contact arithmetic -- and the verdict: no contact, the key on file ----
 	const uint32_t n_bb = min(st->pairs, pair_cap);
@@ -1449,6 +1463,7 @@ __global__ __launch_bounds__(256) void k_pair_begin(nh_DevState* __restrict__ st
 	bool changed = false;
 	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < min(n_list, list_cap); j += gridDim.x * blockDim.x) {
 		const uint32_t r = list[j];
+		if (sleepers_bodies && rec[r].count == NH_REC_SLEEPING) continue;          // (a listed pair whose body has fallen asleep since: a settled sleeping pair, nobody's business)
 		const uint2 kp = r < n_bb ? kept[r] : kept[kept_cap - 1u - (r - n_bb)];
 		const uint32_t ca = kp.x & index_mask, cb = kp.y & index_mask;
 		const float4 amin = aabb_min[ca], amax = aabb_max[ca], bmin = aabb_min[cb], bmax = aabb_max[cb];
@@ -2224,12 +2239,16 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			xf = ctx->own_xf; aabb_min = ctx->own_aabb_min; aabb_max = ctx->own_aabb_max; ctag = ctx->own_ctag;
 			// XFORM AHEAD: the solver of the step before this one -- same nh_step call, plain form -- has written all of that for the dynamic bodies' colliders; this step
 			// starts at the narrowphase
-			const bool plain = !movers && !sleepers && !ss.appended_pairs && (nbox >= 2 || nsph != 0u);
-			const bool ahead_step = plain && ss.ahead_ready && !ss.no_ahead;
+			// SLEEPERS AHEAD (nh_internal.h): the sleeping set has stood still for a few confirmed steps -- the awake bodies' lanes work ahead as in the plain form
+			if (ss.sleep_backoff) ss.sleep_backoff--;
+			const bool sleep_stable = sleepers && !ss.no_sleeper_ahead && !ss.no_pair && ss.sleep_stable >= 4u && ss.sleep_backoff == 0u && !ctx->step_hook && ss.pipelined && !ctx->fused.enabled && C <= (2u << 20);
+			const bool plain = !movers && (!sleepers || sleep_stable) && !ss.appended_pairs && (nbox >= 2 || nsph != 0u);
+			// (sleepers: the whole pair step or the three kernels -- a step that starts at the narrowphase would need its sleepers form there)
+			const bool ahead_step = plain && ss.ahead_ready && !ss.no_ahead && (!sleepers || ss.pair_ready);
 			ss.ahead_ready = false; ss.ahead_plain = plain;
 			// THE ONE-KERNEL STILL STEP (nh_fused.hip): a plain step that starts at the narrowphase, inside nh_step with late verdicts, and is not the call's last -- nothing is
 			// launched here; the solver call launches k_still_fused, which evaluates every kept pair in the lane that solves its body
-			const bool fused = ahead_step && ss.pipelined && ss.more_steps && nh_fused_wanted(ctx, B, C, ss.steps_left);
+			const bool fused = ahead_step && !sleepers && ss.pipelined && ss.more_steps && nh_fused_wanted(ctx, B, C, ss.steps_left);
 			ss.fused = fused;
 			if (movers) ctx->fused.map_valid = false;          // (re-stamped and appended pairs: the position table describes another kept list)
 			if (!fused && ctx->fused.cur != 0u) {
@@ -2261,12 +2280,12 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 				}
 				NH_HIP_CHECK(ctx, hipMemsetAsync(ctx->body_col, 0xff, sizeof(uint32_t) * (size_t)B, ctx->stream));
 				NH_LAUNCH(ctx, "ahead_map", k_ahead_map, nh_grid_for(C, 256, 2048), 256, st, aabb_min, C, ctx->body_col);
-				NH_LAUNCH(ctx, "ahead_check", k_ahead_check, nh_grid_for(C, 256, 1024), 256, st, aabb_min, C, ctx->body_col);
+				NH_LAUNCH(ctx, "ahead_check", k_ahead_check, nh_grid_for(C, 256, 1024), 256, st, aabb_min, C, ctx->body_col, sleepers ? bodies->idle_counters : (const uint8_t*)nullptr);
 				if (ss.pair_owned_seq == 0u && !ss.no_pair && ctx->pair_mark) {
 					// (pair ahead: the kept pairs that are no body's own, listed once per layout)
 					NH_HIP_CHECK(ctx, hipMemsetAsync(&st->pair_unowned, 0, sizeof(uint32_t), ctx->stream));
 					NH_LAUNCH(ctx, "pair_mark", k_pair_mark, nh_grid_for(B, 256, 2048), 256, ctx->body_rec, (ctx->halo_ghost_first && ctx->halo_ghost_first < B) ? ctx->halo_ghost_first : B, ctx->pair_mark, ctx->collide_seq);
-					NH_LAUNCH(ctx, "pair_list", k_pair_list, nh_grid_for(pair_cap, 256, 2048), 256, st, ctx->pair_mark, ctx->collide_seq, ctx->pair_list, ctx->pair_list_capacity);
+					NH_LAUNCH(ctx, "pair_list", k_pair_list, nh_grid_for(pair_cap, 256, 2048), 256, st, ctx->pair_mark, ctx->collide_seq, ctx->pair_list, ctx->pair_list_capacity, sleepers ? ctx->rec : (const nh_Record*)nullptr);
 					ss.pair_owned_seq = ctx->collide_seq;
 				}
 				ss.ahead_map_ok = true;
@@ -2293,7 +2312,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			if (pair_step) {
 			NH_LAUNCH(ctx, "pair_begin", k_pair_begin, 32, 256, st, ctx->step_parity, ctx->collide_seq, ctx->pair_list, ctx->pair_list_capacity, ctx->fat_pairs, ctx->fat_pair_capacity, pair_cap, gen,
 			                         xf, aabb_min, aabb_max, ctag, colliders->boxes.data, colliders->spheres.data, nbox, ctx->sort_keys_by_position, rec,
-			                         ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->still_delta, raw_data, raw_feature, bodies->momentum, bodies->properties, delta_scan ? 1u : 0u);
+			                         ctx->lay_rank, ctx->cnt_sorted, ctx->body_rec, ctx->still_delta, raw_data, raw_feature, bodies->momentum, bodies->properties, delta_scan ? 1u : 0u, sleepers ? B : 0u);
 			ss.early_verdict = false;
 			if (ctx->step_hook && !ss.pipelined && ss.h_ring[0] && !ctx->timing) {
 				NH_HIP_CHECK(ctx, hipMemcpyAsync(ss.h_ring[0], st, NH_COUNTER_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -2323,6 +2342,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 	// The solver reads the caller's cache arrays and this nh_collide lays the dense contact list out -- whatever still steps kept by slot goes home first
 	{ int rc = nh_still_export_cache(ctx); if (rc) return rc; }
 	ctx->still.ahead_ready = false; ctx->still.ahead_plain = false;
+	if (!no_islands) ctx->still.ahead_map_ok = false;          // (sleepers ahead: the static world's share of the scene bounds holds the sleepers' -- and who sleeps may change in a full step)
 	ctx->still.contacts_stale = false; ctx->still.slots_current = false; ctx->still.views_sleepers = false; ctx->still.appended_pairs = false;          // (a full step writes the contact list, the sleeping pairs and the active list itself)
 	NH_LAUNCH(ctx, "collide_begin", k_collide_begin, begin_grid, 256, st, C, B, parent, set_active, ctx->deg, bodies->idle_counters, ctx->step_parity, coarse_parent, coarse_active, no_islands ? 1u : 0u, block_top,
 	          drop_kept ? 1u : 0u, drop_sort_order ? 1u : 0u);

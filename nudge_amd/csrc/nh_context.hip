@@ -173,6 +173,7 @@ extern "C" int nh_set_option(nh_context* ctx, const char* name, int value) {
 	else if (n == "fused_fail_in") ctx->fused.debug_fail_in = (uint32_t)value;   // TEST HOOK: the value-th fused launch from now raises the failure flag at its very end (rollback exercised on purpose)
 	else if (n == "fused_still") ctx->fused.enabled = on;                      // plain still steps inside nh_step as ONE out-of-place kernel with a look-back (nh_fused.hip): bit-exact, measured SLOWER, off by default
 	else if (n == "no_early_counts") ctx->no_early_counts = on;                // a full step's counters by a copy behind its solver, not by the solver's first thread (nh_internal.h: early counters; A/B, tests)
+	else if (n == "no_sleeper_ahead") ctx->still.no_sleeper_ahead = on;        // a still step in sleepers form always launches its three kernels (nh_internal.h: sleepers ahead; A/B, tests)
 	else if (n == "no_sleeper_skip") ctx->still.no_sleeper_skip = on;          // the sleepers form of a still step does all its work for sleeping bodies too (nh_internal.h; A/B, tests)
 	else if (n == "halo_overlap") ctx->halo_overlap = on;                      // nh_partition_step: the next sub-step's halo beside the interior's solver, on a second stream (nh_internal.h: halo split; measured: no gain on one GPU)
 	else if (n == "no_pair_ahead") ctx->still.no_pair = on;                    // every still step launches its narrowphase (nh_internal.h: pair ahead; A/B, tests)

@@ -1009,7 +1009,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 		// floor -- goes straight to its next 64: the second round of loads is the expensive one)
 		if (!STILL && __builtin_amdgcn_ballot_w64(mine) == 0ull) { if (CONTIG) break; x += gridDim.x * blockDim.x; continue; }
 		// (STILL, sleepers form: a wave all of whose bodies are asleep has nothing to fetch, solve, advance or store)
-		if (STILL && !AHEAD && CONTIG && (fs.bits & 8u) && __builtin_amdgcn_ballot_w64(mine) == 0ull) break;
+		// (sleepers ahead: ... nor anything to do ahead -- what its lanes would gather for the next step is the neutral element of everything gathered)
+		if (STILL && CONTIG && (fs.bits & 8u) && __builtin_amdgcn_ballot_w64(mine) == 0ull) break;
 		if (!mine) { sp = make_uint2(0u, 0u); h = NH_HINT_NONE; br = NH_BODY_REC_NONE; }
 		uint32_t cid[M];
 		uint32_t first = 0xFFFFFFFFu;
@@ -2750,6 +2751,8 @@ static void still_note_movers(nh_context* ctx, const nh_DevState* h, uint32_t se
 	nh_StillStep& ss = ctx->still;
 	// (a still step in sleepers form that found NOBODY awake: the next step is a full one -- two of those in a row start the asleep steps, which cost nothing)
 	if (ss.sleepers && h->active == 0u) ss.ok_next = false;
+	// (sleepers ahead: how long has the sleeping set stood still?  Counted over confirmed still steps -- `seq` != 0 -- by the active count they report)
+	if (seq != 0u) { if (h->active == ss.sleep_last_active) { if (ss.sleep_stable < 0xffffu) ss.sleep_stable++; } else { ss.sleep_stable = 0u; ss.sleep_last_active = h->active; } }
 #ifdef NH_DEBUG_PAIR
 	fprintf(stderr, "[pair] verdict: map_ok %d unowned %u records %u pairs %u+%u world_bad %d ok %d ready %d\n", (int)ss.ahead_map_ok, h->pair_unowned, h->records, h->pairs, h->pairs_sph, (int)ss.pair_world_bad, (int)ss.pair_world_ok, (int)ss.pair_ready);
 #endif
@@ -3591,6 +3594,7 @@ static int still_forget_failed(nh_context* ctx, bool advanced, uint32_t voided) 
 	ss.verdict.pending = false;
 	ss.active = false; ss.resolved = false; ss.setup_d = nullptr; ss.ok_next = false; ss.ahead_ready = false;
 	ss.note_failure();
+	if (ss.sleepers) { ss.sleep_backoff = 64u; ss.sleep_stable = 0u; }          // (sleepers ahead: somebody fell asleep, most likely -- and more will)
 	ss.failed += voided;                               // (still steps launched that did not happen: the failed one, and the one launched behind it if it got that far)
 	ctx->pending = nullptr;
 	ctx->grav.pending = false; ctx->grav.rest_pending = false; ctx->adv.done = false;

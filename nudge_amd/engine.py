@@ -31,7 +31,7 @@ NH_VIEW_CONTACTS, NH_VIEW_CACHE, NH_VIEW_ACTIVE, NH_VIEW_ALL = 1, 2, 4, 7
 # environment variables NH_<NAME> that World() forwards to nh_set_option (tests and dev scripts; include/nudge_hip.h lists what each does)
 OPTION_NAMES = ("no_still", "no_kept_pairs", "no_incremental", "no_sort_reuse", "sort_classic", "sort_radix", "bucket_tile", "bucket_target", "colour_jp",
                 "colour_check_seeds", "no_resident", "solver_waves", "fp_sub", "cooperative", "no_blocks", "blk_check", "blk_min", "blk_target", "blk_rows_global",
-                "blk_global_colours", "blk_profile", "no_asleep", "no_blk_chain", "no_local_still", "no_xform_ahead", "measure_skip_chains", "sync_exports_views", "fused_still", "fused_fail_in", "no_pair_ahead", "no_sleeper_skip", "halo_overlap", "no_early_counts")
+                "blk_global_colours", "blk_profile", "no_asleep", "no_blk_chain", "no_local_still", "no_xform_ahead", "measure_skip_chains", "sync_exports_views", "fused_still", "fused_fail_in", "no_pair_ahead", "no_sleeper_skip", "halo_overlap", "no_early_counts", "no_sleeper_ahead")
 
 EXPORTS = [
     "nh_create", "nh_destroy", "nh_set_flags", "nh_synchronize", "nh_read_counts", "nh_export_views", "nh_set_cache_count",

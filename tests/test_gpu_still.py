@@ -372,6 +372,19 @@ def test_what_the_sleepers_form_skips_changes_nothing():
     scene = S.grid_tiles(2, side=32, sphere_fraction=0.5, seed=75, lattice_cols=2)
     nb = len(scene["body_transforms"])
     a, b, c = _world(scene, True), _world(scene, True, env=["NH_NO_SLEEPER_SKIP"]), _plain_world(scene)
+    b2 = _world(scene, True, env=["NH_NO_SLEEPER_AHEAD"])          # (round 6, sleepers ahead: one solver launch per sub-step while the sleeping set stands still -- and the three kernels)
+    class _Both:          # (b and b2 step and are compared together)
+        def __init__(self, *ws): self.ws = ws
+        def step(self, n): [w.step(n) for w in self.ws]
+        def get_bodies(self): return self.ws[0].get_bodies()
+        def set_bodies(self, **kw): [w.set_bodies(**kw) for w in self.ws]
+        def close(self): [w.close() for w in self.ws]
+    _same0 = globals()["_same_sleepy_world"]
+    def _same_sleepy_world(x, y, what=""):
+        if isinstance(y, _Both):
+            for k, w in enumerate(y.ws): _same0(x, w, what + (" [sleepers ahead off]" if k else ""))
+        else: _same0(x, y, what)
+    b = _Both(b, b2)
     for w in (a, b, c):
         w.step(420)
     _same_sleepy_world(a, c, "asleep"); _same_sleepy_world(a, b, "asleep (option off)")
@@ -398,7 +411,7 @@ def test_what_the_sleepers_form_skips_changes_nothing():
         done = cp
         _same_sleepy_world(a, c, f"more woken, step {cp}"); _same_sleepy_world(a, b, f"more woken, step {cp} (option off)")
     c1 = a.counts()
-    print(f"\n[sleeper skip] {c1['still_steps'] - c0['still_steps']} still + {c1['asleep_steps'] - c0['asleep_steps']} asleep steps of {done}; replays {c1['still_replays'] - c0['still_replays']}")
+    print(f"\n[sleeper skip] {c1['still_steps'] - c0['still_steps']} still + {c1['asleep_steps'] - c0['asleep_steps']} asleep steps of {done}; replays {c1['still_replays'] - c0['still_replays']}; pair steps {c1['pair_steps'] - c0['pair_steps']} (sleepers ahead)")
     assert c1["error"] == 0 and c1["still_steps"] - c0["still_steps"] >= 150, (c0, c1)
     a.close(); b.close(); c.close()
 
