@@ -1469,6 +1469,9 @@ __global__ __launch_bounds__(256) void k_pair_begin(nh_DevState* __restrict__ st
 		const float4 amin = aabb_min[ca], amax = aabb_max[ca], bmin = aabb_min[cb], bmax = aabb_max[cb];
 		bool hit = aabb_overlap(amin, amax, bmin, bmax) && (__float_as_uint(bmin.w) != __float_as_uint(amin.w));
 		if (stamps && hit) hit = (uint32_t)(gen[ca] & 0x7Fu) == (kp.x >> NH_GEN_SHIFT) && (uint32_t)(gen[cb] & 0x7Fu) == (kp.y >> NH_GEN_SHIFT);
+		// (sleepers ahead: the boxes of a pair with a SLEEPING end overlap -- an awake body has come within reach of a sleeper, which wakes it (its set holds more than itself,
+		// nudge.cpp:3575-3650), or a sleeper's pair that was no sleeping pair has become one: either way the three kernels' business, k_narrowphase<*, true, true> -- not this step's)
+		if (sleepers_bodies && hit && (__float_as_uint(amax.w) | __float_as_uint(bmax.w)) != 0u) { changed = true; atomicAdd(&st->still_diff[3], 1u); hit = false; }
 		int count = 0;
 		uint64_t key = ~0ull;
 		uint32_t body_a = 0, body_b = 0;
