@@ -2297,7 +2297,9 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 				NH_LAUNCH(ctx, "reinsert_still", k_reinsert, 256, 256, st, nbox, ctx->grid_sbox, ctx->grid_cstart, ctx->grid_large, ctx->fat_box, ctx->fat_gen, ctx->fat_esc_mark, ctx->fat_esc_list,
 				          ctx->fat_moved_list, ctx->collide_seq, ctx->fat_pairs, ctx->fat_pair_capacity, 1u, ctx->step_parity, C, ctx->body_rec, pair_cap);
 			const uint8_t* gen = incremental ? ctx->fat_gen : (const uint8_t*)nullptr;
-			const bool delta_scan = C > (2u << 20) || sleepers;          // (a world dozing off changes thousands of contact counts per step: the scan, not the list)
+			// (a world dozing off changes thousands of contact counts per step: the scan, not the list -- but not in a pair step of a world whose sleeping set stands still,
+			// sleepers ahead: its lanes listed their changes like a plain world's, and the two launches that leave at once are 4 us of an 80 us step)
+			const bool delta_scan = C > (2u << 20) || (sleepers && !pair_step);
 			uint32_t* const sc_count = sleepers ? ctx->sc_count : (uint32_t*)nullptr;
 			if (sleepers) ss.undo_dirty = true;
 			// (the LOCAL form of the narrowphase -- appended pairs, sleeping bodies -- only where it can matter: this step or an earlier one since the layout ran in movers
