@@ -2273,6 +2273,9 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			          xf, aabb_min, aabb_max, ctag, (uint4*)nullptr, 0u, ctx->fat_box, 0u,
 			          movers ? ctx->fat_gen : (uint8_t*)nullptr, ctx->fat_esc_mark, ctx->fat_esc_list, ctx->fat_moved_list, ctx->collide_seq, bodies->idle_counters, B, ctx->step_parity,
 			          sleepers ? ctx->still_awake : (uint8_t*)nullptr, (sleepers && ss.substep > 0u && !ctx->step_hook && !ss.no_sleeper_skip) ? 1u : 0u);          // (the narrowphase's `sleeper_skip` below)
+			// (sleepers ahead: the static world's share of the scene bounds holds the sleepers' -- a step with a k_xform<true> and a narrowphase of its own may be the one in
+			// which somebody falls asleep without failing anything, so every such step of a world with sleepers takes the map again before lanes work ahead on it)
+			if (sleepers && !ahead_step) ss.ahead_map_ok = false;
 			if (!ahead_step && plain && ss.more_steps && !ss.no_ahead && !ss.ahead_world_bad && !ss.ahead_map_ok && bodies->idle_counters) {
 				// (once per nh_step call: which collider each body's lane stands in for, and the static world's share of the scene bounds)
 				if (ctx->body_col_capacity < B) {
