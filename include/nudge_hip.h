@@ -68,7 +68,9 @@
  *      the next sub-step's first kernel ("xform ahead"; option "no_xform_ahead"): the solver lane that has just advanced a body writes its collider's world transform
  *      and AABB, tests it against the inflated box and gathers the scene bounds, so that the next sub-step starts at the narrowphase; what the lane finds wanting fails
  *      THAT sub-step, which is run again in full.  Only for worlds whose dynamic bodies carry one collider each (checked on the device once per call).
- *      nh_Counts.ahead_steps counts the sub-steps that started that way.
+ *      nh_Counts.ahead_steps counts the sub-steps that started that way.  (Round 6: the lane also evaluates its body's own collider pair for the next sub-step -- "pair ahead",
+ *      nh_Counts.pair_steps: such a sub-step starts at the solver -- and while the set of sleeping bodies stands still a world WITH sleepers is stepped the same way, its
+ *      sleepers part of the static world for those sub-steps ("sleepers ahead"; options "no_pair_ahead", "no_sleeper_ahead").)
  *      The caller's dense contact list (contacts->data / bodies / tags / features, contacts->sleeping_pairs), active list and contact cache are VIEWS under this regime: they are
  *      brought up to date by nh_export_views (what: NH_VIEW_CONTACTS, NH_VIEW_CACHE, NH_VIEW_ACTIVE), by nh_append_contacts, and by any step that does not qualify -- not by
  *      every step, and not by the cheap observers: nh_read_counts returns the counters and nh_synchronize waits for the stream, neither exports anything (the

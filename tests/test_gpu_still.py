@@ -439,6 +439,46 @@ def test_early_counters_change_nothing():
             w.close()
 
 
+def test_sleepers_ahead_through_falling_asleep_in_turns():
+    """Round 6 (nh_internal.h: sleepers ahead).  While the sleeping set stands still a step in sleepers form is one solver launch behind k_pair_begin; a body that falls
+    asleep fails the next step (replayed in full) and the form backs off.  A drop scene asleep, then three groups woken with idle counters 0 / 100 / 200 -- they fall asleep
+    again in turns, 55, 155 and 255 steps later, each time in the middle of a long call in which the lanes work ahead -- and a few more woken by the caller between two calls:
+    bodies, idle counters, contacts, sleeping pairs, active list, cache and counters bit for bit against the option off and against the library that runs every step in full."""
+    scene = S.grid_tiles(2, side=32, sphere_fraction=0.5, seed=91, lattice_cols=2)
+    nb = len(scene["body_transforms"])
+    a, b, c = _world(scene, True), _world(scene, True, env=["NH_NO_SLEEPER_AHEAD"]), _plain_world(scene)
+    for w in (a, b, c):
+        w.step(420)
+    _same_sleepy_world(a, c, "asleep"); _same_sleepy_world(a, b, "asleep (option off)")
+    order = np.argsort(scene["body_transforms"]["position"][1:, 2], kind="stable") + 1
+    third = (nb - 1) // 9
+    for w in (a, b, c):
+        idle = w.get_bodies()["idle"].copy()
+        idle[order[:third]] = 0; idle[order[third:2 * third]] = 100; idle[order[2 * third:3 * third]] = 200
+        w.set_bodies(idle=idle)
+    c0 = a.counts()
+    done = 0
+    for cp in (64, 128, 129, 192, 256):
+        for w in (a, b, c):
+            w.step(cp - done)
+        done = cp
+        _same_sleepy_world(a, c, f"groups falling asleep in turns, step {cp}"); _same_sleepy_world(a, b, f"groups falling asleep in turns, step {cp} (option off)")
+    for w in (a, b, c):
+        idle = w.get_bodies()["idle"].copy()
+        idle[order[-25:]] = 0
+        w.set_bodies(idle=idle)
+    for cp in (320, 384, 400, 520, 640):
+        for w in (a, b, c):
+            w.step(cp - done)
+        done = cp
+        _same_sleepy_world(a, c, f"more woken, step {cp}"); _same_sleepy_world(a, b, f"more woken, step {cp} (option off)")
+    c1, cb = a.counts(), b.counts()
+    print(f"\n[sleepers ahead] {c1['still_steps'] - c0['still_steps']} still + {c1['asleep_steps'] - c0['asleep_steps']} asleep steps of {done}; replays {c1['still_replays'] - c0['still_replays']}; "
+          f"pair steps {c1['pair_steps'] - c0['pair_steps']} (option off: {cb['pair_steps']})")
+    assert c1["error"] == 0 and c1["pair_steps"] - c0["pair_steps"] >= 200 and c1["still_replays"] - c0["still_replays"] <= 24, (c0, c1)
+    a.close(); b.close(); c.close()
+
+
 def test_a_sleeper_next_to_an_awake_body_is_not_the_still_steps_business():
     """A sleeping body whose AABB overlaps an awake dynamic body's belongs to a set of more than one body (nudge.cpp:3575-3650): whether it sleeps is not local.  Such a
     step must fail as a still step and be run in full -- the world ends in the bits of the library that never speculates."""
