@@ -2244,6 +2244,9 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			// starts at the narrowphase
 			// SLEEPERS AHEAD (nh_internal.h): the sleeping set has stood still for a few confirmed steps -- the awake bodies' lanes work ahead as in the plain form
 			if (ss.sleep_backoff) ss.sleep_backoff--;
+			// (the step in which the host can no longer rule sleepers out is the one before the first of them falls asleep: what stood still until now was a world awake)
+			if (sleepers && !ss.was_sleepers) ss.sleep_stable = 0u;
+			ss.was_sleepers = sleepers;
 			const bool sleep_stable = sleepers && !ss.no_sleeper_ahead && !ss.no_pair && ss.sleep_stable >= 4u && ss.sleep_backoff == 0u && !ctx->step_hook && ss.pipelined && !ctx->fused.enabled && C <= (2u << 20);
 			const bool plain = !movers && (!sleepers || sleep_stable) && !ss.appended_pairs && (nbox >= 2 || nsph != 0u);
 			// (sleepers: the whole pair step or the three kernels -- a step that starts at the narrowphase would need its sleepers form there)

@@ -218,6 +218,7 @@ extern "C" int nh_bodies_changed(nh_context* ctx) {
 	ctx->idle_bound = -1; ctx->idle_unknown = true;
 	ctx->asleep.streak = 0;
 	ctx->still.ok_next = false;                  // body records rewritten from outside: the next step looks at everything again
+	ctx->still.sleep_backoff = 0u; ctx->still.sleep_stable = 0u;          // (sleepers ahead: whoever sleeps now, it is another set)
 	return NH_OK;
 }
 

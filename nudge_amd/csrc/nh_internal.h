@@ -314,6 +314,7 @@ struct nh_StillStep {
 	// pairs they are, the step's sleeper counts are the last step's (k_pair_begin).  A body that falls asleep fails the NEXT step like in the plain form (the lane that advanced it
 	// sees the saturated counter): that step is replayed in full, and the form is left alone for 64 steps.  Option "no_sleeper_ahead": off.
 	bool no_sleeper_ahead;
+	bool was_sleepers;              // the last still step was launched in sleepers form
 	uint32_t sleep_last_active, sleep_stable, sleep_backoff;      // the active count of the latest confirmed sleepers-form step, how many in a row reported it, steps until the form may be tried again
 	bool no_sleeper_skip;           // option "no_sleeper_skip": the sleepers form does everything for every collider / pair / wave, asleep or not (A/B, tests)
 	bool views_sleepers;            // sleepers-form still steps have run since the caller's active list / sleeping pairs were last written by a full step

@@ -3660,7 +3660,7 @@ extern "C" int nh_step(nh_context* ctx, const nh_StepArgs* a, uint32_t steps) {
 		    a->contacts->sleeping_pairs == ss.lay_contacts.sleeping_pairs && a->active_bodies->indices == ss.lay_active && a->contact_cache->data == ss.cache_data && a->contact_cache->tags == ss.cache_tags && a->contact_cache->features == ss.cache_features) {
 			const int v = nh_asleep_verify(ctx, a->bodies, a->colliders);
 			if (v < 0) { result = -v; break; }
-			if (v == 0) { ctx->asleep.steps += steps - i; if (ctx->stream_state.every) ctx->stream_state.advances += steps - i; i = steps; continue; }          // (no frames: nothing moves)
+			if (v == 0) { ss.sleep_backoff = ss.sleep_backoff > steps - i ? ss.sleep_backoff - (steps - i) : 0u; ctx->asleep.steps += steps - i; if (ctx->stream_state.every) ctx->stream_state.advances += steps - i; i = steps; continue; }          // (no frames: nothing moves)
 			ctx->asleep.streak = 0;
 		}
 		int rc;

@@ -10,8 +10,8 @@ w.step(400); w.synchronize()
 print("asleep:", {k: w.counts()[k] for k in ("active_bodies", "sleeping_pairs", "contacts")})
 order = np.argsort(scene["body_transforms"]["position"][1:, 0], kind="stable") + 1
 idle = w.get_bodies()["idle"].copy(); idle[order[: (nb - 1) // 3]] = 0; w.set_bodies(idle=idle)
-keys = ("active_bodies", "sleeping_pairs", "contacts", "still_steps", "still_replays", "pair_steps", "ahead_steps", "pair_diag_roles", "pair_diag_record", "pair_diag_scale", "pair_diag_owned", "still_diff", "error")
-for k in range(6):
-    w.step(30); w.synchronize()
+keys = ("active_bodies", "sleeping_pairs", "contacts", "still_steps", "still_replays", "pair_steps", "ahead_steps", "pair_diag_roles", "pair_diag_record", "pair_diag_scale", "pair_diag_owned", "still_diff_key", "still_diff_count", "still_diff_feature", "still_diff_escape", "error")
+for k in range(12):
+    w.step(10); w.synchronize()
     c = w.counts()
     print(k, {x: c.get(x) for x in keys}, flush=True)
