@@ -2267,6 +2267,7 @@ static int collide_impl(nh_context* ctx, nh_ActiveBodies* active_bodies, nh_Cont
 			const bool pair_step = ahead_step && ss.pair_ready && !fused && !ss.no_pair;
 			ss.pair_ready = false; ss.pair_step = pair_step; ss.early_verdict = false;
 			if (pair_step) ss.pair_steps++;
+			if (pair_step && sleepers && ss.sleep_run < 0xffffu) ss.sleep_run++;
 			if (!ahead_step) ctx->fused.statics_copied = false;          // (k_xform<true> rewrites the current set of collider buffers, the static world's entries included)
 			if (ahead_step) ss.ahead_steps++;
 			else

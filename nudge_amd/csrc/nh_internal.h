@@ -312,9 +312,10 @@ struct nh_StillStep {
 	// is launched like a plain one: xform ahead and pair ahead by the lanes of the AWAKE bodies, one solver launch per sub-step behind k_pair_begin.  Sleeping bodies are part of
 	// the static world for such a step: their colliders' share of the scene bounds is taken once with the static world's (k_ahead_check), their records stay the settled sleeping
 	// pairs they are, the step's sleeper counts are the last step's (k_pair_begin).  A body that falls asleep fails the NEXT step like in the plain form (the lane that advanced it
-	// sees the saturated counter): that step is replayed in full, and the form is left alone for 64 steps.  Option "no_sleeper_ahead": off.
+	// sees the saturated counter): that step is replayed in full, and the form is left alone for 8 steps -- 16, 32, 64 when failures follow each other within 32 pair steps.  Option "no_sleeper_ahead": off.
 	bool no_sleeper_ahead;
 	bool was_sleepers;              // the last still step was launched in sleepers form
+	uint32_t sleep_backoff_len, sleep_run;          // how long the form is left alone after a failure (8 steps, doubled up to 64 by failures in quick succession), pair steps in sleepers form since the last one
 	uint32_t sleep_last_active, sleep_stable, sleep_backoff;      // the active count of the latest confirmed sleepers-form step, how many in a row reported it, steps until the form may be tried again
 	bool no_sleeper_skip;           // option "no_sleeper_skip": the sleepers form does everything for every collider / pair / wave, asleep or not (A/B, tests)
 	bool views_sleepers;            // sleepers-form still steps have run since the caller's active list / sleeping pairs were last written by a full step

@@ -3594,7 +3594,12 @@ static int still_forget_failed(nh_context* ctx, bool advanced, uint32_t voided) 
 	ss.verdict.pending = false;
 	ss.active = false; ss.resolved = false; ss.setup_d = nullptr; ss.ok_next = false; ss.ahead_ready = false;
 	ss.note_failure();
-	if (ss.sleepers) { ss.sleep_backoff = 64u; ss.sleep_stable = 0u; }          // (sleepers ahead: somebody fell asleep, most likely -- and more will)
+	if (ss.sleepers) {
+		// (sleepers ahead: somebody fell asleep, most likely.  One sleeper now and then costs the form eight steps; failures in quick succession -- a world dozing off in a
+		// trickle -- double that up to 64)
+		if (ss.sleep_backoff_len < 8u || ss.sleep_run >= 32u) ss.sleep_backoff_len = 8u; else if (ss.sleep_backoff_len < 64u) ss.sleep_backoff_len *= 2u;
+		ss.sleep_backoff = ss.sleep_backoff_len; ss.sleep_stable = 0u; ss.sleep_run = 0u;
+	}
 	ss.failed += voided;                               // (still steps launched that did not happen: the failed one, and the one launched behind it if it got that far)
 	ctx->pending = nullptr;
 	ctx->grav.pending = false; ctx->grav.rest_pending = false; ctx->adv.done = false;
