@@ -894,6 +894,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(MAXC ==
 	// nh_apply_impulses will continue from the solver states, so they are not stored
 	const bool keep_states = !(require_inert & 2u);
 	if (nbodies == 0u) return;
+	if (STILL && CONTIG && NW == 1 && !PART && (fs.bits & 8u) && blockIdx.x != 0u) {
+		// (sleepers form: a wave all of whose bodies are asleep has nothing to do in any instantiation -- it finds out with ONE load, before the words and the list every other
+		// wave starts with, and leaves; the first workgroup stays: its first thread files the step's counters)
+		const uint32_t x0 = blockIdx.x * 64u + threadIdx.x;
+		const uint32_t i0 = (x0 < nbodies) ? (uint32_t)fs.idle[x0] : 0xffu;
+		if (__builtin_amdgcn_ballot_w64(i0 != 0xffu) == 0ull) return;
+	}
 	// (the two words of device state -- is body 0 inert, how long is the cache -- are fetched beside the first round of loads, not before it)
 	uint32_t inert_word = (require_inert & 1u) ? cv.st->static_inert : 1u;
 	if (STILL) {
