@@ -479,6 +479,49 @@ def test_sleepers_ahead_through_falling_asleep_in_turns():
     a.close(); b.close(); c.close()
 
 
+@pytest.mark.parametrize("seed", [3, 17])
+def test_sleepers_ahead_against_full_steps_through_random_wake_ups(seed):
+    """Round 6 (sleepers ahead), a seeded random walk: a drop scene of boxes and spheres asleep; eight rounds in which the caller wakes a random few with random idle counters
+    (they fall asleep again at random times, alone or together, in the middle of calls in which the lanes work ahead), gives one of them a shove now and then (a mover among
+    sleepers), and steps in calls of random length.  After every call: bodies, idle counters, contacts, sleeping pairs, active list, cache and counters bit for bit against
+    the library that runs every step in full."""
+    rng = np.random.default_rng(seed)
+    scene = S.grid_tiles(2, side=24, sphere_fraction=0.4, seed=100 + seed, lattice_cols=2)
+    nb = len(scene["body_transforms"])
+    a, c = _world(scene, True), _plain_world(scene)
+    for w in (a, c):
+        w.step(420)
+    _same_sleepy_world(a, c, "asleep")
+    c0 = a.counts()
+    steps = 0
+    for rnd in range(8):
+        k = int(rng.integers(1, nb // 3))
+        who = rng.choice(np.arange(1, nb), size=k, replace=False)
+        idles = rng.integers(0, 255, size=k).astype(np.uint8)
+        if rnd % 3 == 1:
+            idles[:] = int(rng.integers(150, 250))          # (a group that falls asleep together)
+        elif rnd % 3 == 2:
+            idles[:] = 0; idles[: max(1, k // 8)] = rng.integers(100, 255, size=max(1, k // 8)).astype(np.uint8)          # (most of them rest awake for the whole round; a few doze off on the way)
+        shove = rnd % 4 == 2
+        for w in (a, c):
+            bd = w.get_bodies()
+            idle = bd["idle"].copy(); idle[who] = idles
+            if shove:
+                m = bd["momentum"].copy(); m["velocity"][who[0]] = np.float32([0.6, 1.2, -0.4]); idle[who[0]] = 0
+                w.set_bodies(momentum=m, idle=idle)
+            else:
+                w.set_bodies(idle=idle)
+        for n in rng.integers(1, 70, size=4):
+            for w in (a, c):
+                w.step(int(n))
+            steps += int(n)
+            _same_sleepy_world(a, c, f"seed {seed}, round {rnd}, step {steps}")
+    c1 = a.counts()
+    print(f"\n[sleepers ahead, random walk {seed}] {c1['still_steps'] - c0['still_steps']} still + {c1['asleep_steps'] - c0['asleep_steps']} asleep steps of {steps}; replays {c1['still_replays'] - c0['still_replays']}; pair steps {c1['pair_steps'] - c0['pair_steps']}")
+    assert c1["error"] == 0
+    a.close(); c.close()
+
+
 def test_a_sleeper_next_to_an_awake_body_is_not_the_still_steps_business():
     """A sleeping body whose AABB overlaps an awake dynamic body's belongs to a set of more than one body (nudge.cpp:3575-3650): whether it sleeps is not local.  Such a
     step must fail as a still step and be run in full -- the world ends in the bits of the library that never speculates."""
