@@ -117,6 +117,25 @@ __global__ __launch_bounds__(256) void k_cache_lookup(const nh_DevState* __restr
 	}
 }
 
+// ... over a LIST of contacts: the general ones of a world in which they are few (k_contact_class: `general_list`, st->general_contacts of them) -- two bodies touching among a
+// million that rest on the ground cost the lookup 43 us of reading every contact's bodies and classes to find them
+__global__ __launch_bounds__(256) void k_cache_lookup_listed(const nh_DevState* __restrict__ st, const uint32_t* __restrict__ list, const uint64_t* __restrict__ tags, const uint32_t* __restrict__ features,
+                                                             const uint64_t* __restrict__ ctags, const uint32_t* __restrict__ cfeatures, const nh_CachedContactImpulse* __restrict__ cdata,
+                                                             nh_CachedContactImpulse* __restrict__ out) {
+	const uint32_t n = st->contacts, m = st->cache, g = st->general_contacts;
+	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < g; j += gridDim.x * blockDim.x) {
+		const uint32_t i = list[j];
+		if (i >= n) continue;
+		const uint64_t t = tags[i]; const uint32_t f = features[i];
+		uint32_t lo = 0, hi = m;
+		if (i < m && ctags[i] == t && cfeatures[i] == f) { lo = i; hi = i; }
+		while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (tag_less(ctags[mid], cfeatures[mid], t, f)) lo = mid + 1; else hi = mid; }
+		nh_CachedContactImpulse r = { { 0.0f, 0.0f, 0.0f }, 0.0f };
+		if (lo < m && ctags[lo] == t && cfeatures[lo] == f) r = cdata[lo];
+		out[i] = r;
+	}
+}
+
 // cached impulses of sleeping pairs are kept aside (nudge.cpp:4064-4101)
 __global__ __launch_bounds__(256) void k_cull_flags(const nh_DevState* __restrict__ st, const uint64_t* __restrict__ ctags, const uint64_t* __restrict__ sleeping, uint32_t* __restrict__ flags) {
 	uint32_t m = st->cache, ns = st->sleeping;
@@ -2351,9 +2370,15 @@ extern "C" int nh_read_cached_impulses(nh_context* ctx, const nh_ContactCache* c
 }
 
 // `bodies` / `body_class` given: restrict to the contacts that read their warm start from d->data (see k_cache_lookup)
-static void materialize_lookup(nh_context* ctx, nh_ContactImpulseData* d, const nh_BodyPair* bodies = nullptr, const uint8_t* body_class = nullptr) {
+// (`general_list`, `general`: the contacts that read their warm start from d->data are the listed general ones and nothing else -- no body of the rare many-contact class -- and
+// they are few: the lookup walks the list)
+static void materialize_lookup(nh_context* ctx, nh_ContactImpulseData* d, const nh_BodyPair* bodies = nullptr, const uint8_t* body_class = nullptr, const uint32_t* general_list = nullptr, uint32_t general = 0u) {
 	if (!d->lookup_pending) return;
 	d->lookup_pending = false;
+	if (general_list && general != 0u && (uint64_t)general * 16u < d->capacity) {
+		NH_LAUNCH(ctx, "cache_lookup", k_cache_lookup_listed, nh_grid_for(general, 256, 4096), 256, ctx->d_state, general_list, d->tags, d->features, d->ctags, d->cfeatures, d->cdata, d->data);
+		return;
+	}
 	NH_LAUNCH(ctx, "cache_lookup", k_cache_lookup, nh_grid_for(d->capacity, 256, 16384), 256, ctx->d_state, d->tags, d->features, d->ctags, d->cfeatures, d->cdata, d->data, bodies, body_class);
 }
 
@@ -2877,7 +2902,7 @@ static int finish_setup(nh_context* ctx, nh_ContactConstraintData* d) {
 	}
 	if (c.general_contacts) {
 		const uint32_t G = c.general_contacts;
-		materialize_lookup(ctx, imp, contacts->bodies, d->body_class);
+		materialize_lookup(ctx, imp, contacts->bodies, d->body_class, d->has_staticN ? (const uint32_t*)nullptr : general_list, G);
 		// a large set in default order with no contact that no block can own: the blocks colour their own contacts (nh_blocks.h, k_blk_prepare_local) --
 		// no world-wide colouring, no adjacency lists of the general bodies
 		if (!(ctx->flags & NH_FLAG_EXACT_ORDER) && !ctx->env_blk_global_colours) {
